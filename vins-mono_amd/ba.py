@@ -1,0 +1,258 @@
+"""ctypes binding of the BA entry points of include/vinsgpu.h (thin; no arithmetic lives here).
+
+`prob` dicts are the ones produced by `synth.py` (and by the tests): see synth.py's docstring.
+"""
+import ctypes as C
+import numpy as np
+
+from . import lib
+
+VG_MAX_ITERS = 32
+VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
+VG_OK = 0
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int)
+
+
+class ImuPreint(C.Structure):
+    _fields_ = [("sum_dt", C.c_double), ("delta_p", C.c_double * 3), ("delta_q", C.c_double * 4),
+                ("delta_v", C.c_double * 3), ("linearized_ba", C.c_double * 3), ("linearized_bg", C.c_double * 3),
+                ("jacobian", C.c_double * 225), ("covariance", C.c_double * 225), ("valid", C.c_int), ("_pad", C.c_int)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("K", C.c_int), ("L", C.c_int), ("n_obs", C.c_int),
+                ("pose", _pd), ("speedbias", _pd), ("ex_pose", _pd), ("td", C.c_double), ("inv_depth", _pd),
+                ("lm_start", _pi), ("lm_nobs", _pi), ("lm_obs_off", _pi), ("obs", _pd), ("imu", C.POINTER(ImuPreint)),
+                ("prior_n", C.c_int), ("prior_nblocks", C.c_int), ("prior_block_kind", _pi), ("prior_block_index", _pi),
+                ("prior_J0", _pd), ("prior_r0", _pd), ("prior_x0", _pd),
+                ("relo_n", C.c_int), ("relo_pose", _pd), ("relo_lm", _pi), ("relo_xy", _pd),
+                ("estimate_extrinsic", C.c_int), ("estimate_td", C.c_int), ("max_iters", C.c_int),
+                ("focal", C.c_double), ("tr", C.c_double), ("row", C.c_double), ("g_norm", C.c_double)]
+
+
+class State(C.Structure):
+    _fields_ = [("pose", _pd), ("speedbias", _pd), ("ex_pose", _pd), ("td", _pd), ("inv_depth", _pd), ("relo_pose", _pd)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("status", C.c_int), ("termination", C.c_int), ("num_iterations", C.c_int), ("num_accepted", C.c_int),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
+                ("it_cost", C.c_double * VG_MAX_ITERS), ("it_cost_cand", C.c_double * VG_MAX_ITERS),
+                ("it_model", C.c_double * VG_MAX_ITERS), ("it_radius", C.c_double * VG_MAX_ITERS),
+                ("it_step_norm", C.c_double * VG_MAX_ITERS), ("it_flags", C.c_int * VG_MAX_ITERS)]
+
+
+class Prior(C.Structure):
+    _fields_ = [("cap", C.c_int), ("cap_blocks", C.c_int), ("n", C.c_int), ("m", C.c_int), ("nblocks", C.c_int),
+                ("valid", C.c_int), ("block_kind", _pi), ("block_index", _pi), ("J0", _pd), ("r0", _pd), ("x0", _pd)]
+
+
+def _dp(a):
+    return a.ctypes.data_as(_pd)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_pi)
+
+
+_GS = {0: 7, 1: 9, 2: 7, 3: 1}
+
+
+class PackedProblem:
+    """Owns contiguous copies of a prob dict's arrays and the ctypes struct pointing at them."""
+
+    def __init__(self, prob):
+        f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i4 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        self.K = int(prob['pose'].shape[0])
+        self.L = int(prob['inv_depth'].shape[0])
+        self.keep = k = {}
+        k['pose'], k['sb'], k['ex'] = f8(prob['pose']), f8(prob['sb']), f8(prob['ex'])
+        k['lam'] = f8(prob['inv_depth'])
+        k['lm_start'], k['lm_nobs'], k['obs_off'] = i4(prob['lm_start']), i4(prob['lm_nobs']), i4(prob['obs_off'])
+        k['obs'] = f8(prob['obs']).reshape(-1, 7) if self.L else np.zeros((0, 7))
+        imu = (ImuPreint * (self.K - 1))()
+        for i, m in enumerate(prob['imu']):
+            if m is None:
+                imu[i].valid = 0
+                continue
+            imu[i].sum_dt = float(m['sum_dt'])
+            imu[i].delta_p[:] = list(m['delta_p'])
+            imu[i].delta_q[:] = list(m['delta_q'])
+            imu[i].delta_v[:] = list(m['delta_v'])
+            imu[i].linearized_ba[:] = list(m['lin_ba'])
+            imu[i].linearized_bg[:] = list(m['lin_bg'])
+            imu[i].jacobian[:] = list(np.asarray(m['jacobian'], float).ravel())
+            imu[i].covariance[:] = list(np.asarray(m['covariance'], float).ravel())
+            imu[i].valid = 1
+        k['imu'] = imu
+        p = Problem()
+        p.K, p.L, p.n_obs = self.K, self.L, int(k['obs'].shape[0])
+        p.pose, p.speedbias, p.ex_pose, p.td = _dp(k['pose']), _dp(k['sb']), _dp(k['ex']), float(prob['td'])
+        p.inv_depth, p.lm_start, p.lm_nobs, p.lm_obs_off = _dp(k['lam']), _ip(k['lm_start']), _ip(k['lm_nobs']), _ip(k['obs_off'])
+        p.obs, p.imu = _dp(k['obs']), imu
+        pr = prob.get('prior')
+        if pr is not None:
+            k['pk'] = i4([b[0] for b in pr['blocks']])
+            k['pidx'] = i4([b[1] for b in pr['blocks']])
+            k['J0'], k['r0'] = f8(pr['J0']), f8(pr['r0'])
+            k['x0'] = f8(np.concatenate([np.atleast_1d(np.asarray(v, float)) for v in pr['x0']]))
+            p.prior_n, p.prior_nblocks = int(pr['n']), len(pr['blocks'])
+            p.prior_block_kind, p.prior_block_index = _ip(k['pk']), _ip(k['pidx'])
+            p.prior_J0, p.prior_r0, p.prior_x0 = _dp(k['J0']), _dp(k['r0']), _dp(k['x0'])
+        relo = prob.get('relo')
+        if relo is not None:
+            k['relo_pose'] = f8(relo['pose'])
+            k['relo_lm'] = i4([m[0] for m in relo['match']])
+            k['relo_xy'] = f8([[m[1], m[2]] for m in relo['match']])
+            p.relo_n, p.relo_pose, p.relo_lm, p.relo_xy = len(relo['match']), _dp(k['relo_pose']), _ip(k['relo_lm']), _dp(k['relo_xy'])
+        p.estimate_extrinsic, p.estimate_td, p.max_iters = int(prob['estimate_extrinsic']), int(prob['estimate_td']), int(prob['max_iters'])
+        p.focal, p.tr, p.row, p.g_norm = float(prob['focal']), float(prob['tr']), float(prob['row']), float(prob['g_norm'])
+        self.struct = p
+        self.has_relo = relo is not None
+
+
+class _Out:
+    def __init__(self, K, L, has_relo, want_prior):
+        self.pose, self.sb = np.zeros((K, 7)), np.zeros((K, 9))
+        self.ex, self.td, self.lam = np.zeros(7), np.zeros(1), np.zeros(max(L, 1))
+        self.relo = np.zeros(7)
+        self.L = L
+        self.state = State(_dp(self.pose), _dp(self.sb), _dp(self.ex), _dp(self.td), _dp(self.lam),
+                           _dp(self.relo) if has_relo else None)
+        self.prior = None
+        if want_prior:
+            cap, capb = 6 * K + 32, K + 8
+            self.pk, self.pidx = np.zeros(capb, np.int32), np.zeros(capb, np.int32)
+            self.J0, self.r0, self.x0 = np.zeros(cap * cap), np.zeros(cap), np.zeros(9 * capb)
+            self.prior = Prior(cap, capb, 0, 0, 0, 0, _ip(self.pk), _ip(self.pidx), _dp(self.J0), _dp(self.r0), _dp(self.x0))
+
+    def state_dict(self, has_relo):
+        st = dict(pose=self.pose.copy(), sb=self.sb.copy(), ex=self.ex.copy(), td=float(self.td[0]),
+                  inv_depth=self.lam[:self.L].copy())
+        if has_relo:
+            st['relo_pose'] = self.relo.copy()
+        return st
+
+    def prior_dict(self):
+        q = self.prior
+        if q is None or not q.valid:
+            return None
+        n, nb = q.n, q.nblocks
+        blocks = [(int(self.pk[b]), int(self.pidx[b])) for b in range(nb)]
+        x0, off = [], 0
+        for kind, _ in blocks:
+            x0.append(self.x0[off:off + _GS[kind]].copy())
+            off += _GS[kind]
+        return dict(n=n, m=q.m, blocks=blocks, J0=self.J0[:n * n].reshape(n, n).copy(), r0=self.r0[:n].copy(), x0=x0)
+
+
+def summary_dict(s):
+    n = s.num_iterations
+    return dict(status=s.status, termination=s.termination, num_iterations=n, num_accepted=s.num_accepted,
+                initial_cost=s.initial_cost, final_cost=s.final_cost, final_radius=s.final_radius,
+                it_cost=np.array(s.it_cost[:n]), it_cost_cand=np.array(s.it_cost_cand[:n]),
+                it_model=np.array(s.it_model[:n]), it_radius=np.array(s.it_radius[:n]),
+                it_step_norm=np.array(s.it_step_norm[:n]), it_flags=np.array(s.it_flags[:n]))
+
+
+class Handle:
+    """vg_create / vg_destroy wrapper; raises RuntimeError with vg_last_error on failures."""
+
+    def __init__(self):
+        self.lib = lib()
+        L = self.lib
+        L.vg_create.argtypes = [C.POINTER(C.c_void_p)]
+        L.vg_destroy.argtypes = [C.c_void_p]
+        L.vg_sync.argtypes = [C.c_void_p]
+        L.vg_last_error.argtypes = [C.c_void_p]
+        L.vg_last_error.restype = C.c_char_p
+        L.vg_timer_start.argtypes = [C.c_void_p]
+        L.vg_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.vg_ba_batch_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(Problem)), _pi]
+        L.vg_ba_batch_run_async.argtypes = [C.c_void_p]
+        L.vg_ba_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(State)), C.POINTER(Summary),
+                                           C.POINTER(C.POINTER(Prior))]
+        L.vg_ba_batch_info.argtypes = [C.c_void_p, _pd, _pd, _pd, _pi]
+        L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
+        self.h = C.c_void_p()
+        rc = L.vg_create(C.byref(self.h))
+        if rc != VG_OK:
+            raise RuntimeError(f"vg_create failed with status {rc} (no HIP device?)")
+
+    def close(self):
+        if self.h:
+            self.lib.vg_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != VG_OK:
+            raise RuntimeError(f"{what} failed: status {rc}: {self.lib.vg_last_error(self.h).decode()}")
+
+    # ---- timers
+    def timer_start(self):
+        self._chk(self.lib.vg_timer_start(self.h), "vg_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.lib.vg_timer_stop(self.h, C.byref(ms)), "vg_timer_stop")
+        return float(ms.value)
+
+    def sync(self):
+        self._chk(self.lib.vg_sync(self.h), "vg_sync")
+
+    # ---- BA
+    def ba_upload(self, probs, margin_flags=None):
+        self._packed = [p if isinstance(p, PackedProblem) else PackedProblem(p) for p in probs]
+        n = len(self._packed)
+        arr = (C.POINTER(Problem) * n)(*[C.pointer(p.struct) for p in self._packed])
+        mf = np.ascontiguousarray(margin_flags if margin_flags is not None else [VG_MARGIN_NONE] * n, dtype=np.int32)
+        self._margin = mf
+        self._chk(self.lib.vg_ba_batch_upload(self.h, n, arr, _ip(mf)), "vg_ba_batch_upload")
+
+    def ba_run_async(self):
+        self._chk(self.lib.vg_ba_batch_run_async(self.h), "vg_ba_batch_run_async")
+
+    def ba_info(self):
+        fl, bi, bo, lds = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        self._chk(self.lib.vg_ba_batch_info(self.h, C.byref(fl), C.byref(bi), C.byref(bo), C.byref(lds)), "vg_ba_batch_info")
+        return dict(flops=fl.value, bytes_in=bi.value, bytes_out=bo.value, lds_bytes=lds.value)
+
+    def ba_download(self, allow_numeric_failure=False):
+        n = len(self._packed)
+        outs = [_Out(p.K, p.L, p.has_relo, self._margin[i] != VG_MARGIN_NONE) for i, p in enumerate(self._packed)]
+        st = (C.POINTER(State) * n)(*[C.pointer(o.state) for o in outs])
+        pri = (C.POINTER(Prior) * n)(*[C.pointer(o.prior) if o.prior is not None else None for o in outs])
+        sm = (Summary * n)()
+        rc = self.lib.vg_ba_batch_download(self.h, n, st, sm, pri)
+        if rc != VG_OK and not (allow_numeric_failure and rc == -4):
+            self._chk(rc, "vg_ba_batch_download")
+        return ([o.state_dict(p.has_relo) for o, p in zip(outs, self._packed)],
+                [summary_dict(sm[i]) for i in range(n)],
+                [o.prior_dict() for o in outs])
+
+    def ba_optimize(self, prob, margin_flag=VG_MARGIN_NONE):
+        """One Estimator::optimization(): returns (state, summary, new_prior)."""
+        self.ba_upload([prob], [margin_flag])
+        self.ba_run_async()
+        st, sm, pr = self.ba_download()
+        return st[0], sm[0], pr[0]
+
+    def ba_eval_factors(self, prob):
+        p = PackedProblem(prob)
+        F = int((p.keep['lm_nobs'] - 1).sum()) + (len(prob['relo']['match']) if prob.get('relo') else 0)
+        K = p.K
+        n = int(prob['prior']['n']) if prob.get('prior') is not None else 0
+        pr, pJ = np.zeros((F, 2)), np.zeros((F, 2, 20))
+        ir, iJ = np.zeros((K - 1, 15)), np.zeros((K - 1, 15, 30))
+        qr = np.zeros(max(n, 1))
+        self._chk(self.lib.vg_ba_eval_factors(self.h, C.byref(p.struct), _dp(pr), _dp(pJ), _dp(ir), _dp(iJ), _dp(qr)),
+                  "vg_ba_eval_factors")
+        return dict(proj_r=pr, proj_J=pJ, imu_r=ir, imu_J=iJ, prior_r=qr[:n])

@@ -1,0 +1,537 @@
+// ba_host.hip — host side of the BA path behind the C-ABI (include/vinsgpu.h): packs
+// vg_ba_problem windows into the device layout of ba_layout.h, launches the kernels of
+// ba_kernels.hip / ba_marg.hip on the handle's stream and unpacks the results.
+//
+// The packing replaces the ceres::Problem construction of Estimator::optimization()
+// (estimator.cpp:672-764, :769-801): instead of `new`-ing one cost-function object per residual it
+// writes structure-of-arrays tables (factor list, per-chunk pair-sorted slot table, prior block map).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ba_layout.h"
+#include "vg_handle.h"
+#include "../../include/vinsgpu.h"
+
+extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaPtrs& P, hipStream_t stream);
+extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaPtrs& P, double* proj_r, double* proj_J,
+                                            double* imu_r, double* imu_J, double* prior_r, hipStream_t stream);
+extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaPtrs& P, hipStream_t stream);
+
+#define HIPCHK(h, expr)                                                                            \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                          \
+            return VG_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+static inline int up(int v, int m) { return (v + m - 1) / m * m; }
+
+static int blk_lsize(int kind) { return kind == VG_BLK_SPEEDBIAS ? 9 : (kind == VG_BLK_TD ? 1 : 6); }
+static int blk_gsize(int kind) { return kind == VG_BLK_SPEEDBIAS ? 9 : (kind == VG_BLK_TD ? 1 : 7); }
+
+static int check_problem(vg_handle* h, const vg_ba_problem* p) {
+    if (!p || !p->pose || !p->speedbias || !p->ex_pose || !p->imu) { h->err = "null problem pointer"; return VG_ERR_BAD_ARG; }
+    if (p->K < 2 || p->K + 1 > BA_MAX_K) { h->err = "K out of range for the single-workgroup path"; return VG_ERR_UNSUPPORTED; }
+    if (p->L < 0 || p->n_obs < 0 || (p->L > 0 && (!p->inv_depth || !p->lm_start || !p->lm_nobs || !p->lm_obs_off || !p->obs))) {
+        h->err = "bad landmark tables"; return VG_ERR_BAD_ARG;
+    }
+    for (int l = 0; l < p->L; ++l) {
+        if (p->lm_nobs[l] < 2 || p->lm_start[l] < 0 || p->lm_start[l] + p->lm_nobs[l] > p->K ||
+            p->lm_obs_off[l] < 0 || p->lm_obs_off[l] + p->lm_nobs[l] > p->n_obs) {
+            h->err = "landmark track outside the window"; return VG_ERR_BAD_ARG;
+        }
+    }
+    if (p->prior_n < 0 || (p->prior_n > 0 && (!p->prior_block_kind || !p->prior_block_index || !p->prior_J0 || !p->prior_r0 || !p->prior_x0))) {
+        h->err = "bad prior"; return VG_ERR_BAD_ARG;
+    }
+    if (p->prior_n > 0) {
+        int n = 0;
+        for (int b = 0; b < p->prior_nblocks; ++b) {
+            const int k = p->prior_block_kind[b];
+            if (k < 0 || k > 3) { h->err = "bad prior block kind"; return VG_ERR_BAD_ARG; }
+            if ((k == VG_BLK_POSE || k == VG_BLK_SPEEDBIAS) && (p->prior_block_index[b] < 0 || p->prior_block_index[b] >= p->K)) {
+                h->err = "prior block index outside the window"; return VG_ERR_BAD_ARG;
+            }
+            n += blk_lsize(k);
+        }
+        if (n != p->prior_n) { h->err = "prior_n != sum of local block sizes"; return VG_ERR_BAD_ARG; }
+    }
+    if (p->relo_n < 0 || (p->relo_n > 0 && (!p->relo_pose || !p->relo_lm || !p->relo_xy))) { h->err = "bad relo"; return VG_ERR_BAD_ARG; }
+    for (int k = 0; k < p->relo_n; ++k)
+        if (p->relo_lm[k] < 0 || p->relo_lm[k] >= p->L) { h->err = "relo landmark out of range"; return VG_ERR_BAD_ARG; }
+    if (p->max_iters < 0 || p->max_iters > VG_MAX_ITERS) { h->err = "max_iters out of range"; return VG_ERR_BAD_ARG; }
+    return VG_OK;
+}
+
+// ---- layout -------------------------------------------------------------------------------------
+static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, BaLayout& L) {
+    memset(&L, 0, sizeof(L));
+    const vg_ba_problem* p0 = in[0];
+    L.nwin = nwin;
+    L.K = p0->K;
+    bool relo = false;
+    int Lmax = 1, Fmax = 1, Omax = 1, Nmax = 0, NBmax = 0;
+    for (int w = 0; w < nwin; ++w) {
+        const vg_ba_problem* p = in[w];
+        int rc = check_problem(h, p);
+        if (rc) return rc;
+        if (p->K != p0->K || (p->estimate_extrinsic != 0) != (p0->estimate_extrinsic != 0) ||
+            (p->estimate_td != 0) != (p0->estimate_td != 0)) {
+            h->err = "windows of one batch must share K / estimate_extrinsic / estimate_td";
+            return VG_ERR_BAD_ARG;
+        }
+        relo = relo || p->relo_n > 0;
+        int F = p->relo_n;
+        for (int l = 0; l < p->L; ++l) F += p->lm_nobs[l] - 1;
+        Lmax = std::max(Lmax, p->L);
+        Fmax = std::max(Fmax, F);
+        Omax = std::max(Omax, p->n_obs + p->relo_n);
+        Nmax = std::max(Nmax, p->prior_n);
+        NBmax = std::max(NBmax, p->prior_nblocks);
+    }
+    L.Kp = L.K + (relo ? 1 : 0);
+    L.e = p0->estimate_extrinsic ? 1 : 0;
+    L.t = p0->estimate_td ? 1 : 0;
+    L.Rc = 6 * L.Kp + 6 * L.e + L.t;
+    L.RcPad = up(L.Rc, 16);
+    L.R = L.Rc + 9 * L.K;
+    L.Rpad = up(L.R + 1, 8);
+    L.Lcap = up(Lmax, 16);
+    L.Fcap = up(Fmax, 16);
+    L.Ocap = up(Omax, 8);
+    L.Ncap = up(std::max(Nmax, 1), 8);
+    L.NBcap = up(std::max(NBmax, 1), 8);
+    L.REC = 28 + 12 * L.e + 2 * L.t;
+    if (L.RcPad > 80) { h->err = "camera part wider than 80 columns"; return VG_ERR_UNSUPPORTED; }
+    // ---- LDS carve
+    const int total = 160 * 1024 / 8;
+    const int fulltri = (L.R + 1) * (L.R + 2) / 2;
+    const int camtri = L.Rc * (L.Rc + 1) / 2;
+    const int nst = up(7 * L.Kp + 9 * L.K + 8, 2);
+    L.nvec = 8;
+    int tail = 0;
+    const int sz_vec = L.nvec * L.Rpad, sz_red = 32, sz_wd = up(L.RcPad * 17 + 16, 2), sz_misc = 16;
+    tail = sz_vec + sz_red + sz_wd + 2 * nst + sz_misc;
+    L.l_S = 0;
+    L.l_stage = up(camtri, 2);
+    L.l_vec = total - tail;
+    L.l_red = L.l_vec + sz_vec;
+    L.l_wd = L.l_red + sz_red;
+    L.l_x = L.l_wd + sz_wd;
+    L.l_xc = L.l_x + nst;
+    L.l_misc = L.l_xc + nst;
+    L.lds_bytes = total * 8;
+    if (L.l_vec < up(fulltri, 2)) { h->err = "reduced system does not fit in 160 KB of LDS"; return VG_ERR_UNSUPPORTED; }
+    const int stage_cap = L.l_vec - L.l_stage;
+    L.chunk_cap = stage_cap / L.REC;
+    if (L.chunk_cap < 2 * BA_MAX_K || stage_cap < BA_NW * 256) { h->err = "LDS staging area too small"; return VG_ERR_UNSUPPORTED; }
+    L.Ccap = std::max(1, (L.Fcap + L.chunk_cap - 1) / (L.chunk_cap - BA_MAX_K) + 1);
+    // ---- int arrays
+    int o = 0;
+    L.io_hdr = o; o += BA_HDR_INTS;
+    L.io_lm_start = o; o += L.Lcap;
+    L.io_lm_fbeg = o; o += L.Lcap + 8;
+    L.io_fac_i = o; o += L.Fcap;
+    L.io_fac_j = o; o += L.Fcap;
+    L.io_fac_lm = o; o += L.Fcap;
+    L.io_fac_oi = o; o += L.Fcap;
+    L.io_fac_oj = o; o += L.Fcap;
+    L.io_fac_slot = o; o += L.Fcap;
+    L.io_chunk_fbeg = o; o += L.Ccap + 8;
+    L.io_chunk_lbeg = o; o += L.Ccap + 8;
+    L.io_pair_ptr = o; o += L.Ccap * (L.Kp * L.Kp + 1);
+    L.io_imu_valid = o; o += up(L.K, 8);
+    L.io_pb_kind = o; o += L.NBcap;
+    L.io_pb_idx = o; o += L.NBcap;
+    L.io_pb_col = o; o += L.NBcap;
+    L.io_pb_off = o; o += L.NBcap;
+    L.io_pb_x0off = o; o += L.NBcap;
+    L.istride = up(o, 8);
+    // ---- double inputs
+    o = 0;
+    L.do_pose = o; o += up(7 * L.Kp, 2);
+    L.do_sb = o; o += up(9 * L.K, 2);
+    L.do_ex = o; o += 8;
+    L.do_td = o; o += 2;
+    L.do_lam = o; o += L.Lcap;
+    L.do_obs = o; o += L.Ocap * BA_OBS_STRIDE;
+    L.do_imu = o; o += (L.K - 1) * BA_IMU_STRIDE;
+    L.do_pJ0 = o; o += L.Ncap * L.Ncap;
+    L.do_pJ0t = o; o += L.Ncap * L.Ncap;
+    L.do_pr0 = o; o += L.Ncap;
+    L.do_px0 = o; o += L.NBcap * 9;
+    L.do_par = o; o += P_NPAR;
+    L.dstride = up(o, 8);
+    // ---- scratch
+    o = 0;
+    L.so_imuU = o; o += up((L.K - 1) * 225, 2);
+    L.so_imuJ = o; o += (L.K - 1) * 450;
+    L.so_imuR = o; o += up((L.K - 1) * 15, 2);
+    L.so_Hp = o; o += L.Ncap * L.Ncap;
+    L.so_pr = o; o += L.Ncap;
+    L.so_prc = o; o += L.Ncap;
+    L.so_pu = o; o += L.Ncap;
+    L.so_Wt = o; o += L.RcPad * L.Lcap;
+    L.so_h = o; o += L.Lcap;
+    L.so_b = o; o += L.Lcap;
+    L.so_sl = o; o += L.Lcap;
+    L.so_dgl = o; o += L.Lcap;
+    L.so_gtl = o; o += L.Lcap;
+    L.so_gnl = o; o += L.Lcap;
+    L.so_ul = o; o += L.Lcap;
+    L.so_lam = o; o += L.Lcap;
+    L.so_lamc = o; o += L.Lcap;
+    L.so_yl = o; o += L.Lcap;
+    L.sstride = up(o, 8);
+    // ---- outputs
+    o = 0;
+    L.oo_pose = o; o += up(7 * L.Kp, 2);
+    L.oo_sb = o; o += up(9 * L.K, 2);
+    L.oo_ex = o; o += 8;
+    L.oo_td = o; o += 2;
+    L.oo_lam = o; o += L.Lcap;
+    L.oo_sum = o; o += BA_SUM_DOUBLES;
+    L.oo_trace = o; o += 5 * VG_MAX_ITERS;
+    L.ostride = up(o, 8);
+    L.oi_stride = up(4 + VG_MAX_ITERS, 8);
+    // ---- marginalization outputs: kept dimension <= 6*K + 9 + 6 + 1, blocks <= K + 3
+    const int mcap = up(6 * L.K + 9 * 2 + 6 + 1, 8);
+    L.mo_J0 = 0;
+    L.mo_r0 = mcap * mcap;
+    L.mo_x0 = L.mo_r0 + mcap;
+    L.mo_stride = up(L.mo_x0 + (L.K + 4) * 9, 8);
+    L.mi_stride = up(8 + 2 * (L.K + 4), 8);
+    // marg scratch: A (pos x pos) + V (m x m) + V2 (n x n) + vectors; pos <= mcap + 15 + Lcap
+    {
+        const long pos = (long)mcap + 15 + L.Lcap;
+        long s = pos * pos * 2 + (long)mcap * mcap * 2 + 8 * pos + (long)L.Lcap * 64;
+        L.ms_stride = (int)up((int)s, 8);
+    }
+    return VG_OK;
+}
+
+// ---- packing of one window ------------------------------------------------------------------------
+struct FacTmp { int i, j, l, oi, oj; };
+
+static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, int margin, int* ia, double* di) {
+    const int K = L.K, Kp = L.Kp;
+    int* hdr = ia + L.io_hdr;
+    // observations (+ relo rows)
+    for (int o = 0; o < p->n_obs; ++o) {
+        double* d = di + L.do_obs + (size_t)o * BA_OBS_STRIDE;
+        for (int k = 0; k < 7; ++k) d[k] = p->obs[(size_t)o * 7 + k];
+        d[7] = 0.0;
+    }
+    for (int k = 0; k < p->relo_n; ++k) {
+        double* d = di + L.do_obs + (size_t)(p->n_obs + k) * BA_OBS_STRIDE;
+        memset(d, 0, sizeof(double) * BA_OBS_STRIDE);
+        d[0] = p->relo_xy[2 * k];
+        d[1] = p->relo_xy[2 * k + 1];
+    }
+    // factor list, landmark-major; a landmark's relo factor (if any) follows its window factors
+    std::vector<FacTmp> fac;
+    std::vector<int> relo_of(p->L, -1);
+    for (int k = 0; k < p->relo_n; ++k) relo_of[p->relo_lm[k]] = k;
+    for (int l = 0; l < p->L; ++l) {
+        ia[L.io_lm_start + l] = p->lm_start[l];
+        ia[L.io_lm_fbeg + l] = (int)fac.size();
+        const int s = p->lm_start[l], o = p->lm_obs_off[l];
+        for (int k = 1; k < p->lm_nobs[l]; ++k) fac.push_back({s, s + k, l, o, o + k});
+        if (relo_of[l] >= 0) fac.push_back({s, K, l, o, p->n_obs + relo_of[l]});
+    }
+    ia[L.io_lm_fbeg + p->L] = (int)fac.size();
+    const int F = (int)fac.size();
+    for (int f = 0; f < F; ++f) {
+        ia[L.io_fac_i + f] = fac[f].i; ia[L.io_fac_j + f] = fac[f].j; ia[L.io_fac_lm + f] = fac[f].l;
+        ia[L.io_fac_oi + f] = fac[f].oi; ia[L.io_fac_oj + f] = fac[f].oj;
+    }
+    // chunks on landmark boundaries, slots inside a chunk sorted by (i, j)
+    int nchunk = 0, l0 = 0;
+    while (l0 < p->L || nchunk == 0) {
+        int l1 = l0, cnt = 0;
+        while (l1 < p->L) {
+            const int nf = ia[L.io_lm_fbeg + l1 + 1] - ia[L.io_lm_fbeg + l1];
+            if (cnt + nf > L.chunk_cap) break;
+            cnt += nf;
+            ++l1;
+        }
+        if (l1 == l0 && l0 < p->L) { h->err = "a landmark has more factors than a chunk holds"; return VG_ERR_UNSUPPORTED; }
+        if (nchunk >= L.Ccap) { h->err = "too many chunks"; return VG_ERR_UNSUPPORTED; }
+        const int fb = ia[L.io_lm_fbeg + l0], fe = ia[L.io_lm_fbeg + l1];
+        ia[L.io_chunk_fbeg + nchunk] = fb;
+        ia[L.io_chunk_lbeg + nchunk] = l0;
+        int* ptr = ia + L.io_pair_ptr + nchunk * (Kp * Kp + 1);
+        std::vector<int> count(Kp * Kp + 1, 0);
+        for (int f = fb; f < fe; ++f) count[fac[f].i * Kp + fac[f].j + 1]++;
+        ptr[0] = 0;
+        for (int k = 0; k < Kp * Kp; ++k) ptr[k + 1] = ptr[k] + count[k + 1];
+        std::vector<int> cursor(ptr, ptr + Kp * Kp);
+        for (int f = fb; f < fe; ++f) ia[L.io_fac_slot + f] = cursor[fac[f].i * Kp + fac[f].j]++;
+        ++nchunk;
+        l0 = l1;
+        if (p->L == 0) break;
+    }
+    ia[L.io_chunk_fbeg + nchunk] = F;
+    ia[L.io_chunk_lbeg + nchunk] = p->L;
+    hdr[H_L] = p->L; hdr[H_F] = F; hdr[H_NPRIOR] = p->prior_n; hdr[H_NBLK] = p->prior_n ? p->prior_nblocks : 0;
+    hdr[H_MAXIT] = p->max_iters; hdr[H_NCHUNK] = nchunk; hdr[H_MARGIN] = margin; hdr[H_STATUS] = 0;
+    // state
+    memcpy(di + L.do_pose, p->pose, sizeof(double) * 7 * K);
+    if (Kp > K) {
+        if (p->relo_n > 0) memcpy(di + L.do_pose + 7 * K, p->relo_pose, sizeof(double) * 7);
+        else { double id[7] = {0, 0, 0, 0, 0, 0, 1}; memcpy(di + L.do_pose + 7 * K, id, sizeof(id)); }
+    }
+    memcpy(di + L.do_sb, p->speedbias, sizeof(double) * 9 * K);
+    memcpy(di + L.do_ex, p->ex_pose, sizeof(double) * 7);
+    di[L.do_td] = p->td;
+    for (int l = 0; l < p->L; ++l) di[L.do_lam + l] = p->inv_depth[l];
+    for (int k = 0; k < K - 1; ++k) {
+        const vg_imu_preint& m = p->imu[k];
+        double* d = di + L.do_imu + (size_t)k * BA_IMU_STRIDE;
+        d[0] = m.sum_dt;
+        memcpy(d + 1, m.delta_p, 24); memcpy(d + 4, m.delta_q, 32); memcpy(d + 8, m.delta_v, 24);
+        memcpy(d + 11, m.linearized_ba, 24); memcpy(d + 14, m.linearized_bg, 24);
+        memcpy(d + 17, m.jacobian, 225 * 8); memcpy(d + 242, m.covariance, 225 * 8);
+        ia[L.io_imu_valid + k] = (m.valid && m.sum_dt <= 10.0) ? 1 : 0;
+    }
+    // prior
+    if (p->prior_n > 0) {
+        const int n = p->prior_n;
+        int off = 0, x0off = 0;
+        for (int b = 0; b < p->prior_nblocks; ++b) {
+            const int kind = p->prior_block_kind[b], idx = p->prior_block_index[b];
+            ia[L.io_pb_kind + b] = kind;
+            ia[L.io_pb_idx + b] = idx;
+            ia[L.io_pb_off + b] = off;
+            ia[L.io_pb_x0off + b] = x0off;
+            int col = -1;
+            if (kind == VG_BLK_POSE) col = 6 * idx;
+            else if (kind == VG_BLK_SPEEDBIAS) col = L.Rc + 9 * idx;
+            else if (kind == VG_BLK_EXPOSE) col = L.e ? 6 * Kp : -1;
+            else col = L.t ? 6 * Kp + 6 * L.e : -1;
+            ia[L.io_pb_col + b] = col;
+            off += blk_lsize(kind);
+            x0off += blk_gsize(kind);
+        }
+        memcpy(di + L.do_px0, p->prior_x0, sizeof(double) * x0off);
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) {
+                const double v = p->prior_J0[(size_t)r * n + c];
+                di[L.do_pJ0 + (size_t)r * L.Ncap + c] = v;
+                di[L.do_pJ0t + (size_t)c * L.Ncap + r] = v;
+            }
+        memcpy(di + L.do_pr0, p->prior_r0, sizeof(double) * n);
+    }
+    di[L.do_par + P_FOCAL] = p->focal; di[L.do_par + P_TR] = p->tr; di[L.do_par + P_ROW] = p->row;
+    di[L.do_par + P_GNORM] = p->g_norm;
+    return VG_OK;
+}
+
+// ---- device buffers -------------------------------------------------------------------------------
+template <typename T>
+static int ensure(vg_handle* h, T*& ptr, size_t& cap, size_t need) {
+    if (need <= cap && ptr) return VG_OK;
+    if (ptr) HIPCHK(h, hipFree(ptr));
+    ptr = nullptr; cap = 0;
+    HIPCHK(h, hipMalloc((void**)&ptr, need * sizeof(T)));
+    cap = need;
+    return VG_OK;
+}
+
+extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* const* in, const int* margin_flags) {
+    if (!h || nwin <= 0 || !in) return VG_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    BaLayout L;
+    int rc = build_layout(h, nwin, in, L);
+    if (rc) return rc;
+    BaBatch& B = h->ba;
+    B.L = L;
+    B.nwin = nwin;
+    B.h_ia.assign((size_t)nwin * L.istride, 0);
+    B.h_di.assign((size_t)nwin * L.dstride, 0.0);
+    B.flops = 0.0; B.bytes_in = 0.0; B.bytes_out = 0.0;
+    B.margin.assign(nwin, VG_MARGIN_NONE);
+    B.nL.assign(nwin, 0);
+    for (int w = 0; w < nwin; ++w) {
+        const int mf = margin_flags ? margin_flags[w] : VG_MARGIN_NONE;
+        B.margin[w] = mf;
+        B.nL[w] = in[w]->L;
+        rc = pack_window(h, L, in[w], mf, B.h_ia.data() + (size_t)w * L.istride, B.h_di.data() + (size_t)w * L.dstride);
+        if (rc) return rc;
+        // algorithmic flop / byte model of SURVEY.md 8(d)
+        const vg_ba_problem* p = in[w];
+        double F = p->relo_n, schur = 0.0, sumn = 0.0;
+        for (int l = 0; l < p->L; ++l) {
+            const double n = p->lm_nobs[l];
+            F += n - 1;
+            schur += (6 * n) * (6 * n + 1) + 12 * n;
+            sumn += n;
+        }
+        const double np = p->prior_n, R = L.R;
+        const double lin = F * (750 + 416) + schur + 10 * 37000.0 + 4 * np * np + R * R * R / 3 + 2 * R * R + 12 * sumn;
+        const double stepev = F * 145 + 10 * 9000.0;
+        double fl = p->max_iters * (lin + stepev) + 2 * np * np * np;
+        if (mf == VG_MARGIN_OLD) {
+            double m = 15;
+            for (int l = 0; l < p->L; ++l) m += (p->lm_start[l] == 0);
+            const double n = 6.0 * (L.K - 1) + 9 + 6 + L.t;
+            fl += 9 * (m * m * m + n * n * n) + 2 * (m * m * n + m * n * n);
+        }
+        B.flops += fl;
+        B.bytes_in += 8.0 * (16 * L.K + 8 + p->L + 7.0 * p->n_obs + (L.K - 1) * 467.0 + np * np + 2 * np) + 12.0 * p->L;
+        B.bytes_out += 8.0 * (16 * L.K + 8 + p->L) + (mf != VG_MARGIN_NONE ? 8.0 * (75.0 * 75 + 75 + 100) : 0.0);
+    }
+    rc = ensure(h, B.P.iarr, B.cap_ia, (size_t)nwin * L.istride); if (rc) return rc;
+    rc = ensure(h, B.P.din, B.cap_di, (size_t)nwin * L.dstride); if (rc) return rc;
+    rc = ensure(h, B.P.scr, B.cap_sc, (size_t)nwin * L.sstride); if (rc) return rc;
+    rc = ensure(h, B.P.out, B.cap_out, (size_t)nwin * L.ostride); if (rc) return rc;
+    rc = ensure(h, B.P.iout, B.cap_iout, (size_t)nwin * L.oi_stride); if (rc) return rc;
+    rc = ensure(h, B.P.mout, B.cap_mout, (size_t)nwin * L.mo_stride); if (rc) return rc;
+    rc = ensure(h, B.P.miout, B.cap_miout, (size_t)nwin * L.mi_stride); if (rc) return rc;
+    rc = ensure(h, B.P.mscr, B.cap_mscr, (size_t)nwin * L.ms_stride); if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(B.P.iarr, B.h_ia.data(), B.h_ia.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(B.P.din, B.h_di.data(), B.h_di.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(B.P.iout, 0, (size_t)nwin * L.oi_stride * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(B.P.miout, 0, (size_t)nwin * L.mi_stride * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(B.P.out, 0, (size_t)nwin * L.ostride * sizeof(double), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    B.any_margin = false;
+    for (int w = 0; w < nwin; ++w) B.any_margin = B.any_margin || B.margin[w] != VG_MARGIN_NONE;
+    B.uploaded = true;
+    return VG_OK;
+}
+
+extern "C" int vg_ba_batch_run_async(vg_handle* h) {
+    if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    HIPCHK(h, ba_launch_solve(B.L, B.P, h->stream));
+    if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.P, h->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_ba_batch_info(vg_handle* h, double* flops, double* bytes_in, double* bytes_out, int* lds_bytes) {
+    if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
+    if (flops) *flops = h->ba.flops;
+    if (bytes_in) *bytes_in = h->ba.bytes_in;
+    if (bytes_out) *bytes_out = h->ba.bytes_out;
+    if (lds_bytes) *lds_bytes = h->ba.L.lds_bytes;
+    return VG_OK;
+}
+
+extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_summary* sum,
+                                    vg_ba_prior* const* pri) {
+    if (!h || !h->ba.uploaded || nwin != h->ba.nwin) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    const BaLayout& L = B.L;
+    B.h_out.resize((size_t)nwin * L.ostride);
+    B.h_iout.resize((size_t)nwin * L.oi_stride);
+    HIPCHK(h, hipMemcpyAsync(B.h_out.data(), B.P.out, B.h_out.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(B.h_iout.data(), B.P.iout, B.h_iout.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (B.any_margin && pri) {
+        B.h_mout.resize((size_t)nwin * L.mo_stride);
+        B.h_miout.resize((size_t)nwin * L.mi_stride);
+        HIPCHK(h, hipMemcpyAsync(B.h_mout.data(), B.P.mout, B.h_mout.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(B.h_miout.data(), B.P.miout, B.h_miout.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int worst = VG_OK;
+    for (int w = 0; w < nwin; ++w) {
+        const double* o = B.h_out.data() + (size_t)w * L.ostride;
+        const int* io = B.h_iout.data() + (size_t)w * L.oi_stride;
+        if (st && st[w]) {
+            vg_ba_state* s = st[w];
+            if (s->pose) memcpy(s->pose, o + L.oo_pose, sizeof(double) * 7 * L.K);
+            if (s->speedbias) memcpy(s->speedbias, o + L.oo_sb, sizeof(double) * 9 * L.K);
+            if (s->ex_pose) memcpy(s->ex_pose, o + L.oo_ex, sizeof(double) * 7);
+            if (s->td) *s->td = o[L.oo_td];
+            if (s->inv_depth) memcpy(s->inv_depth, o + L.oo_lam, sizeof(double) * B.nL[w]);
+            if (s->relo_pose && L.Kp > L.K) memcpy(s->relo_pose, o + L.oo_pose + 7 * L.K, sizeof(double) * 7);
+        }
+        if (sum) {
+            vg_ba_summary& s = sum[w];
+            memset(&s, 0, sizeof(s));
+            s.status = io[0]; s.termination = io[1]; s.num_iterations = io[2]; s.num_accepted = io[3];
+            s.initial_cost = o[L.oo_sum + 0]; s.final_cost = o[L.oo_sum + 1]; s.final_radius = o[L.oo_sum + 2];
+            for (int k = 0; k < VG_MAX_ITERS; ++k) {
+                s.it_cost[k] = o[L.oo_trace + 0 * VG_MAX_ITERS + k];
+                s.it_cost_cand[k] = o[L.oo_trace + 1 * VG_MAX_ITERS + k];
+                s.it_model[k] = o[L.oo_trace + 2 * VG_MAX_ITERS + k];
+                s.it_radius[k] = o[L.oo_trace + 3 * VG_MAX_ITERS + k];
+                s.it_step_norm[k] = o[L.oo_trace + 4 * VG_MAX_ITERS + k];
+                s.it_flags[k] = io[4 + k];
+            }
+            if (s.status != VG_OK) worst = s.status;
+        }
+        if (pri && pri[w]) {
+            vg_ba_prior* q = pri[w];
+            q->n = q->m = q->nblocks = q->valid = 0;
+            if (B.margin[w] != VG_MARGIN_NONE && B.any_margin) {
+                const double* mo = B.h_mout.data() + (size_t)w * L.mo_stride;
+                const int* mi = B.h_miout.data() + (size_t)w * L.mi_stride;
+                q->valid = mi[0];
+                if (mi[0]) {
+                    const int n = mi[1], nb = mi[3];
+                    if (n > q->cap || nb > q->cap_blocks) { h->err = "vg_ba_prior capacity too small"; return VG_ERR_BAD_ARG; }
+                    q->n = n; q->m = mi[2]; q->nblocks = nb;
+                    const int mcap = (int)std::lround(std::sqrt((double)L.mo_r0));
+                    int x0n = 0;
+                    for (int b = 0; b < nb; ++b) {
+                        q->block_kind[b] = mi[8 + b];
+                        q->block_index[b] = mi[8 + (L.K + 4) + b];
+                        x0n += blk_gsize(q->block_kind[b]);
+                    }
+                    for (int r = 0; r < n; ++r) memcpy(q->J0 + (size_t)r * n, mo + L.mo_J0 + (size_t)r * mcap, sizeof(double) * n);
+                    memcpy(q->r0, mo + L.mo_r0, sizeof(double) * n);
+                    memcpy(q->x0, mo + L.mo_x0, sizeof(double) * x0n);
+                }
+            }
+        }
+    }
+    return worst;
+}
+
+extern "C" int vg_ba_optimize(vg_handle* h, const vg_ba_problem* in, int margin_flag, vg_ba_state* out_state,
+                              vg_ba_summary* out_summary, vg_ba_prior* out_prior) {
+    if (!h || !in) return VG_ERR_BAD_ARG;
+    const vg_ba_problem* arr[1] = {in};
+    int rc = vg_ba_batch_upload(h, 1, arr, &margin_flag);
+    if (rc) return rc;
+    rc = vg_ba_batch_run_async(h);
+    if (rc) return rc;
+    vg_ba_state* sarr[1] = {out_state};
+    vg_ba_prior* parr[1] = {out_prior};
+    return vg_ba_batch_download(h, 1, sarr, out_summary, parr);
+}
+
+extern "C" int vg_ba_eval_factors(vg_handle* h, const vg_ba_problem* in, double* proj_r, double* proj_J,
+                                  double* imu_r, double* imu_J, double* prior_r) {
+    if (!h || !in) return VG_ERR_BAD_ARG;
+    const vg_ba_problem* arr[1] = {in};
+    int mf = VG_MARGIN_NONE;
+    int rc = vg_ba_batch_upload(h, 1, arr, &mf);
+    if (rc) return rc;
+    BaBatch& B = h->ba;
+    const BaLayout& L = B.L;
+    const int F = B.h_ia[L.io_hdr + H_F], nimu = L.K - 1, n = in->prior_n;
+    double* d = nullptr;
+    const size_t tot = (size_t)F * 2 + (size_t)F * 40 + nimu * 15 + nimu * 450 + std::max(n, 1);
+    HIPCHK(h, hipMalloc((void**)&d, tot * sizeof(double)));
+    double* d_pr = d; double* d_pJ = d_pr + (size_t)F * 2; double* d_ir = d_pJ + (size_t)F * 40;
+    double* d_iJ = d_ir + nimu * 15; double* d_qr = d_iJ + nimu * 450;
+    hipError_t e = ba_launch_eval_factors(L, B.P, d_pr, d_pJ, d_ir, d_iJ, d_qr, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && proj_r) e = hipMemcpy(proj_r, d_pr, (size_t)F * 2 * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && proj_J) e = hipMemcpy(proj_J, d_pJ, (size_t)F * 40 * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && imu_r) e = hipMemcpy(imu_r, d_ir, (size_t)nimu * 15 * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && imu_J) e = hipMemcpy(imu_J, d_iJ, (size_t)nimu * 450 * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && prior_r && n) e = hipMemcpy(prior_r, d_qr, (size_t)n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) { h->err = std::string("eval_factors: ") + hipGetErrorString(e); return VG_ERR_HIP; }
+    return VG_OK;
+}

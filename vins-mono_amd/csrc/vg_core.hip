@@ -1,0 +1,63 @@
+// vg_core.hip — handle lifecycle, stream and HIP-event stopwatch of the C-ABI (include/vinsgpu.h).
+#include <hip/hip_runtime.h>
+#include "vg_handle.h"
+#include "../../include/vinsgpu.h"
+
+extern "C" void fe_state_destroy(FeState* s);
+
+extern "C" int vg_abi_version(void) { return VG_ABI_VERSION; }
+
+extern "C" int vg_create(vg_handle** out) {
+    if (!out) return VG_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return VG_ERR_NO_DEVICE;
+    vg_handle* h = new vg_handle();
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return VG_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        delete h;
+        return VG_ERR_HIP;
+    }
+    *out = h;
+    return VG_OK;
+}
+
+extern "C" int vg_destroy(vg_handle* h) {
+    if (!h) return VG_ERR_BAD_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    BaPtrs& P = h->ba.P;
+    (void)hipFree(P.iarr); (void)hipFree(P.din); (void)hipFree(P.scr); (void)hipFree(P.out); (void)hipFree(P.iout);
+    (void)hipFree(P.mout); (void)hipFree(P.miout); (void)hipFree(P.mscr);
+    if (h->fe) fe_state_destroy(h->fe);
+    (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return VG_OK;
+}
+
+extern "C" int vg_sync(vg_handle* h) {
+    if (!h) return VG_ERR_BAD_ARG;
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return VG_ERR_HIP; }
+    return VG_OK;
+}
+
+extern "C" const char* vg_last_error(vg_handle* h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" void* vg_stream(vg_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+extern "C" int vg_timer_start(vg_handle* h) {
+    if (!h) return VG_ERR_BAD_ARG;
+    hipError_t e = hipEventRecord(h->ev0, h->stream);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return VG_ERR_HIP; }
+    return VG_OK;
+}
+
+extern "C" int vg_timer_stop(vg_handle* h, float* ms) {
+    if (!h || !ms) return VG_ERR_BAD_ARG;
+    hipError_t e = hipEventRecord(h->ev1, h->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(h->ev1);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, h->ev0, h->ev1);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return VG_ERR_HIP; }
+    return VG_OK;
+}

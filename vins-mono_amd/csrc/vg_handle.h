@@ -1,0 +1,28 @@
+// vg_handle.h — the opaque handle behind include/vinsgpu.h (host only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "ba_layout.h"
+
+struct BaBatch {
+    BaLayout L;
+    BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap_ia = 0, cap_di = 0, cap_sc = 0, cap_out = 0, cap_iout = 0, cap_mout = 0, cap_miout = 0, cap_mscr = 0;
+    std::vector<int> h_ia, h_iout, h_miout, margin, nL;
+    std::vector<double> h_di, h_out, h_mout;
+    int nwin = 0;
+    bool uploaded = false, any_margin = false;
+    double flops = 0, bytes_in = 0, bytes_out = 0;
+};
+
+struct FeState;   // fe_host.hip
+
+struct vg_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    BaBatch ba;
+    FeState* fe = nullptr;
+};
