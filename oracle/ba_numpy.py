@@ -872,7 +872,32 @@ def marginalize(prob, st, flag, eps=1e-8):
                 new_blocks.append((kind, i - 1 if i == K - 1 else i))
         else:
             new_blocks.append((kind, i))
-    return dict(n=n, m=m, blocks=new_blocks, J0=J0, r0=r0, x0=x0, A=A2, b=b2)
+    return dict(n=n, m=m, blocks=new_blocks, J0=J0, r0=r0, x0=x0, A=A2, b=b2, A_full=A, b_full=bvec)
+
+
+def schur_extended(A, bvec, m):
+    """Schur complement of the leading m x m block in 80-bit extended precision (np.longdouble), exact inverse
+    (no eps cut).  NOT part of the reference algorithm: a yardstick that tells whose double-precision
+    eigen-based pseudo-inverse (numpy's or the device's) is closer to the truth when they disagree at 1e-8."""
+    Al = np.array(A, dtype=np.longdouble)
+    bl = np.array(bvec, dtype=np.longdouble)
+    M = 0.5 * (Al[:m, :m] + Al[:m, :m].T)
+    X = np.concatenate([Al[:m, m:], bl[:m, None]], axis=1)
+    # Gauss-Jordan on the SPD block (symmetric pivots are fine)
+    M = M.copy()
+    for k in range(m):
+        piv = M[k, k]
+        M[k, :] /= piv
+        X[k, :] /= piv
+        for i in range(m):
+            if i != k:
+                f = M[i, k]
+                if f != 0:
+                    M[i, :] -= f * M[k, :]
+                    X[i, :] -= f * X[k, :]
+    A2 = Al[m:, m:] - Al[m:, :m] @ X[:, :-1]
+    b2 = bl[m:] - Al[m:, :m] @ X[:, -1]
+    return np.array(A2, dtype=np.float64), np.array(b2, dtype=np.float64)
 
 
 def optimization(prob, flag):

@@ -128,3 +128,85 @@ def test_batch_is_bit_reproducible(handle):
         assert np.array_equal(a['pose'], b['pose']) and np.array_equal(a['inv_depth'], b['inv_depth'])
     single, _, _ = handle.ba_optimize(probs[1])
     assert np.array_equal(single['pose'], st_a[1]['pose'])
+
+
+def _check_prior(gp, op, tol=1e-7, dx=1e-12):
+    """Prior parity against (A, b) = the Schur complement BEFORE the second eigen-decomposition, recomputed in
+    extended precision from the oracle's assembled system (the double-precision eigen pseudo-inverse of Amm, whose
+    entries span 1e2..1e12, is itself only good to ~1e-8 relative in either implementation).
+    marginalize() drops eigen-directions with lambda <= 1e-8; for a gauge-deficient window those eigenvalues are
+    rounding noise (observed -0.09 .. +1e-3 against a spectrum reaching 4e7), so WHICH subspace is dropped — and
+    therefore J0^T r0 — is only defined up to the component of b in that noise subspace.  Both sides are therefore
+    held to the Schur complement: the HIP result must reproduce (A, b) at least as well as the oracle's own
+    eigen-reconstruction does (x3 slack), plus `dx` * Hessian row sums when the linearisation points differ by dx."""
+    assert gp is not None and op is not None
+    assert gp['blocks'] == op['blocks']
+    assert gp['n'] == op['n'] and gp['m'] == op['m']
+    H_g, H_o = gp['J0'].T @ gp['J0'], op['J0'].T @ op['J0']
+    g_g, g_o = gp['J0'].T @ gp['r0'], op['J0'].T @ op['r0']
+    A, b = B.schur_extended(op['A_full'], op['b_full'], op['m'])     # extended-precision yardstick
+    amax = np.abs(A).max()
+    rows = np.abs(A).sum(axis=1)
+    assert np.abs(H_g - A).max() < max(3 * np.abs(H_o - A).max(), tol * amax) + dx * amax
+    g_scale = np.abs(op['J0']).T @ np.abs(op['r0'])
+    assert np.abs(g_g - b).max() < 3 * np.abs(g_o - b).max() + tol * g_scale.max() + (dx * rows).max()
+    for a, c in zip(gp['x0'], op['x0']):
+        assert np.allclose(a, c, atol=max(1e-9, dx))
+
+
+@pytest.mark.parametrize("ex,td", [(0, 0), (1, 1)])
+def test_marginalize_old_parity(handle, ex, td):
+    """M1-M5 in isolation: both sides marginalise at the SAME state (the oracle's optimum, max_iters = 0)."""
+    seq = synth.SyntheticSequence(40 + ex, L=60, estimate_extrinsic=ex, estimate_td=td)
+    prob = seq.window(0)
+    x, _ = B.solve(prob)
+    at = dict(prob)
+    at.update(pose=x['pose'], sb=x['sb'], ex=x['ex'], td=x['td'], inv_depth=x['inv_depth'], max_iters=0)
+    st_o, _, pr_o = B.optimization(at, B.MARGIN_OLD)
+    st_g, sm_g, pr_g = handle.ba_optimize(at, ba.VG_MARGIN_OLD)
+    assert sm_g['status'] == 0 and sm_g['num_iterations'] == 0
+    assert np.allclose(st_g['pose'], st_o['pose'], atol=1e-13) and np.allclose(st_g['sb'], st_o['sb'], atol=1e-13)
+    _check_prior(pr_g, pr_o)
+
+
+def test_optimization_chain_two_windows(handle):
+    """solve + MARGIN_OLD twice; each side consumes its OWN prior and state (what a drop-in runs)."""
+    seq = synth.SyntheticSequence(40, L=60)
+    prob = seq.window(0)
+    st_o, _, pr_o = B.optimization(prob, B.MARGIN_OLD)
+    st_g, sm_g, pr_g = handle.ba_optimize(prob, ba.VG_MARGIN_OLD)
+    assert sm_g['status'] == 0
+    _check_prior(pr_g, pr_o, dx=1e-9)
+    prob2_o = seq.next_window(st_o, pr_o, 1)
+    seq_b = synth.SyntheticSequence(40, L=60)
+    seq_b.window(0)
+    prob2_g = seq_b.next_window(st_g, pr_g, 1)
+    st2_o, s2_o, pr2_o = B.optimization(prob2_o, B.MARGIN_OLD)
+    st2_g, sm2_g, pr2_g = handle.ba_optimize(prob2_g, ba.VG_MARGIN_OLD)
+    # the prior's constant cost term |r0|^2 divides by eigenvalues just above the 1e-8 cut (gauge directions),
+    # so the cost VALUE is only reproducible to ~1e-4; gradient/Hessian (hence the states) are not affected
+    assert np.isclose(sm2_g['final_cost'], s2_o['final_cost'], rtol=1e-3)
+    assert np.abs(st2_g['pose'] - st2_o['pose']).max() < 1e-4 * max(1.0, np.abs(st2_o['pose']).max())
+    assert np.abs(st2_g['sb'] - st2_o['sb']).max() < 1e-4 * max(1.0, np.abs(st2_o['sb']).max())
+    _check_prior(pr2_g, pr2_o, tol=1e-4, dx=1e-5)
+
+
+def test_marginalize_second_new_parity(handle):
+    _, _, prob2 = _window_with_prior(6, L=150)
+    K = prob2['pose'].shape[0]
+    assert (B.KIND_POSE, K - 2) in prob2['prior']['blocks']
+    prob2 = dict(prob2)
+    prob2['max_iters'] = 0
+    st_o, _, pr_o = B.optimization(prob2, B.MARGIN_SECOND_NEW)
+    st_g, sm, pr_g = handle.ba_optimize(prob2, ba.VG_MARGIN_SECOND_NEW)
+    _check_prior(pr_g, pr_o)
+    assert (B.KIND_POSE, K - 2) not in pr_g['blocks'] and pr_g['n'] == prob2['prior']['n'] - 6
+
+
+def test_marginalize_second_new_keeps_old_prior_when_pose_absent(handle):
+    _, _, prob2 = _window_with_prior(7, L=8)
+    K = prob2['pose'].shape[0]
+    if (B.KIND_POSE, K - 2) in prob2['prior']['blocks']:
+        pytest.skip("prior touches pose K-2 for this seed")
+    _, _, pr_g = handle.ba_optimize(prob2, ba.VG_MARGIN_SECOND_NEW)
+    assert pr_g is None        # valid == 0: caller keeps last_marginalization_info (estimator.cpp:935-936)

@@ -200,18 +200,27 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.oo_trace = o; o += 5 * VG_MAX_ITERS;
     L.ostride = up(o, 8);
     L.oi_stride = up(4 + VG_MAX_ITERS, 8);
-    // ---- marginalization outputs: kept dimension <= 6*K + 9 + 6 + 1, blocks <= K + 3
-    const int mcap = up(6 * L.K + 9 * 2 + 6 + 1, 8);
+    // ---- marginalization: kept dimension <= 6K + 2*9 + 6 + 1; blocks <= K + 4
+    L.mcap = up(6 * L.K + 9 * 2 + 6 + 1, 8);
+    const int mcap = L.mcap;
     L.mo_J0 = 0;
     L.mo_r0 = mcap * mcap;
     L.mo_x0 = L.mo_r0 + mcap;
     L.mo_stride = up(L.mo_x0 + (L.K + 4) * 9, 8);
     L.mi_stride = up(8 + 2 * (L.K + 4), 8);
-    // marg scratch: A (pos x pos) + V (m x m) + V2 (n x n) + vectors; pos <= mcap + 15 + Lcap
+    L.mg_posmax = up(mcap + 15 + L.Lcap, 2);
     {
-        const long pos = (long)mcap + 15 + L.Lcap;
-        long s = pos * pos * 2 + (long)mcap * mcap * 2 + 8 * pos + (long)L.Lcap * 64;
-        L.ms_stride = (int)up((int)s, 8);
+        // LDS of the marginalization kernel: [eigM ld^2][eigV ld^2][cs 2 ld][red 16][state][ints 256]
+        const int nstm = up(16 * L.K + 8 + 1, 2);
+        const int fixed = 16 + nstm + 128;
+        int ld = mcap;                               // big enough for the kept part; also used for Amm when m <= ld
+        while (2 * ld * ld + 2 * ld + fixed > 160 * 1024 / 8) ld -= 2;
+        L.mg_ld = ld;
+        L.mg_lds_bytes = (2 * ld * ld + 2 * ld + fixed) * 8;
+        if (ld < 8) { h->err = "marginalization LDS carve failed"; return VG_ERR_UNSUPPORTED; }
+        const long pm = L.mg_posmax;
+        long sdoubles = pm * pm + pm + (long)L.Fcap * 42 + 2 * pm * (mcap + 1) + 2 * pm * pm + 2L * mcap * mcap + 2 * L.Ncap + 480 + L.Lcap + 64;
+        L.ms_stride = (int)up((int)sdoubles, 8);
     }
     return VG_OK;
 }
@@ -479,7 +488,7 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
                     const int n = mi[1], nb = mi[3];
                     if (n > q->cap || nb > q->cap_blocks) { h->err = "vg_ba_prior capacity too small"; return VG_ERR_BAD_ARG; }
                     q->n = n; q->m = mi[2]; q->nblocks = nb;
-                    const int mcap = (int)std::lround(std::sqrt((double)L.mo_r0));
+                    const int mcap = L.mcap;
                     int x0n = 0;
                     for (int b = 0; b < nb; ++b) {
                         q->block_kind[b] = mi[8 + b];

@@ -1,4 +1,551 @@
-// placeholder until the marginalization kernel lands
+// ba_marg.hip — marginalization step of Estimator::optimization() (estimator.cpp:825-1000) on gfx950,
+// one workgroup per window, launched right after ba_solve_kernel on the same stream.
+//
+// Restates MarginalizationInfo::{addResidualBlockInfo, preMarginalize, marginalize, getParameterBlocks}
+// (factor/marginalization_factor.cpp:89-319) and ResidualBlockInfo::Evaluate's loss correction (:37-68):
+//   M1  re-evaluate the factors to be marginalised at the post-solve (gauge-fixed) state
+//   M2  index map: dropped blocks first (pose, speed-bias, landmarks ascending), kept after
+//       (poses ascending, speed-biases, extrinsic, td) — the reference's order is the iteration order of an
+//       unordered_map keyed by addresses, i.e. arbitrary; this canonical order is documented in DESIGN.md
+//   M3  A = sum J^T J, b = sum J^T r  (owner threads, no atomics -> bit-reproducible)
+//   M4  Amm^+ by symmetric eigen-decomposition with the eps = 1e-8 cut, Schur complement, second
+//       eigen-decomposition -> linearized_jacobians / linearized_residuals
+//   M5  kept-block list re-labelled for the slid window (addr_shift, estimator.cpp:913-930 / :969-996)
+// The eigen-solver is a parallel two-sided Jacobi (round-robin pairing, 2x2 block owners) held in LDS.
 #include <hip/hip_runtime.h>
 #include "ba_layout.h"
-extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaPtrs& P, hipStream_t stream) { return hipSuccess; }
+#include "ba_factors.h"
+#include "../../include/vinsgpu.h"
+
+#define MG_EPS 1e-8
+#define MG_MAXSWEEP 30
+
+struct MCtx {
+    BaLayout L;
+    const int* ia; const int* hdr; const double* di; double* sc; double* ms; double* lds;
+    int tid, lane, wave;
+    double focal, tr, row, gnorm;
+};
+
+DEV double mg_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+DEV double mg_block_sum(const MCtx& c, double* red, double v) {
+    v = mg_wave_sum(v);
+    __syncthreads();
+    if (c.lane == 0) red[c.wave] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BA_NW; ++w) s += red[w];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Parallel two-sided Jacobi eigen-decomposition of the symmetric n x n matrix M (leading dimension ld).
+// On exit diag(M) = eigenvalues, V (ld x ld, row-major) holds the eigenvectors as COLUMNS.
+// `cs` is an LDS scratch of 2*ld doubles, `red` of BA_NW doubles.
+DEV void jacobi_eig(const MCtx& c, double* M, double* V, int n, int ld, double* cs, double* red) {
+    const int N = (n + 1) & ~1;           // even player count (a padding player has zero row/col)
+    const int half = N / 2;
+    for (int k = c.tid; k < ld * ld; k += BA_NT) {
+        const int i = k / ld, j = k % ld;
+        V[k] = (i == j) ? 1.0 : 0.0;
+        if (i >= n || j >= n) M[k] = 0.0;
+    }
+    __syncthreads();
+    double fro = 0.0;
+    for (int k = c.tid; k < n * n; k += BA_NT) { const double v = M[(k / n) * ld + k % n]; fro += v * v; }
+    fro = mg_block_sum(c, red, fro);
+    // stopping rule: a pair is rotated unless |a_pq| <= 1e-16 sqrt(|a_pp a_qq|) (relative accuracy for the small
+    // eigenvalues, which the eps = 1e-8 cut and the 1/lambda of the pseudo-inverse are sensitive to) or
+    // |a_pq| <= 1e-19 ||A||_F (absolute floor for null directions); stop when a sweep rotates nothing.
+    const double floor_abs = sqrt(fro) * 1e-19;
+    for (int sweep = 0; sweep < MG_MAXSWEEP; ++sweep) {
+        double nrot = 0.0;
+        for (int r = 0; r < N - 1; ++r) {
+            // pair k: (p,q)
+            for (int k = c.tid; k < half; k += BA_NT) {
+                int p, q;
+                if (k == 0) { p = N - 1; q = r; }
+                else { p = (r + k) % (N - 1); q = (r - k + N - 1) % (N - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double cc = 1.0, ss = 0.0;
+                if (q < n) {
+                    const double apq = M[p * ld + q], app = M[p * ld + p], aqq = M[q * ld + q];
+                    if (fabs(apq) > floor_abs && fabs(apq) > 1e-16 * sqrt(fabs(app * aqq))) {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        cc = 1.0 / sqrt(t * t + 1.0);
+                        ss = t * cc;
+                        nrot += 1.0;
+                    }
+                }
+                cs[2 * k] = cc; cs[2 * k + 1] = ss;
+            }
+            __syncthreads();
+            // 2x2 block owners: block (ka, kb)
+            for (int w = c.tid; w < half * half; w += BA_NT) {
+                const int ka = w / half, kb = w % half;
+                int p, q, rr, s;
+                if (ka == 0) { p = N - 1; q = r; } else { p = (r + ka) % (N - 1); q = (r - ka + N - 1) % (N - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                if (kb == 0) { rr = N - 1; s = r; } else { rr = (r + kb) % (N - 1); s = (r - kb + N - 1) % (N - 1); }
+                if (rr > s) { const int t = rr; rr = s; s = t; }
+                const double ca = cs[2 * ka], sa = cs[2 * ka + 1], cb = cs[2 * kb], sb = cs[2 * kb + 1];
+                const bool qv = q < n, sv = s < n;   // padding index (== n when n odd) is the larger one
+                const double m00 = M[p * ld + rr];
+                const double m01 = sv ? M[p * ld + s] : 0.0;
+                const double m10 = qv ? M[q * ld + rr] : 0.0;
+                const double m11 = (qv && sv) ? M[q * ld + s] : 0.0;
+                // J_a^T M
+                const double t00 = ca * m00 - sa * m10, t01 = ca * m01 - sa * m11;
+                const double t10 = sa * m00 + ca * m10, t11 = sa * m01 + ca * m11;
+                // (.) J_b
+                double n00 = cb * t00 - sb * t01, n01 = sb * t00 + cb * t01;
+                double n10 = cb * t10 - sb * t11, n11 = sb * t10 + cb * t11;
+                if (ka == kb) { n01 = 0.0; n10 = 0.0; }
+                M[p * ld + rr] = n00;
+                if (sv) M[p * ld + s] = n01;
+                if (qv) M[q * ld + rr] = n10;
+                if (qv && sv) M[q * ld + s] = n11;
+            }
+            // V <- V J_b : thread per (row, pair)
+            for (int w = c.tid; w < n * half; w += BA_NT) {
+                const int i = w / half, kb = w % half;
+                int rr, s;
+                if (kb == 0) { rr = N - 1; s = r; } else { rr = (r + kb) % (N - 1); s = (r - kb + N - 1) % (N - 1); }
+                if (rr > s) { const int t = rr; rr = s; s = t; }
+                if (s >= n) continue;
+                const double cb = cs[2 * kb], sb = cs[2 * kb + 1];
+                const double v0 = V[i * ld + rr], v1 = V[i * ld + s];
+                V[i * ld + rr] = cb * v0 - sb * v1;
+                V[i * ld + s] = sb * v0 + cb * v1;
+            }
+            __syncthreads();
+        }
+        if (mg_block_sum(c, red, nrot) == 0.0) break;
+    }
+    __syncthreads();
+}
+
+// marginalization column maps, kept in LDS ints
+struct MgMap {
+    int* pose;   // [BA_MAX_K] column of pose i or -1
+    int* sb;     // [BA_MAX_K]
+    int* misc;   // [0]=ex col, [1]=td col, [2]=m, [3]=n, [4]=n0, [5]=pos
+    int* lm;     // global: [Lcap] column of landmark l or -1
+    int* l0;     // global: [Lcap] list of frame-0 landmarks
+};
+
+extern "C" __global__ __launch_bounds__(BA_NT) void ba_marg_kernel(BaLayout L, BaPtrs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MCtx c;
+    c.L = L;
+    const int w = blockIdx.x;
+    c.ia = P.iarr + (size_t)w * L.istride;
+    c.hdr = c.ia + L.io_hdr;
+    const int flag = c.hdr[H_MARGIN];
+    int* mi = P.miout + (size_t)w * L.mi_stride;
+    if (flag == VG_MARGIN_NONE) return;
+    const int* iout = P.iout + (size_t)w * L.oi_stride;
+    if (iout[0] != VG_OK) return;                       // failed solve: no prior
+    c.di = P.din + (size_t)w * L.dstride;
+    c.sc = P.scr + (size_t)w * L.sstride;
+    c.ms = P.mscr + (size_t)w * L.ms_stride;
+    c.lds = (double*)smem;
+    c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6;
+    c.focal = c.di[L.do_par + P_FOCAL]; c.tr = c.di[L.do_par + P_TR]; c.row = c.di[L.do_par + P_ROW];
+    c.gnorm = c.di[L.do_par + P_GNORM];
+    const double* outp = P.out + (size_t)w * L.ostride;
+    double* mo = P.mout + (size_t)w * L.mo_stride;
+    const int K = L.K, nL = c.hdr[H_L], nprior = c.hdr[H_NPRIOR], nblk = c.hdr[H_NBLK];
+    const int mcap = L.mcap;
+
+    // ---- LDS carve: [eigM ld*ld][eigV ld*ld][cs 2*ld][red 16][x state][ints]
+    const int ld = L.mg_ld;
+    double* eM = c.lds;
+    double* eV = eM + ld * ld;
+    double* cs = eV + ld * ld;
+    double* red = cs + 2 * ld;
+    double* x = red + 16;
+    const int nst = (7 * K + 9 * K + 8 + 1) & ~1;
+    int* li = (int*)(x + nst);
+    MgMap mp;
+    mp.pose = li; mp.sb = li + 16; mp.misc = li + 32;
+    // ---- global scratch carve
+    const int posmax = L.mg_posmax;
+    double* A = c.ms;                        // posmax x posmax
+    double* bv = A + (size_t)posmax * posmax;
+    double* rec = bv + posmax;               // Fcap x 42 projection records
+    double* T1 = rec + (size_t)L.Fcap * 42;  // posmax x (mcap+1)
+    double* T2 = T1 + (size_t)posmax * (mcap + 1);
+    double* gM = T2 + (size_t)posmax * (mcap + 1);   // staging / eig fallback (posmax^2) x 2
+    double* gV = gM + (size_t)posmax * posmax;
+    double* g2M = gV + (size_t)posmax * posmax;      // second-eig fallback (mcap^2) x 2
+    double* g2V = g2M + (size_t)mcap * mcap;
+    double* prv = g2V + (size_t)mcap * mcap;         // prior residual (Ncap) + dx (Ncap)
+    double* imuJ = prv + 2 * L.Ncap;         // 450 + 15
+    mp.lm = (int*)(imuJ + 480);
+    mp.l0 = mp.lm + L.Lcap;
+
+    // ---- state after the gauge fix (what vector2double() repacks at estimator.cpp:831 / :942)
+    for (int k = c.tid; k < 7 * K; k += BA_NT) x[k] = outp[L.oo_pose + k];
+    for (int k = c.tid; k < 9 * K; k += BA_NT) x[7 * K + k] = outp[L.oo_sb + k];
+    if (c.tid < 7) x[16 * K + c.tid] = outp[L.oo_ex + c.tid];
+    if (c.tid == 7) x[16 * K + 7] = outp[L.oo_td];
+    const double* lam = outp + L.oo_lam;
+    const double* ex = x + 16 * K;
+    const int* pk = c.ia + L.io_pb_kind;
+    const int* pidx = c.ia + L.io_pb_idx;
+    const int* poff = c.ia + L.io_pb_off;
+    const int* px0off = c.ia + L.io_pb_x0off;
+    const bool imu0 = (flag == VG_MARGIN_OLD) && c.ia[L.io_imu_valid + 0] && c.di[L.do_imu + IM_SUMDT] < 10.0;
+    __syncthreads();
+
+    // ---- M2: structure (single thread; tiny)
+    if (c.tid == 0) {
+        bool has_pose[BA_MAX_K], has_sb[BA_MAX_K], has_ex = false, has_td = false;
+        for (int i = 0; i < BA_MAX_K; ++i) { has_pose[i] = false; has_sb[i] = false; }
+        for (int b = 0; b < nblk; ++b) {
+            if (pk[b] == VG_BLK_POSE) has_pose[pidx[b]] = true;
+            else if (pk[b] == VG_BLK_SPEEDBIAS) has_sb[pidx[b]] = true;
+            else if (pk[b] == VG_BLK_EXPOSE) has_ex = true;
+            else has_td = true;
+        }
+        int n0 = 0;
+        bool valid = true;
+        if (flag == VG_MARGIN_OLD) {
+            if (imu0) { has_pose[0] = has_pose[1] = true; has_sb[0] = has_sb[1] = true; }
+            for (int l = 0; l < nL; ++l) {
+                mp.lm[l] = -1;
+                if (c.ia[L.io_lm_start + l] != 0) continue;
+                mp.l0[n0++] = l;
+                has_pose[0] = true; has_ex = true;
+                if (L.t) has_td = true;
+                for (int f = c.ia[L.io_lm_fbeg + l]; f < c.ia[L.io_lm_fbeg + l + 1]; ++f) {
+                    const int j = c.ia[L.io_fac_j + f];
+                    if (j < K) has_pose[j] = true;
+                }
+            }
+            if (nblk == 0 && !imu0 && n0 == 0) valid = false;
+        } else {
+            if (nblk == 0 || !has_pose[K - 2]) valid = false;      // estimator.cpp:935-936
+        }
+        int pos = 0;
+        for (int i = 0; i < BA_MAX_K; ++i) { mp.pose[i] = -1; mp.sb[i] = -1; }
+        if (flag == VG_MARGIN_OLD) {
+            if (has_pose[0]) { mp.pose[0] = pos; pos += 6; }
+            if (has_sb[0]) { mp.sb[0] = pos; pos += 9; }
+            for (int k = 0; k < n0; ++k) mp.lm[mp.l0[k]] = pos++;
+        } else if (valid) { mp.pose[K - 2] = pos; pos += 6; }
+        const int m = pos;
+        for (int i = 0; i < K; ++i) if (has_pose[i] && mp.pose[i] < 0) { mp.pose[i] = pos; pos += 6; }
+        for (int i = 0; i < K; ++i) if (has_sb[i] && mp.sb[i] < 0) { mp.sb[i] = pos; pos += 9; }
+        mp.misc[0] = -1; mp.misc[1] = -1;
+        if (has_ex) { mp.misc[0] = pos; pos += 6; }
+        if (has_td) { mp.misc[1] = pos; pos += 1; }
+        mp.misc[2] = m; mp.misc[3] = pos - m; mp.misc[4] = n0; mp.misc[5] = pos;
+        mp.misc[6] = (valid && pos - m > 0 && pos - m <= mcap && pos <= posmax) ? 1 : 0;
+    }
+    __syncthreads();
+    const int m = mp.misc[2], n = mp.misc[3], n0 = mp.misc[4], pos = mp.misc[5];
+    if (!mp.misc[6]) { if (c.tid == 0) { mi[0] = 0; mi[1] = 0; } return; }
+    const int cex = mp.misc[0], ctd = mp.misc[1];
+
+    for (int k = c.tid; k < pos * pos; k += BA_NT) A[(k / pos) * posmax + k % pos] = 0.0;
+    for (int k = c.tid; k < pos; k += BA_NT) bv[k] = 0.0;
+    __syncthreads();
+
+    // ---- M1/M3 (a): prior factor at the new state: r = r0 + J0 dx ; A += J0^T J0 ; b += J0^T r
+    if (nblk > 0) {
+        double* dx = prv + L.Ncap;
+        for (int b = c.tid; b < nblk; b += BA_NT) {
+            const double* xb = pk[b] == VG_BLK_POSE ? x + 7 * pidx[b] : (pk[b] == VG_BLK_SPEEDBIAS ? x + 7 * K + 9 * pidx[b]
+                               : (pk[b] == VG_BLK_EXPOSE ? ex : ex + 7));
+            const double* x0 = c.di + L.do_px0 + px0off[b];
+            double* d = dx + poff[b];
+            if (pk[b] == VG_BLK_SPEEDBIAS) { for (int k = 0; k < 9; ++k) d[k] = xb[k] - x0[k]; }
+            else if (pk[b] == VG_BLK_TD) d[0] = xb[0] - x0[0];
+            else {
+                d[0] = xb[0] - x0[0]; d[1] = xb[1] - x0[1]; d[2] = xb[2] - x0[2];
+                double qi[4], dq[4];
+                q_inv(x0 + 3, qi);
+                q_mul(qi, xb + 3, dq);
+                const double sgn = (dq[3] >= 0) ? 2.0 : -2.0;
+                d[3] = sgn * dq[0]; d[4] = sgn * dq[1]; d[5] = sgn * dq[2];
+            }
+        }
+        __syncthreads();
+        const double* J0t = c.di + L.do_pJ0t;
+        for (int r = c.tid; r < nprior; r += BA_NT) {
+            double s = c.di[L.do_pr0 + r];
+            for (int k = 0; k < nprior; ++k) s += J0t[k * L.Ncap + r] * dx[k];
+            prv[r] = s;
+        }
+        __syncthreads();
+        const double* Hp = c.sc + L.so_Hp;          // J0^T J0 (lower), left by the solve kernel
+        const double* J0 = c.di + L.do_pJ0;
+        for (int wk = c.tid; wk < nprior * nprior + nprior; wk += BA_NT) {
+            const bool isg = wk >= nprior * nprior;
+            const int a = isg ? wk - nprior * nprior : wk / nprior, b = isg ? 0 : wk % nprior;
+            int ca = -1, cb = -1;
+            for (int blk = 0; blk < nblk; ++blk) {
+                const int sz = pk[blk] == VG_BLK_SPEEDBIAS ? 9 : (pk[blk] == VG_BLK_TD ? 1 : 6);
+                const int base = pk[blk] == VG_BLK_POSE ? mp.pose[pidx[blk]] : (pk[blk] == VG_BLK_SPEEDBIAS ? mp.sb[pidx[blk]]
+                                 : (pk[blk] == VG_BLK_EXPOSE ? cex : ctd));
+                if (a >= poff[blk] && a < poff[blk] + sz) ca = base + a - poff[blk];
+                if (b >= poff[blk] && b < poff[blk] + sz) cb = base + b - poff[blk];
+            }
+            if (isg) {
+                double s = 0.0;
+                for (int r = 0; r < nprior; ++r) s += J0[r * L.Ncap + a] * prv[r];
+                bv[ca] += s;
+            } else {
+                A[ca * posmax + cb] += (a >= b) ? Hp[a * L.Ncap + b] : Hp[b * L.Ncap + a];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- (b) IMU factor 0 -> 1
+    if (imu0) {
+        const double* pre = c.di + L.do_imu;
+        const double* U = c.sc + L.so_imuU;
+        if (c.tid < 31) {
+            ImuCtx ic;
+            imu_ctx<true>(pre, x, x + 7 * K, x + 7, x + 7 * K + 9, c.gnorm, ic);
+            if (c.tid == 30) {
+                for (int r = 0; r < 15; ++r) {
+                    double s = 0.0;
+                    for (int k = r; k < 15; ++k) s += U[r * 15 + k] * ic.r[k];
+                    imuJ[450 + r] = s;
+                }
+            } else {
+                double raw[15];
+                imu_raw_col(ic, pre, c.tid, raw);
+                for (int r = 0; r < 15; ++r) {
+                    double s = 0.0;
+                    for (int k = r; k < 15; ++k) s += U[r * 15 + k] * raw[k];
+                    imuJ[r * 30 + c.tid] = s;
+                }
+            }
+        }
+        __syncthreads();
+        for (int wk = c.tid; wk < 930; wk += BA_NT) {
+            const bool isg = wk >= 900;
+            const int a = isg ? wk - 900 : wk / 30, b = isg ? 0 : wk % 30;
+            auto colof = [&](int lc) {
+                if (lc < 6) return mp.pose[0] + lc;
+                if (lc < 15) return mp.sb[0] + lc - 6;
+                if (lc < 21) return mp.pose[1] + lc - 15;
+                return mp.sb[1] + lc - 21;
+            };
+            double s = 0.0;
+            if (isg) { for (int r = 0; r < 15; ++r) s += imuJ[r * 30 + a] * imuJ[450 + r]; bv[colof(a)] += s; }
+            else { for (int r = 0; r < 15; ++r) s += imuJ[r * 30 + a] * imuJ[r * 30 + b]; A[colof(a) * posmax + colof(b)] += s; }
+        }
+    }
+    __syncthreads();
+    // ---- (c) projection factors of the landmarks anchored at frame 0, with the loss correction
+    int nf0 = 0;
+    if (flag == VG_MARGIN_OLD && n0 > 0) {
+        // compact factor list: factors of L0 landmarks are the contiguous runs lm_fbeg[l]..; enumerate
+        // record layout (42): r[2] | Ji[12] | Jj[12] | Jex[12] | Jl[2] | Jtd[2], rows interleaved as [row][col]
+        for (int k = 0; k < n0; ++k) nf0 += c.ia[L.io_lm_fbeg + mp.l0[k] + 1] - c.ia[L.io_lm_fbeg + mp.l0[k]];
+        for (int wk = c.tid; wk < c.hdr[H_F]; wk += BA_NT) {
+            const int f = wk;
+            const int l = c.ia[L.io_fac_lm + f];
+            if (mp.lm[l] < 0) continue;
+            const int j = c.ia[L.io_fac_j + f];
+            if (j >= K) continue;                 // relocalisation factors are not marginalised (estimator.cpp:864-903)
+            const double* oi = c.di + L.do_obs + c.ia[L.io_fac_oi + f] * BA_OBS_STRIDE;
+            const double* oj = c.di + L.do_obs + c.ia[L.io_fac_oj + f] * BA_OBS_STRIDE;
+            double* R = rec + (size_t)f * 42;
+            double Jtd[2] = {0, 0};
+            if (L.t) proj_eval<true, true, true>(x, x + 7 * j, ex, lam[l], oi, oj, ex[7], c.focal, c.tr, c.row, R, R + 2, R + 14, R + 26, R + 38, Jtd);
+            else proj_eval<false, true, true>(x, x + 7 * j, ex, lam[l], oi, oj, 0.0, c.focal, c.tr, c.row, R, R + 2, R + 14, R + 26, R + 38, Jtd);
+            R[40] = Jtd[0]; R[41] = Jtd[1];
+            const double sq = sqrt(1.0 / (1.0 + R[0] * R[0] + R[1] * R[1]));   // Cauchy: rho'' < 0 branch (:46-50)
+            for (int k = 0; k < 42; ++k) R[k] *= sq;
+        }
+        __syncthreads();
+        // owners of the dense camera part: entries (a, b) over columns of {pose*, ex, td}; loop over factors
+        const int ncam = 6 * K + 7;
+        for (int wk = c.tid; wk < ncam * ncam + ncam; wk += BA_NT) {
+            const bool isg = wk >= ncam * ncam;
+            const int a = isg ? wk - ncam * ncam : wk / ncam, b = isg ? 0 : wk % ncam;
+            // decode camera index -> (block kind, frame, component)
+            const int fa = a / 6, ka = a % 6, fb = b / 6, kb = b % 6;
+            const bool a_pose = a < 6 * K, b_pose = b < 6 * K;
+            const bool a_ex = !a_pose && a < 6 * K + 6, b_ex = !b_pose && b < 6 * K + 6;
+            int ca, cb;
+            if (a_pose) ca = mp.pose[fa] < 0 ? -1 : mp.pose[fa] + ka; else if (a_ex) ca = cex < 0 ? -1 : cex + a - 6 * K; else ca = ctd;
+            if (b_pose) cb = mp.pose[fb] < 0 ? -1 : mp.pose[fb] + kb; else if (b_ex) cb = cex < 0 ? -1 : cex + b - 6 * K; else cb = ctd;
+            if (ca < 0 || (!isg && cb < 0)) continue;
+            if (!L.t && (a == 6 * K + 6 || (!isg && b == 6 * K + 6))) continue;
+            double s = 0.0;
+            for (int k = 0; k < n0; ++k) {
+                const int l = mp.l0[k];
+                for (int f = c.ia[L.io_lm_fbeg + l]; f < c.ia[L.io_lm_fbeg + l + 1]; ++f) {
+                    const int j = c.ia[L.io_fac_j + f];
+                    if (j >= K) continue;
+                    const double* R = rec + (size_t)f * 42;
+                    // Jacobian entry of this factor in camera column a (row 0 / row 1)
+                    double a0, a1, b0, b1;
+                    if (a_pose) { if (fa == 0) { a0 = R[2 + ka]; a1 = R[8 + ka]; } else if (fa == j) { a0 = R[14 + ka]; a1 = R[20 + ka]; } else continue; }
+                    else if (a_ex) { a0 = R[26 + a - 6 * K]; a1 = R[32 + a - 6 * K]; }
+                    else { a0 = R[40]; a1 = R[41]; }
+                    if (isg) { b0 = R[0]; b1 = R[1]; }
+                    else if (b_pose) { if (fb == 0) { b0 = R[2 + kb]; b1 = R[8 + kb]; } else if (fb == j) { b0 = R[14 + kb]; b1 = R[20 + kb]; } else continue; }
+                    else if (b_ex) { b0 = R[26 + b - 6 * K]; b1 = R[32 + b - 6 * K]; }
+                    else { b0 = R[40]; b1 = R[41]; }
+                    s += a0 * b0 + a1 * b1;
+                }
+            }
+            if (isg) bv[ca] += s; else A[ca * posmax + cb] += s;
+        }
+        // landmark rows / columns: thread per (landmark, camera column | self | rhs)
+        for (int wk = c.tid; wk < n0 * (ncam + 2); wk += BA_NT) {
+            const int k = wk / (ncam + 2), a = wk % (ncam + 2);
+            const int l = mp.l0[k], cl = mp.lm[l];
+            int ca = -2;
+            const int fa = a / 6, ka = a % 6;
+            if (a < 6 * K) ca = mp.pose[fa] < 0 ? -1 : mp.pose[fa] + ka;
+            else if (a < 6 * K + 6) ca = cex < 0 ? -1 : cex + a - 6 * K;
+            else if (a == 6 * K + 6) ca = L.t ? ctd : -1;
+            if (ca == -1) continue;
+            double s = 0.0;
+            for (int f = c.ia[L.io_lm_fbeg + l]; f < c.ia[L.io_lm_fbeg + l + 1]; ++f) {
+                const int j = c.ia[L.io_fac_j + f];
+                if (j >= K) continue;
+                const double* R = rec + (size_t)f * 42;
+                double a0, a1;
+                if (a < 6 * K) { if (fa == 0) { a0 = R[2 + ka]; a1 = R[8 + ka]; } else if (fa == j) { a0 = R[14 + ka]; a1 = R[20 + ka]; } else continue; }
+                else if (a < 6 * K + 6) { a0 = R[26 + a - 6 * K]; a1 = R[32 + a - 6 * K]; }
+                else if (a == 6 * K + 6) { a0 = R[40]; a1 = R[41]; }
+                else if (a == ncam) { a0 = R[38]; a1 = R[39]; }          // (l, l)
+                else { a0 = R[0]; a1 = R[1]; }                           // rhs
+                s += a0 * R[38] + a1 * R[39];
+            }
+            if (a == ncam) A[cl * posmax + cl] += s;
+            else if (a == ncam + 1) bv[cl] += s;
+            else { A[cl * posmax + ca] += s; A[ca * posmax + cl] += s; }
+        }
+    }
+    __syncthreads();
+
+    // ---- M4: Amm^+ via eigen-decomposition, Schur complement
+    {
+        const bool in_lds = m <= ld;
+        double* Mm = in_lds ? eM : gM;
+        double* Vm = in_lds ? eV : gV;
+        const int ldm = in_lds ? ld : posmax;
+        for (int k = c.tid; k < m * m; k += BA_NT) {
+            const int i = k / m, j = k % m;
+            Mm[i * ldm + j] = 0.5 * (A[i * posmax + j] + A[j * posmax + i]);
+        }
+        __syncthreads();
+        jacobi_eig(c, Mm, Vm, m, ldm, cs, red);
+        // T1 = Lambda^+ V^T [Amr | bmm]   (m x (n+1))
+        for (int k = c.tid; k < m * (n + 1); k += BA_NT) {
+            const int i = k / (n + 1), j = k % (n + 1);
+            const double lamb = Mm[i * ldm + i];
+            double s = 0.0;
+            if (lamb > MG_EPS) {
+                for (int r = 0; r < m; ++r) s += Vm[r * ldm + i] * (j < n ? A[r * posmax + m + j] : bv[r]);
+                s /= lamb;
+            }
+            T1[i * (mcap + 1) + j] = s;
+        }
+        __syncthreads();
+        // T2 = V T1  = Amm^+ [Amr | bmm]
+        for (int k = c.tid; k < m * (n + 1); k += BA_NT) {
+            const int i = k / (n + 1), j = k % (n + 1);
+            double s = 0.0;
+            for (int r = 0; r < m; ++r) s += Vm[i * ldm + r] * T1[r * (mcap + 1) + j];
+            T2[i * (mcap + 1) + j] = s;
+        }
+        __syncthreads();
+        // A' = Arr - Arm T2[:, :n] ; b' = brr - Arm T2[:, n]   -> eM (n x n, ld), b' -> T1 row 0 (reuse)
+        for (int k = c.tid; k < n * (n + 1); k += BA_NT) {
+            const int i = k / (n + 1), j = k % (n + 1);
+            double s = (j < n) ? A[(m + i) * posmax + m + j] : bv[m + i];
+            for (int r = 0; r < m; ++r) s -= A[(m + i) * posmax + r] * T2[r * (mcap + 1) + j];
+            if (j < n) gM[i * posmax + j] = s; else gV[i] = s;      // stage in global (eM may still be Mm)
+        }
+        __syncthreads();
+    }
+    double* bp = gV;                       // b' (n)
+    const bool n_lds = n <= ld;
+    double* M2 = n_lds ? eM : g2M;
+    double* V2 = n_lds ? eV : g2V;
+    const int ld2 = n_lds ? ld : n;
+    for (int k = c.tid; k < n * n; k += BA_NT) M2[(k / n) * ld2 + k % n] = gM[(k / n) * posmax + k % n];
+    __syncthreads();
+    jacobi_eig(c, M2, V2, n, ld2, cs, red);
+    // ascending order like SelfAdjointEigenSolver: rank of each eigenvalue
+    int* rank = li + 48;
+    for (int i = c.tid; i < n; i += BA_NT) {
+        const double li_ = M2[i * ld2 + i];
+        int rk = 0;
+        for (int j = 0; j < n; ++j) {
+            const double lj = M2[j * ld2 + j];
+            rk += (lj < li_ || (lj == li_ && j < i)) ? 1 : 0;
+        }
+        rank[i] = rk;
+    }
+    __syncthreads();
+    // linearized_jacobians = diag(sqrt(S)) V^T ; linearized_residuals = diag(sqrt(S_inv)) V^T b'
+    for (int k = c.tid; k < n * n; k += BA_NT) {
+        const int i = k / n, j = k % n;           // eigenpair i, column j
+        const double lamb = M2[i * ld2 + i];
+        const double sv = lamb > MG_EPS ? sqrt(lamb) : 0.0;
+        mo[L.mo_J0 + (size_t)rank[i] * mcap + j] = sv * V2[j * ld2 + i];
+    }
+    for (int i = c.tid; i < n; i += BA_NT) {
+        const double lamb = M2[i * ld2 + i];
+        double s = 0.0;
+        if (lamb > MG_EPS) {
+            for (int r = 0; r < n; ++r) s += V2[r * ld2 + i] * bp[r];
+            s *= sqrt(1.0 / lamb);
+        }
+        mo[L.mo_r0 + rank[i]] = s;
+    }
+    // ---- M5: kept blocks, re-labelled for the slid window, with their linearisation point
+    if (c.tid == 0) {
+        int nb = 0, x0o = 0;
+        int* kind = mi + 8;
+        int* idx = mi + 8 + (K + 4);
+        double* x0 = mo + L.mo_x0;
+        for (int i = 0; i < K; ++i) {
+            if (mp.pose[i] < m) continue;
+            kind[nb] = VG_BLK_POSE;
+            idx[nb] = (flag == VG_MARGIN_OLD) ? i - 1 : (i == K - 1 ? i - 1 : i);
+            for (int k = 0; k < 7; ++k) x0[x0o + k] = x[7 * i + k];
+            x0o += 7; ++nb;
+        }
+        for (int i = 0; i < K; ++i) {
+            if (mp.sb[i] < m) continue;
+            kind[nb] = VG_BLK_SPEEDBIAS;
+            idx[nb] = (flag == VG_MARGIN_OLD) ? i - 1 : (i == K - 1 ? i - 1 : i);
+            for (int k = 0; k < 9; ++k) x0[x0o + k] = x[7 * K + 9 * i + k];
+            x0o += 9; ++nb;
+        }
+        if (cex >= 0) { kind[nb] = VG_BLK_EXPOSE; idx[nb] = 0; for (int k = 0; k < 7; ++k) x0[x0o + k] = ex[k]; x0o += 7; ++nb; }
+        if (ctd >= 0) { kind[nb] = VG_BLK_TD; idx[nb] = 0; x0[x0o++] = ex[7]; ++nb; }
+        mi[0] = 1; mi[1] = n; mi[2] = m; mi[3] = nb;
+    }
+}
+
+extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaPtrs& P, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba_marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ba_marg_kernel, dim3(L.nwin), dim3(BA_NT), L.mg_lds_bytes, stream, L, P);
+    return hipGetLastError();
+}
