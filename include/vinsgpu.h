@@ -172,6 +172,8 @@ int vg_ba_optimize(vg_handle* h, const vg_ba_problem* in, int margin_flag,
  * All windows of a batch must share K, estimate_extrinsic, estimate_td and relo presence. */
 int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* const* in, const int* margin_flags);
 int vg_ba_batch_run_async(vg_handle* h);
+/* same as run_async but synchronous and timed with HIP events on the handle's stream: per-kernel durations */
+int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_ms);
 int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* out_states,
                          vg_ba_summary* out_summaries, vg_ba_prior* const* out_priors);
 /* algorithmic work of the uploaded batch for roofline accounting (SURVEY.md 8(d) flop model) */

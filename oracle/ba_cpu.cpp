@@ -1,0 +1,745 @@
+// ba_cpu.cpp — dependency-free single-thread C++17 restatement of Estimator::optimization()
+// (TEST INFRASTRUCTURE + the timed "cpu_baseline" of bench.py; never linked into the product).
+//
+// PARITY UNPINNED: Ceres / Eigen are not available in this environment (see oracle/ASSUMPTIONS.md); this
+// is the "restated single-thread Ceres-equivalent path (DENSE_SCHUR + DOGLEG)".  It is written the way the
+// reference executes on a CPU: one Evaluate() per residual block producing dense small Jacobians
+// (factor/projection_factor.cpp:21-121, projection_td_factor.cpp:34-141, imu_factor.h:19-179,
+// marginalization_factor.cpp:333-381), a per-landmark Schur eliminator, a dense LL^T of the reduced
+// camera matrix, Ceres' dogleg trust-region loop, double2vector's gauge fix
+// (estimator.cpp:530-619) and MarginalizationInfo::marginalize (marginalization_factor.cpp:174-297) with a
+// tridiagonal-QL symmetric eigen-solver (the algorithm family of Eigen::SelfAdjointEigenSolver).
+// It shares NO code with vins-mono_amd/csrc; only the POD structs of include/vinsgpu.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "../include/vinsgpu.h"
+
+namespace {
+typedef std::vector<double> Vec;
+
+// ---------------------------------------------------------------- small fixed-size algebra
+struct Q { double x, y, z, w; };
+inline Q qmul(const Q& a, const Q& b) {
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+            a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+inline Q qinv(const Q& q) { double n = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; return {-q.x / n, -q.y / n, -q.z / n, q.w / n}; }
+inline Q qnorm(const Q& q) { double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w); return {q.x / n, q.y / n, q.z / n, q.w / n}; }
+inline Q qload(const double* p) { return {p[0], p[1], p[2], p[3]}; }
+struct M3 { double m[3][3]; };
+inline M3 q2R(const Q& q) {
+    double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    return {{{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}}};
+}
+inline Q R2q(const M3& M) {
+    const double(*m)[3] = M.m;
+    double t = m[0][0] + m[1][1] + m[2][2];
+    double q[4];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (m[2][1] - m[1][2]) * t; q[1] = (m[0][2] - m[2][0]) * t; q[2] = (m[1][0] - m[0][1]) * t;
+    } else {
+        int i = 0; if (m[1][1] > m[0][0]) i = 1; if (m[2][2] > m[i][i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (m[k][j] - m[j][k]) * t; q[j] = (m[j][i] + m[i][j]) * t; q[k] = (m[k][i] + m[i][k]) * t;
+    }
+    return {q[0], q[1], q[2], q[3]};
+}
+inline M3 mul(const M3& a, const M3& b) { M3 c; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j]; return c; }
+inline M3 tr(const M3& a) { M3 c; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[j][i]; return c; }
+inline void mv(const M3& a, const double* v, double* o) { for (int i = 0; i < 3; ++i) o[i] = a.m[i][0] * v[0] + a.m[i][1] * v[1] + a.m[i][2] * v[2]; }
+inline M3 skew(const double* v) { return {{{0, -v[2], v[1]}, {v[2], 0, -v[0]}, {-v[1], v[0], 0}}}; }
+inline M3 qleft3(const Q& q) { return {{{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}}}; }
+inline M3 qright3(const Q& q) { return {{{q.w, q.z, -q.y}, {-q.z, q.w, q.x}, {q.y, -q.x, q.w}}}; }
+inline void pose_plus(const double* x, const double* d, double* o) {
+    o[0] = x[0] + d[0]; o[1] = x[1] + d[1]; o[2] = x[2] + d[2];
+    Q q = qnorm(qmul(qload(x + 3), Q{d[3] / 2, d[4] / 2, d[5] / 2, 1.0}));
+    o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+}
+
+// ---------------------------------------------------------------- factors
+// projection (+td): r[2]; J blocks 2x6 row-major; Jl[2]; Jtd[2]
+void proj_eval(bool td_on, const double* pi, const double* pj, const double* ex, double lam, const double* oi, const double* oj,
+               double td, double focal, double tr_, double row, bool jac, double* r, double* Ji, double* Jj, double* Jex, double* Jl, double* Jtd) {
+    const double s = focal / 1.5;
+    double pts_i[3] = {oi[0], oi[1], 1.0}, ptj[2] = {oj[0], oj[1]}, vi[3] = {0, 0, 0}, vj[2] = {0, 0};
+    if (td_on) {
+        vi[0] = oi[4]; vi[1] = oi[5]; vj[0] = oj[4]; vj[1] = oj[5];
+        double ai = td - oi[6] + tr_ / row * (oi[3] - row / 2), aj = td - oj[6] + tr_ / row * (oj[3] - row / 2);
+        pts_i[0] -= ai * vi[0]; pts_i[1] -= ai * vi[1]; ptj[0] -= aj * vj[0]; ptj[1] -= aj * vj[1];
+    }
+    Q Qi = qload(pi + 3), Qj = qload(pj + 3), qic = qload(ex + 3);
+    M3 Ri = q2R(Qi), Rj = q2R(Qj), ric = q2R(qic);
+    double pci[3] = {pts_i[0] / lam, pts_i[1] / lam, pts_i[2] / lam}, pbi[3], pw[3], pbj[3], pcj[3], t[3];
+    mv(ric, pci, pbi); for (int k = 0; k < 3; ++k) pbi[k] += ex[k];
+    mv(Ri, pbi, pw); for (int k = 0; k < 3; ++k) pw[k] += pi[k];
+    for (int k = 0; k < 3; ++k) t[k] = pw[k] - pj[k];
+    mv(q2R(qinv(Qj)), t, pbj);
+    for (int k = 0; k < 3; ++k) t[k] = pbj[k] - ex[k];
+    mv(q2R(qinv(qic)), t, pcj);
+    double dep = pcj[2];
+    r[0] = s * (pcj[0] / dep - ptj[0]); r[1] = s * (pcj[1] / dep - ptj[1]);
+    if (!jac) return;
+    double red[2][3] = {{s / dep, 0, -s * pcj[0] / (dep * dep)}, {0, s / dep, -s * pcj[1] / (dep * dep)}};
+    M3 ricT = tr(ric), RjT = tr(Rj);
+    M3 A = mul(ricT, RjT), ARi = mul(A, Ri);
+    M3 ji_r = mul(ARi, skew(pbi)), jj_r = mul(ricT, skew(pbj)), tmp_r = mul(ARi, ric);
+    for (int rr = 0; rr < 2; ++rr)
+        for (int c = 0; c < 3; ++c) {
+            double a = 0, b = 0, d = 0;
+            for (int k = 0; k < 3; ++k) { a += red[rr][k] * A.m[k][c]; b += red[rr][k] * ji_r.m[k][c]; d += red[rr][k] * jj_r.m[k][c]; }
+            Ji[rr * 6 + c] = a; Ji[rr * 6 + 3 + c] = -b; Jj[rr * 6 + c] = -a; Jj[rr * 6 + 3 + c] = d;
+        }
+    double v[3];
+    mv(tmp_r, pts_i, v);
+    for (int rr = 0; rr < 2; ++rr) Jl[rr] = (red[rr][0] * v[0] + red[rr][1] * v[1] + red[rr][2] * v[2]) * -1.0 / (lam * lam);
+    if (td_on) {
+        mv(tmp_r, vi, v);
+        for (int rr = 0; rr < 2; ++rr) Jtd[rr] = (red[rr][0] * v[0] + red[rr][1] * v[1] + red[rr][2] * v[2]) / lam * -1.0 + s * vj[rr];
+    }
+    if (Jex) {
+        M3 left = ARi; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) left.m[i][j] -= ricT.m[i][j];
+        double v1[3], v2[3], v3[3];
+        mv(tmp_r, pci, v1);
+        mv(Ri, ex, v2); for (int k = 0; k < 3; ++k) v2[k] += pi[k] - pj[k];
+        mv(RjT, v2, v3); for (int k = 0; k < 3; ++k) v3[k] -= ex[k];
+        mv(ricT, v3, v2);
+        M3 right = mul(tmp_r, skew(pci)), s1 = skew(v1), s2 = skew(v2);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) right.m[i][j] = -right.m[i][j] + s1.m[i][j] + s2.m[i][j];
+        for (int rr = 0; rr < 2; ++rr)
+            for (int c = 0; c < 3; ++c) {
+                double a = 0, b = 0;
+                for (int k = 0; k < 3; ++k) { a += red[rr][k] * left.m[k][c]; b += red[rr][k] * right.m[k][c]; }
+                Jex[rr * 6 + c] = a; Jex[rr * 6 + 3 + c] = b;
+            }
+    }
+}
+
+// dense helpers (row-major)
+void chol_lower(double* A, int n, bool* ok) {   // in place, lower; *ok=false if not PD
+    // right-looking, trailing update as contiguous AXPYs (vectorises without re-association)
+    *ok = true;
+    Vec colbuf(n);
+    for (int j = 0; j < n; ++j) {
+        double d = A[j * n + j];
+        if (!(d > 0.0) || !std::isfinite(d)) { *ok = false; return; }
+        d = std::sqrt(d);
+        A[j * n + j] = d;
+        const double dinv = 1.0 / d;
+        for (int i = j + 1; i < n; ++i) { A[i * n + j] *= dinv; colbuf[i] = A[i * n + j]; }
+        for (int i = j + 1; i < n; ++i) {
+            const double lij = colbuf[i];
+            double* ri = A + i * n;
+            const double* cb = colbuf.data();
+            for (int k = j + 1; k <= i; ++k) ri[k] -= lij * cb[k];
+        }
+    }
+}
+void chol_solve(const double* Lm, int n, double* b) {
+    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= Lm[i * n + k] * b[k]; b[i] = s / Lm[i * n + i]; }
+    for (int i = n - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < n; ++k) s -= Lm[k * n + i] * b[k]; b[i] = s / Lm[i * n + i]; }
+}
+// general inverse by Gauss-Jordan with partial pivoting (stands in for Eigen's PartialPivLU inverse)
+bool inverse_pp(const double* Ain, int n, double* out) {
+    Vec a(Ain, Ain + n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) out[i * n + j] = (i == j);
+    for (int c = 0; c < n; ++c) {
+        int p = c; for (int r = c + 1; r < n; ++r) if (std::fabs(a[r * n + c]) > std::fabs(a[p * n + c])) p = r;
+        if (a[p * n + c] == 0.0) return false;
+        if (p != c) for (int k = 0; k < n; ++k) { std::swap(a[p * n + k], a[c * n + k]); std::swap(out[p * n + k], out[c * n + k]); }
+        double d = 1.0 / a[c * n + c];
+        for (int k = 0; k < n; ++k) { a[c * n + k] *= d; out[c * n + k] *= d; }
+        for (int r = 0; r < n; ++r) if (r != c) { double f = a[r * n + c]; if (f != 0) for (int k = 0; k < n; ++k) { a[r * n + k] -= f * a[c * n + k]; out[r * n + k] -= f * out[c * n + k]; } }
+    }
+    return true;
+}
+// symmetric eigen-decomposition: Householder tridiagonalisation + implicit QL (EISPACK tred2/tql2 algorithm).
+// a: n x n row-major symmetric (destroyed) -> columns of a = eigenvectors, d = eigenvalues ascending
+void sym_eig(double* a, int n, double* d) {
+    Vec e(n);
+    for (int i = n - 1; i > 0; --i) {
+        int l = i - 1; double h = 0, scale = 0;
+        if (l > 0) {
+            for (int k = 0; k <= l; ++k) scale += std::fabs(a[i * n + k]);
+            if (scale == 0.0) e[i] = a[i * n + l];
+            else {
+                for (int k = 0; k <= l; ++k) { a[i * n + k] /= scale; h += a[i * n + k] * a[i * n + k]; }
+                double f = a[i * n + l], g = (f >= 0 ? -std::sqrt(h) : std::sqrt(h));
+                e[i] = scale * g; h -= f * g; a[i * n + l] = f - g; f = 0;
+                for (int j = 0; j <= l; ++j) {
+                    a[j * n + i] = a[i * n + j] / h; g = 0;
+                    for (int k = 0; k <= j; ++k) g += a[j * n + k] * a[i * n + k];
+                    for (int k = j + 1; k <= l; ++k) g += a[k * n + j] * a[i * n + k];
+                    e[j] = g / h; f += e[j] * a[i * n + j];
+                }
+                double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = a[i * n + j]; e[j] = g = e[j] - hh * f;
+                    for (int k = 0; k <= j; ++k) a[j * n + k] -= (f * e[k] + g * a[i * n + k]);
+                }
+            }
+        } else e[i] = a[i * n + l];
+        d[i] = h;
+    }
+    d[0] = 0; e[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        int l = i - 1;
+        if (d[i] != 0.0) for (int j = 0; j <= l; ++j) { double g = 0; for (int k = 0; k <= l; ++k) g += a[i * n + k] * a[k * n + j]; for (int k = 0; k <= l; ++k) a[k * n + j] -= g * a[k * n + i]; }
+        d[i] = a[i * n + i]; a[i * n + i] = 1.0;
+        for (int j = 0; j <= l; ++j) a[j * n + i] = a[i * n + j] = 0.0;
+    }
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) { double dd = std::fabs(d[m]) + std::fabs(d[m + 1]); if (std::fabs(e[m]) <= 2.2e-16 * dd) break; }
+            if (m != l) {
+                if (iter++ == 60) break;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]), r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+                double s = 1, c = 1, p = 0; int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i], b = c * e[i];
+                    e[i + 1] = (r = std::hypot(f, g));
+                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0; break; }
+                    s = f / r; c = g / r; g = d[i + 1] - p; r = (d[i] - g) * s + 2.0 * c * b; d[i + 1] = g + (p = s * r); g = c * r - b;
+                    for (int k = 0; k < n; ++k) { f = a[k * n + i + 1]; a[k * n + i + 1] = s * a[k * n + i] + c * f; a[k * n + i] = c * a[k * n + i] - s * f; }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[m] = 0;
+            }
+        } while (m != l);
+    }
+    // sort ascending
+    for (int i = 0; i < n - 1; ++i) {
+        int k = i; double p = d[i];
+        for (int j = i + 1; j < n; ++j) if (d[j] < p) { k = j; p = d[j]; }
+        if (k != i) { d[k] = d[i]; d[i] = p; for (int j = 0; j < n; ++j) std::swap(a[j * n + i], a[j * n + k]); }
+    }
+}
+
+// ---------------------------------------------------------------- the window
+struct ImuF { bool valid; double sqrt_info[225]; const vg_imu_preint* pre; double r[15]; double J[15 * 30]; };
+struct ProjF { int l, i, j; const double *oi, *oj; double r[2], Ji[12], Jj[12], Jex[12], Jl[2], Jtd[2]; };
+struct State { Vec pose, sb, ex, lam; double td; };
+
+struct Window {
+    const vg_ba_problem* p;
+    int K, Kp, L, e, t, Rc, R, ncols;
+    std::vector<ImuF> imu;
+    std::vector<ProjF> fac;
+    std::vector<int> lm_fbeg;
+    Vec relo_obs;
+    // prior
+    int np_; std::vector<int> pcol, poff, px0off, pkind, pidx; Vec pr, Hp;
+    double g_norm;
+    int col_pose(int i) const { return 6 * i; }
+    int col_ex() const { return 6 * Kp; }
+    int col_td() const { return 6 * Kp + 6 * e; }
+    int col_sb(int i) const { return Rc + 9 * i; }
+    int col_lm(int l) const { return R + l; }
+
+    void init(const vg_ba_problem* pp) {
+        p = pp; K = p->K; Kp = K + (p->relo_n > 0); L = p->L; e = p->estimate_extrinsic != 0; t = p->estimate_td != 0;
+        Rc = 6 * Kp + 6 * e + t; R = Rc + 9 * K; ncols = R + L; g_norm = p->g_norm;
+        imu.resize(K - 1);
+        for (int k = 0; k < K - 1; ++k) {
+            imu[k].pre = &p->imu[k];
+            imu[k].valid = p->imu[k].valid && p->imu[k].sum_dt <= 10.0;
+        }
+        relo_obs.assign(7 * std::max(1, p->relo_n), 0.0);
+        std::vector<int> relo_of(L, -1);
+        for (int k = 0; k < p->relo_n; ++k) { relo_of[p->relo_lm[k]] = k; relo_obs[7 * k] = p->relo_xy[2 * k]; relo_obs[7 * k + 1] = p->relo_xy[2 * k + 1]; }
+        lm_fbeg.assign(L + 1, 0);
+        for (int l = 0; l < L; ++l) {
+            lm_fbeg[l] = (int)fac.size();
+            int s = p->lm_start[l], o = p->lm_obs_off[l];
+            for (int k = 1; k < p->lm_nobs[l]; ++k) { ProjF f; f.l = l; f.i = s; f.j = s + k; f.oi = p->obs + 7 * o; f.oj = p->obs + 7 * (o + k); fac.push_back(f); }
+            if (relo_of[l] >= 0) { ProjF f; f.l = l; f.i = s; f.j = K; f.oi = p->obs + 7 * o; f.oj = relo_obs.data() + 7 * relo_of[l]; fac.push_back(f); }
+        }
+        lm_fbeg[L] = (int)fac.size();
+        np_ = p->prior_n;
+        int off = 0, x0off = 0;
+        for (int b = 0; b < (np_ ? p->prior_nblocks : 0); ++b) {
+            int kind = p->prior_block_kind[b], idx = p->prior_block_index[b];
+            pkind.push_back(kind); pidx.push_back(idx); poff.push_back(off); px0off.push_back(x0off);
+            int col = kind == VG_BLK_POSE ? col_pose(idx) : kind == VG_BLK_SPEEDBIAS ? col_sb(idx) : kind == VG_BLK_EXPOSE ? (e ? col_ex() : -1) : (t ? col_td() : -1);
+            pcol.push_back(col);
+            off += kind == VG_BLK_SPEEDBIAS ? 9 : kind == VG_BLK_TD ? 1 : 6;
+            x0off += kind == VG_BLK_SPEEDBIAS ? 9 : kind == VG_BLK_TD ? 1 : 7;
+        }
+        pr.assign(std::max(np_, 1), 0.0);
+    }
+    const double* pose_of(const State& s, int i) const { return s.pose.data() + 7 * i; }
+
+    // imu_factor.h:64 exactly as the reference computes it: LLT(covariance.inverse()).matrixL().transpose()
+    void imu_weights() {
+        for (auto& f : imu) {
+            if (!f.valid) continue;
+            double inv[225];
+            inverse_pp(f.pre->covariance, 15, inv);
+            for (int i = 0; i < 15; ++i) for (int j = 0; j < i; ++j) { double a = 0.5 * (inv[i * 15 + j] + inv[j * 15 + i]); inv[i * 15 + j] = inv[j * 15 + i] = a; }
+            bool ok; chol_lower(inv, 15, &ok);
+            for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) f.sqrt_info[i * 15 + j] = (j >= i) ? inv[j * 15 + i] : 0.0;
+        }
+    }
+
+    void imu_eval(ImuF& f, const double* pi, const double* sbi, const double* pj, const double* sbj, bool jac, double* rout = nullptr) const {
+        const vg_imu_preint& m = *f.pre;
+        const double dt = m.sum_dt; const double* Jm = m.jacobian;
+        Q Qi = qload(pi + 3), Qj = qload(pj + 3), Qi_inv = qinv(Qi);
+        M3 Rinv = q2R(Qi_inv);
+        double dba[3], dbg[3], th[3], cdp[3], cdv[3], t3[3], vP[3], vV[3];
+        for (int k = 0; k < 3; ++k) { dba[k] = sbi[3 + k] - m.linearized_ba[k]; dbg[k] = sbi[6 + k] - m.linearized_bg[k]; }
+        for (int k = 0; k < 3; ++k) {
+            th[k] = Jm[(3 + k) * 15 + 12] * dbg[0] + Jm[(3 + k) * 15 + 13] * dbg[1] + Jm[(3 + k) * 15 + 14] * dbg[2];
+            cdp[k] = m.delta_p[k]; cdv[k] = m.delta_v[k];
+            for (int c = 0; c < 3; ++c) { cdp[k] += Jm[k * 15 + 9 + c] * dba[c] + Jm[k * 15 + 12 + c] * dbg[c]; cdv[k] += Jm[(6 + k) * 15 + 9 + c] * dba[c] + Jm[(6 + k) * 15 + 12 + c] * dbg[c]; }
+        }
+        Q dq0 = qload(m.delta_q), cdq = qmul(dq0, Q{th[0] / 2, th[1] / 2, th[2] / 2, 1.0});
+        t3[0] = pj[0] - pi[0] - sbi[0] * dt; t3[1] = pj[1] - pi[1] - sbi[1] * dt; t3[2] = 0.5 * g_norm * dt * dt + pj[2] - pi[2] - sbi[2] * dt;
+        mv(Rinv, t3, vP);
+        t3[0] = sbj[0] - sbi[0]; t3[1] = sbj[1] - sbi[1]; t3[2] = g_norm * dt + sbj[2] - sbi[2];
+        mv(Rinv, t3, vV);
+        Q qe = qmul(qinv(cdq), qmul(Qi_inv, Qj));
+        double raw[15];
+        for (int k = 0; k < 3; ++k) { raw[k] = vP[k] - cdp[k]; raw[6 + k] = vV[k] - cdv[k]; raw[9 + k] = sbj[3 + k] - sbi[3 + k]; raw[12 + k] = sbj[6 + k] - sbi[6 + k]; }
+        raw[3] = 2 * qe.x; raw[4] = 2 * qe.y; raw[5] = 2 * qe.z;
+        double* rdst = rout ? rout : f.r;
+        for (int r = 0; r < 15; ++r) { double s = 0; for (int k = r; k < 15; ++k) s += f.sqrt_info[r * 15 + k] * raw[k]; rdst[r] = s; }
+        if (!jac) return;
+        double Jr[15 * 30]; std::memset(Jr, 0, sizeof(Jr));
+        M3 sP = skew(vP), sV = skew(vV);
+        Q qji = qmul(qinv(Qj), Qi);
+        M3 M1 = mul(qleft3(qji), qright3(cdq));
+        { double a[3] = {qji.x, qji.y, qji.z}, b[3] = {cdq.x, cdq.y, cdq.z}; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M1.m[i][j] -= a[i] * b[j]; }
+        M3 dqdbg; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dqdbg.m[i][j] = Jm[(3 + i) * 15 + 12 + j];
+        M3 M2 = mul(qleft3(qmul(qji, dq0)), dqdbg), M3_ = qleft3(qe);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            Jr[(0 + i) * 30 + 0 + j] = -Rinv.m[i][j]; Jr[(0 + i) * 30 + 3 + j] = sP.m[i][j]; Jr[(3 + i) * 30 + 3 + j] = -M1.m[i][j]; Jr[(6 + i) * 30 + 3 + j] = sV.m[i][j];
+            Jr[(0 + i) * 30 + 6 + j] = -Rinv.m[i][j] * dt; Jr[(0 + i) * 30 + 9 + j] = -Jm[i * 15 + 9 + j]; Jr[(0 + i) * 30 + 12 + j] = -Jm[i * 15 + 12 + j];
+            Jr[(3 + i) * 30 + 12 + j] = -M2.m[i][j];
+            Jr[(6 + i) * 30 + 6 + j] = -Rinv.m[i][j]; Jr[(6 + i) * 30 + 9 + j] = -Jm[(6 + i) * 15 + 9 + j]; Jr[(6 + i) * 30 + 12 + j] = -Jm[(6 + i) * 15 + 12 + j];
+            Jr[(9 + i) * 30 + 9 + j] = -(i == j); Jr[(12 + i) * 30 + 12 + j] = -(i == j);
+            Jr[(0 + i) * 30 + 15 + j] = Rinv.m[i][j]; Jr[(3 + i) * 30 + 18 + j] = M3_.m[i][j];
+            Jr[(6 + i) * 30 + 21 + j] = Rinv.m[i][j]; Jr[(9 + i) * 30 + 24 + j] = (i == j); Jr[(12 + i) * 30 + 27 + j] = (i == j);
+        }
+        for (int r = 0; r < 15; ++r) for (int c = 0; c < 30; ++c) { double s = 0; for (int k = r; k < 15; ++k) s += f.sqrt_info[r * 15 + k] * Jr[k * 30 + c]; f.J[r * 30 + c] = s; }
+    }
+    int imu_col(int f, int lc) const { return lc < 6 ? col_pose(f) + lc : lc < 15 ? col_sb(f) + lc - 6 : lc < 21 ? col_pose(f + 1) + lc - 15 : col_sb(f + 1) + lc - 21; }
+
+    const double* block_ptr(const State& s, int kind, int idx) const {
+        return kind == VG_BLK_POSE ? s.pose.data() + 7 * idx : kind == VG_BLK_SPEEDBIAS ? s.sb.data() + 9 * idx : kind == VG_BLK_EXPOSE ? s.ex.data() : &s.td;
+    }
+    void prior_eval(const State& s, double* r) const {
+        Vec dx(np_);
+        for (size_t b = 0; b < pkind.size(); ++b) {
+            const double* x = block_ptr(s, pkind[b], pidx[b]); const double* x0 = p->prior_x0 + px0off[b]; double* d = dx.data() + poff[b];
+            if (pkind[b] == VG_BLK_SPEEDBIAS) for (int k = 0; k < 9; ++k) d[k] = x[k] - x0[k];
+            else if (pkind[b] == VG_BLK_TD) d[0] = x[0] - x0[0];
+            else {
+                for (int k = 0; k < 3; ++k) d[k] = x[k] - x0[k];
+                Q dq = qmul(qinv(qload(x0 + 3)), qload(x + 3));
+                double sg = dq.w >= 0 ? 2.0 : -2.0; d[3] = sg * dq.x; d[4] = sg * dq.y; d[5] = sg * dq.z;
+            }
+        }
+        for (int i = 0; i < np_; ++i) { double a = p->prior_r0[i]; const double* row = p->prior_J0 + (size_t)i * np_; for (int k = 0; k < np_; ++k) a += row[k] * dx[k]; r[i] = a; }
+    }
+
+    // Ceres evaluator: cost (+ residuals / Jacobians, loss-corrected)
+    double evaluate(const State& s, bool jac) {
+        double cost = 0;
+        if (np_) { prior_eval(s, pr.data()); for (int i = 0; i < np_; ++i) cost += 0.5 * pr[i] * pr[i]; }
+        for (int k = 0; k < K - 1; ++k) if (imu[k].valid) { imu_eval(imu[k], pose_of(s, k), s.sb.data() + 9 * k, pose_of(s, k + 1), s.sb.data() + 9 * (k + 1), jac); for (int r = 0; r < 15; ++r) cost += 0.5 * imu[k].r[r] * imu[k].r[r]; }
+        for (auto& f : fac) {
+            proj_eval(t, pose_of(s, f.i), pose_of(s, f.j), s.ex.data(), s.lam[f.l], f.oi, f.oj, s.td, p->focal, p->tr, p->row, jac, f.r, f.Ji, f.Jj, e ? f.Jex : nullptr, f.Jl, f.Jtd);
+            double sq_norm = f.r[0] * f.r[0] + f.r[1] * f.r[1];
+            cost += 0.5 * std::log1p(sq_norm);
+            double sq = std::sqrt(1.0 / (1.0 + sq_norm));
+            f.r[0] *= sq; f.r[1] *= sq;
+            if (jac) { for (int k = 0; k < 12; ++k) { f.Ji[k] *= sq; f.Jj[k] *= sq; if (e) f.Jex[k] *= sq; } f.Jl[0] *= sq; f.Jl[1] *= sq; if (t) { f.Jtd[0] *= sq; f.Jtd[1] *= sq; } }
+        }
+        return cost;
+    }
+    // residual-only evaluation (candidate point): touches nothing of the stored linearisation
+    double cost_only(const State& s) const {
+        double cost = 0;
+        if (np_) { Vec r(np_); prior_eval(s, r.data()); for (int i = 0; i < np_; ++i) cost += 0.5 * r[i] * r[i]; }
+        for (int k = 0; k < K - 1; ++k) if (imu[k].valid) { double r[15]; imu_eval(const_cast<ImuF&>(imu[k]), pose_of(s, k), s.sb.data() + 9 * k, pose_of(s, k + 1), s.sb.data() + 9 * (k + 1), false, r); for (int q = 0; q < 15; ++q) cost += 0.5 * r[q] * r[q]; }
+        for (const auto& f : fac) {
+            double r[2];
+            proj_eval(t, pose_of(s, f.i), pose_of(s, f.j), s.ex.data(), s.lam[f.l], f.oi, f.oj, s.td, p->focal, p->tr, p->row, false, r, nullptr, nullptr, nullptr, nullptr, nullptr);
+            cost += 0.5 * std::log1p(r[0] * r[0] + r[1] * r[1]);
+        }
+        return cost;
+    }
+    // y = (J * scale) u over all residuals: returns sum (Ju).r and sum (Ju)^2
+    void jvec(const double* u, double& m1, double& m2) const {
+        m1 = m2 = 0;
+        if (np_) for (int i = 0; i < np_; ++i) {
+            double a = 0; const double* row = p->prior_J0 + (size_t)i * np_;
+            for (size_t b = 0; b < pkind.size(); ++b) if (pcol[b] >= 0) { int sz = pkind[b] == VG_BLK_SPEEDBIAS ? 9 : pkind[b] == VG_BLK_TD ? 1 : 6; for (int k = 0; k < sz; ++k) a += row[poff[b] + k] * u[pcol[b] + k]; }
+            m1 += a * pr[i]; m2 += a * a;
+        }
+        for (int k = 0; k < K - 1; ++k) if (imu[k].valid) for (int r = 0; r < 15; ++r) { double a = 0; for (int c = 0; c < 30; ++c) a += imu[k].J[r * 30 + c] * u[imu_col(k, c)]; m1 += a * imu[k].r[r]; m2 += a * a; }
+        for (const auto& f : fac) for (int rr = 0; rr < 2; ++rr) {
+            double a = f.Jl[rr] * u[col_lm(f.l)];
+            for (int k = 0; k < 6; ++k) a += f.Ji[rr * 6 + k] * u[col_pose(f.i) + k] + f.Jj[rr * 6 + k] * u[col_pose(f.j) + k];
+            if (e) for (int k = 0; k < 6; ++k) a += f.Jex[rr * 6 + k] * u[col_ex() + k];
+            if (t) a += f.Jtd[rr] * u[col_td()];
+            m1 += a * f.r[rr]; m2 += a * a;
+        }
+    }
+    // squared column norms and gradient of the (unscaled) Jacobian
+    void colnorm_grad(double* cn, double* g) const {
+        std::fill(cn, cn + ncols, 0.0); std::fill(g, g + ncols, 0.0);
+        if (np_) for (size_t b = 0; b < pkind.size(); ++b) if (pcol[b] >= 0) { int sz = pkind[b] == VG_BLK_SPEEDBIAS ? 9 : pkind[b] == VG_BLK_TD ? 1 : 6; for (int k = 0; k < sz; ++k) { double s = 0, gg = 0; for (int i = 0; i < np_; ++i) { double v = p->prior_J0[(size_t)i * np_ + poff[b] + k]; s += v * v; gg += v * pr[i]; } cn[pcol[b] + k] += s; g[pcol[b] + k] += gg; } }
+        for (int k = 0; k < K - 1; ++k) if (imu[k].valid) for (int c = 0; c < 30; ++c) { double s = 0, gg = 0; for (int r = 0; r < 15; ++r) { double v = imu[k].J[r * 30 + c]; s += v * v; gg += v * imu[k].r[r]; } cn[imu_col(k, c)] += s; g[imu_col(k, c)] += gg; }
+        for (const auto& f : fac) {
+            for (int k = 0; k < 6; ++k) {
+                cn[col_pose(f.i) + k] += f.Ji[k] * f.Ji[k] + f.Ji[6 + k] * f.Ji[6 + k]; g[col_pose(f.i) + k] += f.Ji[k] * f.r[0] + f.Ji[6 + k] * f.r[1];
+                cn[col_pose(f.j) + k] += f.Jj[k] * f.Jj[k] + f.Jj[6 + k] * f.Jj[6 + k]; g[col_pose(f.j) + k] += f.Jj[k] * f.r[0] + f.Jj[6 + k] * f.r[1];
+                if (e) { cn[col_ex() + k] += f.Jex[k] * f.Jex[k] + f.Jex[6 + k] * f.Jex[6 + k]; g[col_ex() + k] += f.Jex[k] * f.r[0] + f.Jex[6 + k] * f.r[1]; }
+            }
+            if (t) { cn[col_td()] += f.Jtd[0] * f.Jtd[0] + f.Jtd[1] * f.Jtd[1]; g[col_td()] += f.Jtd[0] * f.r[0] + f.Jtd[1] * f.r[1]; }
+            cn[col_lm(f.l)] += f.Jl[0] * f.Jl[0] + f.Jl[1] * f.Jl[1]; g[col_lm(f.l)] += f.Jl[0] * f.r[0] + f.Jl[1] * f.r[1];
+        }
+    }
+    // DENSE_SCHUR: solve (Js^T Js + D^2) y = Js^T r with Js = J diag(scale); landmarks eliminated first
+    bool schur_solve(const double* scale, const double* D, const double* gs, double* y, Vec& S, Vec& Wl) const {
+        const int n = R;
+        std::fill(S.begin(), S.end(), 0.0);
+        Vec rhs(gs, gs + n);
+        auto addblk = [&](int ca, int na, const double* Ja, int lda, int cb, int nb, const double* Jb, int ldb, int rows) {
+            for (int a = 0; a < na; ++a) for (int b = 0; b < nb; ++b) { double s = 0; for (int r = 0; r < rows; ++r) s += Ja[r * lda + a] * Jb[r * ldb + b]; S[(size_t)(ca + a) * n + cb + b] += s * scale[ca + a] * scale[cb + b]; }
+        };
+        if (np_) for (size_t a = 0; a < pkind.size(); ++a) if (pcol[a] >= 0) for (size_t b = 0; b < pkind.size(); ++b) if (pcol[b] >= 0) {
+            int sa = pkind[a] == VG_BLK_SPEEDBIAS ? 9 : pkind[a] == VG_BLK_TD ? 1 : 6, sb_ = pkind[b] == VG_BLK_SPEEDBIAS ? 9 : pkind[b] == VG_BLK_TD ? 1 : 6;
+            for (int i = 0; i < sa; ++i) for (int j = 0; j < sb_; ++j) S[(size_t)(pcol[a] + i) * n + pcol[b] + j] += Hp[(size_t)(poff[a] + i) * np_ + poff[b] + j] * scale[pcol[a] + i] * scale[pcol[b] + j];
+        }
+        for (int k = 0; k < K - 1; ++k) if (imu[k].valid) for (int a = 0; a < 30; ++a) for (int b = 0; b < 30; ++b) { double s = 0; for (int r = 0; r < 15; ++r) s += imu[k].J[r * 30 + a] * imu[k].J[r * 30 + b]; int ca = imu_col(k, a), cb = imu_col(k, b); S[(size_t)ca * n + cb] += s * scale[ca] * scale[cb]; }
+        // per landmark (e-block): F^T F, then the Schur update
+        Vec w(Rc);
+        std::vector<int> touched;
+        for (int l = 0; l < L; ++l) {
+            std::fill(w.begin(), w.end(), 0.0);
+            double h = 0, bl = 0;
+            touched.clear();
+            const double sl = scale[col_lm(l)];
+            for (int fi = lm_fbeg[l]; fi < lm_fbeg[l + 1]; ++fi) {
+                const ProjF& f = fac[fi];
+                addblk(col_pose(f.i), 6, f.Ji, 6, col_pose(f.i), 6, f.Ji, 6, 2);
+                addblk(col_pose(f.i), 6, f.Ji, 6, col_pose(f.j), 6, f.Jj, 6, 2);
+                addblk(col_pose(f.j), 6, f.Jj, 6, col_pose(f.i), 6, f.Ji, 6, 2);
+                addblk(col_pose(f.j), 6, f.Jj, 6, col_pose(f.j), 6, f.Jj, 6, 2);
+                if (e) {
+                    addblk(col_ex(), 6, f.Jex, 6, col_ex(), 6, f.Jex, 6, 2);
+                    addblk(col_ex(), 6, f.Jex, 6, col_pose(f.i), 6, f.Ji, 6, 2); addblk(col_pose(f.i), 6, f.Ji, 6, col_ex(), 6, f.Jex, 6, 2);
+                    addblk(col_ex(), 6, f.Jex, 6, col_pose(f.j), 6, f.Jj, 6, 2); addblk(col_pose(f.j), 6, f.Jj, 6, col_ex(), 6, f.Jex, 6, 2);
+                }
+                if (t) {
+                    addblk(col_td(), 1, f.Jtd, 1, col_td(), 1, f.Jtd, 1, 2);
+                    addblk(col_td(), 1, f.Jtd, 1, col_pose(f.i), 6, f.Ji, 6, 2); addblk(col_pose(f.i), 6, f.Ji, 6, col_td(), 1, f.Jtd, 1, 2);
+                    addblk(col_td(), 1, f.Jtd, 1, col_pose(f.j), 6, f.Jj, 6, 2); addblk(col_pose(f.j), 6, f.Jj, 6, col_td(), 1, f.Jtd, 1, 2);
+                    if (e) { addblk(col_td(), 1, f.Jtd, 1, col_ex(), 6, f.Jex, 6, 2); addblk(col_ex(), 6, f.Jex, 6, col_td(), 1, f.Jtd, 1, 2); }
+                }
+                h += f.Jl[0] * f.Jl[0] + f.Jl[1] * f.Jl[1];
+                bl += f.Jl[0] * f.r[0] + f.Jl[1] * f.r[1];
+                for (int k = 0; k < 6; ++k) {
+                    w[col_pose(f.i) + k] += f.Ji[k] * f.Jl[0] + f.Ji[6 + k] * f.Jl[1];
+                    w[col_pose(f.j) + k] += f.Jj[k] * f.Jl[0] + f.Jj[6 + k] * f.Jl[1];
+                    if (e) w[col_ex() + k] += f.Jex[k] * f.Jl[0] + f.Jex[6 + k] * f.Jl[1];
+                }
+                if (t) w[col_td()] += f.Jtd[0] * f.Jl[0] + f.Jtd[1] * f.Jl[1];
+                if (touched.empty()) touched.push_back(f.i);
+                touched.push_back(f.j);
+            }
+            const double ht = sl * sl * h + D[col_lm(l)] * D[col_lm(l)];
+            if (!(ht > 0) || !std::isfinite(ht)) return false;
+            // columns touched: poses + ex + td
+            std::vector<int> cols;
+            for (int blk : touched) for (int k = 0; k < 6; ++k) cols.push_back(col_pose(blk) + k);
+            if (e) for (int k = 0; k < 6; ++k) cols.push_back(col_ex() + k);
+            if (t) cols.push_back(col_td());
+            for (int c : cols) w[c] *= scale[c] * sl;
+            const double bt = sl * bl;
+            for (int a : cols) { const double wa = w[a] / ht; rhs[a] -= wa * bt; double* Sr = S.data() + (size_t)a * n; for (int b : cols) Sr[b] -= wa * w[b]; }
+            double* Wrow = Wl.data() + (size_t)l * (Rc + 2);
+            std::copy(w.begin(), w.end(), Wrow); Wrow[Rc] = ht; Wrow[Rc + 1] = bt;
+        }
+        for (int c = 0; c < n; ++c) S[(size_t)c * n + c] += D[c] * D[c];
+        bool ok; chol_lower(S.data(), n, &ok);
+        if (!ok) return false;
+        std::copy(rhs.begin(), rhs.end(), y);
+        chol_solve(S.data(), n, y);
+        for (int l = 0; l < L; ++l) { const double* Wrow = Wl.data() + (size_t)l * (Rc + 2); double s = Wrow[Rc + 1]; for (int c = 0; c < Rc; ++c) s -= Wrow[c] * y[c]; y[col_lm(l)] = s / Wrow[Rc]; }
+        for (int c = 0; c < ncols; ++c) if (!std::isfinite(y[c])) return false;
+        return true;
+    }
+    void plus(const State& s, const double* d, State& o) const {
+        o = s;
+        for (int i = 0; i < Kp; ++i) pose_plus(s.pose.data() + 7 * i, d + col_pose(i), o.pose.data() + 7 * i);
+        for (int i = 0; i < K; ++i) for (int k = 0; k < 9; ++k) o.sb[9 * i + k] = s.sb[9 * i + k] + d[col_sb(i) + k];
+        if (e) pose_plus(s.ex.data(), d + col_ex(), o.ex.data());
+        if (t) o.td = s.td + d[col_td()];
+        for (int l = 0; l < L; ++l) o.lam[l] = s.lam[l] + d[col_lm(l)];
+    }
+    double ambient_norm2(const State& a, const State* b) const {
+        double s = 0;
+        auto acc = [&](const double* x, const double* y, int n) { for (int k = 0; k < n; ++k) { double d = y ? x[k] - y[k] : x[k]; s += d * d; } };
+        acc(a.pose.data(), b ? b->pose.data() : nullptr, 7 * Kp); acc(a.sb.data(), b ? b->sb.data() : nullptr, 9 * K);
+        if (e) acc(a.ex.data(), b ? b->ex.data() : nullptr, 7);
+        if (t) acc(&a.td, b ? &b->td : nullptr, 1);
+        acc(a.lam.data(), b ? b->lam.data() : nullptr, L);
+        return s;
+    }
+};
+
+void solve(Window& W, State& x, vg_ba_summary* sum) {
+    const int nc = W.ncols, R = W.R;
+    const int max_iters = W.p->max_iters;
+    W.imu_weights();
+    if (W.np_) { W.Hp.assign((size_t)W.np_ * W.np_, 0.0); for (int a = 0; a < W.np_; ++a) for (int b = 0; b <= a; ++b) { double s = 0; for (int r = 0; r < W.np_; ++r) s += W.p->prior_J0[(size_t)r * W.np_ + a] * W.p->prior_J0[(size_t)r * W.np_ + b]; W.Hp[(size_t)a * W.np_ + b] = W.Hp[(size_t)b * W.np_ + a] = s; } }
+    Vec cn(nc), g(nc), scale(nc), Dg(nc), gt(nc), gn(nc), u(nc), y(nc), D(nc), gs(nc), S((size_t)R * R), Wl((size_t)std::max(W.L, 1) * (W.Rc + 2));
+    double cost = W.evaluate(x, true);
+    W.colnorm_grad(cn.data(), g.data());
+    for (int c = 0; c < nc; ++c) scale[c] = 1.0 / (1.0 + std::sqrt(cn[c]));
+    memset(sum, 0, sizeof(*sum));
+    sum->initial_cost = cost;
+    double gmax = 0; for (int c = 0; c < nc; ++c) gmax = std::max(gmax, std::fabs(g[c]));
+    int termination = VG_TERM_NO_CONVERGENCE, it = 0, nacc = 0, ninvalid = 0;
+    if (gmax <= 1e-10) termination = VG_TERM_CONVERGENCE;
+    double radius = 1e4, mu = 1e-8, alpha = 0, gtn2 = 0, gnn2 = 0, gtgn = 0, dogleg_norm = 0;
+    bool reuse = false;
+    double x_norm = std::sqrt(W.ambient_norm2(x, nullptr));
+    State xc = x;
+    while (termination == VG_TERM_NO_CONVERGENCE && it < max_iters) {
+        ++it; const int slot = it - 1; bool ok = true;
+        if (!reuse) {
+            reuse = true;
+            gtn2 = 0;
+            for (int c = 0; c < nc; ++c) { Dg[c] = std::sqrt(std::min(std::max(scale[c] * scale[c] * cn[c], 1e-6), 1e32)); gt[c] = scale[c] * g[c] / Dg[c]; gs[c] = scale[c] * g[c]; u[c] = scale[c] * gt[c] / Dg[c]; gtn2 += gt[c] * gt[c]; }
+            double m1, m2; W.jvec(u.data(), m1, m2);
+            alpha = gtn2 / m2;
+            bool solved = false;
+            while (mu < 1.0) {
+                for (int c = 0; c < nc; ++c) D[c] = Dg[c] * std::sqrt(mu);
+                if (W.schur_solve(scale.data(), D.data(), gs.data(), y.data(), S, Wl)) { solved = true; break; }
+                mu *= 10.0;
+            }
+            if (!solved) ok = false;
+            else { gnn2 = gtgn = 0; for (int c = 0; c < nc; ++c) { gn[c] = -y[c] * Dg[c]; gnn2 += gn[c] * gn[c]; gtgn += gn[c] * gt[c]; } }
+        }
+        double model_change = 0, c_gt = 0, c_gn = 0;
+        if (ok) {
+            const double gtn = std::sqrt(gtn2), gnn = std::sqrt(gnn2);
+            if (gnn <= radius) { c_gn = 1; dogleg_norm = gnn; }
+            else if (gtn * alpha >= radius) { c_gt = -(radius / gtn); dogleg_norm = radius; }
+            else {
+                double b_dot_a = -alpha * gtgn, a_sq = (alpha * gtn) * (alpha * gtn), bma = a_sq - 2 * b_dot_a + gnn2, cc = b_dot_a - a_sq;
+                double dd = std::sqrt(cc * cc + bma * (radius * radius - a_sq));
+                double beta = cc <= 0 ? (dd - cc) / bma : (radius * radius - a_sq) / (dd + cc);
+                c_gt = -alpha * (1 - beta); c_gn = beta;
+                double s2 = 0; for (int c = 0; c < nc; ++c) { double s = c_gt * gt[c] + c_gn * gn[c]; s2 += s * s; } dogleg_norm = std::sqrt(s2);
+            }
+            for (int c = 0; c < nc; ++c) u[c] = scale[c] * ((c_gt * gt[c] + c_gn * gn[c]) / Dg[c]);
+            double m1, m2; W.jvec(u.data(), m1, m2);
+            model_change = -(m1 + 0.5 * m2);
+        }
+        sum->it_cost[slot] = cost; sum->it_radius[slot] = radius; sum->it_model[slot] = model_change;
+        if (!ok || !(model_change > 0)) { sum->it_flags[slot] = 0; if (++ninvalid >= 5) { termination = VG_TERM_FAILURE; break; } mu *= 10; reuse = false; continue; }
+        ninvalid = 0;
+        W.plus(x, u.data(), xc);
+        const double cost_cand = W.cost_only(xc);
+        sum->it_cost_cand[slot] = cost_cand; sum->it_step_norm[slot] = dogleg_norm;
+        const double step_norm = std::sqrt(W.ambient_norm2(x, &xc));
+        if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum->it_flags[slot] = 1; termination = VG_TERM_CONVERGENCE; break; }
+        if (std::fabs(cost - cost_cand) <= 1e-6 * cost) { sum->it_flags[slot] = 1; termination = VG_TERM_CONVERGENCE; break; }
+        const double rho = (cost - cost_cand) / model_change;
+        if (rho > 1e-3) {
+            sum->it_flags[slot] = 3; ++nacc;
+            x = xc; x_norm = std::sqrt(W.ambient_norm2(x, nullptr));
+            cost = W.evaluate(x, true);
+            W.colnorm_grad(cn.data(), g.data());
+            if (rho < 0.25) radius *= 0.5;
+            if (rho > 0.75) radius = std::max(radius, 3.0 * dogleg_norm);
+            mu = std::max(1e-8, 2.0 * mu / 10.0); reuse = false;
+            gmax = 0; for (int c = 0; c < nc; ++c) gmax = std::max(gmax, std::fabs(g[c]));
+            if (gmax <= 1e-10) { termination = VG_TERM_CONVERGENCE; break; }
+        } else { sum->it_flags[slot] = 1; radius *= 0.5; reuse = true; }
+    }
+    sum->status = VG_OK; sum->termination = termination; sum->num_iterations = it; sum->num_accepted = nacc;
+    sum->final_cost = cost; sum->final_radius = radius;
+}
+
+void R2ypr(const M3& R, double* ypr) {
+    double y = std::atan2(R.m[1][0], R.m[0][0]);
+    double p = std::atan2(-R.m[2][0], R.m[0][0] * std::cos(y) + R.m[1][0] * std::sin(y));
+    double r = std::atan2(R.m[0][2] * std::sin(y) - R.m[1][2] * std::cos(y), -R.m[0][1] * std::sin(y) + R.m[1][1] * std::cos(y));
+    ypr[0] = y / M_PI * 180.0; ypr[1] = p / M_PI * 180.0; ypr[2] = r / M_PI * 180.0;
+}
+
+void gauge_fix(const Window& W, const State& x, State& o) {
+    const vg_ba_problem* p = W.p;
+    M3 Rs0 = q2R(qload(p->pose + 3)), R00 = q2R(qload(x.pose.data() + 3));
+    double y0[3], y00[3];
+    R2ypr(Rs0, y0); R2ypr(R00, y00);
+    double yd = (y0[0] - y00[0]) / 180.0 * M_PI;
+    M3 rot = {{{std::cos(yd), -std::sin(yd), 0}, {std::sin(yd), std::cos(yd), 0}, {0, 0, 1}}};
+    if (std::fabs(std::fabs(y0[1]) - 90) < 1.0 || std::fabs(std::fabs(y00[1]) - 90) < 1.0) rot = mul(Rs0, tr(R00));
+    o = x;
+    for (int i = 0; i < W.Kp; ++i) {
+        Q q = qnorm(qload(x.pose.data() + 7 * i + 3));
+        Q qo = R2q(mul(rot, q2R(q)));
+        double d[3] = {x.pose[7 * i] - x.pose[0], x.pose[7 * i + 1] - x.pose[1], x.pose[7 * i + 2] - x.pose[2]}, po[3];
+        mv(rot, d, po);
+        for (int k = 0; k < 3; ++k) o.pose[7 * i + k] = po[k] + p->pose[k];
+        o.pose[7 * i + 3] = qo.x; o.pose[7 * i + 4] = qo.y; o.pose[7 * i + 5] = qo.z; o.pose[7 * i + 6] = qo.w;
+        if (i < W.K) { double vo[3]; mv(rot, x.sb.data() + 9 * i, vo); for (int k = 0; k < 3; ++k) o.sb[9 * i + k] = vo[k]; }
+    }
+    Q qe = R2q(q2R(qload(x.ex.data() + 3)));
+    o.ex[3] = qe.x; o.ex[4] = qe.y; o.ex[5] = qe.z; o.ex[6] = qe.w;
+    for (int l = 0; l < W.L; ++l) o.lam[l] = 1.0 / (1.0 / x.lam[l]);
+}
+
+// MarginalizationInfo::marginalize with the canonical block order (see oracle/ba_numpy.py::marginalize)
+void marginalize(const vg_ba_problem* p, const State& st, int flag, vg_ba_prior* out) {
+    out->valid = 0; out->n = out->m = out->nblocks = 0;
+    Window W; W.init(p);
+    W.imu_weights();
+    const int K = W.K, L = W.L;
+    struct Blk { int kind, idx; };
+    auto key = [](const Blk& b) { int o = b.kind == VG_BLK_POSE ? 0 : b.kind == VG_BLK_SPEEDBIAS ? 1 : b.kind == VG_BLK_EXPOSE ? 2 : b.kind == VG_BLK_TD ? 3 : 4; return o * 100000 + b.idx; };
+    struct Fac { Vec r; std::vector<Vec> J; std::vector<Blk> blocks; std::vector<int> drop; int rows; };
+    std::vector<Fac> facs;
+    auto lsz = [](int kind) { return kind == VG_BLK_SPEEDBIAS ? 9 : (kind == VG_BLK_TD || kind == 4) ? 1 : 6; };
+    bool has_prior = W.np_ > 0;
+    if (has_prior) {
+        Fac f; f.rows = W.np_; f.r.resize(W.np_); W.prior_eval(st, f.r.data());
+        bool found = false;
+        for (size_t b = 0; b < W.pkind.size(); ++b) {
+            int sz = lsz(W.pkind[b]); Vec J((size_t)W.np_ * sz);
+            for (int i = 0; i < W.np_; ++i) for (int k = 0; k < sz; ++k) J[(size_t)i * sz + k] = p->prior_J0[(size_t)i * W.np_ + W.poff[b] + k];
+            f.J.push_back(J); f.blocks.push_back({W.pkind[b], W.pidx[b]});
+            bool dr = flag == VG_MARGIN_OLD ? ((W.pkind[b] == VG_BLK_POSE || W.pkind[b] == VG_BLK_SPEEDBIAS) && W.pidx[b] == 0) : (W.pkind[b] == VG_BLK_POSE && W.pidx[b] == K - 2);
+            if (dr) { f.drop.push_back((int)b); found = true; }
+        }
+        if (flag == VG_MARGIN_SECOND_NEW && !found) return;
+        facs.push_back(f);
+    } else if (flag == VG_MARGIN_SECOND_NEW) return;
+    if (flag == VG_MARGIN_OLD) {
+        if (W.imu[0].valid && p->imu[0].sum_dt < 10.0) {
+            W.imu_eval(W.imu[0], st.pose.data(), st.sb.data(), st.pose.data() + 7, st.sb.data() + 9, true);
+            Fac f; f.rows = 15; f.r.assign(W.imu[0].r, W.imu[0].r + 15);
+            int offs[4] = {0, 6, 15, 21}, szs[4] = {6, 9, 6, 9};
+            for (int b = 0; b < 4; ++b) { Vec J(15 * szs[b]); for (int r = 0; r < 15; ++r) for (int k = 0; k < szs[b]; ++k) J[r * szs[b] + k] = W.imu[0].J[r * 30 + offs[b] + k]; f.J.push_back(J); }
+            f.blocks = {{VG_BLK_POSE, 0}, {VG_BLK_SPEEDBIAS, 0}, {VG_BLK_POSE, 1}, {VG_BLK_SPEEDBIAS, 1}}; f.drop = {0, 1};
+            facs.push_back(f);
+        }
+        for (int l = 0; l < L; ++l) {
+            if (p->lm_start[l] != 0) continue;
+            for (int k = 1; k < p->lm_nobs[l]; ++k) {
+                const double *oi = p->obs + 7 * p->lm_obs_off[l], *oj = p->obs + 7 * (p->lm_obs_off[l] + k);
+                double r[2], Ji[12], Jj[12], Jex[12], Jl[2], Jtd[2] = {0, 0};
+                proj_eval(W.t, st.pose.data(), st.pose.data() + 7 * k, st.ex.data(), st.lam[l], oi, oj, st.td, p->focal, p->tr, p->row, true, r, Ji, Jj, Jex, Jl, Jtd);
+                double sq = std::sqrt(1.0 / (1.0 + r[0] * r[0] + r[1] * r[1]));   // loss correction, rho'' < 0 branch
+                Fac f; f.rows = 2; f.r = {r[0] * sq, r[1] * sq};
+                auto pack = [&](const double* J, int n) { Vec v(2 * n); for (int k2 = 0; k2 < 2 * n; ++k2) v[k2] = J[k2] * sq; return v; };
+                f.J = {pack(Ji, 6), pack(Jj, 6), pack(Jex, 6), pack(Jl, 1)};
+                f.blocks = {{VG_BLK_POSE, 0}, {VG_BLK_POSE, k}, {VG_BLK_EXPOSE, 0}, {4, l}};
+                if (W.t) { f.J.push_back(pack(Jtd, 1)); f.blocks.push_back({VG_BLK_TD, 0}); }
+                f.drop = {0, 3};
+                facs.push_back(f);
+            }
+        }
+    }
+    if (facs.empty()) return;
+    std::vector<Blk> dropl, keepl;
+    auto has = [&](std::vector<Blk>& v, const Blk& b) { for (auto& q : v) if (q.kind == b.kind && q.idx == b.idx) return true; return false; };
+    for (auto& f : facs) for (int d : f.drop) if (!has(dropl, f.blocks[d])) dropl.push_back(f.blocks[d]);
+    for (auto& f : facs) for (auto& b : f.blocks) if (!has(dropl, b) && !has(keepl, b)) keepl.push_back(b);
+    std::sort(dropl.begin(), dropl.end(), [&](const Blk& a, const Blk& b) { return key(a) < key(b); });
+    std::sort(keepl.begin(), keepl.end(), [&](const Blk& a, const Blk& b) { return key(a) < key(b); });
+    auto find = [&](const Blk& b, int& pos0) { int pos = 0; for (auto& q : dropl) { if (q.kind == b.kind && q.idx == b.idx) { pos0 = pos; return; } pos += lsz(q.kind); } for (auto& q : keepl) { if (q.kind == b.kind && q.idx == b.idx) { pos0 = pos; return; } pos += lsz(q.kind); } };
+    int m = 0, n = 0; for (auto& q : dropl) m += lsz(q.kind); for (auto& q : keepl) n += lsz(q.kind);
+    const int pos = m + n;
+    Vec A((size_t)pos * pos, 0.0), b(pos, 0.0);
+    for (auto& f : facs) {
+        std::vector<int> idx(f.blocks.size());
+        for (size_t a = 0; a < f.blocks.size(); ++a) find(f.blocks[a], idx[a]);
+        for (size_t a = 0; a < f.blocks.size(); ++a) {
+            int sa = lsz(f.blocks[a].kind);
+            for (size_t bb = a; bb < f.blocks.size(); ++bb) {
+                int sb_ = lsz(f.blocks[bb].kind);
+                for (int i = 0; i < sa; ++i) for (int j = 0; j < sb_; ++j) {
+                    double s = 0; for (int r = 0; r < f.rows; ++r) s += f.J[a][(size_t)r * sa + i] * f.J[bb][(size_t)r * sb_ + j];
+                    A[(size_t)(idx[a] + i) * pos + idx[bb] + j] += s;
+                    if (a != bb) A[(size_t)(idx[bb] + j) * pos + idx[a] + i] = A[(size_t)(idx[a] + i) * pos + idx[bb] + j];
+                }
+            }
+            for (int i = 0; i < sa; ++i) { double s = 0; for (int r = 0; r < f.rows; ++r) s += f.J[a][(size_t)r * sa + i] * f.r[r]; b[idx[a] + i] += s; }
+        }
+    }
+    const double eps = 1e-8;
+    Vec Amm((size_t)m * m), dm(m);
+    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Amm[(size_t)i * m + j] = 0.5 * (A[(size_t)i * pos + j] + A[(size_t)j * pos + i]);
+    sym_eig(Amm.data(), m, dm.data());
+    Vec T((size_t)m * (n + 1));      // Amm^+ [Amr | bmm]
+    {
+        Vec T1((size_t)m * (n + 1));
+        for (int i = 0; i < m; ++i) for (int j = 0; j <= n; ++j) { double s = 0; if (dm[i] > eps) { for (int r = 0; r < m; ++r) s += Amm[(size_t)r * m + i] * (j < n ? A[(size_t)r * pos + m + j] : b[r]); s /= dm[i]; } T1[(size_t)i * (n + 1) + j] = s; }
+        for (int i = 0; i < m; ++i) for (int j = 0; j <= n; ++j) { double s = 0; for (int r = 0; r < m; ++r) s += Amm[(size_t)i * m + r] * T1[(size_t)r * (n + 1) + j]; T[(size_t)i * (n + 1) + j] = s; }
+    }
+    Vec A2((size_t)n * n), b2(n), d2(n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j <= n; ++j) { double s = j < n ? A[(size_t)(m + i) * pos + m + j] : b[m + i]; for (int r = 0; r < m; ++r) s -= A[(size_t)(m + i) * pos + r] * T[(size_t)r * (n + 1) + j]; if (j < n) A2[(size_t)i * n + j] = s; else b2[i] = s; }
+    sym_eig(A2.data(), n, d2.data());
+    if (n > out->cap || (int)keepl.size() > out->cap_blocks) return;
+    for (int i = 0; i < n; ++i) {
+        const double sv = d2[i] > eps ? std::sqrt(d2[i]) : 0.0;
+        for (int j = 0; j < n; ++j) out->J0[(size_t)i * n + j] = sv * A2[(size_t)j * n + i];
+        double s = 0; if (d2[i] > eps) { for (int r = 0; r < n; ++r) s += A2[(size_t)r * n + i] * b2[r]; s *= std::sqrt(1.0 / d2[i]); }
+        out->r0[i] = s;
+    }
+    int x0o = 0, nb = 0;
+    for (auto& q : keepl) {
+        out->block_kind[nb] = q.kind;
+        out->block_index[nb] = (q.kind == VG_BLK_POSE || q.kind == VG_BLK_SPEEDBIAS) ? (flag == VG_MARGIN_OLD ? q.idx - 1 : (q.idx == K - 1 ? q.idx - 1 : q.idx)) : 0;
+        const double* x = W.block_ptr(st, q.kind, q.idx); int gs = q.kind == VG_BLK_SPEEDBIAS ? 9 : q.kind == VG_BLK_TD ? 1 : 7;
+        for (int k = 0; k < gs; ++k) out->x0[x0o + k] = x[k];
+        x0o += gs; ++nb;
+    }
+    out->n = n; out->m = m; out->nblocks = nb; out->valid = 1;
+}
+}  // namespace
+
+extern "C" int oracle_ba_optimize(const vg_ba_problem* p, int margin_flag, vg_ba_state* os, vg_ba_summary* sum, vg_ba_prior* pri) {
+    Window W; W.init(p);
+    State x;
+    x.pose.assign(p->pose, p->pose + 7 * p->K);
+    if (W.Kp > W.K) x.pose.insert(x.pose.end(), p->relo_pose, p->relo_pose + 7);
+    x.sb.assign(p->speedbias, p->speedbias + 9 * p->K);
+    x.ex.assign(p->ex_pose, p->ex_pose + 7);
+    x.lam.assign(p->inv_depth, p->inv_depth + p->L);
+    x.td = p->td;
+    vg_ba_summary local; if (!sum) sum = &local;
+    solve(W, x, sum);
+    State o; gauge_fix(W, x, o);
+    if (os) {
+        if (os->pose) memcpy(os->pose, o.pose.data(), sizeof(double) * 7 * p->K);
+        if (os->speedbias) memcpy(os->speedbias, o.sb.data(), sizeof(double) * 9 * p->K);
+        if (os->ex_pose) memcpy(os->ex_pose, o.ex.data(), sizeof(double) * 7);
+        if (os->td) *os->td = o.td;
+        if (os->inv_depth) memcpy(os->inv_depth, o.lam.data(), sizeof(double) * p->L);
+        if (os->relo_pose && W.Kp > W.K) memcpy(os->relo_pose, o.pose.data() + 7 * p->K, sizeof(double) * 7);
+    }
+    if (pri && margin_flag != VG_MARGIN_NONE) {
+        // the marginalization problem is the same window at the gauge-fixed state
+        marginalize(p, o, margin_flag, pri);
+    }
+    return VG_OK;
+}

@@ -174,6 +174,7 @@ class Handle:
         L.vg_ba_batch_run_async.argtypes = [C.c_void_p]
         L.vg_ba_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(State)), C.POINTER(Summary),
                                            C.POINTER(C.POINTER(Prior))]
+        L.vg_ba_batch_run_timed.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.vg_ba_batch_info.argtypes = [C.c_void_p, _pd, _pd, _pd, _pi]
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
         self.h = C.c_void_p()
@@ -219,6 +220,12 @@ class Handle:
 
     def ba_run_async(self):
         self._chk(self.lib.vg_ba_batch_run_async(self.h), "vg_ba_batch_run_async")
+
+    def ba_run_timed(self):
+        """Synchronous run; returns (solve_kernel_ms, marg_kernel_ms) from HIP events on the launch stream."""
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.lib.vg_ba_batch_run_timed(self.h, C.byref(a), C.byref(b)), "vg_ba_batch_run_timed")
+        return float(a.value), float(b.value)
 
     def ba_info(self):
         fl, bi, bo, lds = C.c_double(), C.c_double(), C.c_double(), C.c_int()

@@ -424,6 +424,24 @@ extern "C" int vg_ba_batch_run_async(vg_handle* h) {
     return VG_OK;
 }
 
+extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_ms) {
+    if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    hipEvent_t e0 = h->ev0, e1 = h->ev1, e2 = h->ev2;
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    HIPCHK(h, ba_launch_solve(B.L, B.P, h->stream));
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.P, h->stream));
+    HIPCHK(h, hipEventRecord(e2, h->stream));
+    HIPCHK(h, hipEventSynchronize(e2));
+    float a = 0, b = 0;
+    HIPCHK(h, hipEventElapsedTime(&a, e0, e1));
+    HIPCHK(h, hipEventElapsedTime(&b, e1, e2));
+    if (solve_ms) *solve_ms = a;
+    if (marg_ms) *marg_ms = b;
+    return VG_OK;
+}
+
 extern "C" int vg_ba_batch_info(vg_handle* h, double* flops, double* bytes_in, double* bytes_out, int* lds_bytes) {
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
     if (flops) *flops = h->ba.flops;

@@ -14,7 +14,8 @@ extern "C" int vg_create(vg_handle** out) {
     vg_handle* h = new vg_handle();
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return VG_ERR_HIP; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+        hipEventCreate(&h->ev2) != hipSuccess) {
         delete h;
         return VG_ERR_HIP;
     }
@@ -30,7 +31,7 @@ extern "C" int vg_destroy(vg_handle* h) {
     (void)hipFree(P.iarr); (void)hipFree(P.din); (void)hipFree(P.scr); (void)hipFree(P.out); (void)hipFree(P.iout);
     (void)hipFree(P.mout); (void)hipFree(P.miout); (void)hipFree(P.mscr);
     if (h->fe) fe_state_destroy(h->fe);
-    (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
+    (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev2);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return VG_OK;

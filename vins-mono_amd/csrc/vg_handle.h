@@ -21,7 +21,7 @@ struct FeState;   // fe_host.hip
 struct vg_handle {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     std::string err;
     BaBatch ba;
     FeState* fe = nullptr;
