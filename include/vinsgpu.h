@@ -139,6 +139,8 @@ typedef struct {
     double it_radius[VG_MAX_ITERS];     /* trust-region radius used                                */
     double it_step_norm[VG_MAX_ITERS];  /* dogleg step norm (scaled space)                         */
     int it_flags[VG_MAX_ITERS];         /* bit0 valid, bit1 accepted                               */
+    double prof[16];                    /* device phase timers (shader cycles of lane 0); zero unless the library
+                                           was built with -DBA_PROFILE                                  */
 } vg_ba_summary;
 
 /* New marginalization prior (MarginalizationInfo after marginalize() + getParameterBlocks(),

@@ -28,3 +28,14 @@ for n in (1, 16, 256):
     h.ba_run_async(); h.sync()
     h.timer_start(); h.ba_run_async(); ms = h.timer_stop()
     print(f'batch {n}: {ms:.3f} ms -> {n/ms*1e3:.0f} solves/s')
+names = ['PRO','IMU','PRIOR','PROJ','ACC','LMACC','IMUACC','PRACC','JVEC','BUILD','SCHUR','CHOL','BACK','CAND','MISC','TOTAL']
+seq = synth.SyntheticSequence(3, L=150)
+p1 = seq.window(0)
+st1, _, pr1 = h.ba_optimize(p1, ba.VG_MARGIN_OLD)
+p2 = seq.next_window(st1, pr1, 1)
+st, sm, _ = h.ba_optimize(p2, ba.VG_MARGIN_OLD)
+tot = sm['prof'][15]
+if tot > 0:
+    print('phase cycles (single window, with prior), total %.0f cycles = %.3f ms @2.4GHz' % (tot, tot/2.4e6))
+    for n, v in zip(names, sm['prof']): print(f'  {n:8s} {v:12.0f} {100*v/tot:6.1f}%')
+h.ba_upload([p2], [ba.VG_MARGIN_OLD]); print('timed (solve_ms, marg_ms):', [h.ba_run_timed() for _ in range(3)])

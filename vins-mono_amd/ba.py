@@ -40,7 +40,7 @@ class Summary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
                 ("it_cost", C.c_double * VG_MAX_ITERS), ("it_cost_cand", C.c_double * VG_MAX_ITERS),
                 ("it_model", C.c_double * VG_MAX_ITERS), ("it_radius", C.c_double * VG_MAX_ITERS),
-                ("it_step_norm", C.c_double * VG_MAX_ITERS), ("it_flags", C.c_int * VG_MAX_ITERS)]
+                ("it_step_norm", C.c_double * VG_MAX_ITERS), ("it_flags", C.c_int * VG_MAX_ITERS), ("prof", C.c_double * 16)]
 
 
 class Prior(C.Structure):
@@ -154,7 +154,7 @@ def summary_dict(s):
                 initial_cost=s.initial_cost, final_cost=s.final_cost, final_radius=s.final_radius,
                 it_cost=np.array(s.it_cost[:n]), it_cost_cand=np.array(s.it_cost_cand[:n]),
                 it_model=np.array(s.it_model[:n]), it_radius=np.array(s.it_radius[:n]),
-                it_step_norm=np.array(s.it_step_norm[:n]), it_flags=np.array(s.it_flags[:n]))
+                it_step_norm=np.array(s.it_step_norm[:n]), it_flags=np.array(s.it_flags[:n]), prof=np.array(s.prof[:]))
 
 
 class Handle:

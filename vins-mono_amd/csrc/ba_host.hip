@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,10 +17,10 @@
 #include "vg_handle.h"
 #include "../../include/vinsgpu.h"
 
-extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaPtrs& P, hipStream_t stream);
-extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaPtrs& P, double* proj_r, double* proj_J,
+extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream);
+extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, double* proj_r, double* proj_J,
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream);
-extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaPtrs& P, hipStream_t stream);
+extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream);
 
 #define HIPCHK(h, expr)                                                                            \
     do {                                                                                           \
@@ -114,10 +115,11 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     const int fulltri = (L.R + 1) * (L.R + 2) / 2;
     const int camtri = L.Rc * (L.Rc + 1) / 2;
     const int nst = up(7 * L.Kp + 9 * L.K + 8, 2);
-    L.nvec = 8;
+    L.nvec = 9;
     int tail = 0;
-    const int sz_vec = L.nvec * L.Rpad, sz_red = 32, sz_wd = up(L.RcPad * 17 + 16, 2), sz_misc = 16;
-    tail = sz_vec + sz_red + sz_wd + 2 * nst + sz_misc;
+    const int sz_pmap = up(L.Ncap, 4) / 2;
+    const int sz_vec = L.nvec * L.Rpad, sz_red = 32, sz_wd = up(std::max(L.RcPad * 17 + 16, 4 * L.Ncap), 2), sz_misc = 16;
+    tail = sz_vec + sz_red + sz_wd + 2 * nst + sz_misc + sz_pmap;
     L.l_S = 0;
     L.l_stage = up(camtri, 2);
     L.l_vec = total - tail;
@@ -126,6 +128,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.l_x = L.l_wd + sz_wd;
     L.l_xc = L.l_x + nst;
     L.l_misc = L.l_xc + nst;
+    L.l_pmap = L.l_misc + sz_misc;
     L.lds_bytes = total * 8;
     if (L.l_vec < up(fulltri, 2)) { h->err = "reduced system does not fit in 160 KB of LDS"; return VG_ERR_UNSUPPORTED; }
     const int stage_cap = L.l_vec - L.l_stage;
@@ -197,7 +200,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.oo_td = o; o += 2;
     L.oo_lam = o; o += L.Lcap;
     L.oo_sum = o; o += BA_SUM_DOUBLES;
-    L.oo_trace = o; o += 5 * VG_MAX_ITERS;
+    L.oo_trace = o; o += 5 * VG_MAX_ITERS + 16;
     L.ostride = up(o, 8);
     L.oi_stride = up(4 + VG_MAX_ITERS, 8);
     // ---- marginalization: kept dimension <= 6K + 2*9 + 6 + 1; blocks <= K + 4
@@ -212,11 +215,12 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     {
         // LDS of the marginalization kernel: [eigM ld^2][eigV ld^2][cs 2 ld][red 16][state][ints 256]
         const int nstm = up(16 * L.K + 8 + 1, 2);
-        const int fixed = 16 + nstm + 128;
+        L.mg_cs = up(std::max(2 * mcap, 3 * (L.mg_posmax / 2 + 2)), 2);
+        const int fixed = 16 + nstm + 128 + L.mg_cs;
         int ld = mcap;                               // big enough for the kept part; also used for Amm when m <= ld
-        while (2 * ld * ld + 2 * ld + fixed > 160 * 1024 / 8) ld -= 2;
+        while (2 * ld * ld + fixed > 160 * 1024 / 8) ld -= 2;
         L.mg_ld = ld;
-        L.mg_lds_bytes = (2 * ld * ld + 2 * ld + fixed) * 8;
+        L.mg_lds_bytes = (2 * ld * ld + fixed) * 8;
         if (ld < 8) { h->err = "marginalization LDS carve failed"; return VG_ERR_UNSUPPORTED; }
         const long pm = L.mg_posmax;
         long sdoubles = pm * pm + pm + (long)L.Fcap * 42 + 2 * pm * (mcap + 1) + 2 * pm * pm + 2L * mcap * mcap + 2 * L.Ncap + 480 + L.Lcap + 64;
@@ -404,6 +408,8 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     rc = ensure(h, B.P.mout, B.cap_mout, (size_t)nwin * L.mo_stride); if (rc) return rc;
     rc = ensure(h, B.P.miout, B.cap_miout, (size_t)nwin * L.mi_stride); if (rc) return rc;
     rc = ensure(h, B.P.mscr, B.cap_mscr, (size_t)nwin * L.ms_stride); if (rc) return rc;
+    if (!B.dL) HIPCHK(h, hipMalloc((void**)&B.dL, sizeof(BaLayout)));
+    HIPCHK(h, hipMemcpyAsync(B.dL, &B.L, sizeof(BaLayout), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(B.P.iarr, B.h_ia.data(), B.h_ia.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(B.P.din, B.h_di.data(), B.h_di.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(B.P.iout, 0, (size_t)nwin * L.oi_stride * sizeof(int), h->stream));
@@ -419,8 +425,8 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
 extern "C" int vg_ba_batch_run_async(vg_handle* h) {
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
-    HIPCHK(h, ba_launch_solve(B.L, B.P, h->stream));
-    if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.P, h->stream));
+    HIPCHK(h, ba_launch_solve(B.L, B.dL, B.P, h->stream));
+    if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
     return VG_OK;
 }
 
@@ -429,9 +435,9 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
     BaBatch& B = h->ba;
     hipEvent_t e0 = h->ev0, e1 = h->ev1, e2 = h->ev2;
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    HIPCHK(h, ba_launch_solve(B.L, B.P, h->stream));
+    HIPCHK(h, ba_launch_solve(B.L, B.dL, B.P, h->stream));
     HIPCHK(h, hipEventRecord(e1, h->stream));
-    if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.P, h->stream));
+    if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
     HIPCHK(h, hipEventRecord(e2, h->stream));
     HIPCHK(h, hipEventSynchronize(e2));
     float a = 0, b = 0;
@@ -493,6 +499,7 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
                 s.it_step_norm[k] = o[L.oo_trace + 4 * VG_MAX_ITERS + k];
                 s.it_flags[k] = io[4 + k];
             }
+            for (int k = 0; k < 16; ++k) s.prof[k] = o[L.oo_trace + 5 * VG_MAX_ITERS + k];
             if (s.status != VG_OK) worst = s.status;
         }
         if (pri && pri[w]) {
@@ -502,6 +509,7 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
                 const double* mo = B.h_mout.data() + (size_t)w * L.mo_stride;
                 const int* mi = B.h_miout.data() + (size_t)w * L.mi_stride;
                 q->valid = mi[0];
+                if (getenv("VG_DEBUG_MARG")) fprintf(stderr, "[marg] eig2: sweeps=%d total_kcyc=%d rot_kcyc=%d blk_kcyc=%d V_kcyc=%d sync_kcyc=%d\n", mi[5] & 255, mi[5] >> 8, mi[6], mi[7], mi[4], mi[2]);
                 if (mi[0]) {
                     const int n = mi[1], nb = mi[3];
                     if (n > q->cap || nb > q->cap_blocks) { h->err = "vg_ba_prior capacity too small"; return VG_ERR_BAD_ARG; }
@@ -551,7 +559,7 @@ extern "C" int vg_ba_eval_factors(vg_handle* h, const vg_ba_problem* in, double*
     HIPCHK(h, hipMalloc((void**)&d, tot * sizeof(double)));
     double* d_pr = d; double* d_pJ = d_pr + (size_t)F * 2; double* d_ir = d_pJ + (size_t)F * 40;
     double* d_iJ = d_ir + nimu * 15; double* d_qr = d_iJ + nimu * 450;
-    hipError_t e = ba_launch_eval_factors(L, B.P, d_pr, d_pJ, d_ir, d_iJ, d_qr, h->stream);
+    hipError_t e = ba_launch_eval_factors(L, B.dL, B.P, d_pr, d_pJ, d_ir, d_iJ, d_qr, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && proj_r) e = hipMemcpy(proj_r, d_pr, (size_t)F * 2 * 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess && proj_J) e = hipMemcpy(proj_J, d_pJ, (size_t)F * 40 * 8, hipMemcpyDeviceToHost);

@@ -17,20 +17,36 @@
 #include "ba_factors.h"
 #include "../../include/vinsgpu.h"
 
+#define NOINL __device__ __noinline__
+extern __shared__ __attribute__((aligned(16))) char ba_smem[];
+#define LDSB ((double*)ba_smem)
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// optional phase timers (build with -DBA_PROFILE): lane 0 accumulates s_memtime deltas per phase
+#ifdef BA_PROFILE
+#define PROF_DECL long long _pt = 0
+#define PROF_T0() do { if (c.tid == 0) _pt = clock64(); } while (0)
+#define PROF_ADD(id) do { if (c.tid == 0) { const long long _n = clock64(); LDSB[c.Lp->l_misc + (id)] += (double)(_n - _pt); _pt = _n; } } while (0)
+#else
+#define PROF_DECL
+#define PROF_T0()
+#define PROF_ADD(id)
+#endif
+enum { PF_PRO = 0, PF_IMU, PF_PRIOR, PF_PROJ, PF_ACC, PF_LMACC, PF_IMUACC, PF_PRACC, PF_JVEC, PF_BUILD, PF_SCHUR, PF_CHOL, PF_BACK, PF_CAND, PF_MISC, PF_TOTAL };
+#define PF_CH_DIAG PF_MISC
+#define PF_CH_PANEL PF_PRO   /* temporary sub-profile slots */
+
 // R-vectors kept in LDS
-enum { V_G = 0, V_SC, V_DG, V_GT, V_GN, V_U, V_Y, V_T, V_NVEC };
+enum { V_G = 0, V_SC, V_DG, V_GT, V_GN, V_U, V_Y, V_T, V_DI, V_NVEC };
 
 // ------------------------------------------------------------------------------------------------
 struct Ctx {
-    BaLayout L;
+    const BaLayout* Lp;      // layout lives in device memory: uniform scalar loads on demand, no SGPR hoarding
     const int* hdr;
     const int* ia;       // int arrays of this window
     const double* di;    // double inputs
     double* sc;          // scratch
-    double* lds;         // LDS base (as doubles)
     int tid, lane, wave;
     int nL, nF, nprior, nblk, nchunk;
     double focal, tr, row, gnorm;
@@ -43,7 +59,7 @@ DEV double wave_sum(double v) {
 }
 // deterministic block-wide sum, result uniform in every thread (2 barriers)
 DEV double block_sum(const Ctx& c, double v) {
-    double* red = c.lds + c.L.l_red;
+    double* red = LDSB + c.Lp->l_red;
     v = wave_sum(v);
     __syncthreads();
     if (c.lane == 0) red[c.wave] = v;
@@ -54,7 +70,7 @@ DEV double block_sum(const Ctx& c, double v) {
     return s;
 }
 DEV void block_sum2(const Ctx& c, double& a, double& b) {
-    double* red = c.lds + c.L.l_red;
+    double* red = LDSB + c.Lp->l_red;
     a = wave_sum(a);
     b = wave_sum(b);
     __syncthreads();
@@ -66,7 +82,7 @@ DEV void block_sum2(const Ctx& c, double& a, double& b) {
     a = s; b = t;
 }
 DEV double block_max(const Ctx& c, double v) {
-    double* red = c.lds + c.L.l_red;
+    double* red = LDSB + c.Lp->l_red;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
     __syncthreads();
@@ -95,9 +111,9 @@ DEV int st_size(const BaLayout& L) { return 7 * L.Kp + 9 * L.K + 8; }
 // LLT(covariance^-1).matrixL().transpose() of imu_factor.h:64 (the Cholesky factor of the inverse is
 // unique) but never forms the badly conditioned inverse.  One wavefront per factor, matrix in LDS.
 // ================================================================================================
-DEV void imu_sqrt_info(const Ctx& c) {
-    const BaLayout& L = c.L;
-    double* A = c.lds + L.l_stage + c.wave * 256;     // 15x15 scratch per wave (stage region is free)
+NOINL void imu_sqrt_info(const Ctx& c) {
+    const BaLayout& L = *c.Lp;
+    double* A = LDSB + L.l_stage + c.wave * 256;     // 15x15 scratch per wave (stage region is free)
     const int nimu = L.K - 1;
     const int* valid = c.ia + L.io_imu_valid;
     for (int base = 0; base < nimu; base += BA_NW) {
@@ -143,8 +159,8 @@ DEV void imu_sqrt_info(const Ctx& c) {
 // residuals (+ weighted Jacobians) of all IMU factors at state x.  Thread = (factor, column|row).
 // Returns this thread's share of sum r^2.
 template <bool JAC>
-DEV double imu_pass(const Ctx& c, const double* x) {
-    const BaLayout& L = c.L;
+NOINL double imu_pass(const Ctx& c, const double* x) {
+    const BaLayout& L = *c.Lp;
     const int nimu = L.K - 1;
     const int* valid = c.ia + L.io_imu_valid;
     double cost = 0.0;
@@ -194,15 +210,15 @@ DEV int imu_col(const BaLayout& L, int f, int lc) {
 // Prior (MarginalizationFactor::Evaluate, marginalization_factor.cpp:333-381)
 // ================================================================================================
 DEV const double* state_block(const Ctx& c, const double* x, int kind, int idx) {
-    const BaLayout& L = c.L;
+    const BaLayout& L = *c.Lp;
     if (kind == VG_BLK_POSE) return st_pose(L, x, idx);
     if (kind == VG_BLK_SPEEDBIAS) return st_sb(L, x, idx);
     if (kind == VG_BLK_EXPOSE) return st_ex(L, x);
     return st_ex(L, x) + 7;     // td
 }
 // dx into scratch so_pu (n doubles); then r = r0 + J0 dx into so_pr.  Returns share of sum r^2.
-DEV double prior_pass(const Ctx& c, const double* x, double* pr) {
-    const BaLayout& L = c.L;
+NOINL double prior_pass(const Ctx& c, const double* x, double* pr) {
+    const BaLayout& L = *c.Lp;
     if (c.nprior == 0) return 0.0;
     double* dx = c.sc + L.so_pu;
     const int* kind = c.ia + L.io_pb_kind;
@@ -232,10 +248,20 @@ DEV double prior_pass(const Ctx& c, const double* x, double* pr) {
     const int n = c.nprior;
     const double* J0t = c.di + L.do_pJ0t;     // J0t[c*Ncap + r] = J0[r][c]  (coalesced over r)
     const double* r0 = c.di + L.do_pr0;
+    double* part = LDSB + L.l_wd;            // 4 x Ncap partial sums (the Schur tile is idle here)
     double cost = 0.0;
+    {
+        // r = r0 + J0 dx, the n-term dot product of every row split over 4 threads
+        const int r = c.tid % L.Ncap, q = c.tid / L.Ncap;
+        if (q < 4 && r < n) {
+            double s = 0.0;
+            for (int k = q; k < n; k += 4) s += J0t[k * L.Ncap + r] * dx[k];
+            part[q * L.Ncap + r] = s;
+        }
+    }
+    __syncthreads();
     for (int r = c.tid; r < n; r += BA_NT) {
-        double s = r0[r];
-        for (int k = 0; k < n; ++k) s += J0t[k * L.Ncap + r] * dx[k];
+        const double s = r0[r] + ((part[r] + part[L.Ncap + r]) + (part[2 * L.Ncap + r] + part[3 * L.Ncap + r]));
         pr[r] = s;
         cost += s * s;
     }
@@ -251,7 +277,7 @@ struct ProjIn {
     int i, j, l;
 };
 DEV void proj_fetch(const Ctx& c, int f, const double* x, const double* lam, ProjIn& p) {
-    const BaLayout& L = c.L;
+    const BaLayout& L = *c.Lp;
     p.i = c.ia[L.io_fac_i + f];
     p.j = c.ia[L.io_fac_j + f];
     p.l = c.ia[L.io_fac_lm + f];
@@ -263,8 +289,8 @@ DEV void proj_fetch(const Ctx& c, int f, const double* x, const double* lam, Pro
 }
 
 // cost-only pass: returns this thread's share of sum rho(|r|^2)  (CauchyLoss(1.0): rho = log(1+s))
-DEV double proj_cost_pass(const Ctx& c, const double* x, const double* lam) {
-    const BaLayout& L = c.L;
+NOINL double proj_cost_pass(const Ctx& c, const double* x, const double* lam) {
+    const BaLayout& L = *c.Lp;
     const double* ex = st_ex(L, x);
     double cost = 0.0;
     for (int f = c.tid; f < c.nF; f += BA_NT) {
@@ -280,7 +306,7 @@ DEV double proj_cost_pass(const Ctx& c, const double* x, const double* lam) {
 
 DEV void proj_jac(const Ctx& c, const ProjIn& p, const double* ex, double* r, double* Ji, double* Jj, double* Jex,
                   double* Jl, double* Jtd) {
-    const BaLayout& L = c.L;
+    const BaLayout& L = *c.Lp;
     if (L.t) {
         if (L.e) proj_eval<true, true, true>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, ex[7], c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
         else proj_eval<true, true, false>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, ex[7], c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
@@ -290,84 +316,14 @@ DEV void proj_jac(const Ctx& c, const ProjIn& p, const double* ex, double* r, do
     }
 }
 
-// J*u pass over projection factors (u: LDS R-vector of reduced columns, ul: landmark part).
-// Accumulates m1 += (Ju).r_corrected, m2 += |Ju|^2 (Jacobians and residuals loss-corrected).
-DEV void proj_jvec_pass(const Ctx& c, const double* x, const double* lam, const double* u, const double* ul,
-                        double& m1, double& m2) {
-    const BaLayout& L = c.L;
-    const double* ex = st_ex(L, x);
-    for (int f = c.tid; f < c.nF; f += BA_NT) {
-        ProjIn p;
-        proj_fetch(c, f, x, lam, p);
-        double r[2], Ji[12], Jj[12], Jex[12], Jl[2], Jtd[2];
-        proj_jac(c, p, ex, r, Ji, Jj, Jex, Jl, Jtd);
-        const double sq = sqrt(1.0 / (1.0 + r[0] * r[0] + r[1] * r[1]));
-        const double* ui = u + col_pose(L, p.i);
-        const double* uj = u + col_pose(L, p.j);
-        double a0 = Jl[0] * ul[p.l], a1 = Jl[1] * ul[p.l];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            a0 += Ji[k] * ui[k] + Jj[k] * uj[k];
-            a1 += Ji[6 + k] * ui[k] + Jj[6 + k] * uj[k];
-        }
-        if (L.e) {
-            const double* ue = u + col_ex(L);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { a0 += Jex[k] * ue[k]; a1 += Jex[6 + k] * ue[k]; }
-        }
-        if (L.t) { a0 += Jtd[0] * u[col_td(L)]; a1 += Jtd[1] * u[col_td(L)]; }
-        a0 *= sq; a1 *= sq;
-        m1 += a0 * (sq * r[0]) + a1 * (sq * r[1]);
-        m2 += a0 * a0 + a1 * a1;
-    }
-}
-// IMU + prior parts of J*u (stored Jacobians)
-DEV void imu_prior_jvec_pass(const Ctx& c, const double* u, double& m1, double& m2) {
-    const BaLayout& L = c.L;
-    const int nimu = L.K - 1;
-    const int* valid = c.ia + L.io_imu_valid;
-    for (int w = c.tid; w < nimu * 15; w += BA_NT) {
-        const int f = w / 15, r = w % 15;
-        if (!valid[f]) continue;
-        const double* J = c.sc + L.so_imuJ + f * 450 + r * 30;
-        double a = 0.0;
-#pragma unroll
-        for (int k = 0; k < 30; ++k) a += J[k] * u[imu_col(L, f, k)];
-        m1 += a * c.sc[L.so_imuR + f * 15 + r];
-        m2 += a * a;
-    }
-    if (c.nprior) {
-        // u in prior ordering -> so_pu (reuses dx slot; dx is recomputed by the next prior_pass)
-        double* up = c.sc + L.so_pu;
-        const int* colb = c.ia + L.io_pb_col;
-        const int* off = c.ia + L.io_pb_off;
-        const int* kind = c.ia + L.io_pb_kind;
-        __syncthreads();
-        for (int b = c.tid; b < c.nblk; b += BA_NT) {
-            const int sz = (kind[b] == VG_BLK_SPEEDBIAS) ? 9 : (kind[b] == VG_BLK_TD ? 1 : 6);
-            for (int k = 0; k < sz; ++k) up[off[b] + k] = (colb[b] >= 0) ? u[colb[b] + k] : 0.0;
-        }
-        __syncthreads();
-        const int n = c.nprior;
-        const double* J0t = c.di + L.do_pJ0t;
-        const double* pr = c.sc + L.so_pr;
-        for (int r = c.tid; r < n; r += BA_NT) {
-            double a = 0.0;
-            for (int k = 0; k < n; ++k) a += J0t[k * L.Ncap + r] * up[k];
-            m1 += a * pr[r];
-            m2 += a * a;
-        }
-    }
-}
-
 // ---- linearisation of one chunk: thread per factor -> loss-corrected record in LDS staging
 // record (REC doubles): [0..11] Ji as (row0,row1) pairs per column | [12..23] Jj | [24,25] Jl | [26,27] r |
 //                       [28..39] Jex | [40,41] Jtd
-DEV double proj_linearize_chunk(const Ctx& c, int ch, const double* x, const double* lam) {
-    const BaLayout& L = c.L;
+NOINL double proj_linearize_chunk(const Ctx& c, int ch, const double* x, const double* lam) {
+    const BaLayout& L = *c.Lp;
     const double* ex = st_ex(L, x);
     const int fb = c.ia[L.io_chunk_fbeg + ch], fe = c.ia[L.io_chunk_fbeg + ch + 1];
-    double* stage = c.lds + L.l_stage;
+    double* stage = LDSB + L.l_stage;
     double cost = 0.0;
     for (int f = fb + c.tid; f < fe; f += BA_NT) {
         ProjIn p;
@@ -407,12 +363,12 @@ DEV double seg_dot(const double* stage, int REC, int b, int e, int offA, int off
 
 // Owner accumulation of the camera part of S and g from the staged chunk: one wavefront per block
 // task, lane = entry (p,q) of the (<=6)x(<=6) block; lanes 36..41 of diagonal tasks own the gradient.
-DEV void proj_accumulate_chunk(const Ctx& c, int ch) {
-    const BaLayout& L = c.L;
+NOINL void proj_accumulate_chunk(const Ctx& c, int ch) {
+    const BaLayout& L = *c.Lp;
     const int Kp = L.Kp, REC = L.REC;
-    const double* stage = c.lds + L.l_stage;
-    double* S = c.lds + L.l_S;
-    double* g = c.lds + L.l_vec + V_G * L.Rpad;
+    const double* stage = LDSB + L.l_stage;
+    double* S = LDSB + L.l_S;
+    double* g = LDSB + L.l_vec + V_G * L.Rpad;
     const int* ptr = c.ia + L.io_pair_ptr + ch * (Kp * Kp + 1);
     const int nb = Kp + L.e + L.t;                 // block rows: poses, ex, td
     const int ntask = nb * (nb + 1) / 2;
@@ -464,10 +420,10 @@ DEV void proj_accumulate_chunk(const Ctx& c, int ch) {
 }
 
 // per-landmark sums from the staged chunk: h = sum Jl.Jl, b = sum Jl.r, W column -> Wt[col][l]
-DEV void landmark_accumulate_chunk(const Ctx& c, int ch) {
-    const BaLayout& L = c.L;
+NOINL void landmark_accumulate_chunk(const Ctx& c, int ch) {
+    const BaLayout& L = *c.Lp;
     const int REC = L.REC;
-    const double* stage = c.lds + L.l_stage;
+    const double* stage = LDSB + L.l_stage;
     const int lb = c.ia[L.io_chunk_lbeg + ch], le = c.ia[L.io_chunk_lbeg + ch + 1];
     double* Wt = c.sc + L.so_Wt;
     for (int l = lb + c.tid; l < le; l += BA_NT) {
@@ -510,15 +466,19 @@ DEV void landmark_accumulate_chunk(const Ctx& c, int ch) {
 // Linearisation at x: fills S (unscaled, pre-Schur), g, h, b, Wt; returns the cost (uniform).
 // ================================================================================================
 DEV double linearize(const Ctx& c, const double* x, const double* lam) {
-    const BaLayout& L = c.L;
-    double* S = c.lds + L.l_S;
-    double* g = c.lds + L.l_vec + V_G * L.Rpad;
+    const BaLayout& L = *c.Lp;
+    double* S = LDSB + L.l_S;
+    double* g = LDSB + L.l_vec + V_G * L.Rpad;
     const int R = L.R, Rc = L.Rc;
     const int camtri = Rc * (Rc + 1) / 2;
     const int fulltri = (R + 1) * (R + 2) / 2;
     __syncthreads();
+    PROF_DECL;
+    PROF_T0();
     double cost2 = imu_pass<true>(c, x);            // sum r^2 share (IMU + prior, no loss)
+    PROF_ADD(PF_IMU);
     cost2 += prior_pass(c, x, c.sc + L.so_pr);
+    PROF_ADD(PF_PRIOR);
     double costrho = 0.0;                           // sum rho share (projection)
     for (int k = c.tid; k < camtri; k += BA_NT) S[k] = 0.0;
     for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = 0.0;
@@ -531,127 +491,137 @@ DEV double linearize(const Ctx& c, const double* x, const double* lam) {
     for (int ch = 0; ch < c.nchunk; ++ch) {
         costrho += proj_linearize_chunk(c, ch, x, lam);
         __syncthreads();
+        PROF_ADD(PF_PROJ);
         proj_accumulate_chunk(c, ch);
+        __syncthreads();
+        PROF_ADD(PF_ACC);
         landmark_accumulate_chunk(c, ch);
         __syncthreads();
+        PROF_ADD(PF_LMACC);
     }
     for (int k = camtri + c.tid; k < fulltri; k += BA_NT) S[k] = 0.0;
     __syncthreads();
-    // ---- IMU J^T J and J^T r, one factor after the other (adjacent factors share blocks)
+    // ---- IMU J^T J and J^T r: factors k and k+1 share the blocks of frame k+1, so even and odd factors are
+    //      accumulated in two rounds (inside a round every S entry has exactly one writer)
     {
         const int nimu = L.K - 1;
         const int* valid = c.ia + L.io_imu_valid;
-        for (int f = 0; f < nimu; ++f) {
-            if (valid[f]) {
+        for (int par = 0; par < 2; ++par) {
+            const int nf = (nimu - par + 1) / 2;
+            for (int w = c.tid; w < nf * 495; w += BA_NT) {
+                const int f = 2 * (w / 495) + par, e = w % 495;
+                if (!valid[f]) continue;
                 const double* J = c.sc + L.so_imuJ + f * 450;
-                const double* r = c.sc + L.so_imuR + f * 15;
-                for (int w = c.tid; w < 465 + 30; w += BA_NT) {
-                    if (w < 465) {
-                        int a = 0;
-                        while ((a + 1) * (a + 2) / 2 <= w) ++a;
-                        const int b = w - a * (a + 1) / 2;
-                        double s = 0.0;
+                if (e < 465) {
+                    int a = 0;
+                    while ((a + 1) * (a + 2) / 2 <= e) ++a;
+                    const int b = e - a * (a + 1) / 2;
+                    double s = 0.0;
 #pragma unroll
-                        for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
-                        const int ca = imu_col(L, f, a), cb = imu_col(L, f, b);
-                        S[ca >= cb ? tri(ca, cb) : tri(cb, ca)] += s;
-                    } else {
-                        const int a = w - 465;
-                        double s = 0.0;
+                    for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
+                    const int ca = imu_col(L, f, a), cb = imu_col(L, f, b);
+                    S[ca >= cb ? tri(ca, cb) : tri(cb, ca)] += s;
+                } else {
+                    const int a = e - 465;
+                    const double* r = c.sc + L.so_imuR + f * 15;
+                    double s = 0.0;
 #pragma unroll
-                        for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * r[k];
-                        g[imu_col(L, f, a)] += s;
-                    }
+                    for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * r[k];
+                    g[imu_col(L, f, a)] += s;
                 }
             }
             __syncthreads();
         }
     }
-    // ---- prior: S += J0^T J0 (precomputed Hp), g += J0^T r
+    PROF_ADD(PF_IMUACC);
+    // ---- prior: S += J0^T J0 (precomputed Hp), g += J0^T r   (pmap: prior column -> reduced column or -1)
     if (c.nprior) {
         const int n = c.nprior;
         const double* Hp = c.sc + L.so_Hp;
         const double* J0 = c.di + L.do_pJ0;       // row-major: J0[r*Ncap + c] coalesced over c
         const double* pr = c.sc + L.so_pr;
-        const int* pcol = c.ia + L.io_pb_col;     // expanded per prior column below
-        const int* off = c.ia + L.io_pb_off;
-        const int* kind = c.ia + L.io_pb_kind;
-        // map prior column -> reduced column through the block table
+        const int* pmap = (const int*)(LDSB + L.l_pmap);
         for (int w = c.tid; w < n * (n + 1) / 2 + n; w += BA_NT) {
-            int a, b;
             const bool isg = w >= n * (n + 1) / 2;
-            if (isg) { a = w - n * (n + 1) / 2; b = 0; }
-            else {
-                a = (int)((sqrt(8.0 * (double)w + 1.0) - 1.0) * 0.5);
+            if (isg) {
+                const int a = w - n * (n + 1) / 2;
+                const int ca = pmap[a];
+                if (ca >= 0) {
+                    double s0 = 0.0, s1 = 0.0;
+                    int r = 0;
+                    for (; r + 1 < n; r += 2) { s0 += J0[r * L.Ncap + a] * pr[r]; s1 += J0[(r + 1) * L.Ncap + a] * pr[r + 1]; }
+                    if (r < n) s0 += J0[r * L.Ncap + a] * pr[r];
+                    g[ca] += s0 + s1;
+                }
+            } else {
+                int a = (int)((sqrt(8.0 * (double)w + 1.0) - 1.0) * 0.5);
                 while (a * (a + 1) / 2 > w) --a;
                 while ((a + 1) * (a + 2) / 2 <= w) ++a;
-                b = w - a * (a + 1) / 2;
-            }
-            // find blocks of a and b
-            int ca = -1, cb = -1;
-            for (int blk = 0; blk < c.nblk; ++blk) {
-                const int sz = (kind[blk] == VG_BLK_SPEEDBIAS) ? 9 : (kind[blk] == VG_BLK_TD ? 1 : 6);
-                if (a >= off[blk] && a < off[blk] + sz) ca = pcol[blk] >= 0 ? pcol[blk] + a - off[blk] : -1;
-                if (b >= off[blk] && b < off[blk] + sz) cb = pcol[blk] >= 0 ? pcol[blk] + b - off[blk] : -1;
-            }
-            if (isg) {
-                if (ca >= 0) {
-                    double s = 0.0;
-                    for (int r = 0; r < n; ++r) s += J0[r * L.Ncap + a] * pr[r];
-                    g[ca] += s;
-                }
-            } else if (ca >= 0 && cb >= 0) {
-                S[ca >= cb ? tri(ca, cb) : tri(cb, ca)] += Hp[a * L.Ncap + b];
+                const int b = w - a * (a + 1) / 2;
+                const int ca = pmap[a], cb = pmap[b];
+                if (ca >= 0 && cb >= 0) S[ca >= cb ? tri(ca, cb) : tri(cb, ca)] += Hp[a * L.Ncap + b];
             }
         }
     }
     const double tot = block_sum(c, 0.5 * (cost2 + costrho));
+    PROF_ADD(PF_PRACC);
     return tot;
 }
 
 // cost only at (x, lam)
 DEV double cost_only(const Ctx& c, const double* x, const double* lam) {
     __syncthreads();
+    PROF_DECL;
+    PROF_T0();
     double c2 = imu_pass<false>(c, x);
-    c2 += prior_pass(c, x, c.sc + c.L.so_prc);
+    c2 += prior_pass(c, x, c.sc + c.Lp->so_prc);
     const double cr = proj_cost_pass(c, x, lam);
-    return block_sum(c, 0.5 * (c2 + cr));
+    const double tot = block_sum(c, 0.5 * (c2 + cr));
+    PROF_ADD(PF_CAND);
+    return tot;
 }
 
 // ================================================================================================
 // Scaled, damped reduced system + landmark Schur complement (MFMA) + Cholesky
 // ================================================================================================
-// S <- diag(sc) S diag(sc) + mu*Dg^2 ; augmented row R <- sc .* g  (the rhs)
-DEV void build_scaled(const Ctx& c, double mu) {
-    const BaLayout& L = c.L;
-    double* S = c.lds + L.l_S;
-    const double* g = c.lds + L.l_vec + V_G * L.Rpad;
-    const double* sc = c.lds + L.l_vec + V_SC * L.Rpad;
-    const double* dg = c.lds + L.l_vec + V_DG * L.Rpad;
+// S <- diag(sc) S diag(sc) + mu*Dg^2 ; augmented row R <- sc .* g  (the rhs).
+// Also returns this thread's share of  t^T H~ t  over the reduced block (H~ = scaled, UN-damped Hessian,
+// t = V_T = gt / Dg): the Cauchy-point denominator |J~ t|^2 of DoglegStrategy::ComputeCauchyPoint without a
+// second pass over the factors.
+NOINL double build_scaled(const Ctx& c, double mu) {
+    const BaLayout& L = *c.Lp;
+    double* S = LDSB + L.l_S;
+    const double* g = LDSB + L.l_vec + V_G * L.Rpad;
+    const double* sc = LDSB + L.l_vec + V_SC * L.Rpad;
+    const double* dg = LDSB + L.l_vec + V_DG * L.Rpad;
+    const double* tv = LDSB + L.l_vec + V_T * L.Rpad;
     const int R = L.R;
     const int n = R * (R + 1) / 2;
+    double q = 0.0;
     for (int w = c.tid; w < n; w += BA_NT) {
         int a = (int)((sqrt(8.0 * (double)w + 1.0) - 1.0) * 0.5);
         while (a * (a + 1) / 2 > w) --a;
         while ((a + 1) * (a + 2) / 2 <= w) ++a;
         const int b = w - a * (a + 1) / 2;
         double v = S[w] * sc[a] * sc[b];
+        q += v * tv[a] * tv[b] * (a == b ? 1.0 : 2.0);
         if (a == b) v += mu * dg[a] * dg[a];
         S[w] = v;
     }
     for (int k = c.tid; k < R; k += BA_NT) S[tri(R, k)] = sc[k] * g[k];
     if (c.tid == 0) S[tri(R, R)] = 0.0;
+    return q;
 }
 
 // Landmark Schur complement on the camera part:  S_cam -= Wd Wd^T,  rhs_cam -= Wd * bd
 //   Wd[c][l] = sc[c] * Wt[c][l] * sl[l] / sqrt(ht[l]),  bd[l] = sl[l]*b[l]/sqrt(ht[l]),
 //   ht[l] = sl[l]^2 h[l] + mu*dgl[l]^2.
 // 16x16 tiles of Wd Wd^T are accumulated with v_mfma_f64_16x16x4_f64 over chunks of 16 landmarks.
-DEV void schur_mfma(const Ctx& c, double mu) {
-    const BaLayout& L = c.L;
-    double* S = c.lds + L.l_S;
-    double* wd = c.lds + L.l_wd;                   // [RcPad][17] + bd[16]
-    const double* sc = c.lds + L.l_vec + V_SC * L.Rpad;
+NOINL void schur_mfma(const Ctx& c, double mu) {
+    const BaLayout& L = *c.Lp;
+    double* S = LDSB + L.l_S;
+    double* wd = LDSB + L.l_wd;                   // [RcPad][17] + bd[16]
+    const double* sc = LDSB + L.l_vec + V_SC * L.Rpad;
     const double* Wt = c.sc + L.so_Wt;
     const double* h = c.sc + L.so_h;
     const double* b = c.sc + L.so_b;
@@ -673,25 +643,20 @@ DEV void schur_mfma(const Ctx& c, double mu) {
         tm[s] = a; tn[s] = t - a * (a + 1) / 2;
     }
     double* bd = wd + RcPad * 17;
+    double* lsc = c.sc + L.so_yl;                 // sl / sqrt(h~): yl is free until the back substitution
+    for (int l = c.tid; l < c.nL; l += BA_NT) lsc[l] = sl[l] / sqrt(sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l]);
     for (int l0 = 0; l0 < c.nL; l0 += 16) {
         __syncthreads();
         for (int w = c.tid; w < RcPad * 16; w += BA_NT) {
             const int row = w / 16, k = w % 16, l = l0 + k;
-            double v = 0.0;
-            if (row < Rc && l < c.nL) {
-                const double ht = sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l];
-                v = sc[row] * Wt[row * L.Lcap + l] * sl[l] / sqrt(ht);
-            }
+            const bool in = row < Rc && l < c.nL;
+            const double wv = Wt[(in ? row : 0) * L.Lcap + (in ? l : 0)];
+            const double v = in ? sc[row] * wv * lsc[l] : 0.0;
             wd[row * 17 + k] = v;
         }
         if (c.tid < 16) {
             const int l = l0 + c.tid;
-            double v = 0.0;
-            if (l < c.nL) {
-                const double ht = sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l];
-                v = sl[l] * b[l] / sqrt(ht);
-            }
-            bd[c.tid] = v;
+            bd[c.tid] = (l < c.nL) ? b[l] * lsc[l] : 0.0;
         }
         __syncthreads();
 #pragma unroll
@@ -727,59 +692,188 @@ DEV void schur_mfma(const Ctx& c, double mu) {
     __syncthreads();
 }
 
-// In-place Cholesky of the packed lower triangle S (R x R) with the rhs as augmented row R.
-// Right-looking, column at a time.  Returns false (uniform) on a non-positive / non-finite pivot.
-DEV bool cholesky_aug(const Ctx& c) {
-    const BaLayout& L = c.L;
-    double* S = c.lds + L.l_S;
+DEV double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+// 1/sqrt(x): hardware seed + two Newton steps (full double precision, ~10 dependent ops)
+DEV double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
+
+// Blocked right-looking Cholesky (NB = 16) of the packed lower triangle S (R x R) held in LDS, with the rhs as
+// augmented row R (so row R of the factor is the forward-substituted rhs):
+//   (1) the 16x16 diagonal block is factored by ONE wavefront in registers — lane i holds row i, pivots and
+//       multipliers travel through v_readlane, no barrier inside the block;
+//   (2) the panel rows below it are solved one thread per row (x L_D^T = a, L_D broadcast from LDS);
+//   (3) the trailing matrix gets its rank-16 update tile by tile on v_mfma_f64_16x16x4_f64.
+// Three barriers per 16 columns.  1/L_jj goes to V_DI.  Returns false (uniform) on a bad pivot.
+NOINL bool cholesky_aug(const Ctx& c) {
+    const BaLayout& L = *c.Lp;
+    double* S = LDSB + L.l_S;
+    double* dinvv = LDSB + L.l_vec + V_DI * L.Rpad;
+    int* flag = (int*)(LDSB + L.l_red + 24);
     const int R = L.R;
-    bool ok = true;
-    for (int j = 0; j < R; ++j) {
-        __syncthreads();
-        const double djj = S[tri(j, j)];
-        if (!(djj > 0.0) || !(djj < 1e300)) { ok = false; break; }
-        const double d = sqrt(djj);
-        const double dinv = 1.0 / d;
-        __syncthreads();
-        for (int i = j + c.tid; i <= R; i += BA_NT) S[tri(i, j)] = (i == j) ? d : S[tri(i, j)] * dinv;
-        __syncthreads();
-        // trailing update: rows i in (j, R], cols k in (j, min(i, R-1)]
-        const int m = R - j;                     // rows j+1 .. R
-        const int ty = c.tid >> 4, tx = c.tid & 15;
-        for (int ii = ty; ii < m; ii += BA_NT / 16) {
-            const int i = j + 1 + ii;
-            const double lij = S[tri(i, j)];
-            const int kmax = i < R ? i : R - 1;
-            for (int k = j + 1 + tx; k <= kmax; k += 16) S[tri(i, k)] -= lij * S[tri(k, j)];
+    const int lane = c.lane;
+    if (c.tid == 0) *flag = 1;
+    __syncthreads();
+    PROF_DECL;
+    for (int c0 = 0; c0 < R; c0 += 16) {
+        const int nb = (R - c0) < 16 ? (R - c0) : 16;
+        PROF_T0();
+        // ---- (1) diagonal block, wavefront 0
+        if (c.wave == 0) {
+            double a[16];
+            const int i = lane & 15;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) a[m] = (lane < 16 && i < nb && m <= i) ? S[tri(c0 + i, c0 + m)] : 0.0;
+            bool good = true;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                if (jj < nb) {
+                    const double piv = readlane_d(a[jj], jj);
+                    if (!(piv > 0.0) || !(piv < 1e300)) good = false;
+                    const double dinv = rsqrt_nr(piv);
+                    const double l = a[jj] * dinv;              // column jj of row `lane` (lane jj: sqrt(piv))
+                    a[jj] = l;
+                    if (lane == 0) dinvv[c0 + jj] = dinv;
+#pragma unroll
+                    for (int k = jj + 1; k < 16; ++k) {
+                        const double lk = readlane_d(l, k);
+                        a[k] -= l * lk;
+                    }
+                }
+            }
+            if (lane < 16 && i < nb) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) if (m <= i) S[tri(c0 + i, c0 + m)] = a[m];
+            }
+            if (!good && lane == 0) *flag = 0;
         }
+        __syncthreads();
+        PROF_ADD(PF_CH_DIAG);
+        if (*flag == 0) break;
+        // ---- (2) panel: rows i > block, x_c = (a_c - sum_{m<c} x_m L_D[c][m]) / L_D[c][c]
+        const int r1 = c0 + nb;
+        if (nb == 16) {
+            // full block: straight-line code, every LDS read unconditional (the compiler batches them)
+            for (int i = r1 + c.tid; i <= R; i += BA_NT) {
+                double x[16];
+                double* row = S + tri(i, c0);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) x[m] = row[m];
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    const double* ld = S + tri(c0 + cc, c0);
+                    double sacc = x[cc];
+#pragma unroll
+                    for (int m = 0; m < cc; ++m) sacc -= x[m] * ld[m];
+                    x[cc] = sacc * dinvv[c0 + cc];
+                }
+#pragma unroll
+                for (int m = 0; m < 16; ++m) row[m] = x[m];
+            }
+        } else {
+            for (int i = r1 + c.tid; i <= R; i += BA_NT) {
+                double* row = S + tri(i, c0);
+                for (int cc = 0; cc < nb; ++cc) {
+                    const double* ld = S + tri(c0 + cc, c0);
+                    double sacc = row[cc];
+                    for (int m = 0; m < cc; ++m) sacc -= row[m] * ld[m];
+                    row[cc] = sacc * dinvv[c0 + cc];
+                }
+            }
+        }
+        __syncthreads();
+        PROF_ADD(PF_CH_PANEL);
+        // ---- (3) trailing update (only full blocks have anything right of them)
+        if (nb == 16 && r1 < R) {
+            const int t0 = r1 >> 4;
+            const int nt = (R >> 4) + 1;                 // tile rows covering rows 0..R
+            const int m = nt - t0;
+            const int ntile = m * (m + 1) / 2;
+            for (int t = c.wave; t < ntile; t += BA_NW) {
+                int tr_ = 0;
+                while ((tr_ + 1) * (tr_ + 2) / 2 <= t) ++tr_;
+                const int tc_ = t - tr_ * (tr_ + 1) / 2;
+                const int ti = t0 + tr_, tk = t0 + tc_;
+                const int arow = 16 * ti + (lane & 15), brow = 16 * tk + (lane & 15);
+                const bool interior = (16 * ti + 15 <= R) && (ti != tk);     // wave-uniform
+                const double* pa = S + tri(arow <= R ? arow : R, c0) + (lane >> 4);
+                const double* pb = S + tri(brow <= R ? brow : R, c0) + (lane >> 4);
+                const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12];
+                const double b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];
+                const bool av = arow <= R, bv = brow < R;
+                double4_t acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av ? a0 : 0.0, bv ? b0 : 0.0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av ? a1 : 0.0, bv ? b1 : 0.0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av ? a2 : 0.0, bv ? b2 : 0.0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av ? a3 : 0.0, bv ? b3 : 0.0, acc, 0, 0, 0);
+                const int colw = 16 * tk + (lane & 15);
+                const int row0 = 16 * ti + (lane >> 4);
+                if (interior) {
+                    double* q0 = S + tri(row0, colw);
+                    double* q1 = S + tri(row0 + 4, colw);
+                    double* q2 = S + tri(row0 + 8, colw);
+                    double* q3 = S + tri(row0 + 12, colw);
+                    const double c0v = *q0, c1v = *q1, c2v = *q2, c3v = *q3;
+                    *q0 = c0v - acc[0]; *q1 = c1v - acc[1]; *q2 = c2v - acc[2]; *q3 = c3v - acc[3];
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int row = row0 + 4 * reg;
+                        if (row <= R && colw < R && colw <= row) S[tri(row, colw)] -= acc[reg];
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
+    const bool ok = (*flag != 0);
     __syncthreads();
     return ok;
 }
 
-// y <- solve L^T y = (row R of S) by one wavefront; result in V_Y.
-DEV void back_substitute(const Ctx& c) {
-    const BaLayout& L = c.L;
-    double* S = c.lds + L.l_S;
-    double* y = c.lds + L.l_vec + V_Y * L.Rpad;
+
+// y <- solve L^T y = (row R of S) by one wavefront (lane owns entries lane, lane+64, lane+128 of the running
+// rhs in registers; the pivot value travels through v_readlane, the next row of L is prefetched); result in V_Y.
+NOINL void back_substitute(const Ctx& c) {
+    const BaLayout& L = *c.Lp;
+    const double* S = LDSB + L.l_S;
+    const double* dinvv = LDSB + L.l_vec + V_DI * L.Rpad;
+    double* y = LDSB + L.l_vec + V_Y * L.Rpad;
     const int R = L.R;
     __syncthreads();
     if (c.wave == 0) {
-        // lane owns entries i = lane, lane+64, lane+128 of the running rhs
-        double v0 = (c.lane < R) ? S[tri(R, c.lane)] : 0.0;
-        double v1 = (c.lane + 64 < R) ? S[tri(R, c.lane + 64)] : 0.0;
-        double v2 = (c.lane + 128 < R) ? S[tri(R, c.lane + 128)] : 0.0;
-        for (int j = R - 1; j >= 0; --j) {
+        const int l0 = c.lane, l1 = c.lane + 64, l2 = c.lane + 128;
+        const double* rowR = S + tri(R, 0);
+        double v0 = rowR[l0 < R ? l0 : 0], v1 = rowR[l1 < R ? l1 : 0], v2 = rowR[l2 < R ? l2 : 0];
+        v0 = l0 < R ? v0 : 0.0; v1 = l1 < R ? v1 : 0.0; v2 = l2 < R ? v2 : 0.0;
+        int j = R - 1;
+        // row j of L, entries i < j (clamped unconditional loads, masked arithmetically)
+        const double* rj = S + tri(j, 0);
+        double r0 = rj[l0 < j ? l0 : 0], r1 = rj[l1 < j ? l1 : 0], r2 = rj[l2 < j ? l2 : 0];
+        r0 = l0 < j ? r0 : 0.0; r1 = l1 < j ? r1 : 0.0; r2 = l2 < j ? r2 : 0.0;
+        double di = dinvv[j];
+        for (; j >= 0; --j) {
+            const int jp = j > 0 ? j - 1 : 0;
+            const double* rn = S + tri(jp, 0);
+            double n0 = rn[l0 < jp ? l0 : 0], n1 = rn[l1 < jp ? l1 : 0], n2 = rn[l2 < jp ? l2 : 0];
+            const double dn = dinvv[jp];
             const int own = j & 63, slot = j >> 6;
             const double vj = slot == 0 ? v0 : (slot == 1 ? v1 : v2);
-            const double xj = __shfl(vj, own, 64) / S[tri(j, j)];
-            if (c.lane == own) {
-                if (slot == 0) v0 = xj; else if (slot == 1) v1 = xj; else v2 = xj;
-            }
-            // v_i -= L[j][i] * x_j for i < j
-            if (c.lane < j) v0 -= S[tri(j, c.lane)] * xj;
-            if (c.lane + 64 < j) v1 -= S[tri(j, c.lane + 64)] * xj;
-            if (c.lane + 128 < j) v2 -= S[tri(j, c.lane + 128)] * xj;
+            const double xj = readlane_d(vj, own) * di;
+            v0 = (slot == 0 && c.lane == own) ? xj : v0 - r0 * xj;
+            v1 = (slot == 1 && c.lane == own) ? xj : v1 - r1 * xj;
+            v2 = (slot == 2 && c.lane == own) ? xj : v2 - r2 * xj;
+            r0 = l0 < jp ? n0 : 0.0; r1 = l1 < jp ? n1 : 0.0; r2 = l2 < jp ? n2 : 0.0;
+            di = dn;
         }
         if (c.lane < R) y[c.lane] = v0;
         if (c.lane + 64 < R) y[c.lane + 64] = v1;
@@ -804,16 +898,15 @@ DEV void R2ypr_dev(const double* R, double* ypr) {
 // ================================================================================================
 // THE SOLVE KERNEL
 // ================================================================================================
-extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_kernel(BaLayout L, BaPtrs P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
     Ctx c;
-    c.L = L;
+    c.Lp = Lp;
     const int w = blockIdx.x;
     c.ia = P.iarr + (size_t)w * L.istride;
     c.hdr = c.ia + L.io_hdr;
     c.di = P.din + (size_t)w * L.dstride;
     c.sc = P.scr + (size_t)w * L.sstride;
-    c.lds = (double*)smem;
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6;
     c.nL = c.hdr[H_L]; c.nF = c.hdr[H_F]; c.nprior = c.hdr[H_NPRIOR]; c.nblk = c.hdr[H_NBLK];
     c.nchunk = c.hdr[H_NCHUNK];
@@ -824,18 +917,18 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_kernel(BaLayout L, 
     double* out = P.out + (size_t)w * L.ostride;
     int* iout = P.iout + (size_t)w * L.oi_stride;
 
-    double* x = c.lds + L.l_x;        // current state
-    double* xc = c.lds + L.l_xc;      // candidate
+    double* x = LDSB + L.l_x;        // current state
+    double* xc = LDSB + L.l_xc;      // candidate
     double* lam = c.sc + L.so_lam;
     double* lamc = c.sc + L.so_lamc;
-    double* vG = c.lds + L.l_vec + V_G * L.Rpad;
-    double* vSC = c.lds + L.l_vec + V_SC * L.Rpad;
-    double* vDG = c.lds + L.l_vec + V_DG * L.Rpad;
-    double* vGT = c.lds + L.l_vec + V_GT * L.Rpad;
-    double* vGN = c.lds + L.l_vec + V_GN * L.Rpad;
-    double* vU = c.lds + L.l_vec + V_U * L.Rpad;
-    double* vY = c.lds + L.l_vec + V_Y * L.Rpad;
-    double* S = c.lds + L.l_S;
+    double* vG = LDSB + L.l_vec + V_G * L.Rpad;
+    double* vSC = LDSB + L.l_vec + V_SC * L.Rpad;
+    double* vDG = LDSB + L.l_vec + V_DG * L.Rpad;
+    double* vGT = LDSB + L.l_vec + V_GT * L.Rpad;
+    double* vGN = LDSB + L.l_vec + V_GN * L.Rpad;
+    double* vU = LDSB + L.l_vec + V_U * L.Rpad;
+    double* vY = LDSB + L.l_vec + V_Y * L.Rpad;
+    double* S = LDSB + L.l_S;
     double* h = c.sc + L.so_h; double* b = c.sc + L.so_b; double* sl = c.sc + L.so_sl;
     double* dgl = c.sc + L.so_dgl; double* gtl = c.sc + L.so_gtl; double* gnl = c.sc + L.so_gnl;
     double* ul = c.sc + L.so_ul; double* yl = c.sc + L.so_yl;
@@ -849,22 +942,47 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_kernel(BaLayout L, 
     for (int k = c.tid; k < nL; k += BA_NT) lam[k] = c.di[L.do_lam + k];
     __syncthreads();
 
+    PROF_DECL;
+#ifdef BA_PROFILE
+    if (c.tid < 16) LDSB[L.l_misc + c.tid] = 0.0;
+    __syncthreads();
+    const long long _pstart = clock64();
+#endif
+    PROF_T0();
     // ---- once per solve: IMU sqrt_info, prior J0^T J0
     imu_sqrt_info(c);
     if (c.nprior) {
+        // J0^T J0 once per solve, J0 staged in LDS (the factor staging area is idle here)
         const int n = c.nprior;
         const double* J0 = c.di + L.do_pJ0;
         double* Hp = c.sc + L.so_Hp;
-        for (int wk = c.tid; wk < n * n; wk += BA_NT) {
-            const int a = wk / n, bb = wk % n;
-            if (bb > a) continue;
-            double s = 0.0;
-            for (int r = 0; r < n; ++r) s += J0[r * L.Ncap + a] * J0[r * L.Ncap + bb];
-            Hp[a * L.Ncap + bb] = s;
+        double* J0s = LDSB + L.l_stage;          // n x n, row stride n
+        for (int wk = c.tid; wk < n * n; wk += BA_NT) J0s[wk] = J0[(wk / n) * L.Ncap + wk % n];
+        int* pmap = (int*)(LDSB + L.l_pmap);
+        {
+            const int* kind = c.ia + L.io_pb_kind;
+            const int* off = c.ia + L.io_pb_off;
+            const int* pcol = c.ia + L.io_pb_col;
+            for (int blk = c.tid; blk < c.nblk; blk += BA_NT) {
+                const int sz = (kind[blk] == VG_BLK_SPEEDBIAS) ? 9 : (kind[blk] == VG_BLK_TD ? 1 : 6);
+                for (int k = 0; k < sz; ++k) pmap[off[blk] + k] = pcol[blk] >= 0 ? pcol[blk] + k : -1;
+            }
+        }
+        __syncthreads();
+        for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
+            int a = (int)((sqrt(8.0 * (double)wk + 1.0) - 1.0) * 0.5);
+            while (a * (a + 1) / 2 > wk) --a;
+            while ((a + 1) * (a + 2) / 2 <= wk) ++a;
+            const int bb = wk - a * (a + 1) / 2;
+            double s0 = 0.0, s1 = 0.0;
+            int r = 0;
+            for (; r + 1 < n; r += 2) { s0 += J0s[r * n + a] * J0s[r * n + bb]; s1 += J0s[(r + 1) * n + a] * J0s[(r + 1) * n + bb]; }
+            if (r < n) s0 += J0s[r * n + a] * J0s[r * n + bb];
+            Hp[a * L.Ncap + bb] = s0 + s1;
         }
     }
     __syncthreads();
-
+    PROF_ADD(PF_PRO);
     // ---- iteration 0
     double cost = linearize(c, x, lam);
     __syncthreads();
@@ -884,7 +1002,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_kernel(BaLayout L, 
     double radius = 1e4, mu = 1e-8;
     const double min_mu = 1e-8, max_mu = 1.0;
     bool reuse = false;
-    double alpha = 0.0, gtn2 = 0.0, gnn2 = 0.0, gtgn = 0.0, dogleg_norm = 0.0;
+    double alpha = 0.0, gtn2 = 0.0, gnn2 = 0.0, gtgn = 0.0, dogleg_norm = 0.0, mu_solved = 1e-8;
     double x_norm;
     {
         double s = 0.0;
@@ -903,46 +1021,61 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_kernel(BaLayout L, 
         bool ok = true;
         if (!reuse) {
             reuse = true;
-            // Dg, gt (scaled gradient / Dg), Cauchy step length
+            // Dg, gt (scaled gradient / Dg), t = gt / Dg
             __syncthreads();
+            double* vT = LDSB + L.l_vec + V_T * L.Rpad;
             for (int k = c.tid; k < R; k += BA_NT) {
                 const double d2 = vSC[k] * vSC[k] * S[tri(k, k)];
                 const double d = sqrt(fmin(fmax(d2, 1e-6), 1e32));
                 vDG[k] = d;
                 vGT[k] = vSC[k] * vG[k] / d;
-                vU[k] = vSC[k] * (vGT[k] / d);
+                vT[k] = vGT[k] / d;
             }
             for (int k = c.tid; k < nL; k += BA_NT) {
                 const double d2 = sl[k] * sl[k] * h[k];
                 const double d = sqrt(fmin(fmax(d2, 1e-6), 1e32));
                 dgl[k] = d;
                 gtl[k] = sl[k] * b[k] / d;
-                ul[k] = sl[k] * (gtl[k] / d);
             }
             __syncthreads();
+            PROF_T0();
+            double qland = 0.0;        // landmark part of t^T H~ t: sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ]
             {
-                double s = 0.0, m1 = 0.0, m2 = 0.0;
+                double s = 0.0;
                 for (int k = c.tid; k < R; k += BA_NT) s += vGT[k] * vGT[k];
-                for (int k = c.tid; k < nL; k += BA_NT) s += gtl[k] * gtl[k];
-                proj_jvec_pass(c, x, lam, vU, ul, m1, m2);
-                imu_prior_jvec_pass(c, vU, m1, m2);
-                block_sum2(c, s, m2);
-                gtn2 = s;
-                alpha = gtn2 / m2;
+                const double* Wt = c.sc + L.so_Wt;
+                for (int l = c.tid; l < nL; l += BA_NT) {
+                    s += gtl[l] * gtl[l];
+                    const double tl = gtl[l] / dgl[l];
+                    double wdot = 0.0;
+                    for (int k = 0; k < L.Rc; ++k) wdot += vSC[k] * Wt[k * L.Lcap + l] * vT[k];
+                    qland += sl[l] * sl[l] * h[l] * tl * tl + 2.0 * tl * sl[l] * wdot;
+                }
+                gtn2 = block_sum(c, s);
             }
+            PROF_ADD(PF_JVEC);
             // Gauss-Newton step, increasing mu on failure (DoglegStrategy::ComputeGaussNewtonStep)
             bool solved = false;
             bool first = true;
             while (mu < max_mu) {
-                if (!first) { cost = linearize(c, x, lam); }     // S was destroyed by the failed attempt
+                if (!first) { cost = linearize(c, x, lam); }     // S was destroyed by the failed attempt (Wt, h unchanged)
                 first = false;
                 __syncthreads();
-                build_scaled(c, mu);
+                PROF_T0();
+                {
+                    double q = build_scaled(c, mu) + qland;
+                    q = block_sum(c, q);
+                    alpha = gtn2 / q;            // |gt|^2 / |J~ (gt/Dg)|^2
+                }
                 __syncthreads();
+                PROF_ADD(PF_BUILD);
                 schur_mfma(c, mu);
+                PROF_ADD(PF_SCHUR);
                 const bool cok = cholesky_aug(c);
+                PROF_ADD(PF_CHOL);
                 if (cok) {
                     back_substitute(c);
+                    PROF_ADD(PF_BACK);
                     // landmarks: y_l = (bt_l - wt_l . y_cam) / ht_l
                     for (int l = c.tid; l < nL; l += BA_NT) {
                         const double ht = sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l];
@@ -955,7 +1088,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_kernel(BaLayout L, 
                     double fin = 0.0;
                     for (int k = c.tid; k < R; k += BA_NT) fin += (vY[k] == vY[k] && fabs(vY[k]) < 1e300) ? 0.0 : 1.0;
                     for (int k = c.tid; k < nL; k += BA_NT) fin += (yl[k] == yl[k] && fabs(yl[k]) < 1e300) ? 0.0 : 1.0;
-                    if (block_sum(c, fin) == 0.0) { solved = true; break; }
+                    if (block_sum(c, fin) == 0.0) { solved = true; mu_solved = mu; break; }
                 }
                 mu *= 10.0;
             }
@@ -1000,11 +1133,15 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_kernel(BaLayout L, 
             for (int k = c.tid; k < R; k += BA_NT) vU[k] = vSC[k] * ((c_gt * vGT[k] + c_gn * vGN[k]) / vDG[k]);
             for (int k = c.tid; k < nL; k += BA_NT) ul[k] = sl[k] * ((c_gt * gtl[k] + c_gn * gnl[k]) / dgl[k]);
             __syncthreads();
-            double m1 = 0.0, m2 = 0.0;
-            proj_jvec_pass(c, x, lam, vU, ul, m1, m2);
-            imu_prior_jvec_pass(c, vU, m1, m2);
-            block_sum2(c, m1, m2);
-            model_change = -(m1 + 0.5 * m2);
+            // model cost change  -(J~ s)^T (r + J~ s / 2)  with s = c_gt a + c_gn b  (a = gt/Dg, b = gn/Dg = -y):
+            //   a.g~ = |gt|^2, b.g~ = gt.gn, a^T H~ a = |gt|^2 / alpha, and from (H~ + mu Dg^2) y = g~ :
+            //   b^T H~ b = -gt.gn - mu |gn|^2,  a^T H~ b = -|gt|^2 - mu gt.gn      (no pass over the factors)
+            {
+                const double q11 = gtn2 / alpha;
+                const double q12 = -gtn2 - mu_solved * gtgn;
+                const double q22 = -gtgn - mu_solved * gnn2;
+                model_change = -(c_gt * gtn2 + c_gn * gtgn) - 0.5 * (c_gt * c_gt * q11 + 2.0 * c_gt * c_gn * q12 + c_gn * c_gn * q22);
+            }
         }
         if (c.tid == 0) {
             out[L.oo_trace + 0 * VG_MAX_ITERS + slot] = cost;
@@ -1153,6 +1290,13 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_kernel(BaLayout L, 
         }
         // setDepth/getDepthVector round trip (feature_manager.cpp:141-200)
         for (int k = c.tid; k < nL; k += BA_NT) out[L.oo_lam + k] = 1.0 / (1.0 / lam[k]);
+#ifdef BA_PROFILE
+        __syncthreads();
+        if (c.tid == 0) {
+            for (int k = 0; k < 15; ++k) out[L.oo_trace + 5 * VG_MAX_ITERS + k] = LDSB[L.l_misc + k];
+            out[L.oo_trace + 5 * VG_MAX_ITERS + 15] = (double)(clock64() - _pstart);
+        }
+#endif
     }
 }
 
@@ -1160,19 +1304,19 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_kernel(BaLayout L, 
 // Factor-evaluation kernel for parity tests (vg_ba_eval_factors): raw (no loss) residuals/Jacobians.
 // proj_J [F][2][20] = [pose_i 6 | pose_j 6 | ex 6 | lambda | td];  imu_J [K-1][15][30]
 // ================================================================================================
-extern "C" __global__ __launch_bounds__(BA_NT) void ba_eval_factors_kernel(BaLayout L, BaPtrs P, double* proj_r,
+extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_eval_factors_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, double* proj_r,
                                                                           double* proj_J, double* imu_r,
                                                                           double* imu_J, double* prior_r) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const BaLayout& L = *Lp;
     Ctx c;
-    c.L = L;
-    c.ia = P.iarr; c.hdr = c.ia + L.io_hdr; c.di = P.din; c.sc = P.scr; c.lds = (double*)smem;
+    c.Lp = Lp;
+    c.ia = P.iarr; c.hdr = c.ia + L.io_hdr; c.di = P.din; c.sc = P.scr;
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6;
     c.nL = c.hdr[H_L]; c.nF = c.hdr[H_F]; c.nprior = c.hdr[H_NPRIOR]; c.nblk = c.hdr[H_NBLK];
     c.nchunk = c.hdr[H_NCHUNK];
     c.focal = c.di[L.do_par + P_FOCAL]; c.tr = c.di[L.do_par + P_TR]; c.row = c.di[L.do_par + P_ROW];
     c.gnorm = c.di[L.do_par + P_GNORM];
-    double* x = c.lds + L.l_x;
+    double* x = LDSB + L.l_x;
     for (int k = c.tid; k < 7 * L.Kp; k += BA_NT) x[k] = c.di[L.do_pose + k];
     for (int k = c.tid; k < 9 * L.K; k += BA_NT) x[7 * L.Kp + k] = c.di[L.do_sb + k];
     if (c.tid < 7) x[7 * L.Kp + 9 * L.K + c.tid] = c.di[L.do_ex + c.tid];
@@ -1208,7 +1352,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_eval_factors_kernel(BaLay
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaPtrs& P, hipStream_t stream) {
+extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1217,14 +1361,14 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaPtrs& P, hipStr
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(ba_solve_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_bytes, stream, L, P);
+    hipLaunchKernelGGL(ba_solve_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_bytes, stream, dL, P);
     return hipGetLastError();
 }
 
-extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaPtrs& P, double* proj_r, double* proj_J,
+extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, double* proj_r, double* proj_J,
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)ba_eval_factors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ba_eval_factors_kernel, dim3(1), dim3(BA_NT), L.lds_bytes, stream, L, P, proj_r, proj_J, imu_r, imu_J, prior_r);
+    hipLaunchKernelGGL(ba_eval_factors_kernel, dim3(1), dim3(BA_NT), L.lds_bytes, stream, dL, P, proj_r, proj_J, imu_r, imu_J, prior_r);
     return hipGetLastError();
 }

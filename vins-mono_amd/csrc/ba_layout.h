@@ -38,9 +38,9 @@ struct BaLayout {
     int mo_J0, mo_r0, mo_x0, mo_stride;       // doubles
     int mi_stride;                            // ints: [valid, n, m, nblocks, kind[NBcap], idx[NBcap]]
     int ms_stride;                            // marginalization scratch doubles per window
-    int mcap, mg_ld, mg_posmax, mg_lds_bytes; // kept-dimension capacity, LDS eig leading dim, max (m+n)
+    int mcap, mg_ld, mg_posmax, mg_cs, mg_lds_bytes; // kept-dimension capacity, LDS eig leading dim, max (m+n)
     // ---- LDS carve (offsets in doubles)
-    int l_S, l_stage, l_vec, l_red, l_wd, l_x, l_xc, l_misc, lds_bytes;
+    int l_S, l_stage, l_vec, l_red, l_wd, l_x, l_xc, l_misc, l_pmap, lds_bytes;
     int nvec;                                 // number of R-vectors at l_vec, each Rpad long
     int Rpad;
 };

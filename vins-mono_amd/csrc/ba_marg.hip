@@ -20,8 +20,11 @@
 #define MG_EPS 1e-8
 #define MG_MAXSWEEP 30
 
+extern __shared__ __attribute__((aligned(16))) char mg_smem[];
+#define MG_LDS ((double*)mg_smem)
+
 struct MCtx {
-    BaLayout L;
+    const BaLayout* Lp;
     const int* ia; const int* hdr; const double* di; double* sc; double* ms; double* lds;
     int tid, lane, wave;
     double focal, tr, row, gnorm;
@@ -47,7 +50,14 @@ DEV double mg_block_sum(const MCtx& c, double* red, double v) {
 // Parallel two-sided Jacobi eigen-decomposition of the symmetric n x n matrix M (leading dimension ld).
 // On exit diag(M) = eigenvalues, V (ld x ld, row-major) holds the eigenvectors as COLUMNS.
 // `cs` is an LDS scratch of 2*ld doubles, `red` of BA_NW doubles.
-DEV void jacobi_eig(const MCtx& c, double* M, double* V, int n, int ld, double* cs, double* red) {
+// INLDS = true: M, V are offsets (in doubles) into the dynamic LDS block (address space known to the compiler ->
+// ds_read / ds_write); INLDS = false: generic pointers to the global-memory fallback buffers.
+template <bool INLDS>
+DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, int n, int ld, int offcs, int offred, bool relative) {
+    double* M = INLDS ? (MG_LDS + offM) : Mg;
+    double* V = INLDS ? (MG_LDS + offV) : Vg;
+    double* cs = MG_LDS + offcs;
+    double* red = MG_LDS + offred;
     const int N = (n + 1) & ~1;           // even player count (a padding player has zero row/col)
     const int half = N / 2;
     for (int k = c.tid; k < ld * ld; k += BA_NT) {
@@ -61,21 +71,32 @@ DEV void jacobi_eig(const MCtx& c, double* M, double* V, int n, int ld, double* 
     fro = mg_block_sum(c, red, fro);
     // stopping rule: a pair is rotated unless |a_pq| <= 1e-16 sqrt(|a_pp a_qq|) (relative accuracy for the small
     // eigenvalues, which the eps = 1e-8 cut and the 1/lambda of the pseudo-inverse are sensitive to) or
-    // |a_pq| <= 1e-19 ||A||_F (absolute floor for null directions); stop when a sweep rotates nothing.
-    const double floor_abs = sqrt(fro) * 1e-19;
-    for (int sweep = 0; sweep < MG_MAXSWEEP; ++sweep) {
+    // |a_pq| <= 1e-17 ||A||_F (absolute floor, 20x below the rounding noise of the entries, for null directions); stop when a sweep rotates nothing.
+    // relative = true : also rotate while |a_pq| > 1e-16 sqrt(|a_pp a_qq|) (high RELATIVE accuracy of the small
+    //                   eigenvalues: needed for Amm, whose spectrum spans 1e2 .. 1e12 and gets inverted);
+    // relative = false: absolute criterion only, |a_pq| <= 1e-16 ||A||_F — what Eigen's tridiagonal-QL solver of the
+    //                   reference guarantees — which saves ~1/3 of the sweeps on the kept block.
+    const double floor_abs = sqrt(fro) * (relative ? 1e-17 : 1e-16);
+    const double relf = relative ? 1e-16 : 0.0;
+    if (c.tid == 0) { red[10] = red[11] = red[12] = red[13] = 0.0; }
+    int sweep = 0;
+    for (; sweep < MG_MAXSWEEP; ++sweep) {
         double nrot = 0.0;
         for (int r = 0; r < N - 1; ++r) {
-            // pair k: (p,q)
+#ifdef BA_PROFILE
+            const long long _ta = clock64();
+#endif
+            // pair k of this round: (p,q), p < q; table in LDS so that the owners below need no div / mod
+            int* pq = (int*)(cs + 2 * half);          // [2*half] ints
             for (int k = c.tid; k < half; k += BA_NT) {
                 int p, q;
                 if (k == 0) { p = N - 1; q = r; }
-                else { p = (r + k) % (N - 1); q = (r - k + N - 1) % (N - 1); }
+                else { p = r + k; if (p >= N - 1) p -= N - 1; q = r - k; if (q < 0) q += N - 1; }
                 if (p > q) { const int t = p; p = q; q = t; }
                 double cc = 1.0, ss = 0.0;
                 if (q < n) {
                     const double apq = M[p * ld + q], app = M[p * ld + p], aqq = M[q * ld + q];
-                    if (fabs(apq) > floor_abs && fabs(apq) > 1e-16 * sqrt(fabs(app * aqq))) {
+                    if (fabs(apq) > floor_abs && fabs(apq) > relf * sqrt(fabs(app * aqq))) {
                         const double theta = (aqq - app) / (2.0 * apq);
                         const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                         cc = 1.0 / sqrt(t * t + 1.0);
@@ -84,51 +105,118 @@ DEV void jacobi_eig(const MCtx& c, double* M, double* V, int n, int ld, double* 
                     }
                 }
                 cs[2 * k] = cc; cs[2 * k + 1] = ss;
+                pq[2 * k] = p; pq[2 * k + 1] = q;
             }
             __syncthreads();
-            // 2x2 block owners: block (ka, kb)
-            for (int w = c.tid; w < half * half; w += BA_NT) {
-                const int ka = w / half, kb = w % half;
-                int p, q, rr, s;
-                if (ka == 0) { p = N - 1; q = r; } else { p = (r + ka) % (N - 1); q = (r - ka + N - 1) % (N - 1); }
-                if (p > q) { const int t = p; p = q; q = t; }
-                if (kb == 0) { rr = N - 1; s = r; } else { rr = (r + kb) % (N - 1); s = (r - kb + N - 1) % (N - 1); }
-                if (rr > s) { const int t = rr; rr = s; s = t; }
-                const double ca = cs[2 * ka], sa = cs[2 * ka + 1], cb = cs[2 * kb], sb = cs[2 * kb + 1];
-                const bool qv = q < n, sv = s < n;   // padding index (== n when n odd) is the larger one
-                const double m00 = M[p * ld + rr];
-                const double m01 = sv ? M[p * ld + s] : 0.0;
-                const double m10 = qv ? M[q * ld + rr] : 0.0;
-                const double m11 = (qv && sv) ? M[q * ld + s] : 0.0;
-                // J_a^T M
-                const double t00 = ca * m00 - sa * m10, t01 = ca * m01 - sa * m11;
-                const double t10 = sa * m00 + ca * m10, t11 = sa * m01 + ca * m11;
-                // (.) J_b
-                double n00 = cb * t00 - sb * t01, n01 = sb * t00 + cb * t01;
-                double n10 = cb * t10 - sb * t11, n11 = sb * t10 + cb * t11;
-                if (ka == kb) { n01 = 0.0; n10 = 0.0; }
-                M[p * ld + rr] = n00;
-                if (sv) M[p * ld + s] = n01;
-                if (qv) M[q * ld + rr] = n10;
-                if (qv && sv) M[q * ld + s] = n11;
-            }
-            // V <- V J_b : thread per (row, pair)
-            for (int w = c.tid; w < n * half; w += BA_NT) {
-                const int i = w / half, kb = w % half;
-                int rr, s;
-                if (kb == 0) { rr = N - 1; s = r; } else { rr = (r + kb) % (N - 1); s = (r - kb + N - 1) % (N - 1); }
-                if (rr > s) { const int t = rr; rr = s; s = t; }
-                if (s >= n) continue;
+#ifdef BA_PROFILE
+            const long long _tb = clock64();
+#endif
+            // 2x2 block owners: wavefront = pair row ka (strided), lane = pair column kb.  All LDS reads of a lane
+            // are issued first (clamped, unconditional), then the arithmetic, then the stores: the LDS latency is
+            // paid once per round instead of once per block.
+            if (half <= 64 && n <= 96) {
+                const int kb = c.lane < half ? c.lane : 0;
+                const int rr = pq[2 * kb], s = pq[2 * kb + 1];
                 const double cb = cs[2 * kb], sb = cs[2 * kb + 1];
-                const double v0 = V[i * ld + rr], v1 = V[i * ld + s];
-                V[i * ld + rr] = cb * v0 - sb * v1;
-                V[i * ld + s] = sb * v0 + cb * v1;
+                const bool sv = s < n;
+                const int sc_ = sv ? s : rr;
+                double m00[6], m01[6], m10[6], m11[6];
+                int pa[6], qa[6];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int ka = c.wave + BA_NW * t;
+                    const int kac = ka < half ? ka : 0;
+                    const int p = pq[2 * kac], q = pq[2 * kac + 1];
+                    const int qc = q < n ? q : p;
+                    pa[t] = p; qa[t] = q;
+                    m00[t] = M[p * ld + rr]; m01[t] = M[p * ld + sc_]; m10[t] = M[qc * ld + rr]; m11[t] = M[qc * ld + sc_];
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int ka = c.wave + BA_NW * t;
+                    const int kac = ka < half ? ka : 0;
+                    const double ca = cs[2 * kac], sa = cs[2 * kac + 1];
+                    const bool qv = qa[t] < n;
+                    const double x01 = sv ? m01[t] : 0.0, x10 = qv ? m10[t] : 0.0, x11 = (qv && sv) ? m11[t] : 0.0;
+                    const double t00 = ca * m00[t] - sa * x10, t01 = ca * x01 - sa * x11;
+                    const double t10 = sa * m00[t] + ca * x10, t11 = sa * x01 + ca * x11;
+                    m00[t] = cb * t00 - sb * t01; m01[t] = sb * t00 + cb * t01;
+                    m10[t] = cb * t10 - sb * t11; m11[t] = sb * t10 + cb * t11;
+                    if (ka == kb) { m01[t] = 0.0; m10[t] = 0.0; }
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int ka = c.wave + BA_NW * t;
+                    if (ka < half && c.lane < half) {
+                        const bool qv = qa[t] < n;
+                        M[pa[t] * ld + rr] = m00[t];
+                        if (sv) M[pa[t] * ld + s] = m01[t];
+                        if (qv) M[qa[t] * ld + rr] = m10[t];
+                        if (qv && sv) M[qa[t] * ld + s] = m11[t];
+                    }
+                }
+                // V <- V J_b : wavefront = rows (strided), lane = pair; same load-all / store-all structure
+                double v0[12], v1[12];
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {
+                    const int i = c.wave + BA_NW * t;
+                    const int ic = i < n ? i : 0;
+                    v0[t] = V[ic * ld + rr]; v1[t] = V[ic * ld + sc_];
+                }
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {
+                    const int i = c.wave + BA_NW * t;
+                    if (i < n && sv && c.lane < half) {
+                        V[i * ld + rr] = cb * v0[t] - sb * v1[t];
+                        V[i * ld + s] = sb * v0[t] + cb * v1[t];
+                    }
+                }
+            } else {
+                for (int ka = c.wave; ka < half; ka += BA_NW) {
+                    const int p = pq[2 * ka], q = pq[2 * ka + 1];
+                    const double ca = cs[2 * ka], sa = cs[2 * ka + 1];
+                    const bool qv = q < n;
+                    for (int kb = c.lane; kb < half; kb += 64) {
+                        const int rr = pq[2 * kb], s = pq[2 * kb + 1];
+                        const double cb = cs[2 * kb], sb = cs[2 * kb + 1];
+                        const bool sv = s < n;
+                        const int qc = qv ? q : p, sc_ = sv ? s : rr;
+                        double m00 = M[p * ld + rr], m01 = M[p * ld + sc_], m10 = M[qc * ld + rr], m11 = M[qc * ld + sc_];
+                        m01 = sv ? m01 : 0.0; m10 = qv ? m10 : 0.0; m11 = (qv && sv) ? m11 : 0.0;
+                        const double t00 = ca * m00 - sa * m10, t01 = ca * m01 - sa * m11;
+                        const double t10 = sa * m00 + ca * m10, t11 = sa * m01 + ca * m11;
+                        double n00 = cb * t00 - sb * t01, n01 = sb * t00 + cb * t01;
+                        double n10 = cb * t10 - sb * t11, n11 = sb * t10 + cb * t11;
+                        if (ka == kb) { n01 = 0.0; n10 = 0.0; }
+                        M[p * ld + rr] = n00;
+                        if (sv) M[p * ld + s] = n01;
+                        if (qv) M[q * ld + rr] = n10;
+                        if (qv && sv) M[q * ld + s] = n11;
+                    }
+                }
+                for (int i = c.wave; i < n; i += BA_NW) {
+                    for (int kb = c.lane; kb < half; kb += 64) {
+                        const int rr = pq[2 * kb], s = pq[2 * kb + 1];
+                        if (s >= n) continue;
+                        const double cb = cs[2 * kb], sb = cs[2 * kb + 1];
+                        const double v0 = V[i * ld + rr], v1 = V[i * ld + s];
+                        V[i * ld + rr] = cb * v0 - sb * v1;
+                        V[i * ld + s] = sb * v0 + cb * v1;
+                    }
+                }
             }
+#ifdef BA_PROFILE
+            const long long _td = clock64();
+#endif
             __syncthreads();
+#ifdef BA_PROFILE
+            if (c.tid == 0) { red[10] += (double)(_tb - _ta); red[11] += (double)(_td - _tb); red[13] += (double)(clock64() - _td); }
+#endif
         }
         if (mg_block_sum(c, red, nrot) == 0.0) break;
     }
     __syncthreads();
+    return sweep;
 }
 
 // marginalization column maps, kept in LDS ints
@@ -140,10 +228,10 @@ struct MgMap {
     int* l0;     // global: [Lcap] list of frame-0 landmarks
 };
 
-extern "C" __global__ __launch_bounds__(BA_NT) void ba_marg_kernel(BaLayout L, BaPtrs P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
     MCtx c;
-    c.L = L;
+    c.Lp = Lp;
     const int w = blockIdx.x;
     c.ia = P.iarr + (size_t)w * L.istride;
     c.hdr = c.ia + L.io_hdr;
@@ -155,7 +243,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_marg_kernel(BaLayout L, B
     c.di = P.din + (size_t)w * L.dstride;
     c.sc = P.scr + (size_t)w * L.sstride;
     c.ms = P.mscr + (size_t)w * L.ms_stride;
-    c.lds = (double*)smem;
+    c.lds = MG_LDS;
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6;
     c.focal = c.di[L.do_par + P_FOCAL]; c.tr = c.di[L.do_par + P_TR]; c.row = c.di[L.do_par + P_ROW];
     c.gnorm = c.di[L.do_par + P_GNORM];
@@ -163,13 +251,16 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_marg_kernel(BaLayout L, B
     double* mo = P.mout + (size_t)w * L.mo_stride;
     const int K = L.K, nL = c.hdr[H_L], nprior = c.hdr[H_NPRIOR], nblk = c.hdr[H_NBLK];
     const int mcap = L.mcap;
+#ifdef BA_PROFILE
+    const long long _tstart = clock64();
+#endif
 
     // ---- LDS carve: [eigM ld*ld][eigV ld*ld][cs 2*ld][red 16][x state][ints]
     const int ld = L.mg_ld;
-    double* eM = c.lds;
+    double* eM = MG_LDS;
     double* eV = eM + ld * ld;
     double* cs = eV + ld * ld;
-    double* red = cs + 2 * ld;
+    double* red = cs + L.mg_cs;
     double* x = red + 16;
     const int nst = (7 * K + 9 * K + 8 + 1) & ~1;
     int* li = (int*)(x + nst);
@@ -447,7 +538,17 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_marg_kernel(BaLayout L, B
             Mm[i * ldm + j] = 0.5 * (A[i * posmax + j] + A[j * posmax + i]);
         }
         __syncthreads();
-        jacobi_eig(c, Mm, Vm, m, ldm, cs, red);
+#ifdef BA_PROFILE
+        const long long _t1 = clock64();
+#endif
+        const int offcs = (int)(cs - MG_LDS), offred = (int)(red - MG_LDS);
+        const int sw1 = in_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, m, ldm, offcs, offred, true)
+                               : jacobi_eig<false>(c, Mm, Vm, 0, 0, m, ldm, offcs, offred, true);
+#ifdef BA_PROFILE
+        if (c.tid == 0) { mi[4] = sw1; mi[6] = (int)((clock64() - _t1) >> 10); mi[7] = (int)((_t1 - _tstart) >> 10); }
+#else
+        (void)sw1;
+#endif
         // T1 = Lambda^+ V^T [Amr | bmm]   (m x (n+1))
         for (int k = c.tid; k < m * (n + 1); k += BA_NT) {
             const int i = k / (n + 1), j = k % (n + 1);
@@ -484,7 +585,17 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_marg_kernel(BaLayout L, B
     const int ld2 = n_lds ? ld : n;
     for (int k = c.tid; k < n * n; k += BA_NT) M2[(k / n) * ld2 + k % n] = gM[(k / n) * posmax + k % n];
     __syncthreads();
-    jacobi_eig(c, M2, V2, n, ld2, cs, red);
+#ifdef BA_PROFILE
+    const long long _t2 = clock64();
+#endif
+    const int offcs2 = (int)(cs - MG_LDS), offred2 = (int)(red - MG_LDS);
+    const int sw2 = n_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, n, ld2, offcs2, offred2, false)
+                          : jacobi_eig<false>(c, M2, V2, 0, 0, n, ld2, offcs2, offred2, false);
+#ifdef BA_PROFILE
+    if (c.tid == 0) { mi[5] = sw2 | ((int)((clock64() - _t2) >> 10) << 8); mi[6] = (int)red[10] >> 10; mi[7] = (int)red[11] >> 10; mi[4] = (int)red[12] >> 10; }
+#else
+    (void)sw2;
+#endif
     // ascending order like SelfAdjointEigenSolver: rank of each eigenvalue
     int* rank = li + 48;
     for (int i = c.tid; i < n; i += BA_NT) {
@@ -539,13 +650,13 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_marg_kernel(BaLayout L, B
     }
 }
 
-extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaPtrs& P, hipStream_t stream) {
+extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)ba_marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(ba_marg_kernel, dim3(L.nwin), dim3(BA_NT), L.mg_lds_bytes, stream, L, P);
+    hipLaunchKernelGGL(ba_marg_kernel, dim3(L.nwin), dim3(BA_NT), L.mg_lds_bytes, stream, dL, P);
     return hipGetLastError();
 }

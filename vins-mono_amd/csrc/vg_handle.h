@@ -7,6 +7,7 @@
 
 struct BaBatch {
     BaLayout L;
+    BaLayout* dL = nullptr;          // device copy of L (kernels read it through scalar loads)
     BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_ia = 0, cap_di = 0, cap_sc = 0, cap_out = 0, cap_iout = 0, cap_mout = 0, cap_miout = 0, cap_mscr = 0;
     std::vector<int> h_ia, h_iout, h_miout, margin, nL;
