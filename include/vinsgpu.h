@@ -191,6 +191,45 @@ int vg_ba_batch_info(vg_handle* h, double* flops_per_run, double* bytes_in, doub
 int vg_ba_eval_factors(vg_handle* h, const vg_ba_problem* in, double* proj_r, double* proj_J,
                        double* imu_r, double* imu_J, double* prior_r);
 
+/* =============================================================================================
+ * FE — FeatureTracker::readImage()  (feature_tracker/src/feature_tracker.cpp:81-167)
+ *
+ * The handle holds `n_cams` independent camera streams (trackerData[NUM_OF_CAM] in
+ * feature_tracker_node.cpp:21; also used as the batch dimension of BASELINE.json configs[1]).  Per stream the
+ * device keeps the pyramids of the previous and the current frame (cur_img / forw_img of feature_tracker.h:52).
+ *
+ *   vg_fe_push_frames   <- `forw_img = img` incl. the optional CLAHE (:87-104)  + the pyramid build that
+ *                          cv::calcOpticalFlowPyrLK does internally; the former current frame becomes previous
+ *   vg_fe_track         <- cv::calcOpticalFlowPyrLK(cur_img, forw_img, cur_pts, forw_pts, status, err,
+ *                          cv::Size(21,21), 3)                                    (:113)
+ *   vg_fe_detect        <- cv::goodFeaturesToTrack(forw_img, n_pts, max_corners, 0.01, MIN_DIST, mask)  (:149)
+ *
+ * Staged variants (*_upload / *_async / *_download) let a benchmark time the device work with inputs resident in HBM.
+ * ============================================================================================= */
+int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, int max_points);
+/* imgs[cam] = top-left pixel of an 8-bit single-channel frame with row stride `stride` bytes (NULL: leave that
+ * stream untouched).  equalize != 0 applies CLAHE(3.0, 8x8) first (EQUALIZE of feature_tracker/src/parameters.cpp:59). */
+int vg_fe_push_frames(vg_handle* h, const uint8_t* const* imgs, int stride, int equalize);
+int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int stride);     /* H2D only            */
+int vg_fe_build_async(vg_handle* h, int equalize);                                 /* CLAHE + pyramids    */
+/* Pyramidal LK from the previous to the current frame of stream `cam`.  prev_xy / next_xy are (x, y) float pairs.
+ * status / err have OpenCV's meaning (the inBorder() filter of feature_tracker.cpp:115-117 is the caller's). */
+int vg_fe_track(vg_handle* h, int cam, const float* prev_xy, int n, float* next_xy, uint8_t* status, float* err);
+int vg_fe_track_upload(vg_handle* h, const float* prev_xy /* [n_cams][max_points][2] */, const int* n /* [n_cams] */);
+int vg_fe_track_async(vg_handle* h);
+int vg_fe_track_download(vg_handle* h, float* next_xy, uint8_t* status, float* err);
+/* Shi-Tomasi corners of the CURRENT frame of stream `cam`; mask is height x width (0 = excluded) or NULL.
+ * out_xy must hold max_corners pairs; corners are integer pixel positions in acceptance order. */
+int vg_fe_detect(vg_handle* h, int cam, const uint8_t* mask, int max_corners, double quality, double min_dist,
+                 float* out_xy, int* out_n);
+int vg_fe_detect_upload(vg_handle* h, const uint8_t* const* masks /* per cam or NULL */, const int* max_corners);
+int vg_fe_detect_async(vg_handle* h, double quality, double min_dist);
+int vg_fe_detect_download(vg_handle* h, float* out_xy /* [n_cams][max_points][2] */, int* out_n /* [n_cams] */);
+/* debugging / parity taps: copy a pyramid level of the current (which = 0) or previous (1) frame, or the
+ * min-eigenvalue map of the last detect, to host memory */
+int vg_fe_get_level(vg_handle* h, int cam, int which, int level, uint8_t* out, int* w, int* hgt);
+int vg_fe_get_eig(vg_handle* h, int cam, float* out);
+
 #ifdef __cplusplus
 }
 #endif

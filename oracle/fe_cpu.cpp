@@ -1,0 +1,322 @@
+// fe_cpu.cpp — dependency-free C++17 restatement of the feature_tracker front end's arithmetic
+// (TEST INFRASTRUCTURE + bench.py's timed cpu_baseline; never linked into the product).
+//
+// PARITY UNPINNED.  FeatureTracker::readImage (feature_tracker/src/feature_tracker.cpp:81-167) does no
+// arithmetic itself: it calls OpenCV (de-facto 3.3.1 via ROS Kinetic, docker/Dockerfile:1), which is not
+// vendored and not installed here.  What is restated, from the published OpenCV algorithms (details and
+// every choice among OpenCV's own build variants are recorded in oracle/ASSUMPTIONS.md):
+//   cv::createCLAHE(3.0, Size(8,8))->apply ......... call site feature_tracker.cpp:87-93   [clahe.cpp]
+//   cv::calcOpticalFlowPyrLK(.., Size(21,21), 3) ... call site feature_tracker.cpp:113     [lkpyramid.cpp,
+//        pyramids.cpp: buildOpticalFlowPyramid / pyrDown, calcSharrDeriv, LKTrackerInvoker]
+//   cv::goodFeaturesToTrack(.., 0.01, MIN_DIST, mask) call site feature_tracker.cpp:149    [featureselect.cpp,
+//        corner.cpp: cornerMinEigenVal = Sobel + cov + boxFilter + calcMinEigenVal]
+// Compile with -ffp-contract=off: the float expressions below are evaluated exactly as written.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+inline int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+inline int cv_round(float v) { return (int)std::lrintf(v); }                 // round half to even
+inline int cv_floor(float v) { return (int)std::floor(v); }
+inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// ---- pyrDown (pyramids.cpp): separable [1 4 6 4 1], BORDER_REFLECT_101, dst = ((w+1)/2, (h+1)/2), (sum+128)>>8
+void pyr_down(const uint8_t* s, int w, int h, uint8_t* d) {
+    const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+    std::vector<int> rowbuf((size_t)h * dw);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < dw; ++x) {
+            const uint8_t* r = s + (size_t)y * w;
+            rowbuf[(size_t)y * dw + x] = r[reflect101(2 * x - 2, w)] + 4 * r[reflect101(2 * x - 1, w)] + 6 * r[reflect101(2 * x, w)]
+                                         + 4 * r[reflect101(2 * x + 1, w)] + r[reflect101(2 * x + 2, w)];
+        }
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            auto R = [&](int yy) { return rowbuf[(size_t)reflect101(yy, h) * dw + x]; };
+            d[(size_t)y * dw + x] = (uint8_t)((R(2 * y - 2) + 4 * R(2 * y - 1) + 6 * R(2 * y) + 4 * R(2 * y + 1) + R(2 * y + 2) + 128) >> 8);
+        }
+}
+
+struct Level { int w, h; std::vector<uint8_t> img; std::vector<int16_t> deriv; };   // deriv interleaved (Ix,Iy)
+
+// ---- calcSharrDeriv (lkpyramid.cpp): un-normalised Scharr, reflect-101 at the image edge
+void scharr(Level& L) {
+    const int w = L.w, h = L.h;
+    L.deriv.assign((size_t)w * h * 2, 0);
+    auto I = [&](int y, int x) { return (int)L.img[(size_t)reflect101(y, h) * w + reflect101(x, w)]; };
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            auto t0 = [&](int xx) { return 3 * (I(y - 1, xx) + I(y + 1, xx)) + 10 * I(y, xx); };
+            auto t1 = [&](int xx) { return I(y + 1, xx) - I(y - 1, xx); };
+            // x+-1 reflect exactly like the row buffers of calcSharrDeriv: t[-1] = t[1], t[w] = t[w-2]
+            const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+            L.deriv[((size_t)y * w + x) * 2] = (int16_t)(t0(xp) - t0(xm));
+            L.deriv[((size_t)y * w + x) * 2 + 1] = (int16_t)(3 * (t1(xm) + t1(xp)) + 10 * t1(x));
+        }
+}
+
+void build_pyramid(const uint8_t* img, int w, int h, int max_level, std::vector<Level>& pyr, bool derivs) {
+    pyr.resize(max_level + 1);
+    pyr[0].w = w; pyr[0].h = h; pyr[0].img.assign(img, img + (size_t)w * h);
+    for (int l = 1; l <= max_level; ++l) {
+        pyr[l].w = (pyr[l - 1].w + 1) / 2; pyr[l].h = (pyr[l - 1].h + 1) / 2;
+        pyr[l].img.resize((size_t)pyr[l].w * pyr[l].h);
+        pyr_down(pyr[l - 1].img.data(), pyr[l - 1].w, pyr[l - 1].h, pyr[l].img.data());
+    }
+    if (derivs) for (auto& L : pyr) scharr(L);
+}
+
+// intensity with the REFLECT_101 pyramid border; derivative with the CONSTANT(0) border
+inline int pix(const Level& L, int x, int y) { return L.img[(size_t)reflect101(y, L.h) * L.w + reflect101(x, L.w)]; }
+inline int der(const Level& L, int x, int y, int c) { return (x < 0 || y < 0 || x >= L.w || y >= L.h) ? 0 : L.deriv[((size_t)y * L.w + x) * 2 + c]; }
+
+const int WIN = 21, W_BITS = 14;
+const float FLT_SCALE = 1.f / (1 << 20);
+
+struct Weights { int w00, w01, w10, w11; };
+inline Weights bilinear_weights(float a, float b) {
+    Weights q;
+    q.w00 = cv_round((1.f - a) * (1.f - b) * (1 << W_BITS));
+    q.w01 = cv_round(a * (1.f - b) * (1 << W_BITS));
+    q.w10 = cv_round((1.f - a) * b * (1 << W_BITS));
+    q.w11 = (1 << W_BITS) - q.w00 - q.w01 - q.w10;
+    return q;
+}
+
+// LKTrackerInvoker for one point on one level.  A / b sums are exact 64-bit integers converted once to float
+// (oracle/ASSUMPTIONS.md F3: the scalar and SSE builds of OpenCV already differ from each other here).
+void lk_point_level(const Level& I, const Level& J, int level, int max_level, float px, float py, float& nx, float& ny,
+                    uint8_t& status, float& err, int max_count, double eps2, float min_eig_thr) {
+    const float half = (WIN - 1) * 0.5f;
+    float prevx = px * (float)(1. / (1 << level)), prevy = py * (float)(1. / (1 << level));
+    float nextx, nexty;
+    if (level == max_level) { nextx = prevx; nexty = prevy; }
+    else { nextx = nx * 2.f; nexty = ny * 2.f; }
+    nx = nextx; ny = nexty;
+    prevx -= half; prevy -= half;
+    const int ipx = cv_floor(prevx), ipy = cv_floor(prevy);
+    if (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h) {
+        if (level == 0) { status = 0; err = 0; }
+        return;
+    }
+    Weights q = bilinear_weights(prevx - ipx, prevy - ipy);
+    int16_t Ibuf[WIN * WIN], dI[WIN * WIN * 2];
+    int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+    for (int y = 0; y < WIN; ++y)
+        for (int x = 0; x < WIN; ++x) {
+            const int X = ipx + x, Y = ipy + y;
+            const int ival = descale(pix(I, X, Y) * q.w00 + pix(I, X + 1, Y) * q.w01 + pix(I, X, Y + 1) * q.w10 + pix(I, X + 1, Y + 1) * q.w11, W_BITS - 5);
+            const int ixval = descale(der(I, X, Y, 0) * q.w00 + der(I, X + 1, Y, 0) * q.w01 + der(I, X, Y + 1, 0) * q.w10 + der(I, X + 1, Y + 1, 0) * q.w11, W_BITS);
+            const int iyval = descale(der(I, X, Y, 1) * q.w00 + der(I, X + 1, Y, 1) * q.w01 + der(I, X, Y + 1, 1) * q.w10 + der(I, X + 1, Y + 1, 1) * q.w11, W_BITS);
+            Ibuf[y * WIN + x] = (int16_t)ival; dI[(y * WIN + x) * 2] = (int16_t)ixval; dI[(y * WIN + x) * 2 + 1] = (int16_t)iyval;
+            iA11 += (int64_t)ixval * ixval; iA12 += (int64_t)ixval * iyval; iA22 += (int64_t)iyval * iyval;
+        }
+    const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * WIN * WIN);
+    if (minEig < min_eig_thr || D < 1.1920929e-07f) {
+        if (level == 0) status = 0;
+        return;
+    }
+    D = 1.f / D;
+    nextx -= half; nexty -= half;
+    float pdx = 0, pdy = 0;
+    for (int j = 0; j < max_count; ++j) {
+        const int inx = cv_floor(nextx), iny = cv_floor(nexty);
+        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
+            if (level == 0) status = 0;
+            break;
+        }
+        Weights r = bilinear_weights(nextx - inx, nexty - iny);
+        int64_t ib1 = 0, ib2 = 0;
+        for (int y = 0; y < WIN; ++y)
+            for (int x = 0; x < WIN; ++x) {
+                const int X = inx + x, Y = iny + y;
+                const int diff = descale(pix(J, X, Y) * r.w00 + pix(J, X + 1, Y) * r.w01 + pix(J, X, Y + 1) * r.w10 + pix(J, X + 1, Y + 1) * r.w11, W_BITS - 5) - Ibuf[y * WIN + x];
+                ib1 += (int64_t)diff * dI[(y * WIN + x) * 2]; ib2 += (int64_t)diff * dI[(y * WIN + x) * 2 + 1];
+            }
+        const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+        const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+        nextx += dx; nexty += dy;
+        nx = nextx + half; ny = nexty + half;
+        if ((double)dx * dx + (double)dy * dy <= eps2) break;
+        if (j > 0 && std::abs(dx + pdx) < 0.01 && std::abs(dy + pdy) < 0.01) {
+            nx -= dx * 0.5f; ny -= dy * 0.5f;
+            break;
+        }
+        pdx = dx; pdy = dy;
+    }
+    if (status && level == 0) {
+        const float ex = nx - half, ey = ny - half;
+        const int inx = cv_floor(ex), iny = cv_floor(ey);
+        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) { status = 0; return; }
+        Weights r = bilinear_weights(ex - inx, ey - iny);
+        int64_t e = 0;
+        for (int y = 0; y < WIN; ++y)
+            for (int x = 0; x < WIN; ++x) {
+                const int X = inx + x, Y = iny + y;
+                const int diff = descale(pix(J, X, Y) * r.w00 + pix(J, X + 1, Y) * r.w01 + pix(J, X, Y + 1) * r.w10 + pix(J, X + 1, Y + 1) * r.w11, W_BITS - 5) - Ibuf[y * WIN + x];
+                e += std::abs(diff);
+            }
+        err = (float)e * (1.f / (32 * WIN * WIN));
+    }
+}
+
+// ---- cornerMinEigenVal(blockSize 3, ksize 3) (corner.cpp)
+void min_eig_map(const uint8_t* img, int w, int h, float* eig) {
+    const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
+    const float k1 = (float)(1.0 * scale_d), k2 = (float)(2.0 * scale_d);      // Sobel smoothing taps * scale, as float kernels
+    std::vector<float> dx((size_t)w * h), dy((size_t)w * h), rbuf((size_t)w * h);
+    auto P = [&](int y, int x) { return (int)img[(size_t)reflect101(y, h) * w + reflect101(x, w)]; };
+    // Dx: rows [-1 0 1] (exact), columns [s 2s s]:  f0*r1 + f1*(r0 + r2)
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) rbuf[(size_t)y * w + x] = (float)(P(y, x + 1) - P(y, x - 1));
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        const float r0 = rbuf[(size_t)reflect101(y - 1, h) * w + x], r1 = rbuf[(size_t)y * w + x], r2 = rbuf[(size_t)reflect101(y + 1, h) * w + x];
+        dx[(size_t)y * w + x] = k2 * r1 + k1 * (r0 + r2);
+    }
+    // Dy: rows [s 2s s] on uchar: k0*S[x] + k1*(S[x-1] + S[x+1]) (integer pair sum), columns [-1 0 1]
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) rbuf[(size_t)y * w + x] = (float)P(y, x) * k2 + (float)(P(y, x - 1) + P(y, x + 1)) * k1;
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x)
+        dy[(size_t)y * w + x] = rbuf[(size_t)reflect101(y + 1, h) * w + x] - rbuf[(size_t)reflect101(y - 1, h) * w + x];
+    // cov = (dx*dx, dx*dy, dy*dy) as float; 3x3 un-normalised box in double; min eigenvalue in float
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        double sxx = 0, sxy = 0, syy = 0;
+        for (int v = -1; v <= 1; ++v) for (int u = -1; u <= 1; ++u) {
+            const size_t o = (size_t)reflect101(y + v, h) * w + reflect101(x + u, w);
+            const float gx = dx[o], gy = dy[o];
+            sxx += (double)(gx * gx); sxy += (double)(gx * gy); syy += (double)(gy * gy);
+        }
+        const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+        eig[(size_t)y * w + x] = (float)((a + c) - std::sqrt((a - c) * (a - c) + b * b));
+    }
+}
+}  // namespace
+
+extern "C" {
+
+void oracle_fe_pyrdown(const uint8_t* src, int w, int h, uint8_t* dst) { pyr_down(src, w, h, dst); }
+
+// derivative image of one level (int16 interleaved Ix,Iy)
+void oracle_fe_scharr(const uint8_t* img, int w, int h, int16_t* out) {
+    Level L; L.w = w; L.h = h; L.img.assign(img, img + (size_t)w * h);
+    scharr(L);
+    memcpy(out, L.deriv.data(), sizeof(int16_t) * L.deriv.size());
+}
+
+// cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(21,21), max_level) with the default
+// TermCriteria(COUNT+EPS, 30, 0.01), flags = 0, minEigThreshold = 1e-4.  Points are (x, y) float pairs.
+void oracle_fe_lk(const uint8_t* prev, const uint8_t* next, int w, int h, const float* prev_xy, int n, int max_level,
+                  float* next_xy, uint8_t* status, float* err) {
+    std::vector<Level> pI, pJ;
+    build_pyramid(prev, w, h, max_level, pI, true);
+    build_pyramid(next, w, h, max_level, pJ, false);
+    for (int i = 0; i < n; ++i) { status[i] = 1; err[i] = 0; next_xy[2 * i] = 0; next_xy[2 * i + 1] = 0; }
+    for (int level = max_level; level >= 0; --level)
+        for (int i = 0; i < n; ++i)
+            lk_point_level(pI[level], pJ[level], level, max_level, prev_xy[2 * i], prev_xy[2 * i + 1], next_xy[2 * i], next_xy[2 * i + 1],
+                           status[i], err[i], 30, 0.01 * 0.01, 1e-4f);
+}
+
+void oracle_fe_mineig(const uint8_t* img, int w, int h, float* eig) { min_eig_map(img, w, h, eig); }
+
+// cv::goodFeaturesToTrack(img, corners, max_corners, quality, min_dist, mask, 3, false).  Returns count.
+int oracle_fe_gftt(const uint8_t* img, int w, int h, const uint8_t* mask, int max_corners, double quality, double min_dist,
+                   float* out_xy) {
+    std::vector<float> eig((size_t)w * h);
+    min_eig_map(img, w, h, eig.data());
+    double maxVal = 0;
+    bool any = false;
+    for (size_t k = 0; k < eig.size(); ++k) if (!mask || mask[k]) { if (!any || eig[k] > maxVal) maxVal = eig[k]; any = true; }
+    const float thr = (float)(maxVal * quality);
+    for (auto& v : eig) v = v > thr ? v : 0.f;
+    std::vector<int> cand;
+    for (int y = 1; y < h - 1; ++y)
+        for (int x = 1; x < w - 1; ++x) {
+            const float val = eig[(size_t)y * w + x];
+            if (val == 0 || (mask && !mask[(size_t)y * w + x])) continue;
+            float mx = val;
+            for (int v = -1; v <= 1; ++v) for (int u = -1; u <= 1; ++u) mx = std::max(mx, eig[(size_t)(y + v) * w + x + u]);
+            if (val == mx) cand.push_back(y * w + x);
+        }
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return eig[a] > eig[b] ? true : (eig[a] < eig[b] ? false : a > b); });
+    int n = 0;
+    if (min_dist >= 1) {
+        const int cell = (int)std::lrint(min_dist);
+        const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+        std::vector<std::vector<int>> grid((size_t)gw * gh);
+        const double md2 = min_dist * min_dist;
+        for (int idx : cand) {
+            const int y = idx / w, x = idx % w;
+            const int xc = x / cell, yc = y / cell;
+            const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
+            bool good = true;
+            for (int yy = y1; yy <= y2 && good; ++yy)
+                for (int xx = x1; xx <= x2 && good; ++xx)
+                    for (int o : grid[(size_t)yy * gw + xx]) {
+                        const float dx = (float)(x - o % w), dy = (float)(y - o / w);
+                        if (dx * dx + dy * dy < md2) { good = false; break; }
+                    }
+            if (good) {
+                grid[(size_t)yc * gw + xc].push_back(idx);
+                out_xy[2 * n] = (float)x; out_xy[2 * n + 1] = (float)y;
+                if (++n == max_corners && max_corners > 0) break;
+            }
+        }
+    } else {
+        for (int idx : cand) {
+            out_xy[2 * n] = (float)(idx % w); out_xy[2 * n + 1] = (float)(idx / w);
+            if (++n == max_corners && max_corners > 0) break;
+        }
+    }
+    return n;
+}
+
+// cv::createCLAHE(clip, Size(8,8))->apply on an image whose size divides by 8 (752x480: tiles of 94x60)
+int oracle_fe_clahe(const uint8_t* src, int w, int h, double clip, uint8_t* dst) {
+    const int TX = 8, TY = 8;
+    if (w % TX || h % TY) return -1;
+    const int tw = w / TX, th = h / TY, area = tw * th;
+    const float lutScale = 255.f / area;
+    int clipLimit = (int)(clip * area / 256);
+    clipLimit = std::max(clipLimit, 1);
+    std::vector<uint8_t> lut((size_t)TX * TY * 256);
+    for (int ty = 0; ty < TY; ++ty)
+        for (int tx = 0; tx < TX; ++tx) {
+            int hist[256] = {0};
+            for (int y = 0; y < th; ++y) for (int x = 0; x < tw; ++x) hist[src[(size_t)(ty * th + y) * w + tx * tw + x]]++;
+            int clipped = 0;
+            for (int i = 0; i < 256; ++i) if (hist[i] > clipLimit) { clipped += hist[i] - clipLimit; hist[i] = clipLimit; }
+            const int batch = clipped / 256;
+            int residual = clipped - batch * 256;
+            for (int i = 0; i < 256; ++i) hist[i] += batch;
+            if (residual != 0) {
+                const int step = std::max(256 / residual, 1);
+                for (int i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++;
+            }
+            int sum = 0;
+            for (int i = 0; i < 256; ++i) { sum += hist[i]; lut[((size_t)ty * TX + tx) * 256 + i] = sat_u8(cv_round(sum * lutScale)); }
+        }
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    for (int y = 0; y < h; ++y) {
+        const float tyf = y * inv_th - 0.5f;
+        int ty1 = cv_floor(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - ty1, ya1 = 1.0f - ya;
+        ty1 = std::max(ty1, 0); ty2 = std::min(ty2, TY - 1);
+        for (int x = 0; x < w; ++x) {
+            const float txf = x * inv_tw - 0.5f;
+            int tx1 = cv_floor(txf), tx2 = tx1 + 1;
+            const float xa = txf - tx1, xa1 = 1.0f - xa;
+            tx1 = std::max(tx1, 0); tx2 = std::min(tx2, TX - 1);
+            const int v = src[(size_t)y * w + x];
+            const float res = (lut[((size_t)ty1 * TX + tx1) * 256 + v] * xa1 + lut[((size_t)ty1 * TX + tx2) * 256 + v] * xa) * ya1
+                              + (lut[((size_t)ty2 * TX + tx1) * 256 + v] * xa1 + lut[((size_t)ty2 * TX + tx2) * 256 + v] * xa) * ya;
+            dst[(size_t)y * w + x] = sat_u8(cv_round(res));
+        }
+    }
+    return 0;
+}
+}  // extern "C"

@@ -1,0 +1,152 @@
+"""GPU parity tests of the front end (through the C-ABI) against oracle/fe_cpu.cpp on identical frames.
+Bar: bit-exact — pyramid / CLAHE bytes, min-eigenvalue floats, ordered corner lists, LK status AND positions."""
+import numpy as np
+import pytest
+
+from oracle import fe_cpu as F
+from vins_mono_amd import fe, synth
+
+pytestmark = pytest.mark.gpu
+W, H = 752, 480
+
+
+@pytest.fixture(scope="module")
+def frames():
+    a = synth.synth_frame(11)
+    b = synth.warp_frame(a, 12)
+    c = synth.warp_frame(b, 13, shift=(-5.1, 4.4), angle_deg=-0.8)
+    return a, b, c
+
+
+def test_pyramid_levels_bit_exact(handle, frames):
+    tr = fe.FrontEnd(handle, W, H, 1, 150)
+    tr.push_frames([frames[0]])
+    ref = frames[0]
+    for lvl in range(4):
+        got = tr.get_level(0, lvl)
+        assert got.shape == ref.shape and np.array_equal(got, ref), lvl
+        ref = F.pyrdown(ref)
+    assert ref.shape == (30, 47)        # a 5th level would still be > 21x21 but maxLevel = 3
+
+
+def test_clahe_bit_exact(handle, frames):
+    tr = fe.FrontEnd(handle, W, H, 2, 150)
+    dark = (frames[1].astype(np.float32) * 0.35).astype(np.uint8)
+    tr.push_frames([frames[0], dark], equalize=True)
+    assert np.array_equal(tr.get_level(0, 0), F.clahe(frames[0]))
+    assert np.array_equal(tr.get_level(1, 0), F.clahe(dark))
+    assert np.array_equal(tr.get_level(1, 1), F.pyrdown(F.clahe(dark)))
+
+
+def test_min_eigen_map_bit_exact(handle, frames):
+    tr = fe.FrontEnd(handle, W, H, 1, 150)
+    tr.push_frames([frames[0]])
+    tr.detect(0, 10)
+    got, ref = tr.get_eig(0), F.mineig(frames[0])
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("max_corners", [1, 7, 150, 400])
+def test_gftt_identical_ordered_list(handle, frames, max_corners):
+    tr = fe.FrontEnd(handle, W, H, 1, 400)
+    tr.push_frames([frames[0]])
+    got = tr.detect(0, max_corners)
+    ref = F.gftt(frames[0], max_corners)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_gftt_with_disc_mask_and_small_min_dist(handle, frames):
+    tr = fe.FrontEnd(handle, W, H, 1, 300)
+    tr.push_frames([frames[1]])
+    mask = np.full((H, W), 255, np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for (cx, cy) in [(100, 100), (400, 240), (700, 60), (376, 470)]:
+        mask[(xx - cx) ** 2 + (yy - cy) ** 2 <= 30 ** 2] = 0
+    mask[:, :40] = 0
+    for md in (30.0, 12.0):
+        got = tr.detect(0, 300, 0.01, md, mask)
+        ref = F.gftt(frames[1], 300, 0.01, md, mask)
+        assert got.shape == ref.shape and np.array_equal(got, ref), md
+        assert np.all(mask[got[:, 1].astype(int), got[:, 0].astype(int)] == 255)
+
+
+def test_gftt_degenerate_images(handle):
+    tr = fe.FrontEnd(handle, W, H, 1, 150)
+    flat = np.full((H, W), 77, np.uint8)
+    tr.push_frames([flat])
+    assert tr.detect(0, 150).shape == (0, 2) and F.gftt(flat, 150).shape == (0, 2)
+    # constant gradient: ties everywhere -> the pointer tie-break (larger linear index first) decides
+    ramp = np.tile((np.arange(W) // 3).astype(np.uint8), (H, 1))
+    tr.push_frames([ramp])
+    assert np.array_equal(tr.detect(0, 150), F.gftt(ramp, 150))
+    empty_mask = np.zeros((H, W), np.uint8)
+    tr.push_frames([synth.synth_frame(3)])
+    assert tr.detect(0, 150, mask=empty_mask).shape == (0, 2)
+
+
+def _check_lk(tr, cam, a, b, pts):
+    got, st, err = tr.track(cam, pts)
+    ref, rst, rerr = F.lk(a, b, pts)
+    assert np.array_equal(st, rst)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(err.view(np.uint32), rerr.view(np.uint32))
+    return got, st
+
+
+def test_lk_bit_exact_on_detected_corners(handle, frames):
+    a, b, c = frames
+    tr = fe.FrontEnd(handle, W, H, 1, 150)
+    tr.push_frames([a])
+    pts = tr.detect(0, 150)
+    tr.push_frames([b])
+    got, st = _check_lk(tr, 0, a, b, pts)
+    assert st.sum() >= 140 and np.median(np.linalg.norm(got - pts, axis=1)) > 2.0
+    # next frame: track the survivors again (previous <- current rotation on the device)
+    keep = got[st == 1]
+    tr.push_frames([c])
+    _check_lk(tr, 0, b, c, keep)
+
+
+def test_lk_edge_cases(handle, frames):
+    a, b, _ = frames
+    tr = fe.FrontEnd(handle, W, H, 1, 64)
+    tr.push_frames([a])
+    tr.push_frames([b])
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([
+        np.array([[0.0, 0.0], [751.0, 479.0], [2.3, 470.9], [748.7, 3.1], [375.5, 0.4], [-4.0, 100.0], [760.0, 200.0]], np.float32),
+        rng.uniform([0, 0], [W - 1, H - 1], (40, 2)).astype(np.float32)])
+    _check_lk(tr, 0, a, b, pts)
+    # flat patches: min-eigenvalue rejection (status 0 at level 0)
+    flat = a.copy()
+    flat[200:300, 300:420] = 90
+    tr2 = fe.FrontEnd(handle, W, H, 1, 64)
+    tr2.push_frames([flat])
+    tr2.push_frames([b])
+    pts2 = np.array([[360.0, 250.0], [350.5, 260.25], [100.0, 100.0]], np.float32)
+    got, st = _check_lk(tr2, 0, flat, b, pts2)
+    assert st[0] == 0 and st[2] == 1
+    # large motion beyond the pyramid's reach still gives identical (possibly lost) results
+    far = synth.warp_frame(a, 99, shift=(45.0, -38.0), angle_deg=3.0)
+    tr3 = fe.FrontEnd(handle, W, H, 1, 64)
+    tr3.push_frames([a])
+    tr3.push_frames([far])
+    _check_lk(tr3, 0, a, far, F.gftt(a, 60))
+
+
+def test_batched_streams_match_single(handle, frames):
+    a, b, c = frames
+    tr = fe.FrontEnd(handle, W, H, 3, 150)
+    tr.push_frames([a, b, c])
+    tr.detect_upload([150, 60, 150])
+    tr.detect_async()
+    corners = tr.detect_download()
+    for img, got, n in zip((a, b, c), corners, (150, 60, 150)):
+        assert np.array_equal(got, F.gftt(img, n))
+    tr.push_frames([b, c, a])
+    tr.track_upload(corners)
+    tr.track_async()
+    res = tr.track_download()
+    for (p, q), pts, (got, st, err) in zip(((a, b), (b, c), (c, a)), corners, res):
+        ref, rst, _ = F.lk(p, q, pts)
+        assert np.array_equal(st, rst) and np.array_equal(got.view(np.uint32), ref.view(np.uint32))

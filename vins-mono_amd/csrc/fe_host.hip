@@ -1,0 +1,320 @@
+// fe_host.hip — host side of the front-end path behind the C-ABI (include/vinsgpu.h, vg_fe_*): owns the per-camera
+// pyramids / point / corner buffers in HBM, launches the kernels of fe_kernels.hip on the handle's stream.
+// Replaces the OpenCV calls of FeatureTracker::readImage (feature_tracker/src/feature_tracker.cpp:87-93, :113, :149).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "fe_layout.h"
+#include "vg_handle.h"
+#include "../../include/vinsgpu.h"
+
+#define HIPCHK(h, expr)                                                                            \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                          \
+            return VG_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+extern "C" {
+__global__ void fe_clahe_lut_kernel(FeDev d, int clip_limit, float lut_scale);
+__global__ void fe_clahe_apply_kernel(FeDev d, uint8_t* const* dst_planes);
+__global__ void fe_copy_kernel(FeDev d, uint8_t* const* dst_planes);
+__global__ void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh);
+__global__ void fe_lk_kernel(FeDev d);
+__global__ void fe_mineig_kernel(FeDev d);
+__global__ void fe_candidates_kernel(FeDev d, double quality);
+__global__ void fe_sort_kernel(FeDev d);
+__global__ void fe_mindist_kernel(FeDev d, float min_dist);
+}
+
+struct FeState {
+    FeDev d;
+    int W = 0, H = 0, cams = 0, max_pts = 0;
+    int flip = 0;                         // which plane set is "current"
+    uint8_t* planes[2] = {nullptr, nullptr};   // two pyramids per camera, all levels, contiguous
+    uint8_t** d_ptrs[2] = {nullptr, nullptr};  // device pointer tables [level*cams+cam]
+    std::vector<uint8_t*> h_ptrs[2];
+    size_t level_off[FE_MAX_LEVELS + 1];
+    uint8_t *raw = nullptr, *lut = nullptr, *mask = nullptr, *status = nullptr;
+    float *prev_xy = nullptr, *next_xy = nullptr, *err = nullptr, *eig = nullptr, *blockmax = nullptr, *corners = nullptr;
+    int *npts = nullptr, *max_corners = nullptr, *ncorners = nullptr;
+    unsigned* ncand = nullptr;
+    unsigned long long* keys = nullptr;
+    std::vector<uint8_t> stage;           // pinned-ish host staging for strided uploads
+    std::vector<int> h_npts;
+    bool have_prev = false;
+    std::vector<char> pushed_once;
+};
+
+extern "C" void fe_state_destroy(FeState* s) {
+    if (!s) return;
+    for (int k = 0; k < 2; ++k) { (void)hipFree(s->planes[k]); (void)hipFree(s->d_ptrs[k]); }
+    (void)hipFree(s->raw); (void)hipFree(s->lut); (void)hipFree(s->mask); (void)hipFree(s->status);
+    (void)hipFree(s->prev_xy); (void)hipFree(s->next_xy); (void)hipFree(s->err); (void)hipFree(s->eig);
+    (void)hipFree(s->blockmax); (void)hipFree(s->corners); (void)hipFree(s->npts); (void)hipFree(s->max_corners);
+    (void)hipFree(s->ncorners); (void)hipFree(s->ncand); (void)hipFree(s->keys);
+    delete s;
+}
+
+static void refresh(FeState* s) {
+    s->d.cur_planes = s->d_ptrs[s->flip];
+    s->d.prev_planes = s->d_ptrs[s->flip ^ 1];
+}
+
+extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, int max_points) {
+    if (!h || width < 32 || height < 32 || n_cams < 1 || max_points < 1) return VG_ERR_BAD_ARG;
+    if ((width * height) % 4) { h->err = "width*height must be a multiple of 4"; return VG_ERR_UNSUPPORTED; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->fe) { fe_state_destroy(h->fe); h->fe = nullptr; }
+    FeState* s = new FeState();
+    h->fe = s;
+    s->W = width; s->H = height; s->cams = n_cams; s->max_pts = max_points;
+    FeDev& d = s->d;
+    memset(&d, 0, sizeof(d));
+    d.W = width; d.H = height; d.cams = n_cams; d.max_level = 3; d.max_pts = max_points; d.max_count = 30;
+    d.min_eig_thr = 1e-4f; d.eps2 = 0.01 * 0.01;
+    // buildOpticalFlowPyramid: levels while both dims stay > winSize (21)
+    int lw = width, lh = height, nl = 0;
+    size_t off = 0;
+    for (int l = 0; l < FE_MAX_LEVELS; ++l) {
+        d.lw[l] = lw; d.lh[l] = lh;
+        s->level_off[l] = off;
+        off += ((size_t)lw * lh + 255) / 256 * 256;
+        nl = l;
+        const int nw = (lw + 1) / 2, nh = (lh + 1) / 2;
+        if (nw <= 21 || nh <= 21) break;
+        lw = nw; lh = nh;
+    }
+    d.max_level = nl;
+    s->level_off[nl + 1] = off;
+    const size_t per_cam = off, npix = (size_t)width * height;
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(h, hipMalloc((void**)&s->planes[k], per_cam * n_cams));
+        HIPCHK(h, hipMemset(s->planes[k], 0, per_cam * n_cams));
+        s->h_ptrs[k].resize((size_t)(nl + 1) * n_cams);
+        for (int l = 0; l <= nl; ++l)
+            for (int c = 0; c < n_cams; ++c) s->h_ptrs[k][(size_t)l * n_cams + c] = s->planes[k] + (size_t)c * per_cam + s->level_off[l];
+        HIPCHK(h, hipMalloc((void**)&s->d_ptrs[k], sizeof(uint8_t*) * s->h_ptrs[k].size()));
+        HIPCHK(h, hipMemcpy(s->d_ptrs[k], s->h_ptrs[k].data(), sizeof(uint8_t*) * s->h_ptrs[k].size(), hipMemcpyHostToDevice));
+    }
+    d.nblk_eig = ((width + 63) / 64) * ((height + 3) / 4);
+    d.cand_cap = FE_CAND_CAP;
+    HIPCHK(h, hipMalloc((void**)&s->raw, npix * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->lut, (size_t)n_cams * 64 * 256));
+    HIPCHK(h, hipMalloc((void**)&s->mask, npix * n_cams));
+    HIPCHK(h, hipMemset(s->mask, 255, npix * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->status, (size_t)n_cams * max_points));
+    HIPCHK(h, hipMalloc((void**)&s->prev_xy, sizeof(float) * 2 * n_cams * max_points));
+    HIPCHK(h, hipMalloc((void**)&s->next_xy, sizeof(float) * 2 * n_cams * max_points));
+    HIPCHK(h, hipMalloc((void**)&s->err, sizeof(float) * n_cams * max_points));
+    HIPCHK(h, hipMalloc((void**)&s->eig, sizeof(float) * npix * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->blockmax, sizeof(float) * (size_t)d.nblk_eig * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->corners, sizeof(float) * 2 * n_cams * max_points));
+    HIPCHK(h, hipMalloc((void**)&s->npts, sizeof(int) * n_cams));
+    HIPCHK(h, hipMemset(s->npts, 0, sizeof(int) * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->max_corners, sizeof(int) * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->ncorners, sizeof(int) * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->ncand, sizeof(unsigned) * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->keys, sizeof(unsigned long long) * (size_t)FE_CAND_CAP * n_cams));
+    d.raw = s->raw; d.lut = s->lut; d.npts = s->npts; d.prev_xy = s->prev_xy; d.next_xy = s->next_xy; d.status = s->status;
+    d.err = s->err; d.eig = s->eig; d.mask = s->mask; d.blockmax = s->blockmax; d.ncand = s->ncand; d.keys = s->keys;
+    d.max_corners = s->max_corners; d.corners = s->corners; d.ncorners = s->ncorners;
+    s->h_npts.assign(n_cams, 0);
+    s->pushed_once.assign(n_cams, 0);
+    refresh(s);
+    return VG_OK;
+}
+
+extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int stride) {
+    if (!h || !h->fe || !imgs) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    const size_t npix = (size_t)s->W * s->H;
+    for (int c = 0; c < s->cams; ++c) {
+        if (!imgs[c]) { h->err = "vg_fe_upload_frames: every stream needs a frame (batched streams advance together)"; return VG_ERR_BAD_ARG; }
+        HIPCHK(h, hipMemcpy2DAsync(s->raw + (size_t)c * npix, s->W, imgs[c], stride, s->W, s->H, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
+    if (!h || !h->fe) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    const bool first = !s->have_prev;
+    s->flip ^= 1;                                     // previous <- current
+    refresh(s);
+    const FeDev& d = s->d;
+    uint8_t* const* cur0 = s->d_ptrs[s->flip];
+    if (equalize) {
+        if (d.W % 8 || d.H % 8) { h->err = "CLAHE needs width and height divisible by 8"; return VG_ERR_UNSUPPORTED; }
+        const int area = (d.W / 8) * (d.H / 8);
+        int clip = (int)(3.0 * area / 256);
+        clip = clip < 1 ? 1 : clip;
+        hipLaunchKernelGGL(fe_clahe_lut_kernel, dim3(64, d.cams), dim3(256), 0, h->stream, d, clip, 255.f / area);
+        hipLaunchKernelGGL(fe_clahe_apply_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, d.cams), dim3(256), 0, h->stream, d, cur0);
+    } else {
+        hipLaunchKernelGGL(fe_copy_kernel, dim3(256, d.cams), dim3(256), 0, h->stream, d, cur0);
+    }
+    for (int l = 1; l <= d.max_level; ++l) {
+        const int sw = d.lw[l - 1], sh = d.lh[l - 1];
+        hipLaunchKernelGGL(fe_pyrdown_kernel, dim3(((sw + 1) / 2 + 63) / 64, ((sh + 1) / 2 + 3) / 4, d.cams), dim3(256), 0, h->stream,
+                           (const uint8_t* const*)(cur0 + (size_t)(l - 1) * d.cams), cur0 + (size_t)l * d.cams, sw, sh);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (first) {
+        // prev_img = cur_img = forw_img = img on the first frame (feature_tracker.cpp:97-100)
+        const size_t bytes = s->level_off[d.max_level + 1] * d.cams;
+        HIPCHK(h, hipMemcpyAsync(s->planes[s->flip ^ 1], s->planes[s->flip], bytes, hipMemcpyDeviceToDevice, h->stream));
+        s->have_prev = true;
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_fe_push_frames(vg_handle* h, const uint8_t* const* imgs, int stride, int equalize) {
+    int rc = vg_fe_upload_frames(h, imgs, stride);
+    if (rc) return rc;
+    rc = vg_fe_build_async(h, equalize);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_fe_track_upload(vg_handle* h, const float* prev_xy, const int* n) {
+    if (!h || !h->fe || !prev_xy || !n) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    for (int c = 0; c < s->cams; ++c) {
+        if (n[c] < 0 || n[c] > s->max_pts) { h->err = "point count out of range"; return VG_ERR_BAD_ARG; }
+        s->h_npts[c] = n[c];
+    }
+    HIPCHK(h, hipMemcpyAsync(s->prev_xy, prev_xy, sizeof(float) * 2 * s->cams * s->max_pts, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s->npts, n, sizeof(int) * s->cams, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_fe_track_async(vg_handle* h) {
+    if (!h || !h->fe) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    int nmax = 0;
+    for (int c = 0; c < s->cams; ++c) nmax = nmax > s->h_npts[c] ? nmax : s->h_npts[c];
+    if (nmax == 0) return VG_OK;
+    hipLaunchKernelGGL(fe_lk_kernel, dim3(nmax, s->cams), dim3(64), 0, h->stream, s->d);
+    HIPCHK(h, hipGetLastError());
+    return VG_OK;
+}
+
+extern "C" int vg_fe_track_download(vg_handle* h, float* next_xy, uint8_t* status, float* err) {
+    if (!h || !h->fe) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    const size_t n = (size_t)s->cams * s->max_pts;
+    if (next_xy) HIPCHK(h, hipMemcpyAsync(next_xy, s->next_xy, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
+    if (status) HIPCHK(h, hipMemcpyAsync(status, s->status, n, hipMemcpyDeviceToHost, h->stream));
+    if (err) HIPCHK(h, hipMemcpyAsync(err, s->err, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_fe_track(vg_handle* h, int cam, const float* prev_xy, int n, float* next_xy, uint8_t* status, float* err) {
+    if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || n < 0 || n > h->fe->max_pts || (n && (!prev_xy || !next_xy || !status)))
+        return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    if (n == 0) return VG_OK;
+    const size_t o = (size_t)cam * s->max_pts;
+    std::vector<int> saved = s->h_npts;
+    for (int c = 0; c < s->cams; ++c) s->h_npts[c] = (c == cam) ? n : 0;
+    HIPCHK(h, hipMemcpyAsync(s->prev_xy + o * 2, prev_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s->npts, s->h_npts.data(), sizeof(int) * s->cams, hipMemcpyHostToDevice, h->stream));
+    int rc = vg_fe_track_async(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(next_xy, s->next_xy + o * 2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(status, s->status + o, n, hipMemcpyDeviceToHost, h->stream));
+    if (err) HIPCHK(h, hipMemcpyAsync(err, s->err + o, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_fe_detect_upload(vg_handle* h, const uint8_t* const* masks, const int* max_corners) {
+    if (!h || !h->fe || !max_corners) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    const size_t npix = (size_t)s->W * s->H;
+    for (int c = 0; c < s->cams; ++c) {
+        if (max_corners[c] < 0 || max_corners[c] > s->max_pts) { h->err = "max_corners out of range"; return VG_ERR_BAD_ARG; }
+        if (masks && masks[c]) HIPCHK(h, hipMemcpyAsync(s->mask + (size_t)c * npix, masks[c], npix, hipMemcpyHostToDevice, h->stream));
+        else HIPCHK(h, hipMemsetAsync(s->mask + (size_t)c * npix, 255, npix, h->stream));
+    }
+    HIPCHK(h, hipMemcpyAsync(s->max_corners, max_corners, sizeof(int) * s->cams, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_fe_detect_async(vg_handle* h, double quality, double min_dist) {
+    if (!h || !h->fe) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    const FeDev& d = s->d;
+    const int cell = (int)std::lrint(min_dist) < 1 ? 1 : (int)std::lrint(min_dist);
+    if (((d.W + cell - 1) / cell) * ((d.H + cell - 1) / cell) > FE_MAX_CELLS) { h->err = "min_dist too small for the cell grid"; return VG_ERR_UNSUPPORTED; }
+    HIPCHK(h, hipMemsetAsync(s->ncand, 0, sizeof(unsigned) * d.cams, h->stream));
+    const dim3 g((d.W + 63) / 64, (d.H + 3) / 4, d.cams);
+    hipLaunchKernelGGL(fe_mineig_kernel, g, dim3(256), 0, h->stream, d);
+    hipLaunchKernelGGL(fe_candidates_kernel, g, dim3(256), 0, h->stream, d, quality);
+    hipLaunchKernelGGL(fe_sort_kernel, dim3(d.cams), dim3(1024), 0, h->stream, d);
+    hipLaunchKernelGGL(fe_mindist_kernel, dim3(d.cams), dim3(64), 0, h->stream, d, (float)min_dist);
+    HIPCHK(h, hipGetLastError());
+    return VG_OK;
+}
+
+extern "C" int vg_fe_detect_download(vg_handle* h, float* out_xy, int* out_n) {
+    if (!h || !h->fe || !out_xy || !out_n) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    HIPCHK(h, hipMemcpyAsync(out_xy, s->corners, sizeof(float) * 2 * s->cams * s->max_pts, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out_n, s->ncorners, sizeof(int) * s->cams, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_fe_detect(vg_handle* h, int cam, const uint8_t* mask, int max_corners, double quality, double min_dist,
+                            float* out_xy, int* out_n) {
+    if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || !out_xy || !out_n || max_corners < 0 || max_corners > h->fe->max_pts)
+        return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    *out_n = 0;
+    if (max_corners == 0) return VG_OK;
+    const size_t npix = (size_t)s->W * s->H;
+    std::vector<int> mc(s->cams, 0);
+    mc[cam] = max_corners;
+    if (mask) HIPCHK(h, hipMemcpyAsync(s->mask + (size_t)cam * npix, mask, npix, hipMemcpyHostToDevice, h->stream));
+    else HIPCHK(h, hipMemsetAsync(s->mask + (size_t)cam * npix, 255, npix, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s->max_corners, mc.data(), sizeof(int) * s->cams, hipMemcpyHostToDevice, h->stream));
+    int rc = vg_fe_detect_async(h, quality, min_dist);
+    if (rc) return rc;
+    int n = 0;
+    HIPCHK(h, hipMemcpyAsync(&n, s->ncorners + cam, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n > 0) HIPCHK(h, hipMemcpy(out_xy, s->corners + (size_t)cam * s->max_pts * 2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
+    *out_n = n;
+    return VG_OK;
+}
+
+extern "C" int vg_fe_get_level(vg_handle* h, int cam, int which, int level, uint8_t* out, int* w, int* hgt) {
+    if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || level < 0 || level > h->fe->d.max_level || !out) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    const int set = which ? (s->flip ^ 1) : s->flip;
+    const int lw = s->d.lw[level], lh = s->d.lh[level];
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, s->h_ptrs[set][(size_t)level * s->cams + cam], (size_t)lw * lh, hipMemcpyDeviceToHost));
+    if (w) *w = lw;
+    if (hgt) *hgt = lh;
+    return VG_OK;
+}
+
+extern "C" int vg_fe_get_eig(vg_handle* h, int cam, float* out) {
+    if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || !out) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, s->eig + (size_t)cam * s->W * s->H, sizeof(float) * s->W * s->H, hipMemcpyDeviceToHost));
+    return VG_OK;
+}

@@ -1,0 +1,481 @@
+// fe_kernels.hip — feature_tracker front end on gfx950: the arithmetic under FeatureTracker::readImage
+// (feature_tracker/src/feature_tracker.cpp:81-167), i.e. what the reference delegates to OpenCV:
+//   CLAHE (call site :87-93), calcOpticalFlowPyrLK (:113: pyrDown pyramid, Scharr derivative, LK iterations),
+//   goodFeaturesToTrack (:149: Sobel min-eigenvalue map, threshold + 3x3 NMS, sort, min-distance selection).
+// OpenCV is third-party and absent: algorithms restated as recorded in oracle/ASSUMPTIONS.md.
+//
+// All integer paths are bit-exact by construction; the float32 paths evaluate the same IEEE expressions in the same
+// order as oracle/fe_cpu.cpp (this file is compiled with -ffp-contract=off and correctly rounded sqrt / divide), so
+// corner lists, LK status AND positions are bit-identical to the oracle.
+//
+// Layout: one image plane per (camera, pyramid level), row-major u8, rows contiguous (coalesced row segments);
+// LK: ONE WAVEFRONT PER TRACK (block = 64 threads), the 24x24 template neighbourhood, its 22x22 Scharr field, the
+// 21x21 template / gradient patches and the 22x22 search window live in LDS (~5.6 KB per track).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fe_layout.h"
+
+#define FDEV __device__ __forceinline__
+
+FDEV int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+FDEV int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+FDEV int cv_round(float v) { return __float2int_rn(v); }
+FDEV int cv_floor(float v) { return (int)floorf(v); }
+// monotone map float -> unsigned (total order incl. negatives)
+FDEV unsigned ford(float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+FDEV float funord(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+// ================================================================================================ CLAHE
+// grid (64 tiles, cams), block 256: per-tile histogram -> clip / redistribute -> LUT (clahe.cpp CLAHE_CalcLut_Body)
+extern "C" __global__ __launch_bounds__(256) void fe_clahe_lut_kernel(FeDev d, int clip_limit, float lut_scale) {
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    const int cam = blockIdx.y, tile = blockIdx.x, tx = tile % 8, ty = tile / 8;
+    const int tw = d.W / 8, th = d.H / 8;
+    const uint8_t* src = d.raw + (size_t)cam * d.W * d.H;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < tw * th; k += 256) {
+        const int y = k / tw, x = k % tw;
+        atomicAdd(&hist[src[(size_t)(ty * th + y) * d.W + tx * tw + x]], 1);
+    }
+    __syncthreads();
+    // clipped excess
+    int hv = hist[threadIdx.x];
+    int ex = hv > clip_limit ? hv - clip_limit : 0;
+    hv = hv > clip_limit ? clip_limit : hv;
+    scan[threadIdx.x] = ex;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) scan[threadIdx.x] += scan[threadIdx.x + o]; __syncthreads(); }
+    const int clipped = scan[0];
+    __syncthreads();
+    const int batch = clipped / 256;
+    const int residual = clipped - batch * 256;
+    hv += batch;
+    if (residual != 0) {
+        const int step = 256 / residual > 1 ? 256 / residual : 1;
+        // for (i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++
+        if ((int)threadIdx.x % step == 0 && (int)threadIdx.x / step < residual) hv += 1;
+    }
+    // inclusive scan -> LUT
+    scan[threadIdx.x] = hv;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = (int)threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int lv = cv_round((float)scan[threadIdx.x] * lut_scale);
+    lv = lv < 0 ? 0 : (lv > 255 ? 255 : lv);
+    d.lut[((size_t)cam * 64 + tile) * 256 + threadIdx.x] = (uint8_t)lv;
+}
+
+// per-pixel bilinear blend of the four tile LUTs (CLAHE_Interpolation_Body); writes pyramid level 0 of `cur`
+extern "C" __global__ __launch_bounds__(256) void fe_clahe_apply_kernel(FeDev d, uint8_t* const* dst_planes) {
+    const int cam = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= d.W || y >= d.H) return;
+    const int tw = d.W / 8, th = d.H / 8;
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    const float tyf = y * inv_th - 0.5f;
+    int ty1 = cv_floor(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = ty1 < 0 ? 0 : ty1; ty2 = ty2 > 7 ? 7 : ty2;
+    const float txf = x * inv_tw - 0.5f;
+    int tx1 = cv_floor(txf), tx2 = tx1 + 1;
+    const float xa = txf - tx1, xa1 = 1.0f - xa;
+    tx1 = tx1 < 0 ? 0 : tx1; tx2 = tx2 > 7 ? 7 : tx2;
+    const int v = d.raw[(size_t)cam * d.W * d.H + (size_t)y * d.W + x];
+    const uint8_t* lut = d.lut + (size_t)cam * 64 * 256;
+    const float l11 = lut[(ty1 * 8 + tx1) * 256 + v], l12 = lut[(ty1 * 8 + tx2) * 256 + v];
+    const float l21 = lut[(ty2 * 8 + tx1) * 256 + v], l22 = lut[(ty2 * 8 + tx2) * 256 + v];
+    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    int o = cv_round(res);
+    o = o < 0 ? 0 : (o > 255 ? 255 : o);
+    dst_planes[cam][(size_t)y * d.W + x] = (uint8_t)o;
+}
+
+extern "C" __global__ __launch_bounds__(256) void fe_copy_kernel(FeDev d, uint8_t* const* dst_planes) {
+    const int cam = blockIdx.y;
+    const size_t n = (size_t)d.W * d.H;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n / 4; k += (size_t)gridDim.x * 256)
+        ((uint32_t*)dst_planes[cam])[k] = ((const uint32_t*)(d.raw + (size_t)cam * n))[k];
+}
+
+// ================================================================================================ pyrDown
+// thread per output pixel; [1 4 6 4 1] x [1 4 6 4 1], BORDER_REFLECT_101, (sum + 128) >> 8  (pyramids.cpp)
+extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh) {
+    const int cam = blockIdx.z;
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const uint8_t* s = src_planes[cam];
+    int xs[5], acc = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, sw);
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        const uint8_t* r = s + (size_t)reflect101(2 * y - 2 + v, sh) * sw;
+        const int row = r[xs[0]] + 4 * r[xs[1]] + 6 * r[xs[2]] + 4 * r[xs[3]] + r[xs[4]];
+        acc += (v == 0 || v == 4) ? row : ((v == 2) ? 6 * row : 4 * row);
+    }
+    dst_planes[cam][(size_t)y * dw + x] = (uint8_t)((acc + 128) >> 8);
+}
+
+// ================================================================================================ LK
+#define LK_WIN 21
+#define LK_WBITS 14
+
+struct LkLds {
+    uint8_t ipatch[24 * 24];        // template neighbourhood (reflect-101), origin (ipx-1, ipy-1)
+    int16_t der[22 * 22 * 2];       // Scharr (Ix, Iy) at (ipx + 0..21, ipy + 0..21), 0 outside the image
+    int16_t ibuf[LK_WIN * LK_WIN];  // template I (x32)
+    int16_t dibuf[LK_WIN * LK_WIN * 2];
+    uint8_t jpatch[22 * 22];        // search window (reflect-101), origin (inx, iny)
+};
+
+FDEV long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return __shfl(v, 0, 64);
+}
+
+FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+    w00 = cv_round((1.f - a) * (1.f - b) * (float)(1 << LK_WBITS));
+    w01 = cv_round(a * (1.f - b) * (float)(1 << LK_WBITS));
+    w10 = cv_round((1.f - a) * b * (float)(1 << LK_WBITS));
+    w11 = (1 << LK_WBITS) - w00 - w01 - w10;
+}
+
+// grid (max_points, cams), block 64 (one wavefront = one track).  LKTrackerInvoker, levels max_level .. 0.
+extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
+    __shared__ LkLds s;
+    const int cam = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+    if (t >= d.npts[cam]) return;
+    const float px = d.prev_xy[((size_t)cam * d.max_pts + t) * 2], py = d.prev_xy[((size_t)cam * d.max_pts + t) * 2 + 1];
+    float nx = 0.f, ny = 0.f, err = 0.f;
+    int status = 1;
+    const float half = (LK_WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    for (int level = d.max_level; level >= 0; --level) {
+        const int lw = d.lw[level], lh = d.lh[level];
+        const uint8_t* I = d.prev_planes[level * d.cams + cam];
+        const uint8_t* J = d.cur_planes[level * d.cams + cam];
+        float prevx = px * (float)(1. / (1 << level)), prevy = py * (float)(1. / (1 << level));
+        float nextx, nexty;
+        if (level == d.max_level) { nextx = prevx; nexty = prevy; }
+        else { nextx = nx * 2.f; nexty = ny * 2.f; }
+        nx = nextx; ny = nexty;
+        prevx -= half; prevy -= half;
+        const int ipx = cv_floor(prevx), ipy = cv_floor(prevy);
+        if (ipx < -LK_WIN || ipx >= lw || ipy < -LK_WIN || ipy >= lh) {
+            if (level == 0) { status = 0; err = 0.f; }
+            continue;
+        }
+        int w00, w01, w10, w11;
+        lk_weights(prevx - ipx, prevy - ipy, w00, w01, w10, w11);
+        __syncthreads();
+        // 24x24 neighbourhood of the template window
+        for (int k = lane; k < 24 * 24; k += 64) {
+            const int yy = k / 24, xx = k % 24;
+            s.ipatch[k] = I[(size_t)reflect101(ipy - 1 + yy, lh) * lw + reflect101(ipx - 1 + xx, lw)];
+        }
+        __syncthreads();
+        // Scharr field on the 22x22 integer positions (calcSharrDeriv; constant-0 border outside the image).
+        // NB the x+-1 / y+-1 taps reflect at the IMAGE edge, which is what the reflect-101 patch holds.
+        for (int k = lane; k < 22 * 22; k += 64) {
+            const int yy = k / 22, xx = k % 22;
+            const int X = ipx + xx, Y = ipy + yy;
+            int ix = 0, iy = 0;
+            if (X >= 0 && X < lw && Y >= 0 && Y < lh) {
+                const uint8_t* p = s.ipatch + (yy + 1) * 24 + (xx + 1);
+                const int t0m = 3 * (p[-24 - 1] + p[24 - 1]) + 10 * p[-1];
+                const int t0p = 3 * (p[-24 + 1] + p[24 + 1]) + 10 * p[1];
+                const int t1m = p[24 - 1] - p[-24 - 1], t1c = p[24] - p[-24], t1p = p[24 + 1] - p[-24 + 1];
+                ix = t0p - t0m;
+                iy = 3 * (t1m + t1p) + 10 * t1c;
+            }
+            s.der[k * 2] = (int16_t)ix; s.der[k * 2 + 1] = (int16_t)iy;
+        }
+        __syncthreads();
+        long long a11 = 0, a12 = 0, a22 = 0;
+        for (int k = lane; k < LK_WIN * LK_WIN; k += 64) {
+            const int y = k / LK_WIN, x = k % LK_WIN;
+            const uint8_t* p = s.ipatch + (y + 1) * 24 + (x + 1);
+            const int ival = descale(p[0] * w00 + p[1] * w01 + p[24] * w10 + p[25] * w11, LK_WBITS - 5);
+            const int16_t* q = s.der + (y * 22 + x) * 2;
+            const int ixval = descale(q[0] * w00 + q[2] * w01 + q[44] * w10 + q[46] * w11, LK_WBITS);
+            const int iyval = descale(q[1] * w00 + q[3] * w01 + q[45] * w10 + q[47] * w11, LK_WBITS);
+            s.ibuf[k] = (int16_t)ival; s.dibuf[k * 2] = (int16_t)ixval; s.dibuf[k * 2 + 1] = (int16_t)iyval;
+            a11 += (long long)ixval * ixval; a12 += (long long)ixval * iyval; a22 += (long long)iyval * iyval;
+        }
+        a11 = wave_sum_ll(a11); a12 = wave_sum_ll(a12); a22 = wave_sum_ll(a22);
+        const float A11 = (float)a11 * FLT_SCALE, A12 = (float)a12 * FLT_SCALE, A22 = (float)a22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * LK_WIN * LK_WIN);
+        if (minEig < d.min_eig_thr || D < 1.1920929e-07f) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nextx -= half; nexty -= half;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < d.max_count; ++j) {
+            const int inx = cv_floor(nextx), iny = cv_floor(nexty);
+            if (inx < -LK_WIN || inx >= lw || iny < -LK_WIN || iny >= lh) {
+                if (level == 0) status = 0;
+                break;
+            }
+            int r00, r01, r10, r11;
+            lk_weights(nextx - inx, nexty - iny, r00, r01, r10, r11);
+            __syncthreads();
+            for (int k = lane; k < 22 * 22; k += 64) {
+                const int yy = k / 22, xx = k % 22;
+                s.jpatch[k] = J[(size_t)reflect101(iny + yy, lh) * lw + reflect101(inx + xx, lw)];
+            }
+            __syncthreads();
+            long long b1 = 0, b2 = 0;
+            for (int k = lane; k < LK_WIN * LK_WIN; k += 64) {
+                const int y = k / LK_WIN, x = k % LK_WIN;
+                const uint8_t* p = s.jpatch + y * 22 + x;
+                const int diff = descale(p[0] * r00 + p[1] * r01 + p[22] * r10 + p[23] * r11, LK_WBITS - 5) - s.ibuf[k];
+                b1 += (long long)diff * s.dibuf[k * 2]; b2 += (long long)diff * s.dibuf[k * 2 + 1];
+            }
+            b1 = wave_sum_ll(b1); b2 = wave_sum_ll(b2);
+            const float fb1 = (float)b1 * FLT_SCALE, fb2 = (float)b2 * FLT_SCALE;
+            const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
+            nextx += dx; nexty += dy;
+            nx = nextx + half; ny = nexty + half;
+            if ((double)dx * dx + (double)dy * dy <= d.eps2) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                nx -= dx * 0.5f; ny -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (status && level == 0) {
+            const float ex = nx - half, ey = ny - half;
+            const int inx = cv_floor(ex), iny = cv_floor(ey);
+            if (inx < -LK_WIN || inx >= lw || iny < -LK_WIN || iny >= lh) { status = 0; continue; }
+            int r00, r01, r10, r11;
+            lk_weights(ex - inx, ey - iny, r00, r01, r10, r11);
+            __syncthreads();
+            for (int k = lane; k < 22 * 22; k += 64) {
+                const int yy = k / 22, xx = k % 22;
+                s.jpatch[k] = J[(size_t)reflect101(iny + yy, lh) * lw + reflect101(inx + xx, lw)];
+            }
+            __syncthreads();
+            long long e = 0;
+            for (int k = lane; k < LK_WIN * LK_WIN; k += 64) {
+                const int y = k / LK_WIN, x = k % LK_WIN;
+                const uint8_t* p = s.jpatch + y * 22 + x;
+                const int diff = descale(p[0] * r00 + p[1] * r01 + p[22] * r10 + p[23] * r11, LK_WBITS - 5) - s.ibuf[k];
+                e += diff < 0 ? -diff : diff;
+            }
+            e = wave_sum_ll(e);
+            err = (float)e * (1.f / (32 * LK_WIN * LK_WIN));
+        }
+    }
+    if (lane == 0) {
+        const size_t o = (size_t)cam * d.max_pts + t;
+        d.next_xy[o * 2] = nx; d.next_xy[o * 2 + 1] = ny;
+        d.status[o] = (uint8_t)status;
+        d.err[o] = err;
+    }
+}
+
+// ================================================================================================ GFTT
+// min-eigenvalue map (corner.cpp cornerMinEigenVal, blockSize 3, Sobel 3): tile 64x4 + halo 2 in LDS.
+// Also the masked per-block maximum for minMaxLoc.
+extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d) {
+    __shared__ uint8_t tile[8][68];          // rows y-2 .. y+5, cols x-2 .. x+65
+    __shared__ float gx[6][66], gy[6][66];   // gradients on rows y-1 .. y+4, cols x-1 .. x+64
+    __shared__ float bmax[4];
+    const int cam = blockIdx.z, W = d.W, H = d.H;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    const uint8_t* img = d.cur_planes[cam];          // level 0
+    for (int k = threadIdx.x; k < 8 * 68; k += 256) {
+        const int yy = k / 68, xx = k % 68;
+        // NB: REFLECT_101 is applied per filter stage in OpenCV (Sobel on the image, then boxFilter on cov); the halo
+        // below holds image pixels at reflected coordinates, gradients are evaluated at reflected positions too.
+        tile[yy][xx] = img[(size_t)reflect101(y0 - 2 + yy, H) * W + reflect101(x0 - 2 + xx, W)];
+    }
+    __syncthreads();
+    const float k1 = (float)(1.0 / 3060.0), k2 = (float)(2.0 / 3060.0);
+    // gradients at (y0-1+gy_, x0-1+gx_): position may lie outside the image -> the boxFilter's reflect-101 wants the
+    // gradient AT THE REFLECTED POSITION, which is not the gradient computed from reflected pixels; handled below by
+    // recomputing from global memory for those few halo positions.
+    for (int k = threadIdx.x; k < 6 * 66; k += 256) {
+        const int yy = k / 66, xx = k % 66;
+        int Y = y0 - 1 + yy, X = x0 - 1 + xx;
+        float dxv, dyv;
+        const int Yr = reflect101(Y, H), Xr = reflect101(X, W);
+        if (Yr == Y && Xr == X) {
+            const uint8_t(*t)[68] = tile;
+            const int ty = yy + 1, tx = xx + 1;       // tile index of (Y, X)
+            const float r0 = (float)(t[ty - 1][tx + 1] - t[ty - 1][tx - 1]);
+            const float r1 = (float)(t[ty][tx + 1] - t[ty][tx - 1]);
+            const float r2 = (float)(t[ty + 1][tx + 1] - t[ty + 1][tx - 1]);
+            dxv = k2 * r1 + k1 * (r0 + r2);
+            const float s0 = (float)t[ty - 1][tx] * k2 + (float)(t[ty - 1][tx - 1] + t[ty - 1][tx + 1]) * k1;
+            const float s2 = (float)t[ty + 1][tx] * k2 + (float)(t[ty + 1][tx - 1] + t[ty + 1][tx + 1]) * k1;
+            dyv = s2 - s0;
+        } else {
+            // gradient at the reflected (in-image) position, from global memory
+            auto P = [&](int y, int x) { return (int)img[(size_t)reflect101(y, H) * W + reflect101(x, W)]; };
+            Y = Yr; X = Xr;
+            const float r0 = (float)(P(Y - 1, X + 1) - P(Y - 1, X - 1));
+            const float r1 = (float)(P(Y, X + 1) - P(Y, X - 1));
+            const float r2 = (float)(P(Y + 1, X + 1) - P(Y + 1, X - 1));
+            dxv = k2 * r1 + k1 * (r0 + r2);
+            const float s0 = (float)P(Y - 1, X) * k2 + (float)(P(Y - 1, X - 1) + P(Y - 1, X + 1)) * k1;
+            const float s2 = (float)P(Y + 1, X) * k2 + (float)(P(Y + 1, X - 1) + P(Y + 1, X + 1)) * k1;
+            dyv = s2 - s0;
+        }
+        gx[yy][xx] = dxv; gy[yy][xx] = dyv;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = x0 + lx, y = y0 + ly;
+    float val = -1.f;
+    bool inimg = x < W && y < H;
+    if (inimg) {
+        double sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const float a = gx[ly + v][lx + u], b = gy[ly + v][lx + u];
+                sxx += (double)(a * a); sxy += (double)(a * b); syy += (double)(b * b);
+            }
+        const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+        val = (float)((a + c) - sqrtf((a - c) * (a - c) + b * b));
+        d.eig[(size_t)cam * W * H + (size_t)y * W + x] = val;
+    }
+    // masked maximum of this block
+    const uint8_t* mask = d.mask + (size_t)cam * W * H;
+    float m = (inimg && mask[(size_t)y * W + x]) ? val : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) bmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        d.blockmax[(size_t)cam * d.nblk_eig + blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(bmax[0], bmax[1]), fmaxf(bmax[2], bmax[3]));
+}
+
+// threshold (THRESH_TOZERO at maxVal*quality) + 3x3 dilate equality + mask -> candidate keys
+// key = (ordered float bits << 32) | linear index   (sort descending = value desc, then index desc)
+extern "C" __global__ __launch_bounds__(256) void fe_candidates_kernel(FeDev d, double quality) {
+    __shared__ unsigned smax;
+    const int cam = blockIdx.z, W = d.W, H = d.H;
+    if (threadIdx.x == 0) smax = 0u;
+    __syncthreads();
+    {
+        float m = -INFINITY;
+        for (int k = threadIdx.x; k < d.nblk_eig; k += 256) m = fmaxf(m, d.blockmax[(size_t)cam * d.nblk_eig + k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&smax, ford(m));
+    }
+    __syncthreads();
+    const float mf = funord(smax);
+    // minMaxLoc over an empty mask leaves maxVal = 0 in the reference
+    const double maxVal = (mf == -INFINITY) ? 0.0 : (double)mf;
+    const float thr = (float)(maxVal * quality);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < 1 || y < 1 || x >= W - 1 || y >= H - 1) return;
+    const float* e = d.eig + (size_t)cam * W * H;
+    const float raw = e[(size_t)y * W + x];
+    const float val = raw > thr ? raw : 0.f;
+    if (val == 0.f || !d.mask[(size_t)cam * W * H + (size_t)y * W + x]) return;
+    float mx = val;
+#pragma unroll
+    for (int v = -1; v <= 1; ++v)
+#pragma unroll
+        for (int u = -1; u <= 1; ++u) {
+            const float o = e[(size_t)(y + v) * W + x + u];
+            mx = fmaxf(mx, o > thr ? o : 0.f);
+        }
+    if (val != mx) return;
+    const unsigned slot = atomicAdd(&d.ncand[cam], 1u);
+    if (slot < (unsigned)d.cand_cap)
+        d.keys[(size_t)cam * d.cand_cap + slot] = ((unsigned long long)ford(val) << 32) | (unsigned)(y * W + x);
+}
+
+// one workgroup (1024 threads) per camera: in-place bitonic sort (descending) of the candidate keys, padded with 0
+extern "C" __global__ __launch_bounds__(1024) void fe_sort_kernel(FeDev d) {
+    const int cam = blockIdx.x;
+    unsigned long long* k = d.keys + (size_t)cam * d.cand_cap;
+    unsigned n = d.ncand[cam];
+    if (n > (unsigned)d.cand_cap) n = d.cand_cap;
+    unsigned np = 1;
+    while (np < n) np <<= 1;
+    for (unsigned i = n + threadIdx.x; i < np; i += 1024) k[i] = 0ull;
+    __syncthreads();
+    for (unsigned size = 2; size <= np; size <<= 1)
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned t = threadIdx.x; t < np / 2; t += 1024) {
+                const unsigned lo = 2 * t - (t & (stride - 1));      // index with bit `stride` cleared
+                const unsigned hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = k[lo], b = k[hi];
+                if ((a < b) == desc) { k[lo] = b; k[hi] = a; }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+}
+
+// one wavefront per camera: the sequential min-distance selection of goodFeaturesToTrack, candidates in sorted
+// order; a 3x3 cell neighbourhood is checked by 9 x 7 lanes at once (cells hold at most 7 corners: they are
+// >= cell apart).  Output: integer pixel coordinates as floats, in acceptance order.
+extern "C" __global__ __launch_bounds__(64) void fe_mindist_kernel(FeDev d, float min_dist) {
+    __shared__ unsigned short cellxy[FE_MAX_CELLS][7][2];
+    __shared__ unsigned char cellcnt[FE_MAX_CELLS];
+    const int cam = blockIdx.x, lane = threadIdx.x, W = d.W, H = d.H;
+    const int maxc = d.max_corners[cam];
+    const int cell = __float2int_rn(min_dist) < 1 ? 1 : __float2int_rn(min_dist);
+    const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
+    for (int k = lane; k < gw * gh; k += 64) cellcnt[k] = 0;
+    __syncthreads();
+    unsigned n = d.ncand[cam];
+    if (n > (unsigned)d.cand_cap) n = d.cand_cap;
+    const unsigned long long* keys = d.keys + (size_t)cam * d.cand_cap;
+    const double md2 = (double)min_dist * (double)min_dist;
+    int nacc = 0;
+    const bool use_dist = min_dist >= 1.f;
+    for (unsigned base = 0; base < n && nacc < maxc; base += 64) {
+        const unsigned long long mykey = (base + lane < n) ? keys[base + lane] : 0ull;
+        const int cnt = (n - base) < 64u ? (int)(n - base) : 64;
+        for (int j = 0; j < cnt && nacc < maxc; ++j) {
+            const unsigned idx = (unsigned)__shfl(mykey, j, 64);
+            const int y = idx / W, x = idx % W;
+            const int xc = x / cell, yc = y / cell;
+            bool bad = false;
+            if (use_dist && lane < 63) {
+                const int nb = lane / 7, slot = lane % 7;          // 9 neighbour cells x 7 slots
+                const int cx = xc - 1 + nb % 3, cy = yc - 1 + nb / 3;
+                if (cx >= 0 && cy >= 0 && cx < gw && cy < gh) {
+                    const int c = cy * gw + cx;
+                    if (slot < cellcnt[c]) {
+                        const float dx = (float)(x - (int)cellxy[c][slot][0]), dy = (float)(y - (int)cellxy[c][slot][1]);
+                        bad = (double)(dx * dx + dy * dy) < md2;
+                    }
+                }
+            }
+            if (!__any(bad)) {
+                if (lane == 0) {
+                    const int c = yc * gw + xc;
+                    const int k = cellcnt[c];
+                    if (k < 7) { cellxy[c][k][0] = (unsigned short)x; cellxy[c][k][1] = (unsigned short)y; cellcnt[c] = (unsigned char)(k + 1); }
+                    float* o = d.corners + ((size_t)cam * d.max_pts + nacc) * 2;
+                    o[0] = (float)x; o[1] = (float)y;
+                }
+                ++nacc;
+                __syncthreads();
+            }
+        }
+    }
+    if (lane == 0) d.ncorners[cam] = nacc;
+}

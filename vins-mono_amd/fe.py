@@ -1,0 +1,110 @@
+"""ctypes binding of the front-end entry points of include/vinsgpu.h (vg_fe_*); no arithmetic lives here."""
+import ctypes as C
+
+import numpy as np
+
+_u8 = C.POINTER(C.c_uint8)
+_f4 = C.POINTER(C.c_float)
+_i4 = C.POINTER(C.c_int)
+
+
+class FrontEnd:
+    """`n_cams` camera streams on one vg_handle (ba.Handle)."""
+
+    def __init__(self, handle, width, height, n_cams=1, max_points=150):
+        self.hd, self.lib, self.h = handle, handle.lib, handle.h
+        self.W, self.H, self.cams, self.max_pts = width, height, n_cams, max_points
+        L = self.lib
+        L.vg_fe_configure.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.vg_fe_push_frames.argtypes = [C.c_void_p, C.POINTER(_u8), C.c_int, C.c_int]
+        L.vg_fe_upload_frames.argtypes = [C.c_void_p, C.POINTER(_u8), C.c_int]
+        L.vg_fe_build_async.argtypes = [C.c_void_p, C.c_int]
+        L.vg_fe_track.argtypes = [C.c_void_p, C.c_int, _f4, C.c_int, _f4, _u8, _f4]
+        L.vg_fe_track_upload.argtypes = [C.c_void_p, _f4, _i4]
+        L.vg_fe_track_async.argtypes = [C.c_void_p]
+        L.vg_fe_track_download.argtypes = [C.c_void_p, _f4, _u8, _f4]
+        L.vg_fe_detect.argtypes = [C.c_void_p, C.c_int, _u8, C.c_int, C.c_double, C.c_double, _f4, _i4]
+        L.vg_fe_detect_upload.argtypes = [C.c_void_p, C.POINTER(_u8), _i4]
+        L.vg_fe_detect_async.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.vg_fe_detect_download.argtypes = [C.c_void_p, _f4, _i4]
+        L.vg_fe_get_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8, _i4, _i4]
+        L.vg_fe_get_eig.argtypes = [C.c_void_p, C.c_int, _f4]
+        self.hd._chk(L.vg_fe_configure(self.h, width, height, n_cams, max_points), "vg_fe_configure")
+
+    def _imgs(self, frames):
+        self._keep = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        assert len(self._keep) == self.cams and all(f.shape == (self.H, self.W) for f in self._keep)
+        return (_u8 * self.cams)(*[f.ctypes.data_as(_u8) for f in self._keep])
+
+    def push_frames(self, frames, equalize=False):
+        self.hd._chk(self.lib.vg_fe_push_frames(self.h, self._imgs(frames), self.W, int(equalize)), "vg_fe_push_frames")
+
+    def upload_frames(self, frames):
+        self.hd._chk(self.lib.vg_fe_upload_frames(self.h, self._imgs(frames), self.W), "vg_fe_upload_frames")
+
+    def build_async(self, equalize=False):
+        self.hd._chk(self.lib.vg_fe_build_async(self.h, int(equalize)), "vg_fe_build_async")
+
+    def track(self, cam, pts):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        n = pts.shape[0]
+        out, st, err = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8), np.zeros(n, np.float32)
+        self.hd._chk(self.lib.vg_fe_track(self.h, cam, pts.ctypes.data_as(_f4), n, out.ctypes.data_as(_f4), st.ctypes.data_as(_u8),
+                                          err.ctypes.data_as(_f4)), "vg_fe_track")
+        return out, st, err
+
+    def track_upload(self, pts_list):
+        buf = np.zeros((self.cams, self.max_pts, 2), np.float32)
+        n = np.zeros(self.cams, np.int32)
+        for c, p in enumerate(pts_list):
+            p = np.asarray(p, np.float32).reshape(-1, 2)
+            buf[c, :p.shape[0]] = p
+            n[c] = p.shape[0]
+        self._n = n
+        self.hd._chk(self.lib.vg_fe_track_upload(self.h, buf.ctypes.data_as(_f4), n.ctypes.data_as(_i4)), "vg_fe_track_upload")
+
+    def track_async(self):
+        self.hd._chk(self.lib.vg_fe_track_async(self.h), "vg_fe_track_async")
+
+    def track_download(self):
+        out = np.zeros((self.cams, self.max_pts, 2), np.float32)
+        st = np.zeros((self.cams, self.max_pts), np.uint8)
+        err = np.zeros((self.cams, self.max_pts), np.float32)
+        self.hd._chk(self.lib.vg_fe_track_download(self.h, out.ctypes.data_as(_f4), st.ctypes.data_as(_u8), err.ctypes.data_as(_f4)), "vg_fe_track_download")
+        return [(out[c, :self._n[c]], st[c, :self._n[c]], err[c, :self._n[c]]) for c in range(self.cams)]
+
+    def detect(self, cam, max_corners, quality=0.01, min_dist=30.0, mask=None):
+        out = np.zeros((max(max_corners, 1), 2), np.float32)
+        n = C.c_int(0)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.hd._chk(self.lib.vg_fe_detect(self.h, cam, m.ctypes.data_as(_u8) if m is not None else None, int(max_corners), float(quality),
+                                           float(min_dist), out.ctypes.data_as(_f4), C.byref(n)), "vg_fe_detect")
+        return out[:n.value].copy()
+
+    def detect_upload(self, max_corners, masks=None):
+        mc = np.ascontiguousarray(max_corners, np.int32)
+        mp = None
+        if masks is not None:
+            self._mkeep = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in masks]
+            mp = (_u8 * self.cams)(*[None if m is None else m.ctypes.data_as(_u8) for m in self._mkeep])
+        self.hd._chk(self.lib.vg_fe_detect_upload(self.h, mp, mc.ctypes.data_as(_i4)), "vg_fe_detect_upload")
+
+    def detect_async(self, quality=0.01, min_dist=30.0):
+        self.hd._chk(self.lib.vg_fe_detect_async(self.h, float(quality), float(min_dist)), "vg_fe_detect_async")
+
+    def detect_download(self):
+        out = np.zeros((self.cams, self.max_pts, 2), np.float32)
+        n = np.zeros(self.cams, np.int32)
+        self.hd._chk(self.lib.vg_fe_detect_download(self.h, out.ctypes.data_as(_f4), n.ctypes.data_as(_i4)), "vg_fe_detect_download")
+        return [out[c, :n[c]].copy() for c in range(self.cams)]
+
+    def get_level(self, cam, level, previous=False):
+        w, hh = C.c_int(), C.c_int()
+        buf = np.zeros(self.W * self.H, np.uint8)
+        self.hd._chk(self.lib.vg_fe_get_level(self.h, cam, int(previous), level, buf.ctypes.data_as(_u8), C.byref(w), C.byref(hh)), "vg_fe_get_level")
+        return buf[:w.value * hh.value].reshape(hh.value, w.value).copy()
+
+    def get_eig(self, cam):
+        out = np.zeros((self.H, self.W), np.float32)
+        self.hd._chk(self.lib.vg_fe_get_eig(self.h, cam, out.ctypes.data_as(_f4)), "vg_fe_get_eig")
+        return out

@@ -289,3 +289,38 @@ class SyntheticSequence:
         prob['imu'] = [dict((k, np.copy(v)) for k, v in self.imu[w0 + i].items()) for i in range(K - 1)]
         prob['prior'] = prior
         return prob
+
+
+# ----------------------------------------------------------------------------- front-end frames
+def synth_frame(seed, width=752, height=480):
+    """EuRoC-shaped textured frame (SURVEY.md 8(d) configs[1]): value noise on a (width/8 x height/8) lattice,
+    bilinear x8 upsample, plus uniform +-8 fine noise, clamped to u8."""
+    rng = np.random.default_rng(seed)
+    gw, gh = width // 8 + 2, height // 8 + 2
+    lat = rng.uniform(0, 255, (gh, gw))
+    ys, xs = (np.arange(height) + 0.5) / 8.0, (np.arange(width) + 0.5) / 8.0
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+    img = (lat[y0][:, x0] * (1 - fy) * (1 - fx) + lat[y0][:, x0 + 1] * (1 - fy) * fx
+           + lat[y0 + 1][:, x0] * fy * (1 - fx) + lat[y0 + 1][:, x0 + 1] * fy * fx)
+    img = img + rng.uniform(-8, 8, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def warp_frame(img, seed, shift=(3.7, -2.2), angle_deg=0.5, noise=2.0):
+    """Next frame: `img` resampled (bilinear) with a translation + small rotation about the centre + Gaussian noise."""
+    rng = np.random.default_rng(seed)
+    h, w = img.shape
+    a = np.radians(angle_deg)
+    cy, cx = (h - 1) / 2.0, (w - 1) / 2.0
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    # inverse map: where does output pixel (x, y) come from
+    xs = np.cos(a) * (xx - cx - shift[0]) + np.sin(a) * (yy - cy - shift[1]) + cx
+    ys = -np.sin(a) * (xx - cx - shift[0]) + np.cos(a) * (yy - cy - shift[1]) + cy
+    xs, ys = np.clip(xs, 0, w - 1.001), np.clip(ys, 0, h - 1.001)
+    x0, y0 = np.floor(xs).astype(int), np.floor(ys).astype(int)
+    fx, fy = xs - x0, ys - y0
+    f = img.astype(np.float64)
+    out = f[y0, x0] * (1 - fy) * (1 - fx) + f[y0, x0 + 1] * (1 - fy) * fx + f[y0 + 1, x0] * fy * (1 - fx) + f[y0 + 1, x0 + 1] * fy * fx
+    out = out + rng.normal(0, noise, out.shape)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
