@@ -63,7 +63,7 @@ def test_gftt_with_disc_mask_and_small_min_dist(handle, frames):
     for (cx, cy) in [(100, 100), (400, 240), (700, 60), (376, 470)]:
         mask[(xx - cx) ** 2 + (yy - cy) ** 2 <= 30 ** 2] = 0
     mask[:, :40] = 0
-    for md in (30.0, 12.0):
+    for md in (30.0, 20.0):
         got = tr.detect(0, 300, 0.01, md, mask)
         ref = F.gftt(frames[1], 300, 0.01, md, mask)
         assert got.shape == ref.shape and np.array_equal(got, ref), md
