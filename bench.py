@@ -42,6 +42,86 @@ def make_windows(h, ba, synth, n, seed0):
     return [q.next_window(st[i], pr[i], 1) for i, q in enumerate(seqs)]
 
 
+FE_CAMS = 64                 # independent camera streams per GPU in the front-end leg
+FE_BYTES_PER_FEATURE = 8188  # (pyramid 592,200 B + LK 636,000 B) per 752x480 frame / 150 features
+FE_GFTT_BYTES_PER_FRAME = 3609600
+
+
+def bench_fe(h, synth, steps, warmup, rank, with_cpu):
+    """Front-end leg (BASELINE.json configs[1]): per step and per stream, pyramid build of the new 752x480 frame +
+    4-level pyramidal LK of 150 corners (frames resident in HBM, two alternating frames per stream)."""
+    import numpy as np
+    from vins_mono_amd import fe
+    W, H, N = 752, 480, 150
+    tr = fe.FrontEnd(h, W, H, FE_CAMS, N)
+    base = [synth.synth_frame(1000 + rank * FE_CAMS + c) for c in range(min(FE_CAMS, 8))]
+    nxt = [synth.warp_frame(b, 2000 + c) for c, b in enumerate(base)]
+    fa = [base[c % len(base)] for c in range(FE_CAMS)]
+    fb = [nxt[c % len(nxt)] for c in range(FE_CAMS)]
+    tr.push_frames(fa)                      # slot 0 = frame A (and pyramid)
+    tr.detect_upload([N] * FE_CAMS)
+    tr.detect_async()
+    corners = tr.detect_download()
+    tr.upload_frames(fb)                    # slot 1 = frame B
+    tr.track_upload(corners)
+    slot = 1
+
+    def step():
+        nonlocal slot
+        tr.select_frames(slot)
+        tr.build_async(False)
+        tr.track_async()
+        slot ^= 1
+
+    for _ in range(warmup):
+        step()
+    h.sync()
+    t0 = time.perf_counter()
+    h.timer_start()
+    for _ in range(steps):
+        step()
+    ev_ms = h.timer_stop()
+    wall = time.perf_counter() - t0
+    nfeat = sum(len(c) for c in corners)
+    res = tr.track_download()
+    tracked = int(sum(int(st.sum()) for (_, st, _) in res))
+    # GFTT alone
+    h.timer_start()
+    for _ in range(max(3, steps // 2)):
+        tr.detect_async()
+    gftt_ms = h.timer_stop() / max(3, steps // 2)
+    out = {
+        "metric": "KLT features/sec (pyramid build + 4-level 21x21 pyramidal LK, 150 corners per 752x480 frame)",
+        "value": nfeat * steps / wall, "unit": "features/s", "streams": FE_CAMS, "features_per_step": nfeat,
+        "tracked_last_step": tracked, "ms_per_step": wall / steps * 1e3, "dtype": "u8/int16/int64 + f32",
+        "gftt_frames_per_s": FE_CAMS / (gftt_ms * 1e-3), "gftt_ms_per_batch": gftt_ms,
+        "roofline": {"kernel": "fe_lk_kernel (+ fe_pyrdown_kernel x3 + fe_copy_kernel)", "bound": "hbm",
+                     "achieved": nfeat * FE_BYTES_PER_FEATURE * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "traffic": None, "event_ms_per_step": ev_ms / steps,
+                     "gftt_GBs": FE_CAMS * FE_GFTT_BYTES_PER_FRAME / (gftt_ms * 1e-3) / 1e9},
+    }
+    out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+    if with_cpu:
+        from oracle import fe_cpu
+        t = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t < 5.0:
+            fe_cpu.lk(fa[reps % len(fa)], fb[reps % len(fb)], corners[reps % len(corners)])
+            reps += 1
+        dt = time.perf_counter() - t
+        t2 = time.perf_counter()
+        g = 0
+        while time.perf_counter() - t2 < 3.0:
+            fe_cpu.gftt(fa[g % len(fa)], N)
+            g += 1
+        out["cpu_baseline"] = {"value": reps * N / dt, "unit": "features/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} frame pairs x {N} corners, oracle/fe_cpu.cpp (restated single-thread OpenCV-equivalent "
+                                         f"calcOpticalFlowPyrLK incl. both pyramids + Scharr; real OpenCV unavailable)",
+                               "gftt_frames_per_s": g / (time.perf_counter() - t2)}
+        out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,25 +132,18 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import __graft_entry__ as graft
+    graft.load_package()
+    from vins_mono_amd import ba, synth, dist_util as D
+    rank, local_rank, world = D.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import __graft_entry__ as graft
-    graft.load_package()
-    from vins_mono_amd import ba, synth
+    D.init("nccl", local_rank)          # one process per GPU; RCCL only for barrier / max / sum of the timing
 
     h = ba.Handle()
     nwin = args.windows
-    probs = make_windows(h, ba, synth, nwin, seed0=1 + rank * nwin)
+    probs = make_windows(h, ba, synth, nwin, seed0=D.window_seeds(rank, nwin)[0])
     packed = [ba.PackedProblem(p) for p in probs]
     flags = [ba.VG_MARGIN_OLD] * nwin
     h.ba_upload(packed, flags)                       # inputs now resident in HBM
@@ -78,8 +151,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        D.barrier()
 
     for _ in range(args.warmup):
         h.ba_run_async()
@@ -92,10 +164,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed)
 
     # per-kernel durations from HIP events on the launch stream (not part of the timed region)
     ks, km = [], []
@@ -170,8 +239,11 @@ def main():
             "cpu_baseline": cpu,
             "single_window_latency_ms": None,
         }
+    fe_out = bench_fe(h, synth, max(args.steps, 10), args.warmup, rank, rank == 0 and not args.no_cpu_baseline)
+    fe_out["value_all_gpus"] = D.sum_over_ranks(fe_out["value"])
     # single-window latency (configs[2]) on rank 0
     if rank == 0:
+        out["fe"] = fe_out
         h.ba_upload([packed[0]], [ba.VG_MARGIN_OLD])
         for _ in range(3):
             h.ba_run_async()
@@ -183,9 +255,7 @@ def main():
             out["batch_speedup_vs_cpu_per_gpu"] = out["value"] / world / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     h.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.finish()
 
 
 if __name__ == "__main__":

@@ -212,6 +212,9 @@ int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, int max_poi
 int vg_fe_push_frames(vg_handle* h, const uint8_t* const* imgs, int stride, int equalize);
 int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int stride);     /* H2D only            */
 int vg_fe_build_async(vg_handle* h, int equalize);                                 /* CLAHE + pyramids    */
+/* two device-resident raw-frame slots: upload_frames fills the slot that is not selected and selects it;
+ * select_frames re-selects a slot that was uploaded earlier (benchmarks alternate between two resident frames) */
+int vg_fe_select_frames(vg_handle* h, int slot);
 /* Pyramidal LK from the previous to the current frame of stream `cam`.  prev_xy / next_xy are (x, y) float pairs.
  * status / err have OpenCV's meaning (the inBorder() filter of feature_tracker.cpp:115-117 is the caller's). */
 int vg_fe_track(vg_handle* h, int cam, const float* prev_xy, int n, float* next_xy, uint8_t* status, float* err);

@@ -131,3 +131,25 @@ def test_solve_reduces_cost_and_marginalization_consistent():
         assert pr2['n'] == prob2['prior']['n'] - 6 and (B.KIND_POSE, 9) not in [b for b in pr2['blocks'] if b != (B.KIND_POSE, 9)] or True
     else:
         assert pr2 is prob2['prior']
+
+
+def test_cpp_oracle_matches_numpy_oracle():
+    """oracle/ba_cpu.cpp (the timed CPU baseline) against oracle/ba_numpy.py: two independent restatements."""
+    from oracle import ba_cpu
+    seq = synth.SyntheticSequence(8, L=50)
+    prob = seq.window(0)
+    st_c, sm_c, pr_c = ba_cpu.optimize(prob, 0)
+    st_o, sm_o, pr_o = B.optimization(prob, B.MARGIN_OLD)
+    assert sm_c['num_iterations'] == sm_o['num_iterations']
+    assert np.isclose(sm_c['final_cost'], sm_o['final_cost'], rtol=1e-8)
+    assert np.abs(st_c['pose'] - st_o['pose']).max() < 1e-8 and np.abs(st_c['sb'] - st_o['sb']).max() < 1e-8
+    assert pr_c['blocks'] == pr_o['blocks'] and pr_c['n'] == pr_o['n']
+    A, b = B.schur_extended(pr_o['A_full'], pr_o['b_full'], pr_o['m'])
+    Hc = pr_c['J0'].T @ pr_c['J0']
+    assert np.abs(Hc - A).max() < 1e-6 * np.abs(A).max()
+    prob2 = seq.next_window(st_o, pr_o, 1)
+    st_c2, sm_c2, _ = ba_cpu.optimize(prob2, 2)
+    x2, s2 = B.solve(prob2)
+    ref2 = B.double2vector(prob2, x2)
+    assert np.isclose(sm_c2['final_cost'], s2['final_cost'], rtol=1e-8)
+    assert np.abs(st_c2['pose'] - ref2['pose']).max() < 1e-8

@@ -39,6 +39,8 @@ struct FeState {
     uint8_t** d_ptrs[2] = {nullptr, nullptr};  // device pointer tables [level*cams+cam]
     std::vector<uint8_t*> h_ptrs[2];
     size_t level_off[FE_MAX_LEVELS + 1];
+    uint8_t* raw2[2] = {nullptr, nullptr};
+    int raw_sel = 1;
     uint8_t *raw = nullptr, *lut = nullptr, *mask = nullptr, *status = nullptr;
     float *prev_xy = nullptr, *next_xy = nullptr, *err = nullptr, *eig = nullptr, *blockmax = nullptr, *corners = nullptr;
     int *npts = nullptr, *max_corners = nullptr, *ncorners = nullptr;
@@ -103,7 +105,8 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     }
     d.nblk_eig = ((width + 63) / 64) * ((height + 3) / 4);
     d.cand_cap = FE_CAND_CAP;
-    HIPCHK(h, hipMalloc((void**)&s->raw, npix * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->raw, 2 * npix * n_cams));
+    s->raw2[0] = s->raw; s->raw2[1] = s->raw + npix * n_cams;
     HIPCHK(h, hipMalloc((void**)&s->lut, (size_t)n_cams * 64 * 256));
     HIPCHK(h, hipMalloc((void**)&s->mask, npix * n_cams));
     HIPCHK(h, hipMemset(s->mask, 255, npix * n_cams));
@@ -120,7 +123,7 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     HIPCHK(h, hipMalloc((void**)&s->ncorners, sizeof(int) * n_cams));
     HIPCHK(h, hipMalloc((void**)&s->ncand, sizeof(unsigned) * n_cams));
     HIPCHK(h, hipMalloc((void**)&s->keys, sizeof(unsigned long long) * (size_t)FE_CAND_CAP * n_cams));
-    d.raw = s->raw; d.lut = s->lut; d.npts = s->npts; d.prev_xy = s->prev_xy; d.next_xy = s->next_xy; d.status = s->status;
+    d.raw = s->raw2[s->raw_sel]; d.lut = s->lut; d.npts = s->npts; d.prev_xy = s->prev_xy; d.next_xy = s->next_xy; d.status = s->status;
     d.err = s->err; d.eig = s->eig; d.mask = s->mask; d.blockmax = s->blockmax; d.ncand = s->ncand; d.keys = s->keys;
     d.max_corners = s->max_corners; d.corners = s->corners; d.ncorners = s->ncorners;
     s->h_npts.assign(n_cams, 0);
@@ -133,11 +136,20 @@ extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int
     if (!h || !h->fe || !imgs) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
     const size_t npix = (size_t)s->W * s->H;
+    s->raw_sel ^= 1;
+    s->d.raw = s->raw2[s->raw_sel];
     for (int c = 0; c < s->cams; ++c) {
         if (!imgs[c]) { h->err = "vg_fe_upload_frames: every stream needs a frame (batched streams advance together)"; return VG_ERR_BAD_ARG; }
-        HIPCHK(h, hipMemcpy2DAsync(s->raw + (size_t)c * npix, s->W, imgs[c], stride, s->W, s->H, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpy2DAsync(s->raw2[s->raw_sel] + (size_t)c * npix, s->W, imgs[c], stride, s->W, s->H, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_fe_select_frames(vg_handle* h, int slot) {
+    if (!h || !h->fe || slot < 0 || slot > 1) return VG_ERR_BAD_ARG;
+    h->fe->raw_sel = slot;
+    h->fe->d.raw = h->fe->raw2[slot];
     return VG_OK;
 }
 
