@@ -1,0 +1,126 @@
+"""The C++ drop-in classes (vins-mono_amd/host: FeatureTracker::readImage, Estimator::optimization) driven on the GPU:
+the FE replay must equal a Python mirror of the same control flow built directly on the C-ABI + oracle checks, the
+Estimator round trip must equal a direct vg_ba_optimize call (packing / filter / prior bookkeeping under test)."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import fe_cpu as F
+from vins_mono_amd import ba, fe, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "vins-mono_amd", "lib")
+W, H, MAX_CNT, MIN_DIST = 752, 480, 150, 30
+
+
+def _frames(n):
+    f = [synth.synth_frame(50)]
+    for k in range(1, n):
+        f.append(synth.warp_frame(f[-1], 60 + k, shift=(2.1 + 0.3 * k, -1.4), angle_deg=0.3))
+    return f
+
+
+def _in_border(p):
+    x, y = int(np.rint(p[0])), int(np.rint(p[1]))
+    return 1 <= x < W - 1 and 1 <= y < H - 1
+
+
+def _mirror(frames, pub_every):
+    """feature_tracker.cpp:81-167 + feature_tracker_node.cpp:103-111 on top of the ORACLE (CLAHE on, no RANSAC)."""
+    out = []
+    prev = None
+    cur_pts, ids, cnt = np.zeros((0, 2), np.float32), [], []
+    n_id = 0
+    for k, raw in enumerate(frames):
+        img = F.clahe(raw)
+        forw = np.zeros((0, 2), np.float32)
+        if len(cur_pts):
+            nxt, st, _ = F.lk(prev, img, cur_pts)
+            keep = [i for i in range(len(cur_pts)) if st[i] and _in_border(nxt[i])]
+            forw = nxt[keep]
+            ids = [ids[i] for i in keep]
+            cnt = [cnt[i] for i in keep]
+        cnt = [c + 1 for c in cnt]
+        if k % pub_every == 0:
+            mask = np.full((H, W), 255, np.uint8)
+            order = sorted(range(len(forw)), key=lambda i: -cnt[i])          # stable, like the shim
+            kp, ki, kc = [], [], []
+            yy, xx = np.mgrid[0:H, 0:W]
+            for i in order:
+                px, py = int(np.rint(forw[i][0])), int(np.rint(forw[i][1]))
+                if mask[py, px] == 255:
+                    kp.append(forw[i]); ki.append(ids[i]); kc.append(cnt[i])
+                    mask[(xx - px) ** 2 + (yy - py) ** 2 <= MIN_DIST ** 2] = 0
+            forw = np.array(kp, np.float32).reshape(-1, 2)
+            ids, cnt = ki, kc
+            if MAX_CNT - len(forw) > 0:
+                new = F.gftt(img, MAX_CNT - len(forw), 0.01, float(MIN_DIST), mask)
+                forw = np.concatenate([forw, new]).astype(np.float32)
+                ids += [-1] * len(new)
+                cnt += [1] * len(new)
+        prev, cur_pts = img, forw
+        for i in range(len(ids)):
+            if ids[i] == -1:
+                ids[i] = n_id
+                n_id += 1
+        out.append((list(ids), list(cnt), cur_pts.copy()))
+    return out
+
+
+def test_feature_tracker_replay_matches_mirror(tmp_path):
+    frames = _frames(5)
+    path = tmp_path / "frames.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("4i", len(frames), W, H, 2))
+        for im in frames:
+            f.write(im.tobytes())
+    outp = tmp_path / "out.txt"
+    r = subprocess.run([os.path.join(LIBDIR, "vins_replay"), "fe", str(path), str(outp)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got, cur = [], None
+    for line in open(outp):
+        t = line.split()
+        if t[0] == "frame":
+            cur = ([], [], [])
+            got.append(cur)
+        else:
+            cur[0].append(int(t[0])); cur[1].append(int(t[1])); cur[2].append((float(t[2]), float(t[3])))
+    ref = _mirror(frames, 2)
+    assert len(got) == len(ref)
+    for k, ((gi, gc, gp), (ri, rc, rp)) in enumerate(zip(got, ref)):
+        assert gi == ri and gc == rc, k
+        assert np.array_equal(np.array(gp, np.float32).reshape(-1, 2), rp), k
+    assert len(got[-1][0]) >= 100 and max(got[-1][1]) >= 4          # tracks survive several frames
+
+
+def test_estimator_shim_roundtrip_equals_direct_abi(handle):
+    lib = C.CDLL(os.path.join(LIBDIR, "libvins_host.so"))
+    seq = synth.SyntheticSequence(77, L=60)
+    p1 = seq.window(0)
+    st1, _, pr1 = handle.ba_optimize(p1, ba.VG_MARGIN_OLD)
+    prob = seq.next_window(st1, pr1, 1)
+    st, sm, pr = handle.ba_optimize(prob, ba.VG_MARGIN_OLD)
+    pk = ba.PackedProblem(prob)
+    K, L = pk.K, pk.L
+    pose, sb, depth = np.zeros((K, 7)), np.zeros((K, 9)), np.zeros(L)
+    flag, pn, pnb, iters = np.zeros(L, np.int32), C.c_int(), C.c_int(), C.c_int()
+    kind, idx = np.zeros(32, np.int32), np.zeros(32, np.int32)
+    J0, r0 = np.zeros(128 * 128), np.zeros(128)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    rc = lib.vins_host_estimator_roundtrip(C.byref(pk.struct), 0, pose.ctypes.data_as(dp), sb.ctypes.data_as(dp), depth.ctypes.data_as(dp),
+                                           flag.ctypes.data_as(ip), C.byref(pn), C.byref(pnb), kind.ctypes.data_as(ip), idx.ctypes.data_as(ip),
+                                           J0.ctypes.data_as(dp), r0.ctypes.data_as(dp), C.byref(iters))
+    assert rc == 0 and iters.value == sm['num_iterations']
+    # the shim goes para -> Eigen members (q -> R -> q) once more: agreement to rounding
+    assert np.abs(pose - st['pose']).max() < 1e-12 and np.abs(sb - st['sb']).max() < 1e-12
+    assert np.allclose(1.0 / depth, st['inv_depth'], rtol=1e-13)
+    assert np.all(flag == np.where(st['inv_depth'] < 0, 2, 1))
+    assert pn.value == pr['n'] and [(int(kind[b]), int(idx[b])) for b in range(pnb.value)] == pr['blocks']
+    n = pn.value
+    Jg = J0[:n * n].reshape(n, n)
+    assert np.abs(Jg.T @ Jg - pr['J0'].T @ pr['J0']).max() < 1e-6 * np.abs(pr['J0'].T @ pr['J0']).max()

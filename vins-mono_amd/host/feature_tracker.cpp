@@ -1,0 +1,189 @@
+// feature_tracker.cpp — see feature_tracker.h.  Control flow follows feature_tracker/src/feature_tracker.cpp of the
+// reference (cited per block); the arithmetic runs on the GPU through libvinsgpu.so.
+#include "feature_tracker.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+int ROW = 480, COL = 752, MAX_CNT = 150, MIN_DIST = 30, EQUALIZE = 1, FISHEYE = 0, FOCAL_LENGTH = 460;
+bool PUB_THIS_FRAME = false;
+int FeatureTracker::n_id = 0;
+
+static int cvRoundf(float v) { return (int)std::lrintf(v); }
+
+bool inBorder(const cv::Point2f& pt) {                       // feature_tracker.cpp:5-11
+    const int BORDER_SIZE = 1;
+    int img_x = cvRoundf(pt.x);
+    int img_y = cvRoundf(pt.y);
+    return BORDER_SIZE <= img_x && img_x < COL - BORDER_SIZE && BORDER_SIZE <= img_y && img_y < ROW - BORDER_SIZE;
+}
+
+void reduceVector(vector<cv::Point2f>& v, vector<uchar> status) {   // :13-20
+    int j = 0;
+    for (int i = 0; i < int(v.size()); i++)
+        if (status[i]) v[j++] = v[i];
+    v.resize(j);
+}
+void reduceVector(vector<int>& v, vector<uchar> status) {           // :22-29
+    int j = 0;
+    for (int i = 0; i < int(v.size()); i++)
+        if (status[i]) v[j++] = v[i];
+    v.resize(j);
+}
+
+void PinholeModel::liftProjective(double u, double v, double& x, double& y) const {
+    // PinholeCamera::liftProjective, recursive distortion model with n = 8 (PinholeCamera.cc:450-510, :646-661)
+    const double mx_d = (1.0 / fx) * u + (-cx / fx), my_d = (1.0 / fy) * v + (-cy / fy);
+    auto distortion = [&](double px, double py, double& dx, double& dy) {
+        const double mx2 = px * px, my2 = py * py, mxy = px * py, rho2 = mx2 + my2, rad = k1 * rho2 + k2 * rho2 * rho2;
+        dx = px * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2);
+        dy = py * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2);
+    };
+    double dx, dy;
+    distortion(mx_d, my_d, dx, dy);
+    double mx_u = mx_d - dx, my_u = my_d - dy;
+    for (int i = 1; i < 8; ++i) {
+        distortion(mx_u, my_u, dx, dy);
+        mx_u = mx_d - dx; my_u = my_d - dy;
+    }
+    x = mx_u; y = my_u;
+}
+
+FeatureTracker::FeatureTracker() : cur_time(0), prev_time(0) {}
+FeatureTracker::~FeatureTracker() { if (vg_) vg_destroy(vg_); }
+
+static void chk(int rc, vg_handle* h, const char* what) {
+    if (rc != VG_OK) throw std::runtime_error(std::string(what) + ": " + (h ? vg_last_error(h) : "no handle") + " (no CPU fallback)");
+}
+
+void FeatureTracker::setMask() {                             // feature_tracker.cpp:36-69
+    if (FISHEYE) mask = fisheye_mask.clone();
+    else mask = cv::Mat(ROW, COL, cv::CV_8UC1, (uchar)255);
+    vector<pair<int, pair<cv::Point2f, int>>> cnt_pts_id;
+    for (unsigned int i = 0; i < forw_pts.size(); i++) cnt_pts_id.push_back(make_pair(track_cnt[i], make_pair(forw_pts[i], ids[i])));
+    // the reference uses std::sort (unstable); canonicalised to a stable sort (hard part 5)
+    stable_sort(cnt_pts_id.begin(), cnt_pts_id.end(),
+                [](const pair<int, pair<cv::Point2f, int>>& a, const pair<int, pair<cv::Point2f, int>>& b) { return a.first > b.first; });
+    forw_pts.clear(); ids.clear(); track_cnt.clear();
+    for (auto& it : cnt_pts_id) {
+        const int px = cvRoundf(it.second.first.x), py = cvRoundf(it.second.first.y);   // Point2f -> Point conversion rounds (saturate_cast)
+        if (px < 0 || py < 0 || px >= COL || py >= ROW) continue;
+        if (mask.at<uchar>(py, px) == 255) {
+            forw_pts.push_back(it.second.first);
+            ids.push_back(it.second.second);
+            track_cnt.push_back(it.first);
+            // cv::circle(mask, pt, MIN_DIST, 0, -1): filled disc, centre rounded to the nearest pixel
+            const int cx = cvRoundf(it.second.first.x), cy = cvRoundf(it.second.first.y), r = MIN_DIST;
+            for (int y = std::max(0, cy - r); y <= std::min(ROW - 1, cy + r); ++y)
+                for (int x = std::max(0, cx - r); x <= std::min(COL - 1, cx + r); ++x)
+                    if ((x - cx) * (x - cx) + (y - cy) * (y - cy) <= r * r) mask.at<uchar>(y, x) = 0;
+        }
+    }
+}
+
+void FeatureTracker::addPoints() {                            // :71-79
+    for (auto& p : n_pts) {
+        forw_pts.push_back(p);
+        ids.push_back(-1);
+        track_cnt.push_back(1);
+    }
+}
+
+void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {    // :81-167
+    cur_time = _cur_time;
+    if (!configured_) {
+        chk(vg_create(&vg_), vg_, "vg_create");
+        chk(vg_fe_configure(vg_, COL, ROW, 1, std::max(MAX_CNT, 1) * 4), vg_, "vg_fe_configure");
+        configured_ = true;
+    }
+    // EQUALIZE (CLAHE, :87-93) happens on the device; `forw_img = img` (:97-104) = the device pyramid rotation
+    const uint8_t* planes[1] = {_img.data};
+    chk(vg_fe_push_frames(vg_, planes, (int)_img.step, EQUALIZE), vg_, "vg_fe_push_frames");
+    if (forw_img.empty()) prev_img = cur_img = forw_img = _img;
+    else forw_img = _img;
+
+    forw_pts.clear();
+    if (cur_pts.size() > 0) {                                                // :108-125
+        vector<uchar> status(cur_pts.size());
+        vector<float> err(cur_pts.size());
+        forw_pts.resize(cur_pts.size());
+        chk(vg_fe_track(vg_, 0, &cur_pts[0].x, (int)cur_pts.size(), &forw_pts[0].x, status.data(), err.data()), vg_, "vg_fe_track");
+        for (int i = 0; i < int(forw_pts.size()); i++)
+            if (status[i] && !inBorder(forw_pts[i])) status[i] = 0;
+        reduceVector(prev_pts, status);
+        reduceVector(cur_pts, status);
+        reduceVector(forw_pts, status);
+        reduceVector(ids, status);
+        reduceVector(cur_un_pts, status);
+        reduceVector(track_cnt, status);
+    }
+    for (auto& n : track_cnt) n++;                                           // :127-128
+
+    if (PUB_THIS_FRAME) {                                                    // :130-158
+        rejectWithF();
+        setMask();
+        int n_max_cnt = MAX_CNT - static_cast<int>(forw_pts.size());
+        if (n_max_cnt > 0) {
+            n_pts.resize(n_max_cnt);
+            int n = 0;
+            chk(vg_fe_detect(vg_, 0, mask.data, n_max_cnt, 0.01, (double)MIN_DIST, &n_pts[0].x, &n), vg_, "vg_fe_detect");
+            n_pts.resize(n);
+        } else
+            n_pts.clear();
+        addPoints();
+    }
+    prev_img = cur_img;                                                      // :160-166
+    prev_pts = cur_pts;
+    prev_un_pts = cur_un_pts;
+    cur_img = forw_img;
+    cur_pts = forw_pts;
+    undistortedPoints();
+    prev_time = cur_time;
+}
+
+void FeatureTracker::rejectWithF() {
+    // feature_tracker.cpp:169-202 calls cv::findFundamentalMat(FM_RANSAC, F_THRESHOLD, 0.99): third-party RANSAC with
+    // OpenCV's RNG — SURVEY.md 8(f) row 3, not part of the accelerated path.  With real OpenCV the original body
+    // compiles unchanged against this class; in the compat build outlier rejection is skipped.
+}
+
+bool FeatureTracker::updateID(unsigned int i) {                              // :204-214
+    if (i < ids.size()) {
+        if (ids[i] == -1) ids[i] = n_id++;
+        return true;
+    }
+    return false;
+}
+
+void FeatureTracker::readIntrinsicParameter(const string&) {}
+
+void FeatureTracker::undistortedPoints() {                                   // :258-306
+    cur_un_pts.clear();
+    cur_un_pts_map.clear();
+    for (unsigned int i = 0; i < cur_pts.size(); i++) {
+        double bx, by;
+        m_camera.liftProjective(cur_pts[i].x, cur_pts[i].y, bx, by);
+        cur_un_pts.push_back(cv::Point2f((float)bx, (float)by));
+        cur_un_pts_map.insert(make_pair(ids[i], cv::Point2f((float)bx, (float)by)));
+    }
+    if (!prev_un_pts_map.empty()) {
+        double dt = cur_time - prev_time;
+        pts_velocity.clear();
+        for (unsigned int i = 0; i < cur_un_pts.size(); i++) {
+            if (ids[i] != -1) {
+                auto it = prev_un_pts_map.find(ids[i]);
+                if (it != prev_un_pts_map.end()) {
+                    double v_x = (cur_un_pts[i].x - it->second.x) / dt;
+                    double v_y = (cur_un_pts[i].y - it->second.y) / dt;
+                    pts_velocity.push_back(cv::Point2f((float)v_x, (float)v_y));
+                } else
+                    pts_velocity.push_back(cv::Point2f(0, 0));
+            } else
+                pts_velocity.push_back(cv::Point2f(0, 0));
+        }
+    } else {
+        for (unsigned int i = 0; i < cur_pts.size(); i++) pts_velocity.push_back(cv::Point2f(0, 0));
+    }
+    prev_un_pts_map = cur_un_pts_map;
+}

@@ -1,0 +1,92 @@
+// host_test_api.cpp — C entry point used by tests/ to drive the drop-in Estimator from a vg_ba_problem:
+// it fills the Estimator members the way the surrounding reference code would have left them (Ps/Rs/..., the
+// f_manager.feature list incl. features the filter must skip, pre_integrations[], last_marginalization_info), calls
+// Estimator::optimization() and returns the members it wrote.  Test plumbing only.
+#include <cstring>
+#include "estimator.h"
+
+extern "C" int vins_host_estimator_roundtrip(const vg_ba_problem* p, int margin_flag, double* pose_out /*K*7*/, double* sb_out /*K*9*/,
+                                             double* depth_out /*L*/, int* solve_flag_out /*L*/, int* prior_n, int* prior_nblocks,
+                                             int* prior_kind, int* prior_index, double* prior_J0, double* prior_r0, int* iters) {
+    if (p->K != WINDOW_SIZE + 1) return -1;
+    Estimator est;
+    ESTIMATE_EXTRINSIC = p->estimate_extrinsic; ESTIMATE_TD = p->estimate_td; NUM_ITERATIONS = p->max_iters;
+    TR = p->tr; ROW_D = p->row; FOCAL_LENGTH_D = p->focal; G_NORM = p->g_norm;
+    for (int i = 0; i <= WINDOW_SIZE; ++i) {
+        est.Ps[i] = Vector3d(p->pose[7 * i], p->pose[7 * i + 1], p->pose[7 * i + 2]);
+        est.Rs[i] = Quaterniond(p->pose[7 * i + 6], p->pose[7 * i + 3], p->pose[7 * i + 4], p->pose[7 * i + 5]).toRotationMatrix();
+        est.Vs[i] = Vector3d(p->speedbias[9 * i], p->speedbias[9 * i + 1], p->speedbias[9 * i + 2]);
+        est.Bas[i] = Vector3d(p->speedbias[9 * i + 3], p->speedbias[9 * i + 4], p->speedbias[9 * i + 5]);
+        est.Bgs[i] = Vector3d(p->speedbias[9 * i + 6], p->speedbias[9 * i + 7], p->speedbias[9 * i + 8]);
+    }
+    est.tic[0] = Vector3d(p->ex_pose[0], p->ex_pose[1], p->ex_pose[2]);
+    est.ric[0] = Quaterniond(p->ex_pose[6], p->ex_pose[3], p->ex_pose[4], p->ex_pose[5]).toRotationMatrix();
+    est.td = p->td;
+    IntegrationBase pre[WINDOW_SIZE + 1];
+    for (int k = 0; k < WINDOW_SIZE; ++k) {
+        const vg_imu_preint& m = p->imu[k];
+        IntegrationBase& q = pre[k + 1];
+        q.sum_dt = m.sum_dt;
+        q.delta_p = Vector3d(m.delta_p[0], m.delta_p[1], m.delta_p[2]); q.delta_v = Vector3d(m.delta_v[0], m.delta_v[1], m.delta_v[2]);
+        q.linearized_ba = Vector3d(m.linearized_ba[0], m.linearized_ba[1], m.linearized_ba[2]);
+        q.linearized_bg = Vector3d(m.linearized_bg[0], m.linearized_bg[1], m.linearized_bg[2]);
+        q.delta_q = Quaterniond(m.delta_q[3], m.delta_q[0], m.delta_q[1], m.delta_q[2]);
+        memcpy(q.jacobian, m.jacobian, sizeof(q.jacobian)); memcpy(q.covariance, m.covariance, sizeof(q.covariance));
+        est.pre_integrations[k + 1] = m.valid ? &q : nullptr;
+    }
+    // features: the real ones interleaved with decoys the used_num / start_frame filter must drop
+    for (int l = 0; l < p->L; ++l) {
+        FeaturePerId f;
+        f.feature_id = l; f.start_frame = p->lm_start[l]; f.estimated_depth = 1.0 / p->inv_depth[l];
+        for (int k = 0; k < p->lm_nobs[l]; ++k) {
+            const double* o = p->obs + 7 * (p->lm_obs_off[l] + k);
+            FeaturePerFrame fr;
+            fr.point = Vector3d(o[0], o[1], 1.0); fr.uv.x() = o[2]; fr.uv.y() = o[3]; fr.velocity.x() = o[4]; fr.velocity.y() = o[5]; fr.cur_td = o[6];
+            f.feature_per_frame.push_back(fr);
+        }
+        est.f_manager.feature.push_back(f);
+        if (l % 3 == 0) {       // decoys: a single-observation track and a track starting too late
+            FeaturePerId d1; d1.feature_id = 100000 + l; d1.start_frame = 2; d1.estimated_depth = 5.0; d1.feature_per_frame.push_back(f.feature_per_frame[0]);
+            est.f_manager.feature.push_back(d1);
+            FeaturePerId d2 = f; d2.feature_id = 200000 + l; d2.start_frame = WINDOW_SIZE - 2; d2.feature_per_frame.resize(2);
+            est.f_manager.feature.push_back(d2);
+        }
+    }
+    if (p->prior_n > 0) {
+        MarginalizationInfo* mi = new MarginalizationInfo();
+        mi->n = p->prior_n;
+        int x0n = 0;
+        for (int b = 0; b < p->prior_nblocks; ++b) {
+            mi->keep_block_kind.push_back(p->prior_block_kind[b]); mi->keep_block_index.push_back(p->prior_block_index[b]);
+            x0n += p->prior_block_kind[b] == VG_BLK_SPEEDBIAS ? 9 : (p->prior_block_kind[b] == VG_BLK_TD ? 1 : 7);
+        }
+        mi->keep_block_data.assign(p->prior_x0, p->prior_x0 + x0n);
+        mi->linearized_jacobians.assign(p->prior_J0, p->prior_J0 + (size_t)p->prior_n * p->prior_n);
+        mi->linearized_residuals.assign(p->prior_r0, p->prior_r0 + p->prior_n);
+        est.last_marginalization_info = mi;
+    }
+    est.marginalization_flag = margin_flag == VG_MARGIN_OLD ? Estimator::MARGIN_OLD : Estimator::MARGIN_SECOND_NEW;
+    est.optimization();
+    for (int i = 0; i <= WINDOW_SIZE; ++i) {
+        Quaterniond q(est.Rs[i]);
+        const double row[7] = {est.Ps[i].x(), est.Ps[i].y(), est.Ps[i].z(), q.x(), q.y(), q.z(), q.w()};
+        memcpy(pose_out + 7 * i, row, sizeof(row));
+        const double sb[9] = {est.Vs[i].x(), est.Vs[i].y(), est.Vs[i].z(), est.Bas[i].x(), est.Bas[i].y(), est.Bas[i].z(), est.Bgs[i].x(), est.Bgs[i].y(), est.Bgs[i].z()};
+        memcpy(sb_out + 9 * i, sb, sizeof(sb));
+    }
+    int l = 0;
+    for (auto& f : est.f_manager.feature) {
+        if (f.feature_id >= 100000) continue;
+        depth_out[l] = f.estimated_depth; solve_flag_out[l] = f.solve_flag; ++l;
+    }
+    *iters = est.last_summary.num_iterations;
+    *prior_n = 0; *prior_nblocks = 0;
+    if (est.last_marginalization_info) {
+        MarginalizationInfo* mi = est.last_marginalization_info;
+        *prior_n = mi->n; *prior_nblocks = (int)mi->keep_block_kind.size();
+        for (int b = 0; b < *prior_nblocks; ++b) { prior_kind[b] = mi->keep_block_kind[b]; prior_index[b] = mi->keep_block_index[b]; }
+        memcpy(prior_J0, mi->linearized_jacobians.data(), sizeof(double) * mi->n * mi->n);
+        memcpy(prior_r0, mi->linearized_residuals.data(), sizeof(double) * mi->n);
+    }
+    return 0;
+}
