@@ -33,7 +33,8 @@ DEV void proj_eval(const double* pose_i, const double* pose_j, const double* ex,
     q_to_R(pose_i + 3, Ri);
     q_to_R(pose_j + 3, Rj);
     q_to_R(ex + 3, Rc);
-    const double pci[3] = {pts_i[0] / lam, pts_i[1] / lam, pts_i[2] / lam};
+    const double ilam = 1.0 / lam;
+    const double pci[3] = {pts_i[0] * ilam, pts_i[1] * ilam, pts_i[2] * ilam};
     double pbi[3], pw[3], pbj[3], pcj[3], t3[3];
     m3_vec(Rc, pci, pbi);
     pbi[0] += ex[0]; pbi[1] += ex[1]; pbi[2] += ex[2];
@@ -43,12 +44,12 @@ DEV void proj_eval(const double* pose_i, const double* pose_j, const double* ex,
     m3t_vec(Rj, t3, pbj);
     t3[0] = pbj[0] - ex[0]; t3[1] = pbj[1] - ex[1]; t3[2] = pbj[2] - ex[2];
     m3t_vec(Rc, t3, pcj);
-    const double dep = pcj[2];
-    r[0] = s * (pcj[0] / dep - ptj_x);
-    r[1] = s * (pcj[1] / dep - ptj_y);
+    const double idep = 1.0 / pcj[2];
+    r[0] = s * (pcj[0] * idep - ptj_x);
+    r[1] = s * (pcj[1] * idep - ptj_y);
     if (!JAC) return;
     // reduce = sqrt_info * [[1/z,0,-x/z^2],[0,1/z,-y/z^2]]
-    const double r00 = s / dep, r02 = -s * pcj[0] / (dep * dep), r12 = -s * pcj[1] / (dep * dep);
+    const double r00 = s * idep, r02 = -s * pcj[0] * (idep * idep), r12 = -s * pcj[1] * (idep * idep);
     double A[9];                         // ric^T Rj^T
     {
         double RjRc[9];
@@ -85,12 +86,12 @@ DEV void proj_eval(const double* pose_i, const double* pose_j, const double* ex,
     {
         double v[3];
         m3_vec(tmp_r, pts_i, v);
-        const double k = -1.0 / (lam * lam);
+        const double k = -(ilam * ilam);
         Jl[0] = (r00 * v[0] + r02 * v[2]) * k;
         Jl[1] = (r00 * v[1] + r12 * v[2]) * k;
         if (TD) {
             m3_vec(tmp_r, vel_i, v);
-            const double kk = -1.0 / lam;
+            const double kk = -ilam;
             Jtd[0] = (r00 * v[0] + r02 * v[2]) * kk + s * vel_jx;
             Jtd[1] = (r00 * v[1] + r12 * v[2]) * kk + s * vel_jy;
         }
@@ -201,49 +202,38 @@ DEV void imu_ctx(const double* pre, const double* pose_i, const double* sb_i, co
     qleft3(qe, c.M3);
 }
 
-// raw Jacobian column `col` (0..29: pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9) into out[15]
+// raw Jacobian column `col` (0..29: pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9) into out[15].
+// Written with selects only (no run-time register-array index), so that ImuCtx and `out` stay in VGPRs.
+DEV double sel3(double a0, double a1, double a2, int k) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
 DEV void imu_raw_col(const ImuCtx& c, const double* pre, int col, double* out) {
     const double* Jm = pre + IM_JAC;
+    const int cb = col / 3, k = col - 3 * cb;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) out[k] = 0.0;
-    if (col < 3) {
-        const int k = col;
-        out[0] = -c.Rinv[k]; out[1] = -c.Rinv[3 + k]; out[2] = -c.Rinv[6 + k];
-    } else if (col < 6) {
-        const int k = col - 3;
-        double S[9];
-        skew3(c.vP, S);
-        out[0] = S[k]; out[1] = S[3 + k]; out[2] = S[6 + k];
-        out[3] = -c.M1[k]; out[4] = -c.M1[3 + k]; out[5] = -c.M1[6 + k];
-        skew3(c.vV, S);
-        out[6] = S[k]; out[7] = S[3 + k]; out[8] = S[6 + k];
-    } else if (col < 9) {
-        const int k = col - 6;
-        out[0] = -c.Rinv[k] * c.dt; out[1] = -c.Rinv[3 + k] * c.dt; out[2] = -c.Rinv[6 + k] * c.dt;
-        out[6] = -c.Rinv[k]; out[7] = -c.Rinv[3 + k]; out[8] = -c.Rinv[6 + k];
-    } else if (col < 12) {
-        const int k = col - 9;
+    for (int q = 0; q < 15; ++q) out[q] = 0.0;
+    // column k of the 3x3 blocks that can appear
+    const double ri0 = sel3(c.Rinv[0], c.Rinv[1], c.Rinv[2], k), ri1 = sel3(c.Rinv[3], c.Rinv[4], c.Rinv[5], k), ri2 = sel3(c.Rinv[6], c.Rinv[7], c.Rinv[8], k);
+    if (cb == 0) { out[0] = -ri0; out[1] = -ri1; out[2] = -ri2; }
+    else if (cb == 1) {
+        // skew(v) column k: k=0 -> (0, v2, -v1); k=1 -> (-v2, 0, v0); k=2 -> (v1, -v0, 0)
+        out[0] = sel3(0.0, -c.vP[2], c.vP[1], k); out[1] = sel3(c.vP[2], 0.0, -c.vP[0], k); out[2] = sel3(-c.vP[1], c.vP[0], 0.0, k);
+        out[3] = -sel3(c.M1[0], c.M1[1], c.M1[2], k); out[4] = -sel3(c.M1[3], c.M1[4], c.M1[5], k); out[5] = -sel3(c.M1[6], c.M1[7], c.M1[8], k);
+        out[6] = sel3(0.0, -c.vV[2], c.vV[1], k); out[7] = sel3(c.vV[2], 0.0, -c.vV[0], k); out[8] = sel3(-c.vV[1], c.vV[0], 0.0, k);
+    } else if (cb == 2) {
+        out[0] = -ri0 * c.dt; out[1] = -ri1 * c.dt; out[2] = -ri2 * c.dt;
+        out[6] = -ri0; out[7] = -ri1; out[8] = -ri2;
+    } else if (cb == 3) {
         out[0] = -Jm[0 * 15 + 9 + k]; out[1] = -Jm[1 * 15 + 9 + k]; out[2] = -Jm[2 * 15 + 9 + k];
         out[6] = -Jm[6 * 15 + 9 + k]; out[7] = -Jm[7 * 15 + 9 + k]; out[8] = -Jm[8 * 15 + 9 + k];
-        out[9 + k] = -1.0;
-    } else if (col < 15) {
-        const int k = col - 12;
+        out[9] = k == 0 ? -1.0 : 0.0; out[10] = k == 1 ? -1.0 : 0.0; out[11] = k == 2 ? -1.0 : 0.0;
+    } else if (cb == 4) {
         out[0] = -Jm[0 * 15 + 12 + k]; out[1] = -Jm[1 * 15 + 12 + k]; out[2] = -Jm[2 * 15 + 12 + k];
-        out[3] = -c.M2d[k]; out[4] = -c.M2d[3 + k]; out[5] = -c.M2d[6 + k];
+        out[3] = -sel3(c.M2d[0], c.M2d[1], c.M2d[2], k); out[4] = -sel3(c.M2d[3], c.M2d[4], c.M2d[5], k); out[5] = -sel3(c.M2d[6], c.M2d[7], c.M2d[8], k);
         out[6] = -Jm[6 * 15 + 12 + k]; out[7] = -Jm[7 * 15 + 12 + k]; out[8] = -Jm[8 * 15 + 12 + k];
-        out[12 + k] = -1.0;
-    } else if (col < 18) {
-        const int k = col - 15;
-        out[0] = c.Rinv[k]; out[1] = c.Rinv[3 + k]; out[2] = c.Rinv[6 + k];
-    } else if (col < 21) {
-        const int k = col - 18;
-        out[3] = c.M3[k]; out[4] = c.M3[3 + k]; out[5] = c.M3[6 + k];
-    } else if (col < 24) {
-        const int k = col - 21;
-        out[6] = c.Rinv[k]; out[7] = c.Rinv[3 + k]; out[8] = c.Rinv[6 + k];
-    } else if (col < 27) {
-        out[9 + (col - 24)] = 1.0;
-    } else {
-        out[12 + (col - 27)] = 1.0;
-    }
+        out[12] = k == 0 ? -1.0 : 0.0; out[13] = k == 1 ? -1.0 : 0.0; out[14] = k == 2 ? -1.0 : 0.0;
+    } else if (cb == 5) { out[0] = ri0; out[1] = ri1; out[2] = ri2; }
+    else if (cb == 6) {
+        out[3] = sel3(c.M3[0], c.M3[1], c.M3[2], k); out[4] = sel3(c.M3[3], c.M3[4], c.M3[5], k); out[5] = sel3(c.M3[6], c.M3[7], c.M3[8], k);
+    } else if (cb == 7) { out[6] = ri0; out[7] = ri1; out[8] = ri2; }
+    else if (cb == 8) { out[9] = k == 0 ? 1.0 : 0.0; out[10] = k == 1 ? 1.0 : 0.0; out[11] = k == 2 ? 1.0 : 0.0; }
+    else { out[12] = k == 0 ? 1.0 : 0.0; out[13] = k == 1 ? 1.0 : 0.0; out[14] = k == 2 ? 1.0 : 0.0; }
 }

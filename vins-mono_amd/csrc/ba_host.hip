@@ -174,7 +174,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     // ---- scratch
     o = 0;
     L.so_imuU = o; o += up((L.K - 1) * 225, 2);
-    L.so_imuJ = o; o += (L.K - 1) * 450;
+    L.so_imuJ = o; o += (L.K - 1) * 512;       // per factor: 465 lower Hessian entries + 30 gradient entries
     L.so_imuR = o; o += up((L.K - 1) * 15, 2);
     L.so_Hp = o; o += L.Ncap * L.Ncap;
     L.so_pr = o; o += L.Ncap;

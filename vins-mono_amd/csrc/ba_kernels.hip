@@ -156,44 +156,63 @@ NOINL void imu_sqrt_info(const Ctx& c) {
     }
 }
 
-// residuals (+ weighted Jacobians) of all IMU factors at state x.  Thread = (factor, column|row).
-// Returns this thread's share of sum r^2.
+// All IMU factors at state x, ONE WAVEFRONT PER FACTOR (8 factors at a time):
+//   lanes 0..29 = Jacobian columns, lane 30 = the residual "column"; every lane evaluates the (cheap) factor context,
+//   weights its column with the upper-triangular U = sqrt_info read from an LDS copy, parks it in LDS, and the
+//   wavefront then forms the factor's 30x30 Hessian block and J^T r from LDS — so the later accumulation into S is
+//   pure adds.  The LDS used here (U copy + one 15x32 panel per wavefront) is the S / staging area, idle in this phase.
+// JAC = false: residual only (candidate cost).  Returns this thread's share of sum r^2.
+//   global scratch: so_imuR [f][15] weighted residual (JAC only), so_imuJ [f][512]: 465 lower Hessian entries + 30 g.
 template <bool JAC>
 NOINL double imu_pass(const Ctx& c, const double* x) {
     const BaLayout& L = *c.Lp;
     const int nimu = L.K - 1;
     const int* valid = c.ia + L.io_imu_valid;
+    double* Us = LDSB + L.l_S;                              // [nimu][225]
+    double* panel = Us + ((nimu * 225 + 1) & ~1) + c.wave * 480;   // [15][32] per wavefront
     double cost = 0.0;
-    const int per = JAC ? 31 : 1;      // 30 Jacobian columns + 1 residual "column"
-    for (int w = c.tid; w < nimu * per; w += BA_NT) {
-        const int f = w / per, col = w % per;
-        if (!valid[f]) continue;
-        const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
-        const double* U = c.sc + L.so_imuU + f * 225;
-        ImuCtx ic;
-        imu_ctx<JAC>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
-        if (!JAC || col == 30) {
-            double* ro = c.sc + L.so_imuR + f * 15;
-#pragma unroll
-            for (int r = 0; r < 15; ++r) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < 15; ++k) s += (k >= r) ? U[r * 15 + k] * ic.r[k] : 0.0;
-                if (JAC) ro[r] = s;
-                cost += s * s;
-            }
-        } else {
+    __syncthreads();
+    for (int k = c.tid; k < nimu * 225; k += BA_NT) Us[k] = c.sc[L.so_imuU + k];
+    __syncthreads();
+    for (int base = 0; base < nimu; base += BA_NW) {
+        const int f = base + c.wave;
+        const bool act = f < nimu && valid[f];
+        if (act) {
+            const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
+            const double* U = Us + f * 225;
+            ImuCtx ic;
+            imu_ctx<JAC>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
             double raw[15];
-            imu_raw_col(ic, pre, col, raw);
-            double* Jo = c.sc + L.so_imuJ + f * 450;
+            if (JAC && c.lane < 30) imu_raw_col(ic, pre, c.lane, raw);
+            else {
 #pragma unroll
-            for (int r = 0; r < 15; ++r) {
-                double s = 0.0;
+                for (int q = 0; q < 15; ++q) raw[q] = ic.r[q];
+            }
+            if (c.lane <= 30) {
 #pragma unroll
-                for (int k = 0; k < 15; ++k) s += (k >= r) ? U[r * 15 + k] * raw[k] : 0.0;
-                Jo[r * 30 + col] = s;
+                for (int r = 0; r < 15; ++r) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) if (k >= r) s += U[r * 15 + k] * raw[k];
+                    if (JAC) panel[r * 32 + c.lane] = s;
+                    if (c.lane == 30) { cost += s * s; if (JAC) c.sc[L.so_imuR + f * 15 + r] = s; }
+                }
             }
         }
+        __syncthreads();
+        if (JAC && act) {
+            double* Ho = c.sc + L.so_imuJ + f * 512;
+            for (int e = c.lane; e < 495; e += 64) {
+                int a, b;
+                if (e < 465) tri_decode(e, a, b);
+                else { a = e - 465; b = 30; }
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < 15; ++r) s += panel[r * 32 + a] * panel[r * 32 + b];
+                Ho[e] = s;
+            }
+        }
+        __syncthreads();
     }
     return cost;
 }
@@ -376,9 +395,8 @@ NOINL void proj_accumulate_chunk(const Ctx& c, int ch) {
     const int nslots = ptr[Kp * Kp];
     for (int task = c.wave; task < ntask; task += BA_NW) {
         // task -> (br >= bc)
-        int br = 0;
-        while ((br + 1) * (br + 2) / 2 <= task) ++br;
-        const int bc = task - br * (br + 1) / 2;
+        int br, bc;
+        tri_decode(task, br, bc);
         const int kr = br < Kp ? 0 : (br == Kp && L.e ? 1 : 2);     // 0 pose, 1 ex, 2 td
         const int kc = bc < Kp ? 0 : (bc == Kp && L.e ? 1 : 2);
         const int dr = kr == 2 ? 1 : 6, dc = kc == 2 ? 1 : 6;
@@ -501,33 +519,24 @@ DEV double linearize(const Ctx& c, const double* x, const double* lam) {
     }
     for (int k = camtri + c.tid; k < fulltri; k += BA_NT) S[k] = 0.0;
     __syncthreads();
-    // ---- IMU J^T J and J^T r: factors k and k+1 share the blocks of frame k+1, so even and odd factors are
-    //      accumulated in two rounds (inside a round every S entry has exactly one writer)
+    // ---- IMU Hessian blocks (precomputed by imu_pass): factors k and k+1 share the blocks of frame k+1, so even and
+    //      odd factors are added in two rounds (inside a round every S entry has exactly one writer)
     {
         const int nimu = L.K - 1;
         const int* valid = c.ia + L.io_imu_valid;
         for (int par = 0; par < 2; ++par) {
             const int nf = (nimu - par + 1) / 2;
-            for (int w = c.tid; w < nf * 495; w += BA_NT) {
-                const int f = 2 * (w / 495) + par, e = w % 495;
-                if (!valid[f]) continue;
-                const double* J = c.sc + L.so_imuJ + f * 450;
+            for (int w = c.tid; w < nf * 512; w += BA_NT) {
+                const int f = 2 * (w >> 9) + par, e = w & 511;
+                if (e >= 495 || !valid[f]) continue;
+                const double v = c.sc[L.so_imuJ + f * 512 + e];
                 if (e < 465) {
-                    int a = 0;
-                    while ((a + 1) * (a + 2) / 2 <= e) ++a;
-                    const int b = e - a * (a + 1) / 2;
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
+                    int a, b;
+                    tri_decode(e, a, b);
                     const int ca = imu_col(L, f, a), cb = imu_col(L, f, b);
-                    S[ca >= cb ? tri(ca, cb) : tri(cb, ca)] += s;
+                    S[ca >= cb ? tri(ca, cb) : tri(cb, ca)] += v;
                 } else {
-                    const int a = e - 465;
-                    const double* r = c.sc + L.so_imuR + f * 15;
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * r[k];
-                    g[imu_col(L, f, a)] += s;
+                    g[imu_col(L, f, e - 465)] += v;
                 }
             }
             __syncthreads();
@@ -554,10 +563,8 @@ DEV double linearize(const Ctx& c, const double* x, const double* lam) {
                     g[ca] += s0 + s1;
                 }
             } else {
-                int a = (int)((sqrt(8.0 * (double)w + 1.0) - 1.0) * 0.5);
-                while (a * (a + 1) / 2 > w) --a;
-                while ((a + 1) * (a + 2) / 2 <= w) ++a;
-                const int b = w - a * (a + 1) / 2;
+                int a, b;
+                tri_decode(w, a, b);
                 const int ca = pmap[a], cb = pmap[b];
                 if (ca >= 0 && cb >= 0) S[ca >= cb ? tri(ca, cb) : tri(cb, ca)] += Hp[a * L.Ncap + b];
             }
@@ -599,10 +606,8 @@ NOINL double build_scaled(const Ctx& c, double mu) {
     const int n = R * (R + 1) / 2;
     double q = 0.0;
     for (int w = c.tid; w < n; w += BA_NT) {
-        int a = (int)((sqrt(8.0 * (double)w + 1.0) - 1.0) * 0.5);
-        while (a * (a + 1) / 2 > w) --a;
-        while ((a + 1) * (a + 2) / 2 <= w) ++a;
-        const int b = w - a * (a + 1) / 2;
+        int a, b;
+        tri_decode(w, a, b);
         double v = S[w] * sc[a] * sc[b];
         q += v * tv[a] * tv[b] * (a == b ? 1.0 : 2.0);
         if (a == b) v += mu * dg[a] * dg[a];
@@ -638,9 +643,9 @@ NOINL void schur_mfma(const Ctx& c, double mu) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int t = c.wave + s * BA_NW;
-        int a = 0;
-        while ((a + 1) * (a + 2) / 2 <= t) ++a;
-        tm[s] = a; tn[s] = t - a * (a + 1) / 2;
+        int a, bq;
+        tri_decode(t, a, bq);
+        tm[s] = a; tn[s] = bq;
     }
     double* bd = wd + RcPad * 17;
     double* lsc = c.sc + L.so_yl;                 // sl / sqrt(h~): yl is free until the back substitution
@@ -799,9 +804,8 @@ NOINL bool cholesky_aug(const Ctx& c) {
             const int m = nt - t0;
             const int ntile = m * (m + 1) / 2;
             for (int t = c.wave; t < ntile; t += BA_NW) {
-                int tr_ = 0;
-                while ((tr_ + 1) * (tr_ + 2) / 2 <= t) ++tr_;
-                const int tc_ = t - tr_ * (tr_ + 1) / 2;
+                int tr_, tc_;
+                tri_decode(t, tr_, tc_);
                 const int ti = t0 + tr_, tk = t0 + tc_;
                 const int arow = 16 * ti + (lane & 15), brow = 16 * tk + (lane & 15);
                 const bool interior = (16 * ti + 15 <= R) && (ti != tk);     // wave-uniform
@@ -970,10 +974,8 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
         }
         __syncthreads();
         for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
-            int a = (int)((sqrt(8.0 * (double)wk + 1.0) - 1.0) * 0.5);
-            while (a * (a + 1) / 2 > wk) --a;
-            while ((a + 1) * (a + 2) / 2 <= wk) ++a;
-            const int bb = wk - a * (a + 1) / 2;
+            int a, bb;
+            tri_decode(wk, a, bb);
             double s0 = 0.0, s1 = 0.0;
             int r = 0;
             for (; r + 1 < n; r += 2) { s0 += J0s[r * n + a] * J0s[r * n + bb]; s1 += J0s[(r + 1) * n + a] * J0s[(r + 1) * n + bb]; }
@@ -1324,12 +1326,27 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_eval_factors_kernel(co
     __syncthreads();
     imu_sqrt_info(c);
     __syncthreads();
-    imu_pass<true>(c, x);
     prior_pass(c, x, c.sc + L.so_pr);
     __syncthreads();
     const int nimu = L.K - 1;
-    for (int k = c.tid; k < nimu * 15; k += BA_NT) if (imu_r) imu_r[k] = c.sc[L.so_imuR + k];
-    for (int k = c.tid; k < nimu * 450; k += BA_NT) if (imu_J) imu_J[k] = c.sc[L.so_imuJ + k];
+    // weighted IMU residual / Jacobian, thread = (factor, column | residual); U = sqrt_info from imu_sqrt_info
+    for (int w = c.tid; w < nimu * 31; w += BA_NT) {
+        const int f = w / 31, col = w % 31;
+        if (!c.ia[L.io_imu_valid + f]) continue;
+        const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
+        const double* U = c.sc + L.so_imuU + f * 225;
+        ImuCtx ic;
+        imu_ctx<true>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
+        double raw[15];
+        if (col < 30) imu_raw_col(ic, pre, col, raw);
+        else { for (int q = 0; q < 15; ++q) raw[q] = ic.r[q]; }
+        for (int r = 0; r < 15; ++r) {
+            double s = 0.0;
+            for (int k = r; k < 15; ++k) s += U[r * 15 + k] * raw[k];
+            if (col < 30) { if (imu_J) imu_J[(size_t)f * 450 + r * 30 + col] = s; }
+            else if (imu_r) imu_r[f * 15 + r] = s;
+        }
+    }
     for (int k = c.tid; k < c.nprior; k += BA_NT) if (prior_r) prior_r[k] = c.sc[L.so_pr + k];
     const double* ex = st_ex(L, x);
     const double* lam = c.di + L.do_lam;

@@ -7,6 +7,14 @@
 
 #define DEV __device__ __forceinline__
 
+// packed-lower-triangle index w -> (a, b), b <= a, without loops (float sqrt + one fix-up; exact for w < 2^22)
+DEV void tri_decode(int w, int& a, int& b) {
+    int t = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
+    t = (t * (t + 1) / 2 > w) ? t - 1 : t;
+    t = ((t + 1) * (t + 2) / 2 <= w) ? t + 1 : t;
+    a = t; b = w - t * (t + 1) / 2;
+}
+
 DEV void q_mul(const double* a, const double* b, double* o) {
     const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
     const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
@@ -16,12 +24,13 @@ DEV void q_mul(const double* a, const double* b, double* o) {
     o[3] = aw * bw - ax * bx - ay * by - az * bz;
 }
 DEV void q_inv(const double* q, double* o) {
-    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-    o[0] = -q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = q[3] / n2;
+    // one reciprocal instead of four divisions (an f64 divide is ~40 instructions on gfx950)
+    const double inv = 1.0 / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    o[0] = -q[0] * inv; o[1] = -q[1] * inv; o[2] = -q[2] * inv; o[3] = q[3] * inv;
 }
 DEV void q_normalize(double* q) {
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+    const double inv = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
 // Eigen::Quaternion::toRotationMatrix (no normalisation), row-major 3x3
 DEV void q_to_R(const double* q, double* R) {

@@ -384,23 +384,42 @@ extern "C" __global__ __launch_bounds__(256) void fe_candidates_kernel(FeDev d, 
     const double maxVal = (mf == -INFINITY) ? 0.0 : (double)mf;
     const float thr = (float)(maxVal * quality);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < 1 || y < 1 || x >= W - 1 || y >= H - 1) return;
-    const float* e = d.eig + (size_t)cam * W * H;
-    const float raw = e[(size_t)y * W + x];
-    const float val = raw > thr ? raw : 0.f;
-    if (val == 0.f || !d.mask[(size_t)cam * W * H + (size_t)y * W + x]) return;
-    float mx = val;
+    bool is_cand = false;
+    float val = 0.f;
+    if (x >= 1 && y >= 1 && x < W - 1 && y < H - 1) {
+        const float* e = d.eig + (size_t)cam * W * H;
+        const float raw = e[(size_t)y * W + x];
+        val = raw > thr ? raw : 0.f;
+        if (val != 0.f && d.mask[(size_t)cam * W * H + (size_t)y * W + x]) {
+            float mx = val;
 #pragma unroll
-    for (int v = -1; v <= 1; ++v)
+            for (int v = -1; v <= 1; ++v)
 #pragma unroll
-        for (int u = -1; u <= 1; ++u) {
-            const float o = e[(size_t)(y + v) * W + x + u];
-            mx = fmaxf(mx, o > thr ? o : 0.f);
+                for (int u = -1; u <= 1; ++u) {
+                    const float o = e[(size_t)(y + v) * W + x + u];
+                    mx = fmaxf(mx, o > thr ? o : 0.f);
+                }
+            is_cand = (val == mx);
         }
-    if (val != mx) return;
-    const unsigned slot = atomicAdd(&d.ncand[cam], 1u);
-    if (slot < (unsigned)d.cand_cap)
-        d.keys[(size_t)cam * d.cand_cap + slot] = ((unsigned long long)ford(val) << 32) | (unsigned)(y * W + x);
+    }
+    // block-aggregated append: one global atomic per workgroup (the final order comes from the sort)
+    __shared__ unsigned wcount[4], wbase[4];
+    const unsigned long long bal = __ballot(is_cand);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned my = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wcount[wv] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        const unsigned base = tot ? atomicAdd(&d.ncand[cam], tot) : 0u;
+        wbase[0] = base; wbase[1] = base + wcount[0]; wbase[2] = wbase[1] + wcount[1]; wbase[3] = wbase[2] + wcount[2];
+    }
+    __syncthreads();
+    if (is_cand) {
+        const unsigned slot = wbase[wv] + my;
+        if (slot < (unsigned)d.cand_cap)
+            d.keys[(size_t)cam * d.cand_cap + slot] = ((unsigned long long)ford(val) << 32) | (unsigned)(y * W + x);
+    }
 }
 
 // one workgroup (1024 threads) per camera: in-place bitonic sort (descending) of the candidate keys, padded with 0
