@@ -216,7 +216,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         // LDS of the marginalization kernel: [eigM ld^2][eigV ld^2][cs 2 ld][red 16][state][ints 256]
         const int nstm = up(16 * L.K + 8 + 1, 2);
         L.mg_cs = up(std::max(2 * mcap, 3 * (L.mg_posmax / 2 + 2)), 2);
-        const int fixed = 16 + nstm + 128 + L.mg_cs;
+        const int fixed = 32 + nstm + 128 + L.mg_cs;
         int ld = mcap;                               // big enough for the kept part; also used for Amm when m <= ld
         while (2 * ld * ld + fixed > 160 * 1024 / 8) ld -= 2;
         L.mg_ld = ld;
@@ -509,7 +509,7 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
                 const double* mo = B.h_mout.data() + (size_t)w * L.mo_stride;
                 const int* mi = B.h_miout.data() + (size_t)w * L.mi_stride;
                 q->valid = mi[0];
-                if (getenv("VG_DEBUG_MARG")) fprintf(stderr, "[marg] eig2: sweeps=%d total_kcyc=%d rot_kcyc=%d blk_kcyc=%d V_kcyc=%d sync_kcyc=%d\n", mi[5] & 255, mi[5] >> 8, mi[6], mi[7], mi[4], mi[2]);
+                if (getenv("VG_DEBUG_MARG")) fprintf(stderr, "[marg] eig2: sweeps=%d total_kcyc=%d rot_kcyc=%d blkV_kcyc=%d | total kernel kcyc=%d\n", mi[5] & 255, mi[5] >> 8, mi[6], mi[7], mi[4]);
                 if (mi[0]) {
                     const int n = mi[1], nb = mi[3];
                     if (n > q->cap || nb > q->cap_blocks) { h->err = "vg_ba_prior capacity too small"; return VG_ERR_BAD_ARG; }

@@ -17,6 +17,8 @@
 #include "ba_factors.h"
 #include "../../include/vinsgpu.h"
 
+#define MG_NT 1024                 // 16 wavefronts: the Jacobi rounds are LDS-latency bound, more waves in flight
+#define MG_NW (MG_NT / 64)
 #define MG_EPS 1e-8
 #define MG_MAXSWEEP 30
 
@@ -30,6 +32,14 @@ struct MCtx {
     double focal, tr, row, gnorm;
 };
 
+// 1/sqrt(x): hardware seed + two Newton steps
+DEV double mg_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
 DEV double mg_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -42,14 +52,14 @@ DEV double mg_block_sum(const MCtx& c, double* red, double v) {
     __syncthreads();
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < BA_NW; ++w) s += red[w];
+    for (int w = 0; w < MG_NW; ++w) s += red[w];
     return s;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Parallel two-sided Jacobi eigen-decomposition of the symmetric n x n matrix M (leading dimension ld).
 // On exit diag(M) = eigenvalues, V (ld x ld, row-major) holds the eigenvectors as COLUMNS.
-// `cs` is an LDS scratch of 2*ld doubles, `red` of BA_NW doubles.
+// `cs` is an LDS scratch of 2*ld doubles, `red` of MG_NW doubles.
 // INLDS = true: M, V are offsets (in doubles) into the dynamic LDS block (address space known to the compiler ->
 // ds_read / ds_write); INLDS = false: generic pointers to the global-memory fallback buffers.
 template <bool INLDS>
@@ -60,14 +70,14 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
     double* red = MG_LDS + offred;
     const int N = (n + 1) & ~1;           // even player count (a padding player has zero row/col)
     const int half = N / 2;
-    for (int k = c.tid; k < ld * ld; k += BA_NT) {
+    for (int k = c.tid; k < ld * ld; k += MG_NT) {
         const int i = k / ld, j = k % ld;
         V[k] = (i == j) ? 1.0 : 0.0;
         if (i >= n || j >= n) M[k] = 0.0;
     }
     __syncthreads();
     double fro = 0.0;
-    for (int k = c.tid; k < n * n; k += BA_NT) { const double v = M[(k / n) * ld + k % n]; fro += v * v; }
+    for (int k = c.tid; k < n * n; k += MG_NT) { const double v = M[(k / n) * ld + k % n]; fro += v * v; }
     fro = mg_block_sum(c, red, fro);
     // stopping rule: a pair is rotated unless |a_pq| <= 1e-16 sqrt(|a_pp a_qq|) (relative accuracy for the small
     // eigenvalues, which the eps = 1e-8 cut and the 1/lambda of the pseudo-inverse are sensitive to) or
@@ -78,7 +88,7 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
     //                   reference guarantees — which saves ~1/3 of the sweeps on the kept block.
     const double floor_abs = sqrt(fro) * (relative ? 1e-17 : 1e-16);
     const double relf = relative ? 1e-16 : 0.0;
-    if (c.tid == 0) { red[10] = red[11] = red[12] = red[13] = 0.0; }
+    if (c.tid == 0) { red[20] = red[21] = red[22] = red[23] = 0.0; }
     int sweep = 0;
     for (; sweep < MG_MAXSWEEP; ++sweep) {
         double nrot = 0.0;
@@ -88,7 +98,7 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
 #endif
             // pair k of this round: (p,q), p < q; table in LDS so that the owners below need no div / mod
             int* pq = (int*)(cs + 2 * half);          // [2*half] ints
-            for (int k = c.tid; k < half; k += BA_NT) {
+            for (int k = c.tid; k < half; k += MG_NT) {
                 int p, q;
                 if (k == 0) { p = N - 1; q = r; }
                 else { p = r + k; if (p >= N - 1) p -= N - 1; q = r - k; if (q < 0) q += N - 1; }
@@ -98,8 +108,9 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
                     const double apq = M[p * ld + q], app = M[p * ld + p], aqq = M[q * ld + q];
                     if (fabs(apq) > floor_abs && fabs(apq) > relf * sqrt(fabs(app * aqq))) {
                         const double theta = (aqq - app) / (2.0 * apq);
-                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        cc = 1.0 / sqrt(t * t + 1.0);
+                        const double h2 = theta * theta + 1.0;
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + h2 * mg_rsqrt(h2));
+                        cc = mg_rsqrt(t * t + 1.0);
                         ss = t * cc;
                         nrot += 1.0;
                     }
@@ -120,11 +131,11 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
                 const double cb = cs[2 * kb], sb = cs[2 * kb + 1];
                 const bool sv = s < n;
                 const int sc_ = sv ? s : rr;
-                double m00[6], m01[6], m10[6], m11[6];
-                int pa[6], qa[6];
+                double m00[3], m01[3], m10[3], m11[3];
+                int pa[3], qa[3];
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const int ka = c.wave + BA_NW * t;
+                for (int t = 0; t < 3; ++t) {
+                    const int ka = c.wave + MG_NW * t;
                     const int kac = ka < half ? ka : 0;
                     const int p = pq[2 * kac], q = pq[2 * kac + 1];
                     const int qc = q < n ? q : p;
@@ -132,8 +143,8 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
                     m00[t] = M[p * ld + rr]; m01[t] = M[p * ld + sc_]; m10[t] = M[qc * ld + rr]; m11[t] = M[qc * ld + sc_];
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const int ka = c.wave + BA_NW * t;
+                for (int t = 0; t < 3; ++t) {
+                    const int ka = c.wave + MG_NW * t;
                     const int kac = ka < half ? ka : 0;
                     const double ca = cs[2 * kac], sa = cs[2 * kac + 1];
                     const bool qv = qa[t] < n;
@@ -145,8 +156,8 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
                     if (ka == kb) { m01[t] = 0.0; m10[t] = 0.0; }
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const int ka = c.wave + BA_NW * t;
+                for (int t = 0; t < 3; ++t) {
+                    const int ka = c.wave + MG_NW * t;
                     if (ka < half && c.lane < half) {
                         const bool qv = qa[t] < n;
                         M[pa[t] * ld + rr] = m00[t];
@@ -156,23 +167,23 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
                     }
                 }
                 // V <- V J_b : wavefront = rows (strided), lane = pair; same load-all / store-all structure
-                double v0[12], v1[12];
+                double v0[6], v1[6];
 #pragma unroll
-                for (int t = 0; t < 12; ++t) {
-                    const int i = c.wave + BA_NW * t;
+                for (int t = 0; t < 6; ++t) {
+                    const int i = c.wave + MG_NW * t;
                     const int ic = i < n ? i : 0;
                     v0[t] = V[ic * ld + rr]; v1[t] = V[ic * ld + sc_];
                 }
 #pragma unroll
-                for (int t = 0; t < 12; ++t) {
-                    const int i = c.wave + BA_NW * t;
+                for (int t = 0; t < 6; ++t) {
+                    const int i = c.wave + MG_NW * t;
                     if (i < n && sv && c.lane < half) {
                         V[i * ld + rr] = cb * v0[t] - sb * v1[t];
                         V[i * ld + s] = sb * v0[t] + cb * v1[t];
                     }
                 }
             } else {
-                for (int ka = c.wave; ka < half; ka += BA_NW) {
+                for (int ka = c.wave; ka < half; ka += MG_NW) {
                     const int p = pq[2 * ka], q = pq[2 * ka + 1];
                     const double ca = cs[2 * ka], sa = cs[2 * ka + 1];
                     const bool qv = q < n;
@@ -194,7 +205,7 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
                         if (qv && sv) M[q * ld + s] = n11;
                     }
                 }
-                for (int i = c.wave; i < n; i += BA_NW) {
+                for (int i = c.wave; i < n; i += MG_NW) {
                     for (int kb = c.lane; kb < half; kb += 64) {
                         const int rr = pq[2 * kb], s = pq[2 * kb + 1];
                         if (s >= n) continue;
@@ -210,7 +221,7 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
 #endif
             __syncthreads();
 #ifdef BA_PROFILE
-            if (c.tid == 0) { red[10] += (double)(_tb - _ta); red[11] += (double)(_td - _tb); red[13] += (double)(clock64() - _td); }
+            if (c.tid == 0) { red[20] += (double)(_tb - _ta); red[21] += (double)(_td - _tb); red[23] += (double)(clock64() - _td); }
 #endif
         }
         if (mg_block_sum(c, red, nrot) == 0.0) break;
@@ -228,7 +239,7 @@ struct MgMap {
     int* l0;     // global: [Lcap] list of frame-0 landmarks
 };
 
-extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
     const BaLayout& L = *Lp;
     MCtx c;
     c.Lp = Lp;
@@ -261,7 +272,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
     double* eV = eM + ld * ld;
     double* cs = eV + ld * ld;
     double* red = cs + L.mg_cs;
-    double* x = red + 16;
+    double* x = red + 32;
     const int nst = (7 * K + 9 * K + 8 + 1) & ~1;
     int* li = (int*)(x + nst);
     MgMap mp;
@@ -283,8 +294,8 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
     mp.l0 = mp.lm + L.Lcap;
 
     // ---- state after the gauge fix (what vector2double() repacks at estimator.cpp:831 / :942)
-    for (int k = c.tid; k < 7 * K; k += BA_NT) x[k] = outp[L.oo_pose + k];
-    for (int k = c.tid; k < 9 * K; k += BA_NT) x[7 * K + k] = outp[L.oo_sb + k];
+    for (int k = c.tid; k < 7 * K; k += MG_NT) x[k] = outp[L.oo_pose + k];
+    for (int k = c.tid; k < 9 * K; k += MG_NT) x[7 * K + k] = outp[L.oo_sb + k];
     if (c.tid < 7) x[16 * K + c.tid] = outp[L.oo_ex + c.tid];
     if (c.tid == 7) x[16 * K + 7] = outp[L.oo_td];
     const double* lam = outp + L.oo_lam;
@@ -346,14 +357,14 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
     if (!mp.misc[6]) { if (c.tid == 0) { mi[0] = 0; mi[1] = 0; } return; }
     const int cex = mp.misc[0], ctd = mp.misc[1];
 
-    for (int k = c.tid; k < pos * pos; k += BA_NT) A[(k / pos) * posmax + k % pos] = 0.0;
-    for (int k = c.tid; k < pos; k += BA_NT) bv[k] = 0.0;
+    for (int k = c.tid; k < pos * pos; k += MG_NT) A[(k / pos) * posmax + k % pos] = 0.0;
+    for (int k = c.tid; k < pos; k += MG_NT) bv[k] = 0.0;
     __syncthreads();
 
     // ---- M1/M3 (a): prior factor at the new state: r = r0 + J0 dx ; A += J0^T J0 ; b += J0^T r
     if (nblk > 0) {
         double* dx = prv + L.Ncap;
-        for (int b = c.tid; b < nblk; b += BA_NT) {
+        for (int b = c.tid; b < nblk; b += MG_NT) {
             const double* xb = pk[b] == VG_BLK_POSE ? x + 7 * pidx[b] : (pk[b] == VG_BLK_SPEEDBIAS ? x + 7 * K + 9 * pidx[b]
                                : (pk[b] == VG_BLK_EXPOSE ? ex : ex + 7));
             const double* x0 = c.di + L.do_px0 + px0off[b];
@@ -371,7 +382,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
         }
         __syncthreads();
         const double* J0t = c.di + L.do_pJ0t;
-        for (int r = c.tid; r < nprior; r += BA_NT) {
+        for (int r = c.tid; r < nprior; r += MG_NT) {
             double s = c.di[L.do_pr0 + r];
             for (int k = 0; k < nprior; ++k) s += J0t[k * L.Ncap + r] * dx[k];
             prv[r] = s;
@@ -379,7 +390,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
         __syncthreads();
         const double* Hp = c.sc + L.so_Hp;          // J0^T J0 (lower), left by the solve kernel
         const double* J0 = c.di + L.do_pJ0;
-        for (int wk = c.tid; wk < nprior * nprior + nprior; wk += BA_NT) {
+        for (int wk = c.tid; wk < nprior * nprior + nprior; wk += MG_NT) {
             const bool isg = wk >= nprior * nprior;
             const int a = isg ? wk - nprior * nprior : wk / nprior, b = isg ? 0 : wk % nprior;
             int ca = -1, cb = -1;
@@ -424,7 +435,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
             }
         }
         __syncthreads();
-        for (int wk = c.tid; wk < 930; wk += BA_NT) {
+        for (int wk = c.tid; wk < 930; wk += MG_NT) {
             const bool isg = wk >= 900;
             const int a = isg ? wk - 900 : wk / 30, b = isg ? 0 : wk % 30;
             auto colof = [&](int lc) {
@@ -445,7 +456,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
         // compact factor list: factors of L0 landmarks are the contiguous runs lm_fbeg[l]..; enumerate
         // record layout (42): r[2] | Ji[12] | Jj[12] | Jex[12] | Jl[2] | Jtd[2], rows interleaved as [row][col]
         for (int k = 0; k < n0; ++k) nf0 += c.ia[L.io_lm_fbeg + mp.l0[k] + 1] - c.ia[L.io_lm_fbeg + mp.l0[k]];
-        for (int wk = c.tid; wk < c.hdr[H_F]; wk += BA_NT) {
+        for (int wk = c.tid; wk < c.hdr[H_F]; wk += MG_NT) {
             const int f = wk;
             const int l = c.ia[L.io_fac_lm + f];
             if (mp.lm[l] < 0) continue;
@@ -464,7 +475,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
         __syncthreads();
         // owners of the dense camera part: entries (a, b) over columns of {pose*, ex, td}; loop over factors
         const int ncam = 6 * K + 7;
-        for (int wk = c.tid; wk < ncam * ncam + ncam; wk += BA_NT) {
+        for (int wk = c.tid; wk < ncam * ncam + ncam; wk += MG_NT) {
             const bool isg = wk >= ncam * ncam;
             const int a = isg ? wk - ncam * ncam : wk / ncam, b = isg ? 0 : wk % ncam;
             // decode camera index -> (block kind, frame, component)
@@ -498,7 +509,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
             if (isg) bv[ca] += s; else A[ca * posmax + cb] += s;
         }
         // landmark rows / columns: thread per (landmark, camera column | self | rhs)
-        for (int wk = c.tid; wk < n0 * (ncam + 2); wk += BA_NT) {
+        for (int wk = c.tid; wk < n0 * (ncam + 2); wk += MG_NT) {
             const int k = wk / (ncam + 2), a = wk % (ncam + 2);
             const int l = mp.l0[k], cl = mp.lm[l];
             int ca = -2;
@@ -533,7 +544,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
         double* Mm = in_lds ? eM : gM;
         double* Vm = in_lds ? eV : gV;
         const int ldm = in_lds ? ld : posmax;
-        for (int k = c.tid; k < m * m; k += BA_NT) {
+        for (int k = c.tid; k < m * m; k += MG_NT) {
             const int i = k / m, j = k % m;
             Mm[i * ldm + j] = 0.5 * (A[i * posmax + j] + A[j * posmax + i]);
         }
@@ -550,7 +561,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
         (void)sw1;
 #endif
         // T1 = Lambda^+ V^T [Amr | bmm]   (m x (n+1))
-        for (int k = c.tid; k < m * (n + 1); k += BA_NT) {
+        for (int k = c.tid; k < m * (n + 1); k += MG_NT) {
             const int i = k / (n + 1), j = k % (n + 1);
             const double lamb = Mm[i * ldm + i];
             double s = 0.0;
@@ -562,7 +573,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
         }
         __syncthreads();
         // T2 = V T1  = Amm^+ [Amr | bmm]
-        for (int k = c.tid; k < m * (n + 1); k += BA_NT) {
+        for (int k = c.tid; k < m * (n + 1); k += MG_NT) {
             const int i = k / (n + 1), j = k % (n + 1);
             double s = 0.0;
             for (int r = 0; r < m; ++r) s += Vm[i * ldm + r] * T1[r * (mcap + 1) + j];
@@ -570,7 +581,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
         }
         __syncthreads();
         // A' = Arr - Arm T2[:, :n] ; b' = brr - Arm T2[:, n]   -> eM (n x n, ld), b' -> T1 row 0 (reuse)
-        for (int k = c.tid; k < n * (n + 1); k += BA_NT) {
+        for (int k = c.tid; k < n * (n + 1); k += MG_NT) {
             const int i = k / (n + 1), j = k % (n + 1);
             double s = (j < n) ? A[(m + i) * posmax + m + j] : bv[m + i];
             for (int r = 0; r < m; ++r) s -= A[(m + i) * posmax + r] * T2[r * (mcap + 1) + j];
@@ -583,7 +594,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
     double* M2 = n_lds ? eM : g2M;
     double* V2 = n_lds ? eV : g2V;
     const int ld2 = n_lds ? ld : n;
-    for (int k = c.tid; k < n * n; k += BA_NT) M2[(k / n) * ld2 + k % n] = gM[(k / n) * posmax + k % n];
+    for (int k = c.tid; k < n * n; k += MG_NT) M2[(k / n) * ld2 + k % n] = gM[(k / n) * posmax + k % n];
     __syncthreads();
 #ifdef BA_PROFILE
     const long long _t2 = clock64();
@@ -592,13 +603,13 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
     const int sw2 = n_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, n, ld2, offcs2, offred2, false)
                           : jacobi_eig<false>(c, M2, V2, 0, 0, n, ld2, offcs2, offred2, false);
 #ifdef BA_PROFILE
-    if (c.tid == 0) { mi[5] = sw2 | ((int)((clock64() - _t2) >> 10) << 8); mi[6] = (int)red[10] >> 10; mi[7] = (int)red[11] >> 10; mi[4] = (int)red[12] >> 10; }
+    if (c.tid == 0) { mi[5] = sw2 | ((int)((clock64() - _t2) >> 10) << 8); mi[6] = (int)red[20] >> 10; mi[7] = (int)red[21] >> 10; }
 #else
     (void)sw2;
 #endif
     // ascending order like SelfAdjointEigenSolver: rank of each eigenvalue
     int* rank = li + 48;
-    for (int i = c.tid; i < n; i += BA_NT) {
+    for (int i = c.tid; i < n; i += MG_NT) {
         const double li_ = M2[i * ld2 + i];
         int rk = 0;
         for (int j = 0; j < n; ++j) {
@@ -609,13 +620,13 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
     }
     __syncthreads();
     // linearized_jacobians = diag(sqrt(S)) V^T ; linearized_residuals = diag(sqrt(S_inv)) V^T b'
-    for (int k = c.tid; k < n * n; k += BA_NT) {
+    for (int k = c.tid; k < n * n; k += MG_NT) {
         const int i = k / n, j = k % n;           // eigenpair i, column j
         const double lamb = M2[i * ld2 + i];
         const double sv = lamb > MG_EPS ? sqrt(lamb) : 0.0;
         mo[L.mo_J0 + (size_t)rank[i] * mcap + j] = sv * V2[j * ld2 + i];
     }
-    for (int i = c.tid; i < n; i += BA_NT) {
+    for (int i = c.tid; i < n; i += MG_NT) {
         const double lamb = M2[i * ld2 + i];
         double s = 0.0;
         if (lamb > MG_EPS) {
@@ -647,6 +658,9 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_marg_kernel(const BaLa
         if (cex >= 0) { kind[nb] = VG_BLK_EXPOSE; idx[nb] = 0; for (int k = 0; k < 7; ++k) x0[x0o + k] = ex[k]; x0o += 7; ++nb; }
         if (ctd >= 0) { kind[nb] = VG_BLK_TD; idx[nb] = 0; x0[x0o++] = ex[7]; ++nb; }
         mi[0] = 1; mi[1] = n; mi[2] = m; mi[3] = nb;
+#ifdef BA_PROFILE
+        mi[4] = (int)((clock64() - _tstart) >> 10);
+#endif
     }
 }
 
@@ -657,6 +671,6 @@ extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaLayout* dL, cons
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(ba_marg_kernel, dim3(L.nwin), dim3(BA_NT), L.mg_lds_bytes, stream, dL, P);
+    hipLaunchKernelGGL(ba_marg_kernel, dim3(L.nwin), dim3(MG_NT), L.mg_lds_bytes, stream, dL, P);
     return hipGetLastError();
 }
