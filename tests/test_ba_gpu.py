@@ -210,3 +210,89 @@ def test_marginalize_second_new_keeps_old_prior_when_pose_absent(handle):
         pytest.skip("prior touches pose K-2 for this seed")
     _, _, pr_g = handle.ba_optimize(prob2, ba.VG_MARGIN_SECOND_NEW)
     assert pr_g is None        # valid == 0: caller keeps last_marginalization_info (estimator.cpp:935-936)
+
+
+# ---------------------------------------------------------------------------------------- edge cases / full size
+def test_relocalisation_factors(handle):
+    """estimator.cpp:769-801: extra ProjectionFactors to a relocalisation pose (an extra pose block)."""
+    seq = synth.SyntheticSequence(51, L=40)
+    prob = seq.window(0)
+    # loop frame = a perturbed copy of frame 3; matches for landmarks whose track starts at or before frame 3
+    relo_pose = prob['pose'][3].copy()
+    relo_pose[:3] += [0.05, -0.03, 0.02]
+    match = []
+    c = seq.cfg
+    Rr, Pr = B.q2R(relo_pose[3:]), relo_pose[:3]
+    for l in range(len(prob['inv_depth'])):
+        if prob['lm_start'][l] <= 3 and len(match) < 15:
+            s = int(prob['lm_start'][l])
+            o = prob['obs'][int(prob['obs_off'][l])]
+            pc = np.array([o[0], o[1], 1.0]) / prob['inv_depth'][l]
+            Xw = B.q2R(prob['pose'][s][3:]) @ (c['ric'] @ pc + c['tic']) + prob['pose'][s][:3]
+            p = c['ric'].T @ (Rr.T @ (Xw - Pr) - c['tic'])
+            match.append((l, p[0] / p[2], p[1] / p[2]))
+    prob['relo'] = dict(pose=relo_pose, match=match)
+    x, summ = B.solve(prob)
+    ref = B.double2vector(prob, x)
+    st, sm, _ = handle.ba_optimize(prob)
+    assert sm['status'] == 0 and sm['num_iterations'] == summ['num_iterations']
+    assert np.isclose(sm['final_cost'], summ['final_cost'], rtol=1e-6)
+    assert np.abs(st['pose'] - ref['pose']).max() < 1e-6 and np.abs(st['inv_depth'] - ref['inv_depth']).max() < 1e-6
+
+
+def test_no_landmarks_and_skipped_imu_factor(handle):
+    """IMU + prior only (every track filtered out), and one pre-integration longer than 10 s (estimator.cpp:714)."""
+    _, _, prob = _window_with_prior(52, L=30)
+    prob = dict(prob)
+    prob.update(inv_depth=np.zeros(0), lm_start=np.zeros(0, np.int32), lm_nobs=np.zeros(0, np.int32), obs_off=np.zeros(0, np.int32),
+                obs=np.zeros((0, 7)))
+    prob['imu'] = [dict(m) for m in prob['imu']]
+    prob['imu'][4]['sum_dt'] = 10.5                  # -> factor skipped on both sides
+    x, summ = B.solve(prob)
+    ref = B.double2vector(prob, x)
+    st, sm, _ = handle.ba_optimize(prob)
+    assert sm['status'] == 0 and sm['num_iterations'] == summ['num_iterations']
+    assert np.isclose(sm['final_cost'], summ['final_cost'], rtol=1e-6, atol=1e-9)
+    assert np.abs(st['pose'] - ref['pose']).max() < 1e-6 and np.abs(st['sb'] - ref['sb']).max() < 1e-6
+
+
+def test_iteration_limits(handle):
+    prob = synth.SyntheticSequence(53, L=30).window(0)
+    for iters in (0, 1, 3):
+        p = dict(prob)
+        p['max_iters'] = iters
+        x, summ = B.solve(p)
+        st, sm, _ = handle.ba_optimize(p)
+        assert sm['num_iterations'] == summ['num_iterations'] == iters
+        assert np.isclose(sm['final_cost'], summ['final_cost'], rtol=1e-7)
+
+
+def test_full_size_batch_against_cpp_oracle(handle):
+    """BASELINE configs[3] shape: 24 EuRoC-size windows (150 landmarks, prior) in one launch vs oracle/ba_cpu.cpp;
+    acceptance = BASELINE.json north_star: states within 1e-4 relative."""
+    from oracle import ba_cpu
+    seqs = [synth.SyntheticSequence(600 + s) for s in range(24)]
+    first = [q.window(0) for q in seqs]
+    handle.ba_upload(first, [ba.VG_MARGIN_OLD] * len(first))
+    handle.ba_run_async()
+    st1, sm1, pr1 = handle.ba_download()
+    probs = [q.next_window(st1[i], pr1[i], 1) for i, q in enumerate(seqs)]
+    handle.ba_upload(probs, [ba.VG_MARGIN_OLD] * len(probs))
+    handle.ba_run_async()
+    st2, sm2, pr2 = handle.ba_download()
+    worst = 0.0
+    for i, p in enumerate(probs):
+        ref, sref, pref = ba_cpu.optimize(p, ba.VG_MARGIN_OLD)
+        assert sm2[i]['status'] == 0 and sm2[i]['num_iterations'] == sref['num_iterations']
+        e = max(np.abs(st2[i]['pose'][:, :3] - ref['pose'][:, :3]).max() / max(1.0, np.abs(ref['pose'][:, :3]).max()),
+                np.abs(st2[i]['pose'][:, 3:] - ref['pose'][:, 3:]).max(),
+                np.abs(st2[i]['sb'] - ref['sb']).max() / max(1.0, np.abs(ref['sb']).max()))
+        worst = max(worst, e)
+        assert pr2[i]['blocks'] == pref['blocks'] and pr2[i]['n'] == pref['n']
+    assert worst < 1e-4, worst
+    # size-independent properties of the outputs: unit quaternions, frame-0 gauge (position + yaw) preserved
+    for i, p in enumerate(probs):
+        assert np.allclose(np.linalg.norm(st2[i]['pose'][:, 3:], axis=1), 1.0, atol=1e-12)
+        assert np.allclose(st2[i]['pose'][0, :3], p['pose'][0, :3], atol=1e-12)
+        y0, y1 = B.R2ypr(B.q2R(p['pose'][0, 3:]))[0], B.R2ypr(B.q2R(st2[i]['pose'][0, 3:]))[0]
+        assert abs(y0 - y1) < 1e-9

@@ -150,3 +150,22 @@ def test_batched_streams_match_single(handle, frames):
     for (p, q), pts, (got, st, err) in zip(((a, b), (b, c), (c, a)), corners, res):
         ref, rst, _ = F.lk(p, q, pts)
         assert np.array_equal(st, rst) and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_other_image_size_and_stride(handle):
+    """640x480 (divisible by 8 -> CLAHE ok), frames handed over as strided views."""
+    w, h = 640, 480
+    big = synth.synth_frame(31, 752, 480)
+    a = np.ascontiguousarray(big[:, 50:50 + w])
+    b = np.ascontiguousarray(synth.warp_frame(big, 32)[:, 50:50 + w])
+    tr = fe.FrontEnd(handle, w, h, 1, 200)
+    tr.push_frames([a], equalize=True)
+    ea, eb = F.clahe(a), F.clahe(b)
+    pts = tr.detect(0, 200, 0.02, 25.0)
+    assert np.array_equal(pts, F.gftt(ea, 200, 0.02, 25.0))
+    tr.push_frames([b], equalize=True)
+    got, st, err = tr.track(0, pts)
+    ref, rst, rerr = F.lk(ea, eb, pts)
+    assert np.array_equal(st, rst) and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    for lvl in range(4):
+        assert np.array_equal(tr.get_level(0, lvl), eb if lvl == 0 else F.pyrdown(tr.get_level(0, lvl - 1)))
