@@ -97,7 +97,7 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
         "gftt_frames_per_s": FE_CAMS / (gftt_ms * 1e-3), "gftt_ms_per_batch": gftt_ms,
         "roofline": {"kernel": "fe_lk_kernel (+ fe_pyrdown_kernel x3 + fe_copy_kernel)", "bound": "hbm",
                      "achieved": nfeat * FE_BYTES_PER_FEATURE * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "traffic": None, "event_ms_per_step": ev_ms / steps,
+                     "unit": "GB/s", "traffic": fe_traffic(), "event_ms_per_step": ev_ms / steps,
                      "gftt_GBs": FE_CAMS * FE_GFTT_BYTES_PER_FRAME / (gftt_ms * 1e-3) / 1e9},
     }
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
@@ -120,6 +120,23 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
                                "gftt_frames_per_s": g / (time.perf_counter() - t2)}
         out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     return out
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/pmc_latest.json, written by
+    profiles/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def fe_traffic():
+    """HBM bytes per FE step (one fe_lk launch + 3 fe_pyrdown + 1 fe_copy) from the committed PMC summary."""
+    t = [pmc_traffic("fe_lk_kernel"), pmc_traffic("fe_pyrdown_kernel"), pmc_traffic("fe_copy_kernel")]
+    return None if any(v is None for v in t) else t[0] + 3 * t[1] + t[2]
 
 
 def main():
@@ -183,23 +200,36 @@ def main():
         total_solves = world * nwin * args.steps
         value = total_solves / elapsed
         flops_per_launch = info['flops']                 # algorithmic FLOP model of SURVEY.md 8(d), whole batch
+        # One "step" = two launches; the roofline is booked per kernel (FP64: vector peak = MFMA peak = 78.6 TF on gfx950)
+        # with the algorithmic flop model of SURVEY.md 8(d) split per launch; the top-level entry is the DOMINANT kernel
+        # (longest average launch), the other kernel and the pair are listed beside it.
+        per_kernel = {
+            "ba_solve_kernel": {"ms": solve_ms, "flops": info['flops_solve']},
+            "ba_marg_kernel": {"ms": marg_ms, "flops": info['flops_marg']},
+        }
+        for k, v in per_kernel.items():
+            v["achieved"] = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            v["frac"] = v["achieved"] / FP64_PEAK_TFLOPS
+            v["traffic"] = pmc_traffic(k)
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
         roofline = {
-            "kernel": "ba_solve_kernel",
+            "kernel": dom,
             "bound": "mfma",
-            "achieved": flops_per_launch / (solve_ms * 1e-3) / 1e12 * (1.0),   # includes the marg flops: see note
+            "achieved": per_kernel[dom]["achieved"],
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
-            "traffic": None,
-            "note": "FP64 (vector = matrix peak 78.6 TF). achieved = algorithmic flops of solve+marg per batch / "
-                    "(solve+marg kernel time); MFMA is used only for the landmark Schur complement",
-            "solve_kernel_ms": solve_ms,
-            "marg_kernel_ms": marg_ms,
-            "algorithmic_flops_per_batch": flops_per_launch,
+            "frac": per_kernel[dom]["frac"],
+            "traffic": per_kernel[dom]["traffic"],
+            "kernels": per_kernel,
+            "pair": {"ms": solve_ms + marg_ms, "flops": info['flops'],
+                     "achieved": info['flops'] / ((solve_ms + marg_ms) * 1e-3) / 1e12,
+                     "frac": info['flops'] / ((solve_ms + marg_ms) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+            "note": "durations = HIP events on the launch stream, averaged over the launches after the timed region; "
+                    "traffic = HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/, FETCH_SIZE x2 per the "
+                    "gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE), null when no PMC file is present",
             "algorithmic_bytes_per_batch": info['bytes_in'] + info['bytes_out'],
             "hbm_GBs_algorithmic": (info['bytes_in'] + info['bytes_out']) / ((solve_ms + marg_ms) * 1e-3) / 1e9,
         }
-        roofline["achieved"] = flops_per_launch / ((solve_ms + marg_ms) * 1e-3) / 1e12
-        roofline["frac"] = roofline["achieved"] / roofline["peak"]
         cpu = None
         if not args.no_cpu_baseline:
             from oracle import ba_cpu

@@ -180,6 +180,8 @@ int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* out_states,
                          vg_ba_summary* out_summaries, vg_ba_prior* const* out_priors);
 /* algorithmic work of the uploaded batch for roofline accounting (SURVEY.md 8(d) flop model) */
 int vg_ba_batch_info(vg_handle* h, double* flops_per_run, double* bytes_in, double* bytes_out, int* lds_bytes);
+/* the same flop model split per launch: ba_solve_kernel (solve + prior J^T J) and ba_marg_kernel (the marginalization term) */
+int vg_ba_batch_flops(vg_handle* h, double* solve_flops, double* marg_flops);
 
 /* Batched factor evaluation for parity tests (rows B2-B5 of SURVEY.md 8(a)): evaluates every
  * projection / IMU / prior factor of the problem at its input state WITHOUT the robust-loss

@@ -176,6 +176,7 @@ class Handle:
                                            C.POINTER(C.POINTER(Prior))]
         L.vg_ba_batch_run_timed.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.vg_ba_batch_info.argtypes = [C.c_void_p, _pd, _pd, _pd, _pi]
+        L.vg_ba_batch_flops.argtypes = [C.c_void_p, _pd, _pd]
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
         self.h = C.c_void_p()
         rc = L.vg_create(C.byref(self.h))
@@ -230,7 +231,10 @@ class Handle:
     def ba_info(self):
         fl, bi, bo, lds = C.c_double(), C.c_double(), C.c_double(), C.c_int()
         self._chk(self.lib.vg_ba_batch_info(self.h, C.byref(fl), C.byref(bi), C.byref(bo), C.byref(lds)), "vg_ba_batch_info")
-        return dict(flops=fl.value, bytes_in=bi.value, bytes_out=bo.value, lds_bytes=lds.value)
+        fs, fm = C.c_double(), C.c_double()
+        self._chk(self.lib.vg_ba_batch_flops(self.h, C.byref(fs), C.byref(fm)), "vg_ba_batch_flops")
+        return dict(flops=fl.value, flops_solve=fs.value, flops_marg=fm.value, bytes_in=bi.value, bytes_out=bo.value,
+                    lds_bytes=lds.value)
 
     def ba_download(self, allow_numeric_failure=False):
         n = len(self._packed)

@@ -368,7 +368,7 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     B.nwin = nwin;
     B.h_ia.assign((size_t)nwin * L.istride, 0);
     B.h_di.assign((size_t)nwin * L.dstride, 0.0);
-    B.flops = 0.0; B.bytes_in = 0.0; B.bytes_out = 0.0;
+    B.flops = 0.0; B.flops_marg = 0.0; B.bytes_in = 0.0; B.bytes_out = 0.0;
     B.margin.assign(nwin, VG_MARGIN_NONE);
     B.nL.assign(nwin, 0);
     for (int w = 0; w < nwin; ++w) {
@@ -394,7 +394,9 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
             double m = 15;
             for (int l = 0; l < p->L; ++l) m += (p->lm_start[l] == 0);
             const double n = 6.0 * (L.K - 1) + 9 + 6 + L.t;
-            fl += 9 * (m * m * m + n * n * n) + 2 * (m * m * n + m * n * n);
+            const double fm = 9 * (m * m * m + n * n * n) + 2 * (m * m * n + m * n * n);
+            fl += fm;
+            B.flops_marg += fm;
         }
         B.flops += fl;
         B.bytes_in += 8.0 * (16 * L.K + 8 + p->L + 7.0 * p->n_obs + (L.K - 1) * 467.0 + np * np + 2 * np) + 12.0 * p->L;
@@ -445,6 +447,13 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
     HIPCHK(h, hipEventElapsedTime(&b, e1, e2));
     if (solve_ms) *solve_ms = a;
     if (marg_ms) *marg_ms = b;
+    return VG_OK;
+}
+
+extern "C" int vg_ba_batch_flops(vg_handle* h, double* solve_flops, double* marg_flops) {
+    if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
+    if (solve_flops) *solve_flops = h->ba.flops - h->ba.flops_marg;
+    if (marg_flops) *marg_flops = h->ba.flops_marg;
     return VG_OK;
 }
 

@@ -14,7 +14,7 @@ struct BaBatch {
     std::vector<double> h_di, h_out, h_mout;
     int nwin = 0;
     bool uploaded = false, any_margin = false;
-    double flops = 0, bytes_in = 0, bytes_out = 0;
+    double flops = 0, flops_marg = 0, bytes_in = 0, bytes_out = 0;
 };
 
 struct FeState;   // fe_host.hip
