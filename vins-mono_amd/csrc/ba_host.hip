@@ -210,20 +210,23 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.mo_r0 = mcap * mcap;
     L.mo_x0 = L.mo_r0 + mcap;
     L.mo_stride = up(L.mo_x0 + (L.K + 4) * 9, 8);
-    L.mi_stride = up(8 + 2 * (L.K + 4), 8);
+    L.mi_stride = up(8 + 2 * (L.K + 4) + 16, 8);   // + 16 phase stamps (BA_PROFILE builds)
     L.mg_posmax = up(mcap + 15 + L.Lcap, 2);
     {
         // LDS of the marginalization kernel: [eigM ld^2][eigV ld^2][cs 2 ld][red 16][state][ints 256]
         const int nstm = up(16 * L.K + 8 + 1, 2);
-        L.mg_cs = up(std::max(2 * mcap, 3 * (L.mg_posmax / 2 + 2)), 2);
+        L.mg_cs = up(std::max(std::max(2 * mcap, 3 * (L.mg_posmax / 2 + 2)), 2 * (3 * ((mcap + 2) / 2) + 2) + 2), 2);   // generic: one table
+                                                     // of 3*half doubles; fast path: two (double-buffered)
         const int fixed = 32 + nstm + 128 + L.mg_cs;
-        int ld = mcap;                               // big enough for the kept part; also used for Amm when m <= ld
+        int ld = mcap + 1;                           // big enough for the kept part; also used for Amm when m <= ld.  ODD:
+                                                     // the symmetric-storage Jacobi walks columns (stride ld doubles) and
+                                                     // an even stride folds them onto a few LDS banks (96 -> one bank)
         while (2 * ld * ld + fixed > 160 * 1024 / 8) ld -= 2;
         L.mg_ld = ld;
         L.mg_lds_bytes = (2 * ld * ld + fixed) * 8;
         if (ld < 8) { h->err = "marginalization LDS carve failed"; return VG_ERR_UNSUPPORTED; }
         const long pm = L.mg_posmax;
-        long sdoubles = pm * pm + pm + (long)L.Fcap * 42 + 2 * pm * (mcap + 1) + 2 * pm * pm + 2L * mcap * mcap + 2 * L.Ncap + 480 + L.Lcap + 64;
+        long sdoubles = pm * pm + pm + (long)L.Fcap * 42 + 2 * pm * (mcap + 1) + 2 * pm * pm + 2L * mcap * mcap + 2 * L.Ncap + 480 + L.Lcap + 64 + L.Lcap / 2 + 8;
         L.ms_stride = (int)up((int)sdoubles, 8);
     }
     return VG_OK;
@@ -518,7 +521,11 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
                 const double* mo = B.h_mout.data() + (size_t)w * L.mo_stride;
                 const int* mi = B.h_miout.data() + (size_t)w * L.mi_stride;
                 q->valid = mi[0];
-                if (getenv("VG_DEBUG_MARG")) fprintf(stderr, "[marg] eig2: sweeps=%d total_kcyc=%d rot_kcyc=%d blkV_kcyc=%d | total kernel kcyc=%d\n", mi[5] & 255, mi[5] >> 8, mi[6], mi[7], mi[4]);
+                if (getenv("VG_DEBUG_MARG")) {
+                    const int* pf = mi + 8 + 2 * (L.K + 4);
+                    fprintf(stderr, "[marg] eig2: sweeps=%d total_kcyc=%d rot_kcyc=%d blkV_kcyc=%d | total kernel kcyc=%d | stamps: setup %d prior %d imu %d proj %d eig1 %d schur %d eig2 %d out %d | jacobi w0: M %d bar %d rot %d bar %d ; w1: M %d bar %d V %d bar %d\n",
+                            mi[5] & 255, mi[5] >> 8, mi[6], mi[7], mi[4], pf[0], pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6], pf[8], pf[9], pf[10], pf[11], pf[12], pf[13], pf[14], pf[15]);
+                }
                 if (mi[0]) {
                     const int n = mi[1], nb = mi[3];
                     if (n > q->cap || nb > q->cap_blocks) { h->err = "vg_ba_prior capacity too small"; return VG_ERR_BAD_ARG; }

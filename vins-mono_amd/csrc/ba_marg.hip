@@ -87,7 +87,7 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
     // relative = false: absolute criterion only, |a_pq| <= 1e-16 ||A||_F — what Eigen's tridiagonal-QL solver of the
     //                   reference guarantees — which saves ~1/3 of the sweeps on the kept block.
     const double floor_abs = sqrt(fro) * (relative ? 1e-17 : 1e-16);
-    const double relf = relative ? 1e-16 : 0.0;
+    const double relf2 = relative ? 1e-32 : 0.0;
     if (c.tid == 0) { red[20] = red[21] = red[22] = red[23] = 0.0; }
     int sweep = 0;
     for (; sweep < MG_MAXSWEEP; ++sweep) {
@@ -105,13 +105,16 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
                 if (p > q) { const int t = p; p = q; q = t; }
                 double cc = 1.0, ss = 0.0;
                 if (q < n) {
-                    const double apq = M[p * ld + q], app = M[p * ld + p], aqq = M[q * ld + q];
-                    if (fabs(apq) > floor_abs && fabs(apq) > relf * sqrt(fabs(app * aqq))) {
-                        const double theta = (aqq - app) / (2.0 * apq);
-                        const double h2 = theta * theta + 1.0;
-                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + h2 * mg_rsqrt(h2));
-                        cc = mg_rsqrt(t * t + 1.0);
-                        ss = t * cc;
+                    const double apq = M[q * ld + p], app = M[p * ld + p], aqq = M[q * ld + q];
+                    if (fabs(apq) > floor_abs && apq * apq > relf2 * fabs(app * aqq)) {
+                        // inner rotation (|angle| <= pi/4) from cos 2phi = |d| / r, sin 2phi = |apq| / r: two rsqrt
+                        // chains and no division (an f64 divide is ~40 instructions on this pipe)
+                        const double d = 0.5 * (aqq - app);
+                        const double ir = mg_rsqrt(fma(d, d, apq * apq));
+                        const double hc = fma(0.5 * fabs(d), ir, 0.5);            // cos^2 phi in [0.5, 1]
+                        const double ic = mg_rsqrt(hc);
+                        cc = hc * ic;
+                        ss = (d >= 0 ? 0.5 : -0.5) * apq * ir * ic;
                         nrot += 1.0;
                     }
                 }
@@ -122,65 +125,115 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
 #ifdef BA_PROFILE
             const long long _tb = clock64();
 #endif
-            // 2x2 block owners: wavefront = pair row ka (strided), lane = pair column kb.  All LDS reads of a lane
-            // are issued first (clamped, unconditional), then the arithmetic, then the stores: the LDS latency is
-            // paid once per round instead of once per block.
-            if (half <= 64 && n <= 96) {
-                const int kb = c.lane < half ? c.lane : 0;
-                const int rr = pq[2 * kb], s = pq[2 * kb + 1];
-                const double cb = cs[2 * kb], sb = cs[2 * kb + 1];
-                const bool sv = s < n;
-                const int sc_ = sv ? s : rr;
-                double m00[3], m01[3], m10[3], m11[3];
-                int pa[3], qa[3];
+            if (INLDS) {
+                // SYMMETRIC storage: only M[max(i,j)][min(i,j)] is kept current.  One thread per 2x2 block (ka >= kb)
+                // of the pair grid: half(half+1)/2 blocks (741 for n = 75: a single pass of the 1024 threads), all
+                // loads first, then the arithmetic, then the stores; blocks whose two rotations are both the identity
+                // are skipped (most of the late sweeps).
+                const int nblk2 = half * (half + 1) / 2;
+                const unsigned inv_half = 0xFFFFFFFFu / (unsigned)half + 1u;
+                const int2* pq2 = (const int2*)pq;
+                const double2* cs2 = (const double2*)cs;
+                if (nblk2 <= MG_NT && n * half <= 3 * MG_NT) {
+                    // one M block and up to three V items per thread; three LDS round trips per round in total:
+                    // (1) pair tables, (2) all matrix entries (unconditional, clamped), (3) the stores
+                    const bool actM = c.tid < nblk2;
+                    int ka, kb;
+                    tri_decode(actM ? c.tid : 0, ka, kb);
+                    const double2 ra = cs2[ka], rb = cs2[kb];
+                    const int2 pa = pq2[ka], pb = pq2[kb];
+                    int vi[3], vk[3];
+                    double2 rv[3];
+                    int2 pv[3];
+                    bool actV[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int ka = c.wave + MG_NW * t;
-                    const int kac = ka < half ? ka : 0;
-                    const int p = pq[2 * kac], q = pq[2 * kac + 1];
-                    const int qc = q < n ? q : p;
-                    pa[t] = p; qa[t] = q;
-                    m00[t] = M[p * ld + rr]; m01[t] = M[p * ld + sc_]; m10[t] = M[qc * ld + rr]; m11[t] = M[qc * ld + sc_];
-                }
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int ka = c.wave + MG_NW * t;
-                    const int kac = ka < half ? ka : 0;
-                    const double ca = cs[2 * kac], sa = cs[2 * kac + 1];
-                    const bool qv = qa[t] < n;
-                    const double x01 = sv ? m01[t] : 0.0, x10 = qv ? m10[t] : 0.0, x11 = (qv && sv) ? m11[t] : 0.0;
-                    const double t00 = ca * m00[t] - sa * x10, t01 = ca * x01 - sa * x11;
-                    const double t10 = sa * m00[t] + ca * x10, t11 = sa * x01 + ca * x11;
-                    m00[t] = cb * t00 - sb * t01; m01[t] = sb * t00 + cb * t01;
-                    m10[t] = cb * t10 - sb * t11; m11[t] = sb * t10 + cb * t11;
-                    if (ka == kb) { m01[t] = 0.0; m10[t] = 0.0; }
-                }
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int ka = c.wave + MG_NW * t;
-                    if (ka < half && c.lane < half) {
-                        const bool qv = qa[t] < n;
-                        M[pa[t] * ld + rr] = m00[t];
-                        if (sv) M[pa[t] * ld + s] = m01[t];
-                        if (qv) M[qa[t] * ld + rr] = m10[t];
-                        if (qv && sv) M[qa[t] * ld + s] = m11[t];
+                    for (int t = 0; t < 3; ++t) {
+                        const int w = c.tid + t * MG_NT;
+                        actV[t] = w < n * half;
+                        const int wc = actV[t] ? w : 0;
+                        vi[t] = (int)__umulhi((unsigned)wc, inv_half);
+                        vk[t] = wc - vi[t] * half;
+                        rv[t] = cs2[vk[t]];
+                        pv[t] = pq2[vk[t]];
                     }
-                }
-                // V <- V J_b : wavefront = rows (strided), lane = pair; same load-all / store-all structure
-                double v0[6], v1[6];
+                    const int p = pa.x, q = pa.y, rr = pb.x, s = pb.y;
+                    const bool qv = q < n, sv = s < n;
+                    const int qc = qv ? q : p, sc_ = sv ? s : rr;
+                    const int a00 = p > rr ? p * ld + rr : rr * ld + p;
+                    const int a01 = p > sc_ ? p * ld + sc_ : sc_ * ld + p;
+                    const int a10 = qc > rr ? qc * ld + rr : rr * ld + qc;
+                    const int a11 = qc > sc_ ? qc * ld + sc_ : sc_ * ld + qc;
+                    const double m00 = M[a00], l01 = M[a01], l10 = M[a10], l11 = M[a11];
+                    double v0[3], v1[3];
+                    int av0[3], av1[3];
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const int i = c.wave + MG_NW * t;
-                    const int ic = i < n ? i : 0;
-                    v0[t] = V[ic * ld + rr]; v1[t] = V[ic * ld + sc_];
-                }
-#pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const int i = c.wave + MG_NW * t;
-                    if (i < n && sv && c.lane < half) {
-                        V[i * ld + rr] = cb * v0[t] - sb * v1[t];
-                        V[i * ld + s] = sb * v0[t] + cb * v1[t];
+                    for (int t = 0; t < 3; ++t) {
+                        const bool ok = pv[t].y < n;
+                        av0[t] = vi[t] * ld + pv[t].x;
+                        av1[t] = vi[t] * ld + (ok ? pv[t].y : pv[t].x);
+                        actV[t] = actV[t] && ok && rv[t].y != 0.0;
+                        v0[t] = V[av0[t]]; v1[t] = V[av1[t]];
                     }
+                    {
+                        const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
+                        const double x01 = sv ? l01 : 0.0, x10 = qv ? l10 : 0.0, x11 = (qv && sv) ? l11 : 0.0;
+                        const double t00 = ca * m00 - sa * x10, t01 = ca * x01 - sa * x11;
+                        const double t10 = sa * m00 + ca * x10, t11 = sa * x01 + ca * x11;
+                        const double n00 = cb * t00 - sb * t01;
+                        double n01 = sb * t00 + cb * t01, n10 = cb * t10 - sb * t11;
+                        const double n11 = sb * t10 + cb * t11;
+                        if (ka == kb) { n01 = 0.0; n10 = 0.0; }
+                        if (actM && (sa != 0.0 || sb != 0.0)) {
+                            M[a00] = n00;
+                            if (sv) M[a01] = n01;
+                            if (qv) M[a10] = n10;
+                            if (qv && sv) M[a11] = n11;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        if (actV[t]) {
+                            V[av0[t]] = rv[t].x * v0[t] - rv[t].y * v1[t];
+                            V[av1[t]] = rv[t].y * v0[t] + rv[t].x * v1[t];
+                        }
+                    }
+                } else {
+                for (int w = c.tid; w < nblk2; w += MG_NT) {
+                    int ka, kb;
+                    tri_decode(w, ka, kb);
+                    const double ca = cs[2 * ka], sa = cs[2 * ka + 1], cb = cs[2 * kb], sb = cs[2 * kb + 1];
+                    if (sa == 0.0 && sb == 0.0) continue;
+                    const int p = pq[2 * ka], q = pq[2 * ka + 1], rr = pq[2 * kb], s = pq[2 * kb + 1];
+                    const bool qv = q < n, sv = s < n;
+                    const int qc = qv ? q : p, sc_ = sv ? s : rr;
+                    const int a00 = p > rr ? p * ld + rr : rr * ld + p;
+                    const int a01 = p > sc_ ? p * ld + sc_ : sc_ * ld + p;
+                    const int a10 = qc > rr ? qc * ld + rr : rr * ld + qc;
+                    const int a11 = qc > sc_ ? qc * ld + sc_ : sc_ * ld + qc;
+                    const double m00 = M[a00], l01 = M[a01], l10 = M[a10], l11 = M[a11];
+                    const double x01 = sv ? l01 : 0.0, x10 = qv ? l10 : 0.0, x11 = (qv && sv) ? l11 : 0.0;
+                    const double t00 = ca * m00 - sa * x10, t01 = ca * x01 - sa * x11;
+                    const double t10 = sa * m00 + ca * x10, t11 = sa * x01 + ca * x11;
+                    const double n00 = cb * t00 - sb * t01;
+                    double n01 = sb * t00 + cb * t01, n10 = cb * t10 - sb * t11;
+                    const double n11 = sb * t10 + cb * t11;
+                    if (ka == kb) { n01 = 0.0; n10 = 0.0; }
+                    M[a00] = n00;
+                    if (sv) M[a01] = n01;
+                    if (qv) M[a10] = n10;
+                    if (qv && sv) M[a11] = n11;
+                }
+                // V <- V J_b : one thread per (row, pair)
+                for (int w = c.tid; w < n * half; w += MG_NT) {
+                    const int i = (int)__umulhi((unsigned)w, inv_half);
+                    const int kb = w - i * half;
+                    const double cb = cs[2 * kb], sb = cs[2 * kb + 1];
+                    const int rr = pq[2 * kb], s = pq[2 * kb + 1];
+                    if (sb == 0.0 || s >= n) continue;
+                    const double v0 = V[i * ld + rr], v1 = V[i * ld + s];
+                    V[i * ld + rr] = cb * v0 - sb * v1;
+                    V[i * ld + s] = sb * v0 + cb * v1;
+                }
                 }
             } else {
                 for (int ka = c.wave; ka < half; ka += MG_NW) {
@@ -230,6 +283,177 @@ DEV int jacobi_eig(const MCtx& c, double* Mg, double* Vg, int offM, int offV, in
     return sweep;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path of the above for matrices resident in LDS with half(half+1)/2 <= MG_NT and n*half <= 4*(MG_NT-64)
+// (n <= 87): same rotations, same round-robin order, same stopping rule, but software-pipelined:
+//     [all waves]  M <- J_a^T M J_b   for round r          (one 2x2 block per thread, symmetric storage)
+//     barrier
+//     [wave 0]     rotations of round r+1 from the updated M   ||   [waves 1..15]  V <- V J_b of round r
+//     barrier
+// so the serial rotation chain (3 LDS reads -> 2 rsqrt chains -> store) hides behind the V update.  Rotation /
+// pair tables are double-buffered in `cs` (needs 2 * 3 * half doubles).
+DEV int jacobi_eig_fast(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, bool relative) {
+    double* M = MG_LDS + offM;
+    double* V = MG_LDS + offV;
+    double* red = MG_LDS + offred;
+    const int N = (n + 1) & ~1;
+    const int half = N / 2;
+    const int tstride = (3 * half + 2) & ~1;            // doubles per table buffer: [cs 2*half][pq half][flag], even
+    for (int k = c.tid; k < ld * ld; k += MG_NT) {
+        const int i = k / ld, j = k % ld;
+        V[k] = (i == j) ? 1.0 : 0.0;
+        if (i >= n || j >= n) M[k] = 0.0;
+    }
+    __syncthreads();
+    double fro = 0.0;
+    for (int k = c.tid; k < n * n; k += MG_NT) { const double v = M[(k / n) * ld + k % n]; fro += v * v; }
+    fro = mg_block_sum(c, red, fro);
+    const double floor_abs = sqrt(fro) * (relative ? 1e-17 : 1e-16);
+    const double relf2 = relative ? 1e-32 : 0.0;
+    const int nblk2 = half * (half + 1) / 2;
+    const int nround = N - 1;
+    double nrot = 0.0;
+
+    // ---- round-invariant work items: the VALU issue slots of the 16 waves are what bounds a round, so everything
+    //      that does not depend on the round's pairing is decoded once here
+    const bool actM = c.tid < nblk2;
+    int ka, kb;
+    tri_decode(actM ? c.tid : 0, ka, kb);
+    const bool diag = ka == kb;
+    int vrow[4], vkb[4];
+    bool vact[4];
+    {
+        const unsigned inv_half = 0xFFFFFFFFu / (unsigned)half + 1u;
+        const int t0 = c.tid - 64;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int w = t0 + t * (MG_NT - 64);
+            vact[t] = t0 >= 0 && w < n * half;
+            const int wc = vact[t] ? w : 0;
+            const int i = (int)__umulhi((unsigned)wc, inv_half);
+            vkb[t] = wc - i * half;
+            vrow[t] = i * ld;
+        }
+    }
+
+    // rotations + pair table of round r into buffer b (wave 0 only).  An invalid partner (the padding player of an
+    // odd n) is stored as q = p with the identity rotation: loads stay in range, stores are predicated on q != p.
+    auto rotations = [&](int r, int b) {
+        double* csb = MG_LDS + offcs + b * tstride;
+        int* pqb = (int*)(csb + 2 * half);
+        const int k = c.lane;
+        double ss = 0.0;
+        if (k < half) {
+            int p, q;
+            if (k == 0) { p = N - 1; q = r; }
+            else { p = r + k; if (p >= N - 1) p -= N - 1; q = r - k; if (q < 0) q += N - 1; }
+            if (p > q) { const int t = p; p = q; q = t; }
+            const int qc = q < n ? q : p;
+            const double apq = M[qc * ld + p], app = M[p * ld + p], aqq = M[qc * ld + qc];
+            double cc = 1.0;
+            if (q < n && fabs(apq) > floor_abs && apq * apq > relf2 * fabs(app * aqq)) {
+                const double d = 0.5 * (aqq - app);
+                const double ir = mg_rsqrt(fma(d, d, apq * apq));
+                const double hc = fma(0.5 * fabs(d), ir, 0.5);
+                const double ic = mg_rsqrt(hc);
+                cc = hc * ic;
+                ss = (d >= 0 ? 0.5 : -0.5) * apq * ir * ic;
+                nrot += 1.0;
+            }
+            ((double2*)csb)[k] = make_double2(cc, ss);
+            ((int2*)pqb)[k] = make_int2(p, qc);
+        }
+        const unsigned long long any = __ballot(ss != 0.0);
+        if (k == 0) pqb[2 * half] = any != 0ull;
+    };
+    if (c.wave == 0) rotations(0, 0);
+    __syncthreads();
+    int sweep = 0;
+#ifdef BA_PROFILE
+    if (c.tid == 0) for (int k = 20; k < 28; ++k) red[k] = 0.0;
+    long long _p0, _p1, _p2, _p3, _p4;
+#define JP(v) v = clock64()
+#else
+#define JP(v)
+#endif
+    for (int it = 0;; ++it) {
+        JP(_p0);
+        const int b = it & 1;
+        const double2* cs2 = (const double2*)(MG_LDS + offcs + b * tstride);
+        const int2* pq2 = (const int2*)(MG_LDS + offcs + b * tstride + 2 * half);
+        const int any = __builtin_amdgcn_readfirstlane(((const int*)pq2)[2 * half]);   // a round without rotations is skipped
+        if (any && actM) {
+            // ---- M <- J_a^T M J_b on the block (ka >= kb), symmetric storage
+            const double2 ra = cs2[ka], rb = cs2[kb];
+            const int2 pa = pq2[ka], pb = pq2[kb];
+            const int a00 = max(pa.x, pb.x) * ld + min(pa.x, pb.x);
+            const int a01 = max(pa.x, pb.y) * ld + min(pa.x, pb.y);
+            const int a10 = max(pa.y, pb.x) * ld + min(pa.y, pb.x);
+            const int a11 = max(pa.y, pb.y) * ld + min(pa.y, pb.y);
+            const double m00 = M[a00], m01 = M[a01], m10 = M[a10], m11 = M[a11];
+            const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
+            const double t00 = ca * m00 - sa * m10, t01 = ca * m01 - sa * m11;
+            const double t10 = sa * m00 + ca * m10, t11 = sa * m01 + ca * m11;
+            const double n00 = cb * t00 - sb * t01, n11 = sb * t10 + cb * t11;
+            const double n01 = diag ? 0.0 : sb * t00 + cb * t01;
+            const double n10 = diag ? 0.0 : cb * t10 - sb * t11;
+            const bool qv = pa.y != pa.x, sv = pb.y != pb.x;
+            if (sa != 0.0 || sb != 0.0) {
+                M[a00] = n00;
+                if (sv) M[a01] = n01;
+                if (qv) M[a10] = n10;
+                if (qv && sv) M[a11] = n11;
+            }
+        }
+        JP(_p1);
+        __syncthreads();
+        JP(_p2);
+        const int rn = (it + 1) % nround;
+        if (c.wave == 0) {
+            if (rn == 0) {                                // the rotations of the sweep that just ended are all counted
+                const double tot = mg_wave_sum(nrot);
+                if (c.lane == 0) red[16] = tot;
+                nrot = 0.0;
+            }
+            rotations(rn, b ^ 1);
+        } else if (any) {
+            // ---- V <- V J_b of this round: thread = (row, pair), up to four items
+            double2 rv[4];
+            int2 pv[4];
+            double v0[4], v1[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { rv[t] = cs2[vkb[t]]; pv[t] = pq2[vkb[t]]; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { v0[t] = V[vrow[t] + pv[t].x]; v1[t] = V[vrow[t] + pv[t].y]; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (vact[t] && rv[t].y != 0.0) {          // (an invalid partner has the identity rotation)
+                    V[vrow[t] + pv[t].x] = rv[t].x * v0[t] - rv[t].y * v1[t];
+                    V[vrow[t] + pv[t].y] = rv[t].y * v0[t] + rv[t].x * v1[t];
+                }
+            }
+        }
+        JP(_p3);
+        __syncthreads();
+        JP(_p4);
+#ifdef BA_PROFILE
+        if (c.tid == 0) { red[20] += (double)(_p1 - _p0); red[21] += (double)(_p2 - _p1); red[22] += (double)(_p3 - _p2); red[23] += (double)(_p4 - _p3); }
+        if (c.tid == 64) { red[24] += (double)(_p1 - _p0); red[25] += (double)(_p2 - _p1); red[26] += (double)(_p3 - _p2); red[27] += (double)(_p4 - _p3); }
+#endif
+        if (rn == 0) {
+            ++sweep;
+            if (red[16] == 0.0 || sweep >= MG_MAXSWEEP) break;
+        }
+    }
+    __syncthreads();
+    return sweep;
+}
+
+DEV bool mg_fast_ok(int n) {
+    const int half = (n + 1) / 2;
+    return n >= 2 && half * (half + 1) / 2 <= MG_NT && n * half <= 4 * (MG_NT - 64);
+}
+
 // marginalization column maps, kept in LDS ints
 struct MgMap {
     int* pose;   // [BA_MAX_K] column of pose i or -1
@@ -264,6 +488,10 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     const int mcap = L.mcap;
 #ifdef BA_PROFILE
     const long long _tstart = clock64();
+    int* mprof = mi + 8 + 2 * (L.K + 4);
+#define MPROF(i) do { if (threadIdx.x == 0) mprof[i] = (int)((clock64() - _tstart) >> 10); } while (0)
+#else
+#define MPROF(i) do { } while (0)
 #endif
 
     // ---- LDS carve: [eigM ld*ld][eigV ld*ld][cs 2*ld][red 16][x state][ints]
@@ -361,6 +589,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     for (int k = c.tid; k < pos; k += MG_NT) bv[k] = 0.0;
     __syncthreads();
 
+    MPROF(0);
     // ---- M1/M3 (a): prior factor at the new state: r = r0 + J0 dx ; A += J0^T J0 ; b += J0^T r
     if (nblk > 0) {
         double* dx = prv + L.Ncap;
@@ -411,6 +640,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         }
     }
     __syncthreads();
+    MPROF(1);
     // ---- (b) IMU factor 0 -> 1
     if (imu0) {
         const double* pre = c.di + L.do_imu;
@@ -450,94 +680,158 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         }
     }
     __syncthreads();
-    // ---- (c) projection factors of the landmarks anchored at frame 0, with the loss correction
-    int nf0 = 0;
+    MPROF(2);
+    // ---- (c) projection factors of the landmarks anchored at frame 0, with the loss correction.
+    // Records (42 doubles: r[2] | Ji[12] | Jj[12] | Jex[12] | Jl[2] | Jtd[2], rows as [row][col]) are staged in the LDS
+    // area the eigen-solver uses later, in chunks of whole landmarks; every factor couples {pose 0, pose j, ex, td,
+    // landmark}, so an entry of the camera part that touches pose j only visits the factors of target frame j
+    // (a stable counting sort by j -> fixed summation order -> bit-reproducible), the others visit all of them.
     if (flag == VG_MARGIN_OLD && n0 > 0) {
-        // compact factor list: factors of L0 landmarks are the contiguous runs lm_fbeg[l]..; enumerate
-        // record layout (42): r[2] | Ji[12] | Jj[12] | Jex[12] | Jl[2] | Jtd[2], rows interleaved as [row][col]
-        for (int k = 0; k < n0; ++k) nf0 += c.ia[L.io_lm_fbeg + mp.l0[k] + 1] - c.ia[L.io_lm_fbeg + mp.l0[k]];
-        for (int wk = c.tid; wk < c.hdr[H_F]; wk += MG_NT) {
-            const int f = wk;
-            const int l = c.ia[L.io_fac_lm + f];
-            if (mp.lm[l] < 0) continue;
-            const int j = c.ia[L.io_fac_j + f];
-            if (j >= K) continue;                 // relocalisation factors are not marginalised (estimator.cpp:864-903)
-            const double* oi = c.di + L.do_obs + c.ia[L.io_fac_oi + f] * BA_OBS_STRIDE;
-            const double* oj = c.di + L.do_obs + c.ia[L.io_fac_oj + f] * BA_OBS_STRIDE;
-            double* R = rec + (size_t)f * 42;
-            double Jtd[2] = {0, 0};
-            if (L.t) proj_eval<true, true, true>(x, x + 7 * j, ex, lam[l], oi, oj, ex[7], c.focal, c.tr, c.row, R, R + 2, R + 14, R + 26, R + 38, Jtd);
-            else proj_eval<false, true, true>(x, x + 7 * j, ex, lam[l], oi, oj, 0.0, c.focal, c.tr, c.row, R, R + 2, R + 14, R + 26, R + 38, Jtd);
-            R[40] = Jtd[0]; R[41] = Jtd[1];
-            const double sq = sqrt(1.0 / (1.0 + R[0] * R[0] + R[1] * R[1]));   // Cauchy: rho'' < 0 branch (:46-50)
-            for (int k = 0; k < 42; ++k) R[k] *= sq;
-        }
-        __syncthreads();
-        // owners of the dense camera part: entries (a, b) over columns of {pose*, ex, td}; loop over factors
         const int ncam = 6 * K + 7;
-        for (int wk = c.tid; wk < ncam * ncam + ncam; wk += MG_NT) {
-            const bool isg = wk >= ncam * ncam;
-            const int a = isg ? wk - ncam * ncam : wk / ncam, b = isg ? 0 : wk % ncam;
-            // decode camera index -> (block kind, frame, component)
-            const int fa = a / 6, ka = a % 6, fb = b / 6, kb = b % 6;
-            const bool a_pose = a < 6 * K, b_pose = b < 6 * K;
-            const bool a_ex = !a_pose && a < 6 * K + 6, b_ex = !b_pose && b < 6 * K + 6;
-            int ca, cb;
-            if (a_pose) ca = mp.pose[fa] < 0 ? -1 : mp.pose[fa] + ka; else if (a_ex) ca = cex < 0 ? -1 : cex + a - 6 * K; else ca = ctd;
-            if (b_pose) cb = mp.pose[fb] < 0 ? -1 : mp.pose[fb] + kb; else if (b_ex) cb = cex < 0 ? -1 : cex + b - 6 * K; else cb = ctd;
-            if (ca < 0 || (!isg && cb < 0)) continue;
-            if (!L.t && (a == 6 * K + 6 || (!isg && b == 6 * K + 6))) continue;
-            double s = 0.0;
-            for (int k = 0; k < n0; ++k) {
-                const int l = mp.l0[k];
-                for (int f = c.ia[L.io_lm_fbeg + l]; f < c.ia[L.io_lm_fbeg + l + 1]; ++f) {
-                    const int j = c.ia[L.io_fac_j + f];
-                    if (j >= K) continue;
-                    const double* R = rec + (size_t)f * 42;
-                    // Jacobian entry of this factor in camera column a (row 0 / row 1)
-                    double a0, a1, b0, b1;
-                    if (a_pose) { if (fa == 0) { a0 = R[2 + ka]; a1 = R[8 + ka]; } else if (fa == j) { a0 = R[14 + ka]; a1 = R[20 + ka]; } else continue; }
-                    else if (a_ex) { a0 = R[26 + a - 6 * K]; a1 = R[32 + a - 6 * K]; }
-                    else { a0 = R[40]; a1 = R[41]; }
-                    if (isg) { b0 = R[0]; b1 = R[1]; }
-                    else if (b_pose) { if (fb == 0) { b0 = R[2 + kb]; b1 = R[8 + kb]; } else if (fb == j) { b0 = R[14 + kb]; b1 = R[20 + kb]; } else continue; }
-                    else if (b_ex) { b0 = R[26 + b - 6 * K]; b1 = R[32 + b - 6 * K]; }
-                    else { b0 = R[40]; b1 = R[41]; }
-                    s += a0 * b0 + a1 * b1;
+        const int ntri = ncam * (ncam + 1) / 2;
+        const int nent = ntri + ncam;
+        const int cap = (4 * ld * ld) / 87;                  // 42 doubles + jof + sorted list (2 ints) per record
+        double* recL = eM;
+        int* jofL = (int*)(recL + (size_t)cap * 42);         // [cap] target frame or -2
+        int* slist = jofL + cap;                             // [cap] compact ids sorted by target frame (stable)
+        int* bptr = li + 64;                                 // [K + 2] bucket pointers
+        int* cfb = mp.l0 + L.Lcap;                           // [n0 + 1] compact factor offsets
+        if (c.tid == 0) {
+            int acc = 0;
+            for (int k = 0; k < n0; ++k) { cfb[k] = acc; acc += c.ia[L.io_lm_fbeg + mp.l0[k] + 1] - c.ia[L.io_lm_fbeg + mp.l0[k]]; }
+            cfb[n0] = acc;
+        }
+        // per-thread camera entries (chunk-invariant): w = tid + e * MG_NT < nent
+        constexpr int MAXE = 6;
+        double acc[MAXE];
+        int eo[MAXE];        // packed: oa0 | oa1 << 8 | ob0 << 16 | ob1 << 24
+        int erq[MAXE];       // required target frame, -1 = any, -3 = entry unused
+        int eadr[MAXE];      // destination: A index (>= 0) or -(bv index) - 1
+        int emir[MAXE];      // mirrored A index or -1
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            const int w = c.tid + e * MG_NT;
+            acc[e] = 0.0; eo[e] = 0; erq[e] = -3; eadr[e] = 0; emir[e] = -1;
+            if (w < nent) {
+                const bool isg = w >= ntri;
+                int a, b;
+                if (isg) { a = w - ntri; b = 0; } else tri_decode(w, a, b);
+                auto classify = [&](int cidx, int& o0, int& o1, int& rq, int& col) {
+                    if (cidx < 6) { o0 = 2 + cidx; o1 = 8 + cidx; rq = -1; col = mp.pose[0] + cidx; }
+                    else if (cidx < 6 * K) { const int f = cidx / 6, kk = cidx - 6 * f; o0 = 14 + kk; o1 = 20 + kk; rq = f; col = mp.pose[f] < 0 ? -1 : mp.pose[f] + kk; }
+                    else if (cidx < 6 * K + 6) { const int q = cidx - 6 * K; o0 = 26 + q; o1 = 32 + q; rq = -1; col = cex < 0 ? -1 : cex + q; }
+                    else { o0 = 40; o1 = 41; rq = -1; col = L.t ? ctd : -1; }
+                };
+                int oa0, oa1, ra, ca, ob0 = 0, ob1 = 1, rb = -1, cb = 0;
+                classify(a, oa0, oa1, ra, ca);
+                if (!isg) classify(b, ob0, ob1, rb, cb);
+                const bool ok = ca >= 0 && cb >= 0 && !(ra >= 0 && rb >= 0 && ra != rb);
+                if (ok) {
+                    eo[e] = oa0 | (oa1 << 8) | (ob0 << 16) | (ob1 << 24);
+                    erq[e] = ra >= 0 ? ra : rb;
+                    eadr[e] = isg ? -ca - 1 : ca * posmax + cb;
+                    emir[e] = (!isg && a != b) ? cb * posmax + ca : -1;
                 }
             }
-            if (isg) bv[ca] += s; else A[ca * posmax + cb] += s;
         }
-        // landmark rows / columns: thread per (landmark, camera column | self | rhs)
-        for (int wk = c.tid; wk < n0 * (ncam + 2); wk += MG_NT) {
-            const int k = wk / (ncam + 2), a = wk % (ncam + 2);
-            const int l = mp.l0[k], cl = mp.lm[l];
-            int ca = -2;
-            const int fa = a / 6, ka = a % 6;
-            if (a < 6 * K) ca = mp.pose[fa] < 0 ? -1 : mp.pose[fa] + ka;
-            else if (a < 6 * K + 6) ca = cex < 0 ? -1 : cex + a - 6 * K;
-            else if (a == 6 * K + 6) ca = L.t ? ctd : -1;
-            if (ca == -1) continue;
-            double s = 0.0;
-            for (int f = c.ia[L.io_lm_fbeg + l]; f < c.ia[L.io_lm_fbeg + l + 1]; ++f) {
+        __syncthreads();
+        for (int k0 = 0; k0 < n0;) {
+            int k1 = k0 + 1;
+            while (k1 < n0 && cfb[k1 + 1] - cfb[k0] <= cap) ++k1;
+            const int cbase = cfb[k0], ncf = cfb[k1] - cbase;           // (a single landmark never exceeds cap: <= K factors)
+            // evaluate: thread per (landmark of the chunk, slot)
+            for (int wk = c.tid; wk < (k1 - k0) * (K + 1); wk += MG_NT) {
+                const int k = k0 + wk / (K + 1), t = wk % (K + 1);
+                const int l = mp.l0[k];
+                const int f = c.ia[L.io_lm_fbeg + l] + t;
+                if (f >= c.ia[L.io_lm_fbeg + l + 1]) continue;
+                const int cf = cfb[k] - cbase + t;
                 const int j = c.ia[L.io_fac_j + f];
-                if (j >= K) continue;
-                const double* R = rec + (size_t)f * 42;
-                double a0, a1;
-                if (a < 6 * K) { if (fa == 0) { a0 = R[2 + ka]; a1 = R[8 + ka]; } else if (fa == j) { a0 = R[14 + ka]; a1 = R[20 + ka]; } else continue; }
-                else if (a < 6 * K + 6) { a0 = R[26 + a - 6 * K]; a1 = R[32 + a - 6 * K]; }
-                else if (a == 6 * K + 6) { a0 = R[40]; a1 = R[41]; }
-                else if (a == ncam) { a0 = R[38]; a1 = R[39]; }          // (l, l)
-                else { a0 = R[0]; a1 = R[1]; }                           // rhs
-                s += a0 * R[38] + a1 * R[39];
+                if (j >= K) { jofL[cf] = -2; continue; }   // relocalisation factors are not marginalised (estimator.cpp:864-903)
+                jofL[cf] = j;
+                const double* oi = c.di + L.do_obs + c.ia[L.io_fac_oi + f] * BA_OBS_STRIDE;
+                const double* oj = c.di + L.do_obs + c.ia[L.io_fac_oj + f] * BA_OBS_STRIDE;
+                double R[42];
+                double Jtd[2] = {0, 0};
+                if (L.t) proj_eval<true, true, true>(x, x + 7 * j, ex, lam[l], oi, oj, ex[7], c.focal, c.tr, c.row, R, R + 2, R + 14, R + 26, R + 38, Jtd);
+                else proj_eval<false, true, true>(x, x + 7 * j, ex, lam[l], oi, oj, 0.0, c.focal, c.tr, c.row, R, R + 2, R + 14, R + 26, R + 38, Jtd);
+                R[40] = Jtd[0]; R[41] = Jtd[1];
+                const double sq = sqrt(1.0 / (1.0 + R[0] * R[0] + R[1] * R[1]));   // Cauchy: rho'' < 0 branch (:46-50)
+#pragma unroll
+                for (int q = 0; q < 42; ++q) recL[(size_t)cf * 42 + q] = R[q] * sq;
             }
-            if (a == ncam) A[cl * posmax + cl] += s;
-            else if (a == ncam + 1) bv[cl] += s;
-            else { A[cl * posmax + ca] += s; A[ca * posmax + cl] += s; }
+            __syncthreads();
+            // stable counting sort of the chunk's factors by target frame: lane j of wave 0 owns bucket j
+            if (c.tid <= K) {
+                int cnt = 0;
+                if (c.tid < K) for (int cf = 0; cf < ncf; ++cf) cnt += (jofL[cf] == c.tid) ? 1 : 0;
+                bptr[c.tid + 1] = cnt;
+            }
+            __syncthreads();
+            if (c.tid == 0) { bptr[0] = 0; for (int j = 0; j <= K; ++j) bptr[j + 1] += bptr[j]; }
+            __syncthreads();
+            if (c.tid < K) {
+                int o = bptr[c.tid];
+                for (int cf = 0; cf < ncf; ++cf) if (jofL[cf] == c.tid) slist[o++] = cf;
+            }
+            __syncthreads();
+            // camera part
+#pragma unroll
+            for (int e = 0; e < MAXE; ++e) {
+                if (erq[e] == -3) continue;
+                const int oa0 = eo[e] & 255, oa1 = (eo[e] >> 8) & 255, ob0 = (eo[e] >> 16) & 255, ob1 = (eo[e] >> 24) & 255;
+                double s = 0.0;
+                if (erq[e] < 0) {
+                    for (int cf = 0; cf < ncf; ++cf) {
+                        const double* R = recL + (size_t)cf * 42;
+                        const double v = R[oa0] * R[ob0] + R[oa1] * R[ob1];
+                        s += jofL[cf] >= 0 ? v : 0.0;
+                    }
+                } else {
+                    for (int q = bptr[erq[e]]; q < bptr[erq[e] + 1]; ++q) {
+                        const double* R = recL + (size_t)slist[q] * 42;
+                        s += R[oa0] * R[ob0] + R[oa1] * R[ob1];
+                    }
+                }
+                acc[e] += s;
+            }
+            // landmark rows / columns: thread per (landmark, camera column | self | rhs)
+            for (int wk = c.tid; wk < (k1 - k0) * (ncam + 2); wk += MG_NT) {
+                const int k = k0 + wk / (ncam + 2), a = wk % (ncam + 2);
+                const int l = mp.l0[k], cl = mp.lm[l];
+                int ca = -2, o0 = 0, o1 = 1, rq = -1;
+                if (a < 6) { ca = mp.pose[0] + a; o0 = 2 + a; o1 = 8 + a; }
+                else if (a < 6 * K) { const int f = a / 6, kk = a - 6 * f; ca = mp.pose[f] < 0 ? -1 : mp.pose[f] + kk; o0 = 14 + kk; o1 = 20 + kk; rq = f; }
+                else if (a < 6 * K + 6) { ca = cex < 0 ? -1 : cex + a - 6 * K; o0 = 26 + a - 6 * K; o1 = 32 + a - 6 * K; }
+                else if (a == 6 * K + 6) { ca = L.t ? ctd : -1; o0 = 40; o1 = 41; }
+                else if (a == ncam) { o0 = 38; o1 = 39; }              // (l, l)
+                if (ca == -1) continue;
+                double s = 0.0;
+                const int nfl = cfb[k + 1] - cfb[k];
+                for (int t = 0; t < nfl; ++t) {
+                    const int cf = cfb[k] - cbase + t;
+                    const int j = jofL[cf];
+                    const double* R = recL + (size_t)cf * 42;
+                    const double v = R[o0] * R[38] + R[o1] * R[39];
+                    s += (j >= 0 && (rq < 0 || rq == j)) ? v : 0.0;
+                }
+                if (a == ncam) A[cl * posmax + cl] += s;
+                else if (a == ncam + 1) bv[cl] += s;
+                else { A[cl * posmax + ca] += s; A[ca * posmax + cl] += s; }
+            }
+            __syncthreads();
+            k0 = k1;
+        }
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            if (erq[e] == -3) continue;
+            if (eadr[e] < 0) bv[-eadr[e] - 1] += acc[e];
+            else { A[eadr[e]] += acc[e]; if (emir[e] >= 0) A[emir[e]] += acc[e]; }
         }
     }
     __syncthreads();
 
+    MPROF(3);
     // ---- M4: Amm^+ via eigen-decomposition, Schur complement
     {
         const bool in_lds = m <= ld;
@@ -553,13 +847,16 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         const long long _t1 = clock64();
 #endif
         const int offcs = (int)(cs - MG_LDS), offred = (int)(red - MG_LDS);
-        const int sw1 = in_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, m, ldm, offcs, offred, true)
+        const bool fast1 = in_lds && mg_fast_ok(m);
+        const int sw1 = fast1 ? jacobi_eig_fast(c, 0, ld * ld, m, ldm, offcs, offred, true)
+                      : in_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, m, ldm, offcs, offred, true)
                                : jacobi_eig<false>(c, Mm, Vm, 0, 0, m, ldm, offcs, offred, true);
 #ifdef BA_PROFILE
         if (c.tid == 0) { mi[4] = sw1; mi[6] = (int)((clock64() - _t1) >> 10); mi[7] = (int)((_t1 - _tstart) >> 10); }
 #else
         (void)sw1;
 #endif
+        MPROF(4);
         // T1 = Lambda^+ V^T [Amr | bmm]   (m x (n+1))
         for (int k = c.tid; k < m * (n + 1); k += MG_NT) {
             const int i = k / (n + 1), j = k % (n + 1);
@@ -589,6 +886,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         }
         __syncthreads();
     }
+    MPROF(5);
     double* bp = gV;                       // b' (n)
     const bool n_lds = n <= ld;
     double* M2 = n_lds ? eM : g2M;
@@ -600,13 +898,17 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     const long long _t2 = clock64();
 #endif
     const int offcs2 = (int)(cs - MG_LDS), offred2 = (int)(red - MG_LDS);
-    const int sw2 = n_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, n, ld2, offcs2, offred2, false)
+    const bool fast2 = n_lds && mg_fast_ok(n);
+    const int sw2 = fast2 ? jacobi_eig_fast(c, 0, ld * ld, n, ld2, offcs2, offred2, false)
+                  : n_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, n, ld2, offcs2, offred2, false)
                           : jacobi_eig<false>(c, M2, V2, 0, 0, n, ld2, offcs2, offred2, false);
 #ifdef BA_PROFILE
-    if (c.tid == 0) { mi[5] = sw2 | ((int)((clock64() - _t2) >> 10) << 8); mi[6] = (int)red[20] >> 10; mi[7] = (int)red[21] >> 10; }
+    if (c.tid == 0) { mi[5] = sw2 | ((int)((clock64() - _t2) >> 10) << 8); mi[6] = (int)red[20] >> 10; mi[7] = (int)red[21] >> 10;
+                      for (int k = 0; k < 8; ++k) mprof[8 + k] = (int)(red[20 + k] / 1024.0); }
 #else
     (void)sw2;
 #endif
+    MPROF(6);
     // ascending order like SelfAdjointEigenSolver: rank of each eigenvalue
     int* rank = li + 48;
     for (int i = c.tid; i < n; i += MG_NT) {
@@ -635,6 +937,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         }
         mo[L.mo_r0 + rank[i]] = s;
     }
+    MPROF(7);
     // ---- M5: kept blocks, re-labelled for the slid window, with their linearisation point
     if (c.tid == 0) {
         int nb = 0, x0o = 0;
