@@ -52,11 +52,7 @@ struct Ctx {
     double focal, tr, row, gnorm;
 };
 
-DEV double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
+DEV double wave_sum(double v) { return wave_sum_all(v); }     // DPP network, result in every lane (ba_math.h)
 // deterministic block-wide sum, result uniform in every thread (2 barriers)
 DEV double block_sum(const Ctx& c, double v) {
     double* red = LDSB + c.Lp->l_red;
@@ -83,8 +79,7 @@ DEV void block_sum2(const Ctx& c, double& a, double& b) {
 }
 DEV double block_max(const Ctx& c, double v) {
     double* red = LDSB + c.Lp->l_red;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    v = wave_max_all(v);
     __syncthreads();
     if (c.lane == 0) red[c.wave] = v;
     __syncthreads();

@@ -40,11 +40,7 @@ DEV double mg_rsqrt(double x) {
     y = y * fma(-hx * y, y, 1.5);
     return y;
 }
-DEV double mg_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
+DEV double mg_wave_sum(double v) { return wave_sum_all(v); }
 DEV double mg_block_sum(const MCtx& c, double* red, double v) {
     v = mg_wave_sum(v);
     __syncthreads();

@@ -15,6 +15,35 @@ DEV void tri_decode(int w, int& a, int& b) {
     a = t; b = w - t * (t + 1) / 2;
 }
 
+// ---- wavefront reductions on the DPP network (VALU only: a 64-bit __shfl_down costs two ds_bpermute round trips per
+// step, ~700 cycles for a wave sum; this is ~100).  Quad swaps -> half-row mirror -> row mirror leave the 16-lane row
+// total in every lane of the row; the four row totals are combined through SGPRs, so the result is in ALL lanes.
+template <int CTRL> DEV double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+DEV double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+DEV double group8_sum(double v) {            // sum over aligned groups of 8 lanes, result in all 8
+    v += dpp_mov_f64<0xB1>(v);               // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);               // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);              // row_half_mirror
+    return v;
+}
+DEV double wave_sum_all(double v) {
+    v = group8_sum(v);
+    v += dpp_mov_f64<0x140>(v);              // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+DEV double wave_max_all(double v) {
+    v = fmax(v, dpp_mov_f64<0xB1>(v)); v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v)); v = fmax(v, dpp_mov_f64<0x140>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
 DEV void q_mul(const double* a, const double* b, double* o) {
     const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
     const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
