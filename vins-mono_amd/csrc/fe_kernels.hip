@@ -127,18 +127,35 @@ extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_
 #define LK_WIN 21
 #define LK_WBITS 14
 
+#define LK_JR 32
+#define LK_JS ((LK_JR - 22) / 2)
 struct LkLds {
+    alignas(16) uint8_t jreg[LK_JR * LK_JR];    // search REGION (reflect-101), origin (jox, joy): holds every 22x22 search window
+                                    // whose origin lies within +-LK_JS px of the window it was staged for
     uint8_t ipatch[24 * 24];        // template neighbourhood (reflect-101), origin (ipx-1, ipy-1)
     int16_t der[22 * 22 * 2];       // Scharr (Ix, Iy) at (ipx + 0..21, ipy + 0..21), 0 outside the image
-    int16_t ibuf[LK_WIN * LK_WIN];  // template I (x32)
-    int16_t dibuf[LK_WIN * LK_WIN * 2];
-    uint8_t jpatch[22 * 22];        // search window (reflect-101), origin (inx, iny)
 };
 
+// exact int64 wavefront sum on the DPP network (VALU only; a 64-bit __shfl_down tree is 12 dependent LDS-crossbar round
+// trips): quad swaps -> half-row mirror -> row mirror give every lane its 16-lane row total, the four row totals are
+// added through SGPRs.  Integer addition is associative, so the result is independent of the order.
+template <int CTRL> FDEV long long dpp_mov_ll(long long v) {
+    int lo = (int)(unsigned)(v & 0xffffffffll), hi = (int)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+FDEV long long readlane_ll(long long v, int lane) {
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+    return ((long long)hi << 32) | (unsigned)lo;
+}
 FDEV long long wave_sum_ll(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return __shfl(v, 0, 64);
+    v += dpp_mov_ll<0xB1>(v);
+    v += dpp_mov_ll<0x4E>(v);
+    v += dpp_mov_ll<0x141>(v);
+    v += dpp_mov_ll<0x140>(v);
+    return (readlane_ll(v, 0) + readlane_ll(v, 16)) + (readlane_ll(v, 32) + readlane_ll(v, 48));
 }
 
 FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
@@ -146,6 +163,25 @@ FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
     w01 = cv_round(a * (1.f - b) * (float)(1 << LK_WBITS));
     w10 = cv_round((1.f - a) * b * (float)(1 << LK_WBITS));
     w11 = (1 << LK_WBITS) - w00 - w01 - w10;
+}
+
+// Stage the LK_JR x LK_JR search region with origin (ox, oy) of plane J into LDS (reflect-101 outside the image, exactly
+// the pixels the per-window gather of LKTrackerInvoker reads).  lane = (row, 16-byte half): one unaligned 16-byte load
+// per lane when the region lies inside the image, per-byte reflection at the borders.
+FDEV void lk_stage_region(uint8_t* reg, const uint8_t* J, int lw, int lh, int ox, int oy, int lane) {
+    __syncthreads();
+    const int row = lane >> 1, hf = lane & 1;
+    const bool inside = ox >= 0 && ox + LK_JR <= lw && oy >= 0 && oy + LK_JR <= lh;      // uniform
+    if (inside) {
+        uint4 v;
+        __builtin_memcpy(&v, J + (size_t)(oy + row) * lw + ox + 16 * hf, 16);
+        *(uint4*)(reg + row * LK_JR + 16 * hf) = v;
+    } else {
+        const uint8_t* src = J + (size_t)reflect101(oy + row, lh) * lw;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) reg[row * LK_JR + 16 * hf + q] = src[reflect101(ox + 16 * hf + q, lw)];
+    }
+    __syncthreads();
 }
 
 // grid (max_points, cams), block 64 (one wavefront = one track).  LKTrackerInvoker, levels max_level .. 0.
@@ -158,6 +194,9 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
     int status = 1;
     const float half = (LK_WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
+    const int ly = lane / 3, x0 = 7 * (lane - 3 * ly);       // 21 rows x 3 segments of 7 pixels = 63 lanes
+    const bool act = lane < 63;
+    const int lyc = act ? ly : 0;
     for (int level = d.max_level; level >= 0; --level) {
         const int lw = d.lw[level], lh = d.lh[level];
         const uint8_t* I = d.prev_planes[level * d.cams + cam];
@@ -199,16 +238,27 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
             s.der[k * 2] = (int16_t)ix; s.der[k * 2 + 1] = (int16_t)iy;
         }
         __syncthreads();
+        // lane = (window row ly, 7-pixel segment): the template values and gradients of a lane's seven pixels stay in
+        // registers for all iterations of the level (VALU issue, not latency, bounds this kernel at full occupancy)
         long long a11 = 0, a12 = 0, a22 = 0;
-        for (int k = lane; k < LK_WIN * LK_WIN; k += 64) {
-            const int y = k / LK_WIN, x = k % LK_WIN;
-            const uint8_t* p = s.ipatch + (y + 1) * 24 + (x + 1);
-            const int ival = descale(p[0] * w00 + p[1] * w01 + p[24] * w10 + p[25] * w11, LK_WBITS - 5);
-            const int16_t* q = s.der + (y * 22 + x) * 2;
-            const int ixval = descale(q[0] * w00 + q[2] * w01 + q[44] * w10 + q[46] * w11, LK_WBITS);
-            const int iyval = descale(q[1] * w00 + q[3] * w01 + q[45] * w10 + q[47] * w11, LK_WBITS);
-            s.ibuf[k] = (int16_t)ival; s.dibuf[k * 2] = (int16_t)ixval; s.dibuf[k * 2 + 1] = (int16_t)iyval;
-            a11 += (long long)ixval * ixval; a12 += (long long)ixval * iyval; a22 += (long long)iyval * iyval;
+        int iv[7], ixv[7], iyv[7];
+        {
+            const uint8_t* p0 = s.ipatch + (lyc + 1) * 24 + (x0 + 1);
+            const int* dq = (const int*)s.der + lyc * 22 + x0;          // (Ix | Iy << 16)
+            int r0[8], r1[8], d0[8], d1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[24 + q]; d0[q] = dq[q]; d1[q] = dq[22 + q]; }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int ival = descale(r0[q] * w00 + r0[q + 1] * w01 + r1[q] * w10 + r1[q + 1] * w11, LK_WBITS - 5);
+                const int x00 = (short)(d0[q] & 0xffff), x01 = (short)(d0[q + 1] & 0xffff);
+                const int x10 = (short)(d1[q] & 0xffff), x11 = (short)(d1[q + 1] & 0xffff);
+                const int y00 = d0[q] >> 16, y01 = d0[q + 1] >> 16, y10 = d1[q] >> 16, y11 = d1[q + 1] >> 16;
+                const int ixval = descale(x00 * w00 + x01 * w01 + x10 * w10 + x11 * w11, LK_WBITS);
+                const int iyval = descale(y00 * w00 + y01 * w01 + y10 * w10 + y11 * w11, LK_WBITS);
+                iv[q] = (short)ival; ixv[q] = act ? (short)ixval : 0; iyv[q] = act ? (short)iyval : 0;
+                a11 += (long long)ixv[q] * ixv[q]; a12 += (long long)ixv[q] * iyv[q]; a22 += (long long)iyv[q] * iyv[q];
+            }
         }
         a11 = wave_sum_ll(a11); a12 = wave_sum_ll(a12); a22 = wave_sum_ll(a22);
         const float A11 = (float)a11 * FLT_SCALE, A12 = (float)a12 * FLT_SCALE, A22 = (float)a22 * FLT_SCALE;
@@ -221,6 +271,8 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
         D = 1.f / D;
         nextx -= half; nexty -= half;
         float pdx = 0.f, pdy = 0.f;
+        bool staged = false;
+        int jox = 0, joy = 0;
         for (int j = 0; j < d.max_count; ++j) {
             const int inx = cv_floor(nextx), iny = cv_floor(nexty);
             if (inx < -LK_WIN || inx >= lw || iny < -LK_WIN || iny >= lh) {
@@ -229,18 +281,22 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
             }
             int r00, r01, r10, r11;
             lk_weights(nextx - inx, nexty - iny, r00, r01, r10, r11);
-            __syncthreads();
-            for (int k = lane; k < 22 * 22; k += 64) {
-                const int yy = k / 22, xx = k % 22;
-                s.jpatch[k] = J[(size_t)reflect101(iny + yy, lh) * lw + reflect101(inx + xx, lw)];
+            int rx = inx - jox, ry = iny - joy;
+            if (!staged || rx < 0 || rx > LK_JR - 22 || ry < 0 || ry > LK_JR - 22) {      // uniform
+                jox = inx - LK_JS; joy = iny - LK_JS; staged = true; rx = LK_JS; ry = LK_JS;
+                lk_stage_region(s.jreg, J, lw, lh, jox, joy, lane);
             }
-            __syncthreads();
             long long b1 = 0, b2 = 0;
-            for (int k = lane; k < LK_WIN * LK_WIN; k += 64) {
-                const int y = k / LK_WIN, x = k % LK_WIN;
-                const uint8_t* p = s.jpatch + y * 22 + x;
-                const int diff = descale(p[0] * r00 + p[1] * r01 + p[22] * r10 + p[23] * r11, LK_WBITS - 5) - s.ibuf[k];
-                b1 += (long long)diff * s.dibuf[k * 2]; b2 += (long long)diff * s.dibuf[k * 2 + 1];
+            {
+                const uint8_t* p0 = s.jreg + (ry + lyc) * LK_JR + rx + x0;
+                int r0[8], r1[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[LK_JR + q]; }
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const int diff = descale(r0[q] * r00 + r0[q + 1] * r01 + r1[q] * r10 + r1[q + 1] * r11, LK_WBITS - 5) - iv[q];
+                    b1 += (long long)diff * ixv[q]; b2 += (long long)diff * iyv[q];
+                }
             }
             b1 = wave_sum_ll(b1); b2 = wave_sum_ll(b2);
             const float fb1 = (float)b1 * FLT_SCALE, fb2 = (float)b2 * FLT_SCALE;
@@ -260,18 +316,22 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
             if (inx < -LK_WIN || inx >= lw || iny < -LK_WIN || iny >= lh) { status = 0; continue; }
             int r00, r01, r10, r11;
             lk_weights(ex - inx, ey - iny, r00, r01, r10, r11);
-            __syncthreads();
-            for (int k = lane; k < 22 * 22; k += 64) {
-                const int yy = k / 22, xx = k % 22;
-                s.jpatch[k] = J[(size_t)reflect101(iny + yy, lh) * lw + reflect101(inx + xx, lw)];
+            int rx = inx - jox, ry = iny - joy;
+            if (!staged || rx < 0 || rx > LK_JR - 22 || ry < 0 || ry > LK_JR - 22) {
+                jox = inx - LK_JS; joy = iny - LK_JS; staged = true; rx = LK_JS; ry = LK_JS;
+                lk_stage_region(s.jreg, J, lw, lh, jox, joy, lane);
             }
-            __syncthreads();
             long long e = 0;
-            for (int k = lane; k < LK_WIN * LK_WIN; k += 64) {
-                const int y = k / LK_WIN, x = k % LK_WIN;
-                const uint8_t* p = s.jpatch + y * 22 + x;
-                const int diff = descale(p[0] * r00 + p[1] * r01 + p[22] * r10 + p[23] * r11, LK_WBITS - 5) - s.ibuf[k];
-                e += diff < 0 ? -diff : diff;
+            {
+                const uint8_t* p0 = s.jreg + (ry + lyc) * LK_JR + rx + x0;
+                int r0[8], r1[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[LK_JR + q]; }
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const int diff = descale(r0[q] * r00 + r0[q + 1] * r01 + r1[q] * r10 + r1[q + 1] * r11, LK_WBITS - 5) - iv[q];
+                    e += act ? (diff < 0 ? -diff : diff) : 0;
+                }
             }
             e = wave_sum_ll(e);
             err = (float)e * (1.f / (32 * LK_WIN * LK_WIN));
