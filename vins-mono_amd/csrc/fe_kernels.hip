@@ -104,22 +104,41 @@ extern "C" __global__ __launch_bounds__(256) void fe_copy_kernel(FeDev d, uint8_
 }
 
 // ================================================================================================ pyrDown
-// thread per output pixel; [1 4 6 4 1] x [1 4 6 4 1], BORDER_REFLECT_101, (sum + 128) >> 8  (pyramids.cpp)
+// [1 4 6 4 1] x [1 4 6 4 1], BORDER_REFLECT_101, (sum + 128) >> 8  (pyramids.cpp).  Block = 64x4 output tile: the
+// 11 x 136 input tile is staged in LDS (aligned dword rows in the interior, per-byte reflection at the borders),
+// filtered horizontally once (11 x 64 partial sums) and then vertically: ~3x fewer instructions than 25 reflected
+// global byte loads per output pixel, same integers.
 extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh) {
+    __shared__ alignas(16) uint8_t tile[11][136];
+    __shared__ int hs[11][64];
     const int cam = blockIdx.z;
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
+    const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4;
     const uint8_t* s = src_planes[cam];
-    int xs[5], acc = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, sw);
-#pragma unroll
-    for (int v = 0; v < 5; ++v) {
-        const uint8_t* r = s + (size_t)reflect101(2 * y - 2 + v, sh) * sw;
-        const int row = r[xs[0]] + 4 * r[xs[1]] + 6 * r[xs[2]] + 4 * r[xs[3]] + r[xs[4]];
-        acc += (v == 0 || v == 4) ? row : ((v == 2) ? 6 * row : 4 * row);
+    const int ix0 = 2 * bx0 - 4, iy0 = 2 * by0 - 2;         // input coordinates of tile[0][0] (ix0 is 4-byte aligned)
+    const bool interior = (sw & 3) == 0 && ix0 >= 0 && ix0 + 136 <= sw && iy0 >= 0 && iy0 + 11 <= sh;   // uniform
+    if (interior) {
+        for (int k = threadIdx.x; k < 11 * 34; k += 256) {
+            const int r = k / 34, cdw = k - 34 * r;
+            *(uint32_t*)&tile[r][4 * cdw] = *(const uint32_t*)(s + (size_t)(iy0 + r) * sw + ix0 + 4 * cdw);
+        }
+    } else {
+        for (int k = threadIdx.x; k < 11 * 136; k += 256) {
+            const int r = k / 136, cc = k - 136 * r;
+            tile[r][cc] = s[(size_t)reflect101(iy0 + r, sh) * sw + reflect101(ix0 + cc, sw)];
+        }
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 11 * 64; k += 256) {
+        const int r = k >> 6, lx = k & 63;
+        const uint8_t* t = &tile[r][2 * lx + 2];           // input column 2x - 2
+        hs[r][lx] = t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = bx0 + lx, y = by0 + ly;
+    if (x >= dw || y >= dh) return;
+    const int acc = hs[2 * ly][lx] + 4 * hs[2 * ly + 1][lx] + 6 * hs[2 * ly + 2][lx] + 4 * hs[2 * ly + 3][lx] + hs[2 * ly + 4][lx];
     dst_planes[cam][(size_t)y * dw + x] = (uint8_t)((acc + 128) >> 8);
 }
 
