@@ -121,7 +121,7 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     HIPCHK(h, hipMemset(s->npts, 0, sizeof(int) * n_cams));
     HIPCHK(h, hipMalloc((void**)&s->max_corners, sizeof(int) * n_cams));
     HIPCHK(h, hipMalloc((void**)&s->ncorners, sizeof(int) * n_cams));
-    HIPCHK(h, hipMalloc((void**)&s->ncand, sizeof(unsigned) * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->ncand, sizeof(unsigned) * FE_CNT_STRIDE * n_cams));
     HIPCHK(h, hipMalloc((void**)&s->keys, sizeof(unsigned long long) * (size_t)FE_CAND_CAP * n_cams));
     d.raw = s->raw2[s->raw_sel]; d.lut = s->lut; d.npts = s->npts; d.prev_xy = s->prev_xy; d.next_xy = s->next_xy; d.status = s->status;
     d.err = s->err; d.eig = s->eig; d.mask = s->mask; d.blockmax = s->blockmax; d.ncand = s->ncand; d.keys = s->keys;
@@ -269,7 +269,7 @@ extern "C" int vg_fe_detect_async(vg_handle* h, double quality, double min_dist)
     const FeDev& d = s->d;
     const int cell = (int)std::lrint(min_dist) < 1 ? 1 : (int)std::lrint(min_dist);
     if (((d.W + cell - 1) / cell) * ((d.H + cell - 1) / cell) > FE_MAX_CELLS) { h->err = "min_dist too small for the cell grid"; return VG_ERR_UNSUPPORTED; }
-    HIPCHK(h, hipMemsetAsync(s->ncand, 0, sizeof(unsigned) * d.cams, h->stream));
+    HIPCHK(h, hipMemsetAsync(s->ncand, 0, sizeof(unsigned) * FE_CNT_STRIDE * d.cams, h->stream));
     const dim3 g((d.W + 63) / 64, (d.H + 3) / 4, d.cams);
     hipLaunchKernelGGL(fe_mineig_kernel, g, dim3(256), 0, h->stream, d);
     hipLaunchKernelGGL(fe_candidates_kernel, g, dim3(256), 0, h->stream, d, quality);

@@ -439,26 +439,20 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d) {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
     if ((threadIdx.x & 63) == 0) bmax[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0)
-        d.blockmax[(size_t)cam * d.nblk_eig + blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(bmax[0], bmax[1]), fmaxf(bmax[2], bmax[3]));
+    if (threadIdx.x == 0) {
+        const float bm = fmaxf(fmaxf(bmax[0], bmax[1]), fmaxf(bmax[2], bmax[3]));
+        d.blockmax[(size_t)cam * d.nblk_eig + blockIdx.y * gridDim.x + blockIdx.x] = bm;
+        // per-stream maximum for minMaxLoc (max is order-independent -> deterministic); slot zeroed with ncand
+        if (bm != -INFINITY) atomicMax(&d.ncand[FE_CNT_STRIDE * cam + 32], ford(bm));
+    }
 }
 
 // threshold (THRESH_TOZERO at maxVal*quality) + 3x3 dilate equality + mask -> candidate keys
 // key = (ordered float bits << 32) | linear index   (sort descending = value desc, then index desc)
 extern "C" __global__ __launch_bounds__(256) void fe_candidates_kernel(FeDev d, double quality) {
-    __shared__ unsigned smax;
     const int cam = blockIdx.z, W = d.W, H = d.H;
-    if (threadIdx.x == 0) smax = 0u;
-    __syncthreads();
-    {
-        float m = -INFINITY;
-        for (int k = threadIdx.x; k < d.nblk_eig; k += 256) m = fmaxf(m, d.blockmax[(size_t)cam * d.nblk_eig + k]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(&smax, ford(m));
-    }
-    __syncthreads();
-    const float mf = funord(smax);
+    const unsigned smax = d.ncand[FE_CNT_STRIDE * cam + 32];          // ordered-uint maximum left by fe_mineig_kernel (0 = none)
+    const float mf = smax ? funord(smax) : -INFINITY;
     // minMaxLoc over an empty mask leaves maxVal = 0 in the reference
     const double maxVal = (mf == -INFINITY) ? 0.0 : (double)mf;
     const float thr = (float)(maxVal * quality);
@@ -490,7 +484,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_candidates_kernel(FeDev d, 
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-        const unsigned base = tot ? atomicAdd(&d.ncand[cam], tot) : 0u;
+        const unsigned base = tot ? atomicAdd(&d.ncand[FE_CNT_STRIDE * cam], tot) : 0u;
         wbase[0] = base; wbase[1] = base + wcount[0]; wbase[2] = wbase[1] + wcount[1]; wbase[3] = wbase[2] + wcount[2];
     }
     __syncthreads();
@@ -502,19 +496,38 @@ extern "C" __global__ __launch_bounds__(256) void fe_candidates_kernel(FeDev d, 
 }
 
 // one workgroup (1024 threads) per camera: in-place bitonic sort (descending) of the candidate keys, padded with 0
+#define FE_SORT_LDS 8192
 extern "C" __global__ __launch_bounds__(1024) void fe_sort_kernel(FeDev d) {
+    __shared__ unsigned long long sk[FE_SORT_LDS];          // 64 KB: the usual few thousand candidates sort in LDS
     const int cam = blockIdx.x;
     unsigned long long* k = d.keys + (size_t)cam * d.cand_cap;
-    unsigned n = d.ncand[cam];
+    unsigned n = d.ncand[FE_CNT_STRIDE * cam];
     if (n > (unsigned)d.cand_cap) n = d.cand_cap;
     unsigned np = 1;
     while (np < n) np <<= 1;
+    if (np <= FE_SORT_LDS) {
+        for (unsigned i = threadIdx.x; i < np; i += 1024) sk[i] = i < n ? k[i] : 0ull;
+        __syncthreads();
+        for (unsigned size = 2; size <= np; size <<= 1)
+            for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+                for (unsigned t = threadIdx.x; t < np / 2; t += 1024) {
+                    const unsigned lo = 2 * t - (t & (stride - 1));      // index with bit `stride` cleared
+                    const unsigned hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const unsigned long long a = sk[lo], b = sk[hi];
+                    if ((a < b) == desc) { sk[lo] = b; sk[hi] = a; }
+                }
+                __syncthreads();
+            }
+        for (unsigned i = threadIdx.x; i < n; i += 1024) k[i] = sk[i];
+        return;
+    }
     for (unsigned i = n + threadIdx.x; i < np; i += 1024) k[i] = 0ull;
     __syncthreads();
     for (unsigned size = 2; size <= np; size <<= 1)
         for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
             for (unsigned t = threadIdx.x; t < np / 2; t += 1024) {
-                const unsigned lo = 2 * t - (t & (stride - 1));      // index with bit `stride` cleared
+                const unsigned lo = 2 * t - (t & (stride - 1));
                 const unsigned hi = lo + stride;
                 const bool desc = ((lo & size) == 0);
                 const unsigned long long a = k[lo], b = k[hi];
@@ -537,7 +550,7 @@ extern "C" __global__ __launch_bounds__(64) void fe_mindist_kernel(FeDev d, floa
     const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
     for (int k = lane; k < gw * gh; k += 64) cellcnt[k] = 0;
     __syncthreads();
-    unsigned n = d.ncand[cam];
+    unsigned n = d.ncand[FE_CNT_STRIDE * cam];
     if (n > (unsigned)d.cand_cap) n = d.cand_cap;
     const unsigned long long* keys = d.keys + (size_t)cam * d.cand_cap;
     const double md2 = (double)min_dist * (double)min_dist;

@@ -5,6 +5,7 @@
 #define FE_MAX_CELLS 1024
 #define FE_CAND_CAP 65536           // power of two >= number of 3x3 local maxima of a 752x480 frame
 
+#define FE_CNT_STRIDE 64
 struct FeDev {
     int W, H, cams, max_level, max_pts, max_count;
     float min_eig_thr;
@@ -23,7 +24,8 @@ struct FeDev {
     const uint8_t* mask;            // [cams][H][W]
     float* blockmax;                // [cams][nblk_eig]
     int nblk_eig;
-    unsigned* ncand;                // [cams]
+    unsigned* ncand;                // [cams][FE_CNT_STRIDE]: [0] candidate count, [32] ordered-uint eig maximum; one
+                                    // 256-byte line per stream (same-line atomics of different streams serialise in L2)
     unsigned long long* keys;       // [cams][FE_CAND_CAP]
     int cand_cap;
     const int* max_corners;         // [cams]
