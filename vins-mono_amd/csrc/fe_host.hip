@@ -27,8 +27,7 @@ __global__ void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* con
 __global__ void fe_lk_kernel(FeDev d);
 __global__ void fe_mineig_kernel(FeDev d);
 __global__ void fe_candidates_kernel(FeDev d, double quality);
-__global__ void fe_sort_kernel(FeDev d);
-__global__ void fe_mindist_kernel(FeDev d, float min_dist);
+hipError_t fe_launch_select(const FeDev& d, double quality, float min_dist, hipStream_t stream);
 }
 
 struct FeState {
@@ -273,8 +272,7 @@ extern "C" int vg_fe_detect_async(vg_handle* h, double quality, double min_dist)
     const dim3 g((d.W + 63) / 64, (d.H + 3) / 4, d.cams);
     hipLaunchKernelGGL(fe_mineig_kernel, g, dim3(256), 0, h->stream, d);
     hipLaunchKernelGGL(fe_candidates_kernel, g, dim3(256), 0, h->stream, d, quality);
-    hipLaunchKernelGGL(fe_sort_kernel, dim3(d.cams), dim3(1024), 0, h->stream, d);
-    hipLaunchKernelGGL(fe_mindist_kernel, dim3(d.cams), dim3(64), 0, h->stream, d, (float)min_dist);
+    HIPCHK(h, fe_launch_select(d, quality, (float)min_dist, h->stream));
     HIPCHK(h, hipGetLastError());
     return VG_OK;
 }

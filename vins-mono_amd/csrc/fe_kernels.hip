@@ -496,97 +496,197 @@ extern "C" __global__ __launch_bounds__(256) void fe_candidates_kernel(FeDev d, 
 }
 
 // one workgroup (1024 threads) per camera: in-place bitonic sort (descending) of the candidate keys, padded with 0
-#define FE_SORT_LDS 8192
-extern "C" __global__ __launch_bounds__(1024) void fe_sort_kernel(FeDev d) {
-    __shared__ unsigned long long sk[FE_SORT_LDS];          // 64 KB: the usual few thousand candidates sort in LDS
-    const int cam = blockIdx.x;
-    unsigned long long* k = d.keys + (size_t)cam * d.cand_cap;
-    unsigned n = d.ncand[FE_CNT_STRIDE * cam];
-    if (n > (unsigned)d.cand_cap) n = d.cand_cap;
-    unsigned np = 1;
-    while (np < n) np <<= 1;
-    if (np <= FE_SORT_LDS) {
-        for (unsigned i = threadIdx.x; i < np; i += 1024) sk[i] = i < n ? k[i] : 0ull;
-        __syncthreads();
-        for (unsigned size = 2; size <= np; size <<= 1)
-            for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
-                for (unsigned t = threadIdx.x; t < np / 2; t += 1024) {
-                    const unsigned lo = 2 * t - (t & (stride - 1));      // index with bit `stride` cleared
-                    const unsigned hi = lo + stride;
-                    const bool desc = ((lo & size) == 0);
-                    const unsigned long long a = sk[lo], b = sk[hi];
-                    if ((a < b) == desc) { sk[lo] = b; sk[hi] = a; }
-                }
-                __syncthreads();
-            }
-        for (unsigned i = threadIdx.x; i < n; i += 1024) k[i] = sk[i];
-        return;
-    }
-    for (unsigned i = n + threadIdx.x; i < np; i += 1024) k[i] = 0ull;
-    __syncthreads();
-    for (unsigned size = 2; size <= np; size <<= 1)
-        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
-            for (unsigned t = threadIdx.x; t < np / 2; t += 1024) {
-                const unsigned lo = 2 * t - (t & (stride - 1));
-                const unsigned hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long a = k[lo], b = k[hi];
-                if ((a < b) == desc) { k[lo] = b; k[hi] = a; }
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
-}
-
-// one wavefront per camera: the sequential min-distance selection of goodFeaturesToTrack, candidates in sorted
-// order; a 3x3 cell neighbourhood is checked by 9 x 7 lanes at once (cells hold at most 7 corners: they are
-// >= cell apart).  Output: integer pixel coordinates as floats, in acceptance order.
-extern "C" __global__ __launch_bounds__(64) void fe_mindist_kernel(FeDev d, float min_dist) {
-    __shared__ unsigned short cellxy[FE_MAX_CELLS][7][2];
-    __shared__ unsigned char cellcnt[FE_MAX_CELLS];
-    const int cam = blockIdx.x, lane = threadIdx.x, W = d.W, H = d.H;
-    const int maxc = d.max_corners[cam];
-    const int cell = __float2int_rn(min_dist) < 1 ? 1 : __float2int_rn(min_dist);
-    const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
-    for (int k = lane; k < gw * gh; k += 64) cellcnt[k] = 0;
-    __syncthreads();
-    unsigned n = d.ncand[FE_CNT_STRIDE * cam];
-    if (n > (unsigned)d.cand_cap) n = d.cand_cap;
-    const unsigned long long* keys = d.keys + (size_t)cam * d.cand_cap;
-    const double md2 = (double)min_dist * (double)min_dist;
-    int nacc = 0;
-    const bool use_dist = min_dist >= 1.f;
-    for (unsigned base = 0; base < n && nacc < maxc; base += 64) {
-        const unsigned long long mykey = (base + lane < n) ? keys[base + lane] : 0ull;
-        const int cnt = (n - base) < 64u ? (int)(n - base) : 64;
-        for (int j = 0; j < cnt && nacc < maxc; ++j) {
-            const unsigned idx = (unsigned)__shfl(mykey, j, 64);
-            const int y = idx / W, x = idx % W;
-            const int xc = x / cell, yc = y / cell;
+// ================================================================================================ select
+// goodFeaturesToTrack's "sort all corners by quality, then walk them greedily with the min-distance grid"
+// (featureselect.cpp) — but the walk stops after max_corners acceptances, typically inside the best few hundred of
+// tens of thousands of candidates.  One workgroup per stream:
+//   1. histogram of the candidates over 4096 value bins (linear between the threshold and the maximum; monotone)
+//   2. take bins from the top until ~FE_SEL_CAP candidates are covered, compact them into LDS, bitonic-sort (full 64-bit
+//      key: value desc, then index desc = OpenCV's pointer tie-break), wave 0 walks them with the cell grid
+//   3. repeat with the next bins while corners are still missing.
+// The visiting order is exactly the order of the full sort, so the output is identical.  A single bin holding more than
+// FE_SEL_CAP candidates (flat images) falls back to the full bitonic sort in global memory.
+#define FE_SEL_CAP 4096
+#define FE_SEL_BINS 4096
+struct SelWalk {
+    unsigned short (*cellxy)[7][2];
+    unsigned char* cellcnt;
+    int W, H, cell, gw, gh, maxc;
+    double md2;
+    bool use_dist;
+};
+// wave 0 only: visit `cnt` sorted keys, append accepted corners; returns the new acceptance count
+FDEV int sel_walk(const SelWalk& w, const unsigned long long* keys, unsigned cnt, int nacc, float* corners, int lane) {
+    for (unsigned base = 0; base < cnt && nacc < w.maxc; base += 64) {
+        const unsigned long long mykey = (base + lane < cnt) ? keys[base + lane] : 0ull;
+        const int m = (cnt - base) < 64u ? (int)(cnt - base) : 64;
+        for (int j = 0; j < m && nacc < w.maxc; ++j) {
+            const unsigned idx = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mykey & 0xffffffffull), j);
+            const int y = idx / w.W, x = idx % w.W;
+            const int xc = x / w.cell, yc = y / w.cell;
             bool bad = false;
-            if (use_dist && lane < 63) {
+            if (w.use_dist && lane < 63) {
                 const int nb = lane / 7, slot = lane % 7;          // 9 neighbour cells x 7 slots
                 const int cx = xc - 1 + nb % 3, cy = yc - 1 + nb / 3;
-                if (cx >= 0 && cy >= 0 && cx < gw && cy < gh) {
-                    const int c = cy * gw + cx;
-                    if (slot < cellcnt[c]) {
-                        const float dx = (float)(x - (int)cellxy[c][slot][0]), dy = (float)(y - (int)cellxy[c][slot][1]);
-                        bad = (double)(dx * dx + dy * dy) < md2;
+                if (cx >= 0 && cy >= 0 && cx < w.gw && cy < w.gh) {
+                    const int c = cy * w.gw + cx;
+                    if (slot < w.cellcnt[c]) {
+                        const float dx = (float)(x - (int)w.cellxy[c][slot][0]), dy = (float)(y - (int)w.cellxy[c][slot][1]);
+                        bad = (double)(dx * dx + dy * dy) < w.md2;
                     }
                 }
             }
             if (!__any(bad)) {
                 if (lane == 0) {
-                    const int c = yc * gw + xc;
-                    const int k = cellcnt[c];
-                    if (k < 7) { cellxy[c][k][0] = (unsigned short)x; cellxy[c][k][1] = (unsigned short)y; cellcnt[c] = (unsigned char)(k + 1); }
-                    float* o = d.corners + ((size_t)cam * d.max_pts + nacc) * 2;
-                    o[0] = (float)x; o[1] = (float)y;
+                    const int c = yc * w.gw + xc;
+                    const int k = w.cellcnt[c];
+                    if (k < 7) { w.cellxy[c][k][0] = (unsigned short)x; w.cellxy[c][k][1] = (unsigned short)y; w.cellcnt[c] = (unsigned char)(k + 1); }
+                    corners[nacc * 2] = (float)x; corners[nacc * 2 + 1] = (float)y;
                 }
                 ++nacc;
-                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // lane 0's cell update before the next visit
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
-    if (lane == 0) d.ncorners[cam] = nacc;
+    return nacc;
+}
+FDEV void sel_bitonic_lds(unsigned long long* sk, unsigned np) {
+    for (unsigned size = 2; size <= np; size <<= 1)
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned t = threadIdx.x; t < np / 2; t += 1024) {
+                const unsigned lo = 2 * t - (t & (stride - 1));      // index with bit `stride` cleared
+                const unsigned hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = sk[lo], b = sk[hi];
+                if ((a < b) == desc) { sk[lo] = b; sk[hi] = a; }
+            }
+            __syncthreads();
+        }
+}
+extern "C" __global__ __launch_bounds__(1024) void fe_select_kernel(FeDev d, double quality, float min_dist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sel_smem[];
+    unsigned long long* sk = (unsigned long long*)sel_smem;                               // [FE_SEL_CAP]
+    unsigned* hist = (unsigned*)(sk + FE_SEL_CAP);                                        // [FE_SEL_BINS]
+    unsigned* grp = hist + FE_SEL_BINS;                                                   // [64] group sums
+    int* ctl = (int*)(grp + 64);                                                          // [8]
+    unsigned short (*cellxy)[7][2] = (unsigned short (*)[7][2])(ctl + 8);                 // [FE_MAX_CELLS][7][2]
+    unsigned char* cellcnt = (unsigned char*)(cellxy + FE_MAX_CELLS);                     // [FE_MAX_CELLS]
+    const int cam = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SelWalk w;
+    w.cellxy = cellxy; w.cellcnt = cellcnt; w.W = d.W; w.H = d.H;
+    w.maxc = d.max_corners[cam];
+    w.cell = __float2int_rn(min_dist) < 1 ? 1 : __float2int_rn(min_dist);
+    w.gw = (d.W + w.cell - 1) / w.cell; w.gh = (d.H + w.cell - 1) / w.cell;
+    w.md2 = (double)min_dist * (double)min_dist;
+    w.use_dist = min_dist >= 1.f;
+    for (int k = tid; k < w.gw * w.gh; k += 1024) cellcnt[k] = 0;
+    unsigned n = d.ncand[FE_CNT_STRIDE * cam];
+    if (n > (unsigned)d.cand_cap) n = d.cand_cap;
+    unsigned long long* keys = d.keys + (size_t)cam * d.cand_cap;
+    float* corners = d.corners + (size_t)cam * d.max_pts * 2;
+    int nacc = 0;
+    if (n <= FE_SEL_CAP) {
+        unsigned np = 1;
+        while (np < n) np <<= 1;
+        for (unsigned i = tid; i < np; i += 1024) sk[i] = i < n ? keys[i] : 0ull;
+        __syncthreads();
+        sel_bitonic_lds(sk, np);
+        if (wave == 0) { nacc = sel_walk(w, sk, n, 0, corners, lane); if (lane == 0) d.ncorners[cam] = nacc; }
+        return;
+    }
+    // value bins: linear between the threshold and the maximum (same expressions as fe_candidates_kernel)
+    const unsigned smax = d.ncand[FE_CNT_STRIDE * cam + 32];
+    const float mf = smax ? funord(smax) : -INFINITY;
+    const double maxVal = (mf == -INFINITY) ? 0.0 : (double)mf;
+    const float thr = (float)(maxVal * quality);
+    const float span = (float)maxVal - thr;
+    const float scale = span > 0.f ? (float)(FE_SEL_BINS - 1) / span : 0.f;
+    auto bin_of = [&](unsigned long long key) {
+        const float v = funord((unsigned)(key >> 32));
+        int b = (int)((v - thr) * scale);
+        return b < 0 ? 0 : (b > FE_SEL_BINS - 1 ? FE_SEL_BINS - 1 : b);
+    };
+    for (int k = tid; k < FE_SEL_BINS; k += 1024) hist[k] = 0u;
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += 1024) atomicAdd(&hist[bin_of(keys[i])], 1u);
+    __syncthreads();
+    int b_hi = FE_SEL_BINS - 1;
+    for (;;) {
+        // ---- next chunk of bins [b_lo, b_hi]: wave 0 sums groups of 64 bins, lane 0 packs
+        if (wave == 0) {
+            unsigned g = 0;
+            const int top = b_hi - 64 * lane;                 // lane covers bins top-63 .. top (descending groups)
+            for (int q = 0; q < 64; ++q) { const int b = top - q; g += b >= 0 ? hist[b] : 0u; }
+            grp[lane] = g;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                unsigned tot = 0;
+                int b = b_hi, gi = 0;
+                while (gi < 64 && b - 63 >= 0 && tot + grp[gi] <= FE_SEL_CAP) { tot += grp[gi]; b -= 64; ++gi; }
+                while (b >= 0 && tot + hist[b] <= FE_SEL_CAP) { tot += hist[b]; --b; }
+                ctl[0] = b + 1;                               // b_lo
+                ctl[1] = (int)tot;
+                ctl[2] = (b == b_hi) ? 1 : 0;                 // a single bin exceeds the capacity -> fallback
+                ctl[3] = 0;                                   // compaction counter
+            }
+        }
+        __syncthreads();
+        const int b_lo = ctl[0];
+        if (ctl[2]) break;
+        for (unsigned i = tid; i < n; i += 1024) {
+            const unsigned long long key = keys[i];
+            const int b = bin_of(key);
+            if (b >= b_lo && b <= b_hi) sk[atomicAdd((unsigned*)&ctl[3], 1u)] = key;
+        }
+        __syncthreads();
+        const unsigned cnt = (unsigned)ctl[1];
+        unsigned np = 1;
+        while (np < cnt) np <<= 1;
+        for (unsigned i = cnt + tid; i < np; i += 1024) sk[i] = 0ull;
+        __syncthreads();
+        sel_bitonic_lds(sk, np);
+        if (wave == 0) {
+            nacc = sel_walk(w, sk, cnt, nacc, corners, lane);
+            if (lane == 0) ctl[4] = nacc;
+        }
+        __syncthreads();
+        nacc = ctl[4];
+        if (nacc >= w.maxc || b_lo == 0) { if (tid == 0) d.ncorners[cam] = nacc; return; }
+        b_hi = b_lo - 1;
+        __syncthreads();
+    }
+    // ---- fallback: full bitonic sort in global memory, then one walk (restarted from scratch: the chunks walked so
+    //      far are a prefix of the same order, so re-walking them reproduces the same acceptances)
+    for (int k = tid; k < w.gw * w.gh; k += 1024) cellcnt[k] = 0;
+    unsigned np = 1;
+    while (np < n) np <<= 1;
+    for (unsigned i = n + tid; i < np; i += 1024) keys[i] = 0ull;
+    __syncthreads();
+    for (unsigned size = 2; size <= np; size <<= 1)
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned t = tid; t < np / 2; t += 1024) {
+                const unsigned lo = 2 * t - (t & (stride - 1));
+                const unsigned hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    if (wave == 0) { nacc = sel_walk(w, keys, n, 0, corners, lane); if (lane == 0) d.ncorners[cam] = nacc; }
+}
+#define FE_SEL_LDS_BYTES (FE_SEL_CAP * 8 + FE_SEL_BINS * 4 + 64 * 4 + 8 * 4 + FE_MAX_CELLS * 7 * 2 * 2 + FE_MAX_CELLS)
+
+extern "C" hipError_t fe_launch_select(const FeDev& d, double quality, float min_dist, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fe_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FE_SEL_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fe_select_kernel, dim3(d.cams), dim3(1024), FE_SEL_LDS_BYTES, stream, d, quality, min_dist);
+    return hipGetLastError();
 }
