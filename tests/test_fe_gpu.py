@@ -169,3 +169,22 @@ def test_other_image_size_and_stride(handle):
     assert np.array_equal(st, rst) and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     for lvl in range(4):
         assert np.array_equal(tr.get_level(0, lvl), eb if lvl == 0 else F.pyrdown(tr.get_level(0, lvl - 1)))
+
+
+def test_gftt_selection_paths(handle, frames):
+    """fe_select_kernel: (a) more corners wanted than the first value chunk yields -> several chunks are walked;
+    (b) a periodic texture puts thousands of candidates on identical values -> single-bin overflow -> full-sort path;
+    both must give the reference's ordered list (value desc, larger index first)."""
+    tr = fe.FrontEnd(handle, W, H, 1, 1200)
+    tr.push_frames([frames[0]])
+    got = tr.detect(0, 1200, 0.01, 20.0)
+    ref = F.gftt(frames[0], 1200, 0.01, 20.0)
+    assert len(ref) > 500 and got.shape == ref.shape and np.array_equal(got, ref)
+    rng = np.random.default_rng(5)
+    tile = rng.integers(0, 256, (8, 8)).astype(np.uint8)
+    per = np.tile(tile, (H // 8, W // 8))
+    tr.push_frames([per])
+    for n in (150, 1200):
+        got = tr.detect(0, n, 0.01, 20.0)
+        ref = F.gftt(per, n, 0.01, 20.0)
+        assert got.shape == ref.shape and np.array_equal(got, ref), n
