@@ -191,6 +191,17 @@ def main():
         km.append(b)
     solve_ms, marg_ms = float(np.mean(ks)), float(np.mean(km))
 
+    # boundary-inclusive rate (host buffers in, host buffers out: pack + H2D + both launches + D2H), NOT the metric
+    t_pc = time.perf_counter()
+    c_ms = 0.0
+    for _ in range(3):
+        h.ba_upload(packed, flags)
+        h.ba_run_async()
+        h.ba_download()                              # (synchronises on the launches)
+        c_ms += h.last_upload_call_ms + h.last_download_call_ms
+    pcie_ms = (time.perf_counter() - t_pc) / 3 * 1e3
+    c_ms /= 3
+
     # sanity: results of the timed batch are valid
     st, sm, pr = h.ba_download()
     n_ok = sum(1 for s in sm if s['status'] == 0)
@@ -268,6 +279,11 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "single_window_latency_ms": None,
+            "host_boundary_inclusive": {"c_abi_ms_per_batch": c_ms, "c_abi_solves_per_s": nwin / (c_ms * 1e-3),
+                                        "python_ms_per_batch": pcie_ms,
+                                        "what": "c_abi = time inside vg_ba_batch_upload (pack + H2D) and vg_ba_batch_download "
+                                                "(wait for both launches + D2H + unpack), synchronous, single host thread, "
+                                                "per GPU; python = the same incl. the ctypes marshalling of this bench"},
         }
     fe_out = bench_fe(h, synth, max(args.steps, 10), args.warmup, rank, rank == 0 and not args.no_cpu_baseline)
     fe_out["value_all_gpus"] = D.sum_over_ranks(fe_out["value"])

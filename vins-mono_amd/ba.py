@@ -2,6 +2,7 @@
 
 `prob` dicts are the ones produced by `synth.py` (and by the tests): see synth.py's docstring.
 """
+import time
 import ctypes as C
 import numpy as np
 
@@ -217,7 +218,9 @@ class Handle:
         arr = (C.POINTER(Problem) * n)(*[C.pointer(p.struct) for p in self._packed])
         mf = np.ascontiguousarray(margin_flags if margin_flags is not None else [VG_MARGIN_NONE] * n, dtype=np.int32)
         self._margin = mf
+        t0 = time.perf_counter()
         self._chk(self.lib.vg_ba_batch_upload(self.h, n, arr, _ip(mf)), "vg_ba_batch_upload")
+        self.last_upload_call_ms = (time.perf_counter() - t0) * 1e3        # the C-ABI call alone (pack + H2D + sync)
 
     def ba_run_async(self):
         self._chk(self.lib.vg_ba_batch_run_async(self.h), "vg_ba_batch_run_async")
@@ -242,7 +245,9 @@ class Handle:
         st = (C.POINTER(State) * n)(*[C.pointer(o.state) for o in outs])
         pri = (C.POINTER(Prior) * n)(*[C.pointer(o.prior) if o.prior is not None else None for o in outs])
         sm = (Summary * n)()
+        t0 = time.perf_counter()
         rc = self.lib.vg_ba_batch_download(self.h, n, st, sm, pri)
+        self.last_download_call_ms = (time.perf_counter() - t0) * 1e3      # the C-ABI call alone (sync + D2H + unpack)
         if rc != VG_OK and not (allow_numeric_failure and rc == -4):
             self._chk(rc, "vg_ba_batch_download")
         return ([o.state_dict(p.has_relo) for o, p in zip(outs, self._packed)],
