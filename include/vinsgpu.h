@@ -66,6 +66,17 @@ typedef struct {
     int _pad;
 } vg_imu_preint;
 
+/* Batched IMU pre-integration — replaces IntegrationBase::push_back / propagate / midPointIntegration and, with new
+ * linearisation biases, IntegrationBase::repropagate (factor/integration_base.h:30-158), as driven by
+ * Estimator::processIMU (estimator.cpp:93-101) and the bias-change re-propagation of estimator.cpp:600-609.
+ * Interval k integrates the samples [sample_off[k], sample_off[k+1]) — rows (dt, acc_x, acc_y, acc_z, gyr_x, gyr_y,
+ * gyr_z) of `samples` — starting from the measurement first[k] = (acc_0, gyr_0) (IntegrationBase ctor,
+ * integration_base.h:15-27) with the biases bias[k] = (linearized_ba, linearized_bg); noise = (ACC_N, GYR_N, ACC_W,
+ * GYR_W) of the estimator configuration.  out[k].valid is set to 1 (the sum_dt > 10 s rule of estimator.cpp:714 is
+ * applied where the factor is used).  SURVEY.md 8(f) row 2. */
+int vg_imu_preintegrate(vg_handle* h, int n_intervals, const int* sample_off, const double* samples, const double* first,
+                        const double* bias, const double* noise, vg_imu_preint* out);
+
 /* block kinds of the marginalization prior (MarginalizationInfo::keep_block_*) */
 enum { VG_BLK_POSE = 0, VG_BLK_SPEEDBIAS = 1, VG_BLK_EXPOSE = 2, VG_BLK_TD = 3 };
 enum { VG_MARGIN_OLD = 0, VG_MARGIN_SECOND_NEW = 1, VG_MARGIN_NONE = 2 };

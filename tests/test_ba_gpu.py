@@ -301,3 +301,47 @@ def test_full_size_batch_against_cpp_oracle(handle):
         assert np.allclose(st2[i]['pose'][0, :3], p['pose'][0, :3], atol=1e-12)
         y0, y1 = B.R2ypr(B.q2R(p['pose'][0, 3:]))[0], B.R2ypr(B.q2R(st2[i]['pose'][0, 3:]))[0]
         assert abs(y0 - y1) < 1e-9
+
+
+def test_imu_preintegration_on_device(handle):
+    """vg_imu_preintegrate vs the two independent CPU restatements of IntegrationBase
+    (oracle/ba_numpy.Preintegration, synth.preintegrate): mid-point states, 15x15 jacobian and covariance; ragged
+    intervals (1, 20 and 120 samples, the last one longer than 10 s), repropagation with other biases."""
+    rng = np.random.default_rng(77)
+    noise = (0.08, 0.004, 4e-5, 2e-6)
+    intervals, biases = [], []
+    for n, dt in ((1, 0.005), (20, 0.005), (120, 0.1), (7, 0.0049)):
+        iv = [(0.0, rng.normal(0, 1, 3) + [0, 0, 9.8], rng.normal(0, 0.3, 3))]
+        for _ in range(n):
+            iv.append((dt, rng.normal(0, 1, 3) + [0, 0, 9.8], rng.normal(0, 0.3, 3)))
+        intervals.append(iv)
+        biases.append((rng.normal(0, 0.05, 3), rng.normal(0, 0.02, 3)))
+    got = handle.imu_preintegrate(intervals, biases, noise)
+    for iv, (ba_, bg_), g in zip(intervals, biases, got):
+        ref = B.Preintegration(iv[0][1], iv[0][2], ba_, bg_, *noise)
+        for dt, a, w in iv[1:]:
+            ref.push_back(dt, a, w)
+        r = ref.as_dict()
+        r2 = synth.preintegrate(iv, ba_, bg_, *noise)
+        assert np.isclose(g['sum_dt'], r['sum_dt'], rtol=1e-14)
+        for key in ('delta_p', 'delta_q', 'delta_v', 'jacobian', 'covariance'):
+            scale = max(1e-300, np.abs(r[key]).max())
+            assert np.abs(g[key] - r[key]).max() <= 1e-11 * scale, key
+            assert np.abs(g[key] - r2[key]).max() <= 1e-11 * scale, key
+        assert np.array_equal(g['lin_ba'], np.asarray(ba_)) and np.array_equal(g['lin_bg'], np.asarray(bg_))
+    assert got[2]['sum_dt'] > 10.0
+    # the device result feeds the BA unchanged: same window solved with device-side pre-integration
+    seq = synth.SyntheticSequence(61, L=30)
+    prob = seq.window(0)
+    ref_state, _, _ = handle.ba_optimize(prob)
+    c = seq.cfg
+    ivs = []
+    h = seq.frame_dt / seq.imu_per_frame
+    for k in range(prob['pose'].shape[0] - 1):
+        t = seq.times[k]
+        ivs.append([(0.0,) + seq._imu_sample(t)] + [(h,) + seq._imu_sample(t + s * h) for s in range(1, seq.imu_per_frame + 1)])
+    dev = handle.imu_preintegrate(ivs, [(seq.ba_lin, seq.bg_lin)] * len(ivs), (c['acc_n'], c['gyr_n'], c['acc_w'], c['gyr_w']))
+    p2 = dict(prob)
+    p2['imu'] = dev
+    st2, sm2, _ = handle.ba_optimize(p2)
+    assert sm2['status'] == 0 and np.abs(st2['pose'] - ref_state['pose']).max() < 1e-9

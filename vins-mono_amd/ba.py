@@ -179,6 +179,7 @@ class Handle:
         L.vg_ba_batch_info.argtypes = [C.c_void_p, _pd, _pd, _pd, _pi]
         L.vg_ba_batch_flops.argtypes = [C.c_void_p, _pd, _pd]
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
+        L.vg_imu_preintegrate.argtypes = [C.c_void_p, C.c_int, _pi, _pd, _pd, _pd, _pd, C.POINTER(ImuPreint)]
         self.h = C.c_void_p()
         rc = L.vg_create(C.byref(self.h))
         if rc != VG_OK:
@@ -260,6 +261,31 @@ class Handle:
         self.ba_run_async()
         st, sm, pr = self.ba_download()
         return st[0], sm[0], pr[0]
+
+    def imu_preintegrate(self, intervals, biases, noise):
+        """Batched IntegrationBase (integration_base.h:30-158).  intervals[k] = [(dt, acc, gyr), ...] with entry 0 =
+        (0, acc_0, gyr_0) the first measurement (the layout of synth.preintegrate); biases[k] = (ba, bg);
+        noise = (acc_n, gyr_n, acc_w, gyr_w).  Returns the list of pre-integration dicts vg_ba_problem consumes."""
+        n = len(intervals)
+        off = np.zeros(n + 1, np.int32)
+        rows, first = [], np.zeros((n, 6))
+        for k, iv in enumerate(intervals):
+            first[k, :3], first[k, 3:] = iv[0][1], iv[0][2]
+            for dt, a, g in iv[1:]:
+                rows.append([dt, a[0], a[1], a[2], g[0], g[1], g[2]])
+            off[k + 1] = len(rows)
+        smp = np.ascontiguousarray(rows if rows else np.zeros((1, 7)), dtype=np.float64)
+        bias = np.ascontiguousarray([np.concatenate([np.asarray(b[0], float), np.asarray(b[1], float)]) for b in biases])
+        nz = np.ascontiguousarray(noise, dtype=np.float64)
+        out = (ImuPreint * n)()
+        self._chk(self.lib.vg_imu_preintegrate(self.h, n, _ip(off), _dp(smp), _dp(np.ascontiguousarray(first)), _dp(bias), _dp(nz), out),
+                  "vg_imu_preintegrate")
+        res = []
+        for q in out:
+            res.append(dict(sum_dt=q.sum_dt, delta_p=np.array(q.delta_p), delta_q=np.array(q.delta_q), delta_v=np.array(q.delta_v),
+                            lin_ba=np.array(q.linearized_ba), lin_bg=np.array(q.linearized_bg),
+                            jacobian=np.array(q.jacobian).reshape(15, 15), covariance=np.array(q.covariance).reshape(15, 15)))
+        return res
 
     def ba_eval_factors(self, prob):
         p = PackedProblem(prob)
