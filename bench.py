@@ -242,7 +242,7 @@ def main():
             "hbm_GBs_algorithmic": (info['bytes_in'] + info['bytes_out']) / ((solve_ms + marg_ms) * 1e-3) / 1e9,
         }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)
             from oracle import ba_cpu
             ncpu = min(nwin, 64)
             reps = 1
@@ -285,7 +285,7 @@ def main():
                                                 "(wait for both launches + D2H + unpack), synchronous, single host thread, "
                                                 "per GPU; python = the same incl. the ctypes marshalling of this bench"},
         }
-    fe_out = bench_fe(h, synth, max(args.steps, 10), args.warmup, rank, rank == 0 and not args.no_cpu_baseline)
+    fe_out = bench_fe(h, synth, max(args.steps, 10), args.warmup, rank, rank == 0 and world == 1 and not args.no_cpu_baseline)
     fe_out["value_all_gpus"] = D.sum_over_ranks(fe_out["value"])
     # single-window latency (configs[2]) on rank 0
     if rank == 0:
