@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=WINDOWS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
+                    "2-rank self-test on a 1-GPU box together with --share-device)")
+    ap.add_argument("--share-device", action="store_true", help="self-test: all ranks use cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -155,8 +158,10 @@ def main():
     rank, local_rank, world = D.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    D.init("nccl", local_rank)          # one process per GPU; RCCL only for barrier / max / sum of the timing
+    D.init(args.backend, local_rank)    # one process per GPU; RCCL only for barrier / max / sum of the timing
 
     h = ba.Handle()
     nwin = args.windows

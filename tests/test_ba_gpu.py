@@ -345,3 +345,58 @@ def test_imu_preintegration_on_device(handle):
     p2['imu'] = dev
     st2, sm2, _ = handle.ba_optimize(p2)
     assert sm2['status'] == 0 and np.abs(st2['pose'] - ref_state['pose']).max() < 1e-9
+
+
+def test_ragged_batch_matches_single_windows(handle):
+    """One launch with windows of different sizes / structure (L = 12, 60, 150; with and without prior; with and
+    without marginalization): every window must equal its own single-window launch bit for bit, and the oracle."""
+    _, _, wp = _window_with_prior(71, L=60)
+    probs = [synth.SyntheticSequence(72, L=12).window(0), wp, synth.SyntheticSequence(73, L=150).window(0)]
+    flags = [ba.VG_MARGIN_NONE, ba.VG_MARGIN_OLD, ba.VG_MARGIN_SECOND_NEW]
+    handle.ba_upload(probs, flags)
+    handle.ba_run_async()
+    st, sm, pr = handle.ba_download()
+    for i, p in enumerate(probs):
+        s1, m1, p1 = handle.ba_optimize(p, flags[i])
+        assert sm[i]['status'] == 0 and sm[i]['num_iterations'] == m1['num_iterations']
+        assert np.array_equal(st[i]['pose'], s1['pose']) and np.array_equal(st[i]['sb'], s1['sb'])
+        assert np.array_equal(st[i]['inv_depth'], s1['inv_depth'])
+        assert (pr[i] is None) == (p1 is None)
+        if p1 is not None:
+            assert np.array_equal(pr[i]['J0'], p1['J0']) and np.array_equal(pr[i]['r0'], p1['r0'])
+        x, summ = B.solve(p)
+        ref = B.double2vector(p, x)
+        assert np.abs(st[i]['pose'] - ref['pose']).max() < 1e-6
+    assert pr[0] is None and pr[1] is not None
+
+
+def test_error_behaviour(handle):
+    """Status codes instead of exceptions on the data path: a non-finite input poisons only
+    its own window (VG_ERR_NUMERIC, failureDetection() territory); structural errors are refused up front."""
+    good = synth.SyntheticSequence(74, L=30).window(0)
+    bad = dict(good)
+    bad['pose'] = good['pose'].copy()
+    bad['pose'][3, 0] = np.nan
+    handle.ba_upload([good, bad, good], [ba.VG_MARGIN_OLD] * 3)
+    handle.ba_run_async()
+    st, sm, pr = handle.ba_download(allow_numeric_failure=True)
+    assert sm[0]['status'] == 0 and sm[2]['status'] == 0 and sm[1]['status'] == -4
+    assert pr[1] is None and pr[0] is not None
+    assert np.array_equal(st[0]['pose'], st[2]['pose'])
+    with pytest.raises(RuntimeError, match="status -4"):
+        handle.ba_upload([bad])
+        handle.ba_run_async()
+        handle.ba_download()
+    # too many frames for the single-workgroup LDS design -> refused, not silently wrong
+    big = dict(good)                             # 14 frames: R = 15 * 14 + 6 = 216 -> S alone is 189 KB of LDS
+    big['pose'] = np.vstack([good['pose']] + [good['pose'][-1:]] * 3)
+    big['sb'] = np.vstack([good['sb']] + [good['sb'][-1:]] * 3)
+    big['imu'] = list(good['imu']) + [good['imu'][-1]] * 3
+    with pytest.raises(RuntimeError, match="status -3"):
+        handle.ba_upload([big])
+    # inconsistent tables
+    broken = dict(good)
+    broken['lm_nobs'] = good['lm_nobs'].copy()
+    broken['lm_nobs'][0] = 1                     # a landmark needs >= 2 observations (estimator.cpp:723)
+    with pytest.raises(RuntimeError, match="status -1"):
+        handle.ba_upload([broken])

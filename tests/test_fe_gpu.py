@@ -188,3 +188,19 @@ def test_gftt_selection_paths(handle, frames):
         got = tr.detect(0, n, 0.01, 20.0)
         ref = F.gftt(per, n, 0.01, 20.0)
         assert got.shape == ref.shape and np.array_equal(got, ref), n
+
+
+def test_fe_edge_sizes_and_errors(handle, frames):
+    tr = fe.FrontEnd(handle, W, H, 1, 64)
+    tr.push_frames([frames[0]])
+    tr.push_frames([frames[1]])
+    got, st, err = tr.track(0, np.zeros((0, 2), np.float32))          # nothing to track
+    assert got.shape == (0, 2) and st.shape == (0,)
+    assert tr.detect(0, 0).shape == (0, 2)                              # MAX_CNT already reached (feature_tracker.cpp:140)
+    pts = F.gftt(frames[0], 64)
+    assert len(pts) == 64
+    _check_lk(tr, 0, frames[0], frames[1], pts)                         # exactly the configured capacity
+    with pytest.raises(RuntimeError):
+        tr.track(0, np.zeros((65, 2), np.float32))                      # above capacity: refused
+    with pytest.raises(RuntimeError):
+        tr.detect(0, 10, 0.01, 5.0)                                     # min_dist below the cell-grid limit: refused
