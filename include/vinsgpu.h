@@ -241,10 +241,26 @@ int vg_fe_detect(vg_handle* h, int cam, const uint8_t* mask, int max_corners, do
 int vg_fe_detect_upload(vg_handle* h, const uint8_t* const* masks /* per cam or NULL */, const int* max_corners);
 int vg_fe_detect_async(vg_handle* h, double quality, double min_dist);
 int vg_fe_detect_download(vg_handle* h, float* out_xy /* [n_cams][max_points][2] */, int* out_n /* [n_cams] */);
+/* FeatureTracker::setMask() (feature_tracker.cpp:36-69) for all streams: the points of stream c
+ * (pts_xy[c][i], track_cnt[c][i], i < n[c]; arrays are [n_cams][max_points]) are visited by track_cnt descending
+ * (stable), a point is kept iff the mask at its rounded position is still 255, and every kept point blanks the filled
+ * disc of `radius` (MIN_DIST) around it.  base_masks[c] = the FISHEYE mask (:38-41) or NULL (all 255); base_masks may
+ * be NULL.  kept_index[c][k] = index of the k-th kept point, n_kept[c] their number.  The final mask stays on the
+ * device as the mask of stream c for vg_fe_detect_masked(). */
+int vg_fe_set_mask(vg_handle* h, const float* pts_xy, const int* track_cnt, const int* n, const uint8_t* const* base_masks,
+                   int radius, int* kept_index, int* n_kept);
+/* cv::goodFeaturesToTrack(forw_img, n_pts, max_corners, quality, min_dist, mask) (:149) with the mask left on the
+ * device by vg_fe_set_mask: no mask upload */
+int vg_fe_detect_masked(vg_handle* h, int cam, int max_corners, double quality, double min_dist, float* out_xy, int* out_n);
+/* FeatureTracker::undistortedPoints() lifting (:258-271): PinholeCamera::liftProjective with the 8-step recursive
+ * distortion model (camera_model PinholeCamera.cc:450-510, :646-661).  intr = fx fy cx cy k1 k2 p1 p2; out = (x/z, y/z)
+ * as float (cv::Point2f). */
+int vg_fe_undistort(vg_handle* h, const float* pts_xy, int n, const double* intr, float* out_xy);
 /* debugging / parity taps: copy a pyramid level of the current (which = 0) or previous (1) frame, or the
  * min-eigenvalue map of the last detect, to host memory */
 int vg_fe_get_level(vg_handle* h, int cam, int which, int level, uint8_t* out, int* w, int* hgt);
 int vg_fe_get_eig(vg_handle* h, int cam, float* out);
+int vg_fe_get_mask(vg_handle* h, int cam, uint8_t* out);          /* current device mask of the stream */
 
 #ifdef __cplusplus
 }

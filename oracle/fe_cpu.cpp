@@ -319,4 +319,52 @@ int oracle_fe_clahe(const uint8_t* src, int w, int h, double clip, uint8_t* dst)
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// FeatureTracker::setMask (feature_tracker.cpp:36-69): start from the fisheye mask or all-255 (:38-41); visit the
+// points by track_cnt descending (:48-51 — std::sort there, i.e. unstable; canonicalised to STABLE, ASSUMPTIONS F7);
+// keep a point iff mask.at<uchar>(Point(pt)) == 255 (:59; Point2f -> Point rounds half to even) and blank
+// cv::circle(mask, pt, radius, 0, -1) (:64) — restated as { (x, y) : dx^2 + dy^2 <= r^2 } clipped to the image [3P].
+// Points whose rounded position is outside the image are skipped (the reference would read out of bounds).
+// kept_index receives indices into the input in kept order; mask_out (w*h) the final mask.  Returns the kept count.
+int oracle_fe_setmask(const float* pts_xy, const int* track_cnt, int n, const uint8_t* base_mask, int w, int h, int radius,
+                      int* kept_index, uint8_t* mask_out) {
+    std::vector<uint8_t> mask((size_t)w * h, 255);
+    if (base_mask) std::memcpy(mask.data(), base_mask, mask.size());
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return track_cnt[a] > track_cnt[b]; });
+    int nk = 0;
+    for (int i : order) {
+        const int px = (int)std::nearbyintf(pts_xy[2 * i]), py = (int)std::nearbyintf(pts_xy[2 * i + 1]);
+        if (px < 0 || py < 0 || px >= w || py >= h) continue;
+        if (mask[(size_t)py * w + px] != 255) continue;
+        kept_index[nk++] = i;
+        for (int y = std::max(0, py - radius); y <= std::min(h - 1, py + radius); ++y)
+            for (int x = std::max(0, px - radius); x <= std::min(w - 1, px + radius); ++x)
+                if ((x - px) * (x - px) + (y - py) * (y - py) <= radius * radius) mask[(size_t)y * w + x] = 0;
+    }
+    if (mask_out) std::memcpy(mask_out, mask.data(), mask.size());
+    return nk;
+}
+
+// PinholeCamera::liftProjective (camera_model/src/camera_models/PinholeCamera.cc:450-510) with the recursive
+// distortion model, n = 8 (:484-493), distortion() of :646-661; result (x/z, y/z) as float like cv::Point2f
+// (feature_tracker.cpp:262-267).  intr = fx fy cx cy k1 k2 p1 p2.
+void oracle_fe_lift(const float* pts_xy, int n, const double* intr, float* out_xy) {
+    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3], k1 = intr[4], k2 = intr[5], p1 = intr[6], p2 = intr[7];
+    const double m_inv_K11 = 1.0 / fx, m_inv_K13 = -cx / fx, m_inv_K22 = 1.0 / fy, m_inv_K23 = -cy / fy;
+    for (int i = 0; i < n; ++i) {
+        const double mx_d = m_inv_K11 * (double)pts_xy[2 * i] + m_inv_K13, my_d = m_inv_K22 * (double)pts_xy[2 * i + 1] + m_inv_K23;
+        double mx_u = mx_d, my_u = my_d;
+        for (int it = 0; it < 8; ++it) {
+            const double mx2 = mx_u * mx_u, my2 = my_u * my_u, mxy = mx_u * my_u, rho2 = mx2 + my2;
+            const double rad = k1 * rho2 + k2 * rho2 * rho2;
+            const double dx = mx_u * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2);
+            const double dy = my_u * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2);
+            mx_u = mx_d - dx; my_u = my_d - dy;
+        }
+        out_xy[2 * i] = (float)mx_u; out_xy[2 * i + 1] = (float)my_u;
+    }
+}
 }  // extern "C"

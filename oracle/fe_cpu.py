@@ -80,3 +80,29 @@ def clahe(img, clip=3.0):
     rc = lib().oracle_fe_clahe(_p8(img), w, h, float(clip), _p8(out))
     assert rc == 0
     return out
+
+
+def setmask(pts, track_cnt, w, h, radius, base_mask=None):
+    """FeatureTracker::setMask (feature_tracker.cpp:36-69): returns (kept indices in kept order, final mask)."""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    cnt = np.ascontiguousarray(track_cnt, np.int32)
+    n = len(pts)
+    kept = np.zeros(max(n, 1), np.int32)
+    mask = np.zeros((h, w), np.uint8)
+    bm = None if base_mask is None else np.ascontiguousarray(base_mask, np.uint8)
+    f = lib().oracle_fe_setmask
+    f.restype = C.c_int
+    nk = f(pts.ctypes.data_as(_f4), cnt.ctypes.data_as(C.POINTER(C.c_int)), n, _p8(bm) if bm is not None else None,
+           int(w), int(h), int(radius), kept.ctypes.data_as(C.POINTER(C.c_int)), _p8(mask))
+    return kept[:nk].copy(), mask
+
+
+def lift(pts, intr):
+    """PinholeCamera::liftProjective with the 8-step recursive distortion model; intr = fx fy cx cy k1 k2 p1 p2."""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    k = np.ascontiguousarray(intr, np.float64)
+    f = lib().oracle_fe_lift
+    f.restype = None
+    f(pts.ctypes.data_as(_f4), len(pts), k.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(_f4))
+    return out

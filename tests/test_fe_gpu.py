@@ -204,3 +204,32 @@ def test_fe_edge_sizes_and_errors(handle, frames):
         tr.track(0, np.zeros((65, 2), np.float32))                      # above capacity: refused
     with pytest.raises(RuntimeError):
         tr.detect(0, 10, 0.01, 5.0)                                     # min_dist below the cell-grid limit: refused
+
+
+def test_set_mask_and_undistort_on_device(handle, frames):
+    """SURVEY 8(f) row 1: FeatureTracker::setMask + liftProjective on the device vs their CPU restatements: kept
+    order, final mask plane (bit-exact), GFTT with the device-resident mask, lifted points (bit-exact floats)."""
+    rng = np.random.default_rng(11)
+    tr = fe.FrontEnd(handle, W, H, 2, 400)
+    tr.push_frames([frames[0], frames[1]])
+    pts = [rng.uniform([-3, -3], [W + 3, H + 3], (300, 2)).astype(np.float32),       # some outside, many clustered
+           np.concatenate([rng.uniform([100, 100], [200, 180], (150, 2)), rng.uniform([0, 0], [W, H], (100, 2))]).astype(np.float32)]
+    pts[0][:5] = [[10.5, 20.5], [11.5, 20.5], [751.49, 479.49], [0.0, 0.0], [376.0, 240.0]]      # half-way cases, corners
+    cnts = [rng.integers(1, 6, 300), rng.integers(1, 40, 250)]
+    fish = np.full((H, W), 255, np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    fish[(xx - W / 2) ** 2 + (yy - H / 2) ** 2 > 300 ** 2] = 0
+    for base in (None, [fish, None]):
+        kept = tr.set_mask(pts, cnts, 30, base)
+        for c in range(2):
+            rk, rmask = F.setmask(pts[c], cnts[c], W, H, 30, None if base is None else base[c])
+            assert np.array_equal(kept[c], rk), c
+            assert np.array_equal(tr.get_mask(c), rmask), c
+            got = tr.detect_masked(c, 150 - min(150, len(rk)) + 20, 0.01, 30.0)
+            ref = F.gftt(frames[c], 150 - min(150, len(rk)) + 20, 0.01, 30.0, rmask)
+            assert np.array_equal(got, ref), c
+    kept = tr.set_mask([pts[0][:0], pts[1][:1]], [cnts[0][:0], cnts[1][:1]], 30)       # empty / single
+    assert len(kept[0]) == 0 and list(kept[1]) == [0]
+    intr = [461.6, 460.3, 363.0, 248.1, -0.2917, 0.08228, 5.333e-05, -1.578e-04]       # euroc_config.yaml:19-30
+    p = rng.uniform([0, 0], [W, H], (400, 2)).astype(np.float32)
+    assert np.array_equal(tr.undistort(p, intr).view(np.uint32), F.lift(p, intr).view(np.uint32))

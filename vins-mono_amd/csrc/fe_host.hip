@@ -28,6 +28,11 @@ __global__ void fe_lk_kernel(FeDev d);
 __global__ void fe_mineig_kernel(FeDev d);
 __global__ void fe_candidates_kernel(FeDev d, double quality);
 hipError_t fe_launch_select(const FeDev& d, double quality, float min_dist, hipStream_t stream);
+__global__ void fe_setmask_kernel(FeDev d, const float* pts_xy, const int* track_cnt, const int* npts, const uint8_t* const* base_masks,
+                                  int radius, int* kept_index, int* n_kept, int* kept_xy);
+__global__ void fe_stamp_kernel(FeDev d, const int* n_kept, const int* kept_xy, int radius);
+__global__ void fe_lift_kernel(const float* pts_xy, int n, double fx, double fy, double cx, double cy, double k1, double k2, double p1,
+                               double p2, float* out_xy);
 }
 
 struct FeState {
@@ -47,6 +52,12 @@ struct FeState {
     unsigned long long* keys = nullptr;
     std::vector<uint8_t> stage;           // pinned-ish host staging for strided uploads
     std::vector<int> h_npts;
+    // setMask / lift, allocated on first use
+    float* sm_pts = nullptr;
+    int *sm_cnt = nullptr, *sm_n = nullptr, *sm_kidx = nullptr, *sm_nk = nullptr, *sm_kxy = nullptr;
+    uint8_t* sm_base = nullptr;
+    const uint8_t** sm_base_ptrs = nullptr;
+    float *lift_in = nullptr, *lift_out = nullptr;
     bool have_prev = false;
     std::vector<char> pushed_once;
 };
@@ -58,6 +69,8 @@ extern "C" void fe_state_destroy(FeState* s) {
     (void)hipFree(s->prev_xy); (void)hipFree(s->next_xy); (void)hipFree(s->err); (void)hipFree(s->eig);
     (void)hipFree(s->blockmax); (void)hipFree(s->corners); (void)hipFree(s->npts); (void)hipFree(s->max_corners);
     (void)hipFree(s->ncorners); (void)hipFree(s->ncand); (void)hipFree(s->keys);
+    (void)hipFree(s->sm_pts); (void)hipFree(s->sm_cnt); (void)hipFree(s->sm_n); (void)hipFree(s->sm_kidx); (void)hipFree(s->sm_nk);
+    (void)hipFree(s->sm_kxy); (void)hipFree(s->sm_base); (void)hipFree((void*)s->sm_base_ptrs); (void)hipFree(s->lift_in); (void)hipFree(s->lift_out);
     delete s;
 }
 
@@ -306,6 +319,100 @@ extern "C" int vg_fe_detect(vg_handle* h, int cam, const uint8_t* mask, int max_
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n > 0) HIPCHK(h, hipMemcpy(out_xy, s->corners + (size_t)cam * s->max_pts * 2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
     *out_n = n;
+    return VG_OK;
+}
+
+// ---- FeatureTracker::setMask on the device (feature_tracker.cpp:36-69)
+extern "C" int vg_fe_set_mask(vg_handle* h, const float* pts_xy, const int* track_cnt, const int* n, const uint8_t* const* base_masks,
+                              int radius, int* kept_index, int* n_kept) {
+    if (!h || !h->fe || !pts_xy || !track_cnt || !n || !kept_index || !n_kept || radius < 0) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    if (s->max_pts > 2048) { h->err = "vg_fe_set_mask: max_points > 2048"; return VG_ERR_UNSUPPORTED; }
+    for (int c = 0; c < s->cams; ++c)
+        if (n[c] < 0 || n[c] > s->max_pts) { h->err = "vg_fe_set_mask: point count out of range"; return VG_ERR_BAD_ARG; }
+    const size_t npix = (size_t)s->W * s->H, cap = (size_t)s->cams * s->max_pts;
+    if (!s->sm_pts) {
+        HIPCHK(h, hipMalloc((void**)&s->sm_pts, sizeof(float) * 2 * cap));
+        HIPCHK(h, hipMalloc((void**)&s->sm_cnt, sizeof(int) * cap));
+        HIPCHK(h, hipMalloc((void**)&s->sm_n, sizeof(int) * s->cams));
+        HIPCHK(h, hipMalloc((void**)&s->sm_kidx, sizeof(int) * cap));
+        HIPCHK(h, hipMalloc((void**)&s->sm_nk, sizeof(int) * s->cams));
+        HIPCHK(h, hipMalloc((void**)&s->sm_kxy, sizeof(int) * 2 * cap));
+        HIPCHK(h, hipMalloc((void**)&s->sm_base_ptrs, sizeof(uint8_t*) * s->cams));
+    }
+    bool any_base = false;
+    for (int c = 0; c < s->cams; ++c) any_base = any_base || (base_masks && base_masks[c]);
+    if (any_base && !s->sm_base) HIPCHK(h, hipMalloc((void**)&s->sm_base, npix * s->cams));
+    std::vector<const uint8_t*> ptrs(s->cams, nullptr);
+    for (int c = 0; c < s->cams; ++c) {
+        uint8_t* dm = s->mask + (size_t)c * npix;
+        if (base_masks && base_masks[c]) {
+            HIPCHK(h, hipMemcpyAsync(s->sm_base + (size_t)c * npix, base_masks[c], npix, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(dm, s->sm_base + (size_t)c * npix, npix, hipMemcpyDeviceToDevice, h->stream));
+            ptrs[c] = s->sm_base + (size_t)c * npix;
+        } else {
+            HIPCHK(h, hipMemsetAsync(dm, 255, npix, h->stream));
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync((void*)s->sm_base_ptrs, ptrs.data(), sizeof(uint8_t*) * s->cams, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s->sm_pts, pts_xy, sizeof(float) * 2 * cap, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s->sm_cnt, track_cnt, sizeof(int) * cap, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s->sm_n, n, sizeof(int) * s->cams, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(fe_setmask_kernel, dim3(s->cams), dim3(256), 0, h->stream, s->d, s->sm_pts, s->sm_cnt, s->sm_n,
+                       any_base ? s->sm_base_ptrs : (const uint8_t* const*)nullptr, radius, s->sm_kidx, s->sm_nk, s->sm_kxy);
+    hipLaunchKernelGGL(fe_stamp_kernel, dim3(s->max_pts, s->cams), dim3(256), 0, h->stream, s->d, s->sm_nk, s->sm_kxy, radius);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(kept_index, s->sm_kidx, sizeof(int) * cap, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(n_kept, s->sm_nk, sizeof(int) * s->cams, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VG_OK;
+}
+
+// goodFeaturesToTrack with the mask vg_fe_set_mask left on the device (no mask upload)
+extern "C" int vg_fe_detect_masked(vg_handle* h, int cam, int max_corners, double quality, double min_dist, float* out_xy, int* out_n) {
+    if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || !out_xy || !out_n || max_corners < 0 || max_corners > h->fe->max_pts)
+        return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    *out_n = 0;
+    if (max_corners == 0) return VG_OK;
+    std::vector<int> mc(s->cams, 0);
+    mc[cam] = max_corners;
+    HIPCHK(h, hipMemcpyAsync(s->max_corners, mc.data(), sizeof(int) * s->cams, hipMemcpyHostToDevice, h->stream));
+    int rc = vg_fe_detect_async(h, quality, min_dist);
+    if (rc) return rc;
+    int n = 0;
+    HIPCHK(h, hipMemcpyAsync(&n, s->ncorners + cam, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n > 0) HIPCHK(h, hipMemcpy(out_xy, s->corners + (size_t)cam * s->max_pts * 2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
+    *out_n = n;
+    return VG_OK;
+}
+
+extern "C" int vg_fe_get_mask(vg_handle* h, int cam, uint8_t* out) {
+    if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || !out) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    const size_t npix = (size_t)s->W * s->H;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, s->mask + (size_t)cam * npix, npix, hipMemcpyDeviceToHost));
+    return VG_OK;
+}
+
+// PinholeCamera::liftProjective for a batch of points (feature_tracker.cpp:258-271)
+extern "C" int vg_fe_undistort(vg_handle* h, const float* pts_xy, int n, const double* intr, float* out_xy) {
+    if (!h || !h->fe || n < 0 || !intr || (n > 0 && (!pts_xy || !out_xy))) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    if (n == 0) return VG_OK;
+    if ((size_t)n > (size_t)s->cams * s->max_pts) { h->err = "vg_fe_undistort: more points than configured"; return VG_ERR_BAD_ARG; }
+    if (!s->lift_in) {
+        HIPCHK(h, hipMalloc((void**)&s->lift_in, sizeof(float) * 2 * s->cams * s->max_pts));
+        HIPCHK(h, hipMalloc((void**)&s->lift_out, sizeof(float) * 2 * s->cams * s->max_pts));
+    }
+    HIPCHK(h, hipMemcpyAsync(s->lift_in, pts_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(fe_lift_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, s->lift_in, n, intr[0], intr[1], intr[2], intr[3],
+                       intr[4], intr[5], intr[6], intr[7], s->lift_out);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out_xy, s->lift_out, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return VG_OK;
 }
 

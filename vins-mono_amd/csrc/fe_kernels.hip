@@ -678,6 +678,105 @@ extern "C" __global__ __launch_bounds__(1024) void fe_select_kernel(FeDev d, dou
         }
     if (wave == 0) { nacc = sel_walk(w, keys, n, 0, corners, lane); if (lane == 0) d.ncorners[cam] = nacc; }
 }
+// ================================================================================================ setMask / lift
+// FeatureTracker::setMask (feature_tracker.cpp:36-69), SURVEY.md 8(f) row 1.  One workgroup per stream:
+//   1. stable order by track_cnt descending = ascending bitonic sort of (INT_MAX - cnt) << 32 | index in LDS;
+//   2. wave 0 walks the points; a point is kept iff its rounded position is inside the image, the base mask there is
+//      255 and no previously kept point's filled disc covers it — exactly "mask.at(pt) == 255" of :59 without
+//      touching the mask plane (lanes test 64 kept points at a time);
+//   3. the mask plane of the stream is rebuilt by fe_stamp_kernel (base mask or 255, then every kept disc in parallel:
+//      the union does not depend on the order).
+// Disc rule: dx^2 + dy^2 <= r^2 (the restatement of cv::circle(..., -1), oracle/ASSUMPTIONS.md F7).
+#define FE_SETMASK_MAX 2048
+extern "C" __global__ __launch_bounds__(256) void fe_setmask_kernel(FeDev d, const float* __restrict__ pts_xy, const int* __restrict__ track_cnt,
+                                                                    const int* __restrict__ npts, const uint8_t* const* __restrict__ base_masks,
+                                                                    int radius, int* __restrict__ kept_index, int* __restrict__ n_kept,
+                                                                    int* __restrict__ kept_xy) {
+    __shared__ unsigned long long sk[FE_SETMASK_MAX];
+    __shared__ short kx[FE_SETMASK_MAX], ky[FE_SETMASK_MAX];
+    const int cam = blockIdx.x, tid = threadIdx.x, lane = tid & 63, W = d.W, H = d.H;
+    const int n = npts[cam];
+    const float* p = pts_xy + (size_t)cam * d.max_pts * 2;
+    const int* tc = track_cnt + (size_t)cam * d.max_pts;
+    const uint8_t* bm = base_masks ? base_masks[cam] : nullptr;
+    unsigned np = 1;
+    while (np < (unsigned)n) np <<= 1;
+    for (unsigned i = tid; i < np; i += 256)
+        sk[i] = i < (unsigned)n ? (((unsigned long long)(unsigned)(0x7fffffff - tc[i]) << 32) | i) : ~0ull;
+    __syncthreads();
+    for (unsigned size = 2; size <= np; size <<= 1)
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned t = tid; t < np / 2; t += 256) {
+                const unsigned lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool asc = ((lo & size) == 0);
+                const unsigned long long a = sk[lo], b = sk[hi];
+                if ((a > b) == asc) { sk[lo] = b; sk[hi] = a; }
+            }
+            __syncthreads();
+        }
+    if (tid < 64) {
+        const int r2 = radius * radius;
+        int nk = 0;
+        for (int q = 0; q < n; ++q) {
+            const int i = (int)(unsigned)(sk[q] & 0xffffffffull);
+            const int px = __float2int_rn(p[2 * i]), py = __float2int_rn(p[2 * i + 1]);      // Point2f -> Point: round half to even
+            bool ok = px >= 0 && py >= 0 && px < W && py < H;
+            if (ok && bm) ok = bm[(size_t)py * W + px] == 255;
+            if (ok) {
+                bool cov = false;
+                for (int base = 0; base < nk; base += 64) {
+                    const int j = base + lane;
+                    if (j < nk) { const int dx = px - kx[j], dy = py - ky[j]; cov = cov || (dx * dx + dy * dy <= r2); }
+                }
+                ok = !__any(cov);
+            }
+            if (ok) {
+                if (lane == 0) {
+                    kx[nk] = (short)px; ky[nk] = (short)py;
+                    kept_index[(size_t)cam * d.max_pts + nk] = i;
+                    kept_xy[((size_t)cam * d.max_pts + nk) * 2] = px; kept_xy[((size_t)cam * d.max_pts + nk) * 2 + 1] = py;
+                }
+                ++nk;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) n_kept[cam] = nk;
+    }
+}
+// grid (max_pts + 1, cams): block 0 of a stream resets its mask plane to the base mask / 255 ... done by the host with
+// memcpy/memset; blocks stamp the disc of kept point blockIdx.x
+extern "C" __global__ __launch_bounds__(256) void fe_stamp_kernel(FeDev d, const int* __restrict__ n_kept, const int* __restrict__ kept_xy, int radius) {
+    const int cam = blockIdx.y, k = blockIdx.x;
+    if (k >= n_kept[cam]) return;
+    const int cx = kept_xy[((size_t)cam * d.max_pts + k) * 2], cy = kept_xy[((size_t)cam * d.max_pts + k) * 2 + 1];
+    uint8_t* m = const_cast<uint8_t*>(d.mask) + (size_t)cam * d.W * d.H;
+    const int side = 2 * radius + 1, r2 = radius * radius;
+    for (int t = threadIdx.x; t < side * side; t += 256) {
+        const int dy = t / side - radius, dx = t % side - radius;
+        const int x = cx + dx, y = cy + dy;
+        if (x >= 0 && y >= 0 && x < d.W && y < d.H && dx * dx + dy * dy <= r2) m[(size_t)y * d.W + x] = 0;
+    }
+}
+// PinholeCamera::liftProjective, recursive distortion model with n = 8 (PinholeCamera.cc:450-510, :646-661); thread per
+// point, double arithmetic in the reference's order (this file is compiled with -ffp-contract=off)
+extern "C" __global__ __launch_bounds__(256) void fe_lift_kernel(const float* __restrict__ pts_xy, int n, double fx, double fy, double cx, double cy,
+                                                                 double k1, double k2, double p1, double p2, float* __restrict__ out_xy) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double mx_d = (1.0 / fx) * (double)pts_xy[2 * i] + (-cx / fx), my_d = (1.0 / fy) * (double)pts_xy[2 * i + 1] + (-cy / fy);
+    double mx_u = mx_d, my_u = my_d;
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const double mx2 = mx_u * mx_u, my2 = my_u * my_u, mxy = mx_u * my_u, rho2 = mx2 + my2;
+        const double rad = k1 * rho2 + k2 * rho2 * rho2;
+        const double dx = mx_u * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2);
+        const double dy = my_u * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2);
+        mx_u = mx_d - dx; my_u = my_d - dy;
+    }
+    out_xy[2 * i] = (float)mx_u; out_xy[2 * i + 1] = (float)my_u;
+}
+
 #define FE_SEL_LDS_BYTES (FE_SEL_CAP * 8 + FE_SEL_BINS * 4 + 64 * 4 + 8 * 4 + FE_MAX_CELLS * 7 * 2 * 2 + FE_MAX_CELLS)
 
 extern "C" hipError_t fe_launch_select(const FeDev& d, double quality, float min_dist, hipStream_t stream) {

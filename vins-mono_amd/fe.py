@@ -30,6 +30,10 @@ class FrontEnd:
         L.vg_fe_detect_download.argtypes = [C.c_void_p, _f4, _i4]
         L.vg_fe_get_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8, _i4, _i4]
         L.vg_fe_get_eig.argtypes = [C.c_void_p, C.c_int, _f4]
+        L.vg_fe_set_mask.argtypes = [C.c_void_p, _f4, _i4, _i4, C.POINTER(_u8), C.c_int, _i4, _i4]
+        L.vg_fe_detect_masked.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, _f4, _i4]
+        L.vg_fe_get_mask.argtypes = [C.c_void_p, C.c_int, _u8]
+        L.vg_fe_undistort.argtypes = [C.c_void_p, _f4, C.c_int, C.POINTER(C.c_double), _f4]
         self.hd._chk(L.vg_fe_configure(self.h, width, height, n_cams, max_points), "vg_fe_configure")
 
     def _imgs(self, frames):
@@ -84,6 +88,47 @@ class FrontEnd:
         self.hd._chk(self.lib.vg_fe_detect(self.h, cam, m.ctypes.data_as(_u8) if m is not None else None, int(max_corners), float(quality),
                                            float(min_dist), out.ctypes.data_as(_f4), C.byref(n)), "vg_fe_detect")
         return out[:n.value].copy()
+
+    def set_mask(self, pts, track_cnt, radius, base_masks=None):
+        """FeatureTracker::setMask for every stream: pts[c] (n_c x 2 float32), track_cnt[c] (n_c ints).  Returns the list
+        of kept-index arrays (kept order); the final masks stay on the device for detect_masked()."""
+        P = np.zeros((self.cams, self.max_pts, 2), np.float32)
+        T = np.zeros((self.cams, self.max_pts), np.int32)
+        n = np.zeros(self.cams, np.int32)
+        for c in range(self.cams):
+            p = np.ascontiguousarray(pts[c], np.float32).reshape(-1, 2)
+            n[c] = len(p)
+            P[c, :len(p)] = p
+            T[c, :len(p)] = np.asarray(track_cnt[c], np.int32)
+        bp = None
+        if base_masks is not None:
+            self._bkeep = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in base_masks]
+            bp = (_u8 * self.cams)(*[None if m is None else m.ctypes.data_as(_u8) for m in self._bkeep])
+        K = np.zeros((self.cams, self.max_pts), np.int32)
+        nk = np.zeros(self.cams, np.int32)
+        self.hd._chk(self.lib.vg_fe_set_mask(self.h, P.ctypes.data_as(_f4), T.ctypes.data_as(_i4), n.ctypes.data_as(_i4), bp, int(radius),
+                                             K.ctypes.data_as(_i4), nk.ctypes.data_as(_i4)), "vg_fe_set_mask")
+        return [K[c, :nk[c]].copy() for c in range(self.cams)]
+
+    def detect_masked(self, cam, max_corners, quality=0.01, min_dist=30.0):
+        out = np.zeros((max(max_corners, 1), 2), np.float32)
+        n = C.c_int(0)
+        self.hd._chk(self.lib.vg_fe_detect_masked(self.h, cam, int(max_corners), float(quality), float(min_dist), out.ctypes.data_as(_f4),
+                                                  C.byref(n)), "vg_fe_detect_masked")
+        return out[:n.value].copy()
+
+    def get_mask(self, cam):
+        out = np.zeros((self.H, self.W), np.uint8)
+        self.hd._chk(self.lib.vg_fe_get_mask(self.h, cam, out.ctypes.data_as(_u8)), "vg_fe_get_mask")
+        return out
+
+    def undistort(self, pts, intr):
+        p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        out = np.zeros_like(p)
+        k = np.ascontiguousarray(intr, np.float64)
+        self.hd._chk(self.lib.vg_fe_undistort(self.h, p.ctypes.data_as(_f4), len(p), k.ctypes.data_as(C.POINTER(C.c_double)),
+                                              out.ctypes.data_as(_f4)), "vg_fe_undistort")
+        return out
 
     def detect_upload(self, max_corners, masks=None):
         mc = np.ascontiguousarray(max_corners, np.int32)

@@ -57,29 +57,21 @@ static void chk(int rc, vg_handle* h, const char* what) {
     if (rc != VG_OK) throw std::runtime_error(std::string(what) + ": " + (h ? vg_last_error(h) : "no handle") + " (no CPU fallback)");
 }
 
-void FeatureTracker::setMask() {                             // feature_tracker.cpp:36-69
-    if (FISHEYE) mask = fisheye_mask.clone();
-    else mask = cv::Mat(ROW, COL, cv::CV_8UC1, (uchar)255);
-    vector<pair<int, pair<cv::Point2f, int>>> cnt_pts_id;
-    for (unsigned int i = 0; i < forw_pts.size(); i++) cnt_pts_id.push_back(make_pair(track_cnt[i], make_pair(forw_pts[i], ids[i])));
-    // the reference uses std::sort (unstable); canonicalised to a stable sort (hard part 5)
-    stable_sort(cnt_pts_id.begin(), cnt_pts_id.end(),
-                [](const pair<int, pair<cv::Point2f, int>>& a, const pair<int, pair<cv::Point2f, int>>& b) { return a.first > b.first; });
-    forw_pts.clear(); ids.clear(); track_cnt.clear();
-    for (auto& it : cnt_pts_id) {
-        const int px = cvRoundf(it.second.first.x), py = cvRoundf(it.second.first.y);   // Point2f -> Point conversion rounds (saturate_cast)
-        if (px < 0 || py < 0 || px >= COL || py >= ROW) continue;
-        if (mask.at<uchar>(py, px) == 255) {
-            forw_pts.push_back(it.second.first);
-            ids.push_back(it.second.second);
-            track_cnt.push_back(it.first);
-            // cv::circle(mask, pt, MIN_DIST, 0, -1): filled disc, centre rounded to the nearest pixel
-            const int cx = cvRoundf(it.second.first.x), cy = cvRoundf(it.second.first.y), r = MIN_DIST;
-            for (int y = std::max(0, cy - r); y <= std::min(ROW - 1, cy + r); ++y)
-                for (int x = std::max(0, cx - r); x <= std::min(COL - 1, cx + r); ++x)
-                    if ((x - cx) * (x - cx) + (y - cy) * (y - cy) <= r * r) mask.at<uchar>(y, x) = 0;
-        }
-    }
+void FeatureTracker::setMask() {                             // feature_tracker.cpp:36-69, on the device (vg_fe_set_mask)
+    // The reference sorts with std::sort (unstable); canonicalised to a stable order (hard part 5).
+    // `mask` itself stays on the device: goodFeaturesToTrack below consumes it there (vg_fe_detect_masked).
+    const int n = (int)forw_pts.size();
+    if (n > fe_capacity_) throw std::runtime_error("FeatureTracker::setMask: more points than the configured capacity");
+    std::vector<float> xy((size_t)fe_capacity_ * 2, 0.f);
+    std::vector<int> cnt((size_t)fe_capacity_, 0), kept((size_t)fe_capacity_, 0);
+    for (int i = 0; i < n; ++i) { xy[2 * i] = forw_pts[i].x; xy[2 * i + 1] = forw_pts[i].y; cnt[i] = track_cnt[i]; }
+    const uint8_t* base[1] = {FISHEYE ? fisheye_mask.data : nullptr};
+    int nk = 0;
+    chk(vg_fe_set_mask(vg_, xy.data(), cnt.data(), &n, base, MIN_DIST, kept.data(), &nk), vg_, "vg_fe_set_mask");
+    vector<cv::Point2f> pts2(nk);
+    vector<int> ids2(nk), cnt2(nk);
+    for (int k = 0; k < nk; ++k) { pts2[k] = forw_pts[kept[k]]; ids2[k] = ids[kept[k]]; cnt2[k] = track_cnt[kept[k]]; }
+    forw_pts.swap(pts2); ids.swap(ids2); track_cnt.swap(cnt2);
 }
 
 void FeatureTracker::addPoints() {                            // :71-79
@@ -94,7 +86,8 @@ void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {    // :8
     cur_time = _cur_time;
     if (!configured_) {
         chk(vg_create(&vg_), vg_, "vg_create");
-        chk(vg_fe_configure(vg_, COL, ROW, 1, std::max(MAX_CNT, 1) * 4), vg_, "vg_fe_configure");
+        fe_capacity_ = std::max(MAX_CNT, 1) * 4;
+        chk(vg_fe_configure(vg_, COL, ROW, 1, fe_capacity_), vg_, "vg_fe_configure");
         configured_ = true;
     }
     // EQUALIZE (CLAHE, :87-93) happens on the device; `forw_img = img` (:97-104) = the device pyramid rotation
@@ -127,7 +120,7 @@ void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {    // :8
         if (n_max_cnt > 0) {
             n_pts.resize(n_max_cnt);
             int n = 0;
-            chk(vg_fe_detect(vg_, 0, mask.data, n_max_cnt, 0.01, (double)MIN_DIST, &n_pts[0].x, &n), vg_, "vg_fe_detect");
+            chk(vg_fe_detect_masked(vg_, 0, n_max_cnt, 0.01, (double)MIN_DIST, &n_pts[0].x, &n), vg_, "vg_fe_detect_masked");
             n_pts.resize(n);
         } else
             n_pts.clear();
@@ -158,14 +151,16 @@ bool FeatureTracker::updateID(unsigned int i) {                              // 
 
 void FeatureTracker::readIntrinsicParameter(const string&) {}
 
-void FeatureTracker::undistortedPoints() {                                   // :258-306
+void FeatureTracker::undistortedPoints() {                                   // :258-306, lifting on the device
     cur_un_pts.clear();
     cur_un_pts_map.clear();
-    for (unsigned int i = 0; i < cur_pts.size(); i++) {
-        double bx, by;
-        m_camera.liftProjective(cur_pts[i].x, cur_pts[i].y, bx, by);
-        cur_un_pts.push_back(cv::Point2f((float)bx, (float)by));
-        cur_un_pts_map.insert(make_pair(ids[i], cv::Point2f((float)bx, (float)by)));
+    const int n = (int)cur_pts.size();
+    std::vector<float> un((size_t)std::max(n, 1) * 2);
+    const double intr[8] = {m_camera.fx, m_camera.fy, m_camera.cx, m_camera.cy, m_camera.k1, m_camera.k2, m_camera.p1, m_camera.p2};
+    if (n > 0) chk(vg_fe_undistort(vg_, &cur_pts[0].x, n, intr, un.data()), vg_, "vg_fe_undistort");
+    for (int i = 0; i < n; i++) {
+        cur_un_pts.push_back(cv::Point2f(un[2 * i], un[2 * i + 1]));
+        cur_un_pts_map.insert(make_pair(ids[i], cv::Point2f(un[2 * i], un[2 * i + 1])));
     }
     if (!prev_un_pts_map.empty()) {
         double dt = cur_time - prev_time;

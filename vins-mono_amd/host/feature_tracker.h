@@ -61,5 +61,6 @@ class FeatureTracker {
 
   private:
     vg_handle* vg_ = nullptr;      // owns the device-side pyramids of cur_img / forw_img
+    int fe_capacity_ = 0;
     bool configured_ = false;
 };
