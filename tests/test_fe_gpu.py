@@ -233,3 +233,21 @@ def test_set_mask_and_undistort_on_device(handle, frames):
     intr = [461.6, 460.3, 363.0, 248.1, -0.2917, 0.08228, 5.333e-05, -1.578e-04]       # euroc_config.yaml:19-30
     p = rng.uniform([0, 0], [W, H], (400, 2)).astype(np.float32)
     assert np.array_equal(tr.undistort(p, intr).view(np.uint32), F.lift(p, intr).view(np.uint32))
+
+
+def test_odd_image_size(handle):
+    """750x478: level 1 is 375 wide (odd: rows not dword-aligned -> the byte paths of pyrDown) and 239 high."""
+    w, h = 750, 478
+    big = synth.synth_frame(41, 752, 480)
+    a = np.ascontiguousarray(big[:h, :w])
+    b = np.ascontiguousarray(synth.warp_frame(big, 42)[:h, :w])
+    tr = fe.FrontEnd(handle, w, h, 1, 150)
+    tr.push_frames([a])
+    pts = tr.detect(0, 150, 0.01, 30.0)
+    assert np.array_equal(pts, F.gftt(a, 150, 0.01, 30.0))
+    tr.push_frames([b])
+    got, st, err = tr.track(0, pts)
+    ref, rst, rerr = F.lk(a, b, pts)
+    assert np.array_equal(st, rst) and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    for lvl in range(1, 4):
+        assert np.array_equal(tr.get_level(0, lvl), F.pyrdown(tr.get_level(0, lvl - 1)))

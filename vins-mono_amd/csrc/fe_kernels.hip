@@ -234,12 +234,20 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
         int w00, w01, w10, w11;
         lk_weights(prevx - ipx, prevy - ipy, w00, w01, w10, w11);
         __syncthreads();
-        // 24x24 neighbourhood of the template window
-        for (int k = lane; k < 24 * 24; k += 64) {
-            const int yy = k / 24, xx = k % 24;
-            s.ipatch[k] = I[(size_t)reflect101(ipy - 1 + yy, lh) * lw + reflect101(ipx - 1 + xx, lw)];
+        // 24x24 neighbourhood of the template window: 8-byte row chunks in the interior, per-byte reflect-101 at borders
+        if (ipx - 1 >= 0 && ipx + 23 <= lw && ipy - 1 >= 0 && ipy + 23 <= lh) {              // uniform
+            for (int k = lane; k < 24 * 3; k += 64) {
+                const int yy = k / 3, ch = k - 3 * yy;
+                uint2 v;
+                __builtin_memcpy(&v, I + (size_t)(ipy - 1 + yy) * lw + (ipx - 1) + 8 * ch, 8);
+                *(uint2*)(s.ipatch + yy * 24 + 8 * ch) = v;
+            }
+        } else {
+            for (int k = lane; k < 24 * 24; k += 64) {
+                const int yy = k / 24, xx = k % 24;
+                s.ipatch[k] = I[(size_t)reflect101(ipy - 1 + yy, lh) * lw + reflect101(ipx - 1 + xx, lw)];
+            }
         }
-        __syncthreads();
         // Scharr field on the 22x22 integer positions (calcSharrDeriv; constant-0 border outside the image).
         // NB the x+-1 / y+-1 taps reflect at the IMAGE edge, which is what the reflect-101 patch holds.
         for (int k = lane; k < 22 * 22; k += 64) {
