@@ -77,6 +77,14 @@ typedef struct {
 int vg_imu_preintegrate(vg_handle* h, int n_intervals, const int* sample_off, const double* samples, const double* first,
                         const double* bias, const double* noise, vg_imu_preint* out);
 
+/* FeatureManager::triangulate (feature_manager.cpp:202-257) for L landmarks whose depth is
+ * not yet known (the used_num >= 2 && start_frame < WINDOW_SIZE - 2 && estimated_depth <= 0 filter of :206-211 is the
+ * caller's).  Ps [K x 3], Rs [K x 9 row-major] = body poses of the window, tic / ric = camera extrinsics; landmark l is
+ * observed in frames start[l] .. start[l] + nobs[l] - 1 with feature_per_frame.point = points[obs_off[l] + j] (x y z).
+ * depth[l] = svd_V[2] / svd_V[3] of the 2n x 4 DLT system, or init_depth (INIT_DEPTH) when that is < 0.1 (:245-254). */
+int vg_triangulate(vg_handle* h, int K, const double* Ps, const double* Rs, const double* tic, const double* ric, int L,
+                   const int* start, const int* nobs, const int* obs_off, const double* points, double init_depth, double* depth);
+
 /* block kinds of the marginalization prior (MarginalizationInfo::keep_block_*) */
 enum { VG_BLK_POSE = 0, VG_BLK_SPEEDBIAS = 1, VG_BLK_EXPOSE = 2, VG_BLK_TD = 3 };
 enum { VG_MARGIN_OLD = 0, VG_MARGIN_SECOND_NEW = 1, VG_MARGIN_NONE = 2 };

@@ -906,3 +906,33 @@ def optimization(prob, flag):
     st = double2vector(prob, x)
     new_prior = marginalize(prob, st, flag)
     return st, summary, new_prior
+
+
+def triangulate(Ps, Rs, tic, ric, start, nobs, obs_off, points, init_depth=5.0):
+    """FeatureManager::triangulate (feature_manager.cpp:202-257): DLT rows f0*P2 - f2*P0, f1*P2 - f2*P1 relative to the
+    first observing frame (:222-241), svd_V = last right singular vector (:244), depth = V[2]/V[3], INIT_DEPTH if < 0.1."""
+    Ps, Rs, points = np.asarray(Ps, float), np.asarray(Rs, float).reshape(-1, 3, 3), np.asarray(points, float).reshape(-1, 3)
+    tic, ric = np.asarray(tic, float), np.asarray(ric, float).reshape(3, 3)
+    out = np.zeros(len(start))
+    for l in range(len(start)):
+        i0, n = int(start[l]), int(nobs[l])
+        t0 = Ps[i0] + Rs[i0] @ tic
+        R0 = Rs[i0] @ ric
+        A = np.zeros((2 * n, 4))
+        for j in range(n):
+            f_ = i0 + j
+            t1 = Ps[f_] + Rs[f_] @ tic
+            R1 = Rs[f_] @ ric
+            t = R0.T @ (t1 - t0)
+            R = R0.T @ R1
+            P = np.zeros((3, 4))
+            P[:, :3] = R.T
+            P[:, 3] = -R.T @ t
+            f = points[int(obs_off[l]) + j]
+            f = f / np.linalg.norm(f)
+            A[2 * j] = f[0] * P[2] - f[2] * P[0]
+            A[2 * j + 1] = f[1] * P[2] - f[2] * P[1]
+        v = np.linalg.svd(A)[2][-1]
+        d = v[2] / v[3]
+        out[l] = init_depth if d < 0.1 else d
+    return out

@@ -400,3 +400,31 @@ def test_error_behaviour(handle):
     broken['lm_nobs'][0] = 1                     # a landmark needs >= 2 observations (estimator.cpp:723)
     with pytest.raises(RuntimeError, match="status -1"):
         handle.ba_upload([broken])
+
+
+def test_triangulate_on_device(handle):
+    """SURVEY 8(f) row 4 (first half): FeatureManager::triangulate on the device vs the NumPy restatement (LAPACK SVD)
+    on a synthetic window: true depths recovered, parity of the DLT null vector ratio, INIT_DEPTH substitution."""
+    seq = synth.SyntheticSequence(81, L=150)
+    prob = seq.window(0)
+    c = seq.cfg
+    K = prob['pose'].shape[0]
+    Ps = prob['pose'][:, :3]
+    Rs = np.array([B.q2R(q) for q in prob['pose'][:, 3:]])
+    start, nobs, off = prob['lm_start'], prob['lm_nobs'], prob['obs_off']
+    pts = np.concatenate([prob['obs'][:, :2], np.ones((len(prob['obs']), 1))], axis=1)      # (x, y, 1) normalised points
+    ref = B.triangulate(Ps, Rs.reshape(K, 9), c['tic'], c['ric'], start, nobs, off, pts)
+    got = handle.triangulate(Ps, Rs.reshape(K, 9), c['tic'], c['ric'], start, nobs, off, pts)
+    assert got.shape == ref.shape
+    assert np.allclose(got, ref, rtol=1e-8, atol=1e-10)
+    # noisy poses / pixels, yet the depths are close to the window's (also noisy) inverse depths for long tracks
+    lng = nobs >= 6
+    assert np.median(np.abs(got[lng] * prob['inv_depth'][lng] - 1.0)) < 0.25
+    # a point behind the camera / at infinity -> depth < 0.1 -> INIT_DEPTH (feature_manager.cpp:251-254)
+    pts2 = pts.copy()
+    pts2[off[0]:off[0] + nobs[0], :2] = pts2[off[0], :2]                  # zero parallax: rank-deficient system
+    r2 = B.triangulate(Ps, Rs.reshape(K, 9), c['tic'], c['ric'], start[:1], nobs[:1], off[:1], pts2, 7.5)
+    g2 = handle.triangulate(Ps, Rs.reshape(K, 9), c['tic'], c['ric'], start[:1], nobs[:1], off[:1], pts2, 7.5)
+    assert (r2[0] == 7.5) == (g2[0] == 7.5)
+    with pytest.raises(RuntimeError, match="status -1"):
+        handle.triangulate(Ps, Rs.reshape(K, 9), c['tic'], c['ric'], [K - 1], [3], [0], pts)

@@ -179,6 +179,7 @@ class Handle:
         L.vg_ba_batch_info.argtypes = [C.c_void_p, _pd, _pd, _pd, _pi]
         L.vg_ba_batch_flops.argtypes = [C.c_void_p, _pd, _pd]
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
+        L.vg_triangulate.argtypes = [C.c_void_p, C.c_int, _pd, _pd, _pd, _pd, C.c_int, _pi, _pi, _pi, _pd, C.c_double, _pd]
         L.vg_imu_preintegrate.argtypes = [C.c_void_p, C.c_int, _pi, _pd, _pd, _pd, _pd, C.POINTER(ImuPreint)]
         self.h = C.c_void_p()
         rc = L.vg_create(C.byref(self.h))
@@ -286,6 +287,18 @@ class Handle:
                             lin_ba=np.array(q.linearized_ba), lin_bg=np.array(q.linearized_bg),
                             jacobian=np.array(q.jacobian).reshape(15, 15), covariance=np.array(q.covariance).reshape(15, 15)))
         return res
+
+    def triangulate(self, Ps, Rs, tic, ric, start, nobs, obs_off, points, init_depth=5.0):
+        """FeatureManager::triangulate (feature_manager.cpp:202-257); returns the depth per landmark."""
+        Ps = np.ascontiguousarray(Ps, np.float64); Rs = np.ascontiguousarray(Rs, np.float64)
+        K, Ln = len(Ps), len(start)
+        st = np.ascontiguousarray(start, np.int32); nb = np.ascontiguousarray(nobs, np.int32); oo = np.ascontiguousarray(obs_off, np.int32)
+        pts = np.ascontiguousarray(points, np.float64)
+        out = np.zeros(max(Ln, 1))
+        self._chk(self.lib.vg_triangulate(self.h, K, _dp(Ps), _dp(Rs), _dp(np.ascontiguousarray(tic, np.float64)),
+                                          _dp(np.ascontiguousarray(ric, np.float64)), Ln, _ip(st), _ip(nb), _ip(oo), _dp(pts),
+                                          float(init_depth), _dp(out)), "vg_triangulate")
+        return out[:Ln]
 
     def ba_eval_factors(self, prob):
         p = PackedProblem(prob)
