@@ -212,6 +212,17 @@ void oracle_fe_scharr(const uint8_t* img, int w, int h, int16_t* out) {
 void oracle_fe_lk(const uint8_t* prev, const uint8_t* next, int w, int h, const float* prev_xy, int n, int max_level,
                   float* next_xy, uint8_t* status, float* err) {
     std::vector<Level> pI, pJ;
+    // buildOpticalFlowPyramid stops before a level that would not be larger than the window in both dimensions
+    // (lkpyramid.cpp: `if (sz.width <= winSize.width || sz.height <= winSize.height) return level - 1` [3P], F1)
+    {
+        int lw = w, lh = h, lv = 0;
+        while (lv < max_level) {
+            const int nw = (lw + 1) / 2, nh = (lh + 1) / 2;
+            if (nw <= 21 || nh <= 21) break;
+            lw = nw; lh = nh; ++lv;
+        }
+        max_level = lv;
+    }
     build_pyramid(prev, w, h, max_level, pI, true);
     build_pyramid(next, w, h, max_level, pJ, false);
     for (int i = 0; i < n; ++i) { status[i] = 1; err[i] = 0; next_xy[2 * i] = 0; next_xy[2 * i + 1] = 0; }

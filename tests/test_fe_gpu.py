@@ -251,3 +251,18 @@ def test_odd_image_size(handle):
     assert np.array_equal(st, rst) and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     for lvl in range(1, 4):
         assert np.array_equal(tr.get_level(0, lvl), F.pyrdown(tr.get_level(0, lvl - 1)))
+
+
+def test_tiny_levels(handle):
+    """48x44 frames: the coarsest level is 24x22, smaller than the +-5 px staging margin of fe_lk_kernel."""
+    w, h = 96, 88
+    a = synth.synth_frame(51, w, h)
+    b = synth.warp_frame(a, 52)
+    tr = fe.FrontEnd(handle, w, h, 1, 32)
+    tr.push_frames([a])
+    pts = F.gftt(a, 32, 0.01, 19.0)
+    assert np.array_equal(tr.detect(0, 32, 0.01, 19.0), pts) and len(pts) > 4
+    tr.push_frames([b])
+    _check_lk(tr, 0, a, b, pts)
+    edge = np.array([[0.5, 0.5], [w - 1.2, h - 1.4], [2.0, h - 2.0], [w - 3.0, 1.0]], np.float32)
+    _check_lk(tr, 0, a, b, edge)

@@ -196,9 +196,15 @@ FDEV void lk_stage_region(uint8_t* reg, const uint8_t* J, int lw, int lh, int ox
         __builtin_memcpy(&v, J + (size_t)(oy + row) * lw + ox + 16 * hf, 16);
         *(uint4*)(reg + row * LK_JR + 16 * hf) = v;
     } else {
-        const uint8_t* src = J + (size_t)reflect101(oy + row, lh) * lw;
+        // (the +-LK_JS margin may reach more than one image size outside a tiny level; those pixels are never part of a
+        //  window — a window origin is >= -LK_WIN — so they are clamped instead of folded twice)
+        const int ry = reflect101(oy + row, lh);
+        const uint8_t* src = J + (size_t)(ry < 0 ? 0 : (ry >= lh ? lh - 1 : ry)) * lw;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) reg[row * LK_JR + 16 * hf + q] = src[reflect101(ox + 16 * hf + q, lw)];
+        for (int q = 0; q < 16; ++q) {
+            const int rx = reflect101(ox + 16 * hf + q, lw);
+            reg[row * LK_JR + 16 * hf + q] = src[rx < 0 ? 0 : (rx >= lw ? lw - 1 : rx)];
+        }
     }
     __syncthreads();
 }
