@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ba_layout.h"
 #include "vg_handle.h"
@@ -369,17 +370,49 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     BaBatch& B = h->ba;
     B.L = L;
     B.nwin = nwin;
-    B.h_ia.assign((size_t)nwin * L.istride, 0);
-    B.h_di.assign((size_t)nwin * L.dstride, 0.0);
+    const size_t n_ia = (size_t)nwin * L.istride, n_di = (size_t)nwin * L.dstride;
+    if (n_ia > B.hcap_ia) {
+        if (B.h_ia) HIPCHK(h, hipHostFree(B.h_ia));
+        B.h_ia = nullptr; B.hcap_ia = 0;
+        HIPCHK(h, hipHostMalloc((void**)&B.h_ia, n_ia * sizeof(int), hipHostMallocDefault));
+        B.hcap_ia = n_ia;
+    }
+    if (n_di > B.hcap_di) {
+        if (B.h_di) HIPCHK(h, hipHostFree(B.h_di));
+        B.h_di = nullptr; B.hcap_di = 0;
+        HIPCHK(h, hipHostMalloc((void**)&B.h_di, n_di * sizeof(double), hipHostMallocDefault));
+        B.hcap_di = n_di;
+    }
     B.flops = 0.0; B.flops_marg = 0.0; B.bytes_in = 0.0; B.bytes_out = 0.0;
     B.margin.assign(nwin, VG_MARGIN_NONE);
     B.nL.assign(nwin, 0);
+    // pack: windows are independent -> a few host threads (zero-fill + pack of their own slabs)
+    {
+        const int nthr = std::max(1, std::min(8, nwin / 16));
+        std::vector<int> rcs(nthr, VG_OK);
+        auto work = [&](int t) {
+            for (int w = t; w < nwin; w += nthr) {
+                int* ia = B.h_ia + (size_t)w * L.istride;
+                double* di = B.h_di + (size_t)w * L.dstride;
+                memset(ia, 0, sizeof(int) * L.istride);
+                memset(di, 0, sizeof(double) * L.dstride);
+                const int mf = margin_flags ? margin_flags[w] : VG_MARGIN_NONE;
+                const int r = pack_window(h, L, in[w], mf, ia, di);
+                if (r != VG_OK && rcs[t] == VG_OK) rcs[t] = r;
+            }
+        };
+        if (nthr == 1) work(0);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthr; ++t) pool.emplace_back(work, t);
+            for (auto& th : pool) th.join();
+        }
+        for (int t = 0; t < nthr; ++t) if (rcs[t] != VG_OK) return rcs[t];
+    }
     for (int w = 0; w < nwin; ++w) {
         const int mf = margin_flags ? margin_flags[w] : VG_MARGIN_NONE;
         B.margin[w] = mf;
         B.nL[w] = in[w]->L;
-        rc = pack_window(h, L, in[w], mf, B.h_ia.data() + (size_t)w * L.istride, B.h_di.data() + (size_t)w * L.dstride);
-        if (rc) return rc;
         // algorithmic flop / byte model of SURVEY.md 8(d)
         const vg_ba_problem* p = in[w];
         double F = p->relo_n, schur = 0.0, sumn = 0.0;
@@ -415,8 +448,8 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     rc = ensure(h, B.P.mscr, B.cap_mscr, (size_t)nwin * L.ms_stride); if (rc) return rc;
     if (!B.dL) HIPCHK(h, hipMalloc((void**)&B.dL, sizeof(BaLayout)));
     HIPCHK(h, hipMemcpyAsync(B.dL, &B.L, sizeof(BaLayout), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(B.P.iarr, B.h_ia.data(), B.h_ia.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(B.P.din, B.h_di.data(), B.h_di.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(B.P.iarr, B.h_ia, n_ia * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(B.P.din, B.h_di, n_di * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(B.P.iout, 0, (size_t)nwin * L.oi_stride * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(B.P.miout, 0, (size_t)nwin * L.mi_stride * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(B.P.out, 0, (size_t)nwin * L.ostride * sizeof(double), h->stream));

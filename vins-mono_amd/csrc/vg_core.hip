@@ -30,6 +30,8 @@ extern "C" int vg_destroy(vg_handle* h) {
     BaPtrs& P = h->ba.P;
     (void)hipFree(P.iarr); (void)hipFree(P.din); (void)hipFree(P.scr); (void)hipFree(P.out); (void)hipFree(P.iout);
     (void)hipFree(h->ba.dL);
+    if (h->ba.h_ia) (void)hipHostFree(h->ba.h_ia);
+    if (h->ba.h_di) (void)hipHostFree(h->ba.h_di);
     (void)hipFree(P.mout); (void)hipFree(P.miout); (void)hipFree(P.mscr);
     if (h->fe) fe_state_destroy(h->fe);
     (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev2);

@@ -10,8 +10,11 @@ struct BaBatch {
     BaLayout* dL = nullptr;          // device copy of L (kernels read it through scalar loads)
     BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_ia = 0, cap_di = 0, cap_sc = 0, cap_out = 0, cap_iout = 0, cap_mout = 0, cap_miout = 0, cap_mscr = 0;
-    std::vector<int> h_ia, h_iout, h_miout, margin, nL;
-    std::vector<double> h_di, h_out, h_mout;
+    std::vector<int> h_iout, h_miout, margin, nL;
+    std::vector<double> h_out, h_mout;
+    int* h_ia = nullptr;             // pinned host staging of the packed batch (hipHostMalloc: DMA at full PCIe rate)
+    double* h_di = nullptr;
+    size_t hcap_ia = 0, hcap_di = 0;
     int nwin = 0;
     bool uploaded = false, any_margin = false;
     double flops = 0, flops_marg = 0, bytes_in = 0, bytes_out = 0;
