@@ -1,6 +1,6 @@
 """manual GPU debugging aid (not a test)"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g
 g.load_package()
 import numpy as np

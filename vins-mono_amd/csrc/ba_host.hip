@@ -519,6 +519,7 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int worst = VG_OK;
+    static const bool debug_marg = getenv("VG_DEBUG_MARG") != nullptr;      // phase stamps of -DBA_PROFILE builds
     for (int w = 0; w < nwin; ++w) {
         const double* o = B.h_out.data() + (size_t)w * L.ostride;
         const int* io = B.h_iout.data() + (size_t)w * L.oi_stride;
@@ -554,7 +555,7 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
                 const double* mo = B.h_mout.data() + (size_t)w * L.mo_stride;
                 const int* mi = B.h_miout.data() + (size_t)w * L.mi_stride;
                 q->valid = mi[0];
-                if (getenv("VG_DEBUG_MARG")) {
+                if (debug_marg) {
                     const int* pf = mi + 8 + 2 * (L.K + 4);
                     fprintf(stderr, "[marg] eig2: sweeps=%d total_kcyc=%d rot_kcyc=%d blkV_kcyc=%d | total kernel kcyc=%d | stamps: setup %d prior %d imu %d proj %d eig1 %d schur %d eig2 %d out %d | jacobi w0: M %d bar %d rot %d bar %d ; w1: M %d bar %d V %d bar %d\n",
                             mi[5] & 255, mi[5] >> 8, mi[6], mi[7], mi[4], pf[0], pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6], pf[8], pf[9], pf[10], pf[11], pf[12], pf[13], pf[14], pf[15]);
