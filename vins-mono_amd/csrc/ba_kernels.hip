@@ -34,8 +34,6 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 #define PROF_ADD(id)
 #endif
 enum { PF_PRO = 0, PF_IMU, PF_PRIOR, PF_PROJ, PF_ACC, PF_LMACC, PF_IMUACC, PF_PRACC, PF_JVEC, PF_BUILD, PF_SCHUR, PF_CHOL, PF_BACK, PF_CAND, PF_MISC, PF_TOTAL };
-#define PF_CH_DIAG PF_MISC
-#define PF_CH_PANEL PF_PRO   /* temporary sub-profile slots */
 
 // R-vectors kept in LDS
 enum { V_G = 0, V_SC, V_DG, V_GT, V_GN, V_U, V_Y, V_T, V_DI, V_NVEC };
@@ -723,10 +721,8 @@ NOINL bool cholesky_aug(const Ctx& c) {
     const int lane = c.lane;
     if (c.tid == 0) *flag = 1;
     __syncthreads();
-    PROF_DECL;
     for (int c0 = 0; c0 < R; c0 += 16) {
         const int nb = (R - c0) < 16 ? (R - c0) : 16;
-        PROF_T0();
         // ---- (1) diagonal block, wavefront 0
         if (c.wave == 0) {
             double a[16];
@@ -757,7 +753,6 @@ NOINL bool cholesky_aug(const Ctx& c) {
             if (!good && lane == 0) *flag = 0;
         }
         __syncthreads();
-        PROF_ADD(PF_CH_DIAG);
         if (*flag == 0) break;
         // ---- (2) panel: rows i > block, x_c = (a_c - sum_{m<c} x_m L_D[c][m]) / L_D[c][c]
         const int r1 = c0 + nb;
@@ -791,7 +786,6 @@ NOINL bool cholesky_aug(const Ctx& c) {
             }
         }
         __syncthreads();
-        PROF_ADD(PF_CH_PANEL);
         // ---- (3) trailing update (only full blocks have anything right of them)
         if (nb == 16 && r1 < R) {
             const int t0 = r1 >> 4;
