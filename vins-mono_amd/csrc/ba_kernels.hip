@@ -396,6 +396,36 @@ NOINL void proj_accumulate_chunk(const Ctx& c, int ch) {
         const int rowbase = kr == 0 ? 6 * br : (kr == 1 ? col_ex(L) : col_td(L));
         const int colbase = kc == 0 ? 6 * bc : (kc == 1 ? col_ex(L) : col_td(L));
         const bool diag = br == bc;
+        if (kr == 0 && kc == 0 && diag) {
+            // diagonal pose block: it visits every factor anchored at or targeting frame a (~10x the visits of an
+            // off-diagonal block), so its 21 lower-triangle entries + 6 gradient entries are spread over TWO lane
+            // segments (lanes 0-26 / 27-53) that each take half of every slot range; fixed split -> deterministic
+            const int a = br;
+            const int seg = c.lane >= 27 ? 1 : 0, e = c.lane - 27 * seg;
+            const bool on = c.lane < 54;
+            const bool isg2 = e >= 21;
+            int p2 = 0, q2 = 0;
+            if (!isg2) tri_decode(e, p2, q2); else p2 = e - 21;
+            double part = 0.0;
+            if (on) {
+                const int oB_i = isg2 ? 26 : 2 * q2, oB_j = isg2 ? 26 : 12 + 2 * q2;
+                {
+                    const int s0 = ptr[a * Kp], s1 = ptr[(a + 1) * Kp], mid = (s0 + s1) >> 1;
+                    part += seg_dot(stage, REC, seg ? mid : s0, seg ? s1 : mid, 2 * p2, oB_i);
+                }
+                for (int a2 = 0; a2 < a; ++a2) {
+                    const int s0 = ptr[a2 * Kp + a], s1 = ptr[a2 * Kp + a + 1], mid = (s0 + s1) >> 1;
+                    part += seg_dot(stage, REC, seg ? mid : s0, seg ? s1 : mid, 12 + 2 * p2, oB_j);
+                }
+            }
+            const double other = __shfl_down(part, 27, 64);
+            if (c.lane < 27) {
+                const double tot = part + other;
+                if (isg2) g[rowbase + p2] += tot;
+                else S[tri(rowbase + p2, colbase + q2)] += tot;
+            }
+            continue;
+        }
         const bool isg = diag && c.lane >= 36 && c.lane < 36 + dr;
         const int p = isg ? c.lane - 36 : c.lane / 6, q = isg ? 0 : c.lane % 6;
         const bool act = isg || (c.lane < 36 && p < dr && q < dc && (!diag || q <= p));
@@ -403,16 +433,8 @@ NOINL void proj_accumulate_chunk(const Ctx& c, int ch) {
         double acc = 0.0;
         // role offsets of the row / column block inside a record, as anchor (i) or target (j)
         if (kr == 0 && kc == 0) {
-            if (diag) {
-                const int a = br;
-                const int oB_i = isg ? 26 : 2 * q, oB_j = isg ? 26 : 12 + 2 * q;
-                acc += seg_dot(stage, REC, ptr[a * Kp], ptr[(a + 1) * Kp], 2 * p, oB_i);
-                for (int a2 = 0; a2 < a; ++a2)
-                    acc += seg_dot(stage, REC, ptr[a2 * Kp + a], ptr[a2 * Kp + a + 1], 12 + 2 * p, oB_j);
-            } else {
-                // row block br = target j, column block bc = anchor i
-                acc += seg_dot(stage, REC, ptr[bc * Kp + br], ptr[bc * Kp + br + 1], 12 + 2 * p, 2 * q);
-            }
+            // row block br = target j, column block bc = anchor i
+            acc += seg_dot(stage, REC, ptr[bc * Kp + br], ptr[bc * Kp + br + 1], 12 + 2 * p, 2 * q);
         } else {
             const int oA = (kr == 1 ? offEx : offTd) + 2 * p;
             if (kc == 0) {
