@@ -870,25 +870,68 @@ NOINL void back_substitute(const Ctx& c) {
         const double* rowR = S + tri(R, 0);
         double v0 = rowR[l0 < R ? l0 : 0], v1 = rowR[l1 < R ? l1 : 0], v2 = rowR[l2 < R ? l2 : 0];
         v0 = l0 < R ? v0 : 0.0; v1 = l1 < R ? v1 : 0.0; v2 = l2 < R ? v2 : 0.0;
+        // A lone wave pays ~8 cycles per FP64 instruction whatever the dependencies, so the row loop is specialised
+        // by the 64-column slot that holds the pivot: rows j < 128 have no entries in columns >= 128 (v2 is final),
+        // rows j < 64 none in columns >= 64 (v1 final) -> fewer loads, FMAs and selects per row.
         int j = R - 1;
-        // row j of L, entries i < j (clamped unconditional loads, masked arithmetically)
-        const double* rj = S + tri(j, 0);
-        double r0 = rj[l0 < j ? l0 : 0], r1 = rj[l1 < j ? l1 : 0], r2 = rj[l2 < j ? l2 : 0];
-        r0 = l0 < j ? r0 : 0.0; r1 = l1 < j ? r1 : 0.0; r2 = l2 < j ? r2 : 0.0;
-        double di = dinvv[j];
-        for (; j >= 0; --j) {
-            const int jp = j > 0 ? j - 1 : 0;
-            const double* rn = S + tri(jp, 0);
-            double n0 = rn[l0 < jp ? l0 : 0], n1 = rn[l1 < jp ? l1 : 0], n2 = rn[l2 < jp ? l2 : 0];
-            const double dn = dinvv[jp];
-            const int own = j & 63, slot = j >> 6;
-            const double vj = slot == 0 ? v0 : (slot == 1 ? v1 : v2);
-            const double xj = readlane_d(vj, own) * di;
-            v0 = (slot == 0 && c.lane == own) ? xj : v0 - r0 * xj;
-            v1 = (slot == 1 && c.lane == own) ? xj : v1 - r1 * xj;
-            v2 = (slot == 2 && c.lane == own) ? xj : v2 - r2 * xj;
-            r0 = l0 < jp ? n0 : 0.0; r1 = l1 < jp ? n1 : 0.0; r2 = l2 < jp ? n2 : 0.0;
-            di = dn;
+        {   // ---- slot 2: pivot in v2, entries in all three registers
+            const int jlo = 128;
+            if (j >= jlo) {
+                const double* rj = S + tri(j, 0);
+                double r0 = rj[l0], r1 = rj[l1], r2 = rj[l2 < j ? l2 : 0];
+                r2 = l2 < j ? r2 : 0.0;
+                double di = dinvv[j];
+                for (; j >= jlo; --j) {
+                    const int jp = j > jlo ? j - 1 : j;
+                    const double* rn = S + tri(jp, 0);
+                    const double n0 = rn[l0], n1 = rn[l1], n2 = rn[l2 < jp ? l2 : 0];
+                    const double dn = dinvv[jp];
+                    const int own = j & 63;
+                    const double xj = readlane_d(v2, own) * di;
+                    v2 = c.lane == own ? xj : v2 - r2 * xj;
+                    v1 -= r1 * xj;
+                    v0 -= r0 * xj;
+                    r0 = n0; r1 = n1; r2 = l2 < jp ? n2 : 0.0;
+                    di = dn;
+                }
+            }
+        }
+        {   // ---- slot 1: pivot in v1
+            const int jlo = 64;
+            if (j >= jlo) {
+                const double* rj = S + tri(j, 0);
+                double r0 = rj[l0], r1 = rj[l1 < j ? l1 : 0];
+                r1 = l1 < j ? r1 : 0.0;
+                double di = dinvv[j];
+                for (; j >= jlo; --j) {
+                    const int jp = j > jlo ? j - 1 : j;
+                    const double* rn = S + tri(jp, 0);
+                    const double n0 = rn[l0], n1 = rn[l1 < jp ? l1 : 0];
+                    const double dn = dinvv[jp];
+                    const int own = j & 63;
+                    const double xj = readlane_d(v1, own) * di;
+                    v1 = c.lane == own ? xj : v1 - r1 * xj;
+                    v0 -= r0 * xj;
+                    r0 = n0; r1 = l1 < jp ? n1 : 0.0;
+                    di = dn;
+                }
+            }
+        }
+        if (j >= 0) {   // ---- slot 0: pivot in v0
+            const double* rj = S + tri(j, 0);
+            double r0 = rj[l0 < j ? l0 : 0];
+            r0 = l0 < j ? r0 : 0.0;
+            double di = dinvv[j];
+            for (; j >= 0; --j) {
+                const int jp = j > 0 ? j - 1 : 0;
+                const double* rn = S + tri(jp, 0);
+                const double n0 = rn[l0 < jp ? l0 : 0];
+                const double dn = dinvv[jp];
+                const double xj = readlane_d(v0, j) * di;
+                v0 = c.lane == j ? xj : v0 - r0 * xj;
+                r0 = l0 < jp ? n0 : 0.0;
+                di = dn;
+            }
         }
         if (c.lane < R) y[c.lane] = v0;
         if (c.lane + 64 < R) y[c.lane + 64] = v1;
