@@ -149,7 +149,7 @@ NOINL void imu_sqrt_info(const Ctx& c) {
     }
 }
 
-// All IMU factors at state x, ONE WAVEFRONT PER FACTOR (8 factors at a time):
+// All IMU factors at state x, one (half-)wavefront per factor, all factors in one round:
 //   lanes 0..29 = Jacobian columns, lane 30 = the residual "column"; every lane evaluates the (cheap) factor context,
 //   weights its column with the upper-triangular U = sqrt_info read from an LDS copy, parks it in LDS, and the
 //   wavefront then forms the factor's 30x30 Hessian block and J^T r from LDS — so the later accumulation into S is
@@ -162,51 +162,56 @@ NOINL double imu_pass(const Ctx& c, const double* x) {
     const int nimu = L.K - 1;
     const int* valid = c.ia + L.io_imu_valid;
     double* Us = LDSB + L.l_S;                              // [nimu][225]
-    double* panel = Us + ((nimu * 225 + 1) & ~1) + c.wave * 480;   // [15][32] per wavefront
+    double* panels = Us + ((nimu * 225 + 1) & ~1);          // [nimu][15][32]
     double cost = 0.0;
     __syncthreads();
     for (int k = c.tid; k < nimu * 225; k += BA_NT) Us[k] = c.sc[L.so_imuU + k];
     __syncthreads();
-    for (int base = 0; base < nimu; base += BA_NW) {
-        const int f = base + c.wave;
-        const bool act = f < nimu && valid[f];
-        if (act) {
-            const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
-            const double* U = Us + f * 225;
-            ImuCtx ic;
-            imu_ctx<JAC>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
-            double raw[15];
-            if (JAC && c.lane < 30) imu_raw_col(ic, pre, c.lane, raw);
-            else {
+    // phase A: one HALF-wavefront per factor when there are more factors than wavefronts (lanes 0-30 / 32-62), so all
+    // factors are evaluated in one round; phase B: the Hessian entries of all factors are spread over all threads.
+    const int per = nimu > BA_NW ? 2 : 1;
+    const int half = c.lane >> 5, hl = c.lane & 31;
+    const int f = c.wave * per + half;
+    const bool act = f < nimu && half < per && valid[f];
+    if (act) {
+        const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
+        const double* U = Us + f * 225;
+        double* panel = panels + f * 480;
+        ImuCtx ic;
+        imu_ctx<JAC>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
+        double raw[15];
+        if (JAC && hl < 30) imu_raw_col(ic, pre, hl, raw);
+        else {
 #pragma unroll
-                for (int q = 0; q < 15; ++q) raw[q] = ic.r[q];
-            }
-            if (c.lane <= 30) {
-#pragma unroll
-                for (int r = 0; r < 15; ++r) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 15; ++k) if (k >= r) s += U[r * 15 + k] * raw[k];
-                    if (JAC) panel[r * 32 + c.lane] = s;
-                    if (c.lane == 30) { cost += s * s; if (JAC) c.sc[L.so_imuR + f * 15 + r] = s; }
-                }
-            }
+            for (int q = 0; q < 15; ++q) raw[q] = ic.r[q];
         }
-        __syncthreads();
-        if (JAC && act) {
-            double* Ho = c.sc + L.so_imuJ + f * 512;
-            for (int e = c.lane; e < 495; e += 64) {
-                int a, b;
-                if (e < 465) tri_decode(e, a, b);
-                else { a = e - 465; b = 30; }
+        if (hl <= 30) {
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
                 double s = 0.0;
 #pragma unroll
-                for (int r = 0; r < 15; ++r) s += panel[r * 32 + a] * panel[r * 32 + b];
-                Ho[e] = s;
+                for (int k = 0; k < 15; ++k) if (k >= r) s += U[r * 15 + k] * raw[k];
+                if (JAC) panel[r * 32 + hl] = s;
+                if (hl == 30) { cost += s * s; if (JAC) c.sc[L.so_imuR + f * 15 + r] = s; }
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
+    if (JAC) {
+        for (int w = c.tid; w < nimu * 495; w += BA_NT) {
+            const int ff = w / 495, e = w - 495 * ff;
+            if (!valid[ff]) continue;
+            const double* panel = panels + ff * 480;
+            int a, b;
+            if (e < 465) tri_decode(e, a, b);
+            else { a = e - 465; b = 30; }
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 15; ++r) s += panel[r * 32 + a] * panel[r * 32 + b];
+            c.sc[L.so_imuJ + ff * 512 + e] = s;
+        }
+    }
+    __syncthreads();
     return cost;
 }
 
