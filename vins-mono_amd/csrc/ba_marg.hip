@@ -859,7 +859,10 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             const double lamb = Mm[i * ldm + i];
             double s = 0.0;
             if (lamb > MG_EPS) {
-                for (int r = 0; r < m; ++r) s += Vm[r * ldm + i] * (j < n ? A[r * posmax + m + j] : bv[r]);
+                const double* src = j < n ? A + m + j : bv;          // column j of [Amr | bmm]
+                const int sst = j < n ? posmax : 1;
+#pragma unroll 8
+                for (int r = 0; r < m; ++r) s += Vm[r * ldm + i] * src[(size_t)r * sst];
                 s /= lamb;
             }
             T1[i * (mcap + 1) + j] = s;
@@ -869,6 +872,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         for (int k = c.tid; k < m * (n + 1); k += MG_NT) {
             const int i = k / (n + 1), j = k % (n + 1);
             double s = 0.0;
+#pragma unroll 8
             for (int r = 0; r < m; ++r) s += Vm[i * ldm + r] * T1[r * (mcap + 1) + j];
             T2[i * (mcap + 1) + j] = s;
         }
@@ -877,6 +881,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         for (int k = c.tid; k < n * (n + 1); k += MG_NT) {
             const int i = k / (n + 1), j = k % (n + 1);
             double s = (j < n) ? A[(m + i) * posmax + m + j] : bv[m + i];
+#pragma unroll 8
             for (int r = 0; r < m; ++r) s -= A[(m + i) * posmax + r] * T2[r * (mcap + 1) + j];
             if (j < n) gM[i * posmax + j] = s; else gV[i] = s;      // stage in global (eM may still be Mm)
         }
