@@ -743,3 +743,78 @@ extern "C" int oracle_ba_optimize(const vg_ba_problem* p, int margin_flag, vg_ba
     }
     return VG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// FeatureManager::triangulate (feature_manager.cpp:202-257), second independent restatement (the first is
+// ba_numpy.triangulate with LAPACK's SVD): the DLT rows of :222-241 and the smallest right singular vector through a
+// cyclic Jacobi eigen-decomposition of the 4x4 Gram matrix A^T A.  Squaring the condition number costs accuracy that
+// LAPACK / Eigen's JacobiSVD keep; the two restatements agree to ~1e-9 relative on well-conditioned tracks, which is
+// what tests/test_ba_oracle.py asserts.
+extern "C" void oracle_triangulate(int K, const double* Ps, const double* Rs, const double* tic, const double* ric, int L,
+                                   const int* start, const int* nobs, const int* obs_off, const double* points,
+                                   double init_depth, double* depth) {
+    (void)K;
+    auto mul3 = [](const double* A, const double* B, double* C) {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+    };
+    for (int l = 0; l < L; ++l) {
+        const int i0 = start[l], n = nobs[l];
+        double R0[9], t0[3];
+        mul3(Rs + 9 * i0, ric, R0);
+        for (int k = 0; k < 3; ++k) t0[k] = Ps[3 * i0 + k] + Rs[9 * i0 + 3 * k] * tic[0] + Rs[9 * i0 + 3 * k + 1] * tic[1] + Rs[9 * i0 + 3 * k + 2] * tic[2];
+        double G[16] = {0};
+        for (int j = 0; j < n; ++j) {
+            const int f = i0 + j;
+            double R1[9], t1[3], d[3], t[3], R[9], P[12];
+            mul3(Rs + 9 * f, ric, R1);
+            for (int k = 0; k < 3; ++k) {
+                t1[k] = Ps[3 * f + k] + Rs[9 * f + 3 * k] * tic[0] + Rs[9 * f + 3 * k + 1] * tic[1] + Rs[9 * f + 3 * k + 2] * tic[2];
+                d[k] = t1[k] - t0[k];
+            }
+            for (int k = 0; k < 3; ++k) t[k] = R0[k] * d[0] + R0[3 + k] * d[1] + R0[6 + k] * d[2];                 // R0^T d
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) R[a * 3 + b] = R0[a] * R1[b] + R0[3 + a] * R1[3 + b] + R0[6 + a] * R1[6 + b];   // R0^T R1
+            for (int r = 0; r < 3; ++r) {
+                for (int cc = 0; cc < 3; ++cc) P[r * 4 + cc] = R[cc * 3 + r];
+                P[r * 4 + 3] = -(R[r] * t[0] + R[3 + r] * t[1] + R[6 + r] * t[2]);
+            }
+            const double* pt = points + 3 * (size_t)(obs_off[l] + j);
+            const double nrm = std::sqrt(pt[0] * pt[0] + pt[1] * pt[1] + pt[2] * pt[2]);
+            const double fx = pt[0] / nrm, fy = pt[1] / nrm, fz = pt[2] / nrm;
+            double r0[4], r1[4];
+            for (int cc = 0; cc < 4; ++cc) { r0[cc] = fx * P[8 + cc] - fz * P[cc]; r1[cc] = fy * P[8 + cc] - fz * P[4 + cc]; }
+            for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) G[a * 4 + b] += r0[a] * r0[b] + r1[a] * r1[b];
+        }
+        // cyclic Jacobi on the symmetric 4x4 G, eigenvectors in V
+        double V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            double off = 0;
+            for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) off += G[a * 4 + b] * G[a * 4 + b];
+            if (off == 0.0) break;
+            for (int p = 0; p < 3; ++p)
+                for (int q = p + 1; q < 4; ++q) {
+                    const double apq = G[p * 4 + q];
+                    if (apq == 0.0) continue;
+                    const double theta = (G[q * 4 + q] - G[p * 4 + p]) / (2.0 * apq);
+                    const double tt = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / std::sqrt(tt * tt + 1.0), s = tt * c;
+                    for (int k = 0; k < 4; ++k) {
+                        const double gkp = G[k * 4 + p], gkq = G[k * 4 + q];
+                        G[k * 4 + p] = c * gkp - s * gkq; G[k * 4 + q] = s * gkp + c * gkq;
+                    }
+                    for (int k = 0; k < 4; ++k) {
+                        const double gpk = G[p * 4 + k], gqk = G[q * 4 + k];
+                        G[p * 4 + k] = c * gpk - s * gqk; G[q * 4 + k] = s * gpk + c * gqk;
+                    }
+                    for (int k = 0; k < 4; ++k) {
+                        const double vkp = V[k * 4 + p], vkq = V[k * 4 + q];
+                        V[k * 4 + p] = c * vkp - s * vkq; V[k * 4 + q] = s * vkp + c * vkq;
+                    }
+                }
+        }
+        int bi = 0;
+        for (int k = 1; k < 4; ++k) if (G[k * 4 + k] < G[bi * 4 + bi]) bi = k;
+        double dep = V[2 * 4 + bi] / V[3 * 4 + bi];
+        if (dep < 0.1) dep = init_depth;
+        depth[l] = dep;
+    }
+}

@@ -48,3 +48,19 @@ def time_optimize(packed_list, margin_flags, repeats=1):
         for p, o, mf in zip(packed_list, outs, margin_flags):
             L.oracle_ba_optimize(C.byref(p.struct), int(mf), C.byref(o.state), C.byref(sm), C.byref(o.prior))
     return time.perf_counter() - t0
+
+
+def triangulate(Ps, Rs, tic, ric, start, nobs, obs_off, points, init_depth=5.0):
+    """FeatureManager::triangulate, C++ restatement (Gram-matrix Jacobi) — see ba_numpy.triangulate for the SVD one."""
+    import numpy as np
+    Ps = np.ascontiguousarray(Ps, np.float64); Rs = np.ascontiguousarray(Rs, np.float64).reshape(-1, 9)
+    st = np.ascontiguousarray(start, np.int32); nb = np.ascontiguousarray(nobs, np.int32); oo = np.ascontiguousarray(obs_off, np.int32)
+    pts = np.ascontiguousarray(points, np.float64)
+    out = np.zeros(max(len(st), 1))
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    f = lib().oracle_triangulate
+    f.restype = None
+    f(len(Ps), Ps.ctypes.data_as(dp), Rs.ctypes.data_as(dp), np.ascontiguousarray(tic, np.float64).ctypes.data_as(dp),
+      np.ascontiguousarray(ric, np.float64).ctypes.data_as(dp), len(st), st.ctypes.data_as(ip), nb.ctypes.data_as(ip), oo.ctypes.data_as(ip),
+      pts.ctypes.data_as(dp), C.c_double(init_depth), out.ctypes.data_as(dp))
+    return out[:len(st)]

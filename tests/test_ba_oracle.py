@@ -153,3 +153,21 @@ def test_cpp_oracle_matches_numpy_oracle():
     ref2 = B.double2vector(prob2, x2)
     assert np.isclose(sm_c2['final_cost'], s2['final_cost'], rtol=1e-8)
     assert np.abs(st_c2['pose'] - ref2['pose']).max() < 1e-8
+
+
+def test_triangulate_restatements_agree():
+    """FeatureManager::triangulate: NumPy (LAPACK SVD of the DLT matrix) vs C++ (Jacobi on its Gram matrix)."""
+    from oracle import ba_cpu
+    from vins_mono_amd import synth
+    seq = synth.SyntheticSequence(91, L=120)
+    prob = seq.window(0)
+    c = seq.cfg
+    K = prob['pose'].shape[0]
+    Ps = prob['pose'][:, :3]
+    Rs = np.array([B.q2R(q) for q in prob['pose'][:, 3:]]).reshape(K, 9)
+    pts = np.concatenate([prob['obs'][:, :2], np.ones((len(prob['obs']), 1))], axis=1)
+    a = B.triangulate(Ps, Rs, c['tic'], c['ric'], prob['lm_start'], prob['lm_nobs'], prob['obs_off'], pts)
+    b = ba_cpu.triangulate(Ps, Rs, c['tic'], c['ric'], prob['lm_start'], prob['lm_nobs'], prob['obs_off'], pts)
+    assert np.allclose(a, b, rtol=1e-7, atol=1e-9)
+    lng = prob['lm_nobs'] >= 6
+    assert np.median(np.abs(a[lng] * prob['inv_depth'][lng] - 1.0)) < 0.25
