@@ -256,19 +256,31 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
         }
         // Scharr field on the 22x22 integer positions (calcSharrDeriv; constant-0 border outside the image).
         // NB the x+-1 / y+-1 taps reflect at the IMAGE edge, which is what the reflect-101 patch holds.
-        for (int k = lane; k < 22 * 22; k += 64) {
-            const int yy = k / 22, xx = k % 22;
-            const int X = ipx + xx, Y = ipy + yy;
-            int ix = 0, iy = 0;
-            if (X >= 0 && X < lw && Y >= 0 && Y < lh) {
-                const uint8_t* p = s.ipatch + (yy + 1) * 24 + (xx + 1);
-                const int t0m = 3 * (p[-24 - 1] + p[24 - 1]) + 10 * p[-1];
-                const int t0p = 3 * (p[-24 + 1] + p[24 + 1]) + 10 * p[1];
-                const int t1m = p[24 - 1] - p[-24 - 1], t1c = p[24] - p[-24], t1p = p[24 + 1] - p[-24 + 1];
-                ix = t0p - t0m;
-                iy = 3 * (t1m + t1p) + 10 * t1c;
+        // lane = (row yy of the 22x22 lattice, 11-column half): 44 lanes, each walks its 11 positions with a sliding
+        // 3x3 neighbourhood (3 new bytes per position instead of 8): ~40 % fewer instructions than a strided sweep
+        if (lane < 44) {
+            const int yy = lane >> 1, xs = 11 * (lane & 1);
+            const int Y = ipy + yy;
+            const bool yin = Y >= 0 && Y < lh;
+            const uint8_t* p = s.ipatch + (yy + 1) * 24 + (xs + 1);          // centre of the first position
+            int a0 = p[-24 - 1], a1 = p[-1], a2 = p[24 - 1];                  // column x-1 (rows y-1, y, y+1)
+            int b0 = p[-24], b1 = p[0], b2 = p[24];                           // column x
+            int* dq = (int*)s.der + yy * 22 + xs;
+#pragma unroll
+            for (int q = 0; q < 11; ++q) {
+                const int c0 = p[-24 + q + 1], c1 = p[q + 1], c2 = p[24 + q + 1];    // column x+1
+                const int X = ipx + xs + q;
+                int ix = 0, iy = 0;
+                if (yin && X >= 0 && X < lw) {
+                    const int t0m = 3 * (a0 + a2) + 10 * a1;
+                    const int t0p = 3 * (c0 + c2) + 10 * c1;
+                    const int t1m = a2 - a0, t1c = b2 - b0, t1p = c2 - c0;
+                    ix = t0p - t0m;
+                    iy = 3 * (t1m + t1p) + 10 * t1c;
+                }
+                dq[q] = (int)((unsigned)(ix & 0xffff) | ((unsigned)iy << 16));        // (int16 Ix | int16 Iy << 16)
+                a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
             }
-            s.der[k * 2] = (int16_t)ix; s.der[k * 2 + 1] = (int16_t)iy;
         }
         __syncthreads();
         // lane = (window row ly, 7-pixel segment): the template values and gradients of a lane's seven pixels stay in
