@@ -584,7 +584,7 @@ def dense_schur_solve(J, r, D, R):
     return y if np.all(np.isfinite(y)) else None
 
 
-def solve(prob, trace=None):
+def solve(prob, trace=None, min_mu=1e-8):
     """ceres::Solve as configured at estimator.cpp:803-818 (DENSE_SCHUR, DOGLEG, max 8 iterations,
     wall-clock cap OFF).  Returns (state, summary)."""
     lay = Layout(prob)
@@ -600,8 +600,8 @@ def solve(prob, trace=None):
         summary['termination'] = 'CONVERGENCE'
         summary['final_cost'] = cost
         return x, summary
-    radius, mu, reuse = 1e4, 1e-8, False
-    min_mu, max_mu = 1e-8, 1.0
+    radius, mu, reuse = 1e4, min_mu, False
+    max_mu = 1.0
     x_norm = np.linalg.norm(ambient_vector(prob, x))
     num_invalid = 0
     Dg = gt = gn = None
@@ -622,12 +622,15 @@ def solve(prob, trace=None):
             Jg = J @ (gt / Dg)
             alpha = (gt @ gt) / (Jg @ Jg)
             y = None
+            mu_tries = 0
             while mu < max_mu:
                 y = dense_schur_solve(J, r, Dg * np.sqrt(mu), R)
                 if y is None:
                     mu *= 10.0
+                    mu_tries += 1
                     continue
                 break
+            rec.update(mu=mu, mu_tries=mu_tries)
             if y is None:
                 ok = False
             else:
@@ -636,9 +639,12 @@ def solve(prob, trace=None):
             gnorm, gnn = np.linalg.norm(gt), np.linalg.norm(gn)
             if gnn <= radius:
                 s, dogleg_norm = gn.copy(), gnn
+                rec.update(branch='gn')
             elif gnorm * alpha >= radius:
                 s, dogleg_norm = -(radius / gnorm) * gt, radius
+                rec.update(branch='cauchy')
             else:
+                rec.update(branch='dogleg')
                 b_dot_a = -alpha * (gt @ gn)
                 a_sq = (alpha * gnorm) ** 2
                 bma_sq = a_sq - 2 * b_dot_a + gnn ** 2
@@ -668,12 +674,12 @@ def solve(prob, trace=None):
                    step_norm=dogleg_norm)
         step_norm = np.linalg.norm(ambient_vector(prob, x) - ambient_vector(prob, x_cand))
         if step_norm <= 1e-8 * (x_norm + 1e-8):
-            rec.update(accepted=False)
+            rec.update(accepted=False, exit='parameter_tolerance')
             summary['iterations'].append(rec)
             summary['termination'] = 'CONVERGENCE'
             break
         if abs(cost - cost_cand) <= 1e-6 * cost:
-            rec.update(accepted=False)
+            rec.update(accepted=False, exit='function_tolerance')
             summary['iterations'].append(rec)
             summary['termination'] = 'CONVERGENCE'
             break

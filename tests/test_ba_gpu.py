@@ -8,6 +8,8 @@ import pytest
 from oracle import ba_numpy as B
 from vins_mono_amd import ba, synth
 
+import ba_fixtures as FX
+
 pytestmark = pytest.mark.gpu
 
 
@@ -69,29 +71,61 @@ def test_factor_parity(handle, ex, td):
     assert np.allclose(out['prior_r'], qr, rtol=1e-10, atol=1e-10 * np.abs(qr).max())
 
 
+_TERM = {'NO_CONVERGENCE': 0, 'CONVERGENCE': 1, 'FAILURE': 2}
+
+
 def _check_solve(handle, prob, rtol_state=1e-4):
+    """GPU vs oracle, iteration by iteration: same number of iterations, same valid / accepted flags, same termination,
+    and per iteration the cost, candidate cost, model cost change, radius and dogleg step norm; then the gauge-fixed
+    states (positions are compared relative to frame 0 as well, so a far-away world origin cannot hide an error)."""
     x, summ = B.solve(prob)
     ref = B.double2vector(prob, x)
     st, sm, _ = handle.ba_optimize(prob)
     assert sm['status'] == 0
     its = summ['iterations']
     assert sm['num_iterations'] == summ['num_iterations']
+    assert sm['termination'] == _TERM[summ['termination']]
     flags = [(1 if it.get('valid') else 0) | (2 if it.get('accepted') else 0) for it in its]
-    assert list(sm['it_flags']) == flags
+    assert list(sm['it_flags'][:len(flags)]) == flags
     assert np.isclose(sm['initial_cost'], summ['initial_cost'], rtol=1e-9)
     for k, it in enumerate(its):
         if it.get('valid'):
+            assert np.isclose(sm['it_cost'][k], it['cost'], rtol=1e-6, atol=1e-9), k
             assert np.isclose(sm['it_cost_cand'][k], it['cost_cand'], rtol=1e-6, atol=1e-9), k
             assert np.isclose(sm['it_model'][k], it['model_change'], rtol=1e-5), k
             assert np.isclose(sm['it_radius'][k], it['radius'], rtol=1e-6), k
+            assert np.isclose(sm['it_step_norm'][k], it['step_norm'], rtol=1e-5), k
     assert np.isclose(sm['final_cost'], summ['final_cost'], rtol=1e-6)
+    rel_g = st['pose'][:, :3] - st['pose'][0, :3]
+    rel_o = ref['pose'][:, :3] - ref['pose'][0, :3]
+    assert np.abs(rel_g - rel_o).max() < rtol_state * max(1.0, np.abs(rel_o).max())
     scale_p = max(1.0, np.abs(ref['pose'][:, :3]).max())
     assert np.abs(st['pose'][:, :3] - ref['pose'][:, :3]).max() < rtol_state * scale_p
     assert np.abs(st['pose'][:, 3:] - ref['pose'][:, 3:]).max() < rtol_state
     assert np.abs(st['sb'] - ref['sb']).max() < rtol_state * max(1.0, np.abs(ref['sb']).max())
     assert np.allclose(st['inv_depth'], ref['inv_depth'], rtol=1e-4, atol=1e-6)
     assert np.allclose(st['ex'], ref['ex'], atol=rtol_state)
-    return st, sm
+    return st, sm, summ
+
+
+@pytest.mark.parametrize("name", sorted(FX.BRANCH_FIXTURES))
+def test_trust_region_branches(handle, name):
+    """every branch of the restated Ceres loop (Cauchy / interpolated / Gauss-Newton step, rejected
+    step with radius halving and step reuse, mu escalation after a failed factorisation, invalid-step counter and
+    FAILURE, function- and parameter-tolerance exits) on a fixture whose ORACLE trace is asserted to contain it."""
+    build, need = FX.BRANCH_FIXTURES[name]
+    prob = build()
+    _, _, summ = _check_solve(handle, prob)
+    assert need <= FX.trace_features(summ), (name, need - FX.trace_features(summ))
+
+
+def test_trust_region_fixtures_cover_all_branches():
+    """The union of the fixtures above reaches every branch (oracle side; the GPU side is the parametrised test)."""
+    seen = set()
+    for name, (build, need) in FX.BRANCH_FIXTURES.items():
+        seen |= need
+    assert seen >= {'gn', 'cauchy', 'dogleg', 'rejected', 'mu_escalation', 'invalid', 'failure', 'function_tolerance',
+                    'parameter_tolerance'}
 
 
 @pytest.mark.parametrize("seed", [1, 2])

@@ -171,3 +171,110 @@ def test_triangulate_restatements_agree():
     assert np.allclose(a, b, rtol=1e-7, atol=1e-9)
     lng = prob['lm_nobs'] >= 6
     assert np.median(np.abs(a[lng] * prob['inv_depth'][lng] - 1.0)) < 0.25
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Trust-region branch coverage and an independent anchor for the minimiser restatement
+# ---------------------------------------------------------------------------------------------------------------
+import warnings
+
+import pytest
+
+import ba_fixtures as FX
+
+
+@pytest.mark.parametrize("name", sorted(FX.BRANCH_FIXTURES))
+def test_branch_fixture_traces_and_two_restatements_agree(name):
+    """Each fixture's NumPy-oracle trace contains the branches it is there for, and the C++ restatement
+    (oracle/ba_cpu.cpp) walks the same accept / reject / invalid sequence to the same state."""
+    from oracle import ba_cpu
+    build, need = FX.BRANCH_FIXTURES[name]
+    prob = build()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # the overflowing-landmark fixture overflows on purpose
+        x, s = B.solve(prob)
+        ref = B.double2vector(prob, x)
+    assert need <= FX.trace_features(s), need - FX.trace_features(s)
+    st_c, sm_c, _ = ba_cpu.optimize(prob, 2)
+    assert sm_c['num_iterations'] == s['num_iterations']
+    flags = [(1 if it.get('valid') else 0) | (2 if it.get('accepted') else 0) for it in s['iterations']]
+    assert list(sm_c['it_flags'][:len(flags)]) == flags
+    assert sm_c['termination'] == {'NO_CONVERGENCE': 0, 'CONVERGENCE': 1, 'FAILURE': 2}[s['termination']]
+    assert np.isclose(sm_c['final_cost'], s['final_cost'], rtol=1e-6)
+    rel_c = st_c['pose'][:, :3] - st_c['pose'][0, :3]
+    rel_o = ref['pose'][:, :3] - ref['pose'][0, :3]
+    assert np.abs(rel_c - rel_o).max() < 1e-6 and np.abs(st_c['pose'][:, 3:] - ref['pose'][:, 3:]).max() < 1e-7
+
+
+def test_branch_fixtures_cover_every_trust_region_path():
+    seen = set()
+    for build, need in FX.BRANCH_FIXTURES.values():
+        seen |= need
+    assert seen >= {'gn', 'cauchy', 'dogleg', 'rejected', 'mu_escalation', 'invalid', 'failure', 'function_tolerance',
+                    'parameter_tolerance'}
+
+
+def _robust_residuals(prob, x_anchor, delta, need_jac):
+    """f(delta) with 1/2 |f|^2 = the Ceres cost 1/2 sum rho(|r|^2) at x_anchor (+) delta, and its EXACT Jacobian at
+    delta = 0 (not the Triggs-corrected one the minimiser uses): per projection block f = a(s) r, a = sqrt(rho(s)/s),
+    df = (a I + 2 a'(s) r r^T) J.  Built from the loss-corrected (r, J) of B.evaluate by undoing the correction."""
+    st = B.plus(prob, x_anchor, delta)
+    lay = B.Layout(prob)
+    _, r, J = B.evaluate(prob, st, need_jac=need_jac)
+    nprior = prob['prior']['n'] if prob.get('prior') is not None else 0
+    nimu = sum(1 for k in range(lay.K - 1) if prob['imu'][k] is not None and prob['imu'][k]['sum_dt'] <= 10.0)
+    r = r.copy()
+    J = J.copy() if need_jac else None
+    for row in range(nprior + 15 * nimu, r.shape[0], 2):
+        rc = r[row:row + 2]
+        sc = rc @ rc                              # rho'(s) s = s / (1 + s)
+        s = sc / (1.0 - sc)
+        sq = np.sqrt(1.0 / (1.0 + s))
+        raw = rc / sq
+        if s < 1e-300:
+            a, ap = 1.0, 0.0
+        else:
+            rho = np.log1p(s)
+            a = np.sqrt(rho / s)
+            ap = 0.5 / a * (s / (1.0 + s) - rho) / (s * s)
+        r[row:row + 2] = a * raw
+        if need_jac:
+            J[row:row + 2] = (a * np.eye(2) + 2.0 * ap * np.outer(raw, raw)) @ (J[row:row + 2] / sq)
+    return r, J
+
+
+def _scipy_polish(prob, x, rounds=3):
+    """Levenberg-Marquardt (MINPACK through scipy.optimize.least_squares) on the same cost, re-anchoring the tangent
+    space every round so that the supplied Jacobian is exact where it matters (at delta = 0)."""
+    from scipy.optimize import least_squares
+    n = B.Layout(prob).ncols
+    for _ in range(rounds):
+        _, J0 = _robust_residuals(prob, x, np.zeros(n), True)
+        res = least_squares(lambda d: _robust_residuals(prob, x, d, False)[0], np.zeros(n),
+                            jac=lambda d: J0 if not np.any(d) else _robust_residuals(prob, x, d, True)[1],
+                            method='lm', x_scale='jac', max_nfev=60, xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        x = B.plus(prob, x, res.x)
+    return x, B.evaluate(prob, x, need_jac=False)[0]
+
+
+def test_minimiser_converges_to_the_scipy_optimum():
+    """Independent anchor for the restated trust-region minimiser: scipy's MINPACK
+    Levenberg-Marquardt on the same cost, started from the fixture's initial state, reaches the cost the oracle
+    converges to (function-tolerance exit, so equal to ~1e-6), cannot improve the oracle's point by more than that,
+    and its optimum is a fixed point of the oracle (one iteration, parameter-tolerance exit).
+    Fixture: the vision-only window.  With IMU factors the cost has a damping-limited valley (common-mode bias: scaled
+    curvature << Ceres' min mu = 1e-8, decrements of ~2e-3 relative per iteration for thousands of iterations), which
+    is the reference's behaviour over its 8 iterations but makes "the optimum" a poor test quantity."""
+    prob = FX.fx_vision_only()
+    xo, so = B.solve(prob)
+    assert so['termination'] == 'CONVERGENCE' and so['iterations'][-1].get('exit') == 'function_tolerance'
+    xs, c_start = _scipy_polish(prob, B.state_of(prob), rounds=4)
+    assert abs(so['final_cost'] - c_start) <= 2e-6 * c_start
+    _, c_pol = _scipy_polish(prob, xo, rounds=2)
+    assert c_pol <= so['final_cost'] * (1 + 1e-12) and (so['final_cost'] - c_pol) <= 2e-6 * c_pol
+    assert abs(c_pol - c_start) <= 1e-9 * c_start
+    q = dict(prob)
+    q['pose'], q['sb'], q['inv_depth'] = xs['pose'], xs['sb'], xs['inv_depth']
+    _, s2 = B.solve(q)
+    assert s2['termination'] == 'CONVERGENCE' and len(s2['iterations']) == 1
+    assert abs(s2['final_cost'] - c_start) <= 1e-9 * c_start
