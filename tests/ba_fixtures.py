@@ -107,25 +107,15 @@ def fx_single_landmark():
     return q
 
 
-def fx_zero_parallax(L=30):
-    """All key frames at (almost) the same pose: depth is unobservable from parallax, the landmark block is held by
-    the damping; exercises radius growth on a flat valley."""
+def fx_low_parallax(L=40, shrink=0.01):
+    """Near-zero parallax: the trajectory's translation is shrunk to 1 % about frame 0 (centimetre baselines against
+    2-12 m depths, i.e. parallax at the pixel-noise level), tracks re-drawn for it, no IMU factors: the depths are
+    barely observable and the first steps are large, partly rejected ones."""
     seq = synth.SyntheticSequence(5, L=L)
+    seq.P = seq.P[0] + shrink * (seq.P - seq.P[0])
+    seq._make_landmarks()
     q = seq.window(0)
-    K = q['pose'].shape[0]
-    # re-project every landmark from the pose of frame 0 (static camera), keep the IMU factors of the moving truth out
-    c = seq.cfg
-    R0, P0 = B.q2R(q['pose'][0][3:]), q['pose'][0][:3].copy()
-    for i in range(1, K):
-        q['pose'][i] = q['pose'][0].copy()
-        q['sb'][i] = q['sb'][0].copy()
-    q['sb'][:, :3] = 0.0
-    for l in range(q['inv_depth'].shape[0]):
-        o, n = int(q['obs_off'][l]), int(q['lm_nobs'][l])
-        for k in range(1, n):
-            q['obs'][o + k][:2] = q['obs'][o][:2] + 1e-4 * np.array([np.sin(l + k), np.cos(l * k)])
-            q['obs'][o + k][4:6] = 0.0
-    q['imu'] = [None] * (K - 1)
+    q['imu'] = [None] * (q['pose'].shape[0] - 1)
     q['max_iters'] = 16
     return q
 
@@ -139,7 +129,7 @@ BRANCH_FIXTURES = {
     'overflowing_landmark': (fx_overflowing_landmark, {'mu_escalation', 'invalid', 'failure'}),
     'lambda_near_zero': (fx_lambda_near_zero, {'dogleg'}),
     'single_landmark': (fx_single_landmark, set()),
-    'zero_parallax': (fx_zero_parallax, set()),
+    'low_parallax': (fx_low_parallax, {'rejected', 'dogleg', 'gn'}),
 }
 
 
