@@ -133,6 +133,12 @@ BRANCH_FIXTURES = {
 }
 
 
+# relative tolerance of the per-iteration cost comparison GPU vs oracle (default 1e-6): the low-parallax window is
+# ill-conditioned by construction (depths barely observable), its candidate costs agree to ~1e-6 between any two
+# implementations that sum in a different order
+COST_RTOL = {'low_parallax': 1e-4}
+
+
 def trace_features(summary):
     """The set of trust-region branches an oracle run went through (from ba_numpy.solve's per-iteration records)."""
     f = set()

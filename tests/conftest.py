@@ -28,3 +28,48 @@ def handle():
     h = ba.Handle()
     yield h
     h.close()
+
+
+# ---- CPU fiber emulation of the kernel sources (tests/simt): TEST INFRASTRUCTURE, see tests/simt/README.md ---------
+SIMT_DIR = os.path.join(ROOT, "tests", "simt")
+SIMT_LIB = os.path.join(SIMT_DIR, "_build", "libvinsgpu_simt.so")
+
+
+def _build_simt():
+    import subprocess
+    r = subprocess.run(["make", "-C", SIMT_DIR, "-j", str(os.cpu_count() or 4)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building the SIMT emulation library failed:\n" + r.stdout[-4000:])
+
+
+def _simt_handle():
+    import ctypes
+    pkg = graft.load_package()
+    _build_simt()
+    saved = (pkg._lib, pkg.LIB_PATH)
+    pkg._lib, pkg.LIB_PATH = ctypes.CDLL(SIMT_LIB, mode=ctypes.RTLD_LOCAL), SIMT_LIB
+    try:
+        from vins_mono_amd import ba
+        h = ba.Handle()
+    finally:
+        pkg._lib, pkg.LIB_PATH = saved
+    return h
+
+
+@pytest.fixture(scope="session")
+def simt_handle():
+    """A vg_handle of the EMULATED library: the same kernel sources compiled for the CPU fiber emulator.  Used by the
+    `not gpu` tests to check kernel logic (barriers, indexing, control flow) here, where there is no GPU."""
+    h = _simt_handle()
+    yield h
+    h.close()
+
+
+if os.environ.get("VINS_TEST_SIMT") == "1":
+    # development switch: run the `-m gpu` parity tests against the emulated library (slow; BA-sized problems only)
+    @pytest.fixture(scope="session")
+    def handle():  # noqa: F811
+        h = _simt_handle()
+        yield h
+        h.close()

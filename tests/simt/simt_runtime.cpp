@@ -1,0 +1,181 @@
+// tests/simt/simt_runtime.cpp — fiber scheduler + host-runtime stubs behind tests/simt/hip/hip_runtime.h.
+// TEST INFRASTRUCTURE (see the header).  One OS thread; a workgroup = blockDim fibers; workgroups run sequentially.
+#include <hip/hip_runtime.h>
+#include <ucontext.h>
+#include <chrono>
+#include <random>
+#include <string>
+#include <vector>
+
+// dynamic LDS windows of the kernel sources (each `extern __shared__ ... name[]` needs one definition)
+thread_local __attribute__((aligned(16))) char ba_smem[160 * 1024];
+thread_local __attribute__((aligned(16))) char bp_smem[160 * 1024];
+thread_local __attribute__((aligned(16))) char mg_smem[160 * 1024];
+thread_local __attribute__((aligned(16))) unsigned char sel_smem[160 * 1024];
+
+namespace simt {
+thread_local Lane* cur = nullptr;
+thread_local dim3 g_block, g_grid;
+
+namespace {
+enum { RUN = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    Lane lane;
+    int state = RUN;
+    unsigned gen = 0;        // generation of the barrier it waits on
+};
+struct WaveState {
+    int alive = 0, arrived = 0;
+    unsigned gen = 0;
+    uint64_t buf[2][64];
+};
+struct BlockState {
+    std::vector<Fiber> f;
+    std::vector<WaveState> w;
+    int alive = 0, arrived = 0;
+    unsigned gen = 0;
+    ucontext_t sched;
+    int running = -1;
+    const std::function<void()>* body = nullptr;
+};
+thread_local BlockState* B = nullptr;
+const size_t kStack = 256 * 1024;
+
+void release_block() { B->arrived = 0; ++B->gen; }
+void release_wave(WaveState& w) { w.arrived = 0; ++w.gen; }
+
+void fiber_main() {
+    Fiber& me = B->f[B->running];
+    (*B->body)();
+    me.state = DONE;
+    --B->alive;
+    WaveState& w = B->w[me.lane.wave];
+    --w.alive;
+    // a finished lane no longer takes part in barriers: release whoever was waiting for it
+    if (B->alive > 0 && B->arrived == B->alive) release_block();
+    if (w.alive > 0 && w.arrived == w.alive) release_wave(w);
+    swapcontext(&me.ctx, &B->sched);
+}
+
+void yield_to_scheduler() {
+    Fiber& me = B->f[B->running];
+    swapcontext(&me.ctx, &B->sched);
+}
+}  // namespace
+
+void sync_block() {
+    Fiber& me = B->f[B->running];
+    const unsigned g = B->gen;
+    if (++B->arrived == B->alive) { release_block(); return; }
+    me.state = WAIT_BLOCK; me.gen = g;
+    yield_to_scheduler();
+}
+void sync_wave() {
+    Fiber& me = B->f[B->running];
+    WaveState& w = B->w[me.lane.wave];
+    const unsigned g = w.gen;
+    if (++w.arrived == w.alive) { release_wave(w); return; }
+    me.state = WAIT_WAVE; me.gen = g;
+    yield_to_scheduler();
+}
+uint64_t* xchg(unsigned parity) { return B->w[cur->wave].buf[parity & 1]; }
+long long clock() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
+    if (lds_bytes > 160 * 1024) { fprintf(stderr, "simt: %zu bytes of dynamic LDS requested\n", lds_bytes); abort(); }
+    const char* ord = getenv("SIMT_ORDER");
+    const int order = !ord ? 0 : (!strcmp(ord, "reverse") ? 1 : (!strcmp(ord, "shuffle") ? 2 : 0));
+    const int nthr = (int)(block.x * block.y * block.z);
+    const int nwave = (nthr + 63) / 64;
+    g_block = block; g_grid = grid;
+    BlockState bs;
+    bs.f.resize(nthr);
+    for (auto& f : bs.f) f.stack.resize(kStack);
+    std::vector<int> perm(nthr);
+    std::mt19937 rng(12345);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+    for (unsigned bx = 0; bx < grid.x; ++bx) {
+        B = &bs;
+        bs.body = &body;
+        bs.w.assign(nwave, WaveState());
+        bs.alive = nthr; bs.arrived = 0; bs.gen = 0;
+        for (int t = 0; t < nthr; ++t) {
+            Fiber& f = bs.f[t];
+            f.state = RUN; f.gen = 0;
+            f.lane.flat = t; f.lane.lane = t & 63; f.lane.wave = t >> 6; f.lane.xcnt = 0;
+            f.lane.tid.x = t % block.x; f.lane.tid.y = (t / block.x) % block.y; f.lane.tid.z = t / (block.x * block.y);
+            f.lane.bid.x = bx; f.lane.bid.y = by; f.lane.bid.z = bz;
+            bs.w[f.lane.wave].alive++;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack.data();
+            f.ctx.uc_stack.ss_size = kStack;
+            f.ctx.uc_link = nullptr;
+            makecontext(&f.ctx, fiber_main, 0);
+        }
+        for (int t = 0; t < nthr; ++t) perm[t] = order == 1 ? nthr - 1 - t : t;
+        int stalled = 0;
+        while (bs.alive > 0) {
+            if (order == 2) std::shuffle(perm.begin(), perm.end(), rng);
+            bool progressed = false;
+            for (int k = 0; k < nthr; ++k) {
+                Fiber& f = bs.f[perm[k]];
+                if (f.state == DONE) continue;
+                if (f.state == WAIT_BLOCK) { if (bs.gen == f.gen) continue; f.state = RUN; }
+                if (f.state == WAIT_WAVE) { if (bs.w[f.lane.wave].gen == f.gen) continue; f.state = RUN; }
+                bs.running = perm[k];
+                cur = &f.lane;
+                progressed = true;
+                swapcontext(&bs.sched, &f.ctx);
+            }
+            if (!progressed && ++stalled > 2) {
+                fprintf(stderr, "simt: deadlock in block (%u,%u,%u): %d lanes alive, %d at the block barrier; a barrier or a "
+                        "wavefront collective sits in divergent control flow\n", bx, by, bz, bs.alive, bs.arrived);
+                for (int w = 0; w < nwave; ++w)
+                    fprintf(stderr, "   wave %d: alive %d, arrived at wave sync %d\n", w, bs.w[w].alive, bs.w[w].arrived);
+                abort();
+            }
+            if (progressed) stalled = 0;
+        }
+    }
+    B = nullptr; cur = nullptr;
+}
+}  // namespace simt
+
+// ---------------------------------------------------------------------------------------------- host runtime stubs
+struct simt_stream { int id; };
+struct simt_event { long long t; };
+static thread_local hipError_t g_last = hipSuccess;
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); if (*p) memset(*p, 0xCD, n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < h; ++r) memmove((char*)d + r * dp, (const char*)s + r * sp, w);
+    return hipSuccess;
+}
+hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new simt_stream{1}; return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = new simt_stream{1}; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new simt_event{0}; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = simt::clock(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e-6); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipGetLastError() { hipError_t e = g_last; g_last = hipSuccess; return e; }
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess (simt)" : "hip error (simt)"; }
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }

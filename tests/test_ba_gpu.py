@@ -74,7 +74,7 @@ def test_factor_parity(handle, ex, td):
 _TERM = {'NO_CONVERGENCE': 0, 'CONVERGENCE': 1, 'FAILURE': 2}
 
 
-def _check_solve(handle, prob, rtol_state=1e-4):
+def _check_solve(handle, prob, rtol_state=1e-4, rtol_cost=1e-6):
     """GPU vs oracle, iteration by iteration: same number of iterations, same valid / accepted flags, same termination,
     and per iteration the cost, candidate cost, model cost change, radius and dogleg step norm; then the gauge-fixed
     states (positions are compared relative to frame 0 as well, so a far-away world origin cannot hide an error)."""
@@ -90,12 +90,12 @@ def _check_solve(handle, prob, rtol_state=1e-4):
     assert np.isclose(sm['initial_cost'], summ['initial_cost'], rtol=1e-9)
     for k, it in enumerate(its):
         if it.get('valid'):
-            assert np.isclose(sm['it_cost'][k], it['cost'], rtol=1e-6, atol=1e-9), k
-            assert np.isclose(sm['it_cost_cand'][k], it['cost_cand'], rtol=1e-6, atol=1e-9), k
-            assert np.isclose(sm['it_model'][k], it['model_change'], rtol=1e-5), k
+            assert np.isclose(sm['it_cost'][k], it['cost'], rtol=rtol_cost, atol=1e-9), k
+            assert np.isclose(sm['it_cost_cand'][k], it['cost_cand'], rtol=rtol_cost, atol=1e-9), k
+            assert np.isclose(sm['it_model'][k], it['model_change'], rtol=10 * rtol_cost), k
             assert np.isclose(sm['it_radius'][k], it['radius'], rtol=1e-6), k
-            assert np.isclose(sm['it_step_norm'][k], it['step_norm'], rtol=1e-5), k
-    assert np.isclose(sm['final_cost'], summ['final_cost'], rtol=1e-6)
+            assert np.isclose(sm['it_step_norm'][k], it['step_norm'], rtol=10 * rtol_cost), k
+    assert np.isclose(sm['final_cost'], summ['final_cost'], rtol=rtol_cost)
     rel_g = st['pose'][:, :3] - st['pose'][0, :3]
     rel_o = ref['pose'][:, :3] - ref['pose'][0, :3]
     assert np.abs(rel_g - rel_o).max() < rtol_state * max(1.0, np.abs(rel_o).max())
@@ -115,7 +115,7 @@ def test_trust_region_branches(handle, name):
     FAILURE, function- and parameter-tolerance exits) on a fixture whose ORACLE trace is asserted to contain it."""
     build, need = FX.BRANCH_FIXTURES[name]
     prob = build()
-    _, _, summ = _check_solve(handle, prob)
+    _, _, summ = _check_solve(handle, prob, rtol_cost=FX.COST_RTOL.get(name, 1e-6))
     assert need <= FX.trace_features(summ), (name, need - FX.trace_features(summ))
 
 

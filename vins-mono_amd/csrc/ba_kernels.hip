@@ -20,8 +20,7 @@
 #define NOINL __device__ __noinline__
 extern __shared__ __attribute__((aligned(16))) char ba_smem[];
 #define LDSB ((double*)ba_smem)
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double double4_t __attribute__((vector_size(32)));      // v_mfma_f64_16x16x4 accumulator (4 VGPR pairs)
 
 // optional phase timers (build with -DBA_PROFILE): lane 0 accumulates s_memtime deltas per phase
 #ifdef BA_PROFILE
@@ -371,8 +370,8 @@ NOINL double proj_linearize_chunk(const Ctx& c, int ch, const double* x, const d
 DEV double seg_dot(const double* stage, int REC, int b, int e, int offA, int offB) {
     double acc = 0.0;
     for (int s = b; s < e; ++s) {
-        const double2_t a2 = *(const double2_t*)(stage + s * REC + offA);
-        const double2_t b2 = *(const double2_t*)(stage + s * REC + offB);
+        const double2 a2 = *(const double2*)(stage + s * REC + offA);
+        const double2 b2 = *(const double2*)(stage + s * REC + offB);
         acc += a2.x * b2.x + a2.y * b2.y;
     }
     return acc;
