@@ -18,9 +18,10 @@
 #include "vg_handle.h"
 #include "../../include/vinsgpu.h"
 
-extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream);
+extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream);
 extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, double* proj_r, double* proj_J,
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream);
+extern "C" const char* ba_failed_launch();
 extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream);
 
 #define HIPCHK(h, expr)                                                                            \
@@ -63,6 +64,22 @@ static int check_problem(vg_handle* h, const vg_ba_problem* p) {
             n += blk_lsize(k);
         }
         if (n != p->prior_n) { h->err = "prior_n != sum of local block sizes"; return VG_ERR_BAD_ARG; }
+        // every parameter block at most once; speed-bias blocks of a prior must be chain neighbours (the reference's
+        // priors hold sb_0 only: estimator.cpp:836-870, :913-930)
+        int sb_lo = 1 << 30, sb_hi = -1, nsb = 0;
+        for (int b = 0; b < p->prior_nblocks; ++b) {
+            const int k = p->prior_block_kind[b], ix = (k == VG_BLK_POSE || k == VG_BLK_SPEEDBIAS) ? p->prior_block_index[b] : 0;
+            for (int b2 = 0; b2 < b; ++b2) {
+                const int k2 = p->prior_block_kind[b2];
+                const int ix2 = (k2 == VG_BLK_POSE || k2 == VG_BLK_SPEEDBIAS) ? p->prior_block_index[b2] : 0;
+                if (k == k2 && ix == ix2) { h->err = "prior lists a parameter block twice"; return VG_ERR_BAD_ARG; }
+            }
+            if (k == VG_BLK_SPEEDBIAS) { sb_lo = std::min(sb_lo, ix); sb_hi = std::max(sb_hi, ix); ++nsb; }
+        }
+        if (nsb > 2 || (nsb == 2 && sb_hi - sb_lo != 1)) {
+            h->err = "prior couples speed-bias blocks that are not chain neighbours";
+            return VG_ERR_UNSUPPORTED;
+        }
     }
     if (p->relo_n < 0 || (p->relo_n > 0 && (!p->relo_pose || !p->relo_lm || !p->relo_xy))) { h->err = "bad relo"; return VG_ERR_BAD_ARG; }
     for (int k = 0; k < p->relo_n; ++k)
@@ -101,7 +118,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.e = p0->estimate_extrinsic ? 1 : 0;
     L.t = p0->estimate_td ? 1 : 0;
     L.Rc = 6 * L.Kp + 6 * L.e + L.t;
-    L.RcPad = up(L.Rc, 16);
+    L.RcPad = up(L.Rc + 1, 16);                  // + the augmented rhs row / column
     L.R = L.Rc + 9 * L.K;
     L.Rpad = up(L.R + 1, 8);
     L.Lcap = up(Lmax, 16);
@@ -110,32 +127,41 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.Ncap = up(std::max(Nmax, 1), 8);
     L.NBcap = up(std::max(NBmax, 1), 8);
     L.REC = 28 + 12 * L.e + 2 * L.t;
-    if (L.RcPad > 80) { h->err = "camera part wider than 80 columns"; return VG_ERR_UNSUPPORTED; }
-    // ---- LDS carve
-    const int total = 160 * 1024 / 8;
-    const int fulltri = (L.R + 1) * (L.R + 2) / 2;
-    const int camtri = L.Rc * (L.Rc + 1) / 2;
-    const int nst = up(7 * L.Kp + 9 * L.K + 8, 2);
-    L.nvec = 9;
-    int tail = 0;
-    const int sz_pmap = up(L.Ncap, 4) / 2;
-    const int sz_vec = L.nvec * L.Rpad, sz_red = 32, sz_wd = up(std::max(L.RcPad * 17 + 16, 4 * L.Ncap), 2), sz_misc = 16;
-    tail = sz_vec + sz_red + sz_wd + 2 * nst + sz_misc + sz_pmap;
-    L.l_S = 0;
-    L.l_stage = up(camtri, 2);
-    L.l_vec = total - tail;
-    L.l_red = L.l_vec + sz_vec;
-    L.l_wd = L.l_red + sz_red;
-    L.l_x = L.l_wd + sz_wd;
-    L.l_xc = L.l_x + nst;
-    L.l_misc = L.l_xc + nst;
-    L.l_pmap = L.l_misc + sz_misc;
-    L.lds_bytes = total * 8;
-    if (L.l_vec < up(fulltri, 2)) { h->err = "reduced system does not fit in 160 KB of LDS"; return VG_ERR_UNSUPPORTED; }
-    const int stage_cap = L.l_vec - L.l_stage;
-    L.chunk_cap = stage_cap / L.REC;
-    if (L.chunk_cap < 2 * BA_MAX_K || stage_cap < BA_NW * 256) { h->err = "LDS staging area too small"; return VG_ERR_UNSUPPORTED; }
-    L.Ccap = std::max(1, (L.Fcap + L.chunk_cap - 1) / (L.chunk_cap - BA_MAX_K) + 1);
+    L.nst = up(7 * L.Kp + 9 * L.K + 8, 2);
+    if (L.RcPad > 96 || L.Rc > 128) { h->err = "camera part wider than the solve kernel's tiling"; return VG_ERR_UNSUPPORTED; }
+    // ---- workgroups per window
+    L.nbf = (L.Fcap + BA_NT - 1) / BA_NT;
+    L.nbl = L.nbf + 1;
+    if (L.nbl > BA_MAX_PART) { h->err = "too many projection factors per window"; return VG_ERR_UNSUPPORTED; }
+    {
+        const int nb = L.Kp + L.e + L.t;
+        L.ntask = nb * (nb + 1) / 2;
+        const int per = BA_ACC_NT / 64;
+        L.nba = (L.ntask + (L.Lcap + 63) / 64 + per - 1) / per;
+    }
+    // ---- LDS carve of the solve kernel
+    {
+        // XC leading dimension: rows p and p+1 of an MFMA operand read must fall on different halves of the 64 banks
+        int ldc = L.RcPad;
+        if ((2 * ldc) % 64 != 32) ldc += 16;
+        L.ldc = ldc;
+        int o = 0;
+        L.l_S = o; o += up((L.Rc + 1) * (L.Rc + 2) / 2, 2);
+        L.l_XC = o; o += up(9 * L.K, 4) * ldc;
+        L.l_D = o; o += up(81 * L.K, 2);
+        L.l_E = o; o += up(81 * L.K, 2);
+        L.l_dinv = o; o += up(9 * L.K, 2);
+        L.l_vec = o; o += 9 * L.Rpad;
+        L.l_red = o; o += 32;
+        L.l_wd = o; o += up(std::max(L.RcPad * 17, 9 * L.K), 2);
+        L.l_z = o; o += up(36 * L.K, 2);
+        L.l_pmap = o; o += up(L.Ncap, 4) / 2;
+        L.lds_solve = o * 8;
+        if (L.lds_solve > 160 * 1024) { h->err = "solve kernel LDS carve exceeds 160 KB"; return VG_ERR_UNSUPPORTED; }
+        const int nimu = L.K - 1;
+        L.lds_lin = 8 * std::max(up(nimu * 225, 2) + nimu * 480, 5 * L.Ncap);
+        L.lds_pro = 8 * std::max(BA_NW * 256, L.Ncap * L.Ncap);
+    }
     // ---- int arrays
     int o = 0;
     L.io_hdr = o; o += BA_HDR_INTS;
@@ -147,9 +173,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.io_fac_oi = o; o += L.Fcap;
     L.io_fac_oj = o; o += L.Fcap;
     L.io_fac_slot = o; o += L.Fcap;
-    L.io_chunk_fbeg = o; o += L.Ccap + 8;
-    L.io_chunk_lbeg = o; o += L.Ccap + 8;
-    L.io_pair_ptr = o; o += L.Ccap * (L.Kp * L.Kp + 1);
+    L.io_pair_ptr = o; o += up(L.Kp * L.Kp + 1, 8);
     L.io_imu_valid = o; o += up(L.K, 8);
     L.io_pb_kind = o; o += L.NBcap;
     L.io_pb_idx = o; o += L.NBcap;
@@ -174,24 +198,32 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.dstride = up(o, 8);
     // ---- scratch
     o = 0;
+    L.so_ctl = o; o += C_NCTL;
+    L.so_part = o; o += BA_MAX_PART;
+    L.so_x = o; o += 2 * L.nst;
+    L.so_lam = o; o += 2 * L.Lcap;
     L.so_imuU = o; o += up((L.K - 1) * 225, 2);
-    L.so_imuJ = o; o += (L.K - 1) * 512;       // per factor: 465 lower Hessian entries + 30 gradient entries
-    L.so_imuR = o; o += up((L.K - 1) * 15, 2);
     L.so_Hp = o; o += L.Ncap * L.Ncap;
-    L.so_pr = o; o += L.Ncap;
-    L.so_prc = o; o += L.Ncap;
-    L.so_pu = o; o += L.Ncap;
-    L.so_Wt = o; o += L.RcPad * L.Lcap;
-    L.so_h = o; o += L.Lcap;
-    L.so_b = o; o += L.Lcap;
+    L.so_rec = o; o += L.Fcap * L.REC;
+    L.so_sc = o; o += L.Rpad;
     L.so_sl = o; o += L.Lcap;
-    L.so_dgl = o; o += L.Lcap;
-    L.so_gtl = o; o += L.Lcap;
-    L.so_gnl = o; o += L.Lcap;
-    L.so_ul = o; o += L.Lcap;
-    L.so_lam = o; o += L.Lcap;
-    L.so_lamc = o; o += L.Lcap;
+    L.so_dg = o; o += L.Rpad + L.Lcap;
+    L.so_gt = o; o += L.Rpad + L.Lcap;
+    L.so_gn = o; o += L.Rpad + L.Lcap;
     L.so_yl = o; o += L.Lcap;
+    L.so_lsc = o; o += L.Lcap;
+    {
+        int b = 0;
+        L.bo_Sp = b; b += up(L.Rc * (L.Rc + 1) / 2, 2);
+        L.bo_gp = b; b += L.RcPad;
+        L.bo_h = b; b += L.Lcap;
+        L.bo_b = b; b += L.Lcap;
+        L.bo_Wt = b; b += L.RcPad * L.Lcap;
+        L.bo_imuJ = b; b += (L.K - 1) * 512;       // per factor: 465 lower Hessian entries + 30 gradient entries
+        L.bo_pr = b; b += L.Ncap;
+        L.buf_stride = up(b, 8);
+    }
+    L.so_buf = o; o += 2 * L.buf_stride;
     L.sstride = up(o, 8);
     // ---- outputs
     o = 0;
@@ -268,34 +300,18 @@ static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, 
         ia[L.io_fac_i + f] = fac[f].i; ia[L.io_fac_j + f] = fac[f].j; ia[L.io_fac_lm + f] = fac[f].l;
         ia[L.io_fac_oi + f] = fac[f].oi; ia[L.io_fac_oj + f] = fac[f].oj;
     }
-    // chunks on landmark boundaries, slots inside a chunk sorted by (i, j)
-    int nchunk = 0, l0 = 0;
-    while (l0 < p->L || nchunk == 0) {
-        int l1 = l0, cnt = 0;
-        while (l1 < p->L) {
-            const int nf = ia[L.io_lm_fbeg + l1 + 1] - ia[L.io_lm_fbeg + l1];
-            if (cnt + nf > L.chunk_cap) break;
-            cnt += nf;
-            ++l1;
-        }
-        if (l1 == l0 && l0 < p->L) { h->err = "a landmark has more factors than a chunk holds"; return VG_ERR_UNSUPPORTED; }
-        if (nchunk >= L.Ccap) { h->err = "too many chunks"; return VG_ERR_UNSUPPORTED; }
-        const int fb = ia[L.io_lm_fbeg + l0], fe = ia[L.io_lm_fbeg + l1];
-        ia[L.io_chunk_fbeg + nchunk] = fb;
-        ia[L.io_chunk_lbeg + nchunk] = l0;
-        int* ptr = ia + L.io_pair_ptr + nchunk * (Kp * Kp + 1);
+    // slot table: records sorted by (anchor i, target j) pair, so that the owner of an entry of the camera system walks
+    // one contiguous slot range per pair
+    {
+        int* ptr = ia + L.io_pair_ptr;
         std::vector<int> count(Kp * Kp + 1, 0);
-        for (int f = fb; f < fe; ++f) count[fac[f].i * Kp + fac[f].j + 1]++;
+        for (int f = 0; f < F; ++f) count[fac[f].i * Kp + fac[f].j + 1]++;
         ptr[0] = 0;
         for (int k = 0; k < Kp * Kp; ++k) ptr[k + 1] = ptr[k] + count[k + 1];
         std::vector<int> cursor(ptr, ptr + Kp * Kp);
-        for (int f = fb; f < fe; ++f) ia[L.io_fac_slot + f] = cursor[fac[f].i * Kp + fac[f].j]++;
-        ++nchunk;
-        l0 = l1;
-        if (p->L == 0) break;
+        for (int f = 0; f < F; ++f) ia[L.io_fac_slot + f] = cursor[fac[f].i * Kp + fac[f].j]++;
     }
-    ia[L.io_chunk_fbeg + nchunk] = F;
-    ia[L.io_chunk_lbeg + nchunk] = p->L;
+    const int nchunk = 1;
     hdr[H_L] = p->L; hdr[H_F] = F; hdr[H_NPRIOR] = p->prior_n; hdr[H_NBLK] = p->prior_n ? p->prior_nblocks : 0;
     hdr[H_MAXIT] = p->max_iters; hdr[H_NCHUNK] = nchunk; hdr[H_MARGIN] = margin; hdr[H_STATUS] = 0;
     // state
@@ -386,6 +402,9 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     B.flops = 0.0; B.flops_marg = 0.0; B.bytes_in = 0.0; B.bytes_out = 0.0;
     B.margin.assign(nwin, VG_MARGIN_NONE);
     B.nL.assign(nwin, 0);
+    B.rounds = 0;
+    for (int w = 0; w < nwin; ++w) B.rounds = std::max(B.rounds, in[w]->max_iters);
+    B.rounds = std::max(B.rounds, 1);          // round 0 also evaluates the initial cost (max_iters = 0 windows)
     // pack: windows are independent -> a few host threads (zero-fill + pack of their own slabs)
     {
         const int nthr = std::max(1, std::min(8, nwin / 16));
@@ -463,7 +482,10 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
 extern "C" int vg_ba_batch_run_async(vg_handle* h) {
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
-    HIPCHK(h, ba_launch_solve(B.L, B.dL, B.P, h->stream));
+    {
+        const hipError_t e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream);
+        if (e != hipSuccess) { h->err = std::string("launch of ") + ba_failed_launch() + ": " + hipGetErrorString(e); return VG_ERR_HIP; }
+    }
     if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
     return VG_OK;
 }
@@ -473,7 +495,7 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
     BaBatch& B = h->ba;
     hipEvent_t e0 = h->ev0, e1 = h->ev1, e2 = h->ev2;
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    HIPCHK(h, ba_launch_solve(B.L, B.dL, B.P, h->stream));
+    HIPCHK(h, ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream));
     HIPCHK(h, hipEventRecord(e1, h->stream));
     if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
     HIPCHK(h, hipEventRecord(e2, h->stream));
@@ -498,7 +520,7 @@ extern "C" int vg_ba_batch_info(vg_handle* h, double* flops, double* bytes_in, d
     if (flops) *flops = h->ba.flops;
     if (bytes_in) *bytes_in = h->ba.bytes_in;
     if (bytes_out) *bytes_out = h->ba.bytes_out;
-    if (lds_bytes) *lds_bytes = h->ba.L.lds_bytes;
+    if (lds_bytes) *lds_bytes = h->ba.L.lds_solve;
     return VG_OK;
 }
 
@@ -532,6 +554,7 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
             if (s->inv_depth) memcpy(s->inv_depth, o + L.oo_lam, sizeof(double) * B.nL[w]);
             if (s->relo_pose && L.Kp > L.K) memcpy(s->relo_pose, o + L.oo_pose + 7 * L.K, sizeof(double) * 7);
         }
+        if (io[0] != VG_OK) worst = io[0];
         if (sum) {
             vg_ba_summary& s = sum[w];
             memset(&s, 0, sizeof(s));
@@ -546,7 +569,6 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
                 s.it_flags[k] = io[4 + k];
             }
             for (int k = 0; k < 16; ++k) s.prof[k] = o[L.oo_trace + 5 * VG_MAX_ITERS + k];
-            if (s.status != VG_OK) worst = s.status;
         }
         if (pri && pri[w]) {
             vg_ba_prior* q = pri[w];

@@ -1,36 +1,52 @@
-// ba_layout.h — device memory layout of a batch of sliding windows (shared by the host packer
-// ba_host.hip and the kernels in ba_kernels.hip).  One workgroup owns one window; every per-window
-// array lives at  base + window * stride  so a workgroup streams its own contiguous slab of HBM.
+// ba_layout.h — device memory layout of a batch of sliding windows (shared by the host packer ba_host.hip and the
+// kernels of ba_pipeline.hip / ba_marg.hip).  Every per-window array lives at  base + window * stride.
 //
-// Reduced-system column order (tangent space):
-//   [ pose_0 .. pose_{Kp-1} (6 each) | ex (6, if estimated) | td (1, if estimated) | speedbias_0 .. (9 each) ]
-//   `Rc` = width of the "camera part" touched by projection factors, R = Rc + 9K.
+// Tangent-space column order of the reduced system:
+//   camera part  [ pose_0 .. pose_{Kp-1} (6 each) | ex (6, if estimated) | td (1, if estimated) ]   Rc columns
+//   speed-bias   [ sb_0 .. sb_{K-1} (9 each) ]                                                      9K columns
+// The landmark columns (1 each) are eliminated first (Schur complement on MFMA), the speed-bias blocks next (they form
+// a block-tridiagonal chain: IMU factor k couples sb_k, sb_k+1, pose_k, pose_k+1; the prior adds sb_0), and only the
+// Rc x Rc camera part is factorised densely.
 #pragma once
 
-#define BA_NT 512                 // threads per workgroup (8 wavefronts)
+#define BA_NT 512                 // threads per workgroup of the per-window kernels (8 wavefronts)
 #define BA_NW (BA_NT / 64)
+#define BA_ACC_NT 256             // threads per workgroup of the accumulation kernel
 #define BA_MAX_K 13               // frames incl. relocalisation pose
 #define BA_IMU_STRIDE 472         // doubles per vg_imu_preint record on device
 #define BA_OBS_STRIDE 8
 #define BA_SUM_DOUBLES 8
 #define BA_HDR_INTS 16
+#define BA_MAX_PART 16            // cost partial sums per window (one per workgroup of the linearisation kernel)
 
 enum { H_L = 0, H_F, H_NPRIOR, H_NBLK, H_MAXIT, H_NCHUNK, H_MARGIN, H_STATUS };
 
+// per-window solver state that lives in HBM between the launches of one solve (doubles; integers stored exactly)
+enum {
+    C_IT = 0, C_NACC, C_NINV, C_TERM, C_STATUS, C_RADIUS, C_MU, C_MUSOLVED, C_REUSE, C_COST, C_XNORM, C_ALPHA, C_GTN2,
+    C_GNN2, C_GTGN, C_DNORM, C_MODEL, C_CUR, C_PENDING, C_DONE, C_STEPNORM, C_XNORMC, C_INITCOST, C_SCALED, C_NCTL = 32
+};
+
 struct BaLayout {
     int nwin, K, Kp, e, t;
-    int Rc, RcPad, R;
-    int Lcap, Fcap, Ocap, Ncap, NBcap, Ccap;
-    int REC, chunk_cap;
+    int Rc, RcPad, R, Rpad;        // RcPad = up(Rc + 1, 16): the rhs travels as the augmented row / column Rc
+    int Lcap, Fcap, Ocap, Ncap, NBcap;
+    int REC;                       // doubles per projection-factor record
+    int nbf, nbl, nba, ntask;      // workgroups per window: projection tiles, linearisation (nbf + 1), accumulation; owner tasks
+    int nst;                       // doubles of one state copy [pose Kp*7 | sb K*9 | ex 7 | td 1]
     // ---- int arrays (offsets in ints, per window)
     int io_hdr, io_lm_start, io_lm_fbeg, io_fac_i, io_fac_j, io_fac_lm, io_fac_oi, io_fac_oj, io_fac_slot,
-        io_chunk_fbeg, io_chunk_lbeg, io_pair_ptr, io_imu_valid, io_pb_kind, io_pb_idx, io_pb_col, io_pb_off,
-        io_pb_x0off, istride;
+        io_pair_ptr, io_imu_valid, io_pb_kind, io_pb_idx, io_pb_col, io_pb_off, io_pb_x0off, istride;
     // ---- double inputs (offsets in doubles, per window)
     int do_pose, do_sb, do_ex, do_td, do_lam, do_obs, do_imu, do_pJ0, do_pJ0t, do_pr0, do_px0, do_par, dstride;
     // ---- scratch (doubles, per window)
-    int so_imuU, so_imuJ, so_imuR, so_Hp, so_pr, so_prc, so_pu, so_Wt, so_h, so_b, so_sl, so_dgl, so_gtl, so_gnl, so_ul,
-        so_lam, so_lamc, so_yl, sstride;
+    int so_ctl, so_part, so_x, so_lam;          // control block, cost partials, 2 state copies (nst each), 2 x Lcap
+    int so_imuU, so_Hp, so_rec;                 // sqrt_info factors, J0^T J0, projection records [Fcap][REC]
+    int so_sc, so_sl, so_dg, so_gt, so_gn;      // Jacobi scaling (R / Lcap), saved Dg, gt, gn over [R | Lcap] for step reuse
+    int so_yl, so_lsc;                          // landmark step / sl/sqrt(h~)
+    int so_buf, buf_stride;                     // two linearisation buffers; offsets below are relative to a buffer
+    int bo_Sp, bo_gp, bo_h, bo_b, bo_Wt, bo_imuJ, bo_pr;
+    int sstride;
     // ---- outputs (doubles / ints per window)
     int oo_pose, oo_sb, oo_ex, oo_td, oo_lam, oo_sum, oo_trace, ostride;
     int oi_stride;                 // int outputs: [status, termination, num_iterations, num_accepted, flags[VG_MAX_ITERS]]
@@ -39,10 +55,9 @@ struct BaLayout {
     int mi_stride;                            // ints: [valid, n, m, nblocks, kind[NBcap], idx[NBcap]]
     int ms_stride;                            // marginalization scratch doubles per window
     int mcap, mg_ld, mg_posmax, mg_cs, mg_lds_bytes; // kept-dimension capacity, LDS eig leading dim, max (m+n)
-    // ---- LDS carve (offsets in doubles)
-    int l_S, l_stage, l_vec, l_red, l_wd, l_x, l_xc, l_misc, l_pmap, lds_bytes;
-    int nvec;                                 // number of R-vectors at l_vec, each Rpad long
-    int Rpad;
+    // ---- LDS carve of the solve kernel (offsets in doubles)
+    int l_S, l_XC, l_D, l_E, l_dinv, l_vec, l_red, l_wd, l_z, l_pmap, ldc, lds_solve;
+    int lds_lin, lds_pro;                     // dynamic LDS bytes of the linearisation / prologue kernels
 };
 
 struct BaPtrs {

@@ -1,0 +1,1636 @@
+// ba_pipeline.hip — sliding-window bundle adjustment on gfx950 (CDNA4) as a short pipeline of launches per
+// trust-region iteration, every launch sized to the parallelism of its phase.
+//
+// Replaces the arithmetic under Estimator::optimization() (vins_estimator/src/estimator.cpp:670-1003): factor
+// evaluation (factor/*.cpp,h), the Ceres trust-region solve configured at :803-818 (DENSE_SCHUR + DOGLEG + Jacobi
+// scaling + Cauchy loss corrector; third-party behaviour restated in oracle/ASSUMPTIONS.md) and the gauge fix of
+// double2vector() (:530-619).
+//
+//   ba_prologue_kernel   (1 workgroup / window)   IMU sqrt_info factors, J0^T J0 of the prior, solver state init
+//   per round r = 0 .. max_iters-1:
+//     ba_linearize_kernel  (tiles of 512 projection factors + 1 IMU/prior workgroup per window, whole batch in one
+//                           grid) residuals + Jacobians at the point to be judged -> loss-corrected records, IMU
+//                           Hessian blocks, prior residual, cost partials
+//     ba_accumulate_kernel (one wavefront per 6x6 block of the camera system + landmark lanes) J^T J, J^T r of the
+//                           projection factors, per-landmark h, b, W   — deterministic owner sums, no atomics
+//     ba_solve_kernel      (1 workgroup / window) accept / reject the pending candidate, then the linear algebra of
+//                           the next step: landmark Schur complement (v_mfma_f64_16x16x4), block-Thomas elimination
+//                           of the speed-bias chain, dense Cholesky of the Rc x Rc camera part in LDS, back
+//                           substitution, dogleg step, candidate state
+//   ba_linearize_kernel (cost only) + ba_final_kernel: judge the last candidate, gauge fix, outputs.
+//
+// The point evaluated in round r is the CANDIDATE of round r-1, linearised speculatively: if the solve kernel accepts
+// it (the common case) its linearisation is already there; if it rejects, the Gauss-Newton step and gradient of the
+// current point are reused exactly as DoglegStrategy does.  All solver state between launches lives in a small
+// per-window control block in HBM; every sum has a fixed order, so results are bit-reproducible.
+#include <hip/hip_runtime.h>
+#include "ba_layout.h"
+#include "ba_factors.h"
+#include "../../include/vinsgpu.h"
+
+#define NOINL __device__ __noinline__
+extern __shared__ __attribute__((aligned(16))) char bp_smem[];
+#define LDSB ((double*)bp_smem)
+typedef double double4_t __attribute__((vector_size(32)));      // v_mfma_f64_16x16x4 accumulator (4 VGPR pairs)
+
+// R-vectors of the solve kernel in LDS, columns [camera Rc | speed-bias 9K]
+enum { V_G = 0, V_SC, V_DG, V_GT, V_GN, V_U, V_Y, V_T, V_DI, V_NVEC };
+
+struct Ctx {
+    const BaLayout* Lp;      // layout lives in device memory: uniform scalar loads on demand
+    const int* hdr;
+    const int* ia;           // int arrays of this window
+    const double* di;        // double inputs
+    double* sc;              // scratch
+    int tid, lane, wave;
+    int nL, nF, nprior, nblk;
+    double focal, tr, row, gnorm;
+};
+
+DEV void ctx_init(Ctx& c, const BaLayout* Lp, const BaPtrs& P, int w) {
+    const BaLayout& L = *Lp;
+    c.Lp = Lp;
+    c.ia = P.iarr + (size_t)w * L.istride;
+    c.hdr = c.ia + L.io_hdr;
+    c.di = P.din + (size_t)w * L.dstride;
+    c.sc = P.scr + (size_t)w * L.sstride;
+    c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6;
+    c.nL = c.hdr[H_L]; c.nF = c.hdr[H_F]; c.nprior = c.hdr[H_NPRIOR]; c.nblk = c.hdr[H_NBLK];
+    c.focal = c.di[L.do_par + P_FOCAL]; c.tr = c.di[L.do_par + P_TR]; c.row = c.di[L.do_par + P_ROW];
+    c.gnorm = c.di[L.do_par + P_GNORM];
+}
+
+// deterministic workgroup-wide reductions through `red` (>= 2 * waves doubles of LDS), result uniform in every thread
+DEV double block_sum(double* red, int nw, int lane, int wave, double v) {
+    v = wave_sum_all(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    return s;
+}
+DEV void block_sum2(double* red, int nw, int lane, int wave, double& a, double& b) {
+    a = wave_sum_all(a);
+    b = wave_sum_all(b);
+    __syncthreads();
+    if (lane == 0) { red[wave] = a; red[nw + wave] = b; }
+    __syncthreads();
+    double s = 0.0, t = 0.0;
+    for (int w = 0; w < nw; ++w) { s += red[w]; t += red[nw + w]; }
+    a = s; b = t;
+}
+DEV double block_max(double* red, int nw, int lane, int wave, double v) {
+    v = wave_max_all(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = red[0];
+    for (int w = 1; w < nw; ++w) s = fmax(s, red[w]);
+    return s;
+}
+
+DEV int col_pose(const BaLayout& L, int i) { return 6 * i; }
+DEV int col_ex(const BaLayout& L) { return 6 * L.Kp; }
+DEV int col_td(const BaLayout& L) { return 6 * L.Kp + 6 * L.e; }
+DEV int col_sb(const BaLayout& L, int i) { return L.Rc + 9 * i; }
+DEV int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, j <= i
+
+// one state copy: [pose Kp*7 | sb K*9 | ex 7 | td 1]
+DEV const double* st_pose(const BaLayout& L, const double* x, int i) { return x + 7 * i; }
+DEV const double* st_sb(const BaLayout& L, const double* x, int i) { return x + 7 * L.Kp + 9 * i; }
+DEV const double* st_ex(const BaLayout& L, const double* x) { return x + 7 * L.Kp + 9 * L.K; }
+
+DEV double* lin_buf(const Ctx& c, int which) { return c.sc + c.Lp->so_buf + (size_t)which * c.Lp->buf_stride; }
+
+// ---- solver state carried between launches -----------------------------------------------------------------------
+struct Ctl {
+    int it, nacc, ninv, term, status, reuse, cur, pending, done, scaled;
+    double radius, mu, mu_solved, cost, x_norm, alpha, gtn2, gnn2, gtgn, dnorm, model, step_norm, x_norm_c, init_cost;
+};
+DEV void ctl_load(Ctl& s, const double* p) {
+    s.it = (int)p[C_IT]; s.nacc = (int)p[C_NACC]; s.ninv = (int)p[C_NINV]; s.term = (int)p[C_TERM]; s.status = (int)p[C_STATUS];
+    s.reuse = (int)p[C_REUSE]; s.cur = (int)p[C_CUR]; s.pending = (int)p[C_PENDING]; s.done = (int)p[C_DONE]; s.scaled = (int)p[C_SCALED];
+    s.radius = p[C_RADIUS]; s.mu = p[C_MU]; s.mu_solved = p[C_MUSOLVED]; s.cost = p[C_COST]; s.x_norm = p[C_XNORM];
+    s.alpha = p[C_ALPHA]; s.gtn2 = p[C_GTN2]; s.gnn2 = p[C_GNN2]; s.gtgn = p[C_GTGN]; s.dnorm = p[C_DNORM]; s.model = p[C_MODEL];
+    s.step_norm = p[C_STEPNORM]; s.x_norm_c = p[C_XNORMC]; s.init_cost = p[C_INITCOST];
+}
+DEV void ctl_store(const Ctl& s, double* p) {
+    p[C_IT] = s.it; p[C_NACC] = s.nacc; p[C_NINV] = s.ninv; p[C_TERM] = s.term; p[C_STATUS] = s.status;
+    p[C_REUSE] = s.reuse; p[C_CUR] = s.cur; p[C_PENDING] = s.pending; p[C_DONE] = s.done; p[C_SCALED] = s.scaled;
+    p[C_RADIUS] = s.radius; p[C_MU] = s.mu; p[C_MUSOLVED] = s.mu_solved; p[C_COST] = s.cost; p[C_XNORM] = s.x_norm;
+    p[C_ALPHA] = s.alpha; p[C_GTN2] = s.gtn2; p[C_GNN2] = s.gnn2; p[C_GTGN] = s.gtgn; p[C_DNORM] = s.dnorm; p[C_MODEL] = s.model;
+    p[C_STEPNORM] = s.step_norm; p[C_XNORMC] = s.x_norm_c; p[C_INITCOST] = s.init_cost;
+}
+
+// Judge the pending candidate (TrustRegionMinimizer: parameter tolerance, function tolerance, step quality; then
+// DoglegStrategy::StepAccepted / StepRejected).  Uniform: every thread computes the same from the same HBM values;
+// thread 0 writes the trace.  Returns true if the candidate became the current point.
+DEV bool judge_candidate(Ctl& s, const double* part, int nbl, const BaLayout& L, double* out, int* iout, int tid) {
+    double cs = 0.0;
+    for (int b = 0; b < nbl; ++b) cs += part[b];
+    const double cost_cand = 0.5 * cs;
+    const int slot = s.it - 1;
+    bool accepted = false;
+    int flag = 1;
+    if (s.step_norm <= 1e-8 * (s.x_norm + 1e-8)) s.term = VG_TERM_CONVERGENCE;
+    else if (fabs(s.cost - cost_cand) <= 1e-6 * s.cost) s.term = VG_TERM_CONVERGENCE;
+    else {
+        const double rho = (s.cost - cost_cand) / s.model;
+        if (rho > 1e-3) {
+            accepted = true;
+            flag = 3;
+            ++s.nacc;
+            s.cur ^= 1;
+            s.cost = cost_cand;
+            s.x_norm = s.x_norm_c;
+            if (rho < 0.25) s.radius *= 0.5;
+            if (rho > 0.75) s.radius = fmax(s.radius, 3.0 * s.dnorm);
+            s.mu = fmax(1e-8, 2.0 * s.mu / 10.0);
+            s.reuse = 0;
+        } else {
+            s.radius *= 0.5;
+            s.reuse = 1;
+        }
+    }
+    s.pending = 0;
+    if (tid == 0) {
+        out[L.oo_trace + 1 * VG_MAX_ITERS + slot] = cost_cand;
+        iout[4 + slot] = flag;
+    }
+    return accepted;
+}
+
+// ================================================================================================
+// Prologue: IMU sqrt_info = U^-1 where covariance = U U^T (U upper) — exactly
+// LLT(covariance^-1).matrixL().transpose() of imu_factor.h:64 (the Cholesky factor of the inverse is unique) without
+// forming the badly conditioned inverse; J0^T J0 of the prior; state copy 0; control block.
+// ================================================================================================
+NOINL void imu_sqrt_info(const Ctx& c) {
+    const BaLayout& L = *c.Lp;
+    double* A = LDSB + c.wave * 256;                 // 15x15 scratch per wavefront
+    const int nimu = L.K - 1;
+    const int* valid = c.ia + L.io_imu_valid;
+    for (int base = 0; base < nimu; base += BA_NW) {
+        const int f = base + c.wave;
+        const bool act = f < nimu && valid[f];
+        const double* cov = c.di + L.do_imu + f * BA_IMU_STRIDE + IM_COV;
+        if (act)
+            for (int k = c.lane; k < 225; k += 64) A[k] = cov[k];
+        __syncthreads();
+        // UL factorisation, columns from the last to the first: A = U U^T
+        for (int j = 14; j >= 0; --j) {
+            const double d = act ? sqrt(A[j * 15 + j]) : 1.0;
+            __syncthreads();
+            if (act && c.lane < j) A[c.lane * 15 + j] /= d;
+            if (act && c.lane == j) A[j * 15 + j] = d;
+            __syncthreads();
+            if (act)
+                for (int k = c.lane; k < j * j; k += 64) {
+                    const int i = k / j, kk = k % j;
+                    if (kk >= i) A[i * 15 + kk] -= A[i * 15 + j] * A[kk * 15 + j];
+                }
+            __syncthreads();
+        }
+        // X = U^-1 (upper): lane = column j, back-substitute upward
+        double* Uo = c.sc + L.so_imuU + f * 225;
+        if (act && c.lane < 15) {
+            const int j = c.lane;
+            double x[15];
+#pragma unroll
+            for (int i = 14; i >= 0; --i) {
+                double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 14; k > i; --k) s -= (k <= j) ? A[i * 15 + k] * x[k] : 0.0;
+                x[i] = (i <= j) ? s / A[i * 15 + i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 15; ++i) Uo[i * 15 + j] = x[i];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    ctx_init(c, Lp, P, blockIdx.x);
+    double* x = c.sc + L.so_x;
+    for (int k = c.tid; k < 7 * L.Kp; k += BA_NT) x[k] = c.di[L.do_pose + k];
+    for (int k = c.tid; k < 9 * L.K; k += BA_NT) x[7 * L.Kp + k] = c.di[L.do_sb + k];
+    if (c.tid < 7) x[7 * L.Kp + 9 * L.K + c.tid] = c.di[L.do_ex + c.tid];
+    if (c.tid == 7) x[7 * L.Kp + 9 * L.K + 7] = c.di[L.do_td];
+    for (int k = c.tid; k < c.nL; k += BA_NT) c.sc[L.so_lam + k] = c.di[L.do_lam + k];
+    if (c.tid < C_NCTL) {
+        double v = 0.0;
+        if (c.tid == C_RADIUS) v = 1e4;
+        if (c.tid == C_MU || c.tid == C_MUSOLVED) v = 1e-8;
+        c.sc[L.so_ctl + c.tid] = v;
+    }
+    imu_sqrt_info(c);
+    if (c.nprior) {
+        // J0^T J0 once per solve, J0 staged in LDS
+        const int n = c.nprior;
+        const double* J0 = c.di + L.do_pJ0;
+        double* Hp = c.sc + L.so_Hp;
+        double* J0s = LDSB;                      // n x n, row stride n
+        __syncthreads();
+        for (int wk = c.tid; wk < n * n; wk += BA_NT) J0s[wk] = J0[(wk / n) * L.Ncap + wk % n];
+        __syncthreads();
+        for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
+            int a, bb;
+            tri_decode(wk, a, bb);
+            double s0 = 0.0, s1 = 0.0;
+            int r = 0;
+            for (; r + 1 < n; r += 2) { s0 += J0s[r * n + a] * J0s[r * n + bb]; s1 += J0s[(r + 1) * n + a] * J0s[(r + 1) * n + bb]; }
+            if (r < n) s0 += J0s[r * n + a] * J0s[r * n + bb];
+            Hp[a * L.Ncap + bb] = s0 + s1;
+        }
+    }
+}
+
+// ================================================================================================
+// Linearisation kernel
+// ================================================================================================
+// All IMU factors at state x, one (half-)wavefront per factor: lanes 0..29 = Jacobian columns, lane 30 = the residual
+// "column"; every lane evaluates the (cheap) factor context, weights its column with the upper-triangular U = sqrt_info
+// read from an LDS copy and parks it in LDS; the workgroup then forms every factor's 30x30 Hessian block and J^T r.
+//   imuJ [f][512]: 465 lower Hessian entries + 30 gradient entries.   JAC = false: residual only.
+// Returns this thread's share of sum r^2.
+template <bool JAC>
+NOINL double imu_pass(const Ctx& c, const double* x, double* imuJ) {
+    const BaLayout& L = *c.Lp;
+    const int nimu = L.K - 1;
+    const int* valid = c.ia + L.io_imu_valid;
+    double* Us = LDSB;                                      // [nimu][225]
+    double* panels = Us + ((nimu * 225 + 1) & ~1);          // [nimu][15][32]
+    double cost = 0.0;
+    for (int k = c.tid; k < nimu * 225; k += BA_NT) Us[k] = c.sc[L.so_imuU + k];
+    __syncthreads();
+    const int per = nimu > BA_NW ? 2 : 1;
+    const int half = c.lane >> 5, hl = c.lane & 31;
+    const int f = c.wave * per + half;
+    const bool act = f < nimu && half < per && valid[f];
+    if (act) {
+        const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
+        const double* U = Us + f * 225;
+        double* panel = panels + f * 480;
+        ImuCtx ic;
+        imu_ctx<JAC>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
+        double raw[15];
+        if (JAC && hl < 30) imu_raw_col(ic, pre, hl, raw);
+        else {
+#pragma unroll
+            for (int q = 0; q < 15; ++q) raw[q] = ic.r[q];
+        }
+        if (hl <= 30) {
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) if (k >= r) s += U[r * 15 + k] * raw[k];
+                if (JAC) panel[r * 32 + hl] = s;
+                if (hl == 30) cost += s * s;
+            }
+        }
+    }
+    __syncthreads();
+    if (JAC) {
+        for (int w = c.tid; w < nimu * 495; w += BA_NT) {
+            const int ff = w / 495, e = w - 495 * ff;
+            if (!valid[ff]) continue;
+            const double* panel = panels + ff * 480;
+            int a, b;
+            if (e < 465) tri_decode(e, a, b);
+            else { a = e - 465; b = 30; }
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 15; ++r) s += panel[r * 32 + a] * panel[r * 32 + b];
+            imuJ[ff * 512 + e] = s;
+        }
+    }
+    __syncthreads();
+    return cost;
+}
+
+// Prior (MarginalizationFactor::Evaluate, marginalization_factor.cpp:333-381): dx per kept block, r = r0 + J0 dx.
+DEV const double* state_block(const BaLayout& L, const double* x, int kind, int idx) {
+    if (kind == VG_BLK_POSE) return st_pose(L, x, idx);
+    if (kind == VG_BLK_SPEEDBIAS) return st_sb(L, x, idx);
+    if (kind == VG_BLK_EXPOSE) return st_ex(L, x);
+    return st_ex(L, x) + 7;     // td
+}
+// LDS use: dx [Ncap] + part [4 Ncap] at `lds`.  Writes r to pr (global).  Returns this thread's share of sum r^2.
+NOINL double prior_pass(const Ctx& c, const double* x, double* pr, double* lds) {
+    const BaLayout& L = *c.Lp;
+    if (c.nprior == 0) return 0.0;
+    double* dx = lds;
+    double* part = lds + L.Ncap;
+    const int* kind = c.ia + L.io_pb_kind;
+    const int* idx = c.ia + L.io_pb_idx;
+    const int* off = c.ia + L.io_pb_off;
+    const int* x0off = c.ia + L.io_pb_x0off;
+    __syncthreads();
+    for (int b = c.tid; b < c.nblk; b += BA_NT) {
+        const double* xb = state_block(L, x, kind[b], idx[b]);
+        const double* x0 = c.di + L.do_px0 + x0off[b];
+        double* d = dx + off[b];
+        if (kind[b] == VG_BLK_SPEEDBIAS) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) d[k] = xb[k] - x0[k];
+        } else if (kind[b] == VG_BLK_TD) {
+            d[0] = xb[0] - x0[0];
+        } else {
+            d[0] = xb[0] - x0[0]; d[1] = xb[1] - x0[1]; d[2] = xb[2] - x0[2];
+            double qi[4], dq[4];
+            q_inv(x0 + 3, qi);
+            q_mul(qi, xb + 3, dq);
+            const double sgn = (dq[3] >= 0) ? 2.0 : -2.0;
+            d[3] = sgn * dq[0]; d[4] = sgn * dq[1]; d[5] = sgn * dq[2];
+        }
+    }
+    __syncthreads();
+    const int n = c.nprior;
+    const double* J0t = c.di + L.do_pJ0t;     // J0t[c*Ncap + r] = J0[r][c]  (coalesced over r)
+    const double* r0 = c.di + L.do_pr0;
+    double cost = 0.0;
+    // r = r0 + J0 dx, the n-term dot product of every row split over 4 threads (host guarantees 4 Ncap <= BA_NT)
+    for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
+        const int r = w % L.Ncap, q = w / L.Ncap;
+        double s = 0.0;
+        if (r < n)
+            for (int k = q; k < n; k += 4) s += J0t[k * L.Ncap + r] * dx[k];
+        part[w] = s;
+    }
+    __syncthreads();
+    for (int r = c.tid; r < n; r += BA_NT) {
+        const double s = r0[r] + ((part[r] + part[L.Ncap + r]) + (part[2 * L.Ncap + r] + part[3 * L.Ncap + r]));
+        pr[r] = s;
+        cost += s * s;
+    }
+    return cost;
+}
+
+struct ProjIn {
+    const double *pi, *pj, *oi, *oj;
+    double lam;
+    int i, j, l;
+};
+DEV void proj_fetch(const Ctx& c, int f, const double* x, const double* lam, ProjIn& p) {
+    const BaLayout& L = *c.Lp;
+    p.i = c.ia[L.io_fac_i + f];
+    p.j = c.ia[L.io_fac_j + f];
+    p.l = c.ia[L.io_fac_lm + f];
+    p.pi = st_pose(L, x, p.i);
+    p.pj = st_pose(L, x, p.j);
+    p.oi = c.di + L.do_obs + c.ia[L.io_fac_oi + f] * BA_OBS_STRIDE;
+    p.oj = c.di + L.do_obs + c.ia[L.io_fac_oj + f] * BA_OBS_STRIDE;
+    p.lam = lam[p.l];
+}
+DEV void proj_jac(const Ctx& c, const ProjIn& p, const double* ex, double* r, double* Ji, double* Jj, double* Jex,
+                  double* Jl, double* Jtd) {
+    const BaLayout& L = *c.Lp;
+    if (L.t) {
+        if (L.e) proj_eval<true, true, true>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, ex[7], c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+        else proj_eval<true, true, false>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, ex[7], c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+    } else {
+        if (L.e) proj_eval<false, true, true>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+        else proj_eval<false, true, false>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+    }
+}
+
+// One projection factor -> loss-corrected record (CauchyLoss(1.0): rho = log(1+s), residual and Jacobian * sqrt(rho'),
+// rho'' < 0 branch of corrector.cc).  Record (REC doubles): [0..11] Ji as (row0,row1) pairs per column | [12..23] Jj |
+// [24,25] Jl | [26,27] r | [28..39] Jex | [40,41] Jtd.   Returns rho(s).
+NOINL double proj_linearize(const Ctx& c, int f, const double* x, const double* lam, double* recs) {
+    const BaLayout& L = *c.Lp;
+    const double* ex = st_ex(L, x);
+    ProjIn p;
+    proj_fetch(c, f, x, lam, p);
+    double r[2], Ji[12], Jj[12], Jex[12], Jl[2], Jtd[2];
+    proj_jac(c, p, ex, r, Ji, Jj, Jex, Jl, Jtd);
+    const double s = r[0] * r[0] + r[1] * r[1];
+    const double sq = sqrt(1.0 / (1.0 + s));
+    double* rec = recs + (size_t)c.ia[L.io_fac_slot + f] * L.REC;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        rec[2 * k] = sq * Ji[k]; rec[2 * k + 1] = sq * Ji[6 + k];
+        rec[12 + 2 * k] = sq * Jj[k]; rec[12 + 2 * k + 1] = sq * Jj[6 + k];
+    }
+    rec[24] = sq * Jl[0]; rec[25] = sq * Jl[1];
+    rec[26] = sq * r[0]; rec[27] = sq * r[1];
+    if (L.e) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { rec[28 + 2 * k] = sq * Jex[k]; rec[28 + 2 * k + 1] = sq * Jex[6 + k]; }
+    }
+    if (L.t) { rec[28 + 12 * L.e] = sq * Jtd[0]; rec[29 + 12 * L.e] = sq * Jtd[1]; }
+    return log1p(s);
+}
+NOINL double proj_cost(const Ctx& c, int f, const double* x, const double* lam) {
+    const BaLayout& L = *c.Lp;
+    const double* ex = st_ex(L, x);
+    ProjIn p;
+    proj_fetch(c, f, x, lam, p);
+    double r[2];
+    if (L.t) proj_eval<true, false, false>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, ex[7], c.focal, c.tr, c.row, r, 0, 0, 0, 0, 0);
+    else proj_eval<false, false, false>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, 0, 0, 0, 0, 0);
+    return log1p(r[0] * r[0] + r[1] * r[1]);
+}
+
+// grid (nbl, nwin): workgroups 0 .. nbf-1 = tiles of BA_NT projection factors, workgroup nbf = IMU factors + prior.
+// cost_only != 0: residuals only (the last candidate of a solve).
+extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    ctx_init(c, Lp, P, blockIdx.y);
+    const double* ctl = c.sc + L.so_ctl;
+    if (ctl[C_DONE] != 0.0) return;
+    const int which = ((int)ctl[C_CUR]) ^ (ctl[C_PENDING] != 0.0 ? 1 : 0);      // the point to evaluate: candidate if one is pending
+    const double* x = c.sc + L.so_x + which * L.nst;
+    const double* lam = c.sc + L.so_lam + which * L.Lcap;
+    double* buf = lin_buf(c, which);
+    const int b = blockIdx.x;
+    __shared__ double red[2 * BA_NW];
+    double share = 0.0;
+    if (b < L.nbf) {
+        const int f = b * BA_NT + c.tid;
+        if (f < c.nF) share = cost_only ? proj_cost(c, f, x, lam) : proj_linearize(c, f, x, lam, c.sc + L.so_rec);
+    } else {
+        const int nimu = L.K - 1;
+        if (cost_only) share = imu_pass<false>(c, x, buf + L.bo_imuJ);
+        else share = imu_pass<true>(c, x, buf + L.bo_imuJ);
+        share += prior_pass(c, x, buf + L.bo_pr, LDSB);
+    }
+    const double tot = block_sum(red, BA_NW, c.lane, c.wave, share);
+    if (c.tid == 0) c.sc[L.so_part + b] = tot;
+}
+
+// ================================================================================================
+// Accumulation kernel: J^T J / J^T r of the projection factors from their records.
+// ================================================================================================
+// sum over slots [b,e) of  rec[offA..+1] . rec[offB..+1]
+DEV double seg_dot(const double* recs, int REC, int b, int e, int offA, int offB) {
+    double acc = 0.0;
+    for (int s = b; s < e; ++s) {
+        const double2 a2 = *(const double2*)(recs + (size_t)s * REC + offA);
+        const double2 b2 = *(const double2*)(recs + (size_t)s * REC + offB);
+        acc += a2.x * b2.x + a2.y * b2.y;
+    }
+    return acc;
+}
+
+// Owner task = one (<=6)x(<=6) block of the camera part of S: lane = entry (p,q); lanes 36..41 of diagonal tasks own the
+// gradient.  The slot table is sorted by (anchor, target) pair, so an entry that involves pose j only visits the factors
+// with that pair: fixed summation order, no atomics.
+DEV void owner_task(const Ctx& c, int task, int lane, const double* recs, double* Sp, double* gp) {
+    const BaLayout& L = *c.Lp;
+    const int Kp = L.Kp, REC = L.REC;
+    const int* ptr = c.ia + L.io_pair_ptr;
+    const int offEx = 28, offTd = 28 + 12 * L.e;
+    const int nslots = ptr[Kp * Kp];
+    int br, bc;
+    tri_decode(task, br, bc);
+    const int kr = br < Kp ? 0 : (br == Kp && L.e ? 1 : 2);     // 0 pose, 1 ex, 2 td
+    const int kc = bc < Kp ? 0 : (bc == Kp && L.e ? 1 : 2);
+    const int dr = kr == 2 ? 1 : 6, dc = kc == 2 ? 1 : 6;
+    const int rowbase = kr == 0 ? 6 * br : (kr == 1 ? col_ex(L) : col_td(L));
+    const int colbase = kc == 0 ? 6 * bc : (kc == 1 ? col_ex(L) : col_td(L));
+    const bool diag = br == bc;
+    if (kr == 0 && kc == 0 && diag) {
+        // diagonal pose block: visits every factor anchored at or targeting frame a (~10x the visits of an off-diagonal
+        // block): its 21 lower entries + 6 gradient entries are spread over TWO lane segments (0-26 / 27-53) that each
+        // take half of every slot range; fixed split -> deterministic
+        const int a = br;
+        const int seg = lane >= 27 ? 1 : 0, e = lane - 27 * seg;
+        const bool on = lane < 54;
+        const bool isg2 = e >= 21;
+        int p2 = 0, q2 = 0;
+        if (!isg2) tri_decode(e, p2, q2); else p2 = e - 21;
+        double part = 0.0;
+        if (on) {
+            const int oB_i = isg2 ? 26 : 2 * q2, oB_j = isg2 ? 26 : 12 + 2 * q2;
+            {
+                const int s0 = ptr[a * Kp], s1 = ptr[(a + 1) * Kp], mid = (s0 + s1) >> 1;
+                part += seg_dot(recs, REC, seg ? mid : s0, seg ? s1 : mid, 2 * p2, oB_i);
+            }
+            for (int a2 = 0; a2 < a; ++a2) {
+                const int s0 = ptr[a2 * Kp + a], s1 = ptr[a2 * Kp + a + 1], mid = (s0 + s1) >> 1;
+                part += seg_dot(recs, REC, seg ? mid : s0, seg ? s1 : mid, 12 + 2 * p2, oB_j);
+            }
+        }
+        const double other = __shfl_down(part, 27, 64);
+        if (lane < 27) {
+            const double tot = part + other;
+            if (isg2) gp[rowbase + p2] = tot;
+            else Sp[tri(rowbase + p2, colbase + q2)] = tot;
+        }
+        return;
+    }
+    const bool isg = diag && lane >= 36 && lane < 36 + dr;
+    const int p = isg ? lane - 36 : lane / 6, q = isg ? 0 : lane % 6;
+    const bool act = isg || (lane < 36 && p < dr && q < dc && (!diag || q <= p));
+    if (!act) return;
+    double acc = 0.0;
+    if (kr == 0 && kc == 0) {
+        // row block br = target j, column block bc = anchor i
+        acc += seg_dot(recs, REC, ptr[bc * Kp + br], ptr[bc * Kp + br + 1], 12 + 2 * p, 2 * q);
+    } else {
+        const int oA = (kr == 1 ? offEx : offTd) + 2 * p;
+        if (kc == 0) {
+            const int a = bc;
+            acc += seg_dot(recs, REC, ptr[a * Kp], ptr[(a + 1) * Kp], oA, 2 * q);
+            for (int a2 = 0; a2 < a; ++a2)
+                acc += seg_dot(recs, REC, ptr[a2 * Kp + a], ptr[a2 * Kp + a + 1], oA, 12 + 2 * q);
+        } else {
+            const int oB = isg ? 26 : (kc == 1 ? offEx : offTd) + 2 * q;
+            acc += seg_dot(recs, REC, 0, nslots, oA, oB);
+        }
+    }
+    if (isg) gp[rowbase + p] = acc;
+    else Sp[tri(rowbase + p, colbase + q)] = acc;
+}
+
+// per-landmark sums: h = sum Jl.Jl, b = sum Jl.r, W column -> Wt[col][l] (landmark index fastest: coalesced stores)
+DEV void landmark_task(const Ctx& c, int l, const double* recs, double* buf) {
+    const BaLayout& L = *c.Lp;
+    const int REC = L.REC;
+    double* Wt = buf + L.bo_Wt;
+    for (int row = 0; row < L.RcPad; ++row) Wt[(size_t)row * L.Lcap + l] = 0.0;
+    if (l >= c.nL) return;
+    const int fb = c.ia[L.io_lm_fbeg + l], fe = c.ia[L.io_lm_fbeg + l + 1];
+    double h = 0.0, b = 0.0, wi[6] = {0, 0, 0, 0, 0, 0}, wex[6] = {0, 0, 0, 0, 0, 0}, wtd = 0.0;
+    int anchor = -1;
+    for (int f = fb; f < fe; ++f) {
+        const double* rec = recs + (size_t)c.ia[L.io_fac_slot + f] * REC;
+        const double l0 = rec[24], l1 = rec[25];
+        h += l0 * l0 + l1 * l1;
+        b += l0 * rec[26] + l1 * rec[27];
+        anchor = c.ia[L.io_fac_i + f];
+        const int j = c.ia[L.io_fac_j + f];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            wi[k] += rec[2 * k] * l0 + rec[2 * k + 1] * l1;
+            Wt[(size_t)(col_pose(L, j) + k) * L.Lcap + l] = rec[12 + 2 * k] * l0 + rec[12 + 2 * k + 1] * l1;
+        }
+        if (L.e) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wex[k] += rec[28 + 2 * k] * l0 + rec[28 + 2 * k + 1] * l1;
+        }
+        if (L.t) wtd += rec[28 + 12 * L.e] * l0 + rec[29 + 12 * L.e] * l1;
+    }
+    if (anchor >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Wt[(size_t)(col_pose(L, anchor) + k) * L.Lcap + l] = wi[k];
+        if (L.e) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Wt[(size_t)(col_ex(L) + k) * L.Lcap + l] = wex[k];
+        }
+        if (L.t) Wt[(size_t)col_td(L) * L.Lcap + l] = wtd;
+    }
+    buf[L.bo_h + l] = h;
+    buf[L.bo_b + l] = b;
+}
+
+// grid (nba, nwin), BA_ACC_NT threads: wavefront tasks 0 .. ntask-1 = owner blocks, then 64 landmarks per wavefront
+extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    ctx_init(c, Lp, P, blockIdx.y);
+    const double* ctl = c.sc + L.so_ctl;
+    if (ctl[C_DONE] != 0.0) return;
+    const int which = ((int)ctl[C_CUR]) ^ (ctl[C_PENDING] != 0.0 ? 1 : 0);
+    double* buf = lin_buf(c, which);
+    const double* recs = c.sc + L.so_rec;
+    const int g = blockIdx.x * (BA_ACC_NT / 64) + c.wave;
+    if (g < L.ntask) owner_task(c, g, c.lane, recs, buf + L.bo_Sp, buf + L.bo_gp);
+    else {
+        const int l = (g - L.ntask) * 64 + c.lane;
+        if (l < L.Lcap) landmark_task(c, l, recs, buf);
+    }
+}
+
+// ================================================================================================
+// Solve kernel
+// ================================================================================================
+struct SolveLds {
+    double *S, *XC, *D, *E, *dinv, *vec, *red, *wd, *z;
+    int* pmap;
+    int ldc;
+};
+DEV void lds_carve(const BaLayout& L, SolveLds& m) {
+    m.S = LDSB + L.l_S; m.XC = LDSB + L.l_XC; m.D = LDSB + L.l_D; m.E = LDSB + L.l_E; m.dinv = LDSB + L.l_dinv;
+    m.vec = LDSB + L.l_vec; m.red = LDSB + L.l_red; m.wd = LDSB + L.l_wd; m.z = LDSB + L.l_z;
+    m.pmap = (int*)(LDSB + L.l_pmap);
+    m.ldc = L.ldc;
+}
+
+// local column (0..29) of IMU factor f -> reduced column
+DEV int imu_col(const BaLayout& L, int f, int lc) {
+    if (lc < 6) return col_pose(L, f) + lc;
+    if (lc < 15) return col_sb(L, f) + lc - 6;
+    if (lc < 21) return col_pose(L, f + 1) + lc - 15;
+    return col_sb(L, f + 1) + lc - 21;
+}
+// add v to the Hessian entry (ca, cb) of the reduced system, ca != cb or ca == cb, wherever that entry is stored:
+//   camera x camera -> packed S;  sb_k x sb_k -> D_k (full 9x9, both triangles);  sb_k x sb_k-1 -> E_k;
+//   sb_k x camera -> XC row 9k+r (the coupling block that the chain elimination turns into X_k)
+DEV void hess_add(const BaLayout& L, const SolveLds& m, int ca, int cb, double v) {
+    if (ca < cb) { const int t = ca; ca = cb; cb = t; }
+    const int Rc = L.Rc;
+    if (ca < Rc) { m.S[tri(ca, cb)] += v; return; }
+    const int ka = (ca - Rc) / 9, ra = (ca - Rc) - 9 * ka;
+    if (cb < Rc) { m.XC[(9 * ka + ra) * m.ldc + cb] += v; return; }
+    const int kb = (cb - Rc) / 9, rb = (cb - Rc) - 9 * kb;
+    if (ka == kb) {
+        m.D[81 * ka + 9 * ra + rb] += v;
+        if (ra != rb) m.D[81 * ka + 9 * rb + ra] += v;
+    } else {
+        m.E[81 * ka + 9 * ra + rb] += v;          // ka == kb + 1 (the host rejects priors coupling non-adjacent speed-bias blocks)
+    }
+}
+
+// Unscaled Gauss-Newton system of the current point in LDS: S (camera, packed lower), g, chain blocks D, E, XC.
+NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf) {
+    const BaLayout& L = *c.Lp;
+    const int Rc = L.Rc, R = L.R, K = L.K;
+    const int camtri = Rc * (Rc + 1) / 2;
+    double* g = m.vec + V_G * L.Rpad;
+    __syncthreads();
+    for (int k = c.tid; k < camtri; k += BA_NT) m.S[k] = buf[L.bo_Sp + k];
+    for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? buf[L.bo_gp + k] : 0.0;
+    const int nxc = ((9 * K + 3) & ~3) * m.ldc;
+    for (int k = c.tid; k < nxc; k += BA_NT) m.XC[k] = 0.0;
+    for (int k = c.tid; k < 81 * K; k += BA_NT) { m.D[k] = 0.0; m.E[k] = 0.0; }
+    __syncthreads();
+    // ---- IMU Hessian blocks: factors k and k+1 share the blocks of frame k+1, so even and odd factors are added in two
+    //      rounds (inside a round every entry has exactly one writer)
+    {
+        const int nimu = K - 1;
+        const int* valid = c.ia + L.io_imu_valid;
+        const double* imuJ = buf + L.bo_imuJ;
+        for (int par = 0; par < 2; ++par) {
+            const int nf = (nimu - par + 1) / 2;
+            for (int w = c.tid; w < nf * 512; w += BA_NT) {
+                const int f = 2 * (w >> 9) + par, e = w & 511;
+                if (e >= 495 || !valid[f]) continue;
+                const double v = imuJ[f * 512 + e];
+                if (e < 465) {
+                    int a, b;
+                    tri_decode(e, a, b);
+                    hess_add(L, m, imu_col(L, f, a), imu_col(L, f, b), v);
+                } else {
+                    g[imu_col(L, f, e - 465)] += v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- prior: H += J0^T J0 (precomputed Hp), g += J0^T r   (pmap: prior column -> reduced column or -1)
+    if (c.nprior) {
+        const int n = c.nprior;
+        const double* Hp = c.sc + L.so_Hp;
+        const double* J0 = c.di + L.do_pJ0;       // row-major: J0[r*Ncap + c] coalesced over c
+        const double* pr = buf + L.bo_pr;
+        for (int w = c.tid; w < n * (n + 1) / 2 + n; w += BA_NT) {
+            const bool isg = w >= n * (n + 1) / 2;
+            if (isg) {
+                const int a = w - n * (n + 1) / 2;
+                const int ca = m.pmap[a];
+                if (ca >= 0) {
+                    double s0 = 0.0, s1 = 0.0;
+                    int r = 0;
+                    for (; r + 1 < n; r += 2) { s0 += J0[r * L.Ncap + a] * pr[r]; s1 += J0[(r + 1) * L.Ncap + a] * pr[r + 1]; }
+                    if (r < n) s0 += J0[r * L.Ncap + a] * pr[r];
+                    g[ca] += s0 + s1;
+                }
+            } else {
+                int a, b;
+                tri_decode(w, a, b);
+                const int ca = m.pmap[a], cb = m.pmap[b];
+                if (ca >= 0 && cb >= 0) hess_add(L, m, ca, cb, Hp[a * L.Ncap + b]);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// diagonal entry k of the (unscaled) Hessian as stored by assemble()
+DEV double hess_diag(const BaLayout& L, const SolveLds& m, int k) {
+    if (k < L.Rc) return m.S[tri(k, k)];
+    const int kk = (k - L.Rc) / 9, r = (k - L.Rc) - 9 * kk;
+    return m.D[81 * kk + 10 * r];
+}
+
+// H <- diag(sc) H diag(sc) + mu*Dg^2 on every stored block; rhs (scaled gradient) into the augmented row Rc of S and
+// column Rc of XC.  Also returns this thread's share of  t^T H~ t  over the reduced block (H~ = scaled, UN-damped
+// Hessian, t = V_T = gt / Dg): the Cauchy-point denominator |J~ t|^2 of DoglegStrategy::ComputeCauchyPoint without a
+// second pass over the factors.
+NOINL double build_scaled(const Ctx& c, const SolveLds& m, double mu) {
+    const BaLayout& L = *c.Lp;
+    const double* g = m.vec + V_G * L.Rpad;
+    const double* sc = m.vec + V_SC * L.Rpad;
+    const double* dg = m.vec + V_DG * L.Rpad;
+    const double* tv = m.vec + V_T * L.Rpad;
+    const int Rc = L.Rc, K = L.K, ldc = m.ldc;
+    const int n = Rc * (Rc + 1) / 2;
+    double q = 0.0;
+    for (int w = c.tid; w < n; w += BA_NT) {
+        int a, b;
+        tri_decode(w, a, b);
+        double v = m.S[w] * sc[a] * sc[b];
+        q += v * tv[a] * tv[b] * (a == b ? 1.0 : 2.0);
+        if (a == b) v += mu * dg[a] * dg[a];
+        m.S[w] = v;
+    }
+    for (int k = c.tid; k < Rc; k += BA_NT) m.S[tri(Rc, k)] = sc[k] * g[k];
+    if (c.tid == 0) m.S[tri(Rc, Rc)] = 0.0;
+    for (int w = c.tid; w < 81 * K; w += BA_NT) {
+        const int k = w / 81, e = w - 81 * k, r = e / 9, cc = e - 9 * r;
+        const int ca = Rc + 9 * k + r, cb = Rc + 9 * k + cc;
+        double v = m.D[w] * sc[ca] * sc[cb];
+        q += v * tv[ca] * tv[cb];
+        if (r == cc) v += mu * dg[ca] * dg[ca];
+        m.D[w] = v;
+        if (k > 0) {
+            const int cp = Rc + 9 * (k - 1) + cc;
+            const double ve = m.E[w] * sc[ca] * sc[cp];
+            q += 2.0 * ve * tv[ca] * tv[cp];
+            m.E[w] = ve;
+        }
+    }
+    for (int w = c.tid; w < 9 * K * (Rc + 1); w += BA_NT) {
+        const int row = w / (Rc + 1), col = w - row * (Rc + 1);
+        const int ca = Rc + row;
+        if (col < Rc) {
+            const double v = m.XC[row * ldc + col] * sc[ca] * sc[col];
+            q += 2.0 * v * tv[ca] * tv[col];
+            m.XC[row * ldc + col] = v;
+        } else {
+            m.XC[row * ldc + Rc] = sc[ca] * g[ca];
+        }
+    }
+    return q;
+}
+
+DEV double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+// 1/sqrt(x): hardware seed + two Newton steps (full double precision, ~10 dependent ops)
+DEV double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
+
+// Block-Thomas elimination of the speed-bias chain, last block first.  Step k:
+//   (A) wavefront 0: D_k -= Xe_{k+1}^T Xe_{k+1}, then the 9x9 Cholesky D_k = L L^T in registers (lane = row, v_readlane
+//       pivots), L (lower) and 1/L_rr back to LDS;  other wavefronts: [C_k | g_k] -= Xe_{k+1}^T [Xc_{k+1} | xg_{k+1}]
+//   (B) thread per column of [C_k | g_k | E_k]:  X = L^-1 column   (forward substitution, L broadcast from LDS)
+// Afterwards XC holds X = L^-1 [C | g] for every block (rows 9k..9k+8), E holds Xe_k = L_k^-1 E_k, D holds L_k.
+// The camera system gets its  S -= Xc^T Xc  together with the landmark Schur complement in schur_mfma().
+// Returns false (uniform) on a non-positive pivot.
+NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
+    const BaLayout& L = *c.Lp;
+    const int K = L.K, Rc = L.Rc, ldc = m.ldc;
+    int* flag = (int*)(m.red + 24);
+    if (c.tid == 0) *flag = 1;
+    __syncthreads();
+    for (int k = K - 1; k >= 0; --k) {
+        double* Dk = m.D + 81 * k;
+        const bool upd = k + 1 < K;
+        const double* Xe = m.E + 81 * (k + 1);             // rows p (sb_{k+1}), cols r (sb_k)
+        if (c.wave == 0) {
+            if (upd) {
+                for (int e = c.lane; e < 81; e += 64) {
+                    const int r = e / 9, cc = e - 9 * r;
+                    double s = 0.0;
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) s += Xe[9 * p + r] * Xe[9 * p + cc];
+                    Dk[e] -= s;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // Cholesky: lane i < 9 holds row i
+            double a[9];
+            const int i = c.lane < 9 ? c.lane : 8;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) a[q] = (c.lane < 9 && q <= i) ? Dk[9 * i + q] : 0.0;
+            bool good = true;
+#pragma unroll
+            for (int jj = 0; jj < 9; ++jj) {
+                const double piv = readlane_d(a[jj], jj);
+                if (!(piv > 0.0) || !(piv < 1e300)) good = false;
+                const double dinv = rsqrt_nr(piv);
+                const double l = a[jj] * dinv;
+                a[jj] = l;
+                if (c.lane == 0) m.dinv[9 * k + jj] = dinv;
+#pragma unroll
+                for (int q = jj + 1; q < 9; ++q) {
+                    const double lq = readlane_d(l, q);
+                    a[q] -= l * lq;
+                }
+            }
+            if (c.lane < 9) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) if (q <= i) Dk[9 * i + q] = a[q];
+            }
+            if (!good && c.lane == 0) *flag = 0;
+        } else if (upd) {
+            const double* Xn = m.XC + 9 * (k + 1) * ldc;
+            double* Ck = m.XC + 9 * k * ldc;
+            for (int w = c.tid - 64; w < 9 * (Rc + 1); w += BA_NT - 64) {
+                const int r = w / (Rc + 1), j = w - r * (Rc + 1);
+                double s = 0.0;
+#pragma unroll
+                for (int p = 0; p < 9; ++p) s += Xe[9 * p + r] * Xn[p * ldc + j];
+                Ck[r * ldc + j] -= s;
+            }
+        }
+        __syncthreads();
+        if (*flag == 0) break;
+        // ---- (B) columns: Rc + 1 of XC_k, 9 of E_k (k > 0)
+        {
+            const int ncol = Rc + 1 + (k > 0 ? 9 : 0);
+            if (c.tid < ncol) {
+                double* col;
+                int stride;
+                if (c.tid <= Rc) { col = m.XC + 9 * k * ldc + c.tid; stride = ldc; }
+                else { col = m.E + 81 * k + (c.tid - Rc - 1); stride = 9; }
+                double x[9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) x[r] = col[r * stride];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    double s = x[r];
+#pragma unroll
+                    for (int q = 0; q < r; ++q) s -= Dk[9 * r + q] * x[q];
+                    x[r] = s * m.dinv[9 * k + r];
+                }
+#pragma unroll
+                for (int r = 0; r < 9; ++r) col[r * stride] = x[r];
+            }
+        }
+        __syncthreads();
+    }
+    const bool ok = *flag != 0;
+    __syncthreads();
+    return ok;
+}
+
+// Schur complement on the camera part, rhs as the augmented row Rc:
+//   S -= Wd Wd^T  with the 9K rows of X (chain) and, 16 at a time, the landmark columns
+//   Wd[c][l] = sc[c] * Wt[c][l] * lsc[l],  Wd[Rc][l] = b[l] * lsc[l],  lsc[l] = sl[l] / sqrt(sl^2 h + mu dgl^2).
+// 16x16 tiles accumulate in registers on v_mfma_f64_16x16x4_f64; two tiles per wavefront.
+// Also returns this thread's share of the landmark part of t^T H~ t:  sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ].
+NOINL double schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double mu) {
+    const BaLayout& L = *c.Lp;
+    const double* sc = m.vec + V_SC * L.Rpad;
+    const double* tv = m.vec + V_T * L.Rpad;
+    const double* Wt = buf + L.bo_Wt;
+    const double* h = buf + L.bo_h;
+    const double* b = buf + L.bo_b;
+    const double* sl = c.sc + L.so_sl;
+    const double* dgl = c.sc + L.so_dg + L.Rpad;
+    const double* gtl = c.sc + L.so_gt + L.Rpad;
+    double* lsc = c.sc + L.so_lsc;
+    const int Rc = L.Rc, RcPad = L.RcPad, ldc = m.ldc;
+    const int nt = RcPad / 16;
+    const int ntile = nt * (nt + 1) / 2;
+    double4_t acc[3];                              // up to 3 tiles per wavefront (21 tiles / 8 wavefronts)
+    int tm[3], tn[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        acc[s] = (double4_t){0, 0, 0, 0};
+        const int t = c.wave + s * BA_NW;
+        int a, bq;
+        tri_decode(t, a, bq);
+        tm[s] = a; tn[s] = bq;
+    }
+    // ---- chain rows
+    const int nk = (9 * L.K + 3) / 4;
+    for (int kk = 0; kk < nk; ++kk) {
+        const double* xr = m.XC + (kk * 4 + (c.lane >> 4)) * ldc + (c.lane & 15);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (c.wave + s * BA_NW < ntile) {
+                const double a = xr[tm[s] * 16];
+                const double bb = xr[tn[s] * 16];
+                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[s], 0, 0, 0);
+            }
+        }
+    }
+    // ---- landmark columns
+    double qland = 0.0;
+    for (int l = c.tid; l < c.nL; l += BA_NT) lsc[l] = sl[l] / sqrt(sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l]);
+    for (int l0 = 0; l0 < c.nL; l0 += 16) {
+        __syncthreads();
+        for (int w = c.tid; w < RcPad * 16; w += BA_NT) {
+            const int row = w / 16, k = w % 16, l = l0 + k;
+            const bool in = row < Rc && l < c.nL;
+            const double wv = Wt[(size_t)(in ? row : 0) * L.Lcap + (in ? l : 0)];
+            double v = in ? sc[row] * wv * lsc[l] : 0.0;
+            if (row == Rc && l < c.nL) v = b[l] * lsc[l];
+            m.wd[row * 17 + k] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (c.wave + s * BA_NW < ntile) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double a = m.wd[(tm[s] * 16 + (c.lane & 15)) * 17 + kk * 4 + (c.lane >> 4)];
+                    const double bb = m.wd[(tn[s] * 16 + (c.lane & 15)) * 17 + kk * 4 + (c.lane >> 4)];
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[s], 0, 0, 0);
+                }
+            }
+        }
+        // landmark part of t^T H~ t from the staged tile: w~_l . t_cam = (sum_row wd[row][k] t[row]) / lsc_l
+        if (c.tid < 16 && l0 + c.tid < c.nL) {
+            const int l = l0 + c.tid;
+            double wdot = 0.0;
+            for (int row = 0; row < Rc; ++row) wdot += m.wd[row * 17 + c.tid] * tv[row];
+            const double tl = gtl[l] / dgl[l];
+            qland += sl[l] * sl[l] * h[l] * tl * tl + 2.0 * tl * sl[l] * (wdot / lsc[l]);
+        }
+    }
+    __syncthreads();
+    // D[row = (lane>>4) + 4*reg][col = lane&15]
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (c.wave + s * BA_NW < ntile) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = tm[s] * 16 + (c.lane >> 4) + 4 * reg;
+                const int col = tn[s] * 16 + (c.lane & 15);
+                if (row <= Rc && col <= row && col < Rc) m.S[tri(row, col)] -= acc[s][reg];
+            }
+        }
+    }
+    __syncthreads();
+    return qland;
+}
+
+// Blocked right-looking Cholesky (NB = 16) of the packed lower triangle S (R x R) held in LDS, with the rhs as
+// augmented row R (so row R of the factor is the forward-substituted rhs):
+//   (1) the 16x16 diagonal block is factored by ONE wavefront in registers — lane i holds row i, pivots and
+//       multipliers travel through v_readlane, no barrier inside the block;
+//   (2) the panel rows below it are solved one thread per row (x L_D^T = a, L_D broadcast from LDS);
+//   (3) the trailing matrix gets its rank-16 update tile by tile on v_mfma_f64_16x16x4_f64.
+// Three barriers per 16 columns.  1/L_jj goes to V_DI.  Returns false (uniform) on a bad pivot.
+NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
+    const BaLayout& L = *c.Lp;
+    double* S = m.S;
+    double* dinvv = m.vec + V_DI * L.Rpad;
+    int* flag = (int*)(m.red + 24);
+    const int lane = c.lane;
+    if (c.tid == 0) *flag = 1;
+    __syncthreads();
+    for (int c0 = 0; c0 < R; c0 += 16) {
+        const int nb = (R - c0) < 16 ? (R - c0) : 16;
+        // ---- (1) diagonal block, wavefront 0
+        if (c.wave == 0) {
+            double a[16];
+            const int i = lane & 15;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = (lane < 16 && i < nb && q <= i) ? S[tri(c0 + i, c0 + q)] : 0.0;
+            bool good = true;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                if (jj < nb) {
+                    const double piv = readlane_d(a[jj], jj);
+                    if (!(piv > 0.0) || !(piv < 1e300)) good = false;
+                    const double dinv = rsqrt_nr(piv);
+                    const double l = a[jj] * dinv;              // column jj of row `lane` (lane jj: sqrt(piv))
+                    a[jj] = l;
+                    if (lane == 0) dinvv[c0 + jj] = dinv;
+#pragma unroll
+                    for (int k = jj + 1; k < 16; ++k) {
+                        const double lk = readlane_d(l, k);
+                        a[k] -= l * lk;
+                    }
+                }
+            }
+            if (lane < 16 && i < nb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) if (q <= i) S[tri(c0 + i, c0 + q)] = a[q];
+            }
+            if (!good && lane == 0) *flag = 0;
+        }
+        __syncthreads();
+        if (*flag == 0) break;
+        // ---- (2) panel: rows i > block, x_c = (a_c - sum_{m<c} x_m L_D[c][m]) / L_D[c][c]
+        const int r1 = c0 + nb;
+        if (nb == 16) {
+            for (int i = r1 + c.tid; i <= R; i += BA_NT) {
+                double x[16];
+                double* row = S + tri(i, c0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) x[q] = row[q];
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    const double* ld = S + tri(c0 + cc, c0);
+                    double sacc = x[cc];
+#pragma unroll
+                    for (int q = 0; q < cc; ++q) sacc -= x[q] * ld[q];
+                    x[cc] = sacc * dinvv[c0 + cc];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) row[q] = x[q];
+            }
+        } else {
+            for (int i = r1 + c.tid; i <= R; i += BA_NT) {
+                double* row = S + tri(i, c0);
+                for (int cc = 0; cc < nb; ++cc) {
+                    const double* ld = S + tri(c0 + cc, c0);
+                    double sacc = row[cc];
+                    for (int q = 0; q < cc; ++q) sacc -= row[q] * ld[q];
+                    row[cc] = sacc * dinvv[c0 + cc];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- (3) trailing update (only full blocks have anything right of them)
+        if (nb == 16 && r1 < R) {
+            const int t0 = r1 >> 4;
+            const int nt = (R >> 4) + 1;                 // tile rows covering rows 0..R
+            const int mm = nt - t0;
+            const int ntile = mm * (mm + 1) / 2;
+            for (int t = c.wave; t < ntile; t += BA_NW) {
+                int tr_, tc_;
+                tri_decode(t, tr_, tc_);
+                const int ti = t0 + tr_, tk = t0 + tc_;
+                const int arow = 16 * ti + (lane & 15), brow = 16 * tk + (lane & 15);
+                const bool interior = (16 * ti + 15 <= R) && (ti != tk);     // wave-uniform
+                const double* pa = S + tri(arow <= R ? arow : R, c0) + (lane >> 4);
+                const double* pb = S + tri(brow <= R ? brow : R, c0) + (lane >> 4);
+                const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12];
+                const double b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];
+                const bool av = arow <= R, bv = brow < R;
+                double4_t acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av ? a0 : 0.0, bv ? b0 : 0.0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av ? a1 : 0.0, bv ? b1 : 0.0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av ? a2 : 0.0, bv ? b2 : 0.0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av ? a3 : 0.0, bv ? b3 : 0.0, acc, 0, 0, 0);
+                const int colw = 16 * tk + (lane & 15);
+                const int row0 = 16 * ti + (lane >> 4);
+                if (interior) {
+                    double* q0 = S + tri(row0, colw);
+                    double* q1 = S + tri(row0 + 4, colw);
+                    double* q2 = S + tri(row0 + 8, colw);
+                    double* q3 = S + tri(row0 + 12, colw);
+                    const double c0v = *q0, c1v = *q1, c2v = *q2, c3v = *q3;
+                    *q0 = c0v - acc[0]; *q1 = c1v - acc[1]; *q2 = c2v - acc[2]; *q3 = c3v - acc[3];
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int row = row0 + 4 * reg;
+                        if (row <= R && colw < R && colw <= row) S[tri(row, colw)] -= acc[reg];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const bool ok = (*flag != 0);
+    __syncthreads();
+    return ok;
+}
+
+// y_cam <- solve L^T y = (row R of S) by one wavefront (lane owns entries lane and lane+64 of the running rhs in
+// registers; the pivot value travels through v_readlane); result in V_Y[0..R).  R <= 128.
+NOINL void back_substitute(const Ctx& c, const SolveLds& m, int R) {
+    const BaLayout& L = *c.Lp;
+    const double* S = m.S;
+    const double* dinvv = m.vec + V_DI * L.Rpad;
+    double* y = m.vec + V_Y * L.Rpad;
+    __syncthreads();
+    if (c.wave == 0) {
+        const int l0 = c.lane, l1 = c.lane + 64;
+        const double* rowR = S + tri(R, 0);
+        double v0 = rowR[l0 < R ? l0 : 0], v1 = rowR[l1 < R ? l1 : 0];
+        v0 = l0 < R ? v0 : 0.0; v1 = l1 < R ? v1 : 0.0;
+        int j = R - 1;
+        for (; j >= 64; --j) {          // pivot in v1
+            const double* rj = S + tri(j, 0);
+            const double r0 = rj[l0];
+            double r1 = rj[l1 < j ? l1 : 0];
+            r1 = l1 < j ? r1 : 0.0;
+            const int own = j & 63;
+            const double xj = readlane_d(v1, own) * dinvv[j];
+            v1 = c.lane == own ? xj : v1 - r1 * xj;
+            v0 -= r0 * xj;
+        }
+        for (; j >= 0; --j) {           // pivot in v0
+            const double* rj = S + tri(j, 0);
+            double r0 = rj[l0 < j ? l0 : 0];
+            r0 = l0 < j ? r0 : 0.0;
+            const double xj = readlane_d(v0, j) * dinvv[j];
+            v0 = c.lane == j ? xj : v0 - r0 * xj;
+        }
+        if (c.lane < R) y[c.lane] = v0;
+        if (c.lane + 64 < R) y[c.lane + 64] = v1;
+    }
+    __syncthreads();
+}
+
+// speed-bias blocks, first to last:  y_k = L_k^-T ( xg_k - Xc_k y_cam - Xe_k y_{k-1} )
+NOINL void chain_back_substitute(const Ctx& c, const SolveLds& m) {
+    const BaLayout& L = *c.Lp;
+    const int K = L.K, Rc = L.Rc, ldc = m.ldc;
+    double* y = m.vec + V_Y * L.Rpad;
+    // z = xg - Xc y_cam for all 9K rows at once, the Rc-term dot product of every row split over 4 threads
+    {
+        const int nrow = 9 * K;
+        for (int w = c.tid; w < 4 * nrow; w += BA_NT) {
+            const int row = w >> 2, q = w & 3;
+            const double* xr = m.XC + row * ldc;
+            double s = 0.0;
+            for (int j = q; j < Rc; j += 4) s += xr[j] * y[j];
+            m.z[w] = s;
+        }
+        __syncthreads();
+        for (int row = c.tid; row < nrow; row += BA_NT)
+            m.wd[row] = m.XC[row * ldc + Rc] - ((m.z[4 * row] + m.z[4 * row + 1]) + (m.z[4 * row + 2] + m.z[4 * row + 3]));
+        __syncthreads();
+    }
+    if (c.wave == 0) {
+        const int r = c.lane < 9 ? c.lane : 8;
+        double yprev = 0.0;                       // lane r holds y_{k-1}[r]
+        for (int k = 0; k < K; ++k) {
+            const double* Lk = m.D + 81 * k;
+            double v = m.wd[9 * k + r];
+            if (k > 0) {
+                const double* Xe = m.E + 81 * k;
+#pragma unroll
+                for (int cc = 0; cc < 9; ++cc) v -= Xe[9 * r + cc] * readlane_d(yprev, cc);
+            }
+            // L^T y = v: backward over rows j = 8 .. 0; lane r accumulates its rhs entry
+#pragma unroll
+            for (int j = 8; j >= 0; --j) {
+                const double yj = readlane_d(v, j) * m.dinv[9 * k + j];
+                const double lrj = (r < j) ? Lk[9 * j + r] : 0.0;      // L[j][r], r < j
+                v = (r == j) ? yj : v - lrj * yj;
+            }
+            yprev = v;
+            if (c.lane < 9) y[Rc + 9 * k + c.lane] = v;
+        }
+    }
+    __syncthreads();
+}
+
+DEV void R2ypr_dev(const double* R, double* ypr) {
+    const double n0 = R[0], n1 = R[3], n2 = R[6];
+    const double o0 = R[1], o1 = R[4];
+    const double a0 = R[2], a1 = R[5];
+    const double y = atan2(n1, n0);
+    const double p = atan2(-n2, n0 * cos(y) + n1 * sin(y));
+    const double r = atan2(a0 * sin(y) - a1 * cos(y), -o0 * sin(y) + o1 * cos(y));
+    ypr[0] = y / M_PI * 180.0; ypr[1] = p / M_PI * 180.0; ypr[2] = r / M_PI * 180.0;
+}
+
+DEV double state_sqnorm_share(const BaLayout& L, const double* x, const double* lam, int nL, int tid, int nt) {
+    double s = 0.0;
+    const int nx = 7 * L.Kp + 9 * L.K + (L.e ? 7 : 0);
+    for (int k = tid; k < nx; k += nt) s += x[k] * x[k];
+    if (L.t && tid == 0) s += x[7 * L.Kp + 9 * L.K + 7] * x[7 * L.Kp + 9 * L.K + 7];
+    for (int k = tid; k < nL; k += nt) s += lam[k] * lam[k];
+    return s;
+}
+
+extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    const int w = blockIdx.x;
+    ctx_init(c, Lp, P, w);
+    double* ctlp = c.sc + L.so_ctl;
+    Ctl s;
+    ctl_load(s, ctlp);
+    if (s.done) return;
+    SolveLds m;
+    lds_carve(L, m);
+    const int max_iters = c.hdr[H_MAXIT];
+    const int R = L.R, Rc = L.Rc, nL = c.nL;
+    double* out = P.out + (size_t)w * L.ostride;
+    int* iout = P.iout + (size_t)w * L.oi_stride;
+    double* vG = m.vec + V_G * L.Rpad;
+    double* vSC = m.vec + V_SC * L.Rpad;
+    double* vDG = m.vec + V_DG * L.Rpad;
+    double* vGT = m.vec + V_GT * L.Rpad;
+    double* vGN = m.vec + V_GN * L.Rpad;
+    double* vU = m.vec + V_U * L.Rpad;
+    double* vY = m.vec + V_Y * L.Rpad;
+    double* vT = m.vec + V_T * L.Rpad;
+    double* sl = c.sc + L.so_sl;
+    double* dgl = c.sc + L.so_dg + L.Rpad;
+    double* gtl = c.sc + L.so_gt + L.Rpad;
+    double* gnl = c.sc + L.so_gn + L.Rpad;
+    double* yl = c.sc + L.so_yl;
+
+    // prior column map (prior column -> reduced column or -1)
+    if (c.nprior) {
+        const int* kind = c.ia + L.io_pb_kind;
+        const int* off = c.ia + L.io_pb_off;
+        const int* pcol = c.ia + L.io_pb_col;
+        for (int blk = c.tid; blk < c.nblk; blk += BA_NT) {
+            const int sz = (kind[blk] == VG_BLK_SPEEDBIAS) ? 9 : (kind[blk] == VG_BLK_TD ? 1 : 6);
+            for (int k = 0; k < sz; ++k) m.pmap[off[blk] + k] = pcol[blk] >= 0 ? pcol[blk] + k : -1;
+        }
+    }
+    __syncthreads();
+
+    bool assembled = false;
+    bool fresh_point = false;              // a new current point whose gradient has to be tested
+    if (s.pending) {
+        const bool acc = judge_candidate(s, c.sc + L.so_part, L.nbl, L, out, iout, c.tid);
+        if (acc) {
+            if (!(s.cost == s.cost)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
+            fresh_point = true;
+        }
+    } else if (!s.scaled) {
+        // round 0: cost of the initial point
+        double cs = 0.0;
+        for (int b = 0; b < L.nbl; ++b) cs += c.sc[L.so_part + b];
+        s.cost = 0.5 * cs;
+        s.init_cost = s.cost;
+        s.x_norm = sqrt(block_sum(m.red, BA_NW, c.lane, c.wave, state_sqnorm_share(L, c.sc + L.so_x + s.cur * L.nst,
+                                                                                     c.sc + L.so_lam + s.cur * L.Lcap, nL, c.tid, BA_NT)));
+        if (!(s.cost == s.cost) || !(s.cost < 1e300)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
+        fresh_point = true;
+    }
+    const double* buf = lin_buf(c, s.cur);
+    const double* hh = buf + L.bo_h;
+    const double* bb = buf + L.bo_b;
+    if (fresh_point && s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK) {
+        assemble(c, m, buf);
+        assembled = true;
+        if (!s.scaled) {
+            // Jacobi scaling from the first Jacobian, fixed for the solve: 1 / (1 + ||J_col||)
+            for (int k = c.tid; k < R; k += BA_NT) c.sc[L.so_sc + k] = 1.0 / (1.0 + sqrt(hess_diag(L, m, k)));
+            for (int k = c.tid; k < nL; k += BA_NT) sl[k] = 1.0 / (1.0 + sqrt(hh[k]));
+            s.scaled = 1;
+            __syncthreads();
+        }
+        double mx = 0.0;
+        for (int k = c.tid; k < R; k += BA_NT) mx = fmax(mx, fabs(vG[k]));
+        for (int k = c.tid; k < nL; k += BA_NT) mx = fmax(mx, fabs(bb[k]));
+        if (block_max(m.red, BA_NW, c.lane, c.wave, mx) <= 1e-10) s.term = VG_TERM_CONVERGENCE;
+    }
+    for (int k = c.tid; k < R; k += BA_NT) vSC[k] = c.sc[L.so_sc + k];
+    __syncthreads();
+
+    const double* x = c.sc + L.so_x + s.cur * L.nst;
+    const double* lam = c.sc + L.so_lam + s.cur * L.Lcap;
+    double* xc = c.sc + L.so_x + (s.cur ^ 1) * L.nst;
+    double* lamc = c.sc + L.so_lam + (s.cur ^ 1) * L.Lcap;
+    const double min_mu = 1e-8, max_mu = 1.0;
+    (void)min_mu;
+
+    while (s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK && s.it < max_iters) {
+        ++s.it;
+        const int slot = s.it - 1;
+        bool ok = true;
+        if (!s.reuse) {
+            s.reuse = 1;
+            if (!assembled) { assemble(c, m, buf); assembled = true; }
+            // Dg, gt (scaled gradient / Dg), t = gt / Dg
+            for (int k = c.tid; k < R; k += BA_NT) {
+                double d2 = vSC[k] * vSC[k] * hess_diag(L, m, k);
+                d2 = d2 < 1e-6 ? 1e-6 : d2;               // std::min(std::max(.)) of dogleg_strategy.cc: NaN propagates
+                d2 = 1e32 < d2 ? 1e32 : d2;
+                const double d = sqrt(d2);
+                vDG[k] = d;
+                vGT[k] = vSC[k] * vG[k] / d;
+                vT[k] = vGT[k] / d;
+            }
+            for (int k = c.tid; k < nL; k += BA_NT) {
+                double d2 = sl[k] * sl[k] * hh[k];
+                d2 = d2 < 1e-6 ? 1e-6 : d2;
+                d2 = 1e32 < d2 ? 1e32 : d2;
+                const double d = sqrt(d2);
+                dgl[k] = d;
+                gtl[k] = sl[k] * bb[k] / d;
+            }
+            __syncthreads();
+            {
+                double sq = 0.0;
+                for (int k = c.tid; k < R; k += BA_NT) sq += vGT[k] * vGT[k];
+                for (int l = c.tid; l < nL; l += BA_NT) sq += gtl[l] * gtl[l];
+                s.gtn2 = block_sum(m.red, BA_NW, c.lane, c.wave, sq);
+            }
+            // Gauss-Newton step, increasing mu on failure (DoglegStrategy::ComputeGaussNewtonStep)
+            bool solved = false;
+            while (s.mu < max_mu) {
+                if (!assembled) { assemble(c, m, buf); assembled = true; }
+                double q = build_scaled(c, m, s.mu);
+                assembled = false;
+                __syncthreads();
+                bool cok = chain_eliminate(c, m);
+                q += schur_mfma(c, m, buf, s.mu);
+                q = block_sum(m.red, BA_NW, c.lane, c.wave, q);
+                s.alpha = s.gtn2 / q;            // |gt|^2 / |J~ (gt/Dg)|^2
+                if (cok) cok = cholesky_aug(c, m, Rc);
+                if (cok) {
+                    back_substitute(c, m, Rc);
+                    chain_back_substitute(c, m);
+                    // landmarks: y_l = (bt_l - wt_l . y_cam) / ht_l
+                    const double* Wt = buf + L.bo_Wt;
+                    for (int l = c.tid; l < nL; l += BA_NT) {
+                        const double ht = sl[l] * sl[l] * hh[l] + s.mu * dgl[l] * dgl[l];
+                        double acc = 0.0;
+                        for (int k = 0; k < Rc; ++k) acc += vSC[k] * Wt[(size_t)k * L.Lcap + l] * vY[k];
+                        yl[l] = (sl[l] * bb[l] - sl[l] * acc) / ht;
+                    }
+                    double fin = 0.0;
+                    for (int k = c.tid; k < R; k += BA_NT) fin += (vY[k] == vY[k] && fabs(vY[k]) < 1e300) ? 0.0 : 1.0;
+                    for (int k = c.tid; k < nL; k += BA_NT) fin += (yl[k] == yl[k] && fabs(yl[k]) < 1e300) ? 0.0 : 1.0;
+                    if (block_sum(m.red, BA_NW, c.lane, c.wave, fin) == 0.0) { solved = true; s.mu_solved = s.mu; break; }
+                }
+                s.mu *= 10.0;
+            }
+            if (!solved) ok = false;
+            else {
+                double s1 = 0.0, s2 = 0.0;
+                for (int k = c.tid; k < R; k += BA_NT) {
+                    vGN[k] = -vY[k] * vDG[k];
+                    s1 += vGN[k] * vGN[k];
+                    s2 += vGN[k] * vGT[k];
+                }
+                for (int k = c.tid; k < nL; k += BA_NT) {
+                    gnl[k] = -yl[k] * dgl[k];
+                    s1 += gnl[k] * gnl[k];
+                    s2 += gnl[k] * gtl[k];
+                }
+                block_sum2(m.red, BA_NW, c.lane, c.wave, s1, s2);
+                s.gnn2 = s1; s.gtgn = s2;
+                // keep Dg, gt, gn of this point for step reuse after a rejection (DoglegStrategy keeps them as members)
+                for (int k = c.tid; k < R; k += BA_NT) {
+                    c.sc[L.so_dg + k] = vDG[k]; c.sc[L.so_gt + k] = vGT[k]; c.sc[L.so_gn + k] = vGN[k];
+                }
+            }
+        } else {
+            for (int k = c.tid; k < R; k += BA_NT) {
+                vDG[k] = c.sc[L.so_dg + k]; vGT[k] = c.sc[L.so_gt + k]; vGN[k] = c.sc[L.so_gn + k];
+            }
+            __syncthreads();
+        }
+        double model_change = 0.0;
+        double c_gt = 0.0, c_gn = 0.0;
+        if (ok) {
+            // DoglegStrategy::ComputeTraditionalDoglegStep
+            const double gtn = sqrt(s.gtn2), gnn = sqrt(s.gnn2);
+            if (gnn <= s.radius) { c_gt = 0.0; c_gn = 1.0; s.dnorm = gnn; }
+            else if (gtn * s.alpha >= s.radius) { c_gt = -(s.radius / gtn); c_gn = 0.0; s.dnorm = s.radius; }
+            else {
+                const double b_dot_a = -s.alpha * s.gtgn;
+                const double a_sq = (s.alpha * gtn) * (s.alpha * gtn);
+                const double bma_sq = a_sq - 2 * b_dot_a + s.gnn2;
+                const double cc = b_dot_a - a_sq;
+                const double dd = sqrt(cc * cc + bma_sq * (s.radius * s.radius - a_sq));
+                const double beta = (cc <= 0) ? (dd - cc) / bma_sq : (s.radius * s.radius - a_sq) / (dd + cc);
+                c_gt = -s.alpha * (1.0 - beta); c_gn = beta;
+                s.dnorm = sqrt(c_gt * c_gt * s.gtn2 + 2 * c_gt * c_gn * s.gtgn + c_gn * c_gn * s.gnn2);
+            }
+            __syncthreads();
+            // delta = scale .* (s ./ Dg)
+            for (int k = c.tid; k < R; k += BA_NT) vU[k] = vSC[k] * ((c_gt * vGT[k] + c_gn * vGN[k]) / vDG[k]);
+            __syncthreads();
+            // model cost change  -(J~ s)^T (r + J~ s / 2)  with s = c_gt a + c_gn b  (a = gt/Dg, b = gn/Dg = -y):
+            //   a.g~ = |gt|^2, b.g~ = gt.gn, a^T H~ a = |gt|^2 / alpha, and from (H~ + mu Dg^2) y = g~ :
+            //   b^T H~ b = -gt.gn - mu |gn|^2,  a^T H~ b = -|gt|^2 - mu gt.gn      (no pass over the factors)
+            const double q11 = s.gtn2 / s.alpha;
+            const double q12 = -s.gtn2 - s.mu_solved * s.gtgn;
+            const double q22 = -s.gtgn - s.mu_solved * s.gnn2;
+            model_change = -(c_gt * s.gtn2 + c_gn * s.gtgn) - 0.5 * (c_gt * c_gt * q11 + 2.0 * c_gt * c_gn * q12 + c_gn * c_gn * q22);
+        }
+        if (c.tid == 0) {
+            out[L.oo_trace + 0 * VG_MAX_ITERS + slot] = s.cost;
+            out[L.oo_trace + 3 * VG_MAX_ITERS + slot] = s.radius;
+        }
+        if (!ok || !(model_change > 0.0)) {
+            if (c.tid == 0) {
+                out[L.oo_trace + 1 * VG_MAX_ITERS + slot] = 0.0;
+                out[L.oo_trace + 2 * VG_MAX_ITERS + slot] = model_change;
+                out[L.oo_trace + 4 * VG_MAX_ITERS + slot] = 0.0;
+                iout[4 + slot] = 0;
+            }
+            ++s.ninv;
+            if (s.ninv >= 5) { s.term = VG_TERM_FAILURE; break; }
+            s.mu *= 10.0;
+            s.reuse = 0;
+            continue;                   // the linearisation of the unchanged point is still in HBM: next trip re-assembles it
+        }
+        s.ninv = 0;
+        s.model = model_change;
+        // ---- candidate = x (+) delta into the other state copy
+        for (int i = c.tid; i < L.Kp; i += BA_NT) pose_plus(x + 7 * i, vU + col_pose(L, i), xc + 7 * i);
+        for (int k = c.tid; k < 9 * L.K; k += BA_NT) xc[7 * L.Kp + k] = x[7 * L.Kp + k] + vU[col_sb(L, k / 9) + k % 9];
+        if (c.tid == 0) {
+            double* exc = xc + 7 * L.Kp + 9 * L.K;
+            const double* exx = x + 7 * L.Kp + 9 * L.K;
+            if (L.e) pose_plus(exx, vU + col_ex(L), exc);
+            else for (int k = 0; k < 7; ++k) exc[k] = exx[k];
+            exc[7] = L.t ? exx[7] + vU[col_td(L)] : exx[7];
+        }
+        for (int k = c.tid; k < nL; k += BA_NT) lamc[k] = lam[k] + sl[k] * ((c_gt * gtl[k] + c_gn * gnl[k]) / dgl[k]);
+        __syncthreads();
+        {
+            double sd = 0.0;
+            const int nx = 7 * L.Kp + 9 * L.K + (L.e ? 7 : 0);
+            for (int k = c.tid; k < nx; k += BA_NT) { const double d = x[k] - xc[k]; sd += d * d; }
+            if (L.t && c.tid == 0) { const double d = x[7 * L.Kp + 9 * L.K + 7] - xc[7 * L.Kp + 9 * L.K + 7]; sd += d * d; }
+            for (int k = c.tid; k < nL; k += BA_NT) { const double d = lam[k] - lamc[k]; sd += d * d; }
+            double sn = state_sqnorm_share(L, xc, lamc, nL, c.tid, BA_NT);
+            block_sum2(m.red, BA_NW, c.lane, c.wave, sd, sn);
+            s.step_norm = sqrt(sd);
+            s.x_norm_c = sqrt(sn);
+        }
+        if (c.tid == 0) {
+            out[L.oo_trace + 2 * VG_MAX_ITERS + slot] = model_change;
+            out[L.oo_trace + 4 * VG_MAX_ITERS + slot] = s.dnorm;
+        }
+        s.pending = 1;
+        break;
+    }
+    if (!s.pending) s.done = 1;
+    __syncthreads();
+    if (c.tid == 0) ctl_store(s, ctlp);
+}
+
+// ================================================================================================
+// Final kernel: judge the last candidate, then Estimator::double2vector() (estimator.cpp:530-577: yaw / position gauge
+// fix) + the vector2double() repack (:486-528) into the output slab.
+// ================================================================================================
+extern "C" __global__ __launch_bounds__(256) void ba_final_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    const int w = blockIdx.x;
+    ctx_init(c, Lp, P, w);
+    const int NT = 256;
+    double* ctlp = c.sc + L.so_ctl;
+    double* out = P.out + (size_t)w * L.ostride;
+    int* iout = P.iout + (size_t)w * L.oi_stride;
+    Ctl s;
+    ctl_load(s, ctlp);
+    if (s.pending) {
+        const bool acc = judge_candidate(s, c.sc + L.so_part, L.nbl, L, out, iout, c.tid);
+        if (acc && !(s.cost == s.cost)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
+    }
+    const double* x = c.sc + L.so_x + s.cur * L.nst;
+    const double* lam = c.sc + L.so_lam + s.cur * L.Lcap;
+    const double* p0_in = c.di + L.do_pose;          // pre-solve frame 0
+    double Rs0[9], R00[9], y0[3], y00[3], rot[9];
+    q_to_R(p0_in + 3, Rs0);
+    q_to_R(x + 3, R00);
+    R2ypr_dev(Rs0, y0);
+    R2ypr_dev(R00, y00);
+    const double yd = (y0[0] - y00[0]) / 180.0 * M_PI;
+    rot[0] = cos(yd); rot[1] = -sin(yd); rot[2] = 0;
+    rot[3] = sin(yd); rot[4] = cos(yd);  rot[5] = 0;
+    rot[6] = 0;       rot[7] = 0;        rot[8] = 1;
+    if (fabs(fabs(y0[1]) - 90) < 1.0 || fabs(fabs(y00[1]) - 90) < 1.0) m3_mul_t(Rs0, R00, rot);
+    for (int i = c.tid; i < L.Kp; i += NT) {
+        // frames of the window and (i == K) the relocalisation pose: same gauge transform (estimator.cpp:598-603)
+        double q[4] = {x[7 * i + 3], x[7 * i + 4], x[7 * i + 5], x[7 * i + 6]};
+        q_normalize(q);
+        double Rq[9], Ri[9], qo[4], d[3], po[3];
+        q_to_R(q, Rq);
+        m3_mul(rot, Rq, Ri);
+        R_to_q(Ri, qo);
+        d[0] = x[7 * i] - x[0]; d[1] = x[7 * i + 1] - x[1]; d[2] = x[7 * i + 2] - x[2];
+        m3_vec(rot, d, po);
+        double* o = out + L.oo_pose + 7 * i;
+        o[0] = po[0] + p0_in[0]; o[1] = po[1] + p0_in[1]; o[2] = po[2] + p0_in[2];
+        o[3] = qo[0]; o[4] = qo[1]; o[5] = qo[2]; o[6] = qo[3];
+        if (i < L.K) {
+            const double* sb = x + 7 * L.Kp + 9 * i;
+            double vo[3];
+            m3_vec(rot, sb, vo);
+            double* os = out + L.oo_sb + 9 * i;
+            os[0] = vo[0]; os[1] = vo[1]; os[2] = vo[2];
+            for (int k = 3; k < 9; ++k) os[k] = sb[k];
+        }
+    }
+    if (c.tid == 0) {
+        const double* exx = x + 7 * L.Kp + 9 * L.K;
+        double Rcm[9], qo[4];
+        q_to_R(exx + 3, Rcm);
+        R_to_q(Rcm, qo);
+        double* o = out + L.oo_ex;
+        o[0] = exx[0]; o[1] = exx[1]; o[2] = exx[2]; o[3] = qo[0]; o[4] = qo[1]; o[5] = qo[2]; o[6] = qo[3];
+        out[L.oo_td] = exx[7];
+        out[L.oo_sum + 0] = s.init_cost;
+        out[L.oo_sum + 1] = s.cost;
+        out[L.oo_sum + 2] = s.radius;
+        iout[0] = s.status; iout[1] = s.term; iout[2] = s.it; iout[3] = s.nacc;
+        s.done = 1;
+        ctl_store(s, ctlp);
+    }
+    // setDepth/getDepthVector round trip (feature_manager.cpp:141-200)
+    for (int k = c.tid; k < c.nL; k += NT) out[L.oo_lam + k] = 1.0 / (1.0 / lam[k]);
+}
+
+// ================================================================================================
+// Factor-evaluation kernel for parity tests (vg_ba_eval_factors): raw (no loss) residuals/Jacobians at the input state.
+// proj_J [F][2][20] = [pose_i 6 | pose_j 6 | ex 6 | lambda | td];  imu_J [K-1][15][30].  Runs after ba_prologue_kernel
+// (which leaves the sqrt_info factors and state copy 0 in scratch).
+// ================================================================================================
+extern "C" __global__ __launch_bounds__(BA_NT) void ba_eval_factors_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, double* proj_r,
+                                                                       double* proj_J, double* imu_r, double* imu_J, double* prior_r) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    ctx_init(c, Lp, P, 0);
+    const double* x = c.sc + L.so_x;
+    const double* lam = c.sc + L.so_lam;
+    double* buf = lin_buf(c, 0);
+    prior_pass(c, x, buf + L.bo_pr, LDSB);
+    __syncthreads();
+    const int nimu = L.K - 1;
+    // weighted IMU residual / Jacobian, thread = (factor, column | residual); U = sqrt_info from the prologue
+    for (int w = c.tid; w < nimu * 31; w += BA_NT) {
+        const int f = w / 31, col = w % 31;
+        if (!c.ia[L.io_imu_valid + f]) continue;
+        const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
+        const double* U = c.sc + L.so_imuU + f * 225;
+        ImuCtx ic;
+        imu_ctx<true>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
+        double raw[15];
+        if (col < 30) imu_raw_col(ic, pre, col, raw);
+        else { for (int q = 0; q < 15; ++q) raw[q] = ic.r[q]; }
+        for (int r = 0; r < 15; ++r) {
+            double s = 0.0;
+            for (int k = r; k < 15; ++k) s += U[r * 15 + k] * raw[k];
+            if (col < 30) { if (imu_J) imu_J[(size_t)f * 450 + r * 30 + col] = s; }
+            else if (imu_r) imu_r[f * 15 + r] = s;
+        }
+    }
+    for (int k = c.tid; k < c.nprior; k += BA_NT) if (prior_r) prior_r[k] = buf[L.bo_pr + k];
+    const double* ex = st_ex(L, x);
+    for (int f = c.tid; f < c.nF; f += BA_NT) {
+        ProjIn p;
+        proj_fetch(c, f, x, lam, p);
+        double r[2], Ji[12], Jj[12], Jex[12], Jl[2], Jtd[2] = {0, 0};
+        for (int k = 0; k < 12; ++k) Jex[k] = 0.0;
+        if (L.t) proj_eval<true, true, true>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, ex[7], c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+        else proj_eval<false, true, true>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+        if (proj_r) { proj_r[2 * f] = r[0]; proj_r[2 * f + 1] = r[1]; }
+        if (proj_J) {
+            for (int rr = 0; rr < 2; ++rr) {
+                double* o = proj_J + (size_t)f * 40 + rr * 20;
+                for (int k = 0; k < 6; ++k) { o[k] = Ji[rr * 6 + k]; o[6 + k] = Jj[rr * 6 + k]; o[12 + k] = Jex[rr * 6 + k]; }
+                o[18] = Jl[rr]; o[19] = Jtd[rr];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-side launch sequence of one batch solve (rounds = max over the windows of max_iters).
+static hipError_t set_lds_attrs() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (these two also hold a few statically allocated LDS words: static + dynamic must stay within 160 KB)
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_eval_factors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    done = e == hipSuccess;
+    return e;
+}
+
+// last failing launch of this translation unit (for the error text of the C-ABI)
+static const char* g_failed_launch = "";
+extern "C" const char* ba_failed_launch() { return g_failed_launch; }
+#define LAUNCH(name, grid, block, lds, ...)                                              \
+    do {                                                                                 \
+        hipLaunchKernelGGL(name, grid, block, lds, stream, __VA_ARGS__);                 \
+        const hipError_t _le = hipGetLastError();                                        \
+        if (_le != hipSuccess) { g_failed_launch = #name; return _le; }                  \
+    } while (0)
+
+extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream) {
+    hipError_t e = set_lds_attrs();
+    if (e != hipSuccess) { g_failed_launch = "hipFuncSetAttribute"; return e; }
+    LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P);
+    for (int r = 0; r < rounds; ++r) {
+        LAUNCH(ba_linearize_kernel, dim3(L.nbl, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, 0);
+        LAUNCH(ba_accumulate_kernel, dim3(L.nba, L.nwin), dim3(BA_ACC_NT), 0, dL, P);
+        LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P);
+    }
+    LAUNCH(ba_linearize_kernel, dim3(L.nbl, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, 1);
+    LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P);
+    return hipSuccess;
+}
+
+extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, double* proj_r, double* proj_J,
+                                            double* imu_r, double* imu_J, double* prior_r, hipStream_t stream) {
+    hipError_t e = set_lds_attrs();
+    if (e != hipSuccess) { g_failed_launch = "hipFuncSetAttribute"; return e; }
+    LAUNCH(ba_prologue_kernel, dim3(1), dim3(BA_NT), L.lds_pro, dL, P);
+    LAUNCH(ba_eval_factors_kernel, dim3(1), dim3(BA_NT), L.lds_lin, dL, P, proj_r, proj_J, imu_r, imu_J, prior_r);
+    return hipSuccess;
+}

@@ -16,6 +16,7 @@ struct BaBatch {
     double* h_di = nullptr;
     size_t hcap_ia = 0, hcap_di = 0;
     int nwin = 0;
+    int rounds = 0;                  // launches of the linearise / accumulate / solve triple = max over windows of max_iters
     bool uploaded = false, any_margin = false;
     double flops = 0, flops_marg = 0, bytes_in = 0, bytes_out = 0;
 };
