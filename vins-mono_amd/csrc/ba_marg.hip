@@ -445,6 +445,176 @@ DEV int jacobi_eig_fast(const MCtx& c, int offM, int offV, int n, int ld, int of
     return sweep;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Eigen-decomposition of a symmetric n x n matrix that is positive semi-definite up to rounding noise, in LDS (offM,
+// leading dimension ld), by the Veselic-Hari scheme: diagonally pivoted Cholesky  P^T (A + delta I) P = L L^T , then
+// one-sided (Hestenes) Jacobi on the columns of L:  L V = U Sigma , hence  A = U (Sigma^2 - delta) U^T.
+// Why this and not the two-sided iteration above:
+//   * only contiguous column access (no mixed row / column walks of a symmetric storage -> no bank-conflict storm), no
+//     separate eigenvector accumulation, one barrier per round, ~1/3 of the cycles per round;
+//   * eigenvalues of a graded matrix come with high relative accuracy (Amm spans 1e2 .. 1e12 and gets inverted);
+//   * 16 lanes (one DPP row) per column pair, all pairs of a round-robin round at once; squared column norms are carried
+//     in LDS and updated with the rotation (alpha' = alpha - t gamma, beta' = beta + t gamma), so a rotation costs one
+//     length-n dot product (reduced on the DPP row network) and one pass over the two columns held in registers.
+// The shift delta: the kept block A' of a marginalization is singular in the gauge directions and carries indefinite
+// rounding noise (observed -0.08 .. +1e-3 against a spectrum reaching 4e7), so a plain Cholesky breaks down; the
+// factorisation is retried with delta = delta0, 16 delta0, ... (delta0 = delta0_rel * max diagonal, or 1e-12 * that after
+// a failure with delta0 = 0) until every pivot stays above delta / 100.  lambda_i = sigma_i^2 - delta reproduces the
+// spectrum of A itself — noise eigenvalues included, so the lambda <= 1e-8 cut of marginalization_factor.cpp:272-296
+// sees what SelfAdjointEigenSolver would show it.
+// On exit (same convention as jacobi_eig): diag(M) = eigenvalues, V holds the eigenvectors as COLUMNS.
+// A pair is rotated while |g_p . g_q| > tol |g_p| |g_q|: 1e-16 for Amm (it is inverted: at 1e-14 the Schur complement
+// loses a digit against the extended-precision yardstick), 1e-14 for the kept block.
+// `offcs` = LDS scratch of >= 4 n + 8 doubles.  Returns sweeps | attempts << 8.
+DEV double mg_row16_sum(double v) {          // sum over the 16 lanes of a DPP row, result in all 16
+    v += dpp_mov_f64<0xB1>(v);
+    v += dpp_mov_f64<0x4E>(v);
+    v += dpp_mov_f64<0x141>(v);
+    v += dpp_mov_f64<0x140>(v);
+    return v;
+}
+#define MG_HROWS 6                            // elements of a column per lane: n <= 96
+DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, double delta0_rel, double tol) {
+    double* A = MG_LDS + offM;
+    double* Lc = MG_LDS + offV;               // column k of L at Lc[k * ld + i]
+    double* dgn = MG_LDS + offcs;             // running diagonal of the Schur complement
+    double* nrm = dgn + n;
+    double* lamv = nrm + n;
+    int* taken = (int*)(lamv + n);
+    double* red = MG_LDS + offred;
+    const int grp = c.tid >> 4, sub = c.tid & 15;
+    const int ngrp = MG_NT / 16;
+    // ---- diagonally pivoted Cholesky of A + delta I (left-looking: column k from A and the previous columns)
+    double dmax0 = 0.0;
+    for (int i = 0; i < n; ++i) dmax0 = fmax(dmax0, A[i * ld + i]);
+    double delta = delta0_rel * dmax0;
+    int attempts = 0;
+    for (;;) {
+        ++attempts;
+        __syncthreads();
+        for (int i = c.tid; i < n; i += MG_NT) { dgn[i] = A[i * ld + i] + delta; taken[i] = 0; }
+        for (int k = c.tid; k < n * ld; k += MG_NT) Lc[k] = 0.0;
+        __syncthreads();
+        const double floor_ = fmax(0.01 * delta, 1e-15 * dmax0);
+        bool broke = false;
+        for (int k = 0; k < n; ++k) {
+            // pivot = largest remaining diagonal (first index on ties): every thread scans the <= 96 values (uniform)
+            int p = 0;
+            double best = -1e300;
+            for (int i = 0; i < n; ++i) {
+                const double v = dgn[i];
+                if (!taken[i] && v > best) { best = v; p = i; }
+            }
+            if (!(best > floor_)) { broke = true; break; }
+            __syncthreads();
+            const double inv = mg_rsqrt(best);
+            // L[i][k] = (A[i][p] - sum_{j<k} L[i][j] L[p][j]) / L[p][k] for the rows not taken yet; 8 lanes per row
+            const int g8 = c.tid >> 3, s8 = c.tid & 7;
+            for (int i0 = 0; i0 < n; i0 += MG_NT / 8) {
+                const int i = i0 + g8;
+                const bool on = i < n && !taken[i];
+                double sacc = 0.0;
+                if (on)
+                    for (int j = s8; j < k; j += 8) sacc += Lc[j * ld + i] * Lc[j * ld + p];
+                sacc = group8_sum(sacc);
+                if (on && s8 == 0) {
+                    const double v = i == p ? best * inv : (A[i * ld + p] - sacc) * inv;
+                    Lc[k * ld + i] = v;
+                    if (i != p) dgn[i] -= v * v;
+                }
+            }
+            __syncthreads();
+            if (c.tid == 0) taken[p] = 1;
+            __syncthreads();
+        }
+        if (!broke || attempts >= 12) break;
+        delta = fmax(16.0 * delta, 1e-12 * dmax0);
+    }
+    // ---- one-sided Jacobi on the n columns (length n) of L
+    const int N = (n + 1) & ~1, npairs = N / 2, nrounds = N - 1;
+    int sweep = 0;
+    if (n >= 2) {
+        for (;;) {
+            for (int i0 = 0; i0 < n; i0 += ngrp) {       // exact squared norms
+                const int i = i0 + grp;
+                double sq = 0.0;
+                if (i < n)
+                    for (int j = sub; j < n; j += 16) { const double v = Lc[i * ld + j]; sq += v * v; }
+                sq = mg_row16_sum(sq);
+                if (i < n && sub == 0) nrm[i] = sq;
+            }
+            if (c.tid == 0) red[16] = 0.0;
+            __syncthreads();
+            for (int r = 0; r < nrounds; ++r) {
+                // round-robin tournament: player N-1 stays, the others rotate
+                int a, b;
+                if (grp == 0) { a = r; b = N - 1; }
+                else { a = (r + grp) % (N - 1); b = (r - grp + (N - 1)) % (N - 1); }
+                const bool act = grp < npairs && a < n && b < n;
+                double gp[MG_HROWS], gq[MG_HROWS];
+                double gam = 0.0;
+#pragma unroll
+                for (int t = 0; t < MG_HROWS; ++t) {
+                    const int j = sub + 16 * t;
+                    const bool in = act && j < n;
+                    gp[t] = in ? Lc[a * ld + j] : 0.0;
+                    gq[t] = in ? Lc[b * ld + j] : 0.0;
+                    gam += gp[t] * gq[t];
+                }
+                gam = mg_row16_sum(gam);
+                // every lane of the pair reads the norms before lane 0 of the pair may replace them
+                const double al = act ? nrm[a] : 1.0, be = act ? nrm[b] : 1.0;
+                __builtin_amdgcn_wave_barrier();
+                if (act) {
+                    if (fabs(gam) > tol * sqrt(al * be) && al > 0.0 && be > 0.0) {
+                        const double zeta = (be - al) / (2.0 * gam);
+                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = mg_rsqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
+                        for (int u = 0; u < MG_HROWS; ++u) {
+                            const int j = sub + 16 * u;
+                            if (j < n) {
+                                Lc[a * ld + j] = cs * gp[u] - sn * gq[u];
+                                Lc[b * ld + j] = sn * gp[u] + cs * gq[u];
+                            }
+                        }
+                        if (sub == 0) { nrm[a] = al - t * gam; nrm[b] = be + t * gam; red[16] = 1.0; }
+                    }
+                }
+                __syncthreads();
+            }
+            ++sweep;
+            const bool again = red[16] != 0.0 && sweep < MG_MAXSWEEP;
+            __syncthreads();
+            if (!again) break;
+        }
+    }
+    // ---- lambda_i = |column i|^2 - delta, u_i = column_i / |column i|
+    for (int i0 = 0; i0 < n; i0 += ngrp) {
+        const int i = i0 + grp;
+        double sq = 0.0;
+        if (i < n)
+            for (int j = sub; j < n; j += 16) { const double v = Lc[i * ld + j]; sq += v * v; }
+        sq = mg_row16_sum(sq);
+        if (i < n && sub == 0) { nrm[i] = sq; lamv[i] = sq - delta; }
+    }
+    __syncthreads();
+    for (int k = c.tid; k < n * n; k += MG_NT) {       // transposed + normalised into the M area ...
+        const int i = k / n, j = k - i * n;
+        const double l2 = nrm[i];
+        A[j * ld + i] = l2 > 0.0 ? Lc[i * ld + j] * mg_rsqrt(l2) : 0.0;
+    }
+    __syncthreads();
+    for (int k = c.tid; k < n * n; k += MG_NT) {       // ... and back into V
+        const int i = k / n, j = k - i * n;
+        Lc[i * ld + j] = A[i * ld + j];
+    }
+    __syncthreads();
+    for (int i = c.tid; i < n; i += MG_NT) A[i * ld + i] = lamv[i];
+    __syncthreads();
+    return sweep | (attempts << 8);
+}
+
 DEV bool mg_fast_ok(int n) {
     const int half = (n + 1) / 2;
     return n >= 2 && half * (half + 1) / 2 <= MG_NT && n * half <= 4 * (MG_NT - 64);
@@ -843,8 +1013,8 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         const long long _t1 = clock64();
 #endif
         const int offcs = (int)(cs - MG_LDS), offred = (int)(red - MG_LDS);
-        const bool fast1 = in_lds && mg_fast_ok(m);
-        const int sw1 = fast1 ? jacobi_eig_fast(c, 0, ld * ld, m, ldm, offcs, offred, true)
+        const bool fast1 = in_lds && m >= 1 && m <= 16 * MG_HROWS;
+        const int sw1 = fast1 ? (vh_eig(c, 0, ld * ld, m, ldm, offcs, offred, 0.0, 1e-16) & 255)
                       : in_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, m, ldm, offcs, offred, true)
                                : jacobi_eig<false>(c, Mm, Vm, 0, 0, m, ldm, offcs, offred, true);
 #ifdef BA_PROFILE
@@ -899,8 +1069,8 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     const long long _t2 = clock64();
 #endif
     const int offcs2 = (int)(cs - MG_LDS), offred2 = (int)(red - MG_LDS);
-    const bool fast2 = n_lds && mg_fast_ok(n);
-    const int sw2 = fast2 ? jacobi_eig_fast(c, 0, ld * ld, n, ld2, offcs2, offred2, false)
+    const bool fast2 = n_lds && n >= 1 && n <= 16 * MG_HROWS;
+    const int sw2 = fast2 ? (vh_eig(c, 0, ld * ld, n, ld2, offcs2, offred2, 1e-9, 1e-14) & 255)
                   : n_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, n, ld2, offcs2, offred2, false)
                           : jacobi_eig<false>(c, M2, V2, 0, 0, n, ld2, offcs2, offred2, false);
 #ifdef BA_PROFILE

@@ -33,6 +33,17 @@ extern __shared__ __attribute__((aligned(16))) char bp_smem[];
 #define LDSB ((double*)bp_smem)
 typedef double double4_t __attribute__((vector_size(32)));      // v_mfma_f64_16x16x4 accumulator (4 VGPR pairs)
 
+// optional phase timers of the solve kernel (build with -DBA_PROFILE): thread 0 accumulates s_memtime deltas per phase into
+// the trace area of the output slab (vg_ba_summary.prof), summed over the rounds of a solve
+#ifdef BA_PROFILE
+#define PROF_DECL long long _pt = clock64(); double* _pf = out + L.oo_trace + 5 * VG_MAX_ITERS
+#define PROF_ADD(id) do { if (c.tid == 0) { const long long _n = clock64(); _pf[id] += (double)(_n - _pt); _pt = _n; } } while (0)
+#else
+#define PROF_DECL
+#define PROF_ADD(id)
+#endif
+enum { PF_JUDGE = 0, PF_ASM, PF_DG, PF_BUILD, PF_CHAIN, PF_SCHUR, PF_CHOL, PF_BACK, PF_CBACK, PF_LMY, PF_NORMS, PF_CAND, PF_TAIL };
+
 // R-vectors of the solve kernel in LDS, columns [camera Rc | speed-bias 9K]
 enum { V_G = 0, V_SC, V_DG, V_GT, V_GN, V_U, V_Y, V_T, V_DI, V_NVEC };
 
@@ -1231,6 +1242,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     double* gnl = c.sc + L.so_gn + L.Rpad;
     double* yl = c.sc + L.so_yl;
 
+    PROF_DECL;
     // prior column map (prior column -> reduced column or -1)
     if (c.nprior) {
         const int* kind = c.ia + L.io_pb_kind;
@@ -1262,6 +1274,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
         if (!(s.cost == s.cost) || !(s.cost < 1e300)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
         fresh_point = true;
     }
+    PROF_ADD(PF_JUDGE);
     const double* buf = lin_buf(c, s.cur);
     const double* hh = buf + L.bo_h;
     const double* bb = buf + L.bo_b;
@@ -1282,6 +1295,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     }
     for (int k = c.tid; k < R; k += BA_NT) vSC[k] = c.sc[L.so_sc + k];
     __syncthreads();
+    PROF_ADD(PF_ASM);
 
     const double* x = c.sc + L.so_x + s.cur * L.nst;
     const double* lam = c.sc + L.so_lam + s.cur * L.Lcap;
@@ -1297,6 +1311,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
         if (!s.reuse) {
             s.reuse = 1;
             if (!assembled) { assemble(c, m, buf); assembled = true; }
+            PROF_ADD(PF_ASM);
             // Dg, gt (scaled gradient / Dg), t = gt / Dg
             for (int k = c.tid; k < R; k += BA_NT) {
                 double d2 = vSC[k] * vSC[k] * hess_diag(L, m, k);
@@ -1322,21 +1337,28 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
                 for (int l = c.tid; l < nL; l += BA_NT) sq += gtl[l] * gtl[l];
                 s.gtn2 = block_sum(m.red, BA_NW, c.lane, c.wave, sq);
             }
+            PROF_ADD(PF_DG);
             // Gauss-Newton step, increasing mu on failure (DoglegStrategy::ComputeGaussNewtonStep)
             bool solved = false;
             while (s.mu < max_mu) {
-                if (!assembled) { assemble(c, m, buf); assembled = true; }
+                if (!assembled) { assemble(c, m, buf); assembled = true; PROF_ADD(PF_ASM); }
                 double q = build_scaled(c, m, s.mu);
                 assembled = false;
                 __syncthreads();
+                PROF_ADD(PF_BUILD);
                 bool cok = chain_eliminate(c, m);
+                PROF_ADD(PF_CHAIN);
                 q += schur_mfma(c, m, buf, s.mu);
                 q = block_sum(m.red, BA_NW, c.lane, c.wave, q);
                 s.alpha = s.gtn2 / q;            // |gt|^2 / |J~ (gt/Dg)|^2
+                PROF_ADD(PF_SCHUR);
                 if (cok) cok = cholesky_aug(c, m, Rc);
+                PROF_ADD(PF_CHOL);
                 if (cok) {
                     back_substitute(c, m, Rc);
+                    PROF_ADD(PF_BACK);
                     chain_back_substitute(c, m);
+                    PROF_ADD(PF_CBACK);
                     // landmarks: y_l = (bt_l - wt_l . y_cam) / ht_l
                     const double* Wt = buf + L.bo_Wt;
                     for (int l = c.tid; l < nL; l += BA_NT) {
@@ -1348,7 +1370,9 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
                     double fin = 0.0;
                     for (int k = c.tid; k < R; k += BA_NT) fin += (vY[k] == vY[k] && fabs(vY[k]) < 1e300) ? 0.0 : 1.0;
                     for (int k = c.tid; k < nL; k += BA_NT) fin += (yl[k] == yl[k] && fabs(yl[k]) < 1e300) ? 0.0 : 1.0;
-                    if (block_sum(m.red, BA_NW, c.lane, c.wave, fin) == 0.0) { solved = true; s.mu_solved = s.mu; break; }
+                    const bool finite = block_sum(m.red, BA_NW, c.lane, c.wave, fin) == 0.0;
+                    PROF_ADD(PF_LMY);
+                    if (finite) { solved = true; s.mu_solved = s.mu; break; }
                 }
                 s.mu *= 10.0;
             }
@@ -1378,6 +1402,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
             }
             __syncthreads();
         }
+        PROF_ADD(PF_NORMS);
         double model_change = 0.0;
         double c_gt = 0.0, c_gn = 0.0;
         if (ok) {
@@ -1454,11 +1479,13 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
             out[L.oo_trace + 4 * VG_MAX_ITERS + slot] = s.dnorm;
         }
         s.pending = 1;
+        PROF_ADD(PF_CAND);
         break;
     }
     if (!s.pending) s.done = 1;
     __syncthreads();
     if (c.tid == 0) ctl_store(s, ctlp);
+    PROF_ADD(PF_TAIL);
 }
 
 // ================================================================================================
