@@ -137,7 +137,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         const int nb = L.Kp + L.e + L.t;
         L.ntask = nb * (nb + 1) / 2;
         const int per = BA_ACC_NT / 64;
-        L.nba = (L.ntask + (L.Lcap + 63) / 64 + per - 1) / per;
+        L.nba = L.Kp + (L.ntask - L.Kp + (L.Lcap + 63) / 64 + per - 1) / per;   // diagonal pose blocks get a workgroup each
     }
     // ---- LDS carve of the solve kernel
     {
@@ -153,7 +153,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         L.l_dinv = o; o += up(9 * L.K, 2);
         L.l_vec = o; o += 9 * L.Rpad;
         L.l_red = o; o += 32;
-        L.l_wd = o; o += up(std::max(L.RcPad * 17, 9 * L.K), 2);
+        L.l_wd = o; o += up(std::max(L.RcPad * 33, 9 * L.K), 2);       // staged landmark tile [RcPad][32 + 1]
         L.l_z = o; o += up(36 * L.K, 2);
         L.l_pmap = o; o += up(L.Ncap, 4) / 2;
         L.lds_solve = o * 8;
@@ -174,6 +174,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.io_fac_oj = o; o += L.Fcap;
     L.io_fac_slot = o; o += L.Fcap;
     L.io_pair_ptr = o; o += up(L.Kp * L.Kp + 1, 8);
+    L.io_task_list = o; o += up(L.ntask, 8);
     L.io_imu_valid = o; o += up(L.K, 8);
     L.io_pb_kind = o; o += L.NBcap;
     L.io_pb_idx = o; o += L.NBcap;
@@ -313,6 +314,14 @@ static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, 
         for (int f = 0; f < F; ++f) ia[L.io_fac_slot + f] = cursor[fac[f].i * Kp + fac[f].j]++;
     }
     const int nchunk = 1;
+    {
+        // owner tasks other than the diagonal pose blocks (packed-triangle index of the block)
+        const int nb = Kp + L.e + L.t;
+        int n = 0;
+        for (int br = 0; br < nb; ++br)
+            for (int bc = 0; bc <= br; ++bc)
+                if (!(br == bc && br < Kp)) ia[L.io_task_list + n++] = br * (br + 1) / 2 + bc;
+    }
     hdr[H_L] = p->L; hdr[H_F] = F; hdr[H_NPRIOR] = p->prior_n; hdr[H_NBLK] = p->prior_n ? p->prior_nblocks : 0;
     hdr[H_MAXIT] = p->max_iters; hdr[H_NCHUNK] = nchunk; hdr[H_MARGIN] = margin; hdr[H_STATUS] = 0;
     // state

@@ -24,7 +24,7 @@ enum { H_L = 0, H_F, H_NPRIOR, H_NBLK, H_MAXIT, H_NCHUNK, H_MARGIN, H_STATUS };
 // per-window solver state that lives in HBM between the launches of one solve (doubles; integers stored exactly)
 enum {
     C_IT = 0, C_NACC, C_NINV, C_TERM, C_STATUS, C_RADIUS, C_MU, C_MUSOLVED, C_REUSE, C_COST, C_XNORM, C_ALPHA, C_GTN2,
-    C_GNN2, C_GTGN, C_DNORM, C_MODEL, C_CUR, C_PENDING, C_DONE, C_STEPNORM, C_XNORMC, C_INITCOST, C_SCALED, C_NCTL = 32
+    C_GNN2, C_GTGN, C_DNORM, C_MODEL, C_CUR, C_PENDING, C_DONE, C_STEPNORM, C_XNORMC, C_INITCOST, C_SCALED, C_QCAM, C_NCTL = 32
 };
 
 struct BaLayout {
@@ -36,7 +36,7 @@ struct BaLayout {
     int nst;                       // doubles of one state copy [pose Kp*7 | sb K*9 | ex 7 | td 1]
     // ---- int arrays (offsets in ints, per window)
     int io_hdr, io_lm_start, io_lm_fbeg, io_fac_i, io_fac_j, io_fac_lm, io_fac_oi, io_fac_oj, io_fac_slot,
-        io_pair_ptr, io_imu_valid, io_pb_kind, io_pb_idx, io_pb_col, io_pb_off, io_pb_x0off, istride;
+        io_pair_ptr, io_task_list, io_imu_valid, io_pb_kind, io_pb_idx, io_pb_col, io_pb_off, io_pb_x0off, istride;
     // ---- double inputs (offsets in doubles, per window)
     int do_pose, do_sb, do_ex, do_td, do_lam, do_obs, do_imu, do_pJ0, do_pJ0t, do_pr0, do_px0, do_par, dstride;
     // ---- scratch (doubles, per window)

@@ -498,15 +498,19 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
         const double floor_ = fmax(0.01 * delta, 1e-15 * dmax0);
         bool broke = false;
         for (int k = 0; k < n; ++k) {
-            // pivot = largest remaining diagonal (first index on ties): every thread scans the <= 96 values (uniform)
-            int p = 0;
-            double best = -1e300;
-            for (int i = 0; i < n; ++i) {
-                const double v = dgn[i];
-                if (!taken[i] && v > best) { best = v; p = i; }
+            // pivot = largest remaining diagonal (lowest index on ties), found by wavefront 0 (two entries per lane, DPP max)
+            if (c.wave == 0) {
+                const int i0 = c.lane, i1 = c.lane + 64;
+                const double v0 = (i0 < n && !taken[i0]) ? dgn[i0] : -1e300;
+                const double v1 = (i1 < n && !taken[i1]) ? dgn[i1] : -1e300;
+                const double bv = wave_max_all(fmax(v0, v1));
+                const unsigned long long m0 = __ballot(v0 == bv), m1 = __ballot(v1 == bv);
+                if (c.lane == 0) { red[17] = bv; red[18] = (double)(m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1); }
             }
-            if (!(best > floor_)) { broke = true; break; }
             __syncthreads();
+            const double best = red[17];
+            const int p = (int)red[18];
+            if (!(best > floor_)) { broke = true; break; }
             const double inv = mg_rsqrt(best);
             // L[i][k] = (A[i][p] - sum_{j<k} L[i][j] L[p][j]) / L[p][k] for the rows not taken yet; 8 lanes per row
             const int g8 = c.tid >> 3, s8 = c.tid & 7;
@@ -521,17 +525,19 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
                     const double v = i == p ? best * inv : (A[i * ld + p] - sacc) * inv;
                     Lc[k * ld + i] = v;
                     if (i != p) dgn[i] -= v * v;
+                    else taken[p] = 1;             // by the lane that owns row p, after its 8-lane group has tested the flag
                 }
             }
             __syncthreads();
-            if (c.tid == 0) taken[p] = 1;
-            __syncthreads();
         }
+        __syncthreads();
         if (!broke || attempts >= 12) break;
         delta = fmax(16.0 * delta, 1e-12 * dmax0);
     }
     // ---- one-sided Jacobi on the n columns (length n) of L
     const int N = (n + 1) & ~1, npairs = N / 2, nrounds = N - 1;
+    const int hrows = (n + 15) / 16;           // elements of a column per lane actually present
+    const double tol2 = tol * tol;
     int sweep = 0;
     if (n >= 2) {
         for (;;) {
@@ -545,11 +551,10 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
             }
             if (c.tid == 0) red[16] = 0.0;
             __syncthreads();
+            // round-robin tournament: player N-1 stays, the others rotate: group g plays (r + g, r - g) mod N-1 in round r,
+            // i.e. both indices advance by one per round (kept incrementally: no integer division in the loop)
+            int a = grp < npairs ? grp : 0, b = grp == 0 ? N - 1 : (grp < npairs ? N - 1 - grp : 0);
             for (int r = 0; r < nrounds; ++r) {
-                // round-robin tournament: player N-1 stays, the others rotate
-                int a, b;
-                if (grp == 0) { a = r; b = N - 1; }
-                else { a = (r + grp) % (N - 1); b = (r - grp + (N - 1)) % (N - 1); }
                 const bool act = grp < npairs && a < n && b < n;
                 double gp[MG_HROWS], gq[MG_HROWS];
                 double gam = 0.0;
@@ -557,30 +562,38 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
                 for (int t = 0; t < MG_HROWS; ++t) {
                     const int j = sub + 16 * t;
                     const bool in = act && j < n;
-                    gp[t] = in ? Lc[a * ld + j] : 0.0;
-                    gq[t] = in ? Lc[b * ld + j] : 0.0;
-                    gam += gp[t] * gq[t];
+                    if (t < hrows) {
+                        gp[t] = in ? Lc[a * ld + j] : 0.0;
+                        gq[t] = in ? Lc[b * ld + j] : 0.0;
+                        gam += gp[t] * gq[t];
+                    } else { gp[t] = 0.0; gq[t] = 0.0; }
                 }
                 gam = mg_row16_sum(gam);
                 // every lane of the pair reads the norms before lane 0 of the pair may replace them
                 const double al = act ? nrm[a] : 1.0, be = act ? nrm[b] : 1.0;
                 __builtin_amdgcn_wave_barrier();
-                if (act) {
-                    if (fabs(gam) > tol * sqrt(al * be) && al > 0.0 && be > 0.0) {
-                        const double zeta = (be - al) / (2.0 * gam);
-                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        const double cs = mg_rsqrt(1.0 + t * t), sn = cs * t;
+                if (act && gam * gam > tol2 * al * be && al > 0.0 && be > 0.0) {
+                    // rotation that annihilates g_p . g_q, from cos 2phi = |d| / hypot(d, 2 gamma) with two rsqrt chains
+                    // and no division:  c = sqrt((1 + cos 2phi) / 2),  s = sign(d) gamma / (hypot c),  t = s / c
+                    const double d = be - al, g2 = 2.0 * gam;
+                    const double rh = mg_rsqrt(d * d + g2 * g2);
+                    const double xx = 0.5 + 0.5 * fabs(d) * rh;          // c^2 in [1/2, 1]
+                    const double rc = mg_rsqrt(xx);                       // 1 / c
+                    const double cs = xx * rc;
+                    const double sn = (d >= 0.0 ? 0.5 : -0.5) * g2 * rh * rc;
+                    const double t = sn * rc;
 #pragma unroll
-                        for (int u = 0; u < MG_HROWS; ++u) {
-                            const int j = sub + 16 * u;
-                            if (j < n) {
-                                Lc[a * ld + j] = cs * gp[u] - sn * gq[u];
-                                Lc[b * ld + j] = sn * gp[u] + cs * gq[u];
-                            }
+                    for (int u = 0; u < MG_HROWS; ++u) {
+                        const int j = sub + 16 * u;
+                        if (u < hrows && j < n) {
+                            Lc[a * ld + j] = cs * gp[u] - sn * gq[u];
+                            Lc[b * ld + j] = sn * gp[u] + cs * gq[u];
                         }
-                        if (sub == 0) { nrm[a] = al - t * gam; nrm[b] = be + t * gam; red[16] = 1.0; }
                     }
+                    if (sub == 0) { nrm[a] = al - t * gam; nrm[b] = be + t * gam; red[16] = 1.0; }
                 }
+                a = a + 1 == N - 1 ? 0 : a + 1;
+                if (grp != 0) b = b + 1 == N - 1 ? 0 : b + 1;
                 __syncthreads();
             }
             ++sweep;
@@ -1070,7 +1083,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
 #endif
     const int offcs2 = (int)(cs - MG_LDS), offred2 = (int)(red - MG_LDS);
     const bool fast2 = n_lds && n >= 1 && n <= 16 * MG_HROWS;
-    const int sw2 = fast2 ? (vh_eig(c, 0, ld * ld, n, ld2, offcs2, offred2, 1e-9, 1e-14) & 255)
+    const int sw2 = fast2 ? (vh_eig(c, 0, ld * ld, n, ld2, offcs2, offred2, 2e-8, 1e-14) & 255)
                   : n_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, n, ld2, offcs2, offred2, false)
                           : jacobi_eig<false>(c, M2, V2, 0, 0, n, ld2, offcs2, offred2, false);
 #ifdef BA_PROFILE

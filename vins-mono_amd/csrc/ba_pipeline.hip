@@ -117,21 +117,21 @@ DEV double* lin_buf(const Ctx& c, int which) { return c.sc + c.Lp->so_buf + (siz
 // ---- solver state carried between launches -----------------------------------------------------------------------
 struct Ctl {
     int it, nacc, ninv, term, status, reuse, cur, pending, done, scaled;
-    double radius, mu, mu_solved, cost, x_norm, alpha, gtn2, gnn2, gtgn, dnorm, model, step_norm, x_norm_c, init_cost;
+    double radius, mu, mu_solved, cost, x_norm, alpha, gtn2, gnn2, gtgn, dnorm, model, step_norm, x_norm_c, init_cost, qcam;
 };
 DEV void ctl_load(Ctl& s, const double* p) {
     s.it = (int)p[C_IT]; s.nacc = (int)p[C_NACC]; s.ninv = (int)p[C_NINV]; s.term = (int)p[C_TERM]; s.status = (int)p[C_STATUS];
     s.reuse = (int)p[C_REUSE]; s.cur = (int)p[C_CUR]; s.pending = (int)p[C_PENDING]; s.done = (int)p[C_DONE]; s.scaled = (int)p[C_SCALED];
     s.radius = p[C_RADIUS]; s.mu = p[C_MU]; s.mu_solved = p[C_MUSOLVED]; s.cost = p[C_COST]; s.x_norm = p[C_XNORM];
     s.alpha = p[C_ALPHA]; s.gtn2 = p[C_GTN2]; s.gnn2 = p[C_GNN2]; s.gtgn = p[C_GTGN]; s.dnorm = p[C_DNORM]; s.model = p[C_MODEL];
-    s.step_norm = p[C_STEPNORM]; s.x_norm_c = p[C_XNORMC]; s.init_cost = p[C_INITCOST];
+    s.step_norm = p[C_STEPNORM]; s.x_norm_c = p[C_XNORMC]; s.init_cost = p[C_INITCOST]; s.qcam = p[C_QCAM];
 }
 DEV void ctl_store(const Ctl& s, double* p) {
     p[C_IT] = s.it; p[C_NACC] = s.nacc; p[C_NINV] = s.ninv; p[C_TERM] = s.term; p[C_STATUS] = s.status;
     p[C_REUSE] = s.reuse; p[C_CUR] = s.cur; p[C_PENDING] = s.pending; p[C_DONE] = s.done; p[C_SCALED] = s.scaled;
     p[C_RADIUS] = s.radius; p[C_MU] = s.mu; p[C_MUSOLVED] = s.mu_solved; p[C_COST] = s.cost; p[C_XNORM] = s.x_norm;
     p[C_ALPHA] = s.alpha; p[C_GTN2] = s.gtn2; p[C_GNN2] = s.gnn2; p[C_GTGN] = s.gtgn; p[C_DNORM] = s.dnorm; p[C_MODEL] = s.model;
-    p[C_STEPNORM] = s.step_norm; p[C_XNORMC] = s.x_norm_c; p[C_INITCOST] = s.init_cost;
+    p[C_STEPNORM] = s.step_norm; p[C_XNORMC] = s.x_norm_c; p[C_INITCOST] = s.init_cost; p[C_QCAM] = s.qcam;
 }
 
 // Judge the pending candidate (TrustRegionMinimizer: parameter tolerance, function tolerance, step quality; then
@@ -479,15 +479,62 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_kernel(const Ba
 // ================================================================================================
 // Accumulation kernel: J^T J / J^T r of the projection factors from their records.
 // ================================================================================================
-// sum over slots [b,e) of  rec[offA..+1] . rec[offB..+1]
+// sum over slots [b,e) of  rec[offA..+1] . rec[offB..+1]   (two independent accumulation chains: the loads of
+// consecutive records are in flight together; fixed order -> deterministic)
 DEV double seg_dot(const double* recs, int REC, int b, int e, int offA, int offB) {
-    double acc = 0.0;
-    for (int s = b; s < e; ++s) {
+    double acc0 = 0.0, acc1 = 0.0;
+    int s = b;
+    for (; s + 1 < e; s += 2) {
         const double2 a2 = *(const double2*)(recs + (size_t)s * REC + offA);
         const double2 b2 = *(const double2*)(recs + (size_t)s * REC + offB);
-        acc += a2.x * b2.x + a2.y * b2.y;
+        const double2 a3 = *(const double2*)(recs + (size_t)(s + 1) * REC + offA);
+        const double2 b3 = *(const double2*)(recs + (size_t)(s + 1) * REC + offB);
+        acc0 += a2.x * b2.x + a2.y * b2.y;
+        acc1 += a3.x * b3.x + a3.y * b3.y;
     }
-    return acc;
+    if (s < e) {
+        const double2 a2 = *(const double2*)(recs + (size_t)s * REC + offA);
+        const double2 b2 = *(const double2*)(recs + (size_t)s * REC + offB);
+        acc0 += a2.x * b2.x + a2.y * b2.y;
+    }
+    return acc0 + acc1;
+}
+
+// Diagonal pose block a of the camera system: it visits every factor anchored at or targeting frame a (~10x the visits
+// of an off-diagonal block), so one workgroup of 4 wavefronts owns it: 21 lower entries + 6 gradient entries on lanes
+// 0-26 / 27-53 of every wavefront = 8 lane segments that each take an eighth of every (anchor, target) slot range; the
+// eight partial sums are combined through LDS in a fixed order.
+DEV void diag_pose_task(const Ctx& c, int a, const double* recs, double* Sp, double* gp, double* part) {
+    const BaLayout& L = *c.Lp;
+    const int Kp = L.Kp, REC = L.REC;
+    const int* ptr = c.ia + L.io_pair_ptr;
+    const int seg = c.lane >= 27 ? 1 : 0, e = c.lane - 27 * seg;
+    const int sidx = 2 * c.wave + seg;            // 0..7
+    const bool on = c.lane < 54;
+    const bool isg = e >= 21;
+    int p2 = 0, q2 = 0;
+    if (!isg) tri_decode(e, p2, q2); else p2 = e - 21;
+    double sum = 0.0;
+    if (on) {
+        const int oB_i = isg ? 26 : 2 * q2, oB_j = isg ? 26 : 12 + 2 * q2;
+        {
+            const int s0 = ptr[a * Kp], len = ptr[(a + 1) * Kp] - s0;
+            sum += seg_dot(recs, REC, s0 + len * sidx / 8, s0 + len * (sidx + 1) / 8, 2 * p2, oB_i);
+        }
+        for (int a2 = 0; a2 < a; ++a2) {
+            const int s0 = ptr[a2 * Kp + a], len = ptr[a2 * Kp + a + 1] - s0;
+            sum += seg_dot(recs, REC, s0 + len * sidx / 8, s0 + len * (sidx + 1) / 8, 12 + 2 * p2, oB_j);
+        }
+        part[sidx * 27 + e] = sum;
+    }
+    __syncthreads();
+    if (c.tid < 27) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tot += part[q * 27 + c.tid];
+        if (c.tid >= 21) gp[6 * a + c.tid - 21] = tot;
+        else Sp[tri(6 * a + p2, 6 * a + q2)] = tot;
+    }
 }
 
 // Owner task = one (<=6)x(<=6) block of the camera part of S: lane = entry (p,q); lanes 36..41 of diagonal tasks own the
@@ -507,36 +554,6 @@ DEV void owner_task(const Ctx& c, int task, int lane, const double* recs, double
     const int rowbase = kr == 0 ? 6 * br : (kr == 1 ? col_ex(L) : col_td(L));
     const int colbase = kc == 0 ? 6 * bc : (kc == 1 ? col_ex(L) : col_td(L));
     const bool diag = br == bc;
-    if (kr == 0 && kc == 0 && diag) {
-        // diagonal pose block: visits every factor anchored at or targeting frame a (~10x the visits of an off-diagonal
-        // block): its 21 lower entries + 6 gradient entries are spread over TWO lane segments (0-26 / 27-53) that each
-        // take half of every slot range; fixed split -> deterministic
-        const int a = br;
-        const int seg = lane >= 27 ? 1 : 0, e = lane - 27 * seg;
-        const bool on = lane < 54;
-        const bool isg2 = e >= 21;
-        int p2 = 0, q2 = 0;
-        if (!isg2) tri_decode(e, p2, q2); else p2 = e - 21;
-        double part = 0.0;
-        if (on) {
-            const int oB_i = isg2 ? 26 : 2 * q2, oB_j = isg2 ? 26 : 12 + 2 * q2;
-            {
-                const int s0 = ptr[a * Kp], s1 = ptr[(a + 1) * Kp], mid = (s0 + s1) >> 1;
-                part += seg_dot(recs, REC, seg ? mid : s0, seg ? s1 : mid, 2 * p2, oB_i);
-            }
-            for (int a2 = 0; a2 < a; ++a2) {
-                const int s0 = ptr[a2 * Kp + a], s1 = ptr[a2 * Kp + a + 1], mid = (s0 + s1) >> 1;
-                part += seg_dot(recs, REC, seg ? mid : s0, seg ? s1 : mid, 12 + 2 * p2, oB_j);
-            }
-        }
-        const double other = __shfl_down(part, 27, 64);
-        if (lane < 27) {
-            const double tot = part + other;
-            if (isg2) gp[rowbase + p2] = tot;
-            else Sp[tri(rowbase + p2, colbase + q2)] = tot;
-        }
-        return;
-    }
     const bool isg = diag && lane >= 36 && lane < 36 + dr;
     const int p = isg ? lane - 36 : lane / 6, q = isg ? 0 : lane % 6;
     const bool act = isg || (lane < 36 && p < dr && q < dc && (!diag || q <= p));
@@ -602,7 +619,8 @@ DEV void landmark_task(const Ctx& c, int l, const double* recs, double* buf) {
     buf[L.bo_b + l] = b;
 }
 
-// grid (nba, nwin), BA_ACC_NT threads: wavefront tasks 0 .. ntask-1 = owner blocks, then 64 landmarks per wavefront
+// grid (nba, nwin), BA_ACC_NT threads: workgroups 0 .. Kp-1 = the diagonal pose blocks; afterwards wavefront tasks: the other
+// owner blocks (host table io_task_list of packed-triangle block indices), then 64 landmarks per wavefront
 extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
     const BaLayout& L = *Lp;
     Ctx c;
@@ -612,10 +630,13 @@ extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(con
     const int which = ((int)ctl[C_CUR]) ^ (ctl[C_PENDING] != 0.0 ? 1 : 0);
     double* buf = lin_buf(c, which);
     const double* recs = c.sc + L.so_rec;
-    const int g = blockIdx.x * (BA_ACC_NT / 64) + c.wave;
-    if (g < L.ntask) owner_task(c, g, c.lane, recs, buf + L.bo_Sp, buf + L.bo_gp);
+    __shared__ double part[8 * 27];
+    if ((int)blockIdx.x < L.Kp) { diag_pose_task(c, blockIdx.x, recs, buf + L.bo_Sp, buf + L.bo_gp, part); return; }
+    const int g = (blockIdx.x - L.Kp) * (BA_ACC_NT / 64) + c.wave;
+    const int nother = L.ntask - L.Kp;
+    if (g < nother) owner_task(c, c.ia[L.io_task_list + g], c.lane, recs, buf + L.bo_Sp, buf + L.bo_gp);
     else {
-        const int l = (g - L.ntask) * 64 + c.lane;
+        const int l = (g - nother) * 64 + c.lane;
         if (l < L.Lcap) landmark_task(c, l, recs, buf);
     }
 }
@@ -894,20 +915,21 @@ NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
 }
 
 // Schur complement on the camera part, rhs as the augmented row Rc:
-//   S -= Wd Wd^T  with the 9K rows of X (chain) and, 16 at a time, the landmark columns
+//   S -= Wd Wd^T  with the 9K rows of X (chain) and, 32 at a time, the landmark columns
 //   Wd[c][l] = sc[c] * Wt[c][l] * lsc[l],  Wd[Rc][l] = b[l] * lsc[l],  lsc[l] = sl[l] / sqrt(sl^2 h + mu dgl^2).
-// 16x16 tiles accumulate in registers on v_mfma_f64_16x16x4_f64; two tiles per wavefront.
-// Also returns this thread's share of the landmark part of t^T H~ t:  sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ].
-NOINL double schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double mu) {
+// 16x16 tiles accumulate in registers on v_mfma_f64_16x16x4_f64, up to three tiles per wavefront; the Wt values of the
+// next 32 landmarks are fetched into registers while the current tile is multiplied.
+#define SCHUR_LW 32                               // landmarks per staged tile
+#define SCHUR_LD (SCHUR_LW + 1)
+#define SCHUR_PF ((96 * SCHUR_LW + BA_NT - 1) / BA_NT)
+NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double mu) {
     const BaLayout& L = *c.Lp;
     const double* sc = m.vec + V_SC * L.Rpad;
-    const double* tv = m.vec + V_T * L.Rpad;
     const double* Wt = buf + L.bo_Wt;
     const double* h = buf + L.bo_h;
     const double* b = buf + L.bo_b;
     const double* sl = c.sc + L.so_sl;
     const double* dgl = c.sc + L.so_dg + L.Rpad;
-    const double* gtl = c.sc + L.so_gt + L.Rpad;
     double* lsc = c.sc + L.so_lsc;
     const int Rc = L.Rc, RcPad = L.RcPad, ldc = m.ldc;
     const int nt = RcPad / 16;
@@ -922,6 +944,7 @@ NOINL double schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, doub
         tri_decode(t, a, bq);
         tm[s] = a; tn[s] = bq;
     }
+    for (int l = c.tid; l < c.nL; l += BA_NT) lsc[l] = sl[l] / sqrt(sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l]);
     // ---- chain rows
     const int nk = (9 * L.K + 3) / 4;
     for (int kk = 0; kk < nk; ++kk) {
@@ -935,38 +958,43 @@ NOINL double schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, doub
             }
         }
     }
-    // ---- landmark columns
-    double qland = 0.0;
-    for (int l = c.tid; l < c.nL; l += BA_NT) lsc[l] = sl[l] / sqrt(sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l]);
-    for (int l0 = 0; l0 < c.nL; l0 += 16) {
-        __syncthreads();
-        for (int w = c.tid; w < RcPad * 16; w += BA_NT) {
-            const int row = w / 16, k = w % 16, l = l0 + k;
-            const bool in = row < Rc && l < c.nL;
-            const double wv = Wt[(size_t)(in ? row : 0) * L.Lcap + (in ? l : 0)];
-            double v = in ? sc[row] * wv * lsc[l] : 0.0;
-            if (row == Rc && l < c.nL) v = b[l] * lsc[l];
-            m.wd[row * 17 + k] = v;
+    // ---- landmark columns: element w = tid + BA_NT * i of the (RcPad x SCHUR_LW) tile -> row w / 32, landmark l0 + w % 32
+    double pre[SCHUR_PF];
+    const int nel = RcPad * SCHUR_LW;
+    auto fetch = [&](int l0) {
+#pragma unroll
+        for (int i = 0; i < SCHUR_PF; ++i) {
+            const int w = c.tid + BA_NT * i;
+            const int row = w / SCHUR_LW, l = l0 + (w % SCHUR_LW);
+            const bool in = w < nel && row < Rc && l < c.nL;
+            pre[i] = in ? Wt[(size_t)row * L.Lcap + l] : 0.0;
+        }
+    };
+    if (c.nL > 0) fetch(0);
+    for (int l0 = 0; l0 < c.nL; l0 += SCHUR_LW) {
+        __syncthreads();                           // lsc visible (first trip) / previous tile consumed
+#pragma unroll
+        for (int i = 0; i < SCHUR_PF; ++i) {
+            const int w = c.tid + BA_NT * i;
+            if (w < nel) {
+                const int row = w / SCHUR_LW, k = w % SCHUR_LW, l = l0 + k;
+                double v = (row < Rc && l < c.nL) ? sc[row] * pre[i] * lsc[l] : 0.0;
+                if (row == Rc && l < c.nL) v = b[l] * lsc[l];
+                m.wd[row * SCHUR_LD + k] = v;
+            }
         }
         __syncthreads();
+        if (l0 + SCHUR_LW < c.nL) fetch(l0 + SCHUR_LW);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (c.wave + s * BA_NW < ntile) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double a = m.wd[(tm[s] * 16 + (c.lane & 15)) * 17 + kk * 4 + (c.lane >> 4)];
-                    const double bb = m.wd[(tn[s] * 16 + (c.lane & 15)) * 17 + kk * 4 + (c.lane >> 4)];
+                for (int kk = 0; kk < SCHUR_LW / 4; ++kk) {
+                    const double a = m.wd[(tm[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
+                    const double bb = m.wd[(tn[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
                     acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[s], 0, 0, 0);
                 }
             }
-        }
-        // landmark part of t^T H~ t from the staged tile: w~_l . t_cam = (sum_row wd[row][k] t[row]) / lsc_l
-        if (c.tid < 16 && l0 + c.tid < c.nL) {
-            const int l = l0 + c.tid;
-            double wdot = 0.0;
-            for (int row = 0; row < Rc; ++row) wdot += m.wd[row * 17 + c.tid] * tv[row];
-            const double tl = gtl[l] / dgl[l];
-            qland += sl[l] * sl[l] * h[l] * tl * tl + 2.0 * tl * sl[l] * (wdot / lsc[l]);
         }
     }
     __syncthreads();
@@ -983,7 +1011,33 @@ NOINL double schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, doub
         }
     }
     __syncthreads();
-    return qland;
+}
+
+// Landmark part of  t^T H~ t  (the Cauchy-point denominator, see build_scaled):  sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ]
+// with t = gt / Dg.  Only needed when the Gauss-Newton step leaves the trust region, so it is evaluated on demand
+// (thread per landmark, one pass over Wt).  Returns this thread's share.
+NOINL double cauchy_landmark_term(const Ctx& c, const SolveLds& m, const double* buf) {
+    const BaLayout& L = *c.Lp;
+    const double* sc = m.vec + V_SC * L.Rpad;
+    const double* gt = m.vec + V_GT * L.Rpad;
+    const double* dg = m.vec + V_DG * L.Rpad;
+    double* tv = m.vec + V_T * L.Rpad;
+    const double* Wt = buf + L.bo_Wt;
+    const double* h = buf + L.bo_h;
+    const double* sl = c.sc + L.so_sl;
+    const double* dgl = c.sc + L.so_dg + L.Rpad;
+    const double* gtl = c.sc + L.so_gt + L.Rpad;
+    __syncthreads();
+    for (int k = c.tid; k < L.Rc; k += BA_NT) tv[k] = sc[k] * (gt[k] / dg[k]);       // sc .* t on the camera columns
+    __syncthreads();
+    double q = 0.0;
+    for (int l = c.tid; l < c.nL; l += BA_NT) {
+        double wdot = 0.0;
+        for (int row = 0; row < L.Rc; ++row) wdot += Wt[(size_t)row * L.Lcap + l] * tv[row];
+        const double tl = gtl[l] / dgl[l];
+        q += sl[l] * sl[l] * h[l] * tl * tl + 2.0 * tl * sl[l] * wdot;
+    }
+    return q;
 }
 
 // Blocked right-looking Cholesky (NB = 16) of the packed lower triangle S (R x R) held in LDS, with the rhs as
@@ -1348,9 +1402,9 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
                 PROF_ADD(PF_BUILD);
                 bool cok = chain_eliminate(c, m);
                 PROF_ADD(PF_CHAIN);
-                q += schur_mfma(c, m, buf, s.mu);
-                q = block_sum(m.red, BA_NW, c.lane, c.wave, q);
-                s.alpha = s.gtn2 / q;            // |gt|^2 / |J~ (gt/Dg)|^2
+                schur_mfma(c, m, buf, s.mu);
+                s.qcam = block_sum(m.red, BA_NW, c.lane, c.wave, q);      // t^T H~ t without the landmark part
+                s.alpha = -1.0;                  // Cauchy step length |gt|^2 / |J~ (gt/Dg)|^2: completed on demand below
                 PROF_ADD(PF_SCHUR);
                 if (cok) cok = cholesky_aug(c, m, Rc);
                 PROF_ADD(PF_CHOL);
@@ -1408,6 +1462,10 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
         if (ok) {
             // DoglegStrategy::ComputeTraditionalDoglegStep
             const double gtn = sqrt(s.gtn2), gnn = sqrt(s.gnn2);
+            if (!(gnn <= s.radius) && s.alpha < 0.0) {
+                const double ql = block_sum(m.red, BA_NW, c.lane, c.wave, cauchy_landmark_term(c, m, buf));
+                s.alpha = s.gtn2 / (s.qcam + ql);
+            }
             if (gnn <= s.radius) { c_gt = 0.0; c_gn = 1.0; s.dnorm = gnn; }
             else if (gtn * s.alpha >= s.radius) { c_gt = -(s.radius / gtn); c_gn = 0.0; s.dnorm = s.radius; }
             else {
@@ -1427,7 +1485,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
             // model cost change  -(J~ s)^T (r + J~ s / 2)  with s = c_gt a + c_gn b  (a = gt/Dg, b = gn/Dg = -y):
             //   a.g~ = |gt|^2, b.g~ = gt.gn, a^T H~ a = |gt|^2 / alpha, and from (H~ + mu Dg^2) y = g~ :
             //   b^T H~ b = -gt.gn - mu |gn|^2,  a^T H~ b = -|gt|^2 - mu gt.gn      (no pass over the factors)
-            const double q11 = s.gtn2 / s.alpha;
+            const double q11 = c_gt != 0.0 ? s.gtn2 / s.alpha : 0.0;      // (alpha is only evaluated when the step has a gradient part)
             const double q12 = -s.gtn2 - s.mu_solved * s.gtgn;
             const double q22 = -s.gtgn - s.mu_solved * s.gnn2;
             model_change = -(c_gt * s.gtn2 + c_gn * s.gtgn) - 0.5 * (c_gt * c_gt * q11 + 2.0 * c_gt * c_gn * q12 + c_gn * c_gn * q22);
