@@ -85,6 +85,21 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
     nfeat = sum(len(c) for c in corners)
     res = tr.track_download()
     tracked = int(sum(int(st.sum()) for (_, st, _) in res))
+    # the same step with CLAHE(3.0, 8x8) on the incoming frame (EQUALIZE = 1 in the EuRoC configuration,
+    # feature_tracker.cpp:87-93)
+    def step_eq():
+        nonlocal slot
+        tr.select_frames(slot)
+        tr.build_async(True)
+        tr.track_async()
+        slot ^= 1
+    for _ in range(2):
+        step_eq()
+    h.sync()
+    h.timer_start()
+    for _ in range(steps):
+        step_eq()
+    eq_ms = h.timer_stop() / steps
     # GFTT alone
     h.timer_start()
     for _ in range(max(3, steps // 2)):
@@ -95,6 +110,8 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
         "value": nfeat * steps / wall, "unit": "features/s", "streams": FE_CAMS, "features_per_step": nfeat,
         "tracked_last_step": tracked, "ms_per_step": wall / steps * 1e3, "dtype": "u8/int16/int64 + f32",
         "gftt_frames_per_s": FE_CAMS / (gftt_ms * 1e-3), "gftt_ms_per_batch": gftt_ms,
+        "with_clahe": {"ms_per_step": eq_ms, "features_per_s": nfeat / (eq_ms * 1e-3),
+                       "what": "same step with CLAHE(3.0, 8x8) on the incoming frame (EuRoC equalize: 1), HIP events"},
         "roofline": {"kernel": "fe_lk_kernel (+ fe_pyrdown_kernel x3 + fe_copy_kernel)", "bound": "hbm",
                      "achieved": nfeat * FE_BYTES_PER_FEATURE * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "traffic": fe_traffic(), "event_ms_per_step": ev_ms / steps,
@@ -118,6 +135,16 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
                                "sample": f"{reps} frame pairs x {N} corners, oracle/fe_cpu.cpp (restated single-thread OpenCV-equivalent "
                                          f"calcOpticalFlowPyrLK incl. both pyramids + Scharr; real OpenCV unavailable)",
                                "gftt_frames_per_s": g / (time.perf_counter() - t2)}
+        # OpenCV runs the LK point loop under parallel_for_: all host cores, points of a level spread over threads
+        nthr = max(1, min(os.cpu_count() or 1, 64))
+        t3 = time.perf_counter()
+        rm = 0
+        while time.perf_counter() - t3 < 3.0:
+            fe_cpu.lk_mt(fa[rm % len(fa)], fb[rm % len(fb)], corners[rm % len(corners)], nthr)
+            rm += 1
+        out["cpu_baseline"]["all_cores"] = {"value": rm * N / (time.perf_counter() - t3), "unit": "features/s", "cores": nthr,
+                                            "what": "same restatement, points of every pyramid level spread over host threads "
+                                                    "(one frame pair at a time, as one camera stream would run it)"}
         out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     return out
 
@@ -145,6 +172,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=WINDOWS_PER_GPU)
+    ap.add_argument("--in-flight", type=int, default=1, help="independent batches (HIP streams) the steps are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "2-rank self-test on a 1-GPU box together with --share-device)")
@@ -165,38 +193,54 @@ def main():
 
     h = ba.Handle()
     nwin = args.windows
-    probs = make_windows(h, ba, synth, nwin, seed0=D.window_seeds(rank, nwin)[0])
+    nfl = max(1, args.in_flight)
+    # `nfl` independent batches of nwin windows each, one vg_handle (= one HIP stream) per batch: consecutive steps go to
+    # different streams, so the launches of step i+1 overlap the latency-bound phases of step i (a workgroup of the
+    # solve kernel needs < 80 KB of LDS: two windows are resident per CU)
+    handles = [h] + [ba.Handle() for _ in range(nfl - 1)]
+    seed0 = D.window_seeds(rank, nwin)[0]
+    probs = make_windows(h, ba, synth, nwin, seed0=seed0)
     packed = [ba.PackedProblem(p) for p in probs]
     flags = [ba.VG_MARGIN_OLD] * nwin
-    h.ba_upload(packed, flags)                       # inputs now resident in HBM
+    for hh in handles:
+        hh.ba_upload(packed, flags)                  # inputs now resident in HBM (every stream owns its copy of the batch)
     info = h.ba_info()
 
     def barrier():
         torch.cuda.synchronize()
         D.barrier()
 
-    for _ in range(args.warmup):
-        h.ba_run_async()
-    h.sync()
+    def sync_all():
+        for hh in handles:
+            hh.sync()
+
+    for k in range(args.warmup):
+        handles[k % nfl].ba_run_async()
+    sync_all()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        h.ba_run_async()
-    h.sync()
+    for k in range(args.steps):
+        handles[k % nfl].ba_run_async()
+    sync_all()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
     elapsed = D.max_over_ranks(elapsed)
 
-    # per-kernel durations from HIP events on the launch stream (not part of the timed region)
-    ks, km = [], []
+    # one step at a time (no overlap between steps): the latency of a 256-window step
+    ser = []
     for _ in range(max(3, min(args.steps, 10))):
         a, b = h.ba_run_timed()
-        ks.append(a)
-        km.append(b)
-    solve_ms, marg_ms = float(np.mean(ks)), float(np.mean(km))
+        ser.append((a, b))
+    solve_ms, marg_ms = float(np.mean([a for a, _ in ser])), float(np.mean([b for _, b in ser]))
+    # per-kernel durations: a HIP event after every launch on the launch stream (outside the timed region)
+    prof = {}
+    for _ in range(max(3, min(args.steps, 10))):
+        for k, (ms, n) in h.ba_run_profiled().items():
+            a = prof.setdefault(k, [0.0, 0, 0])
+            a[0] += ms; a[1] += n; a[2] += 1
 
-    # boundary-inclusive rate (host buffers in, host buffers out: pack + H2D + both launches + D2H), NOT the metric
+    # boundary-inclusive rate (host buffers in, host buffers out: pack + H2D + all launches + D2H), NOT the metric
     up_ms, dn_ms = [], []
     for _ in range(3):
         h.ba_upload(packed, flags)
@@ -206,6 +250,25 @@ def main():
         h.ba_download()
         dn_ms.append(h.last_download_call_ms)         # vg_ba_batch_download: D2H + unpack
     up_ms, dn_ms = float(np.median(up_ms)), float(np.median(dn_ms))
+    # the same with the three calls of consecutive batches overlapped: one host thread per handle, each looping
+    # upload -> run -> download on its own stream (ctypes releases the GIL inside the C-ABI calls)
+    import threading
+    nb_each = 4
+
+    def boundary_loop(hh):
+        for _ in range(nb_each):
+            hh.ba_upload(packed, flags)
+            hh.ba_run_async()
+            hh.ba_download()
+    tb0 = time.perf_counter()
+    ths = [threading.Thread(target=boundary_loop, args=(hh,)) for hh in handles]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    overlapped_ms = (time.perf_counter() - tb0) / (nb_each * nfl) * 1e3
+    for hh in handles[1:]:
+        hh.ba_upload(packed, flags)
 
     # sanity: results of the timed batch are valid
     st, sm, pr = h.ba_download()
@@ -215,19 +278,21 @@ def main():
     if rank == 0:
         total_solves = world * nwin * args.steps
         value = total_solves / elapsed
-        flops_per_launch = info['flops']                 # algorithmic FLOP model of SURVEY.md 8(d), whole batch
-        # One "step" = two launches; the roofline is booked per kernel (FP64: vector peak = MFMA peak = 78.6 TF on gfx950)
-        # with the algorithmic flop model of SURVEY.md 8(d) split per launch; the top-level entry is the DOMINANT kernel
-        # (longest average launch), the other kernel and the pair are listed beside it.
-        per_kernel = {
-            "ba_solve_kernel": {"ms": solve_ms, "flops": info['flops_solve']},
-            "ba_marg_kernel": {"ms": marg_ms, "flops": info['flops_marg']},
-        }
-        for k, v in per_kernel.items():
-            v["achieved"] = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
-            v["frac"] = v["achieved"] / FP64_PEAK_TFLOPS
-            v["traffic"] = pmc_traffic(k)
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
+        # Roofline per kernel class (FP64: vector peak = MFMA peak = 78.6 TF on gfx950): algorithmic flops of SURVEY.md 8(d)
+        # split per launch class (vg_ba_batch_flops_by_kernel) / average launch duration from the event pass above.
+        # The top-level entry is the DOMINANT kernel: the class with the largest summed duration per step.
+        per_kernel = {}
+        for k, (ms, n, runs) in prof.items():
+            if n == 0:
+                continue
+            fl = info['flops_by_kernel'][k] / (n / runs)                   # flops per launch (whole batch)
+            avg = ms / n
+            per_kernel[k] = {"launches_per_step": n // runs, "ms_per_launch": avg, "ms_per_step": ms / runs,
+                             "flops_per_launch": fl, "achieved": fl / (avg * 1e-3) / 1e12 if avg > 0 else 0.0}
+            per_kernel[k]["frac"] = per_kernel[k]["achieved"] / FP64_PEAK_TFLOPS
+            per_kernel[k]["traffic"] = pmc_traffic(k)
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
+        step_ms = sum(v["ms_per_step"] for v in per_kernel.values())
         roofline = {
             "kernel": dom,
             "bound": "mfma",
@@ -237,31 +302,48 @@ def main():
             "frac": per_kernel[dom]["frac"],
             "traffic": per_kernel[dom]["traffic"],
             "kernels": per_kernel,
-            "pair": {"ms": solve_ms + marg_ms, "flops": info['flops'],
-                     "achieved": info['flops'] / ((solve_ms + marg_ms) * 1e-3) / 1e12,
-                     "frac": info['flops'] / ((solve_ms + marg_ms) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
-            "note": "durations = HIP events on the launch stream, averaged over the launches after the timed region; "
-                    "traffic = HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/, FETCH_SIZE x2 per the "
-                    "gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE), null when no PMC file is present",
+            "whole_step": {"ms_serial": solve_ms + marg_ms, "flops": info['flops'],
+                           "achieved_serial": info['flops'] / ((solve_ms + marg_ms) * 1e-3) / 1e12,
+                           "achieved_timed_region": info['flops'] * args.steps / elapsed / 1e12,
+                           "frac_timed_region": info['flops'] * args.steps / elapsed / 1e12 / FP64_PEAK_TFLOPS},
+            "note": "ms_per_launch = HIP events after every launch on the launch stream (one stream, steps not overlapped), averaged "
+                    "over the passes after the timed region; flops = SURVEY.md 8(d) model split per launch class; traffic = HBM bytes "
+                    "per launch from the committed rocprofv3 PMC pass (profiles/pmc_latest.json, FETCH_SIZE x2 per the gfx950 note of "
+                    "MI355X_MICROARCH.md + WRITE_SIZE), null when that file has no entry for the kernel",
             "algorithmic_bytes_per_batch": info['bytes_in'] + info['bytes_out'],
-            "hbm_GBs_algorithmic": (info['bytes_in'] + info['bytes_out']) / ((solve_ms + marg_ms) * 1e-3) / 1e9,
+            "hbm_GBs_algorithmic": (info['bytes_in'] + info['bytes_out']) * args.steps / elapsed / 1e9,
         }
         cpu = None
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)
             from oracle import ba_cpu
+            try:
+                os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})       # taskset -c <first allowed core>
+                pinned = True
+            except (AttributeError, OSError):
+                pinned = False
             ncpu = min(nwin, 64)
-            reps = 1
-            t_cpu = ba_cpu.time_optimize(packed[:ncpu], flags[:ncpu], repeats=1)
-            while t_cpu * (reps + 1) < 10.0 and reps < 20:
-                reps += 1
-            if reps > 1:
-                t_cpu = ba_cpu.time_optimize(packed[:ncpu], flags[:ncpu], repeats=reps) / reps
+            for i in range(3):                                                      # warm-up
+                ba_cpu.time_optimize([packed[i]], [flags[i]])
+            t_full, t_solve = [], []
+            tstart = time.perf_counter()
+            i = 0
+            while (len(t_full) < 50 or time.perf_counter() - tstart < 10.0) and len(t_full) < 400:
+                t_full.append(ba_cpu.time_optimize([packed[i % ncpu]], [flags[i % ncpu]]))
+                t_solve.append(ba_cpu.time_optimize([packed[i % ncpu]], [ba.VG_MARGIN_NONE]))
+                i += 1
+            if pinned:
+                os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
+            med_full, med_solve = float(np.median(t_full)), float(np.median(t_solve))
             cpu = {
-                "value": ncpu / t_cpu, "unit": "solves/s", "cores": 1, "kind": "port",
-                "sample": f"{ncpu} of the {nwin} timed windows x {reps} passes, oracle/ba_cpu.cpp (restated single-thread "
-                          f"Ceres-equivalent DENSE_SCHUR+DOGLEG + marginalization; real Ceres/Eigen unavailable), "
-                          f"host: {os.cpu_count()} cpus",
-                "ms_per_solve": t_cpu / ncpu * 1e3,
+                "value": 1.0 / med_full, "unit": "solves/s", "cores": 1, "kind": "port",
+                "sample": f"median of {len(t_full)} single solves over {ncpu} of the {nwin} timed windows, pinned to one core "
+                          f"(sched_setaffinity = taskset -c): oracle/ba_cpu.cpp (restated single-thread Ceres-equivalent "
+                          f"DENSE_SCHUR + DOGLEG + marginalization; real Ceres/Eigen unavailable), host: {os.cpu_count()} cpus",
+                "ms_per_solve": med_full * 1e3,
+                "ms_solve_only": med_solve * 1e3,
+                "ms_marginalization": (med_full - med_solve) * 1e3,
+                "marginalization_note": "the reference spreads the marginalization's A = sum J^T J over 4 pthreads "
+                                        "(marginalization_factor.h:13); this figure is single-thread",
             }
         out = {
             "metric": "sliding-window BA solves/sec (Estimator::optimization: 8-iteration dogleg solve + marginalization)",
@@ -276,19 +358,26 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"batch of {nwin} independent EuRoC-shape windows per GPU (K=11 frames, ~150 landmarks, "
+            "config": {"workload": f"batch of {nwin} independent EuRoC-shape windows per step and GPU (K=11 frames, ~150 landmarks, "
                                    f"10 IMU factors, ~600 projection factors, 75-dim marginalization prior, max 8 iterations, "
-                                   f"MARGIN_OLD marginalization); windows resident in HBM",
-                       "windows_per_gpu": nwin, "parallelism": f"independent batches x{world} (no collectives)",
-                       "valid_solves": n_ok},
+                                   f"MARGIN_OLD marginalization); windows resident in HBM; consecutive steps are issued to "
+                                   f"{nfl} HIP streams (independent batches in flight)",
+                       "windows_per_gpu": nwin, "batches_in_flight": nfl,
+                       "parallelism": f"independent batches x{world} (no collectives)", "valid_solves": n_ok},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "step_latency_ms": {"solve_pipeline": solve_ms, "marginalization": marg_ms, "total": solve_ms + marg_ms,
+                                "what": "one 256-window step alone on the GPU (no overlap with other steps), HIP events"},
             "single_window_latency_ms": None,
             "host_boundary_inclusive": {"upload_call_ms": up_ms, "download_call_ms": dn_ms,
                                         "sync_ms_per_batch": up_ms + (solve_ms + marg_ms) + dn_ms,
                                         "sync_solves_per_s": nwin / ((up_ms + solve_ms + marg_ms + dn_ms) * 1e-3),
-                                        "what": "host buffers in, host buffers out, nothing overlapped: vg_ba_batch_upload (pack + "
-                                                "H2D) + both kernels + vg_ba_batch_download (D2H + unpack), per GPU; NOT the metric"},
+                                        "overlapped_ms_per_batch": overlapped_ms,
+                                        "overlapped_solves_per_s": nwin / (overlapped_ms * 1e-3),
+                                        "what": "host buffers in, host buffers out: vg_ba_batch_upload (pack + H2D) + all launches + "
+                                                "vg_ba_batch_download (D2H + unpack), per GPU; sync = one batch at a time, nothing "
+                                                f"overlapped; overlapped = {nfl} host threads, one handle / stream each, so that the "
+                                                "upload, kernels and download of consecutive batches overlap; NOT the metric"},
         }
     fe_out = bench_fe(h, synth, max(args.steps, 10), args.warmup, rank, rank == 0 and world == 1 and not args.no_cpu_baseline)
     fe_out["value_all_gpus"] = D.sum_over_ranks(fe_out["value"])
@@ -299,12 +388,26 @@ def main():
         for _ in range(3):
             h.ba_run_async()
         h.sync()
-        lat = [sum(h.ba_run_timed()) for _ in range(10)]
-        out["single_window_latency_ms"] = float(np.median(lat))
+        lat = [h.ba_run_timed() for _ in range(20)]
+        out["single_window_latency_ms"] = float(np.median([a + b for a, b in lat]))
+        out["single_window"] = {
+            "solve_pipeline_ms": float(np.median([a for a, _ in lat])), "marginalization_ms": float(np.median([b for _, b in lat])),
+            "what": "one window alone on the GPU, device-resident, HIP events; the marginalization result is only needed "
+                    "by the NEXT frame's optimization()"}
+        # the boundary-inclusive single call a drop-in Estimator::optimization() makes: vg_ba_optimize (pack + H2D + launches + D2H)
+        calls = []
+        for _ in range(20):
+            tc = time.perf_counter()
+            h.ba_optimize(packed[0], ba.VG_MARGIN_OLD)
+            calls.append((time.perf_counter() - tc) * 1e3)
+        out["single_window"]["vg_ba_optimize_call_ms"] = float(np.median(calls))
         if out["cpu_baseline"]:
             out["single_window_speedup_vs_cpu"] = out["cpu_baseline"]["ms_per_solve"] / out["single_window_latency_ms"]
+            out["single_window"]["call_speedup_vs_cpu"] = out["cpu_baseline"]["ms_per_solve"] / out["single_window"]["vg_ba_optimize_call_ms"]
             out["batch_speedup_vs_cpu_per_gpu"] = out["value"] / world / out["cpu_baseline"]["value"]
         print(json.dumps(out))
+    for hh in handles[1:]:
+        hh.close()
     h.close()
     D.finish()
 

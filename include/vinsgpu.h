@@ -188,15 +188,23 @@ int vg_ba_optimize(vg_handle* h, const vg_ba_problem* in, int margin_flag,
 /* Batch of independent windows (BASELINE.json configs[3]); staged so that benchmarks can time the
  * device work alone with inputs resident in HBM:
  *   upload   : pack + H2D (synchronous on return)
- *   run_async: enqueue the solve kernel (+ marginalization kernel) for every uploaded window
+ *   run_async: enqueue the solve pipeline (+ marginalization kernel) for every uploaded window
  *   download : D2H + unpack (synchronises first)
  * All windows of a batch must share K, estimate_extrinsic, estimate_td and relo presence. */
 int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* const* in, const int* margin_flags);
 int vg_ba_batch_run_async(vg_handle* h);
-/* same as run_async but synchronous and timed with HIP events on the handle's stream: per-kernel durations */
+/* same as run_async but synchronous and timed with HIP events on the handle's stream: the solve pipeline (all its
+ * launches) and the marginalization kernel */
 int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_ms);
 int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* out_states,
                          vg_ba_summary* out_summaries, vg_ba_prior* const* out_priors);
+/* one synchronous run with a HIP event after every launch of the solve pipeline: ms[k] = summed duration and n[k] =
+ * number of launches of kernel class k (both arrays VG_BA_KERNEL_COUNT long) */
+enum { VG_BA_KERNEL_PROLOGUE = 0, VG_BA_KERNEL_LINEARIZE, VG_BA_KERNEL_ACCUMULATE, VG_BA_KERNEL_SOLVE, VG_BA_KERNEL_FINAL,
+       VG_BA_KERNEL_MARG, VG_BA_KERNEL_COUNT };
+int vg_ba_batch_run_profiled(vg_handle* h, float* ms, int* n);
+/* the SURVEY.md 8(d) flop model of one run of the uploaded batch, split per kernel class (VG_BA_KERNEL_COUNT doubles) */
+int vg_ba_batch_flops_by_kernel(vg_handle* h, double* flops);
 /* algorithmic work of the uploaded batch for roofline accounting (SURVEY.md 8(d) flop model) */
 int vg_ba_batch_info(vg_handle* h, double* flops_per_run, double* bytes_in, double* bytes_out, int* lds_bytes);
 /* the same flop model split per launch: ba_solve_kernel (solve + prior J^T J) and ba_marg_kernel (the marginalization term) */

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -230,6 +231,36 @@ void oracle_fe_lk(const uint8_t* prev, const uint8_t* next, int w, int h, const 
         for (int i = 0; i < n; ++i)
             lk_point_level(pI[level], pJ[level], level, max_level, prev_xy[2 * i], prev_xy[2 * i + 1], next_xy[2 * i], next_xy[2 * i + 1],
                            status[i], err[i], 30, 0.01 * 0.01, 1e-4f);
+}
+
+// the same with the points of every level spread over `nthreads` host threads (OpenCV runs LKTrackerInvoker under
+// parallel_for_ over the points; the pyramids are built once).  Results are identical to oracle_fe_lk.
+void oracle_fe_lk_mt(const uint8_t* prev, const uint8_t* next, int w, int h, const float* prev_xy, int n, int max_level,
+                     float* next_xy, uint8_t* status, float* err, int nthreads) {
+    std::vector<Level> pI, pJ;
+    {
+        int lw = w, lh = h, lv = 0;
+        while (lv < max_level) {
+            const int nw = (lw + 1) / 2, nh = (lh + 1) / 2;
+            if (nw <= 21 || nh <= 21) break;
+            lw = nw; lh = nh; ++lv;
+        }
+        max_level = lv;
+    }
+    build_pyramid(prev, w, h, max_level, pI, true);
+    build_pyramid(next, w, h, max_level, pJ, false);
+    for (int i = 0; i < n; ++i) { status[i] = 1; err[i] = 0; next_xy[2 * i] = 0; next_xy[2 * i + 1] = 0; }
+    nthreads = std::max(1, std::min(nthreads, n));
+    for (int level = max_level; level >= 0; --level) {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t]() {
+                for (int i = t; i < n; i += nthreads)
+                    lk_point_level(pI[level], pJ[level], level, max_level, prev_xy[2 * i], prev_xy[2 * i + 1], next_xy[2 * i],
+                                   next_xy[2 * i + 1], status[i], err[i], 30, 0.01 * 0.01, 1e-4f);
+            });
+        for (auto& th : pool) th.join();
+    }
 }
 
 void oracle_fe_mineig(const uint8_t* img, int w, int h, float* eig) { min_eig_map(img, w, h, eig); }

@@ -56,6 +56,18 @@ def lk(prev, nxt, pts, max_level=3):
     return out, st, err
 
 
+def lk_mt(prev, nxt, pts, nthreads, max_level=3):
+    """lk() with the points of every level spread over host threads (how OpenCV runs it); identical results."""
+    prev, nxt = np.ascontiguousarray(prev, np.uint8), np.ascontiguousarray(nxt, np.uint8)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    n = pts.shape[0]
+    h, w = prev.shape
+    out, st, err = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8), np.zeros(n, np.float32)
+    lib().oracle_fe_lk_mt(_p8(prev), _p8(nxt), w, h, pts.ctypes.data_as(_f4), n, max_level, out.ctypes.data_as(_f4), _p8(st),
+                          err.ctypes.data_as(_f4), int(nthreads))
+    return out, st, err
+
+
 def mineig(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape

@@ -176,6 +176,8 @@ class Handle:
         L.vg_ba_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(State)), C.POINTER(Summary),
                                            C.POINTER(C.POINTER(Prior))]
         L.vg_ba_batch_run_timed.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.vg_ba_batch_run_profiled.argtypes = [C.c_void_p, C.POINTER(C.c_float), _pi]
+        L.vg_ba_batch_flops_by_kernel.argtypes = [C.c_void_p, _pd]
         L.vg_ba_batch_info.argtypes = [C.c_void_p, _pd, _pd, _pd, _pi]
         L.vg_ba_batch_flops.argtypes = [C.c_void_p, _pd, _pd]
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
@@ -233,13 +235,25 @@ class Handle:
         self._chk(self.lib.vg_ba_batch_run_timed(self.h, C.byref(a), C.byref(b)), "vg_ba_batch_run_timed")
         return float(a.value), float(b.value)
 
+    KERNEL_CLASSES = ("ba_prologue_kernel", "ba_linearize_imu_kernel+ba_linearize_proj_kernel", "ba_accumulate_kernel", "ba_solve_kernel",
+                      "ba_final_kernel", "ba_marg_kernel")
+
+    def ba_run_profiled(self):
+        """Synchronous run with a HIP event after every launch: {kernel: (summed ms, launches)}."""
+        ms = (C.c_float * 6)()
+        n = (C.c_int * 6)()
+        self._chk(self.lib.vg_ba_batch_run_profiled(self.h, ms, n), "vg_ba_batch_run_profiled")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
+
     def ba_info(self):
         fl, bi, bo, lds = C.c_double(), C.c_double(), C.c_double(), C.c_int()
         self._chk(self.lib.vg_ba_batch_info(self.h, C.byref(fl), C.byref(bi), C.byref(bo), C.byref(lds)), "vg_ba_batch_info")
         fs, fm = C.c_double(), C.c_double()
         self._chk(self.lib.vg_ba_batch_flops(self.h, C.byref(fs), C.byref(fm)), "vg_ba_batch_flops")
+        fk = (C.c_double * 6)()
+        self._chk(self.lib.vg_ba_batch_flops_by_kernel(self.h, fk), "vg_ba_batch_flops_by_kernel")
         return dict(flops=fl.value, flops_solve=fs.value, flops_marg=fm.value, bytes_in=bi.value, bytes_out=bo.value,
-                    lds_bytes=lds.value)
+                    lds_bytes=lds.value, flops_by_kernel={k: float(fk[i]) for i, k in enumerate(self.KERNEL_CLASSES)})
 
     def ba_download(self, allow_numeric_failure=False):
         n = len(self._packed)

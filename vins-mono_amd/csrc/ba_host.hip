@@ -18,7 +18,8 @@
 #include "vg_handle.h"
 #include "../../include/vinsgpu.h"
 
-extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream);
+extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
+                                      hipEvent_t* ev, int* kinds, int* n_launches);
 extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, double* proj_r, double* proj_J,
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream);
 extern "C" const char* ba_failed_launch();
@@ -130,7 +131,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.nst = up(7 * L.Kp + 9 * L.K + 8, 2);
     if (L.RcPad > 96 || L.Rc > 128) { h->err = "camera part wider than the solve kernel's tiling"; return VG_ERR_UNSUPPORTED; }
     // ---- workgroups per window
-    L.nbf = (L.Fcap + BA_NT - 1) / BA_NT;
+    L.nbf = (L.Fcap + BA_LIN_NT - 1) / BA_LIN_NT;
     L.nbl = L.nbf + 1;
     if (L.nbl > BA_MAX_PART) { h->err = "too many projection factors per window"; return VG_ERR_UNSUPPORTED; }
     {
@@ -410,6 +411,7 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
         B.hcap_di = n_di;
     }
     B.flops = 0.0; B.flops_marg = 0.0; B.bytes_in = 0.0; B.bytes_out = 0.0;
+    for (double& v : B.flops_k) v = 0.0;
     B.margin.assign(nwin, VG_MARGIN_NONE);
     B.nL.assign(nwin, 0);
     B.rounds = 0;
@@ -452,9 +454,14 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
             sumn += n;
         }
         const double np = p->prior_n, R = L.R;
-        const double lin = F * (750 + 416) + schur + 10 * 37000.0 + 4 * np * np + R * R * R / 3 + 2 * R * R + 12 * sumn;
-        const double stepev = F * 145 + 10 * 9000.0;
-        double fl = p->max_iters * (lin + stepev) + 2 * np * np * np;
+        // per launch class (include/vinsgpu.h VG_BA_KERNEL_*), summed over the max_iters rounds of this window
+        const double it = p->max_iters;
+        const double f_lin = it * (F * 750 + 10 * 37000.0 + 4 * np * np + F * 145 + 10 * 9000.0);    // factor evaluation (+ the step evaluation it replaces)
+        const double f_acc = it * (F * 416);                                                       // J^T J / J^T r of the projection factors
+        const double f_sol = it * (schur + R * R * R / 3 + 2 * R * R + 12 * sumn);                  // Schur complement, Cholesky, back substitution
+        const double f_pro = 2 * np * np * np;                                                     // prior J0^T J0
+        B.flops_k[0] += f_pro; B.flops_k[1] += f_lin; B.flops_k[2] += f_acc; B.flops_k[3] += f_sol;
+        double fl = f_lin + f_acc + f_sol + f_pro;
         if (mf == VG_MARGIN_OLD) {
             double m = 15;
             for (int l = 0; l < p->L; ++l) m += (p->lm_start[l] == 0);
@@ -462,6 +469,7 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
             const double fm = 9 * (m * m * m + n * n * n) + 2 * (m * m * n + m * n * n);
             fl += fm;
             B.flops_marg += fm;
+            B.flops_k[5] += fm;
         }
         B.flops += fl;
         B.bytes_in += 8.0 * (16 * L.K + 8 + p->L + 7.0 * p->n_obs + (L.K - 1) * 467.0 + np * np + 2 * np) + 12.0 * p->L;
@@ -493,7 +501,7 @@ extern "C" int vg_ba_batch_run_async(vg_handle* h) {
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
     {
-        const hipError_t e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream);
+        const hipError_t e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream, nullptr, nullptr, nullptr);
         if (e != hipSuccess) { h->err = std::string("launch of ") + ba_failed_launch() + ": " + hipGetErrorString(e); return VG_ERR_HIP; }
     }
     if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
@@ -505,7 +513,10 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
     BaBatch& B = h->ba;
     hipEvent_t e0 = h->ev0, e1 = h->ev1, e2 = h->ev2;
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    HIPCHK(h, ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream));
+    {
+        const hipError_t e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream, nullptr, nullptr, nullptr);
+        if (e != hipSuccess) { h->err = std::string("launch of ") + ba_failed_launch() + ": " + hipGetErrorString(e); return VG_ERR_HIP; }
+    }
     HIPCHK(h, hipEventRecord(e1, h->stream));
     if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
     HIPCHK(h, hipEventRecord(e2, h->stream));
@@ -518,10 +529,46 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
     return VG_OK;
 }
 
+// One batch run with a HIP event after every launch: ms[k] / n[k] = summed duration / number of launches of kernel
+// class k (VG_BA_KERNEL_*).  The gaps between launches are part of the class that follows them.
+extern "C" int vg_ba_batch_run_profiled(vg_handle* h, float* ms, int* n) {
+    if (!h || !h->ba.uploaded || !ms || !n) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    const int nev = 4 * B.rounds + 5 + 1;
+    std::vector<hipEvent_t> ev(nev, nullptr);
+    std::vector<int> kinds(nev, 0);
+    for (int i = 0; i < nev; ++i) HIPCHK(h, hipEventCreate(&ev[i]));
+    int nl = 0;
+    hipError_t e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream, ev.data(), kinds.data(), &nl);
+    if (e != hipSuccess) { h->err = std::string("launch of ") + ba_failed_launch() + ": " + hipGetErrorString(e); return VG_ERR_HIP; }
+    if (B.any_margin) {
+        HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
+        HIPCHK(h, hipEventRecord(ev[nl + 1], h->stream));
+        kinds[nl] = VG_BA_KERNEL_MARG;
+        ++nl;
+    }
+    HIPCHK(h, hipEventSynchronize(ev[nl]));
+    for (int k = 0; k < VG_BA_KERNEL_COUNT; ++k) { ms[k] = 0.f; n[k] = 0; }
+    for (int i = 0; i < nl; ++i) {
+        float t = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+        ms[kinds[i]] += t;
+        n[kinds[i]] += 1;
+    }
+    for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+    return VG_OK;
+}
+
 extern "C" int vg_ba_batch_flops(vg_handle* h, double* solve_flops, double* marg_flops) {
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
     if (solve_flops) *solve_flops = h->ba.flops - h->ba.flops_marg;
     if (marg_flops) *marg_flops = h->ba.flops_marg;
+    return VG_OK;
+}
+
+extern "C" int vg_ba_batch_flops_by_kernel(vg_handle* h, double* flops) {
+    if (!h || !h->ba.uploaded || !flops) return VG_ERR_BAD_ARG;
+    for (int k = 0; k < VG_BA_KERNEL_COUNT; ++k) flops[k] = h->ba.flops_k[k];
     return VG_OK;
 }
 
@@ -589,8 +636,8 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
                 q->valid = mi[0];
                 if (debug_marg) {
                     const int* pf = mi + 8 + 2 * (L.K + 4);
-                    fprintf(stderr, "[marg] eig2: sweeps=%d total_kcyc=%d rot_kcyc=%d blkV_kcyc=%d | total kernel kcyc=%d | stamps: setup %d prior %d imu %d proj %d eig1 %d schur %d eig2 %d out %d | jacobi w0: M %d bar %d rot %d bar %d ; w1: M %d bar %d V %d bar %d\n",
-                            mi[5] & 255, mi[5] >> 8, mi[6], mi[7], mi[4], pf[0], pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6], pf[8], pf[9], pf[10], pf[11], pf[12], pf[13], pf[14], pf[15]);
+                    fprintf(stderr, "[marg] eig1: sweeps=%d attempts=%d | eig2: sweeps=%d attempts=%d | kernel kcyc=%d | stamps: setup %d prior %d imu %d proj %d eig1 %d schur %d eig2 %d out %d\n",
+                            mi[4] & 255, mi[4] >> 8, mi[5] & 255, mi[5] >> 8, mi[7], pf[0], pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6]);
                 }
                 if (mi[0]) {
                     const int n = mi[1], nb = mi[3];

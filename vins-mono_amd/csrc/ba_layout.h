@@ -11,6 +11,7 @@
 
 #define BA_NT 512                 // threads per workgroup of the per-window kernels (8 wavefronts)
 #define BA_NW (BA_NT / 64)
+#define BA_LIN_NT 256             // projection factors per workgroup of the linearisation kernel
 #define BA_ACC_NT 256             // threads per workgroup of the accumulation kernel
 #define BA_MAX_K 13               // frames incl. relocalisation pose
 #define BA_IMU_STRIDE 472         // doubles per vg_imu_preint record on device

@@ -463,8 +463,9 @@ DEV int jacobi_eig_fast(const MCtx& c, int offM, int offV, int n, int ld, int of
 // spectrum of A itself — noise eigenvalues included, so the lambda <= 1e-8 cut of marginalization_factor.cpp:272-296
 // sees what SelfAdjointEigenSolver would show it.
 // On exit (same convention as jacobi_eig): diag(M) = eigenvalues, V holds the eigenvectors as COLUMNS.
-// A pair is rotated while |g_p . g_q| > tol |g_p| |g_q|: 1e-16 for Amm (it is inverted: at 1e-14 the Schur complement
-// loses a digit against the extended-precision yardstick), 1e-14 for the kept block.
+// A pair is rotated while |g_p . g_q| > tol |g_p| |g_q|: 2e-16 for Amm (it is inverted: at 1e-14 the Schur complement
+// loses a digit against the extended-precision yardstick; at that level a few windows keep rotating on rounding noise,
+// hence the cap of 10 sweeps: 5-8 converge the others), 1e-14 / 16 sweeps for the kept block.
 // `offcs` = LDS scratch of >= 4 n + 8 doubles.  Returns sweeps | attempts << 8.
 DEV double mg_row16_sum(double v) {          // sum over the 16 lanes of a DPP row, result in all 16
     v += dpp_mov_f64<0xB1>(v);
@@ -474,7 +475,7 @@ DEV double mg_row16_sum(double v) {          // sum over the 16 lanes of a DPP r
     return v;
 }
 #define MG_HROWS 6                            // elements of a column per lane: n <= 96
-DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, double delta0_rel, double tol) {
+DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, double delta0_rel, double tol, int maxsweep) {
     double* A = MG_LDS + offM;
     double* Lc = MG_LDS + offV;               // column k of L at Lc[k * ld + i]
     double* dgn = MG_LDS + offcs;             // running diagonal of the Schur complement
@@ -597,7 +598,7 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
                 __syncthreads();
             }
             ++sweep;
-            const bool again = red[16] != 0.0 && sweep < MG_MAXSWEEP;
+            const bool again = red[16] != 0.0 && sweep < maxsweep;
             __syncthreads();
             if (!again) break;
         }
@@ -1027,14 +1028,15 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
 #endif
         const int offcs = (int)(cs - MG_LDS), offred = (int)(red - MG_LDS);
         const bool fast1 = in_lds && m >= 1 && m <= 16 * MG_HROWS;
-        const int sw1 = fast1 ? (vh_eig(c, 0, ld * ld, m, ldm, offcs, offred, 0.0, 1e-16) & 255)
+        const int sw1 = fast1 ? vh_eig(c, 0, ld * ld, m, ldm, offcs, offred, 0.0, 2e-16, 10)
                       : in_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, m, ldm, offcs, offred, true)
                                : jacobi_eig<false>(c, Mm, Vm, 0, 0, m, ldm, offcs, offred, true);
 #ifdef BA_PROFILE
-        if (c.tid == 0) { mi[4] = sw1; mi[6] = (int)((clock64() - _t1) >> 10); mi[7] = (int)((_t1 - _tstart) >> 10); }
+        if (c.tid == 0) { mi[6] = (int)((clock64() - _t1) >> 10); mi[7] = (int)((_t1 - _tstart) >> 10); }
 #else
         (void)sw1;
 #endif
+        if (c.tid == 0) mi[4] = sw1;        // the same for Amm
         MPROF(4);
         // T1 = Lambda^+ V^T [Amr | bmm]   (m x (n+1))
         for (int k = c.tid; k < m * (n + 1); k += MG_NT) {
@@ -1083,15 +1085,16 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
 #endif
     const int offcs2 = (int)(cs - MG_LDS), offred2 = (int)(red - MG_LDS);
     const bool fast2 = n_lds && n >= 1 && n <= 16 * MG_HROWS;
-    const int sw2 = fast2 ? (vh_eig(c, 0, ld * ld, n, ld2, offcs2, offred2, 2e-8, 1e-14) & 255)
+    const int sw2 = fast2 ? vh_eig(c, 0, ld * ld, n, ld2, offcs2, offred2, 2e-8, 1e-14, 16)
                   : n_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, n, ld2, offcs2, offred2, false)
                           : jacobi_eig<false>(c, M2, V2, 0, 0, n, ld2, offcs2, offred2, false);
 #ifdef BA_PROFILE
-    if (c.tid == 0) { mi[5] = sw2 | ((int)((clock64() - _t2) >> 10) << 8); mi[6] = (int)red[20] >> 10; mi[7] = (int)red[21] >> 10;
+    if (c.tid == 0) { mi[6] = (int)red[20] >> 10; mi[7] = (int)red[21] >> 10;
                       for (int k = 0; k < 8; ++k) mprof[8 + k] = (int)(red[20 + k] / 1024.0); }
 #else
     (void)sw2;
 #endif
+    if (c.tid == 0) mi[5] = sw2;            // sweeps | Cholesky attempts << 8 of the kept-block eigen-decomposition
     MPROF(6);
     // ascending order like SelfAdjointEigenSolver: rank of each eigenvalue
     int* rank = li + 48;
@@ -1146,7 +1149,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         if (ctd >= 0) { kind[nb] = VG_BLK_TD; idx[nb] = 0; x0[x0o++] = ex[7]; ++nb; }
         mi[0] = 1; mi[1] = n; mi[2] = m; mi[3] = nb;
 #ifdef BA_PROFILE
-        mi[4] = (int)((clock64() - _tstart) >> 10);
+        mi[7] = (int)((clock64() - _tstart) >> 10);
 #endif
     }
 }

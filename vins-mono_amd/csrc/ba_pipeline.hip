@@ -8,8 +8,8 @@
 //
 //   ba_prologue_kernel   (1 workgroup / window)   IMU sqrt_info factors, J0^T J0 of the prior, solver state init
 //   per round r = 0 .. max_iters-1:
-//     ba_linearize_kernel  (tiles of 512 projection factors + 1 IMU/prior workgroup per window, whole batch in one
-//                           grid) residuals + Jacobians at the point to be judged -> loss-corrected records, IMU
+//     ba_linearize_imu_kernel / ba_linearize_proj_kernel  (1 IMU + prior workgroup per window; tiles of 256 projection
+//                           factors, whole batch in one grid) residuals + Jacobians at the point to be judged -> loss-corrected records, IMU
 //                           Hessian blocks, prior residual, cost partials
 //     ba_accumulate_kernel (one wavefront per 6x6 block of the camera system + landmark lanes) J^T J, J^T r of the
 //                           projection factors, per-landmark h, b, W   — deterministic owner sums, no atomics
@@ -17,7 +17,7 @@
 //                           the next step: landmark Schur complement (v_mfma_f64_16x16x4), block-Thomas elimination
 //                           of the speed-bias chain, dense Cholesky of the Rc x Rc camera part in LDS, back
 //                           substitution, dogleg step, candidate state
-//   ba_linearize_kernel (cost only) + ba_final_kernel: judge the last candidate, gauge fix, outputs.
+//   the linearize kernels (cost only) + ba_final_kernel: judge the last candidate, gauge fix, outputs.
 //
 // The point evaluated in round r is the CANDIDATE of round r-1, linearised speculatively: if the solve kernel accepts
 // it (the common case) its linearisation is already there; if it rejects, the Gauss-Newton step and gradient of the
@@ -448,9 +448,9 @@ NOINL double proj_cost(const Ctx& c, int f, const double* x, const double* lam) 
     return log1p(r[0] * r[0] + r[1] * r[1]);
 }
 
-// grid (nbl, nwin): workgroups 0 .. nbf-1 = tiles of BA_NT projection factors, workgroup nbf = IMU factors + prior.
+// Projection factors: grid (nbf, nwin), tiles of BA_LIN_NT factors, thread per factor, no LDS beyond the reduction.
 // cost_only != 0: residuals only (the last candidate of a solve).
-extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
+extern "C" __global__ __launch_bounds__(BA_LIN_NT) void ba_linearize_proj_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
     const BaLayout& L = *Lp;
     Ctx c;
     ctx_init(c, Lp, P, blockIdx.y);
@@ -459,21 +459,32 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_kernel(const Ba
     const int which = ((int)ctl[C_CUR]) ^ (ctl[C_PENDING] != 0.0 ? 1 : 0);      // the point to evaluate: candidate if one is pending
     const double* x = c.sc + L.so_x + which * L.nst;
     const double* lam = c.sc + L.so_lam + which * L.Lcap;
-    double* buf = lin_buf(c, which);
     const int b = blockIdx.x;
-    __shared__ double red[2 * BA_NW];
+    __shared__ double red[2 * (BA_LIN_NT / 64)];
     double share = 0.0;
-    if (b < L.nbf) {
-        const int f = b * BA_NT + c.tid;
-        if (f < c.nF) share = cost_only ? proj_cost(c, f, x, lam) : proj_linearize(c, f, x, lam, c.sc + L.so_rec);
-    } else {
-        const int nimu = L.K - 1;
-        if (cost_only) share = imu_pass<false>(c, x, buf + L.bo_imuJ);
-        else share = imu_pass<true>(c, x, buf + L.bo_imuJ);
-        share += prior_pass(c, x, buf + L.bo_pr, LDSB);
-    }
-    const double tot = block_sum(red, BA_NW, c.lane, c.wave, share);
+    const int f = b * BA_LIN_NT + c.tid;
+    if (f < c.nF) share = cost_only ? proj_cost(c, f, x, lam) : proj_linearize(c, f, x, lam, c.sc + L.so_rec);
+    const double tot = block_sum(red, BA_LIN_NT / 64, c.lane, c.wave, share);
     if (c.tid == 0) c.sc[L.so_part + b] = tot;
+}
+
+// IMU factors + prior: one workgroup per window (LDS: sqrt_info copies + weighted Jacobian panels).
+extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_imu_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    ctx_init(c, Lp, P, blockIdx.x);
+    const double* ctl = c.sc + L.so_ctl;
+    if (ctl[C_DONE] != 0.0) return;
+    const int which = ((int)ctl[C_CUR]) ^ (ctl[C_PENDING] != 0.0 ? 1 : 0);
+    const double* x = c.sc + L.so_x + which * L.nst;
+    double* buf = lin_buf(c, which);
+    __shared__ double red[2 * BA_NW];
+    double share;
+    if (cost_only) share = imu_pass<false>(c, x, buf + L.bo_imuJ);
+    else share = imu_pass<true>(c, x, buf + L.bo_imuJ);
+    share += prior_pass(c, x, buf + L.bo_pr, LDSB);
+    const double tot = block_sum(red, BA_NW, c.lane, c.wave, share);
+    if (c.tid == 0) c.sc[L.so_part + L.nbf] = tot;
 }
 
 // ================================================================================================
@@ -1681,7 +1692,7 @@ static hipError_t set_lds_attrs() {
     hipError_t e = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // (these two also hold a few statically allocated LDS words: static + dynamic must stay within 160 KB)
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linearize_imu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_eval_factors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     done = e == hipSuccess;
     return e;
@@ -1695,19 +1706,33 @@ extern "C" const char* ba_failed_launch() { return g_failed_launch; }
         hipLaunchKernelGGL(name, grid, block, lds, stream, __VA_ARGS__);                 \
         const hipError_t _le = hipGetLastError();                                        \
         if (_le != hipSuccess) { g_failed_launch = #name; return _le; }                  \
+        if (ev) { const hipError_t _ee = hipEventRecord(ev[nev++], stream); if (_ee != hipSuccess) return _ee; } \
     } while (0)
 
-extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream) {
+// Launch sequence of one batch solve.  ev != nullptr: an event is recorded after every launch (ev[0] before the first),
+// kinds[i] = kernel class of the launch that ends at ev[i + 1] (0 prologue, 1 linearize, 2 accumulate, 3 solve, 4 final);
+// the caller provides 4 * rounds + 5 events.
+extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
+                                      hipEvent_t* ev, int* kinds, int* n_launches) {
     hipError_t e = set_lds_attrs();
     if (e != hipSuccess) { g_failed_launch = "hipFuncSetAttribute"; return e; }
+    int nev = 0;
+    if (ev) { e = hipEventRecord(ev[nev++], stream); if (e != hipSuccess) return e; }
+    int nk = 0;
     LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P);
+    if (kinds) kinds[nk++] = 0;
     for (int r = 0; r < rounds; ++r) {
-        LAUNCH(ba_linearize_kernel, dim3(L.nbl, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, 0);
+        LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, 0);
+        LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, 0);
         LAUNCH(ba_accumulate_kernel, dim3(L.nba, L.nwin), dim3(BA_ACC_NT), 0, dL, P);
         LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P);
+        if (kinds) { kinds[nk++] = 1; kinds[nk++] = 1; kinds[nk++] = 2; kinds[nk++] = 3; }
     }
-    LAUNCH(ba_linearize_kernel, dim3(L.nbl, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, 1);
+    LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, 1);
+    LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, 1);
     LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P);
+    if (kinds) { kinds[nk++] = 1; kinds[nk++] = 1; kinds[nk++] = 4; }
+    if (n_launches) *n_launches = nk;
     return hipSuccess;
 }
 
@@ -1715,6 +1740,9 @@ extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* 
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream) {
     hipError_t e = set_lds_attrs();
     if (e != hipSuccess) { g_failed_launch = "hipFuncSetAttribute"; return e; }
+    hipEvent_t* ev = nullptr;
+    int nev = 0;
+    (void)nev;
     LAUNCH(ba_prologue_kernel, dim3(1), dim3(BA_NT), L.lds_pro, dL, P);
     LAUNCH(ba_eval_factors_kernel, dim3(1), dim3(BA_NT), L.lds_lin, dL, P, proj_r, proj_J, imu_r, imu_J, prior_r);
     return hipSuccess;

@@ -19,6 +19,7 @@ struct BaBatch {
     int rounds = 0;                  // launches of the linearise / accumulate / solve triple = max over windows of max_iters
     bool uploaded = false, any_margin = false;
     double flops = 0, flops_marg = 0, bytes_in = 0, bytes_out = 0;
+    double flops_k[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic flops per kernel class (VG_BA_KERNEL_*), one run of the batch
 };
 
 struct FeState;   // fe_host.hip
