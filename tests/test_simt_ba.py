@@ -1,0 +1,37 @@
+"""The BA kernel sources executed by the CPU fiber emulator (tests/simt) against the NumPy oracle — `not gpu` tests, so
+that kernel logic (barriers, indexing, the trust-region state machine spread over launches) is checked in this GPU-less
+container on every run.  The emulated library is test infrastructure; the product never loads it (tests/simt/README.md).
+Sizes are small: a fiber switch per barrier makes a full-size window take ~10 s."""
+import numpy as np
+import pytest
+
+from oracle import ba_numpy as B
+from vins_mono_amd import ba, synth
+
+import ba_fixtures as FX
+from test_ba_gpu import _check_solve, _check_prior
+
+
+def test_emulated_solve_matches_oracle(simt_handle):
+    prob = synth.SyntheticSequence(3, L=30).window(0)
+    _check_solve(simt_handle, prob)
+
+
+def test_emulated_rejected_and_interpolated_steps(simt_handle):
+    build, need = FX.BRANCH_FIXTURES['low_parallax']
+    prob = build(L=24)
+    prob['max_iters'] = 10
+    _, _, summ = _check_solve(simt_handle, prob, rtol_cost=1e-4)
+    assert {'rejected', 'gn'} <= FX.trace_features(summ)
+
+
+def test_emulated_marginalization_matches_oracle(simt_handle):
+    seq = synth.SyntheticSequence(40, L=30)
+    prob = seq.window(0)
+    x, _ = B.solve(prob)
+    at = dict(prob)
+    at.update(pose=x['pose'], sb=x['sb'], ex=x['ex'], td=x['td'], inv_depth=x['inv_depth'], max_iters=0)
+    _, _, pr_o = B.optimization(at, B.MARGIN_OLD)
+    st_g, sm_g, pr_g = simt_handle.ba_optimize(at, ba.VG_MARGIN_OLD)
+    assert sm_g['status'] == 0
+    _check_prior(pr_g, pr_o)

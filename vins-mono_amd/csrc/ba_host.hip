@@ -129,7 +129,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.NBcap = up(std::max(NBmax, 1), 8);
     L.REC = 28 + 12 * L.e + 2 * L.t;
     L.nst = up(7 * L.Kp + 9 * L.K + 8, 2);
-    if (L.RcPad > 96 || L.Rc > 128) { h->err = "camera part wider than the solve kernel's tiling"; return VG_ERR_UNSUPPORTED; }
+    if (L.RcPad > 96 || L.Rc > 127) { h->err = "camera part wider than the solve kernel's tiling"; return VG_ERR_UNSUPPORTED; }
     // ---- workgroups per window
     L.nbf = (L.Fcap + BA_LIN_NT - 1) / BA_LIN_NT;
     L.nbl = L.nbf + 1;
@@ -223,6 +223,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         L.bo_Wt = b; b += L.RcPad * L.Lcap;
         L.bo_imuJ = b; b += (L.K - 1) * 512;       // per factor: 465 lower Hessian entries + 30 gradient entries
         L.bo_pr = b; b += L.Ncap;
+        L.bo_gpr = b; b += L.Ncap;
         L.buf_stride = up(b, 8);
     }
     L.so_buf = o; o += 2 * L.buf_stride;

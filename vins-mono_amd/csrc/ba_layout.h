@@ -46,7 +46,7 @@ struct BaLayout {
     int so_sc, so_sl, so_dg, so_gt, so_gn;      // Jacobi scaling (R / Lcap), saved Dg, gt, gn over [R | Lcap] for step reuse
     int so_yl, so_lsc;                          // landmark step / sl/sqrt(h~)
     int so_buf, buf_stride;                     // two linearisation buffers; offsets below are relative to a buffer
-    int bo_Sp, bo_gp, bo_h, bo_b, bo_Wt, bo_imuJ, bo_pr;
+    int bo_Sp, bo_gp, bo_h, bo_b, bo_Wt, bo_imuJ, bo_pr, bo_gpr;
     int sstride;
     // ---- outputs (doubles / ints per window)
     int oo_pose, oo_sb, oo_ex, oo_td, oo_lam, oo_sum, oo_trace, ostride;

@@ -331,8 +331,9 @@ DEV const double* state_block(const BaLayout& L, const double* x, int kind, int 
     if (kind == VG_BLK_EXPOSE) return st_ex(L, x);
     return st_ex(L, x) + 7;     // td
 }
-// LDS use: dx [Ncap] + part [4 Ncap] at `lds`.  Writes r to pr (global).  Returns this thread's share of sum r^2.
-NOINL double prior_pass(const Ctx& c, const double* x, double* pr, double* lds) {
+// LDS use: dx [Ncap] + part [4 Ncap] at `lds`.  Writes r to pr and (gpr != nullptr) J0^T r to gpr (global).  Returns this
+// thread's share of sum r^2.
+NOINL double prior_pass(const Ctx& c, const double* x, double* pr, double* gpr, double* lds) {
     const BaLayout& L = *c.Lp;
     if (c.nprior == 0) return 0.0;
     double* dx = lds;
@@ -374,10 +375,28 @@ NOINL double prior_pass(const Ctx& c, const double* x, double* pr, double* lds) 
         part[w] = s;
     }
     __syncthreads();
+    __syncthreads();
+    double* rl = dx;                             // the residual replaces dx in LDS
     for (int r = c.tid; r < n; r += BA_NT) {
         const double s = r0[r] + ((part[r] + part[L.Ncap + r]) + (part[2 * L.Ncap + r] + part[3 * L.Ncap + r]));
         pr[r] = s;
+        rl[r] = s;
         cost += s * s;
+    }
+    __syncthreads();
+    if (gpr) {
+        // gradient of the prior J0^T r (the solve kernel adds it to g through the prior column map), same 4-way split
+        const double* J0 = c.di + L.do_pJ0;   // row-major: J0[r*Ncap + c] coalesced over c
+        for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
+            const int a = w % L.Ncap, q = w / L.Ncap;
+            double s = 0.0;
+            if (a < n)
+                for (int k = q; k < n; k += 4) s += J0[k * L.Ncap + a] * rl[k];
+            part[w] = s;
+        }
+        __syncthreads();
+        for (int a = c.tid; a < n; a += BA_NT)
+            gpr[a] = (part[a] + part[L.Ncap + a]) + (part[2 * L.Ncap + a] + part[3 * L.Ncap + a]);
     }
     return cost;
 }
@@ -482,7 +501,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_imu_kernel(cons
     double share;
     if (cost_only) share = imu_pass<false>(c, x, buf + L.bo_imuJ);
     else share = imu_pass<true>(c, x, buf + L.bo_imuJ);
-    share += prior_pass(c, x, buf + L.bo_pr, LDSB);
+    share += prior_pass(c, x, buf + L.bo_pr, cost_only ? nullptr : buf + L.bo_gpr, LDSB);
     const double tot = block_sum(red, BA_NW, c.lane, c.wave, share);
     if (c.tid == 0) c.sc[L.so_part + L.nbf] = tot;
 }
@@ -732,20 +751,13 @@ NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf) {
     if (c.nprior) {
         const int n = c.nprior;
         const double* Hp = c.sc + L.so_Hp;
-        const double* J0 = c.di + L.do_pJ0;       // row-major: J0[r*Ncap + c] coalesced over c
-        const double* pr = buf + L.bo_pr;
+        const double* gpr = buf + L.bo_gpr;        // J0^T r, formed by the linearisation kernel
         for (int w = c.tid; w < n * (n + 1) / 2 + n; w += BA_NT) {
             const bool isg = w >= n * (n + 1) / 2;
             if (isg) {
                 const int a = w - n * (n + 1) / 2;
                 const int ca = m.pmap[a];
-                if (ca >= 0) {
-                    double s0 = 0.0, s1 = 0.0;
-                    int r = 0;
-                    for (; r + 1 < n; r += 2) { s0 += J0[r * L.Ncap + a] * pr[r]; s1 += J0[(r + 1) * L.Ncap + a] * pr[r + 1]; }
-                    if (r < n) s0 += J0[r * L.Ncap + a] * pr[r];
-                    g[ca] += s0 + s1;
-                }
+                if (ca >= 0) g[ca] += gpr[a];
             } else {
                 int a, b;
                 tri_decode(w, a, b);
@@ -1643,7 +1655,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_eval_factors_kernel(const
     const double* x = c.sc + L.so_x;
     const double* lam = c.sc + L.so_lam;
     double* buf = lin_buf(c, 0);
-    prior_pass(c, x, buf + L.bo_pr, LDSB);
+    prior_pass(c, x, buf + L.bo_pr, nullptr, LDSB);
     __syncthreads();
     const int nimu = L.K - 1;
     // weighted IMU residual / Jacobian, thread = (factor, column | residual); U = sqrt_info from the prologue
