@@ -163,7 +163,9 @@ void lk_point_level(const Level& I, const Level& J, int level, int max_level, fl
                 const int diff = descale(pix(J, X, Y) * r.w00 + pix(J, X + 1, Y) * r.w01 + pix(J, X, Y + 1) * r.w10 + pix(J, X + 1, Y + 1) * r.w11, W_BITS - 5) - Ibuf[y * WIN + x];
                 e += std::abs(diff);
             }
-        err = (float)e * (1.f / (32 * WIN * WIN));
+        // lkpyramid.cpp: `err[ptidx] = errval * 1.f/(32*winSize.width*winSize.height)` parses as a DIVISION (found by the
+        // second restatement oracle/fe_numpy.py, which follows SURVEY Appendix B.3; the first version multiplied by 1.f/14112)
+        err = ((float)e * 1.f) / (float)(32 * WIN * WIN);
     }
 }
 

@@ -1,0 +1,74 @@
+"""Two independent CPU restatements of the front-end arithmetic must agree bit for bit: oracle/fe_cpu.cpp (per-pixel
+C++ loops, the timed CPU baseline) and oracle/fe_numpy.py (whole-array NumPy / scipy.ndimage, written from SURVEY.md
+Appendix B).  With OpenCV absent this is what stands in for a golden vector (oracle/ASSUMPTIONS.md: parity unpinned)."""
+import numpy as np
+import pytest
+
+from oracle import fe_cpu as C
+from oracle import fe_numpy as N
+from vins_mono_amd import synth
+
+
+def _img(seed, w=188, h=120):
+    return synth.synth_frame(seed, w, h)
+
+
+@pytest.mark.parametrize("shape", [(188, 120), (95, 61), (64, 47)])
+def test_pyrdown_and_scharr_agree(shape):
+    a = _img(3, *shape)
+    assert np.array_equal(C.pyrdown(a), N.pyrdown(a))
+    sc = C.scharr(a)
+    ix, iy = N.scharr(a)
+    assert np.array_equal(sc[..., 0], ix) and np.array_equal(sc[..., 1], iy)
+
+
+def test_clahe_agrees_on_the_euroc_frame_size():
+    a = synth.synth_frame(5)                      # 752 x 480 -> 8 x 8 tiles of 94 x 60
+    assert np.array_equal(C.clahe(a), N.clahe(a))
+    flat = np.full((480, 752), 77, np.uint8)      # every bin but one is clipped: redistribution path
+    assert np.array_equal(C.clahe(flat), N.clahe(flat))
+
+
+def test_mineig_and_gftt_agree():
+    a = _img(7, 376, 240)
+    e_c, e_n = C.mineig(a), N.mineig(a)
+    assert np.array_equal(e_c.view(np.uint32), e_n.view(np.uint32))
+    for md in (10.0, 30.0):
+        assert np.array_equal(C.gftt(a, 60, 0.01, md), N.gftt(a, 60, 0.01, md))
+    mask = np.full(a.shape, 255, np.uint8)
+    mask[60:140, 100:260] = 0
+    got_c, got_n = C.gftt(a, 40, 0.01, 20.0, mask), N.gftt(a, 40, 0.01, 20.0, mask)
+    assert np.array_equal(got_c, got_n) and len(got_n) > 5
+    # ties: a flat image with two identical corners far apart -> larger linear index first
+    t = np.zeros((60, 80), np.uint8)
+    t[10:14, 10:14] = 200
+    t[40:44, 50:54] = 200
+    assert np.array_equal(C.gftt(t, 8, 0.01, 3.0), N.gftt(t, 8, 0.01, 3.0))
+
+
+def test_lk_agrees_including_borders_and_lost_tracks():
+    a = _img(11, 376, 240)
+    b = synth.warp_frame(a, 12)
+    pts = C.gftt(a, 40, 0.01, 12.0)
+    extra = np.array([[2.0, 3.0], [373.5, 237.2], [188.0, 1.0], [-5.0, 50.0], [-40.0, 50.0], [120.25, 80.75]], np.float32)
+    pts = np.vstack([pts, extra]).astype(np.float32)
+    o_c, s_c, e_c = C.lk(a, b, pts)
+    o_n, s_n, e_n = N.lk(a, b, pts)
+    assert np.array_equal(s_c, s_n)
+    ok = s_c.astype(bool)
+    assert np.array_equal(o_c[ok].view(np.uint32), o_n[ok].view(np.uint32))
+    assert np.array_equal(e_c[ok].view(np.uint32), e_n[ok].view(np.uint32))
+    assert ok.sum() >= 30 and (~ok).sum() >= 1
+    # large motion: most tracks are lost or diverge; both restatements must walk the same path
+    far = np.roll(a, (23, -31), axis=(0, 1))
+    o_c, s_c, _ = C.lk(a, far, pts[:12])
+    o_n, s_n, _ = N.lk(a, far, pts[:12])
+    assert np.array_equal(s_c, s_n)
+    k = s_c.astype(bool)
+    assert np.array_equal(o_c[k].view(np.uint32), o_n[k].view(np.uint32))
+
+
+def test_lk_pyramid_depth_rule():
+    # 44 x 44: the next level (22 x 22) is still larger than the window, the one after (11 x 11) is not
+    assert [l.shape for l in N.pyramid(np.zeros((44, 44), np.uint8))] == [(44, 44), (22, 22)]
+    assert len(N.pyramid(np.zeros((480, 752), np.uint8))) == 4

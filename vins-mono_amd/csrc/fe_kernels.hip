@@ -379,7 +379,7 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 }
             }
             e = wave_sum_ll(e);
-            err = (float)e * (1.f / (32 * LK_WIN * LK_WIN));
+            err = ((float)e * 1.f) / (float)(32 * LK_WIN * LK_WIN);      // a division, as OpenCV's expression parses (F3)
         }
     }
     if (lane == 0) {
