@@ -124,3 +124,49 @@ def test_estimator_shim_roundtrip_equals_direct_abi(handle):
     n = pn.value
     Jg = J0[:n * n].reshape(n, n)
     assert np.abs(Jg.T @ Jg - pr['J0'].T @ pr['J0']).max() < 1e-6 * np.abs(pr['J0'].T @ pr['J0']).max()
+
+
+def test_ba_replay_csv_matches_oracle(tmp_path):
+    """SURVEY section 7 boundary test: an N-window replay through the drop-in Estimator (vins_replay ba: device IMU
+    pre-integration, Estimator::optimization() = solve + MARGIN_OLD on the device, Estimator::slideWindow() with
+    removeBackShiftDepth, prior carried through last_marginalization_info / ..._parameter_blocks) writes the result file
+    of utility/visualization.cpp:157-172; the same replay through the NumPy oracle must give the same CSV to 1e-4."""
+    import replay_util as R
+    plan = R.make_plan(5, 5, L=50)
+    seqf, outf = tmp_path / "seq.bin", tmp_path / "vins_result.csv"
+    R.write_sequence(plan, str(seqf))
+    r = subprocess.run([os.path.join(LIBDIR, "vins_replay"), "ba", str(seqf), str(outf)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[float(v) for v in line.rstrip(",\n").split(",")] for line in open(outf)])
+    ref = R.run_oracle(plan)
+    assert got.shape == ref.shape == (5, 11)
+    assert np.array_equal(got[:, 0], np.round(ref[:, 0]))                 # stamps [ns]
+    assert np.abs(got[:, 1:4] - ref[:, 1:4]).max() < 1e-4 * max(1.0, np.abs(ref[:, 1:4]).max())
+    assert np.abs(got[:, 4:8] - ref[:, 4:8]).max() < 1e-4
+    assert np.abs(got[:, 8:11] - ref[:, 8:11]).max() < 1e-4 * max(1.0, np.abs(ref[:, 8:11]).max())
+    # the windows really are chained: later rows move with the trajectory
+    assert np.abs(got[-1, 1:4] - got[0, 1:4]).max() > 0.1
+
+
+def test_estimator_shim_drops_the_prior_after_a_numeric_failure(handle):
+    """A non-finite solve (VG_ERR_NUMERIC) must not leave the PRE-slide prior behind: after MARGIN_OLD it still names pose /
+    speed-bias 0 and un-shifted frame indices and would be bound to the wrong frames by the next optimization()."""
+    lib = C.CDLL(os.path.join(LIBDIR, "libvins_host.so"))
+    seq = synth.SyntheticSequence(78, L=40)
+    p1 = seq.window(0)
+    st1, _, pr1 = handle.ba_optimize(p1, ba.VG_MARGIN_OLD)
+    prob = seq.next_window(st1, pr1, 1)
+    prob['sb'] = prob['sb'].copy()
+    prob['sb'][4, 1] = np.nan
+    pk = ba.PackedProblem(prob)
+    K, L = pk.K, pk.L
+    pose, sb, depth = np.zeros((K, 7)), np.zeros((K, 9)), np.zeros(L)
+    flag, pn, pnb, iters = np.zeros(L, np.int32), C.c_int(-1), C.c_int(-1), C.c_int()
+    kind, idx = np.zeros(32, np.int32), np.zeros(32, np.int32)
+    J0, r0 = np.zeros(128 * 128), np.zeros(128)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    rc = lib.vins_host_estimator_roundtrip(C.byref(pk.struct), 0, pose.ctypes.data_as(dp), sb.ctypes.data_as(dp), depth.ctypes.data_as(dp),
+                                           flag.ctypes.data_as(ip), C.byref(pn), C.byref(pnb), kind.ctypes.data_as(ip), idx.ctypes.data_as(ip),
+                                           J0.ctypes.data_as(dp), r0.ctypes.data_as(dp), C.byref(iters))
+    assert rc == 0
+    assert pn.value == 0 and pnb.value == 0          # neither the old prior (it was set on entry) nor a new one

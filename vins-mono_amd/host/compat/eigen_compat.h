@@ -4,6 +4,7 @@
 #pragma once
 #ifndef VINS_REAL_EIGEN
 #include <cmath>
+#include <utility>
 #include <vector>
 namespace Eigen {
 struct Vector2d { double d[2] = {0, 0}; double& x() { return d[0]; } double& y() { return d[1]; } double x() const { return d[0]; } double y() const { return d[1]; } };
@@ -14,10 +15,18 @@ struct Vector3d {
     double& x() { return d[0]; } double& y() { return d[1]; } double& z() { return d[2]; }
     double x() const { return d[0]; } double y() const { return d[1]; } double z() const { return d[2]; }
     double& operator()(int i) { return d[i]; } double operator()(int i) const { return d[i]; }
+    Vector3d operator+(const Vector3d& o) const { return Vector3d(d[0] + o.d[0], d[1] + o.d[1], d[2] + o.d[2]); }
+    Vector3d operator-(const Vector3d& o) const { return Vector3d(d[0] - o.d[0], d[1] - o.d[1], d[2] - o.d[2]); }
+    Vector3d operator*(double k) const { return Vector3d(d[0] * k, d[1] * k, d[2] * k); }
+    void swap(Vector3d& o) { std::swap(*this, o); }
 };
 struct Matrix3d {
     double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     double& operator()(int r, int c) { return m[r * 3 + c]; } double operator()(int r, int c) const { return m[r * 3 + c]; }
+    Vector3d operator*(const Vector3d& v) const { return Vector3d(m[0] * v.d[0] + m[1] * v.d[1] + m[2] * v.d[2], m[3] * v.d[0] + m[4] * v.d[1] + m[5] * v.d[2], m[6] * v.d[0] + m[7] * v.d[1] + m[8] * v.d[2]); }
+    Matrix3d operator*(const Matrix3d& o) const { Matrix3d r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i * 3 + j] = m[i * 3] * o.m[j] + m[i * 3 + 1] * o.m[3 + j] + m[i * 3 + 2] * o.m[6 + j]; return r; }
+    Matrix3d transpose() const { Matrix3d r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i * 3 + j] = m[j * 3 + i]; return r; }
+    void swap(Matrix3d& o) { std::swap(*this, o); }
 };
 struct Quaterniond {
     double qw = 1, qx = 0, qy = 0, qz = 0;
@@ -36,6 +45,42 @@ struct Quaterniond {
         R(0, 0) = 1 - (tyy + tzz); R(0, 1) = txy - twz; R(0, 2) = txz + twy; R(1, 0) = txy + twz; R(1, 1) = 1 - (txx + tzz); R(1, 2) = tyz - twx; R(2, 0) = txz - twy; R(2, 1) = tyz + twx; R(2, 2) = 1 - (txx + tyy);
         return R;
     }
+};
+// fixed-size and dynamic matrices, COLUMN-MAJOR like Eigen's default (so that a build against real Eigen sees the same
+// memory order): only operator()(r, c), data(), rows(), cols(), resize(), setZero() are used by the shims
+template <typename T, int R, int C> struct Matrix {
+    T v[R * C] = {};
+    T& operator()(int r, int c) { return v[c * R + r]; }
+    const T& operator()(int r, int c) const { return v[c * R + r]; }
+    T* data() { return v; }
+    const T* data() const { return v; }
+    int rows() const { return R; }
+    int cols() const { return C; }
+    void setZero() { for (auto& x : v) x = T(0); }
+};
+struct MatrixXd {
+    std::vector<double> v;
+    int r = 0, c = 0;
+    MatrixXd() {}
+    MatrixXd(int rr, int cc) { resize(rr, cc); }
+    void resize(int rr, int cc) { r = rr; c = cc; v.assign((size_t)rr * cc, 0.0); }
+    double& operator()(int i, int j) { return v[(size_t)j * r + i]; }
+    double operator()(int i, int j) const { return v[(size_t)j * r + i]; }
+    double* data() { return v.data(); }
+    const double* data() const { return v.data(); }
+    int rows() const { return r; }
+    int cols() const { return c; }
+};
+struct VectorXd {
+    std::vector<double> v;
+    VectorXd() {}
+    explicit VectorXd(int n) { v.assign(n, 0.0); }
+    void resize(int n) { v.assign(n, 0.0); }
+    double& operator()(int i) { return v[i]; }
+    double operator()(int i) const { return v[i]; }
+    double* data() { return v.data(); }
+    const double* data() const { return v.data(); }
+    int size() const { return (int)v.size(); }
 };
 }  // namespace Eigen
 #else

@@ -7,7 +7,7 @@
 #include <string>
 
 int ESTIMATE_EXTRINSIC = 0, ESTIMATE_TD = 0, NUM_ITERATIONS = 8;
-double TD = 0, TR = 0, ROW_D = 480, FOCAL_LENGTH_D = 460.0, G_NORM = 9.81007;
+double TD = 0, TR = 0, ROW_D = 480, FOCAL_LENGTH_D = 460.0, G_NORM = 9.81007, INIT_DEPTH = 5.0;
 
 int FeatureManager::getFeatureCount() {                         // feature_manager.cpp:28-42
     int cnt = 0;
@@ -16,6 +16,76 @@ int FeatureManager::getFeatureCount() {                         // feature_manag
         if (it.used_num >= 2 && it.start_frame < WINDOW_SIZE - 2) cnt++;
     }
     return cnt;
+}
+
+void FeatureManager::removeBackShiftDepth(Matrix3d marg_R, Vector3d marg_P, Matrix3d new_R, Vector3d new_P) {   // feature_manager.cpp:275-313
+    for (auto it = feature.begin(), it_next = feature.begin(); it != feature.end(); it = it_next) {
+        it_next++;
+        if (it->start_frame != 0) it->start_frame--;
+        else {
+            Vector3d uv_i = it->feature_per_frame[0].point;
+            it->feature_per_frame.erase(it->feature_per_frame.begin());
+            if (it->feature_per_frame.size() < 2) { feature.erase(it); continue; }
+            Vector3d pts_i = uv_i * it->estimated_depth;
+            Vector3d w_pts_i = marg_R * pts_i + marg_P;
+            Vector3d pts_j = new_R.transpose() * (w_pts_i - new_P);
+            const double dep_j = pts_j(2);
+            it->estimated_depth = dep_j > 0 ? dep_j : INIT_DEPTH;
+        }
+    }
+}
+
+void FeatureManager::removeBack() {                              // feature_manager.cpp:315-331
+    for (auto it = feature.begin(), it_next = feature.begin(); it != feature.end(); it = it_next) {
+        it_next++;
+        if (it->start_frame != 0) it->start_frame--;
+        else {
+            it->feature_per_frame.erase(it->feature_per_frame.begin());
+            if (it->feature_per_frame.size() == 0) feature.erase(it);
+        }
+    }
+}
+
+void FeatureManager::removeFront(int frame_count) {              // feature_manager.cpp:333-351
+    for (auto it = feature.begin(), it_next = feature.begin(); it != feature.end(); it = it_next) {
+        it_next++;
+        if (it->start_frame == frame_count) it->start_frame--;
+        else {
+            const int j = WINDOW_SIZE - 1 - it->start_frame;
+            if ((int)it->feature_per_frame.size() - 1 < j) continue;       // endFrame() < frame_count - 1
+            it->feature_per_frame.erase(it->feature_per_frame.begin() + j);
+            if (it->feature_per_frame.size() == 0) feature.erase(it);
+        }
+    }
+}
+
+void Estimator::slideWindow() {
+    // estimator.cpp:1005-1126 for frame_count == WINDOW_SIZE and solver_flag == NON_LINEAR; the raw IMU buffers
+    // (dt_buf ...) and all_image_frame belong to processIMU / the initialiser and are not mirrored here
+    if (marginalization_flag == MARGIN_OLD) {
+        back_R0 = Rs[0];
+        back_P0 = Ps[0];
+        for (int i = 0; i < WINDOW_SIZE; i++) {
+            Rs[i].swap(Rs[i + 1]);
+            std::swap(pre_integrations[i], pre_integrations[i + 1]);
+            Ps[i].swap(Ps[i + 1]);
+            Vs[i].swap(Vs[i + 1]);
+            Bas[i].swap(Bas[i + 1]);
+            Bgs[i].swap(Bgs[i + 1]);
+        }
+        Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1]; Vs[WINDOW_SIZE] = Vs[WINDOW_SIZE - 1]; Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1];
+        Bas[WINDOW_SIZE] = Bas[WINDOW_SIZE - 1]; Bgs[WINDOW_SIZE] = Bgs[WINDOW_SIZE - 1];
+        pre_integrations[WINDOW_SIZE] = nullptr;                 // the caller installs the next interval's pre-integration
+        // slideWindowOld(), shift_depth = true (:1115-1126)
+        Matrix3d R0 = back_R0 * ric[0], R1 = Rs[0] * ric[0];
+        Vector3d P0 = back_P0 + back_R0 * tic[0], P1 = Ps[0] + Rs[0] * tic[0];
+        f_manager.removeBackShiftDepth(R0, P0, R1, P1);
+    } else {
+        Ps[WINDOW_SIZE - 1] = Ps[WINDOW_SIZE]; Vs[WINDOW_SIZE - 1] = Vs[WINDOW_SIZE]; Rs[WINDOW_SIZE - 1] = Rs[WINDOW_SIZE];
+        Bas[WINDOW_SIZE - 1] = Bas[WINDOW_SIZE]; Bgs[WINDOW_SIZE - 1] = Bgs[WINDOW_SIZE];
+        pre_integrations[WINDOW_SIZE] = nullptr;
+        f_manager.removeFront(WINDOW_SIZE);                      // slideWindowNew() (:1107-1111)
+    }
 }
 
 Estimator::Estimator() { for (auto& p : pre_integrations) p = nullptr; memset(&last_summary, 0, sizeof(last_summary)); }
@@ -96,7 +166,8 @@ void Estimator::optimization() {
         m.valid = 1; m.sum_dt = p->sum_dt;
         for (int k = 0; k < 3; ++k) { m.delta_p[k] = p->delta_p(k); m.delta_v[k] = p->delta_v(k); m.linearized_ba[k] = p->linearized_ba(k); m.linearized_bg[k] = p->linearized_bg(k); }
         m.delta_q[0] = p->delta_q.x(); m.delta_q[1] = p->delta_q.y(); m.delta_q[2] = p->delta_q.z(); m.delta_q[3] = p->delta_q.w();
-        memcpy(m.jacobian, p->jacobian, sizeof(m.jacobian)); memcpy(m.covariance, p->covariance, sizeof(m.covariance));
+        for (int r = 0; r < 15; ++r)                            // Eigen is column-major, the C-ABI row-major: convert explicitly
+            for (int c = 0; c < 15; ++c) { m.jacobian[r * 15 + c] = p->jacobian(r, c); m.covariance[r * 15 + c] = p->covariance(r, c); }
     }
     vg_ba_problem pb;
     memset(&pb, 0, sizeof(pb));
@@ -104,11 +175,25 @@ void Estimator::optimization() {
     pb.pose = &para_Pose[0][0]; pb.speedbias = &para_SpeedBias[0][0]; pb.ex_pose = &para_Ex_Pose[0][0]; pb.td = para_Td[0][0];
     pb.inv_depth = &para_Feature[0][0];
     pb.lm_start = lm_start.data(); pb.lm_nobs = lm_nobs.data(); pb.lm_obs_off = lm_off.data(); pb.obs = obs.data(); pb.imu = imu.data();
-    if (last_marginalization_info) {                             // MarginalizationFactor (:703-709)
+    // MarginalizationFactor(last_marginalization_info) on last_marginalization_parameter_blocks (:703-709): the blocks are
+    // identified by their para_* ADDRESSES, as in the reference; the C-ABI wants (kind, frame index)
+    vector<int> pkind, pindex;
+    vector<double> pJ0, px0;
+    if (last_marginalization_info) {
         MarginalizationInfo* mi = last_marginalization_info;
-        pb.prior_n = mi->n; pb.prior_nblocks = (int)mi->keep_block_kind.size();
-        pb.prior_block_kind = mi->keep_block_kind.data(); pb.prior_block_index = mi->keep_block_index.data();
-        pb.prior_J0 = mi->linearized_jacobians.data(); pb.prior_r0 = mi->linearized_residuals.data(); pb.prior_x0 = mi->keep_block_data.data();
+        const int n = mi->n, nb = (int)mi->keep_block_size.size();
+        for (int b = 0; b < nb; ++b) {
+            int kind, index;
+            if (!block_of(last_marginalization_parameter_blocks[b], kind, index)) throw std::runtime_error("prior block address outside the para_* arrays");
+            pkind.push_back(kind); pindex.push_back(index);
+            px0.insert(px0.end(), mi->keep_block_data[b], mi->keep_block_data[b] + mi->keep_block_size[b]);
+        }
+        pJ0.resize((size_t)n * n);
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) pJ0[(size_t)r * n + c] = mi->linearized_jacobians(r, c);
+        pb.prior_n = n; pb.prior_nblocks = nb;
+        pb.prior_block_kind = pkind.data(); pb.prior_block_index = pindex.data();
+        pb.prior_J0 = pJ0.data(); pb.prior_r0 = mi->linearized_residuals.data(); pb.prior_x0 = px0.data();
     }
     pb.estimate_extrinsic = ESTIMATE_EXTRINSIC ? 1 : 0; pb.estimate_td = ESTIMATE_TD ? 1 : 0; pb.max_iters = NUM_ITERATIONS;
     pb.focal = FOCAL_LENGTH_D; pb.tr = TR; pb.row = ROW_D; pb.g_norm = G_NORM;
@@ -118,24 +203,63 @@ void Estimator::optimization() {
     st.pose = &para_Pose[0][0]; st.speedbias = &para_SpeedBias[0][0]; st.ex_pose = &para_Ex_Pose[0][0]; st.td = &para_Td[0][0];
     st.inv_depth = lam.data(); st.relo_pose = nullptr;
     const int cap = 6 * K + 32, capb = K + 8;
-    MarginalizationInfo* mi_new = new MarginalizationInfo();
-    mi_new->keep_block_kind.resize(capb); mi_new->keep_block_index.resize(capb); mi_new->keep_block_data.resize(9 * capb);
-    mi_new->linearized_jacobians.resize((size_t)cap * cap); mi_new->linearized_residuals.resize(cap);
+    vector<int> nkind(capb), nindex(capb);
+    vector<double> nJ0((size_t)cap * cap), nr0(cap), nx0(9 * capb);      // x0 holds 9 doubles per block at most (speed-bias)
     vg_ba_prior pr;
-    pr.cap = cap; pr.cap_blocks = capb; pr.block_kind = mi_new->keep_block_kind.data(); pr.block_index = mi_new->keep_block_index.data();
-    pr.J0 = mi_new->linearized_jacobians.data(); pr.r0 = mi_new->linearized_residuals.data(); pr.x0 = mi_new->keep_block_data.data();
+    memset(&pr, 0, sizeof(pr));
+    pr.cap = cap; pr.cap_blocks = capb; pr.block_kind = nkind.data(); pr.block_index = nindex.data();
+    pr.J0 = nJ0.data(); pr.r0 = nr0.data(); pr.x0 = nx0.data();
     const int flag = marginalization_flag == MARGIN_OLD ? VG_MARGIN_OLD : VG_MARGIN_SECOND_NEW;
     const int rc = vg_ba_optimize(vg_, &pb, flag, &st, &last_summary, &pr);       // ceres::Solve (:818) + marginalization (:825-1000)
-    if (rc != VG_OK && rc != VG_ERR_NUMERIC) { delete mi_new; throw std::runtime_error(std::string("vg_ba_optimize: ") + vg_last_error(vg_)); }
+    if (rc != VG_OK && rc != VG_ERR_NUMERIC) throw std::runtime_error(std::string("vg_ba_optimize: ") + vg_last_error(vg_));
     for (int l = 0; l < L; ++l) para_Feature[l][0] = lam[l];
     double2vector();                                            // :823
-    if (pr.valid) {                                             // last_marginalization_info = marginalization_info (:926-929 / :992-996)
-        mi_new->n = pr.n; mi_new->m = pr.m;
-        mi_new->keep_block_kind.resize(pr.nblocks); mi_new->keep_block_index.resize(pr.nblocks);
-        mi_new->linearized_jacobians.resize((size_t)pr.n * pr.n); mi_new->linearized_residuals.resize(pr.n);
+    solver_failed = rc == VG_ERR_NUMERIC;
+    if (solver_failed) {
+        // Non-finite cost / state on the device: no new prior exists, and the OLD one must not survive the caller's
+        // slideWindow() (after MARGIN_OLD it still names pose / speed-bias 0 and un-shifted frame indices).  The reference
+        // would carry a NaN prior on; dropping it is the conservative equivalent until failureDetection() restarts.
         delete last_marginalization_info;
-        last_marginalization_info = mi_new;
-    } else {
-        delete mi_new;      // MARGIN_SECOND_NEW without Pose[WINDOW_SIZE-1] in the prior: the old prior stays (:935-936)
+        last_marginalization_info = nullptr;
+        last_marginalization_parameter_blocks.clear();
+        return;
     }
+    if (pr.valid) {                                             // last_marginalization_info = marginalization_info (:926-929 / :992-996)
+        MarginalizationInfo* mi = new MarginalizationInfo();
+        mi->n = pr.n; mi->m = pr.m;
+        mi->linearized_jacobians.resize(pr.n, pr.n);
+        mi->linearized_residuals.resize(pr.n);
+        for (int r = 0; r < pr.n; ++r) {
+            mi->linearized_residuals(r) = nr0[r];
+            for (int c = 0; c < pr.n; ++c) mi->linearized_jacobians(r, c) = nJ0[(size_t)r * pr.n + c];
+        }
+        vector<double*> blocks;
+        int off = 0, x0o = 0;
+        for (int b = 0; b < pr.nblocks; ++b) {
+            const int kind = nkind[b], idx = nindex[b];
+            const int gs = kind == VG_BLK_SPEEDBIAS ? 9 : (kind == VG_BLK_TD ? 1 : 7), ls = kind == VG_BLK_SPEEDBIAS ? 9 : (kind == VG_BLK_TD ? 1 : 6);
+            mi->keep_block_size.push_back(gs);
+            mi->keep_block_idx.push_back(pr.m + off);
+            double* d = new double[gs];
+            memcpy(d, nx0.data() + x0o, sizeof(double) * gs);
+            mi->keep_block_data.push_back(d);
+            // addr_shift (:913-924 / :969-990): the block's address in the SLID window (the device already re-labelled it)
+            blocks.push_back(kind == VG_BLK_POSE ? para_Pose[idx] : kind == VG_BLK_SPEEDBIAS ? para_SpeedBias[idx] : kind == VG_BLK_EXPOSE ? para_Ex_Pose[0] : para_Td[0]);
+            off += ls; x0o += gs;
+        }
+        delete last_marginalization_info;
+        last_marginalization_info = mi;
+        last_marginalization_parameter_blocks = blocks;
+    }
+    // else: MARGIN_SECOND_NEW without Pose[WINDOW_SIZE-1] in the prior: the old prior and its blocks stay (:935-936)
+}
+
+bool Estimator::block_of(const double* addr, int& kind, int& index) const {
+    for (int i = 0; i <= WINDOW_SIZE; ++i) {
+        if (addr == para_Pose[i]) { kind = VG_BLK_POSE; index = i; return true; }
+        if (addr == para_SpeedBias[i]) { kind = VG_BLK_SPEEDBIAS; index = i; return true; }
+    }
+    if (addr == para_Ex_Pose[0]) { kind = VG_BLK_EXPOSE; index = 0; return true; }
+    if (addr == para_Td[0]) { kind = VG_BLK_TD; index = 0; return true; }
+    return false;
 }

@@ -16,7 +16,7 @@ const int WINDOW_SIZE = 10;                  // vins_estimator/src/parameters.h:
 const int NUM_OF_CAM = 1;
 const int NUM_OF_F = 1000;
 extern int ESTIMATE_EXTRINSIC, ESTIMATE_TD, NUM_ITERATIONS;
-extern double TD, TR, ROW_D, FOCAL_LENGTH_D, G_NORM;
+extern double TD, TR, ROW_D, FOCAL_LENGTH_D, G_NORM, INIT_DEPTH;
 
 struct FeaturePerFrame { Vector3d point; Vector2d uv; Vector2d velocity; double cur_td = 0; };   // feature_manager.h:19-42
 struct FeaturePerId {                                                                             // feature_manager.h:44-66
@@ -26,21 +26,30 @@ struct FeaturePerId {                                                           
     double estimated_depth = -1;
     int solve_flag = 0;            // 0 haven't solved yet; 1 solve succ; 2 solve fail
 };
-struct FeatureManager { list<FeaturePerId> feature; int getFeatureCount(); };
+struct FeatureManager {
+    list<FeaturePerId> feature;
+    int getFeatureCount();
+    // window-shift bookkeeping (feature_manager.cpp:275-341); host code, run between two optimization() calls
+    void removeBackShiftDepth(Matrix3d marg_R, Vector3d marg_P, Matrix3d new_R, Vector3d new_P);
+    void removeBack();
+    void removeFront(int frame_count);
+};
 
-struct IntegrationBase {           // the members IMUFactor reads (factor/integration_base.h:188-208)
+struct IntegrationBase {           // the members IMUFactor reads (factor/integration_base.h:188-208), same types
     double sum_dt = 0;
     Vector3d delta_p, delta_v, linearized_ba, linearized_bg;
     Quaterniond delta_q;
-    double jacobian[225], covariance[225];      // row-major 15x15
+    Eigen::Matrix<double, 15, 15> jacobian, covariance;      // column-major (Eigen default), integration_base.h:195
 };
 
-struct MarginalizationInfo {       // what getParameterBlocks() leaves behind (marginalization_factor.h:44-72)
-    int n = 0, m = 0;
-    vector<int> keep_block_kind, keep_block_index;      // re-labelled for the slid window
-    vector<double> keep_block_data;                     // concatenated, global sizes
-    vector<double> linearized_jacobians;                // n x n row-major
-    vector<double> linearized_residuals;
+struct MarginalizationInfo {       // the members MarginalizationFactor reads (marginalization_factor.h:44-72), same names / types
+    ~MarginalizationInfo() { for (double* p : keep_block_data) delete[] p; }
+    int m = 0, n = 0;
+    std::vector<int> keep_block_size;       // global size of every kept block (7 / 9 / 7 / 1)
+    std::vector<int> keep_block_idx;        // its first column in the [m dropped | n kept] ordering (local, so >= m)
+    std::vector<double*> keep_block_data;   // owned copy of its linearisation point
+    Eigen::MatrixXd linearized_jacobians;   // n x n
+    Eigen::VectorXd linearized_residuals;   // n
 };
 
 class Estimator {
@@ -51,6 +60,7 @@ class Estimator {
     void optimization();           // estimator.h:47
     void vector2double();
     void double2vector();
+    void slideWindow();            // estimator.cpp:1005-1126 (state / pre-integration shift + slideWindowOld / slideWindowNew)
 
     MarginalizationFlag marginalization_flag = MARGIN_OLD;
     Vector3d Ps[(WINDOW_SIZE + 1)], Vs[(WINDOW_SIZE + 1)], Bas[(WINDOW_SIZE + 1)], Bgs[(WINDOW_SIZE + 1)];
@@ -62,7 +72,14 @@ class Estimator {
     FeatureManager f_manager;
     double para_Pose[WINDOW_SIZE + 1][7], para_SpeedBias[WINDOW_SIZE + 1][9], para_Feature[NUM_OF_F][1], para_Ex_Pose[NUM_OF_CAM][7], para_Td[1][1];
     MarginalizationInfo* last_marginalization_info = nullptr;
+    vector<double*> last_marginalization_parameter_blocks;      // para_* address of every kept block, already shifted (estimator.h:117)
+    Matrix3d back_R0;
+    Vector3d back_P0;
+    bool solver_failed = false;    // the device reported a non-finite solve: the prior was dropped (see optimization())
     vg_ba_summary last_summary;    // trace of the last solve (the reference only logs Summary::BriefReport)
+
+    // (kind, frame index) of a parameter-block address inside para_Pose / para_SpeedBias / para_Ex_Pose / para_Td
+    bool block_of(const double* addr, int& kind, int& index) const;
 
   private:
     vg_handle* vg_ = nullptr;

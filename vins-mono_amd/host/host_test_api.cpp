@@ -31,7 +31,8 @@ extern "C" int vins_host_estimator_roundtrip(const vg_ba_problem* p, int margin_
         q.linearized_ba = Vector3d(m.linearized_ba[0], m.linearized_ba[1], m.linearized_ba[2]);
         q.linearized_bg = Vector3d(m.linearized_bg[0], m.linearized_bg[1], m.linearized_bg[2]);
         q.delta_q = Quaterniond(m.delta_q[3], m.delta_q[0], m.delta_q[1], m.delta_q[2]);
-        memcpy(q.jacobian, m.jacobian, sizeof(q.jacobian)); memcpy(q.covariance, m.covariance, sizeof(q.covariance));
+        for (int r = 0; r < 15; ++r)
+            for (int c = 0; c < 15; ++c) { q.jacobian(r, c) = m.jacobian[r * 15 + c]; q.covariance(r, c) = m.covariance[r * 15 + c]; }
         est.pre_integrations[k + 1] = m.valid ? &q : nullptr;
     }
     // features: the real ones interleaved with decoys the used_num / start_frame filter must drop
@@ -53,16 +54,28 @@ extern "C" int vins_host_estimator_roundtrip(const vg_ba_problem* p, int margin_
         }
     }
     if (p->prior_n > 0) {
+        // a prior as the previous optimization() would have left it: reference-typed members + block addresses
         MarginalizationInfo* mi = new MarginalizationInfo();
-        mi->n = p->prior_n;
-        int x0n = 0;
+        mi->n = p->prior_n; mi->m = 0;
+        int off = 0, x0o = 0;
         for (int b = 0; b < p->prior_nblocks; ++b) {
-            mi->keep_block_kind.push_back(p->prior_block_kind[b]); mi->keep_block_index.push_back(p->prior_block_index[b]);
-            x0n += p->prior_block_kind[b] == VG_BLK_SPEEDBIAS ? 9 : (p->prior_block_kind[b] == VG_BLK_TD ? 1 : 7);
+            const int kind = p->prior_block_kind[b], idx = p->prior_block_index[b];
+            const int gs = kind == VG_BLK_SPEEDBIAS ? 9 : (kind == VG_BLK_TD ? 1 : 7), ls = kind == VG_BLK_SPEEDBIAS ? 9 : (kind == VG_BLK_TD ? 1 : 6);
+            mi->keep_block_size.push_back(gs);
+            mi->keep_block_idx.push_back(off);
+            double* d = new double[gs];
+            memcpy(d, p->prior_x0 + x0o, sizeof(double) * gs);
+            mi->keep_block_data.push_back(d);
+            est.last_marginalization_parameter_blocks.push_back(kind == VG_BLK_POSE ? est.para_Pose[idx] : kind == VG_BLK_SPEEDBIAS ? est.para_SpeedBias[idx]
+                                                                : kind == VG_BLK_EXPOSE ? est.para_Ex_Pose[0] : est.para_Td[0]);
+            off += ls; x0o += gs;
         }
-        mi->keep_block_data.assign(p->prior_x0, p->prior_x0 + x0n);
-        mi->linearized_jacobians.assign(p->prior_J0, p->prior_J0 + (size_t)p->prior_n * p->prior_n);
-        mi->linearized_residuals.assign(p->prior_r0, p->prior_r0 + p->prior_n);
+        mi->linearized_jacobians.resize(p->prior_n, p->prior_n);
+        mi->linearized_residuals.resize(p->prior_n);
+        for (int r = 0; r < p->prior_n; ++r) {
+            mi->linearized_residuals(r) = p->prior_r0[r];
+            for (int c = 0; c < p->prior_n; ++c) mi->linearized_jacobians(r, c) = p->prior_J0[(size_t)r * p->prior_n + c];
+        }
         est.last_marginalization_info = mi;
     }
     est.marginalization_flag = margin_flag == VG_MARGIN_OLD ? Estimator::MARGIN_OLD : Estimator::MARGIN_SECOND_NEW;
@@ -83,10 +96,16 @@ extern "C" int vins_host_estimator_roundtrip(const vg_ba_problem* p, int margin_
     *prior_n = 0; *prior_nblocks = 0;
     if (est.last_marginalization_info) {
         MarginalizationInfo* mi = est.last_marginalization_info;
-        *prior_n = mi->n; *prior_nblocks = (int)mi->keep_block_kind.size();
-        for (int b = 0; b < *prior_nblocks; ++b) { prior_kind[b] = mi->keep_block_kind[b]; prior_index[b] = mi->keep_block_index[b]; }
-        memcpy(prior_J0, mi->linearized_jacobians.data(), sizeof(double) * mi->n * mi->n);
-        memcpy(prior_r0, mi->linearized_residuals.data(), sizeof(double) * mi->n);
+        *prior_n = mi->n; *prior_nblocks = (int)mi->keep_block_size.size();
+        for (int b = 0; b < *prior_nblocks; ++b) {
+            int kind = -1, index = -1;
+            est.block_of(est.last_marginalization_parameter_blocks[b], kind, index);
+            prior_kind[b] = kind; prior_index[b] = index;
+        }
+        for (int r = 0; r < mi->n; ++r) {
+            prior_r0[r] = mi->linearized_residuals(r);
+            for (int c = 0; c < mi->n; ++c) prior_J0[(size_t)r * mi->n + c] = mi->linearized_jacobians(r, c);
+        }
     }
     return 0;
 }

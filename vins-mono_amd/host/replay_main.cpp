@@ -1,16 +1,28 @@
-// replay_main.cpp — ROS-free replay harness for the drop-in classes (SURVEY.md 8(d) configs[0] substitute):
+// replay_main.cpp — ROS-free replay harness for the drop-in classes (SURVEY.md 8(d) configs[0] substitute).
+//
 //   vins_replay fe <frames.bin> <out.txt>   frames.bin = int32 n, w, h, pub_every ; n * w*h bytes
-// feeds the frames through FeatureTracker::readImage exactly as img_callback does (feature_tracker_node.cpp:86-111:
-// readImage, then updateID for every feature) and dumps, per frame, ids / cur_pts / track_cnt / cur_un_pts / velocity.
+//     feeds the frames through FeatureTracker::readImage exactly as img_callback does (feature_tracker_node.cpp:86-111:
+//     readImage, then updateID for every feature) and dumps, per frame, ids / cur_pts / track_cnt / cur_un_pts / velocity.
+//
+//   vins_replay ba <sequence.bin> <out.csv>
+//     N consecutive sliding windows through the drop-in Estimator the way process() drives it once the system is
+//     initialised (estimator.cpp:120-170): IMU pre-integration of the new frame interval (here: vg_imu_preintegrate on
+//     the device instead of processIMU's sample-by-sample push_back), Estimator::optimization() (solve + MARGIN_OLD
+//     marginalization, prior carried over through last_marginalization_info / ..._parameter_blocks) and
+//     Estimator::slideWindow() (state shift + removeBackShiftDepth).  Writes one line per window in the format of
+//     pubOdometry's result file (utility/visualization.cpp:157-172): stamp[ns], P, Q(w x y z), V of frame WINDOW_SIZE.
+//     sequence.bin is written by tests/replay_util.py.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <stdexcept>
 #include <vector>
+#include "estimator.h"
 #include "feature_tracker.h"
 
-int main(int argc, char** argv) {
-    if (argc < 4 || strcmp(argv[1], "fe")) { fprintf(stderr, "usage: vins_replay fe <frames.bin> <out.txt>\n"); return 2; }
-    FILE* f = fopen(argv[2], "rb");
+static int replay_fe(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb");
     if (!f) { perror("frames"); return 2; }
     int hdr[4];
     if (fread(hdr, sizeof(int), 4, f) != 4) return 2;
@@ -18,7 +30,7 @@ int main(int argc, char** argv) {
     COL = w; ROW = h;
     std::vector<unsigned char> buf((size_t)w * h);
     FeatureTracker tracker;
-    FILE* o = fopen(argv[3], "w");
+    FILE* o = fopen(out, "w");
     for (int k = 0; k < n; ++k) {
         if (fread(buf.data(), 1, buf.size(), f) != buf.size()) return 2;
         PUB_THIS_FRAME = (k % pub_every) == 0;
@@ -33,4 +45,127 @@ int main(int argc, char** argv) {
     fclose(o);
     fclose(f);
     return 0;
+}
+
+namespace {
+struct Reader {
+    FILE* f;
+    void d(double* p, int n) { if (fread(p, sizeof(double), n, f) != (size_t)n) throw std::runtime_error("sequence file truncated"); }
+    void i(int* p, int n) { if (fread(p, sizeof(int), n, f) != (size_t)n) throw std::runtime_error("sequence file truncated"); }
+};
+struct FrameInit { double t, pose[7], sb[9]; };
+
+void set_frame(Estimator& e, int i, const FrameInit& fr) {
+    e.Ps[i] = Vector3d(fr.pose[0], fr.pose[1], fr.pose[2]);
+    e.Rs[i] = Quaterniond(fr.pose[6], fr.pose[3], fr.pose[4], fr.pose[5]).toRotationMatrix();
+    e.Vs[i] = Vector3d(fr.sb[0], fr.sb[1], fr.sb[2]);
+    e.Bas[i] = Vector3d(fr.sb[3], fr.sb[4], fr.sb[5]);
+    e.Bgs[i] = Vector3d(fr.sb[6], fr.sb[7], fr.sb[8]);
+}
+
+// one frame interval: (acc_0, gyr_0) + S samples (dt, acc, gyr) -> IntegrationBase on the device
+IntegrationBase* preintegrate(vg_handle* h, Reader& rd, int S, const double* bias, const double* noise) {
+    double first[6];
+    rd.d(first, 6);
+    std::vector<double> smp((size_t)S * 7);
+    rd.d(smp.data(), S * 7);
+    const int off[2] = {0, S};
+    vg_imu_preint out;
+    if (vg_imu_preintegrate(h, 1, off, smp.data(), first, bias, noise, &out) != VG_OK) throw std::runtime_error(vg_last_error(h));
+    IntegrationBase* p = new IntegrationBase();
+    p->sum_dt = out.sum_dt;
+    p->delta_p = Vector3d(out.delta_p[0], out.delta_p[1], out.delta_p[2]);
+    p->delta_v = Vector3d(out.delta_v[0], out.delta_v[1], out.delta_v[2]);
+    p->linearized_ba = Vector3d(out.linearized_ba[0], out.linearized_ba[1], out.linearized_ba[2]);
+    p->linearized_bg = Vector3d(out.linearized_bg[0], out.linearized_bg[1], out.linearized_bg[2]);
+    p->delta_q = Quaterniond(out.delta_q[3], out.delta_q[0], out.delta_q[1], out.delta_q[2]);
+    for (int r = 0; r < 15; ++r)
+        for (int c = 0; c < 15; ++c) { p->jacobian(r, c) = out.jacobian[r * 15 + c]; p->covariance(r, c) = out.covariance[r * 15 + c]; }
+    return p;
+}
+}  // namespace
+
+static int replay_ba(const char* in, const char* out) {
+    Reader rd{fopen(in, "rb")};
+    if (!rd.f) { perror("sequence"); return 2; }
+    int hdr[4];
+    rd.i(hdr, 4);
+    if (hdr[0] != 0x31414256) { fprintf(stderr, "not a VBA1 sequence file\n"); return 2; }
+    const int W = hdr[1], K = hdr[2], S = hdr[3];
+    if (K != WINDOW_SIZE + 1) { fprintf(stderr, "sequence has K = %d, the Estimator is built for %d\n", K, WINDOW_SIZE + 1); return 2; }
+    double ex[7], noise[4], par[2], bias[6];
+    rd.d(ex, 7); rd.d(noise, 4); rd.d(par, 2); rd.d(bias, 6);
+    G_NORM = par[0]; FOCAL_LENGTH_D = par[1]; ESTIMATE_EXTRINSIC = 0; ESTIMATE_TD = 0; NUM_ITERATIONS = 8;
+    vg_handle* h = nullptr;
+    if (vg_create(&h) != VG_OK) { fprintf(stderr, "vg_create failed (no CPU fallback)\n"); return 3; }
+    Estimator est;
+    est.tic[0] = Vector3d(ex[0], ex[1], ex[2]);
+    est.ric[0] = Quaterniond(ex[6], ex[3], ex[4], ex[5]).toRotationMatrix();
+    std::vector<double> stamp(K);
+    for (int i = 0; i < K; ++i) {
+        FrameInit fr;
+        rd.d(&fr.t, 1); rd.d(fr.pose, 7); rd.d(fr.sb, 9);
+        set_frame(est, i, fr);
+        stamp[i] = fr.t;
+    }
+    for (int i = 0; i + 1 < K; ++i) est.pre_integrations[i + 1] = preintegrate(h, rd, S, bias, noise);
+    FILE* o = fopen(out, "w");
+    for (int w = 0; w < W; ++w) {
+        if (w > 0) {
+            est.marginalization_flag = Estimator::MARGIN_OLD;
+            IntegrationBase* dropped = est.pre_integrations[1];          // the interval that leaves the window
+            est.slideWindow();
+            delete dropped;
+            est.pre_integrations[0] = nullptr;                          // (slot 0 is never read: factor i uses pre_integrations[i + 1])
+            for (int i = 0; i + 1 < K; ++i) stamp[i] = stamp[i + 1];
+            FrameInit fr;
+            rd.d(&fr.t, 1); rd.d(fr.pose, 7); rd.d(fr.sb, 9);
+            set_frame(est, WINDOW_SIZE, fr);
+            stamp[K - 1] = fr.t;
+            est.pre_integrations[WINDOW_SIZE] = preintegrate(h, rd, S, bias, noise);
+        }
+        // features of this window: tracks from the file, depths carried over by removeBackShiftDepth where the track existed
+        std::map<int, double> carried;
+        for (auto& f : est.f_manager.feature) carried[f.feature_id] = f.estimated_depth;
+        est.f_manager.feature.clear();
+        int L;
+        rd.i(&L, 1);
+        for (int l = 0; l < L; ++l) {
+            int meta[3];
+            double init_inv_depth;
+            rd.i(meta, 3);
+            rd.d(&init_inv_depth, 1);
+            FeaturePerId f;
+            f.feature_id = meta[0]; f.start_frame = meta[1];
+            for (int k = 0; k < meta[2]; ++k) {
+                double r[7];
+                rd.d(r, 7);
+                FeaturePerFrame fr;
+                fr.point = Vector3d(r[0], r[1], 1.0); fr.uv.x() = r[2]; fr.uv.y() = r[3]; fr.velocity.x() = r[4]; fr.velocity.y() = r[5]; fr.cur_td = r[6];
+                f.feature_per_frame.push_back(fr);
+            }
+            auto it = carried.find(f.feature_id);
+            f.estimated_depth = it != carried.end() ? it->second : 1.0 / init_inv_depth;
+            est.f_manager.feature.push_back(f);
+        }
+        est.marginalization_flag = Estimator::MARGIN_OLD;
+        est.optimization();
+        const Quaterniond q(est.Rs[WINDOW_SIZE]);
+        fprintf(o, "%.0f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,\n", stamp[K - 1] * 1e9, est.Ps[WINDOW_SIZE].x(), est.Ps[WINDOW_SIZE].y(),
+                est.Ps[WINDOW_SIZE].z(), q.w(), q.x(), q.y(), q.z(), est.Vs[WINDOW_SIZE].x(), est.Vs[WINDOW_SIZE].y(), est.Vs[WINDOW_SIZE].z());
+    }
+    fclose(o);
+    fclose(rd.f);
+    vg_destroy(h);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 4 && !strcmp(argv[1], "fe")) return replay_fe(argv[2], argv[3]);
+    if (argc >= 4 && !strcmp(argv[1], "ba")) {
+        try { return replay_ba(argv[2], argv[3]); }
+        catch (const std::exception& e) { fprintf(stderr, "vins_replay ba: %s\n", e.what()); return 1; }
+    }
+    fprintf(stderr, "usage: vins_replay fe <frames.bin> <out.txt> | vins_replay ba <sequence.bin> <out.csv>\n");
+    return 2;
 }
