@@ -165,7 +165,8 @@ typedef struct {
 /* New marginalization prior (MarginalizationInfo after marginalize() + getParameterBlocks(),
  * marginalization_factor.cpp:174-319), blocks already re-labelled for the slid window
  * (addr_shift, estimator.cpp:913-930 / :969-996).  Caller allocates J0[cap*cap], r0[cap],
- * x0[7*cap_blocks], block_kind/index[cap_blocks] and sets cap / cap_blocks. */
+ * x0[9*cap_blocks] (global block sizes: 7 pose / 9 speed-bias / 7 extrinsic / 1 td), block_kind/index[cap_blocks] and sets
+ * cap / cap_blocks. */
 typedef struct {
     int cap;                     /* in: capacity (rows) of J0 / r0                                */
     int cap_blocks;              /* in: capacity of the block arrays                              */
@@ -236,8 +237,8 @@ int vg_ba_eval_factors(vg_handle* h, const vg_ba_problem* in, double* proj_r, do
  * Staged variants (*_upload / *_async / *_download) let a benchmark time the device work with inputs resident in HBM.
  * ============================================================================================= */
 int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, int max_points);
-/* imgs[cam] = top-left pixel of an 8-bit single-channel frame with row stride `stride` bytes (NULL: leave that
- * stream untouched).  equalize != 0 applies CLAHE(3.0, 8x8) first (EQUALIZE of feature_tracker/src/parameters.cpp:59). */
+/* imgs[cam] = top-left pixel of an 8-bit single-channel frame with row stride `stride` bytes; every stream needs a frame
+ * (the batched streams advance together: a NULL entry is VG_ERR_BAD_ARG and leaves the device state untouched).  equalize != 0 applies CLAHE(3.0, 8x8) first (EQUALIZE of feature_tracker/src/parameters.cpp:59). */
 int vg_fe_push_frames(vg_handle* h, const uint8_t* const* imgs, int stride, int equalize);
 int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int stride);     /* H2D only            */
 int vg_fe_build_async(vg_handle* h, int equalize);                                 /* CLAHE + pyramids    */

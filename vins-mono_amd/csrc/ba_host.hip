@@ -643,6 +643,7 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
                 if (mi[0]) {
                     const int n = mi[1], nb = mi[3];
                     if (n > q->cap || nb > q->cap_blocks) { h->err = "vg_ba_prior capacity too small"; return VG_ERR_BAD_ARG; }
+                    // (x0 is documented as 9 * cap_blocks doubles: global sizes are 7 / 9 / 7 / 1, so nb <= cap_blocks bounds it)
                     q->n = n; q->m = mi[2]; q->nblocks = nb;
                     const int mcap = L.mcap;
                     int x0n = 0;

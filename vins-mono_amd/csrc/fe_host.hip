@@ -148,10 +148,12 @@ extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int
     if (!h || !h->fe || !imgs) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
     const size_t npix = (size_t)s->W * s->H;
+    for (int c = 0; c < s->cams; ++c)                 // validate before touching any state
+        if (!imgs[c]) { h->err = "vg_fe_upload_frames: every stream needs a frame (batched streams advance together)"; return VG_ERR_BAD_ARG; }
+    if (stride < s->W) { h->err = "vg_fe_upload_frames: stride smaller than the frame width"; return VG_ERR_BAD_ARG; }
     s->raw_sel ^= 1;
     s->d.raw = s->raw2[s->raw_sel];
     for (int c = 0; c < s->cams; ++c) {
-        if (!imgs[c]) { h->err = "vg_fe_upload_frames: every stream needs a frame (batched streams advance together)"; return VG_ERR_BAD_ARG; }
         HIPCHK(h, hipMemcpy2DAsync(s->raw2[s->raw_sel] + (size_t)c * npix, s->W, imgs[c], stride, s->W, s->H, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -168,13 +170,13 @@ extern "C" int vg_fe_select_frames(vg_handle* h, int slot) {
 extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
     if (!h || !h->fe) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
+    if (equalize && (s->d.W % 8 || s->d.H % 8)) { h->err = "CLAHE needs width and height divisible by 8"; return VG_ERR_UNSUPPORTED; }
     const bool first = !s->have_prev;
-    s->flip ^= 1;                                     // previous <- current
+    s->flip ^= 1;                                     // previous <- current (only after the arguments are known to be valid)
     refresh(s);
     const FeDev& d = s->d;
     uint8_t* const* cur0 = s->d_ptrs[s->flip];
     if (equalize) {
-        if (d.W % 8 || d.H % 8) { h->err = "CLAHE needs width and height divisible by 8"; return VG_ERR_UNSUPPORTED; }
         const int area = (d.W / 8) * (d.H / 8);
         int clip = (int)(3.0 * area / 256);
         clip = clip < 1 ? 1 : clip;
@@ -258,6 +260,9 @@ extern "C" int vg_fe_track(vg_handle* h, int cam, const float* prev_xy, int n, f
     HIPCHK(h, hipMemcpyAsync(status, s->status + o, n, hipMemcpyDeviceToHost, h->stream));
     if (err) HIPCHK(h, hipMemcpyAsync(err, s->err + o, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // the single-stream call borrowed the batched point counts: put the other streams' counts back (host and device)
+    s->h_npts = saved;
+    HIPCHK(h, hipMemcpy(s->npts, s->h_npts.data(), sizeof(int) * s->cams, hipMemcpyHostToDevice));
     return VG_OK;
 }
 
