@@ -411,4 +411,135 @@ void oracle_fe_lift(const float* pts_xy, int n, const double* intr, float* out_x
         out_xy[2 * i] = (float)mx_u; out_xy[2 * i + 1] = (float)my_u;
     }
 }
+
+// ---- FeatureTracker::rejectWithF (feature_tracker.cpp:169-202): cv::findFundamentalMat(FM_RANSAC, thr, 0.99) restated as
+// a DETERMINISTIC RANSAC (ASSUMPTIONS.md F9): 256 hypotheses, each from 8 points drawn by a counter-based generator,
+// normalised 8-point algorithm (null vector by one-sided Jacobi on the 9 columns, rank-2 projection), OpenCV's error
+// (max of the two squared point-to-epipolar-line distances, cast to float) against threshold^2; the model with the most
+// inliers wins (lowest index on ties) and its inlier set is the mask.  Returns the inlier count.
+static unsigned long long fr_mix(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static float fr_error(const double* f, double x1, double y1, double x2, double y2) {
+    double a = f[0] * x1 + f[1] * y1 + f[2], b = f[3] * x1 + f[4] * y1 + f[5], c = f[6] * x1 + f[7] * y1 + f[8];
+    const double s2 = 1.0 / (a * a + b * b), d2 = x2 * a + y2 * b + c;
+    a = f[0] * x2 + f[3] * y2 + f[6]; b = f[1] * x2 + f[4] * y2 + f[7]; c = f[2] * x2 + f[5] * y2 + f[8];
+    const double s1 = 1.0 / (a * a + b * b), d1 = x1 * a + y1 * b + c;
+    const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+    return (float)(e1 > e2 ? e1 : e2);
+}
+static bool fr_hypothesis(int k, const float* p1, const float* p2, int n, double* F) {
+    int idx[8], have = 0;
+    for (unsigned d = 0; have < 8; ++d) {
+        const int c = (int)(fr_mix(((unsigned long long)(unsigned)k << 32) | d) % (unsigned long long)n);
+        bool dup = false;
+        for (int q = 0; q < have; ++q) dup = dup || idx[q] == c;
+        if (!dup) idx[have++] = c;
+    }
+    double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+    for (int i = 0; i < 8; ++i) { c1x += p1[2 * idx[i]]; c1y += p1[2 * idx[i] + 1]; c2x += p2[2 * idx[i]]; c2y += p2[2 * idx[i] + 1]; }
+    c1x /= 8; c1y /= 8; c2x /= 8; c2y /= 8;
+    double s1 = 0, s2 = 0;
+    for (int i = 0; i < 8; ++i) {
+        const double ax = p1[2 * idx[i]] - c1x, ay = p1[2 * idx[i] + 1] - c1y, bx = p2[2 * idx[i]] - c2x, by = p2[2 * idx[i] + 1] - c2y;
+        s1 += std::sqrt(ax * ax + ay * ay); s2 += std::sqrt(bx * bx + by * by);
+    }
+    const bool degenerate = !(s1 > 1e-12) || !(s2 > 1e-12);
+    s1 = degenerate ? 1.0 : 8.0 * 1.4142135623730951 / s1;
+    s2 = degenerate ? 1.0 : 8.0 * 1.4142135623730951 / s2;
+    double A[8][9], V[9][9];
+    for (int i = 0; i < 8; ++i) {
+        const double x1 = (p1[2 * idx[i]] - c1x) * s1, y1 = (p1[2 * idx[i] + 1] - c1y) * s1;
+        const double x2 = (p2[2 * idx[i]] - c2x) * s2, y2 = (p2[2 * idx[i] + 1] - c2y) * s2;
+        const double row[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+        for (int c = 0; c < 9; ++c) A[i][c] = row[c];
+    }
+    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) V[r][c] = r == c ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int r = 0; r < 8; ++r) { al += A[r][p] * A[r][p]; be += A[r][q] * A[r][q]; ga += A[r][p] * A[r][q]; }
+                if (std::fabs(ga) > 1e-15 * std::sqrt(al * be) && ga != 0.0) {
+                    rotated = true;
+                    const double zeta = (be - al) / (2.0 * ga);
+                    const double tn = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / std::sqrt(1.0 + tn * tn), sn = cs * tn;
+                    for (int r = 0; r < 8; ++r) { const double a = A[r][p], b = A[r][q]; A[r][p] = cs * a - sn * b; A[r][q] = sn * a + cs * b; }
+                    for (int r = 0; r < 9; ++r) { const double a = V[r][p], b = V[r][q]; V[r][p] = cs * a - sn * b; V[r][q] = sn * a + cs * b; }
+                }
+            }
+        if (!rotated) break;
+    }
+    int bi = 0;
+    double best = 0.0;
+    for (int c = 0; c < 9; ++c) {
+        double nn = 0.0;
+        for (int r = 0; r < 8; ++r) nn += A[r][c] * A[r][c];
+        if (c == 0 || nn < best) { best = nn; bi = c; }
+    }
+    double Fn[9];
+    for (int e = 0; e < 9; ++e) Fn[e] = V[e][bi];
+    {
+        double M[9], W[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i * 3 + j] = Fn[i] * Fn[j] + Fn[3 + i] * Fn[3 + j] + Fn[6 + i] * Fn[6 + j];
+        for (int e = 0; e < 9; ++e) W[e] = (e % 4 == 0) ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            const double off = std::fabs(M[1]) + std::fabs(M[2]) + std::fabs(M[5]);
+            if (!(off > 1e-300)) break;
+            bool rotated = false;
+            for (int pq = 0; pq < 3; ++pq) {
+                const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+                const double apq = M[p * 3 + q];
+                if (std::fabs(apq) <= 1e-17 * std::sqrt(std::fabs(M[p * 4] * M[q * 4])) || apq == 0.0) continue;
+                rotated = true;
+                const double th = (M[q * 4] - M[p * 4]) / (2.0 * apq);
+                const double tn = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(1.0 + th * th));
+                const double cs = 1.0 / std::sqrt(1.0 + tn * tn), sn = cs * tn;
+                for (int r = 0; r < 3; ++r) { const double a = M[r * 3 + p], b = M[r * 3 + q]; M[r * 3 + p] = cs * a - sn * b; M[r * 3 + q] = sn * a + cs * b; }
+                for (int r = 0; r < 3; ++r) { const double a = M[p * 3 + r], b = M[q * 3 + r]; M[p * 3 + r] = cs * a - sn * b; M[q * 3 + r] = sn * a + cs * b; }
+                for (int r = 0; r < 3; ++r) { const double a = W[r * 3 + p], b = W[r * 3 + q]; W[r * 3 + p] = cs * a - sn * b; W[r * 3 + q] = sn * a + cs * b; }
+            }
+            if (!rotated) break;
+        }
+        int mi = 0;
+        if (M[4] < M[mi * 4]) mi = 1;
+        if (M[8] < M[mi * 4]) mi = 2;
+        const double v[3] = {W[mi], W[3 + mi], W[6 + mi]};
+        for (int r = 0; r < 3; ++r) {
+            const double fv = Fn[r * 3] * v[0] + Fn[r * 3 + 1] * v[1] + Fn[r * 3 + 2] * v[2];
+            for (int c = 0; c < 3; ++c) Fn[r * 3 + c] -= fv * v[c];
+        }
+    }
+    const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
+    const double T2[9] = {s2, 0, -s2 * c2x, 0, s2, -s2 * c2y, 0, 0, 1};
+    double tmp[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) tmp[i * 3 + j] = Fn[i * 3] * T1[j] + Fn[i * 3 + 1] * T1[3 + j] + Fn[i * 3 + 2] * T1[6 + j];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F[i * 3 + j] = T2[i] * tmp[j] + T2[3 + i] * tmp[3 + j] + T2[6 + i] * tmp[6 + j];
+    bool finite = true;
+    for (int e = 0; e < 9; ++e) finite = finite && (F[e] == F[e]) && std::fabs(F[e]) < 1e300;
+    return finite && !degenerate;
+}
+
+int oracle_fe_reject_with_f(const float* p1, const float* p2, int n, double threshold, uint8_t* status, double* F_out) {
+    const float thresh2 = (float)(threshold * threshold);
+    int bestk = -1, bestc = -1;
+    double bestF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 256; ++k) {
+        double F[9];
+        if (!fr_hypothesis(k, p1, p2, n, F)) continue;
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) cnt += fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2 ? 1 : 0;
+        if (cnt > bestc) { bestc = cnt; bestk = k; memcpy(bestF, F, sizeof(F)); }
+    }
+    for (int i = 0; i < n; ++i)
+        status[i] = (bestk >= 0 && fr_error(bestF, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2) ? 1 : 0;
+    if (F_out) memcpy(F_out, bestF, sizeof(bestF));
+    return bestk >= 0 ? bestc : 0;
+}
+
 }  // extern "C"

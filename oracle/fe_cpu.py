@@ -118,3 +118,17 @@ def lift(pts, intr):
     f.restype = None
     f(pts.ctypes.data_as(_f4), len(pts), k.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(_f4))
     return out
+
+
+def reject_with_f(p1, p2, threshold=1.0):
+    """FeatureTracker::rejectWithF's findFundamentalMat(FM_RANSAC, threshold, 0.99), deterministic restatement
+    (ASSUMPTIONS.md F9).  p1, p2: [n, 2] float32 pixel coordinates of the virtual pinhole.  Returns (status u8, F 3x3)."""
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    n = p1.shape[0]
+    st = np.zeros(n, np.uint8)
+    Fm = np.zeros(9)
+    f = lib().oracle_fe_reject_with_f
+    f.restype = C.c_int
+    f(p1.ctypes.data_as(_f4), p2.ctypes.data_as(_f4), n, C.c_double(threshold), _p8(st), Fm.ctypes.data_as(C.c_void_p))
+    return st, Fm.reshape(3, 3)

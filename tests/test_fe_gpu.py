@@ -266,3 +266,17 @@ def test_tiny_levels(handle):
     _check_lk(tr, 0, a, b, pts)
     edge = np.array([[0.5, 0.5], [w - 1.2, h - 1.4], [2.0, h - 2.0], [w - 3.0, 1.0]], np.float32)
     _check_lk(tr, 0, a, b, edge)
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_reject_with_f_matches_restatement(handle, seed):
+    """SURVEY 8(f) row 3: FeatureTracker::rejectWithF's findFundamentalMat(FM_RANSAC) as a deterministic device RANSAC;
+    inlier mask identical to the CPU restatement, model equal to rounding, gross outliers rejected."""
+    from test_fe_oracle import _two_view
+    p1, p2, out = _two_view(seed)
+    tr = fe.FrontEnd(handle, 752, 480, 1, 150)
+    st_g, F_g = tr.reject_with_f(p1, p2, 1.0)
+    st_o, F_o = F.reject_with_f(p1, p2, 1.0)
+    assert np.array_equal(st_g, st_o)
+    assert np.abs(F_g - F_o).max() < 1e-9 * np.abs(F_o).max()
+    assert st_g[out].sum() <= 1 and st_g[~out].mean() > 0.9

@@ -72,3 +72,38 @@ def test_lk_pyramid_depth_rule():
     # 44 x 44: the next level (22 x 22) is still larger than the window, the one after (11 x 11) is not
     assert [l.shape for l in N.pyramid(np.zeros((44, 44), np.uint8))] == [(44, 44), (22, 22)]
     assert len(N.pyramid(np.zeros((480, 752), np.uint8))) == 4
+
+
+def _two_view(seed, n=120, n_out=25):
+    """Correspondences of a general 3-D scene under a small camera motion in the virtual pinhole (focal 460, 752x480),
+    with n_out gross outliers; returns (p1, p2, is_outlier)."""
+    rng = np.random.default_rng(seed)
+    X = np.c_[rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(4, 14, n)]
+    a = np.deg2rad(rng.uniform(-3, 3, 3))
+    Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
+    Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+    Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
+    Rm, t = Rz @ Ry @ Rx, rng.uniform(-0.4, 0.4, 3)
+    X2 = X @ Rm.T + t
+    p1 = 460.0 * X[:, :2] / X[:, 2:3] + np.array([376.0, 240.0]) + rng.normal(0, 0.2, (n, 2))
+    p2 = 460.0 * X2[:, :2] / X2[:, 2:3] + np.array([376.0, 240.0]) + rng.normal(0, 0.2, (n, 2))
+    out = np.zeros(n, bool)
+    out[rng.choice(n, n_out, replace=False)] = True
+    p2[out] += rng.uniform(8, 40, (n_out, 2)) * rng.choice([-1, 1], (n_out, 2))
+    return p1.astype(np.float32), p2.astype(np.float32), out
+
+
+def test_reject_with_f_restatement_rejects_outliers_and_is_deterministic():
+    p1, p2, out = _two_view(3)
+    st, Fm = C.reject_with_f(p1, p2, 1.0)
+    st2, _ = C.reject_with_f(p1, p2, 1.0)
+    assert np.array_equal(st, st2)
+    assert st[out].sum() <= 1                         # gross outliers are rejected (one may land near its epipolar line)
+    assert st[~out].mean() > 0.9                      # inliers survive
+    # the model is a rank-2 fundamental matrix of the inlier set
+    assert abs(np.linalg.det(Fm)) < 1e-9 * np.abs(Fm).max() ** 3
+    h1 = np.c_[p1[~out].astype(float), np.ones((~out).sum())]
+    h2 = np.c_[p2[~out].astype(float), np.ones((~out).sum())]
+    l = h1 @ Fm.T
+    d = np.abs((h2 * l).sum(1)) / np.hypot(l[:, 0], l[:, 1])
+    assert np.median(d) < 0.5

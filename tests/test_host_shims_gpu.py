@@ -30,8 +30,30 @@ def _in_border(p):
     return 1 <= x < W - 1 and 1 <= y < H - 1
 
 
+def _virtual_pinhole(pts):
+    """liftProjective (PinholeCamera.cc:450-510, EuRoC intrinsics, 8 fixed-point steps, double) then FOCAL_LENGTH * x + COL / 2."""
+    fx, fy, cx, cy, k1, k2, p1, p2 = 461.6, 460.3, 363.0, 248.1, -2.917e-01, 8.228e-02, 5.333e-05, -1.578e-04
+    out = np.zeros((len(pts), 2), np.float32)
+    for i, (u, v) in enumerate(np.asarray(pts, np.float64)):
+        mxd, myd = (1.0 / fx) * u + (-cx / fx), (1.0 / fy) * v + (-cy / fy)
+
+        def dist(px, py):
+            mx2, my2, mxy = px * px, py * py, px * py
+            rho2 = mx2 + my2
+            rad = k1 * rho2 + k2 * rho2 * rho2
+            return px * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2), py * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2)
+        dx, dy = dist(mxd, myd)
+        mxu, myu = mxd - dx, myd - dy
+        for _ in range(7):
+            dx, dy = dist(mxu, myu)
+            mxu, myu = mxd - dx, myd - dy
+        out[i] = (np.float32(460 * mxu + W / 2.0), np.float32(460 * myu + H / 2.0))
+    return out
+
+
 def _mirror(frames, pub_every):
-    """feature_tracker.cpp:81-167 + feature_tracker_node.cpp:103-111 on top of the ORACLE (CLAHE on, no RANSAC)."""
+    """feature_tracker.cpp:81-167 + feature_tracker_node.cpp:103-111 on top of the ORACLE (CLAHE on, rejectWithF through the
+    restated deterministic RANSAC)."""
     out = []
     prev = None
     cur_pts, ids, cnt = np.zeros((0, 2), np.float32), [], []
@@ -47,6 +69,13 @@ def _mirror(frames, pub_every):
             cnt = [cnt[i] for i in keep]
         cnt = [c + 1 for c in cnt]
         if k % pub_every == 0:
+            if len(forw) >= 8:                                                   # rejectWithF (:169-202)
+                cur_kept = cur_pts[keep]
+                st_f, _ = F.reject_with_f(_virtual_pinhole(cur_kept), _virtual_pinhole(forw), 1.0)
+                sel = [i for i in range(len(forw)) if st_f[i]]
+                forw = forw[sel]
+                ids = [ids[i] for i in sel]
+                cnt = [cnt[i] for i in sel]
             mask = np.full((H, W), 255, np.uint8)
             order = sorted(range(len(forw)), key=lambda i: -cnt[i])          # stable, like the shim
             kp, ki, kc = [], [], []

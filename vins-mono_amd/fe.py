@@ -34,6 +34,7 @@ class FrontEnd:
         L.vg_fe_detect_masked.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, _f4, _i4]
         L.vg_fe_get_mask.argtypes = [C.c_void_p, C.c_int, _u8]
         L.vg_fe_undistort.argtypes = [C.c_void_p, _f4, C.c_int, C.POINTER(C.c_double), _f4]
+        L.vg_fe_reject_with_f.argtypes = [C.c_void_p, _f4, _f4, C.c_int, C.c_double, _u8, _i4, C.POINTER(C.c_double)]
         self.hd._chk(L.vg_fe_configure(self.h, width, height, n_cams, max_points), "vg_fe_configure")
 
     def _imgs(self, frames):
@@ -129,6 +130,20 @@ class FrontEnd:
         self.hd._chk(self.lib.vg_fe_undistort(self.h, p.ctypes.data_as(_f4), len(p), k.ctypes.data_as(C.POINTER(C.c_double)),
                                               out.ctypes.data_as(_f4)), "vg_fe_undistort")
         return out
+
+    def reject_with_f(self, p1, p2, threshold=1.0):
+        """FeatureTracker::rejectWithF's findFundamentalMat(FM_RANSAC, threshold, 0.99) on the device (deterministic RANSAC).
+        p1, p2: [n, 2] float32 virtual-pinhole pixel coordinates.  Returns (status u8 [n], F 3x3)."""
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        n = p1.shape[0]
+        st = np.zeros(n, np.uint8)
+        Fm = np.zeros(9)
+        ni = C.c_int()
+        self.hd._chk(self.lib.vg_fe_reject_with_f(self.h, p1.ctypes.data_as(_f4), p2.ctypes.data_as(_f4), n, float(threshold),
+                                                  st.ctypes.data_as(_u8), C.byref(ni), Fm.ctypes.data_as(C.POINTER(C.c_double))),
+                     "vg_fe_reject_with_f")
+        return st, Fm.reshape(3, 3)
 
     def detect_upload(self, max_corners, masks=None):
         mc = np.ascontiguousarray(max_corners, np.int32)

@@ -8,6 +8,7 @@
 
 int ROW = 480, COL = 752, MAX_CNT = 150, MIN_DIST = 30, EQUALIZE = 1, FISHEYE = 0, FOCAL_LENGTH = 460;
 bool PUB_THIS_FRAME = false;
+double F_THRESHOLD = 1.0;
 int FeatureTracker::n_id = 0;
 
 static int cvRoundf(float v) { return (int)std::lrintf(v); }
@@ -135,10 +136,31 @@ void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {    // :8
     prev_time = cur_time;
 }
 
-void FeatureTracker::rejectWithF() {
-    // feature_tracker.cpp:169-202 calls cv::findFundamentalMat(FM_RANSAC, F_THRESHOLD, 0.99): third-party RANSAC with
-    // OpenCV's RNG — SURVEY.md 8(f) row 3, not part of the accelerated path.  With real OpenCV the original body
-    // compiles unchanged against this class; in the compat build outlier rejection is skipped.
+void FeatureTracker::rejectWithF() {                                       // feature_tracker.cpp:169-202
+    if (forw_pts.size() >= 8) {
+        const int n = (int)forw_pts.size();
+        vector<cv::Point2f> un_cur_pts(cur_pts.size()), un_forw_pts(forw_pts.size());
+        for (unsigned int i = 0; i < cur_pts.size(); i++) {
+            double x, y;
+            m_camera.liftProjective(cur_pts[i].x, cur_pts[i].y, x, y);
+            x = FOCAL_LENGTH * x + COL / 2.0;
+            y = FOCAL_LENGTH * y + ROW / 2.0;
+            un_cur_pts[i] = cv::Point2f((float)x, (float)y);
+            m_camera.liftProjective(forw_pts[i].x, forw_pts[i].y, x, y);
+            x = FOCAL_LENGTH * x + COL / 2.0;
+            y = FOCAL_LENGTH * y + ROW / 2.0;
+            un_forw_pts[i] = cv::Point2f((float)x, (float)y);
+        }
+        vector<uchar> status(n);
+        // cv::findFundamentalMat(un_cur_pts, un_forw_pts, cv::FM_RANSAC, F_THRESHOLD, 0.99, status) on the device
+        chk(vg_fe_reject_with_f(vg_, &un_cur_pts[0].x, &un_forw_pts[0].x, n, F_THRESHOLD, status.data(), nullptr, nullptr), vg_, "vg_fe_reject_with_f");
+        reduceVector(prev_pts, status);
+        reduceVector(cur_pts, status);
+        reduceVector(forw_pts, status);
+        reduceVector(cur_un_pts, status);
+        reduceVector(ids, status);
+        reduceVector(track_cnt, status);
+    }
 }
 
 bool FeatureTracker::updateID(unsigned int i) {                              // :204-214

@@ -4,8 +4,8 @@
 //   cv::createCLAHE(...)->apply      -> vg_fe_push_frames(.., equalize)     (:87-93)
 //   cv::calcOpticalFlowPyrLK         -> vg_fe_track                          (:113)
 //   cv::goodFeaturesToTrack          -> vg_fe_detect                         (:149)
-// Differences (documented in INTEGRATION.md): rejectWithF() needs cv::findFundamentalMat (RANSAC)
-// and is a no-op unless built against real OpenCV; the camera model is the EuRoC pinhole restated from
+//   cv::findFundamentalMat(RANSAC)   -> vg_fe_reject_with_f                  (:191; deterministic RANSAC, ASSUMPTIONS F9)
+// Differences (documented in INTEGRATION.md): the camera model is the EuRoC pinhole restated from
 // camera_model/src/camera_models/PinholeCamera.cc:450-510,646-661 instead of camodocal::CameraPtr.
 #pragma once
 #include <map>
@@ -19,6 +19,7 @@ using namespace std;
 // globals of feature_tracker/src/parameters.h (same names)
 extern int ROW, COL, MAX_CNT, MIN_DIST, EQUALIZE, FISHEYE, FOCAL_LENGTH;
 extern bool PUB_THIS_FRAME;
+extern double F_THRESHOLD;
 
 bool inBorder(const cv::Point2f& pt);
 void reduceVector(vector<cv::Point2f>& v, vector<uchar> status);
