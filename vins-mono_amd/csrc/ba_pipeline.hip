@@ -1721,29 +1721,46 @@ extern "C" const char* ba_failed_launch() { return g_failed_launch; }
         if (ev) { const hipError_t _ee = hipEventRecord(ev[nev++], stream); if (_ee != hipSuccess) return _ee; } \
     } while (0)
 
-// Launch sequence of one batch solve.  ev != nullptr: an event is recorded after every launch (ev[0] before the first),
-// kinds[i] = kernel class of the launch that ends at ev[i + 1] (0 prologue, 1 linearize, 2 accumulate, 3 solve, 4 final);
-// the caller provides 4 * rounds + 5 events.
+// Launch sequence of one batch solve.  The IMU / prior linearisation of a round does not depend on the projection factors:
+// with `aux` != nullptr it is forked onto that second stream (event fork -> aux; join before the solve kernel), so the two
+// linearisation kernels run side by side.  ev != nullptr (profiling): everything stays on `stream`, an event is recorded
+// after every launch (ev[0] before the first), kinds[i] = kernel class of the launch that ends at ev[i + 1] (0 prologue,
+// 1 linearize, 2 accumulate, 3 solve, 4 final); the caller provides 4 * rounds + 5 events.
+struct BaFork { hipStream_t aux; hipEvent_t fork, join; };
 extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
-                                      hipEvent_t* ev, int* kinds, int* n_launches) {
+                                      hipEvent_t* ev, int* kinds, int* n_launches, const BaFork* fk) {
     hipError_t e = set_lds_attrs();
     if (e != hipSuccess) { g_failed_launch = "hipFuncSetAttribute"; return e; }
     int nev = 0;
     if (ev) { e = hipEventRecord(ev[nev++], stream); if (e != hipSuccess) return e; }
+    const bool forked = fk && fk->aux && !ev;
     int nk = 0;
     LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P);
     if (kinds) kinds[nk++] = 0;
-    for (int r = 0; r < rounds; ++r) {
-        LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, 0);
-        LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, 0);
+    for (int r = 0; r <= rounds; ++r) {
+        const int cost_only = r == rounds ? 1 : 0;
+        if (forked) {
+            if ((e = hipEventRecord(fk->fork, stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(fk->aux, fk->fork, 0)) != hipSuccess) return e;
+            hipLaunchKernelGGL(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, fk->aux, dL, P, cost_only);
+            if ((e = hipGetLastError()) != hipSuccess) { g_failed_launch = "ba_linearize_imu_kernel"; return e; }
+            if ((e = hipEventRecord(fk->join, fk->aux)) != hipSuccess) return e;
+        } else {
+            LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only);
+        }
+        LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only);
+        if (kinds) { if (!forked) kinds[nk++] = 1; kinds[nk++] = 1; }
+        if (r == rounds) {
+            if (forked && (e = hipStreamWaitEvent(stream, fk->join, 0)) != hipSuccess) return e;
+            break;
+        }
         LAUNCH(ba_accumulate_kernel, dim3(L.nba, L.nwin), dim3(BA_ACC_NT), 0, dL, P);
+        if (forked && (e = hipStreamWaitEvent(stream, fk->join, 0)) != hipSuccess) return e;
         LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P);
-        if (kinds) { kinds[nk++] = 1; kinds[nk++] = 1; kinds[nk++] = 2; kinds[nk++] = 3; }
+        if (kinds) { kinds[nk++] = 2; kinds[nk++] = 3; }
     }
-    LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, 1);
-    LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, 1);
     LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P);
-    if (kinds) { kinds[nk++] = 1; kinds[nk++] = 1; kinds[nk++] = 4; }
+    if (kinds) kinds[nk++] = 4;
     if (n_launches) *n_launches = nk;
     return hipSuccess;
 }

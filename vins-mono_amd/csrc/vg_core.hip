@@ -15,7 +15,9 @@ extern "C" int vg_create(vg_handle** out) {
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return VG_ERR_HIP; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
-        hipEventCreate(&h->ev2) != hipSuccess) {
+        hipEventCreate(&h->ev2) != hipSuccess || hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete h;
         return VG_ERR_HIP;
     }
@@ -35,6 +37,8 @@ extern "C" int vg_destroy(vg_handle* h) {
     (void)hipFree(P.mout); (void)hipFree(P.miout); (void)hipFree(P.mscr);
     if (h->fe) fe_state_destroy(h->fe);
     (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev2);
+    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join);
+    (void)hipStreamDestroy(h->aux);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return VG_OK;

@@ -28,6 +28,8 @@ struct vg_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    hipStream_t aux = nullptr;                    // second stream: the IMU / prior linearisation runs beside the projection factors
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     BaBatch ba;
     FeState* fe = nullptr;
