@@ -254,7 +254,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         const int nstm = up(16 * L.K + 8 + 1, 2);
         L.mg_cs = up(std::max(std::max(2 * mcap, 3 * (L.mg_posmax / 2 + 2)), 2 * (3 * ((mcap + 2) / 2) + 2) + 2), 2);   // generic: one table
                                                      // of 3*half doubles; fast path: two (double-buffered)
-        L.mg_cs = std::max(L.mg_cs, up(5 * mcap + 8, 2));       // vh_eig: running diagonal, norms, eigenvalues, pivot order, flags
+        L.mg_cs = std::max(L.mg_cs, std::max(up(5 * mcap + 8, 2), 640));   // vh_eig: running diagonal, norms, eigenvalues, flags; Amm^-1 shortcut: 96 + 2 x 256
         const int fixed = 32 + nstm + 128 + L.mg_cs;
         int ld = mcap + 1;                           // big enough for the kept part; also used for Amm when m <= ld.  ODD:
                                                      // the symmetric-storage Jacobi walks columns (stride ld doubles) and

@@ -1023,20 +1023,133 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             Mm[i * ldm + j] = 0.5 * (A[i * posmax + j] + A[j * posmax + i]);
         }
         __syncthreads();
+        const int offcs = (int)(cs - MG_LDS), offred = (int)(red - MG_LDS);
+        // ---- certified shortcut.  The dropped block is [pose 0 | speed-bias 0 | frame-0 landmarks] and the landmark part of
+        // Amm is DIAGONAL (a projection factor touches one landmark), so Amm^-1 follows from the md x md Schur complement
+        // P' = P - W D^-1 W^T (md <= 15) by block elimination.  marginalization_factor.cpp:272-283 takes the eigen
+        // pseudo-inverse with the lambda > 1e-8 cut, which IS the inverse when every eigenvalue exceeds 1e-8; that is
+        // certified here by  lambda_min(Amm) >= 1 / ||Amm^-1||_F > 1e-7.  Otherwise (or if P' is not positive
+        // definite) the eigen-decomposition below runs.
+        const int md = m - n0, ml = n0;
+        bool inverse_ok = false;
+        if (in_lds && md >= 1 && md <= 16 && ml <= 16 * MG_HROWS) {
+            double* dl = cs;                 // [ml] landmark diagonal
+            double* Ls = cs + 96;            // [md][md] Cholesky factor of P', then its inverse
+            double* Pi = Ls + 256;           // [md][md] P'^-1            (mg_cs >= 5 * mcap + 8 >= 96 + 512)
+            int* okf = (int*)(red + 18);
+            if (c.tid == 0) *okf = 1;
+            for (int l = c.tid; l < ml; l += MG_NT) dl[l] = Mm[(md + l) * ldm + md + l];
+            __syncthreads();
+            for (int k = c.tid; k < md * md; k += MG_NT) {
+                const int i = k / md, j = k - i * md;
+                double sacc = Mm[i * ldm + j];
+                for (int l = 0; l < ml; ++l) sacc -= Mm[i * ldm + md + l] * Mm[j * ldm + md + l] / dl[l];
+                Ls[i * md + j] = sacc;
+            }
+            __syncthreads();
+            if (c.wave == 0) {               // Cholesky of P' in registers (lane = row), then L^-1 by lane = column
+                double a[16];
+                const int i = c.lane & 15;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = (c.lane < md && q <= i && q < md) ? Ls[i * md + q] : 0.0;
+                bool good = true;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    if (jj < md) {
+                        const double piv = readlane_f64(a[jj], jj);
+                        if (!(piv > 0.0) || !(piv < 1e300)) good = false;
+                        const double dinv = mg_rsqrt(piv);
+                        const double l = a[jj] * dinv;
+                        a[jj] = l;
+#pragma unroll
+                        for (int q = jj + 1; q < 16; ++q) { const double lq = readlane_f64(l, q); a[q] -= l * lq; }
+                    }
+                }
+                if (c.lane < md) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) if (q <= i && q < md) Ls[i * md + q] = a[q];
+                }
+                __builtin_amdgcn_wave_barrier();
+                // column j of L^-1 (lower): forward substitution on e_j
+                double x[16];
+                const int j = c.lane & 15;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    double sacc = (r == j) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int q = 0; q < r; ++q) sacc -= (r < md && q >= j) ? Ls[r * md + q] * x[q] : 0.0;
+                    x[r] = (r < md && r >= j) ? sacc / Ls[r * md + r] : 0.0;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (c.lane < md) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (r < md) Ls[r * md + j] = x[r];      // Ls <- L^-1 (lower, zeros above)
+                }
+                for (int l = c.lane; l < ml; l += 64) if (!(dl[l] > 0.0)) good = false;
+                if (!good) *okf = 0;
+            }
+            __syncthreads();
+            for (int k = c.tid; k < md * md; k += MG_NT) {          // P'^-1 = L^-T L^-1
+                const int i = k / md, j = k - i * md;
+                double sacc = 0.0;
+                for (int r = (i > j ? i : j); r < md; ++r) sacc += Ls[r * md + i] * Ls[r * md + j];
+                Pi[k] = sacc;
+                Vm[i * ldm + j] = sacc;                               // B11
+            }
+            __syncthreads();
+            for (int k = c.tid; k < md * ml; k += MG_NT) {          // B12 = -P'^-1 W D^-1 (and its transpose)
+                const int p = k / ml, l = k - p * ml;
+                double sacc = 0.0;
+                for (int q = 0; q < md; ++q) sacc += Pi[p * md + q] * Mm[q * ldm + md + l];
+                const double v = -sacc / dl[l];
+                Vm[p * ldm + md + l] = v;
+                Vm[(md + l) * ldm + p] = v;
+            }
+            __syncthreads();
+            for (int k = c.tid; k < ml * ml; k += MG_NT) {          // B22 = D^-1 - D^-1 W^T B12
+                const int a_ = k / ml, b_ = k - a_ * ml;
+                double sacc = 0.0;
+                for (int p = 0; p < md; ++p) sacc += Mm[p * ldm + md + a_] * Vm[p * ldm + md + b_];
+                Vm[(md + a_) * ldm + md + b_] = (a_ == b_ ? 1.0 / dl[a_] : 0.0) - sacc / dl[a_];
+            }
+            __syncthreads();
+            double fro = 0.0, bad = 0.0;
+            for (int k = c.tid; k < m * m; k += MG_NT) {
+                const double v = Vm[(k / m) * ldm + k % m];
+                fro += v * v;
+                bad += (v == v && fabs(v) < 1e300) ? 0.0 : 1.0;
+            }
+            fro = mg_block_sum(c, red, fro);
+            bad = mg_block_sum(c, red, bad);
+            inverse_ok = *okf != 0 && bad == 0.0 && fro > 0.0 && fro < 1e14;      // 1 / sqrt(fro) > 1e-7
+            __syncthreads();
+        }
+        if (inverse_ok) {
+            if (c.tid == 0) mi[4] = 0;       // no sweeps: Amm^-1 by certified block elimination
+            MPROF(4);
+            // T2 = Amm^-1 [Amr | bmm]
+            for (int k = c.tid; k < m * (n + 1); k += MG_NT) {
+                const int i = k / (n + 1), j = k % (n + 1);
+                const double* src = j < n ? A + m + j : bv;          // column j of [Amr | bmm]
+                const int sst = j < n ? posmax : 1;
+                double sacc = 0.0;
+#pragma unroll 8
+                for (int r = 0; r < m; ++r) sacc += Vm[i * ldm + r] * src[(size_t)r * sst];
+                T2[i * (mcap + 1) + j] = sacc;
+            }
+            __syncthreads();
+        } else {
 #ifdef BA_PROFILE
         const long long _t1 = clock64();
 #endif
-        const int offcs = (int)(cs - MG_LDS), offred = (int)(red - MG_LDS);
         const bool fast1 = in_lds && m >= 1 && m <= 16 * MG_HROWS;
         const int sw1 = fast1 ? vh_eig(c, 0, ld * ld, m, ldm, offcs, offred, 0.0, 2e-16, 10)
                       : in_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, m, ldm, offcs, offred, true)
                                : jacobi_eig<false>(c, Mm, Vm, 0, 0, m, ldm, offcs, offred, true);
 #ifdef BA_PROFILE
         if (c.tid == 0) { mi[6] = (int)((clock64() - _t1) >> 10); mi[7] = (int)((_t1 - _tstart) >> 10); }
-#else
-        (void)sw1;
 #endif
-        if (c.tid == 0) mi[4] = sw1;        // the same for Amm
+        if (c.tid == 0) mi[4] = sw1;        // sweeps | Cholesky attempts << 8 of the Amm eigen-decomposition
         MPROF(4);
         // T1 = Lambda^+ V^T [Amr | bmm]   (m x (n+1))
         for (int k = c.tid; k < m * (n + 1); k += MG_NT) {
@@ -1062,6 +1175,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             T2[i * (mcap + 1) + j] = s;
         }
         __syncthreads();
+        }   // eigen path
         // A' = Arr - Arm T2[:, :n] ; b' = brr - Arm T2[:, n]   -> eM (n x n, ld), b' -> T1 row 0 (reuse)
         for (int k = c.tid; k < n * (n + 1); k += MG_NT) {
             const int i = k / (n + 1), j = k % (n + 1);
