@@ -35,3 +35,10 @@ def test_emulated_marginalization_matches_oracle(simt_handle):
     st_g, sm_g, pr_g = simt_handle.ba_optimize(at, ba.VG_MARGIN_OLD)
     assert sm_g['status'] == 0
     _check_prior(pr_g, pr_o)
+
+
+@pytest.mark.parametrize("K", [4, 7, 12])
+def test_emulated_solve_other_window_sizes(simt_handle, K):
+    """The speed-bias chain is eliminated from both ends towards block K / 2: even, odd and maximal K."""
+    seq = synth.SyntheticSequence(11 + K, n_frames=K + 1, K=K, L=24)
+    _check_solve(simt_handle, seq.window(0))

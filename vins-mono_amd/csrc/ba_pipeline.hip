@@ -469,7 +469,10 @@ NOINL double proj_cost(const Ctx& c, int f, const double* x, const double* lam) 
 
 // Projection factors: grid (nbf, nwin), tiles of BA_LIN_NT factors, thread per factor, no LDS beyond the reduction.
 // cost_only != 0: residuals only (the last candidate of a solve).
-extern "C" __global__ __launch_bounds__(BA_LIN_NT) void ba_linearize_proj_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
+#ifndef BA_PROJ_WAVES
+#define BA_PROJ_WAVES 1
+#endif
+extern "C" __global__ __launch_bounds__(BA_LIN_NT, BA_PROJ_WAVES) void ba_linearize_proj_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
     const BaLayout& L = *Lp;
     Ctx c;
     ctx_init(c, Lp, P, blockIdx.y);
@@ -842,92 +845,160 @@ DEV double rsqrt_nr(double x) {
     return y;
 }
 
-// Block-Thomas elimination of the speed-bias chain, last block first.  Step k:
-//   (A) wavefront 0: D_k -= Xe_{k+1}^T Xe_{k+1}, then the 9x9 Cholesky D_k = L L^T in registers (lane = row, v_readlane
-//       pivots), L (lower) and 1/L_rr back to LDS;  other wavefronts: [C_k | g_k] -= Xe_{k+1}^T [Xc_{k+1} | xg_{k+1}]
-//   (B) thread per column of [C_k | g_k | E_k]:  X = L^-1 column   (forward substitution, L broadcast from LDS)
-// Afterwards XC holds X = L^-1 [C | g] for every block (rows 9k..9k+8), E holds Xe_k = L_k^-1 E_k, D holds L_k.
-// The camera system gets its  S -= Xc^T Xc  together with the landmark Schur complement in schur_mfma().
+// Block elimination of the speed-bias chain from BOTH ends towards the middle block mid = K / 2 ("burn at both ends":
+// the two sweeps are independent until they meet, which halves the serial depth of the block-Thomas recursion).
+//   top sweep    k = K-1 .. mid+1 : block k is coupled to k-1 through E_k (rows sb_k, columns sb_k-1)
+//   bottom sweep k = 0 .. mid-1   : block k is coupled to k+1 through E_k+1^T
+//   last         k = mid          : receives the updates of both neighbours
+// One step (both sweeps at once):
+//   (A) wavefront 0 / 1: D_k -= (update of the neighbour eliminated one step earlier), then the 9x9 Cholesky D_k = L L^T in
+//       registers (lane = row, v_readlane pivots), L (lower) and 1/L_rr back to LDS;
+//       other wavefronts: [C_k | g_k] -= (same update) for both blocks
+//   (B) thread per column of [C_k | g_k | coupling block]:  X = L^-1 column  (forward substitution, L broadcast from LDS)
+// Storage after the elimination: XC rows 9k..9k+8 = X_k = L_k^-1 [C_k | g_k];  D_k = L_k;  the coupling block of a pair
+// (k, k-1) lives in the slot E_k: for a TOP block k it holds Xe_k = L_k^-1 E_k as [p][c] (p = row of X_k, c = column sb_k-1),
+// for a BOTTOM block k-1 it holds (L_k-1^-1 E_k^T)^T as [c][p] (c = column sb_k, p = row of X_k-1) — each pair is consumed
+// by exactly one of its two blocks.  The camera system gets  S -= X^T X  in schur_mfma().
 // Returns false (uniform) on a non-positive pivot.
+DEV bool chain_factor(int lane, double* Dk, double* dinvk, int kind, const double* Xc) {
+    // kind 1: Xc = Xe of the upper neighbour as [p][r]  ->  D[r][c] -= sum_p Xc[9p + r] Xc[9p + c]
+    // kind 2: Xc = XuT of the lower neighbour as [r][p]  ->  D[r][c] -= sum_p Xc[9r + p] Xc[9c + p];  kind 3: both (Xc, Xc + 81)
+    if (kind) {
+        for (int e = lane; e < 81; e += 64) {
+            const int r = e / 9, cc = e - 9 * r;
+            double s = 0.0;
+            if (kind & 1) {
+#pragma unroll
+                for (int p = 0; p < 9; ++p) s += Xc[9 * p + r] * Xc[9 * p + cc];
+            }
+            if (kind & 2) {
+                const double* Xu = kind == 3 ? Xc + 81 : Xc;
+#pragma unroll
+                for (int p = 0; p < 9; ++p) s += Xu[9 * r + p] * Xu[9 * cc + p];
+            }
+            Dk[e] -= s;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    double a[9];
+    const int i = lane < 9 ? lane : 8;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) a[q] = (lane < 9 && q <= i) ? Dk[9 * i + q] : 0.0;
+    bool good = true;
+#pragma unroll
+    for (int jj = 0; jj < 9; ++jj) {
+        const double piv = readlane_d(a[jj], jj);
+        if (!(piv > 0.0) || !(piv < 1e300)) good = false;
+        const double dinv = rsqrt_nr(piv);
+        const double l = a[jj] * dinv;
+        a[jj] = l;
+        if (lane == 0) dinvk[jj] = dinv;
+#pragma unroll
+        for (int q = jj + 1; q < 9; ++q) {
+            const double lq = readlane_d(l, q);
+            a[q] -= l * lq;
+        }
+    }
+    if (lane < 9) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) if (q <= i) Dk[9 * i + q] = a[q];
+    }
+    return good;
+}
+// x <- L^-1 x for the 9 values at col[0], col[stride], ...
+DEV void chain_col_solve(const double* Lk, const double* dinvk, double* col, int stride) {
+    double x[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) x[r] = col[r * stride];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        double s = x[r];
+#pragma unroll
+        for (int q = 0; q < r; ++q) s -= Lk[9 * r + q] * x[q];
+        x[r] = s * dinvk[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) col[r * stride] = x[r];
+}
 NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
     const BaLayout& L = *c.Lp;
     const int K = L.K, Rc = L.Rc, ldc = m.ldc;
+    const int mid = K / 2;
+    const int nstep = (K - 1 - mid) > mid ? (K - 1 - mid) : mid;
     int* flag = (int*)(m.red + 24);
     if (c.tid == 0) *flag = 1;
     __syncthreads();
-    for (int k = K - 1; k >= 0; --k) {
-        double* Dk = m.D + 81 * k;
-        const bool upd = k + 1 < K;
-        const double* Xe = m.E + 81 * (k + 1);             // rows p (sb_{k+1}), cols r (sb_k)
+    for (int t = 0; t <= nstep; ++t) {
+        const bool last = t == nstep;
+        // blocks of this step: top kt (coupled downwards), bottom kb (coupled upwards); in the last step only `mid`
+        const int kt = last ? mid : K - 1 - t, kb = last ? -1 : t;
+        const bool has_t = last || kt > mid, has_b = !last && kb < mid;
+        // updates a block receives: from its already eliminated neighbour(s)
+        const bool upd_t_from_above = has_t && kt + 1 <= K - 1 && (last ? (K - 1 > mid) : t > 0);
+        const bool upd_mid_from_below = last && mid > 0;
+        const bool upd_b = has_b && t > 0;
+        // ---- (A)
         if (c.wave == 0) {
-            if (upd) {
-                for (int e = c.lane; e < 81; e += 64) {
-                    const int r = e / 9, cc = e - 9 * r;
+            if (has_t) {
+                int kind = 0;
+                const double* X = nullptr;
+                if (upd_t_from_above && upd_mid_from_below) {
+                    // the middle block takes both: copy the two coupling blocks next to each other (scratch in wd)
+                    for (int e = c.lane; e < 81; e += 64) { m.wd[e] = m.E[81 * (kt + 1) + e]; m.wd[81 + e] = m.E[81 * kt + e]; }
+                    __builtin_amdgcn_wave_barrier();
+                    kind = 3; X = m.wd;
+                } else if (upd_t_from_above) { kind = 1; X = m.E + 81 * (kt + 1); }
+                else if (upd_mid_from_below) { kind = 2; X = m.E + 81 * kt; }
+                if (!chain_factor(c.lane, m.D + 81 * kt, m.dinv + 9 * kt, kind, X) && c.lane == 0) *flag = 0;
+            }
+        } else if (c.wave == 1) {
+            if (has_b && !chain_factor(c.lane, m.D + 81 * kb, m.dinv + 9 * kb, upd_b ? 2 : 0, m.E + 81 * kb) && c.lane == 0) *flag = 0;
+        } else {
+            const int nt = BA_NT - 128, id = c.tid - 128;
+            const int per = 9 * (Rc + 1);
+            for (int w = id; w < 2 * per; w += nt) {
+                const int which = w >= per ? 1 : 0, e = w - which * per;
+                const int r = e / (Rc + 1), j = e - r * (Rc + 1);
+                if (which == 0) {
+                    if (!has_t) continue;
+                    double s = 0.0;
+                    if (upd_t_from_above) {
+                        const double* Xe = m.E + 81 * (kt + 1);
+                        const double* Xn = m.XC + 9 * (kt + 1) * ldc;
+#pragma unroll
+                        for (int p = 0; p < 9; ++p) s += Xe[9 * p + r] * Xn[p * ldc + j];
+                    }
+                    if (upd_mid_from_below) {
+                        const double* Xu = m.E + 81 * kt;
+                        const double* Xn = m.XC + 9 * (kt - 1) * ldc;
+#pragma unroll
+                        for (int p = 0; p < 9; ++p) s += Xu[9 * r + p] * Xn[p * ldc + j];
+                    }
+                    if (upd_t_from_above || upd_mid_from_below) m.XC[(9 * kt + r) * ldc + j] -= s;
+                } else {
+                    if (!upd_b) continue;
+                    const double* Xu = m.E + 81 * kb;
+                    const double* Xn = m.XC + 9 * (kb - 1) * ldc;
                     double s = 0.0;
 #pragma unroll
-                    for (int p = 0; p < 9; ++p) s += Xe[9 * p + r] * Xe[9 * p + cc];
-                    Dk[e] -= s;
+                    for (int p = 0; p < 9; ++p) s += Xu[9 * r + p] * Xn[p * ldc + j];
+                    m.XC[(9 * kb + r) * ldc + j] -= s;
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // Cholesky: lane i < 9 holds row i
-            double a[9];
-            const int i = c.lane < 9 ? c.lane : 8;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) a[q] = (c.lane < 9 && q <= i) ? Dk[9 * i + q] : 0.0;
-            bool good = true;
-#pragma unroll
-            for (int jj = 0; jj < 9; ++jj) {
-                const double piv = readlane_d(a[jj], jj);
-                if (!(piv > 0.0) || !(piv < 1e300)) good = false;
-                const double dinv = rsqrt_nr(piv);
-                const double l = a[jj] * dinv;
-                a[jj] = l;
-                if (c.lane == 0) m.dinv[9 * k + jj] = dinv;
-#pragma unroll
-                for (int q = jj + 1; q < 9; ++q) {
-                    const double lq = readlane_d(l, q);
-                    a[q] -= l * lq;
-                }
-            }
-            if (c.lane < 9) {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) if (q <= i) Dk[9 * i + q] = a[q];
-            }
-            if (!good && c.lane == 0) *flag = 0;
-        } else if (upd) {
-            const double* Xn = m.XC + 9 * (k + 1) * ldc;
-            double* Ck = m.XC + 9 * k * ldc;
-            for (int w = c.tid - 64; w < 9 * (Rc + 1); w += BA_NT - 64) {
-                const int r = w / (Rc + 1), j = w - r * (Rc + 1);
-                double s = 0.0;
-#pragma unroll
-                for (int p = 0; p < 9; ++p) s += Xe[9 * p + r] * Xn[p * ldc + j];
-                Ck[r * ldc + j] -= s;
             }
         }
         __syncthreads();
         if (*flag == 0) break;
-        // ---- (B) columns: Rc + 1 of XC_k, 9 of E_k (k > 0)
+        // ---- (B) columns: threads 0 .. Rc + 9 serve the top block, 128 .. 128 + Rc + 9 the bottom block
         {
-            const int ncol = Rc + 1 + (k > 0 ? 9 : 0);
-            if (c.tid < ncol) {
-                double* col;
-                int stride;
-                if (c.tid <= Rc) { col = m.XC + 9 * k * ldc + c.tid; stride = ldc; }
-                else { col = m.E + 81 * k + (c.tid - Rc - 1); stride = 9; }
-                double x[9];
-#pragma unroll
-                for (int r = 0; r < 9; ++r) x[r] = col[r * stride];
-#pragma unroll
-                for (int r = 0; r < 9; ++r) {
-                    double s = x[r];
-#pragma unroll
-                    for (int q = 0; q < r; ++q) s -= Dk[9 * r + q] * x[q];
-                    x[r] = s * m.dinv[9 * k + r];
-                }
-#pragma unroll
-                for (int r = 0; r < 9; ++r) col[r * stride] = x[r];
+            const int half = c.tid >> 7, id = c.tid & 127;
+            if (half == 0 && has_t) {
+                const double* Lk = m.D + 81 * kt;
+                if (id <= Rc) chain_col_solve(Lk, m.dinv + 9 * kt, m.XC + 9 * kt * ldc + id, ldc);
+                else if (!last && id < Rc + 10) chain_col_solve(Lk, m.dinv + 9 * kt, m.E + 81 * kt + (id - Rc - 1), 9);        // column of E_kt -> Xe
+            } else if (half == 1 && has_b) {
+                const double* Lk = m.D + 81 * kb;
+                if (id <= Rc) chain_col_solve(Lk, m.dinv + 9 * kb, m.XC + 9 * kb * ldc + id, ldc);
+                else if (id < Rc + 10) chain_col_solve(Lk, m.dinv + 9 * kb, m.E + 81 * (kb + 1) + 9 * (id - Rc - 1), 1);        // row of E_kb+1 -> XuT
             }
         }
         __syncthreads();
@@ -1226,12 +1297,24 @@ NOINL void back_substitute(const Ctx& c, const SolveLds& m, int R) {
     __syncthreads();
 }
 
-// speed-bias blocks, first to last:  y_k = L_k^-T ( xg_k - Xc_k y_cam - Xe_k y_{k-1} )
+// speed-bias blocks, from the middle block outwards (two wavefronts, one per direction):
+//   y_mid = L^-T z_mid;   top side  y_k = L_k^-T (z_k - Xe_k y_{k-1});   bottom side  y_k = L_k^-T (z_k - Xu_k y_{k+1})
+// with z = xg - Xc y_cam for all 9K rows first.
+DEV double chain_backsolve9(const double* Lk, const double* dinvk, double v, int r) {
+    // L^T y = v: backward over rows j = 8 .. 0; lane r accumulates its rhs entry and ends up holding y[r]
+#pragma unroll
+    for (int j = 8; j >= 0; --j) {
+        const double yj = readlane_d(v, j) * dinvk[j];
+        const double lrj = (r < j) ? Lk[9 * j + r] : 0.0;      // L[j][r], r < j
+        v = (r == j) ? yj : v - lrj * yj;
+    }
+    return v;
+}
 NOINL void chain_back_substitute(const Ctx& c, const SolveLds& m) {
     const BaLayout& L = *c.Lp;
     const int K = L.K, Rc = L.Rc, ldc = m.ldc;
+    const int mid = K / 2;
     double* y = m.vec + V_Y * L.Rpad;
-    // z = xg - Xc y_cam for all 9K rows at once, the Rc-term dot product of every row split over 4 threads
     {
         const int nrow = 9 * K;
         for (int w = c.tid; w < 4 * nrow; w += BA_NT) {
@@ -1246,26 +1329,29 @@ NOINL void chain_back_substitute(const Ctx& c, const SolveLds& m) {
             m.wd[row] = m.XC[row * ldc + Rc] - ((m.z[4 * row] + m.z[4 * row + 1]) + (m.z[4 * row + 2] + m.z[4 * row + 3]));
         __syncthreads();
     }
-    if (c.wave == 0) {
+    if (c.wave < 2) {
         const int r = c.lane < 9 ? c.lane : 8;
-        double yprev = 0.0;                       // lane r holds y_{k-1}[r]
-        for (int k = 0; k < K; ++k) {
-            const double* Lk = m.D + 81 * k;
-            double v = m.wd[9 * k + r];
-            if (k > 0) {
-                const double* Xe = m.E + 81 * k;
+        // both wavefronts solve the middle block (cheaper than a hand-over through LDS)
+        double yprev = chain_backsolve9(m.D + 81 * mid, m.dinv + 9 * mid, m.wd[9 * mid + r], r);
+        if (c.wave == 0 && c.lane < 9) y[Rc + 9 * mid + c.lane] = yprev;
+        if (c.wave == 0) {
+            for (int k = mid + 1; k < K; ++k) {
+                const double* Xe = m.E + 81 * k;                  // [p][c]
+                double v = m.wd[9 * k + r];
 #pragma unroll
                 for (int cc = 0; cc < 9; ++cc) v -= Xe[9 * r + cc] * readlane_d(yprev, cc);
+                yprev = chain_backsolve9(m.D + 81 * k, m.dinv + 9 * k, v, r);
+                if (c.lane < 9) y[Rc + 9 * k + c.lane] = yprev;
             }
-            // L^T y = v: backward over rows j = 8 .. 0; lane r accumulates its rhs entry
+        } else {
+            for (int k = mid - 1; k >= 0; --k) {
+                const double* Xu = m.E + 81 * (k + 1);            // [c][p]
+                double v = m.wd[9 * k + r];
 #pragma unroll
-            for (int j = 8; j >= 0; --j) {
-                const double yj = readlane_d(v, j) * m.dinv[9 * k + j];
-                const double lrj = (r < j) ? Lk[9 * j + r] : 0.0;      // L[j][r], r < j
-                v = (r == j) ? yj : v - lrj * yj;
+                for (int cc = 0; cc < 9; ++cc) v -= Xu[9 * cc + r] * readlane_d(yprev, cc);
+                yprev = chain_backsolve9(m.D + 81 * k, m.dinv + 9 * k, v, r);
+                if (c.lane < 9) y[Rc + 9 * k + c.lane] = yprev;
             }
-            yprev = v;
-            if (c.lane < 9) y[Rc + 9 * k + c.lane] = v;
         }
     }
     __syncthreads();
