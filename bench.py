@@ -149,14 +149,39 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
     return out
 
 
+def csrc_tag():
+    """Identity of the kernel sources the library was built from: sha1 over vins-mono_amd/csrc/*.{hip,h} (first 12 hex)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vins-mono_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+_PMC = None
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/pmc_latest.json, written by
-    profiles/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
+    """HBM bytes per launch of `kernel` ('a+b' = sum over the kernels of a class) from the committed PMC summary
+    (profiles/pmc_latest.json, written by profiles/run_pmc.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this same command).  None when the summary was recorded for OTHER kernel sources than the ones in the tree (its `build`
+    tag is the sha1 of vins-mono_amd/csrc at recording time) or has no entry for the kernel."""
+    global _PMC
+    if _PMC is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
+        try:
+            with open(path) as f:
+                _PMC = json.load(f)
+        except (OSError, ValueError):
+            _PMC = {}
+        if _PMC.get("build") != csrc_tag():
+            _PMC = {"kernels": {}, "stale": True}
     try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+        return sum(_PMC["kernels"][k]["hbm_bytes_per_launch"] for k in kernel.split("+"))
+    except KeyError:
         return None
 
 
