@@ -42,3 +42,10 @@ def test_emulated_solve_other_window_sizes(simt_handle, K):
     """The speed-bias chain is eliminated from both ends towards block K / 2: even, odd and maximal K."""
     seq = synth.SyntheticSequence(11 + K, n_frames=K + 1, K=K, L=24)
     _check_solve(simt_handle, seq.window(0))
+
+
+@pytest.mark.parametrize("ex,td", [(1, 1), (0, 1), (1, 0)])
+def test_emulated_solve_with_extrinsic_and_td(simt_handle, ex, td):
+    """The blocks among the extrinsic pose and td have a workgroup of their own in the accumulation kernel."""
+    seq = synth.SyntheticSequence(70 + 2 * ex + td, n_frames=6, K=5, L=20, estimate_extrinsic=ex, estimate_td=td)
+    _check_solve(simt_handle, seq.window(0))

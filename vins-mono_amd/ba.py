@@ -255,18 +255,31 @@ class Handle:
         return dict(flops=fl.value, flops_solve=fs.value, flops_marg=fm.value, bytes_in=bi.value, bytes_out=bo.value,
                     lds_bytes=lds.value, flops_by_kernel={k: float(fk[i]) for i, k in enumerate(self.KERNEL_CLASSES)})
 
-    def ba_download(self, allow_numeric_failure=False):
+    def ba_prepare_download(self):
+        """Allocate the host output buffers of the uploaded batch once (reused by every ba_download_raw())."""
         n = len(self._packed)
         outs = [_Out(p.K, p.L, p.has_relo, self._margin[i] != VG_MARGIN_NONE) for i, p in enumerate(self._packed)]
         st = (C.POINTER(State) * n)(*[C.pointer(o.state) for o in outs])
         pri = (C.POINTER(Prior) * n)(*[C.pointer(o.prior) if o.prior is not None else None for o in outs])
         sm = (Summary * n)()
+        self._dl = (outs, st, pri, sm, list(self._packed))
+        return self._dl
+
+    def ba_download_raw(self):
+        """vg_ba_batch_download into the buffers of ba_prepare_download(); returns the C-ABI status."""
+        outs, st, pri, sm, _ = self._dl
         t0 = time.perf_counter()
-        rc = self.lib.vg_ba_batch_download(self.h, n, st, sm, pri)
+        rc = self.lib.vg_ba_batch_download(self.h, len(outs), st, sm, pri)
         self.last_download_call_ms = (time.perf_counter() - t0) * 1e3      # the C-ABI call alone (sync + D2H + unpack)
+        return rc
+
+    def ba_download(self, allow_numeric_failure=False):
+        outs, st, pri, sm, packed = self.ba_prepare_download()
+        n = len(outs)
+        rc = self.ba_download_raw()
         if rc != VG_OK and not (allow_numeric_failure and rc == -4):
             self._chk(rc, "vg_ba_batch_download")
-        return ([o.state_dict(p.has_relo) for o, p in zip(outs, self._packed)],
+        return ([o.state_dict(p.has_relo) for o, p in zip(outs, packed)],
                 [summary_dict(sm[i]) for i in range(n)],
                 [o.prior_dict() for o in outs])
 

@@ -139,7 +139,9 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         const int nb = L.Kp + L.e + L.t;
         L.ntask = nb * (nb + 1) / 2;
         const int per = BA_ACC_NT / 64;
-        L.nba = L.Kp + (L.ntask - L.Kp + (L.Lcap + 63) / 64 + per - 1) / per;   // diagonal pose blocks get a workgroup each
+        const int ng = L.e + L.t, nglob = ng * (ng + 1) / 2;      // blocks among ex / td: they visit EVERY factor
+        // diagonal pose blocks get a workgroup each, the ex / td blocks share one (if present), wavefront tasks after them
+        L.nba = L.Kp + (ng ? 1 : 0) + (L.ntask - L.Kp - nglob + (L.Lcap + 63) / 64 + per - 1) / per;
     }
     // ---- LDS carve of the solve kernel
     {
@@ -318,12 +320,13 @@ static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, 
     }
     const int nchunk = 1;
     {
-        // owner tasks other than the diagonal pose blocks (packed-triangle index of the block)
+        // wavefront owner tasks: every block except the diagonal pose blocks and the blocks among ex / td, which have
+        // workgroups of their own (packed-triangle index of the block)
         const int nb = Kp + L.e + L.t;
         int n = 0;
         for (int br = 0; br < nb; ++br)
             for (int bc = 0; bc <= br; ++bc)
-                if (!(br == bc && br < Kp)) ia[L.io_task_list + n++] = br * (br + 1) / 2 + bc;
+                if (!(br == bc && br < Kp) && !(bc >= Kp)) ia[L.io_task_list + n++] = br * (br + 1) / 2 + bc;
     }
     hdr[H_L] = p->L; hdr[H_F] = F; hdr[H_NPRIOR] = p->prior_n; hdr[H_NBLK] = p->prior_n ? p->prior_nblocks : 0;
     hdr[H_MAXIT] = p->max_iters; hdr[H_NCHUNK] = nchunk; hdr[H_MARGIN] = margin; hdr[H_STATUS] = 0;
@@ -592,13 +595,13 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
     if (!h || !h->ba.uploaded || nwin != h->ba.nwin) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
     const BaLayout& L = B.L;
-    B.h_out.resize((size_t)nwin * L.ostride);
-    B.h_iout.resize((size_t)nwin * L.oi_stride);
+    HIPCHK(h, B.h_out.resize((size_t)nwin * L.ostride));
+    HIPCHK(h, B.h_iout.resize((size_t)nwin * L.oi_stride));
     HIPCHK(h, hipMemcpyAsync(B.h_out.data(), B.P.out, B.h_out.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(B.h_iout.data(), B.P.iout, B.h_iout.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (B.any_margin && pri) {
-        B.h_mout.resize((size_t)nwin * L.mo_stride);
-        B.h_miout.resize((size_t)nwin * L.mi_stride);
+        HIPCHK(h, B.h_mout.resize((size_t)nwin * L.mo_stride));
+        HIPCHK(h, B.h_miout.resize((size_t)nwin * L.mi_stride));
         HIPCHK(h, hipMemcpyAsync(B.h_mout.data(), B.P.mout, B.h_mout.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemcpyAsync(B.h_miout.data(), B.P.miout, B.h_miout.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }

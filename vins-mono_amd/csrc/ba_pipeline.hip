@@ -512,25 +512,35 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_imu_kernel(cons
 // ================================================================================================
 // Accumulation kernel: J^T J / J^T r of the projection factors from their records.
 // ================================================================================================
-// sum over slots [b,e) of  rec[offA..+1] . rec[offB..+1]   (two independent accumulation chains: the loads of
-// consecutive records are in flight together; fixed order -> deterministic)
+// sum over slots [b,e) of  rec[offA..+1] . rec[offB..+1]   (four independent accumulation chains: the eight 16-byte loads
+// of four consecutive records are in flight together -- a task is a chain of L2 round trips, not of flops; fixed order
+// -> deterministic)
 DEV double seg_dot(const double* recs, int REC, int b, int e, int offA, int offB) {
-    double acc0 = 0.0, acc1 = 0.0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    const double* pa = recs + (size_t)b * REC + offA;
+    const double* pb = recs + (size_t)b * REC + offB;
     int s = b;
-    for (; s + 1 < e; s += 2) {
-        const double2 a2 = *(const double2*)(recs + (size_t)s * REC + offA);
-        const double2 b2 = *(const double2*)(recs + (size_t)s * REC + offB);
-        const double2 a3 = *(const double2*)(recs + (size_t)(s + 1) * REC + offA);
-        const double2 b3 = *(const double2*)(recs + (size_t)(s + 1) * REC + offB);
-        acc0 += a2.x * b2.x + a2.y * b2.y;
-        acc1 += a3.x * b3.x + a3.y * b3.y;
+    for (; s + 3 < e; s += 4, pa += 4 * REC, pb += 4 * REC) {
+        const double2 a0 = *(const double2*)(pa), b0 = *(const double2*)(pb);
+        const double2 a1 = *(const double2*)(pa + REC), b1 = *(const double2*)(pb + REC);
+        const double2 a2 = *(const double2*)(pa + 2 * REC), b2 = *(const double2*)(pb + 2 * REC);
+        const double2 a3 = *(const double2*)(pa + 3 * REC), b3 = *(const double2*)(pb + 3 * REC);
+        acc0 += a0.x * b0.x + a0.y * b0.y;
+        acc1 += a1.x * b1.x + a1.y * b1.y;
+        acc2 += a2.x * b2.x + a2.y * b2.y;
+        acc3 += a3.x * b3.x + a3.y * b3.y;
     }
-    if (s < e) {
-        const double2 a2 = *(const double2*)(recs + (size_t)s * REC + offA);
-        const double2 b2 = *(const double2*)(recs + (size_t)s * REC + offB);
-        acc0 += a2.x * b2.x + a2.y * b2.y;
+    const int rem = e - s;                        // 0..3 records left: their loads are issued together too
+    if (rem > 0) {
+        const double2 z = {0.0, 0.0};
+        const double2 a0 = *(const double2*)(pa), b0 = *(const double2*)(pb);
+        const double2 a1 = rem > 1 ? *(const double2*)(pa + REC) : z, b1 = rem > 1 ? *(const double2*)(pb + REC) : z;
+        const double2 a2 = rem > 2 ? *(const double2*)(pa + 2 * REC) : z, b2 = rem > 2 ? *(const double2*)(pb + 2 * REC) : z;
+        acc0 += a0.x * b0.x + a0.y * b0.y;
+        acc1 += a1.x * b1.x + a1.y * b1.y;
+        acc2 += a2.x * b2.x + a2.y * b2.y;
     }
-    return acc0 + acc1;
+    return (acc0 + acc1) + (acc2 + acc3);
 }
 
 // Diagonal pose block a of the camera system: it visits every factor anchored at or targeting frame a (~10x the visits
@@ -570,15 +580,14 @@ DEV void diag_pose_task(const Ctx& c, int a, const double* recs, double* Sp, dou
     }
 }
 
-// Owner task = one (<=6)x(<=6) block of the camera part of S: lane = entry (p,q); lanes 36..41 of diagonal tasks own the
-// gradient.  The slot table is sorted by (anchor, target) pair, so an entry that involves pose j only visits the factors
-// with that pair: fixed summation order, no atomics.
+// Owner task = one off-diagonal (<=6)x(<=6) block of the camera part of S: lane = entry (p,q).  The slot table is sorted
+// by (anchor, target) pair, so an entry that involves pose j only visits the factors with that pair: fixed summation
+// order, no atomics.
 DEV void owner_task(const Ctx& c, int task, int lane, const double* recs, double* Sp, double* gp) {
     const BaLayout& L = *c.Lp;
     const int Kp = L.Kp, REC = L.REC;
     const int* ptr = c.ia + L.io_pair_ptr;
     const int offEx = 28, offTd = 28 + 12 * L.e;
-    const int nslots = ptr[Kp * Kp];
     int br, bc;
     tri_decode(task, br, bc);
     const int kr = br < Kp ? 0 : (br == Kp && L.e ? 1 : 2);     // 0 pose, 1 ex, 2 td
@@ -586,38 +595,66 @@ DEV void owner_task(const Ctx& c, int task, int lane, const double* recs, double
     const int dr = kr == 2 ? 1 : 6, dc = kc == 2 ? 1 : 6;
     const int rowbase = kr == 0 ? 6 * br : (kr == 1 ? col_ex(L) : col_td(L));
     const int colbase = kc == 0 ? 6 * bc : (kc == 1 ? col_ex(L) : col_td(L));
-    const bool diag = br == bc;
-    const bool isg = diag && lane >= 36 && lane < 36 + dr;
-    const int p = isg ? lane - 36 : lane / 6, q = isg ? 0 : lane % 6;
-    const bool act = isg || (lane < 36 && p < dr && q < dc && (!diag || q <= p));
-    if (!act) return;
+    // (neither diagonal blocks nor gradient entries reach this function: diag_pose_task / global_task own them)
+    const int p = lane / 6, q = lane % 6;
+    if (!(lane < 36 && p < dr && q < dc)) return;
     double acc = 0.0;
     if (kr == 0 && kc == 0) {
         // row block br = target j, column block bc = anchor i
         acc += seg_dot(recs, REC, ptr[bc * Kp + br], ptr[bc * Kp + br + 1], 12 + 2 * p, 2 * q);
     } else {
         const int oA = (kr == 1 ? offEx : offTd) + 2 * p;
-        if (kc == 0) {
-            const int a = bc;
-            acc += seg_dot(recs, REC, ptr[a * Kp], ptr[(a + 1) * Kp], oA, 2 * q);
-            for (int a2 = 0; a2 < a; ++a2)
-                acc += seg_dot(recs, REC, ptr[a2 * Kp + a], ptr[a2 * Kp + a + 1], oA, 12 + 2 * q);
-        } else {
-            const int oB = isg ? 26 : (kc == 1 ? offEx : offTd) + 2 * q;
-            acc += seg_dot(recs, REC, 0, nslots, oA, oB);
-        }
+        // kc == 0: the blocks among ex / td are global_task()'s
+        const int a = bc;
+        acc += seg_dot(recs, REC, ptr[a * Kp], ptr[(a + 1) * Kp], oA, 2 * q);
+        for (int a2 = 0; a2 < a; ++a2)
+            acc += seg_dot(recs, REC, ptr[a2 * Kp + a], ptr[a2 * Kp + a + 1], oA, 12 + 2 * q);
     }
-    if (isg) gp[rowbase + p] = acc;
-    else Sp[tri(rowbase + p, colbase + q)] = acc;
+    Sp[tri(rowbase + p, colbase + q)] = acc;
 }
 
-// per-landmark sums: h = sum Jl.Jl, b = sum Jl.r, W column -> Wt[col][l] (landmark index fastest: coalesced stores)
+// The blocks among the extrinsic pose and td (<= 7 columns: <= 28 lower entries + <= 7 gradient entries) visit EVERY factor:
+// one workgroup, entry e on thread e of each of 7 thread segments, every segment takes a seventh of the slot range, the
+// partial sums are combined through LDS in a fixed order (same scheme as diag_pose_task).
+DEV void global_task(const Ctx& c, const double* recs, double* Sp, double* gp, double* part) {
+    const BaLayout& L = *c.Lp;
+    const int REC = L.REC;
+    const int ng = 6 * L.e + L.t, ntri = ng * (ng + 1) / 2, ne = ntri + ng;
+    const int nslots = (c.ia + L.io_pair_ptr)[L.Kp * L.Kp];
+    const int seg = c.tid / 36, e = c.tid - 36 * seg;
+    const bool isg = e >= ntri;
+    int p = 0, q = 0;
+    if (!isg) tri_decode(e, p, q); else p = e - ntri;
+    // global column k -> record offset of its 2-vector: ex columns 28 + 2k, td 28 + 12 e
+    if (seg < 7 && e < ne) {
+        const int oA = 28 + 2 * p, oB = isg ? 26 : 28 + 2 * q;
+        part[seg * 36 + e] = seg_dot(recs, REC, nslots * seg / 7, nslots * (seg + 1) / 7, oA, oB);
+    }
+    __syncthreads();
+    if (c.tid < ne) {
+        double tot = 0.0;
+#pragma unroll
+        for (int s7 = 0; s7 < 7; ++s7) tot += part[s7 * 36 + c.tid];
+        const int base = col_ex(L);               // ex columns first, td last: contiguous from 6 Kp
+        if (isg) gp[base + p] = tot;
+        else Sp[tri(base + p, base + q)] = tot;
+    }
+}
+
+// per-landmark sums: h = sum Jl.Jl, b = sum Jl.r, W column -> Wt[col][l] (landmark index fastest: coalesced stores).
+// Two passes over the landmark's records (the second one hits L1 / L2): the first forms the sums that involve every
+// factor (h, b and the anchor / ex / td entries of W), the second walks the camera columns in order and stores every
+// Wt row exactly once -- a zero fill followed by scattered 8-byte stores costs ~2.5x the write traffic once the
+// zero-filled lines have left L2.
 DEV void landmark_task(const Ctx& c, int l, const double* recs, double* buf) {
     const BaLayout& L = *c.Lp;
     const int REC = L.REC;
-    double* Wt = buf + L.bo_Wt;
-    for (int row = 0; row < L.RcPad; ++row) Wt[(size_t)row * L.Lcap + l] = 0.0;
-    if (l >= c.nL) return;
+    double* Wt = buf + L.bo_Wt + l;
+    const size_t ldw = L.Lcap;
+    if (l >= c.nL) {
+        for (int row = 0; row < L.RcPad; ++row) Wt[row * ldw] = 0.0;
+        return;
+    }
     const int fb = c.ia[L.io_lm_fbeg + l], fe = c.ia[L.io_lm_fbeg + l + 1];
     double h = 0.0, b = 0.0, wi[6] = {0, 0, 0, 0, 0, 0}, wex[6] = {0, 0, 0, 0, 0, 0}, wtd = 0.0;
     int anchor = -1;
@@ -627,46 +664,70 @@ DEV void landmark_task(const Ctx& c, int l, const double* recs, double* buf) {
         h += l0 * l0 + l1 * l1;
         b += l0 * rec[26] + l1 * rec[27];
         anchor = c.ia[L.io_fac_i + f];
-        const int j = c.ia[L.io_fac_j + f];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            wi[k] += rec[2 * k] * l0 + rec[2 * k + 1] * l1;
-            Wt[(size_t)(col_pose(L, j) + k) * L.Lcap + l] = rec[12 + 2 * k] * l0 + rec[12 + 2 * k + 1] * l1;
-        }
+        for (int k = 0; k < 6; ++k) wi[k] += rec[2 * k] * l0 + rec[2 * k + 1] * l1;
         if (L.e) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) wex[k] += rec[28 + 2 * k] * l0 + rec[28 + 2 * k + 1] * l1;
         }
         if (L.t) wtd += rec[28 + 12 * L.e] * l0 + rec[29 + 12 * L.e] * l1;
     }
-    if (anchor >= 0) {
+    // pose columns in order; pack_window stores the factors of a landmark by strictly increasing target frame
+    // (start + 1, start + 2, ..., then the relocalisation pose K)
+    int f = fb;
+    for (int j = 0; j < L.Kp; ++j) {
+        double v[6] = {0, 0, 0, 0, 0, 0};
+        if (j == anchor) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Wt[(size_t)(col_pose(L, anchor) + k) * L.Lcap + l] = wi[k];
-        if (L.e) {
+            for (int k = 0; k < 6; ++k) v[k] = wi[k];
+        } else {
+            if (f < fe && c.ia[L.io_fac_j + f] == j) {
+                const double* rec = recs + (size_t)c.ia[L.io_fac_slot + f++] * REC;
+                const double l0 = rec[24], l1 = rec[25];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) Wt[(size_t)(col_ex(L) + k) * L.Lcap + l] = wex[k];
+                for (int k = 0; k < 6; ++k) v[k] = rec[12 + 2 * k] * l0 + rec[12 + 2 * k + 1] * l1;
+            }
         }
-        if (L.t) Wt[(size_t)col_td(L) * L.Lcap + l] = wtd;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Wt[(size_t)(col_pose(L, j) + k) * ldw] = v[k];
     }
+    int row = 6 * L.Kp;
+    if (L.e) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Wt[(size_t)(col_ex(L) + k) * ldw] = anchor >= 0 ? wex[k] : 0.0;
+        row += 6;
+    }
+    if (L.t) { Wt[(size_t)col_td(L) * ldw] = anchor >= 0 ? wtd : 0.0; row += 1; }
+    for (; row < L.RcPad; ++row) Wt[row * ldw] = 0.0;
     buf[L.bo_h + l] = h;
     buf[L.bo_b + l] = b;
 }
 
-// grid (nba, nwin), BA_ACC_NT threads: workgroups 0 .. Kp-1 = the diagonal pose blocks; afterwards wavefront tasks: the other
-// owner blocks (host table io_task_list of packed-triangle block indices), then 64 landmarks per wavefront
+// grid nba * up(nwin, 8) workgroups of BA_ACC_NT threads.  Workgroups are dealt to the 8 XCDs round-robin by their
+// linear id and every XCD has its own L2: id % 8 selects the window inside a group of 8 windows, so that ALL workgroups
+// of a window run on one XCD and its projection records (read ~2.5 times by the tasks below) are fetched into one L2
+// only.  Inside a window: workgroups 0 .. Kp-1 = the diagonal pose blocks; workgroup Kp = the blocks among ex / td (if
+// estimated); afterwards wavefront tasks: the other owner blocks (host table io_task_list of packed-triangle block
+// indices), then 64 landmarks per wavefront.
 extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
     const BaLayout& L = *Lp;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, rest = bid >> 3;
+    const int bx = rest % L.nba, w = (rest / L.nba) * 8 + xcd;
+    if (w >= L.nwin) return;
     Ctx c;
-    ctx_init(c, Lp, P, blockIdx.y);
+    ctx_init(c, Lp, P, w);
     const double* ctl = c.sc + L.so_ctl;
     if (ctl[C_DONE] != 0.0) return;
     const int which = ((int)ctl[C_CUR]) ^ (ctl[C_PENDING] != 0.0 ? 1 : 0);
     double* buf = lin_buf(c, which);
     const double* recs = c.sc + L.so_rec;
-    __shared__ double part[8 * 27];
-    if ((int)blockIdx.x < L.Kp) { diag_pose_task(c, blockIdx.x, recs, buf + L.bo_Sp, buf + L.bo_gp, part); return; }
-    const int g = (blockIdx.x - L.Kp) * (BA_ACC_NT / 64) + c.wave;
-    const int nother = L.ntask - L.Kp;
+    __shared__ double part[7 * 36 + 4];
+    if (bx < L.Kp) { diag_pose_task(c, bx, recs, buf + L.bo_Sp, buf + L.bo_gp, part); return; }
+    const int ng = L.e + L.t;
+    if (ng && bx == L.Kp) { global_task(c, recs, buf + L.bo_Sp, buf + L.bo_gp, part); return; }
+    const int g = (bx - L.Kp - (ng ? 1 : 0)) * (BA_ACC_NT / 64) + c.wave;
+    const int nother = L.ntask - L.Kp - ng * (ng + 1) / 2;
     if (g < nother) owner_task(c, c.ia[L.io_task_list + g], c.lane, recs, buf + L.bo_Sp, buf + L.bo_gp);
     else {
         const int l = (g - nother) * 64 + c.lane;
@@ -1840,7 +1901,7 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
             if (forked && (e = hipStreamWaitEvent(stream, fk->join, 0)) != hipSuccess) return e;
             break;
         }
-        LAUNCH(ba_accumulate_kernel, dim3(L.nba, L.nwin), dim3(BA_ACC_NT), 0, dL, P);
+        LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P);
         if (forked && (e = hipStreamWaitEvent(stream, fk->join, 0)) != hipSuccess) return e;
         LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P);
         if (kinds) { kinds[nk++] = 2; kinds[nk++] = 3; }

@@ -5,13 +5,33 @@
 #include <vector>
 #include "ba_layout.h"
 
+// pinned host staging that grows on demand (hipHostMalloc: the D2H / H2D copies run as DMA at the PCIe rate)
+template <typename T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t cap = 0, n = 0;
+    hipError_t resize(size_t need) {
+        n = need;
+        if (need <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipHostMalloc((void**)&p, need * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = need;
+        return e;
+    }
+    T* data() { return p; }
+    size_t size() const { return n; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; }
+};
+
 struct BaBatch {
     BaLayout L;
     BaLayout* dL = nullptr;          // device copy of L (kernels read it through scalar loads)
     BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_ia = 0, cap_di = 0, cap_sc = 0, cap_out = 0, cap_iout = 0, cap_mout = 0, cap_miout = 0, cap_mscr = 0;
-    std::vector<int> h_iout, h_miout, margin, nL;
-    std::vector<double> h_out, h_mout;
+    std::vector<int> margin, nL;
+    PinnedBuf<int> h_iout, h_miout;  // download staging
+    PinnedBuf<double> h_out, h_mout;
     int* h_ia = nullptr;             // pinned host staging of the packed batch (hipHostMalloc: DMA at full PCIe rate)
     double* h_di = nullptr;
     size_t hcap_ia = 0, hcap_di = 0;
