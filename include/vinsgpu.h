@@ -17,6 +17,7 @@
  */
 #ifndef VINSGPU_H
 #define VINSGPU_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -210,6 +211,26 @@ int vg_ba_batch_flops_by_kernel(vg_handle* h, double* flops);
 int vg_ba_batch_info(vg_handle* h, double* flops_per_run, double* bytes_in, double* bytes_out, int* lds_bytes);
 /* the same flop model split per launch: ba_solve_kernel (solve + prior J^T J) and ba_marg_kernel (the marginalization term) */
 int vg_ba_batch_flops(vg_handle* h, double* solve_flops, double* marg_flops);
+
+/* ---- Large windows and landmark shards (BASELINE.json configs[4]) --------------------------------
+ * The reference fixes WINDOW_SIZE = 10 and NUM_OF_F = 1000 at compile time (vins_estimator/src/parameters.h:12,14) and
+ * walks every factor in one thread (estimator.cpp:719-764); here both are runtime sizes.  A window whose camera part is
+ * wider than the single-workgroup pipeline's tiling (more than ~13 frames) automatically takes the LARGE-WINDOW PATH: the
+ * landmark Schur complement is formed by a multi-workgroup kernel into a reduce buffer, the reduced system is factorised
+ * out of HBM / LDS by one workgroup.  The same path shards a window over ranks: every rank uploads the SAME frames, IMU
+ * factors and prior but only ITS contiguous share of the landmarks (with their observations), installs an all-reduce
+ * hook, and calls vg_ba_batch_run_async as usual; after the run every rank holds the identical frame states and the
+ * inverse depths of its own landmarks.  Marginalization is not offered on this path (margin_flags must be NONE).
+ *
+ * The hook is called on the host, twice per trust-region round, between two kernel launches: it must enqueue on `stream`
+ * (a hipStream_t) an in-place SUM over all ranks of `count` doubles at `device_buf` -- with RCCL:
+ *     ncclAllReduce(device_buf, device_buf, count, ncclDouble, ncclSum, comm, (hipStream_t)stream)
+ * -- and return 0.  No host synchronisation is needed or wanted.  count is the same on every rank (it depends only on the
+ * window's frame count and flags): vg_ba_reduce_layout reports both counts (reduced system; step norms). */
+typedef int (*vg_allreduce_fn)(void* user, double* device_buf, size_t count, void* stream);
+int vg_ba_set_allreduce(vg_handle* h, vg_allreduce_fn fn, void* user);       /* fn == NULL: single rank */
+int vg_ba_set_large_window(vg_handle* h, int force);     /* force != 0: take the large-window path whatever the size */
+int vg_ba_reduce_layout(vg_handle* h, size_t* count_system, size_t* count_norms);
 
 /* Batched factor evaluation for parity tests (rows B2-B5 of SURVEY.md 8(a)): evaluates every
  * projection / IMU / prior factor of the problem at its input state WITHOUT the robust-loss

@@ -158,6 +158,10 @@ def summary_dict(s):
                 it_step_norm=np.array(s.it_step_norm[:n]), it_flags=np.array(s.it_flags[:n]), prof=np.array(s.prof[:]))
 
 
+# vg_allreduce_fn(user, device_buf, count, stream) -> 0 on success
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
 class Handle:
     """vg_create / vg_destroy wrapper; raises RuntimeError with vg_last_error on failures."""
 
@@ -181,6 +185,9 @@ class Handle:
         L.vg_ba_batch_info.argtypes = [C.c_void_p, _pd, _pd, _pd, _pi]
         L.vg_ba_batch_flops.argtypes = [C.c_void_p, _pd, _pd]
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
+        L.vg_ba_set_large_window.argtypes = [C.c_void_p, C.c_int]
+        L.vg_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+        L.vg_ba_reduce_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.vg_triangulate.argtypes = [C.c_void_p, C.c_int, _pd, _pd, _pd, _pd, C.c_int, _pi, _pi, _pi, _pd, C.c_double, _pd]
         L.vg_imu_preintegrate.argtypes = [C.c_void_p, C.c_int, _pi, _pd, _pd, _pd, _pd, C.POINTER(ImuPreint)]
         self.h = C.c_void_p()
@@ -228,6 +235,33 @@ class Handle:
 
     def ba_run_async(self):
         self._chk(self.lib.vg_ba_batch_run_async(self.h), "vg_ba_batch_run_async")
+
+    # ---- large windows / landmark shards (include/vinsgpu.h "Large windows and landmark shards")
+    def ba_set_large_window(self, force=True):
+        self._chk(self.lib.vg_ba_set_large_window(self.h, 1 if force else 0), "vg_ba_set_large_window")
+
+    def ba_set_allreduce(self, fn):
+        """fn(device_ptr: int, count: int, stream: int) must sum `count` doubles at device_ptr over all ranks in place,
+        stream-ordered on the HIP stream `stream`; None removes the hook (single rank)."""
+        if fn is None:
+            self._hook = None
+            self._chk(self.lib.vg_ba_set_allreduce(self.h, ALLREDUCE_FN(), None), "vg_ba_set_allreduce")
+            return
+
+        def tramp(user, buf, count, stream):
+            try:
+                fn(int(buf or 0), int(count), int(stream or 0))
+                return 0
+            except Exception as exc:                      # an exception must not unwind through the C frame
+                self._hook_error = exc
+                return 1
+        self._hook = ALLREDUCE_FN(tramp)                  # keep the trampoline alive as long as the handle uses it
+        self._chk(self.lib.vg_ba_set_allreduce(self.h, self._hook, None), "vg_ba_set_allreduce")
+
+    def ba_reduce_layout(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        self._chk(self.lib.vg_ba_reduce_layout(self.h, C.byref(a), C.byref(b)), "vg_ba_reduce_layout")
+        return int(a.value), int(b.value)
 
     def ba_run_timed(self):
         """Synchronous run; returns (solve_kernel_ms, marg_kernel_ms) from HIP events on the launch stream."""

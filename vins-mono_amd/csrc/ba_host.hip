@@ -21,6 +21,9 @@
 struct BaFork { hipStream_t aux; hipEvent_t fork, join; };
 extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
                                       hipEvent_t* ev, int* kinds, int* n_launches, const BaFork* fk);
+typedef int (*BaAllReduce)(void* user, double* buf, size_t count, void* stream);
+extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
+                                          BaAllReduce allreduce, void* user, int* hook_rc);
 extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, double* proj_r, double* proj_J,
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream);
 extern "C" const char* ba_failed_launch();
@@ -42,7 +45,7 @@ static int blk_gsize(int kind) { return kind == VG_BLK_SPEEDBIAS ? 9 : (kind == 
 
 static int check_problem(vg_handle* h, const vg_ba_problem* p) {
     if (!p || !p->pose || !p->speedbias || !p->ex_pose || !p->imu) { h->err = "null problem pointer"; return VG_ERR_BAD_ARG; }
-    if (p->K < 2 || p->K + 1 > BA_MAX_K) { h->err = "K out of range for the single-workgroup path"; return VG_ERR_UNSUPPORTED; }
+    if (p->K < 2 || p->K + 1 > BA_MAX_K_LARGE) { h->err = "K out of range"; return VG_ERR_UNSUPPORTED; }
     if (p->L < 0 || p->n_obs < 0 || (p->L > 0 && (!p->inv_depth || !p->lm_start || !p->lm_nobs || !p->lm_obs_off || !p->obs))) {
         h->err = "bad landmark tables"; return VG_ERR_BAD_ARG;
     }
@@ -130,11 +133,13 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.NBcap = up(std::max(NBmax, 1), 8);
     L.REC = 28 + 12 * L.e + 2 * L.t;
     L.nst = up(7 * L.Kp + 9 * L.K + 8, 2);
-    if (L.RcPad > 96 || L.Rc > 127) { h->err = "camera part wider than the solve kernel's tiling"; return VG_ERR_UNSUPPORTED; }
+    // one workgroup solves a window out of LDS while the camera part fits its tiling; wider windows (and windows the
+    // caller shards over ranks) take the large-window path
+    L.big = (L.RcPad > 96 || L.Rc > 127 || L.K + 1 > BA_MAX_K || h->ba.force_large) ? 1 : 0;
+    if (L.big && L.Rc + 10 > 256) { h->err = "camera part wider than the large-window solve kernel's tiling"; return VG_ERR_UNSUPPORTED; }
     // ---- workgroups per window
     L.nbf = (L.Fcap + BA_LIN_NT - 1) / BA_LIN_NT;
     L.nbl = L.nbf + 1;
-    if (L.nbl > BA_MAX_PART) { h->err = "too many projection factors per window"; return VG_ERR_UNSUPPORTED; }
     {
         const int nb = L.Kp + L.e + L.t;
         L.ntask = nb * (nb + 1) / 2;
@@ -143,28 +148,43 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         // diagonal pose blocks get a workgroup each, the ex / td blocks share one (if present), wavefront tasks after them
         L.nba = L.Kp + (ng ? 1 : 0) + (L.ntask - L.Kp - nglob + (L.Lcap + 63) / 64 + per - 1) / per;
     }
-    // ---- LDS carve of the solve kernel
+    // ---- LDS carve of the solve kernel (large-window path: only S, red and 1/L_jj are LDS offsets, the others are
+    //      offsets into the HBM scratch at so_bigm)
+    int bigm_doubles = 0;
     {
         // XC leading dimension: rows p and p+1 of an MFMA operand read must fall on different halves of the 64 banks
         int ldc = L.RcPad;
         if ((2 * ldc) % 64 != 32) ldc += 16;
         L.ldc = ldc;
-        int o = 0;
+        int o = 0, ob = 0;
+        int& oo = L.big ? ob : o;                    // where the movable arrays are carved from
         L.l_S = o; o += up((L.Rc + 1) * (L.Rc + 2) / 2, 2);
-        L.l_XC = o; o += up(9 * L.K, 4) * ldc;
-        L.l_D = o; o += up(81 * L.K, 2);
-        L.l_E = o; o += up(81 * L.K, 2);
-        L.l_dinv = o; o += up(9 * L.K, 2);
-        L.l_vec = o; o += 9 * L.Rpad;
+        L.l_XC = oo; oo += up(9 * L.K, 4) * ldc;
+        L.l_D = oo; oo += up(81 * L.K, 2);
+        L.l_E = oo; oo += up(81 * L.K, 2);
+        L.l_dinv = oo; oo += up(9 * L.K, 2);
+        L.l_vec = oo; oo += 9 * L.Rpad;
         L.l_red = o; o += 32;
-        L.l_wd = o; o += up(std::max(L.RcPad * 33, 9 * L.K), 2);       // staged landmark tile [RcPad][32 + 1]
-        L.l_z = o; o += up(36 * L.K, 2);
-        L.l_pmap = o; o += up(L.Ncap, 4) / 2;
+        L.l_wd = oo; oo += up(std::max(L.big ? 0 : L.RcPad * 33, std::max(9 * L.K, 162)), 2);   // staged landmark tile [RcPad][32 + 1]
+        L.l_z = oo; oo += up(36 * L.K, 2);
+        L.l_pmap = oo; oo += up(L.Ncap, 4) / 2;
+        if (L.big) { L.l_di = o; o += up(L.Rc + 1, 2); }
         L.lds_solve = o * 8;
+        bigm_doubles = ob;
         if (L.lds_solve > 160 * 1024) { h->err = "solve kernel LDS carve exceeds 160 KB"; return VG_ERR_UNSUPPORTED; }
-        const int nimu = L.K - 1;
-        L.lds_lin = 8 * std::max(up(nimu * 225, 2) + nimu * 480, 5 * L.Ncap);
-        L.lds_pro = 8 * std::max(BA_NW * 256, L.Ncap * L.Ncap);
+        const int nib = std::min(L.K - 1, BA_IMU_BATCH);
+        L.lds_lin = 8 * std::max(up(nib * 225, 2) + nib * 480, 5 * L.Ncap);
+        L.lds_pro = 8 * BA_NW * 256;
+        if (8 * L.Ncap * L.Ncap <= 128 * 1024) L.lds_pro = std::max(L.lds_pro, 8 * L.Ncap * L.Ncap);   // J0 staged in LDS when it fits
+        if (L.lds_lin > 128 * 1024) { h->err = "prior too large for the linearisation kernel"; return VG_ERR_UNSUPPORTED; }
+    }
+    if (L.big) {
+        const int nt = (L.Rc + 1 + 15) / 16;
+        L.nts = nt * (nt + 1) / 2;
+        const int ntri = L.Rc * (L.Rc + 1) / 2;
+        L.rb1_T = up(ntri + L.Rc, 2);
+        L.rb1_scal = L.rb1_T + up((L.Rc + 1) * (L.Rc + 2) / 2, 2);
+        L.rb1_len = L.rb1_scal + RB1_NSCAL;
     }
     // ---- int arrays
     int o = 0;
@@ -204,7 +224,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     // ---- scratch
     o = 0;
     L.so_ctl = o; o += C_NCTL;
-    L.so_part = o; o += BA_MAX_PART;
+    L.so_part = o; o += up(L.nbl, 8);
     L.so_x = o; o += 2 * L.nst;
     L.so_lam = o; o += 2 * L.Lcap;
     L.so_imuU = o; o += up((L.K - 1) * 225, 2);
@@ -217,6 +237,11 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.so_gn = o; o += L.Rpad + L.Lcap;
     L.so_yl = o; o += L.Lcap;
     L.so_lsc = o; o += L.Lcap;
+    if (L.big) {
+        L.so_bigm = o; o += up(bigm_doubles, 8);
+        L.so_dgl = o; o += 2 * L.Lcap;
+        L.so_gtl = o; o += 2 * L.Lcap;
+    }
     {
         int b = 0;
         L.bo_Sp = b; b += up(L.Rc * (L.Rc + 1) / 2, 2);
@@ -242,7 +267,12 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.oo_trace = o; o += 5 * VG_MAX_ITERS + 16;
     L.ostride = up(o, 8);
     L.oi_stride = up(4 + VG_MAX_ITERS, 8);
-    // ---- marginalization: kept dimension <= 6K + 2*9 + 6 + 1; blocks <= K + 4
+    // ---- marginalization: kept dimension <= 6K + 2*9 + 6 + 1; blocks <= K + 4   (not offered on the large-window path)
+    if (L.big) {
+        L.mcap = 8; L.mg_ld = 9; L.mg_posmax = 8; L.mg_cs = 640; L.mg_lds_bytes = 0;
+        L.mo_J0 = 0; L.mo_r0 = 64; L.mo_x0 = 72; L.mo_stride = 8; L.mi_stride = up(8 + 2 * (L.K + 4) + 16, 8); L.ms_stride = 8;
+        return VG_OK;
+    }
     L.mcap = up(6 * L.K + 9 * 2 + 6 + 1, 8);
     const int mcap = L.mcap;
     L.mo_J0 = 0;
@@ -417,6 +447,9 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     }
     B.flops = 0.0; B.flops_marg = 0.0; B.bytes_in = 0.0; B.bytes_out = 0.0;
     for (double& v : B.flops_k) v = 0.0;
+    if (L.big && margin_flags)
+        for (int w = 0; w < nwin; ++w)
+            if (margin_flags[w] != VG_MARGIN_NONE) { h->err = "marginalization is not offered on the large-window path"; return VG_ERR_UNSUPPORTED; }
     B.margin.assign(nwin, VG_MARGIN_NONE);
     B.nL.assign(nwin, 0);
     B.rounds = 0;
@@ -488,6 +521,12 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     rc = ensure(h, B.P.mout, B.cap_mout, (size_t)nwin * L.mo_stride); if (rc) return rc;
     rc = ensure(h, B.P.miout, B.cap_miout, (size_t)nwin * L.mi_stride); if (rc) return rc;
     rc = ensure(h, B.P.mscr, B.cap_mscr, (size_t)nwin * L.ms_stride); if (rc) return rc;
+    if (L.big) {
+        rc = ensure(h, B.P.rb1, B.cap_rb1, (size_t)nwin * L.rb1_len); if (rc) return rc;
+        rc = ensure(h, B.P.rb2, B.cap_rb2, (size_t)nwin * RB2_LEN); if (rc) return rc;
+        HIPCHK(h, hipMemsetAsync(B.P.rb1, 0, (size_t)nwin * L.rb1_len * sizeof(double), h->stream));
+        HIPCHK(h, hipMemsetAsync(B.P.rb2, 0, (size_t)nwin * RB2_LEN * sizeof(double), h->stream));
+    }
     if (!B.dL) HIPCHK(h, hipMalloc((void**)&B.dL, sizeof(BaLayout)));
     HIPCHK(h, hipMemcpyAsync(B.dL, &B.L, sizeof(BaLayout), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(B.P.iarr, B.h_ia, n_ia * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -502,16 +541,51 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     return VG_OK;
 }
 
+// all launches of one batch solve on h->stream (single-workgroup pipeline or the large-window path with its all-reduce hook)
+static int launch_solve(vg_handle* h) {
+    BaBatch& B = h->ba;
+    hipError_t e;
+    if (B.L.big) {
+        // the large-window path spends one round per attempted factorisation: max_iters rounds + slack for mu escalations
+        int hook_rc = 0;
+        e = ba_launch_solve_big(B.L, B.dL, B.P, B.rounds + 8, h->stream, (BaAllReduce)B.allreduce, B.allreduce_user, &hook_rc);
+        if (e != hipSuccess && hook_rc) { h->err = "all-reduce hook returned " + std::to_string(hook_rc); return VG_ERR_HIP; }
+    } else {
+        // (forking the IMU / prior kernel onto h->aux was measured: the event record / wait pairs cost more than the ~30 us of
+        //  overlap they buy — 2.72 vs 2.69 ms per 256-window solve — so the launches stay on one stream)
+        e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream, nullptr, nullptr, nullptr, nullptr);
+    }
+    if (e != hipSuccess) { h->err = std::string("launch of ") + ba_failed_launch() + ": " + hipGetErrorString(e); return VG_ERR_HIP; }
+    return VG_OK;
+}
+
 extern "C" int vg_ba_batch_run_async(vg_handle* h) {
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
-    {
-        // (forking the IMU / prior kernel onto h->aux was measured: the event record / wait pairs cost more than the ~30 us of
-        //  overlap they buy — 2.72 vs 2.69 ms per 256-window solve — so the launches stay on one stream)
-        const hipError_t e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream, nullptr, nullptr, nullptr, nullptr);
-        if (e != hipSuccess) { h->err = std::string("launch of ") + ba_failed_launch() + ": " + hipGetErrorString(e); return VG_ERR_HIP; }
-    }
+    const int rc = launch_solve(h);
+    if (rc) return rc;
     if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
+    return VG_OK;
+}
+
+// Large-window path (BASELINE configs[4]): force it for windows that would fit the single-workgroup pipeline (tests, sharded
+// small windows) and install the hook that sums the reduce buffers over the ranks.  Both take effect at the next upload / run.
+extern "C" int vg_ba_set_large_window(vg_handle* h, int force) {
+    if (!h) return VG_ERR_BAD_ARG;
+    h->ba.force_large = force != 0;
+    h->ba.uploaded = false;
+    return VG_OK;
+}
+extern "C" int vg_ba_set_allreduce(vg_handle* h, vg_allreduce_fn fn, void* user) {
+    if (!h) return VG_ERR_BAD_ARG;
+    h->ba.allreduce = (void*)fn;
+    h->ba.allreduce_user = user;
+    return VG_OK;
+}
+extern "C" int vg_ba_reduce_layout(vg_handle* h, size_t* count1, size_t* count2) {
+    if (!h || !h->ba.uploaded || !h->ba.L.big) return VG_ERR_BAD_ARG;
+    if (count1) *count1 = (size_t)h->ba.nwin * h->ba.L.rb1_len;
+    if (count2) *count2 = (size_t)h->ba.nwin * RB2_LEN;
     return VG_OK;
 }
 
@@ -521,10 +595,8 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
     hipEvent_t e0 = h->ev0, e1 = h->ev1, e2 = h->ev2;
     HIPCHK(h, hipEventRecord(e0, h->stream));
     {
-        // (forking the IMU / prior kernel onto h->aux was measured: the event record / wait pairs cost more than the ~30 us of
-        //  overlap they buy — 2.72 vs 2.69 ms per 256-window solve — so the launches stay on one stream)
-        const hipError_t e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream, nullptr, nullptr, nullptr, nullptr);
-        if (e != hipSuccess) { h->err = std::string("launch of ") + ba_failed_launch() + ": " + hipGetErrorString(e); return VG_ERR_HIP; }
+        const int rc = launch_solve(h);
+        if (rc) return rc;
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));
     if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
@@ -543,6 +615,7 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
 extern "C" int vg_ba_batch_run_profiled(vg_handle* h, float* ms, int* n) {
     if (!h || !h->ba.uploaded || !ms || !n) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
+    if (B.L.big) { h->err = "per-kernel profile is not offered on the large-window path (use rocprofv3)"; return VG_ERR_UNSUPPORTED; }
     const int nev = 4 * B.rounds + 5 + 1;
     std::vector<hipEvent_t> ev(nev, nullptr);
     std::vector<int> kinds(nev, 0);

@@ -13,20 +13,32 @@
 #define BA_NW (BA_NT / 64)
 #define BA_LIN_NT 256             // projection factors per workgroup of the linearisation kernel
 #define BA_ACC_NT 256             // threads per workgroup of the accumulation kernel
-#define BA_MAX_K 13               // frames incl. relocalisation pose
+#define BA_MAX_K 13               // frames incl. relocalisation pose, windows solved by one workgroup out of LDS
+#define BA_MAX_K_LARGE 40         // the same for the large-window path (reduced system in HBM, see BaLayout::big)
+#define BA_IMU_BATCH 16           // IMU factors linearised per pass of the linearisation workgroup (LDS panels)
 #define BA_IMU_STRIDE 472         // doubles per vg_imu_preint record on device
 #define BA_OBS_STRIDE 8
 #define BA_SUM_DOUBLES 8
 #define BA_HDR_INTS 16
-#define BA_MAX_PART 16            // cost partial sums per window (one per workgroup of the linearisation kernel)
 
 enum { H_L = 0, H_F, H_NPRIOR, H_NBLK, H_MAXIT, H_NCHUNK, H_MARGIN, H_STATUS };
 
 // per-window solver state that lives in HBM between the launches of one solve (doubles; integers stored exactly)
 enum {
     C_IT = 0, C_NACC, C_NINV, C_TERM, C_STATUS, C_RADIUS, C_MU, C_MUSOLVED, C_REUSE, C_COST, C_XNORM, C_ALPHA, C_GTN2,
-    C_GNN2, C_GTGN, C_DNORM, C_MODEL, C_CUR, C_PENDING, C_DONE, C_STEPNORM, C_XNORMC, C_INITCOST, C_SCALED, C_QCAM, C_NCTL = 32
+    C_GNN2, C_GTGN, C_DNORM, C_MODEL, C_CUR, C_PENDING, C_DONE, C_STEPNORM, C_XNORMC, C_INITCOST, C_SCALED, C_QCAM,
+    // large-window path only: phase of the round (0 nothing to do, 1 Gauss-Newton step solved, 2 step reuse), the camera /
+    // speed-bias shares of |gn|^2, gt.gn, |x - x_cand|^2, |x_cand|^2 (the landmark shares travel through the reduce buffers)
+    C_PHASE, C_GNN2C, C_GTGNC, C_STEP2C, C_XN2C, C_NCTL = 32
 };
+
+// reduce buffer 1 of the large-window path, per window:  [Sp  Rc(Rc+1)/2 | gp  Rc | T  (Rc+1)(Rc+2)/2 | scalars RB1_NSCAL]
+//   Sp, gp = J^T J / J^T r of this rank's projection factors (camera part);  T = sum_l omega_l [W_l; b_l][W_l; b_l]^T of this
+//   rank's landmarks (packed lower, augmented row Rc = rhs);  scalars below.  Summed over the ranks by the caller's
+//   all-reduce (RCCL over xGMI) between the Schur kernel and the solve kernel; a single rank skips the collective.
+enum { RB1_COST = 0, RB1_GTL2, RB1_LAM2, RB1_STEP2, RB1_NBIG, RB1_NSCAL = 8 };
+// reduce buffer 2: landmark shares of |gn|^2, gt.gn, the Cauchy-point term, the count of non-finite step entries
+enum { RB2_GNN2 = 0, RB2_GTGN, RB2_QL, RB2_NONFIN, RB2_LEN = 8 };
 
 struct BaLayout {
     int nwin, K, Kp, e, t;
@@ -59,6 +71,15 @@ struct BaLayout {
     // ---- LDS carve of the solve kernel (offsets in doubles)
     int l_S, l_XC, l_D, l_E, l_dinv, l_vec, l_red, l_wd, l_z, l_pmap, ldc, lds_solve;
     int lds_lin, lds_pro;                     // dynamic LDS bytes of the linearisation / prologue kernels
+    // ---- large-window path (big != 0): the camera part does not fit the LDS carve above.  S stays in LDS (packed, with
+    //      the rhs row), everything else of the carve lives in HBM scratch at so_bigm (the l_* offsets are then relative to
+    //      it); the landmark Schur complement is formed by a multi-workgroup kernel into reduce buffer 1.
+    int big;
+    int so_bigm;                              // HBM home of XC / D / E / dinv / vec / wd / z / pmap
+    int l_di;                                 // LDS offset of the 1/L_jj vector (big path)
+    int so_dgl, so_gtl;                       // landmark Dg, gt per linearisation buffer (2 x Lcap each)
+    int rb1_len, rb1_T, rb1_scal;             // reduce buffer 1: doubles per window, offsets of T and of the scalars
+    int nts;                                  // lower 16x16 tiles of T = workgroups of the Schur kernel (+ 1 landmark workgroup)
 };
 
 struct BaPtrs {
@@ -70,6 +91,8 @@ struct BaPtrs {
     double* mout;
     int* miout;
     double* mscr;
+    double* rb1;                              // large-window path: reduce buffers [nwin][rb1_len], [nwin][RB2_LEN]
+    double* rb2;
 };
 
 // parameter slots at do_par

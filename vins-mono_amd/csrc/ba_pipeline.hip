@@ -116,8 +116,9 @@ DEV double* lin_buf(const Ctx& c, int which) { return c.sc + c.Lp->so_buf + (siz
 
 // ---- solver state carried between launches -----------------------------------------------------------------------
 struct Ctl {
-    int it, nacc, ninv, term, status, reuse, cur, pending, done, scaled;
+    int it, nacc, ninv, term, status, reuse, cur, pending, done, scaled, phase;
     double radius, mu, mu_solved, cost, x_norm, alpha, gtn2, gnn2, gtgn, dnorm, model, step_norm, x_norm_c, init_cost, qcam;
+    double gnn2c, gtgnc, step2c, xn2c;        // large-window path (ba_layout.h)
 };
 DEV void ctl_load(Ctl& s, const double* p) {
     s.it = (int)p[C_IT]; s.nacc = (int)p[C_NACC]; s.ninv = (int)p[C_NINV]; s.term = (int)p[C_TERM]; s.status = (int)p[C_STATUS];
@@ -125,6 +126,7 @@ DEV void ctl_load(Ctl& s, const double* p) {
     s.radius = p[C_RADIUS]; s.mu = p[C_MU]; s.mu_solved = p[C_MUSOLVED]; s.cost = p[C_COST]; s.x_norm = p[C_XNORM];
     s.alpha = p[C_ALPHA]; s.gtn2 = p[C_GTN2]; s.gnn2 = p[C_GNN2]; s.gtgn = p[C_GTGN]; s.dnorm = p[C_DNORM]; s.model = p[C_MODEL];
     s.step_norm = p[C_STEPNORM]; s.x_norm_c = p[C_XNORMC]; s.init_cost = p[C_INITCOST]; s.qcam = p[C_QCAM];
+    s.phase = (int)p[C_PHASE]; s.gnn2c = p[C_GNN2C]; s.gtgnc = p[C_GTGNC]; s.step2c = p[C_STEP2C]; s.xn2c = p[C_XN2C];
 }
 DEV void ctl_store(const Ctl& s, double* p) {
     p[C_IT] = s.it; p[C_NACC] = s.nacc; p[C_NINV] = s.ninv; p[C_TERM] = s.term; p[C_STATUS] = s.status;
@@ -132,14 +134,18 @@ DEV void ctl_store(const Ctl& s, double* p) {
     p[C_RADIUS] = s.radius; p[C_MU] = s.mu; p[C_MUSOLVED] = s.mu_solved; p[C_COST] = s.cost; p[C_XNORM] = s.x_norm;
     p[C_ALPHA] = s.alpha; p[C_GTN2] = s.gtn2; p[C_GNN2] = s.gnn2; p[C_GTGN] = s.gtgn; p[C_DNORM] = s.dnorm; p[C_MODEL] = s.model;
     p[C_STEPNORM] = s.step_norm; p[C_XNORMC] = s.x_norm_c; p[C_INITCOST] = s.init_cost; p[C_QCAM] = s.qcam;
+    p[C_PHASE] = s.phase; p[C_GNN2C] = s.gnn2c; p[C_GTGNC] = s.gtgnc; p[C_STEP2C] = s.step2c; p[C_XN2C] = s.xn2c;
 }
 
 // Judge the pending candidate (TrustRegionMinimizer: parameter tolerance, function tolerance, step quality; then
 // DoglegStrategy::StepAccepted / StepRejected).  Uniform: every thread computes the same from the same HBM values;
 // thread 0 writes the trace.  Returns true if the candidate became the current point.
-DEV bool judge_candidate(Ctl& s, const double* part, int nbl, const BaLayout& L, double* out, int* iout, int tid) {
+DEV double sum_partials(const double* part, int nbl) {
     double cs = 0.0;
     for (int b = 0; b < nbl; ++b) cs += part[b];
+    return cs;
+}
+DEV bool judge_candidate(Ctl& s, double cs, const BaLayout& L, double* out, int* iout, int tid) {
     const double cost_cand = 0.5 * cs;
     const int slot = s.it - 1;
     bool accepted = false;
@@ -244,17 +250,22 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
         const int n = c.nprior;
         const double* J0 = c.di + L.do_pJ0;
         double* Hp = c.sc + L.so_Hp;
-        double* J0s = LDSB;                      // n x n, row stride n
+        const double* J0s = J0;                  // n x n, row stride ld: staged in LDS when it fits (host: lds_pro)
+        int ld = L.Ncap;
         __syncthreads();
-        for (int wk = c.tid; wk < n * n; wk += BA_NT) J0s[wk] = J0[(wk / n) * L.Ncap + wk % n];
+        if ((size_t)n * n * 8 <= (size_t)L.lds_pro) {
+            double* st = LDSB;
+            for (int wk = c.tid; wk < n * n; wk += BA_NT) st[wk] = J0[(wk / n) * L.Ncap + wk % n];
+            J0s = st; ld = n;
+        }
         __syncthreads();
         for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
             int a, bb;
             tri_decode(wk, a, bb);
             double s0 = 0.0, s1 = 0.0;
             int r = 0;
-            for (; r + 1 < n; r += 2) { s0 += J0s[r * n + a] * J0s[r * n + bb]; s1 += J0s[(r + 1) * n + a] * J0s[(r + 1) * n + bb]; }
-            if (r < n) s0 += J0s[r * n + a] * J0s[r * n + bb];
+            for (; r + 1 < n; r += 2) { s0 += J0s[r * ld + a] * J0s[r * ld + bb]; s1 += J0s[(r + 1) * ld + a] * J0s[(r + 1) * ld + bb]; }
+            if (r < n) s0 += J0s[r * ld + a] * J0s[r * ld + bb];
             Hp[a * L.Ncap + bb] = s0 + s1;
         }
     }
@@ -273,54 +284,59 @@ NOINL double imu_pass(const Ctx& c, const double* x, double* imuJ) {
     const BaLayout& L = *c.Lp;
     const int nimu = L.K - 1;
     const int* valid = c.ia + L.io_imu_valid;
-    double* Us = LDSB;                                      // [nimu][225]
-    double* panels = Us + ((nimu * 225 + 1) & ~1);          // [nimu][15][32]
+    const int nb = nimu < BA_IMU_BATCH ? nimu : BA_IMU_BATCH;      // factors per pass (one pass for the reference's window)
+    double* Us = LDSB;                                      // [nb][225]
+    double* panels = Us + ((nb * 225 + 1) & ~1);            // [nb][15][32]
     double cost = 0.0;
-    for (int k = c.tid; k < nimu * 225; k += BA_NT) Us[k] = c.sc[L.so_imuU + k];
-    __syncthreads();
-    const int per = nimu > BA_NW ? 2 : 1;
+    const int per = nb > BA_NW ? 2 : 1;
     const int half = c.lane >> 5, hl = c.lane & 31;
-    const int f = c.wave * per + half;
-    const bool act = f < nimu && half < per && valid[f];
-    if (act) {
-        const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
-        const double* U = Us + f * 225;
-        double* panel = panels + f * 480;
-        ImuCtx ic;
-        imu_ctx<JAC>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
-        double raw[15];
-        if (JAC && hl < 30) imu_raw_col(ic, pre, hl, raw);
-        else {
+    for (int f0 = 0; f0 < nimu; f0 += nb) {
+        const int nf = nimu - f0 < nb ? nimu - f0 : nb;
+        for (int k = c.tid; k < nf * 225; k += BA_NT) Us[k] = c.sc[L.so_imuU + f0 * 225 + k];
+        __syncthreads();
+        const int fl = c.wave * per + half;                 // factor of this (half-)wavefront inside the pass
+        const int f = f0 + fl;
+        const bool act = fl < nf && half < per && valid[f];
+        if (act) {
+            const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
+            const double* U = Us + fl * 225;
+            double* panel = panels + fl * 480;
+            ImuCtx ic;
+            imu_ctx<JAC>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
+            double raw[15];
+            if (JAC && hl < 30) imu_raw_col(ic, pre, hl, raw);
+            else {
 #pragma unroll
-            for (int q = 0; q < 15; ++q) raw[q] = ic.r[q];
-        }
-        if (hl <= 30) {
+                for (int q = 0; q < 15; ++q) raw[q] = ic.r[q];
+            }
+            if (hl <= 30) {
 #pragma unroll
-            for (int r = 0; r < 15; ++r) {
-                double s = 0.0;
+                for (int r = 0; r < 15; ++r) {
+                    double s = 0.0;
 #pragma unroll
-                for (int k = 0; k < 15; ++k) if (k >= r) s += U[r * 15 + k] * raw[k];
-                if (JAC) panel[r * 32 + hl] = s;
-                if (hl == 30) cost += s * s;
+                    for (int k = 0; k < 15; ++k) if (k >= r) s += U[r * 15 + k] * raw[k];
+                    if (JAC) panel[r * 32 + hl] = s;
+                    if (hl == 30) cost += s * s;
+                }
             }
         }
-    }
-    __syncthreads();
-    if (JAC) {
-        for (int w = c.tid; w < nimu * 495; w += BA_NT) {
-            const int ff = w / 495, e = w - 495 * ff;
-            if (!valid[ff]) continue;
-            const double* panel = panels + ff * 480;
-            int a, b;
-            if (e < 465) tri_decode(e, a, b);
-            else { a = e - 465; b = 30; }
-            double s = 0.0;
+        __syncthreads();
+        if (JAC) {
+            for (int w = c.tid; w < nf * 495; w += BA_NT) {
+                const int ff = w / 495, e = w - 495 * ff;
+                if (!valid[f0 + ff]) continue;
+                const double* panel = panels + ff * 480;
+                int a, b;
+                if (e < 465) tri_decode(e, a, b);
+                else { a = e - 465; b = 30; }
+                double s = 0.0;
 #pragma unroll
-            for (int r = 0; r < 15; ++r) s += panel[r * 32 + a] * panel[r * 32 + b];
-            imuJ[ff * 512 + e] = s;
+                for (int r = 0; r < 15; ++r) s += panel[r * 32 + a] * panel[r * 32 + b];
+                imuJ[(f0 + ff) * 512 + e] = s;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     return cost;
 }
 
@@ -698,6 +714,7 @@ DEV void landmark_task(const Ctx& c, int l, const double* recs, double* buf) {
         row += 6;
     }
     if (L.t) { Wt[(size_t)col_td(L) * ldw] = anchor >= 0 ? wtd : 0.0; row += 1; }
+    if (L.big) { Wt[row * ldw] = b; ++row; }      // large-window path: the rhs travels as row Rc of W (ba_big_schur_kernel)
     for (; row < L.RcPad; ++row) Wt[row * ldw] = 0.0;
     buf[L.bo_h + l] = h;
     buf[L.bo_b + l] = b;
@@ -739,7 +756,7 @@ extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(con
 // Solve kernel
 // ================================================================================================
 struct SolveLds {
-    double *S, *XC, *D, *E, *dinv, *vec, *red, *wd, *z;
+    double *S, *XC, *D, *E, *dinv, *vec, *red, *wd, *z, *di;
     int* pmap;
     int ldc;
 };
@@ -747,6 +764,17 @@ DEV void lds_carve(const BaLayout& L, SolveLds& m) {
     m.S = LDSB + L.l_S; m.XC = LDSB + L.l_XC; m.D = LDSB + L.l_D; m.E = LDSB + L.l_E; m.dinv = LDSB + L.l_dinv;
     m.vec = LDSB + L.l_vec; m.red = LDSB + L.l_red; m.wd = LDSB + L.l_wd; m.z = LDSB + L.l_z;
     m.pmap = (int*)(LDSB + L.l_pmap);
+    m.ldc = L.ldc;
+    m.di = m.vec + V_DI * L.Rpad;
+}
+// large-window carve: S, the reduction scratch and 1/L_jj in LDS, the rest in HBM scratch (generic pointers: the helpers
+// below do not care)
+DEV void big_carve(const BaLayout& L, double* sc, SolveLds& m) {
+    double* hb = sc + L.so_bigm;
+    m.S = LDSB + L.l_S; m.red = LDSB + L.l_red; m.di = LDSB + L.l_di;
+    m.XC = hb + L.l_XC; m.D = hb + L.l_D; m.E = hb + L.l_E; m.dinv = hb + L.l_dinv;
+    m.vec = hb + L.l_vec; m.wd = hb + L.l_wd; m.z = hb + L.l_z;
+    m.pmap = (int*)(hb + L.l_pmap);
     m.ldc = L.ldc;
 }
 
@@ -776,14 +804,15 @@ DEV void hess_add(const BaLayout& L, const SolveLds& m, int ca, int cb, double v
 }
 
 // Unscaled Gauss-Newton system of the current point in LDS: S (camera, packed lower), g, chain blocks D, E, XC.
-NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf) {
+// Sp / gp = camera J^T J / J^T r of the projection factors (the buffer's own, or the rank-summed copy of the large-window path)
+NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf, const double* Sp, const double* gp) {
     const BaLayout& L = *c.Lp;
     const int Rc = L.Rc, R = L.R, K = L.K;
     const int camtri = Rc * (Rc + 1) / 2;
     double* g = m.vec + V_G * L.Rpad;
     __syncthreads();
-    for (int k = c.tid; k < camtri; k += BA_NT) m.S[k] = buf[L.bo_Sp + k];
-    for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? buf[L.bo_gp + k] : 0.0;
+    for (int k = c.tid; k < camtri; k += BA_NT) m.S[k] = Sp[k];
+    for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? gp[k] : 0.0;
     const int nxc = ((9 * K + 3) & ~3) * m.ldc;
     for (int k = c.tid; k < nxc; k += BA_NT) m.XC[k] = 0.0;
     for (int k = c.tid; k < 81 * K; k += BA_NT) { m.D[k] = 0.0; m.E[k] = 0.0; }
@@ -1049,9 +1078,9 @@ NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
         }
         __syncthreads();
         if (*flag == 0) break;
-        // ---- (B) columns: threads 0 .. Rc + 9 serve the top block, 128 .. 128 + Rc + 9 the bottom block
+        // ---- (B) columns: threads 0 .. Rc + 9 serve the top block, 256 .. 256 + Rc + 9 the bottom block (Rc + 10 <= 256)
         {
-            const int half = c.tid >> 7, id = c.tid & 127;
+            const int half = c.tid >> 8, id = c.tid & 255;
             if (half == 0 && has_t) {
                 const double* Lk = m.D + 81 * kt;
                 if (id <= Rc) chain_col_solve(Lk, m.dinv + 9 * kt, m.XC + 9 * kt * ldc + id, ldc);
@@ -1205,7 +1234,7 @@ NOINL double cauchy_landmark_term(const Ctx& c, const SolveLds& m, const double*
 NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
     const BaLayout& L = *c.Lp;
     double* S = m.S;
-    double* dinvv = m.vec + V_DI * L.Rpad;
+    double* dinvv = m.di;
     int* flag = (int*)(m.red + 24);
     const int lane = c.lane;
     if (c.tid == 0) *flag = 1;
@@ -1326,7 +1355,7 @@ NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
 NOINL void back_substitute(const Ctx& c, const SolveLds& m, int R) {
     const BaLayout& L = *c.Lp;
     const double* S = m.S;
-    const double* dinvv = m.vec + V_DI * L.Rpad;
+    const double* dinvv = m.di;
     double* y = m.vec + V_Y * L.Rpad;
     __syncthreads();
     if (c.wave == 0) {
@@ -1482,16 +1511,14 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     bool assembled = false;
     bool fresh_point = false;              // a new current point whose gradient has to be tested
     if (s.pending) {
-        const bool acc = judge_candidate(s, c.sc + L.so_part, L.nbl, L, out, iout, c.tid);
+        const bool acc = judge_candidate(s, sum_partials(c.sc + L.so_part, L.nbl), L, out, iout, c.tid);
         if (acc) {
             if (!(s.cost == s.cost)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
             fresh_point = true;
         }
     } else if (!s.scaled) {
         // round 0: cost of the initial point
-        double cs = 0.0;
-        for (int b = 0; b < L.nbl; ++b) cs += c.sc[L.so_part + b];
-        s.cost = 0.5 * cs;
+        s.cost = 0.5 * sum_partials(c.sc + L.so_part, L.nbl);
         s.init_cost = s.cost;
         s.x_norm = sqrt(block_sum(m.red, BA_NW, c.lane, c.wave, state_sqnorm_share(L, c.sc + L.so_x + s.cur * L.nst,
                                                                                      c.sc + L.so_lam + s.cur * L.Lcap, nL, c.tid, BA_NT)));
@@ -1503,7 +1530,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     const double* hh = buf + L.bo_h;
     const double* bb = buf + L.bo_b;
     if (fresh_point && s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK) {
-        assemble(c, m, buf);
+        assemble(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp);
         assembled = true;
         if (!s.scaled) {
             // Jacobi scaling from the first Jacobian, fixed for the solve: 1 / (1 + ||J_col||)
@@ -1534,7 +1561,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
         bool ok = true;
         if (!s.reuse) {
             s.reuse = 1;
-            if (!assembled) { assemble(c, m, buf); assembled = true; }
+            if (!assembled) { assemble(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; }
             PROF_ADD(PF_ASM);
             // Dg, gt (scaled gradient / Dg), t = gt / Dg
             for (int k = c.tid; k < R; k += BA_NT) {
@@ -1565,7 +1592,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
             // Gauss-Newton step, increasing mu on failure (DoglegStrategy::ComputeGaussNewtonStep)
             bool solved = false;
             while (s.mu < max_mu) {
-                if (!assembled) { assemble(c, m, buf); assembled = true; PROF_ADD(PF_ASM); }
+                if (!assembled) { assemble(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; PROF_ADD(PF_ASM); }
                 double q = build_scaled(c, m, s.mu);
                 assembled = false;
                 __syncthreads();
@@ -1717,6 +1744,513 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
 }
 
 // ================================================================================================
+// Large-window path (BaLayout::big): windows whose camera part does not fit the LDS carve of ba_solve_kernel (BASELINE
+// configs[4]: 31 frames x 2000 landmarks, Rc = 193, R = 472) and windows whose landmarks are SHARDED over ranks.
+//
+// Landmarks are conditionally independent given the frames, so a rank that holds a contiguous shard of the landmarks
+// (and all frames, IMU factors and the prior, replicated) can form its share of the reduced camera system on its own:
+//     Sp, gp  = J^T J, J^T r of its projection factors (accumulation kernel)
+//     T       = sum_l omega_l [W_l; b_l] [W_l; b_l]^T,   omega_l = sl^2 / (sl^2 h_l + mu Dg_l^2)      (ba_big_schur_kernel, MFMA)
+// One all-reduce of [Sp | gp | T | scalars] (RCCL over xGMI, issued by the caller's hook between two launches; ~300 KB for
+// Rc = 193) gives every rank the complete reduced system; every rank then factorises it redundantly (no broadcast),
+// back-substitutes its own landmarks, and a second, 4-double all-reduce completes |gn|^2, gt.gn and the Cauchy term for
+// the dogleg step.  The camera scaling commutes with the Schur complement (diag(sc) T diag(sc)), so T is reduced
+// unscaled; the landmark scaling and damping are local to a landmark.  With a pending candidate the Schur kernel runs
+// speculatively at the candidate's linearisation with the mu an accepted step would leave (max(1e-8, mu / 5)): a
+// rejected step reuses the previous Gauss-Newton step and needs no linear solve, exactly as DoglegStrategy does.
+//
+//   per round:  linearize_imu, linearize_proj, accumulate, big_schur | all-reduce 1 | solve_big | all-reduce 2 | big_step
+//
+// Trust-region semantics are those of ba_solve_kernel (one iteration per round; a failed factorisation retries the same
+// iteration with mu x 10 in the next round, because the new T needs the collective).
+// ================================================================================================
+
+// grid (nts + 1, nwin), 256 threads.  Workgroups 0 .. nts-1: one lower 16x16 tile of T each, the four wavefronts take
+// interleaved groups of 16 landmarks (a lane loads 4 consecutive landmarks of its row: 32-byte loads, 128 contiguous
+// bytes per row), partial tiles are summed through LDS in a fixed order.  Workgroup nts: per-landmark Dg, gt (and the
+// landmark scaling in round 0), the scalar partial sums, and the copy of Sp / gp into the reduce buffer.
+extern "C" __global__ __launch_bounds__(256) void ba_big_schur_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    const int w = blockIdx.y;
+    ctx_init(c, Lp, P, w);
+    const double* ctl = c.sc + L.so_ctl;
+    if (ctl[C_DONE] != 0.0) return;
+    const bool pending = ctl[C_PENDING] != 0.0;
+    const int cur = (int)ctl[C_CUR];
+    const int which = cur ^ (pending ? 1 : 0);
+    const double mu = pending ? fmax(1e-8, 2.0 * ctl[C_MU] / 10.0) : ctl[C_MU];
+    const bool scaled = ctl[C_SCALED] != 0.0;
+    const double* buf = lin_buf(c, which);
+    const double* hh = buf + L.bo_h;
+    const double* bb = buf + L.bo_b;
+    double* sl = c.sc + L.so_sl;
+    double* rb = P.rb1 + (size_t)w * L.rb1_len;
+    const int Rc = L.Rc, nL = c.nL;
+    __shared__ double sh[4 * 256];
+    if ((int)blockIdx.x == L.nts) {
+        const int ntri = Rc * (Rc + 1) / 2;
+        if (!cost_only) {
+            for (int k = c.tid; k < ntri; k += 256) rb[k] = buf[L.bo_Sp + k];
+            for (int k = c.tid; k < Rc; k += 256) rb[ntri + k] = buf[L.bo_gp + k];
+        }
+        double* dgl = c.sc + L.so_dgl + which * L.Lcap;
+        double* gtl = c.sc + L.so_gtl + which * L.Lcap;
+        const double* lam = c.sc + L.so_lam + which * L.Lcap;
+        const double* lam0 = c.sc + L.so_lam + cur * L.Lcap;
+        double cost = 0.0, gt2 = 0.0, lam2 = 0.0, st2 = 0.0, nbig = 0.0;
+        for (int b = c.tid; b < L.nbf; b += 256) cost += c.sc[L.so_part + b];
+        for (int l = c.tid; l < nL; l += 256) {
+            lam2 += lam[l] * lam[l];
+            if (pending) { const double d = lam0[l] - lam[l]; st2 += d * d; }
+            if (cost_only) continue;
+            const double h = hh[l];
+            const double s = scaled ? sl[l] : 1.0 / (1.0 + sqrt(h));
+            if (!scaled) sl[l] = s;
+            double d2 = s * s * h;
+            d2 = d2 < 1e-6 ? 1e-6 : d2;
+            d2 = 1e32 < d2 ? 1e32 : d2;
+            const double d = sqrt(d2);
+            dgl[l] = d;
+            const double g = s * bb[l] / d;
+            gtl[l] = g;
+            gt2 += g * g;
+            nbig += fabs(bb[l]) > 1e-10 ? 1.0 : 0.0;
+        }
+        cost = block_sum(sh, 4, c.lane, c.wave, cost);
+        block_sum2(sh, 4, c.lane, c.wave, gt2, lam2);
+        block_sum2(sh, 4, c.lane, c.wave, st2, nbig);
+        if (c.tid == 0) {
+            double* sc = rb + L.rb1_scal;
+            sc[RB1_COST] = cost; sc[RB1_GTL2] = gt2; sc[RB1_LAM2] = lam2; sc[RB1_STEP2] = st2; sc[RB1_NBIG] = nbig;
+            sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
+        }
+        return;
+    }
+    if (cost_only) return;
+    int tm, tn;
+    tri_decode(blockIdx.x, tm, tn);
+    const double* Wt = buf + L.bo_Wt;
+    const int r = c.lane & 15, kk = c.lane >> 4;
+    const double* pa = Wt + (size_t)(tm * 16 + r) * L.Lcap + 4 * kk;
+    const double* pb = Wt + (size_t)(tn * 16 + r) * L.Lcap + 4 * kk;
+    double4_t acc = {0, 0, 0, 0};
+    for (int l0 = 16 * c.wave; l0 < nL; l0 += 64) {
+        const int lb = l0 + 4 * kk;
+        double a[4], bq[4], om[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = pa[l0 + q];                      // (Lcap is a multiple of 16 and columns nL .. Lcap-1 of Wt are zero)
+            bq[q] = pb[l0 + q];
+            const int l = lb + q;
+            double o = 0.0;
+            if (l < nL) {
+                const double h = hh[l];
+                const double s = scaled ? sl[l] : 1.0 / (1.0 + sqrt(h));
+                double d2 = s * s * h;
+                d2 = d2 < 1e-6 ? 1e-6 : d2;
+                d2 = 1e32 < d2 ? 1e32 : d2;
+                o = s * s / (s * s * h + mu * d2);
+            }
+            om[q] = o;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q] * om[q], bq[q], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sh[c.wave * 256 + reg * 64 + c.lane] = acc[reg];
+    __syncthreads();
+    {
+        // element e = reg * 64 + lane of the tile: D[row = (lane >> 4) + 4 reg][col = lane & 15]
+        const int e = c.tid, reg = e >> 6, lane = e & 63;
+        const double v = (sh[e] + sh[256 + e]) + (sh[512 + e] + sh[768 + e]);
+        const int row = tm * 16 + (lane >> 4) + 4 * reg, col = tn * 16 + (lane & 15);
+        if (row <= Rc && col <= row) rb[L.rb1_T + tri(row, col)] = v;
+    }
+}
+
+// S -= X^T X over the 9K chain rows (XC in HBM, rhs in column Rc -> augmented row Rc of S) and S -= diag(sc) T diag(sc)
+// (the rank-summed landmark Schur complement; row Rc: rhs).  Wavefront per 16x16 tile, v_mfma_f64_16x16x4.
+NOINL void schur_chain_big(const Ctx& c, const SolveLds& m, const double* T) {
+    const BaLayout& L = *c.Lp;
+    const double* sc = m.vec + V_SC * L.Rpad;
+    const int Rc = L.Rc, ldc = m.ldc;
+    const int nt = L.RcPad / 16, ntile = nt * (nt + 1) / 2;
+    const int nk = (9 * L.K + 3) / 4;
+    __syncthreads();
+    for (int t = c.wave; t < ntile; t += BA_NW) {
+        int tm, tn;
+        tri_decode(t, tm, tn);
+        double4_t acc = {0, 0, 0, 0};
+        const double* xr = m.XC + (size_t)(c.lane >> 4) * ldc + (c.lane & 15);
+        for (int kk = 0; kk < nk; ++kk) {
+            const double a = xr[(size_t)kk * 4 * ldc + tm * 16];
+            const double bq = xr[(size_t)kk * 4 * ldc + tn * 16];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = tm * 16 + (c.lane >> 4) + 4 * reg, col = tn * 16 + (c.lane & 15);
+            if (row <= Rc && col <= row && col < Rc) {
+                const double sr = row < Rc ? sc[row] : 1.0;
+                m.S[tri(row, col)] -= acc[reg] + sr * sc[col] * T[tri(row, col)];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// back substitution L^T y = (row R of S) for R <= 64 NR, one wavefront, lane owns entries lane + 64 q of the running rhs
+template <int NR>
+NOINL void back_substitute_n(const Ctx& c, const SolveLds& m, int R) {
+    const BaLayout& L = *c.Lp;
+    const double* S = m.S;
+    const double* dinvv = m.di;
+    double* y = m.vec + V_Y * L.Rpad;
+    __syncthreads();
+    if (c.wave == 0) {
+        const double* rowR = S + tri(R, 0);
+        double v[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) { const int l = c.lane + 64 * q; v[q] = l < R ? rowR[l] : 0.0; }
+#pragma unroll
+        for (int qo = NR - 1; qo >= 0; --qo) {
+            const int jhi = R - 1 < 64 * qo + 63 ? R - 1 : 64 * qo + 63;
+            for (int j = jhi; j >= 64 * qo; --j) {
+                const double* rj = S + tri(j, 0);
+                const int own = j & 63;
+                const double xj = readlane_d(v[qo], own) * dinvv[j];
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    if (q < qo) v[q] -= rj[c.lane + 64 * q] * xj;
+                    else if (q == qo) {
+                        const int l = c.lane + 64 * q;
+                        const double rv = l < j ? rj[l] : 0.0;
+                        v[q] = c.lane == own ? xj : v[q] - rv * xj;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) { const int l = c.lane + 64 * q; if (l < R) y[l] = v[q]; }
+    }
+    __syncthreads();
+}
+
+// A factorisation (or a non-finite step) failed at damping s.mu: DoglegStrategy::ComputeGaussNewtonStep raises mu tenfold and
+// tries again; once mu has left [min_mu, max_mu) the iteration is an invalid step (TrustRegionMinimizer: StepIsInvalid).
+// `tried`: a solve at s.mu was attempted (false: mu had already left the range).  Returns through s.phase: 3 = same
+// iteration, solve again next round; 0 = the iteration ended as invalid.
+DEV void big_solve_failed(Ctl& s, const BaLayout& L, double* out, int* iout, int tid, bool tried) {
+    if (tried) {
+        s.mu *= 10.0;
+        if (s.mu < 1.0) { s.phase = 3; return; }
+    }
+    const int slot = s.it - 1;
+    if (tid == 0) {
+        out[L.oo_trace + 0 * VG_MAX_ITERS + slot] = s.cost;
+        out[L.oo_trace + 3 * VG_MAX_ITERS + slot] = s.radius;
+        out[L.oo_trace + 1 * VG_MAX_ITERS + slot] = 0.0;
+        out[L.oo_trace + 2 * VG_MAX_ITERS + slot] = 0.0;
+        out[L.oo_trace + 4 * VG_MAX_ITERS + slot] = 0.0;
+        iout[4 + slot] = 0;
+    }
+    ++s.ninv;
+    if (s.ninv >= 5) s.term = VG_TERM_FAILURE;
+    s.mu *= 10.0;
+    s.reuse = 0;
+    s.phase = 0;
+}
+
+// 1 workgroup / window, BA_NT threads, LDS: S (packed, rhs row), reduction scratch, 1/L_jj.
+extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    const int w = blockIdx.x;
+    ctx_init(c, Lp, P, w);
+    double* ctlp = c.sc + L.so_ctl;
+    Ctl s;
+    ctl_load(s, ctlp);
+    if (s.done) return;
+    SolveLds m;
+    big_carve(L, c.sc, m);
+    const int max_iters = c.hdr[H_MAXIT];
+    const int R = L.R, Rc = L.Rc, nL = c.nL;
+    double* out = P.out + (size_t)w * L.ostride;
+    int* iout = P.iout + (size_t)w * L.oi_stride;
+    const double* rb1 = P.rb1 + (size_t)w * L.rb1_len;
+    const double* scal = rb1 + L.rb1_scal;
+    double* rb2 = P.rb2 + (size_t)w * RB2_LEN;
+    double* vG = m.vec + V_G * L.Rpad;
+    double* vSC = m.vec + V_SC * L.Rpad;
+    double* vDG = m.vec + V_DG * L.Rpad;
+    double* vGT = m.vec + V_GT * L.Rpad;
+    double* vGN = m.vec + V_GN * L.Rpad;
+    double* vU = m.vec + V_U * L.Rpad;
+    double* vY = m.vec + V_Y * L.Rpad;
+    double* vT = m.vec + V_T * L.Rpad;
+    const double* sl = c.sc + L.so_sl;
+    double* gnl = c.sc + L.so_gn + L.Rpad;
+    double* yl = c.sc + L.so_yl;
+    if (c.nprior) {
+        const int* kind = c.ia + L.io_pb_kind;
+        const int* off = c.ia + L.io_pb_off;
+        const int* pcol = c.ia + L.io_pb_col;
+        for (int blk = c.tid; blk < c.nblk; blk += BA_NT) {
+            const int sz = (kind[blk] == VG_BLK_SPEEDBIAS) ? 9 : (kind[blk] == VG_BLK_TD ? 1 : 6);
+            for (int k = 0; k < sz; ++k) m.pmap[off[blk] + k] = pcol[blk] >= 0 ? pcol[blk] + k : -1;
+        }
+    }
+    __syncthreads();
+    const int phase_in = s.phase;
+    s.phase = 0;
+    // cost of the point the linearisation kernels just evaluated: projection factors of all ranks + this rank's copy of the
+    // (replicated) IMU / prior factors
+    const double cs = scal[RB1_COST] + c.sc[L.so_part + L.nbf];
+    bool fresh_point = false;
+    if (s.pending) {
+        s.step_norm = sqrt(s.step2c + scal[RB1_STEP2]);
+        s.x_norm_c = sqrt(s.xn2c + scal[RB1_LAM2]);
+        const bool acc = judge_candidate(s, cs, L, out, iout, c.tid);
+        if (acc) {
+            if (!(s.cost == s.cost)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
+            fresh_point = true;
+        }
+    } else if (!s.scaled) {
+        s.cost = 0.5 * cs;
+        s.init_cost = s.cost;
+        const double xc2 = block_sum(m.red, BA_NW, c.lane, c.wave, state_sqnorm_share(L, c.sc + L.so_x + s.cur * L.nst, nullptr, 0, c.tid, BA_NT));
+        s.x_norm = sqrt(xc2 + scal[RB1_LAM2]);
+        if (!(s.cost == s.cost) || !(s.cost < 1e300)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
+        fresh_point = true;
+    }
+    const double* buf = lin_buf(c, s.cur);
+    const double* hh = buf + L.bo_h;
+    const double* bb = buf + L.bo_b;
+    const bool running = s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK;
+    const bool trip = running && (phase_in == 3 || s.it < max_iters);
+    const bool need_system = running && (fresh_point || (trip && !s.reuse));
+    if (need_system) {
+        const int ntri = Rc * (Rc + 1) / 2;
+        assemble(c, m, buf, rb1, rb1 + ntri);
+        if (!s.scaled) {
+            for (int k = c.tid; k < R; k += BA_NT) c.sc[L.so_sc + k] = 1.0 / (1.0 + sqrt(hess_diag(L, m, k)));
+            s.scaled = 1;
+            __syncthreads();
+        }
+        if (fresh_point) {
+            double mx = 0.0;
+            for (int k = c.tid; k < R; k += BA_NT) mx = fmax(mx, fabs(vG[k]));
+            if (block_max(m.red, BA_NW, c.lane, c.wave, mx) <= 1e-10 && scal[RB1_NBIG] == 0.0) s.term = VG_TERM_CONVERGENCE;
+        }
+    }
+    for (int k = c.tid; k < R; k += BA_NT) vSC[k] = c.sc[L.so_sc + k];
+    __syncthreads();
+    if (trip && s.term == VG_TERM_NO_CONVERGENCE) {
+        if (phase_in != 3) ++s.it;
+        if (s.reuse) s.phase = 2;
+        else if (!(s.mu < 1.0)) big_solve_failed(s, L, out, iout, c.tid, false);
+        else {
+            const double* dgl = c.sc + L.so_dgl + s.cur * L.Lcap;
+            const double* gtl = c.sc + L.so_gtl + s.cur * L.Lcap;
+            for (int k = c.tid; k < R; k += BA_NT) {
+                double d2 = vSC[k] * vSC[k] * hess_diag(L, m, k);
+                d2 = d2 < 1e-6 ? 1e-6 : d2;
+                d2 = 1e32 < d2 ? 1e32 : d2;
+                const double d = sqrt(d2);
+                vDG[k] = d;
+                vGT[k] = vSC[k] * vG[k] / d;
+                vT[k] = vGT[k] / d;
+            }
+            __syncthreads();
+            {
+                double sq = 0.0;
+                for (int k = c.tid; k < R; k += BA_NT) sq += vGT[k] * vGT[k];
+                s.gtn2 = block_sum(m.red, BA_NW, c.lane, c.wave, sq) + scal[RB1_GTL2];
+            }
+            const double q = build_scaled(c, m, s.mu);
+            __syncthreads();
+            bool cok = chain_eliminate(c, m);
+            schur_chain_big(c, m, rb1 + L.rb1_T);
+            s.qcam = block_sum(m.red, BA_NW, c.lane, c.wave, q);
+            if (cok) cok = cholesky_aug(c, m, Rc);
+            if (cok) {
+                back_substitute_n<4>(c, m, Rc);
+                chain_back_substitute(c, m);
+                double fin = 0.0, s1 = 0.0, s2 = 0.0;
+                for (int k = c.tid; k < R; k += BA_NT) {
+                    fin += (vY[k] == vY[k] && fabs(vY[k]) < 1e300) ? 0.0 : 1.0;
+                    vGN[k] = -vY[k] * vDG[k];
+                    s1 += vGN[k] * vGN[k];
+                    s2 += vGN[k] * vGT[k];
+                }
+                // this rank's landmarks: y_l = (bt_l - wt_l . y_cam) / ht_l, and their share of the Cauchy-point term
+                // sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ],  t = gt / Dg
+                for (int k = c.tid; k < Rc; k += BA_NT) { vU[k] = vSC[k] * vY[k]; vT[k] = vSC[k] * vT[k]; }
+                __syncthreads();
+                const double* Wt = buf + L.bo_Wt;
+                double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+                for (int l = c.tid; l < nL; l += BA_NT) {
+                    const double ht = sl[l] * sl[l] * hh[l] + s.mu * dgl[l] * dgl[l];
+                    double acc = 0.0, wdot = 0.0;
+                    for (int k = 0; k < Rc; ++k) {
+                        const double wv = Wt[(size_t)k * L.Lcap + l];
+                        acc += wv * vU[k];
+                        wdot += wv * vT[k];
+                    }
+                    const double y = (sl[l] * bb[l] - sl[l] * acc) / ht;
+                    yl[l] = y;
+                    fin += (y == y && fabs(y) < 1e300) ? 0.0 : 1.0;
+                    const double g = -y * dgl[l];
+                    gnl[l] = g;
+                    p0 += g * g;
+                    p1 += g * gtl[l];
+                    const double tl = gtl[l] / dgl[l];
+                    p2 += sl[l] * sl[l] * hh[l] * tl * tl + 2.0 * tl * sl[l] * wdot;
+                }
+                block_sum2(m.red, BA_NW, c.lane, c.wave, s1, s2);
+                block_sum2(m.red, BA_NW, c.lane, c.wave, p0, p1);
+                block_sum2(m.red, BA_NW, c.lane, c.wave, p2, fin);
+                if (c.tid == 0) {
+                    rb2[RB2_GNN2] = p0; rb2[RB2_GTGN] = p1; rb2[RB2_QL] = p2; rb2[RB2_NONFIN] = fin;
+                    rb2[4] = 0.0; rb2[5] = 0.0; rb2[6] = 0.0; rb2[7] = 0.0;
+                }
+                s.gnn2c = s1; s.gtgnc = s2;
+                s.mu_solved = s.mu;
+                s.reuse = 1;
+                s.phase = 1;
+                for (int k = c.tid; k < R; k += BA_NT) {
+                    c.sc[L.so_dg + k] = vDG[k]; c.sc[L.so_gt + k] = vGT[k]; c.sc[L.so_gn + k] = vGN[k];
+                }
+            } else {
+                big_solve_failed(s, L, out, iout, c.tid, true);
+            }
+        }
+    }
+    if (s.term != VG_TERM_NO_CONVERGENCE || s.status != VG_OK || (s.phase == 0 && s.it >= max_iters)) s.done = 1;
+    __syncthreads();
+    if (c.tid == 0) ctl_store(s, ctlp);
+}
+
+// Dogleg step, model cost change and the candidate state from the completed norms (after all-reduce 2).  1 workgroup per
+// window, no dynamic LDS.
+extern "C" __global__ __launch_bounds__(BA_NT) void ba_big_step_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    const int w = blockIdx.x;
+    ctx_init(c, Lp, P, w);
+    double* ctlp = c.sc + L.so_ctl;
+    Ctl s;
+    ctl_load(s, ctlp);
+    if (s.done || s.phase == 0 || s.phase == 3) return;
+    __shared__ double red[32];
+    const int max_iters = c.hdr[H_MAXIT];
+    const int R = L.R, nL = c.nL;
+    double* out = P.out + (size_t)w * L.ostride;
+    int* iout = P.iout + (size_t)w * L.oi_stride;
+    const double* rb2 = P.rb2 + (size_t)w * RB2_LEN;
+    double* vec = c.sc + L.so_bigm + L.l_vec;
+    const double* vSC = vec + V_SC * L.Rpad;
+    double* vU = vec + V_U * L.Rpad;
+    const double* vDG = c.sc + L.so_dg;
+    const double* vGT = c.sc + L.so_gt;
+    const double* vGN = c.sc + L.so_gn;
+    const double* sl = c.sc + L.so_sl;
+    const double* dgl = c.sc + L.so_dgl + s.cur * L.Lcap;
+    const double* gtl = c.sc + L.so_gtl + s.cur * L.Lcap;
+    const double* gnl = c.sc + L.so_gn + L.Rpad;
+    const int slot = s.it - 1;
+    if (s.phase == 1) {
+        if (rb2[RB2_NONFIN] != 0.0) {
+            big_solve_failed(s, L, out, iout, c.tid, true);
+            if (s.term != VG_TERM_NO_CONVERGENCE || (s.phase == 0 && s.it >= max_iters)) s.done = 1;
+            __syncthreads();
+            if (c.tid == 0) ctl_store(s, ctlp);
+            return;
+        }
+        s.gnn2 = s.gnn2c + rb2[RB2_GNN2];
+        s.gtgn = s.gtgnc + rb2[RB2_GTGN];
+        s.alpha = s.gtn2 / (s.qcam + rb2[RB2_QL]);
+    }
+    s.phase = 0;
+    // DoglegStrategy::ComputeTraditionalDoglegStep (same arithmetic as ba_solve_kernel)
+    double c_gt, c_gn;
+    const double gtn = sqrt(s.gtn2), gnn = sqrt(s.gnn2);
+    if (gnn <= s.radius) { c_gt = 0.0; c_gn = 1.0; s.dnorm = gnn; }
+    else if (gtn * s.alpha >= s.radius) { c_gt = -(s.radius / gtn); c_gn = 0.0; s.dnorm = s.radius; }
+    else {
+        const double b_dot_a = -s.alpha * s.gtgn;
+        const double a_sq = (s.alpha * gtn) * (s.alpha * gtn);
+        const double bma_sq = a_sq - 2 * b_dot_a + s.gnn2;
+        const double cc = b_dot_a - a_sq;
+        const double dd = sqrt(cc * cc + bma_sq * (s.radius * s.radius - a_sq));
+        const double beta = (cc <= 0) ? (dd - cc) / bma_sq : (s.radius * s.radius - a_sq) / (dd + cc);
+        c_gt = -s.alpha * (1.0 - beta); c_gn = beta;
+        s.dnorm = sqrt(c_gt * c_gt * s.gtn2 + 2 * c_gt * c_gn * s.gtgn + c_gn * c_gn * s.gnn2);
+    }
+    const double q11 = c_gt != 0.0 ? s.gtn2 / s.alpha : 0.0;
+    const double q12 = -s.gtn2 - s.mu_solved * s.gtgn;
+    const double q22 = -s.gtgn - s.mu_solved * s.gnn2;
+    const double model_change = -(c_gt * s.gtn2 + c_gn * s.gtgn) - 0.5 * (c_gt * c_gt * q11 + 2.0 * c_gt * c_gn * q12 + c_gn * c_gn * q22);
+    if (c.tid == 0) {
+        out[L.oo_trace + 0 * VG_MAX_ITERS + slot] = s.cost;
+        out[L.oo_trace + 3 * VG_MAX_ITERS + slot] = s.radius;
+    }
+    if (!(model_change > 0.0)) {
+        if (c.tid == 0) {
+            out[L.oo_trace + 1 * VG_MAX_ITERS + slot] = 0.0;
+            out[L.oo_trace + 2 * VG_MAX_ITERS + slot] = model_change;
+            out[L.oo_trace + 4 * VG_MAX_ITERS + slot] = 0.0;
+            iout[4 + slot] = 0;
+        }
+        ++s.ninv;
+        if (s.ninv >= 5) s.term = VG_TERM_FAILURE;
+        s.mu *= 10.0;
+        s.reuse = 0;
+        if (s.term != VG_TERM_NO_CONVERGENCE || s.it >= max_iters) s.done = 1;
+        __syncthreads();
+        if (c.tid == 0) ctl_store(s, ctlp);
+        return;
+    }
+    s.ninv = 0;
+    s.model = model_change;
+    const double* x = c.sc + L.so_x + s.cur * L.nst;
+    const double* lam = c.sc + L.so_lam + s.cur * L.Lcap;
+    double* xc = c.sc + L.so_x + (s.cur ^ 1) * L.nst;
+    double* lamc = c.sc + L.so_lam + (s.cur ^ 1) * L.Lcap;
+    for (int k = c.tid; k < R; k += BA_NT) vU[k] = vSC[k] * ((c_gt * vGT[k] + c_gn * vGN[k]) / vDG[k]);
+    __syncthreads();
+    for (int i = c.tid; i < L.Kp; i += BA_NT) pose_plus(x + 7 * i, vU + col_pose(L, i), xc + 7 * i);
+    for (int k = c.tid; k < 9 * L.K; k += BA_NT) xc[7 * L.Kp + k] = x[7 * L.Kp + k] + vU[col_sb(L, k / 9) + k % 9];
+    if (c.tid == 0) {
+        double* exc = xc + 7 * L.Kp + 9 * L.K;
+        const double* exx = x + 7 * L.Kp + 9 * L.K;
+        if (L.e) pose_plus(exx, vU + col_ex(L), exc);
+        else for (int k = 0; k < 7; ++k) exc[k] = exx[k];
+        exc[7] = L.t ? exx[7] + vU[col_td(L)] : exx[7];
+    }
+    for (int k = c.tid; k < nL; k += BA_NT) lamc[k] = lam[k] + sl[k] * ((c_gt * gtl[k] + c_gn * gnl[k]) / dgl[k]);
+    __syncthreads();
+    {
+        double sd = 0.0;
+        const int nx = 7 * L.Kp + 9 * L.K + (L.e ? 7 : 0);
+        for (int k = c.tid; k < nx; k += BA_NT) { const double d = x[k] - xc[k]; sd += d * d; }
+        if (L.t && c.tid == 0) { const double d = x[7 * L.Kp + 9 * L.K + 7] - xc[7 * L.Kp + 9 * L.K + 7]; sd += d * d; }
+        double sn = state_sqnorm_share(L, xc, nullptr, 0, c.tid, BA_NT);
+        block_sum2(red, BA_NW, c.lane, c.wave, sd, sn);
+        s.step2c = sd;                              // camera / speed-bias shares; the landmark shares are formed by the
+        s.xn2c = sn;                                // next Schur kernel and rank-summed with reduce buffer 1
+    }
+    if (c.tid == 0) {
+        out[L.oo_trace + 2 * VG_MAX_ITERS + slot] = model_change;
+        out[L.oo_trace + 4 * VG_MAX_ITERS + slot] = s.dnorm;
+    }
+    s.pending = 1;
+    __syncthreads();
+    if (c.tid == 0) ctl_store(s, ctlp);
+}
+
+// ================================================================================================
 // Final kernel: judge the last candidate, then Estimator::double2vector() (estimator.cpp:530-577: yaw / position gauge
 // fix) + the vector2double() repack (:486-528) into the output slab.
 // ================================================================================================
@@ -1732,7 +2266,17 @@ extern "C" __global__ __launch_bounds__(256) void ba_final_kernel(const BaLayout
     Ctl s;
     ctl_load(s, ctlp);
     if (s.pending) {
-        const bool acc = judge_candidate(s, c.sc + L.so_part, L.nbl, L, out, iout, c.tid);
+        double cs;
+        if (L.big) {
+            // large-window path: projection cost and landmark norms of all ranks through reduce buffer 1 (ba_big_schur_kernel)
+            const double* scal = P.rb1 + (size_t)w * L.rb1_len + L.rb1_scal;
+            cs = scal[RB1_COST] + c.sc[L.so_part + L.nbf];
+            s.step_norm = sqrt(s.step2c + scal[RB1_STEP2]);
+            s.x_norm_c = sqrt(s.xn2c + scal[RB1_LAM2]);
+        } else {
+            cs = sum_partials(c.sc + L.so_part, L.nbl);
+        }
+        const bool acc = judge_candidate(s, cs, L, out, iout, c.tid);
         if (acc && !(s.cost == s.cost)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
     }
     const double* x = c.sc + L.so_x + s.cur * L.nst;
@@ -1849,6 +2393,7 @@ static hipError_t set_lds_attrs() {
     static bool done = false;
     if (done) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // (these two also hold a few statically allocated LDS words: static + dynamic must stay within 160 KB)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linearize_imu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -1909,6 +2454,45 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
     LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P);
     if (kinds) kinds[nk++] = 4;
     if (n_launches) *n_launches = nk;
+    return hipSuccess;
+}
+
+// Launch sequence of the large-window path.  `allreduce` (may be nullptr: single rank) is called twice per round between
+// launches with a device buffer that has to be summed over the ranks IN PLACE, stream-ordered on `stream` (RCCL:
+// ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, stream)); a non-zero return aborts the sequence.
+// `rounds` = max_iters + slack: a failed factorisation retries its iteration in the next round (see above).
+typedef int (*BaAllReduce)(void* user, double* buf, size_t count, void* stream);
+extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
+                                          BaAllReduce allreduce, void* user, int* hook_rc) {
+    hipError_t e = set_lds_attrs();
+    if (e != hipSuccess) { g_failed_launch = "hipFuncSetAttribute"; return e; }
+    hipEvent_t* ev = nullptr;
+    int nev = 0;
+    (void)nev;
+    if (hook_rc) *hook_rc = 0;
+    const size_t n1 = (size_t)L.nwin * L.rb1_len, n2 = (size_t)L.nwin * RB2_LEN;
+#define REDUCE(buf, n)                                                                   \
+    do {                                                                                 \
+        if (allreduce) {                                                                 \
+            const int _rc = allreduce(user, buf, n, (void*)stream);                      \
+            if (_rc) { if (hook_rc) *hook_rc = _rc; g_failed_launch = "all-reduce hook"; return hipErrorInvalidValue; } \
+        }                                                                                \
+    } while (0)
+    LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P);
+    for (int r = 0; r <= rounds; ++r) {
+        const int cost_only = r == rounds ? 1 : 0;
+        LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only);
+        LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only);
+        if (!cost_only) LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P);
+        LAUNCH(ba_big_schur_kernel, dim3(L.nts + 1, L.nwin), dim3(256), 0, dL, P, cost_only);
+        REDUCE(P.rb1, n1);
+        if (cost_only) break;
+        LAUNCH(ba_solve_big_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P);
+        REDUCE(P.rb2, n2);
+        LAUNCH(ba_big_step_kernel, dim3(L.nwin), dim3(BA_NT), 0, dL, P);
+    }
+    LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P);
+#undef REDUCE
     return hipSuccess;
 }
 

@@ -27,8 +27,8 @@ struct PinnedBuf {
 struct BaBatch {
     BaLayout L;
     BaLayout* dL = nullptr;          // device copy of L (kernels read it through scalar loads)
-    BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t cap_ia = 0, cap_di = 0, cap_sc = 0, cap_out = 0, cap_iout = 0, cap_mout = 0, cap_miout = 0, cap_mscr = 0;
+    BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap_ia = 0, cap_di = 0, cap_sc = 0, cap_out = 0, cap_iout = 0, cap_mout = 0, cap_miout = 0, cap_mscr = 0, cap_rb1 = 0, cap_rb2 = 0;
     std::vector<int> margin, nL;
     PinnedBuf<int> h_iout, h_miout;  // download staging
     PinnedBuf<double> h_out, h_mout;
@@ -38,6 +38,9 @@ struct BaBatch {
     int nwin = 0;
     int rounds = 0;                  // launches of the linearise / accumulate / solve triple = max over windows of max_iters
     bool uploaded = false, any_margin = false;
+    bool force_large = false;        // vg_ba_set_large_window: take the large-window path whatever the size
+    void* allreduce = nullptr;       // vg_allreduce_fn of the large-window path (nullptr: single rank)
+    void* allreduce_user = nullptr;
     double flops = 0, flops_marg = 0, bytes_in = 0, bytes_out = 0;
     double flops_k[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic flops per kernel class (VG_BA_KERNEL_*), one run of the batch
 };
