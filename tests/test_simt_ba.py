@@ -49,3 +49,33 @@ def test_emulated_solve_with_extrinsic_and_td(simt_handle, ex, td):
     """The blocks among the extrinsic pose and td have a workgroup of their own in the accumulation kernel."""
     seq = synth.SyntheticSequence(70 + 2 * ex + td, n_frames=6, K=5, L=20, estimate_extrinsic=ex, estimate_td=td)
     _check_solve(simt_handle, seq.window(0))
+
+
+# ---- large-window path (ba_big_schur_kernel / ba_solve_big_kernel / ba_big_step_kernel), forced on small windows ---------
+@pytest.fixture()
+def simt_large(simt_handle):
+    simt_handle.ba_set_large_window(True)
+    yield simt_handle
+    simt_handle.ba_set_large_window(False)
+
+
+def test_emulated_large_window_path_matches_oracle(simt_large):
+    _check_solve(simt_large, synth.SyntheticSequence(3, L=30).window(0))
+
+
+@pytest.mark.parametrize("name", ["overflowing_landmark", "far_origin"])
+def test_emulated_large_window_path_trust_region_branches(simt_large, name):
+    """Failed factorisations (retried in the next round with mu x 10), invalid steps, FAILURE after five of them, an
+    interpolated dogleg step and the parameter-tolerance exit: the state machine spread over the launches of the large path
+    (rejected steps: tests/test_sharded_window_cpu.py)."""
+    build, need = FX.BRANCH_FIXTURES[name]
+    prob = build()
+    _, _, summ = _check_solve(simt_large, prob, rtol_cost=FX.COST_RTOL.get(name, 1e-6))
+    assert need <= FX.trace_features(summ)
+
+
+def test_emulated_large_window_path_with_relocalisation_extrinsic_td(simt_large):
+    seq = synth.SyntheticSequence(23, n_frames=13, K=12, L=24)
+    _check_solve(simt_large, seq.window(0))
+    seq = synth.SyntheticSequence(73, n_frames=6, K=5, L=20, estimate_extrinsic=1, estimate_td=1)
+    _check_solve(simt_large, seq.window(0))
