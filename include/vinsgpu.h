@@ -203,7 +203,9 @@ int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* out_states,
 /* one synchronous run with a HIP event after every launch of the solve pipeline: ms[k] = summed duration and n[k] =
  * number of launches of kernel class k (both arrays VG_BA_KERNEL_COUNT long) */
 enum { VG_BA_KERNEL_PROLOGUE = 0, VG_BA_KERNEL_LINEARIZE, VG_BA_KERNEL_ACCUMULATE, VG_BA_KERNEL_SOLVE, VG_BA_KERNEL_FINAL,
-       VG_BA_KERNEL_MARG, VG_BA_KERNEL_COUNT };
+       VG_BA_KERNEL_MARG,
+       /* large-window path: landmark Schur kernel; reduced solve (+ the preceding all-reduce); dogleg step (+ its all-reduce) */
+       VG_BA_KERNEL_BIG_SCHUR, VG_BA_KERNEL_BIG_SOLVE, VG_BA_KERNEL_BIG_STEP, VG_BA_KERNEL_COUNT };
 int vg_ba_batch_run_profiled(vg_handle* h, float* ms, int* n);
 /* the SURVEY.md 8(d) flop model of one run of the uploaded batch, split per kernel class (VG_BA_KERNEL_COUNT doubles) */
 int vg_ba_batch_flops_by_kernel(vg_handle* h, double* flops);

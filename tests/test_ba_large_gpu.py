@@ -1,0 +1,120 @@
+"""Large-window path on the GPU (BASELINE configs[4]): forced on the ordinary fixtures it must agree
+with the NumPy oracle exactly like the single-workgroup pipeline does (tests/test_ba_gpu.py::_check_solve: iteration
+trace, flags, termination, gauge-fixed states); at the enlarged size (31 frames x 2000 landmarks, where only the
+C++ restatement oracle/ba_cpu.cpp is fast enough) states within 1e-4 and the same accept / reject trace."""
+import numpy as np
+import pytest
+
+from oracle import ba_cpu, ba_numpy as B
+from vins_mono_amd import ba, synth
+
+import ba_fixtures as FX
+from test_ba_gpu import _check_solve
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def large(handle):
+    handle.ba_set_large_window(True)
+    yield handle
+    handle.ba_set_large_window(False)
+
+
+@pytest.mark.parametrize("seed", [1, 4, 9])
+def test_forced_large_path_matches_oracle(large, seed):
+    _check_solve(large, synth.SyntheticSequence(seed).window(0))
+
+
+@pytest.mark.parametrize("name", sorted(FX.BRANCH_FIXTURES))
+def test_forced_large_path_trust_region_branches(large, name):
+    build, need = FX.BRANCH_FIXTURES[name]
+    _, _, summ = _check_solve(large, build(), rtol_cost=FX.COST_RTOL.get(name, 1e-6))
+    assert need <= FX.trace_features(summ)
+
+
+def test_forced_large_path_with_prior_relocalisation_extrinsic_td(large, handle):
+    seq = synth.SyntheticSequence(31, estimate_extrinsic=1, estimate_td=1)
+    p0 = seq.window(0)
+    handle.ba_set_large_window(False)
+    st, sm, pr = handle.ba_optimize(p0, ba.VG_MARGIN_OLD)          # a real marginalization prior from the ordinary path
+    handle.ba_set_large_window(True)
+    _check_solve(large, seq.next_window(st, pr, 1))
+    _check_solve(large, synth.SyntheticSequence(23, n_frames=13, K=12, L=60).window(0))
+
+
+def test_large_path_refuses_marginalization(large):
+    with pytest.raises(RuntimeError, match="large-window"):
+        large.ba_optimize(synth.SyntheticSequence(2, L=20).window(0), ba.VG_MARGIN_OLD)
+
+
+def _vs_cpp_oracle(h, prob, rtol_state=1e-4):
+    st_o, sm_o, _ = ba_cpu.optimize(prob, margin_flag=ba.VG_MARGIN_NONE)
+    st, sm, _ = h.ba_optimize(prob)
+    assert sm['status'] == 0 and sm_o['status'] == 0
+    n = sm_o['num_iterations']
+    assert sm['num_iterations'] == n and sm['termination'] == sm_o['termination']
+    assert list(sm['it_flags'][:n]) == list(sm_o['it_flags'][:n])
+    assert np.isclose(sm['initial_cost'], sm_o['initial_cost'], rtol=1e-9)
+    np.testing.assert_allclose(sm['it_cost'][:n], sm_o['it_cost'][:n], rtol=1e-6)
+    np.testing.assert_allclose(sm['it_radius'][:n], sm_o['it_radius'][:n], rtol=1e-6)
+    assert np.isclose(sm['final_cost'], sm_o['final_cost'], rtol=1e-6)
+    scale_p = max(1.0, np.abs(st_o['pose'][:, :3]).max())
+    assert np.abs(st['pose'][:, :3] - st_o['pose'][:, :3]).max() < rtol_state * scale_p
+    assert np.abs(st['pose'][:, 3:] - st_o['pose'][:, 3:]).max() < rtol_state
+    assert np.abs(st['sb'] - st_o['sb']).max() < rtol_state * max(1.0, np.abs(st_o['sb']).max())
+    assert np.allclose(st['inv_depth'], st_o['inv_depth'], rtol=1e-4, atol=1e-6)
+    return st, sm
+
+
+@pytest.mark.parametrize("ex,td", [(0, 0), (1, 1)])
+def test_enlarged_window_31_frames_2000_landmarks(handle, ex, td):
+    """BASELINE configs[4] at full size: K = 31 (WINDOW_SIZE 30), 2000 landmarks, ~16K projection factors, 30 IMU factors,
+    prior on the oldest frame; Rc = 186 / 193 -> the large-window path is taken automatically."""
+    seq = synth.SyntheticSequence(5 + ex, n_frames=32, K=31, L=2000, estimate_extrinsic=ex, estimate_td=td)
+    prob = synth.SyntheticSequence.anchor_prior(seq.window(0))
+    st, sm = _vs_cpp_oracle(handle, prob)
+    assert sm['num_accepted'] >= 3
+    # a second solve from the optimum stays there (idempotence at full size)
+    again = dict(prob, pose=st['pose'], sb=st['sb'], ex=st['ex'], td=float(st['td']), inv_depth=st['inv_depth'])
+    st2, sm2, _ = handle.ba_optimize(again)
+    assert sm2['final_cost'] <= sm['final_cost'] * (1 + 1e-9)
+
+
+def test_enlarged_window_without_prior(handle):
+    seq = synth.SyntheticSequence(8, n_frames=32, K=31, L=2000)
+    _vs_cpp_oracle(handle, seq.window(0))
+
+
+def test_allreduce_hook_over_rccl_single_rank(handle):
+    """The hook path end to end on one GPU: torch.distributed 'nccl' (= RCCL) world of ONE rank, the device buffers of
+    the library wrapped zero-copy (__cuda_array_interface__), the collective enqueued on the library's HIP stream.  Summing
+    over one rank must not change a bit of the result."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from vins_mono_amd import shard
+    prob = synth.SyntheticSequence.anchor_prior(synth.SyntheticSequence(5, n_frames=17, K=16, L=300).window(0))
+    st0, sm0, _ = handle.ba_optimize(prob)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29551")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    calls = []
+    inner = shard.torch_allreduce_hook()
+
+    def hook(ptr, count, stream):
+        calls.append(count)
+        inner(ptr, count, stream)
+    try:
+        handle.ba_set_allreduce(hook)
+        st1, sm1, _ = handle.ba_optimize(prob)
+        c1, c2 = handle.ba_reduce_layout()
+    finally:
+        handle.ba_set_allreduce(None)
+        if created:
+            dist.destroy_process_group()
+    assert sm1['status'] == 0 and set(calls) == {c1, c2} and len(calls) >= 2 * sm1['num_iterations']
+    assert np.array_equal(st0['pose'], st1['pose']) and np.array_equal(st0['inv_depth'], st1['inv_depth'])
+    assert list(sm0['it_cost']) == list(sm1['it_cost'])

@@ -79,3 +79,19 @@ def test_emulated_large_window_path_with_relocalisation_extrinsic_td(simt_large)
     _check_solve(simt_large, seq.window(0))
     seq = synth.SyntheticSequence(73, n_frames=6, K=5, L=20, estimate_extrinsic=1, estimate_td=1)
     _check_solve(simt_large, seq.window(0))
+
+
+def test_emulated_enlarged_window_31_frames(simt_handle):
+    """K = 31 (WINDOW_SIZE 30): Rc = 186 -> twelve 16-column tiles, S fills 140 KB of LDS, IMU factors in two passes; few
+    landmarks so that the emulator finishes in seconds (the full 2000-landmark window: tests/test_ba_large_gpu.py)."""
+    from oracle import ba_cpu
+    seq = synth.SyntheticSequence(5, n_frames=32, K=31, L=48)
+    prob = synth.SyntheticSequence.anchor_prior(seq.window(0))
+    st_o, sm_o, _ = ba_cpu.optimize(prob, margin_flag=ba.VG_MARGIN_NONE)
+    st, sm, _ = simt_handle.ba_optimize(prob)
+    n = sm_o['num_iterations']
+    assert sm['status'] == 0 and sm['num_iterations'] == n and list(sm['it_flags'][:n]) == list(sm_o['it_flags'][:n])
+    np.testing.assert_allclose(sm['it_cost'][:n], sm_o['it_cost'][:n], rtol=1e-6)
+    assert np.abs(st['pose'] - st_o['pose']).max() < 1e-4 * max(1.0, np.abs(st_o['pose'][:, :3]).max())
+    assert np.abs(st['sb'] - st_o['sb']).max() < 1e-4 * max(1.0, np.abs(st_o['sb']).max())
+    assert np.allclose(st['inv_depth'], st_o['inv_depth'], rtol=1e-4, atol=1e-6)

@@ -270,12 +270,12 @@ class Handle:
         return float(a.value), float(b.value)
 
     KERNEL_CLASSES = ("ba_prologue_kernel", "ba_linearize_imu_kernel+ba_linearize_proj_kernel", "ba_accumulate_kernel", "ba_solve_kernel",
-                      "ba_final_kernel", "ba_marg_kernel")
+                      "ba_final_kernel", "ba_marg_kernel", "ba_big_schur_kernel", "ba_solve_big_kernel", "ba_big_step_kernel")
 
     def ba_run_profiled(self):
         """Synchronous run with a HIP event after every launch: {kernel: (summed ms, launches)}."""
-        ms = (C.c_float * 6)()
-        n = (C.c_int * 6)()
+        ms = (C.c_float * len(self.KERNEL_CLASSES))()
+        n = (C.c_int * len(self.KERNEL_CLASSES))()
         self._chk(self.lib.vg_ba_batch_run_profiled(self.h, ms, n), "vg_ba_batch_run_profiled")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
 
@@ -284,7 +284,7 @@ class Handle:
         self._chk(self.lib.vg_ba_batch_info(self.h, C.byref(fl), C.byref(bi), C.byref(bo), C.byref(lds)), "vg_ba_batch_info")
         fs, fm = C.c_double(), C.c_double()
         self._chk(self.lib.vg_ba_batch_flops(self.h, C.byref(fs), C.byref(fm)), "vg_ba_batch_flops")
-        fk = (C.c_double * 6)()
+        fk = (C.c_double * len(self.KERNEL_CLASSES))()
         self._chk(self.lib.vg_ba_batch_flops_by_kernel(self.h, fk), "vg_ba_batch_flops_by_kernel")
         return dict(flops=fl.value, flops_solve=fs.value, flops_marg=fm.value, bytes_in=bi.value, bytes_out=bo.value,
                     lds_bytes=lds.value, flops_by_kernel={k: float(fk[i]) for i, k in enumerate(self.KERNEL_CLASSES)})

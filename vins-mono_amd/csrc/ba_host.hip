@@ -23,7 +23,7 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
                                       hipEvent_t* ev, int* kinds, int* n_launches, const BaFork* fk);
 typedef int (*BaAllReduce)(void* user, double* buf, size_t count, void* stream);
 extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
-                                          BaAllReduce allreduce, void* user, int* hook_rc);
+                                          BaAllReduce allreduce, void* user, int* hook_rc, hipEvent_t* ev, int* kinds, int* n_launches);
 extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, double* proj_r, double* proj_J,
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream);
 extern "C" const char* ba_failed_launch();
@@ -498,7 +498,14 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
         const double f_acc = it * (F * 416);                                                       // J^T J / J^T r of the projection factors
         const double f_sol = it * (schur + R * R * R / 3 + 2 * R * R + 12 * sumn);                  // Schur complement, Cholesky, back substitution
         const double f_pro = 2 * np * np * np;                                                     // prior J0^T J0
-        B.flops_k[0] += f_pro; B.flops_k[1] += f_lin; B.flops_k[2] += f_acc; B.flops_k[3] += f_sol;
+        B.flops_k[0] += f_pro; B.flops_k[1] += f_lin; B.flops_k[2] += f_acc;
+        if (L.big) {
+            // large-window path: the landmark Schur complement has a kernel of its own
+            B.flops_k[VG_BA_KERNEL_BIG_SCHUR] += it * schur;
+            B.flops_k[VG_BA_KERNEL_BIG_SOLVE] += f_sol - it * schur;
+        } else {
+            B.flops_k[3] += f_sol;
+        }
         double fl = f_lin + f_acc + f_sol + f_pro;
         if (mf == VG_MARGIN_OLD) {
             double m = 15;
@@ -542,18 +549,19 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
 }
 
 // all launches of one batch solve on h->stream (single-workgroup pipeline or the large-window path with its all-reduce hook)
-static int launch_solve(vg_handle* h) {
+#define BA_BIG_SLACK 8     // extra rounds of the large-window path: one round per attempted factorisation (mu escalations)
+static int launch_solve(vg_handle* h, hipEvent_t* ev = nullptr, int* kinds = nullptr, int* n_launches = nullptr) {
     BaBatch& B = h->ba;
     hipError_t e;
     if (B.L.big) {
-        // the large-window path spends one round per attempted factorisation: max_iters rounds + slack for mu escalations
         int hook_rc = 0;
-        e = ba_launch_solve_big(B.L, B.dL, B.P, B.rounds + 8, h->stream, (BaAllReduce)B.allreduce, B.allreduce_user, &hook_rc);
+        e = ba_launch_solve_big(B.L, B.dL, B.P, B.rounds + BA_BIG_SLACK, h->stream, (BaAllReduce)B.allreduce, B.allreduce_user, &hook_rc,
+                                ev, kinds, n_launches);
         if (e != hipSuccess && hook_rc) { h->err = "all-reduce hook returned " + std::to_string(hook_rc); return VG_ERR_HIP; }
     } else {
         // (forking the IMU / prior kernel onto h->aux was measured: the event record / wait pairs cost more than the ~30 us of
         //  overlap they buy — 2.72 vs 2.69 ms per 256-window solve — so the launches stay on one stream)
-        e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream, nullptr, nullptr, nullptr, nullptr);
+        e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream, ev, kinds, n_launches, nullptr);
     }
     if (e != hipSuccess) { h->err = std::string("launch of ") + ba_failed_launch() + ": " + hipGetErrorString(e); return VG_ERR_HIP; }
     return VG_OK;
@@ -615,14 +623,15 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
 extern "C" int vg_ba_batch_run_profiled(vg_handle* h, float* ms, int* n) {
     if (!h || !h->ba.uploaded || !ms || !n) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
-    if (B.L.big) { h->err = "per-kernel profile is not offered on the large-window path (use rocprofv3)"; return VG_ERR_UNSUPPORTED; }
-    const int nev = 4 * B.rounds + 5 + 1;
+    const int nev = B.L.big ? 6 * (B.rounds + BA_BIG_SLACK) + 8 : 4 * B.rounds + 5 + 1;
     std::vector<hipEvent_t> ev(nev, nullptr);
     std::vector<int> kinds(nev, 0);
     for (int i = 0; i < nev; ++i) HIPCHK(h, hipEventCreate(&ev[i]));
     int nl = 0;
-    hipError_t e = ba_launch_solve(B.L, B.dL, B.P, B.rounds, h->stream, ev.data(), kinds.data(), &nl, nullptr);
-    if (e != hipSuccess) { h->err = std::string("launch of ") + ba_failed_launch() + ": " + hipGetErrorString(e); return VG_ERR_HIP; }
+    {
+        const int rc = launch_solve(h, ev.data(), kinds.data(), &nl);
+        if (rc) return rc;
+    }
     if (B.any_margin) {
         HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
         HIPCHK(h, hipEventRecord(ev[nl + 1], h->stream));

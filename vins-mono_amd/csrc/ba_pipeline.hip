@@ -2463,12 +2463,11 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
 // `rounds` = max_iters + slack: a failed factorisation retries its iteration in the next round (see above).
 typedef int (*BaAllReduce)(void* user, double* buf, size_t count, void* stream);
 extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
-                                          BaAllReduce allreduce, void* user, int* hook_rc) {
+                                          BaAllReduce allreduce, void* user, int* hook_rc, hipEvent_t* ev, int* kinds, int* n_launches) {
     hipError_t e = set_lds_attrs();
     if (e != hipSuccess) { g_failed_launch = "hipFuncSetAttribute"; return e; }
-    hipEvent_t* ev = nullptr;
-    int nev = 0;
-    (void)nev;
+    int nev = 0, nk = 0;
+    if (ev) { e = hipEventRecord(ev[nev++], stream); if (e != hipSuccess) return e; }
     if (hook_rc) *hook_rc = 0;
     const size_t n1 = (size_t)L.nwin * L.rb1_len, n2 = (size_t)L.nwin * RB2_LEN;
 #define REDUCE(buf, n)                                                                   \
@@ -2478,21 +2477,25 @@ extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL,
             if (_rc) { if (hook_rc) *hook_rc = _rc; g_failed_launch = "all-reduce hook"; return hipErrorInvalidValue; } \
         }                                                                                \
     } while (0)
-    LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P);
+#define KIND(k) do { if (kinds) kinds[nk++] = (k); } while (0)
+    // (profiling: the all-reduce sits in the gap before the kernel that consumes it and is counted with that kernel)
+    LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P); KIND(0);
     for (int r = 0; r <= rounds; ++r) {
         const int cost_only = r == rounds ? 1 : 0;
-        LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only);
-        LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only);
-        if (!cost_only) LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P);
-        LAUNCH(ba_big_schur_kernel, dim3(L.nts + 1, L.nwin), dim3(256), 0, dL, P, cost_only);
+        LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only); KIND(1);
+        LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only); KIND(1);
+        if (!cost_only) { LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P); KIND(2); }
+        LAUNCH(ba_big_schur_kernel, dim3(L.nts + 1, L.nwin), dim3(256), 0, dL, P, cost_only); KIND(6);
         REDUCE(P.rb1, n1);
         if (cost_only) break;
-        LAUNCH(ba_solve_big_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P);
+        LAUNCH(ba_solve_big_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P); KIND(7);
         REDUCE(P.rb2, n2);
-        LAUNCH(ba_big_step_kernel, dim3(L.nwin), dim3(BA_NT), 0, dL, P);
+        LAUNCH(ba_big_step_kernel, dim3(L.nwin), dim3(BA_NT), 0, dL, P); KIND(8);
     }
-    LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P);
+    LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P); KIND(4);
 #undef REDUCE
+#undef KIND
+    if (n_launches) *n_launches = nk;
     return hipSuccess;
 }
 

@@ -42,7 +42,7 @@ struct BaBatch {
     void* allreduce = nullptr;       // vg_allreduce_fn of the large-window path (nullptr: single rank)
     void* allreduce_user = nullptr;
     double flops = 0, flops_marg = 0, bytes_in = 0, bytes_out = 0;
-    double flops_k[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic flops per kernel class (VG_BA_KERNEL_*), one run of the batch
+    double flops_k[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic flops per kernel class (VG_BA_KERNEL_*), one run of the batch
 };
 
 struct FeState;   // fe_host.hip

@@ -274,6 +274,24 @@ class SyntheticSequence:
             prob['td'] = 0.002
         return prob
 
+    @staticmethod
+    def anchor_prior(prob, sigma_p=0.02, sigma_q=0.01, sigma_v=0.05, sigma_b=0.02):
+        """A prior factor on the oldest frame (pose 0, speed-bias 0 and, if estimated, the extrinsic pose / td) in the form
+        MarginalizationFactor consumes: r = r0 + J0 (x (-) x0) with J0 = diag(1 / sigma), r0 = 0, x0 = the window's own
+        initial values.  Stands in for the marginalization result where none can be produced (the enlarged window of
+        BASELINE configs[4] has no predecessor): it fixes the gauge like the reference's prior does."""
+        blocks = [(0, 0), (1, 0)]                     # (VG_BLK_POSE, 0), (VG_BLK_SPEEDBIAS, 0)
+        w = [1.0 / sigma_p] * 3 + [1.0 / sigma_q] * 3 + [1.0 / sigma_v] * 3 + [1.0 / sigma_b] * 6
+        x0 = [np.array(prob['pose'][0], float), np.array(prob['sb'][0], float)]
+        if prob['estimate_extrinsic']:
+            blocks.append((2, 0)); w += [1.0 / sigma_p] * 3 + [1.0 / sigma_q] * 3; x0.append(np.array(prob['ex'], float))
+        if prob['estimate_td']:
+            blocks.append((3, 0)); w += [1.0 / 0.01]; x0.append(np.array([float(prob['td'])]))
+        n = len(w)
+        out = dict(prob)
+        out['prior'] = dict(n=n, blocks=blocks, J0=np.diag(np.array(w, float)), r0=np.zeros(n), x0=x0)
+        return out
+
     def next_window(self, prev_state, prior, w0):
         """Window w0 (= previous + 1) after MARGIN_OLD: frames 0..K-2 carry the previous optimum,
         the newest frame is truth (+) noise, `prior` is the previous marginalization result."""
