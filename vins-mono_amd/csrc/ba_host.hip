@@ -159,7 +159,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         int o = 0, ob = 0;
         int& oo = L.big ? ob : o;                    // where the movable arrays are carved from
         L.l_S = o; o += up((L.Rc + 1) * (L.Rc + 2) / 2, 2);
-        L.l_XC = oo; oo += up(9 * L.K, 4) * ldc;
+        L.l_XC = oo; oo += up(9 * L.K, L.big ? 8 : 4) * ldc;      // (large path: two k-steps per trip of schur_chain_big)
         L.l_D = oo; oo += up(81 * L.K, 2);
         L.l_E = oo; oo += up(81 * L.K, 2);
         L.l_dinv = oo; oo += up(9 * L.K, 2);
@@ -168,7 +168,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         L.l_wd = oo; oo += up(std::max(L.big ? 0 : L.RcPad * 33, std::max(9 * L.K, 162)), 2);   // staged landmark tile [RcPad][32 + 1]
         L.l_z = oo; oo += up(36 * L.K, 2);
         L.l_pmap = oo; oo += up(L.Ncap, 4) / 2;
-        if (L.big) { L.l_di = o; o += up(L.Rc + 1, 2); }
+        if (L.big) { L.l_di = o; o += up(L.Rc + 1, 2); L.l_cz = o; o += 6 * 96; }
         L.lds_solve = o * 8;
         bigm_doubles = ob;
         if (L.lds_solve > 160 * 1024) { h->err = "solve kernel LDS carve exceeds 160 KB"; return VG_ERR_UNSUPPORTED; }
@@ -623,7 +623,7 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
 extern "C" int vg_ba_batch_run_profiled(vg_handle* h, float* ms, int* n) {
     if (!h || !h->ba.uploaded || !ms || !n) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
-    const int nev = B.L.big ? 6 * (B.rounds + BA_BIG_SLACK) + 8 : 4 * B.rounds + 5 + 1;
+    const int nev = B.L.big ? 7 * (B.rounds + BA_BIG_SLACK) + 8 : 4 * B.rounds + 5 + 1;
     std::vector<hipEvent_t> ev(nev, nullptr);
     std::vector<int> kinds(nev, 0);
     for (int i = 0; i < nev; ++i) HIPCHK(h, hipEventCreate(&ev[i]));

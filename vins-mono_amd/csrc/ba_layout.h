@@ -37,8 +37,13 @@ enum {
 //   rank's landmarks (packed lower, augmented row Rc = rhs);  scalars below.  Summed over the ranks by the caller's
 //   all-reduce (RCCL over xGMI) between the Schur kernel and the solve kernel; a single rank skips the collective.
 enum { RB1_COST = 0, RB1_GTL2, RB1_LAM2, RB1_STEP2, RB1_NBIG, RB1_NSCAL = 8 };
-// reduce buffer 2: landmark shares of |gn|^2, gt.gn, the Cauchy-point term, the count of non-finite step entries
-enum { RB2_GNN2 = 0, RB2_GTGN, RB2_QL, RB2_NONFIN, RB2_LEN = 8 };
+// reduce buffer 2: landmark shares of |gn|^2, gt.gn, the Cauchy-point term, the count of non-finite step entries -- one
+// group of four per workgroup of ba_big_landmark_kernel (a fixed number, so that the buffer has the same length on every
+// rank), summed in workgroup order by the step kernel
+enum { RB2_GNN2 = 0, RB2_GTGN, RB2_QL, RB2_NONFIN };
+#define BA_BIG_LM_BLOCKS 32
+#define BA_BIG_ZERO_BLOCKS 8      // workgroups of the Schur kernel that clear the chain blocks XC / D / E for the next assembly
+#define RB2_LEN (4 * BA_BIG_LM_BLOCKS)
 
 struct BaLayout {
     int nwin, K, Kp, e, t;
@@ -76,7 +81,7 @@ struct BaLayout {
     //      it); the landmark Schur complement is formed by a multi-workgroup kernel into reduce buffer 1.
     int big;
     int so_bigm;                              // HBM home of XC / D / E / dinv / vec / wd / z / pmap
-    int l_di;                                 // LDS offset of the 1/L_jj vector (big path)
+    int l_di, l_cz;                           // LDS offsets of the 1/L_jj vector and of the chain elimination's scratch (big path)
     int so_dgl, so_gtl;                       // landmark Dg, gt per linearisation buffer (2 x Lcap each)
     int rb1_len, rb1_T, rb1_scal;             // reduce buffer 1: doubles per window, offsets of T and of the scalars
     int nts;                                  // lower 16x16 tiles of T = workgroups of the Schur kernel (+ 1 landmark workgroup)

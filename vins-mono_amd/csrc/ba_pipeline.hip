@@ -250,23 +250,33 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
         const int n = c.nprior;
         const double* J0 = c.di + L.do_pJ0;
         double* Hp = c.sc + L.so_Hp;
-        const double* J0s = J0;                  // n x n, row stride ld: staged in LDS when it fits (host: lds_pro)
-        int ld = L.Ncap;
+        // J0 staged in LDS when it fits (host: lds_pro); the two loops are spelled out so that the staged one keeps its
+        // LDS addressing (a pointer that may be either costs flat loads in the inner loop)
         __syncthreads();
         if ((size_t)n * n * 8 <= (size_t)L.lds_pro) {
-            double* st = LDSB;
-            for (int wk = c.tid; wk < n * n; wk += BA_NT) st[wk] = J0[(wk / n) * L.Ncap + wk % n];
-            J0s = st; ld = n;
-        }
-        __syncthreads();
-        for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
-            int a, bb;
-            tri_decode(wk, a, bb);
-            double s0 = 0.0, s1 = 0.0;
-            int r = 0;
-            for (; r + 1 < n; r += 2) { s0 += J0s[r * ld + a] * J0s[r * ld + bb]; s1 += J0s[(r + 1) * ld + a] * J0s[(r + 1) * ld + bb]; }
-            if (r < n) s0 += J0s[r * ld + a] * J0s[r * ld + bb];
-            Hp[a * L.Ncap + bb] = s0 + s1;
+            double* J0s = LDSB;                  // n x n, row stride n
+            for (int wk = c.tid; wk < n * n; wk += BA_NT) J0s[wk] = J0[(wk / n) * L.Ncap + wk % n];
+            __syncthreads();
+            for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
+                int a, bb;
+                tri_decode(wk, a, bb);
+                double s0 = 0.0, s1 = 0.0;
+                int r = 0;
+                for (; r + 1 < n; r += 2) { s0 += J0s[r * n + a] * J0s[r * n + bb]; s1 += J0s[(r + 1) * n + a] * J0s[(r + 1) * n + bb]; }
+                if (r < n) s0 += J0s[r * n + a] * J0s[r * n + bb];
+                Hp[a * L.Ncap + bb] = s0 + s1;
+            }
+        } else {
+            const int ld = L.Ncap;
+            for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
+                int a, bb;
+                tri_decode(wk, a, bb);
+                double s0 = 0.0, s1 = 0.0;
+                int r = 0;
+                for (; r + 1 < n; r += 2) { s0 += J0[r * ld + a] * J0[r * ld + bb]; s1 += J0[(r + 1) * ld + a] * J0[(r + 1) * ld + bb]; }
+                if (r < n) s0 += J0[r * ld + a] * J0[r * ld + bb];
+                Hp[a * L.Ncap + bb] = s0 + s1;
+            }
         }
     }
 }
@@ -803,6 +813,23 @@ DEV void hess_add(const BaLayout& L, const SolveLds& m, int ca, int cb, double v
     }
 }
 
+// where hess_add() would add the entry (ca, cb): p0, and p1 != nullptr for the mirrored entry of a diagonal chain block
+DEV void hess_slot(const BaLayout& L, const SolveLds& m, int ca, int cb, double*& p0, double*& p1) {
+    if (ca < cb) { const int t = ca; ca = cb; cb = t; }
+    const int Rc = L.Rc;
+    p1 = nullptr;
+    if (ca < Rc) { p0 = m.S + tri(ca, cb); return; }
+    const int ka = (ca - Rc) / 9, ra = (ca - Rc) - 9 * ka;
+    if (cb < Rc) { p0 = m.XC + (9 * ka + ra) * m.ldc + cb; return; }
+    const int kb = (cb - Rc) / 9, rb = (cb - Rc) - 9 * kb;
+    if (ka == kb) {
+        p0 = m.D + 81 * ka + 9 * ra + rb;
+        if (ra != rb) p1 = m.D + 81 * ka + 9 * rb + ra;
+    } else {
+        p0 = m.E + 81 * ka + 9 * ra + rb;
+    }
+}
+
 // Unscaled Gauss-Newton system of the current point in LDS: S (camera, packed lower), g, chain blocks D, E, XC.
 // Sp / gp = camera J^T J / J^T r of the projection factors (the buffer's own, or the rank-summed copy of the large-window path)
 NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf, const double* Sp, const double* gp) {
@@ -813,9 +840,12 @@ NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf, const do
     __syncthreads();
     for (int k = c.tid; k < camtri; k += BA_NT) m.S[k] = Sp[k];
     for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? gp[k] : 0.0;
-    const int nxc = ((9 * K + 3) & ~3) * m.ldc;
-    for (int k = c.tid; k < nxc; k += BA_NT) m.XC[k] = 0.0;
-    for (int k = c.tid; k < 81 * K; k += BA_NT) { m.D[k] = 0.0; m.E[k] = 0.0; }
+    if (!L.big) {
+        // (large-window path: XC / D / E live in HBM and were cleared by the Schur kernel's extra workgroups)
+        const int nxc = ((9 * K + 3) & ~3) * m.ldc;
+        for (int k = c.tid; k < nxc; k += BA_NT) m.XC[k] = 0.0;
+        for (int k = c.tid; k < 81 * K; k += BA_NT) { m.D[k] = 0.0; m.E[k] = 0.0; }
+    }
     __syncthreads();
     // ---- IMU Hessian blocks: factors k and k+1 share the blocks of frame k+1, so even and odd factors are added in two
     //      rounds (inside a round every entry has exactly one writer)
@@ -825,16 +855,47 @@ NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf, const do
         const double* imuJ = buf + L.bo_imuJ;
         for (int par = 0; par < 2; ++par) {
             const int nf = (nimu - par + 1) / 2;
-            for (int w = c.tid; w < nf * 512; w += BA_NT) {
-                const int f = 2 * (w >> 9) + par, e = w & 511;
-                if (e >= 495 || !valid[f]) continue;
-                const double v = imuJ[f * 512 + e];
-                if (e < 465) {
-                    int a, b;
-                    tri_decode(e, a, b);
-                    hess_add(L, m, imu_col(L, f, a), imu_col(L, f, b), v);
-                } else {
-                    g[imu_col(L, f, e - 465)] += v;
+            if (!L.big) {
+                for (int w = c.tid; w < nf * 512; w += BA_NT) {
+                    const int f = 2 * (w >> 9) + par, e = w & 511;
+                    if (e >= 495 || !valid[f]) continue;
+                    const double v = imuJ[f * 512 + e];
+                    if (e < 465) {
+                        int a, b;
+                        tri_decode(e, a, b);
+                        hess_add(L, m, imu_col(L, f, a), imu_col(L, f, b), v);
+                    } else {
+                        g[imu_col(L, f, e - 465)] += v;
+                    }
+                }
+            } else {
+                // large-window path: most targets are in HBM, a read-modify-write per trip would be a chain of memory round
+                // trips.  Thread = entry e of every factor of this parity, eight factors at a time: all loads first, then
+                // all stores (inside a round every entry has exactly one writer, so the slots are distinct).
+                const int e = c.tid;
+                int a = 0, b = 0;
+                if (e < 465) tri_decode(e, a, b);
+                for (int i0 = 0; i0 < nf; i0 += 8) {
+                    double* p0[8];
+                    double* p1[8];
+                    double v[8], t0[8], t1[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int f = 2 * (i0 + q) + par;
+                        p0[q] = nullptr; p1[q] = nullptr; v[q] = 0.0;
+                        if (i0 + q < nf && e < 495 && valid[f]) {
+                            v[q] = imuJ[f * 512 + e];
+                            if (e < 465) hess_slot(L, m, imu_col(L, f, a), imu_col(L, f, b), p0[q], p1[q]);
+                            else p0[q] = g + imu_col(L, f, e - 465);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { t0[q] = p0[q] ? *p0[q] : 0.0; t1[q] = p1[q] ? *p1[q] : 0.0; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (p0[q]) *p0[q] = t0[q] + v[q];
+                        if (p1[q]) *p1[q] = t1[q] + v[q];
+                    }
                 }
             }
             __syncthreads();
@@ -906,15 +967,45 @@ NOINL double build_scaled(const Ctx& c, const SolveLds& m, double mu) {
             m.E[w] = ve;
         }
     }
-    for (int w = c.tid; w < 9 * K * (Rc + 1); w += BA_NT) {
-        const int row = w / (Rc + 1), col = w - row * (Rc + 1);
-        const int ca = Rc + row;
-        if (col < Rc) {
+    if (!L.big) {
+        for (int w = c.tid; w < 9 * K * (Rc + 1); w += BA_NT) {
+            const int row = w / (Rc + 1), col = w - row * (Rc + 1);
+            const int ca = Rc + row;
+            if (col < Rc) {
+                const double v = m.XC[row * ldc + col] * sc[ca] * sc[col];
+                q += 2.0 * v * tv[ca] * tv[col];
+                m.XC[row * ldc + col] = v;
+            } else {
+                m.XC[row * ldc + Rc] = sc[ca] * g[ca];
+            }
+        }
+    } else {
+        // large-window path (XC in HBM): before the elimination a speed-bias row of frame k is non-zero only in the columns of
+        // poses k-1, k, k+1 (IMU factors k-1 and k) -- and anywhere if the prior holds that speed-bias block
+        const int* kind = c.ia + L.io_pb_kind;
+        const int* idx = c.ia + L.io_pb_idx;
+        for (int w = c.tid; w < 9 * K * 20; w += BA_NT) {
+            const int row = w / 20, e = w - 20 * row, k = row / 9;
+            const int ca = Rc + row;
+            if (e == 19) { m.XC[row * ldc + Rc] = sc[ca] * g[ca]; continue; }
+            bool inprior = false;
+            for (int b = 0; b < c.nblk; ++b) inprior = inprior || (kind[b] == VG_BLK_SPEEDBIAS && idx[b] == k);
+            if (inprior) continue;                     // handled densely below
+            const int col = 6 * (k - 1) + e;           // e = 0 .. 17
+            if (e >= 18 || col < 0 || col >= 6 * L.Kp) continue;
             const double v = m.XC[row * ldc + col] * sc[ca] * sc[col];
             q += 2.0 * v * tv[ca] * tv[col];
             m.XC[row * ldc + col] = v;
-        } else {
-            m.XC[row * ldc + Rc] = sc[ca] * g[ca];
+        }
+        for (int b = 0; b < c.nblk; ++b) {
+            if (kind[b] != VG_BLK_SPEEDBIAS) continue;
+            const int k = idx[b];
+            for (int w = c.tid; w < 9 * Rc; w += BA_NT) {
+                const int r = w / Rc, col = w - r * Rc, row = 9 * k + r, ca = Rc + row;
+                const double v = m.XC[row * ldc + col] * sc[ca] * sc[col];
+                q += 2.0 * v * tv[ca] * tv[col];
+                m.XC[row * ldc + col] = v;
+            }
         }
     }
     return q;
@@ -1759,16 +1850,17 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
 // speculatively at the candidate's linearisation with the mu an accepted step would leave (max(1e-8, mu / 5)): a
 // rejected step reuses the previous Gauss-Newton step and needs no linear solve, exactly as DoglegStrategy does.
 //
-//   per round:  linearize_imu, linearize_proj, accumulate, big_schur | all-reduce 1 | solve_big | all-reduce 2 | big_step
+//   per round:  linearize_imu, linearize_proj, accumulate, big_schur | all-reduce 1 | solve_big, big_landmark | all-reduce 2 | big_step
 //
 // Trust-region semantics are those of ba_solve_kernel (one iteration per round; a failed factorisation retries the same
 // iteration with mu x 10 in the next round, because the new T needs the collective).
 // ================================================================================================
 
-// grid (nts + 1, nwin), 256 threads.  Workgroups 0 .. nts-1: one lower 16x16 tile of T each, the four wavefronts take
+// grid (nts + 1 + BA_BIG_ZERO_BLOCKS, nwin), 256 threads.  Workgroups 0 .. nts-1: one lower 16x16 tile of T each, the four wavefronts take
 // interleaved groups of 16 landmarks (a lane loads 4 consecutive landmarks of its row: 32-byte loads, 128 contiguous
 // bytes per row), partial tiles are summed through LDS in a fixed order.  Workgroup nts: per-landmark Dg, gt (and the
-// landmark scaling in round 0), the scalar partial sums, and the copy of Sp / gp into the reduce buffer.
+// landmark scaling in round 0), the scalar partial sums, and the copy of Sp / gp into the reduce buffer.  The last
+// BA_BIG_ZERO_BLOCKS workgroups clear the chain blocks of the reduced system (HBM) for the solve kernel's assembly.
 extern "C" __global__ __launch_bounds__(256) void ba_big_schur_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
     const BaLayout& L = *Lp;
     Ctx c;
@@ -1828,6 +1920,13 @@ extern "C" __global__ __launch_bounds__(256) void ba_big_schur_kernel(const BaLa
         return;
     }
     if (cost_only) return;
+    if ((int)blockIdx.x > L.nts) {
+        // clear the chain blocks XC | D | E (contiguous in the HBM carve) for the assembly of this round
+        double* z = c.sc + L.so_bigm + L.l_XC;
+        const int n = L.l_dinv - L.l_XC;
+        for (int k = ((int)blockIdx.x - L.nts - 1) * 256 + c.tid; k < n; k += BA_BIG_ZERO_BLOCKS * 256) z[k] = 0.0;
+        return;
+    }
     int tm, tn;
     tri_decode(blockIdx.x, tm, tn);
     const double* Wt = buf + L.bo_Wt;
@@ -1870,34 +1969,236 @@ extern "C" __global__ __launch_bounds__(256) void ba_big_schur_kernel(const BaLa
 }
 
 // S -= X^T X over the 9K chain rows (XC in HBM, rhs in column Rc -> augmented row Rc of S) and S -= diag(sc) T diag(sc)
-// (the rank-summed landmark Schur complement; row Rc: rhs).  Wavefront per 16x16 tile, v_mfma_f64_16x16x4.
+// (the rank-summed landmark Schur complement; row Rc: rhs).  v_mfma_f64_16x16x4; a wavefront task = tile row tm x up to four
+// column tiles (the A operand is shared), two k-steps per trip so that ten 128-byte row loads are in flight per wavefront:
+// the operands come from L2, the loop is a chain of round trips, not of flops.  XC has up(9K, 8) rows (zero padded).
 NOINL void schur_chain_big(const Ctx& c, const SolveLds& m, const double* T) {
     const BaLayout& L = *c.Lp;
     const double* sc = m.vec + V_SC * L.Rpad;
     const int Rc = L.Rc, ldc = m.ldc;
-    const int nt = L.RcPad / 16, ntile = nt * (nt + 1) / 2;
-    const int nk = (9 * L.K + 3) / 4;
+    const int nt = L.RcPad / 16;
+    const int nk2 = (9 * L.K + 7) / 8;             // trips of two k-steps (4 rows each)
+    int ntask = 0;
+    for (int tm = 0; tm < nt; ++tm) ntask += (tm + 4) / 4;
     __syncthreads();
-    for (int t = c.wave; t < ntile; t += BA_NW) {
-        int tm, tn;
-        tri_decode(t, tm, tn);
-        double4_t acc = {0, 0, 0, 0};
+    for (int task = c.wave; task < ntask; task += BA_NW) {
+        int tm = 0, base = 0;
+        while (base + (tm + 4) / 4 <= task) { base += (tm + 4) / 4; ++tm; }
+        const int tn0 = 4 * (task - base);
+        const int nc = (tm + 1 - tn0) < 4 ? (tm + 1 - tn0) : 4;
+        double4_t acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0, 0, 0, 0};
         const double* xr = m.XC + (size_t)(c.lane >> 4) * ldc + (c.lane & 15);
-        for (int kk = 0; kk < nk; ++kk) {
-            const double a = xr[(size_t)kk * 4 * ldc + tm * 16];
-            const double bq = xr[(size_t)kk * 4 * ldc + tn * 16];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
+        for (int k2 = 0; k2 < nk2; ++k2) {
+            const double* r0 = xr + (size_t)k2 * 8 * ldc;
+            const double* r1 = r0 + (size_t)4 * ldc;
+            const double a0 = r0[tm * 16], a1 = r1[tm * 16];
+            double b0[4], b1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                b0[q] = q < nc ? r0[(tn0 + q) * 16] : 0.0;
+                b1[q] = q < nc ? r1[(tn0 + q) * 16] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nc) {
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[q], acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[q], acc[q], 0, 0, 0);
+                }
+            }
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = tm * 16 + (c.lane >> 4) + 4 * reg, col = tn * 16 + (c.lane & 15);
-            if (row <= Rc && col <= row && col < Rc) {
-                const double sr = row < Rc ? sc[row] : 1.0;
-                m.S[tri(row, col)] -= acc[reg] + sr * sc[col] * T[tri(row, col)];
+        for (int q = 0; q < 4; ++q) {
+            if (q < nc) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = tm * 16 + (c.lane >> 4) + 4 * reg, col = (tn0 + q) * 16 + (c.lane & 15);
+                    if (row <= Rc && col <= row && col < Rc) {
+                        const double sr = row < Rc ? sc[row] : 1.0;
+                        m.S[tri(row, col)] -= acc[q][reg] + sr * sc[col] * T[tri(row, col)];
+                    }
+                }
             }
         }
     }
     __syncthreads();
+}
+
+// chain_eliminate() for the large-window path, where XC lives in HBM: the same elimination from both ends (same storage
+// conventions afterwards, so schur_chain_big / chain_back_substitute do not care), organised so that every element of XC is
+// loaded once and stored once.  Thread `id` of the first / second half of the workgroup owns column id of [C_k | g_k] for
+// the top / bottom sweep and keeps the solved column of the block it eliminated last in registers: the update a block
+// receives from its neighbour only involves that column and the neighbour's 9x9 coupling block, which travels through LDS
+// (cz: L and 1/L_rr of the two blocks of the step, coupling blocks double-buffered by block parity).
+NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
+    const BaLayout& L = *c.Lp;
+    const int K = L.K, Rc = L.Rc, ldc = m.ldc;
+    const int mid = K / 2;
+    const int nstep = (K - 1 - mid) > mid ? (K - 1 - mid) : mid;
+    double* Lt = cz;            double* dit = cz + 81;
+    double* Lb = cz + 96;       double* dib = cz + 96 + 81;
+    double* XeB = cz + 192;     // [2][96]: Xe of top block k in buffer k & 1
+    double* XuB = cz + 384;     // [2][96]: slot E_k (rows solved by the bottom block k-1) in buffer k & 1
+    int* flag = (int*)(m.red + 24);
+    if (c.tid == 0) *flag = 1;
+    __syncthreads();
+    const int half = c.tid >> 8, id = c.tid & 255;
+    double xprev[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) xprev[r] = 0.0;
+    for (int t = 0; t <= nstep; ++t) {
+        const bool last = t == nstep;
+        const int kt = last ? mid : K - 1 - t, kb = last ? -1 : t;
+        const bool has_t = last || kt > mid, has_b = !last && kb < mid;
+        const bool upd_t_from_above = has_t && kt + 1 <= K - 1 && (last ? (K - 1 > mid) : t > 0);
+        const bool upd_mid_from_below = last && mid > 0;
+        const bool upd_b = has_b && t > 0;
+        const double* XeP = XeB + 96 * ((kt + 1) & 1);          // coupling block of the upper neighbour kt + 1
+        const double* XuM = XuB + 96 * (kt & 1);                // (last step) slot E_mid, solved by the bottom block mid - 1
+        const double* XuP = XuB + 96 * (kb & 1);                // slot E_kb, solved by the bottom block kb - 1
+        // ---- (A) diagonal blocks: update + 9x9 Cholesky in LDS, factor back to HBM for the back substitution
+        if (c.wave == 0 && has_t) {
+            for (int e = c.lane; e < 81; e += 64) {
+                const int r = e / 9, cc = e - 9 * r;
+                double s = 0.0;
+                if (upd_t_from_above) {
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) s += XeP[9 * p + r] * XeP[9 * p + cc];
+                }
+                if (upd_mid_from_below) {
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) s += XuM[9 * r + p] * XuM[9 * cc + p];
+                }
+                Lt[e] = m.D[81 * kt + e] - s;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (!chain_factor(c.lane, Lt, dit, 0, nullptr) && c.lane == 0) *flag = 0;
+            __builtin_amdgcn_wave_barrier();
+            for (int e = c.lane; e < 81; e += 64) m.D[81 * kt + e] = Lt[e];
+            if (c.lane < 9) m.dinv[9 * kt + c.lane] = dit[c.lane];
+        } else if (c.wave == 4 && has_b) {
+            for (int e = c.lane; e < 81; e += 64) {
+                const int r = e / 9, cc = e - 9 * r;
+                double s = 0.0;
+                if (upd_b) {
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) s += XuP[9 * r + p] * XuP[9 * cc + p];
+                }
+                Lb[e] = m.D[81 * kb + e] - s;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (!chain_factor(c.lane, Lb, dib, 0, nullptr) && c.lane == 0) *flag = 0;
+            __builtin_amdgcn_wave_barrier();
+            for (int e = c.lane; e < 81; e += 64) m.D[81 * kb + e] = Lb[e];
+            if (c.lane < 9) m.dinv[9 * kb + c.lane] = dib[c.lane];
+        }
+        __syncthreads();
+        if (*flag == 0) break;
+        // ---- (B) columns
+        if (half == 0 && has_t) {
+            if (id <= Rc) {
+                double* col = m.XC + (size_t)9 * kt * ldc + id;
+                double x[9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) x[r] = col[(size_t)r * ldc];
+                if (upd_t_from_above) {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int p = 0; p < 9; ++p) s += XeP[9 * p + r] * xprev[p];
+                        x[r] -= s;
+                    }
+                }
+                if (upd_mid_from_below) {
+                    const double* cb = m.XC + (size_t)9 * (kt - 1) * ldc + id;
+                    double xb[9];
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) xb[p] = cb[(size_t)p * ldc];
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int p = 0; p < 9; ++p) s += XuM[9 * r + p] * xb[p];
+                        x[r] -= s;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    double s = x[r];
+#pragma unroll
+                    for (int q = 0; q < r; ++q) s -= Lt[9 * r + q] * x[q];
+                    x[r] = s * dit[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 9; ++r) { col[(size_t)r * ldc] = x[r]; xprev[r] = x[r]; }
+            } else if (!last && id < Rc + 10) {
+                // column cc of E_kt -> Xe_kt[p][cc]
+                const int cc = id - Rc - 1;
+                double* e = m.E + 81 * kt + cc;
+                double* xe = XeB + 96 * (kt & 1) + cc;
+                double x[9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) x[r] = e[9 * r];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    double s = x[r];
+#pragma unroll
+                    for (int q = 0; q < r; ++q) s -= Lt[9 * r + q] * x[q];
+                    x[r] = s * dit[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 9; ++r) { e[9 * r] = x[r]; xe[9 * r] = x[r]; }
+            }
+        } else if (half == 1 && has_b) {
+            if (id <= Rc) {
+                double* col = m.XC + (size_t)9 * kb * ldc + id;
+                double x[9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) x[r] = col[(size_t)r * ldc];
+                if (upd_b) {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int p = 0; p < 9; ++p) s += XuP[9 * r + p] * xprev[p];
+                        x[r] -= s;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    double s = x[r];
+#pragma unroll
+                    for (int q = 0; q < r; ++q) s -= Lb[9 * r + q] * x[q];
+                    x[r] = s * dib[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 9; ++r) { col[(size_t)r * ldc] = x[r]; xprev[r] = x[r]; }
+            } else if (id < Rc + 10) {
+                // row cc of E_kb+1 (as [c][p]) -> XuT of the pair (kb + 1, kb)
+                const int cc = id - Rc - 1;
+                double* e = m.E + 81 * (kb + 1) + 9 * cc;
+                double* xu = XuB + 96 * ((kb + 1) & 1) + 9 * cc;
+                double x[9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) x[r] = e[r];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    double s = x[r];
+#pragma unroll
+                    for (int q = 0; q < r; ++q) s -= Lb[9 * r + q] * x[q];
+                    x[r] = s * dib[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 9; ++r) { e[r] = x[r]; xu[r] = x[r]; }
+            }
+        }
+        __syncthreads();
+    }
+    const bool ok = *flag != 0;
+    __syncthreads();
+    return ok;
 }
 
 // back substitution L^T y = (row R of S) for R <= 64 NR, one wavefront, lane owns entries lane + 64 q of the running rhs
@@ -1980,7 +2281,6 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     int* iout = P.iout + (size_t)w * L.oi_stride;
     const double* rb1 = P.rb1 + (size_t)w * L.rb1_len;
     const double* scal = rb1 + L.rb1_scal;
-    double* rb2 = P.rb2 + (size_t)w * RB2_LEN;
     double* vG = m.vec + V_G * L.Rpad;
     double* vSC = m.vec + V_SC * L.Rpad;
     double* vDG = m.vec + V_DG * L.Rpad;
@@ -1992,6 +2292,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     const double* sl = c.sc + L.so_sl;
     double* gnl = c.sc + L.so_gn + L.Rpad;
     double* yl = c.sc + L.so_yl;
+    PROF_DECL;
     if (c.nprior) {
         const int* kind = c.ia + L.io_pb_kind;
         const int* off = c.ia + L.io_pb_off;
@@ -2024,6 +2325,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
         if (!(s.cost == s.cost) || !(s.cost < 1e300)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
         fresh_point = true;
     }
+    PROF_ADD(PF_JUDGE);
     const double* buf = lin_buf(c, s.cur);
     const double* hh = buf + L.bo_h;
     const double* bb = buf + L.bo_b;
@@ -2046,6 +2348,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     }
     for (int k = c.tid; k < R; k += BA_NT) vSC[k] = c.sc[L.so_sc + k];
     __syncthreads();
+    PROF_ADD(PF_ASM);
     if (trip && s.term == VG_TERM_NO_CONVERGENCE) {
         if (phase_in != 3) ++s.it;
         if (s.reuse) s.phase = 2;
@@ -2068,15 +2371,22 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
                 for (int k = c.tid; k < R; k += BA_NT) sq += vGT[k] * vGT[k];
                 s.gtn2 = block_sum(m.red, BA_NW, c.lane, c.wave, sq) + scal[RB1_GTL2];
             }
+            PROF_ADD(PF_DG);
             const double q = build_scaled(c, m, s.mu);
             __syncthreads();
-            bool cok = chain_eliminate(c, m);
+            PROF_ADD(PF_BUILD);
+            bool cok = chain_eliminate_big(c, m, LDSB + L.l_cz);
+            PROF_ADD(PF_CHAIN);
             schur_chain_big(c, m, rb1 + L.rb1_T);
             s.qcam = block_sum(m.red, BA_NW, c.lane, c.wave, q);
+            PROF_ADD(PF_SCHUR);
             if (cok) cok = cholesky_aug(c, m, Rc);
+            PROF_ADD(PF_CHOL);
             if (cok) {
                 back_substitute_n<4>(c, m, Rc);
+                PROF_ADD(PF_BACK);
                 chain_back_substitute(c, m);
+                PROF_ADD(PF_CBACK);
                 double fin = 0.0, s1 = 0.0, s2 = 0.0;
                 for (int k = c.tid; k < R; k += BA_NT) {
                     fin += (vY[k] == vY[k] && fabs(vY[k]) < 1e300) ? 0.0 : 1.0;
@@ -2084,52 +2394,83 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
                     s1 += vGN[k] * vGN[k];
                     s2 += vGN[k] * vGT[k];
                 }
-                // this rank's landmarks: y_l = (bt_l - wt_l . y_cam) / ht_l, and their share of the Cauchy-point term
-                // sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ],  t = gt / Dg
+                // operands of ba_big_landmark_kernel: sc .* y and sc .* t on the camera columns (t = gt / Dg)
                 for (int k = c.tid; k < Rc; k += BA_NT) { vU[k] = vSC[k] * vY[k]; vT[k] = vSC[k] * vT[k]; }
-                __syncthreads();
-                const double* Wt = buf + L.bo_Wt;
-                double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-                for (int l = c.tid; l < nL; l += BA_NT) {
-                    const double ht = sl[l] * sl[l] * hh[l] + s.mu * dgl[l] * dgl[l];
-                    double acc = 0.0, wdot = 0.0;
-                    for (int k = 0; k < Rc; ++k) {
-                        const double wv = Wt[(size_t)k * L.Lcap + l];
-                        acc += wv * vU[k];
-                        wdot += wv * vT[k];
-                    }
-                    const double y = (sl[l] * bb[l] - sl[l] * acc) / ht;
-                    yl[l] = y;
-                    fin += (y == y && fabs(y) < 1e300) ? 0.0 : 1.0;
-                    const double g = -y * dgl[l];
-                    gnl[l] = g;
-                    p0 += g * g;
-                    p1 += g * gtl[l];
-                    const double tl = gtl[l] / dgl[l];
-                    p2 += sl[l] * sl[l] * hh[l] * tl * tl + 2.0 * tl * sl[l] * wdot;
-                }
                 block_sum2(m.red, BA_NW, c.lane, c.wave, s1, s2);
-                block_sum2(m.red, BA_NW, c.lane, c.wave, p0, p1);
-                block_sum2(m.red, BA_NW, c.lane, c.wave, p2, fin);
-                if (c.tid == 0) {
-                    rb2[RB2_GNN2] = p0; rb2[RB2_GTGN] = p1; rb2[RB2_QL] = p2; rb2[RB2_NONFIN] = fin;
-                    rb2[4] = 0.0; rb2[5] = 0.0; rb2[6] = 0.0; rb2[7] = 0.0;
+                fin = block_sum(m.red, BA_NW, c.lane, c.wave, fin);
+                cok = fin == 0.0;
+                PROF_ADD(PF_LMY);
+                if (cok) {
+                    s.gnn2c = s1; s.gtgnc = s2;
+                    s.mu_solved = s.mu;
+                    s.reuse = 1;
+                    s.phase = 1;
+                    for (int k = c.tid; k < R; k += BA_NT) {
+                        c.sc[L.so_dg + k] = vDG[k]; c.sc[L.so_gt + k] = vGT[k]; c.sc[L.so_gn + k] = vGN[k];
+                    }
                 }
-                s.gnn2c = s1; s.gtgnc = s2;
-                s.mu_solved = s.mu;
-                s.reuse = 1;
-                s.phase = 1;
-                for (int k = c.tid; k < R; k += BA_NT) {
-                    c.sc[L.so_dg + k] = vDG[k]; c.sc[L.so_gt + k] = vGT[k]; c.sc[L.so_gn + k] = vGN[k];
-                }
-            } else {
-                big_solve_failed(s, L, out, iout, c.tid, true);
             }
+            if (!cok) big_solve_failed(s, L, out, iout, c.tid, true);
         }
     }
     if (s.term != VG_TERM_NO_CONVERGENCE || s.status != VG_OK || (s.phase == 0 && s.it >= max_iters)) s.done = 1;
     __syncthreads();
     if (c.tid == 0) ctl_store(s, ctlp);
+}
+
+// Landmark part of the Gauss-Newton step (this rank's landmarks): y_l = (bt_l - wt_l . y_cam) / ht_l, and their shares of
+// |gn|^2, gt.gn and the Cauchy-point term  sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ]  (t = gt / Dg).  grid
+// (BA_BIG_LM_BLOCKS, nwin), 256 threads, thread per landmark (grid-stride), the two camera vectors staged in LDS; one group
+// of four partial sums per workgroup into reduce buffer 2.
+extern "C" __global__ __launch_bounds__(256) void ba_big_landmark_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    const int w = blockIdx.y;
+    ctx_init(c, Lp, P, w);
+    const double* ctl = c.sc + L.so_ctl;
+    if (ctl[C_DONE] != 0.0 || (int)ctl[C_PHASE] != 1) return;
+    const int cur = (int)ctl[C_CUR];
+    const double mu = ctl[C_MUSOLVED];
+    const int Rc = L.Rc, nL = c.nL;
+    const double* vec = c.sc + L.so_bigm + L.l_vec;
+    const double* buf = lin_buf(c, cur);
+    const double* hh = buf + L.bo_h;
+    const double* bb = buf + L.bo_b;
+    const double* Wt = buf + L.bo_Wt;
+    const double* sl = c.sc + L.so_sl;
+    const double* dgl = c.sc + L.so_dgl + cur * L.Lcap;
+    const double* gtl = c.sc + L.so_gtl + cur * L.Lcap;
+    double* gnl = c.sc + L.so_gn + L.Rpad;
+    double* yl = c.sc + L.so_yl;
+    __shared__ double su[256], st[256], red[16];
+    for (int k = c.tid; k < Rc; k += 256) { su[k] = vec[V_U * L.Rpad + k]; st[k] = vec[V_T * L.Rpad + k]; }
+    __syncthreads();
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, fin = 0.0;
+    for (int l = blockIdx.x * 256 + c.tid; l < nL; l += BA_BIG_LM_BLOCKS * 256) {
+        const double ht = sl[l] * sl[l] * hh[l] + mu * dgl[l] * dgl[l];
+        double acc = 0.0, wdot = 0.0;
+        const double* wp = Wt + l;
+        for (int k = 0; k < Rc; ++k) {
+            const double wv = wp[(size_t)k * L.Lcap];
+            acc += wv * su[k];
+            wdot += wv * st[k];
+        }
+        const double y = (sl[l] * bb[l] - sl[l] * acc) / ht;
+        yl[l] = y;
+        fin += (y == y && fabs(y) < 1e300) ? 0.0 : 1.0;
+        const double g = -y * dgl[l];
+        gnl[l] = g;
+        p0 += g * g;
+        p1 += g * gtl[l];
+        const double tl = gtl[l] / dgl[l];
+        p2 += sl[l] * sl[l] * hh[l] * tl * tl + 2.0 * tl * sl[l] * wdot;
+    }
+    block_sum2(red, 4, c.lane, c.wave, p0, p1);
+    block_sum2(red, 4, c.lane, c.wave, p2, fin);
+    if (c.tid == 0) {
+        double* rb2 = P.rb2 + (size_t)w * RB2_LEN + 4 * blockIdx.x;
+        rb2[RB2_GNN2] = p0; rb2[RB2_GTGN] = p1; rb2[RB2_QL] = p2; rb2[RB2_NONFIN] = fin;
+    }
 }
 
 // Dogleg step, model cost change and the candidate state from the completed norms (after all-reduce 2).  1 workgroup per
@@ -2160,17 +2501,21 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_big_step_kernel(const BaL
     const double* gtl = c.sc + L.so_gtl + s.cur * L.Lcap;
     const double* gnl = c.sc + L.so_gn + L.Rpad;
     const int slot = s.it - 1;
+    double r_gnn2 = 0.0, r_gtgn = 0.0, r_ql = 0.0, r_nonfin = 0.0;
+    for (int b = 0; b < BA_BIG_LM_BLOCKS; ++b) {
+        r_gnn2 += rb2[4 * b + RB2_GNN2]; r_gtgn += rb2[4 * b + RB2_GTGN]; r_ql += rb2[4 * b + RB2_QL]; r_nonfin += rb2[4 * b + RB2_NONFIN];
+    }
     if (s.phase == 1) {
-        if (rb2[RB2_NONFIN] != 0.0) {
+        if (r_nonfin != 0.0) {
             big_solve_failed(s, L, out, iout, c.tid, true);
             if (s.term != VG_TERM_NO_CONVERGENCE || (s.phase == 0 && s.it >= max_iters)) s.done = 1;
             __syncthreads();
             if (c.tid == 0) ctl_store(s, ctlp);
             return;
         }
-        s.gnn2 = s.gnn2c + rb2[RB2_GNN2];
-        s.gtgn = s.gtgnc + rb2[RB2_GTGN];
-        s.alpha = s.gtn2 / (s.qcam + rb2[RB2_QL]);
+        s.gnn2 = s.gnn2c + r_gnn2;
+        s.gtgn = s.gtgnc + r_gtgn;
+        s.alpha = s.gtn2 / (s.qcam + r_ql);
     }
     s.phase = 0;
     // DoglegStrategy::ComputeTraditionalDoglegStep (same arithmetic as ba_solve_kernel)
@@ -2485,10 +2830,11 @@ extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL,
         LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only); KIND(1);
         LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only); KIND(1);
         if (!cost_only) { LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P); KIND(2); }
-        LAUNCH(ba_big_schur_kernel, dim3(L.nts + 1, L.nwin), dim3(256), 0, dL, P, cost_only); KIND(6);
+        LAUNCH(ba_big_schur_kernel, dim3(L.nts + 1 + BA_BIG_ZERO_BLOCKS, L.nwin), dim3(256), 0, dL, P, cost_only); KIND(6);
         REDUCE(P.rb1, n1);
         if (cost_only) break;
         LAUNCH(ba_solve_big_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P); KIND(7);
+        LAUNCH(ba_big_landmark_kernel, dim3(BA_BIG_LM_BLOCKS, L.nwin), dim3(256), 0, dL, P); KIND(8);
         REDUCE(P.rb2, n2);
         LAUNCH(ba_big_step_kernel, dim3(L.nwin), dim3(BA_NT), 0, dL, P); KIND(8);
     }
