@@ -10,5 +10,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT" -o "$TAG" -- python "$ROOT/bench.py" "$@" > "$OUT/bench.log" 2>&1
 DB=$(find "$OUT" -name '*.db' | head -1)
 python "$ROOT/profiles/summarize_rocpd.py" "$DB" > "$ROOT/gpurun_out/${TAG}_kernel_trace_stats.txt" 2>&1
-tail -1 "$OUT/bench.log" > "$ROOT/gpurun_out/${TAG}_bench.json"
+grep "^{" "$OUT/bench.log" | tail -1 > "$ROOT/gpurun_out/${TAG}_bench.json"
 cat "$ROOT/gpurun_out/${TAG}_kernel_trace_stats.txt"
