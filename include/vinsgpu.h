@@ -129,6 +129,10 @@ typedef struct {
     double tr;                   /* TR  rolling-shutter read-out time                               */
     double row;                  /* ROW image height                                                */
     double g_norm;               /* G = (0,0,g_norm)                                                */
+    double max_solver_time_s;    /* SOLVER_TIME (estimator.cpp:812-815: options.max_solver_time_in_seconds); 0 = no
+                                  * cap.  Checked on the device clock before every trust-region iteration, like Ceres does
+                                  * on the host clock: termination stays NO_CONVERGENCE.  A cap makes the result depend on
+                                  * timing; it is ignored while an all-reduce hook is installed (ranks must agree).        */
 } vg_ba_problem;
 
 /* Optimised state, AFTER Estimator::double2vector()'s gauge fix and the vector2double() repack

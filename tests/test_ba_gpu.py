@@ -252,18 +252,18 @@ def test_marginalize_second_new_keeps_old_prior_when_pose_absent(handle):
 
 
 # ---------------------------------------------------------------------------------------- edge cases / full size
-def test_relocalisation_factors(handle):
-    """estimator.cpp:769-801: extra ProjectionFactors to a relocalisation pose (an extra pose block)."""
-    seq = synth.SyntheticSequence(51, L=40)
+def relocalisation_problem(seed=51, loop_frame=3):
+    """A window with relocalisation factors: loop frame = a perturbed copy of frame `loop_frame`, matches for landmarks whose
+    track starts at or before it (estimator.cpp:781)."""
+    seq = synth.SyntheticSequence(seed, L=40)
     prob = seq.window(0)
-    # loop frame = a perturbed copy of frame 3; matches for landmarks whose track starts at or before frame 3
-    relo_pose = prob['pose'][3].copy()
+    relo_pose = prob['pose'][loop_frame].copy()
     relo_pose[:3] += [0.05, -0.03, 0.02]
     match = []
     c = seq.cfg
     Rr, Pr = B.q2R(relo_pose[3:]), relo_pose[:3]
     for l in range(len(prob['inv_depth'])):
-        if prob['lm_start'][l] <= 3 and len(match) < 15:
+        if prob['lm_start'][l] <= loop_frame and len(match) < 15:
             s = int(prob['lm_start'][l])
             o = prob['obs'][int(prob['obs_off'][l])]
             pc = np.array([o[0], o[1], 1.0]) / prob['inv_depth'][l]
@@ -271,6 +271,12 @@ def test_relocalisation_factors(handle):
             p = c['ric'].T @ (Rr.T @ (Xw - Pr) - c['tic'])
             match.append((l, p[0] / p[2], p[1] / p[2]))
     prob['relo'] = dict(pose=relo_pose, match=match)
+    return prob
+
+
+def test_relocalisation_factors(handle):
+    """estimator.cpp:769-801: extra ProjectionFactors to a relocalisation pose (an extra pose block)."""
+    prob = relocalisation_problem()
     x, summ = B.solve(prob)
     ref = B.double2vector(prob, x)
     st, sm, _ = handle.ba_optimize(prob)
@@ -467,3 +473,17 @@ def test_triangulate_on_device(handle):
     assert (r2[0] == 7.5) == (g2[0] == 7.5)
     with pytest.raises(RuntimeError, match="status -1"):
         handle.triangulate(Ps, Rs.reshape(K, 9), c['tic'], c['ric'], [K - 1], [3], [0], pts)
+
+
+def test_solver_time_cap(handle):
+    """SOLVER_TIME (estimator.cpp:812-815, options.max_solver_time_in_seconds): the cap is tested on the device clock before every
+    iteration.  A cap far above the solve changes nothing; an expired cap ends the solve NO_CONVERGENCE at the current point."""
+    prob = synth.SyntheticSequence(12, L=40).window(0)
+    st0, sm0, _ = handle.ba_optimize(prob)
+    st1, sm1, _ = handle.ba_optimize(dict(prob, max_solver_time_s=10.0))
+    assert sm1['num_iterations'] == sm0['num_iterations'] and np.array_equal(st0['pose'], st1['pose'])
+    st2, sm2, _ = handle.ba_optimize(dict(prob, max_solver_time_s=1e-9))
+    assert sm2['status'] == 0 and sm2['termination'] == sm0['termination'] == 0      # NO_CONVERGENCE, as after max_iters
+    assert sm2['num_iterations'] == 0 and sm2['final_cost'] == sm2['initial_cost'] == sm0['initial_cost']
+    ref = B.double2vector(prob, dict(pose=prob['pose'], sb=prob['sb'], ex=prob['ex'], td=prob['td'], inv_depth=prob['inv_depth']))
+    assert np.abs(st2['pose'] - ref['pose']).max() < 1e-12

@@ -199,3 +199,42 @@ def test_estimator_shim_drops_the_prior_after_a_numeric_failure(handle):
                                            J0.ctypes.data_as(dp), r0.ctypes.data_as(dp), C.byref(iters))
     assert rc == 0
     assert pn.value == 0 and pnb.value == 0          # neither the old prior (it was set on entry) nor a new one
+
+
+def test_estimator_shim_relocalisation_by_products(handle):
+    """estimator.cpp:769-801 + :596-616 through the drop-in Estimator: match_points / relo_Pose as setReloFrame() leaves them ->
+    the matched landmarks' factors reach the device, and double2vector() forms relo_relative_t / q / yaw and drift_correct_r / t
+    from the gauge-fixed loop pose the device returns.  Expected values: the reference's expressions restated in NumPy on
+    the direct-ABI result."""
+    from test_ba_gpu import relocalisation_problem
+    from oracle import ba_numpy as B
+    lib = C.CDLL(os.path.join(LIBDIR, "libvins_host.so"))
+    prob = relocalisation_problem(loop_frame=3)
+    st, sm, _ = handle.ba_optimize(prob)
+    assert sm['status'] == 0
+    pk = ba.PackedProblem(prob)
+    K = pk.K
+    prev_t = np.array([0.3, -0.2, 0.1])
+    yaw0 = np.deg2rad(12.0)
+    prev_r = np.array([[np.cos(yaw0), -np.sin(yaw0), 0], [np.sin(yaw0), np.cos(yaw0), 0], [0, 0, 1.0]])
+    pose, fixed, rt, rq, ryaw, dr, dt = np.zeros((K, 7)), np.zeros(7), np.zeros(3), np.zeros(4), C.c_double(), np.zeros(9), np.zeros(3)
+    dp = C.POINTER(C.c_double)
+    rc = lib.vins_host_estimator_relo_roundtrip(C.byref(pk.struct), 3, prev_t.ctypes.data_as(dp), np.ascontiguousarray(prev_r).ctypes.data_as(dp),
+                                                pose.ctypes.data_as(dp), fixed.ctypes.data_as(dp), rt.ctypes.data_as(dp), rq.ctypes.data_as(dp),
+                                                C.byref(ryaw), dr.ctypes.data_as(dp), dt.ctypes.data_as(dp))
+    assert rc == 0
+    assert np.abs(pose - st['pose']).max() < 1e-9 and np.abs(fixed - st['relo_pose']).max() < 1e-9
+
+    def yaw_deg(R):
+        return np.rad2deg(np.arctan2(R[1, 0], R[0, 0]))
+    relo_r, relo_t = B.q2R(st['relo_pose'][3:]), st['relo_pose'][:3]
+    R3, P3 = B.q2R(st['pose'][3][3:]), st['pose'][3][:3]
+    assert np.allclose(rt, relo_r.T @ (P3 - relo_t), atol=1e-9)
+    Rrel = B.q2R(rq)
+    assert np.allclose(Rrel, relo_r.T @ R3, atol=1e-9)
+    d = yaw_deg(R3) - yaw_deg(relo_r)
+    d = d - 360.0 * np.floor((d + 180.0) / 360.0) if d > 0 else d + 360.0 * np.floor((-d + 180.0) / 360.0)
+    assert abs(ryaw.value - d) < 1e-9
+    dy = np.deg2rad(yaw_deg(prev_r) - yaw_deg(relo_r))
+    Rd = np.array([[np.cos(dy), -np.sin(dy), 0], [np.sin(dy), np.cos(dy), 0], [0, 0, 1.0]])
+    assert np.allclose(dr.reshape(3, 3), Rd, atol=1e-9) and np.allclose(dt, prev_t - Rd @ relo_t, atol=1e-9)

@@ -95,3 +95,15 @@ def test_emulated_enlarged_window_31_frames(simt_handle):
     assert np.abs(st['pose'] - st_o['pose']).max() < 1e-4 * max(1.0, np.abs(st_o['pose'][:, :3]).max())
     assert np.abs(st['sb'] - st_o['sb']).max() < 1e-4 * max(1.0, np.abs(st_o['sb']).max())
     assert np.allclose(st['inv_depth'], st_o['inv_depth'], rtol=1e-4, atol=1e-6)
+
+
+def test_emulated_solver_time_cap(simt_handle):
+    """vg_ba_problem::max_solver_time_s under emulation (both solve kernels): an expired cap stops before the first iteration."""
+    prob = synth.SyntheticSequence(12, L=20).window(0)
+    for large in (False, True):
+        simt_handle.ba_set_large_window(large)
+        try:
+            st, sm, _ = simt_handle.ba_optimize(dict(prob, max_solver_time_s=1e-9))
+        finally:
+            simt_handle.ba_set_large_window(False)
+        assert sm['status'] == 0 and sm['num_iterations'] == 0 and sm['final_cost'] == sm['initial_cost']

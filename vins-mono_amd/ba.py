@@ -29,7 +29,8 @@ class Problem(C.Structure):
                 ("prior_J0", _pd), ("prior_r0", _pd), ("prior_x0", _pd),
                 ("relo_n", C.c_int), ("relo_pose", _pd), ("relo_lm", _pi), ("relo_xy", _pd),
                 ("estimate_extrinsic", C.c_int), ("estimate_td", C.c_int), ("max_iters", C.c_int),
-                ("focal", C.c_double), ("tr", C.c_double), ("row", C.c_double), ("g_norm", C.c_double)]
+                ("focal", C.c_double), ("tr", C.c_double), ("row", C.c_double), ("g_norm", C.c_double),
+                ("max_solver_time_s", C.c_double)]
 
 
 class State(C.Structure):
@@ -110,6 +111,7 @@ class PackedProblem:
             p.relo_n, p.relo_pose, p.relo_lm, p.relo_xy = len(relo['match']), _dp(k['relo_pose']), _ip(k['relo_lm']), _dp(k['relo_xy'])
         p.estimate_extrinsic, p.estimate_td, p.max_iters = int(prob['estimate_extrinsic']), int(prob['estimate_td']), int(prob['max_iters'])
         p.focal, p.tr, p.row, p.g_norm = float(prob['focal']), float(prob['tr']), float(prob['row']), float(prob['g_norm'])
+        p.max_solver_time_s = float(prob.get('max_solver_time_s', 0.0))
         self.struct = p
         self.has_relo = relo is not None
 

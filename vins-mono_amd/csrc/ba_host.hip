@@ -5,6 +5,7 @@
 // The packing replaces the ceres::Problem construction of Estimator::optimization()
 // (estimator.cpp:672-764, :769-801): instead of `new`-ing one cost-function object per residual it
 // writes structure-of-arrays tables (factor list, per-chunk pair-sorted slot table, prior block map).
+#include "vg_range.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -409,6 +410,7 @@ static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, 
     }
     di[L.do_par + P_FOCAL] = p->focal; di[L.do_par + P_TR] = p->tr; di[L.do_par + P_ROW] = p->row;
     di[L.do_par + P_GNORM] = p->g_norm;
+    di[L.do_par + P_MAXTIME] = (p->max_solver_time_s > 0.0 && !h->ba.allreduce) ? p->max_solver_time_s : 0.0;
     return VG_OK;
 }
 
@@ -424,6 +426,7 @@ static int ensure(vg_handle* h, T*& ptr, size_t& cap, size_t need) {
 }
 
 extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* const* in, const int* margin_flags) {
+    VG_RANGE("vg_ba_batch_upload");
     if (!h || nwin <= 0 || !in) return VG_ERR_BAD_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     BaLayout L;
@@ -568,6 +571,7 @@ static int launch_solve(vg_handle* h, hipEvent_t* ev = nullptr, int* kinds = nul
 }
 
 extern "C" int vg_ba_batch_run_async(vg_handle* h) {
+    VG_RANGE("vg_ba_batch_run_async");
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
     const int rc = launch_solve(h);
@@ -674,6 +678,7 @@ extern "C" int vg_ba_batch_info(vg_handle* h, double* flops, double* bytes_in, d
 
 extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_summary* sum,
                                     vg_ba_prior* const* pri) {
+    VG_RANGE("vg_ba_batch_download");
     if (!h || !h->ba.uploaded || nwin != h->ba.nwin) return VG_ERR_BAD_ARG;
     BaBatch& B = h->ba;
     const BaLayout& L = B.L;
@@ -754,6 +759,7 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
 
 extern "C" int vg_ba_optimize(vg_handle* h, const vg_ba_problem* in, int margin_flag, vg_ba_state* out_state,
                               vg_ba_summary* out_summary, vg_ba_prior* out_prior) {
+    VG_RANGE("vg_ba_optimize");
     if (!h || !in) return VG_ERR_BAD_ARG;
     const vg_ba_problem* arr[1] = {in};
     int rc = vg_ba_batch_upload(h, 1, arr, &margin_flag);

@@ -29,7 +29,9 @@ enum {
     C_GNN2, C_GTGN, C_DNORM, C_MODEL, C_CUR, C_PENDING, C_DONE, C_STEPNORM, C_XNORMC, C_INITCOST, C_SCALED, C_QCAM,
     // large-window path only: phase of the round (0 nothing to do, 1 Gauss-Newton step solved, 2 step reuse), the camera /
     // speed-bias shares of |gn|^2, gt.gn, |x - x_cand|^2, |x_cand|^2 (the landmark shares travel through the reduce buffers)
-    C_PHASE, C_GNN2C, C_GTGNC, C_STEP2C, C_XN2C, C_NCTL = 32
+    C_PHASE, C_GNN2C, C_GTGNC, C_STEP2C, C_XN2C,
+    C_T0,                          // device wall clock at the start of the solve (vg_ba_problem::max_solver_time_s)
+    C_NCTL = 32
 };
 
 // reduce buffer 1 of the large-window path, per window:  [Sp  Rc(Rc+1)/2 | gp  Rc | T  (Rc+1)(Rc+2)/2 | scalars RB1_NSCAL]
@@ -101,4 +103,4 @@ struct BaPtrs {
 };
 
 // parameter slots at do_par
-enum { P_FOCAL = 0, P_TR, P_ROW, P_GNORM, P_NPAR = 8 };
+enum { P_FOCAL = 0, P_TR, P_ROW, P_GNORM, P_MAXTIME, P_NPAR = 8 };

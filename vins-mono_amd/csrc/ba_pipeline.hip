@@ -114,6 +114,22 @@ DEV const double* st_ex(const BaLayout& L, const double* x) { return x + 7 * L.K
 
 DEV double* lin_buf(const Ctx& c, int which) { return c.sc + c.Lp->so_buf + (size_t)which * c.Lp->buf_stride; }
 
+// vg_ba_problem::max_solver_time_s against the device's constant-rate wall clock (100 MHz on gfx950; the CPU emulation of
+// tests/simt counts nanoseconds).  The clock is read by ONE thread and the verdict handed to the workgroup through LDS:
+// wavefronts read the clock at different instants and must not disagree about a branch that contains barriers.
+#ifdef VINS_SIMT
+#define BA_WALL_HZ 1e9
+#else
+#define BA_WALL_HZ 1e8
+#endif
+DEV bool time_is_up(const double* ctl, double max_s, double* lds_slot, int tid) {
+    if (max_s <= 0.0) return false;                // (uniform: a kernel argument of the window)
+    __syncthreads();
+    if (tid == 0) *lds_slot = ((double)wall_clock64() - ctl[C_T0]) >= max_s * BA_WALL_HZ ? 1.0 : 0.0;
+    __syncthreads();
+    return *lds_slot != 0.0;
+}
+
 // ---- solver state carried between launches -----------------------------------------------------------------------
 struct Ctl {
     int it, nacc, ninv, term, status, reuse, cur, pending, done, scaled, phase;
@@ -242,6 +258,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
         double v = 0.0;
         if (c.tid == C_RADIUS) v = 1e4;
         if (c.tid == C_MU || c.tid == C_MUSOLVED) v = 1e-8;
+        if (c.tid == C_T0) v = (double)wall_clock64();
         c.sc[L.so_ctl + c.tid] = v;
     }
     imu_sqrt_info(c);
@@ -1645,8 +1662,10 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     double* lamc = c.sc + L.so_lam + (s.cur ^ 1) * L.Lcap;
     const double min_mu = 1e-8, max_mu = 1.0;
     (void)min_mu;
+    // SOLVER_TIME cap (estimator.cpp:812-815): Ceres tests it before every iteration; past it the solve ends NO_CONVERGENCE
+    const bool timed_out = time_is_up(ctlp, c.di[L.do_par + P_MAXTIME], m.red + 30, c.tid);
 
-    while (s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK && s.it < max_iters) {
+    while (s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK && s.it < max_iters && !timed_out) {
         ++s.it;
         const int slot = s.it - 1;
         bool ok = true;
@@ -2330,7 +2349,8 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     const double* hh = buf + L.bo_h;
     const double* bb = buf + L.bo_b;
     const bool running = s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK;
-    const bool trip = running && (phase_in == 3 || s.it < max_iters);
+    const bool timed_out = time_is_up(ctlp, c.di[L.do_par + P_MAXTIME], m.red + 30, c.tid);
+    const bool trip = running && !timed_out && (phase_in == 3 || s.it < max_iters);
     const bool need_system = running && (fresh_point || (trip && !s.reuse));
     if (need_system) {
         const int ntri = Rc * (Rc + 1) / 2;
@@ -2413,7 +2433,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
             if (!cok) big_solve_failed(s, L, out, iout, c.tid, true);
         }
     }
-    if (s.term != VG_TERM_NO_CONVERGENCE || s.status != VG_OK || (s.phase == 0 && s.it >= max_iters)) s.done = 1;
+    if (s.term != VG_TERM_NO_CONVERGENCE || s.status != VG_OK || (s.phase == 0 && (s.it >= max_iters || timed_out))) s.done = 1;
     __syncthreads();
     if (c.tid == 0) ctl_store(s, ctlp);
 }

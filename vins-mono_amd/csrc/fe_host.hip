@@ -1,6 +1,7 @@
 // fe_host.hip — host side of the front-end path behind the C-ABI (include/vinsgpu.h, vg_fe_*): owns the per-camera
 // pyramids / point / corner buffers in HBM, launches the kernels of fe_kernels.hip on the handle's stream.
 // Replaces the OpenCV calls of FeatureTracker::readImage (feature_tracker/src/feature_tracker.cpp:87-93, :113, :149).
+#include "vg_range.h"
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstring>
@@ -145,6 +146,7 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
 }
 
 extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int stride) {
+    VG_RANGE("vg_fe_upload_frames");
     if (!h || !h->fe || !imgs) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
     const size_t npix = (size_t)s->W * s->H;
@@ -168,6 +170,7 @@ extern "C" int vg_fe_select_frames(vg_handle* h, int slot) {
 }
 
 extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
+    VG_RANGE("vg_fe_build_async");
     if (!h || !h->fe) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
     if (equalize && (s->d.W % 8 || s->d.H % 8)) { h->err = "CLAHE needs width and height divisible by 8"; return VG_ERR_UNSUPPORTED; }
@@ -201,6 +204,7 @@ extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
 }
 
 extern "C" int vg_fe_push_frames(vg_handle* h, const uint8_t* const* imgs, int stride, int equalize) {
+    VG_RANGE("vg_fe_push_frames");
     int rc = vg_fe_upload_frames(h, imgs, stride);
     if (rc) return rc;
     rc = vg_fe_build_async(h, equalize);
@@ -223,6 +227,7 @@ extern "C" int vg_fe_track_upload(vg_handle* h, const float* prev_xy, const int*
 }
 
 extern "C" int vg_fe_track_async(vg_handle* h) {
+    VG_RANGE("vg_fe_track_async");
     if (!h || !h->fe) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
     int nmax = 0;
@@ -245,6 +250,7 @@ extern "C" int vg_fe_track_download(vg_handle* h, float* next_xy, uint8_t* statu
 }
 
 extern "C" int vg_fe_track(vg_handle* h, int cam, const float* prev_xy, int n, float* next_xy, uint8_t* status, float* err) {
+    VG_RANGE("vg_fe_track");
     if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || n < 0 || n > h->fe->max_pts || (n && (!prev_xy || !next_xy || !status)))
         return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
@@ -281,6 +287,7 @@ extern "C" int vg_fe_detect_upload(vg_handle* h, const uint8_t* const* masks, co
 }
 
 extern "C" int vg_fe_detect_async(vg_handle* h, double quality, double min_dist) {
+    VG_RANGE("vg_fe_detect_async");
     if (!h || !h->fe) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
     const FeDev& d = s->d;
@@ -306,6 +313,7 @@ extern "C" int vg_fe_detect_download(vg_handle* h, float* out_xy, int* out_n) {
 
 extern "C" int vg_fe_detect(vg_handle* h, int cam, const uint8_t* mask, int max_corners, double quality, double min_dist,
                             float* out_xy, int* out_n) {
+    VG_RANGE("vg_fe_detect");
     if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || !out_xy || !out_n || max_corners < 0 || max_corners > h->fe->max_pts)
         return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
@@ -330,6 +338,7 @@ extern "C" int vg_fe_detect(vg_handle* h, int cam, const uint8_t* mask, int max_
 // ---- FeatureTracker::setMask on the device (feature_tracker.cpp:36-69)
 extern "C" int vg_fe_set_mask(vg_handle* h, const float* pts_xy, const int* track_cnt, const int* n, const uint8_t* const* base_masks,
                               int radius, int* kept_index, int* n_kept) {
+    VG_RANGE("vg_fe_set_mask");
     if (!h || !h->fe || !pts_xy || !track_cnt || !n || !kept_index || !n_kept || radius < 0) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
     if (s->max_pts > 2048) { h->err = "vg_fe_set_mask: max_points > 2048"; return VG_ERR_UNSUPPORTED; }
@@ -375,6 +384,7 @@ extern "C" int vg_fe_set_mask(vg_handle* h, const float* pts_xy, const int* trac
 
 // goodFeaturesToTrack with the mask vg_fe_set_mask left on the device (no mask upload)
 extern "C" int vg_fe_detect_masked(vg_handle* h, int cam, int max_corners, double quality, double min_dist, float* out_xy, int* out_n) {
+    VG_RANGE("vg_fe_detect_masked");
     if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || !out_xy || !out_n || max_corners < 0 || max_corners > h->fe->max_pts)
         return VG_ERR_BAD_ARG;
     FeState* s = h->fe;

@@ -13,6 +13,7 @@
 // 8-point algorithm.  All hypotheses run in parallel, one thread each: the 8 x 9 design matrix and the accumulated right
 // singular vectors live in thread-private LDS columns ([element][thread], conflict-free), the null vector comes from a
 // one-sided Jacobi SVD (as in triangulate.hip).
+#include "vg_range.h"
 #include <hip/hip_runtime.h>
 #include <string>
 #include <vector>
@@ -196,6 +197,7 @@ extern "C" __global__ __launch_bounds__(FE_RANSAC_HYP) void fe_ransac_pick_kerne
 
 extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const float* forw_un_xy, int n, double threshold, uint8_t* status,
                                    int* n_inliers, double* F_out) {
+    VG_RANGE("vg_fe_reject_with_f");
     if (!h || n < 0 || (n && (!cur_un_xy || !forw_un_xy || !status)) || !(threshold > 0)) return VG_ERR_BAD_ARG;
     if (n < 8) { h->err = "vg_fe_reject_with_f: fewer than 8 correspondences"; return VG_ERR_BAD_ARG; }
     if (n > FE_RANSAC_MAXPTS) { h->err = "vg_fe_reject_with_f: more than 1024 correspondences"; return VG_ERR_UNSUPPORTED; }

@@ -9,6 +9,7 @@
 //   jacobian <- F jacobian,   covariance <- F covariance F^T + V diag(noise) V^T
 // entry-wise (225 entries over 64 lanes, k ascending like a plain triple loop).  repropagate() is the same
 // computation started from the stored first sample with new linearisation biases, so one entry point serves both.
+#include "vg_range.h"
 #include <hip/hip_runtime.h>
 #include <vector>
 #include "ba_math.h"
@@ -154,6 +155,7 @@ extern "C" __global__ __launch_bounds__(64) void imu_preint_kernel(int n, const 
 // C-ABI: see include/vinsgpu.h
 extern "C" int vg_imu_preintegrate(vg_handle* h, int n_intervals, const int* sample_off, const double* samples, const double* first,
                                    const double* bias, const double* noise, vg_imu_preint* out) {
+    VG_RANGE("vg_imu_preintegrate");
     if (!h || n_intervals <= 0 || !sample_off || !samples || !first || !bias || !noise || !out) return VG_ERR_BAD_ARG;
     if (sample_off[0] != 0) { h->err = "vg_imu_preintegrate: sample_off[0] must be 0"; return VG_ERR_BAD_ARG; }
     for (int k = 0; k < n_intervals; ++k)

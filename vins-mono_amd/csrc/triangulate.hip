@@ -7,6 +7,7 @@
 // its right singular vector of the smallest singular value comes from a one-sided (Hestenes) Jacobi SVD on the four
 // columns — the same quantity the reference takes from Eigen::JacobiSVD(...).matrixV().rightCols<1>() (:244);
 // depth = v[2] / v[3], replaced by INIT_DEPTH when < 0.1 (:245-254).
+#include "vg_range.h"
 #include <hip/hip_runtime.h>
 #include <vector>
 #include "ba_math.h"
@@ -103,6 +104,7 @@ extern "C" __global__ __launch_bounds__(64) void triangulate_kernel(int K, const
 extern "C" int vg_triangulate(vg_handle* h, int K, const double* Ps, const double* Rs, const double* tic, const double* ric, int L,
                               const int* start, const int* nobs, const int* obs_off, const double* points, double init_depth,
                               double* depth) {
+    VG_RANGE("vg_triangulate");
     if (!h || K < 1 || !Ps || !Rs || !tic || !ric || L < 0 || (L > 0 && (!start || !nobs || !obs_off || !points || !depth))) return VG_ERR_BAD_ARG;
     if (L == 0) return VG_OK;
     size_t npt = 0;

@@ -2,6 +2,7 @@
 // vins_estimator/src/estimator.cpp:486-619; optimization() follows :670-1003 with the ceres::Problem, ceres::Solve
 // and the MarginalizationInfo machinery replaced by ONE call of vg_ba_optimize (solve + gauge fix + marginalization).
 #include "estimator.h"
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -114,6 +115,26 @@ void Estimator::vector2double() {                               // estimator.cpp
     if (ESTIMATE_TD) para_Td[0][0] = td;
 }
 
+// Utility::R2ypr / ypr2R / normalizeAngle (vins_estimator/src/utility/utility.h:70-143), degrees
+static Vector3d R2ypr_deg(const Matrix3d& R) {
+    const double n0 = R(0, 0), n1 = R(1, 0), n2 = R(2, 0), o0 = R(0, 1), o1 = R(1, 1), a0 = R(0, 2), a1 = R(1, 2);
+    const double y = atan2(n1, n0);
+    const double p = atan2(-n2, n0 * cos(y) + n1 * sin(y));
+    const double r = atan2(a0 * sin(y) - a1 * cos(y), -o0 * sin(y) + o1 * cos(y));
+    return Vector3d(y / M_PI * 180.0, p / M_PI * 180.0, r / M_PI * 180.0);
+}
+static Matrix3d yaw2R_deg(double yaw_deg) {
+    const double y = yaw_deg / 180.0 * M_PI;
+    Matrix3d R;
+    R(0, 0) = cos(y); R(0, 1) = -sin(y); R(0, 2) = 0;
+    R(1, 0) = sin(y); R(1, 1) = cos(y);  R(1, 2) = 0;
+    R(2, 0) = 0;      R(2, 1) = 0;       R(2, 2) = 1;
+    return R;
+}
+static double normalize_angle_deg(double a) {
+    return a > 0 ? a - 360.0 * std::floor((a + 180.0) / 360.0) : a + 360.0 * std::floor((-a + 180.0) / 360.0);
+}
+
 void Estimator::double2vector() {
     // estimator.cpp:530-619.  The yaw / position gauge fix (:541-577) is applied on the device (vg_ba_state is
     // post-fix), so this only converts the para_* arrays back to the Eigen members and the depths (setDepth, :141-159).
@@ -136,6 +157,21 @@ void Estimator::double2vector() {
         it.solve_flag = it.estimated_depth < 0 ? 2 : 1;
     }
     if (ESTIMATE_TD) td = para_Td[0][0];
+    if (relocalization_info && !relo_in_problem) relocalization_info = false;   // no matched landmark was optimised: nothing to report
+    if (relocalization_info) {
+        // relative pose between the two loop frames (:596-616).  relo_Pose comes back from the device already in the fixed
+        // gauge (rot_diff * (p - P0) + origin_P0, rot_diff * R): it IS the reference's relo_r / relo_t
+        const Matrix3d relo_r = Quaterniond(relo_Pose[6], relo_Pose[3], relo_Pose[4], relo_Pose[5]).toRotationMatrix();
+        const Vector3d relo_t(relo_Pose[0], relo_Pose[1], relo_Pose[2]);
+        relo_r_fixed = relo_r; relo_t_fixed = relo_t;
+        const double drift_correct_yaw = R2ypr_deg(prev_relo_r).x() - R2ypr_deg(relo_r).x();
+        drift_correct_r = yaw2R_deg(drift_correct_yaw);
+        drift_correct_t = prev_relo_t - drift_correct_r * relo_t;
+        relo_relative_t = relo_r.transpose() * (Ps[relo_frame_local_index] - relo_t);
+        relo_relative_q = Quaterniond(relo_r.transpose() * Rs[relo_frame_local_index]);
+        relo_relative_yaw = normalize_angle_deg(R2ypr_deg(Rs[relo_frame_local_index]).x() - R2ypr_deg(relo_r).x());
+        relocalization_info = false;
+    }
 }
 
 void Estimator::optimization() {
@@ -157,6 +193,27 @@ void Estimator::optimization() {
         }
     }
     const int L = (int)lm_start.size();
+    // relocalisation factors (:769-801): ProjectionFactor(first observation, matched point) on (para_Pose[start], relo_Pose,
+    // ex, depth) for every optimised landmark that started at or before the loop frame and has a match (match_points are
+    // sorted by feature id, like f_manager.feature)
+    vector<int> relo_lm;
+    vector<double> relo_xy;
+    if (relocalization_info) {
+        size_t retrive = 0;
+        int feature_index = -1;
+        for (auto& it : f_manager.feature) {
+            if (!(it.used_num >= 2 && it.start_frame < WINDOW_SIZE - 2)) continue;
+            ++feature_index;
+            if (it.start_frame > relo_frame_local_index) continue;
+            while (retrive < match_points.size() && (int)match_points[retrive].z() < it.feature_id) ++retrive;
+            if (retrive < match_points.size() && (int)match_points[retrive].z() == it.feature_id) {
+                relo_lm.push_back(feature_index);
+                relo_xy.push_back(match_points[retrive].x());
+                relo_xy.push_back(match_points[retrive].y());
+                ++retrive;
+            }
+        }
+    }
     vector<vg_imu_preint> imu(K - 1);
     for (int i = 0; i < WINDOW_SIZE; i++) {                      // IMUFactor(pre_integrations[j]), j = i + 1 (:711-718)
         const IntegrationBase* p = pre_integrations[i + 1];
@@ -195,13 +252,17 @@ void Estimator::optimization() {
         pb.prior_block_kind = pkind.data(); pb.prior_block_index = pindex.data();
         pb.prior_J0 = pJ0.data(); pb.prior_r0 = mi->linearized_residuals.data(); pb.prior_x0 = px0.data();
     }
+    relo_in_problem = relocalization_info && !relo_lm.empty();
+    if (relo_in_problem) {
+        pb.relo_n = (int)relo_lm.size(); pb.relo_pose = relo_Pose; pb.relo_lm = relo_lm.data(); pb.relo_xy = relo_xy.data();
+    }
     pb.estimate_extrinsic = ESTIMATE_EXTRINSIC ? 1 : 0; pb.estimate_td = ESTIMATE_TD ? 1 : 0; pb.max_iters = NUM_ITERATIONS;
     pb.focal = FOCAL_LENGTH_D; pb.tr = TR; pb.row = ROW_D; pb.g_norm = G_NORM;
     // ---- outputs
     vector<double> lam(L > 0 ? L : 1);
     vg_ba_state st;
     st.pose = &para_Pose[0][0]; st.speedbias = &para_SpeedBias[0][0]; st.ex_pose = &para_Ex_Pose[0][0]; st.td = &para_Td[0][0];
-    st.inv_depth = lam.data(); st.relo_pose = nullptr;
+    st.inv_depth = lam.data(); st.relo_pose = pb.relo_n ? relo_Pose : nullptr;
     const int cap = 6 * K + 32, capb = K + 8;
     vector<int> nkind(capb), nindex(capb);
     vector<double> nJ0((size_t)cap * cap), nr0(cap), nx0(9 * capb);      // x0 holds 9 doubles per block at most (speed-bias)

@@ -73,6 +73,17 @@ class Estimator {
     double para_Pose[WINDOW_SIZE + 1][7], para_SpeedBias[WINDOW_SIZE + 1][9], para_Feature[NUM_OF_F][1], para_Ex_Pose[NUM_OF_CAM][7], para_Td[1][1];
     MarginalizationInfo* last_marginalization_info = nullptr;
     vector<double*> last_marginalization_parameter_blocks;      // para_* address of every kept block, already shifted (estimator.h:117)
+    // relocalisation (estimator.h:125-138): setReloFrame() of the surrounding reference code fills the inputs, optimization()
+    // adds the matched landmarks' factors against relo_Pose (:769-801), double2vector() leaves the by-products (:596-616)
+    bool relocalization_info = false;
+    int relo_frame_local_index = 0;
+    vector<Vector3d> match_points;             // (x, y, feature_id), ascending feature_id
+    double relo_Pose[7];
+    Matrix3d drift_correct_r, prev_relo_r, relo_r_fixed;
+    Vector3d drift_correct_t, prev_relo_t, relo_relative_t, relo_t_fixed;
+    Quaterniond relo_relative_q;
+    double relo_relative_yaw = 0;
+    bool relo_in_problem = false;              // the last optimization() carried relocalisation factors
     Matrix3d back_R0;
     Vector3d back_P0;
     bool solver_failed = false;    // the device reported a non-finite solve: the prior was dropped (see optimization())

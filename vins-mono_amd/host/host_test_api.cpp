@@ -109,3 +109,73 @@ extern "C" int vins_host_estimator_roundtrip(const vg_ba_problem* p, int margin_
     }
     return 0;
 }
+
+
+// The same round trip with relocalisation (estimator.cpp:769-801 + :596-616): p->relo_* become match_points / relo_Pose the
+// way setReloFrame() would leave them; outputs = the by-products double2vector() computes + the gauge-fixed loop pose.
+extern "C" int vins_host_estimator_relo_roundtrip(const vg_ba_problem* p, int relo_frame_local_index, const double* prev_relo_t /*3*/,
+                                                  const double* prev_relo_r /*9 row-major*/, double* pose_out /*K*7*/,
+                                                  double* relo_fixed /*7: t, q(x y z w)*/, double* relative_t /*3*/, double* relative_q /*4 x y z w*/,
+                                                  double* relative_yaw, double* drift_r /*9 row-major*/, double* drift_t /*3*/) {
+    if (p->K != WINDOW_SIZE + 1 || p->relo_n <= 0) return -1;
+    Estimator est;
+    ESTIMATE_EXTRINSIC = p->estimate_extrinsic; ESTIMATE_TD = p->estimate_td; NUM_ITERATIONS = p->max_iters;
+    TR = p->tr; ROW_D = p->row; FOCAL_LENGTH_D = p->focal; G_NORM = p->g_norm;
+    for (int i = 0; i <= WINDOW_SIZE; ++i) {
+        est.Ps[i] = Vector3d(p->pose[7 * i], p->pose[7 * i + 1], p->pose[7 * i + 2]);
+        est.Rs[i] = Quaterniond(p->pose[7 * i + 6], p->pose[7 * i + 3], p->pose[7 * i + 4], p->pose[7 * i + 5]).toRotationMatrix();
+        est.Vs[i] = Vector3d(p->speedbias[9 * i], p->speedbias[9 * i + 1], p->speedbias[9 * i + 2]);
+        est.Bas[i] = Vector3d(p->speedbias[9 * i + 3], p->speedbias[9 * i + 4], p->speedbias[9 * i + 5]);
+        est.Bgs[i] = Vector3d(p->speedbias[9 * i + 6], p->speedbias[9 * i + 7], p->speedbias[9 * i + 8]);
+    }
+    est.tic[0] = Vector3d(p->ex_pose[0], p->ex_pose[1], p->ex_pose[2]);
+    est.ric[0] = Quaterniond(p->ex_pose[6], p->ex_pose[3], p->ex_pose[4], p->ex_pose[5]).toRotationMatrix();
+    est.td = p->td;
+    IntegrationBase pre[WINDOW_SIZE + 1];
+    for (int k = 0; k < WINDOW_SIZE; ++k) {
+        const vg_imu_preint& m = p->imu[k];
+        IntegrationBase& q = pre[k + 1];
+        q.sum_dt = m.sum_dt;
+        q.delta_p = Vector3d(m.delta_p[0], m.delta_p[1], m.delta_p[2]); q.delta_v = Vector3d(m.delta_v[0], m.delta_v[1], m.delta_v[2]);
+        q.linearized_ba = Vector3d(m.linearized_ba[0], m.linearized_ba[1], m.linearized_ba[2]);
+        q.linearized_bg = Vector3d(m.linearized_bg[0], m.linearized_bg[1], m.linearized_bg[2]);
+        q.delta_q = Quaterniond(m.delta_q[3], m.delta_q[0], m.delta_q[1], m.delta_q[2]);
+        for (int r = 0; r < 15; ++r)
+            for (int c = 0; c < 15; ++c) { q.jacobian(r, c) = m.jacobian[r * 15 + c]; q.covariance(r, c) = m.covariance[r * 15 + c]; }
+        est.pre_integrations[k + 1] = m.valid ? &q : nullptr;
+    }
+    for (int l = 0; l < p->L; ++l) {
+        FeaturePerId f;
+        f.feature_id = 10 * l + 3; f.start_frame = p->lm_start[l]; f.estimated_depth = 1.0 / p->inv_depth[l];
+        for (int k = 0; k < p->lm_nobs[l]; ++k) {
+            const double* o = p->obs + 7 * (p->lm_obs_off[l] + k);
+            FeaturePerFrame fr;
+            fr.point = Vector3d(o[0], o[1], 1.0); fr.uv.x() = o[2]; fr.uv.y() = o[3]; fr.velocity.x() = o[4]; fr.velocity.y() = o[5]; fr.cur_td = o[6];
+            f.feature_per_frame.push_back(fr);
+        }
+        est.f_manager.feature.push_back(f);
+    }
+    // setReloFrame (estimator.cpp:1128-1148): matches as (x, y, feature id) ascending by id, the loop pose, its local index
+    est.relocalization_info = true;
+    est.relo_frame_local_index = relo_frame_local_index;
+    for (int k = 0; k < p->relo_n; ++k) est.match_points.push_back(Vector3d(p->relo_xy[2 * k], p->relo_xy[2 * k + 1], 10.0 * p->relo_lm[k] + 3));
+    est.match_points.push_back(Vector3d(0, 0, 10.0 * p->L + 7));        // a match of a feature that is not in the window any more
+    for (int k = 0; k < 7; ++k) est.relo_Pose[k] = p->relo_pose[k];
+    est.prev_relo_t = Vector3d(prev_relo_t[0], prev_relo_t[1], prev_relo_t[2]);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) est.prev_relo_r(r, c) = prev_relo_r[3 * r + c];
+    est.marginalization_flag = Estimator::MARGIN_OLD;
+    est.optimization();
+    if (est.relocalization_info) return -2;                               // double2vector() must have consumed it
+    for (int i = 0; i <= WINDOW_SIZE; ++i) {
+        Quaterniond q(est.Rs[i]);
+        const double row[7] = {est.Ps[i].x(), est.Ps[i].y(), est.Ps[i].z(), q.x(), q.y(), q.z(), q.w()};
+        memcpy(pose_out + 7 * i, row, sizeof(row));
+    }
+    for (int k = 0; k < 7; ++k) relo_fixed[k] = est.relo_Pose[k];
+    relative_t[0] = est.relo_relative_t.x(); relative_t[1] = est.relo_relative_t.y(); relative_t[2] = est.relo_relative_t.z();
+    relative_q[0] = est.relo_relative_q.x(); relative_q[1] = est.relo_relative_q.y(); relative_q[2] = est.relo_relative_q.z(); relative_q[3] = est.relo_relative_q.w();
+    *relative_yaw = est.relo_relative_yaw;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) drift_r[3 * r + c] = est.drift_correct_r(r, c);
+    drift_t[0] = est.drift_correct_t.x(); drift_t[1] = est.drift_correct_t.y(); drift_t[2] = est.drift_correct_t.z();
+    return 0;
+}
