@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 1
+#define VG_ABI_VERSION 2    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {

@@ -11,6 +11,7 @@ from . import lib
 VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
 VG_OK = 0
+VG_ABI_VERSION = 2          # include/vinsgpu.h
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int)
 
@@ -192,6 +193,8 @@ class Handle:
         L.vg_ba_reduce_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.vg_triangulate.argtypes = [C.c_void_p, C.c_int, _pd, _pd, _pd, _pd, C.c_int, _pi, _pi, _pi, _pd, C.c_double, _pd]
         L.vg_imu_preintegrate.argtypes = [C.c_void_p, C.c_int, _pi, _pd, _pd, _pd, _pd, C.POINTER(ImuPreint)]
+        if L.vg_abi_version() != VG_ABI_VERSION:
+            raise RuntimeError(f"libvinsgpu.so reports ABI version {L.vg_abi_version()}, this binding was written for {VG_ABI_VERSION}")
         self.h = C.c_void_p()
         rc = L.vg_create(C.byref(self.h))
         if rc != VG_OK:

@@ -175,6 +175,7 @@ void Estimator::double2vector() {
 }
 
 void Estimator::optimization() {
+    if (vg_abi_version() != VG_ABI_VERSION) throw std::runtime_error("libvinsgpu.so was built from another include/vinsgpu.h (ABI version mismatch)");
     if (!vg_ && vg_create(&vg_) != VG_OK) throw std::runtime_error("vg_create failed: no MI355X / libvinsgpu (no CPU fallback)");
     vector2double();                                            // estimator.cpp:701
     const int K = WINDOW_SIZE + 1;
