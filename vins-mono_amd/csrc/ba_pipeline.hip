@@ -29,6 +29,36 @@
 #include "../../include/vinsgpu.h"
 
 #define NOINL __device__ __noinline__
+// Pointers handed to a non-inlined phase function are generic, and generic accesses compile to flat_load / flat_store even
+// when they always hit LDS (slower issue and latency than ds_read / ds_write, and they tie up both memory counters).  The
+// phase functions of the single-workgroup solve therefore re-type their LDS operands explicitly.  (The CPU emulation of
+// tests/simt has one address space.)
+#ifdef VINS_SIMT
+typedef double lds_d;
+#else
+typedef __attribute__((address_space(3))) double lds_d;
+#endif
+#define AS_LDS(p) ((lds_d*)(p))
+#define AS_LDS_C(p) ((const lds_d*)(p))
+#ifdef VINS_SIMT
+typedef double glb_d;
+typedef int glb_i;
+#else
+typedef __attribute__((address_space(1))) double glb_d;    // HBM operands of those functions: global_load instead of flat_load
+typedef __attribute__((address_space(1))) int glb_i;
+#endif
+#define AS_GLB(p) ((glb_d*)(p))
+#define AS_GLB_C(p) ((const glb_d*)(p))
+#define AS_GLB_CI(p) ((const glb_i*)(p))
+// where the arrays of the solve carve that the large-window path keeps in HBM live: LDS (single-workgroup path) or HBM
+#ifdef VINS_SIMT
+typedef int lds_i;
+#else
+typedef __attribute__((address_space(3))) int lds_i;
+#endif
+template <bool BIG> struct MovT { typedef lds_d D; typedef lds_i I; };
+template <> struct MovT<true> { typedef glb_d D; typedef glb_i I; };
+
 extern __shared__ __attribute__((aligned(16))) char bp_smem[];
 #define LDSB ((double*)bp_smem)
 typedef double double4_t __attribute__((vector_size(32)));      // v_mfma_f64_16x16x4 accumulator (4 VGPR pairs)
@@ -41,6 +71,21 @@ typedef double double4_t __attribute__((vector_size(32)));      // v_mfma_f64_16
 #else
 #define PROF_DECL
 #define PROF_ADD(id)
+#endif
+// finer timers for development (build with -DBA_PROFILE_DETAIL): threads 0 and 128 of workgroup 0 accumulate clock deltas of
+// the sub-phases of chain_eliminate / schur_mfma / cholesky_aug into a device array read back by vg_debug_detail_profile
+#ifdef BA_PROFILE_DETAIL
+__device__ double g_dprof[64];
+#define DP_DECL long long _dp = clock64()
+#define DP_ADD(id) do { if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 128)) { const long long _n = clock64(); g_dprof[(threadIdx.x ? 32 : 0) + (id)] += (double)(_n - _dp); _dp = _n; } } while (0)
+extern "C" int vg_debug_detail_profile(double* out64, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dprof), sizeof(double) * 64);
+    if (e == hipSuccess && reset) { double z[64] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_dprof), z, sizeof(z)); }
+    return e == hipSuccess ? 0 : -2;
+}
+#else
+#define DP_DECL
+#define DP_ADD(id)
 #endif
 enum { PF_JUDGE = 0, PF_ASM, PF_DG, PF_BUILD, PF_CHAIN, PF_SCHUR, PF_CHOL, PF_BACK, PF_CBACK, PF_LMY, PF_NORMS, PF_CAND, PF_TAIL };
 
@@ -812,67 +857,74 @@ DEV int imu_col(const BaLayout& L, int f, int lc) {
     if (lc < 21) return col_pose(L, f + 1) + lc - 15;
     return col_sb(L, f + 1) + lc - 21;
 }
+// The stored blocks of the reduced system with their address spaces spelled out: S always in LDS; XC / D / E / the R-vectors /
+// the prior column map in LDS (MV = lds_d) or in HBM (large-window path, MV = glb_d).
+template <typename MV, typename MI>
+struct SysPtrs {
+    lds_d* S;
+    MV *XC, *D, *E, *vec;
+    MI* pmap;
+    int ldc;
+};
+template <bool BIG>
+DEV SysPtrs<typename MovT<BIG>::D, typename MovT<BIG>::I> sys_ptrs(const SolveLds& m) {
+    typedef typename MovT<BIG>::D MV;
+    typedef typename MovT<BIG>::I MI;
+    SysPtrs<MV, MI> q;
+    q.S = AS_LDS(m.S); q.XC = (MV*)m.XC; q.D = (MV*)m.D; q.E = (MV*)m.E; q.vec = (MV*)m.vec; q.pmap = (MI*)m.pmap; q.ldc = m.ldc;
+    return q;
+}
 // add v to the Hessian entry (ca, cb) of the reduced system, ca != cb or ca == cb, wherever that entry is stored:
 //   camera x camera -> packed S;  sb_k x sb_k -> D_k (full 9x9, both triangles);  sb_k x sb_k-1 -> E_k;
 //   sb_k x camera -> XC row 9k+r (the coupling block that the chain elimination turns into X_k)
-DEV void hess_add(const BaLayout& L, const SolveLds& m, int ca, int cb, double v) {
+template <typename Q>
+DEV void hess_add(const BaLayout& L, const Q& q, int ca, int cb, double v) {
     if (ca < cb) { const int t = ca; ca = cb; cb = t; }
     const int Rc = L.Rc;
-    if (ca < Rc) { m.S[tri(ca, cb)] += v; return; }
+    if (ca < Rc) { q.S[tri(ca, cb)] += v; return; }
     const int ka = (ca - Rc) / 9, ra = (ca - Rc) - 9 * ka;
-    if (cb < Rc) { m.XC[(9 * ka + ra) * m.ldc + cb] += v; return; }
+    if (cb < Rc) { q.XC[(9 * ka + ra) * q.ldc + cb] += v; return; }
     const int kb = (cb - Rc) / 9, rb = (cb - Rc) - 9 * kb;
     if (ka == kb) {
-        m.D[81 * ka + 9 * ra + rb] += v;
-        if (ra != rb) m.D[81 * ka + 9 * rb + ra] += v;
+        q.D[81 * ka + 9 * ra + rb] += v;
+        if (ra != rb) q.D[81 * ka + 9 * rb + ra] += v;
     } else {
-        m.E[81 * ka + 9 * ra + rb] += v;          // ka == kb + 1 (the host rejects priors coupling non-adjacent speed-bias blocks)
+        q.E[81 * ka + 9 * ra + rb] += v;          // ka == kb + 1 (the host rejects priors coupling non-adjacent speed-bias blocks)
     }
 }
 
-// where hess_add() would add the entry (ca, cb): p0, and p1 != nullptr for the mirrored entry of a diagonal chain block
-DEV void hess_slot(const BaLayout& L, const SolveLds& m, int ca, int cb, double*& p0, double*& p1) {
-    if (ca < cb) { const int t = ca; ca = cb; cb = t; }
-    const int Rc = L.Rc;
-    p1 = nullptr;
-    if (ca < Rc) { p0 = m.S + tri(ca, cb); return; }
-    const int ka = (ca - Rc) / 9, ra = (ca - Rc) - 9 * ka;
-    if (cb < Rc) { p0 = m.XC + (9 * ka + ra) * m.ldc + cb; return; }
-    const int kb = (cb - Rc) / 9, rb = (cb - Rc) - 9 * kb;
-    if (ka == kb) {
-        p0 = m.D + 81 * ka + 9 * ra + rb;
-        if (ra != rb) p1 = m.D + 81 * ka + 9 * rb + ra;
-    } else {
-        p0 = m.E + 81 * ka + 9 * ra + rb;
-    }
-}
-
-// Unscaled Gauss-Newton system of the current point in LDS: S (camera, packed lower), g, chain blocks D, E, XC.
+// Unscaled Gauss-Newton system of the current point: S (camera, packed lower), g, chain blocks D, E, XC.
 // Sp / gp = camera J^T J / J^T r of the projection factors (the buffer's own, or the rank-summed copy of the large-window path)
-NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf, const double* Sp, const double* gp) {
+template <bool BIG>
+NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf_, const double* Sp_, const double* gp_) {
     const BaLayout& L = *c.Lp;
+    typedef typename MovT<BIG>::D MV;
+    const auto q = sys_ptrs<BIG>(m);
+    const glb_d* buf = AS_GLB_C(buf_);
+    const glb_d* Sp = AS_GLB_C(Sp_);
+    const glb_d* gp = AS_GLB_C(gp_);
     const int Rc = L.Rc, R = L.R, K = L.K;
     const int camtri = Rc * (Rc + 1) / 2;
-    double* g = m.vec + V_G * L.Rpad;
+    MV* g = q.vec + V_G * L.Rpad;
     __syncthreads();
-    for (int k = c.tid; k < camtri; k += BA_NT) m.S[k] = Sp[k];
+    for (int k = c.tid; k < camtri; k += BA_NT) q.S[k] = Sp[k];
     for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? gp[k] : 0.0;
-    if (!L.big) {
+    if (!BIG) {
         // (large-window path: XC / D / E live in HBM and were cleared by the Schur kernel's extra workgroups)
-        const int nxc = ((9 * K + 3) & ~3) * m.ldc;
-        for (int k = c.tid; k < nxc; k += BA_NT) m.XC[k] = 0.0;
-        for (int k = c.tid; k < 81 * K; k += BA_NT) { m.D[k] = 0.0; m.E[k] = 0.0; }
+        const int nxc = ((9 * K + 3) & ~3) * q.ldc;
+        for (int k = c.tid; k < nxc; k += BA_NT) q.XC[k] = 0.0;
+        for (int k = c.tid; k < 81 * K; k += BA_NT) { q.D[k] = 0.0; q.E[k] = 0.0; }
     }
     __syncthreads();
     // ---- IMU Hessian blocks: factors k and k+1 share the blocks of frame k+1, so even and odd factors are added in two
     //      rounds (inside a round every entry has exactly one writer)
     {
         const int nimu = K - 1;
-        const int* valid = c.ia + L.io_imu_valid;
-        const double* imuJ = buf + L.bo_imuJ;
+        const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
+        const glb_d* imuJ = buf + L.bo_imuJ;
         for (int par = 0; par < 2; ++par) {
             const int nf = (nimu - par + 1) / 2;
-            if (!L.big) {
+            if (!BIG) {
                 for (int w = c.tid; w < nf * 512; w += BA_NT) {
                     const int f = 2 * (w >> 9) + par, e = w & 511;
                     if (e >= 495 || !valid[f]) continue;
@@ -880,7 +932,7 @@ NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf, const do
                     if (e < 465) {
                         int a, b;
                         tri_decode(e, a, b);
-                        hess_add(L, m, imu_col(L, f, a), imu_col(L, f, b), v);
+                        hess_add(L, q, imu_col(L, f, a), imu_col(L, f, b), v);
                     } else {
                         g[imu_col(L, f, e - 465)] += v;
                     }
@@ -888,30 +940,42 @@ NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf, const do
             } else {
                 // large-window path: most targets are in HBM, a read-modify-write per trip would be a chain of memory round
                 // trips.  Thread = entry e of every factor of this parity, eight factors at a time: all loads first, then
-                // all stores (inside a round every entry has exactly one writer, so the slots are distinct).
+                // all stores (inside a round every entry has exactly one writer, so the slots are distinct).  Entries of
+                // the camera part live in LDS: they are added directly.
                 const int e = c.tid;
                 int a = 0, b = 0;
                 if (e < 465) tri_decode(e, a, b);
                 for (int i0 = 0; i0 < nf; i0 += 8) {
-                    double* p0[8];
-                    double* p1[8];
+                    MV* p0[8];
+                    MV* p1[8];
                     double v[8], t0[8], t1[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int f = 2 * (i0 + q) + par;
-                        p0[q] = nullptr; p1[q] = nullptr; v[q] = 0.0;
-                        if (i0 + q < nf && e < 495 && valid[f]) {
-                            v[q] = imuJ[f * 512 + e];
-                            if (e < 465) hess_slot(L, m, imu_col(L, f, a), imu_col(L, f, b), p0[q], p1[q]);
-                            else p0[q] = g + imu_col(L, f, e - 465);
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const int f = 2 * (i0 + qq) + par;
+                        p0[qq] = nullptr; p1[qq] = nullptr; v[qq] = 0.0;
+                        if (i0 + qq < nf && e < 495 && valid[f]) {
+                            v[qq] = imuJ[f * 512 + e];
+                            if (e >= 465) { p0[qq] = g + imu_col(L, f, e - 465); continue; }
+                            int ca = imu_col(L, f, a), cb = imu_col(L, f, b);
+                            if (ca < cb) { const int t = ca; ca = cb; cb = t; }
+                            if (ca < Rc) { q.S[tri(ca, cb)] += v[qq]; continue; }
+                            const int ka = (ca - Rc) / 9, ra = (ca - Rc) - 9 * ka;
+                            if (cb < Rc) { p0[qq] = q.XC + (9 * ka + ra) * q.ldc + cb; continue; }
+                            const int kb = (cb - Rc) / 9, rb = (cb - Rc) - 9 * kb;
+                            if (ka == kb) {
+                                p0[qq] = q.D + 81 * ka + 9 * ra + rb;
+                                if (ra != rb) p1[qq] = q.D + 81 * ka + 9 * rb + ra;
+                            } else {
+                                p0[qq] = q.E + 81 * ka + 9 * ra + rb;
+                            }
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { t0[q] = p0[q] ? *p0[q] : 0.0; t1[q] = p1[q] ? *p1[q] : 0.0; }
+                    for (int qq = 0; qq < 8; ++qq) { t0[qq] = p0[qq] ? *p0[qq] : 0.0; t1[qq] = p1[qq] ? *p1[qq] : 0.0; }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (p0[q]) *p0[q] = t0[q] + v[q];
-                        if (p1[q]) *p1[q] = t1[q] + v[q];
+                    for (int qq = 0; qq < 8; ++qq) {
+                        if (p0[qq]) *p0[qq] = t0[qq] + v[qq];
+                        if (p1[qq]) *p1[qq] = t1[qq] + v[qq];
                     }
                 }
             }
@@ -921,19 +985,19 @@ NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf, const do
     // ---- prior: H += J0^T J0 (precomputed Hp), g += J0^T r   (pmap: prior column -> reduced column or -1)
     if (c.nprior) {
         const int n = c.nprior;
-        const double* Hp = c.sc + L.so_Hp;
-        const double* gpr = buf + L.bo_gpr;        // J0^T r, formed by the linearisation kernel
+        const glb_d* Hp = AS_GLB_C(c.sc + L.so_Hp);
+        const glb_d* gpr = buf + L.bo_gpr;        // J0^T r, formed by the linearisation kernel
         for (int w = c.tid; w < n * (n + 1) / 2 + n; w += BA_NT) {
             const bool isg = w >= n * (n + 1) / 2;
             if (isg) {
                 const int a = w - n * (n + 1) / 2;
-                const int ca = m.pmap[a];
+                const int ca = q.pmap[a];
                 if (ca >= 0) g[ca] += gpr[a];
             } else {
                 int a, b;
                 tri_decode(w, a, b);
-                const int ca = m.pmap[a], cb = m.pmap[b];
-                if (ca >= 0 && cb >= 0) hess_add(L, m, ca, cb, Hp[a * L.Ncap + b]);
+                const int ca = q.pmap[a], cb = q.pmap[b];
+                if (ca >= 0 && cb >= 0) hess_add(L, q, ca, cb, Hp[a * L.Ncap + b]);
             }
         }
     }
@@ -951,12 +1015,15 @@ DEV double hess_diag(const BaLayout& L, const SolveLds& m, int k) {
 // column Rc of XC.  Also returns this thread's share of  t^T H~ t  over the reduced block (H~ = scaled, UN-damped
 // Hessian, t = V_T = gt / Dg): the Cauchy-point denominator |J~ t|^2 of DoglegStrategy::ComputeCauchyPoint without a
 // second pass over the factors.
-NOINL double build_scaled(const Ctx& c, const SolveLds& m, double mu) {
+template <bool BIG>
+NOINL double build_scaled(const Ctx& c, const SolveLds& m_, double mu) {
     const BaLayout& L = *c.Lp;
-    const double* g = m.vec + V_G * L.Rpad;
-    const double* sc = m.vec + V_SC * L.Rpad;
-    const double* dg = m.vec + V_DG * L.Rpad;
-    const double* tv = m.vec + V_T * L.Rpad;
+    typedef typename MovT<BIG>::D MV;
+    const auto m = sys_ptrs<BIG>(m_);
+    const MV* g = m.vec + V_G * L.Rpad;
+    const MV* sc = m.vec + V_SC * L.Rpad;
+    const MV* dg = m.vec + V_DG * L.Rpad;
+    const MV* tv = m.vec + V_T * L.Rpad;
     const int Rc = L.Rc, K = L.K, ldc = m.ldc;
     const int n = Rc * (Rc + 1) / 2;
     double q = 0.0;
@@ -984,7 +1051,7 @@ NOINL double build_scaled(const Ctx& c, const SolveLds& m, double mu) {
             m.E[w] = ve;
         }
     }
-    if (!L.big) {
+    if (!BIG) {
         for (int w = c.tid; w < 9 * K * (Rc + 1); w += BA_NT) {
             const int row = w / (Rc + 1), col = w - row * (Rc + 1);
             const int ca = Rc + row;
@@ -999,8 +1066,8 @@ NOINL double build_scaled(const Ctx& c, const SolveLds& m, double mu) {
     } else {
         // large-window path (XC in HBM): before the elimination a speed-bias row of frame k is non-zero only in the columns of
         // poses k-1, k, k+1 (IMU factors k-1 and k) -- and anywhere if the prior holds that speed-bias block
-        const int* kind = c.ia + L.io_pb_kind;
-        const int* idx = c.ia + L.io_pb_idx;
+        const glb_i* kind = AS_GLB_CI(c.ia + L.io_pb_kind);
+        const glb_i* idx = AS_GLB_CI(c.ia + L.io_pb_idx);
         for (int w = c.tid; w < 9 * K * 20; w += BA_NT) {
             const int row = w / 20, e = w - 20 * row, k = row / 9;
             const int ca = Rc + row;
@@ -1058,7 +1125,8 @@ DEV double rsqrt_nr(double x) {
 // for a BOTTOM block k-1 it holds (L_k-1^-1 E_k^T)^T as [c][p] (c = column sb_k, p = row of X_k-1) — each pair is consumed
 // by exactly one of its two blocks.  The camera system gets  S -= X^T X  in schur_mfma().
 // Returns false (uniform) on a non-positive pivot.
-DEV bool chain_factor(int lane, double* Dk, double* dinvk, int kind, const double* Xc) {
+template <typename P, typename PC>
+DEV bool chain_factor(int lane, P Dk, P dinvk, int kind, PC Xc) {
     // kind 1: Xc = Xe of the upper neighbour as [p][r]  ->  D[r][c] -= sum_p Xc[9p + r] Xc[9p + c]
     // kind 2: Xc = XuT of the lower neighbour as [r][p]  ->  D[r][c] -= sum_p Xc[9r + p] Xc[9c + p];  kind 3: both (Xc, Xc + 81)
     if (kind) {
@@ -1070,7 +1138,7 @@ DEV bool chain_factor(int lane, double* Dk, double* dinvk, int kind, const doubl
                 for (int p = 0; p < 9; ++p) s += Xc[9 * p + r] * Xc[9 * p + cc];
             }
             if (kind & 2) {
-                const double* Xu = kind == 3 ? Xc + 81 : Xc;
+                PC Xu = kind == 3 ? Xc + 81 : Xc;
 #pragma unroll
                 for (int p = 0; p < 9; ++p) s += Xu[9 * r + p] * Xu[9 * cc + p];
             }
@@ -1104,7 +1172,8 @@ DEV bool chain_factor(int lane, double* Dk, double* dinvk, int kind, const doubl
     return good;
 }
 // x <- L^-1 x for the 9 values at col[0], col[stride], ...
-DEV void chain_col_solve(const double* Lk, const double* dinvk, double* col, int stride) {
+template <typename PL, typename PD, typename P>
+DEV void chain_col_solve(PL Lk, PD dinvk, P col, int stride) {
     double x[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) x[r] = col[r * stride];
@@ -1123,9 +1192,15 @@ NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
     const int K = L.K, Rc = L.Rc, ldc = m.ldc;
     const int mid = K / 2;
     const int nstep = (K - 1 - mid) > mid ? (K - 1 - mid) : mid;
+    lds_d* const XC = AS_LDS(m.XC);
+    lds_d* const D = AS_LDS(m.D);
+    lds_d* const E = AS_LDS(m.E);
+    lds_d* const dinv = AS_LDS(m.dinv);
+    lds_d* const wd = AS_LDS(m.wd);
     int* flag = (int*)(m.red + 24);
     if (c.tid == 0) *flag = 1;
     __syncthreads();
+    DP_DECL;
     for (int t = 0; t <= nstep; ++t) {
         const bool last = t == nstep;
         // blocks of this step: top kt (coupled downwards), bottom kb (coupled upwards); in the last step only `mid`
@@ -1139,18 +1214,18 @@ NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
         if (c.wave == 0) {
             if (has_t) {
                 int kind = 0;
-                const double* X = nullptr;
+                const lds_d* X = nullptr;
                 if (upd_t_from_above && upd_mid_from_below) {
                     // the middle block takes both: copy the two coupling blocks next to each other (scratch in wd)
-                    for (int e = c.lane; e < 81; e += 64) { m.wd[e] = m.E[81 * (kt + 1) + e]; m.wd[81 + e] = m.E[81 * kt + e]; }
+                    for (int e = c.lane; e < 81; e += 64) { wd[e] = E[81 * (kt + 1) + e]; wd[81 + e] = E[81 * kt + e]; }
                     __builtin_amdgcn_wave_barrier();
-                    kind = 3; X = m.wd;
-                } else if (upd_t_from_above) { kind = 1; X = m.E + 81 * (kt + 1); }
-                else if (upd_mid_from_below) { kind = 2; X = m.E + 81 * kt; }
-                if (!chain_factor(c.lane, m.D + 81 * kt, m.dinv + 9 * kt, kind, X) && c.lane == 0) *flag = 0;
+                    kind = 3; X = wd;
+                } else if (upd_t_from_above) { kind = 1; X = E + 81 * (kt + 1); }
+                else if (upd_mid_from_below) { kind = 2; X = E + 81 * kt; }
+                if (!chain_factor(c.lane, D + 81 * kt, dinv + 9 * kt, kind, X) && c.lane == 0) *flag = 0;
             }
         } else if (c.wave == 1) {
-            if (has_b && !chain_factor(c.lane, m.D + 81 * kb, m.dinv + 9 * kb, upd_b ? 2 : 0, m.E + 81 * kb) && c.lane == 0) *flag = 0;
+            if (has_b && !chain_factor(c.lane, D + 81 * kb, dinv + 9 * kb, upd_b ? 2 : 0, E + 81 * kb) && c.lane == 0) *flag = 0;
         } else {
             const int nt = BA_NT - 128, id = c.tid - 128;
             const int per = 9 * (Rc + 1);
@@ -1161,45 +1236,49 @@ NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
                     if (!has_t) continue;
                     double s = 0.0;
                     if (upd_t_from_above) {
-                        const double* Xe = m.E + 81 * (kt + 1);
-                        const double* Xn = m.XC + 9 * (kt + 1) * ldc;
+                        const lds_d* Xe = E + 81 * (kt + 1);
+                        const lds_d* Xn = XC + 9 * (kt + 1) * ldc;
 #pragma unroll
                         for (int p = 0; p < 9; ++p) s += Xe[9 * p + r] * Xn[p * ldc + j];
                     }
                     if (upd_mid_from_below) {
-                        const double* Xu = m.E + 81 * kt;
-                        const double* Xn = m.XC + 9 * (kt - 1) * ldc;
+                        const lds_d* Xu = E + 81 * kt;
+                        const lds_d* Xn = XC + 9 * (kt - 1) * ldc;
 #pragma unroll
                         for (int p = 0; p < 9; ++p) s += Xu[9 * r + p] * Xn[p * ldc + j];
                     }
-                    if (upd_t_from_above || upd_mid_from_below) m.XC[(9 * kt + r) * ldc + j] -= s;
+                    if (upd_t_from_above || upd_mid_from_below) XC[(9 * kt + r) * ldc + j] -= s;
                 } else {
                     if (!upd_b) continue;
-                    const double* Xu = m.E + 81 * kb;
-                    const double* Xn = m.XC + 9 * (kb - 1) * ldc;
+                    const lds_d* Xu = E + 81 * kb;
+                    const lds_d* Xn = XC + 9 * (kb - 1) * ldc;
                     double s = 0.0;
 #pragma unroll
                     for (int p = 0; p < 9; ++p) s += Xu[9 * r + p] * Xn[p * ldc + j];
-                    m.XC[(9 * kb + r) * ldc + j] -= s;
+                    XC[(9 * kb + r) * ldc + j] -= s;
                 }
             }
         }
+        DP_ADD(0);
         __syncthreads();
+        DP_ADD(1);
         if (*flag == 0) break;
         // ---- (B) columns: threads 0 .. Rc + 9 serve the top block, 256 .. 256 + Rc + 9 the bottom block (Rc + 10 <= 256)
         {
             const int half = c.tid >> 8, id = c.tid & 255;
             if (half == 0 && has_t) {
-                const double* Lk = m.D + 81 * kt;
-                if (id <= Rc) chain_col_solve(Lk, m.dinv + 9 * kt, m.XC + 9 * kt * ldc + id, ldc);
-                else if (!last && id < Rc + 10) chain_col_solve(Lk, m.dinv + 9 * kt, m.E + 81 * kt + (id - Rc - 1), 9);        // column of E_kt -> Xe
+                const lds_d* Lk = D + 81 * kt;
+                if (id <= Rc) chain_col_solve(Lk, dinv + 9 * kt, XC + 9 * kt * ldc + id, ldc);
+                else if (!last && id < Rc + 10) chain_col_solve(Lk, dinv + 9 * kt, E + 81 * kt + (id - Rc - 1), 9);        // column of E_kt -> Xe
             } else if (half == 1 && has_b) {
-                const double* Lk = m.D + 81 * kb;
-                if (id <= Rc) chain_col_solve(Lk, m.dinv + 9 * kb, m.XC + 9 * kb * ldc + id, ldc);
-                else if (id < Rc + 10) chain_col_solve(Lk, m.dinv + 9 * kb, m.E + 81 * (kb + 1) + 9 * (id - Rc - 1), 1);        // row of E_kb+1 -> XuT
+                const lds_d* Lk = D + 81 * kb;
+                if (id <= Rc) chain_col_solve(Lk, dinv + 9 * kb, XC + 9 * kb * ldc + id, ldc);
+                else if (id < Rc + 10) chain_col_solve(Lk, dinv + 9 * kb, E + 81 * (kb + 1) + 9 * (id - Rc - 1), 1);        // row of E_kb+1 -> XuT
             }
         }
+        DP_ADD(2);
         __syncthreads();
+        DP_ADD(3);
     }
     const bool ok = *flag != 0;
     __syncthreads();
@@ -1216,16 +1295,20 @@ NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
 #define SCHUR_PF ((96 * SCHUR_LW + BA_NT - 1) / BA_NT)
 NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double mu) {
     const BaLayout& L = *c.Lp;
-    const double* sc = m.vec + V_SC * L.Rpad;
-    const double* Wt = buf + L.bo_Wt;
-    const double* h = buf + L.bo_h;
-    const double* b = buf + L.bo_b;
-    const double* sl = c.sc + L.so_sl;
-    const double* dgl = c.sc + L.so_dg + L.Rpad;
-    double* lsc = c.sc + L.so_lsc;
+    const lds_d* sc = AS_LDS_C(m.vec + V_SC * L.Rpad);
+    lds_d* const S = AS_LDS(m.S);
+    lds_d* const wd = AS_LDS(m.wd);
+    const lds_d* const XC = AS_LDS_C(m.XC);
+    const glb_d* Wt = AS_GLB_C(buf + L.bo_Wt);
+    const glb_d* h = AS_GLB_C(buf + L.bo_h);
+    const glb_d* b = AS_GLB_C(buf + L.bo_b);
+    const glb_d* sl = AS_GLB_C(c.sc + L.so_sl);
+    const glb_d* dgl = AS_GLB_C(c.sc + L.so_dg + L.Rpad);
+    glb_d* lsc = AS_GLB(c.sc + L.so_lsc);
     const int Rc = L.Rc, RcPad = L.RcPad, ldc = m.ldc;
     const int nt = RcPad / 16;
     const int ntile = nt * (nt + 1) / 2;
+    DP_DECL;
     double4_t acc[3];                              // up to 3 tiles per wavefront (21 tiles / 8 wavefronts)
     int tm[3], tn[3];
 #pragma unroll
@@ -1240,7 +1323,7 @@ NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double
     // ---- chain rows
     const int nk = (9 * L.K + 3) / 4;
     for (int kk = 0; kk < nk; ++kk) {
-        const double* xr = m.XC + (kk * 4 + (c.lane >> 4)) * ldc + (c.lane & 15);
+        const lds_d* xr = XC + (kk * 4 + (c.lane >> 4)) * ldc + (c.lane & 15);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (c.wave + s * BA_NW < ntile) {
@@ -1250,6 +1333,7 @@ NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double
             }
         }
     }
+    DP_ADD(10);
     // ---- landmark columns: element w = tid + BA_NT * i of the (RcPad x SCHUR_LW) tile -> row w / 32, landmark l0 + w % 32
     double pre[SCHUR_PF];
     const int nel = RcPad * SCHUR_LW;
@@ -1265,6 +1349,7 @@ NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double
     if (c.nL > 0) fetch(0);
     for (int l0 = 0; l0 < c.nL; l0 += SCHUR_LW) {
         __syncthreads();                           // lsc visible (first trip) / previous tile consumed
+        DP_ADD(11);
 #pragma unroll
         for (int i = 0; i < SCHUR_PF; ++i) {
             const int w = c.tid + BA_NT * i;
@@ -1272,24 +1357,28 @@ NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double
                 const int row = w / SCHUR_LW, k = w % SCHUR_LW, l = l0 + k;
                 double v = (row < Rc && l < c.nL) ? sc[row] * pre[i] * lsc[l] : 0.0;
                 if (row == Rc && l < c.nL) v = b[l] * lsc[l];
-                m.wd[row * SCHUR_LD + k] = v;
+                wd[row * SCHUR_LD + k] = v;
             }
         }
+        DP_ADD(12);
         __syncthreads();
+        DP_ADD(13);
         if (l0 + SCHUR_LW < c.nL) fetch(l0 + SCHUR_LW);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (c.wave + s * BA_NW < ntile) {
 #pragma unroll
                 for (int kk = 0; kk < SCHUR_LW / 4; ++kk) {
-                    const double a = m.wd[(tm[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
-                    const double bb = m.wd[(tn[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
+                    const double a = wd[(tm[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
+                    const double bb = wd[(tn[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
                     acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[s], 0, 0, 0);
                 }
             }
         }
+        DP_ADD(14);
     }
     __syncthreads();
+    DP_ADD(15);
     // D[row = (lane>>4) + 4*reg][col = lane&15]
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -1298,7 +1387,7 @@ NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = tm[s] * 16 + (c.lane >> 4) + 4 * reg;
                 const int col = tn[s] * 16 + (c.lane & 15);
-                if (row <= Rc && col <= row && col < Rc) m.S[tri(row, col)] -= acc[s][reg];
+                if (row <= Rc && col <= row && col < Rc) S[tri(row, col)] -= acc[s][reg];
             }
         }
     }
@@ -1341,12 +1430,13 @@ NOINL double cauchy_landmark_term(const Ctx& c, const SolveLds& m, const double*
 // Three barriers per 16 columns.  1/L_jj goes to V_DI.  Returns false (uniform) on a bad pivot.
 NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
     const BaLayout& L = *c.Lp;
-    double* S = m.S;
-    double* dinvv = m.di;
-    int* flag = (int*)(m.red + 24);
+    lds_d* S = AS_LDS(m.S);
+    lds_d* dinvv = AS_LDS(m.di);
+    lds_i* flag = (lds_i*)(m.red + 24);
     const int lane = c.lane;
     if (c.tid == 0) *flag = 1;
     __syncthreads();
+    DP_DECL;
     for (int c0 = 0; c0 < R; c0 += 16) {
         const int nb = (R - c0) < 16 ? (R - c0) : 16;
         // ---- (1) diagonal block, wavefront 0
@@ -1378,19 +1468,21 @@ NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
             }
             if (!good && lane == 0) *flag = 0;
         }
+        DP_ADD(4);
         __syncthreads();
+        DP_ADD(5);
         if (*flag == 0) break;
         // ---- (2) panel: rows i > block, x_c = (a_c - sum_{m<c} x_m L_D[c][m]) / L_D[c][c]
         const int r1 = c0 + nb;
         if (nb == 16) {
             for (int i = r1 + c.tid; i <= R; i += BA_NT) {
                 double x[16];
-                double* row = S + tri(i, c0);
+                lds_d* row = S + tri(i, c0);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) x[q] = row[q];
 #pragma unroll
                 for (int cc = 0; cc < 16; ++cc) {
-                    const double* ld = S + tri(c0 + cc, c0);
+                    const lds_d* ld = S + tri(c0 + cc, c0);
                     double sacc = x[cc];
 #pragma unroll
                     for (int q = 0; q < cc; ++q) sacc -= x[q] * ld[q];
@@ -1401,16 +1493,18 @@ NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
             }
         } else {
             for (int i = r1 + c.tid; i <= R; i += BA_NT) {
-                double* row = S + tri(i, c0);
+                lds_d* row = S + tri(i, c0);
                 for (int cc = 0; cc < nb; ++cc) {
-                    const double* ld = S + tri(c0 + cc, c0);
+                    const lds_d* ld = S + tri(c0 + cc, c0);
                     double sacc = row[cc];
                     for (int q = 0; q < cc; ++q) sacc -= row[q] * ld[q];
                     row[cc] = sacc * dinvv[c0 + cc];
                 }
             }
         }
+        DP_ADD(6);
         __syncthreads();
+        DP_ADD(7);
         // ---- (3) trailing update (only full blocks have anything right of them)
         if (nb == 16 && r1 < R) {
             const int t0 = r1 >> 4;
@@ -1423,8 +1517,8 @@ NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
                 const int ti = t0 + tr_, tk = t0 + tc_;
                 const int arow = 16 * ti + (lane & 15), brow = 16 * tk + (lane & 15);
                 const bool interior = (16 * ti + 15 <= R) && (ti != tk);     // wave-uniform
-                const double* pa = S + tri(arow <= R ? arow : R, c0) + (lane >> 4);
-                const double* pb = S + tri(brow <= R ? brow : R, c0) + (lane >> 4);
+                const lds_d* pa = S + tri(arow <= R ? arow : R, c0) + (lane >> 4);
+                const lds_d* pb = S + tri(brow <= R ? brow : R, c0) + (lane >> 4);
                 const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12];
                 const double b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];
                 const bool av = arow <= R, bv = brow < R;
@@ -1436,10 +1530,10 @@ NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
                 const int colw = 16 * tk + (lane & 15);
                 const int row0 = 16 * ti + (lane >> 4);
                 if (interior) {
-                    double* q0 = S + tri(row0, colw);
-                    double* q1 = S + tri(row0 + 4, colw);
-                    double* q2 = S + tri(row0 + 8, colw);
-                    double* q3 = S + tri(row0 + 12, colw);
+                    lds_d* q0 = S + tri(row0, colw);
+                    lds_d* q1 = S + tri(row0 + 4, colw);
+                    lds_d* q2 = S + tri(row0 + 8, colw);
+                    lds_d* q3 = S + tri(row0 + 12, colw);
                     const double c0v = *q0, c1v = *q1, c2v = *q2, c3v = *q3;
                     *q0 = c0v - acc[0]; *q1 = c1v - acc[1]; *q2 = c2v - acc[2]; *q3 = c3v - acc[3];
                 } else {
@@ -1451,7 +1545,9 @@ NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
                 }
             }
         }
+        DP_ADD(8);
         __syncthreads();
+        DP_ADD(9);
     }
     const bool ok = (*flag != 0);
     __syncthreads();
@@ -1462,18 +1558,18 @@ NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
 // registers; the pivot value travels through v_readlane); result in V_Y[0..R).  R <= 128.
 NOINL void back_substitute(const Ctx& c, const SolveLds& m, int R) {
     const BaLayout& L = *c.Lp;
-    const double* S = m.S;
-    const double* dinvv = m.di;
-    double* y = m.vec + V_Y * L.Rpad;
+    const lds_d* S = AS_LDS_C(m.S);
+    const lds_d* dinvv = AS_LDS_C(m.di);
+    lds_d* y = AS_LDS(m.vec + V_Y * L.Rpad);
     __syncthreads();
     if (c.wave == 0) {
         const int l0 = c.lane, l1 = c.lane + 64;
-        const double* rowR = S + tri(R, 0);
+        const lds_d* rowR = S + tri(R, 0);
         double v0 = rowR[l0 < R ? l0 : 0], v1 = rowR[l1 < R ? l1 : 0];
         v0 = l0 < R ? v0 : 0.0; v1 = l1 < R ? v1 : 0.0;
         int j = R - 1;
         for (; j >= 64; --j) {          // pivot in v1
-            const double* rj = S + tri(j, 0);
+            const lds_d* rj = S + tri(j, 0);
             const double r0 = rj[l0];
             double r1 = rj[l1 < j ? l1 : 0];
             r1 = l1 < j ? r1 : 0.0;
@@ -1483,7 +1579,7 @@ NOINL void back_substitute(const Ctx& c, const SolveLds& m, int R) {
             v0 -= r0 * xj;
         }
         for (; j >= 0; --j) {           // pivot in v0
-            const double* rj = S + tri(j, 0);
+            const lds_d* rj = S + tri(j, 0);
             double r0 = rj[l0 < j ? l0 : 0];
             r0 = l0 < j ? r0 : 0.0;
             const double xj = readlane_d(v0, j) * dinvv[j];
@@ -1498,7 +1594,8 @@ NOINL void back_substitute(const Ctx& c, const SolveLds& m, int R) {
 // speed-bias blocks, from the middle block outwards (two wavefronts, one per direction):
 //   y_mid = L^-T z_mid;   top side  y_k = L_k^-T (z_k - Xe_k y_{k-1});   bottom side  y_k = L_k^-T (z_k - Xu_k y_{k+1})
 // with z = xg - Xc y_cam for all 9K rows first.
-DEV double chain_backsolve9(const double* Lk, const double* dinvk, double v, int r) {
+template <typename PL, typename PD>
+DEV double chain_backsolve9(PL Lk, PD dinvk, double v, int r) {
     // L^T y = v: backward over rows j = 8 .. 0; lane r accumulates its rhs entry and ends up holding y[r]
 #pragma unroll
     for (int j = 8; j >= 0; --j) {
@@ -1508,46 +1605,54 @@ DEV double chain_backsolve9(const double* Lk, const double* dinvk, double v, int
     }
     return v;
 }
-NOINL void chain_back_substitute(const Ctx& c, const SolveLds& m) {
+template <bool BIG>
+NOINL void chain_back_substitute(const Ctx& c, const SolveLds& m_) {
     const BaLayout& L = *c.Lp;
-    const int K = L.K, Rc = L.Rc, ldc = m.ldc;
+    typedef typename MovT<BIG>::D MV;
+    const int K = L.K, Rc = L.Rc, ldc = m_.ldc;
     const int mid = K / 2;
-    double* y = m.vec + V_Y * L.Rpad;
+    MV* const XC = (MV*)m_.XC;
+    MV* const D = (MV*)m_.D;
+    MV* const E = (MV*)m_.E;
+    MV* const dinv = (MV*)m_.dinv;
+    MV* const wd = (MV*)m_.wd;
+    MV* const z = (MV*)m_.z;
+    MV* y = (MV*)(m_.vec + V_Y * L.Rpad);
     {
         const int nrow = 9 * K;
         for (int w = c.tid; w < 4 * nrow; w += BA_NT) {
             const int row = w >> 2, q = w & 3;
-            const double* xr = m.XC + row * ldc;
+            const MV* xr = XC + row * ldc;
             double s = 0.0;
             for (int j = q; j < Rc; j += 4) s += xr[j] * y[j];
-            m.z[w] = s;
+            z[w] = s;
         }
         __syncthreads();
         for (int row = c.tid; row < nrow; row += BA_NT)
-            m.wd[row] = m.XC[row * ldc + Rc] - ((m.z[4 * row] + m.z[4 * row + 1]) + (m.z[4 * row + 2] + m.z[4 * row + 3]));
+            wd[row] = XC[row * ldc + Rc] - ((z[4 * row] + z[4 * row + 1]) + (z[4 * row + 2] + z[4 * row + 3]));
         __syncthreads();
     }
     if (c.wave < 2) {
         const int r = c.lane < 9 ? c.lane : 8;
         // both wavefronts solve the middle block (cheaper than a hand-over through LDS)
-        double yprev = chain_backsolve9(m.D + 81 * mid, m.dinv + 9 * mid, m.wd[9 * mid + r], r);
+        double yprev = chain_backsolve9(D + 81 * mid, dinv + 9 * mid, wd[9 * mid + r], r);
         if (c.wave == 0 && c.lane < 9) y[Rc + 9 * mid + c.lane] = yprev;
         if (c.wave == 0) {
             for (int k = mid + 1; k < K; ++k) {
-                const double* Xe = m.E + 81 * k;                  // [p][c]
-                double v = m.wd[9 * k + r];
+                const MV* Xe = E + 81 * k;                  // [p][c]
+                double v = wd[9 * k + r];
 #pragma unroll
                 for (int cc = 0; cc < 9; ++cc) v -= Xe[9 * r + cc] * readlane_d(yprev, cc);
-                yprev = chain_backsolve9(m.D + 81 * k, m.dinv + 9 * k, v, r);
+                yprev = chain_backsolve9(D + 81 * k, dinv + 9 * k, v, r);
                 if (c.lane < 9) y[Rc + 9 * k + c.lane] = yprev;
             }
         } else {
             for (int k = mid - 1; k >= 0; --k) {
-                const double* Xu = m.E + 81 * (k + 1);            // [c][p]
-                double v = m.wd[9 * k + r];
+                const MV* Xu = E + 81 * (k + 1);            // [c][p]
+                double v = wd[9 * k + r];
 #pragma unroll
                 for (int cc = 0; cc < 9; ++cc) v -= Xu[9 * cc + r] * readlane_d(yprev, cc);
-                yprev = chain_backsolve9(m.D + 81 * k, m.dinv + 9 * k, v, r);
+                yprev = chain_backsolve9(D + 81 * k, dinv + 9 * k, v, r);
                 if (c.lane < 9) y[Rc + 9 * k + c.lane] = yprev;
             }
         }
@@ -1638,7 +1743,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     const double* hh = buf + L.bo_h;
     const double* bb = buf + L.bo_b;
     if (fresh_point && s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK) {
-        assemble(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp);
+        assemble<false>(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp);
         assembled = true;
         if (!s.scaled) {
             // Jacobi scaling from the first Jacobian, fixed for the solve: 1 / (1 + ||J_col||)
@@ -1671,7 +1776,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
         bool ok = true;
         if (!s.reuse) {
             s.reuse = 1;
-            if (!assembled) { assemble(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; }
+            if (!assembled) { assemble<false>(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; }
             PROF_ADD(PF_ASM);
             // Dg, gt (scaled gradient / Dg), t = gt / Dg
             for (int k = c.tid; k < R; k += BA_NT) {
@@ -1702,8 +1807,8 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
             // Gauss-Newton step, increasing mu on failure (DoglegStrategy::ComputeGaussNewtonStep)
             bool solved = false;
             while (s.mu < max_mu) {
-                if (!assembled) { assemble(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; PROF_ADD(PF_ASM); }
-                double q = build_scaled(c, m, s.mu);
+                if (!assembled) { assemble<false>(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; PROF_ADD(PF_ASM); }
+                double q = build_scaled<false>(c, m, s.mu);
                 assembled = false;
                 __syncthreads();
                 PROF_ADD(PF_BUILD);
@@ -1718,7 +1823,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
                 if (cok) {
                     back_substitute(c, m, Rc);
                     PROF_ADD(PF_BACK);
-                    chain_back_substitute(c, m);
+                    chain_back_substitute<false>(c, m);
                     PROF_ADD(PF_CBACK);
                     // landmarks: y_l = (bt_l - wt_l . y_cam) / ht_l
                     const double* Wt = buf + L.bo_Wt;
@@ -1991,9 +2096,12 @@ extern "C" __global__ __launch_bounds__(256) void ba_big_schur_kernel(const BaLa
 // (the rank-summed landmark Schur complement; row Rc: rhs).  v_mfma_f64_16x16x4; a wavefront task = tile row tm x up to four
 // column tiles (the A operand is shared), two k-steps per trip so that ten 128-byte row loads are in flight per wavefront:
 // the operands come from L2, the loop is a chain of round trips, not of flops.  XC has up(9K, 8) rows (zero padded).
-NOINL void schur_chain_big(const Ctx& c, const SolveLds& m, const double* T) {
+NOINL void schur_chain_big(const Ctx& c, const SolveLds& m, const double* T_) {
     const BaLayout& L = *c.Lp;
-    const double* sc = m.vec + V_SC * L.Rpad;
+    const glb_d* sc = AS_GLB_C(m.vec + V_SC * L.Rpad);
+    const glb_d* T = AS_GLB_C(T_);
+    const glb_d* XC = AS_GLB_C(m.XC);
+    lds_d* S = AS_LDS(m.S);
     const int Rc = L.Rc, ldc = m.ldc;
     const int nt = L.RcPad / 16;
     const int nk2 = (9 * L.K + 7) / 8;             // trips of two k-steps (4 rows each)
@@ -2008,10 +2116,10 @@ NOINL void schur_chain_big(const Ctx& c, const SolveLds& m, const double* T) {
         double4_t acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0, 0, 0, 0};
-        const double* xr = m.XC + (size_t)(c.lane >> 4) * ldc + (c.lane & 15);
+        const glb_d* xr = XC + (size_t)(c.lane >> 4) * ldc + (c.lane & 15);
         for (int k2 = 0; k2 < nk2; ++k2) {
-            const double* r0 = xr + (size_t)k2 * 8 * ldc;
-            const double* r1 = r0 + (size_t)4 * ldc;
+            const glb_d* r0 = xr + (size_t)k2 * 8 * ldc;
+            const glb_d* r1 = r0 + (size_t)4 * ldc;
             const double a0 = r0[tm * 16], a1 = r1[tm * 16];
             double b0[4], b1[4];
 #pragma unroll
@@ -2035,7 +2143,7 @@ NOINL void schur_chain_big(const Ctx& c, const SolveLds& m, const double* T) {
                     const int row = tm * 16 + (c.lane >> 4) + 4 * reg, col = (tn0 + q) * 16 + (c.lane & 15);
                     if (row <= Rc && col <= row && col < Rc) {
                         const double sr = row < Rc ? sc[row] : 1.0;
-                        m.S[tri(row, col)] -= acc[q][reg] + sr * sc[col] * T[tri(row, col)];
+                        S[tri(row, col)] -= acc[q][reg] + sr * sc[col] * T[tri(row, col)];
                     }
                 }
             }
@@ -2050,16 +2158,21 @@ NOINL void schur_chain_big(const Ctx& c, const SolveLds& m, const double* T) {
 // the top / bottom sweep and keeps the solved column of the block it eliminated last in registers: the update a block
 // receives from its neighbour only involves that column and the neighbour's 9x9 coupling block, which travels through LDS
 // (cz: L and 1/L_rr of the two blocks of the step, coupling blocks double-buffered by block parity).
-NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
+NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz_) {
     const BaLayout& L = *c.Lp;
     const int K = L.K, Rc = L.Rc, ldc = m.ldc;
     const int mid = K / 2;
     const int nstep = (K - 1 - mid) > mid ? (K - 1 - mid) : mid;
-    double* Lt = cz;            double* dit = cz + 81;
-    double* Lb = cz + 96;       double* dib = cz + 96 + 81;
-    double* XeB = cz + 192;     // [2][96]: Xe of top block k in buffer k & 1
-    double* XuB = cz + 384;     // [2][96]: slot E_k (rows solved by the bottom block k-1) in buffer k & 1
-    int* flag = (int*)(m.red + 24);
+    lds_d* cz = AS_LDS(cz_);
+    glb_d* const XC = AS_GLB(m.XC);
+    glb_d* const D = AS_GLB(m.D);
+    glb_d* const E = AS_GLB(m.E);
+    glb_d* const dinv = AS_GLB(m.dinv);
+    lds_d* Lt = cz;            lds_d* dit = cz + 81;
+    lds_d* Lb = cz + 96;       lds_d* dib = cz + 96 + 81;
+    lds_d* XeB = cz + 192;     // [2][96]: Xe of top block k in buffer k & 1
+    lds_d* XuB = cz + 384;     // [2][96]: slot E_k (rows solved by the bottom block k-1) in buffer k & 1
+    lds_i* flag = (lds_i*)(m.red + 24);
     if (c.tid == 0) *flag = 1;
     __syncthreads();
     const int half = c.tid >> 8, id = c.tid & 255;
@@ -2073,9 +2186,9 @@ NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
         const bool upd_t_from_above = has_t && kt + 1 <= K - 1 && (last ? (K - 1 > mid) : t > 0);
         const bool upd_mid_from_below = last && mid > 0;
         const bool upd_b = has_b && t > 0;
-        const double* XeP = XeB + 96 * ((kt + 1) & 1);          // coupling block of the upper neighbour kt + 1
-        const double* XuM = XuB + 96 * (kt & 1);                // (last step) slot E_mid, solved by the bottom block mid - 1
-        const double* XuP = XuB + 96 * (kb & 1);                // slot E_kb, solved by the bottom block kb - 1
+        const lds_d* XeP = XeB + 96 * ((kt + 1) & 1);          // coupling block of the upper neighbour kt + 1
+        const lds_d* XuM = XuB + 96 * (kt & 1);                // (last step) slot E_mid, solved by the bottom block mid - 1
+        const lds_d* XuP = XuB + 96 * (kb & 1);                // slot E_kb, solved by the bottom block kb - 1
         // ---- (A) diagonal blocks: update + 9x9 Cholesky in LDS, factor back to HBM for the back substitution
         if (c.wave == 0 && has_t) {
             for (int e = c.lane; e < 81; e += 64) {
@@ -2089,13 +2202,13 @@ NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
 #pragma unroll
                     for (int p = 0; p < 9; ++p) s += XuM[9 * r + p] * XuM[9 * cc + p];
                 }
-                Lt[e] = m.D[81 * kt + e] - s;
+                Lt[e] = D[81 * kt + e] - s;
             }
             __builtin_amdgcn_wave_barrier();
-            if (!chain_factor(c.lane, Lt, dit, 0, nullptr) && c.lane == 0) *flag = 0;
+            if (!chain_factor(c.lane, Lt, dit, 0, (const lds_d*)nullptr) && c.lane == 0) *flag = 0;
             __builtin_amdgcn_wave_barrier();
-            for (int e = c.lane; e < 81; e += 64) m.D[81 * kt + e] = Lt[e];
-            if (c.lane < 9) m.dinv[9 * kt + c.lane] = dit[c.lane];
+            for (int e = c.lane; e < 81; e += 64) D[81 * kt + e] = Lt[e];
+            if (c.lane < 9) dinv[9 * kt + c.lane] = dit[c.lane];
         } else if (c.wave == 4 && has_b) {
             for (int e = c.lane; e < 81; e += 64) {
                 const int r = e / 9, cc = e - 9 * r;
@@ -2104,20 +2217,20 @@ NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
 #pragma unroll
                     for (int p = 0; p < 9; ++p) s += XuP[9 * r + p] * XuP[9 * cc + p];
                 }
-                Lb[e] = m.D[81 * kb + e] - s;
+                Lb[e] = D[81 * kb + e] - s;
             }
             __builtin_amdgcn_wave_barrier();
-            if (!chain_factor(c.lane, Lb, dib, 0, nullptr) && c.lane == 0) *flag = 0;
+            if (!chain_factor(c.lane, Lb, dib, 0, (const lds_d*)nullptr) && c.lane == 0) *flag = 0;
             __builtin_amdgcn_wave_barrier();
-            for (int e = c.lane; e < 81; e += 64) m.D[81 * kb + e] = Lb[e];
-            if (c.lane < 9) m.dinv[9 * kb + c.lane] = dib[c.lane];
+            for (int e = c.lane; e < 81; e += 64) D[81 * kb + e] = Lb[e];
+            if (c.lane < 9) dinv[9 * kb + c.lane] = dib[c.lane];
         }
         __syncthreads();
         if (*flag == 0) break;
         // ---- (B) columns
         if (half == 0 && has_t) {
             if (id <= Rc) {
-                double* col = m.XC + (size_t)9 * kt * ldc + id;
+                glb_d* col = XC + (size_t)9 * kt * ldc + id;
                 double x[9];
 #pragma unroll
                 for (int r = 0; r < 9; ++r) x[r] = col[(size_t)r * ldc];
@@ -2131,7 +2244,7 @@ NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
                     }
                 }
                 if (upd_mid_from_below) {
-                    const double* cb = m.XC + (size_t)9 * (kt - 1) * ldc + id;
+                    const glb_d* cb = XC + (size_t)9 * (kt - 1) * ldc + id;
                     double xb[9];
 #pragma unroll
                     for (int p = 0; p < 9; ++p) xb[p] = cb[(size_t)p * ldc];
@@ -2155,8 +2268,8 @@ NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
             } else if (!last && id < Rc + 10) {
                 // column cc of E_kt -> Xe_kt[p][cc]
                 const int cc = id - Rc - 1;
-                double* e = m.E + 81 * kt + cc;
-                double* xe = XeB + 96 * (kt & 1) + cc;
+                glb_d* e = E + 81 * kt + cc;
+                lds_d* xe = XeB + 96 * (kt & 1) + cc;
                 double x[9];
 #pragma unroll
                 for (int r = 0; r < 9; ++r) x[r] = e[9 * r];
@@ -2172,7 +2285,7 @@ NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
             }
         } else if (half == 1 && has_b) {
             if (id <= Rc) {
-                double* col = m.XC + (size_t)9 * kb * ldc + id;
+                glb_d* col = XC + (size_t)9 * kb * ldc + id;
                 double x[9];
 #pragma unroll
                 for (int r = 0; r < 9; ++r) x[r] = col[(size_t)r * ldc];
@@ -2197,8 +2310,8 @@ NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
             } else if (id < Rc + 10) {
                 // row cc of E_kb+1 (as [c][p]) -> XuT of the pair (kb + 1, kb)
                 const int cc = id - Rc - 1;
-                double* e = m.E + 81 * (kb + 1) + 9 * cc;
-                double* xu = XuB + 96 * ((kb + 1) & 1) + 9 * cc;
+                glb_d* e = E + 81 * (kb + 1) + 9 * cc;
+                lds_d* xu = XuB + 96 * ((kb + 1) & 1) + 9 * cc;
                 double x[9];
 #pragma unroll
                 for (int r = 0; r < 9; ++r) x[r] = e[r];
@@ -2224,12 +2337,12 @@ NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz) {
 template <int NR>
 NOINL void back_substitute_n(const Ctx& c, const SolveLds& m, int R) {
     const BaLayout& L = *c.Lp;
-    const double* S = m.S;
-    const double* dinvv = m.di;
-    double* y = m.vec + V_Y * L.Rpad;
+    const lds_d* S = AS_LDS_C(m.S);
+    const lds_d* dinvv = AS_LDS_C(m.di);
+    glb_d* y = AS_GLB(m.vec + V_Y * L.Rpad);
     __syncthreads();
     if (c.wave == 0) {
-        const double* rowR = S + tri(R, 0);
+        const lds_d* rowR = S + tri(R, 0);
         double v[NR];
 #pragma unroll
         for (int q = 0; q < NR; ++q) { const int l = c.lane + 64 * q; v[q] = l < R ? rowR[l] : 0.0; }
@@ -2237,7 +2350,7 @@ NOINL void back_substitute_n(const Ctx& c, const SolveLds& m, int R) {
         for (int qo = NR - 1; qo >= 0; --qo) {
             const int jhi = R - 1 < 64 * qo + 63 ? R - 1 : 64 * qo + 63;
             for (int j = jhi; j >= 64 * qo; --j) {
-                const double* rj = S + tri(j, 0);
+                const lds_d* rj = S + tri(j, 0);
                 const int own = j & 63;
                 const double xj = readlane_d(v[qo], own) * dinvv[j];
 #pragma unroll
@@ -2354,7 +2467,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     const bool need_system = running && (fresh_point || (trip && !s.reuse));
     if (need_system) {
         const int ntri = Rc * (Rc + 1) / 2;
-        assemble(c, m, buf, rb1, rb1 + ntri);
+        assemble<true>(c, m, buf, rb1, rb1 + ntri);
         if (!s.scaled) {
             for (int k = c.tid; k < R; k += BA_NT) c.sc[L.so_sc + k] = 1.0 / (1.0 + sqrt(hess_diag(L, m, k)));
             s.scaled = 1;
@@ -2392,7 +2505,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
                 s.gtn2 = block_sum(m.red, BA_NW, c.lane, c.wave, sq) + scal[RB1_GTL2];
             }
             PROF_ADD(PF_DG);
-            const double q = build_scaled(c, m, s.mu);
+            const double q = build_scaled<true>(c, m, s.mu);
             __syncthreads();
             PROF_ADD(PF_BUILD);
             bool cok = chain_eliminate_big(c, m, LDSB + L.l_cz);
@@ -2405,7 +2518,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
             if (cok) {
                 back_substitute_n<4>(c, m, Rc);
                 PROF_ADD(PF_BACK);
-                chain_back_substitute(c, m);
+                chain_back_substitute<true>(c, m);
                 PROF_ADD(PF_CBACK);
                 double fin = 0.0, s1 = 0.0, s2 = 0.0;
                 for (int k = c.tid; k < R; k += BA_NT) {
