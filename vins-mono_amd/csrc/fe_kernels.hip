@@ -184,22 +184,39 @@ FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
     w11 = (1 << LK_WBITS) - w00 - w01 - w10;
 }
 
+// Image planes are reached through pointer tables in HBM: a loaded pointer is generic and its accesses would compile to
+// flat_load (which also ties the LDS counter to the image loads); the planes are HBM, say so.  (One address space under the
+// CPU emulation of tests/simt.)
+#ifdef VINS_SIMT
+typedef uint8_t glb_u8;
+#else
+typedef __attribute__((address_space(1))) uint8_t glb_u8;
+#endif
+
 // Stage the LK_JR x LK_JR search region with origin (ox, oy) of plane J into LDS (reflect-101 outside the image, exactly
 // the pixels the per-window gather of LKTrackerInvoker reads).  lane = (row, 16-byte half): one unaligned 16-byte load
 // per lane when the region lies inside the image, per-byte reflection at the borders.
-FDEV void lk_stage_region(uint8_t* reg, const uint8_t* J, int lw, int lh, int ox, int oy, int lane) {
+FDEV void lk_stage_region(uint8_t* reg, const glb_u8* J, int lw, int lh, int ox, int oy, int lane) {
     __syncthreads();
     const int row = lane >> 1, hf = lane & 1;
     const bool inside = ox >= 0 && ox + LK_JR <= lw && oy >= 0 && oy + LK_JR <= lh;      // uniform
     if (inside) {
         uint4 v;
-        __builtin_memcpy(&v, J + (size_t)(oy + row) * lw + ox + 16 * hf, 16);
+        const glb_u8* pj = J + (size_t)(oy + row) * lw + ox + 16 * hf;      // unaligned 16 bytes
+#ifdef VINS_SIMT
+        __builtin_memcpy(&v, pj, 16);
+#else
+        typedef unsigned int nv4 __attribute__((ext_vector_type(4), aligned(1)));
+        typedef __attribute__((address_space(1))) const nv4 glb_nv4;
+        const nv4 t4 = *(glb_nv4*)pj;
+        v.x = t4.x; v.y = t4.y; v.z = t4.z; v.w = t4.w;
+#endif
         *(uint4*)(reg + row * LK_JR + 16 * hf) = v;
     } else {
         // (the +-LK_JS margin may reach more than one image size outside a tiny level; those pixels are never part of a
         //  window — a window origin is >= -LK_WIN — so they are clamped instead of folded twice)
         const int ry = reflect101(oy + row, lh);
-        const uint8_t* src = J + (size_t)(ry < 0 ? 0 : (ry >= lh ? lh - 1 : ry)) * lw;
+        const glb_u8* src = J + (size_t)(ry < 0 ? 0 : (ry >= lh ? lh - 1 : ry)) * lw;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int rx = reflect101(ox + 16 * hf + q, lw);
@@ -224,8 +241,8 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
     const int lyc = act ? ly : 0;
     for (int level = d.max_level; level >= 0; --level) {
         const int lw = d.lw[level], lh = d.lh[level];
-        const uint8_t* I = d.prev_planes[level * d.cams + cam];
-        const uint8_t* J = d.cur_planes[level * d.cams + cam];
+        const glb_u8* I = (const glb_u8*)d.prev_planes[level * d.cams + cam];
+        const glb_u8* J = (const glb_u8*)d.cur_planes[level * d.cams + cam];
         float prevx = px * (float)(1. / (1 << level)), prevy = py * (float)(1. / (1 << level));
         float nextx, nexty;
         if (level == d.max_level) { nextx = prevx; nexty = prevy; }
@@ -399,7 +416,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d) {
     __shared__ float bmax[4];
     const int cam = blockIdx.z, W = d.W, H = d.H;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
-    const uint8_t* img = d.cur_planes[cam];          // level 0
+    const glb_u8* img = (const glb_u8*)d.cur_planes[cam];          // level 0
     for (int k = threadIdx.x; k < 8 * 68; k += 256) {
         const int yy = k / 68, xx = k % 68;
         // NB: REFLECT_101 is applied per filter stage in OpenCV (Sobel on the image, then boxFilter on cov); the halo
