@@ -924,24 +924,11 @@ NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf_, const d
         const glb_d* imuJ = buf + L.bo_imuJ;
         for (int par = 0; par < 2; ++par) {
             const int nf = (nimu - par + 1) / 2;
-            if (!BIG) {
-                for (int w = c.tid; w < nf * 512; w += BA_NT) {
-                    const int f = 2 * (w >> 9) + par, e = w & 511;
-                    if (e >= 495 || !valid[f]) continue;
-                    const double v = imuJ[f * 512 + e];
-                    if (e < 465) {
-                        int a, b;
-                        tri_decode(e, a, b);
-                        hess_add(L, q, imu_col(L, f, a), imu_col(L, f, b), v);
-                    } else {
-                        g[imu_col(L, f, e - 465)] += v;
-                    }
-                }
-            } else {
-                // large-window path: most targets are in HBM, a read-modify-write per trip would be a chain of memory round
-                // trips.  Thread = entry e of every factor of this parity, eight factors at a time: all loads first, then
-                // all stores (inside a round every entry has exactly one writer, so the slots are distinct).  Entries of
-                // the camera part live in LDS: they are added directly.
+            {
+                // Thread = entry e of every factor of this parity, eight factors at a time: all loads of the IMU blocks first,
+                // then the read-modify-writes (inside a round every entry has exactly one writer, so the slots are distinct).
+                // One trip per entry would be a chain of HBM round trips; on the large-window path most targets are in HBM too.
+                // Entries of the camera part live in LDS on both paths: they are added directly.
                 const int e = c.tid;
                 int a = 0, b = 0;
                 if (e < 465) tri_decode(e, a, b);
@@ -949,12 +936,18 @@ NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf_, const d
                     MV* p0[8];
                     MV* p1[8];
                     double v[8], t0[8], t1[8];
+                    bool on[8];
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {                 // the loads of the chunk, nothing else
+                        const int f = 2 * (i0 + qq) + par;
+                        on[qq] = i0 + qq < nf && e < 495 && valid[f];
+                        v[qq] = on[qq] ? imuJ[f * 512 + e] : 0.0;
+                    }
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
                         const int f = 2 * (i0 + qq) + par;
-                        p0[qq] = nullptr; p1[qq] = nullptr; v[qq] = 0.0;
-                        if (i0 + qq < nf && e < 495 && valid[f]) {
-                            v[qq] = imuJ[f * 512 + e];
+                        p0[qq] = nullptr; p1[qq] = nullptr;
+                        if (on[qq]) {
                             if (e >= 465) { p0[qq] = g + imu_col(L, f, e - 465); continue; }
                             int ca = imu_col(L, f, a), cb = imu_col(L, f, b);
                             if (ca < cb) { const int t = ca; ca = cb; cb = t; }
@@ -987,17 +980,33 @@ NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf_, const d
         const int n = c.nprior;
         const glb_d* Hp = AS_GLB_C(c.sc + L.so_Hp);
         const glb_d* gpr = buf + L.bo_gpr;        // J0^T r, formed by the linearisation kernel
-        for (int w = c.tid; w < n * (n + 1) / 2 + n; w += BA_NT) {
-            const bool isg = w >= n * (n + 1) / 2;
-            if (isg) {
-                const int a = w - n * (n + 1) / 2;
-                const int ca = q.pmap[a];
-                if (ca >= 0) g[ca] += gpr[a];
-            } else {
-                int a, b;
-                tri_decode(w, a, b);
-                const int ca = q.pmap[a], cb = q.pmap[b];
-                if (ca >= 0 && cb >= 0) hess_add(L, q, ca, cb, Hp[a * L.Ncap + b]);
+        const int nent = n * (n + 1) / 2 + n;
+        for (int w0 = 0; w0 < nent; w0 += 8 * BA_NT) {
+            // eight entries per thread: indices and the eight HBM loads first, then the adds (every entry of H is touched by
+            // exactly one prior entry: the column map is injective)
+            int ca[8], cb[8];
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int w = w0 + c.tid + u * BA_NT;
+                ca[u] = -1; cb[u] = -1; v[u] = 0.0;
+                if (w < nent) {
+                    if (w >= n * (n + 1) / 2) {
+                        const int a = w - n * (n + 1) / 2;
+                        ca[u] = q.pmap[a]; cb[u] = -2;          // gradient entry
+                        v[u] = gpr[a];
+                    } else {
+                        int a, b;
+                        tri_decode(w, a, b);
+                        ca[u] = q.pmap[a]; cb[u] = q.pmap[b];
+                        v[u] = Hp[a * L.Ncap + b];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (cb[u] == -2) { if (ca[u] >= 0) g[ca[u]] += v[u]; }
+                else if (ca[u] >= 0 && cb[u] >= 0) hess_add(L, q, ca[u], cb[u], v[u]);
             }
         }
     }
@@ -1322,42 +1331,50 @@ NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double
     for (int l = c.tid; l < c.nL; l += BA_NT) lsc[l] = sl[l] / sqrt(sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l]);
     // ---- chain rows
     const int nk = (9 * L.K + 3) / 4;
-    for (int kk = 0; kk < nk; ++kk) {
-        const lds_d* xr = XC + (kk * 4 + (c.lane >> 4)) * ldc + (c.lane & 15);
+    for (int kk0 = 0; kk0 < nk; kk0 += 4) {        // four k-steps per trip: their operand reads first, then the MFMAs
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (c.wave + s * BA_NW < ntile) {
-                const double a = xr[tm[s] * 16];
-                const double bb = xr[tn[s] * 16];
-                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[s], 0, 0, 0);
+                double av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = kk0 + u < nk ? kk0 + u : nk - 1;
+                    const lds_d* xr = XC + (kk * 4 + (c.lane >> 4)) * ldc + (c.lane & 15);
+                    av[u] = xr[tm[s] * 16];
+                    bv[u] = xr[tn[s] * 16];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (kk0 + u < nk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc[s], 0, 0, 0);
             }
         }
     }
     DP_ADD(10);
-    // ---- landmark columns: element w = tid + BA_NT * i of the (RcPad x SCHUR_LW) tile -> row w / 32, landmark l0 + w % 32
-    double pre[SCHUR_PF];
+    // ---- landmark columns: element w = tid + BA_NT * i of the (RcPad x SCHUR_LW) tile -> row w / 32, landmark l0 + w % 32.
+    //      fetch(): everything of the next tile that comes from HBM (Wt, the landmark factor, b for the rhs row) into registers
+    double pre[SCHUR_PF], pls[SCHUR_PF];
     const int nel = RcPad * SCHUR_LW;
     auto fetch = [&](int l0) {
 #pragma unroll
         for (int i = 0; i < SCHUR_PF; ++i) {
             const int w = c.tid + BA_NT * i;
             const int row = w / SCHUR_LW, l = l0 + (w % SCHUR_LW);
-            const bool in = w < nel && row < Rc && l < c.nL;
-            pre[i] = in ? Wt[(size_t)row * L.Lcap + l] : 0.0;
+            const bool in = w < nel && row <= Rc && l < c.nL;
+            pre[i] = in ? (row < Rc ? Wt[(size_t)row * L.Lcap + l] : b[l]) : 0.0;
+            pls[i] = in ? lsc[l] : 0.0;
         }
     };
+    __syncthreads();                               // lsc of this launch visible to every wavefront
     if (c.nL > 0) fetch(0);
     for (int l0 = 0; l0 < c.nL; l0 += SCHUR_LW) {
-        __syncthreads();                           // lsc visible (first trip) / previous tile consumed
+        __syncthreads();                           // previous tile consumed
         DP_ADD(11);
 #pragma unroll
         for (int i = 0; i < SCHUR_PF; ++i) {
             const int w = c.tid + BA_NT * i;
             if (w < nel) {
-                const int row = w / SCHUR_LW, k = w % SCHUR_LW, l = l0 + k;
-                double v = (row < Rc && l < c.nL) ? sc[row] * pre[i] * lsc[l] : 0.0;
-                if (row == Rc && l < c.nL) v = b[l] * lsc[l];
-                wd[row * SCHUR_LD + k] = v;
+                const int row = w / SCHUR_LW, k = w % SCHUR_LW;
+                wd[row * SCHUR_LD + k] = (row < Rc ? sc[row] : 1.0) * pre[i] * pls[i];
             }
         }
         DP_ADD(12);
@@ -1367,12 +1384,15 @@ NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (c.wave + s * BA_NW < ntile) {
+                // the sixteen operand reads of a tile first, then its eight MFMAs back to back
+                double av[SCHUR_LW / 4], bv[SCHUR_LW / 4];
 #pragma unroll
                 for (int kk = 0; kk < SCHUR_LW / 4; ++kk) {
-                    const double a = wd[(tm[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
-                    const double bb = wd[(tn[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
-                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[s], 0, 0, 0);
+                    av[kk] = wd[(tm[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
+                    bv[kk] = wd[(tn[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
                 }
+#pragma unroll
+                for (int kk = 0; kk < SCHUR_LW / 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc[s], 0, 0, 0);
             }
         }
         DP_ADD(14);
@@ -1826,12 +1846,34 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
                     chain_back_substitute<false>(c, m);
                     PROF_ADD(PF_CBACK);
                     // landmarks: y_l = (bt_l - wt_l . y_cam) / ht_l
+                    // four threads per landmark (rows k = q, q + 4, ...; consecutive lanes = consecutive landmarks: coalesced),
+                    // eight loads in flight per thread, partial sums combined through LDS in a fixed order
                     const double* Wt = buf + L.bo_Wt;
-                    for (int l = c.tid; l < nL; l += BA_NT) {
-                        const double ht = sl[l] * sl[l] * hh[l] + s.mu * dgl[l] * dgl[l];
+                    for (int k = c.tid; k < Rc; k += BA_NT) vU[k] = vSC[k] * vY[k];
+                    __syncthreads();
+                    for (int l0 = 0; l0 < nL; l0 += BA_NT / 4) {
+                        const int l = l0 + (c.tid & (BA_NT / 4 - 1)), qd = c.tid / (BA_NT / 4);
                         double acc = 0.0;
-                        for (int k = 0; k < Rc; ++k) acc += vSC[k] * Wt[(size_t)k * L.Lcap + l] * vY[k];
-                        yl[l] = (sl[l] * bb[l] - sl[l] * acc) / ht;
+                        if (l < nL) {
+                            const double* wp = Wt + l;
+                            int k = qd;
+                            for (; k + 28 < Rc; k += 32) {
+                                double wv[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) wv[u] = wp[(size_t)(k + 4 * u) * L.Lcap];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) acc += wv[u] * vU[k + 4 * u];
+                            }
+                            for (; k < Rc; k += 4) acc += wp[(size_t)k * L.Lcap] * vU[k];
+                        }
+                        m.wd[c.tid] = acc;
+                        __syncthreads();
+                        if (qd == 0 && l < nL) {
+                            const double a4 = (m.wd[c.tid] + m.wd[c.tid + BA_NT / 4]) + (m.wd[c.tid + BA_NT / 2] + m.wd[c.tid + 3 * BA_NT / 4]);
+                            const double ht = sl[l] * sl[l] * hh[l] + s.mu * dgl[l] * dgl[l];
+                            yl[l] = (sl[l] * bb[l] - sl[l] * a4) / ht;
+                        }
+                        __syncthreads();
                     }
                     double fin = 0.0;
                     for (int k = c.tid; k < R; k += BA_NT) fin += (vY[k] == vY[k] && fabs(vY[k]) < 1e300) ? 0.0 : 1.0;
