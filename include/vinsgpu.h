@@ -204,6 +204,16 @@ int vg_ba_batch_run_async(vg_handle* h);
 int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_ms);
 int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* out_states,
                          vg_ba_summary* out_summaries, vg_ba_prior* const* out_priors);
+/* The download in two parts.  The states and summaries are final as soon as the solve pipeline has finished; the
+ * marginalization kernel that follows on the stream only reads them, and its result is consumed by the NEXT frame's
+ * optimization (estimator.cpp:703-709).  download_state returns while the marginalization is still running (it waits for
+ * an event recorded behind the solve pipeline and copies on a second stream); download_prior waits for the whole stream.
+ * Collect the priors before the handle's next upload. */
+int vg_ba_batch_download_state(vg_handle* h, int nwin, vg_ba_state* const* out_states, vg_ba_summary* out_summaries);
+int vg_ba_batch_download_prior(vg_handle* h, int nwin, vg_ba_prior* const* out_priors);
+/* vg_ba_optimize in the same two parts (one window): begin = upload + run + download_state */
+int vg_ba_optimize_begin(vg_handle* h, const vg_ba_problem* in, int margin_flag, vg_ba_state* out_state, vg_ba_summary* out_summary);
+int vg_ba_optimize_prior(vg_handle* h, vg_ba_prior* out_prior);
 /* one synchronous run with a HIP event after every launch of the solve pipeline: ms[k] = summed duration and n[k] =
  * number of launches of kernel class k (both arrays VG_BA_KERNEL_COUNT long) */
 enum { VG_BA_KERNEL_PROLOGUE = 0, VG_BA_KERNEL_LINEARIZE, VG_BA_KERNEL_ACCUMULATE, VG_BA_KERNEL_SOLVE, VG_BA_KERNEL_FINAL,

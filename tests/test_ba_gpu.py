@@ -487,3 +487,24 @@ def test_solver_time_cap(handle):
     assert sm2['num_iterations'] == 0 and sm2['final_cost'] == sm2['initial_cost'] == sm0['initial_cost']
     ref = B.double2vector(prob, dict(pose=prob['pose'], sb=prob['sb'], ex=prob['ex'], td=prob['td'], inv_depth=prob['inv_depth']))
     assert np.abs(st2['pose'] - ref['pose']).max() < 1e-12
+
+
+def test_state_download_overtakes_the_marginalization(handle):
+    """vg_ba_batch_download_state / _prior: the states come back while the marginalization kernel is still queued or running
+    (second stream behind an event recorded after the solve pipeline); both parts equal the one-call download bit for bit."""
+    probs = [_window_with_prior(60 + k, L=40)[2] for k in range(3)]
+    handle.ba_upload(probs, [ba.VG_MARGIN_OLD] * 3)
+    handle.ba_run_async()
+    st0, sm0, pr0 = handle.ba_download()
+    handle.ba_run_async()
+    outs, st, pri, sm, packed = handle.ba_prepare_download()
+    assert handle.ba_download_state_raw() == 0
+    st1 = [o.state_dict(p.has_relo) for o, p in zip(outs, packed)]
+    assert handle.ba_download_prior_raw() == 0
+    pr1 = [o.prior_dict() for o in outs]
+    for a, b in zip(st0, st1):
+        assert np.array_equal(a['pose'], b['pose']) and np.array_equal(a['sb'], b['sb']) and np.array_equal(a['inv_depth'], b['inv_depth'])
+    for a, b in zip(pr0, pr1):
+        assert a['n'] == b['n'] and np.array_equal(a['J0'], b['J0']) and np.array_equal(a['r0'], b['r0'])
+    s, m, p, t_ms = handle.ba_optimize_split(probs[0], ba.VG_MARGIN_OLD)
+    assert np.array_equal(s['pose'], st0[0]['pose']) and np.array_equal(p['J0'], pr0[0]['J0']) and t_ms > 0

@@ -182,6 +182,8 @@ class Handle:
         L.vg_ba_batch_run_async.argtypes = [C.c_void_p]
         L.vg_ba_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(State)), C.POINTER(Summary),
                                            C.POINTER(C.POINTER(Prior))]
+        L.vg_ba_batch_download_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(State)), C.POINTER(Summary)]
+        L.vg_ba_batch_download_prior.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(Prior))]
         L.vg_ba_batch_run_timed.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.vg_ba_batch_run_profiled.argtypes = [C.c_void_p, C.POINTER(C.c_float), _pi]
         L.vg_ba_batch_flops_by_kernel.argtypes = [C.c_void_p, _pd]
@@ -321,6 +323,30 @@ class Handle:
         return ([o.state_dict(p.has_relo) for o, p in zip(outs, packed)],
                 [summary_dict(sm[i]) for i in range(n)],
                 [o.prior_dict() for o in outs])
+
+    def ba_download_state_raw(self):
+        """vg_ba_batch_download_state into the buffers of ba_prepare_download(): returns while the marginalization runs."""
+        outs, st, pri, sm, _ = self._dl
+        t0 = time.perf_counter()
+        rc = self.lib.vg_ba_batch_download_state(self.h, len(outs), st, sm)
+        self.last_download_call_ms = (time.perf_counter() - t0) * 1e3
+        return rc
+
+    def ba_download_prior_raw(self):
+        outs, st, pri, sm, _ = self._dl
+        return self.lib.vg_ba_batch_download_prior(self.h, len(outs), pri)
+
+    def ba_optimize_split(self, prob, margin_flag=VG_MARGIN_NONE):
+        """vg_ba_optimize in two parts: returns (state, summary, prior, ms until the states were on the host)."""
+        t0 = time.perf_counter()
+        self.ba_upload([prob], [margin_flag])
+        self.ba_run_async()
+        outs, st, pri, sm, packed = self.ba_prepare_download()
+        self._chk(self.ba_download_state_raw(), "vg_ba_batch_download_state")
+        t_state = (time.perf_counter() - t0) * 1e3
+        state, summ = outs[0].state_dict(packed[0].has_relo), summary_dict(sm[0])
+        self._chk(self.ba_download_prior_raw(), "vg_ba_batch_download_prior")
+        return state, summ, outs[0].prior_dict(), t_state
 
     def ba_optimize(self, prob, margin_flag=VG_MARGIN_NONE):
         """One Estimator::optimization(): returns (state, summary, new_prior)."""

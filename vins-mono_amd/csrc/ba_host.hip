@@ -547,6 +547,7 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     HIPCHK(h, hipStreamSynchronize(h->stream));
     B.any_margin = false;
     for (int w = 0; w < nwin; ++w) B.any_margin = B.any_margin || B.margin[w] != VG_MARGIN_NONE;
+    B.solved_recorded = false;
     B.uploaded = true;
     return VG_OK;
 }
@@ -576,6 +577,8 @@ extern "C" int vg_ba_batch_run_async(vg_handle* h) {
     BaBatch& B = h->ba;
     const int rc = launch_solve(h);
     if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));           // states final: vg_ba_batch_download_state waits for this only
+    B.solved_recorded = true;
     if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
     return VG_OK;
 }
@@ -676,25 +679,17 @@ extern "C" int vg_ba_batch_info(vg_handle* h, double* flops, double* bytes_in, d
     return VG_OK;
 }
 
-extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_summary* sum,
-                                    vg_ba_prior* const* pri) {
-    VG_RANGE("vg_ba_batch_download");
-    if (!h || !h->ba.uploaded || nwin != h->ba.nwin) return VG_ERR_BAD_ARG;
+// ---- results.  The states (and the solver summaries) are final once ba_final_kernel has run; the marginalization kernel
+// that follows on the stream only READS them.  A caller that needs the prior later than the states (Estimator::optimization():
+// the prior is consumed by the NEXT frame's optimization, estimator.cpp:703-709) collects them separately:
+//   vg_ba_batch_download_state  waits for the event recorded behind ba_final_kernel and copies on the second stream, so it
+//                               returns while the marginalization kernel is still running;
+//   vg_ba_batch_download_prior  waits for the whole stream.
+// vg_ba_batch_download = both, in order.
+static int unpack_states(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_summary* sum) {
     BaBatch& B = h->ba;
     const BaLayout& L = B.L;
-    HIPCHK(h, B.h_out.resize((size_t)nwin * L.ostride));
-    HIPCHK(h, B.h_iout.resize((size_t)nwin * L.oi_stride));
-    HIPCHK(h, hipMemcpyAsync(B.h_out.data(), B.P.out, B.h_out.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(B.h_iout.data(), B.P.iout, B.h_iout.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (B.any_margin && pri) {
-        HIPCHK(h, B.h_mout.resize((size_t)nwin * L.mo_stride));
-        HIPCHK(h, B.h_miout.resize((size_t)nwin * L.mi_stride));
-        HIPCHK(h, hipMemcpyAsync(B.h_mout.data(), B.P.mout, B.h_mout.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(B.h_miout.data(), B.P.miout, B.h_miout.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     int worst = VG_OK;
-    static const bool debug_marg = getenv("VG_DEBUG_MARG") != nullptr;      // phase stamps of -DBA_PROFILE builds
     for (int w = 0; w < nwin; ++w) {
         const double* o = B.h_out.data() + (size_t)w * L.ostride;
         const int* io = B.h_iout.data() + (size_t)w * L.oi_stride;
@@ -723,6 +718,15 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
             }
             for (int k = 0; k < 16; ++k) s.prof[k] = o[L.oo_trace + 5 * VG_MAX_ITERS + k];
         }
+    }
+    return worst;
+}
+
+static int unpack_priors(vg_handle* h, int nwin, vg_ba_prior* const* pri) {
+    BaBatch& B = h->ba;
+    const BaLayout& L = B.L;
+    static const bool debug_marg = getenv("VG_DEBUG_MARG") != nullptr;      // phase stamps of -DBA_PROFILE builds
+    for (int w = 0; w < nwin; ++w) {
         if (pri && pri[w]) {
             vg_ba_prior* q = pri[w];
             q->n = q->m = q->nblocks = q->valid = 0;
@@ -754,6 +758,62 @@ extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* 
             }
         }
     }
+    return VG_OK;
+}
+
+static int copy_states(vg_handle* h, int nwin, hipStream_t stream) {
+    BaBatch& B = h->ba;
+    const BaLayout& L = B.L;
+    HIPCHK(h, B.h_out.resize((size_t)nwin * L.ostride));
+    HIPCHK(h, B.h_iout.resize((size_t)nwin * L.oi_stride));
+    HIPCHK(h, hipMemcpyAsync(B.h_out.data(), B.P.out, B.h_out.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(h, hipMemcpyAsync(B.h_iout.data(), B.P.iout, B.h_iout.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    return VG_OK;
+}
+static int copy_priors(vg_handle* h, int nwin, hipStream_t stream) {
+    BaBatch& B = h->ba;
+    const BaLayout& L = B.L;
+    HIPCHK(h, B.h_mout.resize((size_t)nwin * L.mo_stride));
+    HIPCHK(h, B.h_miout.resize((size_t)nwin * L.mi_stride));
+    HIPCHK(h, hipMemcpyAsync(B.h_mout.data(), B.P.mout, B.h_mout.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(h, hipMemcpyAsync(B.h_miout.data(), B.P.miout, B.h_miout.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    return VG_OK;
+}
+
+extern "C" int vg_ba_batch_download_state(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_summary* sum) {
+    VG_RANGE("vg_ba_batch_download_state");
+    if (!h || !h->ba.uploaded || nwin != h->ba.nwin) return VG_ERR_BAD_ARG;
+    if (!h->ba.solved_recorded) { h->err = "vg_ba_batch_download_state before vg_ba_batch_run_async"; return VG_ERR_BAD_ARG; }
+    HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));        // ev_fork: recorded behind ba_final_kernel by run_async
+    int rc = copy_states(h, nwin, h->aux);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->aux));
+    return unpack_states(h, nwin, st, sum);
+}
+
+extern "C" int vg_ba_batch_download_prior(vg_handle* h, int nwin, vg_ba_prior* const* pri) {
+    VG_RANGE("vg_ba_batch_download_prior");
+    if (!h || !h->ba.uploaded || nwin != h->ba.nwin || !pri) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    if (B.any_margin) {
+        const int rc = copy_priors(h, nwin, h->stream);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return unpack_priors(h, nwin, pri);
+}
+
+extern "C" int vg_ba_batch_download(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_summary* sum,
+                                    vg_ba_prior* const* pri) {
+    VG_RANGE("vg_ba_batch_download");
+    if (!h || !h->ba.uploaded || nwin != h->ba.nwin) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    int rc = copy_states(h, nwin, h->stream);
+    if (rc) return rc;
+    if (B.any_margin && pri) { rc = copy_priors(h, nwin, h->stream); if (rc) return rc; }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int worst = unpack_states(h, nwin, st, sum);
+    if (pri) { rc = unpack_priors(h, nwin, pri); if (rc) return rc; }
     return worst;
 }
 
@@ -769,6 +829,27 @@ extern "C" int vg_ba_optimize(vg_handle* h, const vg_ba_problem* in, int margin_
     vg_ba_state* sarr[1] = {out_state};
     vg_ba_prior* parr[1] = {out_prior};
     return vg_ba_batch_download(h, 1, sarr, out_summary, parr);
+}
+
+// The same in two calls: the first returns as soon as the states are on the host (the marginalization kernel keeps
+// running on the device), the second collects the prior -- any time before the handle's next upload.
+extern "C" int vg_ba_optimize_begin(vg_handle* h, const vg_ba_problem* in, int margin_flag, vg_ba_state* out_state,
+                                    vg_ba_summary* out_summary) {
+    VG_RANGE("vg_ba_optimize_begin");
+    if (!h || !in) return VG_ERR_BAD_ARG;
+    const vg_ba_problem* arr[1] = {in};
+    int rc = vg_ba_batch_upload(h, 1, arr, &margin_flag);
+    if (rc) return rc;
+    rc = vg_ba_batch_run_async(h);
+    if (rc) return rc;
+    vg_ba_state* sarr[1] = {out_state};
+    return vg_ba_batch_download_state(h, 1, sarr, out_summary);
+}
+extern "C" int vg_ba_optimize_prior(vg_handle* h, vg_ba_prior* out_prior) {
+    VG_RANGE("vg_ba_optimize_prior");
+    if (!h || !out_prior) return VG_ERR_BAD_ARG;
+    vg_ba_prior* parr[1] = {out_prior};
+    return vg_ba_batch_download_prior(h, 1, parr);
 }
 
 extern "C" int vg_ba_eval_factors(vg_handle* h, const vg_ba_problem* in, double* proj_r, double* proj_J,

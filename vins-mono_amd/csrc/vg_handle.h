@@ -38,6 +38,7 @@ struct BaBatch {
     int nwin = 0;
     int rounds = 0;                  // launches of the linearise / accumulate / solve triple = max over windows of max_iters
     bool uploaded = false, any_margin = false;
+    bool solved_recorded = false;    // ev_fork recorded behind ba_final_kernel of the current run
     bool force_large = false;        // vg_ba_set_large_window: take the large-window path whatever the size
     void* allreduce = nullptr;       // vg_allreduce_fn of the large-window path (nullptr: single rank)
     void* allreduce_user = nullptr;

@@ -177,6 +177,7 @@ void Estimator::double2vector() {
 void Estimator::optimization() {
     if (vg_abi_version() != VG_ABI_VERSION) throw std::runtime_error("libvinsgpu.so was built from another include/vinsgpu.h (ABI version mismatch)");
     if (!vg_ && vg_create(&vg_) != VG_OK) throw std::runtime_error("vg_create failed: no MI355X / libvinsgpu (no CPU fallback)");
+    collectPrior();                                             // the previous frame's marginalization result, if still on the device
     vector2double();                                            // estimator.cpp:701
     const int K = WINDOW_SIZE + 1;
     // ---- factor tables instead of problem.AddResidualBlock (:711-764)
@@ -264,6 +265,25 @@ void Estimator::optimization() {
     vg_ba_state st;
     st.pose = &para_Pose[0][0]; st.speedbias = &para_SpeedBias[0][0]; st.ex_pose = &para_Ex_Pose[0][0]; st.td = &para_Td[0][0];
     st.inv_depth = lam.data(); st.relo_pose = pb.relo_n ? relo_Pose : nullptr;
+    const int flag = marginalization_flag == MARGIN_OLD ? VG_MARGIN_OLD : VG_MARGIN_SECOND_NEW;
+    // ceres::Solve (:818) returns here as soon as the states are back on the host; the marginalization (:825-1000) keeps
+    // running on the device and is collected by collectPrior() -- its result is first needed by the next optimization()
+    const int rc = vg_ba_optimize_begin(vg_, &pb, flag, &st, &last_summary);
+    if (rc != VG_OK && rc != VG_ERR_NUMERIC) throw std::runtime_error(std::string("vg_ba_optimize_begin: ") + vg_last_error(vg_));
+    for (int l = 0; l < L; ++l) para_Feature[l][0] = lam[l];
+    double2vector();                                            // :823
+    solver_failed = rc == VG_ERR_NUMERIC;
+    prior_pending = true;
+    if (solver_failed) collectPrior();                          // (drops the priors, see there)
+}
+
+// The marginalization result of the last optimization(): last_marginalization_info / ..._parameter_blocks are replaced when
+// the device produced a prior (:926-929 / :992-996).  Called by the next optimization(); call it explicitly before reading
+// last_marginalization_info (tests, serialisation).
+void Estimator::collectPrior() {
+    if (!prior_pending) return;
+    prior_pending = false;
+    const int K = WINDOW_SIZE + 1;
     const int cap = 6 * K + 32, capb = K + 8;
     vector<int> nkind(capb), nindex(capb);
     vector<double> nJ0((size_t)cap * cap), nr0(cap), nx0(9 * capb);      // x0 holds 9 doubles per block at most (speed-bias)
@@ -271,12 +291,8 @@ void Estimator::optimization() {
     memset(&pr, 0, sizeof(pr));
     pr.cap = cap; pr.cap_blocks = capb; pr.block_kind = nkind.data(); pr.block_index = nindex.data();
     pr.J0 = nJ0.data(); pr.r0 = nr0.data(); pr.x0 = nx0.data();
-    const int flag = marginalization_flag == MARGIN_OLD ? VG_MARGIN_OLD : VG_MARGIN_SECOND_NEW;
-    const int rc = vg_ba_optimize(vg_, &pb, flag, &st, &last_summary, &pr);       // ceres::Solve (:818) + marginalization (:825-1000)
-    if (rc != VG_OK && rc != VG_ERR_NUMERIC) throw std::runtime_error(std::string("vg_ba_optimize: ") + vg_last_error(vg_));
-    for (int l = 0; l < L; ++l) para_Feature[l][0] = lam[l];
-    double2vector();                                            // :823
-    solver_failed = rc == VG_ERR_NUMERIC;
+    const int rc = vg_ba_optimize_prior(vg_, &pr);
+    if (rc != VG_OK) throw std::runtime_error(std::string("vg_ba_optimize_prior: ") + vg_last_error(vg_));
     if (solver_failed) {
         // Non-finite cost / state on the device: no new prior exists, and the OLD one must not survive the caller's
         // slideWindow() (after MARGIN_OLD it still names pose / speed-bias 0 and un-shifted frame indices).  The reference

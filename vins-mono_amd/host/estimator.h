@@ -58,6 +58,7 @@ class Estimator {
     Estimator();
     ~Estimator();
     void optimization();           // estimator.h:47
+    void collectPrior();           // picks up the marginalization result of the last optimization() (it runs behind the state download)
     void vector2double();
     void double2vector();
     void slideWindow();            // estimator.cpp:1005-1126 (state / pre-integration shift + slideWindowOld / slideWindowNew)
@@ -86,6 +87,7 @@ class Estimator {
     bool relo_in_problem = false;              // the last optimization() carried relocalisation factors
     Matrix3d back_R0;
     Vector3d back_P0;
+    bool prior_pending = false;    // optimization() has returned, its marginalization result is still on the device
     bool solver_failed = false;    // the device reported a non-finite solve: the prior was dropped (see optimization())
     vg_ba_summary last_summary;    // trace of the last solve (the reference only logs Summary::BriefReport)
 

@@ -80,6 +80,7 @@ extern "C" int vins_host_estimator_roundtrip(const vg_ba_problem* p, int margin_
     }
     est.marginalization_flag = margin_flag == VG_MARGIN_OLD ? Estimator::MARGIN_OLD : Estimator::MARGIN_SECOND_NEW;
     est.optimization();
+    est.collectPrior();
     for (int i = 0; i <= WINDOW_SIZE; ++i) {
         Quaterniond q(est.Rs[i]);
         const double row[7] = {est.Ps[i].x(), est.Ps[i].y(), est.Ps[i].z(), q.x(), q.y(), q.z(), q.w()};
@@ -165,6 +166,7 @@ extern "C" int vins_host_estimator_relo_roundtrip(const vg_ba_problem* p, int re
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) est.prev_relo_r(r, c) = prev_relo_r[3 * r + c];
     est.marginalization_flag = Estimator::MARGIN_OLD;
     est.optimization();
+    est.collectPrior();
     if (est.relocalization_info) return -2;                               // double2vector() must have consumed it
     for (int i = 0; i <= WINDOW_SIZE; ++i) {
         Quaterniond q(est.Rs[i]);
