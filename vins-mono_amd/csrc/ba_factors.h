@@ -141,12 +141,13 @@ struct ImuCtx {
     double dt;
 };
 
-template <bool JAC>
-DEV void imu_ctx(const double* pre, const double* pose_i, const double* sb_i, const double* pose_j,
+// PP: pointer type of the pre-integration record (generic, or typed as global memory by the caller)
+template <bool JAC, typename PP>
+DEV void imu_ctx(PP pre, const double* pose_i, const double* sb_i, const double* pose_j,
                  const double* sb_j, double g_norm, ImuCtx& c) {
     const double dt = pre[IM_SUMDT];
     c.dt = dt;
-    const double* Jm = pre + IM_JAC;
+    const PP Jm = pre + IM_JAC;
     double qi_inv[4], t3[3];
     q_inv(pose_i + 3, qi_inv);
     q_to_R(qi_inv, c.Rinv);
@@ -174,8 +175,9 @@ DEV void imu_ctx(const double* pre, const double* pose_i, const double* sb_i, co
                  + Jm[(6 + k) * 15 + 12] * dbg[0] + Jm[(6 + k) * 15 + 13] * dbg[1] + Jm[(6 + k) * 15 + 14] * dbg[2];
     }
     const double dq[4] = {th[0] / 2.0, th[1] / 2.0, th[2] / 2.0, 1.0};
+    const double pdq[4] = {pre[IM_DQ], pre[IM_DQ + 1], pre[IM_DQ + 2], pre[IM_DQ + 3]};
     double cdq[4], cdq_inv[4], qij[4], qe[4];
-    q_mul(pre + IM_DQ, dq, cdq);
+    q_mul(pdq, dq, cdq);
     q_inv(cdq, cdq_inv);
     q_mul(qi_inv, pose_j + 3, qij);
     q_mul(cdq_inv, qij, qe);
@@ -192,7 +194,7 @@ DEV void imu_ctx(const double* pre, const double* pose_i, const double* sb_i, co
     q_inv(pose_j + 3, qj_inv);
     q_mul(qj_inv, pose_i + 3, qji);
     qleft_qright3(qji, cdq, c.M1);
-    q_mul(qji, pre + IM_DQ, qjid);
+    q_mul(qji, pdq, qjid);
     qleft3(qjid, L3);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -205,8 +207,9 @@ DEV void imu_ctx(const double* pre, const double* pose_i, const double* sb_i, co
 // raw Jacobian column `col` (0..29: pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9) into out[15].
 // Written with selects only (no run-time register-array index), so that ImuCtx and `out` stay in VGPRs.
 DEV double sel3(double a0, double a1, double a2, int k) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
-DEV void imu_raw_col(const ImuCtx& c, const double* pre, int col, double* out) {
-    const double* Jm = pre + IM_JAC;
+template <typename PP>
+DEV void imu_raw_col(const ImuCtx& c, PP pre, int col, double* out) {
+    const PP Jm = pre + IM_JAC;
     const int cb = col / 3, k = col - 3 * cb;
 #pragma unroll
     for (int q = 0; q < 15; ++q) out[q] = 0.0;

@@ -352,10 +352,13 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
 //   imuJ [f][512]: 465 lower Hessian entries + 30 gradient entries.   JAC = false: residual only.
 // Returns this thread's share of sum r^2.
 template <bool JAC>
-NOINL double imu_pass(const Ctx& c, const double* x, double* imuJ) {
+NOINL double imu_pass(const Ctx& c, const double* x_, double* imuJ_) {
     const BaLayout& L = *c.Lp;
     const int nimu = L.K - 1;
-    const int* valid = c.ia + L.io_imu_valid;
+    const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
+    const glb_d* x = AS_GLB_C(x_);
+    glb_d* imuJ = AS_GLB(imuJ_);
+    const glb_d* gU = AS_GLB_C(c.sc + L.so_imuU);
     const int nb = nimu < BA_IMU_BATCH ? nimu : BA_IMU_BATCH;      // factors per pass (one pass for the reference's window)
     double* Us = LDSB;                                      // [nb][225]
     double* panels = Us + ((nb * 225 + 1) & ~1);            // [nb][15][32]
@@ -364,17 +367,22 @@ NOINL double imu_pass(const Ctx& c, const double* x, double* imuJ) {
     const int half = c.lane >> 5, hl = c.lane & 31;
     for (int f0 = 0; f0 < nimu; f0 += nb) {
         const int nf = nimu - f0 < nb ? nimu - f0 : nb;
-        for (int k = c.tid; k < nf * 225; k += BA_NT) Us[k] = c.sc[L.so_imuU + f0 * 225 + k];
+        for (int k = c.tid; k < nf * 225; k += BA_NT) Us[k] = gU[f0 * 225 + k];
         __syncthreads();
         const int fl = c.wave * per + half;                 // factor of this (half-)wavefront inside the pass
         const int f = f0 + fl;
         const bool act = fl < nf && half < per && valid[f];
         if (act) {
-            const double* pre = c.di + L.do_imu + f * BA_IMU_STRIDE;
+            const glb_d* pre = AS_GLB_C(c.di + L.do_imu + f * BA_IMU_STRIDE);
+            double pi[7], si[9], pj[7], sj[9];          // the four state blocks of the factor, through typed loads
+#pragma unroll
+            for (int k = 0; k < 7; ++k) { pi[k] = x[7 * f + k]; pj[k] = x[7 * (f + 1) + k]; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { si[k] = x[7 * L.Kp + 9 * f + k]; sj[k] = x[7 * L.Kp + 9 * (f + 1) + k]; }
             const double* U = Us + fl * 225;
             double* panel = panels + fl * 480;
             ImuCtx ic;
-            imu_ctx<JAC>(pre, st_pose(L, x, f), st_sb(L, x, f), st_pose(L, x, f + 1), st_sb(L, x, f + 1), c.gnorm, ic);
+            imu_ctx<JAC>(pre, pi, si, pj, sj, c.gnorm, ic);
             double raw[15];
             if (JAC && hl < 30) imu_raw_col(ic, pre, hl, raw);
             else {
@@ -421,20 +429,22 @@ DEV const double* state_block(const BaLayout& L, const double* x, int kind, int 
 }
 // LDS use: dx [Ncap] + part [4 Ncap] at `lds`.  Writes r to pr and (gpr != nullptr) J0^T r to gpr (global).  Returns this
 // thread's share of sum r^2.
-NOINL double prior_pass(const Ctx& c, const double* x, double* pr, double* gpr, double* lds) {
+NOINL double prior_pass(const Ctx& c, const double* x, double* pr_, double* gpr_, double* lds_) {
     const BaLayout& L = *c.Lp;
     if (c.nprior == 0) return 0.0;
-    double* dx = lds;
-    double* part = lds + L.Ncap;
-    const int* kind = c.ia + L.io_pb_kind;
-    const int* idx = c.ia + L.io_pb_idx;
-    const int* off = c.ia + L.io_pb_off;
-    const int* x0off = c.ia + L.io_pb_x0off;
+    lds_d* dx = AS_LDS(lds_);
+    lds_d* part = dx + L.Ncap;
+    glb_d* pr = AS_GLB(pr_);
+    glb_d* gpr = AS_GLB(gpr_);
+    const glb_i* kind = AS_GLB_CI(c.ia + L.io_pb_kind);
+    const glb_i* idx = AS_GLB_CI(c.ia + L.io_pb_idx);
+    const glb_i* off = AS_GLB_CI(c.ia + L.io_pb_off);
+    const glb_i* x0off = AS_GLB_CI(c.ia + L.io_pb_x0off);
     __syncthreads();
     for (int b = c.tid; b < c.nblk; b += BA_NT) {
-        const double* xb = state_block(L, x, kind[b], idx[b]);
-        const double* x0 = c.di + L.do_px0 + x0off[b];
-        double* d = dx + off[b];
+        const glb_d* xb = AS_GLB_C(state_block(L, x, kind[b], idx[b]));
+        const glb_d* x0 = AS_GLB_C(c.di + L.do_px0 + x0off[b]);
+        lds_d* d = dx + off[b];
         if (kind[b] == VG_BLK_SPEEDBIAS) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) d[k] = xb[k] - x0[k];
@@ -442,17 +452,18 @@ NOINL double prior_pass(const Ctx& c, const double* x, double* pr, double* gpr, 
             d[0] = xb[0] - x0[0];
         } else {
             d[0] = xb[0] - x0[0]; d[1] = xb[1] - x0[1]; d[2] = xb[2] - x0[2];
+            const double q0[4] = {x0[3], x0[4], x0[5], x0[6]}, qb[4] = {xb[3], xb[4], xb[5], xb[6]};
             double qi[4], dq[4];
-            q_inv(x0 + 3, qi);
-            q_mul(qi, xb + 3, dq);
+            q_inv(q0, qi);
+            q_mul(qi, qb, dq);
             const double sgn = (dq[3] >= 0) ? 2.0 : -2.0;
             d[3] = sgn * dq[0]; d[4] = sgn * dq[1]; d[5] = sgn * dq[2];
         }
     }
     __syncthreads();
     const int n = c.nprior;
-    const double* J0t = c.di + L.do_pJ0t;     // J0t[c*Ncap + r] = J0[r][c]  (coalesced over r)
-    const double* r0 = c.di + L.do_pr0;
+    const glb_d* J0t = AS_GLB_C(c.di + L.do_pJ0t);     // J0t[c*Ncap + r] = J0[r][c]  (coalesced over r)
+    const glb_d* r0 = AS_GLB_C(c.di + L.do_pr0);
     double cost = 0.0;
     // r = r0 + J0 dx, the n-term dot product of every row split over 4 threads (host guarantees 4 Ncap <= BA_NT)
     for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
@@ -464,7 +475,7 @@ NOINL double prior_pass(const Ctx& c, const double* x, double* pr, double* gpr, 
     }
     __syncthreads();
     __syncthreads();
-    double* rl = dx;                             // the residual replaces dx in LDS
+    lds_d* rl = dx;                              // the residual replaces dx in LDS
     for (int r = c.tid; r < n; r += BA_NT) {
         const double s = r0[r] + ((part[r] + part[L.Ncap + r]) + (part[2 * L.Ncap + r] + part[3 * L.Ncap + r]));
         pr[r] = s;
@@ -472,9 +483,9 @@ NOINL double prior_pass(const Ctx& c, const double* x, double* pr, double* gpr, 
         cost += s * s;
     }
     __syncthreads();
-    if (gpr) {
+    if (gpr_) {
         // gradient of the prior J0^T r (the solve kernel adds it to g through the prior column map), same 4-way split
-        const double* J0 = c.di + L.do_pJ0;   // row-major: J0[r*Ncap + c] coalesced over c
+        const glb_d* J0 = AS_GLB_C(c.di + L.do_pJ0);   // row-major: J0[r*Ncap + c] coalesced over c
         for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
             const int a = w % L.Ncap, q = w / L.Ncap;
             double s = 0.0;
@@ -489,31 +500,41 @@ NOINL double prior_pass(const Ctx& c, const double* x, double* pr, double* gpr, 
     return cost;
 }
 
+// inputs of one projection factor, copied into registers through global-memory typed loads (the state / observation
+// pointers are generic: reading the factor's 38 doubles through them would be 38 flat_loads)
 struct ProjIn {
-    const double *pi, *pj, *oi, *oj;
+    double pi[7], pj[7], oi[8], oj[8], ex[8];
     double lam;
     int i, j, l;
 };
-DEV void proj_fetch(const Ctx& c, int f, const double* x, const double* lam, ProjIn& p) {
+DEV void proj_fetch(const Ctx& c, int f, const double* x_, const double* lam_, ProjIn& p) {
     const BaLayout& L = *c.Lp;
-    p.i = c.ia[L.io_fac_i + f];
-    p.j = c.ia[L.io_fac_j + f];
-    p.l = c.ia[L.io_fac_lm + f];
-    p.pi = st_pose(L, x, p.i);
-    p.pj = st_pose(L, x, p.j);
-    p.oi = c.di + L.do_obs + c.ia[L.io_fac_oi + f] * BA_OBS_STRIDE;
-    p.oj = c.di + L.do_obs + c.ia[L.io_fac_oj + f] * BA_OBS_STRIDE;
-    p.lam = lam[p.l];
+    const glb_i* ia = AS_GLB_CI(c.ia);
+    const glb_d* x = AS_GLB_C(x_);
+    const glb_d* obs = AS_GLB_C(c.di + L.do_obs);
+    p.i = ia[L.io_fac_i + f];
+    p.j = ia[L.io_fac_j + f];
+    p.l = ia[L.io_fac_lm + f];
+    const int oi = ia[L.io_fac_oi + f], oj = ia[L.io_fac_oj + f];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { p.pi[k] = x[7 * p.i + k]; p.pj[k] = x[7 * p.j + k]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        p.oi[k] = obs[oi * BA_OBS_STRIDE + k];
+        p.oj[k] = obs[oj * BA_OBS_STRIDE + k];
+        p.ex[k] = x[7 * L.Kp + 9 * L.K + k];
+    }
+    p.lam = AS_GLB_C(lam_)[p.l];
 }
-DEV void proj_jac(const Ctx& c, const ProjIn& p, const double* ex, double* r, double* Ji, double* Jj, double* Jex,
+DEV void proj_jac(const Ctx& c, const ProjIn& p, double* r, double* Ji, double* Jj, double* Jex,
                   double* Jl, double* Jtd) {
     const BaLayout& L = *c.Lp;
     if (L.t) {
-        if (L.e) proj_eval<true, true, true>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, ex[7], c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
-        else proj_eval<true, true, false>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, ex[7], c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+        if (L.e) proj_eval<true, true, true>(p.pi, p.pj, p.ex, p.lam, p.oi, p.oj, p.ex[7], c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+        else proj_eval<true, true, false>(p.pi, p.pj, p.ex, p.lam, p.oi, p.oj, p.ex[7], c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
     } else {
-        if (L.e) proj_eval<false, true, true>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
-        else proj_eval<false, true, false>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+        if (L.e) proj_eval<false, true, true>(p.pi, p.pj, p.ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
+        else proj_eval<false, true, false>(p.pi, p.pj, p.ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, Jex, Jl, Jtd);
     }
 }
 
@@ -522,14 +543,13 @@ DEV void proj_jac(const Ctx& c, const ProjIn& p, const double* ex, double* r, do
 // [24,25] Jl | [26,27] r | [28..39] Jex | [40,41] Jtd.   Returns rho(s).
 NOINL double proj_linearize(const Ctx& c, int f, const double* x, const double* lam, double* recs) {
     const BaLayout& L = *c.Lp;
-    const double* ex = st_ex(L, x);
     ProjIn p;
     proj_fetch(c, f, x, lam, p);
     double r[2], Ji[12], Jj[12], Jex[12], Jl[2], Jtd[2];
-    proj_jac(c, p, ex, r, Ji, Jj, Jex, Jl, Jtd);
+    proj_jac(c, p, r, Ji, Jj, Jex, Jl, Jtd);
     const double s = r[0] * r[0] + r[1] * r[1];
     const double sq = sqrt(1.0 / (1.0 + s));
-    double* rec = recs + (size_t)c.ia[L.io_fac_slot + f] * L.REC;
+    glb_d* rec = AS_GLB(recs) + (size_t)AS_GLB_CI(c.ia)[L.io_fac_slot + f] * L.REC;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         rec[2 * k] = sq * Ji[k]; rec[2 * k + 1] = sq * Ji[6 + k];
@@ -546,12 +566,11 @@ NOINL double proj_linearize(const Ctx& c, int f, const double* x, const double* 
 }
 NOINL double proj_cost(const Ctx& c, int f, const double* x, const double* lam) {
     const BaLayout& L = *c.Lp;
-    const double* ex = st_ex(L, x);
     ProjIn p;
     proj_fetch(c, f, x, lam, p);
     double r[2];
-    if (L.t) proj_eval<true, false, false>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, ex[7], c.focal, c.tr, c.row, r, 0, 0, 0, 0, 0);
-    else proj_eval<false, false, false>(p.pi, p.pj, ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, 0, 0, 0, 0, 0);
+    if (L.t) proj_eval<true, false, false>(p.pi, p.pj, p.ex, p.lam, p.oi, p.oj, p.ex[7], c.focal, c.tr, c.row, r, 0, 0, 0, 0, 0);
+    else proj_eval<false, false, false>(p.pi, p.pj, p.ex, p.lam, p.oi, p.oj, 0.0, c.focal, c.tr, c.row, r, 0, 0, 0, 0, 0);
     return log1p(r[0] * r[0] + r[1] * r[1]);
 }
 
