@@ -466,6 +466,7 @@ def main():
             "hbm_GBs_algorithmic": (info['bytes_in'] + info['bytes_out']) * args.steps / elapsed / 1e9,
         }
         cpu = None
+        parity = None
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)
             from oracle import ba_cpu
             try:
@@ -486,6 +487,22 @@ def main():
             if pinned:
                 os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
             med_full, med_solve = float(np.median(t_full)), float(np.median(t_solve))
+            # parity of the TIMED batch (all windows, not a sample): the same oracle, states within 1e-4 relative as north_star asks
+            worst_pose = worst_sb = worst_cost = 0.0
+            same_trace = 0
+            for i in range(nwin):
+                st_o, sm_o, _ = ba_cpu.optimize(probs[i], margin_flag=flags[i], packed=packed[i])
+                scale_p = max(1.0, float(np.abs(st_o['pose'][:, :3]).max()))
+                worst_pose = max(worst_pose, float(np.abs(st[i]['pose'][:, :3] - st_o['pose'][:, :3]).max()) / scale_p,
+                                 float(np.abs(st[i]['pose'][:, 3:] - st_o['pose'][:, 3:]).max()))
+                worst_sb = max(worst_sb, float(np.abs(st[i]['sb'] - st_o['sb']).max()) / max(1.0, float(np.abs(st_o['sb']).max())))
+                worst_cost = max(worst_cost, abs(sm[i]['final_cost'] - sm_o['final_cost']) / max(sm_o['final_cost'], 1e-300))
+                n_it = sm_o['num_iterations']
+                same_trace += int(sm[i]['num_iterations'] == n_it and list(sm[i]['it_flags'][:n_it]) == list(sm_o['it_flags'][:n_it]))
+            parity = {"windows": nwin, "max_rel_pose_error": worst_pose, "max_rel_speedbias_error": worst_sb,
+                      "max_rel_final_cost_error": worst_cost, "identical_accept_reject_traces": same_trace,
+                      "what": "every window of the timed batch against oracle/ba_cpu.cpp (positions relative to the window's extent, "
+                              "quaternion components absolute); tolerance of north_star: 1e-4"}
             cpu = {
                 "value": 1.0 / med_full, "unit": "solves/s", "cores": 1, "kind": "port",
                 "sample": f"median of {len(t_full)} single solves over {ncpu} of the {nwin} timed windows, pinned to one core "
@@ -518,6 +535,7 @@ def main():
                        "parallelism": f"independent batches x{world} (no collectives)", "valid_solves": n_ok},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "parity": parity,
             "step_latency_ms": {"solve_pipeline": solve_ms, "marginalization": marg_ms, "total": solve_ms + marg_ms,
                                 "what": "one 256-window step alone on the GPU (no overlap with other steps), HIP events"},
             "single_window_latency_ms": None,

@@ -15,7 +15,9 @@
 #define BA_ACC_NT 256             // threads per workgroup of the accumulation kernel
 #define BA_MAX_K 13               // frames incl. relocalisation pose, windows solved by one workgroup out of LDS
 #define BA_MAX_K_LARGE 40         // the same for the large-window path (reduced system in HBM, see BaLayout::big)
+#ifndef BA_IMU_BATCH
 #define BA_IMU_BATCH 16           // IMU factors linearised per pass of the linearisation workgroup (LDS panels)
+#endif
 #define BA_IMU_STRIDE 472         // doubles per vg_imu_preint record on device
 #define BA_OBS_STRIDE 8
 #define BA_SUM_DOUBLES 8
