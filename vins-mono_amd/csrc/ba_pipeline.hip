@@ -244,8 +244,9 @@ DEV bool judge_candidate(Ctl& s, double cs, const BaLayout& L, double* out, int*
 // LLT(covariance^-1).matrixL().transpose() of imu_factor.h:64 (the Cholesky factor of the inverse is unique) without
 // forming the badly conditioned inverse; J0^T J0 of the prior; state copy 0; control block.
 // ================================================================================================
-NOINL void imu_sqrt_info(const Ctx& c) {
-    const BaLayout& L = *c.Lp;
+NOINL void imu_sqrt_info(const Ctx& c_in) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
     double* A = LDSB + c.wave * 256;                 // 15x15 scratch per wavefront
     const int nimu = L.K - 1;
     const int* valid = c.ia + L.io_imu_valid;
@@ -352,8 +353,9 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
 //   imuJ [f][512]: 465 lower Hessian entries + 30 gradient entries.   JAC = false: residual only.
 // Returns this thread's share of sum r^2.
 template <bool JAC>
-NOINL double imu_pass(const Ctx& c, const double* x_, double* imuJ_) {
-    const BaLayout& L = *c.Lp;
+NOINL double imu_pass(const Ctx& c_in, const double* x_, double* imuJ_) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
     const int nimu = L.K - 1;
     const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
     const glb_d* x = AS_GLB_C(x_);
@@ -429,8 +431,9 @@ DEV const double* state_block(const BaLayout& L, const double* x, int kind, int 
 }
 // LDS use: dx [Ncap] + part [4 Ncap] at `lds`.  Writes r to pr and (gpr != nullptr) J0^T r to gpr (global).  Returns this
 // thread's share of sum r^2.
-NOINL double prior_pass(const Ctx& c, const double* x, double* pr_, double* gpr_, double* lds_) {
-    const BaLayout& L = *c.Lp;
+NOINL double prior_pass(const Ctx& c_in, const double* x, double* pr_, double* gpr_, double* lds_) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
     if (c.nprior == 0) return 0.0;
     lds_d* dx = AS_LDS(lds_);
     lds_d* part = dx + L.Ncap;
@@ -541,8 +544,9 @@ DEV void proj_jac(const Ctx& c, const ProjIn& p, double* r, double* Ji, double* 
 // One projection factor -> loss-corrected record (CauchyLoss(1.0): rho = log(1+s), residual and Jacobian * sqrt(rho'),
 // rho'' < 0 branch of corrector.cc).  Record (REC doubles): [0..11] Ji as (row0,row1) pairs per column | [12..23] Jj |
 // [24,25] Jl | [26,27] r | [28..39] Jex | [40,41] Jtd.   Returns rho(s).
-NOINL double proj_linearize(const Ctx& c, int f, const double* x, const double* lam, double* recs) {
-    const BaLayout& L = *c.Lp;
+NOINL double proj_linearize(const Ctx& c_in, int f, const double* x, const double* lam, double* recs) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
     ProjIn p;
     proj_fetch(c, f, x, lam, p);
     double r[2], Ji[12], Jj[12], Jex[12], Jl[2], Jtd[2];
@@ -564,8 +568,9 @@ NOINL double proj_linearize(const Ctx& c, int f, const double* x, const double* 
     if (L.t) { rec[28 + 12 * L.e] = sq * Jtd[0]; rec[29 + 12 * L.e] = sq * Jtd[1]; }
     return log1p(s);
 }
-NOINL double proj_cost(const Ctx& c, int f, const double* x, const double* lam) {
-    const BaLayout& L = *c.Lp;
+NOINL double proj_cost(const Ctx& c_in, int f, const double* x, const double* lam) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
     ProjIn p;
     proj_fetch(c, f, x, lam, p);
     double r[2];
@@ -915,8 +920,10 @@ DEV void hess_add(const BaLayout& L, const Q& q, int ca, int cb, double v) {
 // Unscaled Gauss-Newton system of the current point: S (camera, packed lower), g, chain blocks D, E, XC.
 // Sp / gp = camera J^T J / J^T r of the projection factors (the buffer's own, or the rank-summed copy of the large-window path)
 template <bool BIG>
-NOINL void assemble(const Ctx& c, const SolveLds& m, const double* buf_, const double* Sp_, const double* gp_) {
-    const BaLayout& L = *c.Lp;
+NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, const double* Sp_, const double* gp_) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+    const SolveLds m = m_in;
     typedef typename MovT<BIG>::D MV;
     const auto q = sys_ptrs<BIG>(m);
     const glb_d* buf = AS_GLB_C(buf_);
@@ -1044,8 +1051,9 @@ DEV double hess_diag(const BaLayout& L, const SolveLds& m, int k) {
 // Hessian, t = V_T = gt / Dg): the Cauchy-point denominator |J~ t|^2 of DoglegStrategy::ComputeCauchyPoint without a
 // second pass over the factors.
 template <bool BIG>
-NOINL double build_scaled(const Ctx& c, const SolveLds& m_, double mu) {
-    const BaLayout& L = *c.Lp;
+NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_, double mu) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
     typedef typename MovT<BIG>::D MV;
     const auto m = sys_ptrs<BIG>(m_);
     const MV* g = m.vec + V_G * L.Rpad;
@@ -1215,8 +1223,10 @@ DEV void chain_col_solve(PL Lk, PD dinvk, P col, int stride) {
 #pragma unroll
     for (int r = 0; r < 9; ++r) col[r * stride] = x[r];
 }
-NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
-    const BaLayout& L = *c.Lp;
+NOINL bool chain_eliminate(const Ctx& c_in, const SolveLds& m_in) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+    const SolveLds m = m_in;
     const int K = L.K, Rc = L.Rc, ldc = m.ldc;
     const int mid = K / 2;
     const int nstep = (K - 1 - mid) > mid ? (K - 1 - mid) : mid;
@@ -1321,8 +1331,10 @@ NOINL bool chain_eliminate(const Ctx& c, const SolveLds& m) {
 #define SCHUR_LW 32                               // landmarks per staged tile
 #define SCHUR_LD (SCHUR_LW + 1)
 #define SCHUR_PF ((96 * SCHUR_LW + BA_NT - 1) / BA_NT)
-NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double mu) {
-    const BaLayout& L = *c.Lp;
+NOINL void schur_mfma(const Ctx& c_in, const SolveLds& m_in, const double* buf, double mu) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+    const SolveLds m = m_in;
     const lds_d* sc = AS_LDS_C(m.vec + V_SC * L.Rpad);
     lds_d* const S = AS_LDS(m.S);
     lds_d* const wd = AS_LDS(m.wd);
@@ -1436,8 +1448,10 @@ NOINL void schur_mfma(const Ctx& c, const SolveLds& m, const double* buf, double
 // Landmark part of  t^T H~ t  (the Cauchy-point denominator, see build_scaled):  sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ]
 // with t = gt / Dg.  Only needed when the Gauss-Newton step leaves the trust region, so it is evaluated on demand
 // (thread per landmark, one pass over Wt).  Returns this thread's share.
-NOINL double cauchy_landmark_term(const Ctx& c, const SolveLds& m, const double* buf) {
-    const BaLayout& L = *c.Lp;
+NOINL double cauchy_landmark_term(const Ctx& c_in, const SolveLds& m_in, const double* buf) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+    const SolveLds m = m_in;
     const double* sc = m.vec + V_SC * L.Rpad;
     const double* gt = m.vec + V_GT * L.Rpad;
     const double* dg = m.vec + V_DG * L.Rpad;
@@ -1467,8 +1481,10 @@ NOINL double cauchy_landmark_term(const Ctx& c, const SolveLds& m, const double*
 //   (2) the panel rows below it are solved one thread per row (x L_D^T = a, L_D broadcast from LDS);
 //   (3) the trailing matrix gets its rank-16 update tile by tile on v_mfma_f64_16x16x4_f64.
 // Three barriers per 16 columns.  1/L_jj goes to V_DI.  Returns false (uniform) on a bad pivot.
-NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
-    const BaLayout& L = *c.Lp;
+NOINL bool cholesky_aug(const Ctx& c_in, const SolveLds& m_in, int R) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+    const SolveLds m = m_in;
     lds_d* S = AS_LDS(m.S);
     lds_d* dinvv = AS_LDS(m.di);
     lds_i* flag = (lds_i*)(m.red + 24);
@@ -1595,8 +1611,10 @@ NOINL bool cholesky_aug(const Ctx& c, const SolveLds& m, int R) {
 
 // y_cam <- solve L^T y = (row R of S) by one wavefront (lane owns entries lane and lane+64 of the running rhs in
 // registers; the pivot value travels through v_readlane); result in V_Y[0..R).  R <= 128.
-NOINL void back_substitute(const Ctx& c, const SolveLds& m, int R) {
-    const BaLayout& L = *c.Lp;
+NOINL void back_substitute(const Ctx& c_in, const SolveLds& m_in, int R) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+    const SolveLds m = m_in;
     const lds_d* S = AS_LDS_C(m.S);
     const lds_d* dinvv = AS_LDS_C(m.di);
     lds_d* y = AS_LDS(m.vec + V_Y * L.Rpad);
@@ -1645,8 +1663,9 @@ DEV double chain_backsolve9(PL Lk, PD dinvk, double v, int r) {
     return v;
 }
 template <bool BIG>
-NOINL void chain_back_substitute(const Ctx& c, const SolveLds& m_) {
-    const BaLayout& L = *c.Lp;
+NOINL void chain_back_substitute(const Ctx& c_in, const SolveLds& m_) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
     typedef typename MovT<BIG>::D MV;
     const int K = L.K, Rc = L.Rc, ldc = m_.ldc;
     const int mid = K / 2;
@@ -2157,8 +2176,10 @@ extern "C" __global__ __launch_bounds__(256) void ba_big_schur_kernel(const BaLa
 // (the rank-summed landmark Schur complement; row Rc: rhs).  v_mfma_f64_16x16x4; a wavefront task = tile row tm x up to four
 // column tiles (the A operand is shared), two k-steps per trip so that ten 128-byte row loads are in flight per wavefront:
 // the operands come from L2, the loop is a chain of round trips, not of flops.  XC has up(9K, 8) rows (zero padded).
-NOINL void schur_chain_big(const Ctx& c, const SolveLds& m, const double* T_) {
-    const BaLayout& L = *c.Lp;
+NOINL void schur_chain_big(const Ctx& c_in, const SolveLds& m_in, const double* T_) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+    const SolveLds m = m_in;
     const glb_d* sc = AS_GLB_C(m.vec + V_SC * L.Rpad);
     const glb_d* T = AS_GLB_C(T_);
     const glb_d* XC = AS_GLB_C(m.XC);
@@ -2219,8 +2240,10 @@ NOINL void schur_chain_big(const Ctx& c, const SolveLds& m, const double* T_) {
 // the top / bottom sweep and keeps the solved column of the block it eliminated last in registers: the update a block
 // receives from its neighbour only involves that column and the neighbour's 9x9 coupling block, which travels through LDS
 // (cz: L and 1/L_rr of the two blocks of the step, coupling blocks double-buffered by block parity).
-NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz_) {
-    const BaLayout& L = *c.Lp;
+NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz_) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+    const SolveLds m = m_in;
     const int K = L.K, Rc = L.Rc, ldc = m.ldc;
     const int mid = K / 2;
     const int nstep = (K - 1 - mid) > mid ? (K - 1 - mid) : mid;
@@ -2396,8 +2419,10 @@ NOINL bool chain_eliminate_big(const Ctx& c, const SolveLds& m, double* cz_) {
 
 // back substitution L^T y = (row R of S) for R <= 64 NR, one wavefront, lane owns entries lane + 64 q of the running rhs
 template <int NR>
-NOINL void back_substitute_n(const Ctx& c, const SolveLds& m, int R) {
-    const BaLayout& L = *c.Lp;
+NOINL void back_substitute_n(const Ctx& c_in, const SolveLds& m_in, int R) {
+    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
+    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+    const SolveLds m = m_in;
     const lds_d* S = AS_LDS_C(m.S);
     const lds_d* dinvv = AS_LDS_C(m.di);
     glb_d* y = AS_GLB(m.vec + V_Y * L.Rpad);
