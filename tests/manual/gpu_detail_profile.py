@@ -19,7 +19,8 @@ h.lib.vg_debug_detail_profile(out.ctypes.data_as(C.POINTER(C.c_double)), 1)
 st2, sm2, _ = h.ba_optimize(prob, ba.VG_MARGIN_NONE)
 h.lib.vg_debug_detail_profile(out.ctypes.data_as(C.POINTER(C.c_double)), 1)
 names = ["chain A work", "chain A wait", "chain B work", "chain B wait", "chol diag", "chol wait1", "chol panel", "chol wait2", "chol trailing",
-         "chol wait3", "schur lsc+chain rows", "schur trip wait", "schur stage", "schur wait", "schur fetch+mfma", "schur end wait"]
+         "chol wait3", "schur lsc+chain rows", "schur trip wait", "schur stage", "schur wait", "schur fetch+mfma", "schur end wait",
+         "assemble copy + clear", "assemble wait", "assemble IMU scatter", "assemble IMU wait", "assemble prior scatter", "assemble end wait"]
 it = max(sm2['num_iterations'], 1)
 print("iterations", it, "(cycles per round)")
 print(f"{'phase':<24}{'thread 0':>12}{'thread 128':>12}")

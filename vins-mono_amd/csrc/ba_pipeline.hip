@@ -933,6 +933,7 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
     const int camtri = Rc * (Rc + 1) / 2;
     MV* g = q.vec + V_G * L.Rpad;
     __syncthreads();
+    DP_DECL;
     for (int k = c.tid; k < camtri; k += BA_NT) q.S[k] = Sp[k];
     for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? gp[k] : 0.0;
     if (!BIG) {
@@ -941,7 +942,9 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
         for (int k = c.tid; k < nxc; k += BA_NT) q.XC[k] = 0.0;
         for (int k = c.tid; k < 81 * K; k += BA_NT) { q.D[k] = 0.0; q.E[k] = 0.0; }
     }
+    DP_ADD(16);
     __syncthreads();
+    DP_ADD(17);
     // ---- IMU Hessian blocks: factors k and k+1 share the blocks of frame k+1, so even and odd factors are added in two
     //      rounds (inside a round every entry has exactly one writer)
     {
@@ -998,7 +1001,9 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
                     }
                 }
             }
+            DP_ADD(18);
             __syncthreads();
+            DP_ADD(19);
         }
     }
     // ---- prior: H += J0^T J0 (precomputed Hp), g += J0^T r   (pmap: prior column -> reduced column or -1)
@@ -1036,7 +1041,9 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
             }
         }
     }
+    DP_ADD(20);
     __syncthreads();
+    DP_ADD(21);
 }
 
 // diagonal entry k of the (unscaled) Hessian as stored by assemble()
