@@ -118,3 +118,65 @@ def test_allreduce_hook_over_rccl_single_rank(handle):
     assert sm1['status'] == 0 and set(calls) == {c1, c2} and len(calls) >= 2 * sm1['num_iterations']
     assert np.array_equal(st0['pose'], st1['pose']) and np.array_equal(st0['inv_depth'], st1['inv_depth'])
     assert list(sm0['it_cost']) == list(sm1['it_cost'])
+
+
+SHARD_WORKER = r'''
+import os, sys, json
+ROOT = %r
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import __graft_entry__ as g
+g.load_package()
+from vins_mono_amd import ba, dist_util as D, synth, shard
+rank, local, world = D.env_rank()
+torch.cuda.set_device(0)                                  # both ranks share the one GPU of the box
+assert D.init("gloo")
+seq = synth.SyntheticSequence(5, n_frames=32, K=31, L=600)
+prob = synth.SyntheticSequence.anchor_prior(seq.window(0))
+h = ba.Handle()
+st1, sm1, _ = h.ba_optimize(prob)                         # the whole window on this rank alone
+sub = shard.shard_problem(prob, rank, world)
+h.ba_set_allreduce(shard.torch_allreduce_hook(device_buffers=True))
+st, sm, _ = h.ba_optimize(sub)
+D.barrier()
+lo, hi = (int(v) for v in sub["shard"])
+fl = lambda a: [float(v) for v in np.asarray(a).ravel()]
+pack = lambda s, m: dict(pose=fl(s["pose"]), sb=fl(s["sb"]), lam=fl(s["inv_depth"]), it_cost=fl(m["it_cost"]),
+                         it_flags=[int(v) for v in m["it_flags"]], n=int(m["num_iterations"]), status=int(m["status"]))
+sys.stdout.write(json.dumps(dict(rank=rank, lo=lo, hi=hi, sharded=pack(st, sm), single=pack(st1, sm1))) + "\n")
+sys.stdout.flush()
+D.finish()
+'''
+
+
+def test_two_ranks_share_one_gpu_landmark_shards(tmp_path):
+    """The sharded window with the REAL kernels and two ranks: both processes run on the single GPU of the box (RCCL refuses two
+    ranks on one device, so the reduce buffers are staged through gloo), each with its contiguous share of the landmarks of a
+    31-frame x 600-landmark window.  Both ranks must end with bit-identical frame states, equal to the single-rank solve."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(SHARD_WORKER % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29561", str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows, dec, txt, pos = [], json.JSONDecoder(), r.stdout, 0
+    while (pos := txt.find('{"rank"', pos)) >= 0:
+        obj, pos = dec.raw_decode(txt, pos)
+        rows.append(obj)
+    assert len(rows) == 2
+    rows.sort(key=lambda d: d["rank"])
+    a, b, one = rows[0]["sharded"], rows[1]["sharded"], rows[0]["single"]
+    assert rows[0]["lo"] == 0 and rows[0]["hi"] == rows[1]["lo"] and rows[1]["hi"] == 600
+    for k in ("pose", "sb", "it_cost", "it_flags", "n", "status"):
+        assert a[k] == b[k], k                                        # replicated part: bit-identical on both ranks
+    assert a["status"] == 0 and a["n"] == one["n"] and a["it_flags"] == one["it_flags"]
+    n = a["n"]
+    np.testing.assert_allclose(a["it_cost"][:n], one["it_cost"][:n], rtol=1e-7)
+    np.testing.assert_allclose(np.array(a["pose"]), np.array(one["pose"]), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.array(a["lam"] + b["lam"]), np.array(one["lam"]), rtol=1e-6, atol=1e-9)

@@ -50,13 +50,17 @@ def shard_problem(prob, rank, world):
     return sub
 
 
-def torch_allreduce_hook():
-    """An all-reduce hook for Handle.ba_set_allreduce on top of torch.distributed: backend nccl (= RCCL) sums the device
-    buffer on the library's HIP stream; backend gloo (CPU tests against the emulated library) sums the host buffer."""
+def torch_allreduce_hook(device_buffers=None):
+    """An all-reduce hook for Handle.ba_set_allreduce on top of torch.distributed.
+    backend nccl (= RCCL): sums the device buffer in place on the library's HIP stream (zero-copy view of the pointer).
+    backend gloo with host buffers (CPU tests against the emulated library): sums the host buffer.
+    backend gloo with DEVICE buffers (device_buffers=True: two ranks sharing one GPU in a test, where RCCL refuses duplicate
+    devices): staged through the host on the library's stream."""
     import torch
     import torch.distributed as dist
 
-    on_gpu = dist.get_backend() == "nccl"
+    nccl = dist.get_backend() == "nccl"
+    on_gpu = nccl if device_buffers is None else bool(device_buffers)
 
     class _DevBuf:
         def __init__(self, ptr, count):
@@ -66,7 +70,12 @@ def torch_allreduce_hook():
         if on_gpu:
             t = torch.as_tensor(_DevBuf(ptr, count), device="cuda")
             with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                if nccl:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                else:
+                    host = t.cpu()                       # synchronises the library's stream up to here
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                    t.copy_(host)
         else:
             a = np.ctypeslib.as_array((C.c_double * count).from_address(ptr))
             t = torch.from_numpy(a)
