@@ -164,7 +164,7 @@ def bench_sharded(args, ba, synth, D, rank, world):
     sub = shard.shard_problem(prob, rank, world)
     h = ba.Handle()
     if world > 1:
-        h.ba_set_allreduce(shard.torch_allreduce_hook())
+        h.ba_set_allreduce(shard.torch_allreduce_hook(device_buffers=True))     # (gloo self-test on a shared GPU: staged through the host)
     packed = ba.PackedProblem(sub)
     h.ba_upload([packed], [ba.VG_MARGIN_NONE])
     info = h.ba_info()
