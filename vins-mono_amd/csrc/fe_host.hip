@@ -190,7 +190,7 @@ extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
     }
     for (int l = 1; l <= d.max_level; ++l) {
         const int sw = d.lw[l - 1], sh = d.lh[l - 1];
-        hipLaunchKernelGGL(fe_pyrdown_kernel, dim3(((sw + 1) / 2 + 63) / 64, ((sh + 1) / 2 + 3) / 4, d.cams), dim3(256), 0, h->stream,
+        hipLaunchKernelGGL(fe_pyrdown_kernel, dim3(((sw + 1) / 2 + 63) / 64, ((sh + 1) / 2 + 15) / 16, d.cams), dim3(256), 0, h->stream,
                            (const uint8_t* const*)(cur0 + (size_t)(l - 1) * d.cams), cur0 + (size_t)l * d.cams, sw, sh);
     }
     HIPCHK(h, hipGetLastError());

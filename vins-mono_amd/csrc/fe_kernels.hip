@@ -108,38 +108,55 @@ extern "C" __global__ __launch_bounds__(256) void fe_copy_kernel(FeDev d, uint8_
 // 11 x 136 input tile is staged in LDS (aligned dword rows in the interior, per-byte reflection at the borders),
 // filtered horizontally once (11 x 64 partial sums) and then vertically: ~3x fewer instructions than 25 reflected
 // global byte loads per output pixel, same integers.
+#define PD_ROWS 16                              // output rows per workgroup (64 x 16 outputs = 4 per thread)
+#define PD_IN (2 * PD_ROWS + 3)                 // input rows a workgroup reads
 extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh) {
-    __shared__ alignas(16) uint8_t tile[11][136];
-    __shared__ int hs[11][64];
+    __shared__ alignas(16) uint8_t tile[PD_IN][136];
+    __shared__ alignas(16) int hs[PD_IN][64];
     const int cam = blockIdx.z;
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4;
+    const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * PD_ROWS;
     const uint8_t* s = src_planes[cam];
     const int ix0 = 2 * bx0 - 4, iy0 = 2 * by0 - 2;         // input coordinates of tile[0][0] (ix0 is 4-byte aligned)
-    const bool interior = (sw & 3) == 0 && ix0 >= 0 && ix0 + 136 <= sw && iy0 >= 0 && iy0 + 11 <= sh;   // uniform
+    const bool interior = (sw & 3) == 0 && ix0 >= 0 && ix0 + 136 <= sw && iy0 >= 0 && iy0 + PD_IN <= sh;   // uniform
     if (interior) {
-        for (int k = threadIdx.x; k < 11 * 34; k += 256) {
+        for (int k = threadIdx.x; k < PD_IN * 34; k += 256) {
             const int r = k / 34, cdw = k - 34 * r;
             *(uint32_t*)&tile[r][4 * cdw] = *(const uint32_t*)(s + (size_t)(iy0 + r) * sw + ix0 + 4 * cdw);
         }
     } else {
-        for (int k = threadIdx.x; k < 11 * 136; k += 256) {
+        for (int k = threadIdx.x; k < PD_IN * 136; k += 256) {
             const int r = k / 136, cc = k - 136 * r;
             tile[r][cc] = s[(size_t)reflect101(iy0 + r, sh) * sw + reflect101(ix0 + cc, sw)];
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 11 * 64; k += 256) {
+    for (int k = threadIdx.x; k < PD_IN * 64; k += 256) {
         const int r = k >> 6, lx = k & 63;
         const uint8_t* t = &tile[r][2 * lx + 2];           // input column 2x - 2
         hs[r][lx] = t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4];
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const int x = bx0 + lx, y = by0 + ly;
+    // thread = 4 horizontally adjacent outputs of one row: five 16-byte LDS reads, one 4-byte store (a byte store per thread
+    // moves 64 bytes per wavefront instruction)
+    const int lq = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = bx0 + 4 * lq, y = by0 + ly;
     if (x >= dw || y >= dh) return;
-    const int acc = hs[2 * ly][lx] + 4 * hs[2 * ly + 1][lx] + 6 * hs[2 * ly + 2][lx] + 4 * hs[2 * ly + 3][lx] + hs[2 * ly + 4][lx];
-    dst_planes[cam][(size_t)y * dw + x] = (uint8_t)((acc + 128) >> 8);
+    int acc[4] = {0, 0, 0, 0};
+    const int wgt[5] = {1, 4, 6, 4, 1};
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int4 v = *(const int4*)&hs[2 * ly + r][4 * lq];
+        acc[0] += wgt[r] * v.x; acc[1] += wgt[r] * v.y; acc[2] += wgt[r] * v.z; acc[3] += wgt[r] * v.w;
+    }
+    uint8_t* o = dst_planes[cam] + (size_t)y * dw + x;
+    if (x + 3 < dw && (dw & 3) == 0) {
+        *(uint32_t*)o = (uint32_t)((acc[0] + 128) >> 8) | ((uint32_t)((acc[1] + 128) >> 8) << 8) | ((uint32_t)((acc[2] + 128) >> 8) << 16) |
+                        ((uint32_t)((acc[3] + 128) >> 8) << 24);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (x + q < dw) o[q] = (uint8_t)((acc[q] + 128) >> 8);
+    }
 }
 
 // ================================================================================================ LK
