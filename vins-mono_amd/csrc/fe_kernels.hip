@@ -19,6 +19,18 @@
 
 FDEV int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 FDEV int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// exact product of two integers known to fit 24 bits (pixels, 14-bit bilinear weights, int16 derivatives, 14-bit differences)
+// whose product fits 32: v_mul_i32_i24 runs at full rate, v_mul_lo_u32 at a quarter of it -- and the LK kernel is bound by
+// VALU issue
+#ifdef VINS_SIMT
+FDEV int mul24(int a, int b) { return a * b; }
+#else
+FDEV int mul24(int a, int b) { return __mul24(a, b); }
+#endif
+// sum of four such products (bilinear tap)
+FDEV int tap4(int p00, int p01, int p10, int p11, int w00, int w01, int w10, int w11) {
+    return mul24(p00, w00) + mul24(p01, w01) + mul24(p10, w10) + mul24(p11, w11);
+}
 FDEV int cv_round(float v) { return __float2int_rn(v); }
 FDEV int cv_floor(float v) { return (int)floorf(v); }
 // monotone map float -> unsigned (total order incl. negatives)
@@ -329,14 +341,14 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
             for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[24 + q]; d0[q] = dq[q]; d1[q] = dq[22 + q]; }
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
-                const int ival = descale(r0[q] * w00 + r0[q + 1] * w01 + r1[q] * w10 + r1[q + 1] * w11, LK_WBITS - 5);
+                const int ival = descale(tap4(r0[q], r0[q + 1], r1[q], r1[q + 1], w00, w01, w10, w11), LK_WBITS - 5);
                 const int x00 = (short)(d0[q] & 0xffff), x01 = (short)(d0[q + 1] & 0xffff);
                 const int x10 = (short)(d1[q] & 0xffff), x11 = (short)(d1[q + 1] & 0xffff);
                 const int y00 = d0[q] >> 16, y01 = d0[q + 1] >> 16, y10 = d1[q] >> 16, y11 = d1[q + 1] >> 16;
-                const int ixval = descale(x00 * w00 + x01 * w01 + x10 * w10 + x11 * w11, LK_WBITS);
-                const int iyval = descale(y00 * w00 + y01 * w01 + y10 * w10 + y11 * w11, LK_WBITS);
+                const int ixval = descale(tap4(x00, x01, x10, x11, w00, w01, w10, w11), LK_WBITS);
+                const int iyval = descale(tap4(y00, y01, y10, y11, w00, w01, w10, w11), LK_WBITS);
                 iv[q] = (short)ival; ixv[q] = act ? (short)ixval : 0; iyv[q] = act ? (short)iyval : 0;
-                a11 += (long long)ixv[q] * ixv[q]; a12 += (long long)ixv[q] * iyv[q]; a22 += (long long)iyv[q] * iyv[q];
+                a11 += (long long)mul24(ixv[q], ixv[q]); a12 += (long long)mul24(ixv[q], iyv[q]); a22 += (long long)mul24(iyv[q], iyv[q]);
             }
         }
         a11 = wave_sum_ll(a11); a12 = wave_sum_ll(a12); a22 = wave_sum_ll(a22);
@@ -373,8 +385,8 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[LK_JR + q]; }
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
-                    const int diff = descale(r0[q] * r00 + r0[q + 1] * r01 + r1[q] * r10 + r1[q + 1] * r11, LK_WBITS - 5) - iv[q];
-                    b1 += (long long)diff * ixv[q]; b2 += (long long)diff * iyv[q];
+                    const int diff = descale(tap4(r0[q], r0[q + 1], r1[q], r1[q + 1], r00, r01, r10, r11), LK_WBITS - 5) - iv[q];
+                    b1 += (long long)mul24(diff, ixv[q]); b2 += (long long)mul24(diff, iyv[q]);
                 }
             }
             b1 = wave_sum_ll(b1); b2 = wave_sum_ll(b2);
@@ -408,7 +420,7 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[LK_JR + q]; }
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
-                    const int diff = descale(r0[q] * r00 + r0[q + 1] * r01 + r1[q] * r10 + r1[q + 1] * r11, LK_WBITS - 5) - iv[q];
+                    const int diff = descale(tap4(r0[q], r0[q + 1], r1[q], r1[q + 1], r00, r01, r10, r11), LK_WBITS - 5) - iv[q];
                     e += act ? (diff < 0 ? -diff : diff) : 0;
                 }
             }
