@@ -318,11 +318,12 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 const int X = ipx + xs + q;
                 int ix = 0, iy = 0;
                 if (yin && X >= 0 && X < lw) {
-                    const int t0m = 3 * (a0 + a2) + 10 * a1;
-                    const int t0p = 3 * (c0 + c2) + 10 * c1;
+                    // (small constants times byte sums: spelled as 24-bit multiplies, see mul24)
+                    const int t0m = mul24(3, a0 + a2) + mul24(10, a1);
+                    const int t0p = mul24(3, c0 + c2) + mul24(10, c1);
                     const int t1m = a2 - a0, t1c = b2 - b0, t1p = c2 - c0;
                     ix = t0p - t0m;
-                    iy = 3 * (t1m + t1p) + 10 * t1c;
+                    iy = mul24(3, t1m + t1p) + mul24(10, t1c);
                 }
                 dq[q] = (int)((unsigned)(ix & 0xffff) | ((unsigned)iy << 16));        // (int16 Ix | int16 Iy << 16)
                 a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
@@ -377,17 +378,21 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 jox = inx - LK_JS; joy = iny - LK_JS; staged = true; rx = LK_JS; ry = LK_JS;
                 lk_stage_region(s.jreg, J, lw, lh, jox, joy, lane);
             }
-            long long b1 = 0, b2 = 0;
+            long long b1, b2;
             {
                 const uint8_t* p0 = s.jreg + (ry + lyc) * LK_JR + rx + x0;
                 int r0[8], r1[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[LK_JR + q]; }
+                // a lane's seven products fit 32 bits with room to spare (|diff| <= 255 * 32, |Ix|, |Iy| <= 16 * 255: < 2.4e8 in
+                // total), so the lane sums are formed in 32 bits and widened once; the wavefront sums stay exact int64
+                int s1 = 0, s2 = 0;
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
                     const int diff = descale(tap4(r0[q], r0[q + 1], r1[q], r1[q + 1], r00, r01, r10, r11), LK_WBITS - 5) - iv[q];
-                    b1 += (long long)mul24(diff, ixv[q]); b2 += (long long)mul24(diff, iyv[q]);
+                    s1 += mul24(diff, ixv[q]); s2 += mul24(diff, iyv[q]);
                 }
+                b1 = s1; b2 = s2;
             }
             b1 = wave_sum_ll(b1); b2 = wave_sum_ll(b2);
             const float fb1 = (float)b1 * FLT_SCALE, fb2 = (float)b2 * FLT_SCALE;
