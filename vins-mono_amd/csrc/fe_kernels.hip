@@ -198,6 +198,16 @@ FDEV long long readlane_ll(long long v, int lane) {
     const int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
     return ((long long)hi << 32) | (unsigned)lo;
 }
+// the same for lane values whose 8-lane totals still fit 32 bits (|v| < 2^28): the first three DPP stages in 32 bits, widened
+// for the last one and the four row totals
+FDEV long long wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);
+    long long w = v;
+    w += dpp_mov_ll<0x140>(w);
+    return (readlane_ll(w, 0) + readlane_ll(w, 16)) + (readlane_ll(w, 32) + readlane_ll(w, 48));
+}
 FDEV long long wave_sum_ll(long long v) {
     v += dpp_mov_ll<0xB1>(v);
     v += dpp_mov_ll<0x4E>(v);
@@ -392,9 +402,8 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                     const int diff = descale(tap4(r0[q], r0[q + 1], r1[q], r1[q + 1], r00, r01, r10, r11), LK_WBITS - 5) - iv[q];
                     s1 += mul24(diff, ixv[q]); s2 += mul24(diff, iyv[q]);
                 }
-                b1 = s1; b2 = s2;
+                b1 = wave_sum_i32(s1); b2 = wave_sum_i32(s2);       // (|s| <= 7 * 8160 * 4080 = 2.3e8 < 2^28)
             }
-            b1 = wave_sum_ll(b1); b2 = wave_sum_ll(b2);
             const float fb1 = (float)b1 * FLT_SCALE, fb2 = (float)b2 * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
             nextx += dx; nexty += dy;
