@@ -1483,9 +1483,14 @@ NOINL double cauchy_landmark_term(const Ctx& c_in, const SolveLds& m_in, const d
 
 // Blocked right-looking Cholesky (NB = 16) of the packed lower triangle S (R x R) held in LDS, with the rhs as
 // augmented row R (so row R of the factor is the forward-substituted rhs):
-//   (1) the 16x16 diagonal block is factored by ONE wavefront in registers — lane i holds row i, pivots and
-//       multipliers travel through v_readlane, no barrier inside the block;
-//   (2) the panel rows below it are solved one thread per row (x L_D^T = a, L_D broadcast from LDS);
+//   (1+2) diagonal block AND panel in one phase, without a barrier in between: every wavefront holds the (symmetric) 16x16
+//       diagonal block and ONE 16-row tile of the panel, transposed, in the accumulator layout of v_mfma_f64_16x16x4_f64
+//       (D[i = (lane>>4) + 4 reg][j = lane & 15]).  Row r of an accumulator sits in ONE register (r >> 2) of the 16 lanes
+//       16 (r & 3) .. +15 — exactly the lanes of k-slot r & 3 of the A and B operands — so pivot r is: read the pivot with
+//       v_readlane, scale the row in place (that IS column r of L, for the diagonal block and for the tile), and apply the
+//       rank-1 update with one MFMA per accumulator whose other three k-slots are zero.  No cross-lane traffic besides the
+//       pivot, no LDS in the dependency chain (the L values are written out on the side).  The diagonal block is factored
+//       redundantly by every wavefront that owns a tile; a short block is padded with the identity.
 //   (3) the trailing matrix gets its rank-16 update tile by tile on v_mfma_f64_16x16x4_f64.
 // Three barriers per 16 columns.  1/L_jj goes to V_DI.  Returns false (uniform) on a bad pivot.
 NOINL bool cholesky_aug(const Ctx& c_in, const SolveLds& m_in, int R) {
@@ -1496,84 +1501,98 @@ NOINL bool cholesky_aug(const Ctx& c_in, const SolveLds& m_in, int R) {
     lds_d* dinvv = AS_LDS(m.di);
     lds_i* flag = (lds_i*)(m.red + 24);
     const int lane = c.lane;
+    R = __builtin_amdgcn_readfirstlane(R);              // arguments arrive in vector registers: tell the compiler they are uniform
+    const int wave = __builtin_amdgcn_readfirstlane(c.wave);
     if (c.tid == 0) *flag = 1;
     __syncthreads();
     DP_DECL;
+    double msk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) msk[k] = (lane >> 4) == k ? 1.0 : 0.0;
     for (int c0 = 0; c0 < R; c0 += 16) {
         const int nb = (R - c0) < 16 ? (R - c0) : 16;
-        // ---- (1) diagonal block, wavefront 0
-        if (c.wave == 0) {
-            double a[16];
-            const int i = lane & 15;
+        const int r1 = c0 + nb;
+        const int ntp = (R - r1) / 16 + 1;             // panel tiles: rows r1 .. R
+        const int jc = lane & 15, kq = lane >> 4;
+        double4_t dg0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) a[q] = (lane < 16 && i < nb && q <= i) ? S[tri(c0 + i, c0 + q)] : 0.0;
-            bool good = true;
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = kq + 4 * reg;
+            const bool in = i < nb && jc < nb;
+            const int gi = c0 + (i > jc ? i : jc), gj = c0 + (i > jc ? jc : i);
+            const double dv = S[in ? tri(gi, gj) : 0];
+            dg0[reg] = in ? dv : (i == jc ? 1.0 : 0.0);
+        }
+        __syncthreads();                               // every wavefront has the block before wavefront 0 overwrites it with L
+        for (int t = wave; t < ntp; t += BA_NW) {
+            const int prow = r1 + 16 * t + jc;         // this lane's panel row (column of the transposed tile)
+            double4_t dg = dg0, pt;
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                if (jj < nb) {
-                    const double piv = readlane_d(a[jj], jj);
-                    if (!(piv > 0.0) || !(piv < 1e300)) good = false;
-                    const double dinv = rsqrt_nr(piv);
-                    const double l = a[jj] * dinv;              // column jj of row `lane` (lane jj: sqrt(piv))
-                    a[jj] = l;
-                    if (lane == 0) dinvv[c0 + jj] = dinv;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = kq + 4 * reg;
+                const bool pin = i < nb && prow <= R;
+                const double pv = S[pin ? tri(prow, c0 + i) : 0];
+                pt[reg] = pin ? pv : 0.0;
+            }
+            // A lone wavefront issues one instruction every ~6-8 cycles whatever the dependencies (profiles/ubench), so the pivot
+            // step is written for instruction COUNT: dm = 1/sqrt(pivot) in the lanes of k-slot r & 3 and 0 elsewhere scales the
+            // row into column r of L (lv for the block, lp for the tile) with one multiply each; lane (kq, jc) collects the four
+            // columns r = kq + 4 q it owns by plain additions (the other lanes add 0) and writes them after the last pivot; a
+            // non-positive pivot is not tested here — it turns 1/sqrt and everything after it into NaN / Inf, caught below.
+            // (Entries j < r of row r are rounding residue of the eliminated columns; they only reach dead rows / columns.)
+            double4_t ld = {0, 0, 0, 0}, lq = {0, 0, 0, 0}, di = {0, 0, 0, 0};
+#define CHOL_PIVOT(r)                                                                                         \
+            {                                                                                                     \
+                const double piv = readlane_d(dg[(r) >> 2], 16 * ((r) & 3) + (r));                                \
+                const double dm = rsqrt_nr(piv) * msk[(r) & 3];                                                   \
+                const double lv = dg[(r) >> 2] * dm, nlv = dg[(r) >> 2] * -dm, nlp = pt[(r) >> 2] * -dm;          \
+                dg = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, nlv, dg, 0, 0, 0);                                  \
+                pt = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, nlp, pt, 0, 0, 0);                                  \
+                ld[(r) >> 2] += lv;                                                                               \
+                lq[(r) >> 2] -= nlp;                                                                              \
+                di[(r) >> 2] += dm;                                                                               \
+            }
+            if (nb == 16) {                            // straight-line: no control flow between the sixteen pivots
 #pragma unroll
-                    for (int k = jj + 1; k < 16; ++k) {
-                        const double lk = readlane_d(l, k);
-                        a[k] -= l * lk;
+                for (int r = 0; r < 16; ++r) CHOL_PIVOT(r)
+            } else {                                   // the last, short block (padded with the identity): groups of four pivots
+#pragma unroll
+                for (int r4 = 0; r4 < 16; r4 += 4) {
+                    if (r4 < nb) {
+#pragma unroll
+                        for (int r = r4; r < r4 + 4; ++r) CHOL_PIVOT(r)
                     }
                 }
             }
-            if (lane < 16 && i < nb) {
+#undef CHOL_PIVOT
+            bool good = true;
+            lds_d* const outd = S + tri(c0 + jc, c0) + kq;                  // + 4 q: L[c0 + jc][c0 + kq + 4 q]
+            lds_d* const outp = S + tri(prow <= R ? prow : R, c0) + kq;     // + 4 q: L[prow][c0 + kq + 4 q]
 #pragma unroll
-                for (int q = 0; q < 16; ++q) if (q <= i) S[tri(c0 + i, c0 + q)] = a[q];
+            for (int q = 0; q < 4; ++q) {
+                const int r = kq + 4 * q;
+                if (r < nb) {
+                    if (!(di[q] > 0.0) || !(di[q] < 1e300)) good = false;   // pivot <= 0, NaN or Inf
+                    if (t == 0 && jc < nb && jc >= r) outd[4 * q] = ld[q];
+                    if (prow <= R) outp[4 * q] = lq[q];
+                    if (t == 0 && jc == 0) dinvv[c0 + r] = di[q];
+                }
             }
-            if (!good && lane == 0) *flag = 0;
+            if (!good) *flag = 0;
         }
         DP_ADD(4);
-        __syncthreads();
         DP_ADD(5);
-        if (*flag == 0) break;
-        // ---- (2) panel: rows i > block, x_c = (a_c - sum_{m<c} x_m L_D[c][m]) / L_D[c][c]
-        const int r1 = c0 + nb;
-        if (nb == 16) {
-            for (int i = r1 + c.tid; i <= R; i += BA_NT) {
-                double x[16];
-                lds_d* row = S + tri(i, c0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) x[q] = row[q];
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) {
-                    const lds_d* ld = S + tri(c0 + cc, c0);
-                    double sacc = x[cc];
-#pragma unroll
-                    for (int q = 0; q < cc; ++q) sacc -= x[q] * ld[q];
-                    x[cc] = sacc * dinvv[c0 + cc];
-                }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) row[q] = x[q];
-            }
-        } else {
-            for (int i = r1 + c.tid; i <= R; i += BA_NT) {
-                lds_d* row = S + tri(i, c0);
-                for (int cc = 0; cc < nb; ++cc) {
-                    const lds_d* ld = S + tri(c0 + cc, c0);
-                    double sacc = row[cc];
-                    for (int q = 0; q < cc; ++q) sacc -= row[q] * ld[q];
-                    row[cc] = sacc * dinvv[c0 + cc];
-                }
-            }
-        }
         DP_ADD(6);
         __syncthreads();
         DP_ADD(7);
+        if (*flag == 0) break;
         // ---- (3) trailing update (only full blocks have anything right of them)
         if (nb == 16 && r1 < R) {
             const int t0 = r1 >> 4;
             const int nt = (R >> 4) + 1;                 // tile rows covering rows 0..R
             const int mm = nt - t0;
             const int ntile = mm * (mm + 1) / 2;
-            for (int t = c.wave; t < ntile; t += BA_NW) {
+            for (int t = wave; t < ntile; t += BA_NW) {
                 int tr_, tc_;
                 tri_decode(t, tr_, tc_);
                 const int ti = t0 + tr_, tk = t0 + tc_;
