@@ -238,6 +238,12 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.so_gn = o; o += L.Rpad + L.Lcap;
     L.so_yl = o; o += L.Lcap;
     L.so_lsc = o; o += L.Lcap;
+    L.ptab_cap = 0; L.so_ptab = 0; L.so_Hpk = 0;
+    if (!L.big) {
+        L.ptab_cap = up(L.Ncap * (L.Ncap + 1) / 2 + L.Ncap, 2);
+        L.so_ptab = o; o += L.ptab_cap;                          // 2 x ptab_cap ints
+        L.so_Hpk = o; o += up(L.Ncap * (L.Ncap + 1) / 2, 2);
+    }
     if (L.big) {
         L.so_bigm = o; o += up(bigm_doubles, 8);
         L.so_dgl = o; o += 2 * L.Lcap;

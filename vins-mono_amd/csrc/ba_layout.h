@@ -66,6 +66,8 @@ struct BaLayout {
     int so_imuU, so_Hp, so_rec;                 // sqrt_info factors, J0^T J0, projection records [Fcap][REC]
     int so_sc, so_sl, so_dg, so_gt, so_gn;      // Jacobi scaling (R / Lcap), saved Dg, gt, gn over [R | Lcap] for step reuse
     int so_yl, so_lsc;                          // landmark step / sl/sqrt(h~)
+    int so_ptab, so_Hpk, ptab_cap;              // prior scatter table (2 x ptab_cap ints: LDS slot of every prior entry and of its
+                                                // mirror, -1 = none; built once per solve by the prologue) and J0^T J0 packed by entry
     int so_buf, buf_stride;                     // two linearisation buffers; offsets below are relative to a buffer
     int bo_Sp, bo_gp, bo_h, bo_b, bo_Wt, bo_imuJ, bo_pr, bo_gpr;
     int sstride;

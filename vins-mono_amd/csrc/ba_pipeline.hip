@@ -201,7 +201,8 @@ DEV void ctl_store(const Ctl& s, double* p) {
 // Judge the pending candidate (TrustRegionMinimizer: parameter tolerance, function tolerance, step quality; then
 // DoglegStrategy::StepAccepted / StepRejected).  Uniform: every thread computes the same from the same HBM values;
 // thread 0 writes the trace.  Returns true if the candidate became the current point.
-DEV double sum_partials(const double* part, int nbl) {
+template <typename P>
+DEV double sum_partials(P part, int nbl) {
     double cs = 0.0;
     for (int b = 0; b < nbl; ++b) cs += part[b];
     return cs;
@@ -328,6 +329,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
                 for (; r + 1 < n; r += 2) { s0 += J0s[r * n + a] * J0s[r * n + bb]; s1 += J0s[(r + 1) * n + a] * J0s[(r + 1) * n + bb]; }
                 if (r < n) s0 += J0s[r * n + a] * J0s[r * n + bb];
                 Hp[a * L.Ncap + bb] = s0 + s1;
+                if (!L.big) c.sc[L.so_Hpk + wk] = s0 + s1;
             }
         } else {
             const int ld = L.Ncap;
@@ -339,6 +341,52 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
                 for (; r + 1 < n; r += 2) { s0 += J0[r * ld + a] * J0[r * ld + bb]; s1 += J0[(r + 1) * ld + a] * J0[(r + 1) * ld + bb]; }
                 if (r < n) s0 += J0[r * ld + a] * J0[r * ld + bb];
                 Hp[a * L.Ncap + bb] = s0 + s1;
+                if (!L.big) c.sc[L.so_Hpk + wk] = s0 + s1;
+            }
+        }
+        if (!L.big) {
+            // Where every prior entry lands in the solve kernel's LDS image of the reduced system (offsets in doubles from the
+            // start of LDS, as carved by lds_carve): decoded once per solve here, so that assemble() is load + add + store.
+            // Entry wk < n(n+1)/2: Hessian (a, b) -> slot of (pmap[a], pmap[b]) and, inside a speed-bias block, its mirror;
+            // entry n(n+1)/2 + a: gradient -> g[pmap[a]].
+            __syncthreads();
+            int* pmap = (int*)LDSB;
+            {
+                const int* kind = c.ia + L.io_pb_kind;
+                const int* off = c.ia + L.io_pb_off;
+                const int* pcol = c.ia + L.io_pb_col;
+                for (int blk = c.tid; blk < c.nblk; blk += BA_NT) {
+                    const int sz = (kind[blk] == VG_BLK_SPEEDBIAS) ? 9 : (kind[blk] == VG_BLK_TD ? 1 : 6);
+                    for (int k = 0; k < sz; ++k) pmap[off[blk] + k] = pcol[blk] >= 0 ? pcol[blk] + k : -1;
+                }
+            }
+            __syncthreads();
+            int* tab0 = (int*)(c.sc + L.so_ptab);
+            int* tab1 = tab0 + L.ptab_cap;
+            const int ntri = n * (n + 1) / 2, Rc = L.Rc;
+            for (int wk = c.tid; wk < ntri + n; wk += BA_NT) {
+                int d0 = -1, d1 = -1;
+                if (wk >= ntri) {
+                    const int ca = pmap[wk - ntri];
+                    if (ca >= 0) d0 = L.l_vec + V_G * L.Rpad + ca;
+                } else {
+                    int a, bb;
+                    tri_decode(wk, a, bb);
+                    const int ca = pmap[a], cb = pmap[bb];
+                    if (ca >= 0 && cb >= 0) {
+                        const int hi = ca > cb ? ca : cb, lo = ca > cb ? cb : ca;
+                        if (hi < Rc) d0 = L.l_S + tri(hi, lo);
+                        else if (lo < Rc) d0 = L.l_XC + (hi - Rc) * L.ldc + lo;
+                        else {
+                            const int ia = hi - Rc, ib = lo - Rc, ka = ia / 9, kb = ib / 9;
+                            if (ka == kb) {
+                                d0 = L.l_D + 9 * ia + (ib - 9 * kb);
+                                if (ia != ib) d1 = L.l_D + 9 * ib + (ia - 9 * ka);
+                            } else d0 = L.l_E + 9 * ia + (ib - 9 * kb);
+                        }
+                    }
+                }
+                tab0[wk] = d0; tab1[wk] = d1;
             }
         }
     }
@@ -958,46 +1006,82 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
                 // then the read-modify-writes (inside a round every entry has exactly one writer, so the slots are distinct).
                 // One trip per entry would be a chain of HBM round trips; on the large-window path most targets are in HBM too.
                 // Entries of the camera part live in LDS on both paths: they are added directly.
+                // The destination of entry e is the same for every factor up to a shift by the frame index, so it is decoded ONCE
+                // per thread: camera x camera -> packed S at (6 f + xa, 6 f + xb); everything else -> base + f * stride in the
+                // block that stores it (XC: 9 ldc + 6, D / E: 81, gradient: 6 or 9), D entries off the diagonal with a mirror.
                 const int e = c.tid;
-                int a = 0, b = 0;
-                if (e < 465) tri_decode(e, a, b);
+                int xa = -1, xb = 0, stride = 0;
+                MV* base0 = nullptr;
+                MV* base1 = nullptr;
+                if (e < 465) {
+                    int a, b;
+                    tri_decode(e, a, b);                             // a >= b
+                    const int ba = a < 6 ? 0 : a < 15 ? 1 : a < 21 ? 2 : 3, oa = a - (ba == 0 ? 0 : ba == 1 ? 6 : ba == 2 ? 15 : 21);
+                    const int bb = b < 6 ? 0 : b < 15 ? 1 : b < 21 ? 2 : 3, ob = b - (bb == 0 ? 0 : bb == 1 ? 6 : bb == 2 ? 15 : 21);
+                    const bool sa = ba & 1, sb = bb & 1;             // speed-bias block?
+                    if (!sa && !sb) { xa = oa + 3 * ba; xb = ob + 3 * bb; }                          // pose_f / pose_f+1
+                    else if (sa && !sb) { base0 = q.XC + (9 * (ba >> 1) + oa) * q.ldc + 3 * bb + ob; stride = 9 * q.ldc + 6; }
+                    else if (!sa && sb) { base0 = q.XC + ob * q.ldc + 6 + oa; stride = 9 * q.ldc + 6; }  // pose_f+1 x sb_f
+                    else if (ba == bb) {
+                        base0 = q.D + 81 * (ba >> 1) + 9 * oa + ob; stride = 81;
+                        if (oa != ob) base1 = q.D + 81 * (ba >> 1) + 9 * ob + oa;
+                    } else { base0 = q.E + 81 + 9 * oa + ob; stride = 81; }                          // sb_f+1 x sb_f
+                } else if (e < 495) {
+                    const int lc = e - 465;
+                    const int bl = lc < 6 ? 0 : lc < 15 ? 1 : lc < 21 ? 2 : 3, ol = lc - (bl == 0 ? 0 : bl == 1 ? 6 : bl == 2 ? 15 : 21);
+                    if (bl & 1) { base0 = g + Rc + 9 * (bl >> 1) + ol; stride = 9; }
+                    else { base0 = g + 3 * bl + ol; stride = 6; }
+                }
                 for (int i0 = 0; i0 < nf; i0 += 8) {
                     MV* p0[8];
                     MV* p1[8];
                     double v[8], t0[8], t1[8];
                     bool on[8];
+                    int vld[8];
 #pragma unroll
-                    for (int qq = 0; qq < 8; ++qq) {                 // the loads of the chunk, nothing else
-                        const int f = 2 * (i0 + qq) + par;
-                        on[qq] = i0 + qq < nf && e < 495 && valid[f];
-                        v[qq] = on[qq] ? imuJ[f * 512 + e] : 0.0;
+                    for (int qq = 0; qq < 8; ++qq) {                 // the loads of the chunk, nothing else: value and validity flag
+                        const int f = 2 * (i0 + qq) + par;           // in ONE round trip (clamped addresses, masked afterwards)
+                        const int fc = f < nimu ? f : nimu - 1;
+                        vld[qq] = valid[fc];
+                        v[qq] = imuJ[fc * 512 + e];
                     }
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
-                        const int f = 2 * (i0 + qq) + par;
-                        p0[qq] = nullptr; p1[qq] = nullptr;
-                        if (on[qq]) {
-                            if (e >= 465) { p0[qq] = g + imu_col(L, f, e - 465); continue; }
-                            int ca = imu_col(L, f, a), cb = imu_col(L, f, b);
-                            if (ca < cb) { const int t = ca; ca = cb; cb = t; }
-                            if (ca < Rc) { q.S[tri(ca, cb)] += v[qq]; continue; }
-                            const int ka = (ca - Rc) / 9, ra = (ca - Rc) - 9 * ka;
-                            if (cb < Rc) { p0[qq] = q.XC + (9 * ka + ra) * q.ldc + cb; continue; }
-                            const int kb = (cb - Rc) / 9, rb = (cb - Rc) - 9 * kb;
-                            if (ka == kb) {
-                                p0[qq] = q.D + 81 * ka + 9 * ra + rb;
-                                if (ra != rb) p1[qq] = q.D + 81 * ka + 9 * rb + ra;
-                            } else {
-                                p0[qq] = q.E + 81 * ka + 9 * ra + rb;
-                            }
+                        on[qq] = i0 + qq < nf && e < 495 && vld[qq];
+                        v[qq] = on[qq] ? v[qq] : 0.0;
+                    }
+                    if constexpr (!BIG) {
+                        // every target is in LDS: lanes without a target aim at a scratch slot and add 0, so the eight
+                        // read-modify-writes of a chunk are straight-line code (no divergent branch per entry)
+                        lds_d* const dummy = AS_LDS(m.wd);
+                        lds_d* a0[8];
+                        lds_d* a1[8];
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {
+                            const int f = 2 * (i0 + qq) + par;
+                            lds_d* t = xa >= 0 ? q.S + tri(6 * f + xa, 6 * f + xb) : (base0 ? base0 + f * stride : dummy);
+                            a0[qq] = on[qq] ? t : dummy;
+                            a1[qq] = (on[qq] && base1) ? base1 + f * stride : dummy;
                         }
-                    }
 #pragma unroll
-                    for (int qq = 0; qq < 8; ++qq) { t0[qq] = p0[qq] ? *p0[qq] : 0.0; t1[qq] = p1[qq] ? *p1[qq] : 0.0; }
+                        for (int qq = 0; qq < 8; ++qq) { t0[qq] = *a0[qq]; t1[qq] = *a1[qq]; }
 #pragma unroll
-                    for (int qq = 0; qq < 8; ++qq) {
-                        if (p0[qq]) *p0[qq] = t0[qq] + v[qq];
-                        if (p1[qq]) *p1[qq] = t1[qq] + v[qq];
+                        for (int qq = 0; qq < 8; ++qq) { *a0[qq] = t0[qq] + v[qq]; *a1[qq] = t1[qq] + v[qq]; }
+                    } else {
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {
+                            const int f = 2 * (i0 + qq) + par;
+                            p0[qq] = (on[qq] && base0) ? base0 + f * stride : nullptr;
+                            p1[qq] = (on[qq] && base1) ? base1 + f * stride : nullptr;
+                            if (on[qq] && xa >= 0) q.S[tri(6 * f + xa, 6 * f + xb)] += v[qq];
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) { t0[qq] = p0[qq] ? *p0[qq] : 0.0; t1[qq] = p1[qq] ? *p1[qq] : 0.0; }
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {
+                            if (p0[qq]) *p0[qq] = t0[qq] + v[qq];
+                            if (p1[qq]) *p1[qq] = t1[qq] + v[qq];
+                        }
                     }
                 }
             }
@@ -1006,7 +1090,44 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
             DP_ADD(19);
         }
     }
-    // ---- prior: H += J0^T J0 (precomputed Hp), g += J0^T r   (pmap: prior column -> reduced column or -1)
+    // ---- prior: H += J0^T J0, g += J0^T r.  Reference window: the slot of every entry was decoded by the prologue kernel
+    //      (so_ptab), the values are packed by entry — per entry two table reads, one value, one or two LDS adds.
+    if constexpr (!BIG) {
+        if (c.nprior) {
+            const int n = c.nprior, ntri = n * (n + 1) / 2, nent = ntri + n;
+            const glb_i* tab0 = AS_GLB_CI((const int*)(c.sc + L.so_ptab));
+            const glb_i* tab1 = tab0 + L.ptab_cap;
+            const glb_d* Hpk = AS_GLB_C(c.sc + L.so_Hpk);
+            const glb_d* gpr = buf + L.bo_gpr;        // J0^T r, formed by the linearisation kernel
+            lds_d* const lds0 = AS_LDS(LDSB);
+            lds_d* const dummy = AS_LDS(m.wd);
+            for (int w0 = 0; w0 < nent; w0 += 8 * BA_NT) {
+                int d0[8], d1[8];
+                double v[8], t0[8], t1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int w = w0 + c.tid + u * BA_NT;
+                    const int wc = w < nent ? w : nent - 1;
+                    d0[u] = tab0[wc]; d1[u] = tab1[wc];
+                    const double hv = Hpk[wc < ntri ? wc : 0], gv = gpr[wc >= ntri ? wc - ntri : 0];
+                    v[u] = wc < ntri ? hv : gv;
+                    if (w >= nent) { d0[u] = -1; d1[u] = -1; }
+                }
+                lds_d* a0[8];
+                lds_d* a1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    a0[u] = d0[u] >= 0 ? lds0 + d0[u] : dummy;
+                    a1[u] = d1[u] >= 0 ? lds0 + d1[u] : dummy;
+                    v[u] = d0[u] >= 0 ? v[u] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { t0[u] = *a0[u]; t1[u] = *a1[u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { *a0[u] = t0[u] + v[u]; *a1[u] = t1[u] + v[u]; }
+            }
+        }
+    } else
     if (c.nprior) {
         const int n = c.nprior;
         const glb_d* Hp = AS_GLB_C(c.sc + L.so_Hp);
@@ -1168,51 +1289,71 @@ DEV double rsqrt_nr(double x) {
 // for a BOTTOM block k-1 it holds (L_k-1^-1 E_k^T)^T as [c][p] (c = column sb_k, p = row of X_k-1) — each pair is consumed
 // by exactly one of its two blocks.  The camera system gets  S -= X^T X  in schur_mfma().
 // Returns false (uniform) on a non-positive pivot.
+// One wavefront, the block in the accumulator layout of v_mfma_f64_16x16x4_f64 (padded to 16x16 with the identity), as in
+// cholesky_aug(): the neighbour update is three MFMAs per coupling block (k = 9 padded to 12; the B operand of A A^T is the A
+// operand itself, negated), a pivot is v_readlane + 1/sqrt + one rank-1 MFMA, and no LDS access sits between the first load
+// and the final stores.
 template <typename P, typename PC>
-DEV bool chain_factor(int lane, P Dk, P dinvk, int kind, PC Xc) {
-    // kind 1: Xc = Xe of the upper neighbour as [p][r]  ->  D[r][c] -= sum_p Xc[9p + r] Xc[9p + c]
-    // kind 2: Xc = XuT of the lower neighbour as [r][p]  ->  D[r][c] -= sum_p Xc[9r + p] Xc[9c + p];  kind 3: both (Xc, Xc + 81)
-    if (kind) {
-        for (int e = lane; e < 81; e += 64) {
-            const int r = e / 9, cc = e - 9 * r;
-            double s = 0.0;
-            if (kind & 1) {
+DEV bool chain_factor(int lane, P Dk, P dinvk, int kind, PC Xc, PC Xu) {
+    // kind & 1: Xc = Xe of the upper neighbour as [p][r]  ->  D[r][c] -= sum_p Xc[9p + r] Xc[9p + c]
+    // kind & 2: Xu = XuT of the lower neighbour as [r][p]  ->  D[r][c] -= sum_p Xu[9r + p] Xu[9c + p]
+    const int jc = lane & 15, kq = lane >> 4;
+    double4_t dg;
 #pragma unroll
-                for (int p = 0; p < 9; ++p) s += Xc[9 * p + r] * Xc[9 * p + cc];
-            }
-            if (kind & 2) {
-                PC Xu = kind == 3 ? Xc + 81 : Xc;
-#pragma unroll
-                for (int p = 0; p < 9; ++p) s += Xu[9 * r + p] * Xu[9 * cc + p];
-            }
-            Dk[e] -= s;
-        }
+    for (int reg = 0; reg < 4; ++reg) {
+        const int i = kq + 4 * reg;
+        const bool in = i < 9 && jc < 9;
+        const double dv = Dk[in ? 9 * (i > jc ? i : jc) + (i > jc ? jc : i) : 0];
+        dg[reg] = in ? dv : (i == jc ? 1.0 : 0.0);
     }
-    __builtin_amdgcn_wave_barrier();
-    double a[9];
-    const int i = lane < 9 ? lane : 8;
+    if (kind & 1) {
+        double av[3];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) a[q] = (lane < 9 && q <= i) ? Dk[9 * i + q] : 0.0;
+        for (int s = 0; s < 3; ++s) {
+            const int pp = 4 * s + kq;
+            const bool in = pp < 9 && jc < 9;
+            const double v = Xc[in ? 9 * pp + jc : 0];
+            av[s] = in ? v : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], -av[s], dg, 0, 0, 0);
+    }
+    if (kind & 2) {
+        double av[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int pp = 4 * s + kq;
+            const bool in = pp < 9 && jc < 9;
+            const double v = Xu[in ? 9 * jc + pp : 0];
+            av[s] = in ? v : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], -av[s], dg, 0, 0, 0);
+    }
+    double msk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) msk[k] = kq == k ? 1.0 : 0.0;
+    double4_t ld = {0, 0, 0, 0}, di = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const double piv = readlane_d(dg[r >> 2], 16 * (r & 3) + r);
+        const double dm = rsqrt_nr(piv) * msk[r & 3];                 // a bad pivot turns everything behind it into NaN / Inf
+        const double lv = dg[r >> 2] * dm, nlv = dg[r >> 2] * -dm;
+        dg = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, nlv, dg, 0, 0, 0);
+        ld[r >> 2] += lv;
+        di[r >> 2] += dm;
+    }
     bool good = true;
 #pragma unroll
-    for (int jj = 0; jj < 9; ++jj) {
-        const double piv = readlane_d(a[jj], jj);
-        if (!(piv > 0.0) || !(piv < 1e300)) good = false;
-        const double dinv = rsqrt_nr(piv);
-        const double l = a[jj] * dinv;
-        a[jj] = l;
-        if (lane == 0) dinvk[jj] = dinv;
-#pragma unroll
-        for (int q = jj + 1; q < 9; ++q) {
-            const double lq = readlane_d(l, q);
-            a[q] -= l * lq;
+    for (int q = 0; q < 3; ++q) {
+        const int r = kq + 4 * q;
+        if (r < 9) {
+            if (!(di[q] > 0.0) || !(di[q] < 1e300)) good = false;
+            if (jc >= r && jc < 9) Dk[9 * jc + r] = ld[q];
+            if (jc == 0) dinvk[r] = di[q];
         }
     }
-    if (lane < 9) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) if (q <= i) Dk[9 * i + q] = a[q];
-    }
-    return good;
+    return !__any(!good);
 }
 // x <- L^-1 x for the 9 values at col[0], col[stride], ...
 template <typename PL, typename PD, typename P>
@@ -1258,50 +1399,36 @@ NOINL bool chain_eliminate(const Ctx& c_in, const SolveLds& m_in) {
         // ---- (A)
         if (c.wave == 0) {
             if (has_t) {
-                int kind = 0;
-                const lds_d* X = nullptr;
-                if (upd_t_from_above && upd_mid_from_below) {
-                    // the middle block takes both: copy the two coupling blocks next to each other (scratch in wd)
-                    for (int e = c.lane; e < 81; e += 64) { wd[e] = E[81 * (kt + 1) + e]; wd[81 + e] = E[81 * kt + e]; }
-                    __builtin_amdgcn_wave_barrier();
-                    kind = 3; X = wd;
-                } else if (upd_t_from_above) { kind = 1; X = E + 81 * (kt + 1); }
-                else if (upd_mid_from_below) { kind = 2; X = E + 81 * kt; }
-                if (!chain_factor(c.lane, D + 81 * kt, dinv + 9 * kt, kind, X) && c.lane == 0) *flag = 0;
+                const int kind = (upd_t_from_above ? 1 : 0) | (upd_mid_from_below ? 2 : 0);
+                if (!chain_factor(c.lane, D + 81 * kt, dinv + 9 * kt, kind, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt)) && c.lane == 0) *flag = 0;
             }
         } else if (c.wave == 1) {
-            if (has_b && !chain_factor(c.lane, D + 81 * kb, dinv + 9 * kb, upd_b ? 2 : 0, E + 81 * kb) && c.lane == 0) *flag = 0;
+            if (has_b && !chain_factor(c.lane, D + 81 * kb, dinv + 9 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb)) && c.lane == 0) *flag = 0;
         } else {
-            const int nt = BA_NT - 128, id = c.tid - 128;
-            const int per = 9 * (Rc + 1);
-            for (int w = id; w < 2 * per; w += nt) {
-                const int which = w >= per ? 1 : 0, e = w - which * per;
-                const int r = e / (Rc + 1), j = e - r * (Rc + 1);
-                if (which == 0) {
-                    if (!has_t) continue;
-                    double s = 0.0;
-                    if (upd_t_from_above) {
-                        const lds_d* Xe = E + 81 * (kt + 1);
-                        const lds_d* Xn = XC + 9 * (kt + 1) * ldc;
+            // [C_k | g_k] -= (coupling block)^T X_neighbour: thread = (three rows of the block, column j); the nine X values of the
+            // column are read once for the three rows, the coupling entries are wavefront-uniform (LDS broadcast reads)
+            const int id = c.tid - 128;
+            const int r3 = 3 * (id >> 7), j = id & 127;
+            if (j <= Rc) {
+                // coef[p * sp + r * sr] = coupling entry (row r of this block, row p of the neighbour's X)
+                auto upd = [&](const lds_d* coef, int sp, int sr, const lds_d* Xn, lds_d* Ck) {
+                    double xn[9], s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-                        for (int p = 0; p < 9; ++p) s += Xe[9 * p + r] * Xn[p * ldc + j];
+                    for (int p = 0; p < 9; ++p) xn[p] = Xn[p * ldc + j];
+                    const lds_d* cf = coef + r3 * sr;
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) {
+                        s0 += cf[p * sp] * xn[p];
+                        s1 += cf[p * sp + sr] * xn[p];
+                        s2 += cf[p * sp + 2 * sr] * xn[p];
                     }
-                    if (upd_mid_from_below) {
-                        const lds_d* Xu = E + 81 * kt;
-                        const lds_d* Xn = XC + 9 * (kt - 1) * ldc;
-#pragma unroll
-                        for (int p = 0; p < 9; ++p) s += Xu[9 * r + p] * Xn[p * ldc + j];
-                    }
-                    if (upd_t_from_above || upd_mid_from_below) XC[(9 * kt + r) * ldc + j] -= s;
-                } else {
-                    if (!upd_b) continue;
-                    const lds_d* Xu = E + 81 * kb;
-                    const lds_d* Xn = XC + 9 * (kb - 1) * ldc;
-                    double s = 0.0;
-#pragma unroll
-                    for (int p = 0; p < 9; ++p) s += Xu[9 * r + p] * Xn[p * ldc + j];
-                    XC[(9 * kb + r) * ldc + j] -= s;
-                }
+                    lds_d* o = Ck + r3 * ldc + j;
+                    const double c0v = o[0], c1v = o[ldc], c2v = o[2 * ldc];
+                    o[0] = c0v - s0; o[ldc] = c1v - s1; o[2 * ldc] = c2v - s2;
+                };
+                if (has_t && upd_t_from_above) upd(E + 81 * (kt + 1), 9, 1, XC + 9 * (kt + 1) * ldc, XC + 9 * kt * ldc);
+                if (has_t && upd_mid_from_below) upd(E + 81 * kt, 1, 9, XC + 9 * (kt - 1) * ldc, XC + 9 * kt * ldc);
+                if (upd_b) upd(E + 81 * kb, 1, 9, XC + 9 * (kb - 1) * ldc, XC + 9 * kb * ldc);
             }
         }
         DP_ADD(0);
@@ -1650,8 +1777,27 @@ NOINL void back_substitute(const Ctx& c_in, const SolveLds& m_in, int R) {
         const lds_d* rowR = S + tri(R, 0);
         double v0 = rowR[l0 < R ? l0 : 0], v1 = rowR[l1 < R ? l1 : 0];
         v0 = l0 < R ? v0 : 0.0; v1 = l1 < R ? v1 : 0.0;
+        // Four pivots per trip: the rows of L and the 1/L_jj of all four are read first (they do not depend on the running
+        // rhs), so that one LDS round trip is paid per four dependent steps instead of per step.
         int j = R - 1;
-        for (; j >= 64; --j) {          // pivot in v1
+        for (; j >= 64 + 3; j -= 4) {   // pivot in v1
+            double r0[4], r1[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const lds_d* rj = S + tri(j - u, 0);
+                r0[u] = rj[l0];
+                r1[u] = rj[l1 < j - u ? l1 : 0];
+                dv[u] = dinvv[j - u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int own = (j - u) & 63;
+                const double xj = readlane_d(v1, own) * dv[u];
+                v1 = c.lane == own ? xj : (l1 < j - u ? v1 - r1[u] * xj : v1);
+                v0 -= r0[u] * xj;
+            }
+        }
+        for (; j >= 64; --j) {
             const lds_d* rj = S + tri(j, 0);
             const double r0 = rj[l0];
             double r1 = rj[l1 < j ? l1 : 0];
@@ -1661,7 +1807,20 @@ NOINL void back_substitute(const Ctx& c_in, const SolveLds& m_in, int R) {
             v1 = c.lane == own ? xj : v1 - r1 * xj;
             v0 -= r0 * xj;
         }
-        for (; j >= 0; --j) {           // pivot in v0
+        for (; j >= 3; j -= 4) {        // pivot in v0
+            double r0[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                r0[u] = S[tri(j - u, 0) + (l0 < j - u ? l0 : 0)];
+                dv[u] = dinvv[j - u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double xj = readlane_d(v0, j - u) * dv[u];
+                v0 = c.lane == j - u ? xj : (l0 < j - u ? v0 - r0[u] * xj : v0);
+            }
+        }
+        for (; j >= 0; --j) {
             const lds_d* rj = S + tri(j, 0);
             double r0 = rj[l0 < j ? l0 : 0];
             r0 = l0 < j ? r0 : 0.0;
@@ -1769,6 +1928,9 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     const int w = blockIdx.x;
     ctx_init(c, Lp, P, w);
     double* ctlp = c.sc + L.so_ctl;
+    // Everything the first phase reads from HBM is requested in one batch (control block, cost partials of the linearisation
+    // kernels).  The prior column map is not needed here: the prologue kernel left a slot table (so_ptab) for assemble().
+    const double cs_part = sum_partials(AS_GLB_C(c.sc + L.so_part), L.nbl);
     Ctl s;
     ctl_load(s, ctlp);
     if (s.done) return;
@@ -1793,29 +1955,19 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     double* yl = c.sc + L.so_yl;
 
     PROF_DECL;
-    // prior column map (prior column -> reduced column or -1)
-    if (c.nprior) {
-        const int* kind = c.ia + L.io_pb_kind;
-        const int* off = c.ia + L.io_pb_off;
-        const int* pcol = c.ia + L.io_pb_col;
-        for (int blk = c.tid; blk < c.nblk; blk += BA_NT) {
-            const int sz = (kind[blk] == VG_BLK_SPEEDBIAS) ? 9 : (kind[blk] == VG_BLK_TD ? 1 : 6);
-            for (int k = 0; k < sz; ++k) m.pmap[off[blk] + k] = pcol[blk] >= 0 ? pcol[blk] + k : -1;
-        }
-    }
     __syncthreads();
 
     bool assembled = false;
     bool fresh_point = false;              // a new current point whose gradient has to be tested
     if (s.pending) {
-        const bool acc = judge_candidate(s, sum_partials(c.sc + L.so_part, L.nbl), L, out, iout, c.tid);
+        const bool acc = judge_candidate(s, cs_part, L, out, iout, c.tid);
         if (acc) {
             if (!(s.cost == s.cost)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
             fresh_point = true;
         }
     } else if (!s.scaled) {
         // round 0: cost of the initial point
-        s.cost = 0.5 * sum_partials(c.sc + L.so_part, L.nbl);
+        s.cost = 0.5 * cs_part;
         s.init_cost = s.cost;
         s.x_norm = sqrt(block_sum(m.red, BA_NW, c.lane, c.wave, state_sqnorm_share(L, c.sc + L.so_x + s.cur * L.nst,
                                                                                      c.sc + L.so_lam + s.cur * L.Lcap, nL, c.tid, BA_NT)));
@@ -2027,25 +2179,59 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
         }
         s.ninv = 0;
         s.model = model_change;
-        // ---- candidate = x (+) delta into the other state copy
-        for (int i = c.tid; i < L.Kp; i += BA_NT) pose_plus(x + 7 * i, vU + col_pose(L, i), xc + 7 * i);
-        for (int k = c.tid; k < 9 * L.K; k += BA_NT) xc[7 * L.Kp + k] = x[7 * L.Kp + k] + vU[col_sb(L, k / 9) + k % 9];
-        if (c.tid == 0) {
-            double* exc = xc + 7 * L.Kp + 9 * L.K;
-            const double* exx = x + 7 * L.Kp + 9 * L.K;
-            if (L.e) pose_plus(exx, vU + col_ex(L), exc);
-            else for (int k = 0; k < 7; ++k) exc[k] = exx[k];
-            exc[7] = L.t ? exx[7] + vU[col_td(L)] : exx[7];
-        }
-        for (int k = c.tid; k < nL; k += BA_NT) lamc[k] = lam[k] + sl[k] * ((c_gt * gtl[k] + c_gn * gnl[k]) / dgl[k]);
-        __syncthreads();
+        // ---- candidate = x (+) delta into the other state copy, |x_c - x| and |x_c| in the same pass (one HBM round trip: the
+        //      values are summed where they are produced instead of being read back)
         {
-            double sd = 0.0;
-            const int nx = 7 * L.Kp + 9 * L.K + (L.e ? 7 : 0);
-            for (int k = c.tid; k < nx; k += BA_NT) { const double d = x[k] - xc[k]; sd += d * d; }
-            if (L.t && c.tid == 0) { const double d = x[7 * L.Kp + 9 * L.K + 7] - xc[7 * L.Kp + 9 * L.K + 7]; sd += d * d; }
-            for (int k = c.tid; k < nL; k += BA_NT) { const double d = lam[k] - lamc[k]; sd += d * d; }
-            double sn = state_sqnorm_share(L, xc, lamc, nL, c.tid, BA_NT);
+            const glb_d* xg = AS_GLB_C(x);
+            glb_d* xcg = AS_GLB(xc);
+            const glb_d* lamg = AS_GLB_C(lam);
+            glb_d* lamcg = AS_GLB(lamc);
+            const glb_d* slg = AS_GLB_C(sl);
+            const glb_d* gtlg = AS_GLB_C(gtl);
+            const glb_d* gnlg = AS_GLB_C(gnl);
+            const glb_d* dglg = AS_GLB_C(dgl);
+            double sd = 0.0, sn = 0.0;
+            // poses: threads 0 .. Kp-1; the extrinsic pose + td: thread 64 (another wavefront)
+            const bool isex = c.tid == 64;
+            for (int i = isex ? L.Kp : c.tid; i < L.Kp + (isex ? 1 : 0); i += BA_NT) {
+                const int xo = isex ? 7 * L.Kp + 9 * L.K : 7 * i;
+                double xi[8], o[7], dl[6];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xi[k] = xg[xo + (k < 7 || isex ? k : 0)];
+                if (!isex || L.e) {
+                    const int co = isex ? col_ex(L) : col_pose(L, i);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) dl[k] = vU[co + k];
+                    pose_plus(xi, dl, o);
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) { const double d = xi[k] - o[k]; sd += d * d; sn += o[k] * o[k]; }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) o[k] = xi[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 7; ++k) xcg[xo + k] = o[k];
+                if (isex) {
+                    const double o7 = L.t ? xi[7] + vU[col_td(L)] : xi[7];
+                    xcg[xo + 7] = o7;
+                    if (L.t) { const double d = xi[7] - o7; sd += d * d; sn += o7 * o7; }
+                }
+            }
+            // speed-bias entries: from the last thread downwards (the first wavefront has the poses)
+            for (int k = BA_NT - 1 - c.tid; k < 9 * L.K; k += BA_NT) {
+                const double xv = xg[7 * L.Kp + k];
+                const double o = xv + vU[col_sb(L, k / 9) + k % 9];
+                xcg[7 * L.Kp + k] = o;
+                const double d = xv - o;
+                sd += d * d; sn += o * o;
+            }
+            for (int k = c.tid; k < nL; k += BA_NT) {
+                const double lv = lamg[k];
+                const double o = lv + slg[k] * ((c_gt * gtlg[k] + c_gn * gnlg[k]) / dglg[k]);
+                lamcg[k] = o;
+                const double d = lv - o;
+                sd += d * d; sn += o * o;
+            }
             block_sum2(m.red, BA_NW, c.lane, c.wave, sd, sn);
             s.step_norm = sqrt(sd);
             s.x_norm_c = sqrt(sn);
@@ -2315,7 +2501,7 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
                 Lt[e] = D[81 * kt + e] - s;
             }
             __builtin_amdgcn_wave_barrier();
-            if (!chain_factor(c.lane, Lt, dit, 0, (const lds_d*)nullptr) && c.lane == 0) *flag = 0;
+            if (!chain_factor(c.lane, Lt, dit, 0, (const lds_d*)nullptr, (const lds_d*)nullptr) && c.lane == 0) *flag = 0;
             __builtin_amdgcn_wave_barrier();
             for (int e = c.lane; e < 81; e += 64) D[81 * kt + e] = Lt[e];
             if (c.lane < 9) dinv[9 * kt + c.lane] = dit[c.lane];
@@ -2330,7 +2516,7 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
                 Lb[e] = D[81 * kb + e] - s;
             }
             __builtin_amdgcn_wave_barrier();
-            if (!chain_factor(c.lane, Lb, dib, 0, (const lds_d*)nullptr) && c.lane == 0) *flag = 0;
+            if (!chain_factor(c.lane, Lb, dib, 0, (const lds_d*)nullptr, (const lds_d*)nullptr) && c.lane == 0) *flag = 0;
             __builtin_amdgcn_wave_barrier();
             for (int e = c.lane; e < 81; e += 64) D[81 * kb + e] = Lb[e];
             if (c.lane < 9) dinv[9 * kb + c.lane] = dib[c.lane];
