@@ -982,14 +982,50 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
     MV* g = q.vec + V_G * L.Rpad;
     __syncthreads();
     DP_DECL;
-    for (int k = c.tid; k < camtri; k += BA_NT) q.S[k] = Sp[k];
-    for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? gp[k] : 0.0;
+    // Reference window: every HBM value the two scatter phases below need (IMU blocks of both parities, prior entries) is
+    // requested HERE, so that its latency runs under the copy / clear phase instead of in front of each scatter round.
+    const bool pre_imu = !BIG && K - 1 <= 16;
+    const bool pre_pri = !BIG && c.nprior && c.nprior * (c.nprior + 1) / 2 + c.nprior <= 8 * BA_NT;
+    double pv[2][8], qv[8];
+    int pvl[2][8], qd0[8], qd1[8];
+    if (pre_imu) {
+        const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
+        const glb_d* imuJ = buf + L.bo_imuJ;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                const int f = 2 * qq + par, fc = f < K - 1 ? f : K - 2;
+                pvl[par][qq] = valid[fc];
+                pv[par][qq] = imuJ[fc * 512 + c.tid];
+            }
+        }
+    }
+    if (pre_pri) {
+        const int n = c.nprior, ntri = n * (n + 1) / 2, nent = ntri + n;
+        const glb_i* tab0 = AS_GLB_CI((const int*)(c.sc + L.so_ptab));
+        const glb_i* tab1 = tab0 + L.ptab_cap;
+        const glb_d* Hpk = AS_GLB_C(c.sc + L.so_Hpk);
+        const glb_d* gpr = buf + L.bo_gpr;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = c.tid + u * BA_NT;
+            const int wc = w < nent ? w : nent - 1;
+            qd0[u] = tab0[wc]; qd1[u] = tab1[wc];
+            const double hv = Hpk[wc < ntri ? wc : 0], gv = gpr[wc >= ntri ? wc - ntri : 0];
+            qv[u] = wc < ntri ? hv : gv;
+            if (w >= nent) { qd0[u] = -1; qd1[u] = -1; }
+        }
+    }
     if (!BIG) {
         // (large-window path: XC / D / E live in HBM and were cleared by the Schur kernel's extra workgroups)
+        // The clears come first: they wait for nothing, the copies below wait for the loads already in flight.
         const int nxc = ((9 * K + 3) & ~3) * q.ldc;
         for (int k = c.tid; k < nxc; k += BA_NT) q.XC[k] = 0.0;
         for (int k = c.tid; k < 81 * K; k += BA_NT) { q.D[k] = 0.0; q.E[k] = 0.0; }
     }
+    for (int k = c.tid; k < camtri; k += BA_NT) q.S[k] = Sp[k];
+    for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? gp[k] : 0.0;
     DP_ADD(16);
     __syncthreads();
     DP_ADD(17);
@@ -999,6 +1035,7 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
         const int nimu = K - 1;
         const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
         const glb_d* imuJ = buf + L.bo_imuJ;
+#pragma unroll
         for (int par = 0; par < 2; ++par) {
             const int nf = (nimu - par + 1) / 2;
             {
@@ -1038,12 +1075,17 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
                     double v[8], t0[8], t1[8];
                     bool on[8];
                     int vld[8];
+                    if (pre_imu) {
 #pragma unroll
-                    for (int qq = 0; qq < 8; ++qq) {                 // the loads of the chunk, nothing else: value and validity flag
-                        const int f = 2 * (i0 + qq) + par;           // in ONE round trip (clamped addresses, masked afterwards)
-                        const int fc = f < nimu ? f : nimu - 1;
-                        vld[qq] = valid[fc];
-                        v[qq] = imuJ[fc * 512 + e];
+                        for (int qq = 0; qq < 8; ++qq) { vld[qq] = pvl[par][qq]; v[qq] = pv[par][qq]; }
+                    } else {
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {             // the loads of the chunk, nothing else: value and validity flag
+                            const int f = 2 * (i0 + qq) + par;       // in ONE round trip (clamped addresses, masked afterwards)
+                            const int fc = f < nimu ? f : nimu - 1;
+                            vld[qq] = valid[fc];
+                            v[qq] = imuJ[fc * 512 + e];
+                        }
                     }
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
@@ -1104,14 +1146,19 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
             for (int w0 = 0; w0 < nent; w0 += 8 * BA_NT) {
                 int d0[8], d1[8];
                 double v[8], t0[8], t1[8];
+                if (pre_pri) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int w = w0 + c.tid + u * BA_NT;
-                    const int wc = w < nent ? w : nent - 1;
-                    d0[u] = tab0[wc]; d1[u] = tab1[wc];
-                    const double hv = Hpk[wc < ntri ? wc : 0], gv = gpr[wc >= ntri ? wc - ntri : 0];
-                    v[u] = wc < ntri ? hv : gv;
-                    if (w >= nent) { d0[u] = -1; d1[u] = -1; }
+                    for (int u = 0; u < 8; ++u) { d0[u] = qd0[u]; d1[u] = qd1[u]; v[u] = qv[u]; }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int w = w0 + c.tid + u * BA_NT;
+                        const int wc = w < nent ? w : nent - 1;
+                        d0[u] = tab0[wc]; d1[u] = tab1[wc];
+                        const double hv = Hpk[wc < ntri ? wc : 0], gv = gpr[wc >= ntri ? wc - ntri : 0];
+                        v[u] = wc < ntri ? hv : gv;
+                        if (w >= nent) { d0[u] = -1; d1[u] = -1; }
+                    }
                 }
                 lds_d* a0[8];
                 lds_d* a1[8];
