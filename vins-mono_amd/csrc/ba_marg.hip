@@ -495,7 +495,7 @@ extern "C" int vg_debug_marg_profile(double* out16, int reset) {
 #define MP_DECL
 #define MP_ADD(id)
 #endif
-DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, double delta0_rel, double tol, int maxsweep) {
+DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, double delta0_rel, double tol, double tolq, int maxsweep) {
     double* A = MG_LDS + offM;
     double* Lc = MG_LDS + offV;               // column k of L at Lc[k * ld + i]
     double* dgn = MG_LDS + offcs;             // running diagonal of the Schur complement
@@ -558,7 +558,7 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
     // ---- one-sided Jacobi on the n columns (length n) of L
     const int N = (n + 1) & ~1, npairs = N / 2, nrounds = N - 1;
     const int hrows = (n + 15) / 16;           // elements of a column per lane actually present
-    const double tol2 = tol * tol;
+    const double tol2 = tol * tol, tolq2 = tolq * tolq;
     int sweep = 0;
     if (n >= 2) {
         for (;;) {
@@ -570,7 +570,7 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
                 sq = mg_row16_sum(sq);
                 if (i < n && sub == 0) nrm[i] = sq;
             }
-            if (c.tid == 0) red[16] = 0.0;
+            if (c.tid == 0) { red[16] = 0.0; red[19] = 0.0; }
             __syncthreads();
             // round-robin tournament: player N-1 stays, the others rotate: group g plays (r + g, r - g) mod N-1 in round r,
             // i.e. both indices advance by one per round (kept incrementally: no integer division in the loop)
@@ -628,7 +628,10 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
                             Lc[b * ld + j] = sn * gp[u] + cs * gq[u];
                         }
                     }
-                    if (sub == 0) { nrm[a] = al - t * gam; nrm[b] = be + t * gam; red[16] = 1.0; }
+                    if (sub == 0) {
+                        nrm[a] = al - t * gam; nrm[b] = be + t * gam; red[16] = 1.0;
+                        if (gam * gam > tolq2 * al * be) red[19] = 1.0;          // a rotation above the look-ahead threshold
+                    }
 #ifdef BA_PROFILE_DETAIL
                     if (sub == 0 && blockIdx.x == 0 && sweep < 11) {
                         atomicAdd(&g_mprof[5 + sweep], 1.0);
@@ -644,7 +647,9 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
                 MP_ADD(4);
             }
             ++sweep;
-            const bool again = red[16] != 0.0 && sweep < maxsweep;
+            // Stop when a sweep rotated nothing — or nothing above tolq: the sweep that just ended has annihilated those pairs,
+            // and what they leave behind is of second order (the verification sweep would rotate nothing).
+            const bool again = red[16] != 0.0 && red[19] != 0.0 && sweep < maxsweep;
             __syncthreads();
             if (!again) break;
         }
@@ -1189,7 +1194,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         const long long _t1 = clock64();
 #endif
         const bool fast1 = in_lds && m >= 1 && m <= 16 * MG_HROWS;
-        const int sw1 = fast1 ? vh_eig(c, 0, ld * ld, m, ldm, offcs, offred, 0.0, 2e-16, 10)
+        const int sw1 = fast1 ? vh_eig(c, 0, ld * ld, m, ldm, offcs, offred, 0.0, 2e-16, 0.0, 10)
                       : in_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, m, ldm, offcs, offred, true)
                                : jacobi_eig<false>(c, Mm, Vm, 0, 0, m, ldm, offcs, offred, true);
 #ifdef BA_PROFILE
@@ -1250,8 +1255,9 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     // only matter for the eps = 1e-8 cut: theta = 1e-9 moves a small eigenvalue by ~theta^2 lambda_max ~ 1e-11, two decades
     // below the ~u |A| noise of the reference's tridiagonal QR on the same matrix.  Measured on the EuRoC-shape windows: the
     // largest |g_p.g_q| / (|g_p||g_q|) per sweep runs 0.66, 0.44, 0.41, 6e-2, 7e-3, 1e-5, 9e-8, 8e-9, 1e-10 -- each further
-    // decade costs a full sweep of 75 rounds.
-    const int sw2 = fast2 ? vh_eig(c, 0, ld * ld, n, ld2, offcs2, offred2, 2e-8, 1e-9, 16)
+    // decade costs a full sweep of 75 rounds.  The last of them used to be a pure verification sweep (no rotation): the loop
+    // now ends after the first sweep whose largest rotated pair was below 1e-7 (what it leaves is ~theta^2).
+    const int sw2 = fast2 ? vh_eig(c, 0, ld * ld, n, ld2, offcs2, offred2, 2e-8, 1e-9, 1e-7, 16)
                   : n_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, n, ld2, offcs2, offred2, false)
                           : jacobi_eig<false>(c, M2, V2, 0, 0, n, ld2, offcs2, offred2, false);
 #ifdef BA_PROFILE
