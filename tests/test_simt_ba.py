@@ -25,6 +25,16 @@ def test_emulated_rejected_and_interpolated_steps(simt_handle):
     assert {'rejected', 'gn'} <= FX.trace_features(summ)
 
 
+def test_emulated_failed_factorisations_escalate_mu_then_fail(simt_handle):
+    """The blocked Cholesky reports a bad pivot through the 1/sqrt values of a 16-column block (NaN / Inf / <= 0), the 9x9
+    chain factors likewise: a window whose every linear solve fails must walk mu x 10, five invalid steps and FAILURE with the
+    same per-iteration trace as the oracle."""
+    build, need = FX.BRANCH_FIXTURES['overflowing_landmark']
+    with np.errstate(all='ignore'):
+        _, _, summ = _check_solve(simt_handle, build(L=24))
+    assert need <= FX.trace_features(summ)
+
+
 def test_emulated_marginalization_matches_oracle(simt_handle):
     seq = synth.SyntheticSequence(40, L=30)
     prob = seq.window(0)
