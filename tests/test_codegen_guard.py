@@ -1,0 +1,94 @@
+"""Static guard on the device code of libvinsgpu.so (no GPU needed): the phase functions of the BA solve kernel must keep
+their explicit address spaces and their MFMA factorisations.
+
+A pointer handed to a non-inlined device function is generic; every access through it compiles to flat_load / flat_store
+(re-typing the operands as address_space(3) / address_space(1) was worth 17 % of the solve kernel).  A refactor
+that drops a cast silently brings the flat accesses back without failing any parity test, so the instruction mix of the built
+library is pinned here: a handful of flat loads per function (the by-reference context structs), LDS traffic as ds_*, HBM
+traffic as global_*, and v_mfma_f64_16x16x4 where the dense factors are supposed to use it."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "..", "vins-mono_amd", "lib", "libvinsgpu.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _device_functions():
+    """{symbol: [instruction mnemonics]} over every gfx950 code object embedded in the library."""
+    if not os.path.exists(LIB):
+        import __graft_entry__ as g
+        g.build()
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(LIB, so)
+        subprocess.run([OBJDUMP, "--offloading", so], cwd=tmp, check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            txt = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            name = None
+            for line in txt.splitlines():
+                m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+                if m:
+                    name = m.group(1)
+                    out.setdefault(name, [])
+                    continue
+                m = re.match(r"^\s+([a-z_0-9]+)\s", line)
+                if m and name:
+                    out[name].append(m.group(1))
+    return out
+
+
+@pytest.fixture(scope="module")
+def funcs():
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    return _device_functions()
+
+
+def _find(funcs, *needles):
+    hits = [k for k in funcs if all(n in k for n in needles)]
+    assert hits, f"no device function matching {needles}"
+    return hits
+
+
+def _count(ops, prefix):
+    return sum(1 for o in ops if o.startswith(prefix))
+
+
+# function name fragment -> (max flat accesses, min ds accesses, min MFMAs)
+PHASES = {
+    "cholesky_aug": (12, 30, 32),        # 16 pivots x (diagonal block + panel tile) + the trailing update
+    "15chain_eliminateRK3Ctx": (24, 150, 12),    # two 9x9 factors with their neighbour updates (MFMA), column solves in LDS
+    "schur_mfma": (24, 50, 24),
+    "15back_substituteRK3Ctx": (16, 12, 0),
+    "build_scaledILb0E": (16, 20, 0),
+    "assembleILb0E": (30, 60, 0),
+}
+
+
+@pytest.mark.parametrize("frag", sorted(PHASES))
+def test_phase_function_keeps_its_address_spaces(funcs, frag):
+    max_flat, min_ds, min_mfma = PHASES[frag]
+    for name in _find(funcs, frag):
+        ops = funcs[name]
+        flat = _count(ops, "flat_load") + _count(ops, "flat_store")
+        ds = _count(ops, "ds_read") + _count(ops, "ds_write")
+        mfma = _count(ops, "v_mfma_f64_16x16x4")
+        assert flat <= max_flat, f"{name}: {flat} flat accesses (generic pointers are back)"
+        assert ds >= min_ds, f"{name}: only {ds} LDS accesses"
+        assert mfma >= min_mfma, f"{name}: only {mfma} v_mfma_f64_16x16x4"
+
+
+def test_kernels_do_not_fall_back_to_flat_memory(funcs):
+    for k in ("ba_accumulate_kernel", "ba_linearize_imu_kernel", "ba_linearize_proj_kernel", "ba_solve_kernel", "fe_lk_kernel"):
+        for name in _find(funcs, k):
+            ops = funcs[name]
+            assert _count(ops, "flat_load") + _count(ops, "flat_store") <= 4, name
