@@ -1,0 +1,493 @@
+// TEST INFRASTRUCTURE — C entry points into the REFERENCE'S OWN back-end code, compiled unchanged from
+// /root/reference/vins_estimator/src (see oracle/Makefile target `ref`; output oracle/_ref/libvins_ref.so).
+//
+// What is the reference here:  estimator.cpp (Estimator::processIMU / processImage / optimization / vector2double /
+// double2vector / slideWindow*), feature_manager.cpp, factor/{projection_factor,projection_td_factor,
+// marginalization_factor,pose_local_parameterization}.cpp, factor/{imu_factor,integration_base}.h, utility/utility.{h,cpp}.
+// What is NOT the reference: the header stand-ins under oracle/ref_stubs (mini-Eigen, ceres modelling API + restated
+// trust-region solver, ros/opencv names) and this file, which only moves plain arrays in and out of the reference classes
+// and defines the globals of parameters.cpp (vins_estimator/src/parameters.cpp:3-33) that readParameters() would fill
+// from the YAML file.  initial/* (SfM bootstrap) is out of scope: its four entry points abort.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "estimator.h"
+
+// ---- globals of vins_estimator/src/parameters.cpp:3-33 (EuRoC defaults; vref_set_config overwrites them)
+double INIT_DEPTH = 5.0;
+double MIN_PARALLAX = 10.0 / 460.0;
+double ACC_N = 0.08, ACC_W = 0.00004;
+double GYR_N = 0.004, GYR_W = 2.0e-6;
+std::vector<Eigen::Matrix3d> RIC;
+std::vector<Eigen::Vector3d> TIC;
+Eigen::Vector3d G{0.0, 0.0, 9.8};
+double BIAS_ACC_THRESHOLD = 0.1;
+double BIAS_GYR_THRESHOLD = 0.1;
+double SOLVER_TIME = 0.04;
+int NUM_ITERATIONS = 8;
+int ESTIMATE_EXTRINSIC = 0;
+int ESTIMATE_TD = 0;
+int ROLLING_SHUTTER = 0;
+std::string EX_CALIB_RESULT_PATH;
+std::string VINS_RESULT_PATH;
+std::string IMU_TOPIC;
+double ROW = 480, COL = 752;
+double TD = 0, TR = 0;
+
+// ---- initial/* entry points named by estimator.cpp; never reached (the driver starts in NON_LINEAR mode)
+[[noreturn]] static void out_of_scope(const char *what) {
+    std::fprintf(stderr, "oracle/_ref: %s reached — vins_estimator/src/initial/* is out of scope (SURVEY.md 8)\n", what);
+    std::abort();
+}
+bool MotionEstimator::solveRelativeRT(const vector<pair<Vector3d, Vector3d>> &, Matrix3d &, Vector3d &) { out_of_scope("MotionEstimator::solveRelativeRT"); }
+GlobalSFM::GlobalSFM() {}
+bool GlobalSFM::construct(int, Quaterniond *, Vector3d *, int, const Matrix3d, const Vector3d, vector<SFMFeature> &, map<int, Vector3d> &) {
+    out_of_scope("GlobalSFM::construct");
+}
+bool VisualIMUAlignment(map<double, ImageFrame> &, Vector3d *, Vector3d &, VectorXd &) { out_of_scope("VisualIMUAlignment"); }
+InitialEXRotation::InitialEXRotation() { frame_count = 0; }
+bool InitialEXRotation::CalibrationExRotation(vector<pair<Vector3d, Vector3d>>, Quaterniond, Matrix3d &) { out_of_scope("InitialEXRotation::CalibrationExRotation"); }
+
+namespace ceres {
+extern Solver::Summary vins_ref_last_summary;   // solver_summary_tap.cc
+}
+
+namespace {
+Eigen::Matrix3d mat3(const double *rowmajor) {
+    Eigen::Matrix3d m;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) m(i, j) = rowmajor[3 * i + j];
+    return m;
+}
+Eigen::Vector3d vec3(const double *v) { return Eigen::Vector3d(v[0], v[1], v[2]); }
+void out3(const Eigen::Vector3d &v, double *o) { o[0] = v(0), o[1] = v(1), o[2] = v(2); }
+void out_rowmajor(const Eigen::MatrixXd &m, double *o) {
+    for (Eigen::Index i = 0; i < m.rows(); i++)
+        for (Eigen::Index j = 0; j < m.cols(); j++) o[i * m.cols() + j] = m(i, j);
+}
+IntegrationBase *as_pre(void *p) { return static_cast<IntegrationBase *>(p); }
+Estimator *as_est(void *p) { return static_cast<Estimator *>(p); }
+}  // namespace
+
+extern "C" {
+
+int vref_abi_version() { return 1; }
+int vref_window_size() { return WINDOW_SIZE; }
+
+// ------------------------------------------------------------------------------------------ configuration
+void vref_set_config(double acc_n, double acc_w, double gyr_n, double gyr_w, double g_norm, int estimate_extrinsic, int estimate_td,
+                     double td, double tr, double row, int num_iterations, double init_depth, double min_parallax,
+                     const double *ric_rowmajor, const double *tic) {
+    ACC_N = acc_n, ACC_W = acc_w, GYR_N = gyr_n, GYR_W = gyr_w;
+    G = Eigen::Vector3d(0.0, 0.0, g_norm);
+    ESTIMATE_EXTRINSIC = estimate_extrinsic;
+    ESTIMATE_TD = estimate_td;
+    TD = td, TR = tr, ROW = row;
+    NUM_ITERATIONS = num_iterations;
+    INIT_DEPTH = init_depth;
+    MIN_PARALLAX = min_parallax;
+    RIC.clear();
+    TIC.clear();
+    RIC.push_back(mat3(ric_rowmajor));
+    TIC.push_back(vec3(tic));
+    ProjectionFactor::sqrt_info = FOCAL_LENGTH / 1.5 * Eigen::Matrix2d::Identity();     // estimator.cpp:17-18
+    ProjectionTdFactor::sqrt_info = FOCAL_LENGTH / 1.5 * Eigen::Matrix2d::Identity();
+}
+
+// ------------------------------------------------------------------------------------------ utility/utility.h
+void vref_R2ypr(const double *R_rowmajor, double *ypr) { out3(Utility::R2ypr(mat3(R_rowmajor)), ypr); }
+void vref_ypr2R(const double *ypr, double *R_rowmajor) { out_rowmajor(Utility::ypr2R(vec3(ypr)), R_rowmajor); }
+void vref_g2R(const double *g, double *R_rowmajor) { out_rowmajor(Utility::g2R(vec3(g)), R_rowmajor); }
+void vref_quat_from_R(const double *R_rowmajor, double *q_xyzw) {
+    Eigen::Quaterniond q(mat3(R_rowmajor));
+    q_xyzw[0] = q.x(), q_xyzw[1] = q.y(), q_xyzw[2] = q.z(), q_xyzw[3] = q.w();
+}
+
+// ------------------------------------------------------------------------------------------ B1 PoseLocalParameterization
+void vref_pose_plus(const double *x7, const double *delta6, double *out7) {
+    PoseLocalParameterization *lp = new PoseLocalParameterization();
+    static_cast<ceres::LocalParameterization *>(lp)->Plus(x7, delta6, out7);
+    delete lp;
+}
+void vref_pose_plus_jacobian(const double *x7, double *jac_7x6) {
+    PoseLocalParameterization *lp = new PoseLocalParameterization();
+    static_cast<ceres::LocalParameterization *>(lp)->ComputeJacobian(x7, jac_7x6);
+    delete lp;
+}
+
+// ------------------------------------------------------------------------------------------ 8(f)-2 IntegrationBase
+void *vref_preint_create(const double *acc0, const double *gyr0, const double *ba, const double *bg) {
+    return new IntegrationBase(vec3(acc0), vec3(gyr0), vec3(ba), vec3(bg));
+}
+void vref_preint_destroy(void *p) { delete as_pre(p); }
+void vref_preint_push(void *p, double dt, const double *acc, const double *gyr) { as_pre(p)->push_back(dt, vec3(acc), vec3(gyr)); }
+void vref_preint_repropagate(void *p, const double *ba, const double *bg) { as_pre(p)->repropagate(vec3(ba), vec3(bg)); }
+// delta_q as x y z w; jacobian / covariance 15x15 row-major
+void vref_preint_get(void *p, double *sum_dt, double *dp, double *dq_xyzw, double *dv, double *lin_ba, double *lin_bg, double *jac, double *cov) {
+    IntegrationBase *b = as_pre(p);
+    *sum_dt = b->sum_dt;
+    out3(b->delta_p, dp);
+    dq_xyzw[0] = b->delta_q.x(), dq_xyzw[1] = b->delta_q.y(), dq_xyzw[2] = b->delta_q.z(), dq_xyzw[3] = b->delta_q.w();
+    out3(b->delta_v, dv);
+    out3(b->linearized_ba, lin_ba);
+    out3(b->linearized_bg, lin_bg);
+    out_rowmajor(b->jacobian, jac);
+    out_rowmajor(b->covariance, cov);
+}
+// an IntegrationBase whose RESULT fields are given (the windows of the test generators carry pre-integrated terms)
+void *vref_preint_from_terms(double sum_dt, const double *dp, const double *dq_xyzw, const double *dv, const double *lin_ba, const double *lin_bg,
+                             const double *jac, const double *cov) {
+    IntegrationBase *b = new IntegrationBase(Eigen::Vector3d::Zero(), Eigen::Vector3d::Zero(), vec3(lin_ba), vec3(lin_bg));
+    b->sum_dt = sum_dt;
+    b->delta_p = vec3(dp);
+    b->delta_q = Eigen::Quaterniond(dq_xyzw[3], dq_xyzw[0], dq_xyzw[1], dq_xyzw[2]);
+    b->delta_v = vec3(dv);
+    for (int i = 0; i < 15; i++)
+        for (int j = 0; j < 15; j++) {
+            b->jacobian(i, j) = jac[15 * i + j];
+            b->covariance(i, j) = cov[15 * i + j];
+        }
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------ B2 IMUFactor::Evaluate
+// poses as [p(3) q(xyzw)], speed-bias as [v ba bg]; Jacobians row-major 15x7 / 15x9 as Ceres hands them over
+void vref_imu_factor(void *pre, const double *pose_i, const double *sb_i, const double *pose_j, const double *sb_j, double *res15, double *J_pose_i,
+                     double *J_sb_i, double *J_pose_j, double *J_sb_j) {
+    IMUFactor f(as_pre(pre));
+    const double *par[4] = {pose_i, sb_i, pose_j, sb_j};
+    double *jac[4] = {J_pose_i, J_sb_i, J_pose_j, J_sb_j};
+    f.Evaluate(par, res15, J_pose_i ? jac : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------ B3 / B4 projection factors
+void vref_projection_factor(const double *pts_i, const double *pts_j, const double *pose_i, const double *pose_j, const double *ex, double inv_dep,
+                            double *res2, double *J_pose_i, double *J_pose_j, double *J_ex, double *J_feature) {
+    ProjectionFactor f(vec3(pts_i), vec3(pts_j));
+    const double *par[4] = {pose_i, pose_j, ex, &inv_dep};
+    double *jac[4] = {J_pose_i, J_pose_j, J_ex, J_feature};
+    f.Evaluate(par, res2, J_pose_i ? jac : nullptr);
+}
+void vref_projection_td_factor(const double *pts_i, const double *pts_j, const double *vel_i, const double *vel_j, double td_i, double td_j, double row_i,
+                               double row_j, const double *pose_i, const double *pose_j, const double *ex, double inv_dep, double td, double *res2,
+                               double *J_pose_i, double *J_pose_j, double *J_ex, double *J_feature, double *J_td) {
+    ProjectionTdFactor f(vec3(pts_i), vec3(pts_j), Eigen::Vector2d(vel_i[0], vel_i[1]), Eigen::Vector2d(vel_j[0], vel_j[1]), td_i, td_j, row_i, row_j);
+    const double *par[5] = {pose_i, pose_j, ex, &inv_dep, &td};
+    double *jac[5] = {J_pose_i, J_pose_j, J_ex, J_feature, J_td};
+    f.Evaluate(par, res2, J_pose_i ? jac : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------ Estimator
+void *vref_est_create() {
+    void *mem = std::calloc(1, sizeof(Estimator));   // estimator_node.cpp:19 keeps it in static storage (zero-initialised)
+    Estimator *e = new (mem) Estimator();
+    e->setParameter();
+    return e;
+}
+void vref_est_destroy(void *p) {
+    Estimator *e = as_est(p);
+    e->clearState();
+    e->~Estimator();
+    std::free(p);
+}
+void vref_est_process_imu(void *p, double dt, const double *acc, const double *gyr) { as_est(p)->processIMU(dt, vec3(acc), vec3(gyr)); }
+// rows of 7: x y z(=1) u v vx vy  (feature_tracker_node.cpp:125-147 -> estimator_node.cpp:262-286)
+void vref_est_process_image(void *p, double stamp, int n, const int *ids, const double *rows7) {
+    map<int, vector<pair<int, Eigen::Matrix<double, 7, 1>>>> image;
+    for (int i = 0; i < n; i++) {
+        Eigen::Matrix<double, 7, 1> v;
+        for (int k = 0; k < 7; k++) v(k) = rows7[7 * i + k];
+        image[ids[i]].emplace_back(0, v);
+    }
+    std_msgs::Header h;
+    h.stamp.fromSec(stamp);
+    as_est(p)->processImage(image, h);
+}
+void vref_est_set_solver_flag(void *p, int nonlinear) { as_est(p)->solver_flag = nonlinear ? Estimator::NON_LINEAR : Estimator::INITIAL; }
+int vref_est_get_solver_flag(void *p) { return as_est(p)->solver_flag == Estimator::NON_LINEAR; }
+void vref_est_set_frame_count(void *p, int fc) { as_est(p)->frame_count = fc; }
+int vref_est_get_frame_count(void *p) { return as_est(p)->frame_count; }
+void vref_est_set_marginalization_flag(void *p, int second_new) {
+    as_est(p)->marginalization_flag = second_new ? Estimator::MARGIN_SECOND_NEW : Estimator::MARGIN_OLD;
+}
+int vref_est_get_marginalization_flag(void *p) { return as_est(p)->marginalization_flag == Estimator::MARGIN_SECOND_NEW; }
+void vref_est_set_stamp(void *p, int i, double t) { as_est(p)->Headers[i].stamp.fromSec(t); }
+void vref_est_set_g(void *p, const double *g) { as_est(p)->g = vec3(g); }
+// frame state: P(3), R row-major (9), V, Ba, Bg
+void vref_est_set_frame(void *p, int i, const double *P, const double *R_rowmajor, const double *V, const double *Ba, const double *Bg) {
+    Estimator *e = as_est(p);
+    e->Ps[i] = vec3(P);
+    e->Rs[i] = mat3(R_rowmajor);
+    e->Vs[i] = vec3(V);
+    e->Bas[i] = vec3(Ba);
+    e->Bgs[i] = vec3(Bg);
+}
+void vref_est_get_frame(void *p, int i, double *P, double *R_rowmajor, double *V, double *Ba, double *Bg) {
+    Estimator *e = as_est(p);
+    out3(e->Ps[i], P);
+    out_rowmajor(e->Rs[i], R_rowmajor);
+    out3(e->Vs[i], V);
+    out3(e->Bas[i], Ba);
+    out3(e->Bgs[i], Bg);
+}
+void vref_est_set_extrinsic(void *p, const double *ric_rowmajor, const double *tic, double td) {
+    Estimator *e = as_est(p);
+    e->ric[0] = mat3(ric_rowmajor);
+    e->tic[0] = vec3(tic);
+    e->f_manager.setRic(e->ric);
+    e->td = td;
+}
+void vref_est_get_extrinsic(void *p, double *ric_rowmajor, double *tic, double *td) {
+    Estimator *e = as_est(p);
+    out_rowmajor(e->ric[0], ric_rowmajor);
+    out3(e->tic[0], tic);
+    *td = e->td;
+}
+// para_* arrays as vector2double leaves them (pose rows [p q(xyzw)])
+void vref_est_get_para(void *p, double *pose_Kx7, double *sb_Kx9, double *ex7, double *td) {
+    Estimator *e = as_est(p);
+    e->vector2double();
+    std::memcpy(pose_Kx7, e->para_Pose, sizeof(double) * (WINDOW_SIZE + 1) * SIZE_POSE);
+    std::memcpy(sb_Kx9, e->para_SpeedBias, sizeof(double) * (WINDOW_SIZE + 1) * SIZE_SPEEDBIAS);
+    std::memcpy(ex7, e->para_Ex_Pose[0], sizeof(double) * SIZE_POSE);
+    *td = e->td;
+}
+void vref_est_set_preintegration(void *p, int j, void *pre) {   // takes ownership
+    Estimator *e = as_est(p);
+    if (e->pre_integrations[j]) delete e->pre_integrations[j];
+    e->pre_integrations[j] = as_pre(pre);
+}
+void *vref_est_get_preintegration(void *p, int j) { return as_est(p)->pre_integrations[j]; }
+
+// ---- features
+void vref_est_clear_features(void *p) { as_est(p)->f_manager.clearState(); }
+// one FeaturePerId: observations rows of 7 [x y u v vx vy cur_td] (the layout of the test windows), depth = estimated_depth
+void vref_est_add_feature(void *p, int feature_id, int start_frame, int nobs, const double *obs7, double estimated_depth) {
+    Estimator *e = as_est(p);
+    e->f_manager.feature.push_back(FeaturePerId(feature_id, start_frame));
+    FeaturePerId &f = e->f_manager.feature.back();
+    for (int k = 0; k < nobs; k++) {
+        const double *o = obs7 + 7 * k;
+        Eigen::Matrix<double, 7, 1> v;
+        v << o[0], o[1], 1.0, o[2], o[3], o[4], o[5];
+        f.feature_per_frame.push_back(FeaturePerFrame(v, o[6]));
+    }
+    f.estimated_depth = estimated_depth;
+}
+int vref_est_num_features(void *p) { return static_cast<int>(as_est(p)->f_manager.feature.size()); }
+// all FeaturePerId in list order
+int vref_est_get_features(void *p, int cap, int *ids, int *start, int *nobs, double *depth, int *solve_flag) {
+    int k = 0;
+    for (auto &f : as_est(p)->f_manager.feature) {
+        if (k >= cap) break;
+        ids[k] = f.feature_id, start[k] = f.start_frame, nobs[k] = static_cast<int>(f.feature_per_frame.size());
+        depth[k] = f.estimated_depth, solve_flag[k] = f.solve_flag;
+        k++;
+    }
+    return k;
+}
+int vref_est_feature_count(void *p) { return as_est(p)->f_manager.getFeatureCount(); }
+void vref_est_get_depth_vector(void *p, double *inv_depth) {
+    VectorXd d = as_est(p)->f_manager.getDepthVector();
+    for (Eigen::Index i = 0; i < d.size(); i++) inv_depth[i] = d(i);
+}
+void vref_est_triangulate(void *p) {
+    Estimator *e = as_est(p);
+    e->f_manager.triangulate(e->Ps, e->tic, e->ric);
+}
+void vref_est_remove_failures(void *p) { as_est(p)->f_manager.removeFailures(); }
+
+// ---- prior (MarginalizationInfo)
+// kinds: 0 pose, 1 speed-bias, 2 extrinsic, 3 td (the VG_BLK_* numbering of include/vinsgpu.h)
+static double *block_addr(Estimator *e, int kind, int idx) {
+    switch (kind) {
+    case 0: return e->para_Pose[idx];
+    case 1: return e->para_SpeedBias[idx];
+    case 2: return e->para_Ex_Pose[idx];
+    case 3: return e->para_Td[0];
+    }
+    return nullptr;
+}
+static bool block_of(Estimator *e, double *addr, int *kind, int *idx) {
+    for (int i = 0; i <= WINDOW_SIZE; i++) {
+        if (addr == e->para_Pose[i]) { *kind = 0, *idx = i; return true; }
+        if (addr == e->para_SpeedBias[i]) { *kind = 1, *idx = i; return true; }
+    }
+    if (addr == e->para_Ex_Pose[0]) { *kind = 2, *idx = 0; return true; }
+    if (addr == e->para_Td[0]) { *kind = 3, *idx = 0; return true; }
+    return false;
+}
+// install `last_marginalization_info` from plain arrays: residual n, blocks (kind, idx), J0 n x ncols row-major over the blocks'
+// tangent columns in the given order, r0, x0 concatenated global-size values
+void vref_est_set_prior(void *p, int n, int nblocks, const int *kinds, const int *idxs, const double *J0, const double *r0, const double *x0) {
+    Estimator *e = as_est(p);
+    if (e->last_marginalization_info) delete e->last_marginalization_info;
+    e->last_marginalization_info = nullptr;
+    e->last_marginalization_parameter_blocks.clear();
+    if (n <= 0) return;
+    MarginalizationInfo *mi = new MarginalizationInfo();
+    int ncols = 0;
+    const double *xp = x0;
+    for (int b = 0; b < nblocks; b++) {
+        const int gs = (kinds[b] == 0 || kinds[b] == 2) ? 7 : (kinds[b] == 1 ? 9 : 1);
+        double *data = new double[gs];
+        std::memcpy(data, xp, sizeof(double) * gs);
+        xp += gs;
+        mi->parameter_block_data[-(b + 1)] = data;   // owned (and freed) by ~MarginalizationInfo; the key is never looked up
+        mi->keep_block_size.push_back(gs);
+        mi->keep_block_idx.push_back(ncols);
+        mi->keep_block_data.push_back(data);
+        e->last_marginalization_parameter_blocks.push_back(block_addr(e, kinds[b], idxs[b]));
+        ncols += mi->localSize(gs);
+    }
+    mi->m = 0;
+    mi->n = n;
+    mi->linearized_jacobians.resize(n, ncols);
+    mi->linearized_residuals.resize(n);
+    for (int i = 0; i < n; i++) {
+        mi->linearized_residuals(i) = r0[i];
+        for (int j = 0; j < ncols; j++) mi->linearized_jacobians(i, j) = J0[i * ncols + j];
+    }
+    e->last_marginalization_info = mi;
+}
+// sizes first (J0 may be NULL), then the arrays; returns the number of residuals (0 = no prior)
+int vref_est_get_prior(void *p, int *nblocks, int *kinds, int *idxs, int *ncols_out, double *J0, double *r0, double *x0) {
+    Estimator *e = as_est(p);
+    MarginalizationInfo *mi = e->last_marginalization_info;
+    *nblocks = 0;
+    *ncols_out = 0;
+    if (!mi) return 0;
+    const int nb = static_cast<int>(e->last_marginalization_parameter_blocks.size());
+    *nblocks = nb;
+    const int ncols = static_cast<int>(mi->linearized_jacobians.cols());
+    *ncols_out = ncols;
+    int col = 0;
+    double *xp = x0;
+    for (int b = 0; b < nb; b++) {
+        int kind = -1, idx = -1;
+        if (!block_of(e, e->last_marginalization_parameter_blocks[b], &kind, &idx)) {
+            std::fprintf(stderr, "oracle/_ref: prior block %d is not a window parameter\n", b);
+            std::abort();
+        }
+        kinds[b] = kind, idxs[b] = idx;
+        const int gs = mi->keep_block_size[b], ls = mi->localSize(gs), src = mi->keep_block_idx[b] - mi->m;
+        if (J0)
+            for (int i = 0; i < mi->n; i++)
+                for (int c = 0; c < ls; c++) J0[i * ncols + col + c] = mi->linearized_jacobians(i, src + c);
+        if (x0) {
+            std::memcpy(xp, mi->keep_block_data[b], sizeof(double) * gs);
+            xp += gs;
+        }
+        col += ls;
+    }
+    if (r0)
+        for (int i = 0; i < mi->n; i++) r0[i] = mi->linearized_residuals(i);
+    return mi->n;
+}
+
+// ---- relocalisation inputs as setReloFrame() leaves them (estimator.cpp:1128-1147)
+void vref_est_set_relo(void *p, int local_index, const double *relo_pose7, int nmatch, const double *match_xyid, const double *prev_relo_t,
+                       const double *prev_relo_r_rowmajor) {
+    Estimator *e = as_est(p);
+    e->relocalization_info = true;
+    e->relo_frame_local_index = local_index;
+    for (int k = 0; k < 7; k++) e->relo_Pose[k] = relo_pose7[k];
+    e->match_points.clear();
+    for (int k = 0; k < nmatch; k++) e->match_points.push_back(Vector3d(match_xyid[3 * k], match_xyid[3 * k + 1], match_xyid[3 * k + 2]));
+    e->prev_relo_t = vec3(prev_relo_t);
+    e->prev_relo_r = mat3(prev_relo_r_rowmajor);
+}
+void vref_est_get_relo(void *p, double *relo_pose7, double *relative_t, double *relative_q_xyzw, double *relative_yaw, double *drift_r_rowmajor, double *drift_t) {
+    Estimator *e = as_est(p);
+    for (int k = 0; k < 7; k++) relo_pose7[k] = e->relo_Pose[k];
+    out3(e->relo_relative_t, relative_t);
+    relative_q_xyzw[0] = e->relo_relative_q.x(), relative_q_xyzw[1] = e->relo_relative_q.y(), relative_q_xyzw[2] = e->relo_relative_q.z(),
+    relative_q_xyzw[3] = e->relo_relative_q.w();
+    *relative_yaw = e->relo_relative_yaw;
+    out_rowmajor(e->drift_correct_r, drift_r_rowmajor);
+    out3(e->drift_correct_t, drift_t);
+}
+
+// ---- the linearised factors MarginalizationInfo::preMarginalize() evaluated for the CURRENT last_marginalization_info
+// (marginalization_factor.cpp:110-131, loss-corrected by ResidualBlockInfo::Evaluate :3-69), serialised as doubles:
+//   [nfactors, m, n, then per factor: nres, nblocks, nblocks x (kind, idx, local_size, dropped), residuals, nblocks x J(nres x local_size)]
+// kinds as above plus 4 = landmark (idx = row of para_Feature); addresses are the PRE-shift ones.  Returns the number of
+// doubles needed (call with cap = 0 first).
+int vref_est_marg_factors(void *p, int cap, double *out) {
+    Estimator *e = as_est(p);
+    MarginalizationInfo *mi = e->last_marginalization_info;
+    if (!mi) return 0;
+    std::vector<double> buf;
+    buf.push_back(static_cast<double>(mi->factors.size()));
+    buf.push_back(mi->m);
+    buf.push_back(mi->n);
+    for (ResidualBlockInfo *f : mi->factors) {
+        const int nres = static_cast<int>(f->residuals.size()), nb = static_cast<int>(f->parameter_blocks.size());
+        buf.push_back(nres);
+        buf.push_back(nb);
+        for (int b = 0; b < nb; b++) {
+            double *addr = f->parameter_blocks[b];
+            int kind = -1, idx = -1;
+            if (!block_of(e, addr, &kind, &idx)) {
+                for (int l = 0; l < NUM_OF_F; l++)
+                    if (addr == e->para_Feature[l]) kind = 4, idx = l;
+            }
+            if (kind < 0) {
+                std::fprintf(stderr, "oracle/_ref: marginalization factor block is not a window parameter\n");
+                std::abort();
+            }
+            bool dropped = false;
+            for (int d : f->drop_set) dropped |= (d == b);
+            buf.push_back(kind);
+            buf.push_back(idx);
+            buf.push_back(f->localSize(static_cast<int>(f->jacobians[b].cols())));
+            buf.push_back(dropped ? 1.0 : 0.0);
+        }
+        for (int k = 0; k < nres; k++) buf.push_back(f->residuals(k));
+        for (int b = 0; b < nb; b++) {
+            const int ls = f->localSize(static_cast<int>(f->jacobians[b].cols()));
+            for (int k = 0; k < nres; k++)
+                for (int c = 0; c < ls; c++) buf.push_back(f->jacobians[b](k, c));
+        }
+    }
+    if (cap >= static_cast<int>(buf.size())) std::memcpy(out, buf.data(), sizeof(double) * buf.size());
+    return static_cast<int>(buf.size());
+}
+
+// an all_image_frame entry for a window frame (slideWindow() looks Headers[0].stamp up there, estimator.cpp:1047-1061)
+void vref_est_add_image_frame(void *p, double stamp) {
+    Estimator *e = as_est(p);
+    map<int, vector<pair<int, Eigen::Matrix<double, 7, 1>>>> none;
+    const double key = ros::Time().fromSec(stamp).toSec();   // the key processImage() uses: header.stamp.toSec()
+    ImageFrame f(none, key);
+    f.pre_integration = nullptr;
+    e->all_image_frame.insert(make_pair(key, f));
+}
+
+// ---- the hot-path entry points themselves
+void vref_est_optimization(void *p) { as_est(p)->optimization(); }
+void vref_est_solve_odometry(void *p) { as_est(p)->solveOdometry(); }
+void vref_est_slide_window(void *p) { as_est(p)->slideWindow(); }
+int vref_est_failure_detection(void *p) { return as_est(p)->failureDetection() ? 1 : 0; }
+
+// ---- trace of the last ceres::Solve (restated minimiser): rows of 10
+// [iteration, valid, successful, cost, candidate_cost, model_cost_change, trust_region_radius, step_norm, mu, exit_reason]
+int vref_last_solve_trace(int cap, double *rows10, double *initial_cost, double *final_cost, int *termination) {
+    const ceres::Solver::Summary &s = ceres::vins_ref_last_summary;
+    *initial_cost = s.initial_cost;
+    *final_cost = s.final_cost;
+    *termination = static_cast<int>(s.termination_type);
+    int k = 0;
+    for (auto &it : s.iterations) {
+        if (k >= cap) break;
+        double *r = rows10 + 10 * k;
+        r[0] = it.iteration, r[1] = it.step_is_valid, r[2] = it.step_is_successful, r[3] = it.cost, r[4] = it.candidate_cost;
+        r[5] = it.model_cost_change, r[6] = it.trust_region_radius, r[7] = it.step_norm, r[8] = it.mu, r[9] = it.exit_reason;
+        k++;
+    }
+    return static_cast<int>(s.iterations.size());
+}
+
+}  // extern "C"

@@ -1,0 +1,547 @@
+"""Parity against the REFERENCE ITSELF: oracle/_ref/libvins_ref.so is vins_estimator/src/{estimator,feature_manager}.cpp,
+factor/*.{h,cpp} and utility/utility.{h,cpp} compiled unchanged from /root/reference (oracle/Makefile `ref`; header stand-ins
+for the absent Eigen / Ceres / ROS / OpenCV in oracle/ref_stubs).  This file holds BOTH restatements (oracle/ba_numpy.py,
+oracle/ba_cpu.cpp) and the HIP path to it:
+
+  row of SURVEY 8(a)                 reference code exercised                                  here
+  B1  PoseLocalParameterization      pose_local_parameterization.cpp:3-27                      test_pose_plus
+  B2  IMUFactor::Evaluate            imu_factor.h:19-179, integration_base.h:160-186           test_imu_factor / *_on_device
+  B3/B4 Projection(Td)Factor         projection_factor.cpp:21-121, projection_td_factor.cpp    test_projection_factors / *_on_device
+  B5  MarginalizationFactor          marginalization_factor.cpp:333-381                        through optimization with a prior
+  B0/B6-B8 Estimator::optimization   estimator.cpp:670-823 (problem build), :530-619 (gauge)   test_optimization_* (minimiser: restated Ceres)
+  M1-M5 marginalization              estimator.cpp:825-1000, marginalization_factor.cpp:3-319  test_marginalization_*
+  8(f)-2 IntegrationBase             integration_base.h:30-158                                 test_preintegration / *_on_device
+  8(f)-4 triangulate, slideWindow    feature_manager.cpp:202-313, estimator.cpp:1005-1126      test_triangulate, test_replay_*
+
+What stays restated even here: the third-party trust-region minimiser (oracle/ref_stubs/ceres/solver_stub.cc — generic, it
+only sees the ceres::Problem the reference builds) and the dense linear algebra inside the stand-in Eigen.  Tolerances are
+those of two double-precision implementations of the same formulas: 1e-12..1e-9; the marginalization prior is held to an
+extended-precision Schur complement of the REFERENCE's own evaluated factors (its double eigen-decomposition reproduces
+itself only to ~1e-7, oracle/ASSUMPTIONS.md)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import ba_numpy as B
+from oracle import ref as R
+from vins_mono_amd import ba, synth
+
+import ba_fixtures as FX
+import replay_util as RU
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref/libvins_ref.so is not built and /root/reference is absent")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NOISE = (0.08, 0.004, 4e-5, 2e-6)        # acc_n, gyr_n, acc_w, gyr_w (euroc_config.yaml:58-62)
+
+
+# ------------------------------------------------------------------------------------------ the library is the reference
+def test_ref_library_holds_the_reference_translation_units():
+    """The recipe compiles the reference sources where they lie (never a copy), and the library exports their symbols."""
+    mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+    assert "REF ?= /root/reference/vins_estimator/src" in mk
+    for src in ("estimator.cpp", "feature_manager.cpp", "utility/utility.cpp", "factor/projection_factor.cpp", "factor/projection_td_factor.cpp",
+                "factor/marginalization_factor.cpp", "factor/pose_local_parameterization.cpp"):
+        assert src in mk
+        if os.path.isdir("/root/reference"):
+            assert os.path.exists(os.path.join("/root/reference/vins_estimator/src", src))
+    assert not any(f.endswith((".cpp", ".h")) and "estimator" in f for f in os.listdir(os.path.join(ROOT, "oracle", "ref_stubs")))   # no copies
+    R.lib()
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "oracle", "_ref", "libvins_ref.so")], capture_output=True, text=True).stdout
+    for mangled in ("_ZN9Estimator12optimizationEv", "_ZN9Estimator11slideWindowEv", "_ZN9Estimator13double2vectorEv", "_ZN19MarginalizationInfo11marginalizeEv",
+                    "_ZN14FeatureManager11triangulateEPN5Eigen6MatrixIdLi3ELi1ELi0EEES3_PNS1_IdLi3ELi3ELi0EEE", "_ZNK16ProjectionFactor8EvaluateEPKPKdPdPS4_",
+                    "_ZNK25PoseLocalParameterization4PlusEPKdS1_Pd"):
+        assert mangled in syms, mangled
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def _intervals(rng, spec=((1, 0.005), (20, 0.005), (120, 0.1), (7, 0.0049))):
+    ivs, biases = [], []
+    for n, dt in spec:
+        iv = [(0.0, rng.normal(0, 1, 3) + [0, 0, 9.8], rng.normal(0, 0.3, 3))]
+        for _ in range(n):
+            iv.append((dt, rng.normal(0, 1, 3) + [0, 0, 9.8], rng.normal(0, 0.3, 3)))
+        ivs.append(iv)
+        biases.append((rng.normal(0, 0.05, 3), rng.normal(0, 0.02, 3)))
+    return ivs, biases
+
+
+def _close(a, b, rel):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() <= rel * max(1e-300, np.abs(b).max())
+
+
+def _ref_factor_tables(prob):
+    """The tables of tests/test_ba_gpu.py::_oracle_factor_tables, filled by the REFERENCE's Evaluate() methods."""
+    R.configure_for(prob)
+    st = B.state_of(prob)
+    lay = B.Layout(prob)
+    facs = B.factor_list(prob)
+    pr, pJ = np.zeros((len(facs), 2)), np.zeros((len(facs), 2, 20))
+
+    def pose(i):
+        return st['pose'][i] if i < lay.K else st['relo_pose']
+    for f, (l, fi, fj, oi, oj) in enumerate(facs):
+        if lay.est_td:
+            r, J = R.projection_td_factor(pose(fi), pose(fj), st['ex'], st['inv_depth'][l], st['td'], oi, oj)
+            pJ[f, :, 19] = J[4][:, 0]
+        else:
+            r, J = R.projection_factor(pose(fi), pose(fj), st['ex'], st['inv_depth'][l], [oi[0], oi[1], 1.0], [oj[0], oj[1], 1.0])
+        pr[f] = r
+        pJ[f, :, 0:6], pJ[f, :, 6:12], pJ[f, :, 12:18], pJ[f, :, 18] = J[0][:, :6], J[1][:, :6], J[2][:, :6], J[3][:, 0]
+        assert not J[0][:, 6].any() and not J[1][:, 6].any() and not J[2][:, 6].any()      # the w column of the global Jacobians
+    K = lay.K
+    ir, iJ = np.zeros((K - 1, 15)), np.zeros((K - 1, 15, 30))
+    for k in range(K - 1):
+        if prob['imu'][k] is None:
+            continue
+        r, J = R.imu_factor(prob['imu'][k], st['pose'][k], st['sb'][k], st['pose'][k + 1], st['sb'][k + 1])
+        ir[k] = r
+        iJ[k] = np.hstack([J[0][:, :6], J[1], J[2][:, :6], J[3]])
+    return pr, pJ, ir, iJ
+
+
+def _window_with_prior(seed, L=40, **kw):
+    seq = synth.SyntheticSequence(seed, L=L, **kw)
+    prob = seq.window(0)
+    if kw.get('estimate_td'):
+        prob['tr'] = 0.02
+    st, _, pr = R.optimization(prob, 0)
+    nxt = seq.next_window(st, pr, 1)
+    nxt['tr'] = prob['tr']
+    return seq, prob, nxt
+
+
+def _rel_state_err(a, b):
+    return max(np.abs(a['pose'][:, :3] - b['pose'][:, :3]).max() / max(1.0, np.abs(b['pose'][:, :3]).max()),
+               np.abs(a['pose'][:, 3:] - b['pose'][:, 3:]).max(),
+               np.abs(a['sb'] - b['sb']).max() / max(1.0, np.abs(b['sb']).max()),
+               np.abs(a['ex'] - b['ex']).max(), abs(a['td'] - b['td']))
+
+
+def _check_prior_against_reference(got, est_ref, tol=1e-7, dx=1e-12):
+    """`got` (a prior dict of any implementation) against the Schur complement of the REFERENCE's evaluated factors, formed in
+    extended precision; it must reproduce (A, b) at least as well as the reference's own eigen-based result does (x3)."""
+    facs, m_ref, n_ref = est_ref.marg_factors()
+    A_full, b_full, b_abs, m, _, keep = R.assemble_marginalization(facs)
+    assert m == m_ref and A_full.shape[0] - m == n_ref
+    A, b = B.schur_extended(A_full, b_full, m)
+    ref_prior = est_ref.get_prior()
+    blocks_r, H_r, g_r, x0_r = R.canonical_prior(ref_prior)
+    blocks_g, H_g, g_g, x0_g = R.canonical_prior(got)
+    assert blocks_g == blocks_r and got['n'] == ref_prior['n']
+    amax, rows = np.abs(A).max(), np.abs(A).sum(axis=1)
+    assert np.abs(H_g - A).max() < max(3 * np.abs(H_r - A).max(), tol * amax) + dx * amax
+    g_scale = (np.abs(ref_prior['J0']).T @ np.abs(ref_prior['r0'])).max()
+    assert np.abs(g_g - b).max() < 3 * np.abs(g_r - b).max() + tol * g_scale + (dx * rows).max()
+    for a, c in zip(x0_g, x0_r):
+        assert np.allclose(a, c, atol=max(1e-9, dx))
+    return A_full, b_full, b_abs, m
+
+
+def _ref_optimization_keep(prob, flag):
+    """R.optimization, but the Estimator stays alive (its marginalization factors are read afterwards)."""
+    R.configure_for(prob)
+    e = R.Estimator()
+    e.load_window(prob)
+    e.optimization(flag)
+    return e, e.state(len(prob['inv_depth'])), e.solve_trace()
+
+
+# ------------------------------------------------------------------------------------------ B1, 8(f)-2, B2-B4: the restatements
+def test_pose_plus_and_euler_helpers():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        q = rng.normal(size=4)
+        x = np.concatenate([rng.normal(size=3), q / np.linalg.norm(q)])
+        d = rng.normal(scale=0.2, size=6)
+        assert np.allclose(R.pose_plus(x, d), B.pose_plus(x, d), rtol=0, atol=1e-15)
+        Rm = B.q2R(x[3:])
+        assert np.allclose(R.R2ypr(Rm), B.R2ypr(Rm), atol=1e-12)
+        ypr = rng.uniform(-170, 170, 3)
+        assert np.allclose(R.ypr2R(ypr), B.ypr2R(ypr), atol=1e-15)
+        assert np.allclose(R.quat_from_R(Rm), B.R2q(Rm), atol=1e-15)
+    J = R.pose_plus_jacobian(x)
+    assert np.array_equal(J[:6], np.eye(6)) and not J[6].any()
+
+
+def test_preintegration_restatements_equal_the_reference():
+    R.configure(*[NOISE[0], NOISE[2], NOISE[1], NOISE[3]])
+    ivs, biases = _intervals(np.random.default_rng(77))
+    for iv, (ba_, bg_) in zip(ivs, biases):
+        ref = R.Preintegration(iv[0][1], iv[0][2], ba_, bg_)
+        mine = B.Preintegration(iv[0][1], iv[0][2], ba_, bg_, *NOISE)
+        for dt, a, w in iv[1:]:
+            ref.push_back(dt, a, w)
+            mine.push_back(dt, a, w)
+        r, m1, m2 = ref.as_dict(), mine.as_dict(), synth.preintegrate(iv, ba_, bg_, *NOISE)
+        assert r['sum_dt'] == m1['sum_dt']
+        for key in ('delta_p', 'delta_q', 'delta_v', 'jacobian', 'covariance'):
+            assert _close(m1[key], r[key], 1e-13), key
+            assert _close(m2[key], r[key], 1e-13), key
+        ref.repropagate(ba_ + 0.01, bg_ - 0.002)                     # IntegrationBase::repropagate (:38-52) = a fresh integration
+        again = synth.preintegrate(iv, ba_ + 0.01, bg_ - 0.002, *NOISE)
+        for key in ('delta_p', 'delta_q', 'delta_v', 'jacobian', 'covariance'):
+            assert _close(again[key], ref.as_dict()[key], 1e-13), key
+
+
+@pytest.mark.parametrize("ex,td", [(0, 0), (1, 1)])
+def test_factor_restatements_equal_the_reference(ex, td):
+    _, _, prob = _window_with_prior(21 + ex, estimate_extrinsic=ex, estimate_td=td)
+    pr, pJ, ir, iJ = _ref_factor_tables(prob)
+    st = B.state_of(prob)
+    for f, (l, fi, fj, oi, oj) in enumerate(B.factor_list(prob)):
+        if td:
+            r, J = B.projection_td_factor(st['pose'][fi], st['pose'][fj], st['ex'], st['inv_depth'][l], st['td'], oi, oj, prob['focal'], prob['tr'], prob['row'])
+            assert np.allclose(J[4][:, 0], pJ[f, :, 19], rtol=1e-11, atol=1e-11)
+        else:
+            r, J = B.projection_factor(st['pose'][fi], st['pose'][fj], st['ex'], st['inv_depth'][l], np.array([oi[0], oi[1], 1.0]), np.array([oj[0], oj[1], 1.0]))
+        assert np.allclose(r, pr[f], rtol=1e-11, atol=1e-11)
+        assert np.allclose(np.hstack([J[0], J[1], J[2], J[3]]), pJ[f, :, :19], rtol=1e-11, atol=1e-10)
+    for k in range(prob['pose'].shape[0] - 1):
+        r, J = B.imu_factor(prob['imu'][k], st['pose'][k], st['sb'][k], st['pose'][k + 1], st['sb'][k + 1], prob['g_norm'])
+        W = np.abs(B.imu_sqrt_info(prob['imu'][k]['covariance'])).sum(axis=1)
+        assert np.abs((r - ir[k]) / W).max() < 1e-12
+        assert np.abs((np.hstack(J) - iJ[k]) / W[:, None]).max() < 1e-12
+
+
+# ------------------------------------------------------------------------------------------ B0, B5-B8: Estimator::optimization
+def _compare_traces(ref_sm, sm, rtol=1e-7):
+    """Reference run (restated minimiser inside the stand-in Ceres) vs ba_numpy.solve: same decisions, same numbers."""
+    assert ref_sm['termination'] == sm['termination'] and ref_sm['num_iterations'] == sm['num_iterations']
+    assert np.isclose(ref_sm['initial_cost'], sm['initial_cost'], rtol=1e-12)
+    for a, b in zip(ref_sm['iterations'], sm['iterations']):
+        assert a['valid'] == bool(b.get('valid')) and a['accepted'] == bool(b.get('accepted'))
+        assert a['exit'] == b.get('exit')
+        if a['valid']:
+            assert np.isclose(a['cost'], b['cost'], rtol=rtol) and np.isclose(a['cost_cand'], b['cost_cand'], rtol=rtol, atol=1e-9)
+            assert np.isclose(a['radius'], b['radius'], rtol=10 * rtol) and np.isclose(a['step_norm'], b['step_norm'], rtol=10 * rtol)
+    assert np.isclose(ref_sm['final_cost'], sm['final_cost'], rtol=rtol)
+
+
+@pytest.mark.parametrize("name", sorted(FX.BRANCH_FIXTURES))
+def test_optimization_branch_fixtures(name):
+    """Every trust-region branch fixture through the reference's problem construction: the problem the restatements build by
+    hand (factor list, parameter blocks, constant extrinsic, IMU factors skipped above 10 s) is the one estimator.cpp:670-801
+    builds; gauge fix = Estimator::double2vector."""
+    from oracle import ba_cpu
+    build, need = FX.BRANCH_FIXTURES[name]
+    prob = build()
+    st_r, sm_r, _ = R.optimization(prob, 1)                     # MARGIN_SECOND_NEW without a prior: no marginalization work
+    x, sm = B.solve(prob)
+    st_n = B.double2vector(prob, x)
+    assert need <= FX.trace_features(sm)
+    _compare_traces(sm_r, sm, rtol=FX.COST_RTOL.get(name, 1e-6))
+    tol = 1e-4 if name in ('low_parallax', 'very_large_perturbation') else 1e-6
+    assert _rel_state_err(st_n, st_r) < tol
+    assert np.allclose(st_n['inv_depth'], st_r['inv_depth'], rtol=10 * tol, atol=tol)
+    st_c, sm_c, _ = ba_cpu.optimize(prob, ba.VG_MARGIN_NONE)
+    assert sm_c['num_iterations'] == sm_r['num_iterations'] and _rel_state_err(st_c, st_r) < tol
+
+
+@pytest.mark.parametrize("ex,td", [(0, 0), (1, 0), (1, 1)])
+def test_optimization_with_prior_extrinsic_td(ex, td):
+    from oracle import ba_cpu
+    _, _, prob = _window_with_prior(4 + ex + td, L=60, estimate_extrinsic=ex, estimate_td=td)
+    st_r, sm_r, _ = R.optimization(prob, 1)
+    x, sm = B.solve(prob)
+    st_n = B.double2vector(prob, x)
+    _compare_traces(sm_r, sm)
+    assert _rel_state_err(st_n, st_r) < 1e-7 and np.allclose(st_n['inv_depth'], st_r['inv_depth'], rtol=1e-6, atol=1e-9)
+    st_c, _, _ = ba_cpu.optimize(prob, ba.VG_MARGIN_NONE)
+    assert _rel_state_err(st_c, st_r) < 1e-7
+
+
+def _pitch_window(pitch_deg, seed=90):
+    """A window whose frame 0 is pitched to within 1 degree of +-90: double2vector takes the `euler singular point` branch
+    (estimator.cpp:548-555).  The whole window (poses, velocities, gravity-consistent IMU terms stay valid because the rotation
+    is about the world's own y axis composed on the left of every pose: a rigid motion of the gauge, then gravity is no longer
+    along z for the IMU factors — they are dropped, the solve is vision + prior-free, which is all the gauge fix needs)."""
+    seq = synth.SyntheticSequence(seed, L=40)
+    prob = seq.window(0)
+    R0 = B.q2R(prob['pose'][0][3:])
+    ypr = B.R2ypr(R0)
+    target = B.ypr2R(np.array([ypr[0], pitch_deg, ypr[2]]))
+    T = target @ R0.T
+    p0 = prob['pose'][0][:3].copy()
+    for i in range(prob['pose'].shape[0]):
+        Ri = T @ B.q2R(prob['pose'][i][3:])
+        prob['pose'][i][:3] = T @ (prob['pose'][i][:3] - p0) + p0
+        prob['pose'][i][3:] = B.R2q(Ri)
+        prob['sb'][i][:3] = T @ prob['sb'][i][:3]
+    prob['imu'] = [None] * (prob['pose'].shape[0] - 1)
+    prob['max_iters'] = 6
+    return prob
+
+
+@pytest.mark.parametrize("pitch", [89.6, -89.5, 88.0])
+def test_gauge_fix_near_the_euler_singularity(pitch):
+    prob = _pitch_window(pitch)
+    assert (abs(abs(B.R2ypr(B.q2R(prob['pose'][0][3:]))[1]) - 90) < 1.0) == (abs(pitch) > 89)
+    st_r, sm_r, _ = R.optimization(prob, 1)
+    x, sm = B.solve(prob)
+    st_n = B.double2vector(prob, x)
+    _compare_traces(sm_r, sm)
+    assert _rel_state_err(st_n, st_r) < 1e-8
+    if abs(pitch) > 89:                                        # singular branch: frame 0 keeps its full attitude, not only the yaw
+        assert np.allclose(B.q2R(st_r['pose'][0][3:]), B.q2R(prob['pose'][0][3:]), atol=1e-9)
+    assert np.allclose(st_r['pose'][0][:3], prob['pose'][0][:3], atol=1e-12)
+
+
+def test_relocalisation_through_the_reference():
+    from test_ba_gpu import relocalisation_problem
+    prob = relocalisation_problem(loop_frame=3)
+    prob['relo'].update(local_index=3, prev_t=np.array([0.3, -0.2, 0.1]), prev_r=B.ypr2R(np.array([12.0, 0, 0])))
+    st_r, sm_r, _ = R.optimization(prob, 1)
+    x, sm = B.solve(prob)
+    st_n = B.double2vector(prob, x)
+    _compare_traces(sm_r, sm)
+    assert _rel_state_err(st_n, st_r) < 1e-8
+    # relo_Pose itself is left un-fixed by the reference; its gauge-fixed form enters the by-products (estimator.cpp:596-616)
+    y_diff = B.R2ypr(B.q2R(prob['pose'][0][3:]))[0] - B.R2ypr(B.q2R(x['pose'][0][3:]))[0]
+    rot_diff = B.ypr2R(np.array([y_diff, 0, 0]))
+    relo_r = rot_diff @ B.q2R(B.qnormalized(x['relo_pose'][3:]))
+    relo_t = rot_diff @ (x['relo_pose'][:3] - x['pose'][0][:3]) + prob['pose'][0][:3]
+    assert np.allclose(st_r['relo_pose'], x['relo_pose'], atol=1e-8)
+    R3, P3 = B.q2R(st_r['pose'][3][3:]), st_r['pose'][3][:3]
+    assert np.allclose(st_r['relo_relative_t'], relo_r.T @ (P3 - relo_t), atol=1e-8)
+    assert np.allclose(B.q2R(st_r['relo_relative_q']), relo_r.T @ R3, atol=1e-8)
+    dy = B.R2ypr(prob['relo']['prev_r'])[0] - B.R2ypr(relo_r)[0]
+    assert np.allclose(st_r['drift_correct_r'], B.ypr2R(np.array([dy, 0, 0])), atol=1e-9)
+    assert np.allclose(st_r['drift_correct_t'], prob['relo']['prev_t'] - st_r['drift_correct_r'] @ relo_t, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------ M1-M5
+@pytest.mark.parametrize("ex,td", [(0, 0), (1, 1)])
+def test_marginalization_old_restatements_vs_reference(ex, td):
+    """Both sides marginalise at the SAME state (max_iters = 0).  The restatement's assembled (A, b) must equal the sum of the
+    REFERENCE's evaluated, loss-corrected factors; its prior must reproduce their extended-precision Schur complement."""
+    from oracle import ba_cpu
+    seq = synth.SyntheticSequence(40 + ex, L=60, estimate_extrinsic=ex, estimate_td=td)
+    prob = seq.window(0)
+    if td:
+        prob['tr'] = 0.02
+    x, _ = B.solve(prob)
+    at = dict(prob)
+    at.update(pose=x['pose'], sb=x['sb'], ex=x['ex'], td=x['td'], inv_depth=x['inv_depth'], max_iters=0)
+    e, st_r, _ = _ref_optimization_keep(at, 0)
+    try:
+        st_n, _, pr_n = B.optimization(at, B.MARGIN_OLD)
+        assert _rel_state_err(st_n, st_r) < 1e-12
+        A_full, b_full, b_abs, m = _check_prior_against_reference(pr_n, e)
+        assert m == pr_n['m'] and _close(pr_n['A_full'], A_full, 1e-11)
+        # entries of b cancel at an optimum: scale = sum |J|^T |r|.  1e-8 of it: the two linearisation points differ by
+        # ~1e-11 m (q -> R -> q round trips of vector2double / double2vector), which a projection row (|J| ~ 3e2) turns into
+        # ~3e-9 of a residual of order one; measured 6e-9
+        assert np.all(np.abs(pr_n['b_full'] - b_full) <= 1e-8 * b_abs)
+        _, _, pr_c = ba_cpu.optimize(at, ba.VG_MARGIN_OLD)
+        _check_prior_against_reference(pr_c, e)
+    finally:
+        e.close()
+
+
+def test_marginalization_second_new_vs_reference():
+    _, _, prob2 = _window_with_prior(6, L=150)
+    K = prob2['pose'].shape[0]
+    assert (B.KIND_POSE, K - 2) in prob2['prior']['blocks']
+    prob2 = dict(prob2, max_iters=0)
+    e, st_r, _ = _ref_optimization_keep(prob2, 1)
+    try:
+        _, _, pr_n = B.optimization(prob2, B.MARGIN_SECOND_NEW)
+        _check_prior_against_reference(pr_n, e)
+        assert (B.KIND_POSE, K - 2) not in pr_n['blocks'] and pr_n['n'] == prob2['prior']['n'] - 6
+    finally:
+        e.close()
+
+
+def test_second_new_keeps_the_prior_when_the_pose_is_absent():
+    _, _, prob2 = _window_with_prior(7, L=8)
+    K = prob2['pose'].shape[0]
+    if (B.KIND_POSE, K - 2) in prob2['prior']['blocks']:
+        pytest.skip("prior touches pose K-2 for this seed")
+    _, _, pr_r = R.optimization(prob2, 1)
+    b0, H0, g0, _ = R.canonical_prior(prob2['prior'])
+    b1, H1, g1, _ = R.canonical_prior(pr_r)
+    assert b0 == b1 and np.array_equal(H0, H1) and np.array_equal(g0, g1)   # estimator.cpp:935-936: untouched
+
+
+# ------------------------------------------------------------------------------------------ 8(f)-4
+def _triangulate_by_reference(prob, Ps, Rs, tic, ric, depths_in):
+    R.configure_for(prob)
+    e = R.Estimator()
+    try:
+        import ctypes as C
+        e.load_window(prob)
+        H = C.c_void_p(e.h)
+        for i in range(len(Ps)):
+            e.set_frame(i, np.concatenate([Ps[i], B.R2q(Rs[i])]), prob['sb'][i])
+        e.L.vref_est_set_extrinsic(H, R._p(R._d(ric)), R._p(R._d(tic)), C.c_double(0.0))
+        e.L.vref_est_clear_features(H)
+        for l in range(len(prob['inv_depth'])):
+            o, n = int(prob['obs_off'][l]), int(prob['lm_nobs'][l])
+            e.L.vref_est_add_feature(H, l, int(prob['lm_start'][l]), n, R._p(R._d(prob['obs'][o:o + n])), C.c_double(depths_in[l]))
+        e.L.vref_est_triangulate(H)
+        return e.features()['depth'].copy()
+    finally:
+        e.close()
+
+
+def test_triangulate_restatements_vs_reference():
+    from oracle import ba_cpu
+    seq = synth.SyntheticSequence(81, L=150)
+    prob = seq.window(0)
+    c = seq.cfg
+    K = prob['pose'].shape[0]
+    Ps = prob['pose'][:, :3]
+    Rs = np.array([B.q2R(q) for q in prob['pose'][:, 3:]])
+    Rs = np.array([B.q2R(B.R2q(r)) for r in Rs])
+    start, nobs, off = prob['lm_start'], prob['lm_nobs'], prob['obs_off']
+    pts = np.concatenate([prob['obs'][:, :2], np.ones((len(prob['obs']), 1))], axis=1)
+    keep = np.full(len(start), -1.0)
+    keep[::7] = 3.25                                             # estimated_depth > 0: left alone (feature_manager.cpp:210-211)
+    ref = _triangulate_by_reference(prob, Ps, Rs, c['tic'], c['ric'], keep)
+    mine = B.triangulate(Ps, Rs.reshape(K, 9), c['tic'], c['ric'], start, nobs, off, pts)
+    cpp = ba_cpu.triangulate(Ps, Rs.reshape(K, 9), c['tic'], c['ric'], start, nobs, off, pts)
+    fresh = keep < 0
+    assert np.all(ref[~fresh] == 3.25)
+    assert np.allclose(mine[fresh], ref[fresh], rtol=1e-8, atol=1e-10) and np.allclose(cpp[fresh], ref[fresh], rtol=1e-7, atol=1e-9)
+
+
+def test_replay_chain_restatement_vs_reference():
+    """N chained windows: the reference's optimization() + slideWindow() (states, pre-integrations, depths through
+    removeBackShiftDepth, prior through addr_shift) against the NumPy mirror of the same plan.  The chain passes through the
+    marginalization's double eigen-decomposition, which reproduces itself only to ~1e-7 (ASSUMPTIONS.md): window 0 agrees to
+    1e-9, later windows to the north-star tolerance 1e-4."""
+    plan = RU.make_plan(5, 5, L=50)
+    ref, mine = R.replay(plan), RU.run_oracle(plan)
+    assert ref.shape == mine.shape == (5, 11) and np.array_equal(ref[:, 0], mine[:, 0])
+    assert np.abs(ref[0, 1:] - mine[0, 1:]).max() < 1e-9
+    assert np.abs(ref[:, 1:4] - mine[:, 1:4]).max() < 1e-4 * max(1.0, np.abs(ref[:, 1:4]).max())
+    assert np.abs(ref[:, 4:8] - mine[:, 4:8]).max() < 1e-4
+    assert np.abs(ref[:, 8:11] - mine[:, 8:11]).max() < 1e-4 * max(1.0, np.abs(ref[:, 8:11]).max())
+
+
+# ========================================================================================== the HIP path against the reference
+@pytest.mark.gpu
+def test_preintegration_on_device_vs_reference(handle):
+    R.configure(NOISE[0], NOISE[2], NOISE[1], NOISE[3])
+    ivs, biases = _intervals(np.random.default_rng(78))
+    got = handle.imu_preintegrate(ivs, biases, NOISE)
+    for iv, (ba_, bg_), g in zip(ivs, biases, got):
+        r = R.preintegrate(iv, ba_, bg_)
+        assert np.isclose(g['sum_dt'], r['sum_dt'], rtol=1e-14)
+        for key in ('delta_p', 'delta_q', 'delta_v', 'jacobian', 'covariance'):
+            assert _close(g[key], r[key], 1e-11), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ex,td", [(0, 0), (1, 1)])
+def test_factors_on_device_vs_reference(handle, ex, td):
+    _, _, prob = _window_with_prior(21 + ex, estimate_extrinsic=ex, estimate_td=td)
+    pr, pJ, ir, iJ = _ref_factor_tables(prob)
+    out = handle.ba_eval_factors(prob)
+    assert np.allclose(out['proj_r'], pr, rtol=1e-9, atol=1e-9)
+    assert np.allclose(out['proj_J'], pJ, rtol=1e-9, atol=1e-8)
+    for k in range(prob['pose'].shape[0] - 1):
+        W = np.abs(B.imu_sqrt_info(prob['imu'][k]['covariance'])).sum(axis=1)
+        assert np.allclose(out['imu_r'][k] / W, ir[k] / W, atol=1e-6), k               # U^-1 of cov = U U^T on the device (ASSUMPTIONS.md)
+        assert np.allclose(out['imu_J'][k] / W[:, None], iJ[k] / W[:, None], atol=1e-6), k
+        assert np.isclose(out['imu_r'][k] @ out['imu_r'][k], ir[k] @ ir[k], rtol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(FX.BRANCH_FIXTURES))
+def test_optimization_on_device_vs_reference(handle, name):
+    build, _ = FX.BRANCH_FIXTURES[name]
+    prob = build()
+    st_r, sm_r, _ = R.optimization(prob, 1)
+    st, sm, _ = handle.ba_optimize(prob)
+    assert sm['status'] == 0 and sm['num_iterations'] == sm_r['num_iterations']
+    flags = [(1 if it['valid'] else 0) | (2 if it['accepted'] else 0) for it in sm_r['iterations']]
+    assert list(sm['it_flags'][:len(flags)]) == flags
+    assert np.isclose(sm['final_cost'], sm_r['final_cost'], rtol=FX.COST_RTOL.get(name, 1e-6))
+    assert _rel_state_err(st, st_r) < 1e-4                           # BASELINE.json north_star
+    assert np.allclose(st['inv_depth'], st_r['inv_depth'], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pitch", [89.6, -89.5])
+def test_gauge_fix_on_device_near_the_euler_singularity(handle, pitch):
+    prob = _pitch_window(pitch)
+    st_r, sm_r, _ = R.optimization(prob, 1)
+    st, sm, _ = handle.ba_optimize(prob)
+    assert sm['status'] == 0 and sm['num_iterations'] == sm_r['num_iterations']
+    assert _rel_state_err(st, st_r) < 1e-6
+    assert np.allclose(B.q2R(st['pose'][0][3:]), B.q2R(prob['pose'][0][3:]), atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ex,td", [(0, 0), (1, 1)])
+def test_marginalization_on_device_vs_reference(handle, ex, td):
+    seq = synth.SyntheticSequence(40 + ex, L=60, estimate_extrinsic=ex, estimate_td=td)
+    prob = seq.window(0)
+    if td:
+        prob['tr'] = 0.02
+    x, _ = B.solve(prob)
+    at = dict(prob)
+    at.update(pose=x['pose'], sb=x['sb'], ex=x['ex'], td=x['td'], inv_depth=x['inv_depth'], max_iters=0)
+    e, st_r, _ = _ref_optimization_keep(at, 0)
+    try:
+        st_g, sm_g, pr_g = handle.ba_optimize(at, ba.VG_MARGIN_OLD)
+        assert sm_g['status'] == 0 and _rel_state_err(st_g, st_r) < 1e-12
+        _check_prior_against_reference(pr_g, e)
+    finally:
+        e.close()
+
+
+@pytest.mark.gpu
+def test_full_size_chain_on_device_vs_reference(handle):
+    """EuRoC-size windows (150 landmarks), two chained optimizations with MARGIN_OLD: the HIP chain against the reference chain."""
+    worst = 0.0
+    for s in range(4):
+        seq_g, seq_r = synth.SyntheticSequence(700 + s), synth.SyntheticSequence(700 + s)
+        pg, pr_ = seq_g.window(0), seq_r.window(0)
+        st_g, _, prior_g = handle.ba_optimize(pg, ba.VG_MARGIN_OLD)
+        st_r, _, prior_r = R.optimization(pr_, 0)
+        assert _rel_state_err(st_g, st_r) < 1e-6
+        p2g, p2r = seq_g.next_window(st_g, prior_g, 1), seq_r.next_window(st_r, prior_r, 1)
+        st2_g, sm2, _ = handle.ba_optimize(p2g, ba.VG_MARGIN_OLD)
+        st2_r, sm2_r, _ = R.optimization(p2r, 0)
+        assert sm2['num_iterations'] == sm2_r['num_iterations']
+        worst = max(worst, _rel_state_err(st2_g, st2_r))
+    assert worst < 1e-4, worst
+
+
+@pytest.mark.gpu
+def test_triangulate_on_device_vs_reference(handle):
+    seq = synth.SyntheticSequence(82, L=150)
+    prob = seq.window(0)
+    c = seq.cfg
+    K = prob['pose'].shape[0]
+    Ps = prob['pose'][:, :3]
+    Rs = np.array([B.q2R(q) for q in prob['pose'][:, 3:]])
+    Rs = np.array([B.q2R(B.R2q(r)) for r in Rs])
+    start, nobs, off = prob['lm_start'], prob['lm_nobs'], prob['obs_off']
+    pts = np.concatenate([prob['obs'][:, :2], np.ones((len(prob['obs']), 1))], axis=1)
+    ref = _triangulate_by_reference(prob, Ps, Rs, c['tic'], c['ric'], np.full(len(start), -1.0))
+    got = handle.triangulate(Ps, Rs.reshape(K, 9), c['tic'], c['ric'], start, nobs, off, pts)
+    assert np.allclose(got, ref, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_ba_replay_csv_vs_reference(tmp_path):
+    """The drop-in Estimator's N-window replay (vins_replay ba) against the same plan run by the reference's own
+    Estimator::optimization() + slideWindow()."""
+    plan = RU.make_plan(5, 5, L=50)
+    seqf, outf = tmp_path / "seq.bin", tmp_path / "vins_result.csv"
+    RU.write_sequence(plan, str(seqf))
+    r = subprocess.run([os.path.join(ROOT, "vins-mono_amd", "lib", "vins_replay"), "ba", str(seqf), str(outf)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[float(v) for v in line.rstrip(",\n").split(",")] for line in open(outf)])
+    ref = R.replay(plan)
+    assert got.shape == ref.shape == (5, 11) and np.array_equal(got[:, 0], np.round(ref[:, 0]))
+    assert np.abs(got[0, 1:] - ref[0, 1:]).max() < 2e-5                     # the CSV carries 5 decimals
+    assert np.abs(got[:, 1:4] - ref[:, 1:4]).max() < 1e-4 * max(1.0, np.abs(ref[:, 1:4]).max())
+    assert np.abs(got[:, 4:8] - ref[:, 4:8]).max() < 1e-4
+    assert np.abs(got[:, 8:11] - ref[:, 8:11]).max() < 1e-4 * max(1.0, np.abs(ref[:, 8:11]).max())
