@@ -1,7 +1,9 @@
 // ba_cpu.cpp — dependency-free single-thread C++17 restatement of Estimator::optimization()
 // (TEST INFRASTRUCTURE + the timed "cpu_baseline" of bench.py; never linked into the product).
 //
-// PARITY UNPINNED: Ceres / Eigen are not available in this environment (see oracle/ASSUMPTIONS.md); this
+// Pinning: everything restated from the reference's own sources here (factors, problem build, gauge fix, marginalization) is
+// held to oracle/_ref = those sources compiled unchanged (tests/test_ref_parity.py).  The minimiser stays UNPINNED: Ceres /
+// Eigen are not available in this environment (see oracle/ASSUMPTIONS.md); this
 // is the "restated single-thread Ceres-equivalent path (DENSE_SCHUR + DOGLEG)".  It is written the way the
 // reference executes on a CPU: one Evaluate() per residual block producing dense small Jacobians
 // (factor/projection_factor.cpp:21-121, projection_td_factor.cpp:34-141, imu_factor.h:19-179,

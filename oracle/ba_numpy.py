@@ -1,6 +1,7 @@
 """float64 NumPy oracle for the sliding-window BA hot path (TEST INFRASTRUCTURE — never shipped).
 
-PARITY UNPINNED (see oracle/__init__.py).  Restates, citing /root/reference:
+Pinned against the reference itself for everything in-tree (oracle/_ref, tests/test_ref_parity.py); the Ceres minimiser
+stays restated / unpinned (see oracle/__init__.py).  Restates, citing /root/reference:
 
 * quaternion / so(3) helpers ............ vins_estimator/src/utility/utility.h:16-68
 * PoseLocalParameterization::Plus ...... factor/pose_local_parameterization.cpp:3-18

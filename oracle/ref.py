@@ -443,3 +443,36 @@ def replay(plan, cfg=None):
     finally:
         e.close()
     return np.array(out)
+
+
+def factor_tables(prob):
+    """Residuals / Jacobians of every factor of a window at its initial state, by the REFERENCE's Evaluate() methods, in the
+    table layout of `Handle.ba_eval_factors`: proj_r (F,2), proj_J (F,2,20) [pose_i 6 | pose_j 6 | ex 6 | lambda | td],
+    imu_r (K-1,15), imu_J (K-1,15,30) [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9]."""
+    from oracle import ba_numpy as B          # window bookkeeping only (factor list order, state dict)
+    configure_for(prob)
+    st = B.state_of(prob)
+    lay = B.Layout(prob)
+    facs = B.factor_list(prob)
+    pr, pJ = np.zeros((len(facs), 2)), np.zeros((len(facs), 2, 20))
+
+    def pose(i):
+        return st['pose'][i] if i < lay.K else st['relo_pose']
+    for f, (l, fi, fj, oi, oj) in enumerate(facs):
+        if lay.est_td:
+            r, J = projection_td_factor(pose(fi), pose(fj), st['ex'], st['inv_depth'][l], st['td'], oi, oj)
+            pJ[f, :, 19] = J[4][:, 0]
+        else:
+            r, J = projection_factor(pose(fi), pose(fj), st['ex'], st['inv_depth'][l], [oi[0], oi[1], 1.0], [oj[0], oj[1], 1.0])
+        pr[f] = r
+        pJ[f, :, 0:6], pJ[f, :, 6:12], pJ[f, :, 12:18], pJ[f, :, 18] = J[0][:, :6], J[1][:, :6], J[2][:, :6], J[3][:, 0]
+        assert not J[0][:, 6].any() and not J[1][:, 6].any() and not J[2][:, 6].any()      # the w column of the global Jacobians
+    K = lay.K
+    ir, iJ = np.zeros((K - 1, 15)), np.zeros((K - 1, 15, 30))
+    for k in range(K - 1):
+        if prob['imu'][k] is None:
+            continue
+        r, J = imu_factor(prob['imu'][k], st['pose'][k], st['sb'][k], st['pose'][k + 1], st['sb'][k + 1])
+        ir[k] = r
+        iJ[k] = np.hstack([J[0][:, :6], J[1], J[2][:, :6], J[3]])
+    return pr, pJ, ir, iJ

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """Regenerate tests/golden/*.npz.
 
-PARITY UNPINNED: the reference has no golden vectors and cannot be built here, so these files hold
-the outputs of THIS repo's CPU oracles (oracle/ba_numpy.py, oracle/fe_cpu.cpp) on small seeded inputs.  They are
-regression anchors — they pin the oracles (and through the parity tests the HIP path) against silent drift, e.g. a
-NumPy/LAPACK or compiler change — not evidence of agreement with Ceres / OpenCV.
+golden_ba.npz holds outputs of THE REFERENCE: oracle/_ref/libvins_ref.so = the reference's own estimator / factor /
+marginalization sources compiled unchanged (oracle/Makefile `ref`, needs /root/reference, i.e. this container) — two chained
+Estimator::optimization() calls with MARGIN_OLD and the factor tables of the second window.  The minimiser inside is the
+restated Ceres of oracle/ref_stubs/ceres (third party, absent).  It travels to the GPU box as a fixture: there the reference
+library may be missing, the vectors are not.
+
+golden_fe.npz: PARITY UNPINNED — OpenCV is not in /root/reference and not in this image, so the FE file holds the outputs of
+this repo's restatement (oracle/fe_cpu.cpp): a regression anchor, not evidence of agreement with OpenCV.
 
 usage: python tests/golden/make_golden.py        (run from the repository root; CPU only)"""
 import os
@@ -18,7 +22,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 graft.load_package()
 from vins_mono_amd import synth  # noqa: E402
-from oracle import ba_numpy as B, fe_cpu as F  # noqa: E402
+from oracle import ba_numpy as B, fe_cpu as F, ref as R  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -26,12 +30,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def ba_case():
     seq = synth.SyntheticSequence(1234, L=24)
     prob = seq.window(0)
-    st, summ, pr = B.optimization(prob, B.MARGIN_OLD)
+    st, summ, pr = R.optimization(prob, 0)
+    _, H1, g1, _ = R.canonical_prior(pr)
     prob2 = seq.next_window(st, pr, 1)
-    st2, summ2, pr2 = B.optimization(prob2, B.MARGIN_OLD)
-    return dict(seed=1234, L=24,
+    proj_r, proj_J, imu_r, imu_J = R.factor_tables(prob2)
+    st2, summ2, pr2 = R.optimization(prob2, 0)
+    return dict(seed=1234, L=24, source="oracle/_ref (reference sources compiled unchanged)",
                 w1_pose=st['pose'], w1_sb=st['sb'], w1_inv_depth=st['inv_depth'], w1_final_cost=summ['final_cost'],
-                w1_iters=summ['num_iterations'], w1_H=pr['J0'].T @ pr['J0'], w1_g=pr['J0'].T @ pr['r0'],
+                w1_iters=summ['num_iterations'], w1_H=H1, w1_g=g1,
+                w1_prior_n=pr['n'], w1_prior_blocks=np.array(pr['blocks'], np.int32), w1_prior_J0=pr['J0'], w1_prior_r0=pr['r0'],
+                w1_prior_x0=np.concatenate(pr['x0']),
+                w2_proj_r=proj_r, w2_proj_J=proj_J, w2_imu_r=imu_r, w2_imu_J=imu_J,
                 w2_pose=st2['pose'], w2_sb=st2['sb'], w2_final_cost=summ2['final_cost'], w2_iters=summ2['num_iterations'])
 
 

@@ -72,34 +72,7 @@ def _close(a, b, rel):
     return np.abs(a - b).max() <= rel * max(1e-300, np.abs(b).max())
 
 
-def _ref_factor_tables(prob):
-    """The tables of tests/test_ba_gpu.py::_oracle_factor_tables, filled by the REFERENCE's Evaluate() methods."""
-    R.configure_for(prob)
-    st = B.state_of(prob)
-    lay = B.Layout(prob)
-    facs = B.factor_list(prob)
-    pr, pJ = np.zeros((len(facs), 2)), np.zeros((len(facs), 2, 20))
-
-    def pose(i):
-        return st['pose'][i] if i < lay.K else st['relo_pose']
-    for f, (l, fi, fj, oi, oj) in enumerate(facs):
-        if lay.est_td:
-            r, J = R.projection_td_factor(pose(fi), pose(fj), st['ex'], st['inv_depth'][l], st['td'], oi, oj)
-            pJ[f, :, 19] = J[4][:, 0]
-        else:
-            r, J = R.projection_factor(pose(fi), pose(fj), st['ex'], st['inv_depth'][l], [oi[0], oi[1], 1.0], [oj[0], oj[1], 1.0])
-        pr[f] = r
-        pJ[f, :, 0:6], pJ[f, :, 6:12], pJ[f, :, 12:18], pJ[f, :, 18] = J[0][:, :6], J[1][:, :6], J[2][:, :6], J[3][:, 0]
-        assert not J[0][:, 6].any() and not J[1][:, 6].any() and not J[2][:, 6].any()      # the w column of the global Jacobians
-    K = lay.K
-    ir, iJ = np.zeros((K - 1, 15)), np.zeros((K - 1, 15, 30))
-    for k in range(K - 1):
-        if prob['imu'][k] is None:
-            continue
-        r, J = R.imu_factor(prob['imu'][k], st['pose'][k], st['sb'][k], st['pose'][k + 1], st['sb'][k + 1])
-        ir[k] = r
-        iJ[k] = np.hstack([J[0][:, :6], J[1], J[2][:, :6], J[3]])
-    return pr, pJ, ir, iJ
+_ref_factor_tables = R.factor_tables
 
 
 def _window_with_prior(seed, L=40, **kw):
