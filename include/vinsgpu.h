@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 2    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points */
+#define VG_ABI_VERSION 3    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_* */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {
@@ -165,6 +165,11 @@ typedef struct {
     int it_flags[VG_MAX_ITERS];         /* bit0 valid, bit1 accepted                               */
     double prof[16];                    /* device phase timers (shader cycles of lane 0); zero unless the library
                                            was built with -DBA_PROFILE                                  */
+    /* the gauge transform double2vector() applied (estimator.cpp:541-577): x_fixed = gauge_rot (x - gauge_p0) + Ps[0]_before,
+     * R_fixed = gauge_rot R; gauge_rot = rot_diff (3x3 row-major), gauge_p0 = para_Pose[0] position right after the solve.
+     * For quantities outside the window, e.g. relo_Pose when no matched landmark put it into the problem (:598-603).   */
+    double gauge_rot[9];
+    double gauge_p0[3];
 } vg_ba_summary;
 
 /* New marginalization prior (MarginalizationInfo after marginalize() + getParameterBlocks(),

@@ -536,10 +536,11 @@ int oracle_fe_reject_with_f(const float* p1, const float* p2, int n, double thre
         for (int i = 0; i < n; ++i) cnt += fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2 ? 1 : 0;
         if (cnt > bestc) { bestc = cnt; bestk = k; memcpy(bestF, F, sizeof(F)); }
     }
+    // no usable hypothesis: nothing is rejected (the same documented choice as the product, ASSUMPTIONS.md F9)
     for (int i = 0; i < n; ++i)
-        status[i] = (bestk >= 0 && fr_error(bestF, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2) ? 1 : 0;
+        status[i] = (bestk < 0 || fr_error(bestF, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2) ? 1 : 0;
     if (F_out) memcpy(F_out, bestF, sizeof(bestF));
-    return bestk >= 0 ? bestc : 0;
+    return bestk >= 0 ? bestc : n;
 }
 
 }  // extern "C"

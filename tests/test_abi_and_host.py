@@ -28,13 +28,13 @@ def test_library_exports_every_declared_symbol(pkg):
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     lib.vg_abi_version.restype = C.c_int
-    assert lib.vg_abi_version() == 2 == ba.VG_ABI_VERSION
+    assert lib.vg_abi_version() == 3 == ba.VG_ABI_VERSION
 
 
 def test_struct_sizes_match_header():
     # sizes implied by include/vinsgpu.h on LP64
     assert C.sizeof(ba.ImuPreint) == 8 * (1 + 3 + 4 + 3 + 3 + 3 + 225 + 225) + 8
-    assert C.sizeof(ba.Summary) == 16 + 24 + 5 * 8 * 32 + 4 * 32 + 8 * 16
+    assert C.sizeof(ba.Summary) == 16 + 24 + 5 * 8 * 32 + 4 * 32 + 8 * 16 + 8 * 12
     assert C.sizeof(ba.State) == 6 * 8
     assert C.sizeof(ba.Prior) == 6 * 4 + 5 * 8
 

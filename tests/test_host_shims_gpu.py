@@ -238,3 +238,83 @@ def test_estimator_shim_relocalisation_by_products(handle):
     dy = np.deg2rad(yaw_deg(prev_r) - yaw_deg(relo_r))
     Rd = np.array([[np.cos(dy), -np.sin(dy), 0], [np.sin(dy), np.cos(dy), 0], [0, 0, 1.0]])
     assert np.allclose(dr.reshape(3, 3), Rd, atol=1e-9) and np.allclose(dt, prev_t - Rd @ relo_t, atol=1e-9)
+
+
+def test_slide_window_second_new_merges_the_imu_interval(handle):
+    """estimator.cpp:1069-1099 through the drop-in Estimator::slideWindow(): after a non-keyframe the interval that ended at the
+    dropped frame is folded into its predecessor.  Expected values: the REFERENCE's IntegrationBase fed the concatenated
+    samples (push_back, integration_base.h:30-36), when oracle/_ref is present; the NumPy restatement otherwise."""
+    from oracle import ba_numpy as B, ref as R
+    lib = C.CDLL(os.path.join(LIBDIR, "libvins_host.so"))
+    rng = np.random.default_rng(123)
+    noise = np.array([0.08, 0.004, 4e-5, 2e-6])
+
+    def interval(n):
+        first = np.concatenate([rng.normal(0, 1, 3) + [0, 0, 9.8], rng.normal(0, 0.3, 3)])
+        smp = np.array([[0.005, *(rng.normal(0, 1, 3) + [0, 0, 9.8]), *rng.normal(0, 0.3, 3)] for _ in range(n)])
+        return first, smp
+    fa, sa = interval(20)
+    fb, sb_ = interval(13)
+    bias = np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.02, 3)])
+    q = rng.normal(size=4)
+    st_prev = np.concatenate([rng.normal(size=3), q / np.linalg.norm(q), rng.normal(size=9)])
+    q = rng.normal(size=4)
+    st_new = np.concatenate([rng.normal(size=3), q / np.linalg.norm(q), rng.normal(size=9)])
+    merged, out, rel, ns = ba.ImuPreint(), np.zeros(16), C.c_int(), C.c_int()
+    dp = C.POINTER(C.c_double)
+    rc = lib.vins_host_slide_second_new(len(sa), np.ascontiguousarray(sa).ctypes.data_as(dp), fa.ctypes.data_as(dp), len(sb_), np.ascontiguousarray(sb_).ctypes.data_as(dp),
+                                        fb.ctypes.data_as(dp), bias.ctypes.data_as(dp), noise.ctypes.data_as(dp), st_prev.ctypes.data_as(dp), st_new.ctypes.data_as(dp),
+                                        C.byref(merged), out.ctypes.data_as(dp), C.byref(rel), C.byref(ns))
+    assert rc == 0 and rel.value == 1 and ns.value == 33
+    samples = [(0.0, fa[:3], fa[3:])] + [(r[0], r[1:4], r[4:7]) for r in sa] + [(r[0], r[1:4], r[4:7]) for r in sb_]
+    if R.available():
+        R.configure(noise[0], noise[2], noise[1], noise[3])
+        ref = R.preintegrate(samples, bias[:3], bias[3:])
+    else:
+        ref = synth.preintegrate(samples, bias[:3], bias[3:], *noise)
+    got = dict(delta_p=np.array(merged.delta_p), delta_q=np.array(merged.delta_q), delta_v=np.array(merged.delta_v),
+               jacobian=np.array(merged.jacobian).reshape(15, 15), covariance=np.array(merged.covariance).reshape(15, 15))
+    assert np.isclose(merged.sum_dt, ref['sum_dt'], rtol=1e-13)
+    for key, val in got.items():
+        assert np.abs(val - ref[key]).max() <= 1e-11 * np.abs(ref[key]).max(), key
+    exp = st_new.copy()
+    exp[3:7] = B.R2q(B.q2R(st_new[3:7]))
+    assert np.allclose(out, exp, atol=1e-12)                      # frame WINDOW_SIZE moved into slot WINDOW_SIZE-1
+
+
+def test_estimator_shim_relocalisation_without_a_matched_landmark(handle):
+    """setReloFrame() happened but no feature of match_points is in the window any more: the reference still adds relo_Pose as a
+    parameter block (estimator.cpp:771-772), the solve leaves it alone, and double2vector() gauge-fixes it for the by-products
+    (:598-616).  Expected values: the REFERENCE's Estimator run on the same window (oracle/_ref) when it is present."""
+    from test_ba_gpu import relocalisation_problem
+    from oracle import ba_numpy as B, ref as R
+    lib = C.CDLL(os.path.join(LIBDIR, "libvins_host.so"))
+    prob = relocalisation_problem(loop_frame=3)
+    pk = ba.PackedProblem(prob)
+    K = pk.K
+    prev_t = np.array([0.3, -0.2, 0.1])
+    prev_r = B.ypr2R(np.array([12.0, 0, 0]))
+    pose, fixed, rt, rq, ryaw, dr, dt = np.zeros((K, 7)), np.zeros(7), np.zeros(3), np.zeros(4), C.c_double(), np.zeros(9), np.zeros(3)
+    dp = C.POINTER(C.c_double)
+    rc = lib.vins_host_estimator_relo_nomatch_roundtrip(C.byref(pk.struct), 3, prev_t.ctypes.data_as(dp), np.ascontiguousarray(prev_r).ctypes.data_as(dp),
+                                                        pose.ctypes.data_as(dp), fixed.ctypes.data_as(dp), rt.ctypes.data_as(dp), rq.ctypes.data_as(dp),
+                                                        C.byref(ryaw), dr.ctypes.data_as(dp), dt.ctypes.data_as(dp))
+    assert rc == 0
+    plain = dict(prob, relo=None)                                   # what reaches the solver: the window without relo factors
+    st, sm, _ = handle.ba_optimize(plain)
+    assert np.abs(pose - st['pose']).max() < 1e-9
+    # the transform the device reports reproduces its own gauge fix
+    x, _ = B.solve(plain)
+    assert np.allclose(sm['gauge_rot'] @ (x['pose'][5][:3] - sm['gauge_p0']) + prob['pose'][0][:3], st['pose'][5][:3], atol=1e-6)
+    relo_r = sm['gauge_rot'] @ B.q2R(B.qnormalized(prob['relo']['pose'][3:]))
+    relo_t = sm['gauge_rot'] @ (prob['relo']['pose'][:3] - sm['gauge_p0']) + st['pose'][0][:3]
+    assert np.allclose(B.q2R(fixed[3:]), relo_r, atol=1e-9) and np.allclose(fixed[:3], relo_t, atol=1e-9)
+    R3, P3 = B.q2R(st['pose'][3][3:]), st['pose'][3][:3]
+    assert np.allclose(rt, relo_r.T @ (P3 - relo_t), atol=1e-9) and np.allclose(B.q2R(rq), relo_r.T @ R3, atol=1e-9)
+    if R.available():
+        ref_prob = dict(prob)
+        ref_prob['relo'] = dict(prob['relo'], match=[(len(prob['inv_depth']) + 50 + k, 0.0, 0.0) for k in range(3)], local_index=3, prev_t=prev_t, prev_r=prev_r)
+        st_r, _, _ = R.optimization(ref_prob, 1)
+        assert np.allclose(rt, st_r['relo_relative_t'], atol=1e-6) and np.allclose(B.q2R(rq), B.q2R(st_r['relo_relative_q']), atol=1e-6)
+        assert abs(ryaw.value - st_r['relo_relative_yaw']) < 1e-6
+        assert np.allclose(dr.reshape(3, 3), st_r['drift_correct_r'], atol=1e-8) and np.allclose(dt, st_r['drift_correct_t'], atol=1e-6)

@@ -11,7 +11,7 @@ from . import lib
 VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
 VG_OK = 0
-VG_ABI_VERSION = 2          # include/vinsgpu.h
+VG_ABI_VERSION = 3          # include/vinsgpu.h
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int)
 
@@ -43,7 +43,8 @@ class Summary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
                 ("it_cost", C.c_double * VG_MAX_ITERS), ("it_cost_cand", C.c_double * VG_MAX_ITERS),
                 ("it_model", C.c_double * VG_MAX_ITERS), ("it_radius", C.c_double * VG_MAX_ITERS),
-                ("it_step_norm", C.c_double * VG_MAX_ITERS), ("it_flags", C.c_int * VG_MAX_ITERS), ("prof", C.c_double * 16)]
+                ("it_step_norm", C.c_double * VG_MAX_ITERS), ("it_flags", C.c_int * VG_MAX_ITERS), ("prof", C.c_double * 16),
+                ("gauge_rot", C.c_double * 9), ("gauge_p0", C.c_double * 3)]
 
 
 class Prior(C.Structure):
@@ -158,7 +159,8 @@ def summary_dict(s):
                 initial_cost=s.initial_cost, final_cost=s.final_cost, final_radius=s.final_radius,
                 it_cost=np.array(s.it_cost[:n]), it_cost_cand=np.array(s.it_cost_cand[:n]),
                 it_model=np.array(s.it_model[:n]), it_radius=np.array(s.it_radius[:n]),
-                it_step_norm=np.array(s.it_step_norm[:n]), it_flags=np.array(s.it_flags[:n]), prof=np.array(s.prof[:]))
+                it_step_norm=np.array(s.it_step_norm[:n]), it_flags=np.array(s.it_flags[:n]), prof=np.array(s.prof[:]),
+                gauge_rot=np.array(s.gauge_rot[:]).reshape(3, 3), gauge_p0=np.array(s.gauge_p0[:]))
 
 
 # vg_allreduce_fn(user, device_buf, count, stream) -> 0 on success

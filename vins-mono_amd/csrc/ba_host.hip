@@ -435,10 +435,12 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     VG_RANGE("vg_ba_batch_upload");
     if (!h || nwin <= 0 || !in) return VG_ERR_BAD_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    BaBatch& B = h->ba;
+    B.uploaded = false;              // a failed upload must not leave the previous batch's flags next to the new layout
+    B.solved_recorded = false;
     BaLayout L;
     int rc = build_layout(h, nwin, in, L);
     if (rc) return rc;
-    BaBatch& B = h->ba;
     B.L = L;
     B.nwin = nwin;
     const size_t n_ia = (size_t)nwin * L.istride, n_di = (size_t)nwin * L.dstride;
@@ -580,6 +582,7 @@ static int launch_solve(vg_handle* h, hipEvent_t* ev = nullptr, int* kinds = nul
 extern "C" int vg_ba_batch_run_async(vg_handle* h) {
     VG_RANGE("vg_ba_batch_run_async");
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
     BaBatch& B = h->ba;
     const int rc = launch_solve(h);
     if (rc) return rc;
@@ -612,6 +615,7 @@ extern "C" int vg_ba_reduce_layout(vg_handle* h, size_t* count1, size_t* count2)
 
 extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_ms) {
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
     BaBatch& B = h->ba;
     hipEvent_t e0 = h->ev0, e1 = h->ev1, e2 = h->ev2;
     HIPCHK(h, hipEventRecord(e0, h->stream));
@@ -635,6 +639,7 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
 // class k (VG_BA_KERNEL_*).  The gaps between launches are part of the class that follows them.
 extern "C" int vg_ba_batch_run_profiled(vg_handle* h, float* ms, int* n) {
     if (!h || !h->ba.uploaded || !ms || !n) return VG_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
     BaBatch& B = h->ba;
     const int nev = B.L.big ? 7 * (B.rounds + BA_BIG_SLACK) + 8 : 4 * B.rounds + 5 + 1;
     std::vector<hipEvent_t> ev(nev, nullptr);
@@ -714,6 +719,8 @@ static int unpack_states(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_s
             memset(&s, 0, sizeof(s));
             s.status = io[0]; s.termination = io[1]; s.num_iterations = io[2]; s.num_accepted = io[3];
             s.initial_cost = o[L.oo_sum + 0]; s.final_cost = o[L.oo_sum + 1]; s.final_radius = o[L.oo_sum + 2];
+            for (int k = 0; k < 9; ++k) s.gauge_rot[k] = o[L.oo_sum + 3 + k];
+            for (int k = 0; k < 3; ++k) s.gauge_p0[k] = o[L.oo_sum + 12 + k];
             for (int k = 0; k < VG_MAX_ITERS; ++k) {
                 s.it_cost[k] = o[L.oo_trace + 0 * VG_MAX_ITERS + k];
                 s.it_cost_cand[k] = o[L.oo_trace + 1 * VG_MAX_ITERS + k];

@@ -20,7 +20,7 @@
 #endif
 #define BA_IMU_STRIDE 472         // doubles per vg_imu_preint record on device
 #define BA_OBS_STRIDE 8
-#define BA_SUM_DOUBLES 8
+#define BA_SUM_DOUBLES 16     // init cost, cost, radius, gauge rot_diff (9), post-solve position of frame 0 (3)
 #define BA_HDR_INTS 16
 
 enum { H_L = 0, H_F, H_NPRIOR, H_NBLK, H_MAXIT, H_NCHUNK, H_MARGIN, H_STATUS };

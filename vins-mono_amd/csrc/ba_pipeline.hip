@@ -24,6 +24,7 @@
 // current point are reused exactly as DoglegStrategy does.  All solver state between launches lives in a small
 // per-window control block in HBM; every sum has a fixed order, so results are bit-reproducible.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "ba_layout.h"
 #include "ba_factors.h"
 #include "../../include/vinsgpu.h"
@@ -3148,6 +3149,10 @@ extern "C" __global__ __launch_bounds__(256) void ba_final_kernel(const BaLayout
         out[L.oo_sum + 0] = s.init_cost;
         out[L.oo_sum + 1] = s.cost;
         out[L.oo_sum + 2] = s.radius;
+        // the gauge transform itself (estimator.cpp:541-556): x_fixed = rot (x - p0_solved) + P0_before — lets the caller map
+        // quantities outside the window (the relocalisation pose when it carries no factor, :598-603)
+        for (int k = 0; k < 9; ++k) out[L.oo_sum + 3 + k] = rot[k];
+        for (int k = 0; k < 3; ++k) out[L.oo_sum + 12 + k] = x[k];
         iout[0] = s.status; iout[1] = s.term; iout[2] = s.it; iout[3] = s.nacc;
         s.done = 1;
         ctl_store(s, ctlp);
@@ -3212,16 +3217,23 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_eval_factors_kernel(const
 
 // ------------------------------------------------------------------------------------------------
 // Host-side launch sequence of one batch solve (rounds = max over the windows of max_iters).
+// hipFuncSetAttribute applies to the function object of the CURRENT device: the set-up is tracked per device (a process may hold
+// handles on several GPUs) under a mutex (handles may be driven from several host threads).
 static hipError_t set_lds_attrs() {
-    static bool done = false;
-    if (done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static std::mutex mu;
+    static unsigned long long done_mask = 0;      // bit d: device d is set up
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && ((done_mask >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // (these two also hold a few statically allocated LDS words: static + dynamic must stay within 160 KB)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linearize_imu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_eval_factors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    done = e == hipSuccess;
+    if (e == hipSuccess && dev >= 0 && dev < 64) done_mask |= 1ull << dev;
     return e;
 }
 

@@ -202,20 +202,21 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
     if (n < 8) { h->err = "vg_fe_reject_with_f: fewer than 8 correspondences"; return VG_ERR_BAD_ARG; }
     if (n > FE_RANSAC_MAXPTS) { h->err = "vg_fe_reject_with_f: more than 1024 correspondences"; return VG_ERR_UNSUPPORTED; }
     hipError_t e = hipSetDevice(h->device);
-    float* d_p = nullptr;
-    double* d_F = nullptr;
-    int* d_i = nullptr;
-    unsigned char* d_s = nullptr;
     auto fail = [&](hipError_t err) {
         h->err = std::string("vg_fe_reject_with_f: ") + hipGetErrorString(err);
-        (void)hipFree(d_p); (void)hipFree(d_F); (void)hipFree(d_i); (void)hipFree(d_s);
         return VG_ERR_HIP;
     };
     if (e != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&d_p, sizeof(float) * 4 * n)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&d_F, sizeof(double) * 9 * FE_RANSAC_HYP)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&d_i, sizeof(int) * (FE_RANSAC_HYP + 2))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&d_s, n)) != hipSuccess) return fail(e);
+    // One allocation for the life of the handle (n <= FE_RANSAC_MAXPTS): this call sits on the per-frame path, and hipFree
+    // synchronises the whole device — it would stall the BA handle's asynchronous marginalization / state download.
+    const size_t off_F = sizeof(float) * 4 * FE_RANSAC_MAXPTS, off_i = off_F + sizeof(double) * 9 * FE_RANSAC_HYP;
+    const size_t off_s = off_i + sizeof(int) * (FE_RANSAC_HYP + 2 + 2), total = off_s + FE_RANSAC_MAXPTS;
+    if (!h->ransac_buf && (e = hipMalloc(&h->ransac_buf, total)) != hipSuccess) { h->ransac_buf = nullptr; return fail(e); }
+    char* base = (char*)h->ransac_buf;
+    float* d_p = (float*)base;
+    double* d_F = (double*)(base + off_F);
+    int* d_i = (int*)(base + off_i);
+    unsigned char* d_s = (unsigned char*)(base + off_s);
     if ((e = hipMemcpyAsync(d_p, cur_un_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
     if ((e = hipMemcpyAsync(d_p + 2 * n, forw_un_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
     const float thresh2 = (float)(threshold * threshold);
@@ -230,7 +231,12 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
         if (res[0] >= 0) { if ((e = hipMemcpy(F_out, d_F + (size_t)res[0] * 9, sizeof(double) * 9, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e); }
         else for (int k = 0; k < 9; ++k) F_out[k] = 0.0;
     }
+    if (res[0] < 0) {
+        // no usable hypothesis (every sample degenerate or non-finite): the estimate failed, nothing is rejected — the tracks
+        // survive the frame instead of being wiped (documented choice, oracle/ASSUMPTIONS.md F9)
+        for (int i = 0; i < n; ++i) status[i] = 1;
+        res[1] = n;
+    }
     if (n_inliers) *n_inliers = res[1];
-    (void)hipFree(d_p); (void)hipFree(d_F); (void)hipFree(d_i); (void)hipFree(d_s);
     return VG_OK;
 }

@@ -37,6 +37,7 @@ extern "C" int vg_destroy(vg_handle* h) {
     h->ba.h_out.release(); h->ba.h_iout.release(); h->ba.h_mout.release(); h->ba.h_miout.release();
     (void)hipFree(P.mout); (void)hipFree(P.miout); (void)hipFree(P.mscr); (void)hipFree(P.rb1); (void)hipFree(P.rb2);
     if (h->fe) fe_state_destroy(h->fe);
+    (void)hipFree(h->ransac_buf);
     (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev2);
     (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join);
     (void)hipStreamDestroy(h->aux);

@@ -57,4 +57,5 @@ struct vg_handle {
     std::string err;
     BaBatch ba;
     FeState* fe = nullptr;
+    void* ransac_buf = nullptr;                   // device scratch of vg_fe_reject_with_f (fixed size, allocated on first use)
 };

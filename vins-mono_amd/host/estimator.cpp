@@ -8,7 +8,8 @@
 #include <string>
 
 int ESTIMATE_EXTRINSIC = 0, ESTIMATE_TD = 0, NUM_ITERATIONS = 8;
-double TD = 0, TR = 0, ROW_D = 480, FOCAL_LENGTH_D = 460.0, G_NORM = 9.81007, INIT_DEPTH = 5.0;
+double TD = 0, TR = 0, ROW_D = 480, FOCAL_LENGTH_D = 460.0, G_NORM = 9.81007, INIT_DEPTH = 5.0, SOLVER_TIME = 0.0;
+double ACC_N = 0.08, ACC_W = 0.00004, GYR_N = 0.004, GYR_W = 2.0e-6;      // config/euroc/euroc_config.yaml:58-62
 
 int FeatureManager::getFeatureCount() {                         // feature_manager.cpp:28-42
     int cnt = 0;
@@ -60,9 +61,34 @@ void FeatureManager::removeFront(int frame_count) {              // feature_mana
     }
 }
 
+void Estimator::repropagate(IntegrationBase* p) {
+    if (!vg_ && vg_create(&vg_) != VG_OK) throw std::runtime_error("vg_create failed: no MI355X / libvinsgpu (no CPU fallback)");
+    const int n = (int)p->dt_buf.size();
+    std::vector<double> smp((size_t)(n > 0 ? n : 1) * 7, 0.0);
+    for (int i = 0; i < n; ++i) {
+        double* r = &smp[(size_t)7 * i];
+        r[0] = p->dt_buf[i];
+        for (int k = 0; k < 3; ++k) { r[1 + k] = p->acc_buf[i](k); r[4 + k] = p->gyr_buf[i](k); }
+    }
+    const double first[6] = {p->linearized_acc(0), p->linearized_acc(1), p->linearized_acc(2), p->linearized_gyr(0), p->linearized_gyr(1), p->linearized_gyr(2)};
+    const double bias[6] = {p->linearized_ba(0), p->linearized_ba(1), p->linearized_ba(2), p->linearized_bg(0), p->linearized_bg(1), p->linearized_bg(2)};
+    const double noise[4] = {ACC_N, GYR_N, ACC_W, GYR_W};
+    const int off[2] = {0, n};
+    vg_imu_preint out;
+    if (vg_imu_preintegrate(vg_, 1, off, smp.data(), first, bias, noise, &out) != VG_OK) throw std::runtime_error(std::string("vg_imu_preintegrate: ") + vg_last_error(vg_));
+    p->sum_dt = out.sum_dt;
+    p->delta_p = Vector3d(out.delta_p[0], out.delta_p[1], out.delta_p[2]);
+    p->delta_v = Vector3d(out.delta_v[0], out.delta_v[1], out.delta_v[2]);
+    p->delta_q = Quaterniond(out.delta_q[3], out.delta_q[0], out.delta_q[1], out.delta_q[2]);
+    for (int r = 0; r < 15; ++r)
+        for (int c = 0; c < 15; ++c) { p->jacobian(r, c) = out.jacobian[r * 15 + c]; p->covariance(r, c) = out.covariance[r * 15 + c]; }
+}
+
 void Estimator::slideWindow() {
-    // estimator.cpp:1005-1126 for frame_count == WINDOW_SIZE and solver_flag == NON_LINEAR; the raw IMU buffers
-    // (dt_buf ...) and all_image_frame belong to processIMU / the initialiser and are not mirrored here
+    // estimator.cpp:1005-1126 for frame_count == WINDOW_SIZE and solver_flag == NON_LINEAR; all_image_frame belongs to the
+    // initialiser and is not mirrored here.  Ownership as in the reference: the IntegrationBase that ends up in slot
+    // WINDOW_SIZE is deleted here (:1036 / :1093); the caller installs the next interval's object (the reference re-creates
+    // an empty one and processIMU fills it).
     if (marginalization_flag == MARGIN_OLD) {
         back_R0 = Rs[0];
         back_P0 = Ps[0];
@@ -76,14 +102,31 @@ void Estimator::slideWindow() {
         }
         Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1]; Vs[WINDOW_SIZE] = Vs[WINDOW_SIZE - 1]; Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1];
         Bas[WINDOW_SIZE] = Bas[WINDOW_SIZE - 1]; Bgs[WINDOW_SIZE] = Bgs[WINDOW_SIZE - 1];
+        delete pre_integrations[WINDOW_SIZE];                    // (the object that was in slot 0)
         pre_integrations[WINDOW_SIZE] = nullptr;                 // the caller installs the next interval's pre-integration
         // slideWindowOld(), shift_depth = true (:1115-1126)
         Matrix3d R0 = back_R0 * ric[0], R1 = Rs[0] * ric[0];
         Vector3d P0 = back_P0 + back_R0 * tic[0], P1 = Ps[0] + Rs[0] * tic[0];
         f_manager.removeBackShiftDepth(R0, P0, R1, P1);
     } else {
+        // :1069-1085: the IMU samples between frames WINDOW_SIZE-1 and WINDOW_SIZE are appended to the interval that ends at
+        // frame WINDOW_SIZE-1, which then spans WINDOW_SIZE-2 .. WINDOW_SIZE.  The reference continues the running
+        // integration sample by sample (push_back); integrating the concatenated list with the same linearisation biases is
+        // the same sequence of operations (vg_imu_preintegrate).
+        IntegrationBase* a = pre_integrations[WINDOW_SIZE - 1];
+        IntegrationBase* b = pre_integrations[WINDOW_SIZE];
+        if (b) {
+            if (!a) throw std::runtime_error("slideWindow(MARGIN_SECOND_NEW): pre_integrations[WINDOW_SIZE - 1] is missing");
+            if (b->dt_buf.empty() || (a->dt_buf.empty() && a->sum_dt != 0))
+                throw std::runtime_error("slideWindow(MARGIN_SECOND_NEW): the pre-integrations carry no raw IMU samples (dt_buf / acc_buf / gyr_buf) to merge");
+            a->dt_buf.insert(a->dt_buf.end(), b->dt_buf.begin(), b->dt_buf.end());
+            a->acc_buf.insert(a->acc_buf.end(), b->acc_buf.begin(), b->acc_buf.end());
+            a->gyr_buf.insert(a->gyr_buf.end(), b->gyr_buf.begin(), b->gyr_buf.end());
+            repropagate(a);
+        }
         Ps[WINDOW_SIZE - 1] = Ps[WINDOW_SIZE]; Vs[WINDOW_SIZE - 1] = Vs[WINDOW_SIZE]; Rs[WINDOW_SIZE - 1] = Rs[WINDOW_SIZE];
         Bas[WINDOW_SIZE - 1] = Bas[WINDOW_SIZE]; Bgs[WINDOW_SIZE - 1] = Bgs[WINDOW_SIZE];
+        delete pre_integrations[WINDOW_SIZE];                    // :1093
         pre_integrations[WINDOW_SIZE] = nullptr;
         f_manager.removeFront(WINDOW_SIZE);                      // slideWindowNew() (:1107-1111)
     }
@@ -157,12 +200,21 @@ void Estimator::double2vector() {
         it.solve_flag = it.estimated_depth < 0 ? 2 : 1;
     }
     if (ESTIMATE_TD) td = para_Td[0][0];
-    if (relocalization_info && !relo_in_problem) relocalization_info = false;   // no matched landmark was optimised: nothing to report
     if (relocalization_info) {
-        // relative pose between the two loop frames (:596-616).  relo_Pose comes back from the device already in the fixed
-        // gauge (rot_diff * (p - P0) + origin_P0, rot_diff * R): it IS the reference's relo_r / relo_t
-        const Matrix3d relo_r = Quaterniond(relo_Pose[6], relo_Pose[3], relo_Pose[4], relo_Pose[5]).toRotationMatrix();
-        const Vector3d relo_t(relo_Pose[0], relo_Pose[1], relo_Pose[2]);
+        // relative pose between the two loop frames (:596-616).  With matched landmarks relo_Pose was a parameter block of the
+        // problem and comes back from the device already in the fixed gauge (rot_diff * (p - P0) + origin_P0, rot_diff * R): it
+        // IS the reference's relo_r / relo_t.  Without a match the reference still adds the block (:771-772; no residual touches
+        // it, the solve leaves it alone) and applies the gauge transform to it (:598-603): done here with the transform the
+        // device reports (vg_ba_summary::gauge_rot / gauge_p0); origin_P0 = the gauge-fixed Ps[0].
+        Matrix3d relo_r = Quaterniond(relo_Pose[6], relo_Pose[3], relo_Pose[4], relo_Pose[5]).toRotationMatrix();
+        Vector3d relo_t(relo_Pose[0], relo_Pose[1], relo_Pose[2]);
+        if (!relo_in_problem) {
+            Matrix3d rot;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rot(r, c) = last_summary.gauge_rot[3 * r + c];
+            const double qn = std::sqrt(relo_Pose[3] * relo_Pose[3] + relo_Pose[4] * relo_Pose[4] + relo_Pose[5] * relo_Pose[5] + relo_Pose[6] * relo_Pose[6]);
+            relo_r = rot * Quaterniond(relo_Pose[6] / qn, relo_Pose[3] / qn, relo_Pose[4] / qn, relo_Pose[5] / qn).toRotationMatrix();
+            relo_t = rot * Vector3d(relo_Pose[0] - last_summary.gauge_p0[0], relo_Pose[1] - last_summary.gauge_p0[1], relo_Pose[2] - last_summary.gauge_p0[2]) + Ps[0];
+        }
         relo_r_fixed = relo_r; relo_t_fixed = relo_t;
         const double drift_correct_yaw = R2ypr_deg(prev_relo_r).x() - R2ypr_deg(relo_r).x();
         drift_correct_r = yaw2R_deg(drift_correct_yaw);
@@ -260,6 +312,9 @@ void Estimator::optimization() {
     }
     pb.estimate_extrinsic = ESTIMATE_EXTRINSIC ? 1 : 0; pb.estimate_td = ESTIMATE_TD ? 1 : 0; pb.max_iters = NUM_ITERATIONS;
     pb.focal = FOCAL_LENGTH_D; pb.tr = TR; pb.row = ROW_D; pb.g_norm = G_NORM;
+    // options.max_solver_time_in_seconds (:812-815); SOLVER_TIME = 0 (the default of this library) = no cap: a wall-clock cap makes
+    // the result depend on timing
+    pb.max_solver_time_s = marginalization_flag == MARGIN_OLD ? SOLVER_TIME * 4.0 / 5.0 : SOLVER_TIME;
     // ---- outputs
     vector<double> lam(L > 0 ? L : 1);
     vg_ba_state st;

@@ -16,7 +16,8 @@ const int WINDOW_SIZE = 10;                  // vins_estimator/src/parameters.h:
 const int NUM_OF_CAM = 1;
 const int NUM_OF_F = 1000;
 extern int ESTIMATE_EXTRINSIC, ESTIMATE_TD, NUM_ITERATIONS;
-extern double TD, TR, ROW_D, FOCAL_LENGTH_D, G_NORM, INIT_DEPTH;
+extern double TD, TR, ROW_D, FOCAL_LENGTH_D, G_NORM, INIT_DEPTH, SOLVER_TIME;
+extern double ACC_N, ACC_W, GYR_N, GYR_W;          // vins_estimator/src/parameters.cpp:5-6 (the device pre-integration needs them)
 
 struct FeaturePerFrame { Vector3d point; Vector2d uv; Vector2d velocity; double cur_td = 0; };   // feature_manager.h:19-42
 struct FeaturePerId {                                                                             // feature_manager.h:44-66
@@ -40,6 +41,11 @@ struct IntegrationBase {           // the members IMUFactor reads (factor/integr
     Vector3d delta_p, delta_v, linearized_ba, linearized_bg;
     Quaterniond delta_q;
     Eigen::Matrix<double, 15, 15> jacobian, covariance;      // column-major (Eigen default), integration_base.h:195
+    // the raw samples of the interval (integration_base.h:192, :205-208): slideWindow() folds the samples of a dropped
+    // non-keyframe into the previous interval (estimator.cpp:1073-1085) and re-integrates it on the device
+    Vector3d linearized_acc, linearized_gyr;                 // first measurement of the interval
+    std::vector<double> dt_buf;
+    std::vector<Vector3d> acc_buf, gyr_buf;
 };
 
 struct MarginalizationInfo {       // the members MarginalizationFactor reads (marginalization_factor.h:44-72), same names / types
@@ -62,6 +68,8 @@ class Estimator {
     void vector2double();
     void double2vector();
     void slideWindow();            // estimator.cpp:1005-1126 (state / pre-integration shift + slideWindowOld / slideWindowNew)
+    // IntegrationBase::repropagate (integration_base.h:38-52) on the device: integrates p's raw samples with its linearized biases
+    void repropagate(IntegrationBase* p);
 
     MarginalizationFlag marginalization_flag = MARGIN_OLD;
     Vector3d Ps[(WINDOW_SIZE + 1)], Vs[(WINDOW_SIZE + 1)], Bas[(WINDOW_SIZE + 1)], Bgs[(WINDOW_SIZE + 1)];

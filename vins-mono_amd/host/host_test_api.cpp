@@ -2,7 +2,9 @@
 // it fills the Estimator members the way the surrounding reference code would have left them (Ps/Rs/..., the
 // f_manager.feature list incl. features the filter must skip, pre_integrations[], last_marginalization_info), calls
 // Estimator::optimization() and returns the members it wrote.  Test plumbing only.
+#include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include "estimator.h"
 
 extern "C" int vins_host_estimator_roundtrip(const vg_ba_problem* p, int margin_flag, double* pose_out /*K*7*/, double* sb_out /*K*9*/,
@@ -114,10 +116,23 @@ extern "C" int vins_host_estimator_roundtrip(const vg_ba_problem* p, int margin_
 
 // The same round trip with relocalisation (estimator.cpp:769-801 + :596-616): p->relo_* become match_points / relo_Pose the
 // way setReloFrame() would leave them; outputs = the by-products double2vector() computes + the gauge-fixed loop pose.
+static int relo_roundtrip(const vg_ba_problem* p, int relo_frame_local_index, const double* prev_relo_t, const double* prev_relo_r, double* pose_out,
+                          double* relo_fixed, double* relative_t, double* relative_q, double* relative_yaw, double* drift_r, double* drift_t, bool no_match);
 extern "C" int vins_host_estimator_relo_roundtrip(const vg_ba_problem* p, int relo_frame_local_index, const double* prev_relo_t /*3*/,
                                                   const double* prev_relo_r /*9 row-major*/, double* pose_out /*K*7*/,
                                                   double* relo_fixed /*7: t, q(x y z w)*/, double* relative_t /*3*/, double* relative_q /*4 x y z w*/,
                                                   double* relative_yaw, double* drift_r /*9 row-major*/, double* drift_t /*3*/) {
+    return relo_roundtrip(p, relo_frame_local_index, prev_relo_t, prev_relo_r, pose_out, relo_fixed, relative_t, relative_q, relative_yaw, drift_r, drift_t, false);
+}
+// the same with match_points that name no feature of the window: relo_Pose carries no factor (estimator.cpp:771-772 still adds the
+// block), the by-products of :596-616 must come out of the gauge transform alone; relo_fixed returns relo_r / relo_t as used there
+extern "C" int vins_host_estimator_relo_nomatch_roundtrip(const vg_ba_problem* p, int relo_frame_local_index, const double* prev_relo_t,
+                                                          const double* prev_relo_r, double* pose_out, double* relo_fixed, double* relative_t,
+                                                          double* relative_q, double* relative_yaw, double* drift_r, double* drift_t) {
+    return relo_roundtrip(p, relo_frame_local_index, prev_relo_t, prev_relo_r, pose_out, relo_fixed, relative_t, relative_q, relative_yaw, drift_r, drift_t, true);
+}
+static int relo_roundtrip(const vg_ba_problem* p, int relo_frame_local_index, const double* prev_relo_t, const double* prev_relo_r, double* pose_out,
+                          double* relo_fixed, double* relative_t, double* relative_q, double* relative_yaw, double* drift_r, double* drift_t, bool no_match) {
     if (p->K != WINDOW_SIZE + 1 || p->relo_n <= 0) return -1;
     Estimator est;
     ESTIMATE_EXTRINSIC = p->estimate_extrinsic; ESTIMATE_TD = p->estimate_td; NUM_ITERATIONS = p->max_iters;
@@ -159,7 +174,7 @@ extern "C" int vins_host_estimator_relo_roundtrip(const vg_ba_problem* p, int re
     // setReloFrame (estimator.cpp:1128-1148): matches as (x, y, feature id) ascending by id, the loop pose, its local index
     est.relocalization_info = true;
     est.relo_frame_local_index = relo_frame_local_index;
-    for (int k = 0; k < p->relo_n; ++k) est.match_points.push_back(Vector3d(p->relo_xy[2 * k], p->relo_xy[2 * k + 1], 10.0 * p->relo_lm[k] + 3));
+    for (int k = 0; k < p->relo_n; ++k) est.match_points.push_back(Vector3d(p->relo_xy[2 * k], p->relo_xy[2 * k + 1], 10.0 * p->relo_lm[k] + (no_match ? 5 : 3)));
     est.match_points.push_back(Vector3d(0, 0, 10.0 * p->L + 7));        // a match of a feature that is not in the window any more
     for (int k = 0; k < 7; ++k) est.relo_Pose[k] = p->relo_pose[k];
     est.prev_relo_t = Vector3d(prev_relo_t[0], prev_relo_t[1], prev_relo_t[2]);
@@ -174,10 +189,85 @@ extern "C" int vins_host_estimator_relo_roundtrip(const vg_ba_problem* p, int re
         memcpy(pose_out + 7 * i, row, sizeof(row));
     }
     for (int k = 0; k < 7; ++k) relo_fixed[k] = est.relo_Pose[k];
+    if (no_match) {
+        Quaterniond q(est.relo_r_fixed);
+        const double f[7] = {est.relo_t_fixed.x(), est.relo_t_fixed.y(), est.relo_t_fixed.z(), q.x(), q.y(), q.z(), q.w()};
+        memcpy(relo_fixed, f, sizeof(f));
+    }
     relative_t[0] = est.relo_relative_t.x(); relative_t[1] = est.relo_relative_t.y(); relative_t[2] = est.relo_relative_t.z();
     relative_q[0] = est.relo_relative_q.x(); relative_q[1] = est.relo_relative_q.y(); relative_q[2] = est.relo_relative_q.z(); relative_q[3] = est.relo_relative_q.w();
     *relative_yaw = est.relo_relative_yaw;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) drift_r[3 * r + c] = est.drift_correct_r(r, c);
     drift_t[0] = est.drift_correct_t.x(); drift_t[1] = est.drift_correct_t.y(); drift_t[2] = est.drift_correct_t.z();
     return 0;
+}
+
+
+// Estimator::slideWindow() with MARGIN_SECOND_NEW (estimator.cpp:1069-1099): the interval WINDOW_SIZE-1 -> WINDOW_SIZE is folded
+// into the interval that ends at frame WINDOW_SIZE-1.  Inputs: the two intervals as raw samples ([dt acc gyr] rows, first
+// measurement [acc gyr], linearisation biases [ba bg]) and the states of the two newest frames (pose7 + sb9 each).
+// Outputs: the merged pre-integration, the state now in slot WINDOW_SIZE-1, whether slot WINDOW_SIZE was released.
+extern "C" int vins_host_slide_second_new(int na, const double* smp_a, const double* first_a, int nb, const double* smp_b, const double* first_b,
+                                          const double* bias, const double* noise4 /*acc_n gyr_n acc_w gyr_w*/, const double* state_prev /*16*/,
+                                          const double* state_new /*16*/, vg_imu_preint* merged, double* state_out /*16*/, int* slot_ws_released,
+                                          int* nsamples_out) {
+    try {
+        Estimator est;
+        ACC_N = noise4[0]; GYR_N = noise4[1]; ACC_W = noise4[2]; GYR_W = noise4[3];
+        auto fill = [&](int n, const double* smp, const double* first) {
+            IntegrationBase* p = new IntegrationBase();
+            p->linearized_acc = Vector3d(first[0], first[1], first[2]);
+            p->linearized_gyr = Vector3d(first[3], first[4], first[5]);
+            p->linearized_ba = Vector3d(bias[0], bias[1], bias[2]);
+            p->linearized_bg = Vector3d(bias[3], bias[4], bias[5]);
+            for (int i = 0; i < n; ++i) {
+                p->dt_buf.push_back(smp[7 * i]);
+                p->acc_buf.push_back(Vector3d(smp[7 * i + 1], smp[7 * i + 2], smp[7 * i + 3]));
+                p->gyr_buf.push_back(Vector3d(smp[7 * i + 4], smp[7 * i + 5], smp[7 * i + 6]));
+            }
+            est.repropagate(p);
+            return p;
+        };
+        auto set = [&](int i, const double* s) {
+            est.Ps[i] = Vector3d(s[0], s[1], s[2]);
+            est.Rs[i] = Quaterniond(s[6], s[3], s[4], s[5]).toRotationMatrix();
+            est.Vs[i] = Vector3d(s[7], s[8], s[9]); est.Bas[i] = Vector3d(s[10], s[11], s[12]); est.Bgs[i] = Vector3d(s[13], s[14], s[15]);
+        };
+        est.pre_integrations[WINDOW_SIZE - 1] = fill(na, smp_a, first_a);
+        est.pre_integrations[WINDOW_SIZE] = fill(nb, smp_b, first_b);
+        set(WINDOW_SIZE - 1, state_prev);
+        set(WINDOW_SIZE, state_new);
+        FeaturePerId f;                                   // one track that starts at the dropped frame and one that spans it
+        f.feature_id = 1; f.start_frame = WINDOW_SIZE; f.feature_per_frame.resize(1);
+        est.f_manager.feature.push_back(f);
+        f.feature_id = 2; f.start_frame = WINDOW_SIZE - 3; f.feature_per_frame.resize(4);
+        est.f_manager.feature.push_back(f);
+        est.marginalization_flag = Estimator::MARGIN_SECOND_NEW;
+        est.slideWindow();
+        const IntegrationBase* p = est.pre_integrations[WINDOW_SIZE - 1];
+        memset(merged, 0, sizeof(*merged));
+        merged->valid = 1; merged->sum_dt = p->sum_dt;
+        for (int k = 0; k < 3; ++k) { merged->delta_p[k] = p->delta_p(k); merged->delta_v[k] = p->delta_v(k); merged->linearized_ba[k] = p->linearized_ba(k); merged->linearized_bg[k] = p->linearized_bg(k); }
+        merged->delta_q[0] = p->delta_q.x(); merged->delta_q[1] = p->delta_q.y(); merged->delta_q[2] = p->delta_q.z(); merged->delta_q[3] = p->delta_q.w();
+        for (int r = 0; r < 15; ++r)
+            for (int c = 0; c < 15; ++c) { merged->jacobian[r * 15 + c] = p->jacobian(r, c); merged->covariance[r * 15 + c] = p->covariance(r, c); }
+        *nsamples_out = (int)p->dt_buf.size();
+        const int i = WINDOW_SIZE - 1;
+        Quaterniond q(est.Rs[i]);
+        const double so[16] = {est.Ps[i].x(), est.Ps[i].y(), est.Ps[i].z(), q.x(), q.y(), q.z(), q.w(), est.Vs[i].x(), est.Vs[i].y(), est.Vs[i].z(),
+                               est.Bas[i].x(), est.Bas[i].y(), est.Bas[i].z(), est.Bgs[i].x(), est.Bgs[i].y(), est.Bgs[i].z()};
+        memcpy(state_out, so, sizeof(so));
+        *slot_ws_released = est.pre_integrations[WINDOW_SIZE] == nullptr;
+        // removeFront (feature_manager.cpp:333-351): track 1 moved to start WINDOW_SIZE-1, track 2 lost its observation at WINDOW_SIZE-1
+        auto it = est.f_manager.feature.begin();
+        if (it->start_frame != WINDOW_SIZE - 1) return -3;
+        ++it;
+        if (it->feature_per_frame.size() != 3) return -4;
+        delete est.pre_integrations[WINDOW_SIZE - 1];
+        est.pre_integrations[WINDOW_SIZE - 1] = nullptr;
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "vins_host_slide_second_new: %s\n", e.what());
+        return -2;
+    }
 }

@@ -73,6 +73,13 @@ IntegrationBase* preintegrate(vg_handle* h, Reader& rd, int S, const double* bia
     vg_imu_preint out;
     if (vg_imu_preintegrate(h, 1, off, smp.data(), first, bias, noise, &out) != VG_OK) throw std::runtime_error(vg_last_error(h));
     IntegrationBase* p = new IntegrationBase();
+    p->linearized_acc = Vector3d(first[0], first[1], first[2]);          // raw samples: slideWindow(MARGIN_SECOND_NEW) merges intervals
+    p->linearized_gyr = Vector3d(first[3], first[4], first[5]);
+    for (int i = 0; i < S; ++i) {
+        p->dt_buf.push_back(smp[7 * i]);
+        p->acc_buf.push_back(Vector3d(smp[7 * i + 1], smp[7 * i + 2], smp[7 * i + 3]));
+        p->gyr_buf.push_back(Vector3d(smp[7 * i + 4], smp[7 * i + 5], smp[7 * i + 6]));
+    }
     p->sum_dt = out.sum_dt;
     p->delta_p = Vector3d(out.delta_p[0], out.delta_p[1], out.delta_p[2]);
     p->delta_v = Vector3d(out.delta_v[0], out.delta_v[1], out.delta_v[2]);
@@ -96,6 +103,7 @@ static int replay_ba(const char* in, const char* out) {
     double ex[7], noise[4], par[2], bias[6];
     rd.d(ex, 7); rd.d(noise, 4); rd.d(par, 2); rd.d(bias, 6);
     G_NORM = par[0]; FOCAL_LENGTH_D = par[1]; ESTIMATE_EXTRINSIC = 0; ESTIMATE_TD = 0; NUM_ITERATIONS = 8;
+    ACC_N = noise[0]; GYR_N = noise[1]; ACC_W = noise[2]; GYR_W = noise[3];
     vg_handle* h = nullptr;
     if (vg_create(&h) != VG_OK) { fprintf(stderr, "vg_create failed (no CPU fallback)\n"); return 3; }
     Estimator est;
@@ -113,10 +121,7 @@ static int replay_ba(const char* in, const char* out) {
     for (int w = 0; w < W; ++w) {
         if (w > 0) {
             est.marginalization_flag = Estimator::MARGIN_OLD;
-            IntegrationBase* dropped = est.pre_integrations[1];          // the interval that leaves the window
-            est.slideWindow();
-            delete dropped;
-            est.pre_integrations[0] = nullptr;                          // (slot 0 is never read: factor i uses pre_integrations[i + 1])
+            est.slideWindow();                                           // (deletes the IntegrationBase that rotated out, like the reference)
             for (int i = 0; i + 1 < K; ++i) stamp[i] = stamp[i + 1];
             FrameInit fr;
             rd.d(&fr.t, 1); rd.d(fr.pose, 7); rd.d(fr.sb, 9);
