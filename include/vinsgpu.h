@@ -251,6 +251,16 @@ int vg_ba_batch_flops(vg_handle* h, double* solve_flops, double* marg_flops);
 typedef int (*vg_allreduce_fn)(void* user, double* device_buf, size_t count, void* stream);
 int vg_ba_set_allreduce(vg_handle* h, vg_allreduce_fn fn, void* user);       /* fn == NULL: single rank */
 int vg_ba_set_large_window(vg_handle* h, int force);     /* force != 0: take the large-window path whatever the size */
+
+/* Form of the prior factor the marginalization hands back (marginalization_factor.cpp:285-296 builds J0 = S^1/2 V^T,
+ * r0 = S^-1/2 V^T b' from the eigen-decomposition A' = V S V^T of the kept system).  Everything downstream uses the factor
+ * only through J0^T J0, J0^T r0 and |r0|^2, which do not change under an orthogonal transformation from the left:
+ *   VG_MARG_SQRT  (default)  J0 = L^T, r0 = L^-1 b' from the diagonally pivoted Cholesky factor of A', cut where no remaining
+ *                            pivot exceeds eps = 1e-8 (the reference cuts eigenvalues at the same eps);
+ *   VG_MARG_EIGEN            the reference's eigen form (rows ordered by ascending eigenvalue).
+ * Takes effect at the next upload / vg_ba_optimize. */
+enum { VG_MARG_SQRT = 0, VG_MARG_EIGEN = 1 };
+int vg_ba_set_marg_mode(vg_handle* h, int mode);
 int vg_ba_reduce_layout(vg_handle* h, size_t* count_system, size_t* count_norms);
 
 /* Batched factor evaluation for parity tests (rows B2-B5 of SURVEY.md 8(a)): evaluates every

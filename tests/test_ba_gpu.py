@@ -203,6 +203,45 @@ def test_marginalize_old_parity(handle, ex, td):
     _check_prior(pr_g, pr_o)
 
 
+@pytest.mark.parametrize("flag", ["old", "second_new"])
+def test_marginalization_eigen_form_matches_the_square_root_form(handle, flag):
+    """vg_ba_set_marg_mode: the default prior factor is the pivoted-Cholesky square root of the kept system, VG_MARG_EIGEN the
+    reference's S^1/2 V^T (marginalization_factor.cpp:285-296).  Both must reproduce the same (A', b') — what everything downstream
+    consumes — and the same constant |r0|^2 = b'^T A'^+ b'; the next solve must not see the difference."""
+    if flag == "old":
+        seq = synth.SyntheticSequence(43, L=80)
+        prob = seq.window(0)
+        mflag = ba.VG_MARGIN_OLD
+    else:
+        seq, _, prob = _window_with_prior(6, L=150)
+        mflag = ba.VG_MARGIN_SECOND_NEW
+    out = {}
+    for mode in (ba.VG_MARG_SQRT, ba.VG_MARG_EIGEN):
+        handle.ba_set_marg_mode(mode)
+        try:
+            out[mode] = handle.ba_optimize(prob, mflag)
+        finally:
+            handle.ba_set_marg_mode(ba.VG_MARG_SQRT)
+    (st_a, _, pa), (st_b, _, pb) = out[ba.VG_MARG_SQRT], out[ba.VG_MARG_EIGEN]
+    assert np.array_equal(st_a['pose'], st_b['pose'])            # the solve is the same launch sequence
+    assert pa['blocks'] == pb['blocks'] and pa['n'] == pb['n']
+    Ha, Hb = pa['J0'].T @ pa['J0'], pb['J0'].T @ pb['J0']
+    ga, gb = pa['J0'].T @ pa['r0'], pb['J0'].T @ pb['r0']
+    assert np.abs(Ha - Hb).max() < 1e-7 * np.abs(Hb).max()
+    assert np.abs(ga - gb).max() < 1e-6 * (np.abs(pb['J0']).T @ np.abs(pb['r0'])).max()
+    assert np.isclose(pa['r0'] @ pa['r0'], pb['r0'] @ pb['r0'], rtol=1e-4)
+    assert np.count_nonzero(np.abs(pa['J0']).sum(axis=1)) <= pa['n']
+    if flag == "old":
+        nxt_a, nxt_b = seq.next_window(st_a, pa, 1), None
+        seq2 = synth.SyntheticSequence(43, L=80)
+        seq2.window(0)
+        nxt_b = seq2.next_window(st_b, pb, 1)
+        s2a, sma, _ = handle.ba_optimize(nxt_a)
+        s2b, smb, _ = handle.ba_optimize(nxt_b)
+        assert sma['num_iterations'] == smb['num_iterations']
+        assert np.abs(s2a['pose'] - s2b['pose']).max() < 1e-6 and np.abs(s2a['sb'] - s2b['sb']).max() < 1e-6
+
+
 def test_optimization_chain_two_windows(handle):
     """solve + MARGIN_OLD twice; each side consumes its OWN prior and state (what a drop-in runs)."""
     seq = synth.SyntheticSequence(40, L=60)

@@ -42,9 +42,16 @@ def test_emulated_marginalization_matches_oracle(simt_handle):
     at = dict(prob)
     at.update(pose=x['pose'], sb=x['sb'], ex=x['ex'], td=x['td'], inv_depth=x['inv_depth'], max_iters=0)
     _, _, pr_o = B.optimization(at, B.MARGIN_OLD)
-    st_g, sm_g, pr_g = simt_handle.ba_optimize(at, ba.VG_MARGIN_OLD)
-    assert sm_g['status'] == 0
-    _check_prior(pr_g, pr_o)
+    for mode in (ba.VG_MARG_SQRT, ba.VG_MARG_EIGEN):          # pivoted-Cholesky square root (default) / the reference's eigen form
+        simt_handle.ba_set_marg_mode(mode)
+        try:
+            st_g, sm_g, pr_g = simt_handle.ba_optimize(at, ba.VG_MARGIN_OLD)
+        finally:
+            simt_handle.ba_set_marg_mode(ba.VG_MARG_SQRT)
+        assert sm_g['status'] == 0
+        _check_prior(pr_g, pr_o)
+        rows = int((np.abs(pr_g['J0']).sum(axis=1) > 0).sum())
+        assert rows < pr_g['n']                                  # a first window is gauge-deficient: the cut removes directions
 
 
 @pytest.mark.parametrize("K", [4, 7, 12])

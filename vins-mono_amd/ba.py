@@ -10,6 +10,7 @@ from . import lib
 
 VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
+VG_MARG_SQRT, VG_MARG_EIGEN = 0, 1     # vg_ba_set_marg_mode
 VG_OK = 0
 VG_ABI_VERSION = 3          # include/vinsgpu.h
 _pd = C.POINTER(C.c_double)
@@ -193,6 +194,7 @@ class Handle:
         L.vg_ba_batch_flops.argtypes = [C.c_void_p, _pd, _pd]
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
         L.vg_ba_set_large_window.argtypes = [C.c_void_p, C.c_int]
+        L.vg_ba_set_marg_mode.argtypes = [C.c_void_p, C.c_int]
         L.vg_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         L.vg_ba_reduce_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.vg_triangulate.argtypes = [C.c_void_p, C.c_int, _pd, _pd, _pd, _pd, C.c_int, _pi, _pi, _pi, _pd, C.c_double, _pd]
@@ -246,6 +248,10 @@ class Handle:
         self._chk(self.lib.vg_ba_batch_run_async(self.h), "vg_ba_batch_run_async")
 
     # ---- large windows / landmark shards (include/vinsgpu.h "Large windows and landmark shards")
+    def ba_set_marg_mode(self, mode):
+        """VG_MARG_SQRT (0, default) / VG_MARG_EIGEN (1): form of the prior factor (include/vinsgpu.h)."""
+        self._chk(self.lib.vg_ba_set_marg_mode(self.h, int(mode)), "vg_ba_set_marg_mode")
+
     def ba_set_large_window(self, force=True):
         self._chk(self.lib.vg_ba_set_large_window(self.h, 1 if force else 0), "vg_ba_set_large_window")
 

@@ -367,6 +367,7 @@ static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, 
     }
     hdr[H_L] = p->L; hdr[H_F] = F; hdr[H_NPRIOR] = p->prior_n; hdr[H_NBLK] = p->prior_n ? p->prior_nblocks : 0;
     hdr[H_MAXIT] = p->max_iters; hdr[H_NCHUNK] = nchunk; hdr[H_MARGIN] = margin; hdr[H_STATUS] = 0;
+    hdr[H_MARGMODE] = h->ba.marg_mode;
     // state
     memcpy(di + L.do_pose, p->pose, sizeof(double) * 7 * K);
     if (Kp > K) {
@@ -597,6 +598,13 @@ extern "C" int vg_ba_batch_run_async(vg_handle* h) {
 extern "C" int vg_ba_set_large_window(vg_handle* h, int force) {
     if (!h) return VG_ERR_BAD_ARG;
     h->ba.force_large = force != 0;
+    h->ba.uploaded = false;
+    return VG_OK;
+}
+// Form of the new prior factor (see sqrt_factor in ba_marg.hip).  Takes effect at the next upload.
+extern "C" int vg_ba_set_marg_mode(vg_handle* h, int mode) {
+    if (!h || (mode != VG_MARG_SQRT && mode != VG_MARG_EIGEN)) return VG_ERR_BAD_ARG;
+    h->ba.marg_mode = mode;
     h->ba.uploaded = false;
     return VG_OK;
 }

@@ -23,7 +23,7 @@
 #define BA_SUM_DOUBLES 16     // init cost, cost, radius, gauge rot_diff (9), post-solve position of frame 0 (3)
 #define BA_HDR_INTS 16
 
-enum { H_L = 0, H_F, H_NPRIOR, H_NBLK, H_MAXIT, H_NCHUNK, H_MARGIN, H_STATUS };
+enum { H_L = 0, H_F, H_NPRIOR, H_NBLK, H_MAXIT, H_NCHUNK, H_MARGIN, H_STATUS, H_MARGMODE };
 
 // per-window solver state that lives in HBM between the launches of one solve (doubles; integers stored exactly)
 enum {

@@ -13,6 +13,7 @@
 //   M5  kept-block list re-labelled for the slid window (addr_shift, estimator.cpp:913-930 / :969-996)
 // The eigen-solver is a parallel two-sided Jacobi (round-robin pairing, 2x2 block owners) held in LDS.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "ba_layout.h"
 #include "ba_factors.h"
 #include "../../include/vinsgpu.h"
@@ -680,6 +681,78 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
     return sweep | (attempts << 8);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Square-root form of the new prior WITHOUT an eigen-decomposition (VG_MARG_SQRT, the default).
+// marginalization_factor.cpp:285-296 turns the kept system (A', b') into a factor  J0 = S^1/2 V^T ,  r0 = S^-1/2 V^T b'  from
+// A' = V S V^T.  Everything downstream — MarginalizationFactor::Evaluate (:333-381), the solver, the next marginalization —
+// sees that factor only through  J0^T J0 = A' ,  J0^T r0 = b'  and  |r0|^2 = b'^T A'^+ b' : all three are unchanged when J0
+// and r0 are multiplied from the left by an orthogonal matrix (the eigenvector signs / order Eigen happens to return are such
+// a freedom already).  The diagonally pivoted Cholesky factor  P^T A' P = L L^T  is such a factor:  J0 = L^T ,  r0 = L^-1 b'.
+// The reference's cut `lambda > eps` (eps = 1e-8, marginalization_factor.h:70) drops the directions in which A' carries no
+// information (the gauge freedoms of the window: their eigenvalues are rounding noise); the pivoted factorisation stops when
+// no remaining diagonal entry of the Schur complement exceeds the same eps: rank r, rows r .. n-1 of J0 and r0 are zero, and
+// J0^T J0 differs from A' by that residual (<= (n - r) eps in trace when it is positive semi-definite, rounding noise
+// otherwise) — the same order as the part the eigenvalue cut removes.  75 dependent pivots instead of ~7 Jacobi sweeps of 75
+// rounds: 1.41M -> ~0.1M cycles per window.  b' rides along as an augmented row, so r0 needs no separate substitution.
+// On exit: column k of L at V[k * ld + i] (k < rank; zero for the rows pivoted earlier), y = r0 in cs[2n .. 3n).  Returns rank.
+DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, const double* bglob) {
+    double* A = MG_LDS + offM;
+    double* Lc = MG_LDS + offV;               // column k of L at Lc[k * ld + i]
+    double* dgn = MG_LDS + offcs;             // running diagonal of the Schur complement
+    double* bl = dgn + n;                     // b'
+    double* yv = bl + n;                      // y = L^-1 P^T b'
+    int* taken = (int*)(yv + n);
+    double* red = MG_LDS + offred;
+    __syncthreads();
+    for (int i = c.tid; i < n; i += MG_NT) { dgn[i] = A[i * ld + i]; taken[i] = 0; bl[i] = bglob[i]; yv[i] = 0.0; }
+    for (int k = c.tid; k < n * ld; k += MG_NT) Lc[k] = 0.0;
+    __syncthreads();
+    int rank = 0;
+    for (int k = 0; k < n; ++k) {
+        // pivot = largest remaining diagonal (lowest index on ties), found by wavefront 0 (two entries per lane, DPP max)
+        if (c.wave == 0) {
+            const int i0 = c.lane, i1 = c.lane + 64;
+            const double v0 = (i0 < n && !taken[i0]) ? dgn[i0] : -1e300;
+            const double v1 = (i1 < n && !taken[i1]) ? dgn[i1] : -1e300;
+            const double bv = wave_max_all(fmax(v0, v1));
+            const unsigned long long m0 = __ballot(v0 == bv), m1 = __ballot(v1 == bv);
+            if (c.lane == 0) { red[17] = bv; red[18] = (double)(m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1); }
+        }
+        __syncthreads();
+        const double best = red[17];
+        const int p = (int)red[18];
+        if (!(best > MG_EPS)) break;          // (uniform) nothing above eps is left: the rest is what the reference's cut drops
+        const double inv = mg_rsqrt(best);
+        // L[i][k] = (A'[i][p] - sum_{j<k} L[i][j] L[p][j]) / L[p][k] for the rows not pivoted yet and for the augmented row
+        // i == n that carries b' (its "L" entries are y); 8 lanes per row
+        const int g8 = c.tid >> 3, s8 = c.tid & 7;
+        for (int i0 = 0; i0 <= n; i0 += MG_NT / 8) {
+            const int i = i0 + g8;
+            const bool aug = i == n;
+            const bool on = aug || (i < n && !taken[i]);
+            double sacc = 0.0;
+            if (on) {
+                if (aug) { for (int j = s8; j < k; j += 8) sacc += yv[j] * Lc[j * ld + p]; }
+                else     { for (int j = s8; j < k; j += 8) sacc += Lc[j * ld + i] * Lc[j * ld + p]; }
+            }
+            sacc = group8_sum(sacc);
+            if (on && s8 == 0) {
+                if (aug) yv[k] = (bl[p] - sacc) * inv;
+                else {
+                    const double v = i == p ? best * inv : (A[i * ld + p] - sacc) * inv;
+                    Lc[k * ld + i] = v;
+                    if (i != p) dgn[i] -= v * v;
+                    else taken[p] = 1;             // by the lane that owns row p, after its 8-lane group has tested the flag
+                }
+            }
+        }
+        rank = k + 1;
+        __syncthreads();
+    }
+    __syncthreads();
+    return rank;
+}
+
 DEV bool mg_fast_ok(int n) {
     const int half = (n + 1) / 2;
     return n >= 2 && half * (half + 1) / 2 <= MG_NT && n * half <= 4 * (MG_NT - 64);
@@ -1250,6 +1323,18 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
 #endif
     const int offcs2 = (int)(cs - MG_LDS), offred2 = (int)(red - MG_LDS);
     const bool fast2 = n_lds && n >= 1 && n <= 16 * MG_HROWS;
+    if (fast2 && c.hdr[H_MARGMODE] == 0) {
+        // square-root form by pivoted Cholesky (see sqrt_factor): J0 = L^T, r0 = L^-1 b'
+        const int rk = sqrt_factor(c, 0, ld * ld, n, ld2, offcs2, offred2, bp);
+        const double* yv = cs + 2 * n;
+        if (c.tid == 0) mi[5] = rk << 16;        // rank of the factor (the eigen path reports sweeps | attempts << 8 here)
+        MPROF(6);
+        for (int k = c.tid; k < n * n; k += MG_NT) {
+            const int i = k / n, j = k - i * n;  // row i of J0 = column i of L
+            mo[L.mo_J0 + (size_t)i * mcap + j] = i < rk ? V2[i * ld2 + j] : 0.0;
+        }
+        for (int i = c.tid; i < n; i += MG_NT) mo[L.mo_r0 + i] = i < rk ? yv[i] : 0.0;
+    } else {
     // Column orthogonality 1e-9 (relative).  The reconstruction sum_i (|g_i|^2 - delta) u_i u_i^T = A does not depend on how
     // far the sweeps went (G G^T is invariant under the rotations); what converges are the individual eigenvalues, which
     // only matter for the eps = 1e-8 cut: theta = 1e-9 moves a small eigenvalue by ~theta^2 lambda_max ~ 1e-11, two decades
@@ -1296,6 +1381,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         }
         mo[L.mo_r0 + rank[i]] = s;
     }
+    }   // eigen form
     MPROF(7);
     // ---- M5: kept blocks, re-labelled for the slid window, with their linearisation point
     if (c.tid == 0) {
@@ -1327,11 +1413,18 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
 }
 
 extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ba_marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {   // per device, under a mutex (see set_lds_attrs in ba_pipeline.hip)
+        static std::mutex mu;
+        static unsigned long long done_mask = 0;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!(dev >= 0 && dev < 64 && ((done_mask >> dev) & 1ull))) {
+            e = hipFuncSetAttribute((const void*)ba_marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
+        }
     }
     hipLaunchKernelGGL(ba_marg_kernel, dim3(L.nwin), dim3(MG_NT), L.mg_lds_bytes, stream, dL, P);
     return hipGetLastError();

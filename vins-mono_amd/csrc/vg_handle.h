@@ -40,6 +40,7 @@ struct BaBatch {
     bool uploaded = false, any_margin = false;
     bool solved_recorded = false;    // ev_fork recorded behind ba_final_kernel of the current run
     bool force_large = false;        // vg_ba_set_large_window: take the large-window path whatever the size
+    int marg_mode = 0;               // vg_ba_set_marg_mode: VG_MARG_SQRT (default) / VG_MARG_EIGEN
     void* allreduce = nullptr;       // vg_allreduce_fn of the large-window path (nullptr: single rank)
     void* allreduce_user = nullptr;
     double flops = 0, flops_marg = 0, bytes_in = 0, bytes_out = 0;
