@@ -17,7 +17,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_ref", "libvins_ref.so")
 _REF_SRC = "/root/reference/vins_estimator/src/estimator.cpp"
+_LIB_GPU = os.path.join(_HERE, "_ref", "libvins_ref_gpu.so")
 _lib = None
+_lib_gpu = None
 K_REF = 11                       # WINDOW_SIZE + 1 is a compile-time constant of the reference (parameters.h:12)
 DP, IP = C.POINTER(C.c_double), C.POINTER(C.c_int)
 KIND_POSE, KIND_SB, KIND_EX, KIND_TD = 0, 1, 2, 3
@@ -36,12 +38,33 @@ def lib():
             subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
         if not os.path.exists(_LIB):
             raise RuntimeError("oracle/_ref/libvins_ref.so is missing and /root/reference is not here to build it")
-        L = C.CDLL(_LIB)
-        assert L.vref_abi_version() == 1 and L.vref_window_size() == K_REF - 1
-        for name in ("vref_preint_create", "vref_preint_from_terms", "vref_est_create", "vref_est_get_preintegration"):
-            getattr(L, name).restype = C.c_void_p
-        _lib = L
+        _lib = _prepare(C.CDLL(_LIB))
+        assert _lib.vref_has_gpu_optimization() == 0
     return _lib
+
+
+def _prepare(L):
+    assert L.vref_abi_version() == 1 and L.vref_window_size() == K_REF - 1
+    for name in ("vref_preint_create", "vref_preint_from_terms", "vref_est_create", "vref_est_get_preintegration"):
+        getattr(L, name).restype = C.c_void_p
+    return L
+
+
+def gpu_available():
+    return os.path.exists(_LIB_GPU)
+
+
+def lib_gpu():
+    """libvins_ref_gpu.so: the same reference objects with Estimator::optimization() replaced by the product's drop-in body
+    (vins-mono_amd/host/dropin/estimator_optimization.cpp -> libvinsgpu.so).  Needs a GPU at the first optimization()."""
+    global _lib_gpu
+    if _lib_gpu is None:
+        lib()                                    # (builds both when the reference is present)
+        if not os.path.exists(_LIB_GPU):
+            raise RuntimeError("oracle/_ref/libvins_ref_gpu.so is missing")
+        _lib_gpu = _prepare(C.CDLL(_LIB_GPU))
+        assert _lib_gpu.vref_has_gpu_optimization() == 1
+    return _lib_gpu
 
 
 def _d(a):
@@ -60,23 +83,24 @@ def _q2R(q):
 
 
 def configure(acc_n=0.08, acc_w=0.00004, gyr_n=0.004, gyr_w=2.0e-6, g_norm=9.81007, estimate_extrinsic=0, estimate_td=0,
-              td=0.0, tr=0.0, row=480.0, num_iterations=8, init_depth=5.0, min_parallax=10.0 / 460.0, ric=None, tic=None):
-    """The globals readParameters() would fill (vins_estimator/src/parameters.cpp:42-137)."""
+              td=0.0, tr=0.0, row=480.0, num_iterations=8, init_depth=5.0, min_parallax=10.0 / 460.0, ric=None, tic=None, L=None):
+    """The globals readParameters() would fill (vins_estimator/src/parameters.cpp:42-137).  They are per library: pass L =
+    lib_gpu() to configure the drop-in build."""
     ric = _d(np.eye(3) if ric is None else ric)
     tic = _d(np.zeros(3) if tic is None else tic)
-    lib().vref_set_config(C.c_double(acc_n), C.c_double(acc_w), C.c_double(gyr_n), C.c_double(gyr_w), C.c_double(g_norm),
+    (L or lib()).vref_set_config(C.c_double(acc_n), C.c_double(acc_w), C.c_double(gyr_n), C.c_double(gyr_w), C.c_double(g_norm),
                           int(estimate_extrinsic), int(estimate_td), C.c_double(td), C.c_double(tr), C.c_double(row), int(num_iterations),
                           C.c_double(init_depth), C.c_double(min_parallax), _p(ric), _p(tic))
 
 
-def configure_for(prob, cfg=None):
+def configure_for(prob, cfg=None, L=None, min_parallax=10.0 / 460.0):
     """Globals for a test window (`vins_mono_amd.synth` layout)."""
     from vins_mono_amd import synth
     c = dict(synth.EUROC if cfg is None else cfg)
     assert prob['focal'] == 460.0, "FOCAL_LENGTH is a compile-time constant of the reference (parameters.h:11)"
     configure(c['acc_n'], c['acc_w'], c['gyr_n'], c['gyr_w'], prob['g_norm'], prob['estimate_extrinsic'], prob['estimate_td'],
-              float(prob['td']), float(prob['tr']), float(prob['row']), int(prob['max_iters']), 5.0, 10.0 / 460.0,
-              _q2R(prob['ex'][3:]), prob['ex'][:3])
+              float(prob['td']), float(prob['tr']), float(prob['row']), int(prob['max_iters']), 5.0, min_parallax,
+              _q2R(prob['ex'][3:]), prob['ex'][:3], L=L)
 
 
 # ------------------------------------------------------------------------------------------ small entry points
@@ -194,8 +218,8 @@ def projection_td_factor(pose_i, pose_j, ex, inv_dep, td, obs_i, obs_j, need_jac
 class Estimator:
     """The reference's `Estimator` object (estimator.h:26-139)."""
 
-    def __init__(self):
-        self.L = lib()
+    def __init__(self, L=None):
+        self.L = L or lib()
         self.h = self.L.vref_est_create()
 
     def close(self):
@@ -476,3 +500,82 @@ def factor_tables(prob):
         ir[k] = r
         iJ[k] = np.hstack([J[0][:, :6], J[1], J[2][:, :6], J[3]])
     return pr, pJ, ir, iJ
+
+
+def run_sequence(seq, n_frames, L=None, min_parallax=10.0 / 460.0, noise_seed=0):
+    """The reference's own per-frame loop on a synthetic sequence: Estimator::processIMU for every IMU sample and
+    Estimator::processImage for every frame (estimator.cpp:81-215) — feature bookkeeping, key-frame decision by parallax,
+    triangulation, optimization(), failure detection, slideWindow() for BOTH marginalization flags with the IMU buffers merged
+    (:1069-1099), removeFailures.  The SfM bootstrap (initial/*) is bypassed: the first WINDOW_SIZE frames are collected in
+    INITIAL mode exactly as the reference does, then the window is given noisy ground-truth states and switched to
+    NON_LINEAR (what initialStructure() + visualInitialAlign() hand over).
+    L: lib() (all reference) or lib_gpu() (optimization() = the product's drop-in).  Returns a list of per-frame records."""
+    L = L or lib()
+    K = K_REF
+    c = seq.cfg
+    base = seq._base()
+    configure_for(base, c, L=L, min_parallax=min_parallax)
+    rng = np.random.default_rng(noise_seed)
+    e = Estimator(L=L)
+    H = C.c_void_p(e.h)
+    h = seq.frame_dt / seq.imu_per_frame
+
+    def noisy_state(f):
+        th = rng.normal(0, np.radians(0.3), 3)
+        Rn = seq.Rm[f] @ (np.eye(3) + np.array([[0, -th[2], th[1]], [th[2], 0, -th[0]], [-th[1], th[0], 0]]))
+        q = quat_from_R(Rn)
+        q = q / np.linalg.norm(q)
+        return np.concatenate([seq.P[f] + rng.normal(0, 0.03, 3), q]), np.concatenate([seq.V[f] + rng.normal(0, 0.03, 3), seq.ba_lin, seq.bg_lin])
+
+    def feed_imu(f):                                   # the samples between frame f and f + 1
+        t = seq.times[f]
+        for s_ in range(1, seq.imu_per_frame + 1):
+            a, g = seq._imu_sample(t + s_ * h)
+            L.vref_est_process_imu(H, C.c_double(h), _p(_d(a)), _p(_d(g)))
+
+    def image(f):
+        ids, rows = [], []
+        for lid, lm in enumerate(seq.lm):
+            k = f - lm['f0']
+            if 0 <= k < len(lm['obs']):
+                xy = lm['obs'][k]
+                prev = lm['obs'][k - 1] if k > 0 else xy
+                vel = (xy - prev) / seq.frame_dt
+                ids.append(lid)
+                rows.append([xy[0], xy[1], 1.0, c['fx'] * xy[0] + c['cx'], c['fy'] * xy[1] + c['cy'], vel[0], vel[1]])
+        ids = np.array(ids, np.int32)
+        rows = _d(rows)
+        L.vref_est_process_image(H, C.c_double(float(seq.times[f])), len(ids), ids.ctypes.data_as(IP), _p(rows))
+
+    out = []
+    try:
+        L.vref_est_set_extrinsic(H, _p(_d(_q2R(base['ex'][3:]))), _p(_d(base['ex'][:3])), C.c_double(0.0))
+        L.vref_est_set_g(H, _p(_d([0.0, 0.0, c['g_norm']])))
+        zero = np.zeros(3)
+        for i in range(K):                             # linearisation biases of the pre-integrations created in INITIAL mode
+            L.vref_est_set_frame(H, i, _p(zero), _p(_d(np.eye(3))), _p(zero), _p(_d(seq.ba_lin)), _p(_d(seq.bg_lin)))
+        a0, g0 = seq._imu_sample(seq.times[0])
+        L.vref_est_process_imu(H, C.c_double(0.0), _p(_d(a0)), _p(_d(g0)))     # first_imu: acc_0 / gyr_0
+        for f in range(K - 1):                         # frames 0 .. WINDOW_SIZE-1: INITIAL mode only counts them in
+            if f > 0:
+                feed_imu(f - 1)
+            image(f)
+        assert L.vref_est_get_frame_count(H) == K - 1 and L.vref_est_get_solver_flag(H) == 0
+        for i in range(K - 1):
+            pose, sb = noisy_state(i)
+            e.set_frame(i, pose, sb)
+        pose, sb = noisy_state(K - 2)                  # slot WINDOW_SIZE starts from the previous frame and is propagated by processIMU
+        e.set_frame(K - 1, pose, sb)
+        L.vref_est_set_solver_flag(H, 1)
+        L.vref_est_set_last_from_window(H)
+        for f in range(K - 1, n_frames):
+            feed_imu(f - 1)
+            image(f)
+            pose, sb, ex, td = e.para()
+            feats = e.features()
+            out.append(dict(frame=f, flag=int(L.vref_est_get_marginalization_flag(H)), pose=pose.copy(), sb=sb.copy(), ex=ex.copy(), td=td,
+                            n_features=len(feats['id']), depth=dict(zip(feats['id'].tolist(), feats['depth'].tolist())),
+                            solver_flag=int(L.vref_est_get_solver_flag(H)), prior=e.get_prior()))
+    finally:
+        e.close()
+    return out
