@@ -419,6 +419,42 @@ def main():
     overlapped_ms = (time.perf_counter() - tb0) / (nb_pipe + 1) * 1e3
     if hb not in handles:
         hb.close()
+    # the same boundary with one HOST THREAD PER HANDLE (the calls release the GIL; the C-ABI is re-entrant across handles):
+    # every thread loops upload -> run_async -> download on its own handle / stream / pinned staging, so the pack + H2D and
+    # D2H + unpack of some batches always run beside the kernels of another
+    import threading
+    nthr = 4
+    th_handles = (handles + [ba.Handle() for _ in range(max(0, nthr - len(handles)))])[:nthr]
+    for hh in th_handles:
+        hh.ba_upload(packed, flags); hh.ba_prepare_download()
+    nb_thr = 6
+    errs = []
+
+    def boundary_worker(hh, nb):
+        try:
+            for _ in range(nb):
+                hh.ba_upload(packed, flags); hh.ba_run_async()
+                rc = hh.ba_download_raw()
+                if rc != 0:
+                    errs.append(rc)
+        except Exception as ex:                       # noqa: BLE001
+            errs.append(repr(ex))
+
+    def threaded(nb):
+        ts = [threading.Thread(target=boundary_worker, args=(hh, nb)) for hh in th_handles]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    threaded(1)
+    tt0 = time.perf_counter()
+    threaded(nb_thr)
+    threaded_ms = (time.perf_counter() - tt0) / (nb_thr * nthr) * 1e3
+    if errs:
+        raise SystemExit(f"threaded boundary loop failed: {errs[:3]}")
+    for hh in th_handles:
+        if hh not in handles:
+            hh.close()
     h.ba_upload(packed, flags)
     h.ba_run_async()
 
@@ -544,10 +580,16 @@ def main():
                                         "sync_solves_per_s": nwin / ((up_ms + solve_ms + marg_ms + dn_ms) * 1e-3),
                                         "overlapped_ms_per_batch": overlapped_ms,
                                         "overlapped_solves_per_s": nwin / (overlapped_ms * 1e-3),
+                                        "threaded_ms_per_batch": threaded_ms, "threaded_host_threads": nthr,
+                                        "threaded_solves_per_s": nwin / (threaded_ms * 1e-3),
+                                        "threaded_over_device_resident": (nwin / (threaded_ms * 1e-3)) / value,
                                         "what": "host buffers in, host buffers out: vg_ba_batch_upload (pack + H2D) + all launches + "
                                                 "vg_ba_batch_download (D2H + unpack), per GPU; sync = one batch at a time, nothing "
                                                 "overlapped; overlapped = two handles (streams, pinned staging) driven by one host thread, the "
-                                                "pack + upload of batch i+1 issued while batch i runs, then batch i downloaded; NOT the metric"},
+                                                "pack + upload of batch i+1 issued while batch i runs, then batch i downloaded; threaded = one host "
+                                                "thread per handle (4 handles), each looping upload -> run -> download, so the host work of some "
+                                                "batches always runs beside the kernels of another: the rate a caller with host buffers gets from one "
+                                                "GPU; NOT the metric (bench contract: `value` is device-resident)"},
         }
     fe_out = bench_fe(h, synth, max(args.steps, 10), args.warmup, rank, rank == 0 and world == 1 and not args.no_cpu_baseline)
     fe_out["value_all_gpus"] = D.sum_over_ranks(fe_out["value"])

@@ -280,6 +280,12 @@ class Estimator:
         n = self.L.vref_est_get_features(C.c_void_p(self.h), cap, ids.ctypes.data_as(IP), st.ctypes.data_as(IP), nb.ctypes.data_as(IP), _p(dep), fl.ctypes.data_as(IP))
         return dict(id=ids[:n], start=st[:n], nobs=nb[:n], depth=dep[:n], solve_flag=fl[:n])
 
+    def last_trace(self):
+        """Per-iteration rows [valid, accepted, cost, candidate cost, radius, step norm] of this estimator's last optimization()."""
+        rows = np.zeros((40, 6))
+        n = self.L.vref_est_last_trace(C.c_void_p(self.h), 40, _p(rows))
+        return rows[:min(n, 40)].copy()
+
     def solve_trace(self):
         rows, ic, fc, term = np.zeros((64, 10)), C.c_double(), C.c_double(), C.c_int()
         n = self.L.vref_last_solve_trace(64, _p(rows), C.byref(ic), C.byref(fc), C.byref(term))
@@ -575,7 +581,8 @@ def run_sequence(seq, n_frames, L=None, min_parallax=10.0 / 460.0, noise_seed=0)
             feats = e.features()
             out.append(dict(frame=f, flag=int(L.vref_est_get_marginalization_flag(H)), pose=pose.copy(), sb=sb.copy(), ex=ex.copy(), td=td,
                             n_features=len(feats['id']), depth=dict(zip(feats['id'].tolist(), feats['depth'].tolist())),
-                            solver_flag=int(L.vref_est_get_solver_flag(H)), prior=e.get_prior()))
+                            solver_flag=int(L.vref_est_get_solver_flag(H)), prior=e.get_prior(), iterations=int(L.vref_est_last_iterations(H)),
+                            trace=e.last_trace()))
     finally:
         e.close()
     return out

@@ -14,6 +14,7 @@
 #include <new>
 
 #include "estimator.h"
+#include "vinsgpu.h"        // (struct vg_ba_summary only: the trace of the drop-in build; no symbol of libvinsgpu is referenced here)
 
 // ---- globals of vins_estimator/src/parameters.cpp:3-33 (EuRoC defaults; vref_set_config overwrites them)
 double INIT_DEPTH = 5.0;
@@ -57,6 +58,8 @@ extern Solver::Summary vins_ref_last_summary;   // ref_stubs/ceres/solver_stub.c
 // replaced by the product's drop-in body (vins-mono_amd/host/dropin/estimator_optimization.cpp -> libvinsgpu.so).
 extern "C" void vins_gpu_collect_prior(Estimator *) __attribute__((weak));
 extern "C" void vins_gpu_release(Estimator *) __attribute__((weak));
+extern "C" int vins_gpu_last_iterations(Estimator *) __attribute__((weak));
+extern "C" const vg_ba_summary *vins_gpu_last_summary(Estimator *) __attribute__((weak));
 
 namespace {
 Eigen::Matrix3d mat3(const double *rowmajor) {
@@ -486,6 +489,33 @@ void vref_est_optimization(void *p) { as_est(p)->optimization(); }
 void vref_est_solve_odometry(void *p) { as_est(p)->solveOdometry(); }
 void vref_est_slide_window(void *p) { as_est(p)->slideWindow(); }
 int vref_est_failure_detection(void *p) { return as_est(p)->failureDetection() ? 1 : 0; }
+
+// trust-region iterations of the last optimization() (Ceres counts the initial evaluation as iteration 0)
+int vref_est_last_iterations(void *p) {
+    if (vins_gpu_last_iterations) return vins_gpu_last_iterations(as_est(p));
+    return static_cast<int>(ceres::vins_ref_last_summary.iterations.size()) - 1;
+}
+
+// per-iteration trace of the last optimization() of THIS estimator, whichever build: rows of 6
+// [valid, accepted, cost, candidate cost, trust-region radius, step norm]
+int vref_est_last_trace(void *p, int cap, double *rows6) {
+    int k = 0;
+    if (vins_gpu_last_summary) {
+        const vg_ba_summary *s = vins_gpu_last_summary(as_est(p));
+        for (; k < s->num_iterations && k < cap; k++) {
+            double *r = rows6 + 6 * k;
+            r[0] = s->it_flags[k] & 1, r[1] = (s->it_flags[k] >> 1) & 1, r[2] = s->it_cost[k], r[3] = s->it_cost_cand[k], r[4] = s->it_radius[k], r[5] = s->it_step_norm[k];
+        }
+        return s->num_iterations;
+    }
+    const ceres::Solver::Summary &s = ceres::vins_ref_last_summary;
+    for (size_t i = 1; i < s.iterations.size() && k < cap; i++, k++) {
+        const ceres::IterationSummary &it = s.iterations[i];
+        double *r = rows6 + 6 * k;
+        r[0] = it.step_is_valid, r[1] = it.step_is_successful, r[2] = it.cost, r[3] = it.candidate_cost, r[4] = it.trust_region_radius, r[5] = it.step_norm;
+    }
+    return static_cast<int>(s.iterations.size()) - 1;
+}
 
 // ---- trace of the last ceres::Solve (restated minimiser): rows of 10
 // [iteration, valid, successful, cost, candidate_cost, model_cost_change, trust_region_radius, step_norm, mu, exit_reason]

@@ -449,6 +449,26 @@ def test_ragged_batch_matches_single_windows(handle):
     assert pr[0] is None and pr[1] is not None
 
 
+def test_throughput_and_latency_layouts_agree(handle):
+    """The IMU / prior linearisation runs as one workgroup per window in a full batch and as (K-1)/2 + 1 workgroups per window
+    while they all fit the chip at once (BaLayout::nig / nprw): a batch large enough for the first layout must give every window
+    the result it gets alone (second layout).  The cost partials are summed in a different grouping, so equality is to
+    rounding, not bitwise."""
+    seqs = [synth.SyntheticSequence(900 + s, L=40) for s in range(48)]           # 48 * 6 > 256 workgroups: throughput layout
+    probs = [q.window(0) for q in seqs]
+    handle.ba_upload(probs, [ba.VG_MARGIN_OLD] * len(probs))
+    handle.ba_run_async()
+    st, sm, pr = handle.ba_download()
+    for i in (0, 7, 23, 47):
+        s1, m1, p1 = handle.ba_optimize(probs[i], ba.VG_MARGIN_OLD)              # latency layout
+        assert sm[i]['status'] == 0 and sm[i]['num_iterations'] == m1['num_iterations']
+        assert np.array_equal(sm[i]['it_flags'], m1['it_flags'])
+        assert np.abs(st[i]['pose'] - s1['pose']).max() < 1e-9 and np.abs(st[i]['sb'] - s1['sb']).max() < 1e-9
+        assert np.isclose(sm[i]['final_cost'], m1['final_cost'], rtol=1e-10)
+        Ha, Hb = pr[i]['J0'].T @ pr[i]['J0'], p1['J0'].T @ p1['J0']
+        assert np.abs(Ha - Hb).max() < 1e-7 * np.abs(Hb).max()
+
+
 def test_error_behaviour(handle):
     """Status codes instead of exceptions on the data path: a non-finite input poisons only
     its own window (VG_ERR_NUMERIC, failureDetection() territory); structural errors are refused up front."""

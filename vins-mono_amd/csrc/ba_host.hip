@@ -140,7 +140,15 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     if (L.big && L.Rc + 10 > 256) { h->err = "camera part wider than the large-window solve kernel's tiling"; return VG_ERR_UNSUPPORTED; }
     // ---- workgroups per window
     L.nbf = (L.Fcap + BA_LIN_NT - 1) / BA_LIN_NT;
-    L.nbl = L.nbf + 1;
+    // IMU / prior linearisation: spread over workgroups only while all of them fit the chip at once (latency mode)
+    {
+        const int nsplit = (L.K - 1 + BA_IMU_GROUP - 1) / BA_IMU_GROUP;
+        const bool split = (long)nwin * (nsplit + 1) <= 256;
+        L.igs = split ? BA_IMU_GROUP : L.K - 1;
+        L.nig = split ? nsplit : 1;
+        L.nprw = split ? 1 : 0;
+    }
+    L.nbl = L.nbf + L.nig + L.nprw;
     {
         const int nb = L.Kp + L.e + L.t;
         L.ntask = nb * (nb + 1) / 2;
@@ -173,7 +181,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         L.lds_solve = o * 8;
         bigm_doubles = ob;
         if (L.lds_solve > 160 * 1024) { h->err = "solve kernel LDS carve exceeds 160 KB"; return VG_ERR_UNSUPPORTED; }
-        const int nib = std::min(L.K - 1, BA_IMU_BATCH);
+        const int nib = std::min(std::min(L.K - 1, BA_IMU_BATCH), L.igs);
         L.lds_lin = 8 * std::max(up(nib * 225, 2) + nib * 480, 5 * L.Ncap);
         L.lds_pro = 8 * BA_NW * 256;
         if (8 * L.Ncap * L.Ncap <= 128 * 1024) L.lds_pro = std::max(L.lds_pro, 8 * L.Ncap * L.Ncap);   // J0 staged in LDS when it fits

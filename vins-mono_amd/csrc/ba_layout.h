@@ -18,6 +18,9 @@
 #ifndef BA_IMU_BATCH
 #define BA_IMU_BATCH 16           // IMU factors linearised per pass of the linearisation workgroup (LDS panels)
 #endif
+#ifndef BA_IMU_GROUP
+#define BA_IMU_GROUP 2            // IMU factors per workgroup of the linearisation kernel
+#endif
 #define BA_IMU_STRIDE 472         // doubles per vg_imu_preint record on device
 #define BA_OBS_STRIDE 8
 #define BA_SUM_DOUBLES 16     // init cost, cost, radius, gauge rot_diff (9), post-solve position of frame 0 (3)
@@ -54,7 +57,8 @@ struct BaLayout {
     int Rc, RcPad, R, Rpad;        // RcPad = up(Rc + 1, 16): the rhs travels as the augmented row / column Rc
     int Lcap, Fcap, Ocap, Ncap, NBcap;
     int REC;                       // doubles per projection-factor record
-    int nbf, nbl, nba, ntask;      // workgroups per window: projection tiles, linearisation (nbf + 1), accumulation; owner tasks
+    int nbf, nbl, nba, ntask;      // workgroups per window: projection tiles, cost partials (nbf + nig + 1), accumulation; owner tasks
+    int nig, igs, nprw;            // IMU linearisation: groups per window, factors per group (one workgroup each), workgroups for the prior (0: group 0 does it)
     int nst;                       // doubles of one state copy [pose Kp*7 | sb K*9 | ex 7 | td 1]
     // ---- int arrays (offsets in ints, per window)
     int io_hdr, io_lm_start, io_lm_fbeg, io_fac_i, io_fac_j, io_fac_lm, io_fac_oi, io_fac_oj, io_fac_slot,

@@ -402,21 +402,21 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
 //   imuJ [f][512]: 465 lower Hessian entries + 30 gradient entries.   JAC = false: residual only.
 // Returns this thread's share of sum r^2.
 template <bool JAC>
-NOINL double imu_pass(const Ctx& c_in, const double* x_, double* imuJ_) {
+NOINL double imu_pass(const Ctx& c_in, const double* x_, double* imuJ_, int fbeg, int fend) {
     const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
     const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const int nimu = L.K - 1;
+    const int nimu = fend;                    // this workgroup's factors: [fbeg, fend)
     const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
     const glb_d* x = AS_GLB_C(x_);
     glb_d* imuJ = AS_GLB(imuJ_);
     const glb_d* gU = AS_GLB_C(c.sc + L.so_imuU);
-    const int nb = nimu < BA_IMU_BATCH ? nimu : BA_IMU_BATCH;      // factors per pass (one pass for the reference's window)
+    const int nb = fend - fbeg < BA_IMU_BATCH ? fend - fbeg : BA_IMU_BATCH;      // factors per pass (one pass per workgroup normally)
     double* Us = LDSB;                                      // [nb][225]
     double* panels = Us + ((nb * 225 + 1) & ~1);            // [nb][15][32]
     double cost = 0.0;
     const int per = nb > BA_NW ? 2 : 1;
     const int half = c.lane >> 5, hl = c.lane & 31;
-    for (int f0 = 0; f0 < nimu; f0 += nb) {
+    for (int f0 = fbeg; f0 < nimu; f0 += nb) {
         const int nf = nimu - f0 < nb ? nimu - f0 : nb;
         for (int k = c.tid; k < nf * 225; k += BA_NT) Us[k] = gU[f0 * 225 + k];
         __syncthreads();
@@ -655,19 +655,28 @@ extern "C" __global__ __launch_bounds__(BA_LIN_NT, BA_PROJ_WAVES) void ba_linear
 extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_imu_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
     const BaLayout& L = *Lp;
     Ctx c;
-    ctx_init(c, Lp, P, blockIdx.x);
+    ctx_init(c, Lp, P, blockIdx.y);
     const double* ctl = c.sc + L.so_ctl;
     if (ctl[C_DONE] != 0.0) return;
     const int which = ((int)ctl[C_CUR]) ^ (ctl[C_PENDING] != 0.0 ? 1 : 0);
     const double* x = c.sc + L.so_x + which * L.nst;
     double* buf = lin_buf(c, which);
     __shared__ double red[2 * BA_NW];
-    double share;
-    if (cost_only) share = imu_pass<false>(c, x, buf + L.bo_imuJ);
-    else share = imu_pass<true>(c, x, buf + L.bo_imuJ);
-    share += prior_pass(c, x, buf + L.bo_pr, cost_only ? nullptr : buf + L.bo_gpr, LDSB);
+    // grid (nig + nprw, nwin): workgroup g < nig linearises the IMU factors [g igs, (g + 1) igs); the prior is handled by
+    // workgroup nig (nprw = 1) or by workgroup 0 (nprw = 0).  Few windows in the batch (latency matters, the chip is empty):
+    // nig = (K-1)/2 groups + a prior workgroup — the factors are independent chains of dependent steps, spread over
+    // workgroups the launch lasts as long as one group.  Full batches: one workgroup per window (nig = 1, nprw = 0) — six
+    // half-empty workgroups per window cost more issue slots than the latency they save (measured: 40 -> 90 us per launch).
+    const int g = blockIdx.x;
+    double share = 0.0;
+    if (g < L.nig) {
+        const int fbeg = g * L.igs, fend = (fbeg + L.igs < L.K - 1) ? fbeg + L.igs : L.K - 1;
+        if (cost_only) share = imu_pass<false>(c, x, buf + L.bo_imuJ, fbeg, fend);
+        else share = imu_pass<true>(c, x, buf + L.bo_imuJ, fbeg, fend);
+    }
+    if (L.nprw ? g == L.nig : g == 0) share += prior_pass(c, x, buf + L.bo_pr, cost_only ? nullptr : buf + L.bo_gpr, LDSB);
     const double tot = block_sum(red, BA_NW, c.lane, c.wave, share);
-    if (c.tid == 0) c.sc[L.so_part + L.nbf] = tot;
+    if (c.tid == 0) c.sc[L.so_part + L.nbf + g] = tot;
 }
 
 // ================================================================================================
@@ -2785,7 +2794,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     s.phase = 0;
     // cost of the point the linearisation kernels just evaluated: projection factors of all ranks + this rank's copy of the
     // (replicated) IMU / prior factors
-    const double cs = scal[RB1_COST] + c.sc[L.so_part + L.nbf];
+    const double cs = scal[RB1_COST] + sum_partials(c.sc + L.so_part + L.nbf, L.nig + L.nprw);
     bool fresh_point = false;
     if (s.pending) {
         s.step_norm = sqrt(s.step2c + scal[RB1_STEP2]);
@@ -3094,7 +3103,7 @@ extern "C" __global__ __launch_bounds__(256) void ba_final_kernel(const BaLayout
         if (L.big) {
             // large-window path: projection cost and landmark norms of all ranks through reduce buffer 1 (ba_big_schur_kernel)
             const double* scal = P.rb1 + (size_t)w * L.rb1_len + L.rb1_scal;
-            cs = scal[RB1_COST] + c.sc[L.so_part + L.nbf];
+            cs = scal[RB1_COST] + sum_partials(c.sc + L.so_part + L.nbf, L.nig + L.nprw);
             s.step_norm = sqrt(s.step2c + scal[RB1_STEP2]);
             s.x_norm_c = sqrt(s.xn2c + scal[RB1_LAM2]);
         } else {
@@ -3269,11 +3278,11 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
         if (forked) {
             if ((e = hipEventRecord(fk->fork, stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(fk->aux, fk->fork, 0)) != hipSuccess) return e;
-            hipLaunchKernelGGL(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, fk->aux, dL, P, cost_only);
+            hipLaunchKernelGGL(ba_linearize_imu_kernel, dim3(L.nig + L.nprw, L.nwin), dim3(BA_NT), L.lds_lin, fk->aux, dL, P, cost_only);
             if ((e = hipGetLastError()) != hipSuccess) { g_failed_launch = "ba_linearize_imu_kernel"; return e; }
             if ((e = hipEventRecord(fk->join, fk->aux)) != hipSuccess) return e;
         } else {
-            LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only);
+            LAUNCH(ba_linearize_imu_kernel, dim3(L.nig + L.nprw, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only);
         }
         LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only);
         if (kinds) { if (!forked) kinds[nk++] = 1; kinds[nk++] = 1; }
@@ -3317,7 +3326,7 @@ extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL,
     LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P); KIND(0);
     for (int r = 0; r <= rounds; ++r) {
         const int cost_only = r == rounds ? 1 : 0;
-        LAUNCH(ba_linearize_imu_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only); KIND(1);
+        LAUNCH(ba_linearize_imu_kernel, dim3(L.nig + L.nprw, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only); KIND(1);
         LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only); KIND(1);
         if (!cost_only) { LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P); KIND(2); }
         LAUNCH(ba_big_schur_kernel, dim3(L.nts + 1 + BA_BIG_ZERO_BLOCKS, L.nwin), dim3(256), 0, dL, P, cost_only); KIND(6);

@@ -5,6 +5,7 @@
 #pragma once
 #include <dlfcn.h>
 #include <initializer_list>
+#include <mutex>
 
 struct VgRange {
     typedef int (*PushFn)(const char*);
@@ -12,9 +13,8 @@ struct VgRange {
     static void resolve(PushFn& push, PopFn& pop) {
         static PushFn s_push = nullptr;
         static PopFn s_pop = nullptr;
-        static bool tried = false;
-        if (!tried) {
-            tried = true;
+        static std::once_flag once;               // handles may be driven from several host threads
+        std::call_once(once, [] {
             for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
                 void* lib = dlopen(name, RTLD_LAZY | RTLD_LOCAL);
                 if (!lib) continue;
@@ -23,7 +23,7 @@ struct VgRange {
                 if (s_push && s_pop) break;
                 s_push = nullptr; s_pop = nullptr;
             }
-        }
+        });
         push = s_push; pop = s_pop;
     }
     PopFn pop_ = nullptr;

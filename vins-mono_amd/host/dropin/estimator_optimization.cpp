@@ -247,6 +247,7 @@ extern "C" {
 void vins_gpu_collect_prior(Estimator* e) { collect_prior(*e, side_of(e)); }
 // trace of the last solve
 const vg_ba_summary* vins_gpu_last_summary(Estimator* e) { return &side_of(e).last; }
+int vins_gpu_last_iterations(Estimator* e) { return side_of(e).last.num_iterations; }
 // release the device handle of an Estimator that is about to be destroyed
 void vins_gpu_release(Estimator* e) {
     std::lock_guard<std::mutex> lock(g_mu);
