@@ -696,58 +696,72 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
 // rounds: 1.41M -> ~0.1M cycles per window.  b' rides along as an augmented row, so r0 needs no separate substitution.
 // On exit: column k of L at V[k * ld + i] (k < rank; zero for the rows pivoted earlier), y = r0 in cs[2n .. 3n).  Returns rank.
 DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, const double* bglob) {
-    double* A = MG_LDS + offM;
+    // Right-looking, the Schur complement in REGISTERS: thread t owns the entries t, t + MG_NT, ... of the lower triangle of A'
+    // (packed by rows, tri_decode) and of the augmented row n that carries b'.  Per pivot: every wavefront finds the largest
+    // remaining diagonal entry itself (the running diagonal is mirrored in LDS; a wavefront-local search needs no barrier),
+    // the owners of column / row p publish l = a[., p] / sqrt(pivot) through LDS, everybody subtracts l_i l_j from what it
+    // owns: two barriers and ~3 FMAs per thread and pivot (n = 75: 2925 entries on 1024 threads).
+    const double* A = MG_LDS + offM;
     double* Lc = MG_LDS + offV;               // column k of L at Lc[k * ld + i]
-    double* dgn = MG_LDS + offcs;             // running diagonal of the Schur complement
-    double* bl = dgn + n;                     // b'
-    double* yv = bl + n;                      // y = L^-1 P^T b'
-    int* taken = (int*)(yv + n);
-    double* red = MG_LDS + offred;
+    double* dgn = MG_LDS + offcs;             // running diagonal of the Schur complement (-1e300 once pivoted)
+    double* lcol = dgn + n;                   // current column of L, entry n = the augmented row's (y_k)
+    double* yv = lcol + n + 1;                // y = L^-1 P^T b'   (kept for the caller)
+    (void)offred;
+    const int ntri = n * (n + 1) / 2, nent = ntri + n;
+    enum { MAXE = 5 };                        // n <= 96: (4656 + 96) / 1024
+    double a[MAXE];
+    int ii[MAXE], jj[MAXE];
+    bool alive[MAXE];
     __syncthreads();
-    for (int i = c.tid; i < n; i += MG_NT) { dgn[i] = A[i * ld + i]; taken[i] = 0; bl[i] = bglob[i]; yv[i] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) {
+        const int e = c.tid + q * MG_NT;
+        alive[q] = e < nent;
+        ii[q] = 0; jj[q] = 0; a[q] = 0.0;
+        if (alive[q]) {
+            if (e < ntri) { tri_decode(e, ii[q], jj[q]); a[q] = A[ii[q] * ld + jj[q]]; }
+            else { ii[q] = n; jj[q] = e - ntri; a[q] = bglob[jj[q]]; }
+        }
+    }
+    __syncthreads();                          // (A' = the M area is read completely before Lc — possibly the same LDS — is cleared)
     for (int k = c.tid; k < n * ld; k += MG_NT) Lc[k] = 0.0;
-    __syncthreads();
+    for (int i = c.tid; i < n; i += MG_NT) yv[i] = 0.0;
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q)
+        if (alive[q] && ii[q] == jj[q]) dgn[ii[q]] = a[q];
     int rank = 0;
     for (int k = 0; k < n; ++k) {
-        // pivot = largest remaining diagonal (lowest index on ties), found by wavefront 0 (two entries per lane, DPP max)
-        if (c.wave == 0) {
-            const int i0 = c.lane, i1 = c.lane + 64;
-            const double v0 = (i0 < n && !taken[i0]) ? dgn[i0] : -1e300;
-            const double v1 = (i1 < n && !taken[i1]) ? dgn[i1] : -1e300;
-            const double bv = wave_max_all(fmax(v0, v1));
-            const unsigned long long m0 = __ballot(v0 == bv), m1 = __ballot(v1 == bv);
-            if (c.lane == 0) { red[17] = bv; red[18] = (double)(m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1); }
-        }
         __syncthreads();
-        const double best = red[17];
-        const int p = (int)red[18];
+        // pivot = largest remaining diagonal (lowest index on ties): every wavefront on its own, two entries per lane
+        const int i0 = c.lane, i1 = c.lane + 64;
+        const double v0 = i0 < n ? dgn[i0] : -1e300;
+        const double v1 = i1 < n ? dgn[i1] : -1e300;
+        const double best = wave_max_all(fmax(v0, v1));
+        const unsigned long long m0 = __ballot(v0 == best), m1 = __ballot(v1 == best);
+        const int p = m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1;
         if (!(best > MG_EPS)) break;          // (uniform) nothing above eps is left: the rest is what the reference's cut drops
         const double inv = mg_rsqrt(best);
-        // L[i][k] = (A'[i][p] - sum_{j<k} L[i][j] L[p][j]) / L[p][k] for the rows not pivoted yet and for the augmented row
-        // i == n that carries b' (its "L" entries are y); 8 lanes per row
-        const int g8 = c.tid >> 3, s8 = c.tid & 7;
-        for (int i0 = 0; i0 <= n; i0 += MG_NT / 8) {
-            const int i = i0 + g8;
-            const bool aug = i == n;
-            const bool on = aug || (i < n && !taken[i]);
-            double sacc = 0.0;
-            if (on) {
-                if (aug) { for (int j = s8; j < k; j += 8) sacc += yv[j] * Lc[j * ld + p]; }
-                else     { for (int j = s8; j < k; j += 8) sacc += Lc[j * ld + i] * Lc[j * ld + p]; }
-            }
-            sacc = group8_sum(sacc);
-            if (on && s8 == 0) {
-                if (aug) yv[k] = (bl[p] - sacc) * inv;
-                else {
-                    const double v = i == p ? best * inv : (A[i * ld + p] - sacc) * inv;
-                    Lc[k * ld + i] = v;
-                    if (i != p) dgn[i] -= v * v;
-                    else taken[p] = 1;             // by the lane that owns row p, after its 8-lane group has tested the flag
-                }
-            }
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            if (!alive[q]) continue;
+            const bool inrow = ii[q] == p, incol = jj[q] == p;
+            if (!(inrow || incol)) continue;
+            // entry (i, p) of the column below / (p, j) of the row left of the pivot (the same by symmetry), or the pivot itself
+            const int other = incol ? ii[q] : jj[q];
+            const double v = (inrow && incol) ? best * inv : a[q] * inv;
+            lcol[other] = v;
+            if (other < n) Lc[k * ld + other] = v; else yv[k] = v;
+            if (inrow && incol) dgn[p] = -1e300;
+            alive[q] = false;
         }
         rank = k + 1;
         __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            if (!alive[q]) continue;
+            a[q] -= lcol[ii[q]] * lcol[jj[q]];
+            if (ii[q] == jj[q]) dgn[ii[q]] = a[q];
+        }
     }
     __syncthreads();
     return rank;
@@ -1326,7 +1340,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     if (fast2 && c.hdr[H_MARGMODE] == 0) {
         // square-root form by pivoted Cholesky (see sqrt_factor): J0 = L^T, r0 = L^-1 b'
         const int rk = sqrt_factor(c, 0, ld * ld, n, ld2, offcs2, offred2, bp);
-        const double* yv = cs + 2 * n;
+        const double* yv = cs + 2 * n + 1;
         if (c.tid == 0) mi[5] = rk << 16;        // rank of the factor (the eigen path reports sweeps | attempts << 8 here)
         MPROF(6);
         for (int k = c.tid; k < n * n; k += MG_NT) {
