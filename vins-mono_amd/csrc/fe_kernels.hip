@@ -310,6 +310,9 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 s.ipatch[k] = I[(size_t)reflect101(ipy - 1 + yy, lh) * lw + reflect101(ipx - 1 + xx, lw)];
             }
         }
+        // (the patch was written by other lanes of this wavefront: LDS operations of one wavefront complete in order on the
+        //  hardware; the wave barrier states the dependency for the compiler and for the CPU emulation of tests/simt)
+        __builtin_amdgcn_wave_barrier();
         // Scharr field on the 22x22 integer positions (calcSharrDeriv; constant-0 border outside the image).
         // NB the x+-1 / y+-1 taps reflect at the IMAGE edge, which is what the reflect-101 patch holds.
         // lane = (row yy of the 22x22 lattice, 11-column half): 44 lanes, each walks its 11 positions with a sliding
