@@ -6,7 +6,9 @@
 #define VINS_REF_STUB_OPENCV_HPP
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
+#include "yaml_config.h"      // vins-mono_amd/host (the product's configuration reader)
 namespace cv {
 [[noreturn]] inline void vins_ref_unreachable(const char *what) {
     std::fprintf(stderr, "oracle/_ref: cv::%s reached — the initialisation path is out of scope for this build\n", what);
@@ -29,6 +31,7 @@ typedef Point3_<double> Point3d;
 class Mat {
   public:
     int rows = 0, cols = 0;
+    std::vector<double> data;      // row-major doubles (what the configuration matrices hold: dt: d)
     Mat() {}
 };
 template <typename T> class Mat_;
@@ -47,6 +50,41 @@ template <typename T> class Mat_ : public Mat {
 };
 template <typename T> MatCommaInitializer_<T>::operator Mat_<T>() const { return Mat_<T>(); }
 inline void Rodrigues(const Mat &, Mat &) { vins_ref_unreachable("Rodrigues"); }
+
+// cv::FileStorage (READ) as far as {vins_estimator,feature_tracker}/src/parameters.cpp use it, implemented by the PRODUCT's
+// configuration reader (vins-mono_amd/host/yaml_config.h): the reference's readParameters() compiled unchanged against this
+// stand-in is the check of that reader (tests/test_config_reader.py).
+class FileNode {
+  public:
+    FileNode(const VinsYaml *y, const std::string &key) : y_(y), key_(key) {}
+    operator int() const { return static_cast<int>(y_->number(key_)); }
+    operator float() const { return static_cast<float>(y_->number(key_)); }
+    operator double() const { return y_->number(key_); }
+    operator std::string() const { return y_->str(key_); }
+    bool empty() const { return !y_->has(key_); }
+    const VinsYaml *y_;
+    std::string key_;
+};
+inline void operator>>(const FileNode &n, std::string &v) { v = n.y_->str(n.key_); }
+inline void operator>>(const FileNode &n, int &v) { v = static_cast<int>(n.y_->number(n.key_)); }
+inline void operator>>(const FileNode &n, double &v) { v = n.y_->number(n.key_); }
+inline void operator>>(const FileNode &n, Mat &m) {
+    const VinsYaml::Matrix *src = n.y_->matrix(n.key_);
+    m = Mat();
+    if (src) { m.rows = src->rows; m.cols = src->cols; m.data = src->data; }
+}
+class FileStorage {
+  public:
+    enum Mode { READ = 0, WRITE = 1 };
+    FileStorage() {}
+    FileStorage(const std::string &path, int) { y_.load(path); }
+    bool isOpened() const { return y_.opened(); }
+    FileNode operator[](const std::string &key) const { return FileNode(&y_, key); }
+    FileNode operator[](const char *key) const { return FileNode(&y_, key); }
+    void release() {}
+  private:
+    VinsYaml y_;
+};
 template <typename P3, typename P2>
 inline bool solvePnP(const std::vector<P3> &, const std::vector<P2> &, const Mat &, const Mat &, Mat &, Mat &, bool = false, int = 0) {
     vins_ref_unreachable("solvePnP");

@@ -6,8 +6,7 @@
 // marginalization_factor,pose_local_parameterization}.cpp, factor/{imu_factor,integration_base}.h, utility/utility.{h,cpp}.
 // What is NOT the reference: the header stand-ins under oracle/ref_stubs (mini-Eigen, ceres modelling API + restated
 // trust-region solver, ros/opencv names) and this file, which only moves plain arrays in and out of the reference classes
-// and defines the globals of parameters.cpp (vins_estimator/src/parameters.cpp:3-33) that readParameters() would fill
-// from the YAML file.  initial/* (SfM bootstrap) is out of scope: its four entry points abort.
+// (the globals of vins_estimator/src/parameters.cpp are the reference's own: that file is compiled in too).  initial/* (SfM bootstrap) is out of scope: its four entry points abort.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,26 +15,8 @@
 #include "estimator.h"
 #include "vinsgpu.h"        // (struct vg_ba_summary only: the trace of the drop-in build; no symbol of libvinsgpu is referenced here)
 
-// ---- globals of vins_estimator/src/parameters.cpp:3-33 (EuRoC defaults; vref_set_config overwrites them)
-double INIT_DEPTH = 5.0;
-double MIN_PARALLAX = 10.0 / 460.0;
-double ACC_N = 0.08, ACC_W = 0.00004;
-double GYR_N = 0.004, GYR_W = 2.0e-6;
-std::vector<Eigen::Matrix3d> RIC;
-std::vector<Eigen::Vector3d> TIC;
-Eigen::Vector3d G{0.0, 0.0, 9.8};
-double BIAS_ACC_THRESHOLD = 0.1;
-double BIAS_GYR_THRESHOLD = 0.1;
-double SOLVER_TIME = 0.04;
-int NUM_ITERATIONS = 8;
-int ESTIMATE_EXTRINSIC = 0;
-int ESTIMATE_TD = 0;
-int ROLLING_SHUTTER = 0;
-std::string EX_CALIB_RESULT_PATH;
-std::string VINS_RESULT_PATH;
-std::string IMU_TOPIC;
-double ROW = 480, COL = 752;
-double TD = 0, TR = 0;
+// (the globals INIT_DEPTH ... TR are DEFINED by the reference's own parameters.cpp, compiled into this library; readParameters()
+// fills them from a YAML file, vref_set_config from plain arguments)
 
 // ---- initial/* entry points named by estimator.cpp; never reached (the driver starts in NON_LINEAR mode)
 [[noreturn]] static void out_of_scope(const char *what) {
@@ -103,6 +84,26 @@ void vref_set_config(double acc_n, double acc_w, double gyr_n, double gyr_w, dou
     ProjectionFactor::sqrt_info = FOCAL_LENGTH / 1.5 * Eigen::Matrix2d::Identity();     // estimator.cpp:17-18
     ProjectionTdFactor::sqrt_info = FOCAL_LENGTH / 1.5 * Eigen::Matrix2d::Identity();
 }
+
+// vins_estimator/src/parameters.cpp:42-137 itself (cv::FileStorage = the product's YAML reader behind the stand-in).
+// out: the globals in the order of vins_host_read_parameters (vins-mono_amd/host/host_test_api.cpp)
+int vref_read_parameters(const char *config_file, double *out) {
+    ros::NodeHandle n;
+    n.params["config_file"] = config_file;
+    RIC.clear();
+    TIC.clear();
+    readParameters(n);
+    if (RIC.empty() || TIC.empty()) return -1;
+    int k = 0;
+    out[k++] = SOLVER_TIME; out[k++] = NUM_ITERATIONS; out[k++] = MIN_PARALLAX; out[k++] = ACC_N; out[k++] = ACC_W; out[k++] = GYR_N; out[k++] = GYR_W;
+    out[k++] = G.z(); out[k++] = ROW; out[k++] = COL; out[k++] = ESTIMATE_EXTRINSIC; out[k++] = INIT_DEPTH; out[k++] = BIAS_ACC_THRESHOLD;
+    out[k++] = BIAS_GYR_THRESHOLD; out[k++] = TD; out[k++] = ESTIMATE_TD; out[k++] = ROLLING_SHUTTER; out[k++] = TR;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) out[k++] = RIC[0](r, c);
+    for (int r = 0; r < 3; ++r) out[k++] = TIC[0](r);
+    return 0;
+}
+const char *vref_result_path() { return VINS_RESULT_PATH.c_str(); }
+const char *vref_imu_topic() { return IMU_TOPIC.c_str(); }
 
 // ------------------------------------------------------------------------------------------ utility/utility.h
 void vref_R2ypr(const double *R_rowmajor, double *ypr) { out3(Utility::R2ypr(mat3(R_rowmajor)), ypr); }

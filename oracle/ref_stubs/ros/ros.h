@@ -2,6 +2,7 @@
 #ifndef VINS_REF_STUB_ROS_ROS_H
 #define VINS_REF_STUB_ROS_ROS_H
 #include <cstdint>
+#include <map>
 #include <string>
 #include "console.h"
 #include "assert.h"
@@ -22,6 +23,15 @@ class NodeHandle {
   public:
     NodeHandle() {}
     explicit NodeHandle(const std::string &) {}
+    // private parameters of the node (the launch files pass config_file / vins_folder this way)
+    std::map<std::string, std::string> params;
+    bool getParam(const std::string &name, std::string &v) const {
+        auto it = params.find(name);
+        if (it == params.end()) return false;
+        v = it->second;
+        return true;
+    }
+    void shutdown() {}
 };
 }  // namespace ros
 #endif

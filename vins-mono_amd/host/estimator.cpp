@@ -2,6 +2,7 @@
 // vins_estimator/src/estimator.cpp:486-619; optimization() follows :670-1003 with the ceres::Problem, ceres::Solve
 // and the MarginalizationInfo machinery replaced by ONE call of vg_ba_optimize (solve + gauge fix + marginalization).
 #include "estimator.h"
+#include "yaml_config.h"
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -10,6 +11,54 @@
 int ESTIMATE_EXTRINSIC = 0, ESTIMATE_TD = 0, NUM_ITERATIONS = 8;
 double TD = 0, TR = 0, ROW_D = 480, FOCAL_LENGTH_D = 460.0, G_NORM = 9.81007, INIT_DEPTH = 5.0, SOLVER_TIME = 0.0;
 double ACC_N = 0.08, ACC_W = 0.00004, GYR_N = 0.004, GYR_W = 2.0e-6;      // config/euroc/euroc_config.yaml:58-62
+double MIN_PARALLAX = 10.0 / 460.0, BIAS_ACC_THRESHOLD = 0.1, BIAS_GYR_THRESHOLD = 0.1, COL_D = 752;
+int ROLLING_SHUTTER = 0;
+std::string IMU_TOPIC, VINS_RESULT_PATH, EX_CALIB_RESULT_PATH;
+std::vector<Matrix3d> RIC;
+std::vector<Vector3d> TIC;
+
+void readEstimatorParameters(const std::string& config_file) {               // vins_estimator/src/parameters.cpp:42-137
+    VinsYaml fs;
+    if (!fs.load(config_file)) throw std::runtime_error("ERROR: Wrong path to settings: " + config_file);
+    IMU_TOPIC = fs.str("imu_topic");
+    SOLVER_TIME = fs.number("max_solver_time");
+    NUM_ITERATIONS = (int)fs.number("max_num_iterations");
+    MIN_PARALLAX = fs.number("keyframe_parallax");
+    MIN_PARALLAX = MIN_PARALLAX / FOCAL_LENGTH_D;
+    const std::string OUTPUT_PATH = fs.str("output_path");
+    VINS_RESULT_PATH = OUTPUT_PATH + "/vins_result_no_loop.csv";
+    ACC_N = fs.number("acc_n"); ACC_W = fs.number("acc_w");
+    GYR_N = fs.number("gyr_n"); GYR_W = fs.number("gyr_w");
+    G_NORM = fs.number("g_norm");
+    ROW_D = fs.number("image_height");
+    COL_D = fs.number("image_width");
+    ESTIMATE_EXTRINSIC = (int)fs.number("estimate_extrinsic");
+    RIC.clear(); TIC.clear();
+    if (ESTIMATE_EXTRINSIC == 2) {
+        RIC.push_back(Matrix3d());           // identity
+        TIC.push_back(Vector3d());
+        EX_CALIB_RESULT_PATH = OUTPUT_PATH + "/extrinsic_parameter.csv";
+    } else {
+        if (ESTIMATE_EXTRINSIC == 1) EX_CALIB_RESULT_PATH = OUTPUT_PATH + "/extrinsic_parameter.csv";
+        const VinsYaml::Matrix* R = fs.matrix("extrinsicRotation");
+        const VinsYaml::Matrix* T = fs.matrix("extrinsicTranslation");
+        if (!R || !T || R->rows != 3 || R->cols != 3 || T->data.size() != 3) throw std::runtime_error("extrinsicRotation / extrinsicTranslation missing or not 3x3 / 3x1");
+        Matrix3d eigen_R;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) eigen_R(r, c) = R->data[3 * r + c];
+        // Eigen::Quaterniond Q(eigen_R); eigen_R = Q.normalized();   (:105-106: the matrix is re-orthonormalised through a quaternion)
+        const Quaterniond Q(eigen_R);
+        const double qn = std::sqrt(Q.w() * Q.w() + Q.x() * Q.x() + Q.y() * Q.y() + Q.z() * Q.z());
+        RIC.push_back(Quaterniond(Q.w() / qn, Q.x() / qn, Q.y() / qn, Q.z() / qn).toRotationMatrix());
+        TIC.push_back(Vector3d(T->data[0], T->data[1], T->data[2]));
+    }
+    INIT_DEPTH = 5.0;
+    BIAS_ACC_THRESHOLD = 0.1;
+    BIAS_GYR_THRESHOLD = 0.1;
+    TD = fs.number("td");
+    ESTIMATE_TD = (int)fs.number("estimate_td");
+    ROLLING_SHUTTER = (int)fs.number("rolling_shutter");
+    TR = ROLLING_SHUTTER ? fs.number("rolling_shutter_tr") : 0;
+}
 
 int FeatureManager::getFeatureCount() {                         // feature_manager.cpp:28-42
     int cnt = 0;

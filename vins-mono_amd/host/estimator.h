@@ -5,6 +5,7 @@
 // unchanged around this method in a real catkin build.
 #pragma once
 #include <list>
+#include <string>
 #include <vector>
 #include "compat/eigen_compat.h"
 #include "../../include/vinsgpu.h"
@@ -18,6 +19,14 @@ const int NUM_OF_F = 1000;
 extern int ESTIMATE_EXTRINSIC, ESTIMATE_TD, NUM_ITERATIONS;
 extern double TD, TR, ROW_D, FOCAL_LENGTH_D, G_NORM, INIT_DEPTH, SOLVER_TIME;
 extern double ACC_N, ACC_W, GYR_N, GYR_W;          // vins_estimator/src/parameters.cpp:5-6 (the device pre-integration needs them)
+extern double MIN_PARALLAX, BIAS_ACC_THRESHOLD, BIAS_GYR_THRESHOLD, COL_D;
+extern int ROLLING_SHUTTER;
+extern std::string IMU_TOPIC, VINS_RESULT_PATH, EX_CALIB_RESULT_PATH;
+extern std::vector<Matrix3d> RIC;
+extern std::vector<Vector3d> TIC;
+// vins_estimator/src/parameters.cpp:42-137 without the ROS node handle and without touching the file system (the reference
+// creates OUTPUT_PATH and truncates the result file there; here only the names are formed)
+void readEstimatorParameters(const std::string& config_file);
 
 struct FeaturePerFrame { Vector3d point; Vector2d uv; Vector2d velocity; double cur_td = 0; };   // feature_manager.h:19-42
 struct FeaturePerId {                                                                             // feature_manager.h:44-66

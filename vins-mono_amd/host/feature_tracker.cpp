@@ -1,6 +1,7 @@
 // feature_tracker.cpp — see feature_tracker.h.  Control flow follows feature_tracker/src/feature_tracker.cpp of the
 // reference (cited per block); the arithmetic runs on the GPU through libvinsgpu.so.
 #include "feature_tracker.h"
+#include "yaml_config.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -9,6 +10,29 @@
 int ROW = 480, COL = 752, MAX_CNT = 150, MIN_DIST = 30, EQUALIZE = 1, FISHEYE = 0, FOCAL_LENGTH = 460;
 bool PUB_THIS_FRAME = false;
 double F_THRESHOLD = 1.0;
+int FREQ = 10, SHOW_TRACK = 1, FE_WINDOW_SIZE = 20;
+std::string IMAGE_TOPIC, FE_IMU_TOPIC, FISHEYE_MASK;
+
+void readFeatureTrackerParameters(const std::string& config_file, const std::string& vins_folder) {   // feature_tracker/src/parameters.cpp:37-74
+    VinsYaml fs;
+    if (!fs.load(config_file)) throw std::runtime_error("ERROR: Wrong path to settings: " + config_file);
+    IMAGE_TOPIC = fs.str("image_topic");
+    FE_IMU_TOPIC = fs.str("imu_topic");
+    MAX_CNT = (int)fs.number("max_cnt");
+    MIN_DIST = (int)fs.number("min_dist");
+    ROW = (int)fs.number("image_height");
+    COL = (int)fs.number("image_width");
+    FREQ = (int)fs.number("freq");
+    F_THRESHOLD = fs.number("F_threshold");
+    SHOW_TRACK = (int)fs.number("show_track");
+    EQUALIZE = (int)fs.number("equalize");
+    FISHEYE = (int)fs.number("fisheye");
+    if (FISHEYE == 1) FISHEYE_MASK = vins_folder + "config/fisheye_mask.jpg";
+    FE_WINDOW_SIZE = 20;
+    FOCAL_LENGTH = 460;
+    PUB_THIS_FRAME = false;
+    if (FREQ == 0) FREQ = 100;
+}
 int FeatureTracker::n_id = 0;
 
 static int cvRoundf(float v) { return (int)std::lrintf(v); }
@@ -171,7 +195,19 @@ bool FeatureTracker::updateID(unsigned int i) {                              // 
     return false;
 }
 
-void FeatureTracker::readIntrinsicParameter(const string&) {}
+void FeatureTracker::readIntrinsicParameter(const string& calib_file) {
+    // feature_tracker.cpp:216-220 -> CameraFactory::generateCameraFromYamlFile -> PinholeCamera::Parameters::readFromYamlFile
+    // (camera_model/src/camera_models/PinholeCamera.cc): model_type PINHOLE, distortion_parameters k1 k2 p1 p2, projection_parameters
+    // fx fy cx cy.  Other camera models (MEI, KANNALA_BRANDT) are outside this front end (camodocal is out of scope).
+    VinsYaml fs;
+    if (!fs.load(calib_file)) throw std::runtime_error("readIntrinsicParameter: cannot read " + calib_file);
+    const std::string model = fs.str("model_type", "PINHOLE");
+    if (model != "PINHOLE") throw std::runtime_error("readIntrinsicParameter: camera model " + model + " is not supported (PINHOLE only)");
+    m_camera.k1 = fs.number("distortion_parameters.k1"); m_camera.k2 = fs.number("distortion_parameters.k2");
+    m_camera.p1 = fs.number("distortion_parameters.p1"); m_camera.p2 = fs.number("distortion_parameters.p2");
+    m_camera.fx = fs.number("projection_parameters.fx"); m_camera.fy = fs.number("projection_parameters.fy");
+    m_camera.cx = fs.number("projection_parameters.cx"); m_camera.cy = fs.number("projection_parameters.cy");
+}
 
 void FeatureTracker::undistortedPoints() {                                   // :258-306, lifting on the device
     cur_un_pts.clear();

@@ -20,6 +20,10 @@ using namespace std;
 extern int ROW, COL, MAX_CNT, MIN_DIST, EQUALIZE, FISHEYE, FOCAL_LENGTH;
 extern bool PUB_THIS_FRAME;
 extern double F_THRESHOLD;
+extern int FREQ, SHOW_TRACK, FE_WINDOW_SIZE;
+extern std::string IMAGE_TOPIC, FE_IMU_TOPIC, FISHEYE_MASK;
+// feature_tracker/src/parameters.cpp:37-74 without the ROS node handle: the path of the configuration file is passed directly
+void readFeatureTrackerParameters(const std::string& config_file, const std::string& vins_folder = "");
 
 bool inBorder(const cv::Point2f& pt);
 void reduceVector(vector<cv::Point2f>& v, vector<uchar> status);
@@ -39,7 +43,7 @@ class FeatureTracker {
     void setMask();
     void addPoints();
     bool updateID(unsigned int i);
-    void readIntrinsicParameter(const string& calib_file);   // keeps the EuRoC defaults; YAML parsing is out of scope
+    void readIntrinsicParameter(const string& calib_file);   // PINHOLE section of the configuration file (host/yaml_config.h)
     void rejectWithF();
     void undistortedPoints();
 

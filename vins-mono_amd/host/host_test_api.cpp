@@ -6,6 +6,7 @@
 #include <cstring>
 #include <stdexcept>
 #include "estimator.h"
+#include "feature_tracker.h"
 
 extern "C" int vins_host_estimator_roundtrip(const vg_ba_problem* p, int margin_flag, double* pose_out /*K*7*/, double* sb_out /*K*9*/,
                                              double* depth_out /*L*/, int* solve_flag_out /*L*/, int* prior_n, int* prior_nblocks,
@@ -271,3 +272,32 @@ extern "C" int vins_host_slide_second_new(int na, const double* smp_a, const dou
         return -2;
     }
 }
+
+
+// Configuration readers (host/yaml_config.h): out[0..31] = the estimator globals in a fixed order, out[32..] the tracker's;
+// intr[8] = fx fy cx cy k1 k2 p1 p2 after FeatureTracker::readIntrinsicParameter.
+extern "C" int vins_host_read_parameters(const char* config_file, double* out /*64*/, double* intr /*8*/) {
+    try {
+        readEstimatorParameters(config_file);
+        readFeatureTrackerParameters(config_file, "/vins/");
+        FeatureTracker tr;
+        tr.readIntrinsicParameter(config_file);
+        int k = 0;
+        out[k++] = SOLVER_TIME; out[k++] = NUM_ITERATIONS; out[k++] = MIN_PARALLAX; out[k++] = ACC_N; out[k++] = ACC_W; out[k++] = GYR_N; out[k++] = GYR_W;
+        out[k++] = G_NORM; out[k++] = ROW_D; out[k++] = COL_D; out[k++] = ESTIMATE_EXTRINSIC; out[k++] = INIT_DEPTH; out[k++] = BIAS_ACC_THRESHOLD;
+        out[k++] = BIAS_GYR_THRESHOLD; out[k++] = TD; out[k++] = ESTIMATE_TD; out[k++] = ROLLING_SHUTTER; out[k++] = TR;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) out[k++] = RIC[0](r, c);
+        for (int r = 0; r < 3; ++r) out[k++] = TIC[0](r);
+        k = 32;
+        out[k++] = MAX_CNT; out[k++] = MIN_DIST; out[k++] = ROW; out[k++] = COL; out[k++] = FREQ; out[k++] = F_THRESHOLD; out[k++] = SHOW_TRACK;
+        out[k++] = EQUALIZE; out[k++] = FISHEYE; out[k++] = FE_WINDOW_SIZE; out[k++] = FOCAL_LENGTH;
+        const double v[8] = {tr.m_camera.fx, tr.m_camera.fy, tr.m_camera.cx, tr.m_camera.cy, tr.m_camera.k1, tr.m_camera.k2, tr.m_camera.p1, tr.m_camera.p2};
+        memcpy(intr, v, sizeof(v));
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "vins_host_read_parameters: %s\n", e.what());
+        return -1;
+    }
+}
+extern "C" const char* vins_host_result_path() { return VINS_RESULT_PATH.c_str(); }
+extern "C" const char* vins_host_imu_topic() { return IMU_TOPIC.c_str(); }
