@@ -163,8 +163,20 @@ def bench_sharded(args, ba, synth, D, rank, world):
     prob = synth.SyntheticSequence.anchor_prior(seq.window(0))        # same seed -> the same window on every rank
     sub = shard.shard_problem(prob, rank, world)
     h = ba.Handle()
-    if world > 1:
-        h.ba_set_allreduce(shard.torch_allreduce_hook(device_buffers=True))     # (gloo self-test on a shared GPU: staged through the host)
+    hook_kind = "none (single rank)"
+    if world > 1 or args.rccl_hook:
+        import torch.distributed as dist
+        if (dist.is_initialized() and dist.get_backend() == "nccl" and not args.share_device) or (world == 1 and args.rccl_hook):
+            # the C hook inside the library (csrc/vg_rccl.hip): ncclAllReduce on the launch stream, no Python in the loop; the
+            # unique id travels over torch.distributed's own rendezvous
+            ids = [h.rccl_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            h.ba_rccl_init(world, rank, ids[0])
+            hook_kind = "RCCL in the library (vg_ba_rccl_init)"
+        else:
+            h.ba_set_allreduce(shard.torch_allreduce_hook(device_buffers=True))     # (gloo self-test on a shared GPU: staged through the host)
+            hook_kind = "torch.distributed gloo, staged through the host (self-test)" 
     packed = ba.PackedProblem(sub)
     h.ba_upload([packed], [ba.VG_MARGIN_NONE])
     info = h.ba_info()
@@ -244,6 +256,7 @@ def bench_sharded(args, ba, synth, D, rank, world):
                                f"sum (6 n_l)^2; per iteration two all-reduces of {counts[0]} and {counts[1]} doubles (RCCL, in place, on the "
                                f"launch stream); reduced camera system factorised redundantly on every rank",
                    "parallelism": f"landmark shards x{world} + all-reduce of the reduced camera system" if world > 1 else "single rank (no collective)",
+                   "allreduce_hook": hook_kind,
                    "valid_solves": int(ok_all)},
         "roofline": {"kernel": dom, "bound": "mfma", "achieved": per_kernel[dom]["achieved"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"], "kernels": per_kernel,
@@ -315,6 +328,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "2-rank self-test on a 1-GPU box together with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="self-test: all ranks use cuda:0")
+    ap.add_argument("--rccl-hook", action="store_true", help="--config sharded with one rank: still route the reductions through RCCL")
     args = ap.parse_args()
 
     import torch

@@ -252,6 +252,17 @@ typedef int (*vg_allreduce_fn)(void* user, double* device_buf, size_t count, voi
 int vg_ba_set_allreduce(vg_handle* h, vg_allreduce_fn fn, void* user);       /* fn == NULL: single rank */
 int vg_ba_set_large_window(vg_handle* h, int force);     /* force != 0: take the large-window path whatever the size */
 
+/* The same hook bound to RCCL over xGMI inside the library (csrc/vg_rccl.hip; librccl is opened with dlopen at the first call,
+ * VG_ERR_UNSUPPORTED if it cannot be).  One process per GPU: rank 0 calls vg_rccl_unique_id and hands the 128 bytes to the
+ * other ranks by whatever channel the application has (torch.distributed / MPI broadcast); every rank then calls
+ * vg_ba_rccl_init(handle, nranks, rank, id) — collective, it creates the communicator on the handle's device and installs
+ * ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, launch stream) as the hook.  vg_ba_rccl_finalize (also run by
+ * vg_destroy) removes the hook and destroys the communicator. */
+#define VG_RCCL_ID_BYTES 128
+int vg_rccl_unique_id(char* id128);
+int vg_ba_rccl_init(vg_handle* h, int nranks, int rank, const char* id128);
+int vg_ba_rccl_finalize(vg_handle* h);
+
 /* Form of the prior factor the marginalization hands back (marginalization_factor.cpp:285-296 builds J0 = S^1/2 V^T,
  * r0 = S^-1/2 V^T b' from the eigen-decomposition A' = V S V^T of the kept system).  Everything downstream uses the factor
  * only through J0^T J0, J0^T r0 and |r0|^2, which do not change under an orthogonal transformation from the left:

@@ -120,6 +120,26 @@ def test_allreduce_hook_over_rccl_single_rank(handle):
     assert list(sm0['it_cost']) == list(sm1['it_cost'])
 
 
+def test_allreduce_hook_in_the_library_single_rank(handle):
+    """vg_ba_rccl_init: the RCCL communicator and the ncclAllReduce hook live inside libvinsgpu.so (csrc/vg_rccl.hip, librccl
+    opened with dlopen).  World of ONE rank on the box's GPU: the reductions really go through ncclAllReduce on the launch
+    stream, and summing over one rank must not change a bit."""
+    prob = synth.SyntheticSequence.anchor_prior(synth.SyntheticSequence(5, n_frames=17, K=16, L=300).window(0))
+    st0, sm0, _ = handle.ba_optimize(prob)
+    h2 = ba.Handle()
+    try:
+        h2.ba_rccl_init(1, 0, h2.rccl_unique_id())
+        st1, sm1, _ = h2.ba_optimize(prob)
+        st2, sm2, _ = h2.ba_optimize(prob)          # the communicator is reused
+        h2.ba_rccl_finalize()
+        st3, sm3, _ = h2.ba_optimize(prob)          # hook removed again
+    finally:
+        h2.close()
+    for st, sm in ((st1, sm1), (st2, sm2), (st3, sm3)):
+        assert sm['status'] == 0 and list(sm0['it_cost']) == list(sm['it_cost'])
+        assert np.array_equal(st0['pose'], st['pose']) and np.array_equal(st0['inv_depth'], st['inv_depth'])
+
+
 SHARD_WORKER = r'''
 import os, sys, json
 ROOT = %r

@@ -195,6 +195,8 @@ class Handle:
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
         L.vg_ba_set_large_window.argtypes = [C.c_void_p, C.c_int]
         L.vg_ba_set_marg_mode.argtypes = [C.c_void_p, C.c_int]
+        L.vg_ba_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        L.vg_ba_rccl_finalize.argtypes = [C.c_void_p]
         L.vg_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         L.vg_ba_reduce_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.vg_triangulate.argtypes = [C.c_void_p, C.c_int, _pd, _pd, _pd, _pd, C.c_int, _pi, _pi, _pi, _pd, C.c_double, _pd]
@@ -251,6 +253,19 @@ class Handle:
     def ba_set_marg_mode(self, mode):
         """VG_MARG_SQRT (0, default) / VG_MARG_EIGEN (1): form of the prior factor (include/vinsgpu.h)."""
         self._chk(self.lib.vg_ba_set_marg_mode(self.h, int(mode)), "vg_ba_set_marg_mode")
+
+    def rccl_unique_id(self):
+        """128 bytes from ncclGetUniqueId (rank 0 calls this and broadcasts them)."""
+        buf = C.create_string_buffer(128)
+        self._chk(self.lib.vg_rccl_unique_id(buf), "vg_rccl_unique_id")
+        return buf.raw
+
+    def ba_rccl_init(self, nranks, rank, unique_id):
+        """Collective: RCCL communicator on this handle's device + the C all-reduce hook (include/vinsgpu.h)."""
+        self._chk(self.lib.vg_ba_rccl_init(self.h, int(nranks), int(rank), bytes(unique_id)), "vg_ba_rccl_init")
+
+    def ba_rccl_finalize(self):
+        self._chk(self.lib.vg_ba_rccl_finalize(self.h), "vg_ba_rccl_finalize")
 
     def ba_set_large_window(self, force=True):
         self._chk(self.lib.vg_ba_set_large_window(self.h, 1 if force else 0), "vg_ba_set_large_window")

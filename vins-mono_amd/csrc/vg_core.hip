@@ -4,6 +4,7 @@
 #include "../../include/vinsgpu.h"
 
 extern "C" void fe_state_destroy(FeState* s);
+extern "C" int vg_ba_rccl_finalize(vg_handle* h);
 
 extern "C" int vg_abi_version(void) { return VG_ABI_VERSION; }
 
@@ -29,6 +30,7 @@ extern "C" int vg_destroy(vg_handle* h) {
     if (!h) return VG_ERR_BAD_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    (void)vg_ba_rccl_finalize(h);
     BaPtrs& P = h->ba.P;
     (void)hipFree(P.iarr); (void)hipFree(P.din); (void)hipFree(P.scr); (void)hipFree(P.out); (void)hipFree(P.iout);
     (void)hipFree(h->ba.dL);

@@ -58,5 +58,6 @@ struct vg_handle {
     std::string err;
     BaBatch ba;
     FeState* fe = nullptr;
+    void* rccl_comm = nullptr;                    // ncclComm_t of vg_ba_rccl_init (csrc/vg_rccl.hip)
     void* ransac_buf = nullptr;                   // device scratch of vg_fe_reject_with_f (fixed size, allocated on first use)
 };
