@@ -9,3 +9,5 @@ bash "$ROOT/profiles/run_profile.sh" "$TAG" --steps 20 --warmup 5 > /dev/null
 bash "$ROOT/profiles/run_profile.sh" "${TAG}_sharded" --config sharded --steps 10 --warmup 2 > /dev/null
 bash "$ROOT/profiles/run_pmc.sh" "$TAG" > /dev/null
 ls -la "$ROOT"/gpurun_out/${TAG}*
+# the raw rocprofv3 databases stay on the box (gpurun merges at most 64 MiB back): only the summaries travel
+rm -rf "$ROOT"/gpurun_out/prof_${TAG} "$ROOT"/gpurun_out/prof_${TAG}_sharded "$ROOT"/gpurun_out/pmc_${TAG}

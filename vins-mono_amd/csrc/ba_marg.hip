@@ -18,7 +18,9 @@
 #include "ba_factors.h"
 #include "../../include/vinsgpu.h"
 
+#ifndef MG_NT
 #define MG_NT 1024                 // 16 wavefronts: the Jacobi rounds are LDS-latency bound, more waves in flight
+#endif
 #define MG_NW (MG_NT / 64)
 #define MG_EPS 1e-8
 #define MG_MAXSWEEP 30
@@ -708,7 +710,7 @@ DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs,
     double* yv = lcol + n + 1;                // y = L^-1 P^T b'   (kept for the caller)
     (void)offred;
     const int ntri = n * (n + 1) / 2, nent = ntri + n;
-    enum { MAXE = 5 };                        // n <= 96: (4656 + 96) / 1024
+    enum { MAXE = (96 * 97 / 2 + 96 + MG_NT - 1) / MG_NT };      // n <= 96
     double a[MAXE];
     int ii[MAXE], jj[MAXE];
     bool alive[MAXE];
@@ -1020,7 +1022,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             cfb[n0] = acc;
         }
         // per-thread camera entries (chunk-invariant): w = tid + e * MG_NT < nent
-        constexpr int MAXE = 6;
+        constexpr int MAXE = ((6 * BA_MAX_K + 7) * (6 * BA_MAX_K + 8) / 2 + 6 * BA_MAX_K + 7 + MG_NT - 1) / MG_NT;
         double acc[MAXE];
         int eo[MAXE];        // packed: oa0 | oa1 << 8 | ob0 << 16 | ob1 << 24
         int erq[MAXE];       // required target frame, -1 = any, -3 = entry unused

@@ -4,7 +4,8 @@
 #include "../../include/vinsgpu.h"
 
 extern "C" void fe_state_destroy(FeState* s);
-extern "C" int vg_ba_rccl_finalize(vg_handle* h);
+// (weak: builds without csrc/vg_rccl.hip — the CPU emulation of tests/simt — have no communicator to release)
+extern "C" int vg_ba_rccl_finalize(vg_handle* h) __attribute__((weak));
 
 extern "C" int vg_abi_version(void) { return VG_ABI_VERSION; }
 
@@ -30,7 +31,7 @@ extern "C" int vg_destroy(vg_handle* h) {
     if (!h) return VG_ERR_BAD_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    (void)vg_ba_rccl_finalize(h);
+    if (vg_ba_rccl_finalize) (void)vg_ba_rccl_finalize(h);
     BaPtrs& P = h->ba.P;
     (void)hipFree(P.iarr); (void)hipFree(P.din); (void)hipFree(P.scr); (void)hipFree(P.out); (void)hipFree(P.iout);
     (void)hipFree(h->ba.dL);
