@@ -195,8 +195,9 @@ class Handle:
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
         L.vg_ba_set_large_window.argtypes = [C.c_void_p, C.c_int]
         L.vg_ba_set_marg_mode.argtypes = [C.c_void_p, C.c_int]
-        L.vg_ba_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
-        L.vg_ba_rccl_finalize.argtypes = [C.c_void_p]
+        if hasattr(L, 'vg_ba_rccl_init'):            # (absent from the CPU-emulated build of tests/simt)
+            L.vg_ba_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+            L.vg_ba_rccl_finalize.argtypes = [C.c_void_p]
         L.vg_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         L.vg_ba_reduce_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.vg_triangulate.argtypes = [C.c_void_p, C.c_int, _pd, _pd, _pd, _pd, C.c_int, _pi, _pi, _pi, _pd, C.c_double, _pd]
