@@ -21,6 +21,11 @@ import time
 
 import numpy as np
 
+# ROCm maps HIP streams onto 4 hardware queues by default; the boundary loops below drive 8 handles (16 streams) from 8 host
+# threads, and a stream whose next packet waits for a copy holds up the other streams of its queue (measured: 3.87 vs
+# 3.25 ms per batch).  Must be set before the HIP runtime initialises; no effect on `value`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -33,13 +38,30 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md
 def make_windows(h, ba, synth, n, seed0):
     """n timed windows: for every seed, window 1 (no prior) is solved + marginalised by the PRODUCT path to
     create the prior, then window 2 (with prior) is assembled — the timed one (SURVEY.md 8(d) configs[2])."""
-    seqs = [synth.SyntheticSequence(seed0 + s) for s in range(n)]
+    seqs = [synth.SyntheticSequence(seed0 + s, n_frames=12 + CHAIN_FRAMES) for s in range(n)]
     first = [q.window(0) for q in seqs]
     h.ba_upload(first, [ba.VG_MARGIN_OLD] * n)
     h.ba_run_async()
     st, sm, pr = h.ba_download()
     assert all(s['status'] == 0 for s in sm), "window-1 solve failed"
-    return [q.next_window(st[i], pr[i], 1) for i, q in enumerate(seqs)]
+    return [q.next_window(st[i], pr[i], 1) for i, q in enumerate(seqs)], seqs
+
+
+CHAIN_FRAMES = 4             # consecutive frames every sequence advances in the chained boundary loop
+
+
+def make_chain(h, ba, seqs, packed, flags):
+    """Frames 2 .. 1+CHAIN_FRAMES of every sequence: frame 2 is the timed window (prior from the host), each following one is
+    built by the sliding-window bookkeeping (SyntheticSequence.next_window = slideWindow + the new frame) from the product's
+    own result of the frame before, and its prior is the one that solve's marginalization left ON THE DEVICE."""
+    chain = [ba.PackedBatch(packed)]
+    for k in range(1, CHAIN_FRAMES):
+        h.ba_upload(chain[-1], flags)
+        h.ba_run_async()
+        st, sm, _ = h.ba_download()
+        assert all(s['status'] == 0 for s in sm), "chain solve failed"
+        chain.append(ba.PackedBatch([q.next_window(st[i], 'resident', k + 1) for i, q in enumerate(seqs)]))
+    return chain
 
 
 FE_CAMS = 64                 # independent camera streams per GPU in the front-end leg
@@ -356,7 +378,7 @@ def main():
     # solve kernel needs < 80 KB of LDS: two windows are resident per CU)
     handles = [h] + [ba.Handle() for _ in range(nfl - 1)]
     seed0 = D.window_seeds(rank, nwin)[0]
-    probs = make_windows(h, ba, synth, nwin, seed0=seed0)
+    probs, seqs = make_windows(h, ba, synth, nwin, seed0=seed0)
     packed = [ba.PackedProblem(p) for p in probs]
     flags = [ba.VG_MARGIN_OLD] * nwin
     for hh in handles:
@@ -437,11 +459,11 @@ def main():
     # every thread loops upload -> run_async -> download on its own handle / stream / pinned staging, so the pack + H2D and
     # D2H + unpack of some batches always run beside the kernels of another
     import threading
-    nthr = 4
+    nthr = 8
     th_handles = (handles + [ba.Handle() for _ in range(max(0, nthr - len(handles)))])[:nthr]
     for hh in th_handles:
         hh.ba_upload(packed, flags); hh.ba_prepare_download()
-    nb_thr = 6
+    nb_thr = 16
     errs = []
 
     def boundary_worker(hh, nb):
@@ -466,6 +488,42 @@ def main():
     threaded_ms = (time.perf_counter() - tt0) / (nb_thr * nthr) * 1e3
     if errs:
         raise SystemExit(f"threaded boundary loop failed: {errs[:3]}")
+    # the same threads over CHAINS of consecutive frames (what a caller that tracks sequences does): every thread walks its
+    # handle through frames 2 .. 1+CHAIN_FRAMES of its 256 sequences; from the second frame on the prior is the one the
+    # previous solve's marginalization left on the device (VG_PRIOR_RESIDENT) and only the states come back
+    chain = make_chain(h, ba, seqs, packed, flags)
+    dls = {}
+    for hh in th_handles:
+        for k, cb in enumerate(chain):                # (every handle's slots get the prior of frame k-1 from its own run)
+            hh.ba_upload(cb, flags)
+            dls[(id(hh), k)] = hh.ba_prepare_download()
+            hh.ba_run_async()
+        hh.sync()
+
+    def chain_worker(hh, nb):
+        try:
+            for _ in range(nb):
+                for k, cb in enumerate(chain):
+                    hh.ba_upload(cb, flags); hh.ba_run_async()
+                    rc = hh.ba_download_state_raw(dls[(id(hh), k)])
+                    if rc != 0:
+                        errs.append(rc)
+        except Exception as ex:                       # noqa: BLE001
+            errs.append(repr(ex))
+
+    def chained(nb):
+        ts = [threading.Thread(target=chain_worker, args=(hh, nb)) for hh in th_handles]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    chained(1)
+    tc0 = time.perf_counter()
+    nb_ch = 5
+    chained(nb_ch)
+    chained_ms = (time.perf_counter() - tc0) / (nb_ch * CHAIN_FRAMES * nthr) * 1e3
+    if errs:
+        raise SystemExit(f"chained boundary loop failed: {errs[:3]}")
     for hh in th_handles:
         if hh not in handles:
             hh.close()
@@ -597,13 +655,20 @@ def main():
                                         "threaded_ms_per_batch": threaded_ms, "threaded_host_threads": nthr,
                                         "threaded_solves_per_s": nwin / (threaded_ms * 1e-3),
                                         "threaded_over_device_resident": (nwin / (threaded_ms * 1e-3)) / value,
+                                        "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+                                        "chained_ms_per_batch": chained_ms, "chained_frames": CHAIN_FRAMES,
+                                        "chained_solves_per_s": nwin / (chained_ms * 1e-3),
+                                        "chained_over_device_resident": (nwin / (chained_ms * 1e-3)) / value,
                                         "what": "host buffers in, host buffers out: vg_ba_batch_upload (pack + H2D) + all launches + "
                                                 "vg_ba_batch_download (D2H + unpack), per GPU; sync = one batch at a time, nothing "
                                                 "overlapped; overlapped = two handles (streams, pinned staging) driven by one host thread, the "
                                                 "pack + upload of batch i+1 issued while batch i runs, then batch i downloaded; threaded = one host "
-                                                "thread per handle (4 handles), each looping upload -> run -> download, so the host work of some "
+                                                "thread per handle (8 handles), each looping upload -> run -> download, so the host work of some "
                                                 "batches always runs beside the kernels of another: the rate a caller with host buffers gets from one "
-                                                "GPU; NOT the metric (bench contract: `value` is device-resident)"},
+                                                "GPU; chained = the same 8 threads, each walking its handle through CHAIN_FRAMES consecutive frames "
+                                                "of its 256 sequences: frame 2 uploads its prior, the following frames use the prior the previous "
+                                                "solve's marginalization left in HBM (VG_PRIOR_RESIDENT) and download the states only; "
+                                                "NOT the metric (bench contract: `value` is device-resident)"},
         }
     fe_out = bench_fe(h, synth, max(args.steps, 10), args.warmup, rank, rank == 0 and world == 1 and not args.no_cpu_baseline)
     fe_out["value_all_gpus"] = D.sum_over_ranks(fe_out["value"])

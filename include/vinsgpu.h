@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 3    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_* */
+#define VG_ABI_VERSION 4    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
+                             * 4: VG_PRIOR_RESIDENT */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {
@@ -94,6 +95,7 @@ enum { VG_MARGIN_OLD = 0, VG_MARGIN_SECOND_NEW = 1, VG_MARGIN_NONE = 2 };
  * para_Pose / para_SpeedBias / para_Ex_Pose / para_Feature / para_Td (estimator.cpp:486-528),
  * f_manager.feature (:719-764), pre_integrations[] (:711-718) and last_marginalization_info (:703-709).
  * All arrays are caller-owned host memory, read-only. */
+#define VG_PRIOR_RESIDENT (-1)
 typedef struct {
     int K;                       /* frames in the window = WINDOW_SIZE + 1                        */
     int L;                       /* landmarks that pass used_num>=2 && start_frame<WINDOW_SIZE-2  */
@@ -108,7 +110,13 @@ typedef struct {
     const int* lm_obs_off;       /* L      first row of this landmark in `obs`                     */
     const double* obs;           /* n_obs x 7  [x y u v vx vy cur_td]; x,y normalised (z = 1)      */
     const vg_imu_preint* imu;    /* K-1    factor k links frame k -> k+1                           */
-    /* prior (MarginalizationFactor, marginalization_factor.cpp:321-381); prior_n == 0: none */
+    /* prior (MarginalizationFactor, marginalization_factor.cpp:321-381); prior_n == 0: none.
+     * prior_n == VG_PRIOR_RESIDENT: the prior this window slot (index in the batch) holds ON THE DEVICE -- the result of the
+     * marginalization of the handle's last run for that slot if it produced one (flag != VG_MARGIN_NONE, vg_ba_prior.valid),
+     * else the prior the slot was last given.  The reference keeps last_marginalization_info in place between two calls of
+     * optimization() (estimator.cpp:703-709, :836-870); this is the same thing for a prior that lives in HBM: nothing of it
+     * crosses the host boundary (download the states with out_priors = NULL).  The other prior_* fields are ignored.  Needs
+     * the same K and the same batch slot as the run that produced it; VG_ERR_BAD_ARG if the slot holds nothing.          */
     int prior_n;                 /* rows of the prior = sum of local block sizes                   */
     int prior_nblocks;
     const int* prior_block_kind; /* VG_BLK_*                                                       */

@@ -203,6 +203,28 @@ def test_marginalize_old_parity(handle, ex, td):
     _check_prior(pr_g, pr_o)
 
 
+def marginalize_many_frame0_landmarks(h, K=11, L=200, w0=6, n_frames=18, min_m=100):
+    """A window that has been sliding for a while: most landmarks are anchored at frame 0 (long tracks pile up there as
+    slideWindow() shifts start_frame down, feature_manager.cpp:297-323), so the dropped block [pose 0 | speed-bias 0 | their
+    inverse depths] is wider than the kept part.  Amm^-1 [Amr | bmm] comes from the block elimination over the diagonal
+    landmark part for any such width (no m x m eigen-decomposition, no LDS-size cliff).  Shared with the emulator tests."""
+    seq = synth.SyntheticSequence(47, n_frames=n_frames, K=K, L=L)
+    prob = seq.window(w0)
+    m = 15 + int((np.asarray(prob['lm_start']) == 0).sum())
+    assert m >= min_m, m
+    x, _ = B.solve(prob)
+    at = dict(prob)
+    at.update(pose=x['pose'], sb=x['sb'], ex=x['ex'], td=x['td'], inv_depth=x['inv_depth'], max_iters=0)
+    _, _, pr_o = B.optimization(at, B.MARGIN_OLD)
+    _, sm_g, pr_g = h.ba_optimize(at, ba.VG_MARGIN_OLD)
+    assert sm_g['status'] == 0 and pr_g['m'] == m
+    _check_prior(pr_g, pr_o)
+
+
+def test_marginalize_many_frame0_landmarks(handle):
+    marginalize_many_frame0_landmarks(handle)
+
+
 @pytest.mark.parametrize("flag", ["old", "second_new"])
 def test_marginalization_eigen_form_matches_the_square_root_form(handle, flag):
     """vg_ba_set_marg_mode: the default prior factor is the pivoted-Cholesky square root of the kept system, VG_MARG_EIGEN the
@@ -267,6 +289,66 @@ def test_optimization_chain_two_windows(handle):
     # own window at the HIP chain's own optimum.
     pr2_ref = B.marginalize(prob2_g, st2_g, B.MARGIN_OLD)
     _check_prior(pr2_g, pr2_ref, dx=1e-9)
+
+
+def _same_prior(a, b):
+    return (a is None) == (b is None) and (a is None or (a['n'] == b['n'] and a['blocks'] == b['blocks'] and np.array_equal(a['J0'], b['J0'])
+                                                      and np.array_equal(a['r0'], b['r0'])
+                                                      and all(np.array_equal(u, v) for u, v in zip(a['x0'], b['x0']))))
+
+
+def _same_state(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in ('pose', 'sb', 'ex', 'inv_depth')) and a['td'] == b['td']
+
+
+def resident_prior_chain(h, L=40):
+    """VG_PRIOR_RESIDENT: the prior a run's marginalization leaves on the device feeds the next frame's solve of the same batch
+    slot without crossing the host boundary — bit-identical to taking it through vg_ba_prior and back (last_marginalization_info
+    staying in place between two calls of optimization(), estimator.cpp:703-709).  Shared with the CPU emulator tests."""
+    seqs = [synth.SyntheticSequence(90 + s, n_frames=14, L=L) for s in range(3)]
+    first = [q.window(0) for q in seqs]
+    old = [ba.VG_MARGIN_OLD] * 3
+
+    def step(probs, flags):
+        h.ba_upload(probs, flags)
+        h.ba_run_async()
+        return h.ba_download()
+
+    st1, sm1, pr1 = step(first, old)
+    assert all(s['status'] == 0 for s in sm1) and all(p is not None for p in pr1)
+
+    def with_priors(probs, priors):
+        return [dict(p, prior=q) for p, q in zip(probs, priors)]
+    # (next_window draws the new frame's noise from the sequence's generator: every window is built once, the prior swapped)
+    w2 = [q.next_window(st1[i], pr1[i], 1) for i, q in enumerate(seqs)]
+    # frame 2: slot 1 brings its prior from the host (a mixed batch), slots 0 and 2 use what the run left on the device
+    st2r, sm2r, pr2r = step(with_priors(w2, ['resident', pr1[1], 'resident']), old)
+    # frame 3 on top of it: the carry a second time; slot 1 is not marginalized in this run ...
+    w3 = [q.next_window(st2r[i], pr2r[i], 2) for i, q in enumerate(seqs)]
+    flags3 = [ba.VG_MARGIN_OLD, ba.VG_MARGIN_NONE, ba.VG_MARGIN_OLD]
+    st3r, sm3r, pr3r = step(with_priors(w3, ['resident'] * 3), flags3)
+    assert pr3r[1] is None
+    # ... so its slot still holds frame 2's prior while slots 0 and 2 have moved on: give those two frame 2's prior again
+    st3m, sm3m, _ = step(with_priors(w3, [pr2r[0], 'resident', pr2r[2]]), [ba.VG_MARGIN_NONE] * 3)
+    # the same chain with every prior taken through the host
+    st1h, _, pr1h = step(first, old)
+    assert all(_same_state(a, b) for a, b in zip(st1, st1h)) and all(_same_prior(a, b) for a, b in zip(pr1, pr1h))
+    st2h, sm2h, pr2h = step(w2, old)
+    for i in range(3):
+        assert sm2r[i]['status'] == 0 and sm2r[i]['num_iterations'] == sm2h[i]['num_iterations']
+        assert _same_state(st2r[i], st2h[i]) and _same_prior(pr2r[i], pr2h[i]), i
+    st3h, sm3h, pr3h = step(w3, flags3)
+    for i in range(3):
+        assert _same_state(st3r[i], st3h[i]) and _same_prior(pr3r[i], pr3h[i]), i
+        assert _same_state(st3m[i], st3h[i]), i
+    # a slot that holds nothing is refused
+    hh = h
+    with pytest.raises(RuntimeError, match="status -1.*holds no prior"):
+        hh.ba_upload(with_priors(w2, ['resident'] * 3) + [dict(first[0], prior='resident')])       # a fourth slot was never used
+
+
+def test_prior_stays_on_the_device_between_frames(handle):
+    resident_prior_chain(handle, L=60)
 
 
 def test_marginalize_second_new_parity(handle):

@@ -9,7 +9,7 @@ from oracle import ba_numpy as B
 from vins_mono_amd import ba, synth
 
 import ba_fixtures as FX
-from test_ba_gpu import _check_solve, _check_prior
+from test_ba_gpu import _check_solve, _check_prior, resident_prior_chain, marginalize_many_frame0_landmarks
 
 
 def test_emulated_solve_matches_oracle(simt_handle):
@@ -52,6 +52,15 @@ def test_emulated_marginalization_matches_oracle(simt_handle):
         _check_prior(pr_g, pr_o)
         rows = int((np.abs(pr_g['J0']).sum(axis=1) > 0).sum())
         assert rows < pr_g['n']                                  # a first window is gauge-deficient: the cut removes directions
+
+
+def test_emulated_marginalization_many_frame0_landmarks(simt_handle):
+    """m = 15 + 60 landmarks > the LDS leading dimension of a 5-frame window (57): the case that used to leave the fast path."""
+    marginalize_many_frame0_landmarks(simt_handle, K=5, L=70, w0=2, n_frames=10, min_m=60)
+
+
+def test_emulated_prior_stays_on_the_device_between_frames(simt_handle):
+    resident_prior_chain(simt_handle, L=16)
 
 
 @pytest.mark.parametrize("K", [4, 7, 12])

@@ -8,6 +8,7 @@
 #include "vg_range.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,9 @@ extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* 
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream);
 extern "C" const char* ba_failed_launch();
 extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream);
+extern "C" hipError_t ba_launch_carry_prior(int nwin, const double* mout, const int* miout, int mo_J0, int mo_r0, int mo_x0, int mo_stride,
+                                            int mi_stride, int mcap, int x0cap, double* pri, int po_x0, int po_r0, int po_J0, int pld,
+                                            int pstride, hipStream_t stream);
 
 #define HIPCHK(h, expr)                                                                            \
     do {                                                                                           \
@@ -56,7 +60,9 @@ static int check_problem(vg_handle* h, const vg_ba_problem* p) {
             h->err = "landmark track outside the window"; return VG_ERR_BAD_ARG;
         }
     }
-    if (p->prior_n < 0 || (p->prior_n > 0 && (!p->prior_block_kind || !p->prior_block_index || !p->prior_J0 || !p->prior_r0 || !p->prior_x0))) {
+    if (p->prior_n == VG_PRIOR_RESIDENT) {
+        // the prior this window slot holds on the device: its block table is checked when it is resolved (vg_ba_batch_upload)
+    } else if (p->prior_n < 0 || (p->prior_n > 0 && (!p->prior_block_kind || !p->prior_block_index || !p->prior_J0 || !p->prior_r0 || !p->prior_x0))) {
         h->err = "bad prior"; return VG_ERR_BAD_ARG;
     }
     if (p->prior_n > 0) {
@@ -94,8 +100,17 @@ static int check_problem(vg_handle* h, const vg_ba_problem* p) {
     return VG_OK;
 }
 
+// The prior of a window as the packer sees it: the caller's arrays, or (VG_PRIOR_RESIDENT) the block table of what the
+// window slot holds on the device.
+struct PriorRef {
+    int n = 0, nb = 0;
+    const int* kind = nullptr;
+    const int* idx = nullptr;
+    bool resident = false;
+};
+
 // ---- layout -------------------------------------------------------------------------------------
-static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, BaLayout& L) {
+static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, const PriorRef* pr, BaLayout& L) {
     memset(&L, 0, sizeof(L));
     const vg_ba_problem* p0 = in[0];
     L.nwin = nwin;
@@ -117,8 +132,8 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         Lmax = std::max(Lmax, p->L);
         Fmax = std::max(Fmax, F);
         Omax = std::max(Omax, p->n_obs + p->relo_n);
-        Nmax = std::max(Nmax, p->prior_n);
-        NBmax = std::max(NBmax, p->prior_nblocks);
+        Nmax = std::max(Nmax, pr[w].n);
+        NBmax = std::max(NBmax, pr[w].nb);
     }
     L.Kp = L.K + (relo ? 1 : 0);
     L.e = p0->estimate_extrinsic ? 1 : 0;
@@ -224,12 +239,15 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.do_lam = o; o += L.Lcap;
     L.do_obs = o; o += L.Ocap * BA_OBS_STRIDE;
     L.do_imu = o; o += (L.K - 1) * BA_IMU_STRIDE;
-    L.do_pJ0 = o; o += L.Ncap * L.Ncap;
-    L.do_pJ0t = o; o += L.Ncap * L.Ncap;
-    L.do_pr0 = o; o += L.Ncap;
-    L.do_px0 = o; o += L.NBcap * 9;
     L.do_par = o; o += P_NPAR;
     L.dstride = up(o, 8);
+    // ---- prior factor: a buffer of its own whose layout depends on K alone as long as the prior is one the marginalization
+    //      can have produced (n <= 6K + 25, <= K + 4 blocks) -- so that a prior can stay where it is between frames
+    L.pld = std::max(up(6 * L.K + 9 * 2 + 6 + 1, 8), L.Ncap);
+    L.po_x0 = 0;
+    L.po_r0 = 9 * std::max(up(L.K + 4, 8), L.NBcap);
+    L.po_J0 = L.po_r0 + L.pld;
+    L.pstride = up(L.po_J0 + L.pld * L.pld, 8);
     // ---- scratch
     o = 0;
     L.so_ctl = o; o += C_NCTL;
@@ -238,6 +256,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.so_lam = o; o += 2 * L.Lcap;
     L.so_imuU = o; o += up((L.K - 1) * 225, 2);
     L.so_Hp = o; o += L.Ncap * L.Ncap;
+    L.so_J0t = o; o += L.Ncap * L.Ncap;
     L.so_rec = o; o += L.Fcap * L.REC;
     L.so_sc = o; o += L.Rpad;
     L.so_sl = o; o += L.Lcap;
@@ -301,7 +320,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         const int nstm = up(16 * L.K + 8 + 1, 2);
         L.mg_cs = up(std::max(std::max(2 * mcap, 3 * (L.mg_posmax / 2 + 2)), 2 * (3 * ((mcap + 2) / 2) + 2) + 2), 2);   // generic: one table
                                                      // of 3*half doubles; fast path: two (double-buffered)
-        L.mg_cs = std::max(L.mg_cs, std::max(up(5 * mcap + 8, 2), 640));   // vh_eig: running diagonal, norms, eigenvalues, flags; Amm^-1 shortcut: 96 + 2 x 256
+        L.mg_cs = std::max(L.mg_cs, std::max(up(5 * mcap + 8, 2), up(L.Lcap + 512, 2)));   // vh_eig: running diagonal, norms, eigenvalues, flags; Amm block elimination: Lcap + 2 x 256
         const int fixed = 32 + nstm + 128 + L.mg_cs;
         int ld = mcap + 1;                           // big enough for the kept part; also used for Amm when m <= ld.  ODD:
                                                      // the symmetric-storage Jacobi walks columns (stride ld doubles) and
@@ -320,7 +339,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
 // ---- packing of one window ------------------------------------------------------------------------
 struct FacTmp { int i, j, l, oi, oj; };
 
-static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, int margin, int* ia, double* di) {
+static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, const PriorRef& pr, int margin, int* ia, double* di, double* hp) {
     const int K = L.K, Kp = L.Kp;
     int* hdr = ia + L.io_hdr;
     // observations (+ relo rows)
@@ -373,7 +392,7 @@ static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, 
             for (int bc = 0; bc <= br; ++bc)
                 if (!(br == bc && br < Kp) && !(bc >= Kp)) ia[L.io_task_list + n++] = br * (br + 1) / 2 + bc;
     }
-    hdr[H_L] = p->L; hdr[H_F] = F; hdr[H_NPRIOR] = p->prior_n; hdr[H_NBLK] = p->prior_n ? p->prior_nblocks : 0;
+    hdr[H_L] = p->L; hdr[H_F] = F; hdr[H_NPRIOR] = pr.n; hdr[H_NBLK] = pr.n ? pr.nb : 0;
     hdr[H_MAXIT] = p->max_iters; hdr[H_NCHUNK] = nchunk; hdr[H_MARGIN] = margin; hdr[H_STATUS] = 0;
     hdr[H_MARGMODE] = h->ba.marg_mode;
     // state
@@ -395,12 +414,13 @@ static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, 
         memcpy(d + 17, m.jacobian, 225 * 8); memcpy(d + 242, m.covariance, 225 * 8);
         ia[L.io_imu_valid + k] = (m.valid && m.sum_dt <= 10.0) ? 1 : 0;
     }
-    // prior
-    if (p->prior_n > 0) {
-        const int n = p->prior_n;
+    // prior: block table (where the rows / columns of J0 sit in the solver's ordering); the factor itself goes to the
+    // window's slot of the prior buffer unless it is there already
+    if (pr.n > 0) {
+        const int n = pr.n;
         int off = 0, x0off = 0;
-        for (int b = 0; b < p->prior_nblocks; ++b) {
-            const int kind = p->prior_block_kind[b], idx = p->prior_block_index[b];
+        for (int b = 0; b < pr.nb; ++b) {
+            const int kind = pr.kind[b], idx = pr.idx[b];
             ia[L.io_pb_kind + b] = kind;
             ia[L.io_pb_idx + b] = idx;
             ia[L.io_pb_off + b] = off;
@@ -414,19 +434,31 @@ static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, 
             off += blk_lsize(kind);
             x0off += blk_gsize(kind);
         }
-        memcpy(di + L.do_px0, p->prior_x0, sizeof(double) * x0off);
-        for (int r = 0; r < n; ++r)
-            for (int c = 0; c < n; ++c) {
-                const double v = p->prior_J0[(size_t)r * n + c];
-                di[L.do_pJ0 + (size_t)r * L.Ncap + c] = v;
-                di[L.do_pJ0t + (size_t)c * L.Ncap + r] = v;
-            }
-        memcpy(di + L.do_pr0, p->prior_r0, sizeof(double) * n);
+        if (!pr.resident) {
+            memcpy(hp + L.po_x0, p->prior_x0, sizeof(double) * x0off);
+            memcpy(hp + L.po_r0, p->prior_r0, sizeof(double) * n);
+            for (int r = 0; r < n; ++r) memcpy(hp + L.po_J0 + (size_t)r * L.pld, p->prior_J0 + (size_t)r * n, sizeof(double) * n);
+        }
     }
     di[L.do_par + P_FOCAL] = p->focal; di[L.do_par + P_TR] = p->tr; di[L.do_par + P_ROW] = p->row;
     di[L.do_par + P_GNORM] = p->g_norm;
     di[L.do_par + P_MAXTIME] = (p->max_solver_time_s > 0.0 && !h->ba.allreduce) ? p->max_solver_time_s : 0.0;
     return VG_OK;
+}
+
+// windows are independent: a few host threads share the packing / unpacking of a batch (strided assignment)
+static int host_threads_for(int nwin) {
+    static const int cap = [] { const char* e = getenv("VG_PACK_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? std::min(v, 64) : 8; }();
+    return std::max(1, std::min(cap, nwin / 16));
+}
+template <typename F>
+static void for_windows(int nwin, F&& body) {            // body(thread, window)
+    const int nthr = host_threads_for(nwin);
+    if (nthr == 1) { for (int w = 0; w < nwin; ++w) body(0, w); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthr; ++t)
+        pool.emplace_back([&, t] { for (int w = t; w < nwin; w += nthr) body(t, w); });
+    for (auto& th : pool) th.join();
 }
 
 // ---- device buffers -------------------------------------------------------------------------------
@@ -440,19 +472,76 @@ static int ensure(vg_handle* h, T*& ptr, size_t& cap, size_t need) {
     return VG_OK;
 }
 
+// ---- priors that stay on the device -----------------------------------------------------------------
+// The first upload after a run that asks for a resident prior collects the block tables of that run's marginalization
+// (a few dozen ints per window) and moves the factors device-to-device from the marginalization output into the prior slots.
+static int resolve_resident(vg_handle* h, int nwin, const vg_ba_problem* const* in, std::vector<PriorRef>& pr, bool& carry) {
+    BaBatch& B = h->ba;
+    carry = false;
+    bool any = false;
+    for (int w = 0; w < nwin; ++w) any = any || in[w]->prior_n == VG_PRIOR_RESIDENT;
+    if (any && B.mout_pending) {
+        if (B.run_K != in[0]->K) { h->err = "resident prior: the window size changed since the run that produced it"; return VG_ERR_BAD_ARG; }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<int> mi((size_t)B.run_nwin * B.run_mi_stride);
+        HIPCHK(h, hipMemcpy(mi.data(), B.P.miout, mi.size() * sizeof(int), hipMemcpyDeviceToHost));
+        if ((int)B.slot.size() < B.run_nwin) B.slot.resize(B.run_nwin);
+        for (int w = 0; w < B.run_nwin; ++w) {
+            const int* m = mi.data() + (size_t)w * B.run_mi_stride;
+            if (B.run_margin[w] == VG_MARGIN_NONE || !m[0]) continue;      // no new prior: the slot keeps what it holds
+            BaBatch::PriorSlot& s = B.slot[w];
+            s.n = m[1]; s.nb = m[3];
+            s.kind.assign(m + 8, m + 8 + s.nb);
+            s.idx.assign(m + 8 + (B.run_K + 4), m + 8 + (B.run_K + 4) + s.nb);
+            carry = true;
+        }
+    }
+    for (int w = 0; w < nwin; ++w) {
+        const vg_ba_problem* p = in[w];
+        PriorRef& r = pr[w];
+        if (p->prior_n != VG_PRIOR_RESIDENT) {
+            r.n = p->prior_n; r.nb = p->prior_n ? p->prior_nblocks : 0; r.kind = p->prior_block_kind; r.idx = p->prior_block_index;
+            continue;
+        }
+        if (w >= (int)B.slot.size() || B.slot[w].n <= 0) {
+            h->err = "VG_PRIOR_RESIDENT: window " + std::to_string(w) + " holds no prior on the device";
+            return VG_ERR_BAD_ARG;
+        }
+        const BaBatch::PriorSlot& s = B.slot[w];
+        r.n = s.n; r.nb = s.nb; r.kind = s.kind.data(); r.idx = s.idx.data(); r.resident = true;
+    }
+    return VG_OK;
+}
+
 extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* const* in, const int* margin_flags) {
     VG_RANGE("vg_ba_batch_upload");
     if (!h || nwin <= 0 || !in) return VG_ERR_BAD_ARG;
+    for (int w = 0; w < nwin; ++w) if (!in[w]) return VG_ERR_BAD_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     BaBatch& B = h->ba;
     B.uploaded = false;              // a failed upload must not leave the previous batch's flags next to the new layout
     B.solved_recorded = false;
-    BaLayout L;
-    int rc = build_layout(h, nwin, in, L);
+    static const bool debug_upload = getenv("VG_DEBUG_UPLOAD") != nullptr;      // phase times of this call on stderr
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto t_prev = t_0;
+    double t_ph[6] = {0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int k) { const auto n = std::chrono::steady_clock::now(); t_ph[k] += std::chrono::duration<double, std::micro>(n - t_prev).count(); t_prev = n; };
+    std::vector<PriorRef> pr(nwin);
+    bool carry = false, any_resident = false, any_host_prior = false;
+    int rc = resolve_resident(h, nwin, in, pr, carry);
+    stamp(0);
     if (rc) return rc;
+    for (int w = 0; w < nwin; ++w) { any_resident = any_resident || pr[w].resident; any_host_prior = any_host_prior || (!pr[w].resident && pr[w].n > 0); }
+    BaLayout L;
+    rc = build_layout(h, nwin, in, pr.data(), L);
+    if (rc) return rc;
+    if ((any_resident || carry) && B.cap_pri && (B.slot_K != L.K || B.slot_po_r0 != L.po_r0 || B.slot_pld != L.pld || B.slot_pstride != L.pstride)) {
+        h->err = "resident prior: the batch needs a different prior layout (window size or prior capacity changed)";
+        return VG_ERR_UNSUPPORTED;
+    }
     B.L = L;
     B.nwin = nwin;
-    const size_t n_ia = (size_t)nwin * L.istride, n_di = (size_t)nwin * L.dstride;
+    const size_t n_ia = (size_t)nwin * L.istride, n_di = (size_t)nwin * L.dstride, n_pri = (size_t)nwin * L.pstride;
     if (n_ia > B.hcap_ia) {
         if (B.h_ia) HIPCHK(h, hipHostFree(B.h_ia));
         B.h_ia = nullptr; B.hcap_ia = 0;
@@ -465,6 +554,12 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
         HIPCHK(h, hipHostMalloc((void**)&B.h_di, n_di * sizeof(double), hipHostMallocDefault));
         B.hcap_di = n_di;
     }
+    if (any_host_prior && n_pri > B.hcap_pri) {
+        if (B.h_pri) HIPCHK(h, hipHostFree(B.h_pri));
+        B.h_pri = nullptr; B.hcap_pri = 0;
+        HIPCHK(h, hipHostMalloc((void**)&B.h_pri, n_pri * sizeof(double), hipHostMallocDefault));
+        B.hcap_pri = n_pri;
+    }
     B.flops = 0.0; B.flops_marg = 0.0; B.bytes_in = 0.0; B.bytes_out = 0.0;
     for (double& v : B.flops_k) v = 0.0;
     if (L.big && margin_flags)
@@ -475,29 +570,21 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     B.rounds = 0;
     for (int w = 0; w < nwin; ++w) B.rounds = std::max(B.rounds, in[w]->max_iters);
     B.rounds = std::max(B.rounds, 1);          // round 0 also evaluates the initial cost (max_iters = 0 windows)
-    // pack: windows are independent -> a few host threads (zero-fill + pack of their own slabs)
+    // pack: zero-fill + pack of every window's slabs
     {
-        const int nthr = std::max(1, std::min(8, nwin / 16));
-        std::vector<int> rcs(nthr, VG_OK);
-        auto work = [&](int t) {
-            for (int w = t; w < nwin; w += nthr) {
-                int* ia = B.h_ia + (size_t)w * L.istride;
-                double* di = B.h_di + (size_t)w * L.dstride;
-                memset(ia, 0, sizeof(int) * L.istride);
-                memset(di, 0, sizeof(double) * L.dstride);
-                const int mf = margin_flags ? margin_flags[w] : VG_MARGIN_NONE;
-                const int r = pack_window(h, L, in[w], mf, ia, di);
-                if (r != VG_OK && rcs[t] == VG_OK) rcs[t] = r;
-            }
-        };
-        if (nthr == 1) work(0);
-        else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthr; ++t) pool.emplace_back(work, t);
-            for (auto& th : pool) th.join();
-        }
-        for (int t = 0; t < nthr; ++t) if (rcs[t] != VG_OK) return rcs[t];
+        std::vector<int> rcs(64, VG_OK);
+        for_windows(nwin, [&](int t, int w) {
+            int* ia = B.h_ia + (size_t)w * L.istride;
+            double* di = B.h_di + (size_t)w * L.dstride;
+            memset(ia, 0, sizeof(int) * L.istride);
+            memset(di, 0, sizeof(double) * L.dstride);
+            const int mf = margin_flags ? margin_flags[w] : VG_MARGIN_NONE;
+            const int r = pack_window(h, L, in[w], pr[w], mf, ia, di, B.h_pri ? B.h_pri + (size_t)w * L.pstride : nullptr);
+            if (r != VG_OK && rcs[t] == VG_OK) rcs[t] = r;
+        });
+        for (int r : rcs) if (r != VG_OK) return r;
     }
+    stamp(1);
     for (int w = 0; w < nwin; ++w) {
         const int mf = margin_flags ? margin_flags[w] : VG_MARGIN_NONE;
         B.margin[w] = mf;
@@ -511,7 +598,7 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
             schur += (6 * n) * (6 * n + 1) + 12 * n;
             sumn += n;
         }
-        const double np = p->prior_n, R = L.R;
+        const double np = pr[w].n, R = L.R;
         // per launch class (include/vinsgpu.h VG_BA_KERNEL_*), summed over the max_iters rounds of this window
         const double it = p->max_iters;
         const double f_lin = it * (F * 750 + 10 * 37000.0 + 4 * np * np + F * 145 + 10 * 9000.0);    // factor evaluation (+ the step evaluation it replaces)
@@ -537,36 +624,103 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
             B.flops_k[5] += fm;
         }
         B.flops += fl;
-        B.bytes_in += 8.0 * (16 * L.K + 8 + p->L + 7.0 * p->n_obs + (L.K - 1) * 467.0 + np * np + 2 * np) + 12.0 * p->L;
+        B.bytes_in += 8.0 * (16 * L.K + 8 + p->L + 7.0 * p->n_obs + (L.K - 1) * 467.0 + np * np + 2 * np) + 12.0 * p->L;   // (a resident prior is still read by the kernels)
         B.bytes_out += 8.0 * (16 * L.K + 8 + p->L) + (mf != VG_MARGIN_NONE ? 8.0 * (75.0 * 75 + 75 + 100) : 0.0);
     }
+    stamp(2);
     rc = ensure(h, B.P.iarr, B.cap_ia, (size_t)nwin * L.istride); if (rc) return rc;
     rc = ensure(h, B.P.din, B.cap_di, (size_t)nwin * L.dstride); if (rc) return rc;
     rc = ensure(h, B.P.scr, B.cap_sc, (size_t)nwin * L.sstride); if (rc) return rc;
     rc = ensure(h, B.P.out, B.cap_out, (size_t)nwin * L.ostride); if (rc) return rc;
     rc = ensure(h, B.P.iout, B.cap_iout, (size_t)nwin * L.oi_stride); if (rc) return rc;
+    rc = ensure(h, B.P.mscr, B.cap_mscr, (size_t)nwin * L.ms_stride); if (rc) return rc;
+    // prior slots: growing keeps what the slots hold (same layout: slot w stays at w * pstride)
+    {
+        const size_t need = std::max(n_pri, carry ? (size_t)B.run_nwin * L.pstride : (size_t)0);
+        if (need > B.cap_pri || !B.P.pri) {
+            double* fresh = nullptr;
+            HIPCHK(h, hipMalloc((void**)&fresh, need * sizeof(double)));
+            if (B.P.pri && B.cap_pri && B.slot_pstride == L.pstride)
+                HIPCHK(h, hipMemcpy(fresh, B.P.pri, std::min(B.cap_pri, need) * sizeof(double), hipMemcpyDeviceToDevice));
+            if (B.P.pri) HIPCHK(h, hipFree(B.P.pri));
+            B.P.pri = fresh; B.cap_pri = need;
+        }
+    }
+    if (B.slot_K != L.K || B.slot_po_r0 != L.po_r0 || B.slot_pld != L.pld || B.slot_pstride != L.pstride) {
+        B.slot.clear();              // another layout: nothing the slots held can be addressed any more
+        B.slot_K = L.K; B.slot_po_r0 = L.po_r0; B.slot_pld = L.pld; B.slot_pstride = L.pstride;
+    }
+    if (carry) {
+        hipError_t e = ba_launch_carry_prior(B.run_nwin, B.P.mout, B.P.miout, B.run_mo_J0, B.run_mo_r0, B.run_mo_x0, B.run_mo_stride,
+                                             B.run_mi_stride, B.run_mcap, 9 * (B.run_K + 4), B.P.pri, L.po_x0, L.po_r0, L.po_J0, L.pld,
+                                             L.pstride, h->stream);
+        if (e != hipSuccess) { h->err = std::string("launch of ba_carry_prior_kernel: ") + hipGetErrorString(e); return VG_ERR_HIP; }
+        HIPCHK(h, hipStreamSynchronize(h->stream));      // mout / miout may be re-allocated and are cleared below
+        B.mout_pending = false;
+    }
+    stamp(3);
     rc = ensure(h, B.P.mout, B.cap_mout, (size_t)nwin * L.mo_stride); if (rc) return rc;
     rc = ensure(h, B.P.miout, B.cap_miout, (size_t)nwin * L.mi_stride); if (rc) return rc;
-    rc = ensure(h, B.P.mscr, B.cap_mscr, (size_t)nwin * L.ms_stride); if (rc) return rc;
     if (L.big) {
         rc = ensure(h, B.P.rb1, B.cap_rb1, (size_t)nwin * L.rb1_len); if (rc) return rc;
         rc = ensure(h, B.P.rb2, B.cap_rb2, (size_t)nwin * RB2_LEN); if (rc) return rc;
         HIPCHK(h, hipMemsetAsync(B.P.rb1, 0, (size_t)nwin * L.rb1_len * sizeof(double), h->stream));
         HIPCHK(h, hipMemsetAsync(B.P.rb2, 0, (size_t)nwin * RB2_LEN * sizeof(double), h->stream));
     }
-    if (!B.dL) HIPCHK(h, hipMalloc((void**)&B.dL, sizeof(BaLayout)));
-    HIPCHK(h, hipMemcpyAsync(B.dL, &B.L, sizeof(BaLayout), hipMemcpyHostToDevice, h->stream));
+    if (!B.dL) { HIPCHK(h, hipMalloc((void**)&B.dL, sizeof(BaLayout))); B.dL_valid = false; }
+    if (!B.dL_valid || memcmp(&B.dL_host, &B.L, sizeof(BaLayout)) != 0) {      // frame after frame the layout does not change
+        HIPCHK(h, hipMemcpyAsync(B.dL, &B.L, sizeof(BaLayout), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));                            // (&B.L is pageable memory)
+        B.dL_host = B.L; B.dL_valid = true;
+    }
     HIPCHK(h, hipMemcpyAsync(B.P.iarr, B.h_ia, n_ia * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(B.P.din, B.h_di, n_di * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(B.P.iout, 0, (size_t)nwin * L.oi_stride * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(B.P.miout, 0, (size_t)nwin * L.mi_stride * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(B.P.out, 0, (size_t)nwin * L.ostride * sizeof(double), h->stream));
+    if (any_host_prior) {
+        // priors that come from the host: the used part of every slot (x0, r0 and the first n rows of J0)
+        if (!any_resident) {
+            int nmax = 0;
+            for (int w = 0; w < nwin; ++w) nmax = std::max(nmax, pr[w].n);
+            const size_t used = (size_t)L.po_J0 + (size_t)nmax * L.pld;
+            if (nwin == 1) HIPCHK(h, hipMemcpyAsync(B.P.pri, B.h_pri, used * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            else HIPCHK(h, hipMemcpy2DAsync(B.P.pri, (size_t)L.pstride * sizeof(double), B.h_pri, (size_t)L.pstride * sizeof(double),
+                                            used * sizeof(double), nwin, hipMemcpyHostToDevice, h->stream));
+        } else {
+            for (int w = 0; w < nwin; ++w)
+                if (!pr[w].resident && pr[w].n > 0)
+                    HIPCHK(h, hipMemcpyAsync(B.P.pri + (size_t)w * L.pstride, B.h_pri + (size_t)w * L.pstride,
+                                             ((size_t)L.po_J0 + (size_t)pr[w].n * L.pld) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    // (the output slabs are cleared by the prologue kernel of every run)
+    stamp(4);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    stamp(5);
+    if (debug_upload)
+        fprintf(stderr, "[upload] %d windows: resolve %.0f us, layout + pack %.0f, model %.0f, alloc + carry %.0f, enqueue %.0f, wait %.0f | bytes: ints %.2f MB, doubles %.2f MB, priors %s\n",
+                nwin, t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4], t_ph[5], n_ia * 4e-6, n_di * 8e-6, any_host_prior ? "host" : (any_resident ? "resident" : "none"));
+    // what the slots hold now
+    if ((int)B.slot.size() < nwin) B.slot.resize(nwin);
+    for (int w = 0; w < nwin; ++w) {
+        if (pr[w].resident) continue;
+        BaBatch::PriorSlot& sl = B.slot[w];
+        sl.n = pr[w].n; sl.nb = pr[w].nb;
+        sl.kind.assign(pr[w].kind, pr[w].kind + (pr[w].n ? pr[w].nb : 0));
+        sl.idx.assign(pr[w].idx, pr[w].idx + (pr[w].n ? pr[w].nb : 0));
+    }
     B.any_margin = false;
     for (int w = 0; w < nwin; ++w) B.any_margin = B.any_margin || B.margin[w] != VG_MARGIN_NONE;
     B.solved_recorded = false;
     B.uploaded = true;
     return VG_OK;
+}
+
+// a marginalization run leaves new priors in mout / miout: remember how to find them (resolve_resident)
+static void note_marg_run(BaBatch& B) {
+    B.mout_pending = true;
+    B.run_margin = B.margin;
+    B.run_nwin = B.nwin; B.run_K = B.L.K;
+    B.run_mo_J0 = B.L.mo_J0; B.run_mo_r0 = B.L.mo_r0; B.run_mo_x0 = B.L.mo_x0; B.run_mo_stride = B.L.mo_stride;
+    B.run_mi_stride = B.L.mi_stride; B.run_mcap = B.L.mcap;
 }
 
 // all launches of one batch solve on h->stream (single-workgroup pipeline or the large-window path with its all-reduce hook)
@@ -597,7 +751,7 @@ extern "C" int vg_ba_batch_run_async(vg_handle* h) {
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));           // states final: vg_ba_batch_download_state waits for this only
     B.solved_recorded = true;
-    if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
+    if (B.any_margin) { HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream)); note_marg_run(B); }
     return VG_OK;
 }
 
@@ -640,7 +794,7 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
         if (rc) return rc;
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));
-    if (B.any_margin) HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
+    if (B.any_margin) { HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream)); note_marg_run(B); }
     HIPCHK(h, hipEventRecord(e2, h->stream));
     HIPCHK(h, hipEventSynchronize(e2));
     float a = 0, b = 0;
@@ -668,6 +822,7 @@ extern "C" int vg_ba_batch_run_profiled(vg_handle* h, float* ms, int* n) {
     }
     if (B.any_margin) {
         HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
+        note_marg_run(B);
         HIPCHK(h, hipEventRecord(ev[nl + 1], h->stream));
         kinds[nl] = VG_BA_KERNEL_MARG;
         ++nl;
@@ -716,8 +871,9 @@ extern "C" int vg_ba_batch_info(vg_handle* h, double* flops, double* bytes_in, d
 static int unpack_states(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_summary* sum) {
     BaBatch& B = h->ba;
     const BaLayout& L = B.L;
-    int worst = VG_OK;
-    for (int w = 0; w < nwin; ++w) {
+    std::vector<int> worst_t(64, VG_OK);
+    for_windows(nwin, [&](int t, int w) {
+        int& worst = worst_t[t];
         const double* o = B.h_out.data() + (size_t)w * L.ostride;
         const int* io = B.h_iout.data() + (size_t)w * L.oi_stride;
         if (st && st[w]) {
@@ -747,7 +903,9 @@ static int unpack_states(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_s
             }
             for (int k = 0; k < 16; ++k) s.prof[k] = o[L.oo_trace + 5 * VG_MAX_ITERS + k];
         }
-    }
+    });
+    int worst = VG_OK;
+    for (int v : worst_t) if (v != VG_OK) worst = v;
     return worst;
 }
 
@@ -755,7 +913,8 @@ static int unpack_priors(vg_handle* h, int nwin, vg_ba_prior* const* pri) {
     BaBatch& B = h->ba;
     const BaLayout& L = B.L;
     static const bool debug_marg = getenv("VG_DEBUG_MARG") != nullptr;      // phase stamps of -DBA_PROFILE builds
-    for (int w = 0; w < nwin; ++w) {
+    std::vector<int> too_small(64, 0);
+    for_windows(nwin, [&](int t, int w) {
         if (pri && pri[w]) {
             vg_ba_prior* q = pri[w];
             q->n = q->m = q->nblocks = q->valid = 0;
@@ -770,7 +929,7 @@ static int unpack_priors(vg_handle* h, int nwin, vg_ba_prior* const* pri) {
                 }
                 if (mi[0]) {
                     const int n = mi[1], nb = mi[3];
-                    if (n > q->cap || nb > q->cap_blocks) { h->err = "vg_ba_prior capacity too small"; return VG_ERR_BAD_ARG; }
+                    if (n > q->cap || nb > q->cap_blocks) { too_small[t] = 1; return; }
                     // (x0 is documented as 9 * cap_blocks doubles: global sizes are 7 / 9 / 7 / 1, so nb <= cap_blocks bounds it)
                     q->n = n; q->m = mi[2]; q->nblocks = nb;
                     const int mcap = L.mcap;
@@ -786,7 +945,8 @@ static int unpack_priors(vg_handle* h, int nwin, vg_ba_prior* const* pri) {
                 }
             }
         }
-    }
+    });
+    for (int v : too_small) if (v) { h->err = "vg_ba_prior capacity too small"; return VG_ERR_BAD_ARG; }
     return VG_OK;
 }
 
@@ -890,7 +1050,7 @@ extern "C" int vg_ba_eval_factors(vg_handle* h, const vg_ba_problem* in, double*
     if (rc) return rc;
     BaBatch& B = h->ba;
     const BaLayout& L = B.L;
-    const int F = B.h_ia[L.io_hdr + H_F], nimu = L.K - 1, n = in->prior_n;
+    const int F = B.h_ia[L.io_hdr + H_F], nimu = L.K - 1, n = B.h_ia[L.io_hdr + H_NPRIOR];
     double* d = nullptr;
     const size_t tot = (size_t)F * 2 + (size_t)F * 40 + nimu * 15 + nimu * 450 + std::max(n, 1);
     HIPCHK(h, hipMalloc((void**)&d, tot * sizeof(double)));

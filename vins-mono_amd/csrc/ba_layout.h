@@ -64,10 +64,14 @@ struct BaLayout {
     int io_hdr, io_lm_start, io_lm_fbeg, io_fac_i, io_fac_j, io_fac_lm, io_fac_oi, io_fac_oj, io_fac_slot,
         io_pair_ptr, io_task_list, io_imu_valid, io_pb_kind, io_pb_idx, io_pb_col, io_pb_off, io_pb_x0off, istride;
     // ---- double inputs (offsets in doubles, per window)
-    int do_pose, do_sb, do_ex, do_td, do_lam, do_obs, do_imu, do_pJ0, do_pJ0t, do_pr0, do_px0, do_par, dstride;
+    int do_pose, do_sb, do_ex, do_td, do_lam, do_obs, do_imu, do_par, dstride;
+    // ---- prior factor (doubles per window, buffer of its own: it can stay on the device from one frame's marginalization to
+    //      the next frame's solve, VG_PRIOR_RESIDENT): x0 [NB x 9] | r0 [pld] | J0 [pld x pld], row stride pld
+    int po_x0, po_r0, po_J0, pld, pstride;
     // ---- scratch (doubles, per window)
     int so_ctl, so_part, so_x, so_lam;          // control block, cost partials, 2 state copies (nst each), 2 x Lcap
     int so_imuU, so_Hp, so_rec;                 // sqrt_info factors, J0^T J0, projection records [Fcap][REC]
+    int so_J0t;                                 // J0 transposed (row stride Ncap), written by the prologue
     int so_sc, so_sl, so_dg, so_gt, so_gn;      // Jacobi scaling (R / Lcap), saved Dg, gt, gn over [R | Lcap] for step reuse
     int so_yl, so_lsc;                          // landmark step / sl/sqrt(h~)
     int so_ptab, so_Hpk, ptab_cap;              // prior scatter table (2 x ptab_cap ints: LDS slot of every prior entry and of its
@@ -108,6 +112,7 @@ struct BaPtrs {
     double* mscr;
     double* rb1;                              // large-window path: reduce buffers [nwin][rb1_len], [nwin][RB2_LEN]
     double* rb2;
+    double* pri;                              // prior factors [nwin][pstride]
 };
 
 // parameter slots at do_par

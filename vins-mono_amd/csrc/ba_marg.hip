@@ -30,7 +30,7 @@ extern __shared__ __attribute__((aligned(16))) char mg_smem[];
 
 struct MCtx {
     const BaLayout* Lp;
-    const int* ia; const int* hdr; const double* di; double* sc; double* ms; double* lds;
+    const int* ia; const int* hdr; const double* di; const double* pri; double* sc; double* ms; double* lds;
     int tid, lane, wave;
     double focal, tr, row, gnorm;
 };
@@ -796,6 +796,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     const int* iout = P.iout + (size_t)w * L.oi_stride;
     if (iout[0] != VG_OK) return;                       // failed solve: no prior
     c.di = P.din + (size_t)w * L.dstride;
+    c.pri = P.pri + (size_t)w * L.pstride;
     c.sc = P.scr + (size_t)w * L.sstride;
     c.ms = P.mscr + (size_t)w * L.ms_stride;
     c.lds = MG_LDS;
@@ -916,7 +917,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         for (int b = c.tid; b < nblk; b += MG_NT) {
             const double* xb = pk[b] == VG_BLK_POSE ? x + 7 * pidx[b] : (pk[b] == VG_BLK_SPEEDBIAS ? x + 7 * K + 9 * pidx[b]
                                : (pk[b] == VG_BLK_EXPOSE ? ex : ex + 7));
-            const double* x0 = c.di + L.do_px0 + px0off[b];
+            const double* x0 = c.pri + L.po_x0 + px0off[b];
             double* d = dx + poff[b];
             if (pk[b] == VG_BLK_SPEEDBIAS) { for (int k = 0; k < 9; ++k) d[k] = xb[k] - x0[k]; }
             else if (pk[b] == VG_BLK_TD) d[0] = xb[0] - x0[0];
@@ -930,15 +931,15 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             }
         }
         __syncthreads();
-        const double* J0t = c.di + L.do_pJ0t;
+        const double* J0t = c.sc + L.so_J0t;         // left by the prologue of the solve pipeline
         for (int r = c.tid; r < nprior; r += MG_NT) {
-            double s = c.di[L.do_pr0 + r];
+            double s = c.pri[L.po_r0 + r];
             for (int k = 0; k < nprior; ++k) s += J0t[k * L.Ncap + r] * dx[k];
             prv[r] = s;
         }
         __syncthreads();
         const double* Hp = c.sc + L.so_Hp;          // J0^T J0 (lower), left by the solve kernel
-        const double* J0 = c.di + L.do_pJ0;
+        const double* J0 = c.pri + L.po_J0;
         for (int wk = c.tid; wk < nprior * nprior + nprior; wk += MG_NT) {
             const bool isg = wk >= nprior * nprior;
             const int a = isg ? wk - nprior * nprior : wk / nprior, b = isg ? 0 : wk % nprior;
@@ -952,7 +953,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             }
             if (isg) {
                 double s = 0.0;
-                for (int r = 0; r < nprior; ++r) s += J0[r * L.Ncap + a] * prv[r];
+                for (int r = 0; r < nprior; ++r) s += J0[r * L.pld + a] * prv[r];
                 bv[ca] += s;
             } else {
                 A[ca * posmax + cb] += (a >= b) ? Hp[a * L.Ncap + b] : Hp[b * L.Ncap + a];
@@ -1152,38 +1153,42 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     __syncthreads();
 
     MPROF(3);
-    // ---- M4: Amm^+ via eigen-decomposition, Schur complement
+    // ---- M4: Amm^+ [Amr | bmm], Schur complement
     {
         const bool in_lds = m <= ld;
         double* Mm = in_lds ? eM : gM;
         double* Vm = in_lds ? eV : gV;
         const int ldm = in_lds ? ld : posmax;
-        for (int k = c.tid; k < m * m; k += MG_NT) {
-            const int i = k / m, j = k % m;
-            Mm[i * ldm + j] = 0.5 * (A[i * posmax + j] + A[j * posmax + i]);
-        }
-        __syncthreads();
         const int offcs = (int)(cs - MG_LDS), offred = (int)(red - MG_LDS);
-        // ---- certified shortcut.  The dropped block is [pose 0 | speed-bias 0 | frame-0 landmarks] and the landmark part of
-        // Amm is DIAGONAL (a projection factor touches one landmark), so Amm^-1 follows from the md x md Schur complement
-        // P' = P - W D^-1 W^T (md <= 15) by block elimination.  marginalization_factor.cpp:272-283 takes the eigen
-        // pseudo-inverse with the lambda > 1e-8 cut, which IS the inverse when every eigenvalue exceeds 1e-8; that is
-        // certified here by  lambda_min(Amm) >= 1 / ||Amm^-1||_F > 1e-7.  Otherwise (or if P' is not positive
-        // definite) the eigen-decomposition below runs.
+        // ---- certified block elimination.  The dropped block is [pose 0 | speed-bias 0 | frame-0 landmarks] and the landmark
+        // part of Amm is DIAGONAL (a projection factor touches one landmark):  Amm = [P W; W^T D].  With the md x md Schur
+        // complement P' = P - W D^-1 W^T (md <= 15)
+        //     X1 = P'^-1 (R1 - W D^-1 R2),   X2 = D^-1 (R2 - W^T X1)       solves  Amm X = [Amr | bmm] = [R1; R2]
+        // in O(md ml n) operations for ANY number of frame-0 landmarks, without the m x m eigen-decomposition.
+        // marginalization_factor.cpp:272-283 takes the eigen pseudo-inverse with the lambda > 1e-8 cut, which IS the inverse
+        // when every eigenvalue exceeds 1e-8; that is certified here by  lambda_min(Amm) >= 1 / ||Amm^-1||_F > 1e-7, the norm
+        // summed block by block (Amm^-1 = [B11 B12; B12^T B22], B11 = P'^-1, B12 = -P'^-1 W D^-1, B22 = D^-1 - D^-1 W^T B12)
+        // without storing B22.  Otherwise (or if P' is not positive definite) the eigen-decomposition below runs.
         const int md = m - n0, ml = n0;
         bool inverse_ok = false;
-        if (in_lds && md >= 1 && md <= 16 && ml <= 16 * MG_HROWS) {
-            double* dl = cs;                 // [ml] landmark diagonal
-            double* Ls = cs + 96;            // [md][md] Cholesky factor of P', then its inverse
-            double* Pi = Ls + 256;           // [md][md] P'^-1            (mg_cs >= 5 * mcap + 8 >= 96 + 512)
+        if (md >= 1 && md <= 16 && md * ml <= ld * ld) {
+            double* dl = cs;                 // [ml <= Lcap] landmark diagonal        (mg_cs >= Lcap + 512 checked on the host)
+            double* Ls = cs + L.Lcap;        // [md][md] Cholesky factor of P', then its inverse
+            double* Pi = Ls + 256;           // [md][md] P'^-1
+            double* Wl = eM;                 // [md][ml]
+            double* B12 = eV;                // [md][ml]
             int* okf = (int*)(red + 18);
             if (c.tid == 0) *okf = 1;
-            for (int l = c.tid; l < ml; l += MG_NT) dl[l] = Mm[(md + l) * ldm + md + l];
+            for (int l = c.tid; l < ml; l += MG_NT) dl[l] = A[(size_t)(md + l) * posmax + md + l];
+            for (int k = c.tid; k < md * ml; k += MG_NT) {
+                const int p = k / ml, l = k - p * ml;
+                Wl[k] = 0.5 * (A[(size_t)p * posmax + md + l] + A[(size_t)(md + l) * posmax + p]);
+            }
             __syncthreads();
             for (int k = c.tid; k < md * md; k += MG_NT) {
                 const int i = k / md, j = k - i * md;
-                double sacc = Mm[i * ldm + j];
-                for (int l = 0; l < ml; ++l) sacc -= Mm[i * ldm + md + l] * Mm[j * ldm + md + l] / dl[l];
+                double sacc = 0.5 * (A[(size_t)i * posmax + j] + A[(size_t)j * posmax + i]);
+                for (int l = 0; l < ml; ++l) sacc -= Wl[i * ml + l] * Wl[j * ml + l] / dl[l];
                 Ls[i * md + j] = sacc;
             }
             __syncthreads();
@@ -1234,28 +1239,23 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                 double sacc = 0.0;
                 for (int r = (i > j ? i : j); r < md; ++r) sacc += Ls[r * md + i] * Ls[r * md + j];
                 Pi[k] = sacc;
-                Vm[i * ldm + j] = sacc;                               // B11
             }
             __syncthreads();
-            for (int k = c.tid; k < md * ml; k += MG_NT) {          // B12 = -P'^-1 W D^-1 (and its transpose)
+            for (int k = c.tid; k < md * ml; k += MG_NT) {          // B12 = -P'^-1 W D^-1
                 const int p = k / ml, l = k - p * ml;
                 double sacc = 0.0;
-                for (int q = 0; q < md; ++q) sacc += Pi[p * md + q] * Mm[q * ldm + md + l];
-                const double v = -sacc / dl[l];
-                Vm[p * ldm + md + l] = v;
-                Vm[(md + l) * ldm + p] = v;
-            }
-            __syncthreads();
-            for (int k = c.tid; k < ml * ml; k += MG_NT) {          // B22 = D^-1 - D^-1 W^T B12
-                const int a_ = k / ml, b_ = k - a_ * ml;
-                double sacc = 0.0;
-                for (int p = 0; p < md; ++p) sacc += Mm[p * ldm + md + a_] * Vm[p * ldm + md + b_];
-                Vm[(md + a_) * ldm + md + b_] = (a_ == b_ ? 1.0 / dl[a_] : 0.0) - sacc / dl[a_];
+                for (int q = 0; q < md; ++q) sacc += Pi[p * md + q] * Wl[q * ml + l];
+                B12[k] = -sacc / dl[l];
             }
             __syncthreads();
             double fro = 0.0, bad = 0.0;
-            for (int k = c.tid; k < m * m; k += MG_NT) {
-                const double v = Vm[(k / m) * ldm + k % m];
+            for (int k = c.tid; k < md * md; k += MG_NT) { const double v = Pi[k]; fro += v * v; bad += (v == v && fabs(v) < 1e300) ? 0.0 : 1.0; }
+            for (int k = c.tid; k < md * ml; k += MG_NT) { const double v = B12[k]; fro += 2.0 * v * v; bad += (v == v && fabs(v) < 1e300) ? 0.0 : 1.0; }
+            for (int k = c.tid; k < ml * ml; k += MG_NT) {          // B22 = D^-1 - D^-1 W^T B12, entry by entry
+                const int a_ = k / ml, b_ = k - a_ * ml;
+                double sacc = 0.0;
+                for (int p = 0; p < md; ++p) sacc += Wl[p * ml + a_] * B12[p * ml + b_];
+                const double v = (a_ == b_ ? 1.0 / dl[a_] : 0.0) - sacc / dl[a_];
                 fro += v * v;
                 bad += (v == v && fabs(v) < 1e300) ? 0.0 : 1.0;
             }
@@ -1263,25 +1263,48 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             bad = mg_block_sum(c, red, bad);
             inverse_ok = *okf != 0 && bad == 0.0 && fro > 0.0 && fro < 1e14;      // 1 / sqrt(fro) > 1e-7
             __syncthreads();
+            if (inverse_ok) {
+                // T2 = Amm^-1 [Amr | bmm]: column j of the right-hand side is A[:, m + j] (j < n) or bv (j == n)
+                const int nc = n + 1;
+                double* U = T1;                  // [md][nc]  u = R1 - W D^-1 R2, then X1 = P'^-1 u in T2 rows 0 .. md-1
+                for (int k = c.tid; k < md * nc; k += MG_NT) {
+                    const int p = k / nc, j = k - p * nc;
+                    double sacc = j < n ? A[(size_t)p * posmax + m + j] : bv[p];
+                    for (int l = 0; l < ml; ++l) {
+                        const double r2 = j < n ? A[(size_t)(md + l) * posmax + m + j] : bv[md + l];
+                        sacc -= Wl[p * ml + l] * r2 / dl[l];
+                    }
+                    U[p * nc + j] = sacc;
+                }
+                __syncthreads();
+                for (int k = c.tid; k < md * nc; k += MG_NT) {
+                    const int p = k / nc, j = k - p * nc;
+                    double sacc = 0.0;
+                    for (int q = 0; q < md; ++q) sacc += Pi[p * md + q] * U[q * nc + j];
+                    T2[p * (mcap + 1) + j] = sacc;
+                }
+                __syncthreads();
+                for (int k = c.tid; k < ml * nc; k += MG_NT) {
+                    const int l = k / nc, j = k - l * nc;
+                    double sacc = j < n ? A[(size_t)(md + l) * posmax + m + j] : bv[md + l];
+                    for (int p = 0; p < md; ++p) sacc -= Wl[p * ml + l] * T2[p * (mcap + 1) + j];
+                    T2[(md + l) * (mcap + 1) + j] = sacc / dl[l];
+                }
+                __syncthreads();
+            }
         }
         if (inverse_ok) {
             if (c.tid == 0) mi[4] = 0;       // no sweeps: Amm^-1 by certified block elimination
             MPROF(4);
-            // T2 = Amm^-1 [Amr | bmm]
-            for (int k = c.tid; k < m * (n + 1); k += MG_NT) {
-                const int i = k / (n + 1), j = k % (n + 1);
-                const double* src = j < n ? A + m + j : bv;          // column j of [Amr | bmm]
-                const int sst = j < n ? posmax : 1;
-                double sacc = 0.0;
-#pragma unroll 8
-                for (int r = 0; r < m; ++r) sacc += Vm[i * ldm + r] * src[(size_t)r * sst];
-                T2[i * (mcap + 1) + j] = sacc;
-            }
-            __syncthreads();
         } else {
 #ifdef BA_PROFILE
         const long long _t1 = clock64();
 #endif
+        for (int k = c.tid; k < m * m; k += MG_NT) {
+            const int i = k / m, j = k % m;
+            Mm[i * ldm + j] = 0.5 * (A[i * posmax + j] + A[j * posmax + i]);
+        }
+        __syncthreads();
         const bool fast1 = in_lds && m >= 1 && m <= 16 * MG_HROWS;
         const int sw1 = fast1 ? vh_eig(c, 0, ld * ld, m, ldm, offcs, offred, 0.0, 2e-16, 0.0, 10)
                       : in_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, m, ldm, offcs, offred, true)
@@ -1426,6 +1449,29 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         mi[7] = (int)((clock64() - _tstart) >> 10);
 #endif
     }
+}
+
+// Moves the priors a marginalization run produced (mout / miout of that run's layout) into the prior slots the next solve
+// reads (BaPtrs::pri): x0, r0 and the n used rows of J0.  One workgroup per window; windows without a new prior keep their slot.
+extern "C" __global__ __launch_bounds__(256) void ba_carry_prior_kernel(const double* __restrict__ mout, const int* __restrict__ miout,
+        int mo_J0, int mo_r0, int mo_x0, int mo_stride, int mi_stride, int mcap, int x0cap, double* __restrict__ pri, int po_x0,
+        int po_r0, int po_J0, int pld, int pstride) {
+    const int w = blockIdx.x;
+    const int* mi = miout + (size_t)w * mi_stride;
+    if (!mi[0]) return;
+    const int n = mi[1];
+    const double* mo = mout + (size_t)w * mo_stride;
+    double* p = pri + (size_t)w * pstride;
+    for (int k = threadIdx.x; k < x0cap; k += 256) p[po_x0 + k] = mo[mo_x0 + k];
+    for (int k = threadIdx.x; k < n; k += 256) p[po_r0 + k] = mo[mo_r0 + k];
+    for (int k = threadIdx.x; k < n * n; k += 256) { const int r = k / n, cc = k % n; p[po_J0 + (size_t)r * pld + cc] = mo[mo_J0 + (size_t)r * mcap + cc]; }
+}
+extern "C" hipError_t ba_launch_carry_prior(int nwin, const double* mout, const int* miout, int mo_J0, int mo_r0, int mo_x0, int mo_stride,
+                                            int mi_stride, int mcap, int x0cap, double* pri, int po_x0, int po_r0, int po_J0, int pld,
+                                            int pstride, hipStream_t stream) {
+    hipLaunchKernelGGL(ba_carry_prior_kernel, dim3(nwin), dim3(256), 0, stream, mout, miout, mo_J0, mo_r0, mo_x0, mo_stride, mi_stride,
+                       mcap, x0cap, pri, po_x0, po_r0, po_J0, pld, pstride);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream) {

@@ -98,6 +98,7 @@ struct Ctx {
     const int* hdr;
     const int* ia;           // int arrays of this window
     const double* di;        // double inputs
+    const double* pri;       // prior factor [x0 | r0 | J0]
     double* sc;              // scratch
     int tid, lane, wave;
     int nL, nF, nprior, nblk;
@@ -111,6 +112,7 @@ DEV void ctx_init(Ctx& c, const BaLayout* Lp, const BaPtrs& P, int w) {
     c.hdr = c.ia + L.io_hdr;
     c.di = P.din + (size_t)w * L.dstride;
     c.sc = P.scr + (size_t)w * L.sstride;
+    c.pri = P.pri + (size_t)w * L.pstride;
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6;
     c.nL = c.hdr[H_L]; c.nF = c.hdr[H_F]; c.nprior = c.hdr[H_NPRIOR]; c.nblk = c.hdr[H_NBLK];
     c.focal = c.di[L.do_par + P_FOCAL]; c.tr = c.di[L.do_par + P_TR]; c.row = c.di[L.do_par + P_ROW];
@@ -297,6 +299,14 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
     Ctx c;
     ctx_init(c, Lp, P, blockIdx.x);
     double* x = c.sc + L.so_x;
+    {   // outputs of this window start from zero in every run (status words, iteration trace, "new prior valid" flag)
+        double* out = P.out + (size_t)blockIdx.x * L.ostride;
+        int* iout = P.iout + (size_t)blockIdx.x * L.oi_stride;
+        int* miout = P.miout + (size_t)blockIdx.x * L.mi_stride;
+        for (int k = c.tid; k < L.ostride; k += BA_NT) out[k] = 0.0;
+        for (int k = c.tid; k < L.oi_stride; k += BA_NT) iout[k] = 0;
+        for (int k = c.tid; k < L.mi_stride; k += BA_NT) miout[k] = 0;
+    }
     for (int k = c.tid; k < 7 * L.Kp; k += BA_NT) x[k] = c.di[L.do_pose + k];
     for (int k = c.tid; k < 9 * L.K; k += BA_NT) x[7 * L.Kp + k] = c.di[L.do_sb + k];
     if (c.tid < 7) x[7 * L.Kp + 9 * L.K + c.tid] = c.di[L.do_ex + c.tid];
@@ -313,14 +323,19 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
     if (c.nprior) {
         // J0^T J0 once per solve, J0 staged in LDS
         const int n = c.nprior;
-        const double* J0 = c.di + L.do_pJ0;
+        const double* J0 = c.pri + L.po_J0;
         double* Hp = c.sc + L.so_Hp;
+        // the transposed copy the linearisation reads (its dot products run down the columns of J0)
+        {
+            double* J0t = c.sc + L.so_J0t;
+            for (int wk = c.tid; wk < n * n; wk += BA_NT) { const int r = wk / n, cc = wk % n; J0t[cc * L.Ncap + r] = J0[r * L.pld + cc]; }
+        }
         // J0 staged in LDS when it fits (host: lds_pro); the two loops are spelled out so that the staged one keeps its
         // LDS addressing (a pointer that may be either costs flat loads in the inner loop)
         __syncthreads();
         if ((size_t)n * n * 8 <= (size_t)L.lds_pro) {
             double* J0s = LDSB;                  // n x n, row stride n
-            for (int wk = c.tid; wk < n * n; wk += BA_NT) J0s[wk] = J0[(wk / n) * L.Ncap + wk % n];
+            for (int wk = c.tid; wk < n * n; wk += BA_NT) J0s[wk] = J0[(wk / n) * L.pld + wk % n];
             __syncthreads();
             for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
                 int a, bb;
@@ -333,7 +348,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
                 if (!L.big) c.sc[L.so_Hpk + wk] = s0 + s1;
             }
         } else {
-            const int ld = L.Ncap;
+            const int ld = L.pld;
             for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
                 int a, bb;
                 tri_decode(wk, a, bb);
@@ -495,7 +510,7 @@ NOINL double prior_pass(const Ctx& c_in, const double* x, double* pr_, double* g
     __syncthreads();
     for (int b = c.tid; b < c.nblk; b += BA_NT) {
         const glb_d* xb = AS_GLB_C(state_block(L, x, kind[b], idx[b]));
-        const glb_d* x0 = AS_GLB_C(c.di + L.do_px0 + x0off[b]);
+        const glb_d* x0 = AS_GLB_C(c.pri + L.po_x0 + x0off[b]);
         lds_d* d = dx + off[b];
         if (kind[b] == VG_BLK_SPEEDBIAS) {
 #pragma unroll
@@ -514,8 +529,8 @@ NOINL double prior_pass(const Ctx& c_in, const double* x, double* pr_, double* g
     }
     __syncthreads();
     const int n = c.nprior;
-    const glb_d* J0t = AS_GLB_C(c.di + L.do_pJ0t);     // J0t[c*Ncap + r] = J0[r][c]  (coalesced over r)
-    const glb_d* r0 = AS_GLB_C(c.di + L.do_pr0);
+    const glb_d* J0t = AS_GLB_C(c.sc + L.so_J0t);     // J0t[c*Ncap + r] = J0[r][c]  (coalesced over r)
+    const glb_d* r0 = AS_GLB_C(c.pri + L.po_r0);
     double cost = 0.0;
     // r = r0 + J0 dx, the n-term dot product of every row split over 4 threads (host guarantees 4 Ncap <= BA_NT)
     for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
@@ -537,12 +552,12 @@ NOINL double prior_pass(const Ctx& c_in, const double* x, double* pr_, double* g
     __syncthreads();
     if (gpr_) {
         // gradient of the prior J0^T r (the solve kernel adds it to g through the prior column map), same 4-way split
-        const glb_d* J0 = AS_GLB_C(c.di + L.do_pJ0);   // row-major: J0[r*Ncap + c] coalesced over c
+        const glb_d* J0 = AS_GLB_C(c.pri + L.po_J0);   // row-major: J0[r*pld + c] coalesced over c
         for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
             const int a = w % L.Ncap, q = w / L.Ncap;
             double s = 0.0;
             if (a < n)
-                for (int k = q; k < n; k += 4) s += J0[k * L.Ncap + a] * rl[k];
+                for (int k = q; k < n; k += 4) s += J0[k * L.pld + a] * rl[k];
             part[w] = s;
         }
         __syncthreads();

@@ -37,6 +37,8 @@ extern "C" int vg_destroy(vg_handle* h) {
     (void)hipFree(h->ba.dL);
     if (h->ba.h_ia) (void)hipHostFree(h->ba.h_ia);
     if (h->ba.h_di) (void)hipHostFree(h->ba.h_di);
+    if (h->ba.h_pri) (void)hipHostFree(h->ba.h_pri);
+    (void)hipFree(P.pri);
     h->ba.h_out.release(); h->ba.h_iout.release(); h->ba.h_mout.release(); h->ba.h_miout.release();
     (void)hipFree(P.mout); (void)hipFree(P.miout); (void)hipFree(P.mscr); (void)hipFree(P.rb1); (void)hipFree(P.rb2);
     if (h->fe) fe_state_destroy(h->fe);

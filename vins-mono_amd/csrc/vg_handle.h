@@ -27,7 +27,9 @@ struct PinnedBuf {
 struct BaBatch {
     BaLayout L;
     BaLayout* dL = nullptr;          // device copy of L (kernels read it through scalar loads)
-    BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    BaLayout dL_host;                // what dL holds (re-sent only when the layout changes)
+    bool dL_valid = false;
+    BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_ia = 0, cap_di = 0, cap_sc = 0, cap_out = 0, cap_iout = 0, cap_mout = 0, cap_miout = 0, cap_mscr = 0, cap_rb1 = 0, cap_rb2 = 0;
     std::vector<int> margin, nL;
     PinnedBuf<int> h_iout, h_miout;  // download staging
@@ -43,6 +45,18 @@ struct BaBatch {
     int marg_mode = 0;               // vg_ba_set_marg_mode: VG_MARG_SQRT (default) / VG_MARG_EIGEN
     void* allreduce = nullptr;       // vg_allreduce_fn of the large-window path (nullptr: single rank)
     void* allreduce_user = nullptr;
+    // ---- prior factors on the device (BaPtrs::pri).  slot[w] describes what window slot w holds: the block table of the last
+    //      prior uploaded or carried there.  A run that marginalizes leaves its result in mout / miout; the first upload that
+    //      asks for a resident prior (VG_PRIOR_RESIDENT) moves every valid result into the slots (carry kernel).
+    struct PriorSlot { int n = 0, nb = 0; std::vector<int> kind, idx; };
+    std::vector<PriorSlot> slot;
+    int slot_K = 0, slot_po_r0 = 0, slot_pld = 0, slot_pstride = 0;   // layout the slots were written with
+    size_t cap_pri = 0;
+    double* h_pri = nullptr;         // pinned staging of the priors that come from the host
+    size_t hcap_pri = 0;
+    bool mout_pending = false;       // the last run's marginalization result has not been carried yet
+    std::vector<int> run_margin;     // margin flags + output layout of that run
+    int run_nwin = 0, run_K = 0, run_mo_J0 = 0, run_mo_r0 = 0, run_mo_x0 = 0, run_mo_stride = 0, run_mi_stride = 0, run_mcap = 0;
     double flops = 0, flops_marg = 0, bytes_in = 0, bytes_out = 0;
     double flops_k[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic flops per kernel class (VG_BA_KERNEL_*), one run of the batch
 };
