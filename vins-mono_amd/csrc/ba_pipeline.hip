@@ -105,8 +105,10 @@ struct Ctx {
     double focal, tr, row, gnorm;
 };
 
+DEV BaLayout layout_load(const BaLayout* Lp) { return const_load(Lp); }      // scalar loads (ba_math.h)
+
 DEV void ctx_init(Ctx& c, const BaLayout* Lp, const BaPtrs& P, int w) {
-    const BaLayout& L = *Lp;
+    const BaLayout L = layout_load(Lp);
     c.Lp = Lp;
     c.ia = P.iarr + (size_t)w * L.istride;
     c.hdr = c.ia + L.io_hdr;
@@ -114,9 +116,9 @@ DEV void ctx_init(Ctx& c, const BaLayout* Lp, const BaPtrs& P, int w) {
     c.sc = P.scr + (size_t)w * L.sstride;
     c.pri = P.pri + (size_t)w * L.pstride;
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6;
-    c.nL = c.hdr[H_L]; c.nF = c.hdr[H_F]; c.nprior = c.hdr[H_NPRIOR]; c.nblk = c.hdr[H_NBLK];
-    c.focal = c.di[L.do_par + P_FOCAL]; c.tr = c.di[L.do_par + P_TR]; c.row = c.di[L.do_par + P_ROW];
-    c.gnorm = c.di[L.do_par + P_GNORM];
+    c.nL = uni(c.hdr[H_L]); c.nF = uni(c.hdr[H_F]); c.nprior = uni(c.hdr[H_NPRIOR]); c.nblk = uni(c.hdr[H_NBLK]);
+    c.focal = uni(c.di[L.do_par + P_FOCAL]); c.tr = uni(c.di[L.do_par + P_TR]); c.row = uni(c.di[L.do_par + P_ROW]);
+    c.gnorm = uni(c.di[L.do_par + P_GNORM]);
 }
 
 // deterministic workgroup-wide reductions through `red` (>= 2 * waves doubles of LDS), result uniform in every thread
@@ -127,7 +129,7 @@ DEV double block_sum(double* red, int nw, int lane, int wave, double v) {
     __syncthreads();
     double s = 0.0;
     for (int w = 0; w < nw; ++w) s += red[w];
-    return s;
+    return uni(s);
 }
 DEV void block_sum2(double* red, int nw, int lane, int wave, double& a, double& b) {
     a = wave_sum_all(a);
@@ -137,7 +139,7 @@ DEV void block_sum2(double* red, int nw, int lane, int wave, double& a, double& 
     __syncthreads();
     double s = 0.0, t = 0.0;
     for (int w = 0; w < nw; ++w) { s += red[w]; t += red[nw + w]; }
-    a = s; b = t;
+    a = uni(s); b = uni(t);
 }
 DEV double block_max(double* red, int nw, int lane, int wave, double v) {
     v = wave_max_all(v);
@@ -146,7 +148,7 @@ DEV double block_max(double* red, int nw, int lane, int wave, double v) {
     __syncthreads();
     double s = red[0];
     for (int w = 1; w < nw; ++w) s = fmax(s, red[w]);
-    return s;
+    return uni(s);
 }
 
 DEV int col_pose(const BaLayout& L, int i) { return 6 * i; }
@@ -185,12 +187,12 @@ struct Ctl {
     double gnn2c, gtgnc, step2c, xn2c;        // large-window path (ba_layout.h)
 };
 DEV void ctl_load(Ctl& s, const double* p) {
-    s.it = (int)p[C_IT]; s.nacc = (int)p[C_NACC]; s.ninv = (int)p[C_NINV]; s.term = (int)p[C_TERM]; s.status = (int)p[C_STATUS];
-    s.reuse = (int)p[C_REUSE]; s.cur = (int)p[C_CUR]; s.pending = (int)p[C_PENDING]; s.done = (int)p[C_DONE]; s.scaled = (int)p[C_SCALED];
-    s.radius = p[C_RADIUS]; s.mu = p[C_MU]; s.mu_solved = p[C_MUSOLVED]; s.cost = p[C_COST]; s.x_norm = p[C_XNORM];
-    s.alpha = p[C_ALPHA]; s.gtn2 = p[C_GTN2]; s.gnn2 = p[C_GNN2]; s.gtgn = p[C_GTGN]; s.dnorm = p[C_DNORM]; s.model = p[C_MODEL];
-    s.step_norm = p[C_STEPNORM]; s.x_norm_c = p[C_XNORMC]; s.init_cost = p[C_INITCOST]; s.qcam = p[C_QCAM];
-    s.phase = (int)p[C_PHASE]; s.gnn2c = p[C_GNN2C]; s.gtgnc = p[C_GTGNC]; s.step2c = p[C_STEP2C]; s.xn2c = p[C_XN2C];
+    s.it = uni((int)p[C_IT]); s.nacc = uni((int)p[C_NACC]); s.ninv = uni((int)p[C_NINV]); s.term = uni((int)p[C_TERM]); s.status = uni((int)p[C_STATUS]);
+    s.reuse = uni((int)p[C_REUSE]); s.cur = uni((int)p[C_CUR]); s.pending = uni((int)p[C_PENDING]); s.done = uni((int)p[C_DONE]); s.scaled = uni((int)p[C_SCALED]);
+    s.radius = uni(p[C_RADIUS]); s.mu = uni(p[C_MU]); s.mu_solved = uni(p[C_MUSOLVED]); s.cost = uni(p[C_COST]); s.x_norm = uni(p[C_XNORM]);
+    s.alpha = uni(p[C_ALPHA]); s.gtn2 = uni(p[C_GTN2]); s.gnn2 = uni(p[C_GNN2]); s.gtgn = uni(p[C_GTGN]); s.dnorm = uni(p[C_DNORM]); s.model = uni(p[C_MODEL]);
+    s.step_norm = uni(p[C_STEPNORM]); s.x_norm_c = uni(p[C_XNORMC]); s.init_cost = uni(p[C_INITCOST]); s.qcam = uni(p[C_QCAM]);
+    s.phase = uni((int)p[C_PHASE]); s.gnn2c = uni(p[C_GNN2C]); s.gtgnc = uni(p[C_GTGNC]); s.step2c = uni(p[C_STEP2C]); s.xn2c = uni(p[C_XN2C]);
 }
 DEV void ctl_store(const Ctl& s, double* p) {
     p[C_IT] = s.it; p[C_NACC] = s.nacc; p[C_NINV] = s.ninv; p[C_TERM] = s.term; p[C_STATUS] = s.status;
@@ -208,7 +210,7 @@ template <typename P>
 DEV double sum_partials(P part, int nbl) {
     double cs = 0.0;
     for (int b = 0; b < nbl; ++b) cs += part[b];
-    return cs;
+    return uni(cs);
 }
 DEV bool judge_candidate(Ctl& s, double cs, const BaLayout& L, double* out, int* iout, int tid) {
     const double cost_cand = 0.5 * cs;
@@ -947,6 +949,34 @@ DEV void big_carve(const BaLayout& L, double* sc, SolveLds& m) {
     m.ldc = L.ldc;
 }
 
+// The phase functions of the solve kernels are not inlined.  A Ctx / SolveLds handed over by reference has to sit in the caller's
+// private stack frame (scratch stores at kernel entry, scratch / flat loads in every callee) and arrives as vector data, so the
+// callee's address arithmetic runs on the VALU.  Everything in them is a function of the kernel arguments and the workgroup
+// index: each phase rebuilds it from the kernarg segment with scalar loads instead (the reference arguments stay for the CPU
+// emulation, which has no kernarg segment, and are dropped as dead arguments on the device).
+#ifdef VINS_SIMT
+#define PHASE_ENTER(BIGV) const Ctx c = c_in; const BaLayout L = *c.Lp; const SolveLds m = m_in
+#define PHASE_SELF_CHECK(cref) do { } while (0)
+#else
+DEV void phase_ctx(Ctx& c, BaLayout& L, SolveLds& m, int big) {        // big: 0 / 1, -1 = whichever path the layout says
+    // (llvm.amdgcn.kernarg.segment.ptr is null outside a kernel; the implicit-argument pointer is handed down to callees and
+    //  the hidden arguments start right behind the explicit ones: (const BaLayout* Lp, BaPtrs P) for both solve kernels)
+    typedef const __attribute__((address_space(4))) char* KArg;
+    static_assert(sizeof(const BaLayout*) + sizeof(BaPtrs) == 96 && alignof(BaPtrs) == 8, "explicit kernel arguments of the solve kernels");
+    KArg ka = (KArg)__builtin_amdgcn_implicitarg_ptr() - 96;
+    const BaLayout* Lp;
+    BaPtrs P;
+    __builtin_memcpy(&Lp, ka, sizeof(Lp));
+    __builtin_memcpy(&P, ka + 8, sizeof(BaPtrs));
+    L = layout_load(Lp);
+    ctx_init(c, Lp, P, blockIdx.x);
+    if (big < 0 ? L.big != 0 : big != 0) big_carve(L, c.sc, m); else lds_carve(L, m);
+}
+// the kernels compare what the phases will derive with their real arguments once (a wrong hidden-argument offset must not be silent)
+#define PHASE_SELF_CHECK(cref) do { Ctx c_; BaLayout L_; SolveLds m_; phase_ctx(c_, L_, m_, 0); if (c_.sc != (cref).sc || c_.ia != (cref).ia || c_.pri != (cref).pri) __builtin_trap(); } while (0)
+#define PHASE_ENTER(BIGV) Ctx c; BaLayout L; SolveLds m; phase_ctx(c, L, m, BIGV); asm volatile("" :: "v"(c_in.tid)); (void)m_in
+#endif
+
 // local column (0..29) of IMU factor f -> reduced column
 DEV int imu_col(const BaLayout& L, int f, int lc) {
     if (lc < 6) return col_pose(L, f) + lc;
@@ -994,9 +1024,7 @@ DEV void hess_add(const BaLayout& L, const Q& q, int ca, int cb, double v) {
 // Sp / gp = camera J^T J / J^T r of the projection factors (the buffer's own, or the rank-summed copy of the large-window path)
 template <bool BIG>
 NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, const double* Sp_, const double* gp_) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const SolveLds m = m_in;
+    PHASE_ENTER(BIG);
     typedef typename MovT<BIG>::D MV;
     const auto q = sys_ptrs<BIG>(m);
     const glb_d* buf = AS_GLB_C(buf_);
@@ -1251,40 +1279,40 @@ DEV double hess_diag(const BaLayout& L, const SolveLds& m, int k) {
 // Hessian, t = V_T = gt / Dg): the Cauchy-point denominator |J~ t|^2 of DoglegStrategy::ComputeCauchyPoint without a
 // second pass over the factors.
 template <bool BIG>
-NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_, double mu) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_in, double mu) {
+    PHASE_ENTER(BIG);
+    mu = uni(mu);                             // (arguments arrive in vector registers)
     typedef typename MovT<BIG>::D MV;
-    const auto m = sys_ptrs<BIG>(m_);
-    const MV* g = m.vec + V_G * L.Rpad;
-    const MV* sc = m.vec + V_SC * L.Rpad;
-    const MV* dg = m.vec + V_DG * L.Rpad;
-    const MV* tv = m.vec + V_T * L.Rpad;
-    const int Rc = L.Rc, K = L.K, ldc = m.ldc;
+    const auto mq = sys_ptrs<BIG>(m);
+    const MV* g = mq.vec + V_G * L.Rpad;
+    const MV* sc = mq.vec + V_SC * L.Rpad;
+    const MV* dg = mq.vec + V_DG * L.Rpad;
+    const MV* tv = mq.vec + V_T * L.Rpad;
+    const int Rc = L.Rc, K = L.K, ldc = mq.ldc;
     const int n = Rc * (Rc + 1) / 2;
     double q = 0.0;
     for (int w = c.tid; w < n; w += BA_NT) {
         int a, b;
         tri_decode(w, a, b);
-        double v = m.S[w] * sc[a] * sc[b];
+        double v = mq.S[w] * sc[a] * sc[b];
         q += v * tv[a] * tv[b] * (a == b ? 1.0 : 2.0);
         if (a == b) v += mu * dg[a] * dg[a];
-        m.S[w] = v;
+        mq.S[w] = v;
     }
-    for (int k = c.tid; k < Rc; k += BA_NT) m.S[tri(Rc, k)] = sc[k] * g[k];
-    if (c.tid == 0) m.S[tri(Rc, Rc)] = 0.0;
+    for (int k = c.tid; k < Rc; k += BA_NT) mq.S[tri(Rc, k)] = sc[k] * g[k];
+    if (c.tid == 0) mq.S[tri(Rc, Rc)] = 0.0;
     for (int w = c.tid; w < 81 * K; w += BA_NT) {
         const int k = w / 81, e = w - 81 * k, r = e / 9, cc = e - 9 * r;
         const int ca = Rc + 9 * k + r, cb = Rc + 9 * k + cc;
-        double v = m.D[w] * sc[ca] * sc[cb];
+        double v = mq.D[w] * sc[ca] * sc[cb];
         q += v * tv[ca] * tv[cb];
         if (r == cc) v += mu * dg[ca] * dg[ca];
-        m.D[w] = v;
+        mq.D[w] = v;
         if (k > 0) {
             const int cp = Rc + 9 * (k - 1) + cc;
-            const double ve = m.E[w] * sc[ca] * sc[cp];
+            const double ve = mq.E[w] * sc[ca] * sc[cp];
             q += 2.0 * ve * tv[ca] * tv[cp];
-            m.E[w] = ve;
+            mq.E[w] = ve;
         }
     }
     if (!BIG) {
@@ -1292,11 +1320,11 @@ NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_, double mu) {
             const int row = w / (Rc + 1), col = w - row * (Rc + 1);
             const int ca = Rc + row;
             if (col < Rc) {
-                const double v = m.XC[row * ldc + col] * sc[ca] * sc[col];
+                const double v = mq.XC[row * ldc + col] * sc[ca] * sc[col];
                 q += 2.0 * v * tv[ca] * tv[col];
-                m.XC[row * ldc + col] = v;
+                mq.XC[row * ldc + col] = v;
             } else {
-                m.XC[row * ldc + Rc] = sc[ca] * g[ca];
+                mq.XC[row * ldc + Rc] = sc[ca] * g[ca];
             }
         }
     } else {
@@ -1307,24 +1335,24 @@ NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_, double mu) {
         for (int w = c.tid; w < 9 * K * 20; w += BA_NT) {
             const int row = w / 20, e = w - 20 * row, k = row / 9;
             const int ca = Rc + row;
-            if (e == 19) { m.XC[row * ldc + Rc] = sc[ca] * g[ca]; continue; }
+            if (e == 19) { mq.XC[row * ldc + Rc] = sc[ca] * g[ca]; continue; }
             bool inprior = false;
             for (int b = 0; b < c.nblk; ++b) inprior = inprior || (kind[b] == VG_BLK_SPEEDBIAS && idx[b] == k);
             if (inprior) continue;                     // handled densely below
             const int col = 6 * (k - 1) + e;           // e = 0 .. 17
             if (e >= 18 || col < 0 || col >= 6 * L.Kp) continue;
-            const double v = m.XC[row * ldc + col] * sc[ca] * sc[col];
+            const double v = mq.XC[row * ldc + col] * sc[ca] * sc[col];
             q += 2.0 * v * tv[ca] * tv[col];
-            m.XC[row * ldc + col] = v;
+            mq.XC[row * ldc + col] = v;
         }
         for (int b = 0; b < c.nblk; ++b) {
             if (kind[b] != VG_BLK_SPEEDBIAS) continue;
             const int k = idx[b];
             for (int w = c.tid; w < 9 * Rc; w += BA_NT) {
                 const int r = w / Rc, col = w - r * Rc, row = 9 * k + r, ca = Rc + row;
-                const double v = m.XC[row * ldc + col] * sc[ca] * sc[col];
+                const double v = mq.XC[row * ldc + col] * sc[ca] * sc[col];
                 q += 2.0 * v * tv[ca] * tv[col];
-                m.XC[row * ldc + col] = v;
+                mq.XC[row * ldc + col] = v;
             }
         }
     }
@@ -1444,9 +1472,7 @@ DEV void chain_col_solve(PL Lk, PD dinvk, P col, int stride) {
     for (int r = 0; r < 9; ++r) col[r * stride] = x[r];
 }
 NOINL bool chain_eliminate(const Ctx& c_in, const SolveLds& m_in) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const SolveLds m = m_in;
+    PHASE_ENTER(false);
     const int K = L.K, Rc = L.Rc, ldc = m.ldc;
     const int mid = K / 2;
     const int nstep = (K - 1 - mid) > mid ? (K - 1 - mid) : mid;
@@ -1538,9 +1564,7 @@ NOINL bool chain_eliminate(const Ctx& c_in, const SolveLds& m_in) {
 #define SCHUR_LD (SCHUR_LW + 1)
 #define SCHUR_PF ((96 * SCHUR_LW + BA_NT - 1) / BA_NT)
 NOINL void schur_mfma(const Ctx& c_in, const SolveLds& m_in, const double* buf, double mu) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const SolveLds m = m_in;
+    PHASE_ENTER(false);
     const lds_d* sc = AS_LDS_C(m.vec + V_SC * L.Rpad);
     lds_d* const S = AS_LDS(m.S);
     lds_d* const wd = AS_LDS(m.wd);
@@ -1655,9 +1679,7 @@ NOINL void schur_mfma(const Ctx& c_in, const SolveLds& m_in, const double* buf, 
 // with t = gt / Dg.  Only needed when the Gauss-Newton step leaves the trust region, so it is evaluated on demand
 // (thread per landmark, one pass over Wt).  Returns this thread's share.
 NOINL double cauchy_landmark_term(const Ctx& c_in, const SolveLds& m_in, const double* buf) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const SolveLds m = m_in;
+    PHASE_ENTER(false);
     const double* sc = m.vec + V_SC * L.Rpad;
     const double* gt = m.vec + V_GT * L.Rpad;
     const double* dg = m.vec + V_DG * L.Rpad;
@@ -1693,9 +1715,7 @@ NOINL double cauchy_landmark_term(const Ctx& c_in, const SolveLds& m_in, const d
 //   (3) the trailing matrix gets its rank-16 update tile by tile on v_mfma_f64_16x16x4_f64.
 // Three barriers per 16 columns.  1/L_jj goes to V_DI.  Returns false (uniform) on a bad pivot.
 NOINL bool cholesky_aug(const Ctx& c_in, const SolveLds& m_in, int R) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const SolveLds m = m_in;
+    PHASE_ENTER(-1);
     lds_d* S = AS_LDS(m.S);
     lds_d* dinvv = AS_LDS(m.di);
     lds_i* flag = (lds_i*)(m.red + 24);
@@ -1837,9 +1857,7 @@ NOINL bool cholesky_aug(const Ctx& c_in, const SolveLds& m_in, int R) {
 // y_cam <- solve L^T y = (row R of S) by one wavefront (lane owns entries lane and lane+64 of the running rhs in
 // registers; the pivot value travels through v_readlane); result in V_Y[0..R).  R <= 128.
 NOINL void back_substitute(const Ctx& c_in, const SolveLds& m_in, int R) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const SolveLds m = m_in;
+    PHASE_ENTER(false);
     const lds_d* S = AS_LDS_C(m.S);
     const lds_d* dinvv = AS_LDS_C(m.di);
     lds_d* y = AS_LDS(m.vec + V_Y * L.Rpad);
@@ -1920,9 +1938,9 @@ DEV double chain_backsolve9(PL Lk, PD dinvk, double v, int r) {
     return v;
 }
 template <bool BIG>
-NOINL void chain_back_substitute(const Ctx& c_in, const SolveLds& m_) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
+NOINL void chain_back_substitute(const Ctx& c_in, const SolveLds& m_in) {
+    PHASE_ENTER(BIG);
+    const SolveLds& m_ = m;
     typedef typename MovT<BIG>::D MV;
     const int K = L.K, Rc = L.Rc, ldc = m_.ldc;
     const int mid = K / 2;
@@ -1995,10 +2013,11 @@ DEV double state_sqnorm_share(const BaLayout& L, const double* x, const double* 
 }
 
 extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
-    const BaLayout& L = *Lp;
+    const BaLayout L = layout_load(Lp);
     Ctx c;
     const int w = blockIdx.x;
     ctx_init(c, Lp, P, w);
+    PHASE_SELF_CHECK(c);
     double* ctlp = c.sc + L.so_ctl;
     // Everything the first phase reads from HBM is requested in one batch (control block, cost partials of the linearisation
     // kernels).  The prior column map is not needed here: the prologue kernel left a slot table (so_ptab) for assemble().
@@ -2461,9 +2480,7 @@ extern "C" __global__ __launch_bounds__(256) void ba_big_schur_kernel(const BaLa
 // column tiles (the A operand is shared), two k-steps per trip so that ten 128-byte row loads are in flight per wavefront:
 // the operands come from L2, the loop is a chain of round trips, not of flops.  XC has up(9K, 8) rows (zero padded).
 NOINL void schur_chain_big(const Ctx& c_in, const SolveLds& m_in, const double* T_) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const SolveLds m = m_in;
+    PHASE_ENTER(true);
     const glb_d* sc = AS_GLB_C(m.vec + V_SC * L.Rpad);
     const glb_d* T = AS_GLB_C(T_);
     const glb_d* XC = AS_GLB_C(m.XC);
@@ -2525,9 +2542,7 @@ NOINL void schur_chain_big(const Ctx& c_in, const SolveLds& m_in, const double* 
 // receives from its neighbour only involves that column and the neighbour's 9x9 coupling block, which travels through LDS
 // (cz: L and 1/L_rr of the two blocks of the step, coupling blocks double-buffered by block parity).
 NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz_) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const SolveLds m = m_in;
+    PHASE_ENTER(true);
     const int K = L.K, Rc = L.Rc, ldc = m.ldc;
     const int mid = K / 2;
     const int nstep = (K - 1 - mid) > mid ? (K - 1 - mid) : mid;
@@ -2704,9 +2719,7 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
 // back substitution L^T y = (row R of S) for R <= 64 NR, one wavefront, lane owns entries lane + 64 q of the running rhs
 template <int NR>
 NOINL void back_substitute_n(const Ctx& c_in, const SolveLds& m_in, int R) {
-    const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
-    const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    const SolveLds m = m_in;
+    PHASE_ENTER(true);
     const lds_d* S = AS_LDS_C(m.S);
     const lds_d* dinvv = AS_LDS_C(m.di);
     glb_d* y = AS_GLB(m.vec + V_Y * L.Rpad);
@@ -2767,10 +2780,11 @@ DEV void big_solve_failed(Ctl& s, const BaLayout& L, double* out, int* iout, int
 
 // 1 workgroup / window, BA_NT threads, LDS: S (packed, rhs row), reduction scratch, 1/L_jj.
 extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
-    const BaLayout& L = *Lp;
+    const BaLayout L = layout_load(Lp);
     Ctx c;
     const int w = blockIdx.x;
     ctx_init(c, Lp, P, w);
+    PHASE_SELF_CHECK(c);
     double* ctlp = c.sc + L.so_ctl;
     Ctl s;
     ctl_load(s, ctlp);
