@@ -23,7 +23,7 @@ import numpy as np
 
 # ROCm maps HIP streams onto 4 hardware queues by default; the boundary loops below drive 8 handles (16 streams) from 8 host
 # threads, and a stream whose next packet waits for a copy holds up the other streams of its queue (measured: 3.87 vs
-# 3.25 ms per batch, INTEGRATION.md section 6).  Must be set before the HIP runtime initialises; no effect on `value`.
+# 3.25 ms per batch, INTEGRATION.md section 4).  Must be set before the HIP runtime initialises; no effect on `value`.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -622,6 +622,25 @@ def main():
                 "marginalization_note": "the reference spreads the marginalization's A = sum J^T J over 4 pthreads "
                                         "(marginalization_factor.h:13); this figure is single-thread",
             }
+            # The reference's OWN translation units (estimator.cpp, factor/*.cpp compiled unchanged into oracle/_ref, see oracle/Makefile)
+            # timed on the same windows -- for orientation only: they run on the stand-in headers of oracle/ref_stubs (an eager
+            # matrix class without expression templates or vectorisation, a restated dense trust-region solver), so this is NOT
+            # the speed of the reference on real Eigen + Ceres and is not the baseline.
+            try:
+                from oracle import ref as R
+                if R.available():
+                    R.configure_for(probs[0], None)
+                    est = R.Estimator()
+                    t_ref = []
+                    for i in range(6):
+                        est.load_window(probs[i % ncpu])
+                        tr0 = time.perf_counter()
+                        est.optimization(0)
+                        t_ref.append(time.perf_counter() - tr0)
+                    est.close()
+                    cpu["reference_sources_on_stand_in_headers_ms"] = float(np.median(t_ref[1:])) * 1e3
+            except Exception as ex:                       # noqa: BLE001  (informational: never fails the bench)
+                cpu["reference_sources_on_stand_in_headers_ms"] = f"unavailable: {ex!r}"
         out = {
             "metric": "sliding-window BA solves/sec (Estimator::optimization: 8-iteration dogleg solve + marginalization)",
             "value": value,
