@@ -64,7 +64,8 @@ def make_chain(h, ba, seqs, packed, flags):
     return chain
 
 
-FE_CAMS = 64                 # independent camera streams per GPU in the front-end leg
+FE_CAMS = 256                # independent camera streams per GPU in the front-end leg (like the 256 windows of the BA leg; with 64 the LK launch is
+                             # dominated by its slowest tracks: 137 us for 9600 tracks against 9.7 ns per additional track, tests/manual/gpu_lk_scaling.py)
 FE_BYTES_PER_FEATURE = 8188  # (pyramid 592,200 B + LK 636,000 B) per 752x480 frame / 150 features
 FE_GFTT_BYTES_PER_FRAME = 3609600
 
