@@ -43,9 +43,32 @@ def test_forced_large_path_with_prior_relocalisation_extrinsic_td(large, handle)
     _check_solve(large, synth.SyntheticSequence(23, n_frames=13, K=12, L=60).window(0))
 
 
-def test_large_path_refuses_marginalization(large):
-    with pytest.raises(RuntimeError, match="large-window"):
-        large.ba_optimize(synth.SyntheticSequence(2, L=20).window(0), ba.VG_MARGIN_OLD)
+def test_forced_large_path_marginalizes_like_the_single_workgroup_path(large, handle):
+    """MARGIN_OLD and MARGIN_SECOND_NEW on the large-window path (forced on a window that also fits the other path): the same
+    kernel, fed by the other solve pipeline, must produce the same prior as the oracle."""
+    from test_ba_gpu import _check_prior, _window_with_prior
+    seq = synth.SyntheticSequence(40, L=60)
+    prob = seq.window(0)
+    x, _ = B.solve(prob)
+    at = dict(prob)
+    at.update(pose=x['pose'], sb=x['sb'], ex=x['ex'], td=x['td'], inv_depth=x['inv_depth'], max_iters=0)
+    _, _, pr_o = B.optimization(at, B.MARGIN_OLD)
+    _, sm, pr_g = large.ba_optimize(at, ba.VG_MARGIN_OLD)
+    assert sm['status'] == 0
+    _check_prior(pr_g, pr_o)
+    _, _, prob2 = _window_with_prior(6, L=150)
+    prob2 = dict(prob2, max_iters=0)
+    _, _, pr2_o = B.optimization(prob2, B.MARGIN_SECOND_NEW)
+    _, _, pr2_g = large.ba_optimize(prob2, ba.VG_MARGIN_SECOND_NEW)
+    _check_prior(pr2_g, pr2_o)
+
+
+def test_enlarged_window_marginalization(handle):
+    """A 31-frame window (large-window path by itself): kept block n = 6 * 30 + 9 + 7 = 196 columns (pivoted Cholesky in global
+    memory), camera part of the projection assembly in five entry passes, dropped block [pose 0 | speed-bias 0 | the landmarks
+    anchored at frame 0] by block elimination."""
+    from test_ba_gpu import marginalize_many_frame0_landmarks
+    marginalize_many_frame0_landmarks(handle, K=31, L=400, w0=3, n_frames=40, min_m=60)
 
 
 def _vs_cpp_oracle(h, prob, rtol_state=1e-4):

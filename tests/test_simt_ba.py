@@ -59,6 +59,12 @@ def test_emulated_marginalization_many_frame0_landmarks(simt_handle):
     marginalize_many_frame0_landmarks(simt_handle, K=5, L=70, w0=2, n_frames=10, min_m=60)
 
 
+def test_emulated_enlarged_window_marginalization(simt_handle):
+    """K = 16 takes the large-window path by itself: kept block n = 106 > 96 (pivoted Cholesky in global memory), camera part of
+    the projection assembly in two entry passes."""
+    marginalize_many_frame0_landmarks(simt_handle, K=16, L=40, w0=1, n_frames=20, min_m=20)
+
+
 def test_emulated_prior_stays_on_the_device_between_frames(simt_handle):
     resident_prior_chain(simt_handle, L=16)
 

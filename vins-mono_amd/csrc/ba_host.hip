@@ -301,13 +301,10 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.oo_trace = o; o += 5 * VG_MAX_ITERS + 16;
     L.ostride = up(o, 8);
     L.oi_stride = up(4 + VG_MAX_ITERS, 8);
-    // ---- marginalization: kept dimension <= 6K + 2*9 + 6 + 1; blocks <= K + 4   (not offered on the large-window path)
-    if (L.big) {
-        L.mcap = 8; L.mg_ld = 9; L.mg_posmax = 8; L.mg_cs = 640; L.mg_lds_bytes = 0;
-        L.mo_J0 = 0; L.mo_r0 = 64; L.mo_x0 = 72; L.mo_stride = 8; L.mi_stride = up(8 + 2 * (L.K + 4) + 16, 8); L.ms_stride = 8;
-        return VG_OK;
-    }
+    // ---- marginalization: kept dimension <= 6K + 2*9 + 6 + 1; blocks <= K + 4.  Both paths: the kernel's LDS tables are
+    //      sized for BA_MAX_K_LARGE frames; a kept block wider than the LDS tile is factored in global memory.
     L.mcap = up(6 * L.K + 9 * 2 + 6 + 1, 8);
+    if (L.mcap > 256) { h->err = "kept dimension of the marginalization beyond the kernel's tables"; return VG_ERR_UNSUPPORTED; }
     const int mcap = L.mcap;
     L.mo_J0 = 0;
     L.mo_r0 = mcap * mcap;
@@ -321,7 +318,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         L.mg_cs = up(std::max(std::max(2 * mcap, 3 * (L.mg_posmax / 2 + 2)), 2 * (3 * ((mcap + 2) / 2) + 2) + 2), 2);   // generic: one table
                                                      // of 3*half doubles; fast path: two (double-buffered)
         L.mg_cs = std::max(L.mg_cs, std::max(up(5 * mcap + 8, 2), up(L.Lcap + 512, 2)));   // vh_eig: running diagonal, norms, eigenvalues, flags; Amm block elimination: Lcap + 2 x 256
-        const int fixed = 32 + nstm + 128 + L.mg_cs;
+        const int fixed = 32 + nstm + BA_MARG_LDS_INTS / 2 + L.mg_cs;
         int ld = mcap + 1;                           // big enough for the kept part; also used for Amm when m <= ld.  ODD:
                                                      // the symmetric-storage Jacobi walks columns (stride ld doubles) and
                                                      // an even stride folds them onto a few LDS banks (96 -> one bank)
@@ -562,9 +559,13 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     }
     B.flops = 0.0; B.flops_marg = 0.0; B.bytes_in = 0.0; B.bytes_out = 0.0;
     for (double& v : B.flops_k) v = 0.0;
-    if (L.big && margin_flags)
-        for (int w = 0; w < nwin; ++w)
-            if (margin_flags[w] != VG_MARGIN_NONE) { h->err = "marginalization is not offered on the large-window path"; return VG_ERR_UNSUPPORTED; }
+    {
+        // the marginalization scratch of a large window is 3 (Lcap + 6K + 40)^2 doubles: only when one is asked for
+        bool any = false;
+        for (int w = 0; w < nwin && margin_flags; ++w) any = any || margin_flags[w] != VG_MARGIN_NONE;
+        if (!any && L.big) { L.ms_stride = 8; B.L.ms_stride = 8; }
+        if (any && B.allreduce) { h->err = "marginalization of a landmark shard: every rank would need all frame-0 landmarks"; return VG_ERR_UNSUPPORTED; }
+    }
     B.margin.assign(nwin, VG_MARGIN_NONE);
     B.nL.assign(nwin, 0);
     B.rounds = 0;

@@ -15,6 +15,7 @@
 #define BA_ACC_NT 256             // threads per workgroup of the accumulation kernel
 #define BA_MAX_K 13               // frames incl. relocalisation pose, windows solved by one workgroup out of LDS
 #define BA_MAX_K_LARGE 40         // the same for the large-window path (reduced system in HBM, see BaLayout::big)
+#define BA_MARG_LDS_INTS 400      // int tables of ba_marg_kernel in LDS (MGI_* in ba_marg.hip)
 #ifndef BA_IMU_BATCH
 #define BA_IMU_BATCH 16           // IMU factors linearised per pass of the linearisation workgroup (LDS panels)
 #endif

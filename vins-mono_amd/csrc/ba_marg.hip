@@ -769,15 +769,80 @@ DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs,
     return rank;
 }
 
+// The same factor for a kept block that does not fit the register-resident form (n > 96: windows of the large-window path, kept
+// dimension up to 6 * 39 + 16): the Schur complement stays where it is (M, n x n in global memory, lower triangle updated in
+// place), running diagonal / current column / y in LDS.  Same pivot rule, same cut, same output layout.
+DEV int sqrt_factor_glb(const MCtx& c, double* M, double* Lc, int n, int ld, int offcs, const double* bglob) {
+    double* dgn = MG_LDS + offcs;             // running diagonal (-1e300 once pivoted)
+    double* lcol = dgn + n;                   // current column of L (0 for pivoted rows), entry n = y_k
+    double* yv = lcol + n + 1;                // y = L^-1 P^T b'   (kept for the caller)
+    double* yb = yv + n;                      // running right-hand side
+    const int ntri = n * (n + 1) / 2;
+    __syncthreads();
+    for (int k = c.tid; k < n * ld; k += MG_NT) Lc[k] = 0.0;
+    for (int i = c.tid; i < n; i += MG_NT) { dgn[i] = M[i * ld + i]; yv[i] = 0.0; yb[i] = bglob[i]; }
+    int rank = 0;
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        // pivot = largest remaining diagonal (lowest index on ties): every wavefront on its own, four entries per lane (n <= 256)
+        double best = -1e300;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = c.lane + 64 * u; best = fmax(best, i < n ? dgn[i] : -1e300); }
+        best = wave_max_all(best);
+        int p = n;
+#pragma unroll
+        for (int u = 3; u >= 0; --u) {
+            const int i = c.lane + 64 * u;
+            const unsigned long long mk = __ballot(i < n && dgn[i] == best);
+            if (mk) p = 64 * u + __ffsll((long long)mk) - 1;
+        }
+        if (!(best > MG_EPS)) break;          // (uniform)
+        const double inv = mg_rsqrt(best);
+        const double yk = yb[p] * inv;
+        for (int i = c.tid; i < n; i += MG_NT) {
+            double v = 0.0;
+            if (i == p) v = best * inv;
+            else if (dgn[i] > -1e299) v = (i > p ? M[i * ld + p] : M[p * ld + i]) * inv;
+            lcol[i] = v;
+            Lc[k * ld + i] = v;
+        }
+        if (c.tid == 0) { lcol[n] = yk; yv[k] = yk; }
+        rank = k + 1;
+        __syncthreads();
+        if (c.tid == 0) dgn[p] = -1e300;
+        for (int i = c.tid; i < n; i += MG_NT) if (i != p && dgn[i] > -1e299) yb[i] -= lcol[i] * yk;
+        for (int e = c.tid; e < ntri; e += MG_NT) {
+            int i, j;
+            tri_decode(e, i, j);                                  // i >= j
+            const double li = lcol[i], lj = lcol[j];
+            if (i == p || j == p || li == 0.0 || lj == 0.0) continue;
+            const double v = M[i * ld + j] - li * lj;
+            M[i * ld + j] = v;
+            if (i == j && dgn[i] > -1e299) dgn[i] = v;
+        }
+    }
+    __syncthreads();
+    return rank;
+}
+
 DEV bool mg_fast_ok(int n) {
     const int half = (n + 1) / 2;
     return n >= 2 && half * (half + 1) / 2 <= MG_NT && n * half <= 4 * (MG_NT - 64);
 }
 
 // marginalization column maps, kept in LDS ints
+// LDS int tables of the kernel (offsets in ints behind the state copy; the host reserves MGI_TOTAL ints): sized for the
+// large-window path (BA_MAX_K_LARGE frames, kept dimension <= 256)
+#define MGI_POSE 0
+#define MGI_SB BA_MAX_K_LARGE
+#define MGI_MISC (2 * BA_MAX_K_LARGE)
+#define MGI_RANK (2 * BA_MAX_K_LARGE + 16)
+#define MGI_BPTR (MGI_RANK + 256)
+#define MGI_TOTAL (MGI_BPTR + BA_MAX_K_LARGE + 8)
+static_assert(MGI_TOTAL <= BA_MARG_LDS_INTS, "LDS int tables of ba_marg_kernel");
 struct MgMap {
-    int* pose;   // [BA_MAX_K] column of pose i or -1
-    int* sb;     // [BA_MAX_K]
+    int* pose;   // [BA_MAX_K_LARGE] column of pose i or -1
+    int* sb;     // [BA_MAX_K_LARGE]
     int* misc;   // [0]=ex col, [1]=td col, [2]=m, [3]=n, [4]=n0, [5]=pos
     int* lm;     // global: [Lcap] column of landmark l or -1
     int* l0;     // global: [Lcap] list of frame-0 landmarks
@@ -825,7 +890,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     const int nst = (7 * K + 9 * K + 8 + 1) & ~1;
     int* li = (int*)(x + nst);
     MgMap mp;
-    mp.pose = li; mp.sb = li + 16; mp.misc = li + 32;
+    mp.pose = li + MGI_POSE; mp.sb = li + MGI_SB; mp.misc = li + MGI_MISC;
     // ---- global scratch carve
     const int posmax = L.mg_posmax;
     double* A = c.ms;                        // posmax x posmax
@@ -856,52 +921,93 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     const bool imu0 = (flag == VG_MARGIN_OLD) && c.ia[L.io_imu_valid + 0] && c.di[L.do_imu + IM_SUMDT] < 10.0;
     __syncthreads();
 
-    // ---- M2: structure (single thread; tiny)
-    if (c.tid == 0) {
-        bool has_pose[BA_MAX_K], has_sb[BA_MAX_K], has_ex = false, has_td = false;
-        for (int i = 0; i < BA_MAX_K; ++i) { has_pose[i] = false; has_sb[i] = false; }
-        for (int b = 0; b < nblk; ++b) {
-            if (pk[b] == VG_BLK_POSE) has_pose[pidx[b]] = true;
-            else if (pk[b] == VG_BLK_SPEEDBIAS) has_sb[pidx[b]] = true;
-            else if (pk[b] == VG_BLK_EXPOSE) has_ex = true;
-            else has_td = true;
-        }
-        int n0 = 0;
-        bool valid = true;
-        if (flag == VG_MARGIN_OLD) {
-            if (imu0) { has_pose[0] = has_pose[1] = true; has_sb[0] = has_sb[1] = true; }
-            for (int l = 0; l < nL; ++l) {
-                mp.lm[l] = -1;
-                if (c.ia[L.io_lm_start + l] != 0) continue;
-                mp.l0[n0++] = l;
-                has_pose[0] = true; has_ex = true;
-                if (L.t) has_td = true;
+    // ---- M2: structure.  Which frames / blocks take part is gathered by all threads (flags in LDS: idempotent stores of 1) and
+    //      the list of frame-0 landmarks by an ordered compaction (ballot prefix per wavefront, wavefront counts through LDS):
+    //      a single thread walking the landmark and factor tables was a chain of ~750 dependent HBM round trips, 160K of the
+    //      kernel's 1M cycles (and 2000 landmarks on the large-window path).  The column assignment itself is a few loops over K.
+    int* hpose = mp.pose;                    // flags first, columns afterwards
+    int* hsb = mp.sb;
+    int* hflag = mp.misc + 8;                // [0] extrinsic, [1] td
+    int* wcnt = li + MGI_RANK;               // [waves] (the rank table is not in use yet)
+    for (int i = c.tid; i < BA_MAX_K_LARGE; i += MG_NT) { hpose[i] = 0; hsb[i] = 0; }
+    if (c.tid < 2) hflag[c.tid] = 0;
+    __syncthreads();
+    for (int b = c.tid; b < nblk; b += MG_NT) {
+        if (pk[b] == VG_BLK_POSE) hpose[pidx[b]] = 1;
+        else if (pk[b] == VG_BLK_SPEEDBIAS) hsb[pidx[b]] = 1;
+        else if (pk[b] == VG_BLK_EXPOSE) hflag[0] = 1;
+        else hflag[1] = 1;
+    }
+    int n0_all = 0;                          // uniform
+    if (flag == VG_MARGIN_OLD) {
+        if (c.tid == 0 && imu0) { hpose[0] = 1; hpose[1] = 1; hsb[0] = 1; hsb[1] = 1; }
+        for (int base = 0; base < nL; base += MG_NT) {
+            const int l = base + c.tid;
+            const bool is0 = l < nL && c.ia[L.io_lm_start + l] == 0;
+            if (l < nL) mp.lm[l] = -1;
+            if (is0) {
+                hpose[0] = 1; hflag[0] = 1;
+                if (L.t) hflag[1] = 1;
                 for (int f = c.ia[L.io_lm_fbeg + l]; f < c.ia[L.io_lm_fbeg + l + 1]; ++f) {
                     const int j = c.ia[L.io_fac_j + f];
-                    if (j < K) has_pose[j] = true;
+                    if (j < K) hpose[j] = 1;
                 }
             }
+            const unsigned long long bal = __ballot(is0);
+            const int before = __popcll(bal & ((1ull << c.lane) - 1ull));
+            __syncthreads();                 // (wcnt of the previous trip has been read)
+            if (c.lane == 0) wcnt[c.wave] = __popcll(bal);
+            __syncthreads();
+            int off = n0_all, tot = 0;
+            for (int w2 = 0; w2 < MG_NT / 64; ++w2) { const int cw = wcnt[w2]; if (w2 < c.wave) off += cw; tot += cw; }
+            if (is0) mp.l0[off + before] = l;
+            n0_all += tot;
+        }
+    }
+    __syncthreads();
+    if (c.tid == 0) {
+        const int n0 = n0_all;
+        const bool has_ex = hflag[0] != 0, has_td = hflag[1] != 0;
+        bool valid = true;
+        if (flag == VG_MARGIN_OLD) {
             if (nblk == 0 && !imu0 && n0 == 0) valid = false;
         } else {
-            if (nblk == 0 || !has_pose[K - 2]) valid = false;      // estimator.cpp:935-936
+            if (nblk == 0 || !hpose[K - 2]) valid = false;      // estimator.cpp:935-936
         }
-        int pos = 0;
-        for (int i = 0; i < BA_MAX_K; ++i) { mp.pose[i] = -1; mp.sb[i] = -1; }
+        // flags -> columns (in place: a flag is consumed before its slot is overwritten)
+        int pos = 0, lm_base = 0;
+        int colp[2] = {-1, -1};              // MARGIN_OLD: pose 0 / speed-bias 0;  SECOND_NEW: pose K-2
         if (flag == VG_MARGIN_OLD) {
-            if (has_pose[0]) { mp.pose[0] = pos; pos += 6; }
-            if (has_sb[0]) { mp.sb[0] = pos; pos += 9; }
-            for (int k = 0; k < n0; ++k) mp.lm[mp.l0[k]] = pos++;
-        } else if (valid) { mp.pose[K - 2] = pos; pos += 6; }
+            if (hpose[0]) { colp[0] = pos; pos += 6; }
+            if (hsb[0]) { colp[1] = pos; pos += 9; }
+            lm_base = pos; pos += n0;
+        } else if (valid) { colp[0] = pos; pos += 6; }
         const int m = pos;
-        for (int i = 0; i < K; ++i) if (has_pose[i] && mp.pose[i] < 0) { mp.pose[i] = pos; pos += 6; }
-        for (int i = 0; i < K; ++i) if (has_sb[i] && mp.sb[i] < 0) { mp.sb[i] = pos; pos += 9; }
+        const int first_pose = (flag == VG_MARGIN_OLD) ? 0 : K - 2;
+        for (int i = 0; i < K; ++i) {
+            const bool has = hpose[i] != 0;
+            int col = -1;
+            if (i == first_pose && colp[0] >= 0) col = colp[0];
+            else if (has) { col = pos; pos += 6; }
+            hpose[i] = col;
+        }
+        for (int i = 0; i < K; ++i) {
+            const bool has = hsb[i] != 0;
+            int col = -1;
+            if (flag == VG_MARGIN_OLD && i == 0 && colp[1] >= 0) col = colp[1];
+            else if (has) { col = pos; pos += 9; }
+            hsb[i] = col;
+        }
+        for (int i = K; i < BA_MAX_K_LARGE; ++i) { hpose[i] = -1; hsb[i] = -1; }
         mp.misc[0] = -1; mp.misc[1] = -1;
         if (has_ex) { mp.misc[0] = pos; pos += 6; }
         if (has_td) { mp.misc[1] = pos; pos += 1; }
         mp.misc[2] = m; mp.misc[3] = pos - m; mp.misc[4] = n0; mp.misc[5] = pos;
         mp.misc[6] = (valid && pos - m > 0 && pos - m <= mcap && pos <= posmax) ? 1 : 0;
+        mp.misc[7] = lm_base;
     }
     __syncthreads();
+    for (int k = c.tid; k < mp.misc[4]; k += MG_NT) mp.lm[mp.l0[k]] = mp.misc[7] + k;
     const int m = mp.misc[2], n = mp.misc[3], n0 = mp.misc[4], pos = mp.misc[5];
     if (!mp.misc[6]) { if (c.tid == 0) { mi[0] = 0; mi[1] = 0; } return; }
     const int cex = mp.misc[0], ctd = mp.misc[1];
@@ -1015,23 +1121,27 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         double* recL = eM;
         int* jofL = (int*)(recL + (size_t)cap * 42);         // [cap] target frame or -2
         int* slist = jofL + cap;                             // [cap] compact ids sorted by target frame (stable)
-        int* bptr = li + 64;                                 // [K + 2] bucket pointers
+        int* bptr = li + MGI_BPTR;                           // [K + 2] bucket pointers
         int* cfb = mp.l0 + L.Lcap;                           // [n0 + 1] compact factor offsets
         if (c.tid == 0) {
             int acc = 0;
             for (int k = 0; k < n0; ++k) { cfb[k] = acc; acc += c.ia[L.io_lm_fbeg + mp.l0[k] + 1] - c.ia[L.io_lm_fbeg + mp.l0[k]]; }
             cfb[n0] = acc;
         }
-        // per-thread camera entries (chunk-invariant): w = tid + e * MG_NT < nent
+        // per-thread camera entries: w = tid + (pass * MAXE + e) * MG_NT < nent.  A window of the single-workgroup path has one
+        // pass (the entries are decoded once and summed in registers over all chunks); wider windows (large-window path: up to
+        // 6 * 39 + 7 camera columns) take several passes per chunk and add every chunk's sums to A directly.
         constexpr int MAXE = ((6 * BA_MAX_K + 7) * (6 * BA_MAX_K + 8) / 2 + 6 * BA_MAX_K + 7 + MG_NT - 1) / MG_NT;
+        const int npass = (nent + MAXE * MG_NT - 1) / (MAXE * MG_NT);
         double acc[MAXE];
         int eo[MAXE];        // packed: oa0 | oa1 << 8 | ob0 << 16 | ob1 << 24
         int erq[MAXE];       // required target frame, -1 = any, -3 = entry unused
         int eadr[MAXE];      // destination: A index (>= 0) or -(bv index) - 1
         int emir[MAXE];      // mirrored A index or -1
+        auto decode_pass = [&](int pass) {
 #pragma unroll
         for (int e = 0; e < MAXE; ++e) {
-            const int w = c.tid + e * MG_NT;
+            const int w = c.tid + (pass * MAXE + e) * MG_NT;
             acc[e] = 0.0; eo[e] = 0; erq[e] = -3; eadr[e] = 0; emir[e] = -1;
             if (w < nent) {
                 const bool isg = w >= ntri;
@@ -1055,6 +1165,17 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                 }
             }
         }
+        };
+        auto flush_pass = [&]() {
+#pragma unroll
+            for (int e = 0; e < MAXE; ++e) {
+                if (erq[e] == -3) continue;
+                if (eadr[e] < 0) bv[-eadr[e] - 1] += acc[e];
+                else { A[eadr[e]] += acc[e]; if (emir[e] >= 0) A[emir[e]] += acc[e]; }
+                acc[e] = 0.0;
+            }
+        };
+        decode_pass(0);
         __syncthreads();
         for (int k0 = 0; k0 < n0;) {
             int k1 = k0 + 1;
@@ -1097,6 +1218,8 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             }
             __syncthreads();
             // camera part
+            for (int pass = 0; pass < npass; ++pass) {
+            if (npass > 1) decode_pass(pass);
 #pragma unroll
             for (int e = 0; e < MAXE; ++e) {
                 if (erq[e] == -3) continue;
@@ -1115,6 +1238,8 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                     }
                 }
                 acc[e] += s;
+            }
+            if (npass > 1) flush_pass();
             }
             // landmark rows / columns: thread per (landmark, camera column | self | rhs)
             for (int wk = c.tid; wk < (k1 - k0) * (ncam + 2); wk += MG_NT) {
@@ -1143,12 +1268,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             __syncthreads();
             k0 = k1;
         }
-#pragma unroll
-        for (int e = 0; e < MAXE; ++e) {
-            if (erq[e] == -3) continue;
-            if (eadr[e] < 0) bv[-eadr[e] - 1] += acc[e];
-            else { A[eadr[e]] += acc[e]; if (emir[e] >= 0) A[emir[e]] += acc[e]; }
-        }
+        if (npass == 1) flush_pass();
     }
     __syncthreads();
 
@@ -1362,9 +1482,10 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
 #endif
     const int offcs2 = (int)(cs - MG_LDS), offred2 = (int)(red - MG_LDS);
     const bool fast2 = n_lds && n >= 1 && n <= 16 * MG_HROWS;
-    if (fast2 && c.hdr[H_MARGMODE] == 0) {
+    if ((fast2 || !n_lds) && c.hdr[H_MARGMODE] == 0) {
         // square-root form by pivoted Cholesky (see sqrt_factor): J0 = L^T, r0 = L^-1 b'
-        const int rk = sqrt_factor(c, 0, ld * ld, n, ld2, offcs2, offred2, bp);
+        const int rk = fast2 ? sqrt_factor(c, 0, ld * ld, n, ld2, offcs2, offred2, bp)
+                             : sqrt_factor_glb(c, M2, V2, n, ld2, offcs2, bp);
         const double* yv = cs + 2 * n + 1;
         if (c.tid == 0) mi[5] = rk << 16;        // rank of the factor (the eigen path reports sweeps | attempts << 8 here)
         MPROF(6);
@@ -1393,7 +1514,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     if (c.tid == 0) mi[5] = sw2;            // sweeps | Cholesky attempts << 8 of the kept-block eigen-decomposition
     MPROF(6);
     // ascending order like SelfAdjointEigenSolver: rank of each eigenvalue
-    int* rank = li + 48;
+    int* rank = li + MGI_RANK;
     for (int i = c.tid; i < n; i += MG_NT) {
         const double li_ = M2[i * ld2 + i];
         int rk = 0;
