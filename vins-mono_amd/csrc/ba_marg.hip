@@ -1046,17 +1046,23 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         __syncthreads();
         const double* Hp = c.sc + L.so_Hp;          // J0^T J0 (lower), left by the solve kernel
         const double* J0 = c.pri + L.po_J0;
-        for (int wk = c.tid; wk < nprior * nprior + nprior; wk += MG_NT) {
-            const bool isg = wk >= nprior * nprior;
-            const int a = isg ? wk - nprior * nprior : wk / nprior, b = isg ? 0 : wk % nprior;
-            int ca = -1, cb = -1;
+        // prior row / column -> column of the marginalization system, once (the rank table is not in use yet)
+        int* pcol = li + MGI_RANK;
+        for (int a = c.tid; a < nprior; a += MG_NT) {
+            int ca = -1;
             for (int blk = 0; blk < nblk; ++blk) {
                 const int sz = pk[blk] == VG_BLK_SPEEDBIAS ? 9 : (pk[blk] == VG_BLK_TD ? 1 : 6);
                 const int base = pk[blk] == VG_BLK_POSE ? mp.pose[pidx[blk]] : (pk[blk] == VG_BLK_SPEEDBIAS ? mp.sb[pidx[blk]]
                                  : (pk[blk] == VG_BLK_EXPOSE ? cex : ctd));
                 if (a >= poff[blk] && a < poff[blk] + sz) ca = base + a - poff[blk];
-                if (b >= poff[blk] && b < poff[blk] + sz) cb = base + b - poff[blk];
             }
+            pcol[a] = ca;
+        }
+        __syncthreads();
+        for (int wk = c.tid; wk < nprior * nprior + nprior; wk += MG_NT) {
+            const bool isg = wk >= nprior * nprior;
+            const int a = isg ? wk - nprior * nprior : wk / nprior, b = isg ? 0 : wk % nprior;
+            const int ca = pcol[a], cb = pcol[b];
             if (isg) {
                 double s = 0.0;
                 for (int r = 0; r < nprior; ++r) s += J0[r * L.pld + a] * prv[r];
@@ -1386,13 +1392,32 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             if (inverse_ok) {
                 // T2 = Amm^-1 [Amr | bmm]: column j of the right-hand side is A[:, m + j] (j < n) or bv (j == n)
                 const int nc = n + 1;
-                double* U = T1;                  // [md][nc]  u = R1 - W D^-1 R2, then X1 = P'^-1 u in T2 rows 0 .. md-1
+                // R = [Amr | bmm] staged in LDS behind W (rows 0 .. m-1, nc columns) when it fits, u / X1 behind B12: the loops
+                // below are dot products over ml or md terms per entry — through global memory a chain of round trips each
+                const bool stage = md * ml + m * nc <= ld * ld && md * ml + md * nc <= ld * ld;
+                double* Rs = Wl + md * ml;       // [m][nc]
+                double* U = stage ? B12 + md * ml : T1;      // [md][nc]  u = R1 - W D^-1 R2, then X1 = P'^-1 u
+                double* X1 = stage ? U : T2;
+                const int ldx = stage ? nc : mcap + 1;
+                if (stage) {
+                    for (int k = c.tid; k < m * nc; k += MG_NT) {
+                        const int r = k / nc, j = k - r * nc;
+                        Rs[k] = j < n ? A[(size_t)r * posmax + m + j] : bv[r];
+                    }
+                    __syncthreads();
+                }
                 for (int k = c.tid; k < md * nc; k += MG_NT) {
                     const int p = k / nc, j = k - p * nc;
-                    double sacc = j < n ? A[(size_t)p * posmax + m + j] : bv[p];
-                    for (int l = 0; l < ml; ++l) {
-                        const double r2 = j < n ? A[(size_t)(md + l) * posmax + m + j] : bv[md + l];
-                        sacc -= Wl[p * ml + l] * r2 / dl[l];
+                    double sacc;
+                    if (stage) {
+                        sacc = Rs[p * nc + j];
+                        for (int l = 0; l < ml; ++l) sacc -= Wl[p * ml + l] * Rs[(md + l) * nc + j] / dl[l];
+                    } else {
+                        sacc = j < n ? A[(size_t)p * posmax + m + j] : bv[p];
+                        for (int l = 0; l < ml; ++l) {
+                            const double r2 = j < n ? A[(size_t)(md + l) * posmax + m + j] : bv[md + l];
+                            sacc -= Wl[p * ml + l] * r2 / dl[l];
+                        }
                     }
                     U[p * nc + j] = sacc;
                 }
@@ -1404,10 +1429,14 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                     T2[p * (mcap + 1) + j] = sacc;
                 }
                 __syncthreads();
+                if (stage) {                     // X1 into LDS (U's place) for the last loop
+                    for (int k = c.tid; k < md * nc; k += MG_NT) { const int p = k / nc, j = k - p * nc; X1[p * nc + j] = T2[p * (mcap + 1) + j]; }
+                    __syncthreads();
+                }
                 for (int k = c.tid; k < ml * nc; k += MG_NT) {
                     const int l = k / nc, j = k - l * nc;
-                    double sacc = j < n ? A[(size_t)(md + l) * posmax + m + j] : bv[md + l];
-                    for (int p = 0; p < md; ++p) sacc -= Wl[p * ml + l] * T2[p * (mcap + 1) + j];
+                    double sacc = stage ? Rs[(md + l) * nc + j] : (j < n ? A[(size_t)(md + l) * posmax + m + j] : bv[md + l]);
+                    for (int p = 0; p < md; ++p) sacc -= Wl[p * ml + l] * X1[p * ldx + j];
                     T2[(md + l) * (mcap + 1) + j] = sacc / dl[l];
                 }
                 __syncthreads();
@@ -1459,13 +1488,33 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         }
         __syncthreads();
         }   // eigen path
-        // A' = Arr - Arm T2[:, :n] ; b' = brr - Arm T2[:, n]   -> eM (n x n, ld), b' -> T1 row 0 (reuse)
-        for (int k = c.tid; k < n * (n + 1); k += MG_NT) {
-            const int i = k / (n + 1), j = k % (n + 1);
-            double s = (j < n) ? A[(m + i) * posmax + m + j] : bv[m + i];
+        // A' = Arr - Arm T2[:, :n] ; b' = brr - Arm T2[:, n]   -> staged in global (gM, gV)
+        if (n * m <= ld * ld && m * (n + 1) <= ld * ld) {
+            // both operands through LDS (the two eigen-solver tiles are free here): the m-term dot product of every entry used to
+            // be a chain of global round trips (125K of the kernel's 850K cycles)
+            double* Arm = eM;                    // [n][m]
+            double* T2s = eV;                    // [m][n + 1]
+            __syncthreads();
+            for (int k = c.tid; k < n * m; k += MG_NT) { const int i = k / m, r = k - i * m; Arm[k] = A[(m + i) * posmax + r]; }
+            for (int k = c.tid; k < m * (n + 1); k += MG_NT) { const int r = k / (n + 1), j = k - r * (n + 1); T2s[k] = T2[r * (mcap + 1) + j]; }
+            __syncthreads();
+            for (int k = c.tid; k < n * (n + 1); k += MG_NT) {
+                const int i = k / (n + 1), j = k % (n + 1);
+                double s = (j < n) ? A[(m + i) * posmax + m + j] : bv[m + i];
+                const double* ar = Arm + i * m;
+                const double* tc = T2s + j;
 #pragma unroll 8
-            for (int r = 0; r < m; ++r) s -= A[(m + i) * posmax + r] * T2[r * (mcap + 1) + j];
-            if (j < n) gM[i * posmax + j] = s; else gV[i] = s;      // stage in global (eM may still be Mm)
+                for (int r = 0; r < m; ++r) s -= ar[r] * tc[r * (n + 1)];
+                if (j < n) gM[i * posmax + j] = s; else gV[i] = s;
+            }
+        } else {
+            for (int k = c.tid; k < n * (n + 1); k += MG_NT) {
+                const int i = k / (n + 1), j = k % (n + 1);
+                double s = (j < n) ? A[(m + i) * posmax + m + j] : bv[m + i];
+#pragma unroll 8
+                for (int r = 0; r < m; ++r) s -= A[(m + i) * posmax + r] * T2[r * (mcap + 1) + j];
+                if (j < n) gM[i * posmax + j] = s; else gV[i] = s;      // stage in global (eM may still be Mm)
+            }
         }
         __syncthreads();
     }
