@@ -203,6 +203,16 @@ DEV void ctl_store(const Ctl& s, double* p) {
     p[C_PHASE] = s.phase; p[C_GNN2C] = s.gnn2c; p[C_GTGNC] = s.gtgnc; p[C_STEP2C] = s.step2c; p[C_XN2C] = s.xn2c;
 }
 
+// every field wave-uniform again (values recomputed on the VALU since the load are vector registers to the compiler)
+DEV void ctl_uniform(Ctl& s) {
+    s.it = uni(s.it); s.nacc = uni(s.nacc); s.ninv = uni(s.ninv); s.term = uni(s.term); s.status = uni(s.status);
+    s.reuse = uni(s.reuse); s.cur = uni(s.cur); s.pending = uni(s.pending); s.done = uni(s.done); s.scaled = uni(s.scaled);
+    s.radius = uni(s.radius); s.mu = uni(s.mu); s.mu_solved = uni(s.mu_solved); s.cost = uni(s.cost); s.x_norm = uni(s.x_norm);
+    s.alpha = uni(s.alpha); s.gtn2 = uni(s.gtn2); s.gnn2 = uni(s.gnn2); s.gtgn = uni(s.gtgn); s.dnorm = uni(s.dnorm); s.model = uni(s.model);
+    s.step_norm = uni(s.step_norm); s.x_norm_c = uni(s.x_norm_c); s.init_cost = uni(s.init_cost); s.qcam = uni(s.qcam);
+    s.phase = uni(s.phase);
+}
+
 // Judge the pending candidate (TrustRegionMinimizer: parameter tolerance, function tolerance, step quality; then
 // DoglegStrategy::StepAccepted / StepRejected).  Uniform: every thread computes the same from the same HBM values;
 // thread 0 writes the trace.  Returns true if the candidate became the current point.
@@ -974,7 +984,7 @@ DEV void phase_ctx(Ctx& c, BaLayout& L, SolveLds& m, int big) {        // big: 0
 }
 // the kernels compare what the phases will derive with their real arguments once (a wrong hidden-argument offset must not be silent)
 #define PHASE_SELF_CHECK(cref) do { Ctx c_; BaLayout L_; SolveLds m_; phase_ctx(c_, L_, m_, 0); if (c_.sc != (cref).sc || c_.ia != (cref).ia || c_.pri != (cref).pri) __builtin_trap(); } while (0)
-#define PHASE_ENTER(BIGV) Ctx c; BaLayout L; SolveLds m; phase_ctx(c, L, m, BIGV); asm volatile("" :: "v"(c_in.tid)); (void)m_in
+#define PHASE_ENTER(BIGV) Ctx c; BaLayout L; SolveLds m; phase_ctx(c, L, m, BIGV); asm volatile("" :: "v"(&c_in)); (void)m_in
 #endif
 
 // local column (0..29) of IMU factor f -> reduced column
@@ -2070,6 +2080,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     const double* hh = buf + L.bo_h;
     const double* bb = buf + L.bo_b;
     if (fresh_point && s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK) {
+        ctl_uniform(s);
         assemble<false>(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp);
         assembled = true;
         if (!s.scaled) {
@@ -2103,6 +2114,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
         bool ok = true;
         if (!s.reuse) {
             s.reuse = 1;
+            ctl_uniform(s);
             if (!assembled) { assemble<false>(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; }
             PROF_ADD(PF_ASM);
             // Dg, gt (scaled gradient / Dg), t = gt / Dg
@@ -2135,6 +2147,7 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
             bool solved = false;
             while (s.mu < max_mu) {
                 if (!assembled) { assemble<false>(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; PROF_ADD(PF_ASM); }
+                ctl_uniform(s);
                 double q = build_scaled<false>(c, m, s.mu);
                 assembled = false;
                 __syncthreads();
