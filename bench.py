@@ -342,7 +342,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=WINDOWS_PER_GPU)
-    ap.add_argument("--in-flight", type=int, default=3, help="independent batches (HIP streams) the steps are spread over")
+    ap.add_argument("--in-flight", type=int, default=2, help="independent batches (HIP streams) the steps are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=["batch", "sharded"], default="batch",
                     help="batch = BASELINE configs[3] (the headline: independent EuRoC-shape windows, replicas over GPUs); sharded = "
@@ -375,8 +375,9 @@ def main():
     nwin = args.windows
     nfl = max(1, args.in_flight)
     # `nfl` independent batches of nwin windows each, one vg_handle (= one HIP stream) per batch: consecutive steps go to
-    # different streams, so the launches of step i+1 overlap the latency-bound phases of step i (a workgroup of the
-    # solve kernel needs < 80 KB of LDS: two windows are resident per CU)
+    # different streams, so the launches of step i+1 fill the tails of step i's (a solve workgroup fills a CU by itself: the
+    # kernels of two steps do not share CUs).  Two in flight measured best (96.1K / 95.4K against 92.9K / 93.4K with three and
+    # 88.0K with one, same box, same call).
     handles = [h] + [ba.Handle() for _ in range(nfl - 1)]
     seed0 = D.window_seeds(rank, nwin)[0]
     probs, seqs = make_windows(h, ba, synth, nwin, seed0=seed0)
