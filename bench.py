@@ -81,13 +81,13 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
     nxt = [synth.warp_frame(b, 2000 + c) for c, b in enumerate(base)]
     fa = [base[c % len(base)] for c in range(FE_CAMS)]
     fb = [nxt[c % len(nxt)] for c in range(FE_CAMS)]
-    tr.push_frames(fa)                      # slot 0 = frame A (and pyramid)
+    tr.push_frames(fa)                      # frame A (and its pyramid)
     tr.detect_upload([N] * FE_CAMS)
     tr.detect_async()
     corners = tr.detect_download()
-    tr.upload_frames(fb)                    # slot 1 = frame B
+    tr.upload_frames(fb)                    # frame B into the other frame slot
     tr.track_upload(corners)
-    slot = 1
+    slot = tr.frame_slot()                  # the steps alternate between the two resident frames, starting with B
 
     def step():
         nonlocal slot
@@ -135,7 +135,7 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
         "gftt_frames_per_s": FE_CAMS / (gftt_ms * 1e-3), "gftt_ms_per_batch": gftt_ms,
         "with_clahe": {"ms_per_step": eq_ms, "features_per_s": nfeat / (eq_ms * 1e-3),
                        "what": "same step with CLAHE(3.0, 8x8) on the incoming frame (EuRoC equalize: 1), HIP events"},
-        "roofline": {"kernel": "fe_lk_kernel (+ fe_pyrdown_kernel x3 + fe_copy_kernel)", "bound": "hbm",
+        "roofline": {"kernel": "fe_lk_kernel (+ fe_pyrdown_kernel x3)", "bound": "hbm",
                      "achieved": nfeat * FE_BYTES_PER_FEATURE * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "traffic": fe_traffic(), "event_ms_per_step": ev_ms / steps,
                      "gftt_GBs": FE_CAMS * FE_GFTT_BYTES_PER_FRAME / (gftt_ms * 1e-3) / 1e9},
@@ -331,9 +331,10 @@ def pmc_traffic(kernel):
 
 
 def fe_traffic():
-    """HBM bytes per FE step (one fe_lk launch + 3 fe_pyrdown + 1 fe_copy) from the committed PMC summary."""
-    t = [pmc_traffic("fe_lk_kernel"), pmc_traffic("fe_pyrdown_kernel"), pmc_traffic("fe_copy_kernel")]
-    return None if any(v is None for v in t) else t[0] + 3 * t[1] + t[2]
+    """HBM bytes per FE step (one fe_lk launch + 3 fe_pyrdown; the frame is level 0 of its pyramid, there is no copy) from the
+    committed PMC summary (per-launch figures of the PMC pass scale with the number of streams of THAT pass)."""
+    t = [pmc_traffic("fe_lk_kernel"), pmc_traffic("fe_pyrdown_kernel")]
+    return None if any(v is None for v in t) else t[0] + 3 * t[1]
 
 
 def main():

@@ -313,8 +313,12 @@ int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, int max_poi
 int vg_fe_push_frames(vg_handle* h, const uint8_t* const* imgs, int stride, int equalize);
 int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int stride);     /* H2D only            */
 int vg_fe_build_async(vg_handle* h, int equalize);                                 /* CLAHE + pyramids    */
-/* two device-resident raw-frame slots: upload_frames fills the slot that is not selected and selects it;
- * select_frames re-selects a slot that was uploaded earlier (benchmarks alternate between two resident frames) */
+/* Two device-resident frame slots, one per pyramid set.  upload_frames fills the slot of the set the NEXT build will fill and
+ * selects it; a frame that is not equalized then IS level 0 of its pyramid (no copy).  Consequence: after upload_frames the
+ * older of the two pyramids is incomplete until build_async has run — upload, build, then track (push_frames does the first
+ * two).  frame_slot returns the selected slot; select_frames re-selects a slot that was uploaded earlier (benchmarks alternate
+ * between two resident frames; building from the slot the current pyramid already uses falls back to a copy). */
+int vg_fe_frame_slot(vg_handle* h);
 int vg_fe_select_frames(vg_handle* h, int slot);
 /* Pyramidal LK from the previous to the current frame of stream `cam`.  prev_xy / next_xy are (x, y) float pairs.
  * status / err have OpenCV's meaning (the inBorder() filter of feature_tracker.cpp:115-117 is the caller's). */

@@ -17,7 +17,7 @@ for cams in (1, 4, 16, 34, 64, 128, 256):
     tr.detect_upload([N] * cams); tr.detect_async(); corners = tr.detect_download()
     tr.upload_frames(fb)
     tr.track_upload(corners)
-    tr.select_frames(1); tr.build_async(False)
+    tr.select_frames(tr.frame_slot()); tr.build_async(False)
     for _ in range(3):
         tr.track_async()
     h.sync()

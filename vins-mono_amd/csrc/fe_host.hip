@@ -43,6 +43,12 @@ struct FeState {
     uint8_t* planes[2] = {nullptr, nullptr};   // two pyramids per camera, all levels, contiguous
     uint8_t** d_ptrs[2] = {nullptr, nullptr};  // device pointer tables [level*cams+cam]
     std::vector<uint8_t*> h_ptrs[2];
+    // The same tables with level 0 pointing INTO the frame slot: pyramid set k <-> frame slot k.  A frame that is not equalized
+    // is its own level 0 — the upload already put it into HBM, a copy into the pyramid's plane moves 361 KB per frame for
+    // nothing (44 of 567 us per 256-stream step).  alias_on[k]: set k currently uses its frame slot as level 0.
+    uint8_t** d_ptrs_alias[2] = {nullptr, nullptr};
+    std::vector<uint8_t*> h_ptrs_alias[2];
+    bool alias_on[2] = {false, false};
     size_t level_off[FE_MAX_LEVELS + 1];
     uint8_t* raw2[2] = {nullptr, nullptr};
     int raw_sel = 1;
@@ -65,7 +71,7 @@ struct FeState {
 
 extern "C" void fe_state_destroy(FeState* s) {
     if (!s) return;
-    for (int k = 0; k < 2; ++k) { (void)hipFree(s->planes[k]); (void)hipFree(s->d_ptrs[k]); }
+    for (int k = 0; k < 2; ++k) { (void)hipFree(s->planes[k]); (void)hipFree(s->d_ptrs[k]); (void)hipFree(s->d_ptrs_alias[k]); }
     (void)hipFree(s->raw); (void)hipFree(s->lut); (void)hipFree(s->mask); (void)hipFree(s->status);
     (void)hipFree(s->prev_xy); (void)hipFree(s->next_xy); (void)hipFree(s->err); (void)hipFree(s->eig);
     (void)hipFree(s->blockmax); (void)hipFree(s->corners); (void)hipFree(s->npts); (void)hipFree(s->max_corners);
@@ -76,8 +82,9 @@ extern "C" void fe_state_destroy(FeState* s) {
 }
 
 static void refresh(FeState* s) {
-    s->d.cur_planes = s->d_ptrs[s->flip];
-    s->d.prev_planes = s->d_ptrs[s->flip ^ 1];
+    const int a = s->flip, b = s->flip ^ 1;
+    s->d.cur_planes = s->alias_on[a] ? s->d_ptrs_alias[a] : s->d_ptrs[a];
+    s->d.prev_planes = s->alias_on[b] ? s->d_ptrs_alias[b] : s->d_ptrs[b];
 }
 
 extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, int max_points) {
@@ -120,6 +127,13 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     d.cand_cap = FE_CAND_CAP;
     HIPCHK(h, hipMalloc((void**)&s->raw, 2 * npix * n_cams));
     s->raw2[0] = s->raw; s->raw2[1] = s->raw + npix * n_cams;
+    for (int k = 0; k < 2; ++k) {
+        s->h_ptrs_alias[k] = s->h_ptrs[k];
+        for (int c = 0; c < n_cams; ++c) s->h_ptrs_alias[k][c] = s->raw2[k] + (size_t)c * npix;
+        HIPCHK(h, hipMalloc((void**)&s->d_ptrs_alias[k], sizeof(uint8_t*) * s->h_ptrs_alias[k].size()));
+        HIPCHK(h, hipMemcpy(s->d_ptrs_alias[k], s->h_ptrs_alias[k].data(), sizeof(uint8_t*) * s->h_ptrs_alias[k].size(), hipMemcpyHostToDevice));
+        s->alias_on[k] = false;
+    }
     HIPCHK(h, hipMalloc((void**)&s->lut, (size_t)n_cams * 64 * 256));
     HIPCHK(h, hipMalloc((void**)&s->mask, npix * n_cams));
     HIPCHK(h, hipMemset(s->mask, 255, npix * n_cams));
@@ -153,13 +167,19 @@ extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int
     for (int c = 0; c < s->cams; ++c)                 // validate before touching any state
         if (!imgs[c]) { h->err = "vg_fe_upload_frames: every stream needs a frame (batched streams advance together)"; return VG_ERR_BAD_ARG; }
     if (stride < s->W) { h->err = "vg_fe_upload_frames: stride smaller than the frame width"; return VG_ERR_BAD_ARG; }
-    s->raw_sel ^= 1;
+    // into the frame slot of the pyramid set the next build fills (set k <-> slot k): never the slot the CURRENT pyramid may be
+    // using as its level 0 -- that image is the "previous" one of the next tracking step
+    s->raw_sel = s->flip ^ 1;
     s->d.raw = s->raw2[s->raw_sel];
     for (int c = 0; c < s->cams; ++c) {
         HIPCHK(h, hipMemcpy2DAsync(s->raw2[s->raw_sel] + (size_t)c * npix, s->W, imgs[c], stride, s->W, s->H, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return VG_OK;
+}
+
+extern "C" int vg_fe_frame_slot(vg_handle* h) {
+    return (h && h->fe) ? h->fe->raw_sel : -1;
 }
 
 extern "C" int vg_fe_select_frames(vg_handle* h, int slot) {
@@ -176,16 +196,20 @@ extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
     if (equalize && (s->d.W % 8 || s->d.H % 8)) { h->err = "CLAHE needs width and height divisible by 8"; return VG_ERR_UNSUPPORTED; }
     const bool first = !s->have_prev;
     s->flip ^= 1;                                     // previous <- current (only after the arguments are known to be valid)
+    // level 0 = the frame slot itself when the frame is used as it is and sits in the slot that belongs to this pyramid set
+    // (the normal alternation: upload -> build -> upload -> build); otherwise it is written into the set's own plane
+    const bool alias = !equalize && !first && s->raw_sel == s->flip;
+    s->alias_on[s->flip] = alias;
     refresh(s);
     const FeDev& d = s->d;
-    uint8_t* const* cur0 = s->d_ptrs[s->flip];
+    uint8_t* const* cur0 = alias ? s->d_ptrs_alias[s->flip] : s->d_ptrs[s->flip];
     if (equalize) {
         const int area = (d.W / 8) * (d.H / 8);
         int clip = (int)(3.0 * area / 256);
         clip = clip < 1 ? 1 : clip;
         hipLaunchKernelGGL(fe_clahe_lut_kernel, dim3(64, d.cams), dim3(256), 0, h->stream, d, clip, 255.f / area);
         hipLaunchKernelGGL(fe_clahe_apply_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, d.cams), dim3(256), 0, h->stream, d, cur0);
-    } else {
+    } else if (!alias) {
         hipLaunchKernelGGL(fe_copy_kernel, dim3(256, d.cams), dim3(256), 0, h->stream, d, cur0);
     }
     for (int l = 1; l <= d.max_level; ++l) {
@@ -437,7 +461,8 @@ extern "C" int vg_fe_get_level(vg_handle* h, int cam, int which, int level, uint
     const int set = which ? (s->flip ^ 1) : s->flip;
     const int lw = s->d.lw[level], lh = s->d.lh[level];
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, s->h_ptrs[set][(size_t)level * s->cams + cam], (size_t)lw * lh, hipMemcpyDeviceToHost));
+    const std::vector<uint8_t*>& tab = s->alias_on[set] ? s->h_ptrs_alias[set] : s->h_ptrs[set];
+    HIPCHK(h, hipMemcpy(out, tab[(size_t)level * s->cams + cam], (size_t)lw * lh, hipMemcpyDeviceToHost));
     if (w) *w = lw;
     if (hgt) *hgt = lh;
     return VG_OK;

@@ -146,7 +146,18 @@ extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_
     for (int k = threadIdx.x; k < PD_IN * 64; k += 256) {
         const int r = k >> 6, lx = k & 63;
         const uint8_t* t = &tile[r][2 * lx + 2];           // input column 2x - 2
+#ifdef VINS_SIMT
         hs[r][lx] = t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4];
+#else
+        // the five taps start at an even byte: they lie in two aligned dwords (two LDS reads and a funnel shift instead of five
+        // byte reads -- this pass was 44 of the kernel's ~60 LDS instructions per thread)
+        const unsigned off = (2u * lx + 2u) & 3u;          // 0 or 2
+        const unsigned* w = (const unsigned*)(t - off);
+        const unsigned w0 = w[0], w1 = w[1];
+        const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, off);
+        const unsigned t4 = (off ? w1 >> 16 : w1) & 255u;
+        hs[r][lx] = (int)((lo & 255u) + 4u * ((lo >> 8) & 255u) + 6u * ((lo >> 16) & 255u) + 4u * (lo >> 24) + t4);
+#endif
     }
     __syncthreads();
     // thread = 4 horizontally adjacent outputs of one row: five 16-byte LDS reads, one 4-byte store (a byte store per thread

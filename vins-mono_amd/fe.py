@@ -20,6 +20,7 @@ class FrontEnd:
         L.vg_fe_upload_frames.argtypes = [C.c_void_p, C.POINTER(_u8), C.c_int]
         L.vg_fe_build_async.argtypes = [C.c_void_p, C.c_int]
         L.vg_fe_select_frames.argtypes = [C.c_void_p, C.c_int]
+        L.vg_fe_frame_slot.argtypes = [C.c_void_p]
         L.vg_fe_track.argtypes = [C.c_void_p, C.c_int, _f4, C.c_int, _f4, _u8, _f4]
         L.vg_fe_track_upload.argtypes = [C.c_void_p, _f4, _i4]
         L.vg_fe_track_async.argtypes = [C.c_void_p]
@@ -47,6 +48,10 @@ class FrontEnd:
 
     def upload_frames(self, frames):
         self.hd._chk(self.lib.vg_fe_upload_frames(self.h, self._imgs(frames), self.W), "vg_fe_upload_frames")
+
+    def frame_slot(self):
+        """The frame slot the last upload went into (vg_fe_frame_slot)."""
+        return int(self.lib.vg_fe_frame_slot(self.h))
 
     def select_frames(self, slot):
         self.hd._chk(self.lib.vg_fe_select_frames(self.h, int(slot)), "vg_fe_select_frames")
