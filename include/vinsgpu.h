@@ -350,10 +350,11 @@ int vg_fe_detect_masked(vg_handle* h, int cam, int max_corners, double quality, 
 int vg_fe_undistort(vg_handle* h, const float* pts_xy, int n, const double* intr, float* out_xy);
 /* FeatureTracker::rejectWithF() (feature_tracker.cpp:169-202): cv::findFundamentalMat(un_cur_pts, un_forw_pts, FM_RANSAC,
  * threshold, 0.99, status) on n >= 8 correspondences given in the pixel coordinates of the virtual pinhole camera
- * (FOCAL_LENGTH * x/z + COL/2, ...).  status[i] = 1 for the inliers of the best of 256 deterministic 8-point hypotheses
- * (error = max of the two squared point-to-epipolar-line distances <= threshold^2, OpenCV's FMEstimatorCallback);
- * n_inliers / F_out (row-major 3x3) may be NULL.  OpenCV's RNG, adaptive iteration count and 7-point solver are NOT
- * reproduced (oracle/ASSUMPTIONS.md F9): the result is a pure function of the input.  SURVEY.md 8(f) row 3. */
+ * (FOCAL_LENGTH * x/z + COL/2, ...).  Follows OpenCV 3.3's registrators as recalled (oracle/ASSUMPTIONS.md F9): cv::RNG((uint64)-1)
+ * sample schedule, 7-point solver, error = max of the two squared point-to-epipolar-line distances (float) <= threshold^2, adaptive
+ * iteration bound, LMedS instead of RANSAC below 15 points.  status[i] = 1 for the inliers of the winning model; if no model is
+ * found every status is 1 (nothing is rejected).  n_inliers / F_out (row-major 3x3, F33 = 1) may be NULL.  A pure function of the
+ * input.  SURVEY.md 8(f) row 3. */
 int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const float* forw_un_xy, int n, double threshold, uint8_t* status,
                         int* n_inliers, double* F_out);
 /* debugging / parity taps: copy a pyramid level of the current (which = 0) or previous (1) frame, or the

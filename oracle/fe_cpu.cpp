@@ -412,17 +412,20 @@ void oracle_fe_lift(const float* pts_xy, int n, const double* intr, float* out_x
     }
 }
 
-// ---- FeatureTracker::rejectWithF (feature_tracker.cpp:169-202): cv::findFundamentalMat(FM_RANSAC, thr, 0.99) restated as
-// a DETERMINISTIC RANSAC (ASSUMPTIONS.md F9): 256 hypotheses, each from 8 points drawn by a counter-based generator,
-// normalised 8-point algorithm (null vector by one-sided Jacobi on the 9 columns, rank-2 projection), OpenCV's error
-// (max of the two squared point-to-epipolar-line distances, cast to float) against threshold^2; the model with the most
-// inliers wins (lowest index on ties) and its inlier set is the mask.  Returns the inlier count.
-static unsigned long long fr_mix(unsigned long long z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
+// ---- FeatureTracker::rejectWithF (feature_tracker.cpp:169-202): cv::findFundamentalMat(un_cur, un_forw, FM_RANSAC, thr, 0.99,
+// status), restated after OpenCV 3.3's fundam.cpp / ptsetreg.cpp AS RECALLED (ASSUMPTIONS.md F9 lists what is matched and
+// what cannot be):
+//   * n >= 15: RANSACPointSetRegistrator(modelPoints 7, maxIters 1000): cv::RNG((uint64)-1) (multiply-with-carry, coefficient
+//     4164903690), getSubset (7 distinct rng.uniform(0, n) draws, redrawn while the last point of either sample is collinear
+//     with two earlier ones), run7Point (null space of the 7 x 9 design matrix of the RAW points, cubic det(x G + H) = 0 by
+//     cv::solveCubic, up to three models, each scaled to F33 = 1), the error max(d1^2/|l1|^2, d2^2/|l2|^2) as float against
+//     thr^2, a model replaces the best one if it has MORE inliers than max(best, 6), and after every improvement
+//     niters = RANSACUpdateNumIters(0.99, outlier ratio, 7, niters);
+//   * 8 <= n < 15: LMeDSPointSetRegistrator: niters = max(RANSACUpdateNumIters(0.99, 0.45, 7, 1000), 3) samples, the model with
+//     the smallest median error, inliers = error <= (2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median))^2, at least 0.001^2.
+// The models of ONE sample are visited best first with a canonical tie order (the order OpenCV visits them in depends on the
+// basis its SVD returns for the two-dimensional null space, which no restatement can reproduce).
+// Returns the inlier count (n and an all-ones status if no model was found: documented choice).
 static float fr_error(const double* f, double x1, double y1, double x2, double y2) {
     double a = f[0] * x1 + f[1] * y1 + f[2], b = f[3] * x1 + f[4] * y1 + f[5], c = f[6] * x1 + f[7] * y1 + f[8];
     const double s2 = 1.0 / (a * a + b * b), d2 = x2 * a + y2 * b + c;
@@ -431,116 +434,226 @@ static float fr_error(const double* f, double x1, double y1, double x2, double y
     const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
     return (float)(e1 > e2 ? e1 : e2);
 }
-static bool fr_hypothesis(int k, const float* p1, const float* p2, int n, double* F) {
-    int idx[8], have = 0;
-    for (unsigned d = 0; have < 8; ++d) {
-        const int c = (int)(fr_mix(((unsigned long long)(unsigned)k << 32) | d) % (unsigned long long)n);
-        bool dup = false;
-        for (int q = 0; q < have; ++q) dup = dup || idx[q] == c;
-        if (!dup) idx[have++] = c;
+struct CvRng {                                        // cv::RNG
+    unsigned long long state;
+    explicit CvRng(unsigned long long s) : state(s ? s : 0xffffffffull) {}
+    unsigned next() { state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32); return (unsigned)state; }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+static bool fr_collinear_last(const float* p, const int* idx, int count) {      // haveCollinearPoints: last point against pairs
+    const int i = count - 1;
+    for (int j = 0; j < i; ++j) {
+        const double dx1 = (double)p[2 * idx[j]] - p[2 * idx[i]], dy1 = (double)p[2 * idx[j] + 1] - p[2 * idx[i] + 1];
+        for (int k = 0; k < j; ++k) {
+            const double dx2 = (double)p[2 * idx[k]] - p[2 * idx[i]], dy2 = (double)p[2 * idx[k] + 1] - p[2 * idx[i] + 1];
+            if (std::fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2))) return true;
+        }
     }
-    double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
-    for (int i = 0; i < 8; ++i) { c1x += p1[2 * idx[i]]; c1y += p1[2 * idx[i] + 1]; c2x += p2[2 * idx[i]]; c2y += p2[2 * idx[i] + 1]; }
-    c1x /= 8; c1y /= 8; c2x /= 8; c2y /= 8;
-    double s1 = 0, s2 = 0;
-    for (int i = 0; i < 8; ++i) {
-        const double ax = p1[2 * idx[i]] - c1x, ay = p1[2 * idx[i] + 1] - c1y, bx = p2[2 * idx[i]] - c2x, by = p2[2 * idx[i] + 1] - c2y;
-        s1 += std::sqrt(ax * ax + ay * ay); s2 += std::sqrt(bx * bx + by * by);
+    return false;
+}
+static bool fr_get_subset(CvRng& rng, const float* p1, const float* p2, int n, int* idx, int max_attempts) {
+    int iters = 0, i = 0;
+    for (; iters < max_attempts; ++iters) {
+        for (i = 0; i < 7 && iters < max_attempts;) {
+            int c;
+            for (;;) {
+                c = idx[i] = rng.uniform(0, n);
+                int j = 0;
+                for (; j < i; ++j) if (c == idx[j]) break;
+                if (j == i) break;
+            }
+            ++i;
+        }
+        if (i == 7 && (fr_collinear_last(p1, idx, 7) || fr_collinear_last(p2, idx, 7))) continue;
+        break;
     }
-    const bool degenerate = !(s1 > 1e-12) || !(s2 > 1e-12);
-    s1 = degenerate ? 1.0 : 8.0 * 1.4142135623730951 / s1;
-    s2 = degenerate ? 1.0 : 8.0 * 1.4142135623730951 / s2;
-    double A[8][9], V[9][9];
-    for (int i = 0; i < 8; ++i) {
-        const double x1 = (p1[2 * idx[i]] - c1x) * s1, y1 = (p1[2 * idx[i] + 1] - c1y) * s1;
-        const double x2 = (p2[2 * idx[i]] - c2x) * s2, y2 = (p2[2 * idx[i] + 1] - c2y) * s2;
-        const double row[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
-        for (int c = 0; c < 9; ++c) A[i][c] = row[c];
+    return i == 7 && iters < max_attempts;
+}
+static int fr_solve_cubic(const double* cf, double* r) {          // cv::solveCubic(c0 x^3 + c1 x^2 + c2 x + c3)
+    double a0 = cf[0], a1 = cf[1], a2 = cf[2], a3 = cf[3];
+    if (a0 == 0) {
+        if (a1 == 0) {
+            if (a2 == 0) return a3 == 0 ? -1 : 0;
+            r[0] = -a3 / a2;
+            return 1;
+        }
+        double d = a2 * a2 - 4 * a1 * a3;
+        if (d < 0) return 0;
+        d = std::sqrt(d);
+        const double q1 = (-a2 + d) * 0.5, q2 = (a2 + d) * -0.5;
+        if (std::fabs(q1) > std::fabs(q2)) { r[0] = q1 / a1; r[1] = a3 / q1; } else { r[0] = q2 / a1; r[1] = a3 / q2; }
+        return d > 0 ? 2 : 1;
     }
-    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) V[r][c] = r == c ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        bool rotated = false;
+    a0 = 1.0 / a0; a1 *= a0; a2 *= a0; a3 *= a0;
+    const double Q = (a1 * a1 - 3 * a2) * (1.0 / 9), R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1.0 / 54);
+    const double Qcubed = Q * Q * Q;
+    double d = Qcubed - R * R;
+    if (d >= 0) {
+        const double theta = std::acos(R / std::sqrt(Qcubed)), sqrtQ = std::sqrt(Q);
+        const double t0 = -2 * sqrtQ, t1 = theta * (1.0 / 3), t2 = a1 * (1.0 / 3);
+        r[0] = t0 * std::cos(t1) - t2;
+        r[1] = t0 * std::cos(t1 + (2.0 * 3.1415926535897932384626433832795 / 3)) - t2;
+        r[2] = t0 * std::cos(t1 + (4.0 * 3.1415926535897932384626433832795 / 3)) - t2;
+        return 3;
+    }
+    d = std::sqrt(-d);
+    double e = std::pow(d + std::fabs(R), 0.333333333333);
+    if (R > 0) e = -e;
+    r[0] = (e + Q / e) - a1 * (1.0 / 3);
+    return 1;
+}
+// run7Point on the sampled correspondences: up to three 3x3 models (row-major), count returned
+static int fr_seven_point(const float* p1, const float* p2, const int* idx, double* models) {
+    double AtA[81];
+    for (int e = 0; e < 81; ++e) AtA[e] = 0.0;
+    for (int i = 0; i < 7; ++i) {
+        const double x0 = p1[2 * idx[i]], y0 = p1[2 * idx[i] + 1], x1 = p2[2 * idx[i]], y1 = p2[2 * idx[i] + 1];
+        const double row[9] = {x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1.0};
+        for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) AtA[a * 9 + b] += row[a] * row[b];
+    }
+    // null space = eigenvectors of the two smallest eigenvalues of A^T A (two-sided cyclic Jacobi)
+    double V[81];
+    for (int e = 0; e < 81; ++e) V[e] = (e % 10 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) (a == b ? dia : off) += AtA[a * 9 + b] * AtA[a * 9 + b];
+        if (!(off > 1e-60 * dia)) break;
         for (int p = 0; p < 8; ++p)
             for (int q = p + 1; q < 9; ++q) {
-                double al = 0.0, be = 0.0, ga = 0.0;
-                for (int r = 0; r < 8; ++r) { al += A[r][p] * A[r][p]; be += A[r][q] * A[r][q]; ga += A[r][p] * A[r][q]; }
-                if (std::fabs(ga) > 1e-15 * std::sqrt(al * be) && ga != 0.0) {
-                    rotated = true;
-                    const double zeta = (be - al) / (2.0 * ga);
-                    const double tn = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                    const double cs = 1.0 / std::sqrt(1.0 + tn * tn), sn = cs * tn;
-                    for (int r = 0; r < 8; ++r) { const double a = A[r][p], b = A[r][q]; A[r][p] = cs * a - sn * b; A[r][q] = sn * a + cs * b; }
-                    for (int r = 0; r < 9; ++r) { const double a = V[r][p], b = V[r][q]; V[r][p] = cs * a - sn * b; V[r][q] = sn * a + cs * b; }
-                }
-            }
-        if (!rotated) break;
-    }
-    int bi = 0;
-    double best = 0.0;
-    for (int c = 0; c < 9; ++c) {
-        double nn = 0.0;
-        for (int r = 0; r < 8; ++r) nn += A[r][c] * A[r][c];
-        if (c == 0 || nn < best) { best = nn; bi = c; }
-    }
-    double Fn[9];
-    for (int e = 0; e < 9; ++e) Fn[e] = V[e][bi];
-    {
-        double M[9], W[9];
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i * 3 + j] = Fn[i] * Fn[j] + Fn[3 + i] * Fn[3 + j] + Fn[6 + i] * Fn[6 + j];
-        for (int e = 0; e < 9; ++e) W[e] = (e % 4 == 0) ? 1.0 : 0.0;
-        for (int sweep = 0; sweep < 30; ++sweep) {
-            const double off = std::fabs(M[1]) + std::fabs(M[2]) + std::fabs(M[5]);
-            if (!(off > 1e-300)) break;
-            bool rotated = false;
-            for (int pq = 0; pq < 3; ++pq) {
-                const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
-                const double apq = M[p * 3 + q];
-                if (std::fabs(apq) <= 1e-17 * std::sqrt(std::fabs(M[p * 4] * M[q * 4])) || apq == 0.0) continue;
-                rotated = true;
-                const double th = (M[q * 4] - M[p * 4]) / (2.0 * apq);
+                const double apq = AtA[p * 9 + q];
+                if (apq == 0.0) continue;
+                const double th = (AtA[q * 9 + q] - AtA[p * 9 + p]) / (2.0 * apq);
                 const double tn = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(1.0 + th * th));
                 const double cs = 1.0 / std::sqrt(1.0 + tn * tn), sn = cs * tn;
-                for (int r = 0; r < 3; ++r) { const double a = M[r * 3 + p], b = M[r * 3 + q]; M[r * 3 + p] = cs * a - sn * b; M[r * 3 + q] = sn * a + cs * b; }
-                for (int r = 0; r < 3; ++r) { const double a = M[p * 3 + r], b = M[q * 3 + r]; M[p * 3 + r] = cs * a - sn * b; M[q * 3 + r] = sn * a + cs * b; }
-                for (int r = 0; r < 3; ++r) { const double a = W[r * 3 + p], b = W[r * 3 + q]; W[r * 3 + p] = cs * a - sn * b; W[r * 3 + q] = sn * a + cs * b; }
+                for (int r = 0; r < 9; ++r) { const double a = AtA[r * 9 + p], b = AtA[r * 9 + q]; AtA[r * 9 + p] = cs * a - sn * b; AtA[r * 9 + q] = sn * a + cs * b; }
+                for (int r = 0; r < 9; ++r) { const double a = AtA[p * 9 + r], b = AtA[q * 9 + r]; AtA[p * 9 + r] = cs * a - sn * b; AtA[q * 9 + r] = sn * a + cs * b; }
+                for (int r = 0; r < 9; ++r) { const double a = V[r * 9 + p], b = V[r * 9 + q]; V[r * 9 + p] = cs * a - sn * b; V[r * 9 + q] = sn * a + cs * b; }
             }
-            if (!rotated) break;
-        }
-        int mi = 0;
-        if (M[4] < M[mi * 4]) mi = 1;
-        if (M[8] < M[mi * 4]) mi = 2;
-        const double v[3] = {W[mi], W[3 + mi], W[6 + mi]};
-        for (int r = 0; r < 3; ++r) {
-            const double fv = Fn[r * 3] * v[0] + Fn[r * 3 + 1] * v[1] + Fn[r * 3 + 2] * v[2];
-            for (int c = 0; c < 3; ++c) Fn[r * 3 + c] -= fv * v[c];
-        }
     }
-    const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
-    const double T2[9] = {s2, 0, -s2 * c2x, 0, s2, -s2 * c2y, 0, 0, 1};
-    double tmp[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) tmp[i * 3 + j] = Fn[i * 3] * T1[j] + Fn[i * 3 + 1] * T1[3 + j] + Fn[i * 3 + 2] * T1[6 + j];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F[i * 3 + j] = T2[i] * tmp[j] + T2[3 + i] * tmp[3 + j] + T2[6 + i] * tmp[6 + j];
-    bool finite = true;
-    for (int e = 0; e < 9; ++e) finite = finite && (F[e] == F[e]) && std::fabs(F[e]) < 1e300;
-    return finite && !degenerate;
+    int i2 = 0, i1 = -1;                                   // i2: smallest eigenvalue, i1: second smallest
+    for (int c = 1; c < 9; ++c) if (AtA[c * 10] < AtA[i2 * 10]) i2 = c;
+    for (int c = 0; c < 9; ++c) if (c != i2 && (i1 < 0 || AtA[c * 10] < AtA[i1 * 10])) i1 = c;
+    double f1[9], f2[9];
+    for (int e = 0; e < 9; ++e) { f1[e] = V[e * 9 + i1]; f2[e] = V[e * 9 + i2]; }
+    for (int e = 0; e < 9; ++e) f1[e] -= f2[e];
+    double c[4];
+    double t0 = f2[4] * f2[8] - f2[5] * f2[7], t1 = f2[3] * f2[8] - f2[5] * f2[6], t2 = f2[3] * f2[7] - f2[4] * f2[6];
+    c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+    c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) + f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) -
+           f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) + f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+           f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+    t0 = f1[4] * f1[8] - f1[5] * f1[7]; t1 = f1[3] * f1[8] - f1[5] * f1[6]; t2 = f1[3] * f1[7] - f1[4] * f1[6];
+    c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+    c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) + f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) -
+           f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) + f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+           f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+    double r[3];
+    const int nr = fr_solve_cubic(c, r);
+    if (nr < 1 || nr > 3) return 0;
+    int nm = 0;
+    for (int k = 0; k < nr; ++k) {
+        double lambda = r[k], mu = 1.0;
+        const double sc = f1[8] * r[k] + f2[8];
+        double* F = models + 9 * nm;
+        if (std::fabs(sc) > 2.220446049250313e-16) { mu = 1.0 / sc; lambda *= mu; F[8] = 1.0; } else F[8] = 0.0;
+        for (int e = 0; e < 8; ++e) F[e] = f1[e] * lambda + f2[e] * mu;
+        bool finite = true;
+        for (int e = 0; e < 9; ++e) finite = finite && (F[e] == F[e]) && std::fabs(F[e]) < 1e300;
+        if (finite) ++nm;
+    }
+    return nm;
+}
+// canonical comparison of two models of one sample (scale- and sign-free): by the entries of F / (its entry of largest magnitude)
+static bool fr_model_before(const double* Fa, const double* Fb) {
+    double ma = 0, mb = 0;
+    for (int e = 0; e < 9; ++e) { if (std::fabs(Fa[e]) > std::fabs(ma)) ma = Fa[e]; if (std::fabs(Fb[e]) > std::fabs(mb)) mb = Fb[e]; }
+    for (int e = 0; e < 9; ++e) {
+        const double va = ma != 0 ? Fa[e] / ma : Fa[e], vb = mb != 0 ? Fb[e] / mb : Fb[e];
+        if (std::fabs(va - vb) > 1e-6) return va < vb;
+    }
+    return false;
+}
+static int fr_update_iters(double p, double ep, int model_points, int max_iters) {      // RANSACUpdateNumIters
+    p = std::max(p, 0.0); p = std::min(p, 1.0);
+    ep = std::max(ep, 0.0); ep = std::min(ep, 1.0);
+    double num = std::max(1.0 - p, 2.2250738585072014e-308);
+    double denom = 1.0 - std::pow(1.0 - ep, model_points);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = std::log(num); denom = std::log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::nearbyint(num / denom);
 }
 
 int oracle_fe_reject_with_f(const float* p1, const float* p2, int n, double threshold, uint8_t* status, double* F_out) {
-    const float thresh2 = (float)(threshold * threshold);
-    int bestk = -1, bestc = -1;
     double bestF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < 256; ++k) {
-        double F[9];
-        if (!fr_hypothesis(k, p1, p2, n, F)) continue;
-        int cnt = 0;
-        for (int i = 0; i < n; ++i) cnt += fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2 ? 1 : 0;
-        if (cnt > bestc) { bestc = cnt; bestk = k; memcpy(bestF, F, sizeof(F)); }
+    bool have = false;
+    int ninl = 0;
+    std::vector<float> err(n), srt(n);
+    CvRng rng((unsigned long long)-1);
+    if (n >= 15) {
+        const float t2 = (float)(threshold * threshold);
+        int niters = 1000, max_good = 0;
+        for (int iter = 0; iter < niters; ++iter) {
+            int idx[7];
+            if (!fr_get_subset(rng, p1, p2, n, idx, 10000)) break;
+            double models[27];
+            const int nm = fr_seven_point(p1, p2, idx, models);
+            int bm = -1, bgood = -1;
+            for (int m = 0; m < nm; ++m) {
+                int good = 0;
+                for (int i = 0; i < n; ++i) good += fr_error(models + 9 * m, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= t2 ? 1 : 0;
+                if (good > bgood || (good == bgood && fr_model_before(models + 9 * m, models + 9 * bm))) { bgood = good; bm = m; }
+            }
+            if (bm >= 0 && bgood > std::max(max_good, 6)) {
+                memcpy(bestF, models + 9 * bm, sizeof(bestF));
+                have = true;
+                max_good = bgood;
+                niters = fr_update_iters(0.99, (double)(n - bgood) / n, 7, niters);
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            status[i] = (!have || fr_error(bestF, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= t2) ? 1 : 0;
+            ninl += status[i];
+        }
+    } else {
+        int niters = std::max(fr_update_iters(0.99, 0.45, 7, 1000), 3);
+        double min_median = 1.7976931348623157e308;
+        for (int iter = 0; iter < niters; ++iter) {
+            int idx[7];
+            if (!fr_get_subset(rng, p1, p2, n, idx, 1000)) break;      // (LMeDS: getSubset's default maxAttempts)
+            double models[27];
+            const int nm = fr_seven_point(p1, p2, idx, models);
+            int bm = -1;
+            double bmed = 0.0;
+            for (int m = 0; m < nm; ++m) {
+                for (int i = 0; i < n; ++i) srt[i] = fr_error(models + 9 * m, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+                std::sort(srt.begin(), srt.end());
+                double med = n % 2 != 0 ? (double)srt[n / 2] : (double)(srt[n / 2 - 1] + srt[n / 2]) * 0.5;
+                if (!(med == med)) continue;
+                // (n <= 13: the median of a model that fits its 7 sample points exactly lies inside the fitted set and is rounding
+                //  noise, 1e-20 .. 1e-30 px^2; such medians are snapped to zero so that the FIRST such sample wins instead of noise)
+                if (med < 1e-12) med = 0.0;
+                if (bm < 0 || med < bmed || (med == bmed && fr_model_before(models + 9 * m, models + 9 * bm))) { bmed = med; bm = m; }
+            }
+            if (bm >= 0 && bmed < min_median) { min_median = bmed; memcpy(bestF, models + 9 * bm, sizeof(bestF)); have = true; }
+        }
+        double sigma = 0.0;
+        if (have) {
+            sigma = 2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * std::sqrt(min_median);
+            sigma = std::max(sigma, 0.001);
+        }
+        const float t2 = (float)(sigma * sigma);
+        for (int i = 0; i < n; ++i) {
+            status[i] = (!have || fr_error(bestF, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= t2) ? 1 : 0;
+            ninl += status[i];
+        }
+        if (have && ninl < 7) {                       // LMedS reports failure below modelPoints inliers
+            for (int i = 0; i < n; ++i) status[i] = 1;
+            ninl = n; have = false;
+            for (int e = 0; e < 9; ++e) bestF[e] = 0.0;
+        }
     }
-    // no usable hypothesis: nothing is rejected (the same documented choice as the product, ASSUMPTIONS.md F9)
-    for (int i = 0; i < n; ++i)
-        status[i] = (bestk < 0 || fr_error(bestF, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2) ? 1 : 0;
     if (F_out) memcpy(F_out, bestF, sizeof(bestF));
-    return bestk >= 0 ? bestc : n;
+    return ninl;
 }
 
 }  // extern "C"

@@ -268,15 +268,18 @@ def test_tiny_levels(handle):
     _check_lk(tr, 0, a, b, edge)
 
 
-@pytest.mark.parametrize("seed", [3, 4, 5])
-def test_reject_with_f_matches_restatement(handle, seed):
-    """SURVEY 8(f) row 3: FeatureTracker::rejectWithF's findFundamentalMat(FM_RANSAC) as a deterministic device RANSAC;
-    inlier mask identical to the CPU restatement, model equal to rounding, gross outliers rejected."""
+@pytest.mark.parametrize("seed,n,n_out", [(3, 120, 25), (4, 120, 25), (5, 120, 25), (6, 150, 60), (7, 20, 3), (8, 14, 2), (9, 12, 2), (10, 9, 0)])
+def test_reject_with_f_matches_restatement(handle, seed, n, n_out):
+    """SURVEY 8(f) row 3: FeatureTracker::rejectWithF's findFundamentalMat(FM_RANSAC) after OpenCV's registrators — the host draws
+    cv::RNG's sample schedule, the device solves every 7-point sample, the host replays the sequential bookkeeping (adaptive
+    iteration bound).  Inlier mask identical to the sequential CPU restatement, model equal to rounding; RANSAC for n >= 15,
+    LMedS below (n = 14: a meaningful median; n <= 13: the first sample wins, ASSUMPTIONS F9)."""
     from test_fe_oracle import _two_view
-    p1, p2, out = _two_view(seed)
+    p1, p2, out = _two_view(seed, n=n, n_out=n_out)
     tr = fe.FrontEnd(handle, 752, 480, 1, 150)
     st_g, F_g = tr.reject_with_f(p1, p2, 1.0)
     st_o, F_o = F.reject_with_f(p1, p2, 1.0)
     assert np.array_equal(st_g, st_o)
-    assert np.abs(F_g - F_o).max() < 1e-9 * np.abs(F_o).max()
-    assert st_g[out].sum() <= 1 and st_g[~out].mean() > 0.9
+    assert np.abs(F_g - F_o).max() < 1e-6 * np.abs(F_o).max()
+    if n >= 15:
+        assert st_g[out].sum() <= 1 and st_g[~out].mean() > 0.8

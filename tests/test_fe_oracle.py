@@ -107,3 +107,25 @@ def test_reject_with_f_restatement_rejects_outliers_and_is_deterministic():
     l = h1 @ Fm.T
     d = np.abs((h2 * l).sum(1)) / np.hypot(l[:, 0], l[:, 1])
     assert np.median(d) < 0.5
+
+
+def test_reject_with_f_small_sets_take_the_lmeds_branch():
+    """cv::findFundamentalMat runs RANSAC only from 15 points on; below, FM_RANSAC silently becomes LMedS (fundam.cpp).  A model
+    from 7 points fits them exactly, so with at most 14 points the median error is (close to) zero and the inlier band
+    2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median) is tight: the estimator keeps its sample and little else.  That is the
+    behaviour being restated, not a defect of the restatement; what is asserted is determinism and the >= 7 inliers LMedS needs
+    to report success."""
+    for seed in (8, 9, 13):
+        p1, p2, out = _two_view(seed, n=14, n_out=2)
+        st, Fm = C.reject_with_f(p1, p2, 1.0)
+        assert 7 <= st.sum() < 14 and st[out].sum() <= 1
+        st2, _ = C.reject_with_f(p1, p2, 1.0)
+        assert np.array_equal(st, st2)
+
+
+def test_reject_with_f_clean_pairs_keep_everything():
+    """No outliers: every correspondence is an inlier of the best model and the adaptive iteration bound ends the loop early
+    (the result is the first model whose support is complete)."""
+    p1, p2, out = _two_view(12, n=100, n_out=0)
+    st, Fm = C.reject_with_f(p1, p2, 1.0)
+    assert st.mean() > 0.85                           # (no refit: the first sufficiently supported 7-point model wins)

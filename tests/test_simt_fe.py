@@ -45,3 +45,31 @@ def test_emulated_lk_is_bit_exact_in_every_fiber_order(order):
     env = dict(os.environ, SIMT_ORDER=order)
     r = subprocess.run([sys.executable, "-c", _CHILD % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_CHILD_F = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+import conftest
+from oracle import fe_cpu as F
+from vins_mono_amd import fe
+from test_fe_oracle import _two_view
+h = conftest._simt_handle()
+tr = fe.FrontEnd(h, 64, 64, 1, 8)
+for seed, n, n_out in ((3, 60, 8), (5, 40, 0), (8, 12, 2), (9, 9, 0)):       # n >= 15: RANSAC; n < 15: LMedS
+    p1, p2, out = _two_view(seed, n=n, n_out=n_out)
+    st_g, F_g = tr.reject_with_f(p1, p2, 1.0)
+    st_o, F_o = F.reject_with_f(p1, p2, 1.0)
+    assert np.array_equal(st_g, st_o), (seed, st_g, st_o)
+    s = np.abs(F_o).max()
+    assert np.abs(F_g - F_o).max() < 1e-6 * s, (seed, F_g, F_o)
+print("OK")
+"""
+
+
+def test_emulated_reject_with_f_matches_restatement():
+    """vg_fe_reject_with_f (host schedule + fe_ransac7_kernel + host bookkeeping) against the sequential restatement of
+    OpenCV's loop: same inlier mask, same model — RANSAC for n >= 15, LMedS below."""
+    r = subprocess.run([sys.executable, "-c", _CHILD_F % dict(root=ROOT)], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1,46 +1,35 @@
 // fe_ransac.hip — FeatureTracker::rejectWithF (feature_tracker/src/feature_tracker.cpp:169-202) on gfx950:
 // cv::findFundamentalMat(un_cur_pts, un_forw_pts, cv::FM_RANSAC, F_THRESHOLD, 0.99, status)  (SURVEY.md 8(f) row 3).
 //
-// What is kept from OpenCV's RANSACPointSetRegistrator + FMEstimatorCallback ([3P], fundam.cpp / ptsetreg.cpp):
-//   * the per-point error  max(d1^2 / |l1|^2, d2^2 / |l2|^2)  of the two point-to-epipolar-line distances, evaluated in
-//     double, cast to float and compared with threshold^2;  the model with the most inliers wins (first one on ties);
-//     the returned mask is the inlier set of that model (no final refit);
-//   * Hartley normalisation of the sampled points, the linear solve for f as the null vector of the 9-column design
-//     matrix, the rank-2 projection of F.
-// What is NOT reproducible and is replaced, documented in oracle/ASSUMPTIONS.md (F9): OpenCV draws its samples from
-// cv::RNG(-1) with an adaptive iteration count and solves 7-point cubics; here FE_RANSAC_HYP = 256 hypotheses are drawn
-// by a counter-based generator (so the result is a pure function of the input), each from 8 points with the normalised
-// 8-point algorithm.  All hypotheses run in parallel, one thread each: the 8 x 9 design matrix and the accumulated right
-// singular vectors live in thread-private LDS columns ([element][thread], conflict-free), the null vector comes from a
-// one-sided Jacobi SVD (as in triangulate.hip).
+// Follows OpenCV 3.3's RANSACPointSetRegistrator / LMeDSPointSetRegistrator + FMEstimatorCallback ([3P], fundam.cpp /
+// ptsetreg.cpp, as recalled: oracle/ASSUMPTIONS.md F9 lists what is matched and what cannot be):
+//   * the SAMPLE SCHEDULE is what OpenCV's sequential loop would draw: cv::RNG((uint64)-1), seven distinct rng.uniform(0, n)
+//     indices per iteration, redrawn while the last point of a sample is collinear with two earlier ones.  It depends on
+//     the points only, not on any model, so the host generates all of it up front (maxIters = 1000 iterations) ...
+//   * ... and the device evaluates every iteration in parallel, one thread each: run7Point (null space of the 7 x 9 design
+//     matrix of the raw points by one-sided Jacobi, the cubic det(x G + H) = 0 by cv::solveCubic, up to three models scaled
+//     to F33 = 1), per model the inlier count (n >= 15: error max(d1^2/|l1|^2, d2^2/|l2|^2) as float <= threshold^2) or the
+//     median error (8 <= n < 15: OpenCV falls back to LMedS there);
+//   * the host then replays the sequential bookkeeping over the per-iteration results: a model replaces the best one if it
+//     has more inliers than max(best, 6), after every improvement niters = RANSACUpdateNumIters(0.99, outlier ratio, 7,
+//     niters), and iterations at or beyond niters do not count — the same model OpenCV's loop ends with;
+//   * the mask is the inlier set of that model (LMedS: error <= (2.5 * 1.4826 (1 + 5 / (n - 7)) sqrt(median))^2).
+// The models of one sample are ranked best first with a canonical tie order (OpenCV's visiting order follows the basis its
+// SVD returns for the two-dimensional null space).  The null vectors live in thread-private LDS columns
+// ([element][thread], conflict-free).
 #include "vg_range.h"
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 #include "ba_math.h"
 #include "vg_handle.h"
 #include "../../include/vinsgpu.h"
 
-#define FE_RANSAC_HYP 256
+#define FE_RANSAC_MAXIT 1000
 #define FE_RANSAC_MAXPTS 1024
-
-// counter-based generator: hash of (hypothesis, draw) — SplitMix64 finaliser
-DEV unsigned long long fr_mix(unsigned long long z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-// 8 distinct indices in [0, n), n >= 8: draw d = 0, 1, ... of hypothesis k, skipping repeats
-DEV void fr_sample(int k, int n, int* idx) {
-    int have = 0;
-    for (unsigned d = 0; have < 8; ++d) {
-        const int c = (int)(fr_mix(((unsigned long long)(unsigned)k << 32) | d) % (unsigned long long)n);
-        bool dup = false;
-        for (int q = 0; q < have; ++q) dup = dup || idx[q] == c;
-        if (!dup) idx[have++] = c;
-    }
-}
+#define FE_LMEDS_MAXPTS 14
 
 // error of correspondence (x1,y1) -> (x2,y2) under F (row-major 3x3), FMEstimatorCallback::computeError
 DEV float fr_error(const double* f, double x1, double y1, double x2, double y2) {
@@ -52,46 +41,82 @@ DEV float fr_error(const double* f, double x1, double y1, double x2, double y2) 
     return (float)(e1 > e2 ? e1 : e2);
 }
 
-// hypotheses: F[k][9] and its inlier count
-extern "C" __global__ __launch_bounds__(64) void fe_ransac_hyp_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n,
-                                                                      float thresh2, double* __restrict__ Fout, int* __restrict__ count) {
-    __shared__ double A[72][64];          // design matrix, element (row r, col c) at A[r * 9 + c][thread]
+// cv::solveCubic for c0 x^3 + c1 x^2 + c2 x + c3 (the branch structure of OpenCV 3.3)
+DEV int fr_solve_cubic(const double* cf, double* r) {
+    double a0 = cf[0], a1 = cf[1], a2 = cf[2], a3 = cf[3];
+    if (a0 == 0) {
+        if (a1 == 0) {
+            if (a2 == 0) return a3 == 0 ? -1 : 0;
+            r[0] = -a3 / a2;
+            return 1;
+        }
+        double d = a2 * a2 - 4 * a1 * a3;
+        if (d < 0) return 0;
+        d = sqrt(d);
+        const double q1 = (-a2 + d) * 0.5, q2 = (a2 + d) * -0.5;
+        if (fabs(q1) > fabs(q2)) { r[0] = q1 / a1; r[1] = a3 / q1; } else { r[0] = q2 / a1; r[1] = a3 / q2; }
+        return d > 0 ? 2 : 1;
+    }
+    a0 = 1.0 / a0; a1 *= a0; a2 *= a0; a3 *= a0;
+    const double Q = (a1 * a1 - 3 * a2) * (1.0 / 9), R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1.0 / 54);
+    const double Qcubed = Q * Q * Q;
+    double d = Qcubed - R * R;
+    if (d >= 0) {
+        const double theta = acos(R / sqrt(Qcubed)), sqrtQ = sqrt(Q);
+        const double t0 = -2 * sqrtQ, t1 = theta * (1.0 / 3), t2 = a1 * (1.0 / 3);
+        r[0] = t0 * cos(t1) - t2;
+        r[1] = t0 * cos(t1 + (2.0 * 3.1415926535897932384626433832795 / 3)) - t2;
+        r[2] = t0 * cos(t1 + (4.0 * 3.1415926535897932384626433832795 / 3)) - t2;
+        return 3;
+    }
+    d = sqrt(-d);
+    double e = pow(d + fabs(R), 0.333333333333);
+    if (R > 0) e = -e;
+    r[0] = (e + Q / e) - a1 * (1.0 / 3);
+    return 1;
+}
+// canonical order of two models of one sample (scale- and sign-free): entries of F / (its entry of largest magnitude)
+DEV bool fr_model_before(const double* Fa, const double* Fb) {
+    double ma = 0, mb = 0;
+    for (int e = 0; e < 9; ++e) { if (fabs(Fa[e]) > fabs(ma)) ma = Fa[e]; if (fabs(Fb[e]) > fabs(mb)) mb = Fb[e]; }
+    for (int e = 0; e < 9; ++e) {
+        const double va = ma != 0 ? Fa[e] / ma : Fa[e], vb = mb != 0 ? Fb[e] / mb : Fb[e];
+        if (fabs(va - vb) > 1e-6) return va < vb;
+    }
+    return false;
+}
+
+// One iteration of the schedule per thread: the best model of its sample (F[k][9]) and that model's inlier count (lmeds == 0)
+// or median error (lmeds != 0, n <= FE_LMEDS_MAXPTS); count -1 = the sample gave no model.
+extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n,
+                                                                   float thresh2, int lmeds, const int* __restrict__ sched, int nsched,
+                                                                   double* __restrict__ Fout, int* __restrict__ count,
+                                                                   double* __restrict__ median) {
+    __shared__ double A[63][64];          // design matrix, element (row r, col c) at A[r * 9 + c][thread]
     __shared__ double V[81][64];          // accumulated right singular vectors
     const int t = threadIdx.x, k = blockIdx.x * 64 + t;
-    int idx[8];
-    fr_sample(k, n, idx);
-    // Hartley normalisation of the 8 sampled points of each image
-    double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
-    for (int i = 0; i < 8; ++i) { c1x += p1[2 * idx[i]]; c1y += p1[2 * idx[i] + 1]; c2x += p2[2 * idx[i]]; c2y += p2[2 * idx[i] + 1]; }
-    c1x /= 8; c1y /= 8; c2x /= 8; c2y /= 8;
-    double s1 = 0, s2 = 0;
-    for (int i = 0; i < 8; ++i) {
-        const double ax = p1[2 * idx[i]] - c1x, ay = p1[2 * idx[i] + 1] - c1y, bx = p2[2 * idx[i]] - c2x, by = p2[2 * idx[i] + 1] - c2y;
-        s1 += sqrt(ax * ax + ay * ay); s2 += sqrt(bx * bx + by * by);
-    }
-    bool degenerate = !(s1 > 1e-12) || !(s2 > 1e-12);
-    s1 = degenerate ? 1.0 : 8.0 * 1.4142135623730951 / s1;
-    s2 = degenerate ? 1.0 : 8.0 * 1.4142135623730951 / s2;
-    for (int i = 0; i < 8; ++i) {
-        const double x1 = (p1[2 * idx[i]] - c1x) * s1, y1 = (p1[2 * idx[i] + 1] - c1y) * s1;
-        const double x2 = (p2[2 * idx[i]] - c2x) * s2, y2 = (p2[2 * idx[i] + 1] - c2y) * s2;
-        const double row[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+    const bool live = k < nsched;
+    int idx[7];
+    for (int i = 0; i < 7; ++i) idx[i] = live ? sched[(size_t)k * 7 + i] : i;
+    for (int i = 0; i < 7; ++i) {
+        const double x0 = p1[2 * idx[i]], y0 = p1[2 * idx[i] + 1], x1 = p2[2 * idx[i]], y1 = p2[2 * idx[i] + 1];
+        const double row[9] = {x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1.0};
         for (int c = 0; c < 9; ++c) A[i * 9 + c][t] = row[c];
     }
     for (int e = 0; e < 81; ++e) V[e][t] = (e % 10 == 0) ? 1.0 : 0.0;
-    // one-sided Jacobi on the 9 columns: A V = U Sigma; the column that ends with the smallest norm spans the null space
-    for (int sweep = 0; sweep < 30; ++sweep) {
+    // one-sided Jacobi on the 9 columns: A V = U Sigma; the two columns that end with the smallest norms span the null space
+    for (int sweep = 0; sweep < 40; ++sweep) {
         bool rotated = false;
         for (int p = 0; p < 8; ++p)
             for (int q = p + 1; q < 9; ++q) {
                 double al = 0.0, be = 0.0, ga = 0.0;
-                for (int r = 0; r < 8; ++r) { const double a = A[r * 9 + p][t], b = A[r * 9 + q][t]; al += a * a; be += b * b; ga += a * b; }
+                for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + p][t], b = A[r * 9 + q][t]; al += a * a; be += b * b; ga += a * b; }
                 if (fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
                     rotated = true;
                     const double zeta = (be - al) / (2.0 * ga);
                     const double tn = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                     const double cs = 1.0 / sqrt(1.0 + tn * tn), sn = cs * tn;
-                    for (int r = 0; r < 8; ++r) {
+                    for (int r = 0; r < 7; ++r) {
                         const double a = A[r * 9 + p][t], b = A[r * 9 + q][t];
                         A[r * 9 + p][t] = cs * a - sn * b; A[r * 9 + q][t] = sn * a + cs * b;
                     }
@@ -103,97 +128,149 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac_hyp_kernel(const floa
             }
         if (!rotated) break;
     }
-    int bi = 0;
-    double best = 0.0;
-    for (int c = 0; c < 9; ++c) {
-        double nn = 0.0;
-        for (int r = 0; r < 8; ++r) { const double a = A[r * 9 + c][t]; nn += a * a; }
-        if (c == 0 || nn < best) { best = nn; bi = c; }
-    }
-    double Fn[9];
-    for (int e = 0; e < 9; ++e) Fn[e] = V[e * 9 + bi][t];
-    // rank 2: F <- F (I - v3 v3^T), v3 = right singular vector of the smallest singular value = eigenvector of F^T F
+    int i2 = 0, i1 = -1;                                  // i2: smallest column norm, i1: second smallest
     {
-        double M[9], W[9];
-        m3t_mul(Fn, Fn, M);                                   // F^T F
-        for (int e = 0; e < 9; ++e) W[e] = (e % 4 == 0) ? 1.0 : 0.0;
-        for (int sweep = 0; sweep < 30; ++sweep) {            // cyclic two-sided Jacobi on the symmetric 3x3
-            double off = fabs(M[1]) + fabs(M[2]) + fabs(M[5]);
-            if (!(off > 1e-300)) break;
-            bool rotated = false;
-#pragma unroll
-            for (int pq = 0; pq < 3; ++pq) {
-                const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
-                const double apq = M[p * 3 + q];
-                if (fabs(apq) <= 1e-17 * sqrt(fabs(M[p * 4] * M[q * 4])) || apq == 0.0) continue;
-                rotated = true;
-                const double th = (M[q * 4] - M[p * 4]) / (2.0 * apq);
-                const double tn = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(1.0 + th * th));
-                const double cs = 1.0 / sqrt(1.0 + tn * tn), sn = cs * tn;
-                for (int r = 0; r < 3; ++r) {                 // M <- M J
-                    const double a = M[r * 3 + p], b = M[r * 3 + q];
-                    M[r * 3 + p] = cs * a - sn * b; M[r * 3 + q] = sn * a + cs * b;
-                }
-                for (int r = 0; r < 3; ++r) {                 // M <- J^T M
-                    const double a = M[p * 3 + r], b = M[q * 3 + r];
-                    M[p * 3 + r] = cs * a - sn * b; M[q * 3 + r] = sn * a + cs * b;
-                }
-                for (int r = 0; r < 3; ++r) {
-                    const double a = W[r * 3 + p], b = W[r * 3 + q];
-                    W[r * 3 + p] = cs * a - sn * b; W[r * 3 + q] = sn * a + cs * b;
-                }
+        double n2 = 0.0, n1 = 0.0;
+        for (int c = 0; c < 9; ++c) {
+            double nn = 0.0;
+            for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + c][t]; nn += a * a; }
+            if (c == 0 || nn < n2) { n2 = nn; i2 = c; }
+        }
+        for (int c = 0; c < 9; ++c) {
+            if (c == i2) continue;
+            double nn = 0.0;
+            for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + c][t]; nn += a * a; }
+            if (i1 < 0 || nn < n1) { n1 = nn; i1 = c; }
+        }
+    }
+    double f1[9], f2[9];
+    for (int e = 0; e < 9; ++e) { f2[e] = V[e * 9 + i2][t]; f1[e] = V[e * 9 + i1][t] - f2[e]; }
+    double cf[4];
+    {
+        double t0 = f2[4] * f2[8] - f2[5] * f2[7], t1 = f2[3] * f2[8] - f2[5] * f2[6], t2 = f2[3] * f2[7] - f2[4] * f2[6];
+        cf[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+        cf[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) + f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) -
+                f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) + f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+                f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+        t0 = f1[4] * f1[8] - f1[5] * f1[7]; t1 = f1[3] * f1[8] - f1[5] * f1[6]; t2 = f1[3] * f1[7] - f1[4] * f1[6];
+        cf[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+        cf[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) + f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) -
+                f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) + f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+                f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+    }
+    double roots[3] = {0, 0, 0};
+    const int nr = fr_solve_cubic(cf, roots);
+    double bestF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int bgood = -1;
+    double bmed = 0.0;
+    bool have = false;
+    for (int m = 0; m < 3; ++m) {
+        if (!(nr >= 1 && nr <= 3) || m >= nr) continue;
+        double F[9];
+        double lambda = roots[m], mu = 1.0;
+        const double sc = f1[8] * roots[m] + f2[8];
+        if (fabs(sc) > 2.220446049250313e-16) { mu = 1.0 / sc; lambda *= mu; F[8] = 1.0; } else F[8] = 0.0;
+        for (int e = 0; e < 8; ++e) F[e] = f1[e] * lambda + f2[e] * mu;
+        bool finite = true;
+        for (int e = 0; e < 9; ++e) finite = finite && (F[e] == F[e]) && fabs(F[e]) < 1e300;
+        if (!finite) continue;
+        if (!lmeds) {
+            int good = 0;
+            for (int i = 0; i < n; ++i) good += fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2 ? 1 : 0;
+            if (!have || good > bgood || (good == bgood && fr_model_before(F, bestF))) {
+                bgood = good; have = true;
+                for (int e = 0; e < 9; ++e) bestF[e] = F[e];
             }
-            if (!rotated) break;
-        }
-        int mi = 0;
-        if (M[4] < M[mi * 4]) mi = 1;
-        if (M[8] < M[mi * 4]) mi = 2;
-        const double v[3] = {W[mi], W[3 + mi], W[6 + mi]};
-        for (int r = 0; r < 3; ++r) {
-            const double fv = Fn[r * 3] * v[0] + Fn[r * 3 + 1] * v[1] + Fn[r * 3 + 2] * v[2];
-            for (int c = 0; c < 3; ++c) Fn[r * 3 + c] -= fv * v[c];
+        } else {
+            float er[FE_LMEDS_MAXPTS];
+            for (int i = 0; i < FE_LMEDS_MAXPTS; ++i) er[i] = i < n ? fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) : 3.0e38f;
+            bool nan = false;
+            for (int i = 0; i < FE_LMEDS_MAXPTS; ++i) nan = nan || (i < n && !(er[i] == er[i]));
+            // selection by rank (no dynamically indexed sort of a register array): median = element(s) of rank n/2 (and n/2 - 1)
+            float lo = 0.f, hi = 0.f;
+            for (int i = 0; i < FE_LMEDS_MAXPTS; ++i) {
+                if (i >= n) continue;
+                int rk = 0;
+                for (int j = 0; j < FE_LMEDS_MAXPTS; ++j) rk += (j < n && (er[j] < er[i] || (er[j] == er[i] && j < i))) ? 1 : 0;
+                if (rk == n / 2) hi = er[i];
+                if (rk == n / 2 - 1) lo = er[i];
+            }
+            double med = (n & 1) ? (double)hi : (double)(lo + hi) * 0.5;
+            if (nan) continue;
+            // (n <= 13: the median of a model that fits its 7 sample points exactly lies inside the fitted set and is rounding noise;
+            //  snapped to zero so that the FIRST such sample wins instead of noise: oracle/ASSUMPTIONS.md F9)
+            if (med < 1e-12) med = 0.0;
+            if (!have || med < bmed || (med == bmed && fr_model_before(F, bestF))) {
+                bmed = med; have = true; bgood = 0;
+                for (int e = 0; e < 9; ++e) bestF[e] = F[e];
+            }
         }
     }
-    // de-normalise: F = T2^T Fn T1,  T = [s 0 -s cx; 0 s -s cy; 0 0 1]
-    double F[9];
-    {
-        const double T1[9] = {s1, 0, -s1 * c1x, 0, s1, -s1 * c1y, 0, 0, 1};
-        const double T2[9] = {s2, 0, -s2 * c2x, 0, s2, -s2 * c2y, 0, 0, 1};
-        double tmp[9];
-        m3_mul(Fn, T1, tmp);
-        m3t_mul(T2, tmp, F);
+    if (live) {
+        for (int e = 0; e < 9; ++e) Fout[(size_t)k * 9 + e] = bestF[e];
+        count[k] = have ? bgood : -1;
+        median[k] = bmed;
     }
-    int cnt = 0;
-    bool finite = true;
-    for (int e = 0; e < 9; ++e) finite = finite && (F[e] == F[e]) && fabs(F[e]) < 1e300;
-    if (finite && !degenerate)
-        for (int i = 0; i < n; ++i) cnt += fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2 ? 1 : 0;
-    for (int e = 0; e < 9; ++e) Fout[(size_t)k * 9 + e] = F[e];
-    count[k] = (finite && !degenerate) ? cnt : -1;
 }
 
-// best hypothesis (most inliers, lowest index on ties) and its inlier mask
-extern "C" __global__ __launch_bounds__(FE_RANSAC_HYP) void fe_ransac_pick_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n,
-                                                                                 float thresh2, const double* __restrict__ Fall,
-                                                                                 const int* __restrict__ count, unsigned char* __restrict__ status,
-                                                                                 int* __restrict__ out) {
-    __shared__ int key[FE_RANSAC_HYP];
+// inlier mask of model F[sel] against thresh2
+extern "C" __global__ __launch_bounds__(256) void fe_ransac_mask_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n, float thresh2,
+                                                                       const double* __restrict__ Fall, int sel, unsigned char* __restrict__ status) {
     __shared__ double F[9];
-    const int t = threadIdx.x;
-    key[t] = count[t] * FE_RANSAC_HYP + (FE_RANSAC_HYP - 1 - t);          // max key = most inliers, then the lowest index
+    if (threadIdx.x < 9) F[threadIdx.x] = Fall[(size_t)sel * 9 + threadIdx.x];
     __syncthreads();
-    for (int s = FE_RANSAC_HYP / 2; s > 0; s >>= 1) {
-        if (t < s) key[t] = key[t] > key[t + s] ? key[t] : key[t + s];
-        __syncthreads();
-    }
-    const int bestk = FE_RANSAC_HYP - 1 - (key[0] % FE_RANSAC_HYP + FE_RANSAC_HYP) % FE_RANSAC_HYP;
-    const bool any = key[0] >= 0;
-    if (t < 9) F[t] = Fall[(size_t)bestk * 9 + t];
-    __syncthreads();
-    for (int i = t; i < n; i += FE_RANSAC_HYP)
-        status[i] = (any && fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2) ? 1 : 0;
-    if (t == 0) { out[0] = any ? bestk : -1; out[1] = any ? count[bestk] : 0; }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) status[i] = fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2 ? 1 : 0;
 }
+
+// ---- host side: OpenCV's sample schedule and its sequential bookkeeping --------------------------------------------------
+namespace {
+struct CvRng {                                        // cv::RNG
+    unsigned long long state;
+    explicit CvRng(unsigned long long s) : state(s ? s : 0xffffffffull) {}
+    unsigned next() { state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32); return (unsigned)state; }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+// haveCollinearPoints(): is the LAST point of the sample collinear with two earlier ones
+bool last_point_collinear(const float* p, const int* idx, int count) {
+    const int i = count - 1;
+    for (int j = 0; j < i; ++j) {
+        const double dx1 = (double)p[2 * idx[j]] - p[2 * idx[i]], dy1 = (double)p[2 * idx[j] + 1] - p[2 * idx[i] + 1];
+        for (int k = 0; k < j; ++k) {
+            const double dx2 = (double)p[2 * idx[k]] - p[2 * idx[i]], dy2 = (double)p[2 * idx[k] + 1] - p[2 * idx[i] + 1];
+            if (std::fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2))) return true;
+        }
+    }
+    return false;
+}
+// PointSetRegistrator getSubset() (checkPartialSubsets == false)
+bool get_subset(CvRng& rng, const float* p1, const float* p2, int n, int* idx, int max_attempts) {
+    int iters = 0, i = 0;
+    for (; iters < max_attempts; ++iters) {
+        for (i = 0; i < 7 && iters < max_attempts;) {
+            for (;;) {
+                const int c = idx[i] = rng.uniform(0, n);
+                int j = 0;
+                for (; j < i; ++j) if (c == idx[j]) break;
+                if (j == i) break;
+            }
+            ++i;
+        }
+        if (i == 7 && (last_point_collinear(p1, idx, 7) || last_point_collinear(p2, idx, 7))) continue;
+        break;
+    }
+    return i == 7 && iters < max_attempts;
+}
+int update_num_iters(double p, double ep, int model_points, int max_iters) {         // RANSACUpdateNumIters
+    p = std::min(std::max(p, 0.0), 1.0);
+    ep = std::min(std::max(ep, 0.0), 1.0);
+    double num = std::max(1.0 - p, 2.2250738585072014e-308);
+    double denom = 1.0 - std::pow(1.0 - ep, model_points);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = std::log(num); denom = std::log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::nearbyint(num / denom);
+}
+}  // namespace
 
 extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const float* forw_un_xy, int n, double threshold, uint8_t* status,
                                    int* n_inliers, double* F_out) {
@@ -207,36 +284,83 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
         return VG_ERR_HIP;
     };
     if (e != hipSuccess) return fail(e);
+    // the schedule: what OpenCV's loop would draw in its first maxIters iterations (it depends on the points only)
+    const bool lmeds = n < 15;                         // findFundamentalMat: RANSAC needs 15 points, LMedS otherwise
+    const int maxit = lmeds ? std::max(update_num_iters(0.99, 0.45, 7, 1000), 3) : FE_RANSAC_MAXIT;
+    std::vector<int> sched((size_t)maxit * 7);
+    int nsched = 0;
+    {
+        CvRng rng((unsigned long long)-1);
+        for (; nsched < maxit; ++nsched)
+            if (!get_subset(rng, cur_un_xy, forw_un_xy, n, sched.data() + (size_t)nsched * 7, lmeds ? 1000 : 10000)) break;
+    }
     // One allocation for the life of the handle (n <= FE_RANSAC_MAXPTS): this call sits on the per-frame path, and hipFree
     // synchronises the whole device — it would stall the BA handle's asynchronous marginalization / state download.
-    const size_t off_F = sizeof(float) * 4 * FE_RANSAC_MAXPTS, off_i = off_F + sizeof(double) * 9 * FE_RANSAC_HYP;
-    const size_t off_s = off_i + sizeof(int) * (FE_RANSAC_HYP + 2 + 2), total = off_s + FE_RANSAC_MAXPTS;
+    const size_t off_F = sizeof(float) * 4 * FE_RANSAC_MAXPTS, off_m = off_F + sizeof(double) * 9 * FE_RANSAC_MAXIT;
+    const size_t off_i = off_m + sizeof(double) * FE_RANSAC_MAXIT, off_sc = off_i + sizeof(int) * FE_RANSAC_MAXIT;
+    const size_t off_s = off_sc + sizeof(int) * 7 * FE_RANSAC_MAXIT, total = off_s + FE_RANSAC_MAXPTS;
     if (!h->ransac_buf && (e = hipMalloc(&h->ransac_buf, total)) != hipSuccess) { h->ransac_buf = nullptr; return fail(e); }
     char* base = (char*)h->ransac_buf;
     float* d_p = (float*)base;
     double* d_F = (double*)(base + off_F);
-    int* d_i = (int*)(base + off_i);
+    double* d_med = (double*)(base + off_m);
+    int* d_cnt = (int*)(base + off_i);
+    int* d_sched = (int*)(base + off_sc);
     unsigned char* d_s = (unsigned char*)(base + off_s);
-    if ((e = hipMemcpyAsync(d_p, cur_un_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpyAsync(d_p + 2 * n, forw_un_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
-    const float thresh2 = (float)(threshold * threshold);
-    hipLaunchKernelGGL(fe_ransac_hyp_kernel, dim3(FE_RANSAC_HYP / 64), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, thresh2, d_F, d_i);
-    hipLaunchKernelGGL(fe_ransac_pick_kernel, dim3(1), dim3(FE_RANSAC_HYP), 0, h->stream, d_p, d_p + 2 * n, n, thresh2, d_F, d_i, d_s, d_i + FE_RANSAC_HYP);
-    if ((e = hipGetLastError()) != hipSuccess) return fail(e);
-    int res[2] = {-1, 0};
-    if ((e = hipMemcpyAsync(status, d_s, n, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpyAsync(res, d_i + FE_RANSAC_HYP, sizeof(res), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
-    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail(e);
-    if (F_out) {
-        if (res[0] >= 0) { if ((e = hipMemcpy(F_out, d_F + (size_t)res[0] * 9, sizeof(double) * 9, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e); }
-        else for (int k = 0; k < 9; ++k) F_out[k] = 0.0;
+    int best = -1, n_in = n;
+    double t2_mask = threshold * threshold;
+    if (nsched > 0) {
+        if ((e = hipMemcpyAsync(d_p, cur_un_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(d_p + 2 * n, forw_un_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(d_sched, sched.data(), sizeof(int) * 7 * nsched, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
+        const float thresh2 = (float)(threshold * threshold);
+        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((nsched + 63) / 64), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, thresh2, lmeds ? 1 : 0, d_sched,
+                           nsched, d_F, d_cnt, d_med);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e);
+        std::vector<int> cnt(nsched);
+        std::vector<double> med(nsched);
+        if ((e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * nsched, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(med.data(), d_med, sizeof(double) * nsched, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
+        if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail(e);
+        // the sequential bookkeeping of the registrator over the per-iteration results
+        if (!lmeds) {
+            int niters = FE_RANSAC_MAXIT, max_good = 0;
+            for (int it = 0; it < nsched && it < niters; ++it) {
+                if (cnt[it] < 0) continue;
+                if (cnt[it] > std::max(max_good, 6)) {
+                    best = it; max_good = cnt[it];
+                    niters = update_num_iters(0.99, (double)(n - cnt[it]) / n, 7, niters);
+                }
+            }
+        } else {
+            double min_median = 1.7976931348623157e308;
+            for (int it = 0; it < nsched; ++it) {
+                if (cnt[it] < 0) continue;
+                if (med[it] < min_median) { min_median = med[it]; best = it; }
+            }
+            if (best >= 0) {
+                const double sigma = std::max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * std::sqrt(min_median), 0.001);
+                t2_mask = sigma * sigma;
+            }
+        }
+        if (best >= 0) {
+            hipLaunchKernelGGL(fe_ransac_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_p, d_p + 2 * n, n, (float)t2_mask, d_F, best, d_s);
+            if ((e = hipGetLastError()) != hipSuccess) return fail(e);
+            if ((e = hipMemcpyAsync(status, d_s, n, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
+            if (F_out && (e = hipMemcpyAsync(F_out, d_F + (size_t)best * 9, sizeof(double) * 9, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
+            if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail(e);
+            n_in = 0;
+            for (int i = 0; i < n; ++i) n_in += status[i];
+            if (lmeds && n_in < 7) best = -1;          // LMeDS reports failure below modelPoints inliers
+        }
     }
-    if (res[0] < 0) {
-        // no usable hypothesis (every sample degenerate or non-finite): the estimate failed, nothing is rejected — the tracks
-        // survive the frame instead of being wiped (documented choice, oracle/ASSUMPTIONS.md F9)
+    if (best < 0) {
+        // no model (no valid sample, no finite solution): the estimate failed, nothing is rejected — the tracks survive the frame
+        // instead of being wiped (documented choice, oracle/ASSUMPTIONS.md F9)
         for (int i = 0; i < n; ++i) status[i] = 1;
-        res[1] = n;
+        n_in = n;
+        if (F_out) for (int k = 0; k < 9; ++k) F_out[k] = 0.0;
     }
-    if (n_inliers) *n_inliers = res[1];
+    if (n_inliers) *n_inliers = n_in;
     return VG_OK;
 }
