@@ -345,6 +345,8 @@ def main():
     ap.add_argument("--windows", type=int, default=WINDOWS_PER_GPU)
     ap.add_argument("--in-flight", type=int, default=2, help="independent batches (HIP streams) the steps are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-mode", choices=["graph", "direct"], default=None,
+                    help="VG_BA_LAUNCH_MODE for every handle of the run (default: the library's, see vg_ba_set_launch_mode)")
     ap.add_argument("--config", choices=["batch", "sharded"], default="batch",
                     help="batch = BASELINE configs[3] (the headline: independent EuRoC-shape windows, replicas over GPUs); sharded = "
                          "configs[4]: ONE enlarged 31-frame x 2000-landmark window, landmark shards over the GPUs, RCCL all-reduce "
@@ -354,6 +356,8 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="self-test: all ranks use cuda:0")
     ap.add_argument("--rccl-hook", action="store_true", help="--config sharded with one rank: still route the reductions through RCCL")
     args = ap.parse_args()
+    if args.launch_mode:
+        os.environ["VG_BA_LAUNCH_MODE"] = args.launch_mode       # read by the library when a handle first launches
 
     import torch
     import __graft_entry__ as graft
@@ -409,6 +413,7 @@ def main():
     barrier()
     elapsed = D.max_over_ranks(elapsed)
 
+    launch_stats = h.ba_launch_stats()               # mode in effect + graph launches / captures of the timed handle so far
     # one step at a time (no overlap between steps): the latency of a 256-window step
     ser = []
     for _ in range(max(3, min(args.steps, 10))):
@@ -661,7 +666,7 @@ def main():
                                    f"10 IMU factors, ~600 projection factors, 75-dim marginalization prior, max 8 iterations, "
                                    f"MARGIN_OLD marginalization); windows resident in HBM; consecutive steps are issued to "
                                    f"{nfl} HIP streams (independent batches in flight)",
-                       "windows_per_gpu": nwin, "batches_in_flight": nfl,
+                       "windows_per_gpu": nwin, "batches_in_flight": nfl, "launch": launch_stats,
                        "parallelism": f"independent batches x{world} (no collectives)", "valid_solves": n_ok},
             "roofline": roofline,
             "cpu_baseline": cpu,

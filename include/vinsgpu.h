@@ -23,8 +23,8 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 4    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
-                             * 4: VG_PRIOR_RESIDENT */
+#define VG_ABI_VERSION 5    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
+                             * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {
@@ -270,6 +270,23 @@ int vg_ba_set_large_window(vg_handle* h, int force);     /* force != 0: take the
 int vg_rccl_unique_id(char* id128);
 int vg_ba_rccl_init(vg_handle* h, int nranks, int rank, const char* id128);
 int vg_ba_rccl_finalize(vg_handle* h);
+
+/* How vg_ba_batch_run_async / vg_ba_optimize* issue the solve pipeline (prologue, max_iters x {linearise IMU + prior,
+ * linearise projections, accumulate, solve}, cost pass, final: 4 * max_iters + 4 launches):
+ *   VG_LAUNCH_DIRECT  one hipLaunchKernelGGL per kernel;
+ *   VG_LAUNCH_GRAPH   the sequence is captured from the handle's stream into a hipGraph the first time a given combination of
+ *                     device buffers, grid sizes and round count is run, and replayed by ONE hipGraphLaunch afterwards (the
+ *                     kernel arguments of a batch do not change from run to run; a re-allocation or a different size class
+ *                     re-captures).  Same kernels, same results, bit for bit.
+ * Default: environment VG_BA_LAUNCH_MODE = "graph" | "direct", else VG_LAUNCH_DEFAULT.  The large-window path (all-reduce hook
+ * between launches) and the profiled run always launch directly.  vg_ba_launch_stats reports the mode in effect and how many
+ * graph launches / captures the handle has made. */
+enum { VG_LAUNCH_DIRECT = 0, VG_LAUNCH_GRAPH = 1 };
+#ifndef VG_LAUNCH_DEFAULT
+#define VG_LAUNCH_DEFAULT VG_LAUNCH_DIRECT
+#endif
+int vg_ba_set_launch_mode(vg_handle* h, int mode);
+int vg_ba_launch_stats(vg_handle* h, int* mode, long long* graph_launches, long long* graph_captures);
 
 /* Form of the prior factor the marginalization hands back (marginalization_factor.cpp:285-296 builds J0 = S^1/2 V^T,
  * r0 = S^-1/2 V^T b' from the eigen-decomposition A' = V S V^T of the kept system).  Everything downstream uses the factor

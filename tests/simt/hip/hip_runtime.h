@@ -242,7 +242,22 @@ hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipFuncSetAttribute(const void* f, hipFuncAttribute a, int v);
 
+// stream capture / graphs: while a stream is capturing, launches are recorded (grid, block, LDS size, argument values) instead
+// of executed; a graph launch replays them in order (other stream operations are not part of an emulated graph)
+typedef struct simt_graph* hipGraph_t;
+typedef struct simt_graph* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode mode);
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);
+hipError_t hipGraphInstantiate(hipGraphExec_t* x, hipGraph_t g, void*, void*, size_t);
+hipError_t hipGraphDestroy(hipGraph_t g);
+hipError_t hipGraphExecDestroy(hipGraphExec_t x);
+hipError_t hipGraphLaunch(hipGraphExec_t x, hipStream_t s);
+namespace simt { bool capture_launch(hipStream_t s, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body); }
+
 template <typename... KArgs, typename... Args>
-inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t, Args... args) {
-    simt::launch(grid, block, lds, [=]() { kernel(args...); });
+inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    std::function<void()> body = [=]() { kernel(args...); };
+    if (simt::capture_launch(st, grid, block, lds, body)) return;
+    simt::launch(grid, block, lds, body);
 }

@@ -147,7 +147,9 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
 }  // namespace simt
 
 // ---------------------------------------------------------------------------------------------- host runtime stubs
-struct simt_stream { int id; };
+struct simt_node { dim3 grid, block; size_t lds; std::function<void()> body; };
+struct simt_graph { std::vector<simt_node> nodes; };
+struct simt_stream { int id; simt_graph* cap = nullptr; };
 struct simt_event { long long t; };
 static thread_local hipError_t g_last = hipSuccess;
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
@@ -177,6 +179,30 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = simt::clock(); ret
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e-6); return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+namespace simt {
+bool capture_launch(hipStream_t s, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
+    if (!s || !s->cap) return false;
+    s->cap->nodes.push_back(simt_node{grid, block, lds_bytes, body});
+    return true;
+}
+}
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+    if (!s || s->cap) return hipErrorInvalidValue;
+    s->cap = new simt_graph();
+    return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
+    if (!s || !s->cap) return hipErrorInvalidValue;
+    *g = s->cap; s->cap = nullptr;
+    return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* x, hipGraph_t g, void*, void*, size_t) { *x = new simt_graph(*g); return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t x) { delete x; return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t x, hipStream_t) {
+    for (const simt_node& n : x->nodes) simt::launch(n.grid, n.block, n.lds, n.body);
+    return hipSuccess;
+}
 hipError_t hipGetLastError() { hipError_t e = g_last; g_last = hipSuccess; return e; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess (simt)" : "hip error (simt)"; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }

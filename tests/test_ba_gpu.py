@@ -351,6 +351,63 @@ def test_prior_stays_on_the_device_between_frames(handle):
     resident_prior_chain(handle, L=60)
 
 
+def launch_modes_agree(h, L=40, nwin=3):
+    """vg_ba_set_launch_mode: the solve pipeline replayed as a hipGraph gives the bits of the direct launches — same kernels, same
+    arguments.  Covers the replay of one captured graph over several runs and re-uploads (the kernel arguments do not change, the
+    data does), a re-capture when the size class changes, and the way back to direct launches.  Shared with the CPU emulator
+    tests (which record the launches of a capturing stream and replay them)."""
+    seqs = [synth.SyntheticSequence(130 + s, n_frames=13, L=L) for s in range(nwin)]
+    first = [q.window(0) for q in seqs]
+    old = [ba.VG_MARGIN_OLD] * nwin
+
+    def chain(mode):
+        h.ba_set_launch_mode(mode)
+        before = h.ba_launch_stats()
+        out = []
+        probs, flags = first, old
+        for frame in range(3):
+            h.ba_upload(probs, flags)
+            h.ba_run_async()
+            st, sm, pr = h.ba_download()
+            out.append((st, sm, pr))
+            if frame < 2:
+                probs = [q.next_window(st[i], pr[i], frame + 1) for i, q in enumerate(seqs)]
+        # a batch of another size class (fewer windows, another landmark count): new grid sizes -> another graph
+        h.ba_upload([synth.SyntheticSequence(7, L=max(8, L // 2)).window(0)], [ba.VG_MARGIN_NONE])
+        h.ba_run_async()
+        out.append(h.ba_download())
+        h.ba_run_async()                                   # the same batch again: replay (re-solves from the uploaded state)
+        out.append(h.ba_download())
+        after = h.ba_launch_stats()
+        return out, {k: after[k] - before[k] for k in ('graph_launches', 'graph_captures')}, after['mode']
+
+    seqs_state = [q.rng.bit_generator.state for q in seqs] if hasattr(seqs[0], 'rng') else None
+    direct, d_stats, d_mode = chain(ba.VG_LAUNCH_DIRECT)
+    if seqs_state is not None:
+        for q, s in zip(seqs, seqs_state):
+            q.rng.bit_generator.state = s
+    try:
+        graph, g_stats, g_mode = chain(ba.VG_LAUNCH_GRAPH)
+    finally:
+        h.ba_set_launch_mode(ba.VG_LAUNCH_DEFAULT)
+    assert d_mode == 'direct' and d_stats == {'graph_launches': 0, 'graph_captures': 0}
+    assert g_mode == 'graph' and g_stats['graph_launches'] == 5 and 2 <= g_stats['graph_captures'] <= 5, g_stats
+    for (st_d, sm_d, pr_d), (st_g, sm_g, pr_g) in zip(direct, graph):
+        for a, b in zip(st_d if isinstance(st_d, list) else [st_d], st_g if isinstance(st_g, list) else [st_g]):
+            for k in ('pose', 'sb', 'inv_depth'):
+                assert np.array_equal(a[k], b[k]), k
+        for a, b in zip(sm_d if isinstance(sm_d, list) else [sm_d], sm_g if isinstance(sm_g, list) else [sm_g]):
+            assert a['status'] == 0 == b['status'] and a['final_cost'] == b['final_cost'] and a['num_iterations'] == b['num_iterations']
+        for a, b in zip(pr_d if isinstance(pr_d, list) else [pr_d], pr_g if isinstance(pr_g, list) else [pr_g]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert np.array_equal(a['J0'], b['J0']) and np.array_equal(a['r0'], b['r0'])
+
+
+def test_graph_and_direct_launches_agree(handle):
+    launch_modes_agree(handle, L=60)
+
+
 def test_marginalize_second_new_parity(handle):
     _, _, prob2 = _window_with_prior(6, L=150)
     K = prob2['pose'].shape[0]

@@ -9,7 +9,7 @@ from oracle import ba_numpy as B
 from vins_mono_amd import ba, synth
 
 import ba_fixtures as FX
-from test_ba_gpu import _check_solve, _check_prior, resident_prior_chain, marginalize_many_frame0_landmarks
+from test_ba_gpu import _check_solve, _check_prior, resident_prior_chain, marginalize_many_frame0_landmarks, launch_modes_agree
 
 
 def test_emulated_solve_matches_oracle(simt_handle):
@@ -67,6 +67,13 @@ def test_emulated_enlarged_window_marginalization(simt_handle):
 
 def test_emulated_prior_stays_on_the_device_between_frames(simt_handle):
     resident_prior_chain(simt_handle, L=16)
+
+
+def test_emulated_graph_and_direct_launches_agree(simt_handle):
+    """vg_ba_set_launch_mode under emulation: the emulated runtime records the launches of a capturing stream (grid, block, LDS
+    size, argument values) and replays them on hipGraphLaunch, so the capture key, the replay over re-uploaded data and the
+    re-capture on a size change are exercised here."""
+    launch_modes_agree(simt_handle, L=14, nwin=2)
 
 
 @pytest.mark.parametrize("K", [4, 7, 12])

@@ -12,7 +12,9 @@ VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
 VG_MARG_SQRT, VG_MARG_EIGEN = 0, 1     # vg_ba_set_marg_mode
 VG_OK = 0
-VG_ABI_VERSION = 4          # include/vinsgpu.h
+VG_ABI_VERSION = 5          # include/vinsgpu.h
+VG_LAUNCH_DIRECT, VG_LAUNCH_GRAPH = 0, 1   # vg_ba_set_launch_mode
+VG_LAUNCH_DEFAULT = VG_LAUNCH_DIRECT        # include/vinsgpu.h
 VG_PRIOR_RESIDENT = -1
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int)
@@ -206,6 +208,8 @@ class Handle:
         L.vg_ba_eval_factors.argtypes = [C.c_void_p, C.POINTER(Problem), _pd, _pd, _pd, _pd, _pd]
         L.vg_ba_set_large_window.argtypes = [C.c_void_p, C.c_int]
         L.vg_ba_set_marg_mode.argtypes = [C.c_void_p, C.c_int]
+        L.vg_ba_set_launch_mode.argtypes = [C.c_void_p, C.c_int]
+        L.vg_ba_launch_stats.argtypes = [C.c_void_p, _pi, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         if hasattr(L, 'vg_ba_rccl_init'):            # (absent from the CPU-emulated build of tests/simt)
             L.vg_ba_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
             L.vg_ba_rccl_finalize.argtypes = [C.c_void_p]
@@ -264,6 +268,15 @@ class Handle:
 
     def ba_run_async(self):
         self._chk(self.lib.vg_ba_batch_run_async(self.h), "vg_ba_batch_run_async")
+
+    def ba_set_launch_mode(self, mode):
+        """VG_LAUNCH_DIRECT (0) / VG_LAUNCH_GRAPH (1): one launch per kernel, or the captured pipeline replayed as a hipGraph."""
+        self._chk(self.lib.vg_ba_set_launch_mode(self.h, int(mode)), "vg_ba_set_launch_mode")
+
+    def ba_launch_stats(self):
+        mode, nl, ncap = C.c_int(), C.c_longlong(), C.c_longlong()
+        self._chk(self.lib.vg_ba_launch_stats(self.h, C.byref(mode), C.byref(nl), C.byref(ncap)), "vg_ba_launch_stats")
+        return {"mode": "graph" if mode.value == VG_LAUNCH_GRAPH else "direct", "graph_launches": nl.value, "graph_captures": ncap.value}
 
     # ---- large windows / landmark shards (include/vinsgpu.h "Large windows and landmark shards")
     def ba_set_marg_mode(self, mode):

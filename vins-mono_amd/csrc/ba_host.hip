@@ -29,6 +29,7 @@ extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL,
 extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, double* proj_r, double* proj_J,
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream);
 extern "C" const char* ba_failed_launch();
+extern "C" hipError_t ba_prepare_launch();
 extern "C" hipError_t ba_launch_marg(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, hipStream_t stream);
 extern "C" hipError_t ba_launch_carry_prior(int nwin, const double* mout, const int* miout, int mo_J0, int mo_r0, int mo_x0, int mo_stride,
                                             int mi_stride, int mcap, int x0cap, double* pri, int po_x0, int po_r0, int po_J0, int pld,
@@ -743,12 +744,85 @@ static int launch_solve(vg_handle* h, hipEvent_t* ev = nullptr, int* kinds = nul
     return VG_OK;
 }
 
+// ---- the solve pipeline as a hipGraph ---------------------------------------------------------------------------------
+// One batch solve is 4 * rounds + 4 launches whose arguments (device layout block, buffer pointers, cost_only) do not change
+// from run to run; in VG_LAUNCH_GRAPH mode they are captured from the handle's stream once and replayed with a single
+// hipGraphLaunch.  The key holds everything a launch's grid / block / LDS size and arguments are computed from; what the
+// kernels READ (layout block, tables, states) is data, not part of the graph.  The large-window path stays on direct
+// launches (its all-reduce hook is arbitrary host code).  If the runtime cannot capture (hipStreamBeginCapture fails), the
+// handle stays on direct launches: the same kernels either way, never another compute path.
+static int resolve_launch_mode(BaBatch& B) {
+    if (B.launch_mode < 0) {
+        const char* e = getenv("VG_BA_LAUNCH_MODE");
+        B.launch_mode = VG_LAUNCH_DEFAULT;
+        if (e && !strcmp(e, "graph")) B.launch_mode = VG_LAUNCH_GRAPH;
+        if (e && !strcmp(e, "direct")) B.launch_mode = VG_LAUNCH_DIRECT;
+    }
+    return B.launch_mode;
+}
+static void graph_key(const BaBatch& B, BaBatch::GraphKey& k) {
+    const BaLayout& L = B.L;
+    k.dL = B.dL; k.P = B.P;
+    const int d[12] = {L.nwin, L.nig, L.nprw, L.nbf, L.nba, L.lds_pro, L.lds_lin, L.lds_solve, B.rounds, 0, 0, 0};
+    memcpy(k.dims, d, sizeof(d));
+}
+static void graph_drop(BaBatch& B) {
+    if (B.gexec) (void)hipGraphExecDestroy(B.gexec);
+    B.gexec = nullptr;
+}
+extern "C" void ba_graph_release(vg_handle* h) { graph_drop(h->ba); }
+static int launch_solve_graph(vg_handle* h) {
+    BaBatch& B = h->ba;
+    BaBatch::GraphKey k;
+    graph_key(B, k);
+    if (!B.gexec || memcmp(&k, &B.gkey, sizeof(k)) != 0) {
+        graph_drop(B);
+        HIPCHK(h, ba_prepare_launch());
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            B.graph_unavailable = true;
+            return launch_solve(h);
+        }
+        const int rc = launch_solve(h);
+        hipGraph_t g = nullptr;
+        const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        HIPCHK(h, ec);
+        const hipError_t ei = hipGraphInstantiate(&B.gexec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) { B.gexec = nullptr; HIPCHK(h, ei); }
+        B.gkey = k;
+        ++B.n_graph_captures;
+    }
+    HIPCHK(h, hipGraphLaunch(B.gexec, h->stream));
+    ++B.n_graph_launches;
+    return VG_OK;
+}
+static int launch_solve_in_mode(vg_handle* h) {
+    BaBatch& B = h->ba;
+    const bool graph = resolve_launch_mode(B) == VG_LAUNCH_GRAPH && !B.L.big && !B.graph_unavailable;
+    return graph ? launch_solve_graph(h) : launch_solve(h);
+}
+extern "C" int vg_ba_set_launch_mode(vg_handle* h, int mode) {
+    if (!h || (mode != VG_LAUNCH_DIRECT && mode != VG_LAUNCH_GRAPH)) return VG_ERR_BAD_ARG;
+    h->ba.launch_mode = mode;
+    if (mode == VG_LAUNCH_DIRECT) graph_drop(h->ba);
+    return VG_OK;
+}
+extern "C" int vg_ba_launch_stats(vg_handle* h, int* mode, long long* graph_launches, long long* graph_captures) {
+    if (!h) return VG_ERR_BAD_ARG;
+    if (mode) *mode = h->ba.graph_unavailable ? VG_LAUNCH_DIRECT : resolve_launch_mode(h->ba);
+    if (graph_launches) *graph_launches = h->ba.n_graph_launches;
+    if (graph_captures) *graph_captures = h->ba.n_graph_captures;
+    return VG_OK;
+}
+
 extern "C" int vg_ba_batch_run_async(vg_handle* h) {
     VG_RANGE("vg_ba_batch_run_async");
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     BaBatch& B = h->ba;
-    const int rc = launch_solve(h);
+    const int rc = launch_solve_in_mode(h);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));           // states final: vg_ba_batch_download_state waits for this only
     B.solved_recorded = true;
@@ -791,7 +865,7 @@ extern "C" int vg_ba_batch_run_timed(vg_handle* h, float* solve_ms, float* marg_
     hipEvent_t e0 = h->ev0, e1 = h->ev1, e2 = h->ev2;
     HIPCHK(h, hipEventRecord(e0, h->stream));
     {
-        const int rc = launch_solve(h);
+        const int rc = launch_solve_in_mode(h);
         if (rc) return rc;
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));

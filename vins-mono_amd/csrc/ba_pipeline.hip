@@ -3288,6 +3288,9 @@ static hipError_t set_lds_attrs() {
     return e;
 }
 
+// (stream capture must not meet the first-use set-up above: the host calls this before hipStreamBeginCapture)
+extern "C" hipError_t ba_prepare_launch() { return set_lds_attrs(); }
+
 // last failing launch of this translation unit (for the error text of the C-ABI)
 static const char* g_failed_launch = "";
 extern "C" const char* ba_failed_launch() { return g_failed_launch; }

@@ -57,6 +57,19 @@ struct BaBatch {
     bool mout_pending = false;       // the last run's marginalization result has not been carried yet
     std::vector<int> run_margin;     // margin flags + output layout of that run
     int run_nwin = 0, run_K = 0, run_mo_J0 = 0, run_mo_r0 = 0, run_mo_x0 = 0, run_mo_stride = 0, run_mi_stride = 0, run_mcap = 0;
+    // ---- the solve pipeline as a hipGraph (vg_ba_set_launch_mode).  The ~36 launches of one batch solve have the same kernel
+    //      arguments from run to run (device layout block, buffer pointers, cost_only flags): captured once per (pointers, grid
+    //      sizes, rounds) key and replayed with one hipGraphLaunch; a re-allocation or a different factor-count class re-captures.
+    struct GraphKey {
+        const void* dL = nullptr;
+        BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        int dims[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    int launch_mode = -1;            // VG_LAUNCH_*; -1: not resolved yet (environment VG_BA_LAUNCH_MODE, else the default)
+    hipGraphExec_t gexec = nullptr;
+    GraphKey gkey;
+    bool graph_unavailable = false;  // stream capture failed once on this handle: stay with direct launches
+    long long n_graph_launches = 0, n_graph_captures = 0;
     double flops = 0, flops_marg = 0, bytes_in = 0, bytes_out = 0;
     double flops_k[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic flops per kernel class (VG_BA_KERNEL_*), one run of the batch
 };
