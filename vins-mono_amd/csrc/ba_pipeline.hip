@@ -839,10 +839,14 @@ DEV void global_task(const Ctx& c, const double* recs, double* Sp, double* gp, d
 }
 
 // per-landmark sums: h = sum Jl.Jl, b = sum Jl.r, W column -> Wt[col][l] (landmark index fastest: coalesced stores).
-// Two passes over the landmark's records (the second one hits L1 / L2): the first forms the sums that involve every
-// factor (h, b and the anchor / ex / td entries of W), the second walks the camera columns in order and stores every
-// Wt row exactly once -- a zero fill followed by scattered 8-byte stores costs ~2.5x the write traffic once the
-// zero-filled lines have left L2.
+// ONE pass over the landmark's records, every Wt row stored exactly once (a zero fill followed by scattered 8-byte stores costs
+// ~2.5x the write traffic once the zero-filled lines have left L2).  pack_window stores the factors of a landmark by strictly
+// increasing target frame (start + 1, start + 2, ..., then the relocalisation pose K) and the anchor precedes every target, so
+// the target columns can be written as the factors come by -- zeros for the frames in between -- and only the anchor's column
+// (a sum over all factors, like h / b and the ex / td rows) waits for the end.  The task is a chain of L2 round trips (slot
+// index -> record), not of flops: the slot and target indices of the next factor are requested one factor ahead.  (Until round
+// 3 this was two passes, the second re-reading every record to walk the columns in order: same values, same order of every
+// sum, twice the chain.)
 DEV void landmark_task(const Ctx& c, int l, const double* recs, double* buf) {
     const BaLayout& L = *c.Lp;
     const int REC = L.REC;
@@ -853,52 +857,67 @@ DEV void landmark_task(const Ctx& c, int l, const double* recs, double* buf) {
         return;
     }
     const int fb = c.ia[L.io_lm_fbeg + l], fe = c.ia[L.io_lm_fbeg + l + 1];
-    double h = 0.0, b = 0.0, wi[6] = {0, 0, 0, 0, 0, 0}, wex[6] = {0, 0, 0, 0, 0, 0}, wtd = 0.0;
-    int anchor = -1;
+    double h = 0.0, b = 0.0, wi[6] = {0, 0, 0, 0, 0, 0};
+    const int anchor = fb < fe ? c.ia[L.io_fac_i + fb] : -1;
+    int jn = 0;                                   // next pose column to store
+    int slot_n = 0, j_n = 0;
+    if (fb < fe) { slot_n = c.ia[L.io_fac_slot + fb]; j_n = c.ia[L.io_fac_j + fb]; }
     for (int f = fb; f < fe; ++f) {
-        const double* rec = recs + (size_t)c.ia[L.io_fac_slot + f] * REC;
+        const double* rec = recs + (size_t)slot_n * REC;
+        const int j = j_n;
+        if (f + 1 < fe) { slot_n = c.ia[L.io_fac_slot + f + 1]; j_n = c.ia[L.io_fac_j + f + 1]; }
         const double l0 = rec[24], l1 = rec[25];
+        double v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = rec[12 + 2 * k] * l0 + rec[12 + 2 * k + 1] * l1;
         h += l0 * l0 + l1 * l1;
         b += l0 * rec[26] + l1 * rec[27];
-        anchor = c.ia[L.io_fac_i + f];
 #pragma unroll
         for (int k = 0; k < 6; ++k) wi[k] += rec[2 * k] * l0 + rec[2 * k + 1] * l1;
-        if (L.e) {
+        for (; jn < j; ++jn) {                    // frames without a factor of this landmark (the anchor's column comes last)
+            if (jn == anchor) continue;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) wex[k] += rec[28 + 2 * k] * l0 + rec[28 + 2 * k + 1] * l1;
-        }
-        if (L.t) wtd += rec[28 + 12 * L.e] * l0 + rec[29 + 12 * L.e] * l1;
-    }
-    // pose columns in order; pack_window stores the factors of a landmark by strictly increasing target frame
-    // (start + 1, start + 2, ..., then the relocalisation pose K)
-    int f = fb;
-    for (int j = 0; j < L.Kp; ++j) {
-        double v[6] = {0, 0, 0, 0, 0, 0};
-        if (j == anchor) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) v[k] = wi[k];
-        } else {
-            if (f < fe && c.ia[L.io_fac_j + f] == j) {
-                const double* rec = recs + (size_t)c.ia[L.io_fac_slot + f++] * REC;
-                const double l0 = rec[24], l1 = rec[25];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) v[k] = rec[12 + 2 * k] * l0 + rec[12 + 2 * k + 1] * l1;
-            }
+            for (int k = 0; k < 6; ++k) Wt[(size_t)(col_pose(L, jn) + k) * ldw] = 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) Wt[(size_t)(col_pose(L, j) + k) * ldw] = v[k];
+        jn = j + 1;
     }
-    int row = 6 * L.Kp;
-    if (L.e) {
+    for (; jn < L.Kp; ++jn) {
+        if (jn == anchor) continue;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Wt[(size_t)(col_ex(L) + k) * ldw] = anchor >= 0 ? wex[k] : 0.0;
-        row += 6;
+        for (int k = 0; k < 6; ++k) Wt[(size_t)(col_pose(L, jn) + k) * ldw] = 0.0;
     }
-    if (L.t) { Wt[(size_t)col_td(L) * ldw] = anchor >= 0 ? wtd : 0.0; row += 1; }
-    if (L.big) { Wt[row * ldw] = b; ++row; }      // large-window path: the rhs travels as row Rc of W (ba_big_schur_kernel)
-    for (; row < L.RcPad; ++row) Wt[row * ldw] = 0.0;
+    if (anchor >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Wt[(size_t)(col_pose(L, anchor) + k) * ldw] = wi[k];
+    }
     buf[L.bo_h + l] = h;
     buf[L.bo_b + l] = b;
+    int row = 6 * L.Kp;
+    if (L.e | L.t) {
+        // the rows of the extrinsic pose / td (only when they are estimated): a pass of their own over the records (now in L1 /
+        // L2), so that the pass above -- the one every configuration runs -- keeps the kernel at 4 wavefronts per SIMD
+        double wex[6] = {0, 0, 0, 0, 0, 0}, wtd = 0.0;
+        const int otd = 28 + 12 * L.e;
+        for (int f = fb; f < fe; ++f) {
+            const double* rec = recs + (size_t)c.ia[L.io_fac_slot + f] * REC;
+            const double l0 = rec[24], l1 = rec[25];
+            if (L.e) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) wex[k] += rec[28 + 2 * k] * l0 + rec[28 + 2 * k + 1] * l1;
+            }
+            if (L.t) wtd += rec[otd] * l0 + rec[otd + 1] * l1;
+        }
+        if (L.e) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Wt[(size_t)(col_ex(L) + k) * ldw] = anchor >= 0 ? wex[k] : 0.0;
+            row += 6;
+        }
+        if (L.t) { Wt[(size_t)col_td(L) * ldw] = anchor >= 0 ? wtd : 0.0; row += 1; }
+    }
+    if (L.big) { Wt[row * ldw] = b; ++row; }      // large-window path: the rhs travels as row Rc of W (ba_big_schur_kernel)
+    for (; row < L.RcPad; ++row) Wt[row * ldw] = 0.0;
 }
 
 // grid nba * up(nwin, 8) workgroups of BA_ACC_NT threads.  Workgroups are dealt to the 8 XCDs round-robin by their
