@@ -9,7 +9,9 @@
 // Rc x Rc camera part is factorised densely.
 #pragma once
 
+#ifndef BA_NT
 #define BA_NT 512                 // threads per workgroup of the per-window kernels (8 wavefronts)
+#endif
 #define BA_NW (BA_NT / 64)
 #define BA_LIN_NT 256             // projection factors per workgroup of the linearisation kernel
 #define BA_ACC_NT 256             // threads per workgroup of the accumulation kernel
