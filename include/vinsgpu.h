@@ -23,8 +23,8 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 5    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
-                             * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode */
+#define VG_ABI_VERSION 6    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
+                             * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode; 6: vg_ba_reserve, vg_ba_seq_* (windows that stay on the device) */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {
@@ -287,6 +287,89 @@ enum { VG_LAUNCH_DIRECT = 0, VG_LAUNCH_GRAPH = 1 };
 #endif
 int vg_ba_set_launch_mode(vg_handle* h, int mode);
 int vg_ba_launch_stats(vg_handle* h, int* mode, long long* graph_launches, long long* graph_captures);
+
+/* Capacities the layout of every later batch is built for at least (landmarks, projection factors and observation rows per window,
+ * rows of the prior): a caller whose windows fluctuate from frame to frame keeps one layout -- no re-allocation, and in
+ * VG_LAUNCH_GRAPH mode no re-capture.  Zero leaves a capacity to the data.  Takes effect at the next upload. */
+int vg_ba_reserve(vg_handle* h, int max_landmarks, int max_factors, int max_obs, int max_prior_n);
+
+/* ---- Windows that stay on the device from frame to frame ------------------------------------------------
+ * The reference keeps the sliding window in host members between two calls of optimization(): f_manager.feature (every track,
+ * also the ones not yet in the problem), Ps / Rs / Vs / Bas / Bgs, pre_integrations[], last_marginalization_info.  Around
+ * optimization() it runs, per frame (Estimator::processImage, estimator.cpp:120-215):
+ *     f_manager.addFeatureCheckParallax   (feature_manager.cpp:45-107)   new observations, key-frame decision
+ *     f_manager.triangulate               (feature_manager.cpp:202-257)  depth of the tracks that enter the problem
+ *     optimization()                      (estimator.cpp:670-1003)       solve + marginalization
+ *     slideWindow()                       (estimator.cpp:1005-1126)      state / pre-integration shift,
+ *                                         FeatureManager::removeBackShiftDepth / removeFront (feature_manager.cpp:275-351)
+ *     f_manager.removeFailures            (feature_manager.cpp:161-171)
+ * A sequence does all of that on the device for a batch of independent windows: the track tables, the states, the IMU constants
+ * and the prior never leave HBM; per frame the host sends the new frame's observations (id + 7 doubles each), its state guess
+ * (what processIMU propagated) and the pre-integration of the new interval, and reads back the states.  No per-frame packing,
+ * no re-upload of the window.  Relocalisation factors and the large-window path are not offered in a sequence.              */
+typedef struct {
+    int n_features;              /* f_manager.feature.size(), list order                                                     */
+    const int* feature_id;       /* FeaturePerId::feature_id                                                                 */
+    const int* start_frame;
+    const int* n_obs;            /* feature_per_frame.size() (consecutive frames from start_frame)                           */
+    const int* solve_flag;       /* may be NULL (all 0)                                                                      */
+    const double* depth;         /* estimated_depth (-1: not triangulated yet)                                               */
+    const double* obs;           /* sum(n_obs) rows, feature-major: [x y z u v vx vy cur_td] (FeaturePerFrame)                */
+} vg_ba_tracks;
+
+typedef struct {
+    int max_features;            /* capacity of a window's track table                                                       */
+    int max_new_obs;             /* capacity of one frame's observation list                                                 */
+    int max_landmarks;           /* tracks in the problem at once (0: max_features)                                           */
+    int max_factors;             /* projection factors at once (0: 6 x max_landmarks)                                         */
+    double init_depth;           /* INIT_DEPTH   (vins_estimator/src/parameters.cpp:3)                                       */
+    double min_parallax;         /* MIN_PARALLAX (keyframe_parallax / FOCAL_LENGTH, parameters.cpp:79-80)                    */
+} vg_ba_seq_config;
+
+/* The new frame of one window: what Estimator::processImage receives (the `image` map in ascending feature id: one
+ * observation per feature, rows [x y z u v vx vy]) plus what Estimator::processIMU has produced since the last frame: the
+ * propagated state of the newest frame (Ps / Rs / Vs [WINDOW_SIZE], biases copied from the frame before) and
+ * pre_integrations[WINDOW_SIZE].  imu_merged: after a frame that was NOT a key frame (margin flag VG_MARGIN_SECOND_NEW)
+ * slideWindow folds the dropped interval's samples into pre_integrations[WINDOW_SIZE - 1] (estimator.cpp:1069-1085); the
+ * caller re-integrates that interval (vg_imu_preintegrate over the concatenated samples) and hands it over here; NULL otherwise. */
+typedef struct {
+    double pose[7];
+    double speedbias[9];
+    const vg_imu_preint* imu_new;
+    const vg_imu_preint* imu_merged;
+    int n_obs;
+    const int* feature_id;       /* ascending                                                                                */
+    const double* obs;           /* n_obs x 7                                                                                */
+} vg_ba_frame;
+
+/* per-window record of the last step (vg_ba_seq_info) */
+enum { VG_SEQ_FLAG = 0,          /* marginalization flag the key-frame test chose (VG_MARGIN_OLD: the frame before was a key frame) */
+       VG_SEQ_N_FEATURES,        /* tracks in the table after the new observations were added                                 */
+       VG_SEQ_N_TRACKED,         /* last_track_num                                                                            */
+       VG_SEQ_N_PARALLAX,        /* parallax_num                                                                              */
+       VG_SEQ_N_LANDMARKS,       /* tracks in the problem                                                                     */
+       VG_SEQ_N_FACTORS,
+       VG_SEQ_STATUS,            /* VG_OK or VG_ERR_UNSUPPORTED: a capacity of vg_ba_seq_config was exceeded (the step is void)  */
+       VG_SEQ_N_AFTER,           /* tracks left after slideWindow + removeFailures                                            */
+       VG_SEQ_INFO_INTS = 8 };
+
+/* windows[w]: states of the K frames, imu[K-1], prior, options of window w as in vg_ba_optimize (its landmark tables are ignored;
+ * frame K-1 and imu[K-2] are placeholders that the first step overwrites); tracks[w]: its track table.  This is the state
+ * the reference is in between two frames (after slideWindow).  All windows share K and the estimate_* options. */
+int vg_ba_seq_begin(vg_handle* h, int nwin, const vg_ba_seq_config* cfg, const vg_ba_problem* const* windows,
+                    const vg_ba_tracks* const* tracks);
+/* One frame for every window: add + key-frame test + triangulate + problem tables + solve + marginalization + slide, all
+ * enqueued on the handle's stream. */
+int vg_ba_seq_step_async(vg_handle* h, int nwin, const vg_ba_frame* const* frames);
+/* States of the window as solved by the last step (before the slide) and its summaries: vg_ba_batch_download_state;
+ * vg_ba_state::inv_depth, if not NULL, must hold max_landmarks rounded up to a multiple of 16 values (the first
+ * info[VG_SEQ_N_LANDMARKS] are the problem's, in track-list order).  info: [nwin][VG_SEQ_INFO_INTS]. */
+int vg_ba_seq_info(vg_handle* h, int nwin, int* info);
+/* parity tap: the track table of one window as the last step left it; arrays of capacity cap (obs may be NULL; else
+ * cap x K x 8 doubles, rows [x y u v vx vy cur_td z] of feature f at obs + (f * K + j) * 8) */
+int vg_ba_seq_get_tracks(vg_handle* h, int window, int cap, int* n_features, int* feature_id, int* start_frame, int* n_obs,
+                         int* solve_flag, double* depth, double* obs);
+int vg_ba_seq_end(vg_handle* h);
 
 /* Form of the prior factor the marginalization hands back (marginalization_factor.cpp:285-296 builds J0 = S^1/2 V^T,
  * r0 = S^-1/2 V^T b' from the eigen-decomposition A' = V S V^T of the kept system).  Everything downstream uses the factor

@@ -36,9 +36,14 @@ SIMT_LIB = os.path.join(SIMT_DIR, "_build", "libvinsgpu_simt.so")
 
 
 def _build_simt():
+    import fcntl
     import subprocess
-    r = subprocess.run(["make", "-C", SIMT_DIR, "-j", str(os.cpu_count() or 4)], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True)
+    os.makedirs(os.path.join(SIMT_DIR, "_build"), exist_ok=True)
+    # several processes may get here at once (xdist workers, the ranks of the world-2 tests): one make at a time
+    with open(os.path.join(SIMT_DIR, "_build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-C", SIMT_DIR, "-j", str(os.cpu_count() or 4)], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("building the SIMT emulation library failed:\n" + r.stdout[-4000:])
 

@@ -12,7 +12,7 @@ VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
 VG_MARG_SQRT, VG_MARG_EIGEN = 0, 1     # vg_ba_set_marg_mode
 VG_OK = 0
-VG_ABI_VERSION = 5          # include/vinsgpu.h
+VG_ABI_VERSION = 6          # include/vinsgpu.h
 VG_LAUNCH_DIRECT, VG_LAUNCH_GRAPH = 0, 1   # vg_ba_set_launch_mode
 VG_LAUNCH_DEFAULT = VG_LAUNCH_DIRECT        # include/vinsgpu.h
 VG_PRIOR_RESIDENT = -1
@@ -54,6 +54,39 @@ class Summary(C.Structure):
 class Prior(C.Structure):
     _fields_ = [("cap", C.c_int), ("cap_blocks", C.c_int), ("n", C.c_int), ("m", C.c_int), ("nblocks", C.c_int),
                 ("valid", C.c_int), ("block_kind", _pi), ("block_index", _pi), ("J0", _pd), ("r0", _pd), ("x0", _pd)]
+
+
+class Tracks(C.Structure):            # vg_ba_tracks
+    _fields_ = [("n_features", C.c_int), ("feature_id", _pi), ("start_frame", _pi), ("n_obs", _pi), ("solve_flag", _pi),
+                ("depth", _pd), ("obs", _pd)]
+
+
+class SeqConfig(C.Structure):         # vg_ba_seq_config
+    _fields_ = [("max_features", C.c_int), ("max_new_obs", C.c_int), ("max_landmarks", C.c_int), ("max_factors", C.c_int),
+                ("init_depth", C.c_double), ("min_parallax", C.c_double)]
+
+
+class Frame(C.Structure):             # vg_ba_frame
+    _fields_ = [("pose", C.c_double * 7), ("speedbias", C.c_double * 9), ("imu_new", C.POINTER(ImuPreint)),
+                ("imu_merged", C.POINTER(ImuPreint)), ("n_obs", C.c_int), ("feature_id", _pi), ("obs", _pd)]
+
+
+SEQ_INFO = ("flag", "n_features", "n_tracked", "n_parallax", "n_landmarks", "n_factors", "status", "n_after")
+
+
+def imu_struct(m):
+    """vg_imu_preint from a pre-integration dict (synth.preintegrate / Handle.imu_preintegrate); None: no factor."""
+    q = ImuPreint()
+    if m is None:
+        q.valid = 0
+        return q
+    q.sum_dt = float(m['sum_dt'])
+    q.delta_p[:] = list(m['delta_p']); q.delta_q[:] = list(m['delta_q']); q.delta_v[:] = list(m['delta_v'])
+    q.linearized_ba[:] = list(m['lin_ba']); q.linearized_bg[:] = list(m['lin_bg'])
+    q.jacobian[:] = list(np.asarray(m['jacobian'], float).ravel())
+    q.covariance[:] = list(np.asarray(m['covariance'], float).ravel())
+    q.valid = 1
+    return q
 
 
 def _dp(a):
@@ -217,6 +250,12 @@ class Handle:
         L.vg_ba_reduce_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.vg_triangulate.argtypes = [C.c_void_p, C.c_int, _pd, _pd, _pd, _pd, C.c_int, _pi, _pi, _pi, _pd, C.c_double, _pd]
         L.vg_imu_preintegrate.argtypes = [C.c_void_p, C.c_int, _pi, _pd, _pd, _pd, _pd, C.POINTER(ImuPreint)]
+        L.vg_ba_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.vg_ba_seq_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(SeqConfig), C.POINTER(C.POINTER(Problem)), C.POINTER(C.POINTER(Tracks))]
+        L.vg_ba_seq_step_async.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(Frame))]
+        L.vg_ba_seq_info.argtypes = [C.c_void_p, C.c_int, _pi]
+        L.vg_ba_seq_get_tracks.argtypes = [C.c_void_p, C.c_int, C.c_int, _pi, _pi, _pi, _pi, _pi, _pd, _pd]
+        L.vg_ba_seq_end.argtypes = [C.c_void_p]
         if L.vg_abi_version() != VG_ABI_VERSION:
             raise RuntimeError(f"libvinsgpu.so reports ABI version {L.vg_abi_version()}, this binding was written for {VG_ABI_VERSION}")
         self.h = C.c_void_p()
@@ -406,6 +445,86 @@ class Handle:
         self.ba_run_async()
         st, sm, pr = self.ba_download()
         return st[0], sm[0], pr[0]
+
+    # ---- windows that stay on the device (include/vinsgpu.h vg_ba_seq_*)
+    def ba_reserve(self, max_landmarks=0, max_factors=0, max_obs=0, max_prior_n=0):
+        self._chk(self.lib.vg_ba_reserve(self.h, int(max_landmarks), int(max_factors), int(max_obs), int(max_prior_n)), "vg_ba_reserve")
+
+    def seq_begin(self, windows, tracks, max_features=512, max_new_obs=512, max_landmarks=0, max_factors=0, init_depth=5.0,
+                  min_parallax=10.0 / 460.0):
+        """windows: prob dicts (states, imu, prior, options; landmark tables ignored); tracks[w]: dict(id, start, nobs, depth, obs
+        [sum nobs x 8: x y z u v vx vy cur_td], optional solve_flag)."""
+        n = len(windows)
+        self._packed = [PackedProblem(p) for p in windows]
+        arr = (C.POINTER(Problem) * n)(*[C.pointer(p.struct) for p in self._packed])
+        self._margin = np.zeros(n, np.int32)
+        keep, ts = [], (Tracks * n)()
+        for w, t in enumerate(tracks):
+            i4 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+            a = dict(id=i4(t['id']), start=i4(t['start']), nobs=i4(t['nobs']), depth=np.ascontiguousarray(t['depth'], dtype=np.float64),
+                     obs=np.ascontiguousarray(t['obs'], dtype=np.float64).reshape(-1, 8),
+                     flag=i4(t['solve_flag']) if t.get('solve_flag') is not None else None)
+            keep.append(a)
+            ts[w].n_features = len(a['id'])
+            ts[w].feature_id, ts[w].start_frame, ts[w].n_obs = _ip(a['id']), _ip(a['start']), _ip(a['nobs'])
+            ts[w].solve_flag = _ip(a['flag']) if a['flag'] is not None else None
+            ts[w].depth, ts[w].obs = _dp(a['depth']), _dp(a['obs'])
+        tp = (C.POINTER(Tracks) * n)(*[C.pointer(ts[w]) for w in range(n)])
+        cfg = SeqConfig(int(max_features), int(max_new_obs), int(max_landmarks), int(max_factors), float(init_depth), float(min_parallax))
+        self._chk(self.lib.vg_ba_seq_begin(self.h, n, C.byref(cfg), arr, tp), "vg_ba_seq_begin")
+        self._seq_n = n
+        for p in self._packed:                            # size of the inverse-depth slab a state download fills
+            p.L = (int(max_landmarks or max_features) + 15) // 16 * 16
+
+    def seq_step(self, frames):
+        """frames[w]: dict(pose (7,), sb (9,), imu_new, imu_merged (pre-integration dicts; imu_merged None unless the frame before
+        was dropped as a non-keyframe), ids (n,), obs (n, 7) [x y z u v vx vy])."""
+        n = len(frames)
+        fs, keep = (Frame * n)(), []
+        for w, f in enumerate(frames):
+            ids = np.ascontiguousarray(f['ids'], dtype=np.int32)
+            obs = np.ascontiguousarray(f['obs'], dtype=np.float64).reshape(-1, 7)
+            inew = imu_struct(f['imu_new'])
+            imrg = imu_struct(f['imu_merged']) if f.get('imu_merged') is not None else None
+            keep.append((ids, obs, inew, imrg))
+            fs[w].pose[:] = list(np.asarray(f['pose'], float)); fs[w].speedbias[:] = list(np.asarray(f['sb'], float))
+            fs[w].imu_new = C.pointer(inew)
+            fs[w].imu_merged = C.pointer(imrg) if imrg is not None else None
+            fs[w].n_obs = len(ids)
+            fs[w].feature_id, fs[w].obs = _ip(ids), _dp(obs)
+        fp = (C.POINTER(Frame) * n)(*[C.pointer(fs[w]) for w in range(n)])
+        self._chk(self.lib.vg_ba_seq_step_async(self.h, n, fp), "vg_ba_seq_step_async")
+
+    def seq_states(self, allow_numeric_failure=False):
+        """States of the windows as the last step solved them (before the slide) and the summaries."""
+        outs, st, pri, sm, packed = self.ba_prepare_download()
+        rc = self.ba_download_state_raw()
+        if rc != VG_OK and not (allow_numeric_failure and rc == -4):
+            self._chk(rc, "vg_ba_batch_download_state")
+        return [o.state_dict(False) for o in outs], [summary_dict(sm[i]) for i in range(len(outs))]
+
+    def seq_priors(self):
+        """parity tap: the priors the last step's marginalization produced (None where the old one stays)."""
+        outs, st, pri, sm, packed = self._dl
+        self._chk(self.ba_download_prior_raw(), "vg_ba_batch_download_prior")
+        return [o.prior_dict() for o in outs]
+
+    def seq_info(self):
+        a = np.zeros((self._seq_n, len(SEQ_INFO)), np.int32)
+        self._chk(self.lib.vg_ba_seq_info(self.h, self._seq_n, _ip(a)), "vg_ba_seq_info")
+        return [dict(zip(SEQ_INFO, map(int, r))) for r in a]
+
+    def seq_tracks(self, w, K, cap=1024):
+        n = C.c_int()
+        ids, st, nb, fl = (np.zeros(cap, np.int32) for _ in range(4))
+        dep, obs = np.zeros(cap), np.zeros((cap, K, 8))
+        self._chk(self.lib.vg_ba_seq_get_tracks(self.h, int(w), cap, C.byref(n), _ip(ids), _ip(st), _ip(nb), _ip(fl), _dp(dep), _dp(obs)),
+                  "vg_ba_seq_get_tracks")
+        m = n.value
+        return dict(id=ids[:m].copy(), start=st[:m].copy(), nobs=nb[:m].copy(), solve_flag=fl[:m].copy(), depth=dep[:m].copy(), obs=obs[:m].copy())
+
+    def seq_end(self):
+        self._chk(self.lib.vg_ba_seq_end(self.h), "vg_ba_seq_end")
 
     def imu_preintegrate(self, intervals, biases, noise):
         """Batched IntegrationBase (integration_base.h:30-158).  intervals[k] = [(dt, acc, gyr), ...] with entry 0 =

@@ -136,6 +136,8 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         Nmax = std::max(Nmax, pr[w].n);
         NBmax = std::max(NBmax, pr[w].nb);
     }
+    Lmax = std::max(Lmax, h->ba.res_L); Fmax = std::max(Fmax, h->ba.res_F); Omax = std::max(Omax, h->ba.res_O);      // vg_ba_reserve
+    if (h->ba.res_N > Nmax) { Nmax = h->ba.res_N; NBmax = std::max(NBmax, L.K + 4); }
     L.Kp = L.K + (relo ? 1 : 0);
     L.e = p0->estimate_extrinsic ? 1 : 0;
     L.t = p0->estimate_td ? 1 : 0;
@@ -470,6 +472,8 @@ static int ensure(vg_handle* h, T*& ptr, size_t& cap, size_t need) {
     return VG_OK;
 }
 
+extern "C" void ba_seq_release(vg_handle* h);        // (below: windows that stay on the device)
+
 // ---- priors that stay on the device -----------------------------------------------------------------
 // The first upload after a run that asks for a resident prior collects the block tables of that run's marginalization
 // (a few dozen ints per window) and moves the factors device-to-device from the marginalization output into the prior slots.
@@ -517,6 +521,10 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     for (int w = 0; w < nwin; ++w) if (!in[w]) return VG_ERR_BAD_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     BaBatch& B = h->ba;
+    if (B.seq.active) {              // an ordinary upload takes the batch buffers back: the sequence ends here
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        ba_seq_release(h);
+    }
     B.uploaded = false;              // a failed upload must not leave the previous batch's flags next to the new layout
     B.solved_recorded = false;
     static const bool debug_upload = getenv("VG_DEBUG_UPLOAD") != nullptr;      // phase times of this call on stderr
@@ -1140,5 +1148,228 @@ extern "C" int vg_ba_eval_factors(vg_handle* h, const vg_ba_problem* in, double*
     if (e == hipSuccess && prior_r && n) e = hipMemcpy(prior_r, d_qr, (size_t)n * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) { h->err = std::string("eval_factors: ") + hipGetErrorString(e); return VG_ERR_HIP; }
+    return VG_OK;
+}
+
+// ---- capacities every layout is built for at least (build_layout) ---------------------------------------------------------
+extern "C" int vg_ba_reserve(vg_handle* h, int max_landmarks, int max_factors, int max_obs, int max_prior_n) {
+    if (!h || max_landmarks < 0 || max_factors < 0 || max_obs < 0 || max_prior_n < 0) return VG_ERR_BAD_ARG;
+    h->ba.res_L = max_landmarks; h->ba.res_F = max_factors; h->ba.res_O = max_obs; h->ba.res_N = max_prior_n;
+    h->ba.uploaded = false;
+    return VG_OK;
+}
+
+// ---- windows that stay on the device from frame to frame (kernels: csrc/ba_seq.hip) ---------------------------------------
+extern "C" hipError_t ba_seq_launch_front(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, const SeqDev& S, int cur, hipStream_t stream);
+extern "C" hipError_t ba_seq_launch_slide(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, const SeqDev& S, int cur, hipStream_t stream);
+extern "C" int ba_seq_limits(int* ft_max, int* nin_max, int* hdr_ints, int* in_rows_off);
+
+static void seq_free(BaSeq& Q) {
+    SeqDev& D = Q.D;
+    for (int k = 0; k < 2; ++k) { (void)hipFree(D.ft_i[k]); (void)hipFree(D.ft_d[k]); D.ft_i[k] = nullptr; D.ft_d[k] = nullptr; }
+    (void)hipFree(D.sp); (void)hipFree(D.in_i); (void)hipFree(D.in_d); (void)hipFree(D.info);
+    D.sp = nullptr; D.in_i = nullptr; D.in_d = nullptr; D.info = nullptr;
+    Q.h_in_i.release(); Q.h_in_d.release(); Q.h_info.release();
+    Q.active = false;
+}
+extern "C" void ba_seq_release(vg_handle* h) { seq_free(h->ba.seq); }
+
+extern "C" int vg_ba_seq_end(vg_handle* h) {
+    if (!h) return VG_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    seq_free(h->ba.seq);
+    return VG_OK;
+}
+
+extern "C" int vg_ba_seq_begin(vg_handle* h, int nwin, const vg_ba_seq_config* cfg, const vg_ba_problem* const* windows,
+                               const vg_ba_tracks* const* tracks) {
+    VG_RANGE("vg_ba_seq_begin");
+    if (!h || nwin <= 0 || !cfg || !windows || !tracks) return VG_ERR_BAD_ARG;
+    for (int w = 0; w < nwin; ++w) if (!windows[w] || !tracks[w]) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    BaSeq& Q = B.seq;
+    int ft_max = 0, nin_max = 0, hdr_ints = 0, rows_off = 0;
+    const int l_max = ba_seq_limits(&ft_max, &nin_max, &hdr_ints, &rows_off);
+    const int K = windows[0]->K;
+    const int FT = cfg->max_features, NIN = cfg->max_new_obs;
+    const int Lres = cfg->max_landmarks > 0 ? cfg->max_landmarks : FT;
+    const int Fres = cfg->max_factors > 0 ? cfg->max_factors : 6 * Lres;
+    if (FT < 1 || FT > ft_max || NIN < 1 || NIN > nin_max || Lres > l_max) { h->err = "vg_ba_seq_begin: capacities outside the kernels' tables"; return VG_ERR_UNSUPPORTED; }
+    if (K < 4 || K > 12) { h->err = "vg_ba_seq_begin: a sequence needs 4 <= K <= 12 frames"; return VG_ERR_UNSUPPORTED; }
+    if (B.allreduce || B.force_large) { h->err = "vg_ba_seq_begin: not offered on the large-window path"; return VG_ERR_UNSUPPORTED; }
+    for (int w = 0; w < nwin; ++w) {
+        const vg_ba_problem* p = windows[w];
+        const vg_ba_tracks* t = tracks[w];
+        if (p->relo_n != 0) { h->err = "vg_ba_seq_begin: relocalisation factors are not offered in a sequence"; return VG_ERR_UNSUPPORTED; }
+        if (p->prior_n == VG_PRIOR_RESIDENT) { h->err = "vg_ba_seq_begin: the first prior comes from the host"; return VG_ERR_BAD_ARG; }
+        if (p->max_iters != windows[0]->max_iters) { h->err = "vg_ba_seq_begin: windows must share max_iters"; return VG_ERR_BAD_ARG; }
+        if (t->n_features < 0 || t->n_features > FT || (t->n_features > 0 && (!t->feature_id || !t->start_frame || !t->n_obs || !t->depth || !t->obs))) {
+            h->err = "vg_ba_seq_begin: bad track table"; return VG_ERR_BAD_ARG;
+        }
+        for (int f = 0; f < t->n_features; ++f)
+            if (t->n_obs[f] < 1 || t->start_frame[f] < 0 || t->start_frame[f] + t->n_obs[f] > K - 1) {
+                h->err = "vg_ba_seq_begin: a track reaches beyond frame K - 2 (the newest slot is filled by the first step)"; return VG_ERR_BAD_ARG;
+            }
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    seq_free(Q);
+    // the batch layout, the states, the pre-integrations and the first prior go the ordinary way (the windows' own landmark
+    // tables are packed too and overwritten by the first step)
+    B.res_L = std::max(B.res_L, Lres); B.res_F = std::max(B.res_F, Fres); B.res_O = std::max(B.res_O, Fres + Lres);
+    B.res_N = std::max(B.res_N, 6 * K + 9 * 2 + 6 + 1);
+    std::vector<int> flags(nwin, VG_MARGIN_OLD);
+    int rc = vg_ba_batch_upload(h, nwin, windows, flags.data());
+    if (rc) return rc;
+    if (B.L.big) { h->err = "vg_ba_seq_begin: window too wide for the single-workgroup pipeline"; B.uploaded = false; return VG_ERR_UNSUPPORTED; }
+    std::fill(B.nL.begin(), B.nL.end(), B.L.Lcap);    // (state downloads: vg_ba_state::inv_depth, if given, takes the whole landmark slab)
+    SeqDev& D = Q.D;
+    D.K = K; D.FT = FT; D.NIN = NIN;
+    D.fi_stride = up(hdr_ints + 5 * FT, 8);
+    D.fd_stride = up(FT + FT * K * 8, 8);
+    D.ii_stride = up(8 + NIN, 8);
+    D.id_stride = up(rows_off + NIN * 8, 8);
+    D.sp_stride = up(2 + 2 * (K + 4), 8);
+    D.max_iters = windows[0]->max_iters; D.marg_mode = B.marg_mode;
+    D.init_depth = cfg->init_depth; D.min_parallax = cfg->min_parallax;
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(h, hipMalloc((void**)&D.ft_i[k], (size_t)nwin * D.fi_stride * sizeof(int)));
+        HIPCHK(h, hipMalloc((void**)&D.ft_d[k], (size_t)nwin * D.fd_stride * sizeof(double)));
+        HIPCHK(h, hipMemsetAsync(D.ft_i[k], 0, (size_t)nwin * D.fi_stride * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(D.ft_d[k], 0, (size_t)nwin * D.fd_stride * sizeof(double), h->stream));
+    }
+    HIPCHK(h, hipMalloc((void**)&D.sp, (size_t)nwin * D.sp_stride * sizeof(int)));
+    HIPCHK(h, hipMalloc((void**)&D.in_i, (size_t)nwin * D.ii_stride * sizeof(int)));
+    HIPCHK(h, hipMalloc((void**)&D.in_d, (size_t)nwin * D.id_stride * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&D.info, (size_t)nwin * VG_SEQ_INFO_INTS * sizeof(int)));
+    HIPCHK(h, hipMemsetAsync(D.info, 0, (size_t)nwin * VG_SEQ_INFO_INTS * sizeof(int), h->stream));
+    // track tables and prior block tables
+    std::vector<int> ti((size_t)nwin * D.fi_stride, 0), sp((size_t)nwin * D.sp_stride, 0);
+    std::vector<double> td((size_t)nwin * D.fd_stride, 0.0);
+    for (int w = 0; w < nwin; ++w) {
+        const vg_ba_tracks* t = tracks[w];
+        int* i = ti.data() + (size_t)w * D.fi_stride;
+        double* d = td.data() + (size_t)w * D.fd_stride;
+        i[0] = t->n_features;
+        size_t row = 0;
+        for (int f = 0; f < t->n_features; ++f) {
+            i[hdr_ints + f] = t->feature_id[f];
+            i[hdr_ints + FT + f] = t->start_frame[f];
+            i[hdr_ints + 2 * FT + f] = t->n_obs[f];
+            i[hdr_ints + 3 * FT + f] = t->solve_flag ? t->solve_flag[f] : 0;
+            i[hdr_ints + 4 * FT + f] = -1;
+            d[f] = t->depth[f];
+            for (int j = 0; j < t->n_obs[f]; ++j, ++row) {
+                const double* r = t->obs + row * 8;                       // [x y z u v vx vy cur_td]
+                double* o = d + FT + ((size_t)f * K + j) * 8;             // [x y u v vx vy cur_td z]
+                o[0] = r[0]; o[1] = r[1]; o[2] = r[3]; o[3] = r[4]; o[4] = r[5]; o[5] = r[6]; o[6] = r[7]; o[7] = r[2];
+            }
+        }
+        const BaBatch::PriorSlot& s = B.slot[w];
+        int* q = sp.data() + (size_t)w * D.sp_stride;
+        q[0] = s.n; q[1] = s.n ? s.nb : 0;
+        for (int b = 0; b < q[1]; ++b) { q[2 + b] = s.kind[b]; q[2 + (K + 4) + b] = s.idx[b]; }
+    }
+    HIPCHK(h, hipMemcpy(D.ft_i[0], ti.data(), ti.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(D.ft_d[0], td.data(), td.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(D.sp, sp.data(), sp.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    Q.nwin = nwin; Q.cur = 0; Q.active = true;
+    B.solved_recorded = false;
+    return VG_OK;
+}
+
+extern "C" int vg_ba_seq_step_async(vg_handle* h, int nwin, const vg_ba_frame* const* frames) {
+    VG_RANGE("vg_ba_seq_step_async");
+    if (!h || !frames) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    BaSeq& Q = B.seq;
+    if (!Q.active || !B.uploaded || nwin != Q.nwin || nwin != B.nwin) { h->err = "vg_ba_seq_step_async: no sequence with that many windows"; return VG_ERR_BAD_ARG; }
+    const SeqDev& D = Q.D;
+    int rows_off = 0;
+    (void)ba_seq_limits(nullptr, nullptr, nullptr, &rows_off);
+    for (int w = 0; w < nwin; ++w) {
+        const vg_ba_frame* f = frames[w];
+        if (!f || !f->imu_new || f->n_obs < 0 || (f->n_obs > 0 && (!f->feature_id || !f->obs))) return VG_ERR_BAD_ARG;
+        if (f->n_obs > D.NIN) { h->err = "vg_ba_seq_step_async: more observations than vg_ba_seq_config::max_new_obs"; return VG_ERR_UNSUPPORTED; }
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    // the staging buffers are re-used: the previous step's copies must have left them
+    HIPCHK(h, hipEventSynchronize(h->ev_join));
+    HIPCHK(h, Q.h_in_i.resize((size_t)nwin * D.ii_stride));
+    HIPCHK(h, Q.h_in_d.resize((size_t)nwin * D.id_stride));
+    auto put_imu = [](double* d, const vg_imu_preint& m) {
+        d[0] = m.sum_dt;
+        memcpy(d + 1, m.delta_p, 24); memcpy(d + 4, m.delta_q, 32); memcpy(d + 8, m.delta_v, 24);
+        memcpy(d + 11, m.linearized_ba, 24); memcpy(d + 14, m.linearized_bg, 24);
+        memcpy(d + 17, m.jacobian, 225 * 8); memcpy(d + 242, m.covariance, 225 * 8);
+    };
+    for_windows(nwin, [&](int, int w) {
+        const vg_ba_frame* f = frames[w];
+        int* i = Q.h_in_i.data() + (size_t)w * D.ii_stride;
+        double* d = Q.h_in_d.data() + (size_t)w * D.id_stride;
+        i[0] = f->n_obs; i[1] = f->imu_merged ? 1 : 0; i[2] = f->imu_new->valid; i[3] = f->imu_merged ? f->imu_merged->valid : 0;
+        i[4] = i[5] = i[6] = i[7] = 0;
+        memcpy(i + 8, f->feature_id, sizeof(int) * f->n_obs);
+        memcpy(d, f->pose, 7 * 8); memcpy(d + 7, f->speedbias, 9 * 8);
+        put_imu(d + 16, *f->imu_new);
+        if (f->imu_merged) put_imu(d + 16 + BA_IMU_STRIDE, *f->imu_merged);
+        for (int k = 0; k < f->n_obs; ++k) { memcpy(d + rows_off + (size_t)k * 8, f->obs + (size_t)k * 7, 7 * 8); d[rows_off + (size_t)k * 8 + 7] = 0.0; }
+    });
+    HIPCHK(h, hipMemcpyAsync(D.in_i, Q.h_in_i.data(), Q.h_in_i.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(D.in_d, Q.h_in_d.data(), Q.h_in_d.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_join, h->stream));
+    hipError_t e = ba_seq_launch_front(B.L, B.dL, B.P, D, Q.cur, h->stream);
+    if (e != hipSuccess) { h->err = std::string("launch of the sequence front kernels: ") + hipGetErrorString(e); return VG_ERR_HIP; }
+    int rc = launch_solve_in_mode(h);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));           // states final (vg_ba_batch_download_state)
+    B.solved_recorded = true;
+    B.any_margin = true;
+    HIPCHK(h, ba_launch_marg(B.L, B.dL, B.P, h->stream));
+    e = ba_launch_carry_prior(B.nwin, B.P.mout, B.P.miout, B.L.mo_J0, B.L.mo_r0, B.L.mo_x0, B.L.mo_stride, B.L.mi_stride, B.L.mcap,
+                              9 * (B.L.K + 4), B.P.pri, B.L.po_x0, B.L.po_r0, B.L.po_J0, B.L.pld, B.L.pstride, h->stream);
+    if (e == hipSuccess) e = ba_seq_launch_slide(B.L, B.dL, B.P, D, Q.cur, h->stream);
+    if (e != hipSuccess) { h->err = std::string("launch of the sequence slide kernels: ") + hipGetErrorString(e); return VG_ERR_HIP; }
+    Q.cur ^= 1;
+    B.mout_pending = false;                                      // (carried already; the slots' host mirror is not maintained in a sequence)
+    return VG_OK;
+}
+
+extern "C" int vg_ba_seq_info(vg_handle* h, int nwin, int* info) {
+    if (!h || !info) return VG_ERR_BAD_ARG;
+    BaSeq& Q = h->ba.seq;
+    if (!Q.active || nwin != Q.nwin) return VG_ERR_BAD_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(info, Q.D.info, (size_t)nwin * VG_SEQ_INFO_INTS * sizeof(int), hipMemcpyDeviceToHost));
+    return VG_OK;
+}
+
+extern "C" int vg_ba_seq_get_tracks(vg_handle* h, int window, int cap, int* n_features, int* feature_id, int* start_frame, int* n_obs,
+                                    int* solve_flag, double* depth, double* obs) {
+    if (!h || !n_features || cap < 0) return VG_ERR_BAD_ARG;
+    BaSeq& Q = h->ba.seq;
+    if (!Q.active || window < 0 || window >= Q.nwin) return VG_ERR_BAD_ARG;
+    const SeqDev& D = Q.D;
+    int hdr_ints = 0;
+    (void)ba_seq_limits(nullptr, nullptr, &hdr_ints, nullptr);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<int> ti(D.fi_stride);
+    HIPCHK(h, hipMemcpy(ti.data(), D.ft_i[Q.cur] + (size_t)window * D.fi_stride, ti.size() * sizeof(int), hipMemcpyDeviceToHost));
+    const int n = ti[0];
+    *n_features = n;
+    if (n > cap) { h->err = "vg_ba_seq_get_tracks: capacity too small"; return VG_ERR_BAD_ARG; }
+    for (int f = 0; f < n; ++f) {
+        if (feature_id) feature_id[f] = ti[hdr_ints + f];
+        if (start_frame) start_frame[f] = ti[hdr_ints + D.FT + f];
+        if (n_obs) n_obs[f] = ti[hdr_ints + 2 * D.FT + f];
+        if (solve_flag) solve_flag[f] = ti[hdr_ints + 3 * D.FT + f];
+    }
+    const double* dsrc = D.ft_d[Q.cur] + (size_t)window * D.fd_stride;
+    if (depth && n) HIPCHK(h, hipMemcpy(depth, dsrc, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (obs && n) HIPCHK(h, hipMemcpy(obs, dsrc + D.FT, (size_t)n * D.K * 8 * sizeof(double), hipMemcpyDeviceToHost));
     return VG_OK;
 }

@@ -5,6 +5,7 @@
 
 extern "C" void fe_state_destroy(FeState* s);
 extern "C" void ba_graph_release(vg_handle* h);
+extern "C" void ba_seq_release(vg_handle* h);
 // (weak: builds without csrc/vg_rccl.hip — the CPU emulation of tests/simt — have no communicator to release)
 extern "C" int vg_ba_rccl_finalize(vg_handle* h) __attribute__((weak));
 
@@ -34,6 +35,7 @@ extern "C" int vg_destroy(vg_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     if (vg_ba_rccl_finalize) (void)vg_ba_rccl_finalize(h);
     ba_graph_release(h);
+    ba_seq_release(h);
     BaPtrs& P = h->ba.P;
     (void)hipFree(P.iarr); (void)hipFree(P.din); (void)hipFree(P.scr); (void)hipFree(P.out); (void)hipFree(P.iout);
     (void)hipFree(h->ba.dL);

@@ -24,6 +24,29 @@ struct PinnedBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; }
 };
 
+// Windows that stay on the device between frames (vg_ba_seq_*, csrc/ba_seq.hip): what the kernels get by value
+struct SeqDev {
+    int K, FT, NIN;                  // frames per window, capacity of the track table, capacity of one frame's observation list
+    int fi_stride, fd_stride;        // track table per window: ints [SEQ_HDR | id | start | nobs | solve_flag | landmark][FT], doubles [depth[FT] | obs[FT][K][8]]
+    int ii_stride, id_stride;        // frame staging per window: ints [n_obs, has_merged, valid_new, valid_merged, ... | id[NIN]], doubles [pose 7 | sb 9 | imu_new 472 | imu_merged 472 | rows NIN x 8]
+    int sp_stride;                   // prior block table per window: [n, nblocks | kind[K+4] | idx[K+4]]
+    int max_iters, marg_mode;
+    double init_depth, min_parallax;
+    int* ft_i[2];                    // two tables: the slide writes the other one
+    double* ft_d[2];
+    int* sp;
+    int* in_i;
+    double* in_d;
+    int* info;                       // [nwin][VG_SEQ_INFO_INTS]
+};
+struct BaSeq {
+    bool active = false;
+    int nwin = 0, cur = 0;
+    SeqDev D = {};
+    PinnedBuf<int> h_in_i, h_info;
+    PinnedBuf<double> h_in_d;
+};
+
 struct BaBatch {
     BaLayout L;
     BaLayout* dL = nullptr;          // device copy of L (kernels read it through scalar loads)
@@ -43,6 +66,8 @@ struct BaBatch {
     bool solved_recorded = false;    // ev_fork recorded behind ba_final_kernel of the current run
     bool force_large = false;        // vg_ba_set_large_window: take the large-window path whatever the size
     int marg_mode = 0;               // vg_ba_set_marg_mode: VG_MARG_SQRT (default) / VG_MARG_EIGEN
+    int res_L = 0, res_F = 0, res_O = 0, res_N = 0;   // vg_ba_reserve: capacities every layout is built for at least
+    BaSeq seq;                       // vg_ba_seq_*
     void* allreduce = nullptr;       // vg_allreduce_fn of the large-window path (nullptr: single rank)
     void* allreduce_user = nullptr;
     // ---- prior factors on the device (BaPtrs::pri).  slot[w] describes what window slot w holds: the block table of the last
