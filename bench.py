@@ -64,6 +64,69 @@ def make_chain(h, ba, seqs, packed, flags):
     return chain
 
 
+def bench_resident(ba, synth, seqs, nthr=4, rounds=3):
+    """Windows that stay on the device (vg_ba_seq_*): every thread walks its handle through the same CHAIN_FRAMES consecutive
+    frames of the sequences as the chained loop, but the window never crosses the boundary -- per frame the host sends the new
+    frame's observations, state guess and pre-integration (vg_ba_seq_step_async) and reads the states back.  Returns ms per
+    256-window frame (all threads together) and the per-step record of the last round."""
+    import threading
+    K = 11
+    src = [synth.FrameSource(q, noise_seed=1000 + i) for i, q in enumerate(seqs)]
+    wins, trks = zip(*[synth.sequence_inputs(s.initial_window(K, 0)) for s in src])
+    steps = []
+    for k in range(1 + CHAIN_FRAMES):                    # global frames K-1 .. K-1+CHAIN_FRAMES
+        g = K - 1 + k
+        frames = []
+        for s, q in zip(src, seqs):
+            ids, rows = s.image(g)
+            pose, sb = s.guess(g)
+            frames.append(dict(pose=pose, sb=sb, imu_new=q.imu[g - 1], imu_merged=None, ids=ids, obs=rows))
+        steps.append(ba.Handle.seq_pack_frames(frames))
+    hs = [ba.Handle() for _ in range(nthr)]
+    errs, info = [], None
+
+    def begin(hh):
+        # min_parallax = 0: every frame is a key frame (MARGIN_OLD), like the flags of the chained loop
+        hh.seq_begin(list(wins), list(trks), max_features=384, max_new_obs=384, max_landmarks=256, max_factors=1536, min_parallax=0.0)
+        hh.seq_step(steps[0])                             # first frame: no prior yet; creates it
+        hh.ba_prepare_download()
+        hh.sync()
+
+    def worker(hh):
+        try:
+            for st in steps[1:]:
+                hh.seq_step(st)
+                rc = hh.ba_download_state_raw()
+                if rc != 0:
+                    errs.append(rc)
+        except Exception as ex:                           # noqa: BLE001
+            errs.append(repr(ex))
+
+    total = 0.0
+    for r in range(rounds + 1):
+        for hh in hs:
+            begin(hh)
+        ts = [threading.Thread(target=worker, args=(hh,)) for hh in hs]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if r > 0:                                         # round 0 warms up (allocations, graph capture)
+            total += time.perf_counter() - t0
+    info = hs[0].seq_info()
+    for hh in hs:
+        hh.seq_end(); hh.close()
+    if errs:
+        raise RuntimeError(f"resident-sequence loop failed: {errs[:3]}")
+    bad = [i for i in info if i['status'] != 0]
+    if bad:
+        raise RuntimeError(f"resident-sequence loop: capacity exceeded in {len(bad)} windows")
+    ms = total / (rounds * CHAIN_FRAMES * nthr) * 1e3
+    return ms, {"host_threads": nthr, "frames": CHAIN_FRAMES, "landmarks_mean": float(np.mean([i['n_landmarks'] for i in info])),
+                "factors_mean": float(np.mean([i['n_factors'] for i in info])), "tracks_mean": float(np.mean([i['n_features'] for i in info]))}
+
+
 FE_CAMS = 256                # independent camera streams per GPU in the front-end leg (like the 256 windows of the BA leg; with 64 the LK launch is
                              # dominated by its slowest tracks: 137 us for 9600 tracks against 9.7 ns per additional track, tests/manual/gpu_lk_scaling.py)
 FE_BYTES_PER_FEATURE = 8188  # SURVEY.md 8(d): (pyramid 592,200 B + LK 636,000 B) per 752x480 frame / 150 features
@@ -535,6 +598,11 @@ def main():
     for hh in th_handles:
         if hh not in handles:
             hh.close()
+    # windows that stay on the device from frame to frame (vg_ba_seq_*): informational, never fails the bench
+    try:
+        resident_ms, resident_info = bench_resident(ba, synth, seqs)
+    except Exception as ex:                               # noqa: BLE001
+        resident_ms, resident_info = None, {"error": repr(ex)}
     h.ba_upload(packed, flags)
     h.ba_run_async()
 
@@ -686,6 +754,10 @@ def main():
                                         "chained_ms_per_batch": chained_ms, "chained_frames": CHAIN_FRAMES,
                                         "chained_solves_per_s": nwin / (chained_ms * 1e-3),
                                         "chained_over_device_resident": (nwin / (chained_ms * 1e-3)) / value,
+                                        "resident_sequence_ms_per_batch": resident_ms,
+                                        "resident_sequence_solves_per_s": (nwin / (resident_ms * 1e-3)) if resident_ms else None,
+                                        "resident_sequence_over_device_resident": ((nwin / (resident_ms * 1e-3)) / value) if resident_ms else None,
+                                        "resident_sequence": resident_info,
                                         "what": "host buffers in, host buffers out: vg_ba_batch_upload (pack + H2D) + all launches + "
                                                 "vg_ba_batch_download (D2H + unpack), per GPU; sync = one batch at a time, nothing "
                                                 "overlapped; overlapped = two handles (streams, pinned staging) driven by one host thread, the "
@@ -695,6 +767,9 @@ def main():
                                                 "GPU; chained = the same 8 threads, each walking its handle through CHAIN_FRAMES consecutive frames "
                                                 "of its 256 sequences: frame 2 uploads its prior, the following frames use the prior the previous "
                                                 "solve's marginalization left in HBM (VG_PRIOR_RESIDENT) and download the states only; "
+                                                "resident_sequence = windows that stay on the device (vg_ba_seq_*): 4 threads, per frame only the "
+                                                "new observations / state guess / pre-integration go in and the states come back, the track "
+                                                "bookkeeping (addFeatureCheckParallax, triangulate, problem tables, slideWindow) runs on the device; "
                                                 "NOT the metric (bench contract: `value` is device-resident)"},
         }
     fe_out = bench_fe(h, synth, max(args.steps, 10), args.warmup, rank, rank == 0 and world == 1 and not args.no_cpu_baseline)

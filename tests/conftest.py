@@ -71,6 +71,14 @@ def simt_handle():
     h.close()
 
 
+def new_handle():
+    """A further handle of the kind the `handle` fixture gives (tests that drive two handles side by side)."""
+    if os.environ.get("VINS_TEST_SIMT") == "1":
+        return _simt_handle()
+    from vins_mono_amd import ba
+    return ba.Handle()
+
+
 if os.environ.get("VINS_TEST_SIMT") == "1":
     # development switch: run the `-m gpu` parity tests against the emulated library (slow; BA-sized problems only)
     @pytest.fixture(scope="session")

@@ -21,3 +21,13 @@ def test_resident_sequence_equals_host_bookkeeping(two_handles, min_parallax, wa
     flags = M.run_both(h_seq, h_ref, seeds=seeds, K=11, L=70, n_steps=n_steps, min_parallax=min_parallax, max_features=128, check=M.check_step)
     flat = [f for fr in flags for f in fr]
     assert (M.NEW in flat) == want_new and (M.OLD in flat or want_new)
+
+
+def test_resident_sequence_against_the_reference_loop(two_handles):
+    """The reference's own processIMU / processImage loop (oracle/_ref) against the device-resident sequence, emulated kernels,
+    five frames with non-keyframes among them (the full-length runs are tests/test_seq_gpu.py)."""
+    from oracle import ref as R
+    if not R.available():
+        pytest.skip("oracle/_ref is not built")
+    flags, worst, flips = M.run_against_reference(two_handles[0], 0.1, n_frames=15)
+    assert 1 in flags

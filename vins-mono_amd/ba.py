@@ -476,9 +476,11 @@ class Handle:
         for p in self._packed:                            # size of the inverse-depth slab a state download fills
             p.L = (int(max_landmarks or max_features) + 15) // 16 * 16
 
-    def seq_step(self, frames):
-        """frames[w]: dict(pose (7,), sb (9,), imu_new, imu_merged (pre-integration dicts; imu_merged None unless the frame before
-        was dropped as a non-keyframe), ids (n,), obs (n, 7) [x y z u v vx vy])."""
+    @staticmethod
+    def seq_pack_frames(frames):
+        """The vg_ba_frame* array of one step, built once (what a native caller holds): frames[w] = dict(pose (7,), sb (9,), imu_new,
+        imu_merged (pre-integration dicts; imu_merged None unless the frame before was dropped as a non-keyframe), ids (n,),
+        obs (n, 7) [x y z u v vx vy])."""
         n = len(frames)
         fs, keep = (Frame * n)(), []
         for w, f in enumerate(frames):
@@ -493,7 +495,12 @@ class Handle:
             fs[w].n_obs = len(ids)
             fs[w].feature_id, fs[w].obs = _ip(ids), _dp(obs)
         fp = (C.POINTER(Frame) * n)(*[C.pointer(fs[w]) for w in range(n)])
-        self._chk(self.lib.vg_ba_seq_step_async(self.h, n, fp), "vg_ba_seq_step_async")
+        return (n, fp, fs, keep)
+
+    def seq_step(self, frames):
+        """One frame for every window (vg_ba_seq_step_async); frames: a list of dicts or the result of seq_pack_frames."""
+        packed = frames if isinstance(frames, tuple) else self.seq_pack_frames(frames)
+        self._chk(self.lib.vg_ba_seq_step_async(self.h, packed[0], packed[1]), "vg_ba_seq_step_async")
 
     def seq_states(self, allow_numeric_failure=False):
         """States of the windows as the last step solved them (before the slide) and the summaries."""

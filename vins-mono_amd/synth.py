@@ -309,6 +309,80 @@ class SyntheticSequence:
         return prob
 
 
+class FrameSource:
+    """Per-frame inputs of a sliding-window estimator (device-resident sequences, vg_ba_seq_*).
+    Frames of a synth.SyntheticSequence the way the estimator node receives them: the `image` map of a frame (feature id =
+    landmark number, rows [x y 1 u v vx vy]), the IMU samples of an interval, noisy state guesses."""
+
+    def __init__(self, seq, noise_seed=0):
+        self.seq, self.rng = seq, np.random.default_rng(noise_seed)
+        self.c = seq.cfg
+        self.h = seq.frame_dt / seq.imu_per_frame
+
+    def image(self, f):
+        seq, c = self.seq, self.c
+        ids, rows = [], []
+        for lid, lm in enumerate(seq.lm):
+            k = f - lm['f0']
+            if 0 <= k < len(lm['obs']):
+                xy = lm['obs'][k]
+                prev = lm['obs'][k - 1] if k > 0 else xy
+                vel = (xy - prev) / seq.frame_dt
+                ids.append(lid)
+                rows.append([xy[0], xy[1], 1.0, c['fx'] * xy[0] + c['cx'], c['fy'] * xy[1] + c['cy'], vel[0], vel[1]])
+        return np.array(ids, np.int32), np.array(rows, float).reshape(-1, 7)
+
+    def samples(self, f):
+        """(dt, acc, gyr) of the interval f -> f + 1; entry 0 = the first measurement (dt 0)."""
+        seq = self.seq
+        t = seq.times[f]
+        out = [(0.0,) + seq._imu_sample(t)]
+        for s in range(1, seq.imu_per_frame + 1):
+            out.append((self.h,) + seq._imu_sample(t + s * self.h))
+        return out
+
+    def preintegrate(self, samples, ba, bg):
+        c = self.c
+        return preintegrate(samples, ba, bg, c['acc_n'], c['gyr_n'], c['acc_w'], c['gyr_w'])
+
+    def guess(self, f):
+        rng, seq = self.rng, self.seq
+        th = rng.normal(0, np.radians(0.3), 3)
+        q = _qmul(_R2q(seq.Rm[f]), np.array([th[0] / 2, th[1] / 2, th[2] / 2, 1.0]))
+        q /= np.linalg.norm(q)
+        return (np.concatenate([seq.P[f] + rng.normal(0, 0.03, 3), q]), np.concatenate([seq.V[f] + rng.normal(0, 0.03, 3), seq.ba_lin, seq.bg_lin]))
+
+    def initial_window(self, K, g0=0):
+        """The state between two frames: global frames g0 .. g0 + K - 2 are in the window, the newest slot is a copy of the
+        frame before it (what slideWindow leaves), no prior yet, no depths yet."""
+        seq = self.seq
+        pose, sb = zip(*[self.guess(g0 + i) for i in range(K - 1)])
+        pose, sb = list(pose) + [pose[-1]], list(sb) + [sb[-1]]
+        smp = [self.samples(g0 + i) for i in range(K - 2)] + [None]
+        imu = [self.preintegrate(s, seq.ba_lin, seq.bg_lin) for s in smp[:-1]] + [None]
+        feats = {}
+        for f in range(g0, g0 + K - 1):
+            ids, rows = self.image(f)
+            for fid, r in zip(ids, rows):
+                ft = feats.setdefault(int(fid), dict(id=int(fid), start=f - g0, obs=[], depth=-1.0))
+                ft['obs'].append(list(r) + [0.0])
+        tracks = list(feats.values())                     # list order of f_manager.feature: by first frame, ids ascending inside a frame
+        return dict(K=K, base=seq._base(), pose=np.array(pose), sb=np.array(sb), imu=imu, samples=smp, tracks=tracks)
+
+
+def sequence_inputs(win):
+    """(prob dict, tracks dict) of an initial window (FrameSource.initial_window) for vg_ba_seq_begin."""
+    prob = dict(win['base'])
+    prob.update(pose=win['pose'].copy(), sb=win['sb'].copy(), prior=None, relo=None, imu=[None if m is None else dict(m) for m in win['imu']],
+                lm_start=np.zeros(0, np.int32), lm_nobs=np.zeros(0, np.int32), obs_off=np.zeros(0, np.int32), obs=np.zeros((0, 7)),
+                inv_depth=np.zeros(0))
+    t = win['tracks']
+    tracks = dict(id=np.array([f['id'] for f in t], np.int32), start=np.array([f['start'] for f in t], np.int32),
+                  nobs=np.array([len(f['obs']) for f in t], np.int32), depth=np.array([f['depth'] for f in t], float),
+                  obs=np.array([r for f in t for r in f['obs']], float).reshape(-1, 8))
+    return prob, tracks
+
+
 # ----------------------------------------------------------------------------- front-end frames
 def synth_frame(seed, width=752, height=480):
     """EuRoC-shaped textured frame (SURVEY.md 8(d) configs[1]): value noise on a (width/8 x height/8) lattice,
