@@ -362,3 +362,110 @@ def run_against_reference(h_seq, min_parallax, n_frames=24):
     assert n_flips <= max(1, len(ref) // 4)
     print("resident sequence vs the reference's loop: worst state difference", worst, "trust-region flips", n_flips)
     return flags, worst, n_flips
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def write_seq_file(path, sources, K, n_frames, min_parallax=10.0 / 460.0, init_depth=5.0):
+    """frames.bin of `vins_replay seq` (vins-mono_amd/host/replay_main.cpp): for every source the window between two frames, then
+    `n_frames` frames at the level of the node's callbacks (IMU samples since the last frame + the image map)."""
+    import struct
+    seq0 = sources[0].seq
+    S = seq0.imu_per_frame
+    c = seq0.cfg
+    with open(path, "wb") as f:
+        f.write(struct.pack("<5i", 0x31515356, len(sources), n_frames, K, S))
+        f.write(np.array([c['acc_n'], c['gyr_n'], c['acc_w'], c['gyr_w']], float).tobytes())
+        f.write(np.array([c['g_norm'], c['focal'], min_parallax, init_depth], float).tobytes())
+        wins = []
+        for src in sources:
+            seq = src.seq
+            win = src.initial_window(K, 0)
+            wins.append(win)
+            f.write(np.asarray(win['base']['ex'], float).tobytes())
+            f.write(np.concatenate([seq.ba_lin, seq.bg_lin]).tobytes())
+            for k in range(K):
+                f.write(np.array([seq.times[min(k, K - 2)]], float).tobytes())
+                f.write(np.asarray(win['pose'][k], float).tobytes()); f.write(np.asarray(win['sb'][k], float).tobytes())
+            for k in range(K - 2):
+                smp = win['samples'][k]
+                f.write(np.concatenate([smp[0][1], smp[0][2]]).astype(float).tobytes())
+                for dt, a, g in smp[1:]:
+                    f.write(np.concatenate([[dt], a, g]).astype(float).tobytes())
+            last = win['samples'][K - 3][-1]
+            f.write(np.concatenate([last[1], last[2]]).astype(float).tobytes())
+            f.write(struct.pack("<i", len(win['tracks'])))
+            for t in win['tracks']:
+                f.write(struct.pack("<3i", t['id'], t['start'], len(t['obs'])))
+                f.write(np.array([t['depth']], float).tobytes())
+                f.write(np.asarray(t['obs'], float).tobytes())
+        for w in range(n_frames):
+            g = K - 1 + w
+            for src in sources:
+                f.write(np.array([src.seq.times[g]], float).tobytes())
+                for dt, a, gy in src.samples(g - 1)[1:]:
+                    f.write(np.concatenate([[dt], a, gy]).astype(float).tobytes())
+                ids, rows = src.image(g)
+                f.write(struct.pack("<i", len(ids)))
+                for fid, r in zip(ids, rows):
+                    f.write(struct.pack("<i", int(fid)))
+                    f.write(np.asarray(r, float).tobytes())
+    return wins
+
+
+def drive_sequence(h_seq, sources, wins, K, n_frames, min_parallax=10.0 / 460.0, init_depth=5.0):
+    """The same frames through the Python binding: what ResidentEstimators does on the host (processIMU's propagation, the
+    pre-integration of the running and of merged intervals), restated here.  Returns [frame][source] = (P, q_wxyz, V, flag, n)."""
+    from oracle import ref as R
+    n = len(sources)
+    probs, trks = zip(*[synth.sequence_inputs(w) for w in wins])
+    h_seq.seq_begin(list(probs), list(trks), max_features=512, max_new_obs=512, init_depth=init_depth, min_parallax=min_parallax)
+    newest = [(w['pose'][K - 1].copy(), w['sb'][K - 1].copy()) for w in wins]
+    prev = [dict(samples=list(w['samples'][K - 3]), ba=s.seq.ba_lin, bg=s.seq.bg_lin) for w, s in zip(wins, sources)]
+    merged = [None] * n
+    out = []
+    for w in range(n_frames):
+        g = K - 1 + w
+        frames, cur = [], []
+        for i, src in enumerate(sources):
+            smp = src.samples(g - 1)
+            rec = src.preintegrate(smp, newest[i][1][3:6], newest[i][1][6:9])
+            pose, sb = _propagate(newest[i][0], newest[i][1], smp, src.seq.cfg['g_norm'])
+            ids, rows = src.image(g)
+            frames.append(dict(pose=pose, sb=sb, imu_new=rec, imu_merged=merged[i], ids=ids, obs=rows))
+            cur.append(dict(samples=smp, ba=newest[i][1][3:6].copy(), bg=newest[i][1][6:9].copy()))
+        h_seq.seq_step(frames)
+        sts, _ = h_seq.seq_states()
+        info = h_seq.seq_info()
+        row = []
+        for i, src in enumerate(sources):
+            st = sts[i]
+            newest[i] = (st['pose'][K - 1].copy(), st['sb'][K - 1].copy())
+            if info[i]['flag'] == NEW:
+                prev[i]['samples'] = prev[i]['samples'] + cur[i]['samples'][1:]
+                merged[i] = src.preintegrate(prev[i]['samples'], prev[i]['ba'], prev[i]['bg'])
+            else:
+                prev[i], merged[i] = cur[i], None
+            q = st['pose'][K - 1][3:]
+            qm = R.quat_from_R(q2R(q))                              # (the C++ side prints Quaterniond(Rs[WINDOW_SIZE]))
+            row.append((st['pose'][K - 1][:3].copy(), np.array([qm[3], qm[0], qm[1], qm[2]]), st['sb'][K - 1][:3].copy(), info[i]['flag'], info[i]['n_after']))
+        out.append(row)
+    h_seq.seq_end()
+    return out
+
+
+def compare_replay_csv(csv_path, expected, n, tol=1e-6):
+    lines = [l.split(',') for l in open(csv_path).read().strip().splitlines()]
+    assert len(lines) == len(expected) * n
+    worst = 0.0
+    for k, l in enumerate(lines):
+        w, i = divmod(k, n)
+        assert int(l[0]) == i
+        P, q, V, flag, nf = expected[w][i]
+        got = np.array(list(map(float, l[2:12])))
+        if np.dot(got[3:7], q) < 0:
+            q = -q
+        e = np.abs(got - np.concatenate([P, q, V])).max()
+        worst = max(worst, e)
+        assert int(l[12]) == flag and int(l[13]) == nf and int(l[14]) == 0, (w, i, l[12:], flag, nf)
+        assert e < tol, (w, i, e)
+    return worst

@@ -85,3 +85,24 @@ def test_resident_sequence_against_the_reference_loop(two_handles, min_parallax,
         pytest.skip("oracle/_ref is not built")
     flags, worst, flips = M.run_against_reference(two_handles[0], min_parallax, n_frames=24)
     assert (1 in flags) == expect_second_new and 0 in flags
+
+
+def test_cpp_resident_estimators_replay(two_handles, tmp_path):
+    """`vins_replay seq`: the C++ host side of the sequences (ResidentEstimators: processIMU / processImage / solve, hand-over of an
+    Estimator's window) on the GPU against the same frames driven through the Python binding."""
+    import os
+    import subprocess
+    from vins_mono_amd import synth
+    if os.environ.get("VINS_TEST_SIMT") == "1":
+        pytest.skip("the emulated variant is tests/test_seq_simt.py")
+    K, n_frames, mp = 11, 10, 0.25
+    mk = lambda: [M.FrameSource(synth.SyntheticSequence(s, n_frames=K + n_frames + 1, K=K + n_frames + 1, L=220), noise_seed=300 + s) for s in (81, 82, 83)]
+    M.write_seq_file(tmp_path / "frames.bin", mk(), K, n_frames, min_parallax=mp)
+    exe = os.path.join(conftest.ROOT, "vins-mono_amd", "lib", "vins_replay")
+    r = subprocess.run([exe, "seq", str(tmp_path / "frames.bin"), str(tmp_path / "out.csv")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    src = mk()
+    wins = [s.initial_window(K, 0) for s in src]
+    expected = M.drive_sequence(two_handles[0], src, wins, K, n_frames, min_parallax=mp)
+    worst = M.compare_replay_csv(tmp_path / "out.csv", expected, 3, tol=1e-5)
+    print("C++ ResidentEstimators vs the Python-driven sequence: worst difference", worst)

@@ -31,3 +31,26 @@ def test_resident_sequence_against_the_reference_loop(two_handles):
         pytest.skip("oracle/_ref is not built")
     flags, worst, flips = M.run_against_reference(two_handles[0], 0.1, n_frames=15)
     assert 1 in flags
+
+
+def test_cpp_resident_estimators_replay(two_handles, tmp_path):
+    """The C++ host side of the sequences (vins-mono_amd/host/resident_estimator.cpp: processIMU's propagation and sample
+    buffers, processImage, the batched pre-integration of running and merged intervals, the hand-over of an Estimator's window)
+    through `vins_replay seq`, linked against the emulated library, against the same frames driven through the Python binding."""
+    import os
+    import subprocess
+    from vins_mono_amd import synth
+    conftest._build_simt()
+    K, n_frames, mp = 11, 4, 0.25
+    mk = lambda: [M.FrameSource(synth.SyntheticSequence(s, n_frames=K + n_frames + 1, K=K + n_frames + 1, L=70), noise_seed=200 + s) for s in (21, 22)]
+    wins = M.write_seq_file(tmp_path / "frames.bin", mk(), K, n_frames, min_parallax=mp)
+    exe = os.path.join(conftest.SIMT_DIR, "_build", "vins_replay_simt")
+    r = subprocess.run([exe, "seq", str(tmp_path / "frames.bin"), str(tmp_path / "out.csv")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    src = mk()                                                # (same seeds: the generator's noise stream starts over)
+    wins = [s.initial_window(K, 0) for s in src]
+    expected = M.drive_sequence(two_handles[0], src, wins, K, n_frames, min_parallax=mp)
+    worst = M.compare_replay_csv(tmp_path / "out.csv", expected, 2)
+    flags = [e[3] for row in expected for e in row]
+    assert M.NEW in flags and M.OLD in flags
+    print("C++ ResidentEstimators vs the Python-driven sequence: worst difference", worst)

@@ -12,6 +12,12 @@
 //     Estimator::slideWindow() (state shift + removeBackShiftDepth).  Writes one line per window in the format of
 //     pubOdometry's result file (utility/visualization.cpp:157-172): stamp[ns], P, Q(w x y z), V of frame WINDOW_SIZE.
 //     sequence.bin is written by tests/replay_util.py.
+//
+//   vins_replay seq <frames.bin> <out.csv>
+//     N estimators whose windows stay ON THE DEVICE (ResidentEstimators, resident_estimator.h): the file holds, per estimator, the
+//     window as it stands between two frames (states, the IMU samples of its intervals, every track) and then W frames at the level
+//     of the node's callbacks: the IMU samples since the last frame (processIMU) and the `image` map (processImage).  One line per
+//     frame and estimator: index, stamp[ns], P, Q(w x y z), V of frame WINDOW_SIZE as solved, the key-frame decision, tracks left.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +26,7 @@
 #include <vector>
 #include "estimator.h"
 #include "feature_tracker.h"
+#include "resident_estimator.h"
 
 static int replay_fe(const char* in, const char* out) {
     FILE* f = fopen(in, "rb");
@@ -165,12 +172,105 @@ static int replay_ba(const char* in, const char* out) {
     return 0;
 }
 
+static int replay_seq(const char* in, const char* out) {
+    Reader rd{fopen(in, "rb")};
+    if (!rd.f) { perror("frames"); return 2; }
+    int hdr[5];
+    rd.i(hdr, 5);
+    if (hdr[0] != 0x31515356) { fprintf(stderr, "not a VSQ1 file\n"); return 2; }
+    const int N = hdr[1], W = hdr[2], K = hdr[3], S = hdr[4];
+    if (K != WINDOW_SIZE + 1) { fprintf(stderr, "file has K = %d, the Estimator is built for %d\n", K, WINDOW_SIZE + 1); return 2; }
+    double noise[4], par[4];
+    rd.d(noise, 4); rd.d(par, 4);
+    G_NORM = par[0]; FOCAL_LENGTH_D = par[1]; MIN_PARALLAX = par[2]; INIT_DEPTH = par[3];
+    ESTIMATE_EXTRINSIC = 0; ESTIMATE_TD = 0; NUM_ITERATIONS = 8;
+    ACC_N = noise[0]; GYR_N = noise[1]; ACC_W = noise[2]; GYR_W = noise[3];
+    vg_handle* h = nullptr;
+    if (vg_create(&h) != VG_OK) { fprintf(stderr, "vg_create failed (no CPU fallback)\n"); return 3; }
+    ResidentEstimators res(N, 512, 512);
+    for (int i = 0; i < N; ++i) {
+        // the estimator as the reference's code would hold it between two frames, then handed over
+        Estimator est;
+        double ex[7], bias[6], last[6];
+        rd.d(ex, 7); rd.d(bias, 6);
+        est.tic[0] = Vector3d(ex[0], ex[1], ex[2]);
+        est.ric[0] = Quaterniond(ex[6], ex[3], ex[4], ex[5]).toRotationMatrix();
+        for (int k = 0; k < K; ++k) {
+            FrameInit fr;
+            rd.d(&fr.t, 1); rd.d(fr.pose, 7); rd.d(fr.sb, 9);
+            set_frame(est, k, fr);
+        }
+        for (int k = 0; k + 2 < K; ++k) est.pre_integrations[k + 1] = preintegrate(h, rd, S, bias, noise);
+        rd.d(last, 6);
+        int L;
+        rd.i(&L, 1);
+        for (int l = 0; l < L; ++l) {
+            int meta[3];
+            double depth;
+            rd.i(meta, 3); rd.d(&depth, 1);
+            FeaturePerId f;
+            f.feature_id = meta[0]; f.start_frame = meta[1]; f.estimated_depth = depth;
+            for (int k = 0; k < meta[2]; ++k) {
+                double r[8];
+                rd.d(r, 8);
+                FeaturePerFrame fr;
+                fr.point = Vector3d(r[0], r[1], r[2]); fr.uv.x() = r[3]; fr.uv.y() = r[4]; fr.velocity.x() = r[5]; fr.velocity.y() = r[6]; fr.cur_td = r[7];
+                f.feature_per_frame.push_back(fr);
+            }
+            est.f_manager.feature.push_back(f);
+        }
+        res.handOver(i, est, Vector3d(last[0], last[1], last[2]), Vector3d(last[3], last[4], last[5]));
+        for (int k = 0; k <= WINDOW_SIZE; ++k) { delete est.pre_integrations[k]; est.pre_integrations[k] = nullptr; }
+    }
+    res.begin();
+    FILE* o = fopen(out, "w");
+    std::vector<double> smp((size_t)S * 7);
+    for (int w = 0; w < W; ++w) {
+        std::vector<double> stamp(N);
+        for (int i = 0; i < N; ++i) {
+            rd.d(&stamp[i], 1);
+            rd.d(smp.data(), S * 7);
+            for (int s = 0; s < S; ++s)
+                res.processIMU(i, smp[7 * s], Vector3d(smp[7 * s + 1], smp[7 * s + 2], smp[7 * s + 3]), Vector3d(smp[7 * s + 4], smp[7 * s + 5], smp[7 * s + 6]));
+            int n;
+            rd.i(&n, 1);
+            ResidentEstimators::Image image;
+            for (int k = 0; k < n; ++k) {
+                int id;
+                double r[7];
+                rd.i(&id, 1); rd.d(r, 7);
+                Eigen::Matrix<double, 7, 1> p;
+                for (int c = 0; c < 7; ++c) p(c, 0) = r[c];
+                image[id].emplace_back(0, p);
+            }
+            res.processImage(i, image);
+        }
+        res.solve();
+        for (int i = 0; i < N; ++i) {
+            // (the mirror is post-slide: the frame just solved sits in slot WINDOW_SIZE either way)
+            const ResidentEstimators::One& e = res[i];
+            const Quaterniond q(e.Rs[WINDOW_SIZE]);
+            fprintf(o, "%d,%.0f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%d,%d,%d\n", i, stamp[i] * 1e9, e.Ps[WINDOW_SIZE].x(), e.Ps[WINDOW_SIZE].y(),
+                    e.Ps[WINDOW_SIZE].z(), q.w(), q.x(), q.y(), q.z(), e.Vs[WINDOW_SIZE].x(), e.Vs[WINDOW_SIZE].y(), e.Vs[WINDOW_SIZE].z(),
+                    (int)e.marginalization_flag, e.n_features, e.status);
+        }
+    }
+    fclose(o);
+    fclose(rd.f);
+    vg_destroy(h);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 4 && !strcmp(argv[1], "fe")) return replay_fe(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "ba")) {
         try { return replay_ba(argv[2], argv[3]); }
         catch (const std::exception& e) { fprintf(stderr, "vins_replay ba: %s\n", e.what()); return 1; }
     }
-    fprintf(stderr, "usage: vins_replay fe <frames.bin> <out.txt> | vins_replay ba <sequence.bin> <out.csv>\n");
+    if (argc >= 4 && !strcmp(argv[1], "seq")) {
+        try { return replay_seq(argv[2], argv[3]); }
+        catch (const std::exception& e) { fprintf(stderr, "vins_replay seq: %s\n", e.what()); return 1; }
+    }
+    fprintf(stderr, "usage: vins_replay fe <frames.bin> <out.txt> | vins_replay ba <sequence.bin> <out.csv> | vins_replay seq <frames.bin> <out.csv>\n");
     return 2;
 }
