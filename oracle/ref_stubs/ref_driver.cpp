@@ -414,7 +414,14 @@ void vref_est_set_relo(void *p, int local_index, const double *relo_pose7, int n
     e->relo_frame_local_index = local_index;
     for (int k = 0; k < 7; k++) e->relo_Pose[k] = relo_pose7[k];
     e->match_points.clear();
+    // estimator.cpp:784-787 walks match_points with `while ((int)match_points[i].z() < feature_id) i++` and no bound: once the last
+    // match is consumed it reads PAST THE END of the vector, and what the heap holds there decides whether the loop stops and
+    // whether a phantom factor is added (seen here as a rare order-dependent difference of the initial cost).  The harness makes
+    // that memory defined: spare capacity behind the matches, filled with an id no feature has.
+    e->match_points.reserve(nmatch + 8);
     for (int k = 0; k < nmatch; k++) e->match_points.push_back(Vector3d(match_xyid[3 * k], match_xyid[3 * k + 1], match_xyid[3 * k + 2]));
+    for (int k = 0; k < 8; k++) e->match_points.push_back(Vector3d(0, 0, 1e9));
+    e->match_points.resize(nmatch);           // (size back to the matches; the sentinels stay in the spare capacity)
     e->prev_relo_t = vec3(prev_relo_t);
     e->prev_relo_r = mat3(prev_relo_r_rowmajor);
 }
