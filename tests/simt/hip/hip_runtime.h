@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
+#include <vector>
 
 #define SIMT_EMULATION 1
 #define __global__
@@ -255,9 +257,25 @@ hipError_t hipGraphExecDestroy(hipGraphExec_t x);
 hipError_t hipGraphLaunch(hipGraphExec_t x, hipStream_t s);
 namespace simt { bool capture_launch(hipStream_t s, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body); }
 
+// The explicit kernel arguments laid out as the kernarg segment of a real launch holds them (natural alignment, in order); the
+// hidden arguments would follow: __builtin_amdgcn_implicitarg_ptr() points there, and device code that rebuilds its context from
+// the kernarg segment (phase_ctx in ba_pipeline.hip) finds its arguments at the same negative offsets as on the GPU.
+namespace simt {
+extern thread_local const char* kernarg_end;
+template <typename T> inline void pack_kernarg(std::vector<char>& b, const T& v) {
+    const size_t o = (b.size() + alignof(T) - 1) / alignof(T) * alignof(T);
+    b.resize(o + sizeof(T));
+    memcpy(b.data() + o, &v, sizeof(T));
+}
+}  // namespace simt
+inline const char* __builtin_amdgcn_implicitarg_ptr() { return simt::kernarg_end; }
+
 template <typename... KArgs, typename... Args>
 inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
-    std::function<void()> body = [=]() { kernel(args...); };
+    auto ka = std::make_shared<std::vector<char>>();
+    (simt::pack_kernarg<KArgs>(*ka, static_cast<KArgs>(args)), ...);
+    ka->resize((ka->size() + 7) / 8 * 8);
+    std::function<void()> body = [=]() { simt::kernarg_end = ka->data() + ka->size(); kernel(args...); };
     if (simt::capture_launch(st, grid, block, lds, body)) return;
     simt::launch(grid, block, lds, body);
 }

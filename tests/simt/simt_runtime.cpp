@@ -16,6 +16,7 @@ thread_local __attribute__((aligned(16))) unsigned char sel_smem[160 * 1024];
 namespace simt {
 thread_local Lane* cur = nullptr;
 thread_local dim3 g_block, g_grid;
+thread_local const char* kernarg_end = nullptr;
 
 namespace {
 enum { RUN = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };

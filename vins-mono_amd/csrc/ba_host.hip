@@ -1217,13 +1217,16 @@ extern "C" int vg_ba_seq_begin(vg_handle* h, int nwin, const vg_ba_seq_config* c
     seq_free(Q);
     // the batch layout, the states, the pre-integrations and the first prior go the ordinary way (the windows' own landmark
     // tables are packed too and overwritten by the first step)
+    const int keep_res[4] = {B.res_L, B.res_F, B.res_O, B.res_N};     // (the sequence's capacities hold for this layout only)
     B.res_L = std::max(B.res_L, Lres); B.res_F = std::max(B.res_F, Fres); B.res_O = std::max(B.res_O, Fres + Lres);
     B.res_N = std::max(B.res_N, 6 * K + 9 * 2 + 6 + 1);
     std::vector<int> flags(nwin, VG_MARGIN_OLD);
     int rc = vg_ba_batch_upload(h, nwin, windows, flags.data());
+    B.res_L = keep_res[0]; B.res_F = keep_res[1]; B.res_O = keep_res[2]; B.res_N = keep_res[3];
     if (rc) return rc;
     if (B.L.big) { h->err = "vg_ba_seq_begin: window too wide for the single-workgroup pipeline"; B.uploaded = false; return VG_ERR_UNSUPPORTED; }
-    std::fill(B.nL.begin(), B.nL.end(), B.L.Lcap);    // (state downloads: vg_ba_state::inv_depth, if given, takes the whole landmark slab)
+    std::fill(B.nL.begin(), B.nL.end(), std::min(B.L.Lcap, up(Lres, 16)));   // (state downloads: vg_ba_state::inv_depth, if given, takes
+                                                                              //  max_landmarks rounded up to 16 values, as the header says)
     SeqDev& D = Q.D;
     D.K = K; D.FT = FT; D.NIN = NIN;
     D.fi_stride = up(hdr_ints + 5 * FT, 8);

@@ -4,6 +4,7 @@
 // perturbations are right-multiplied.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "vg_target.h"
 
 #define DEV __device__ __forceinline__
 
@@ -27,32 +28,7 @@ template <int CTRL> DEV double dpp_mov_f64(double v) {
 DEV double readlane_f64(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-// A value every lane of the wavefront holds identically (solver control state, results of workgroup reductions), marked as
-// such: the compiler keeps it in SGPRs.  What is live in VGPRs across a call to a non-inlined phase function is saved to
-// scratch per lane; uniform state in SGPRs is not.
-#ifdef VINS_SIMT
-DEV int uni(int v) { return v; }
-DEV double uni(double v) { return v; }
-#else
-DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-DEV double uni(double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-#endif
-// A block the host wrote before the launch and no kernel ever writes (the batch layout), read through the constant address
-// space: every field becomes a scalar load (s_load) and everything derived from it — strides, buffer offsets, the pointers of a
-// window — wave-uniform SGPR arithmetic.  Through a generic pointer the same fields arrive by vector loads, the derived pointers
-// sit in VGPRs and are saved to scratch around every call of a non-inlined function.
-template <typename T>
-DEV T const_load(const T* p) {
-#ifdef VINS_SIMT
-    return *p;
-#else
-    T v;
-    __builtin_memcpy(&v, (const __attribute__((address_space(4))) void*)p, sizeof(T));
-    return v;
-#endif
-}
+// (uni() = a wave-uniform value kept in SGPRs, const_load() = a read through the constant address space: vg_target.h)
 DEV double group8_sum(double v) {            // sum over aligned groups of 8 lanes, result in all 8
     v += dpp_mov_f64<0xB1>(v);               // quad_perm [1,0,3,2]
     v += dpp_mov_f64<0x4E>(v);               // quad_perm [2,3,0,1]

@@ -34,29 +34,13 @@
 // when they always hit LDS (slower issue and latency than ds_read / ds_write, and they tie up both memory counters).  The
 // phase functions of the single-workgroup solve therefore re-type their LDS operands explicitly.  (The CPU emulation of
 // tests/simt has one address space.)
-#ifdef VINS_SIMT
-typedef double lds_d;
-#else
-typedef __attribute__((address_space(3))) double lds_d;
-#endif
+// (the address-space typedefs lds_d / lds_i / glb_d / glb_i: vg_target.h)
 #define AS_LDS(p) ((lds_d*)(p))
 #define AS_LDS_C(p) ((const lds_d*)(p))
-#ifdef VINS_SIMT
-typedef double glb_d;
-typedef int glb_i;
-#else
-typedef __attribute__((address_space(1))) double glb_d;    // HBM operands of those functions: global_load instead of flat_load
-typedef __attribute__((address_space(1))) int glb_i;
-#endif
 #define AS_GLB(p) ((glb_d*)(p))
 #define AS_GLB_C(p) ((const glb_d*)(p))
 #define AS_GLB_CI(p) ((const glb_i*)(p))
 // where the arrays of the solve carve that the large-window path keeps in HBM live: LDS (single-workgroup path) or HBM
-#ifdef VINS_SIMT
-typedef int lds_i;
-#else
-typedef __attribute__((address_space(3))) int lds_i;
-#endif
 template <bool BIG> struct MovT { typedef lds_d D; typedef lds_i I; };
 template <> struct MovT<true> { typedef glb_d D; typedef glb_i I; };
 
@@ -164,14 +148,8 @@ DEV const double* st_ex(const BaLayout& L, const double* x) { return x + 7 * L.K
 
 DEV double* lin_buf(const Ctx& c, int which) { return c.sc + c.Lp->so_buf + (size_t)which * c.Lp->buf_stride; }
 
-// vg_ba_problem::max_solver_time_s against the device's constant-rate wall clock (100 MHz on gfx950; the CPU emulation of
-// tests/simt counts nanoseconds).  The clock is read by ONE thread and the verdict handed to the workgroup through LDS:
+// vg_ba_problem::max_solver_time_s against the device's constant-rate wall clock (BA_WALL_HZ, vg_target.h).  The clock is read by ONE thread and the verdict handed to the workgroup through LDS:
 // wavefronts read the clock at different instants and must not disagree about a branch that contains barriers.
-#ifdef VINS_SIMT
-#define BA_WALL_HZ 1e9
-#else
-#define BA_WALL_HZ 1e8
-#endif
 DEV bool time_is_up(const double* ctl, double max_s, double* lds_slot, int tid) {
     if (max_s <= 0.0) return false;                // (uniform: a kernel argument of the window)
     __syncthreads();
@@ -981,16 +959,12 @@ DEV void big_carve(const BaLayout& L, double* sc, SolveLds& m) {
 // The phase functions of the solve kernels are not inlined.  A Ctx / SolveLds handed over by reference has to sit in the caller's
 // private stack frame (scratch stores at kernel entry, scratch / flat loads in every callee) and arrives as vector data, so the
 // callee's address arithmetic runs on the VALU.  Everything in them is a function of the kernel arguments and the workgroup
-// index: each phase rebuilds it from the kernarg segment with scalar loads instead (the reference arguments stay for the CPU
-// emulation, which has no kernarg segment, and are dropped as dead arguments on the device).
-#ifdef VINS_SIMT
-#define PHASE_ENTER(BIGV) const Ctx c = c_in; const BaLayout L = *c.Lp; const SolveLds m = m_in
-#define PHASE_SELF_CHECK(cref) do { } while (0)
-#else
+// index: each phase rebuilds it from the kernarg segment with scalar loads instead (the reference arguments are dropped as dead
+// arguments; the CPU emulation of tests/simt lays the launch arguments out like a kernarg segment, so it runs this code too).
 DEV void phase_ctx(Ctx& c, BaLayout& L, SolveLds& m, int big) {        // big: 0 / 1, -1 = whichever path the layout says
     // (llvm.amdgcn.kernarg.segment.ptr is null outside a kernel; the implicit-argument pointer is handed down to callees and
     //  the hidden arguments start right behind the explicit ones: (const BaLayout* Lp, BaPtrs P) for both solve kernels)
-    typedef const __attribute__((address_space(4))) char* KArg;
+    typedef vg_kernarg_ptr KArg;
     static_assert(sizeof(const BaLayout*) + sizeof(BaPtrs) == 96 && alignof(BaPtrs) == 8, "explicit kernel arguments of the solve kernels");
     KArg ka = (KArg)__builtin_amdgcn_implicitarg_ptr() - 96;
     const BaLayout* Lp;
@@ -1003,8 +977,7 @@ DEV void phase_ctx(Ctx& c, BaLayout& L, SolveLds& m, int big) {        // big: 0
 }
 // the kernels compare what the phases will derive with their real arguments once (a wrong hidden-argument offset must not be silent)
 #define PHASE_SELF_CHECK(cref) do { Ctx c_; BaLayout L_; SolveLds m_; phase_ctx(c_, L_, m_, 0); if (c_.sc != (cref).sc || c_.ia != (cref).ia || c_.pri != (cref).pri) __builtin_trap(); } while (0)
-#define PHASE_ENTER(BIGV) Ctx c; BaLayout L; SolveLds m; phase_ctx(c, L, m, BIGV); asm volatile("" :: "v"(&c_in)); (void)m_in
-#endif
+#define PHASE_ENTER(BIGV) Ctx c; BaLayout L; SolveLds m; phase_ctx(c, L, m, BIGV); VG_KEEP_ALIVE(&c_in); (void)m_in
 
 // local column (0..29) of IMU factor f -> reduced column
 DEV int imu_col(const BaLayout& L, int f, int lc) {

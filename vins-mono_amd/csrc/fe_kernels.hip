@@ -13,6 +13,7 @@
 // 21x21 template / gradient patches and the 22x22 search window live in LDS (~5.6 KB per track).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "vg_target.h"
 #include "fe_layout.h"
 
 #define FDEV __device__ __forceinline__
@@ -22,11 +23,7 @@ FDEV int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 // exact product of two integers known to fit 24 bits (pixels, 14-bit bilinear weights, int16 derivatives, 14-bit differences)
 // whose product fits 32: v_mul_i32_i24 runs at full rate, v_mul_lo_u32 at a quarter of it -- and the LK kernel is bound by
 // VALU issue
-#ifdef VINS_SIMT
-FDEV int mul24(int a, int b) { return a * b; }
-#else
-FDEV int mul24(int a, int b) { return __mul24(a, b); }
-#endif
+FDEV int mul24(int a, int b) { return vg_mul24(a, b); }
 // sum of four such products (bilinear tap)
 FDEV int tap4(int p00, int p01, int p10, int p11, int w00, int w01, int w10, int w11) {
     return mul24(p00, w00) + mul24(p01, w01) + mul24(p10, w10) + mul24(p11, w11);
@@ -146,18 +143,9 @@ extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_
     for (int k = threadIdx.x; k < PD_IN * 64; k += 256) {
         const int r = k >> 6, lx = k & 63;
         const uint8_t* t = &tile[r][2 * lx + 2];           // input column 2x - 2
-#ifdef VINS_SIMT
-        hs[r][lx] = t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4];
-#else
         // the five taps start at an even byte: they lie in two aligned dwords (two LDS reads and a funnel shift instead of five
-        // byte reads -- this pass was 44 of the kernel's ~60 LDS instructions per thread)
-        const unsigned off = (2u * lx + 2u) & 3u;          // 0 or 2
-        const unsigned* w = (const unsigned*)(t - off);
-        const unsigned w0 = w[0], w1 = w[1];
-        const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, off);
-        const unsigned t4 = (off ? w1 >> 16 : w1) & 255u;
-        hs[r][lx] = (int)((lo & 255u) + 4u * ((lo >> 8) & 255u) + 6u * ((lo >> 16) & 255u) + 4u * (lo >> 24) + t4);
-#endif
+        // byte reads -- this pass was 44 of the kernel's ~60 LDS instructions per thread): vg_target.h
+        hs[r][lx] = vg_taps5_even(t, 2u * lx + 2u);
     }
     __syncthreads();
     // thread = 4 horizontally adjacent outputs of one row: five 16-byte LDS reads, one 4-byte store (a byte store per thread
@@ -235,13 +223,7 @@ FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
 }
 
 // Image planes are reached through pointer tables in HBM: a loaded pointer is generic and its accesses would compile to
-// flat_load (which also ties the LDS counter to the image loads); the planes are HBM, say so.  (One address space under the
-// CPU emulation of tests/simt.)
-#ifdef VINS_SIMT
-typedef uint8_t glb_u8;
-#else
-typedef __attribute__((address_space(1))) uint8_t glb_u8;
-#endif
+// flat_load (which also ties the LDS counter to the image loads); the planes are HBM, say so (glb_u8, vg_target.h).
 
 // Stage the LK_JR x LK_JR search region with origin (ox, oy) of plane J into LDS (reflect-101 outside the image, exactly
 // the pixels the per-window gather of LKTrackerInvoker reads).  lane = (row, 16-byte half): one unaligned 16-byte load
@@ -251,16 +233,8 @@ FDEV void lk_stage_region(uint8_t* reg, const glb_u8* J, int lw, int lh, int ox,
     const int row = lane >> 1, hf = lane & 1;
     const bool inside = ox >= 0 && ox + LK_JR <= lw && oy >= 0 && oy + LK_JR <= lh;      // uniform
     if (inside) {
-        uint4 v;
         const glb_u8* pj = J + (size_t)(oy + row) * lw + ox + 16 * hf;      // unaligned 16 bytes
-#ifdef VINS_SIMT
-        __builtin_memcpy(&v, pj, 16);
-#else
-        typedef unsigned int nv4 __attribute__((ext_vector_type(4), aligned(1)));
-        typedef __attribute__((address_space(1))) const nv4 glb_nv4;
-        const nv4 t4 = *(glb_nv4*)pj;
-        v.x = t4.x; v.y = t4.y; v.z = t4.z; v.w = t4.w;
-#endif
+        const uint4 v = vg_load16_unaligned(pj);
         *(uint4*)(reg + row * LK_JR + 16 * hf) = v;
     } else {
         // (the +-LK_JS margin may reach more than one image size outside a tiny level; those pixels are never part of a

@@ -162,20 +162,25 @@ extern "C" int vg_imu_preintegrate(vg_handle* h, int n_intervals, const int* sam
         if (sample_off[k + 1] < sample_off[k]) { h->err = "vg_imu_preintegrate: sample_off must be non-decreasing"; return VG_ERR_BAD_ARG; }
     const size_t S = (size_t)sample_off[n_intervals];
     hipError_t e = hipSetDevice(h->device);
-    int* d_off = nullptr;
-    double *d_s = nullptr, *d_f = nullptr, *d_b = nullptr, *d_o = nullptr;
     std::vector<double> host((size_t)n_intervals * IMU_OUT);
-    auto fail = [&](hipError_t err) {
-        h->err = std::string("vg_imu_preintegrate: ") + hipGetErrorString(err);
-        (void)hipFree(d_off); (void)hipFree(d_s); (void)hipFree(d_f); (void)hipFree(d_b); (void)hipFree(d_o);
-        return VG_ERR_HIP;
-    };
+    auto fail = [&](hipError_t err) { h->err = std::string("vg_imu_preintegrate: ") + hipGetErrorString(err); return VG_ERR_HIP; };
     if (e != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&d_off, sizeof(int) * (n_intervals + 1))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&d_s, sizeof(double) * 7 * (S ? S : 1))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&d_f, sizeof(double) * 6 * n_intervals)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&d_b, sizeof(double) * 6 * n_intervals)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void**)&d_o, sizeof(double) * IMU_OUT * n_intervals)) != hipSuccess) return fail(e);
+    // one scratch allocation per handle, grown on demand (this call sits on the per-frame path of a sequence: a hipMalloc /
+    // hipFree pair per call would synchronise the device every frame): [samples | first | bias | out | offsets]
+    const size_t nd = 7 * (S ? S : 1) + 12 * (size_t)n_intervals + (size_t)IMU_OUT * n_intervals;
+    const size_t need = nd * sizeof(double) + sizeof(int) * ((size_t)n_intervals + 1);
+    if (need > h->imu_cap) {
+        if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail(e);
+        (void)hipFree(h->imu_buf);
+        h->imu_buf = nullptr; h->imu_cap = 0;
+        if ((e = hipMalloc(&h->imu_buf, 2 * need)) != hipSuccess) return fail(e);
+        h->imu_cap = 2 * need;
+    }
+    double* d_s = (double*)h->imu_buf;
+    double* d_f = d_s + 7 * (S ? S : 1);
+    double* d_b = d_f + 6 * (size_t)n_intervals;
+    double* d_o = d_b + 6 * (size_t)n_intervals;
+    int* d_off = (int*)(d_o + (size_t)IMU_OUT * n_intervals);
     if ((e = hipMemcpyAsync(d_off, sample_off, sizeof(int) * (n_intervals + 1), hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
     if (S && (e = hipMemcpyAsync(d_s, samples, sizeof(double) * 7 * S, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
     if ((e = hipMemcpyAsync(d_f, first, sizeof(double) * 6 * n_intervals, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
@@ -185,7 +190,6 @@ extern "C" int vg_imu_preintegrate(vg_handle* h, int n_intervals, const int* sam
     if ((e = hipGetLastError()) != hipSuccess) return fail(e);
     if ((e = hipMemcpyAsync(host.data(), d_o, sizeof(double) * IMU_OUT * n_intervals, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail(e);
-    (void)hipFree(d_off); (void)hipFree(d_s); (void)hipFree(d_f); (void)hipFree(d_b); (void)hipFree(d_o);
     for (int k = 0; k < n_intervals; ++k) {
         const double* o = host.data() + (size_t)k * IMU_OUT;
         vg_imu_preint& q = out[k];

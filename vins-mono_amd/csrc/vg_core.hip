@@ -47,6 +47,7 @@ extern "C" int vg_destroy(vg_handle* h) {
     (void)hipFree(P.mout); (void)hipFree(P.miout); (void)hipFree(P.mscr); (void)hipFree(P.rb1); (void)hipFree(P.rb2);
     if (h->fe) fe_state_destroy(h->fe);
     (void)hipFree(h->ransac_buf);
+    (void)hipFree(h->imu_buf);
     (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev2);
     (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join);
     (void)hipStreamDestroy(h->aux);

@@ -111,5 +111,7 @@ struct vg_handle {
     BaBatch ba;
     FeState* fe = nullptr;
     void* rccl_comm = nullptr;                    // ncclComm_t of vg_ba_rccl_init (csrc/vg_rccl.hip)
+    void* imu_buf = nullptr;                      // device scratch of vg_imu_preintegrate (grown on demand)
+    size_t imu_cap = 0;
     void* ransac_buf = nullptr;                   // device scratch of vg_fe_reject_with_f (fixed size, allocated on first use)
 };

@@ -1,0 +1,78 @@
+// vg_target.h — everything that is spelled differently for gfx950 and for the CPU fiber emulation of tests/simt (which compiles
+// these same kernel sources with g++: one address space, no DPP / readlane hardware, no kernarg segment), in ONE place, so that
+// the kernel translation units themselves carry no emulator branches.  Each item: the gfx950 form and why it is written that way,
+// then the plain form the emulator uses.  Nothing here is a second compute path: the emulated form is the same arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef VINS_SIMT
+// ---- address spaces.  A pointer handed to a non-inlined function, or loaded from a table in HBM, is generic, and generic
+//      accesses compile to flat_load / flat_store even when they always hit LDS or always hit HBM (slower issue and latency, and
+//      they tie up both memory counters): the kernels re-type such operands explicitly.
+typedef __attribute__((address_space(3))) double lds_d;
+typedef __attribute__((address_space(3))) int lds_i;
+typedef __attribute__((address_space(1))) double glb_d;
+typedef __attribute__((address_space(1))) int glb_i;
+typedef __attribute__((address_space(1))) uint8_t glb_u8;
+// ---- the kernarg segment (explicit kernel arguments, then the hidden ones): constant address space
+typedef const __attribute__((address_space(4))) char* vg_kernarg_ptr;
+// ---- the constant-rate wall clock behind wall_clock64(): 100 MHz on gfx950
+#define BA_WALL_HZ 1e8
+// ---- a pointer the optimiser must consider used (keeps a call out of tail position: see PHASE_ENTER in ba_pipeline.hip)
+#define VG_KEEP_ALIVE(p) asm volatile("" :: "v"(p))
+// ---- exact product of two integers known to fit 24 bits whose product fits 32: v_mul_i32_i24 runs at full rate, v_mul_lo_u32 at
+//      a quarter of it
+__device__ __forceinline__ int vg_mul24(int a, int b) { return __mul24(a, b); }
+// ---- uni(): a value every lane of the wavefront holds identically (solver control state, results of workgroup reductions), marked
+//      as such (v_readfirstlane): the compiler keeps it in SGPRs.  What is live in VGPRs across a call to a non-inlined phase
+//      function is saved to scratch per lane; uniform state in SGPRs is not.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// ---- const_load(): a block the host wrote before the launch and no kernel ever writes (the batch layout), read through the
+//      constant address space: every field becomes a scalar load (s_load) and everything derived from it -- strides, buffer
+//      offsets, the pointers of a window -- wave-uniform SGPR arithmetic
+template <typename T>
+__device__ __forceinline__ T const_load(const T* p) {
+    T v;
+    __builtin_memcpy(&v, (const __attribute__((address_space(4))) void*)p, sizeof(T));
+    return v;
+}
+// ---- 16 bytes from an arbitrary byte address of an image plane in HBM: one global_load_dwordx4
+__device__ __forceinline__ uint4 vg_load16_unaligned(const glb_u8* p) {
+    typedef unsigned int nv4 __attribute__((ext_vector_type(4), aligned(1)));
+    typedef __attribute__((address_space(1))) const nv4 glb_nv4;
+    const nv4 t4 = *(glb_nv4*)p;
+    uint4 v;
+    v.x = t4.x; v.y = t4.y; v.z = t4.z; v.w = t4.w;
+    return v;
+}
+// ---- t[0] + 4 t[1] + 6 t[2] + 4 t[3] + t[4] over five bytes of LDS starting at an EVEN byte offset (lx2 = that offset): they lie
+//      in two aligned dwords -- two ds_read_b32 and a v_alignbyte_b32 instead of five ds_read_u8
+__device__ __forceinline__ int vg_taps5_even(const uint8_t* t, unsigned lx2) {
+    const unsigned off = lx2 & 3u;                         // 0 or 2
+    const unsigned* w = (const unsigned*)(t - off);
+    const unsigned w0 = w[0], w1 = w[1];
+    const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, off);
+    const unsigned t4 = (off ? w1 >> 16 : w1) & 255u;
+    return (int)((lo & 255u) + 4u * ((lo >> 8) & 255u) + 6u * ((lo >> 16) & 255u) + 4u * (lo >> 24) + t4);
+}
+
+#else   // ------------------------------------------------------------------------------ CPU fiber emulation (tests/simt)
+typedef double lds_d;
+typedef int lds_i;
+typedef double glb_d;
+typedef int glb_i;
+typedef uint8_t glb_u8;
+typedef const char* vg_kernarg_ptr;                        // (hipLaunchKernelGGL of the emulator packs the arguments the same way)
+#define BA_WALL_HZ 1e9                                     // (the emulated clock counts nanoseconds)
+#define VG_KEEP_ALIVE(p) ((void)(p))
+inline int vg_mul24(int a, int b) { return a * b; }
+inline int uni(int v) { return v; }
+inline double uni(double v) { return v; }
+template <typename T> inline T const_load(const T* p) { return *p; }
+inline uint4 vg_load16_unaligned(const glb_u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+inline int vg_taps5_even(const uint8_t* t, unsigned) { return t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4]; }
+#endif
