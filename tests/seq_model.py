@@ -467,6 +467,6 @@ def compare_replay_csv(csv_path, expected, n, tol=1e-6):
             q = -q
         e = np.abs(got - np.concatenate([P, q, V])).max()
         worst = max(worst, e)
-        assert int(l[12]) == flag and int(l[13]) == nf and int(l[14]) == 0, (w, i, l[12:], flag, nf)
+        assert int(l[12]) == flag and int(l[13]) == nf and int(l[14]) == 0 and int(l[15]) == 0, (w, i, l[12:], flag, nf)   # (+ no failureDetection() alarm)
         assert e < tol, (w, i, e)
     return worst

@@ -250,9 +250,9 @@ static int replay_seq(const char* in, const char* out) {
             // (the mirror is post-slide: the frame just solved sits in slot WINDOW_SIZE either way)
             const ResidentEstimators::One& e = res[i];
             const Quaterniond q(e.Rs[WINDOW_SIZE]);
-            fprintf(o, "%d,%.0f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%d,%d,%d\n", i, stamp[i] * 1e9, e.Ps[WINDOW_SIZE].x(), e.Ps[WINDOW_SIZE].y(),
+            fprintf(o, "%d,%.0f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%d,%d,%d,%d\n", i, stamp[i] * 1e9, e.Ps[WINDOW_SIZE].x(), e.Ps[WINDOW_SIZE].y(),
                     e.Ps[WINDOW_SIZE].z(), q.w(), q.x(), q.y(), q.z(), e.Vs[WINDOW_SIZE].x(), e.Vs[WINDOW_SIZE].y(), e.Vs[WINDOW_SIZE].z(),
-                    (int)e.marginalization_flag, e.n_features, e.status);
+                    (int)e.marginalization_flag, e.n_features, e.status, e.failure_occur ? 1 : 0);
         }
     }
     fclose(o);

@@ -100,6 +100,8 @@ void ResidentEstimators::handOver(int i, Estimator& e, const Vector3d& acc_0, co
     o.cur = Interval();
     o.cur.linearized_acc = acc_0; o.cur.linearized_gyr = gyr_0; o.cur.linearized_ba = o.Bas[WINDOW_SIZE]; o.cur.linearized_bg = o.Bgs[WINDOW_SIZE];
     o.merge_pending = false; o.have_frame = false;
+    o.last_R = o.Rs[WINDOW_SIZE]; o.last_P = o.Ps[WINDOW_SIZE]; o.last_R0 = o.Rs[0]; o.last_P0 = o.Ps[0];      // estimator.cpp:205-208
+    o.failure_occur = false;
 }
 
 void ResidentEstimators::begin() {
@@ -222,12 +224,20 @@ void ResidentEstimators::solve() {
             R[k] = Quaterniond(x[6] / qn, x[3] / qn, x[4] / qn, x[5] / qn).toRotationMatrix();
             V[k] = Vector3d(s[0], s[1], s[2]); Ba[k] = Vector3d(s[3], s[4], s[5]); Bg[k] = Vector3d(s[6], s[7], s[8]);
         }
+        o.last_track_num = nf[VG_SEQ_N_TRACKED];
+        {
+            // failureDetection() on the solved window (estimator.cpp:621-667; the commented-out returns stay commented out)
+            auto norm = [](const Vector3d& v) { return std::sqrt(v.x() * v.x() + v.y() * v.y() + v.z() * v.z()); };
+            const Vector3d dP = P[WINDOW_SIZE] - o.last_P;
+            o.failure_occur = sum[i].status != VG_OK || norm(Ba[WINDOW_SIZE]) > 2.5 || norm(Bg[WINDOW_SIZE]) > 1.0 || norm(dP) > 5 || std::fabs(dP.z()) > 1;
+        }
         for (int k = 0; k < K; ++k) {
             int from;
             if (o.marginalization_flag == Estimator::MARGIN_OLD) from = k < K - 1 ? k + 1 : K - 1;
             else from = k <= K - 3 ? k : K - 1;
             o.Ps[k] = P[from]; o.Rs[k] = R[from]; o.Vs[k] = V[from]; o.Bas[k] = Ba[from]; o.Bgs[k] = Bg[from];
         }
+        o.last_R = o.Rs[WINDOW_SIZE]; o.last_P = o.Ps[WINDOW_SIZE]; o.last_R0 = o.Rs[0]; o.last_P0 = o.Ps[0];      // :205-208
         {
             const double* e = st[i].ex_pose;
             const double qn = std::sqrt(e[3] * e[3] + e[4] * e[4] + e[5] * e[5] + e[6] * e[6]);

@@ -32,6 +32,14 @@ class ResidentEstimators {
         Estimator::MarginalizationFlag marginalization_flag = Estimator::MARGIN_OLD;   // of the last solve()
         vg_ba_summary last_summary;
         int n_features = 0, status = 0;       // tracks left after the slide; VG_OK or VG_ERR_UNSUPPORTED (a capacity was exceeded)
+        int last_track_num = 0;               // f_manager.last_track_num of the last frame
+        // Estimator::failureDetection() (estimator.cpp:621-667) on the window as solved, BEFORE its slide, against last_P / last_R
+        // of the frame before (:205-208).  The reference reboots on failure (clearState + setParameter, :193-199).  Here the flag is
+        // raised and the caller decides: the windows of a batch begin together (vg_ba_seq_begin), so re-initialising ONE estimator
+        // means handing the batch over again (a per-window re-seed of a running sequence is not offered yet).
+        bool failure_occur = false;
+        Vector3d last_P, last_P0;
+        Matrix3d last_R, last_R0;
         // ---- internal
         Interval cur, prev;                   // pre_integrations[WINDOW_SIZE] (running) and [WINDOW_SIZE - 1] (may take cur's samples, estimator.cpp:1069-1085)
         bool merge_pending = false;
