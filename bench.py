@@ -476,6 +476,17 @@ def main():
     barrier()
     elapsed = D.max_over_ranks(elapsed)
 
+    # the same loop ten times as long (>= 200 steps): the timed region above is ~50 ms, too short for round-to-round deltas of a
+    # few per cent to mean much; reported next to `value`, never instead of it
+    n_long = max(200, 10 * args.steps)
+    barrier()
+    tl0 = time.perf_counter()
+    for k in range(n_long):
+        handles[k % nfl].ba_run_async()
+    sync_all()
+    torch.cuda.synchronize()
+    long_elapsed = D.max_over_ranks(time.perf_counter() - tl0)
+    barrier()
     launch_stats = h.ba_launch_stats()               # mode in effect + graph launches / captures of the timed handle so far
     # one step at a time (no overlap between steps): the latency of a 256-window step
     ser = []
@@ -725,6 +736,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "long_run": {"steps": n_long, "value": world * nwin * n_long / long_elapsed, "ms_per_step": long_elapsed / n_long * 1e3,
+                         "what": "the same timed loop over ten times as many steps (run right after the timed region)"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

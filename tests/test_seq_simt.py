@@ -54,3 +54,24 @@ def test_cpp_resident_estimators_replay(two_handles, tmp_path):
     flags = [e[3] for row in expected for e in row]
     assert M.NEW in flags and M.OLD in flags
     print("C++ ResidentEstimators vs the Python-driven sequence: worst difference", worst)
+
+
+def test_reserved_capacities_do_not_change_the_solve(two_handles):
+    """vg_ba_reserve pins the batch layout (what a sequence does for its lifetime): wider capacities change strides and grid sizes,
+    not the arithmetic -- states, trace and the new prior are bit-identical."""
+    from vins_mono_amd import ba, synth
+    h = two_handles[1]
+    seq = synth.SyntheticSequence(9, L=40)
+    first = seq.window(0)
+    st, sm, pr = h.ba_optimize(first, ba.VG_MARGIN_OLD)
+    prob = seq.next_window(st, pr, 1)
+    a = h.ba_optimize(prob, ba.VG_MARGIN_OLD)
+    h.ba_reserve(max_landmarks=128, max_factors=1024, max_obs=1200, max_prior_n=91)
+    try:
+        b = h.ba_optimize(prob, ba.VG_MARGIN_OLD)
+    finally:
+        h.ba_reserve()
+    for k in ('pose', 'sb', 'ex', 'inv_depth'):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert a[1]['final_cost'] == b[1]['final_cost'] and np.array_equal(a[1]['it_flags'], b[1]['it_flags'])
+    assert a[2]['blocks'] == b[2]['blocks'] and np.array_equal(a[2]['J0'], b[2]['J0']) and np.array_equal(a[2]['r0'], b[2]['r0'])
