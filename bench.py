@@ -358,15 +358,35 @@ def bench_sharded(args, ba, synth, D, rank, world):
 
 
 def csrc_tag():
-    """Identity of the kernel sources the library was built from: sha1 over vins-mono_amd/csrc/*.{hip,h} (first 12 hex)."""
-    import glob
+    """Identity of the DEVICE code the library carries: sha1 over the .hip_fatbin section of vins-mono_amd/lib/libvinsgpu.so (the
+    embedded gfx950 code objects; first 12 hex).  Byte-identical for the same kernel sources whatever the build directory and
+    whatever changes in host-only code, comments or headers that do not reach the generated code; any change of a kernel changes
+    it.  (Until r03s the tag was a hash of the source text of csrc/, which host-side edits invalidated although the kernels the
+    PMC pass had measured were unchanged.)"""
     import hashlib
-    h = hashlib.sha1()
-    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vins-mono_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:12]
+    import struct
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vins-mono_amd", "lib", "libvinsgpu.so")
+    try:
+        b = open(lib, "rb").read()
+        if b[:4] != b"\x7fELF" or b[4] != 2:
+            return "not-elf64"
+        shoff = struct.unpack_from("<Q", b, 0x28)[0]
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+
+        def section(i):
+            name, _, _, _, off, size = struct.unpack_from("<IIQQQQ", b, shoff + i * shentsize)
+            return name, off, size
+        _, stroff, _ = section(shstrndx)
+        h = hashlib.sha1()
+        found = False
+        for i in range(shnum):
+            name, off, size = section(i)
+            if b[stroff + name:b.index(b"\0", stroff + name)] == b".hip_fatbin":
+                h.update(b[off:off + size])
+                found = True
+        return h.hexdigest()[:12] if found else "no-fatbin"
+    except (OSError, struct.error, ValueError):
+        return "no-library"
 
 
 _PMC = None
@@ -375,8 +395,8 @@ _PMC = None
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` ('a+b' = sum over the kernels of a class) from the committed PMC summary
     (profiles/pmc_latest.json, written by profiles/run_pmc.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-    this same command).  None when the summary was recorded for OTHER kernel sources than the ones in the tree (its `build`
-    tag is the sha1 of vins-mono_amd/csrc at recording time) or has no entry for the kernel."""
+    this same command).  None when the summary was recorded for OTHER device code than the library holds (its `build` tag is
+    csrc_tag() at recording time) or has no entry for the kernel."""
     global _PMC
     if _PMC is None:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")

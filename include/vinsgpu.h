@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 6    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
-                             * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode; 6: vg_ba_reserve, vg_ba_seq_* (windows that stay on the device) */
+#define VG_ABI_VERSION 7    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
+                             * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode; 6: vg_ba_reserve, vg_ba_seq_* (windows that stay on the device);
+                             * 7: vg_ba_seq_export / vg_ba_seq_import */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {
@@ -369,6 +370,17 @@ int vg_ba_seq_info(vg_handle* h, int nwin, int* info);
  * cap x K x 8 doubles, rows [x y u v vx vy cur_td z] of feature f at obs + (f * K + j) * 8) */
 int vg_ba_seq_get_tracks(vg_handle* h, int window, int cap, int* n_features, int* feature_id, int* start_frame, int* n_obs,
                          int* solve_flag, double* depth, double* obs);
+/* Hand-back and re-seed of ONE window of a running sequence, between two frames (after a step):
+ *   export  the window of slot `window` in the form vg_ba_seq_begin takes it -- states (K x 7, K x 9, 7, 1), the K-1 pre-integration
+ *           records (the newest one is the placeholder the next step fills: valid = 0), the prior (caller-allocated as for
+ *           vg_ba_optimize; n = 0: none) -- together with vg_ba_seq_get_tracks this is everything the reference keeps in
+ *           Ps / Rs / Vs / Bas / Bgs, pre_integrations[], f_manager.feature and last_marginalization_info: a host Estimator can
+ *           take the window back (a relocalisation frame, which a sequence does not offer; a checkpoint; a failure re-start);
+ *   import  replaces what slot `window` holds (same K and estimate_* options as the sequence; prior from the host or none) while
+ *           the other windows stay where they are.  Any output pointer of export may be NULL. */
+int vg_ba_seq_export(vg_handle* h, int window, double* pose, double* speedbias, double* ex_pose, double* td, vg_imu_preint* imu,
+                     vg_ba_prior* prior);
+int vg_ba_seq_import(vg_handle* h, int window, const vg_ba_problem* in, const vg_ba_tracks* tracks);
 int vg_ba_seq_end(vg_handle* h);
 
 /* Form of the prior factor the marginalization hands back (marginalization_factor.cpp:285-296 builds J0 = S^1/2 V^T,

@@ -470,3 +470,84 @@ def compare_replay_csv(csv_path, expected, n, tol=1e-6):
         assert int(l[12]) == flag and int(l[13]) == nf and int(l[14]) == 0 and int(l[15]) == 0, (w, i, l[12:], flag, nf)   # (+ no failureDetection() alarm)
         assert e < tol, (w, i, e)
     return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def run_handback(h_a, h_b, seeds, K=11, L=70, n_before=2, n_after=2, min_parallax=0.25):
+    """Hand-back and re-seed (vg_ba_seq_export / vg_ba_seq_import): h_a runs n_before + n_after frames straight through; h_b runs
+    n_before frames, its windows are exported, a NEW sequence begins from the exported windows (slot order reversed, the second
+    half of the slots re-seeded through import), and the remaining frames follow.  Returns the two lists of final states."""
+    n = len(seeds)
+    n_total = n_before + n_after
+    mk = lambda: [synth.FrameSource(synth.SyntheticSequence(s, n_frames=K + n_total + 1, K=K + n_total + 1, L=L), noise_seed=400 + s) for s in seeds]
+
+    def frames_for(srcs, g, newest_sb, merged):
+        out = []
+        for i, s in enumerate(srcs):
+            ids, rows = s.image(g)
+            pose, sb = s.guess(g)
+            rec = s.preintegrate(s.samples(g - 1), newest_sb[i][3:6], newest_sb[i][6:9])
+            out.append(dict(pose=pose, sb=sb, imu_new=rec, imu_merged=merged[i], ids=ids, obs=rows))
+        return out
+
+    def drive(h, srcs, steps, state):
+        """state: dict(newest_sb, prev (samples, ba, bg per window), merged)"""
+        res = None
+        for g in steps:
+            fr = frames_for(srcs, g, state['newest_sb'], state['merged'])
+            h.seq_step(fr)
+            sts, sms = h.seq_states()
+            info = h.seq_info()
+            for i, s in enumerate(srcs):
+                smp = s.samples(g - 1)
+                cur = dict(samples=smp, ba=state['newest_sb'][i][3:6].copy(), bg=state['newest_sb'][i][6:9].copy())
+                if info[i]['flag'] == NEW:
+                    state['prev'][i]['samples'] = state['prev'][i]['samples'] + smp[1:]
+                    state['merged'][i] = s.preintegrate(state['prev'][i]['samples'], state['prev'][i]['ba'], state['prev'][i]['bg'])
+                else:
+                    state['prev'][i], state['merged'][i] = cur, None
+                state['newest_sb'][i] = sts[i]['sb'][K - 1].copy()
+            res = (sts, sms, info)
+        return res
+
+    def fresh_state(srcs, wins):
+        return dict(newest_sb=[w['sb'][K - 1].copy() for w in wins], prev=[dict(samples=list(w['samples'][K - 3]), ba=s.seq.ba_lin, bg=s.seq.bg_lin) for w, s in zip(wins, srcs)],
+                    merged=[None] * len(srcs))
+
+    # ---- straight through
+    src_a = mk()
+    wins = [s.initial_window(K, 0) for s in src_a]
+    pa, ta = zip(*[synth.sequence_inputs(w) for w in wins])
+    h_a.seq_begin(list(pa), list(ta), max_features=256, max_new_obs=256, min_parallax=min_parallax)
+    st_a = fresh_state(src_a, wins)
+    ref = drive(h_a, src_a, range(K - 1, K - 1 + n_total), st_a)
+    h_a.seq_end()
+    # ---- with a hand-back in the middle
+    src_b = mk()
+    wins = [s.initial_window(K, 0) for s in src_b]
+    pb, tb = zip(*[synth.sequence_inputs(w) for w in wins])
+    h_b.seq_begin(list(pb), list(tb), max_features=256, max_new_obs=256, min_parallax=min_parallax)
+    st_b = fresh_state(src_b, wins)
+    drive(h_b, src_b, range(K - 1, K - 1 + n_before), st_b)
+    exported = [h_b.seq_export(w, K) for w in range(n)]
+    h_b.seq_end()
+    base = src_b[0].seq._base()
+    order = list(reversed(range(n)))                         # new slot k holds old window order[k]
+
+    def as_prob(e):
+        p = dict(base)
+        p.update(pose=e['pose'], sb=e['sb'], ex=e['ex'], td=e['td'], imu=e['imu'], prior=e['prior'], relo=None, lm_start=np.zeros(0, np.int32),
+                 lm_nobs=np.zeros(0, np.int32), obs_off=np.zeros(0, np.int32), obs=np.zeros((0, 7)), inv_depth=np.zeros(0))
+        return p
+    probs = [as_prob(exported[o][0]) for o in order]
+    trks = [exported[o][1] for o in order]
+    half = n // 2
+    # the second half of the slots starts with SOMEBODY ELSE's window and is re-seeded through import
+    h_b.seq_begin(probs[:half] + [probs[0]] * (n - half), trks[:half] + [trks[0]] * (n - half), max_features=256, max_new_obs=256, min_parallax=min_parallax)
+    for k in range(half, n):
+        h_b.seq_import(k, probs[k], trks[k])
+    src_c = [src_b[o] for o in order]
+    st_c = dict(newest_sb=[st_b['newest_sb'][o] for o in order], prev=[st_b['prev'][o] for o in order], merged=[st_b['merged'][o] for o in order])
+    got = drive(h_b, src_c, range(K - 1 + n_before, K - 1 + n_total), st_c)
+    h_b.seq_end()
+    return ref, got, order

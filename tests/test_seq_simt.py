@@ -41,7 +41,7 @@ def test_cpp_resident_estimators_replay(two_handles, tmp_path):
     import subprocess
     from vins_mono_amd import synth
     conftest._build_simt()
-    K, n_frames, mp = 11, 4, 0.25
+    K, n_frames, mp = 11, 3, 0.25
     mk = lambda: [M.FrameSource(synth.SyntheticSequence(s, n_frames=K + n_frames + 1, K=K + n_frames + 1, L=70), noise_seed=200 + s) for s in (21, 22)]
     wins = M.write_seq_file(tmp_path / "frames.bin", mk(), K, n_frames, min_parallax=mp)
     exe = os.path.join(conftest.SIMT_DIR, "_build", "vins_replay_simt")
@@ -75,3 +75,42 @@ def test_reserved_capacities_do_not_change_the_solve(two_handles):
         assert np.array_equal(a[0][k], b[0][k]), k
     assert a[1]['final_cost'] == b[1]['final_cost'] and np.array_equal(a[1]['it_flags'], b[1]['it_flags'])
     assert a[2]['blocks'] == b[2]['blocks'] and np.array_equal(a[2]['J0'], b[2]['J0']) and np.array_equal(a[2]['r0'], b[2]['r0'])
+
+
+def test_hand_back_and_reseed(two_handles):
+    """vg_ba_seq_export / vg_ba_seq_import: windows exported between two frames and taken up by a new sequence (begin and import)
+    continue exactly as if they had never left the device."""
+    ref, got, order = M.run_handback(two_handles[0], two_handles[1], seeds=[21, 22], n_before=2, n_after=1)
+    for k, o in enumerate(order):
+        for key in ('pose', 'sb', 'ex'):
+            assert np.array_equal(ref[0][o][key], got[0][k][key]), (k, key, np.abs(ref[0][o][key] - got[0][k][key]).max())
+        assert ref[2][o]['flag'] == got[2][k]['flag'] and ref[2][o]['n_after'] == got[2][k]['n_after']
+        assert ref[1][o]['final_cost'] == got[1][k]['final_cost']
+
+
+def test_cpp_hand_back_and_take_over_again(two_handles, tmp_path):
+    """ResidentEstimators::handBack / handOver / reseed in the middle of a `vins_replay seq` run (VINS_REPLAY_HANDBACK): the windows go
+    back into host Estimator objects (states as rotation matrices, IntegrationBase objects, f_manager.feature,
+    last_marginalization_info), a new batch takes them over, and the remaining frames come out as in the uninterrupted run."""
+    import os
+    import subprocess
+    from vins_mono_amd import synth
+    conftest._build_simt()
+    K, n_frames, mp = 11, 3, 0.25
+    mk = lambda: [M.FrameSource(synth.SyntheticSequence(s, n_frames=K + n_frames + 1, K=K + n_frames + 1, L=70), noise_seed=200 + s) for s in (21, 22)]
+    M.write_seq_file(tmp_path / "frames.bin", mk(), K, n_frames, min_parallax=mp)
+    exe = os.path.join(conftest.SIMT_DIR, "_build", "vins_replay_simt")
+    outs = []
+    for tag, env in (("plain", {}), ("handback", {"VINS_REPLAY_HANDBACK": "0"})):
+        out = tmp_path / f"{tag}.csv"
+        r = subprocess.run([exe, "seq", str(tmp_path / "frames.bin"), str(out)], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l.split(',') for l in open(out).read().strip().splitlines()])
+    a, b = outs
+    assert len(a) == len(b) == 2 * n_frames
+    worst = 0.0
+    for la, lb in zip(a, b):
+        assert la[0] == lb[0] and la[12:] == lb[12:]             # same estimator, same key-frame decision, tracks, status, no failure
+        worst = max(worst, max(abs(float(x) - float(y)) for x, y in zip(la[2:12], lb[2:12])))
+    assert worst < 1e-6, worst
+    print("hand-back in the middle of the run: worst difference to the uninterrupted run", worst)

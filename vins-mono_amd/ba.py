@@ -12,7 +12,7 @@ VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
 VG_MARG_SQRT, VG_MARG_EIGEN = 0, 1     # vg_ba_set_marg_mode
 VG_OK = 0
-VG_ABI_VERSION = 6          # include/vinsgpu.h
+VG_ABI_VERSION = 7          # include/vinsgpu.h
 VG_LAUNCH_DIRECT, VG_LAUNCH_GRAPH = 0, 1   # vg_ba_set_launch_mode
 VG_LAUNCH_DEFAULT = VG_LAUNCH_DIRECT        # include/vinsgpu.h
 VG_PRIOR_RESIDENT = -1
@@ -256,6 +256,8 @@ class Handle:
         L.vg_ba_seq_info.argtypes = [C.c_void_p, C.c_int, _pi]
         L.vg_ba_seq_get_tracks.argtypes = [C.c_void_p, C.c_int, C.c_int, _pi, _pi, _pi, _pi, _pi, _pd, _pd]
         L.vg_ba_seq_end.argtypes = [C.c_void_p]
+        L.vg_ba_seq_export.argtypes = [C.c_void_p, C.c_int, _pd, _pd, _pd, _pd, C.POINTER(ImuPreint), C.POINTER(Prior)]
+        L.vg_ba_seq_import.argtypes = [C.c_void_p, C.c_int, C.POINTER(Problem), C.POINTER(Tracks)]
         if L.vg_abi_version() != VG_ABI_VERSION:
             raise RuntimeError(f"libvinsgpu.so reports ABI version {L.vg_abi_version()}, this binding was written for {VG_ABI_VERSION}")
         self.h = C.c_void_p()
@@ -529,6 +531,35 @@ class Handle:
                   "vg_ba_seq_get_tracks")
         m = n.value
         return dict(id=ids[:m].copy(), start=st[:m].copy(), nobs=nb[:m].copy(), solve_flag=fl[:m].copy(), depth=dep[:m].copy(), obs=obs[:m].copy())
+
+    def seq_export(self, w, K):
+        """The window of slot w between two frames, as vg_ba_seq_begin takes it: (prob-dict fields, tracks dict)."""
+        o = _Out(K, 0, False, True)
+        imu = (ImuPreint * (K - 1))()
+        self._chk(self.lib.vg_ba_seq_export(self.h, int(w), _dp(o.pose), _dp(o.sb), _dp(o.ex), _dp(o.td), imu, C.byref(o.prior)), "vg_ba_seq_export")
+        recs = []
+        for q in imu:
+            recs.append(None if not q.valid else dict(
+                sum_dt=q.sum_dt, delta_p=np.array(q.delta_p), delta_q=np.array(q.delta_q), delta_v=np.array(q.delta_v), lin_ba=np.array(q.linearized_ba),
+                lin_bg=np.array(q.linearized_bg), jacobian=np.array(q.jacobian).reshape(15, 15), covariance=np.array(q.covariance).reshape(15, 15)))
+        t = self.seq_tracks(w, K)
+        rows = np.concatenate([t['obs'][f, :n][:, [0, 1, 7, 2, 3, 4, 5, 6]] for f, n in enumerate(t['nobs'])]) if len(t['id']) else np.zeros((0, 8))
+        tracks = dict(id=t['id'], start=t['start'], nobs=t['nobs'], depth=t['depth'], solve_flag=t['solve_flag'], obs=rows)
+        return dict(pose=o.pose.copy(), sb=o.sb.copy(), ex=o.ex.copy(), td=float(o.td[0]), imu=recs, prior=o.prior_dict()), tracks
+
+    def seq_import(self, w, prob, tracks):
+        """Replace what slot w of the running sequence holds (vg_ba_seq_import); prob / tracks as for seq_begin."""
+        p = PackedProblem(prob)
+        i4 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        a = dict(id=i4(tracks['id']), start=i4(tracks['start']), nobs=i4(tracks['nobs']), depth=np.ascontiguousarray(tracks['depth'], dtype=np.float64),
+                 obs=np.ascontiguousarray(tracks['obs'], dtype=np.float64).reshape(-1, 8),
+                 flag=i4(tracks['solve_flag']) if tracks.get('solve_flag') is not None else None)
+        t = Tracks()
+        t.n_features = len(a['id'])
+        t.feature_id, t.start_frame, t.n_obs = _ip(a['id']), _ip(a['start']), _ip(a['nobs'])
+        t.solve_flag = _ip(a['flag']) if a['flag'] is not None else None
+        t.depth, t.obs = _dp(a['depth']), _dp(a['obs'])
+        self._chk(self.lib.vg_ba_seq_import(self.h, int(w), C.byref(p.struct), C.byref(t)), "vg_ba_seq_import")
 
     def seq_end(self):
         self._chk(self.lib.vg_ba_seq_end(self.h), "vg_ba_seq_end")

@@ -1182,6 +1182,35 @@ extern "C" int vg_ba_seq_end(vg_handle* h) {
     return VG_OK;
 }
 
+// the track table of one window as the kernels of csrc/ba_seq.hip hold it, from the caller's arrays
+static void seq_fill_tracks(const vg_ba_tracks* t, int FT, int K, int hdr_ints, int* i, double* d) {
+    i[0] = t->n_features;
+    size_t row = 0;
+    for (int f = 0; f < t->n_features; ++f) {
+        i[hdr_ints + f] = t->feature_id[f];
+        i[hdr_ints + FT + f] = t->start_frame[f];
+        i[hdr_ints + 2 * FT + f] = t->n_obs[f];
+        i[hdr_ints + 3 * FT + f] = t->solve_flag ? t->solve_flag[f] : 0;
+        i[hdr_ints + 4 * FT + f] = -1;
+        d[f] = t->depth[f];
+        for (int j = 0; j < t->n_obs[f]; ++j, ++row) {
+            const double* r = t->obs + row * 8;                       // [x y z u v vx vy cur_td]
+            double* o = d + FT + ((size_t)f * K + j) * 8;             // [x y u v vx vy cur_td z]
+            o[0] = r[0]; o[1] = r[1]; o[2] = r[3]; o[3] = r[4]; o[4] = r[5]; o[5] = r[6]; o[6] = r[7]; o[7] = r[2];
+        }
+    }
+}
+static int seq_check_tracks(vg_handle* h, const vg_ba_tracks* t, int FT, int K) {
+    if (t->n_features < 0 || t->n_features > FT || (t->n_features > 0 && (!t->feature_id || !t->start_frame || !t->n_obs || !t->depth || !t->obs))) {
+        h->err = "bad track table"; return VG_ERR_BAD_ARG;
+    }
+    for (int f = 0; f < t->n_features; ++f)
+        if (t->n_obs[f] < 1 || t->start_frame[f] < 0 || t->start_frame[f] + t->n_obs[f] > K - 1) {
+            h->err = "a track reaches beyond frame K - 2 (the newest slot is filled by the next step)"; return VG_ERR_BAD_ARG;
+        }
+    return VG_OK;
+}
+
 extern "C" int vg_ba_seq_begin(vg_handle* h, int nwin, const vg_ba_seq_config* cfg, const vg_ba_problem* const* windows,
                                const vg_ba_tracks* const* tracks) {
     VG_RANGE("vg_ba_seq_begin");
@@ -1204,13 +1233,8 @@ extern "C" int vg_ba_seq_begin(vg_handle* h, int nwin, const vg_ba_seq_config* c
         if (p->relo_n != 0) { h->err = "vg_ba_seq_begin: relocalisation factors are not offered in a sequence"; return VG_ERR_UNSUPPORTED; }
         if (p->prior_n == VG_PRIOR_RESIDENT) { h->err = "vg_ba_seq_begin: the first prior comes from the host"; return VG_ERR_BAD_ARG; }
         if (p->max_iters != windows[0]->max_iters) { h->err = "vg_ba_seq_begin: windows must share max_iters"; return VG_ERR_BAD_ARG; }
-        if (t->n_features < 0 || t->n_features > FT || (t->n_features > 0 && (!t->feature_id || !t->start_frame || !t->n_obs || !t->depth || !t->obs))) {
-            h->err = "vg_ba_seq_begin: bad track table"; return VG_ERR_BAD_ARG;
-        }
-        for (int f = 0; f < t->n_features; ++f)
-            if (t->n_obs[f] < 1 || t->start_frame[f] < 0 || t->start_frame[f] + t->n_obs[f] > K - 1) {
-                h->err = "vg_ba_seq_begin: a track reaches beyond frame K - 2 (the newest slot is filled by the first step)"; return VG_ERR_BAD_ARG;
-            }
+        const int rct = seq_check_tracks(h, t, FT, K);
+        if (rct) return rct;
     }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1251,24 +1275,7 @@ extern "C" int vg_ba_seq_begin(vg_handle* h, int nwin, const vg_ba_seq_config* c
     std::vector<int> ti((size_t)nwin * D.fi_stride, 0), sp((size_t)nwin * D.sp_stride, 0);
     std::vector<double> td((size_t)nwin * D.fd_stride, 0.0);
     for (int w = 0; w < nwin; ++w) {
-        const vg_ba_tracks* t = tracks[w];
-        int* i = ti.data() + (size_t)w * D.fi_stride;
-        double* d = td.data() + (size_t)w * D.fd_stride;
-        i[0] = t->n_features;
-        size_t row = 0;
-        for (int f = 0; f < t->n_features; ++f) {
-            i[hdr_ints + f] = t->feature_id[f];
-            i[hdr_ints + FT + f] = t->start_frame[f];
-            i[hdr_ints + 2 * FT + f] = t->n_obs[f];
-            i[hdr_ints + 3 * FT + f] = t->solve_flag ? t->solve_flag[f] : 0;
-            i[hdr_ints + 4 * FT + f] = -1;
-            d[f] = t->depth[f];
-            for (int j = 0; j < t->n_obs[f]; ++j, ++row) {
-                const double* r = t->obs + row * 8;                       // [x y z u v vx vy cur_td]
-                double* o = d + FT + ((size_t)f * K + j) * 8;             // [x y u v vx vy cur_td z]
-                o[0] = r[0]; o[1] = r[1]; o[2] = r[3]; o[3] = r[4]; o[4] = r[5]; o[5] = r[6]; o[6] = r[7]; o[7] = r[2];
-            }
-        }
+        seq_fill_tracks(tracks[w], FT, K, hdr_ints, ti.data() + (size_t)w * D.fi_stride, td.data() + (size_t)w * D.fd_stride);
         const BaBatch::PriorSlot& s = B.slot[w];
         int* q = sp.data() + (size_t)w * D.sp_stride;
         q[0] = s.n; q[1] = s.n ? s.nb : 0;
@@ -1374,5 +1381,106 @@ extern "C" int vg_ba_seq_get_tracks(vg_handle* h, int window, int cap, int* n_fe
     const double* dsrc = D.ft_d[Q.cur] + (size_t)window * D.fd_stride;
     if (depth && n) HIPCHK(h, hipMemcpy(depth, dsrc, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (obs && n) HIPCHK(h, hipMemcpy(obs, dsrc + D.FT, (size_t)n * D.K * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return VG_OK;
+}
+
+// ---- hand-back / re-seed of one window of a running sequence ----------------------------------------------------------------
+extern "C" int vg_ba_seq_export(vg_handle* h, int window, double* pose, double* speedbias, double* ex_pose, double* td,
+                                vg_imu_preint* imu, vg_ba_prior* prior) {
+    VG_RANGE("vg_ba_seq_export");
+    if (!h) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    BaSeq& Q = B.seq;
+    if (!Q.active || window < 0 || window >= Q.nwin) return VG_ERR_BAD_ARG;
+    const BaLayout& L = B.L;
+    const int K = L.K;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<double> di(L.dstride);
+    std::vector<int> ia(L.istride), sp(Q.D.sp_stride);
+    HIPCHK(h, hipMemcpy(di.data(), B.P.din + (size_t)window * L.dstride, di.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(ia.data(), B.P.iarr + (size_t)window * L.istride, ia.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(sp.data(), Q.D.sp + (size_t)window * Q.D.sp_stride, sp.size() * sizeof(int), hipMemcpyDeviceToHost));
+    if (pose) memcpy(pose, di.data() + L.do_pose, sizeof(double) * 7 * K);
+    if (speedbias) memcpy(speedbias, di.data() + L.do_sb, sizeof(double) * 9 * K);
+    if (ex_pose) memcpy(ex_pose, di.data() + L.do_ex, sizeof(double) * 7);
+    if (td) *td = di[L.do_td];
+    if (imu) {
+        for (int k = 0; k < K - 1; ++k) {
+            const double* d = di.data() + L.do_imu + (size_t)k * BA_IMU_STRIDE;
+            vg_imu_preint& m = imu[k];
+            memset(&m, 0, sizeof(m));
+            m.sum_dt = d[0];
+            memcpy(m.delta_p, d + 1, 24); memcpy(m.delta_q, d + 4, 32); memcpy(m.delta_v, d + 8, 24);
+            memcpy(m.linearized_ba, d + 11, 24); memcpy(m.linearized_bg, d + 14, 24);
+            memcpy(m.jacobian, d + 17, 225 * 8); memcpy(m.covariance, d + 242, 225 * 8);
+            m.valid = (k < K - 2) ? ia[L.io_imu_valid + k] : 0;      // (the newest interval is a placeholder between two frames)
+        }
+    }
+    if (prior) {
+        prior->n = prior->m = prior->nblocks = prior->valid = 0;
+        const int n = sp[0], nb = n ? sp[1] : 0;
+        if (n > 0) {
+            if (n > prior->cap || nb > prior->cap_blocks) { h->err = "vg_ba_prior capacity too small"; return VG_ERR_BAD_ARG; }
+            std::vector<double> pr(L.pstride);
+            HIPCHK(h, hipMemcpy(pr.data(), B.P.pri + (size_t)window * L.pstride, pr.size() * sizeof(double), hipMemcpyDeviceToHost));
+            int x0n = 0;
+            for (int b = 0; b < nb; ++b) {
+                prior->block_kind[b] = sp[2 + b];
+                prior->block_index[b] = sp[2 + (K + 4) + b];
+                x0n += blk_gsize(sp[2 + b]);
+            }
+            for (int r = 0; r < n; ++r) memcpy(prior->J0 + (size_t)r * n, pr.data() + L.po_J0 + (size_t)r * L.pld, sizeof(double) * n);
+            memcpy(prior->r0, pr.data() + L.po_r0, sizeof(double) * n);
+            memcpy(prior->x0, pr.data() + L.po_x0, sizeof(double) * x0n);
+            prior->n = n; prior->nblocks = nb; prior->valid = 1;
+        }
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_ba_seq_import(vg_handle* h, int window, const vg_ba_problem* p, const vg_ba_tracks* t) {
+    VG_RANGE("vg_ba_seq_import");
+    if (!h || !p || !t) return VG_ERR_BAD_ARG;
+    BaBatch& B = h->ba;
+    BaSeq& Q = B.seq;
+    if (!Q.active || window < 0 || window >= Q.nwin) return VG_ERR_BAD_ARG;
+    const BaLayout& L = B.L;
+    const SeqDev& D = Q.D;
+    const int K = L.K, FT = D.FT;
+    int hdr_ints = 0;
+    (void)ba_seq_limits(nullptr, nullptr, &hdr_ints, nullptr);
+    if (p->K != K || (p->estimate_extrinsic != 0) != (L.e != 0) || (p->estimate_td != 0) != (L.t != 0) || p->relo_n != 0 || p->prior_n == VG_PRIOR_RESIDENT ||
+        p->max_iters != D.max_iters) { h->err = "vg_ba_seq_import: the window does not fit the running sequence (K, options)"; return VG_ERR_BAD_ARG; }
+    int rc = check_problem(h, p);
+    if (rc) return rc;
+    if (p->prior_n > L.Ncap || p->prior_nblocks > L.NBcap || p->prior_nblocks > K + 4) { h->err = "vg_ba_seq_import: prior beyond the sequence's capacities"; return VG_ERR_UNSUPPORTED; }
+    rc = seq_check_tracks(h, t, FT, K);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // states, pre-integrations, parameters: the slot's input slab, packed like an upload (the landmark tables are rebuilt by the
+    // next step anyway); the prior into the slot of the prior buffer
+    std::vector<int> ia(L.istride, 0);
+    std::vector<double> di(L.dstride, 0.0), pr(L.pstride, 0.0);
+    PriorRef ref;
+    ref.n = p->prior_n; ref.nb = p->prior_n ? p->prior_nblocks : 0; ref.kind = p->prior_block_kind; ref.idx = p->prior_block_index;
+    vg_ba_problem q = *p;
+    q.L = 0; q.n_obs = 0;
+    rc = pack_window(h, L, &q, ref, VG_MARGIN_OLD, ia.data(), di.data(), pr.data());
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(B.P.iarr + (size_t)window * L.istride, ia.data(), ia.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(B.P.din + (size_t)window * L.dstride, di.data(), di.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (ref.n > 0) HIPCHK(h, hipMemcpy(B.P.pri + (size_t)window * L.pstride, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<int> sp(D.sp_stride, 0);
+    sp[0] = ref.n; sp[1] = ref.nb;
+    for (int b = 0; b < ref.nb; ++b) { sp[2 + b] = ref.kind[b]; sp[2 + (K + 4) + b] = ref.idx[b]; }
+    HIPCHK(h, hipMemcpy(D.sp + (size_t)window * D.sp_stride, sp.data(), sp.size() * sizeof(int), hipMemcpyHostToDevice));
+    // the track table the next step reads
+    std::vector<int> ti(D.fi_stride, 0);
+    std::vector<double> td(D.fd_stride, 0.0);
+    seq_fill_tracks(t, FT, K, hdr_ints, ti.data(), td.data());
+    HIPCHK(h, hipMemcpy(D.ft_i[Q.cur] + (size_t)window * D.fi_stride, ti.data(), ti.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(D.ft_d[Q.cur] + (size_t)window * D.fd_stride, td.data(), td.size() * sizeof(double), hipMemcpyHostToDevice));
     return VG_OK;
 }

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <vector>
 #include "estimator.h"
@@ -187,7 +188,11 @@ static int replay_seq(const char* in, const char* out) {
     ACC_N = noise[0]; GYR_N = noise[1]; ACC_W = noise[2]; GYR_W = noise[3];
     vg_handle* h = nullptr;
     if (vg_create(&h) != VG_OK) { fprintf(stderr, "vg_create failed (no CPU fallback)\n"); return 3; }
-    ResidentEstimators res(N, 512, 512);
+    std::unique_ptr<ResidentEstimators> resp(new ResidentEstimators(N, 512, 512));
+    // VINS_REPLAY_HANDBACK=<frame>: after that frame every window is handed back into a host Estimator (handBack), a NEW batch
+    // takes them over (handOver + begin) and estimator 0 is re-seeded once more in place (reseed): the rest of the run must not notice
+    const char* hb_env = getenv("VINS_REPLAY_HANDBACK");
+    const int handback_frame = hb_env ? atoi(hb_env) : -1;
     for (int i = 0; i < N; ++i) {
         // the estimator as the reference's code would hold it between two frames, then handed over
         Estimator est;
@@ -219,10 +224,10 @@ static int replay_seq(const char* in, const char* out) {
             }
             est.f_manager.feature.push_back(f);
         }
-        res.handOver(i, est, Vector3d(last[0], last[1], last[2]), Vector3d(last[3], last[4], last[5]));
+        resp->handOver(i, est, Vector3d(last[0], last[1], last[2]), Vector3d(last[3], last[4], last[5]));
         for (int k = 0; k <= WINDOW_SIZE; ++k) { delete est.pre_integrations[k]; est.pre_integrations[k] = nullptr; }
     }
-    res.begin();
+    resp->begin();
     FILE* o = fopen(out, "w");
     std::vector<double> smp((size_t)S * 7);
     for (int w = 0; w < W; ++w) {
@@ -231,7 +236,7 @@ static int replay_seq(const char* in, const char* out) {
             rd.d(&stamp[i], 1);
             rd.d(smp.data(), S * 7);
             for (int s = 0; s < S; ++s)
-                res.processIMU(i, smp[7 * s], Vector3d(smp[7 * s + 1], smp[7 * s + 2], smp[7 * s + 3]), Vector3d(smp[7 * s + 4], smp[7 * s + 5], smp[7 * s + 6]));
+                resp->processIMU(i, smp[7 * s], Vector3d(smp[7 * s + 1], smp[7 * s + 2], smp[7 * s + 3]), Vector3d(smp[7 * s + 4], smp[7 * s + 5], smp[7 * s + 6]));
             int n;
             rd.i(&n, 1);
             ResidentEstimators::Image image;
@@ -243,16 +248,30 @@ static int replay_seq(const char* in, const char* out) {
                 for (int c = 0; c < 7; ++c) p(c, 0) = r[c];
                 image[id].emplace_back(0, p);
             }
-            res.processImage(i, image);
+            resp->processImage(i, image);
         }
-        res.solve();
+        resp->solve();
         for (int i = 0; i < N; ++i) {
             // (the mirror is post-slide: the frame just solved sits in slot WINDOW_SIZE either way)
-            const ResidentEstimators::One& e = res[i];
+            const ResidentEstimators::One& e = (*resp)[i];
             const Quaterniond q(e.Rs[WINDOW_SIZE]);
             fprintf(o, "%d,%.0f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%d,%d,%d,%d\n", i, stamp[i] * 1e9, e.Ps[WINDOW_SIZE].x(), e.Ps[WINDOW_SIZE].y(),
                     e.Ps[WINDOW_SIZE].z(), q.w(), q.x(), q.y(), q.z(), e.Vs[WINDOW_SIZE].x(), e.Vs[WINDOW_SIZE].y(), e.Vs[WINDOW_SIZE].z(),
                     (int)e.marginalization_flag, e.n_features, e.status, e.failure_occur ? 1 : 0);
+        }
+        if (w == handback_frame) {
+            std::unique_ptr<ResidentEstimators> next(new ResidentEstimators(N, 512, 512));
+            std::vector<std::unique_ptr<Estimator>> back;
+            for (int i = 0; i < N; ++i) {
+                back.emplace_back(new Estimator());
+                resp->handBack(i, *back[i]);
+                next->handOver(i, *back[i], (*resp)[i].acc_0, (*resp)[i].gyr_0);
+            }
+            next->begin();
+            next->reseed(0, *back[0], (*resp)[0].acc_0, (*resp)[0].gyr_0);
+            for (auto& e : back)
+                for (int k = 0; k <= WINDOW_SIZE; ++k) { delete e->pre_integrations[k]; e->pre_integrations[k] = nullptr; }
+            resp = std::move(next);
         }
     }
     fclose(o);

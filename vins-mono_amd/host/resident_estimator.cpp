@@ -37,11 +37,23 @@ ResidentEstimators::~ResidentEstimators() {
 }
 
 void ResidentEstimators::handOver(int i, Estimator& e, const Vector3d& acc_0, const Vector3d& gyr_0) {
-    if (begun_) throw std::runtime_error("handOver after begin()");
+    if (begun_) throw std::runtime_error("handOver after begin(): use reseed()");
+    delete win_[i];
+    win_[i] = pack(i, e, acc_0, gyr_0);
+}
+
+void ResidentEstimators::reseed(int i, Estimator& e, const Vector3d& acc_0, const Vector3d& gyr_0) {
+    if (!begun_) throw std::runtime_error("reseed() before begin(): use handOver()");
+    Window* w = pack(i, e, acc_0, gyr_0);
+    const int rc = vg_ba_seq_import(vg_, i, &w->prob, &w->tracks);
+    delete w;
+    if (rc != VG_OK) throw std::runtime_error(std::string("vg_ba_seq_import: ") + vg_last_error(vg_));
+}
+
+ResidentEstimators::Window* ResidentEstimators::pack(int i, Estimator& e, const Vector3d& acc_0, const Vector3d& gyr_0) {
     const int K = WINDOW_SIZE + 1;
     One& o = est_[i];
-    delete win_[i];
-    Window* w = win_[i] = new Window();
+    Window* w = new Window();
     e.collectPrior();                                             // a marginalization result still on the estimator's own handle
     e.vector2double();
     w->pose.assign(&e.para_Pose[0][0], &e.para_Pose[0][0] + 7 * K);
@@ -102,6 +114,106 @@ void ResidentEstimators::handOver(int i, Estimator& e, const Vector3d& acc_0, co
     o.merge_pending = false; o.have_frame = false;
     o.last_R = o.Rs[WINDOW_SIZE]; o.last_P = o.Ps[WINDOW_SIZE]; o.last_R0 = o.Rs[0]; o.last_P0 = o.Ps[0];      // estimator.cpp:205-208
     o.failure_occur = false;
+    return w;
+}
+
+void ResidentEstimators::handBack(int i, Estimator& e) {
+    if (!begun_) throw std::runtime_error("handBack() before begin()");
+    const int K = WINDOW_SIZE + 1;
+    One& o = est_[i];
+    std::vector<double> pose(7 * K), sb(9 * K), ex(7);
+    double td = 0;
+    std::vector<vg_imu_preint> imu(K - 1);
+    const int cap = 6 * K + 32, capb = K + 8;
+    std::vector<int> pkind(capb), pindex(capb);
+    std::vector<double> pJ0((size_t)cap * cap), pr0(cap), px0(9 * capb);
+    vg_ba_prior pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.cap = cap; pr.cap_blocks = capb; pr.block_kind = pkind.data(); pr.block_index = pindex.data(); pr.J0 = pJ0.data(); pr.r0 = pr0.data(); pr.x0 = px0.data();
+    if (vg_ba_seq_export(vg_, i, pose.data(), sb.data(), ex.data(), &td, imu.data(), &pr) != VG_OK) throw std::runtime_error(std::string("vg_ba_seq_export: ") + vg_last_error(vg_));
+    for (int k = 0; k < K; ++k) {
+        const double* x = &pose[7 * k];
+        const double* s = &sb[9 * k];
+        const double qn = std::sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+        e.Ps[k] = Vector3d(x[0], x[1], x[2]);
+        e.Rs[k] = Quaterniond(x[6] / qn, x[3] / qn, x[4] / qn, x[5] / qn).toRotationMatrix();
+        e.Vs[k] = Vector3d(s[0], s[1], s[2]); e.Bas[k] = Vector3d(s[3], s[4], s[5]); e.Bgs[k] = Vector3d(s[6], s[7], s[8]);
+    }
+    {
+        const double qn = std::sqrt(ex[3] * ex[3] + ex[4] * ex[4] + ex[5] * ex[5] + ex[6] * ex[6]);
+        e.tic[0] = Vector3d(ex[0], ex[1], ex[2]);
+        e.ric[0] = Quaterniond(ex[6] / qn, ex[3] / qn, ex[4] / qn, ex[5] / qn).toRotationMatrix();
+        e.td = td;
+    }
+    for (int j = 0; j <= WINDOW_SIZE; ++j) { delete e.pre_integrations[j]; e.pre_integrations[j] = nullptr; }
+    for (int k = 0; k + 2 < K; ++k) {                               // imu[k] links frame k -> k + 1 = pre_integrations[k + 1]
+        const vg_imu_preint& m = imu[k];
+        if (!m.valid) continue;
+        IntegrationBase* p = new IntegrationBase();
+        p->sum_dt = m.sum_dt;
+        p->delta_p = Vector3d(m.delta_p[0], m.delta_p[1], m.delta_p[2]); p->delta_v = Vector3d(m.delta_v[0], m.delta_v[1], m.delta_v[2]);
+        p->linearized_ba = Vector3d(m.linearized_ba[0], m.linearized_ba[1], m.linearized_ba[2]);
+        p->linearized_bg = Vector3d(m.linearized_bg[0], m.linearized_bg[1], m.linearized_bg[2]);
+        p->delta_q = Quaterniond(m.delta_q[3], m.delta_q[0], m.delta_q[1], m.delta_q[2]);
+        for (int r = 0; r < 15; ++r)
+            for (int c = 0; c < 15; ++c) { p->jacobian(r, c) = m.jacobian[r * 15 + c]; p->covariance(r, c) = m.covariance[r * 15 + c]; }
+        if (k + 3 == K) {                                           // pre_integrations[WINDOW_SIZE - 1]: with the samples a later merge needs
+            p->linearized_acc = o.prev.linearized_acc; p->linearized_gyr = o.prev.linearized_gyr;
+            for (size_t q = 0; q + 6 < o.prev.samples.size(); q += 7) {
+                p->dt_buf.push_back(o.prev.samples[q]);
+                p->acc_buf.push_back(Vector3d(o.prev.samples[q + 1], o.prev.samples[q + 2], o.prev.samples[q + 3]));
+                p->gyr_buf.push_back(Vector3d(o.prev.samples[q + 4], o.prev.samples[q + 5], o.prev.samples[q + 6]));
+            }
+        }
+        e.pre_integrations[k + 1] = p;
+    }
+    // f_manager.feature
+    int n = 0;
+    std::vector<int> id(max_features_), start(max_features_), nobs(max_features_), flag(max_features_);
+    std::vector<double> depth(max_features_), rows((size_t)max_features_ * K * 8);
+    if (vg_ba_seq_get_tracks(vg_, i, max_features_, &n, id.data(), start.data(), nobs.data(), flag.data(), depth.data(), rows.data()) != VG_OK)
+        throw std::runtime_error(std::string("vg_ba_seq_get_tracks: ") + vg_last_error(vg_));
+    e.f_manager.feature.clear();
+    for (int f = 0; f < n; ++f) {
+        FeaturePerId it;
+        it.feature_id = id[f]; it.start_frame = start[f]; it.estimated_depth = depth[f]; it.solve_flag = flag[f]; it.used_num = nobs[f];
+        for (int j = 0; j < nobs[f]; ++j) {
+            const double* r = &rows[((size_t)f * K + j) * 8];        // [x y u v vx vy cur_td z]
+            FeaturePerFrame fr;
+            fr.point = Vector3d(r[0], r[1], r[7]); fr.uv.x() = r[2]; fr.uv.y() = r[3]; fr.velocity.x() = r[4]; fr.velocity.y() = r[5]; fr.cur_td = r[6];
+            it.feature_per_frame.push_back(fr);
+        }
+        e.f_manager.feature.push_back(it);
+    }
+    // last_marginalization_info + parameter blocks (what collectPrior() builds from a vg_ba_prior)
+    delete e.last_marginalization_info;
+    e.last_marginalization_info = nullptr;
+    e.last_marginalization_parameter_blocks.clear();
+    e.prior_pending = false;
+    if (pr.valid && pr.n > 0) {
+        MarginalizationInfo* mi = new MarginalizationInfo();
+        mi->n = pr.n; mi->m = 0;
+        mi->linearized_jacobians.resize(pr.n, pr.n);
+        mi->linearized_residuals.resize(pr.n);
+        for (int r = 0; r < pr.n; ++r) {
+            mi->linearized_residuals(r) = pr0[r];
+            for (int c = 0; c < pr.n; ++c) mi->linearized_jacobians(r, c) = pJ0[(size_t)r * pr.n + c];
+        }
+        int off = 0, x0o = 0;
+        for (int b = 0; b < pr.nblocks; ++b) {
+            const int kind = pkind[b], idx = pindex[b];
+            const int gs = kind == VG_BLK_SPEEDBIAS ? 9 : (kind == VG_BLK_TD ? 1 : 7), ls = kind == VG_BLK_SPEEDBIAS ? 9 : (kind == VG_BLK_TD ? 1 : 6);
+            mi->keep_block_size.push_back(gs);
+            mi->keep_block_idx.push_back(off);
+            double* d = new double[gs];
+            memcpy(d, px0.data() + x0o, sizeof(double) * gs);
+            mi->keep_block_data.push_back(d);
+            e.last_marginalization_parameter_blocks.push_back(kind == VG_BLK_POSE ? e.para_Pose[idx] : kind == VG_BLK_SPEEDBIAS ? e.para_SpeedBias[idx]
+                                                              : kind == VG_BLK_EXPOSE ? e.para_Ex_Pose[0] : e.para_Td[0]);
+            off += ls; x0o += gs;
+        }
+        e.last_marginalization_info = mi;
+    }
 }
 
 void ResidentEstimators::begin() {

@@ -57,6 +57,12 @@ class ResidentEstimators {
     // last one with its raw samples), f_manager.feature and last_marginalization_info; acc_0 / gyr_0 = the newest IMU sample.
     void handOver(int i, Estimator& e, const Vector3d& acc_0, const Vector3d& gyr_0);
     void begin();                             // vg_ba_seq_begin once every estimator has been handed over
+    // The way back, between two frames: window i of the running sequence into the members of a host Estimator (Ps / Rs / Vs / Bas /
+    // Bgs, ric / tic / td, pre_integrations[1 .. WINDOW_SIZE - 1] -- the last one with its raw samples --, f_manager.feature,
+    // last_marginalization_info + parameter blocks): vg_ba_seq_export + vg_ba_seq_get_tracks.  For a relocalisation frame (not
+    // offered in a sequence), a checkpoint, a re-start after failureDetection().  The device keeps its copy; reseed() replaces it.
+    void handBack(int i, Estimator& e);
+    void reseed(int i, Estimator& e, const Vector3d& acc_0, const Vector3d& gyr_0);     // vg_ba_seq_import: estimator i only
     void processIMU(int i, double dt, const Vector3d& linear_acceleration, const Vector3d& angular_velocity);
     void processImage(int i, const Image& image);
     void solve();                             // one frame for every estimator (all must have received their image)
@@ -65,6 +71,7 @@ class ResidentEstimators {
 
   private:
     struct Window;                            // the hand-over arrays of one estimator (alive until begin())
+    Window* pack(int i, Estimator& e, const Vector3d& acc_0, const Vector3d& gyr_0);
     std::vector<One> est_;
     std::vector<Window*> win_;
     vg_handle* vg_ = nullptr;
