@@ -373,7 +373,8 @@ int vg_ba_seq_get_tracks(vg_handle* h, int window, int cap, int* n_features, int
 /* Hand-back and re-seed of ONE window of a running sequence, between two frames (after a step):
  *   export  the window of slot `window` in the form vg_ba_seq_begin takes it -- states (K x 7, K x 9, 7, 1), the K-1 pre-integration
  *           records (the newest one is the placeholder the next step fills: valid = 0), the prior (caller-allocated as for
- *           vg_ba_optimize; n = 0: none) -- together with vg_ba_seq_get_tracks this is everything the reference keeps in
+ *           vg_ba_optimize; n = 0: none; after a step that chose VG_MARGIN_SECOND_NEW the record of interval K-3 is still the
+ *           un-merged one -- the merged record reaches the device with the next frame's imu_merged) -- together with vg_ba_seq_get_tracks this is everything the reference keeps in
  *           Ps / Rs / Vs / Bas / Bgs, pre_integrations[], f_manager.feature and last_marginalization_info: a host Estimator can
  *           take the window back (a relocalisation frame, which a sequence does not offer; a checkpoint; a failure re-start);
  *   import  replaces what slot `window` holds (same K and estimate_* options as the sequence; prior from the host or none) while

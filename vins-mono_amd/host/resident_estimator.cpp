@@ -146,6 +146,17 @@ void ResidentEstimators::handBack(int i, Estimator& e) {
         e.td = td;
     }
     for (int j = 0; j <= WINDOW_SIZE; ++j) { delete e.pre_integrations[j]; e.pre_integrations[j] = nullptr; }
+    if (o.merge_pending) {
+        // the last frame was dropped as a non-keyframe: pre_integrations[WINDOW_SIZE - 1] has taken its samples (estimator.cpp:1069-1085)
+        // but the device still holds the record of the shorter interval (the merged one travels with the NEXT frame): integrate it now
+        const int ns = (int)o.prev.samples.size() / 7;
+        const int off[2] = {0, ns};
+        const double first[6] = {o.prev.linearized_acc.x(), o.prev.linearized_acc.y(), o.prev.linearized_acc.z(), o.prev.linearized_gyr.x(), o.prev.linearized_gyr.y(), o.prev.linearized_gyr.z()};
+        const double bias[6] = {o.prev.linearized_ba.x(), o.prev.linearized_ba.y(), o.prev.linearized_ba.z(), o.prev.linearized_bg.x(), o.prev.linearized_bg.y(), o.prev.linearized_bg.z()};
+        const double noise[4] = {ACC_N, GYR_N, ACC_W, GYR_W};
+        if (vg_imu_preintegrate(vg_, 1, off, o.prev.samples.data(), first, bias, noise, &imu[K - 3]) != VG_OK)
+            throw std::runtime_error(std::string("vg_imu_preintegrate: ") + vg_last_error(vg_));
+    }
     for (int k = 0; k + 2 < K; ++k) {                               // imu[k] links frame k -> k + 1 = pre_integrations[k + 1]
         const vg_imu_preint& m = imu[k];
         if (!m.valid) continue;
