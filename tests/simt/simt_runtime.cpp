@@ -1,7 +1,9 @@
 // tests/simt/simt_runtime.cpp — fiber scheduler + host-runtime stubs behind tests/simt/hip/hip_runtime.h.
 // TEST INFRASTRUCTURE (see the header).  One OS thread; a workgroup = blockDim fibers; workgroups run sequentially.
 #include <hip/hip_runtime.h>
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 #include <chrono>
 #include <random>
 #include <string>
@@ -13,6 +15,63 @@ thread_local __attribute__((aligned(16))) char bp_smem[160 * 1024];
 thread_local __attribute__((aligned(16))) char mg_smem[160 * 1024];
 thread_local __attribute__((aligned(16))) unsigned char sel_smem[160 * 1024];
 
+// ---- fiber switch.  glibc's swapcontext saves / restores the signal mask with a system call on every switch (half of the run time
+//      of the emulated tests was kernel time); a fiber here only needs its callee-saved registers and its stack pointer.
+#if defined(__x86_64__)
+extern "C" void simt_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl simt_switch
+    .type simt_switch,@function
+simt_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size simt_switch,.-simt_switch
+)");
+struct FiberCtx { void* sp = nullptr; };
+static void ctx_make(FiberCtx& c, char* stack, size_t size, void (*entry)()) {
+    // the frame simt_switch pops: [mxcsr | x87 cw][r15 r14 r13 r12 rbx rbp][return address = entry][0]; at `entry` the stack is
+    // aligned as after a call (rsp = 16k + 8)
+    uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+    uint64_t* a = (uint64_t*)(top - 16);
+    a[1] = 0;
+    a[0] = (uint64_t)(uintptr_t)entry;
+    for (int k = 1; k <= 6; ++k) a[-k] = 0;
+    uint32_t* fp = (uint32_t*)(a - 7);
+    fp[0] = 0x1F80;                    // mxcsr: default rounding, exceptions masked
+    fp[1] = 0x037F;                    // x87 control word
+    c.sp = (void*)(a - 7);
+}
+static inline void ctx_switch(FiberCtx& from, FiberCtx& to) { simt_switch(&from.sp, to.sp); }
+#else
+struct FiberCtx { ucontext_t uc; };
+static void ctx_make(FiberCtx& c, char* stack, size_t size, void (*entry)()) {
+    getcontext(&c.uc);
+    c.uc.uc_stack.ss_sp = stack; c.uc.uc_stack.ss_size = size; c.uc.uc_link = nullptr;
+    makecontext(&c.uc, entry, 0);
+}
+static inline void ctx_switch(FiberCtx& from, FiberCtx& to) { swapcontext(&from.uc, &to.uc); }
+#endif
+
 namespace simt {
 thread_local Lane* cur = nullptr;
 thread_local dim3 g_block, g_grid;
@@ -21,8 +80,8 @@ thread_local const char* kernarg_end = nullptr;
 namespace {
 enum { RUN = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
 struct Fiber {
-    ucontext_t ctx;
-    std::vector<char> stack;
+    FiberCtx ctx;
+    char* stack = nullptr;   // from the thread's pool (below)
     Lane lane;
     int state = RUN;
     unsigned gen = 0;        // generation of the barrier it waits on
@@ -37,12 +96,23 @@ struct BlockState {
     std::vector<WaveState> w;
     int alive = 0, arrived = 0;
     unsigned gen = 0;
-    ucontext_t sched;
+    FiberCtx sched;
     int running = -1;
     const std::function<void()>* body = nullptr;
 };
 thread_local BlockState* B = nullptr;
 const size_t kStack = 256 * 1024;
+// fiber stacks are kept per host thread and re-used by every launch: allocating (and zero-filling) 256 KB per lane and launch was
+// most of the run time of the emulated tests (page faults).  Uninitialised on purpose: only the pages a fiber touches get mapped.
+struct StackPool {
+    std::vector<char*> s;
+    ~StackPool() { for (char* p : s) free(p); }
+    char* get(size_t i) {
+        while (s.size() <= i) { void* p = nullptr; if (posix_memalign(&p, 64, kStack)) abort(); s.push_back((char*)p); }
+        return s[i];
+    }
+};
+thread_local StackPool g_stacks;
 
 void release_block() { B->arrived = 0; ++B->gen; }
 void release_wave(WaveState& w) { w.arrived = 0; ++w.gen; }
@@ -57,12 +127,12 @@ void fiber_main() {
     // a finished lane no longer takes part in barriers: release whoever was waiting for it
     if (B->alive > 0 && B->arrived == B->alive) release_block();
     if (w.alive > 0 && w.arrived == w.alive) release_wave(w);
-    swapcontext(&me.ctx, &B->sched);
+    ctx_switch(me.ctx, B->sched);
 }
 
 void yield_to_scheduler() {
     Fiber& me = B->f[B->running];
-    swapcontext(&me.ctx, &B->sched);
+    ctx_switch(me.ctx, B->sched);
 }
 }  // namespace
 
@@ -95,7 +165,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
     g_block = block; g_grid = grid;
     BlockState bs;
     bs.f.resize(nthr);
-    for (auto& f : bs.f) f.stack.resize(kStack);
+    for (int t = 0; t < nthr; ++t) bs.f[t].stack = g_stacks.get(t);
     std::vector<int> perm(nthr);
     std::mt19937 rng(12345);
     for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -112,11 +182,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
             f.lane.tid.x = t % block.x; f.lane.tid.y = (t / block.x) % block.y; f.lane.tid.z = t / (block.x * block.y);
             f.lane.bid.x = bx; f.lane.bid.y = by; f.lane.bid.z = bz;
             bs.w[f.lane.wave].alive++;
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = f.stack.data();
-            f.ctx.uc_stack.ss_size = kStack;
-            f.ctx.uc_link = nullptr;
-            makecontext(&f.ctx, fiber_main, 0);
+            ctx_make(f.ctx, f.stack, kStack, fiber_main);
         }
         for (int t = 0; t < nthr; ++t) perm[t] = order == 1 ? nthr - 1 - t : t;
         int stalled = 0;
@@ -131,7 +197,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
                 bs.running = perm[k];
                 cur = &f.lane;
                 progressed = true;
-                swapcontext(&bs.sched, &f.ctx);
+                ctx_switch(bs.sched, f.ctx);
             }
             if (!progressed && ++stalled > 2) {
                 fprintf(stderr, "simt: deadlock in block (%u,%u,%u): %d lanes alive, %d at the block barrier; a barrier or a "
