@@ -23,6 +23,16 @@ def test_resident_sequence_equals_host_bookkeeping(two_handles, min_parallax, wa
     assert (M.NEW in flat) == want_new
 
 
+@pytest.mark.parametrize("order", ["reverse", "shuffle"])
+def test_resident_sequence_under_other_fiber_orders(two_handles, monkeypatch, order):
+    """The emulator has no wavefront lock-step: a missing barrier in the sequence kernels (ordered compactions, table builds that
+    read what other lanes wrote) shows up as a result that depends on the order the lanes run in (tests/simt/README.md)."""
+    monkeypatch.setenv("SIMT_ORDER", order)
+    h_seq, h_ref = two_handles
+    flags = M.run_both(h_seq, h_ref, seeds=[22], K=11, L=70, n_steps=3, min_parallax=0.25, max_features=128, check=M.check_step)
+    assert M.NEW in [f for fr in flags for f in fr]
+
+
 def test_resident_sequence_against_the_reference_loop(two_handles):
     """The reference's own processIMU / processImage loop (oracle/_ref) against the device-resident sequence, emulated kernels,
     five frames with non-keyframes among them (the full-length runs are tests/test_seq_gpu.py)."""
