@@ -24,7 +24,7 @@ struct BaFork { hipStream_t aux; hipEvent_t fork, join; };
 extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
                                       hipEvent_t* ev, int* kinds, int* n_launches, const BaFork* fk);
 typedef int (*BaAllReduce)(void* user, double* buf, size_t count, void* stream);
-extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
+extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, int slack, hipStream_t stream,
                                           BaAllReduce allreduce, void* user, int* hook_rc, hipEvent_t* ev, int* kinds, int* n_launches);
 extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, double* proj_r, double* proj_J,
                                             double* imu_r, double* imu_J, double* prior_r, hipStream_t stream);
@@ -740,7 +740,7 @@ static int launch_solve(vg_handle* h, hipEvent_t* ev = nullptr, int* kinds = nul
     hipError_t e;
     if (B.L.big) {
         int hook_rc = 0;
-        e = ba_launch_solve_big(B.L, B.dL, B.P, B.rounds + BA_BIG_SLACK, h->stream, (BaAllReduce)B.allreduce, B.allreduce_user, &hook_rc,
+        e = ba_launch_solve_big(B.L, B.dL, B.P, B.rounds + BA_BIG_SLACK, BA_BIG_SLACK, h->stream, (BaAllReduce)B.allreduce, B.allreduce_user, &hook_rc,
                                 ev, kinds, n_launches);
         if (e != hipSuccess && hook_rc) { h->err = "all-reduce hook returned " + std::to_string(hook_rc); return VG_ERR_HIP; }
     } else {

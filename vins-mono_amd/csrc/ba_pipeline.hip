@@ -24,6 +24,7 @@
 // current point are reused exactly as DoglegStrategy does.  All solver state between launches lives in a small
 // per-window control block in HBM; every sum has a fixed order, so results are bit-reproducible.
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <mutex>
 #include "ba_layout.h"
 #include "ba_factors.h"
@@ -3343,7 +3344,7 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
 // ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, stream)); a non-zero return aborts the sequence.
 // `rounds` = max_iters + slack: a failed factorisation retries its iteration in the next round (see above).
 typedef int (*BaAllReduce)(void* user, double* buf, size_t count, void* stream);
-extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
+extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, int slack, hipStream_t stream,
                                           BaAllReduce allreduce, void* user, int* hook_rc, hipEvent_t* ev, int* kinds, int* n_launches) {
     hipError_t e = set_lds_attrs();
     if (e != hipSuccess) { g_failed_launch = "hipFuncSetAttribute"; return e; }
@@ -3361,8 +3362,25 @@ extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL,
 #define KIND(k) do { if (kinds) kinds[nk++] = (k); } while (0)
     // (profiling: the all-reduce sits in the gap before the kernel that consumes it and is counted with that kernel)
     LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P); KIND(0);
+    // `rounds` = max_iters + slack: a failed factorisation retries in the NEXT round (the new T needs the collective), so a solve
+    // can need more rounds than iterations.  Usually it does not: once the nominal number of rounds has been issued the host
+    // looks at the windows' DONE flags (one strided 8-byte-per-window copy + a stream synchronisation) before every further
+    // round and stops issuing when every window has finished -- rounds of kernels that return at their first instruction and, on
+    // several ranks, two all-reduces each.  The flags are functions of the reduced (rank-identical) data: every rank stops at the
+    // same round.
+    std::vector<double> done_flags;
     for (int r = 0; r <= rounds; ++r) {
         const int cost_only = r == rounds ? 1 : 0;
+        if (slack > 0 && r >= rounds - slack) {
+            done_flags.assign(L.nwin, 0.0);
+            e = hipMemcpy2DAsync(done_flags.data(), sizeof(double), P.scr + L.so_ctl + C_DONE, (size_t)L.sstride * sizeof(double), sizeof(double),
+                                 L.nwin, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) { g_failed_launch = "read-back of the DONE flags"; return e; }
+            bool all_done = true;
+            for (double v : done_flags) all_done = all_done && v != 0.0;
+            if (all_done) break;             // (the cost-only pass would return at its first instruction too)
+        }
         LAUNCH(ba_linearize_imu_kernel, dim3(L.nig + L.nprw, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only); KIND(1);
         LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only); KIND(1);
         if (!cost_only) { LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P); KIND(2); }
