@@ -249,8 +249,9 @@ int vg_ba_batch_flops(vg_handle* h, double* solve_flops, double* marg_flops);
  * landmark Schur complement is formed by a multi-workgroup kernel into a reduce buffer, the reduced system is factorised
  * out of HBM / LDS by one workgroup.  The same path shards a window over ranks: every rank uploads the SAME frames, IMU
  * factors and prior but only ITS contiguous share of the landmarks (with their observations), installs an all-reduce
- * hook, and calls vg_ba_batch_run_async as usual; after the run every rank holds the identical frame states and the
- * inverse depths of its own landmarks.  Marginalization is not offered on this path (margin_flags must be NONE).
+ * hook, and calls vg_ba_batch_run_async as usual (on this path the call waits for the stream once or a few times near the end of
+ * the solve: the rounds that only exist for retried factorisations are issued on demand, after a look at the windows' DONE flags);
+ * after the run every rank holds the identical frame states and the inverse depths of its own landmarks.  Marginalization is not offered on this path (margin_flags must be NONE).
  *
  * The hook is called on the host, twice per trust-region round, between two kernel launches: it must enqueue on `stream`
  * (a hipStream_t) an in-place SUM over all ranks of `count` doubles at `device_buf` -- with RCCL:
