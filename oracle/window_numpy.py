@@ -1,0 +1,225 @@
+"""oracle/window_numpy.py — TEST INFRASTRUCTURE (never imported by the product): the reference's per-frame bookkeeping around
+Estimator::optimization(), restated on Python lists.  Together with a solver (oracle/ba_cpu.cpp, oracle/ba_numpy.py, or the product
+through the C-ABI) it is the whole NON_LINEAR branch of Estimator::processImage (vins_estimator/src/estimator.cpp:120-215); the
+windows that stay on the device (vg_ba_seq_*, vins-mono_amd/csrc/ba_seq.hip) are held to it, and it is itself pinned against the
+reference's own translation units (oracle/_ref) by tests/test_ref_parity.py::test_window_bookkeeping_restatement_follows_the_reference_loop.
+Follows:
+  FeatureManager::addFeatureCheckParallax / compensatedParallax2   vins_estimator/src/feature_manager.cpp:45-107, :352-382
+  FeatureManager::triangulate (filter; the DLT is ba_numpy.triangulate)   feature_manager.cpp:202-257
+  FeatureManager::setDepth / removeFailures                         feature_manager.cpp:141-171
+  FeatureManager::removeBackShiftDepth / removeFront                feature_manager.cpp:275-313, :333-351
+  Estimator::slideWindow (both flags, incl. the IMU merge)          estimator.cpp:1005-1126
+  Estimator::optimization (problem construction)                    estimator.cpp:719-764
+  Estimator::processIMU (state propagation)                         estimator.cpp:83-117
+"""
+import numpy as np
+
+from vins_mono_amd import synth
+
+OLD, NEW = 0, 1
+
+
+def q2R(q):
+    q = np.asarray(q, float)
+    q = q * (1.0 / np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]))
+    return synth._q2R(q)
+
+
+class SlidingWindow:
+    def __init__(self, K, base, pose, sb, imu, samples, tracks, init_depth=5.0, min_parallax=10.0 / 460.0):
+        self.K, self.WS = K, K - 1
+        self.base = dict(base)
+        self.ex, self.td = np.array(base['ex'], float), float(base['td'])
+        self.pose, self.sb = np.array(pose, float), np.array(sb, float)
+        self.imu, self.samples = list(imu), list(samples)          # K-1 intervals: record dict + raw sample list
+        self.features = [dict(id=int(t['id']), start=int(t['start']), obs=[list(map(float, r)) for r in t['obs']], depth=float(t['depth']), flag=0)
+                         for t in tracks]
+        self.prior = None
+        self.init_depth, self.min_parallax = init_depth, min_parallax
+
+    # ---- feature_manager.cpp:45-107
+    def add_frame(self, ids, rows):
+        WS = self.WS
+        last_track_num = 0
+        for fid, r in zip(ids, rows):
+            row = [float(v) for v in r] + [self.td]                # [x y z u v vx vy cur_td]
+            ft = next((f for f in self.features if f['id'] == int(fid)), None)
+            if ft is None:
+                self.features.append(dict(id=int(fid), start=WS, obs=[row], depth=-1.0, flag=0))
+            else:
+                ft['obs'].append(row)
+                last_track_num += 1
+        self.last_track_num = last_track_num
+        if last_track_num < 20:
+            return OLD
+        s, num = 0.0, 0
+        for ft in self.features:
+            if ft['start'] <= WS - 2 and ft['start'] + len(ft['obs']) - 1 >= WS - 1:
+                fi, fj = ft['obs'][WS - 2 - ft['start']], ft['obs'][WS - 1 - ft['start']]
+                du, dv = fi[0] / fi[2] - fj[0], fi[1] / fi[2] - fj[1]
+                s += max(0.0, float(np.sqrt(du * du + dv * dv)))
+                num += 1
+        self.parallax_num = num
+        if num == 0:
+            return OLD
+        return OLD if s / num >= self.min_parallax else NEW
+
+    def in_problem(self, ft):
+        return len(ft['obs']) >= 2 and ft['start'] < self.WS - 2
+
+    # ---- feature_manager.cpp:202-257; `handle`: a vg_handle wrapper whose triangulate() runs the DLT on the device, None: NumPy
+    def triangulate(self, handle=None):
+        todo = [ft for ft in self.features if self.in_problem(ft) and not ft['depth'] > 0]
+        if not todo:
+            return
+        Ps = self.pose[:, :3]
+        Rs = np.array([q2R(p[3:]) for p in self.pose]).reshape(self.K, 9)
+        start, nobs, off, pts = [], [], [], []
+        for ft in todo:
+            start.append(ft['start']); nobs.append(len(ft['obs'])); off.append(len(pts))
+            pts += [r[:3] for r in ft['obs']]
+        if handle is None:
+            from oracle import ba_numpy
+            dep = ba_numpy.triangulate(Ps, Rs, self.ex[:3], q2R(self.ex[3:]).reshape(9), start, nobs, off, np.array(pts), self.init_depth)
+        else:
+            dep = handle.triangulate(Ps, Rs, self.ex[:3], q2R(self.ex[3:]).reshape(9), start, nobs, off, np.array(pts), self.init_depth)
+        for ft, d in zip(todo, dep):
+            ft['depth'] = float(d)
+
+    # ---- estimator.cpp:486-528, :719-764
+    def problem(self):
+        prob = dict(self.base)
+        prob.update(pose=self.pose.copy(), sb=self.sb.copy(), ex=self.ex.copy(), td=self.td, prior=self.prior, relo=None)
+        start, nobs, off, obs, lam = [], [], [], [], []
+        for ft in self.features:
+            if not self.in_problem(ft):
+                continue
+            start.append(ft['start']); nobs.append(len(ft['obs'])); off.append(len(obs))
+            obs += [[r[0], r[1], r[3], r[4], r[5], r[6], r[7]] for r in ft['obs']]
+            lam.append(1.0 / ft['depth'])
+        prob.update(lm_start=np.array(start, np.int32), lm_nobs=np.array(nobs, np.int32), obs_off=np.array(off, np.int32),
+                    obs=np.array(obs, float).reshape(-1, 7), inv_depth=np.array(lam, float))
+        prob['imu'] = [None if m is None else dict(m) for m in self.imu]
+        return prob
+
+    # ---- double2vector's setDepth, slideWindow, removeFailures
+    def after_solve(self, st, new_prior, flag, merge):
+        K, WS = self.K, self.WS
+        idx = -1
+        for ft in self.features:
+            if not self.in_problem(ft):
+                continue
+            idx += 1
+            ft['depth'] = 1.0 / float(st['inv_depth'][idx])
+            ft['flag'] = 2 if ft['depth'] < 0 else 1
+        self.ex, self.td = st['ex'].copy(), float(st['td'])
+        pose, sb = st['pose'], st['sb']
+        ric, tic = q2R(self.ex[3:]), self.ex[:3]
+        if flag == OLD:
+            R0, P0 = q2R(pose[0][3:]) @ ric, pose[0][:3] + q2R(pose[0][3:]) @ tic
+            R1, P1 = q2R(pose[1][3:]) @ ric, pose[1][:3] + q2R(pose[1][3:]) @ tic
+            self.pose = np.vstack([pose[1:], pose[K - 1:K]])
+            self.sb = np.vstack([sb[1:], sb[K - 1:K]])
+            self.imu = self.imu[1:] + [None]
+            self.samples = self.samples[1:] + [None]
+            keep = []
+            for ft in self.features:                               # removeBackShiftDepth
+                if ft['start'] != 0:
+                    ft['start'] -= 1
+                    keep.append(ft)
+                    continue
+                uv = np.array(ft['obs'][0][:3])
+                ft['obs'] = ft['obs'][1:]
+                if len(ft['obs']) < 2:
+                    continue
+                pj = R1.T @ (R0 @ (uv * ft['depth']) + P0 - P1)
+                ft['depth'] = float(pj[2]) if pj[2] > 0 else self.init_depth
+                keep.append(ft)
+            self.features = keep
+        else:
+            self.pose = np.vstack([pose[:K - 2], pose[K - 1:K], pose[K - 1:K]])
+            self.sb = np.vstack([sb[:K - 2], sb[K - 1:K], sb[K - 1:K]])
+            # pre_integrations[WS - 1] takes the samples of pre_integrations[WS] (estimator.cpp:1069-1085)
+            self.samples[K - 3] = self.samples[K - 3] + self.samples[K - 2][1:]
+            self.imu[K - 3] = merge(self.samples[K - 3], self.imu[K - 3])
+            self.imu[K - 2], self.samples[K - 2] = None, None
+            keep = []
+            for ft in self.features:                               # removeFront(WS)
+                if ft['start'] == WS:
+                    ft['start'] -= 1
+                else:
+                    j = WS - 1 - ft['start']
+                    if len(ft['obs']) - 1 >= j:
+                        del ft['obs'][j]
+                        if not ft['obs']:
+                            continue
+                keep.append(ft)
+            self.features = keep
+        self.features = [ft for ft in self.features if ft['flag'] != 2]      # removeFailures
+        if new_prior is not None:
+            self.prior = new_prior
+
+    def tracks(self):
+        return dict(id=np.array([f['id'] for f in self.features], np.int32), start=np.array([f['start'] for f in self.features], np.int32),
+                    nobs=np.array([len(f['obs']) for f in self.features], np.int32), depth=np.array([f['depth'] for f in self.features], float),
+                    solve_flag=np.array([f['flag'] for f in self.features], np.int32),
+                    obs=np.array([r for f in self.features for r in f['obs']], float).reshape(-1, 8))
+
+
+def propagate(pose, sb, samples, g_norm):
+    """Estimator::processIMU (estimator.cpp:83-117): the newest frame's state carried through the IMU samples of the interval."""
+    P, V, Ba, Bg = pose[:3].copy(), sb[:3].copy(), sb[3:6], sb[6:9]
+    Rm = q2R(pose[3:])
+    g = np.array([0.0, 0.0, g_norm])
+    acc_0, gyr_0 = np.asarray(samples[0][1], float), np.asarray(samples[0][2], float)
+    for dt, acc, gyr in samples[1:]:
+        acc, gyr = np.asarray(acc, float), np.asarray(gyr, float)
+        un_acc_0 = Rm @ (acc_0 - Ba) - g
+        un_gyr = 0.5 * (gyr_0 + gyr) - Bg
+        th = un_gyr * dt                                            # Utility::deltaQ(theta) = (1, theta / 2), toRotationMatrix normalises
+        Rm = Rm @ q2R(np.array([th[0] / 2, th[1] / 2, th[2] / 2, 1.0]))
+        un_acc_1 = Rm @ (acc - Ba) - g
+        un_acc = 0.5 * (un_acc_0 + un_acc_1)
+        P = P + dt * V + 0.5 * dt * dt * un_acc
+        V = V + dt * un_acc
+        acc_0, gyr_0 = acc, gyr
+    q = synth._R2q(Rm)
+    return np.concatenate([P, q / np.linalg.norm(q)]), np.concatenate([V, Ba, Bg])
+
+
+def run_sequence(seq, n_frames, K=11, min_parallax=10.0 / 460.0, noise_seed=0, init_depth=5.0, solver=None):
+    """The NON_LINEAR branch of Estimator::processImage frame by frame on a synth.SyntheticSequence, with the draws and the
+    hand-over of oracle/ref.py run_sequence (so that both can be compared record by record): bookkeeping = SlidingWindow,
+    solver(prob, flag) -> (state, summary, new prior) = oracle/ba_cpu.cpp by default.  Returns one record per frame: the states
+    AFTER slideWindow (what vector2double() packs then), the key-frame flag, the surviving track ids, iterations, accept flags."""
+    if solver is None:
+        from oracle import ba_cpu
+        solver = lambda prob, flag: ba_cpu.optimize(prob, margin_flag=flag)
+    src = synth.FrameSource(seq, noise_seed=noise_seed)
+    rng = np.random.default_rng(noise_seed)
+
+    def noisy_state(f):
+        th = rng.normal(0, np.radians(0.3), 3)
+        Rn = seq.Rm[f] @ (np.eye(3) + np.array([[0, -th[2], th[1]], [th[2], 0, -th[0]], [-th[1], th[0], 0]]))
+        q = synth._R2q(Rn)
+        return np.concatenate([seq.P[f] + rng.normal(0, 0.03, 3), q / np.linalg.norm(q)]), np.concatenate([seq.V[f] + rng.normal(0, 0.03, 3), seq.ba_lin, seq.bg_lin])
+
+    w = src.initial_window(K, 0)
+    states = [noisy_state(i) for i in range(K - 1)] + [noisy_state(K - 2)]
+    win = SlidingWindow(K, w['base'], np.array([s[0] for s in states]), np.array([s[1] for s in states]), w['imu'], w['samples'], w['tracks'],
+                        init_depth, min_parallax)
+    out = []
+    for f in range(K - 1, n_frames):
+        smp = src.samples(f - 1)
+        newest = (win.pose[K - 1].copy(), win.sb[K - 1].copy())
+        win.imu[K - 2], win.samples[K - 2] = src.preintegrate(smp, newest[1][3:6], newest[1][6:9]), smp
+        win.pose[K - 1], win.sb[K - 1] = propagate(newest[0], newest[1], smp, seq.cfg['g_norm'])
+        ids, rows = src.image(f)
+        flag = win.add_frame(ids, rows)
+        win.triangulate()
+        prob = win.problem()
+        st, sm, prior = solver(prob, flag)
+        win.after_solve(st, prior, flag, lambda samples, old: src.preintegrate(samples, old['lin_ba'], old['lin_bg']))
+        out.append(dict(frame=f, flag=flag, pose=win.pose.copy(), sb=win.sb.copy(), ids=set(ft['id'] for ft in win.features), n=len(win.features),
+                        iters=sm['num_iterations'], flags=list(sm['it_flags'])))
+    return out

@@ -1,161 +1,11 @@
-"""TEST INFRASTRUCTURE: the reference's per-frame bookkeeping around Estimator::optimization(), restated on Python lists, and
-the drivers that feed the same synthetic frames to (a) this host model + the ordinary C-ABI (`vg_ba_optimize` per frame) and
-(b) the device-resident sequence (`vg_ba_seq_*`).  Follows:
-  FeatureManager::addFeatureCheckParallax / compensatedParallax2   vins_estimator/src/feature_manager.cpp:45-107, :352-382
-  FeatureManager::triangulate (filter)                              feature_manager.cpp:202-211
-  FeatureManager::setDepth / removeFailures                         feature_manager.cpp:141-171
-  FeatureManager::removeBackShiftDepth / removeFront                feature_manager.cpp:275-313, :333-351
-  Estimator::slideWindow (both flags, incl. the IMU merge)          estimator.cpp:1005-1126
-  Estimator::optimization (problem construction)                    estimator.cpp:719-764
-"""
+"""TEST INFRASTRUCTURE: drivers around the restated per-frame bookkeeping of the reference (oracle/window_numpy.py).  They feed the
+same synthetic frames to (a) that host model + the ordinary C-ABI (`vg_ba_optimize` per frame), (b) the device-resident sequence
+(`vg_ba_seq_*`), (c) the reference's own loop (oracle/_ref), (d) the C++ caller (`vins_replay seq`)."""
 import numpy as np
 
 from vins_mono_amd import synth
 
-OLD, NEW = 0, 1
-
-
-def q2R(q):
-    q = np.asarray(q, float)
-    q = q * (1.0 / np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]))
-    return synth._q2R(q)
-
-
-class HostWindow:
-    def __init__(self, K, base, pose, sb, imu, samples, tracks, init_depth=5.0, min_parallax=10.0 / 460.0):
-        self.K, self.WS = K, K - 1
-        self.base = dict(base)
-        self.ex, self.td = np.array(base['ex'], float), float(base['td'])
-        self.pose, self.sb = np.array(pose, float), np.array(sb, float)
-        self.imu, self.samples = list(imu), list(samples)          # K-1 intervals: record dict + raw sample list
-        self.features = [dict(id=int(t['id']), start=int(t['start']), obs=[list(map(float, r)) for r in t['obs']], depth=float(t['depth']), flag=0)
-                         for t in tracks]
-        self.prior = None
-        self.init_depth, self.min_parallax = init_depth, min_parallax
-
-    # ---- feature_manager.cpp:45-107
-    def add_frame(self, ids, rows):
-        WS = self.WS
-        last_track_num = 0
-        for fid, r in zip(ids, rows):
-            row = [float(v) for v in r] + [self.td]                # [x y z u v vx vy cur_td]
-            ft = next((f for f in self.features if f['id'] == int(fid)), None)
-            if ft is None:
-                self.features.append(dict(id=int(fid), start=WS, obs=[row], depth=-1.0, flag=0))
-            else:
-                ft['obs'].append(row)
-                last_track_num += 1
-        self.last_track_num = last_track_num
-        if last_track_num < 20:
-            return OLD
-        s, num = 0.0, 0
-        for ft in self.features:
-            if ft['start'] <= WS - 2 and ft['start'] + len(ft['obs']) - 1 >= WS - 1:
-                fi, fj = ft['obs'][WS - 2 - ft['start']], ft['obs'][WS - 1 - ft['start']]
-                du, dv = fi[0] / fi[2] - fj[0], fi[1] / fi[2] - fj[1]
-                s += max(0.0, float(np.sqrt(du * du + dv * dv)))
-                num += 1
-        self.parallax_num = num
-        if num == 0:
-            return OLD
-        return OLD if s / num >= self.min_parallax else NEW
-
-    def in_problem(self, ft):
-        return len(ft['obs']) >= 2 and ft['start'] < self.WS - 2
-
-    # ---- feature_manager.cpp:202-257 (the DLT itself runs on the device: vg_triangulate)
-    def triangulate(self, handle):
-        todo = [ft for ft in self.features if self.in_problem(ft) and not ft['depth'] > 0]
-        if not todo:
-            return
-        Ps = self.pose[:, :3]
-        Rs = np.array([q2R(p[3:]) for p in self.pose]).reshape(self.K, 9)
-        start, nobs, off, pts = [], [], [], []
-        for ft in todo:
-            start.append(ft['start']); nobs.append(len(ft['obs'])); off.append(len(pts))
-            pts += [r[:3] for r in ft['obs']]
-        dep = handle.triangulate(Ps, Rs, self.ex[:3], q2R(self.ex[3:]).reshape(9), start, nobs, off, np.array(pts), self.init_depth)
-        for ft, d in zip(todo, dep):
-            ft['depth'] = float(d)
-
-    # ---- estimator.cpp:486-528, :719-764
-    def problem(self):
-        prob = dict(self.base)
-        prob.update(pose=self.pose.copy(), sb=self.sb.copy(), ex=self.ex.copy(), td=self.td, prior=self.prior, relo=None)
-        start, nobs, off, obs, lam = [], [], [], [], []
-        for ft in self.features:
-            if not self.in_problem(ft):
-                continue
-            start.append(ft['start']); nobs.append(len(ft['obs'])); off.append(len(obs))
-            obs += [[r[0], r[1], r[3], r[4], r[5], r[6], r[7]] for r in ft['obs']]
-            lam.append(1.0 / ft['depth'])
-        prob.update(lm_start=np.array(start, np.int32), lm_nobs=np.array(nobs, np.int32), obs_off=np.array(off, np.int32),
-                    obs=np.array(obs, float).reshape(-1, 7), inv_depth=np.array(lam, float))
-        prob['imu'] = [None if m is None else dict(m) for m in self.imu]
-        return prob
-
-    # ---- double2vector's setDepth, slideWindow, removeFailures
-    def after_solve(self, st, new_prior, flag, merge):
-        K, WS = self.K, self.WS
-        idx = -1
-        for ft in self.features:
-            if not self.in_problem(ft):
-                continue
-            idx += 1
-            ft['depth'] = 1.0 / float(st['inv_depth'][idx])
-            ft['flag'] = 2 if ft['depth'] < 0 else 1
-        self.ex, self.td = st['ex'].copy(), float(st['td'])
-        pose, sb = st['pose'], st['sb']
-        ric, tic = q2R(self.ex[3:]), self.ex[:3]
-        if flag == OLD:
-            R0, P0 = q2R(pose[0][3:]) @ ric, pose[0][:3] + q2R(pose[0][3:]) @ tic
-            R1, P1 = q2R(pose[1][3:]) @ ric, pose[1][:3] + q2R(pose[1][3:]) @ tic
-            self.pose = np.vstack([pose[1:], pose[K - 1:K]])
-            self.sb = np.vstack([sb[1:], sb[K - 1:K]])
-            self.imu = self.imu[1:] + [None]
-            self.samples = self.samples[1:] + [None]
-            keep = []
-            for ft in self.features:                               # removeBackShiftDepth
-                if ft['start'] != 0:
-                    ft['start'] -= 1
-                    keep.append(ft)
-                    continue
-                uv = np.array(ft['obs'][0][:3])
-                ft['obs'] = ft['obs'][1:]
-                if len(ft['obs']) < 2:
-                    continue
-                pj = R1.T @ (R0 @ (uv * ft['depth']) + P0 - P1)
-                ft['depth'] = float(pj[2]) if pj[2] > 0 else self.init_depth
-                keep.append(ft)
-            self.features = keep
-        else:
-            self.pose = np.vstack([pose[:K - 2], pose[K - 1:K], pose[K - 1:K]])
-            self.sb = np.vstack([sb[:K - 2], sb[K - 1:K], sb[K - 1:K]])
-            # pre_integrations[WS - 1] takes the samples of pre_integrations[WS] (estimator.cpp:1069-1085)
-            self.samples[K - 3] = self.samples[K - 3] + self.samples[K - 2][1:]
-            self.imu[K - 3] = merge(self.samples[K - 3], self.imu[K - 3])
-            self.imu[K - 2], self.samples[K - 2] = None, None
-            keep = []
-            for ft in self.features:                               # removeFront(WS)
-                if ft['start'] == WS:
-                    ft['start'] -= 1
-                else:
-                    j = WS - 1 - ft['start']
-                    if len(ft['obs']) - 1 >= j:
-                        del ft['obs'][j]
-                        if not ft['obs']:
-                            continue
-                keep.append(ft)
-            self.features = keep
-        self.features = [ft for ft in self.features if ft['flag'] != 2]      # removeFailures
-        if new_prior is not None:
-            self.prior = new_prior
-
-    def tracks(self):
-        return dict(id=np.array([f['id'] for f in self.features], np.int32), start=np.array([f['start'] for f in self.features], np.int32),
-                    nobs=np.array([len(f['obs']) for f in self.features], np.int32), depth=np.array([f['depth'] for f in self.features], float),
-                    solve_flag=np.array([f['flag'] for f in self.features], np.int32),
-                    obs=np.array([r for f in self.features for r in f['obs']], float).reshape(-1, 8))
+from oracle.window_numpy import NEW, OLD, SlidingWindow as HostWindow, propagate as _propagate, q2R  # noqa: F401
 
 
 class FrameSource(synth.FrameSource):
@@ -271,28 +121,6 @@ def check_step(step, w, host, flag, dev, tol=1e-9, tol_depth=1e-7):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-def _propagate(pose, sb, samples, g_norm):
-    """Estimator::processIMU (estimator.cpp:83-117): the newest frame's state carried through the IMU samples of the interval."""
-    from oracle import ref as R
-    P, V, Ba, Bg = pose[:3].copy(), sb[:3].copy(), sb[3:6], sb[6:9]
-    Rm = q2R(pose[3:])
-    g = np.array([0.0, 0.0, g_norm])
-    acc_0, gyr_0 = np.asarray(samples[0][1], float), np.asarray(samples[0][2], float)
-    for dt, acc, gyr in samples[1:]:
-        acc, gyr = np.asarray(acc, float), np.asarray(gyr, float)
-        un_acc_0 = Rm @ (acc_0 - Ba) - g
-        un_gyr = 0.5 * (gyr_0 + gyr) - Bg
-        th = un_gyr * dt                                            # Utility::deltaQ(theta) = (1, theta / 2), toRotationMatrix normalises
-        Rm = Rm @ q2R(np.array([th[0] / 2, th[1] / 2, th[2] / 2, 1.0]))
-        un_acc_1 = Rm @ (acc - Ba) - g
-        un_acc = 0.5 * (un_acc_0 + un_acc_1)
-        P = P + dt * V + 0.5 * dt * dt * un_acc
-        V = V + dt * un_acc
-        acc_0, gyr_0 = acc, gyr
-    q = R.quat_from_R(Rm)
-    return np.concatenate([P, q / np.linalg.norm(q)]), np.concatenate([V, Ba, Bg])
-
-
 def run_against_reference(h_seq, min_parallax, n_frames=24):
     """The reference's OWN per-frame loop (oracle/_ref: estimator.cpp + feature_manager.cpp compiled unchanged, driven through
     processIMU / processImage as in tests/test_dropin_gpu.py) against the device-resident sequence on the same frames: the same

@@ -518,3 +518,42 @@ def test_ba_replay_csv_vs_reference(tmp_path):
     assert np.abs(got[:, 1:4] - ref[:, 1:4]).max() < 1e-4 * max(1.0, np.abs(ref[:, 1:4]).max())
     assert np.abs(got[:, 4:8] - ref[:, 4:8]).max() < 1e-4
     assert np.abs(got[:, 8:11] - ref[:, 8:11]).max() < 1e-4 * max(1.0, np.abs(ref[:, 8:11]).max())
+
+
+# ------------------------------------------------------------------------------------------ 8(f) row 4: the loop around optimization()
+@pytest.mark.parametrize("min_parallax,expect_second_new", [(10.0 / 460.0, False), (0.1, True)])
+def test_window_bookkeeping_restatement_follows_the_reference_loop(min_parallax, expect_second_new):
+    """oracle/window_numpy.py (addFeatureCheckParallax, triangulate, problem construction, setDepth, slideWindow for both flags with
+    the IMU merge, removeBackShiftDepth / removeFront / removeFailures, processIMU's propagation) + oracle/ba_cpu.cpp, against the
+    reference's OWN processIMU / processImage loop (oracle/_ref) on the same frames: identical key-frame decisions, identical
+    surviving tracks on every frame; states: 2e-11 after the first frame, 1e-6 after the second, then the chain's own sensitivity
+    shows (the prior is cut at eps = 1e-8 along weakly observed directions; two solvers that agree to 1e-11 per solve drift
+    1e-4 .. 3e-4 apart over ten marginalizations and come back: measured, with identical accept / reject traces) -- bar 5e-4, 3e-3
+    in the frame of a trust-region flip and the two after it.  This is the restatement the device-resident windows (vg_ba_seq_*)
+    are held to in tests/test_seq_*.py."""
+    from oracle import window_numpy as W
+    K, n_frames = 11, 20
+    ref = R.run_sequence(synth.SyntheticSequence(11, n_frames=26, K=26, L=500), n_frames, L=R.lib(), min_parallax=min_parallax)
+    got = W.run_sequence(synth.SyntheticSequence(11, n_frames=26, K=26, L=500), n_frames, K=K, min_parallax=min_parallax)
+    assert len(ref) == len(got)
+    flags = [r['flag'] for r in ref]
+    assert (1 in flags) == expect_second_new and 0 in flags
+    loose, n_flips, worst = 0, 0, 0.0
+    for r, g in zip(ref, got):
+        assert r['frame'] == g['frame'] and r['solver_flag'] == 1
+        assert r['flag'] == g['flag'], r['frame']
+        assert r['n_features'] == g['n'] and set(r['depth']) == g['ids'], r['frame']
+        same = r['trace'].shape[0] == g['iters'] and np.array_equal(r['trace'][:, 1].astype(int), (np.array(g['flags'][:g['iters']], int) >> 1) & 1)
+        if not same:
+            n_flips += 1
+            loose = 3
+        tol = 3e-3 if loose > 0 else 5e-4
+        loose = max(0, loose - 1)
+        e = max(np.abs(g['pose'][:, :3] - r['pose'][:, :3]).max() / max(1.0, np.abs(r['pose'][:, :3]).max()), np.abs(np.abs(g['pose'][:, 3:]) - np.abs(r['pose'][:, 3:])).max(),
+                np.abs(g['sb'][:, :3] - r['sb'][:, :3]).max() / max(1.0, np.abs(r['sb'][:, :3]).max()), np.abs(g['sb'][:, 3:] - r['sb'][:, 3:]).max())
+        worst = max(worst, e)
+        assert e < tol, (r['frame'], e, same)
+        if r['frame'] == K - 1:
+            assert e < 1e-9, e                  # one solve on identical windows
+    assert n_flips <= max(1, len(ref) // 4)
+    print("restated loop vs the reference's loop: worst state difference", worst, "flips", n_flips)
