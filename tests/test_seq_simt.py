@@ -124,3 +124,24 @@ def test_cpp_hand_back_and_take_over_again(two_handles, tmp_path):
         worst = max(worst, max(abs(float(x) - float(y)) for x, y in zip(la[2:12], lb[2:12])))
     assert worst < 1e-6, worst
     print("hand-back in the middle of the run: worst difference to the uninterrupted run", worst)
+
+
+def test_frame_inputs_are_validated(two_handles):
+    """A frame whose feature ids are not strictly ascending (the reference's `image` map cannot hold one) is refused on the host."""
+    from vins_mono_amd import synth
+    h = two_handles[0]
+    src = synth.FrameSource(synth.SyntheticSequence(21, n_frames=14, K=14, L=40), noise_seed=1)
+    win = src.initial_window(11, 0)
+    prob, tracks = synth.sequence_inputs(win)
+    h.seq_begin([prob], [tracks], max_features=128, max_new_obs=128)
+    try:
+        ids, rows = src.image(10)
+        pose, sb = src.guess(10)
+        frame = dict(pose=pose, sb=sb, imu_new=src.seq.imu[9], imu_merged=None, ids=ids[::-1].copy(), obs=rows[::-1].copy())
+        with pytest.raises(RuntimeError, match="strictly ascending"):
+            h.seq_step([frame])
+        frame.update(ids=ids, obs=rows)
+        h.seq_step([frame])                                # the sequence is still usable
+        assert h.seq_info()[0]['status'] == 0
+    finally:
+        h.seq_end()

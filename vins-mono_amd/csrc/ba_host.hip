@@ -1303,6 +1303,10 @@ extern "C" int vg_ba_seq_step_async(vg_handle* h, int nwin, const vg_ba_frame* c
         const vg_ba_frame* f = frames[w];
         if (!f || !f->imu_new || f->n_obs < 0 || (f->n_obs > 0 && (!f->feature_id || !f->obs))) return VG_ERR_BAD_ARG;
         if (f->n_obs > D.NIN) { h->err = "vg_ba_seq_step_async: more observations than vg_ba_seq_config::max_new_obs"; return VG_ERR_UNSUPPORTED; }
+        // the `image` map of the reference is keyed by feature id: one observation per id, ascending (the device matches every
+        // observation to its track independently: a repeated id would be two lanes appending to one track)
+        for (int k = 1; k < f->n_obs; ++k)
+            if (f->feature_id[k] <= f->feature_id[k - 1]) { h->err = "vg_ba_seq_step_async: feature ids of a frame must be strictly ascending"; return VG_ERR_BAD_ARG; }
     }
     HIPCHK(h, hipSetDevice(h->device));
     // the staging buffers are re-used: the previous step's copies must have left them
