@@ -292,6 +292,28 @@ def bench_sharded(args, ba, synth, D, rank, world):
             a[0] += ms; a[1] += n
     st, sm, _ = h.ba_download()
     ok = int(sm[0]['status'] == 0)
+    # marginalization of the sharded window (shard.marginalize_sharded: all-gather of the frame-0 tracks, then the same small
+    # single-rank problem on every rank, on a handle of its own) -- informational, outside the timed region
+    def gather(obj):
+        if world == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+    marg_info = None
+    h2 = ba.Handle()
+    tm0 = time.perf_counter()
+    new_prior = shard.marginalize_sharded(h2, sub, st[0], ba.VG_MARGIN_OLD, gather)
+    marg_first_ms = (time.perf_counter() - tm0) * 1e3
+    tm0 = time.perf_counter()
+    new_prior = shard.marginalize_sharded(h2, sub, st[0], ba.VG_MARGIN_OLD, gather)
+    marg_info = {"ms": (time.perf_counter() - tm0) * 1e3, "first_call_ms": marg_first_ms, "kept_dimension": int(new_prior['n']) if new_prior else 0,
+                 "dropped_dimension": int(new_prior['m']) if new_prior else 0,
+                 "what": "MARGIN_OLD of the sharded window: all-gather of the tracks anchored at frame 0 (a few KB), then every rank "
+                         "marginalizes the same reduced single-rank problem (all frames at the solved states, IMU, old prior, the "
+                         "frame-0 tracks; max_iters = 0) on a second handle: host packing + H2D + kernels + D2H, wall clock"}
+    h2.close()
     nfac_all = D.sum_over_ranks(float(int(np.sum(np.asarray(sub['lm_nobs']) - 1))))
     flops_all = D.sum_over_ranks(info['flops_by_kernel']["ba_big_schur_kernel"])          # the sharded part of the model
     ok_all = D.sum_over_ranks(float(ok))
@@ -350,6 +372,7 @@ def bench_sharded(args, ba, synth, D, rank, world):
                              "counted with that kernel; flops = SURVEY.md 8(d) model split per launch class (Schur-kernel flops of all "
                              f"ranks: {flops_all:.4g})"},
         "cpu_baseline": cpu,
+        "marginalization_of_the_sharded_window": marg_info,
     }
     if cpu:
         out["speedup_vs_cpu"] = value / cpu["value"]

@@ -38,13 +38,41 @@ h.ba_set_allreduce(shard.torch_allreduce_hook())
 st, sm, _ = h.ba_optimize(sub)
 counts = h.ba_reduce_layout()
 D.barrier()
-lo, hi = (int(v) for v in sub["shard"])
+# marginalization of the sharded window (shard.marginalize_sharded) against the single-rank solve + marginalization of the whole
+# window, and against the whole window marginalized at the SHARDED state (max_iters = 0)
+import torch.distributed as dist
 fl = lambda a: [float(v) for v in np.asarray(a).ravel()]
+def gather(obj):
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+marg = None
+if case in ("plain", "extd"):
+    from vins_mono_amd import ba
+    h2 = conftest._simt_handle()                       # the marginalization runs on a handle of its own (no hook)
+    h2.ba_set_large_window(True)
+    pr_sh = shard.marginalize_sharded(h2, sub, st, ba.VG_MARGIN_OLD, gather)
+    h.ba_set_allreduce(None)
+    _, _, pr_one = h.ba_optimize(prob, ba.VG_MARGIN_OLD)
+    at = dict(prob)
+    lam_all = gather([float(v) for v in st["inv_depth"]])
+    at.update(pose=st["pose"], sb=st["sb"], ex=st["ex"], td=st["td"], inv_depth=np.array([v for p in lam_all for v in p]), max_iters=0)
+    _, _, pr_at = h.ba_optimize(at, ba.VG_MARGIN_OLD)
+    import hashlib
+    def prod(p):
+        return p["J0"].T @ p["J0"], p["J0"].T @ p["r0"]
+    (A, b), (A1, b1), (Aat, bat) = prod(pr_sh), prod(pr_one), prod(pr_at)
+    scale = float(np.abs(Aat).max())
+    marg = dict(n=[int(pr_sh["n"]), int(pr_one["n"]), int(pr_at["n"])], blocks_equal=bool(pr_sh["blocks"] == pr_one["blocks"] == pr_at["blocks"]),
+                sha=hashlib.sha1(np.ascontiguousarray(pr_sh["J0"]).tobytes() + np.ascontiguousarray(pr_sh["r0"]).tobytes()).hexdigest(),
+                dA_at=float(np.abs(A - Aat).max()) / scale, db_at=float(np.abs(b - bat).max()) / max(1.0, float(np.abs(bat).max())),
+                dA_one=float(np.abs(A - A1).max()) / scale, db_one=float(np.abs(b - b1).max()) / max(1.0, float(np.abs(b1).max())))
+lo, hi = (int(v) for v in sub["shard"])
 def pack(s, m):
     return dict(pose=fl(s["pose"]), sb=fl(s["sb"]), ex=fl(s["ex"]), td=float(s["td"]), lam=fl(s["inv_depth"]),
                 it_cost=fl(m["it_cost"]), it_cost_cand=fl(m["it_cost_cand"]), it_flags=[int(v) for v in m["it_flags"]], it_radius=fl(m["it_radius"]),
                 n=int(m["num_iterations"]), term=int(m["termination"]), status=int(m["status"]), final_cost=float(m["final_cost"]))
-sys.stdout.write(json.dumps(dict(rank=rank, lo=lo, hi=hi, counts=[int(v) for v in counts], sharded=pack(st, sm), single=pack(st1, sm1))) + "\n")
+sys.stdout.write(json.dumps(dict(rank=rank, lo=lo, hi=hi, counts=[int(v) for v in counts], sharded=pack(st, sm), single=pack(st1, sm1), marg=marg)) + "\n")
 sys.stdout.flush()
 D.finish()
 ''' % ROOT
@@ -88,9 +116,20 @@ def _check(rows, first=1e-12, rest=1e-7, state=1e-7):
     return a, lam
 
 
+def _check_marg(rows, tol_single=1e-5):
+    """Both ranks hold the identical new prior; it equals the whole window marginalized at the same (sharded) state to rounding
+    and the single-rank solve + marginalization to what the states differ by (J0^T J0 relative to its largest entry, J0^T r0)."""
+    m0, m1 = rows[0]["marg"], rows[1]["marg"]
+    assert m0["sha"] == m1["sha"]                                      # bit-identical on both ranks, no broadcast
+    assert m0["n"][0] == m0["n"][1] == m0["n"][2] and m0["blocks_equal"]
+    assert m0["dA_at"] <= 1e-9 and m0["db_at"] <= 1e-9, m0
+    assert m0["dA_one"] <= tol_single and m0["db_one"] <= tol_single, m0
+
+
 def test_two_rank_landmark_shards_equal_the_single_rank_solve(tmp_path):
     rows = _run(tmp_path, "plain", 29541)
     a, lam = _check(rows)
+    _check_marg(rows)
     # and the oracle: same bounds as tests/test_ba_gpu.py::_check_solve
     from oracle import ba_numpy as B
     from vins_mono_amd import synth
@@ -107,4 +146,6 @@ def test_two_rank_landmark_shards_equal_the_single_rank_solve(tmp_path):
 def test_two_rank_shards_with_rejected_steps_extrinsic_and_td(tmp_path):
     # (the low-parallax window is ill-conditioned by construction: tests/ba_fixtures.py COST_RTOL)
     _check(_run(tmp_path, "low_parallax", 29542), first=1e-9, rest=1e-5, state=1e-5)
-    _check(_run(tmp_path, "extd", 29543))
+    rows = _run(tmp_path, "extd", 29543)
+    _check(rows)
+    _check_marg(rows)

@@ -81,3 +81,47 @@ def torch_allreduce_hook(device_buffers=None):
             t = torch.from_numpy(a)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return hook
+
+
+# ---- marginalization of a sharded window --------------------------------------------------------------------------------------
+def frame0_share(sub, inv_depth):
+    """What a MARGIN_OLD marginalization needs from this rank's landmark share: the tracks anchored at frame 0 with their
+    observation rows and their (solved) inverse depths.  The reference hands MarginalizationInfo only the projection factors of
+    features with start_frame == 0 (estimator.cpp:853-888) next to the IMU factor of the first interval and the old prior; tracks
+    anchored later do not touch the dropped states."""
+    start = np.asarray(sub['lm_start'])
+    nobs = np.asarray(sub['lm_nobs'])
+    off = np.asarray(sub['obs_off'])
+    obs = np.asarray(sub['obs'], dtype=np.float64).reshape(-1, 7)
+    sel = [l for l in range(len(start)) if start[l] == 0]
+    rows = [obs[off[l]:off[l] + nobs[l]] for l in sel]
+    return dict(lm_nobs=[int(nobs[l]) for l in sel], inv_depth=[float(np.asarray(inv_depth)[l]) for l in sel],
+                obs=(np.concatenate(rows) if rows else np.zeros((0, 7))).tolist())
+
+
+def marginalize_sharded(handle, sub, state, flag, gather):
+    """Marginalization of a window whose landmarks are spread over ranks (Estimator::optimization's second half,
+    estimator.cpp:825-1000), after the sharded solve.  MARGIN_OLD touches frame 0 only: the ranks all-gather their frame-0
+    shares (`gather(obj)` -> the objects of all ranks in rank order, e.g. torch.distributed.all_gather_object; a few KB), and
+    every rank marginalizes the SAME small single-rank problem -- all frames at their solved states, the IMU factors, the old
+    prior, the frame-0 tracks of all ranks in landmark order, max_iters = 0 (the factors are evaluated where the solve ended;
+    with nothing to iterate the gauge fix is the identity) -- so every rank holds the identical new prior without a broadcast.
+    MARGIN_SECOND_NEW involves the prior alone.  `handle`: a vg_handle WITHOUT an all-reduce hook (a second handle on the rank's
+    device: the one that runs the sharded solve keeps its hook / RCCL communicator).  Returns the new prior (None if the old one
+    stays, estimator.cpp:935-936)."""
+    from . import ba
+    pieces = gather(frame0_share(sub, state['inv_depth'])) if flag == ba.VG_MARGIN_OLD else []
+    red = dict(sub)
+    red.pop('shard', None)
+    red.update(pose=np.asarray(state['pose'], float), sb=np.asarray(state['sb'], float), ex=np.asarray(state['ex'], float), td=float(state['td']),
+               max_iters=0, relo=None)
+    nobs = [n for p in pieces for n in p['lm_nobs']]
+    red['lm_nobs'] = np.array(nobs, np.int32)
+    red['lm_start'] = np.zeros(len(nobs), np.int32)
+    red['obs_off'] = np.concatenate([[0], np.cumsum(nobs)[:-1]]).astype(np.int32) if nobs else np.zeros(0, np.int32)
+    red['inv_depth'] = np.array([d for p in pieces for d in p['inv_depth']], float)
+    red['obs'] = np.array([r for p in pieces for r in p['obs']], float).reshape(-1, 7)
+    _, sm, prior = handle.ba_optimize(red, flag)
+    if sm['status'] != 0:
+        raise RuntimeError(f"marginalization of the sharded window failed with status {sm['status']}")
+    return prior
