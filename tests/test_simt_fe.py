@@ -73,3 +73,55 @@ def test_emulated_reject_with_f_matches_restatement():
     OpenCV's loop: same inlier mask, same model — RANSAC for n >= 15, LMedS below."""
     r = subprocess.run([sys.executable, "-c", _CHILD_F % dict(root=ROOT)], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_CHILD_D = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+import conftest
+from oracle import fe_cpu as F
+from vins_mono_amd import fe, synth
+h = conftest._simt_handle()
+W, H = 256, 160
+a = synth.synth_frame(31, W, H)
+b = synth.warp_frame(a, 32, shift=(1.5, 2.0), angle_deg=0.3)
+tr = fe.FrontEnd(h, W, H, 2, 200)
+# CLAHE (fe_clahe_lut_kernel / fe_clahe_apply_kernel) + the pyramid built from the equalized frame
+tr.push_frames([a, b], equalize=True)
+ea, eb = F.clahe(a), F.clahe(b)
+assert np.array_equal(tr.get_level(0, 0), ea) and np.array_equal(tr.get_level(1, 0), eb)
+assert np.array_equal(tr.get_level(1, 1), F.pyrdown(eb))
+# GFTT (fe_mineig_kernel, fe_candidates_kernel, fe_select_kernel): ordered corner lists, small and large min distance, host mask
+for cam, img in ((0, ea), (1, eb)):
+    for n, md in ((40, 12.0), (150, 20.0)):
+        assert np.array_equal(tr.detect(cam, n, 0.01, md), F.gftt(img, n, 0.01, md)), (cam, n, md)
+mask = np.full((H, W), 255, np.uint8)
+yy, xx = np.mgrid[0:H, 0:W]
+mask[(xx - 100) ** 2 + (yy - 70) ** 2 < 45 ** 2] = 0
+assert np.array_equal(tr.detect(0, 60, 0.01, 12.0, mask), F.gftt(ea, 60, 0.01, 12.0, mask))
+# setMask (fe_setmask_kernel / fe_stamp_kernel) + GFTT with the mask left on the device, undistortedPoints' lifting (fe_lift_kernel)
+rng = np.random.default_rng(5)
+pts = [rng.uniform([-3, -3], [W + 3, H + 3], (120, 2)).astype(np.float32),
+       np.concatenate([rng.uniform([60, 40], [120, 90], (60, 2)), rng.uniform([0, 0], [W, H], (40, 2))]).astype(np.float32)]
+cnts = [rng.integers(1, 6, 120), rng.integers(1, 40, 100)]
+kept = tr.set_mask(pts, cnts, 12, None)
+for c, img in ((0, ea), (1, eb)):
+    rk, rmask = F.setmask(pts[c], cnts[c], W, H, 12, None)
+    assert np.array_equal(kept[c], rk), c
+    assert np.array_equal(tr.get_mask(c), rmask), c
+    assert np.array_equal(tr.detect_masked(c, 50, 0.01, 12.0), F.gftt(img, 50, 0.01, 12.0, rmask)), c
+intr = [461.6, 460.3, 363.0, 248.1, -0.2917, 0.08228, 5.333e-05, -1.578e-04]
+p = rng.uniform([0, 0], [752, 480], (200, 2)).astype(np.float32)
+assert np.array_equal(tr.undistort(p, intr).view(np.uint32), F.lift(p, intr).view(np.uint32))
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("order", ["forward", "reverse", "shuffle"])
+def test_emulated_detection_path_is_bit_exact_in_every_fiber_order(order):
+    """CLAHE, goodFeaturesToTrack (min-eigenvalue map, candidates, selection with the cell grid), setMask + stamping, liftProjective
+    under the emulator: the kernels of the detection path that the tracking test above does not reach, in all three fiber orders."""
+    env = dict(os.environ, SIMT_ORDER=order)
+    r = subprocess.run([sys.executable, "-c", _CHILD_D % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
