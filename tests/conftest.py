@@ -32,7 +32,8 @@ def handle():
 
 # ---- CPU fiber emulation of the kernel sources (tests/simt): TEST INFRASTRUCTURE, see tests/simt/README.md ---------
 SIMT_DIR = os.path.join(ROOT, "tests", "simt")
-SIMT_LIB = os.path.join(SIMT_DIR, "_build", "libvinsgpu_simt.so")
+# (VINS_SIMT_LIB: another build of the emulated library, e.g. the AddressSanitizer one of `make -C tests/simt asan`)
+SIMT_LIB = os.environ.get("VINS_SIMT_LIB") or os.path.join(SIMT_DIR, "_build", "libvinsgpu_simt.so")
 
 
 def _build_simt():

@@ -1,0 +1,41 @@
+"""The kernel sources under the CPU fiber emulator AND AddressSanitizer (race detection / sanitizers).  In the
+emulated build every device buffer is a heap block, so an out-of-bounds read or write of a kernel -- or of the host code that packs,
+uploads and unpacks around it, including writes into caller-owned (NumPy) buffers -- is a reported heap-buffer-overflow instead of a
+silent corruption.  (The one host overflow of round 3, a state download that wrote more inverse depths than the caller's buffer
+held, was found on the GPU as a crash three tests later; this run reports it at the memcpy.)  A representative subset runs here on
+every `not gpu` pass; `tests/simt/README.md` has the command for all of them (37 tests, 2.5 min)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMT = os.path.join(ROOT, "tests", "simt")
+
+
+def _asan_runtime():
+    r = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True)
+    p = r.stdout.strip()
+    return p if r.returncode == 0 and os.path.isabs(p) and os.path.exists(p) else None
+
+
+def test_emulated_kernels_under_address_sanitizer():
+    rt = _asan_runtime()
+    if rt is None:
+        pytest.skip("no libasan in this toolchain")
+    b = subprocess.run(["make", "-C", SIMT, "-j", str(os.cpu_count() or 4), "asan"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout[-3000:] + b.stderr[-3000:]
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0",
+               VINS_SIMT_LIB=os.path.join(SIMT, "_build_asan", "libvinsgpu_simt.so"))
+    sel = ("test_emulated_solve_matches_oracle or test_emulated_marginalization_matches_oracle or test_emulated_large_window_path_matches_oracle "
+           "or test_emulated_enlarged_window_marginalization or test_resident_sequence_equals_host_bookkeeping or test_hand_back_and_reseed "
+           "or test_emulated_detection_path_is_bit_exact_in_every_fiber_order or test_emulated_lk_is_bit_exact_in_every_fiber_order")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_simt_ba.py"), os.path.join(ROOT, "tests", "test_seq_simt.py"),
+                        os.path.join(ROOT, "tests", "test_simt_fe.py"), "-q", "-x", "-p", "no:cacheprovider", "-k", sel, "--deselect",
+                        "tests/test_simt_fe.py::test_emulated_lk_is_bit_exact_in_every_fiber_order[reverse]", "--deselect",
+                        "tests/test_simt_fe.py::test_emulated_lk_is_bit_exact_in_every_fiber_order[shuffle]"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    tail = r.stdout[-3000:] + r.stderr[-3000:]
+    assert "AddressSanitizer" not in r.stdout + r.stderr, tail
+    assert r.returncode == 0 and " passed" in r.stdout, tail
