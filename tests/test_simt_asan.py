@@ -39,3 +39,37 @@ def test_emulated_kernels_under_address_sanitizer():
     tail = r.stdout[-3000:] + r.stderr[-3000:]
     assert "AddressSanitizer" not in r.stdout + r.stderr, tail
     assert r.returncode == 0 and " passed" in r.stdout, tail
+
+
+def test_cpp_host_side_under_address_and_leak_sanitizer(tmp_path):
+    """The C++ host side (Estimator / FeatureTracker shims, ResidentEstimators incl. handBack / reseed, the replay harness) built with
+    -fsanitize=address against the sanitized emulated library: `vins_replay seq` (plain and with a hand-back), `ba` and `fe`, with the
+    leak checker on."""
+    import struct
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import replay_util
+    import seq_model as M
+    from vins_mono_amd import synth
+    if _asan_runtime() is None:
+        pytest.skip("no libasan in this toolchain")
+    b = subprocess.run(["make", "-C", SIMT, "-j", str(os.cpu_count() or 4), "asan"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout[-3000:] + b.stderr[-3000:]
+    exe = os.path.join(SIMT, "_build_asan", "vins_replay_simt")
+    K, n_frames = 11, 3
+    src = [M.FrameSource(synth.SyntheticSequence(s, n_frames=K + n_frames + 1, K=K + n_frames + 1, L=70), noise_seed=200 + s) for s in (21, 22)]
+    M.write_seq_file(tmp_path / "frames.bin", src, K, n_frames, min_parallax=0.25)
+    replay_util.write_sequence(replay_util.make_plan(5, 3, L=40), str(tmp_path / "seq.bin"))
+    W, H = 376, 240
+    frames = [synth.synth_frame(3, W, H)]
+    for k in range(1, 3):
+        frames.append(synth.warp_frame(frames[-1], 10 + k, shift=(2.1, -1.3), angle_deg=0.4))
+    with open(tmp_path / "fe.bin", "wb") as f:
+        f.write(struct.pack("<4i", len(frames), W, H, 1))
+        for fr in frames:
+            f.write(np.ascontiguousarray(fr).tobytes())
+    runs = [(["seq", "frames.bin"], {}), (["seq", "frames.bin"], {"VINS_REPLAY_HANDBACK": "0"}), (["ba", "seq.bin"], {}), (["fe", "fe.bin"], {})]
+    for args, extra in runs:
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:detect_stack_use_after_return=0", **extra)
+        r = subprocess.run([exe, args[0], str(tmp_path / args[1]), str(tmp_path / "out.txt")], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr, (args, extra, r.stderr[-3000:])

@@ -167,6 +167,7 @@ static int replay_ba(const char* in, const char* out) {
         fprintf(o, "%.0f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,\n", stamp[K - 1] * 1e9, est.Ps[WINDOW_SIZE].x(), est.Ps[WINDOW_SIZE].y(),
                 est.Ps[WINDOW_SIZE].z(), q.w(), q.x(), q.y(), q.z(), est.Vs[WINDOW_SIZE].x(), est.Vs[WINDOW_SIZE].y(), est.Vs[WINDOW_SIZE].z());
     }
+    for (int k = 0; k <= WINDOW_SIZE; ++k) { delete est.pre_integrations[k]; est.pre_integrations[k] = nullptr; }   // (the harness owns them, like the reference's clearState)
     fclose(o);
     fclose(rd.f);
     vg_destroy(h);
