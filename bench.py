@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+QUICK = False                # --emulated: the contract self-test on the CPU (tests/test_bench_contract.py): tiny loop counts, timings meaningless
 WINDOWS_PER_GPU = 256
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix peak (AMD datasheet)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md
@@ -208,13 +209,13 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
         from oracle import fe_cpu
         t = time.perf_counter()
         reps = 0
-        while time.perf_counter() - t < 5.0:
+        while time.perf_counter() - t < (0.2 if QUICK else 5.0):
             fe_cpu.lk(fa[reps % len(fa)], fb[reps % len(fb)], corners[reps % len(corners)])
             reps += 1
         dt = time.perf_counter() - t
         t2 = time.perf_counter()
         g = 0
-        while time.perf_counter() - t2 < 3.0:
+        while time.perf_counter() - t2 < (0.2 if QUICK else 3.0):
             fe_cpu.gftt(fa[g % len(fa)], N)
             g += 1
         out["cpu_baseline"] = {"value": reps * N / dt, "unit": "features/s", "cores": 1, "kind": "port",
@@ -226,7 +227,7 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
         nthr = max(1, min(os.cpu_count() or 1, 8))
         t3 = time.perf_counter()
         rm = 0
-        while time.perf_counter() - t3 < 3.0:
+        while time.perf_counter() - t3 < (0.2 if QUICK else 3.0):
             fe_cpu.lk_mt(fa[rm % len(fa)], fb[rm % len(fb)], corners[rm % len(corners)], nthr)
             rm += 1
         out["cpu_baseline"]["all_cores"] = {"value": rm * N / (time.perf_counter() - t3), "unit": "features/s", "cores": nthr,
@@ -461,21 +462,38 @@ def main():
                     "2-rank self-test on a 1-GPU box together with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="self-test: all ranks use cuda:0")
     ap.add_argument("--rccl-hook", action="store_true", help="--config sharded with one rank: still route the reductions through RCCL")
+    ap.add_argument("--emulated", action="store_true",
+                    help="contract self-test WITHOUT a GPU (tests/test_bench_contract.py): the kernel sources under the CPU fiber emulator of "
+                         "tests/simt, tiny loop counts; every number it prints is meaningless except that the line has the right shape")
     args = ap.parse_args()
     if args.launch_mode:
         os.environ["VG_BA_LAUNCH_MODE"] = args.launch_mode       # read by the library when a handle first launches
 
     import torch
     import __graft_entry__ as graft
-    graft.load_package()
+    pkg = graft.load_package()
     from vins_mono_amd import ba, synth, dist_util as D
     rank, local_rank, world = D.env_rank()
-    if not torch.cuda.is_available():
+    global QUICK, FE_CAMS
+    if args.emulated:
+        # TEST INFRASTRUCTURE, never a measurement: the emulated library of tests/simt stands in for libvinsgpu.so so that the code of
+        # this file (legs, JSON assembly) can be exercised where there is no GPU
+        import ctypes
+        import subprocess
+        simt = os.path.join(ROOT, "tests", "simt")
+        subprocess.run(["make", "-C", simt, "-j", str(os.cpu_count() or 4)], check=True, stdout=subprocess.DEVNULL)
+        pkg._lib, pkg.LIB_PATH = ctypes.CDLL(os.path.join(simt, "_build", "libvinsgpu_simt.so"), mode=ctypes.RTLD_LOCAL), "emulated"
+        QUICK, FE_CAMS = True, 2
+        if args.config != "batch" or world != 1:
+            raise SystemExit("--emulated: the batch config on one rank only")
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.share_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    D.init(args.backend, local_rank)    # one process per GPU; RCCL only for barrier / max / sum of the timing
+    if not args.emulated:
+        torch.cuda.set_device(local_rank)
+        D.init(args.backend, local_rank)    # one process per GPU; RCCL only for barrier / max / sum of the timing
+    cuda_sync = (lambda: None) if args.emulated else torch.cuda.synchronize
 
     if args.config == "sharded":
         bench_sharded(args, ba, synth, D, rank, world)
@@ -499,7 +517,7 @@ def main():
     info = h.ba_info()
 
     def barrier():
-        torch.cuda.synchronize()
+        cuda_sync()
         D.barrier()
 
     def sync_all():
@@ -514,20 +532,20 @@ def main():
     for k in range(args.steps):
         handles[k % nfl].ba_run_async()
     sync_all()
-    torch.cuda.synchronize()
+    cuda_sync()
     elapsed = time.perf_counter() - t0
     barrier()
     elapsed = D.max_over_ranks(elapsed)
 
     # the same loop ten times as long (>= 200 steps): the timed region above is ~50 ms, too short for round-to-round deltas of a
     # few per cent to mean much; reported next to `value`, never instead of it
-    n_long = max(200, 10 * args.steps)
+    n_long = 2 if QUICK else max(200, 10 * args.steps)
     barrier()
     tl0 = time.perf_counter()
     for k in range(n_long):
         handles[k % nfl].ba_run_async()
     sync_all()
-    torch.cuda.synchronize()
+    cuda_sync()
     long_elapsed = D.max_over_ranks(time.perf_counter() - tl0)
     barrier()
     launch_stats = h.ba_launch_stats()               # mode in effect + graph launches / captures of the timed handle so far
@@ -562,7 +580,7 @@ def main():
     if hb not in handles:
         hb.ba_upload(packed, flags)
     ha.ba_prepare_download(); hb.ba_prepare_download()
-    nb_pipe = 8
+    nb_pipe = 1 if QUICK else 8
 
     def pipelined(nb):
         ha.ba_upload(packed, flags); ha.ba_run_async()
@@ -584,11 +602,11 @@ def main():
     # every thread loops upload -> run_async -> download on its own handle / stream / pinned staging, so the pack + H2D and
     # D2H + unpack of some batches always run beside the kernels of another
     import threading
-    nthr = 8
+    nthr = 2 if QUICK else 8
     th_handles = (handles + [ba.Handle() for _ in range(max(0, nthr - len(handles)))])[:nthr]
     for hh in th_handles:
         hh.ba_upload(packed, flags); hh.ba_prepare_download()
-    nb_thr = 16
+    nb_thr = 1 if QUICK else 16
     errs = []
 
     def boundary_worker(hh, nb):
@@ -644,7 +662,7 @@ def main():
             t.join()
     chained(1)
     tc0 = time.perf_counter()
-    nb_ch = 5
+    nb_ch = 1 if QUICK else 5
     chained(nb_ch)
     chained_ms = (time.perf_counter() - tc0) / (nb_ch * CHAIN_FRAMES * nthr) * 1e3
     if errs:
@@ -654,7 +672,7 @@ def main():
             hh.close()
     # windows that stay on the device from frame to frame (vg_ba_seq_*): informational, never fails the bench
     try:
-        resident_ms, resident_info = bench_resident(ba, synth, seqs)
+        resident_ms, resident_info = bench_resident(ba, synth, seqs, nthr=2 if QUICK else 4, rounds=1 if QUICK else 3)
     except Exception as ex:                               # noqa: BLE001
         resident_ms, resident_info = None, {"error": repr(ex)}
     h.ba_upload(packed, flags)
@@ -714,11 +732,11 @@ def main():
                 pinned = False
             ncpu = min(nwin, 64)
             for i in range(3):                                                      # warm-up
-                ba_cpu.time_optimize([packed[i]], [flags[i]])
+                ba_cpu.time_optimize([packed[i % nwin]], [flags[i % nwin]])
             t_full, t_solve = [], []
             tstart = time.perf_counter()
             i = 0
-            while (len(t_full) < 50 or time.perf_counter() - tstart < 10.0) and len(t_full) < 400:
+            while (len(t_full) < (3 if QUICK else 50) or time.perf_counter() - tstart < (0.1 if QUICK else 10.0)) and len(t_full) < 400:
                 t_full.append(ba_cpu.time_optimize([packed[i % ncpu]], [flags[i % ncpu]]))
                 t_solve.append(ba_cpu.time_optimize([packed[i % ncpu]], [ba.VG_MARGIN_NONE]))
                 i += 1
@@ -828,7 +846,7 @@ def main():
                                                 "bookkeeping (addFeatureCheckParallax, triangulate, problem tables, slideWindow) runs on the device; "
                                                 "NOT the metric (bench contract: `value` is device-resident)"},
         }
-    fe_out = bench_fe(h, synth, max(args.steps, 10), args.warmup, rank, rank == 0 and world == 1 and not args.no_cpu_baseline)
+    fe_out = bench_fe(h, synth, 2 if QUICK else max(args.steps, 10), args.warmup, rank, rank == 0 and world == 1 and not args.no_cpu_baseline)
     fe_out["value_all_gpus"] = D.sum_over_ranks(fe_out["value"])
     # single-window latency (configs[2]) on rank 0
     if rank == 0:
@@ -837,7 +855,7 @@ def main():
         for _ in range(3):
             h.ba_run_async()
         h.sync()
-        lat = [h.ba_run_timed() for _ in range(20)]
+        lat = [h.ba_run_timed() for _ in range(2 if QUICK else 20)]
         out["single_window_latency_ms"] = float(np.median([a + b for a, b in lat]))
         out["single_window"] = {
             "solve_pipeline_ms": float(np.median([a for a, _ in lat])), "marginalization_ms": float(np.median([b for _, b in lat])),
@@ -845,14 +863,14 @@ def main():
                     "by the NEXT frame's optimization()"}
         # the boundary-inclusive single call a drop-in Estimator::optimization() makes: vg_ba_optimize (pack + H2D + launches + D2H)
         calls = []
-        for _ in range(20):
+        for _ in range(2 if QUICK else 20):
             tc = time.perf_counter()
             h.ba_optimize(packed[0], ba.VG_MARGIN_OLD)
             calls.append((time.perf_counter() - tc) * 1e3)
         out["single_window"]["vg_ba_optimize_call_ms"] = float(np.median(calls))
         # the same in two parts (vg_ba_optimize_begin / _prior): time until the STATES are back on the host -- what
         # Estimator::optimization() waits for; the marginalization runs behind it and is collected by the next frame
-        ready = [h.ba_optimize_split(packed[0], ba.VG_MARGIN_OLD)[3] for _ in range(20)]
+        ready = [h.ba_optimize_split(packed[0], ba.VG_MARGIN_OLD)[3] for _ in range(2 if QUICK else 20)]
         out["single_window"]["states_on_host_ms"] = float(np.median(ready))
         if out["cpu_baseline"]:
             out["single_window_speedup_vs_cpu"] = out["cpu_baseline"]["ms_per_solve"] / out["single_window_latency_ms"]
