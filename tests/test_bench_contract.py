@@ -43,3 +43,21 @@ def test_bench_line_has_the_contract_shape():
     fe = d["fe"]
     assert fe["unit"] == "features/s" and fe["roofline"]["bound"] == "hbm" and fe["roofline"]["unit"] == "GB/s" and fe["tracked_last_step"] > 0
     assert d["single_window"]["solve_pipeline_ms"] > 0 and d["single_window_latency_ms"] > 0
+
+
+def test_sharded_bench_line_runs_end_to_end():
+    """`bench.py --config sharded` (BASELINE configs[4]) under the emulator on a small window: the large-window path with its on-demand
+    rounds, the per-kernel events, the marginalization of the sharded window, the CPU baseline and parity fields."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulated", "--config", "sharded", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["unit"] == "solves/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None
+    k = d["roofline"]["kernels"]
+    assert {"ba_big_schur_kernel", "ba_solve_big_kernel", "ba_big_step_kernel"} <= set(k)
+    assert k["ba_solve_big_kernel"]["launches_per_step"] <= 10          # 8 iterations + the round that judges the last candidate: no empty slack rounds
+    m = d["marginalization_of_the_sharded_window"]
+    assert m["kept_dimension"] > 0 and m["dropped_dimension"] >= 15 and m["ms"] > 0
+    assert d["cpu_baseline"]["parity"]["final_cost_rel"] < 1e-6
