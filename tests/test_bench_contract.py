@@ -61,3 +61,20 @@ def test_sharded_bench_line_runs_end_to_end():
     m = d["marginalization_of_the_sharded_window"]
     assert m["kept_dimension"] > 0 and m["dropped_dimension"] >= 15 and m["ms"] > 0
     assert d["cpu_baseline"]["parity"]["final_cost_rel"] < 1e-6
+
+
+def test_smoke_entry_point_runs_against_the_emulated_library():
+    """__graft_entry__.smoke() (the driver runs it on the GPU before the bench): the same code with the emulated library standing in
+    for libvinsgpu.so -- one BA window and one front-end frame pair against the oracles."""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    conftest._build_simt()
+    saved = (pkg._lib, pkg.LIB_PATH)
+    pkg._lib, pkg.LIB_PATH = ctypes.CDLL(conftest.SIMT_LIB, mode=ctypes.RTLD_LOCAL), conftest.SIMT_LIB
+    try:
+        graft.smoke()
+    finally:
+        pkg._lib, pkg.LIB_PATH = saved
