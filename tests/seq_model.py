@@ -23,7 +23,7 @@ def window_inputs(hw):
 
 
 def run_both(h_seq, h_ref, seeds, K=11, L=150, n_steps=6, min_parallax=10.0 / 460.0, max_features=512, estimate_td=0, check=None,
-             teacher=True):
+             teacher=True, mutate=None):
     """Feeds `n_steps` frames of len(seeds) synthetic sequences to the host model (+ vg_ba_optimize per frame on h_ref) and to the
     device-resident sequence on h_seq; calls check(step, window, host, device) after every step and returns the flags taken.
     teacher: after the comparison of a step the host model continues from the DEVICE's solved states, inverse depths and prior, so
@@ -44,6 +44,8 @@ def run_both(h_seq, h_ref, seeds, K=11, L=150, n_steps=6, min_parallax=10.0 / 46
         for w in range(nwin):
             s, win = src[w], hw[w]
             ids, rows = s.image(g)
+            if mutate is not None:                          # (edge cases: thinned-out or empty frames)
+                ids, rows = mutate(step, w, ids, rows)
             pose, sb = s.guess(g)
             smp = s.samples(g - 1)                          # the interval in front of the new frame
             ba_, bg_ = win.sb[K - 1][3:6], win.sb[K - 1][6:9]       # Bas / Bgs[WINDOW_SIZE] when the IntegrationBase is created

@@ -145,3 +145,24 @@ def test_frame_inputs_are_validated(two_handles):
         assert h.seq_info()[0]['status'] == 0
     finally:
         h.seq_end()
+
+
+def test_thin_and_empty_frames(two_handles):
+    """Edge cases of addFeatureCheckParallax (feature_manager.cpp:45-107): a frame that continues fewer than 20 tracks is a key frame
+    whatever the parallax (:73-74), a frame without any observation, a frame of new ids only, then normal frames again -- the track
+    tables, flags and solves of the device-resident window against the host bookkeeping, with the parallax threshold set so that
+    ordinary frames are NOT key frames."""
+    h_seq, h_ref = two_handles
+
+    def mutate(step, w, ids, rows):
+        if step == 0:
+            return ids[:12], rows[:12]                     # 12 continued tracks: last_track_num < 20
+        if step == 1:
+            return ids[:0], rows[:0]                       # nothing seen
+        if step == 2:
+            return ids + 100000, rows                      # only ids nobody has seen before
+        return ids, rows
+
+    flags = M.run_both(h_seq, h_ref, seeds=[22], K=11, L=70, n_steps=5, min_parallax=0.5, max_features=256, check=M.check_step, mutate=mutate)
+    flat = [f for fr in flags for f in fr]
+    assert flat[:3] == [M.OLD, M.OLD, M.OLD]               # < 20 continued tracks every time
