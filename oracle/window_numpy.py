@@ -32,8 +32,8 @@ class SlidingWindow:
         self.ex, self.td = np.array(base['ex'], float), float(base['td'])
         self.pose, self.sb = np.array(pose, float), np.array(sb, float)
         self.imu, self.samples = list(imu), list(samples)          # K-1 intervals: record dict + raw sample list
-        self.features = [dict(id=int(t['id']), start=int(t['start']), obs=[list(map(float, r)) for r in t['obs']], depth=float(t['depth']), flag=0)
-                         for t in tracks]
+        self.features = [dict(id=int(t['id']), start=int(t['start']), obs=[list(map(float, r)) for r in t['obs']], depth=float(t['depth']),
+                              flag=int(t.get('flag', 0))) for t in tracks]
         self.prior = None
         self.init_depth, self.min_parallax = init_depth, min_parallax
 

@@ -23,7 +23,7 @@ def window_inputs(hw):
 
 
 def run_both(h_seq, h_ref, seeds, K=11, L=150, n_steps=6, min_parallax=10.0 / 460.0, max_features=512, estimate_td=0, check=None,
-             teacher=True, mutate=None):
+             teacher=True, mutate=None, prepare=None):
     """Feeds `n_steps` frames of len(seeds) synthetic sequences to the host model (+ vg_ba_optimize per frame on h_ref) and to the
     device-resident sequence on h_seq; calls check(step, window, host, device) after every step and returns the flags taken.
     teacher: after the comparison of a step the host model continues from the DEVICE's solved states, inverse depths and prior, so
@@ -33,6 +33,9 @@ def run_both(h_seq, h_ref, seeds, K=11, L=150, n_steps=6, min_parallax=10.0 / 46
     seqs = [synth.SyntheticSequence(s, n_frames=K + n_steps + 1, K=K + n_steps + 1, L=L, estimate_td=estimate_td) for s in seeds]
     src = [FrameSource(q, noise_seed=100 + i) for i, q in enumerate(seqs)]
     hw = [s.initial_host_window(K, 0, 5.0, min_parallax) for s in src]
+    if prepare is not None:                                 # (edge cases: doctor the windows before they are handed over)
+        for w_ in hw:
+            prepare(w_)
     wins, trks = zip(*[window_inputs(w) for w in hw])
     h_seq.seq_begin(list(wins), list(trks), max_features=max_features, max_new_obs=max_features, init_depth=5.0, min_parallax=min_parallax)
     newest = [K - 2] * nwin                                 # global frame in slot K - 2

@@ -166,3 +166,31 @@ def test_thin_and_empty_frames(two_handles):
     flags = M.run_both(h_seq, h_ref, seeds=[22], K=11, L=70, n_steps=5, min_parallax=0.5, max_features=256, check=M.check_step, mutate=mutate)
     flat = [f for fr in flags for f in fr]
     assert flat[:3] == [M.OLD, M.OLD, M.OLD]               # < 20 continued tracks every time
+
+
+def test_failed_tracks_are_removed_at_the_slide(two_handles):
+    """FeatureManager::removeFailures (feature_manager.cpp:161-171) erases every track whose solve_flag is 2 -- set by setDepth for the
+    tracks of the problem (negative depth), or carried by a track that is not in the problem: windows are handed over with such
+    tracks, and the first slide must drop exactly those (device = host bookkeeping, list order kept)."""
+    h_seq, h_ref = two_handles
+    marked = []
+
+    def prepare(win):
+        out_of_problem = [ft for ft in win.features if not win.in_problem(ft)]
+        in_problem = [ft for ft in win.features if win.in_problem(ft)]
+        assert len(out_of_problem) >= 3 and len(in_problem) >= 3
+        for ft in out_of_problem[::2] + in_problem[:2]:
+            ft['flag'] = 2
+        marked.append(([ft['id'] for ft in out_of_problem[::2]], [ft['id'] for ft in in_problem[:2]]))
+
+    survivors = {}
+
+    def check(step, w, host, flag, dev):
+        M.check_step(step, w, host, flag, dev)
+        survivors.setdefault(step, set(dev['tracks']['id'].tolist()))
+
+    M.run_both(h_seq, h_ref, seeds=[21], K=11, L=70, n_steps=2, min_parallax=10.0 / 460.0, max_features=256, check=check, prepare=prepare)
+    gone, resolved = marked[0]
+    still_observed = [i for i in gone if i in survivors[0]]
+    assert not still_observed, still_observed               # tracks outside the problem keep their flag: removed at the first slide
+    assert any(i in survivors[0] for i in resolved)         # tracks of the problem get a fresh flag from setDepth (their depth is positive)

@@ -379,6 +379,7 @@ def sequence_inputs(win):
     t = win['tracks']
     tracks = dict(id=np.array([f['id'] for f in t], np.int32), start=np.array([f['start'] for f in t], np.int32),
                   nobs=np.array([len(f['obs']) for f in t], np.int32), depth=np.array([f['depth'] for f in t], float),
+                  solve_flag=np.array([f.get('flag', 0) for f in t], np.int32),
                   obs=np.array([r for f in t for r in f['obs']], float).reshape(-1, 8))
     return prob, tracks
 
