@@ -251,7 +251,11 @@ int vg_ba_batch_flops(vg_handle* h, double* solve_flops, double* marg_flops);
  * factors and prior but only ITS contiguous share of the landmarks (with their observations), installs an all-reduce
  * hook, and calls vg_ba_batch_run_async as usual (on this path the call waits for the stream once or a few times near the end of
  * the solve: the rounds that only exist for retried factorisations are issued on demand, after a look at the windows' DONE flags);
- * after the run every rank holds the identical frame states and the inverse depths of its own landmarks.  Marginalization is not offered on this path (margin_flags must be NONE).
+ * after the run every rank holds the identical frame states and the inverse depths of its own landmarks.  Marginalization: a large
+ * window on ONE rank is marginalized like any other (margin_flags); with an all-reduce hook installed margin_flags must be NONE --
+ * a MARGIN_OLD marginalization only involves the tracks anchored at frame 0, so the ranks all-gather those (a few KB) and every rank
+ * marginalizes the same reduced single-rank problem (all frames at the solved states, imu[], the old prior, those tracks,
+ * max_iters = 0) on a second handle without a hook: identical result everywhere (vins-mono_amd/shard.py marginalize_sharded).
  *
  * The hook is called on the host, twice per trust-region round, between two kernel launches: it must enqueue on `stream`
  * (a hipStream_t) an in-place SUM over all ranks of `count` doubles at `device_buf` -- with RCCL:
