@@ -1,0 +1,103 @@
+"""Malformed inputs at the C-ABI: a caller's mistake must come back as a vg_status, never as an out-of-bounds access.  Random
+corruptions of valid problems (sizes, offsets, indices, prior block tables, frame inputs of a sequence) are thrown at the emulated
+library built with AddressSanitizer (tests/simt, `make asan`): every call must return a status and ASAN must stay silent; calls that
+are accepted must solve without a sanitizer report.  Runs in a child process (a crash must not take pytest down)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMT = os.path.join(ROOT, "tests", "simt")
+
+_CHILD = r"""
+import sys, ctypes as C
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+import conftest
+from vins_mono_amd import ba, synth
+h = conftest._simt_handle()
+rng = np.random.default_rng(7)
+seq = synth.SyntheticSequence(3, L=30)
+base = seq.anchor_prior(seq.window(0))
+n_err = n_ok = 0
+def mutate(prob, k):
+    p = dict(prob)
+    for key in ('lm_start', 'lm_nobs', 'obs_off', 'inv_depth', 'obs', 'pose', 'sb'):
+        p[key] = np.array(p[key]).copy()
+    pr = dict(p['prior']); pr['blocks'] = list(pr['blocks']); p['prior'] = pr
+    L = len(p['lm_start'])
+    l = int(rng.integers(0, L))
+    if k == 0: p['lm_nobs'][l] = int(rng.choice([0, 1, -3, 40]))
+    elif k == 1: p['lm_start'][l] = int(rng.choice([-1, 10, 11, 1000]))
+    elif k == 2: p['obs_off'][l] = int(rng.choice([-5, 10**6, p['obs'].shape[0] - 1]))
+    elif k == 3: pr['blocks'][int(rng.integers(0, len(pr['blocks'])))] = (int(rng.choice([-1, 4, 7])), 0)
+    elif k == 4: pr['blocks'][0] = (0, int(rng.choice([-2, 11, 500])))
+    elif k == 5: pr['blocks'] = pr['blocks'] + [pr['blocks'][0]]            # a block twice (n no longer matches)
+    elif k == 6: p['max_iters'] = int(rng.choice([-1, 33, 10**6]))
+    elif k == 7: pr['n'] = pr['n'] + int(rng.choice([-3, 5]))
+    elif k == 8: p['relo'] = dict(pose=np.array([0, 0, 0, 0, 0, 0, 1.0]), match=[(int(rng.choice([-1, L, L + 7])), 0.1, 0.2)])
+    elif k == 9: p['lm_nobs'][l] = 11 - int(p['lm_start'][l]) + 1           # one observation past the last frame
+    return p
+for it in range(60):
+    p = mutate(base, it %% 10)
+    try:
+        st, sm, pr = h.ba_optimize(p, int(rng.integers(0, 3)))
+        n_ok += 1
+    except RuntimeError as e:
+        assert "status -" in str(e), e
+        n_err += 1
+    except (AssertionError, ValueError, IndexError):      # (the Python binding itself may refuse: not the library's business)
+        n_err += 1
+# a valid call still works afterwards
+st, sm, pr = h.ba_optimize(base, 0)
+assert sm['status'] == 0
+# sequences: bad frame inputs
+src = synth.FrameSource(synth.SyntheticSequence(21, n_frames=14, K=14, L=40), noise_seed=1)
+prob, tracks = synth.sequence_inputs(src.initial_window(11, 0))
+for bad in range(4):
+    t = {k: np.array(v).copy() for k, v in tracks.items()}
+    if bad == 0: t['nobs'][0] = 0
+    if bad == 1: t['start'][1] = 10
+    if bad == 2: t['start'][2] = -1
+    if bad == 3: t['nobs'][3] = 30
+    try:
+        h.seq_begin([prob], [t], max_features=128, max_new_obs=128)
+        raise SystemExit("a malformed track table was accepted: case %%d" %% bad)
+    except RuntimeError as e:
+        assert "status -" in str(e), e
+        n_err += 1
+h.seq_begin([prob], [tracks], max_features=128, max_new_obs=128)
+ids, rows = src.image(10)
+pose, sb = src.guess(10)
+for bad in range(3):
+    f = dict(pose=pose, sb=sb, imu_new=src.seq.imu[9], imu_merged=None, ids=ids.copy(), obs=rows.copy())
+    if bad == 0: f['ids'][3] = f['ids'][2]                  # repeated id
+    if bad == 1: f['ids'] = f['ids'][::-1].copy()
+    if bad == 2: f['ids'] = np.concatenate([f['ids']] * 4); f['obs'] = np.concatenate([f['obs']] * 4)   # more than max_new_obs (and not ascending)
+    try:
+        h.seq_step([f])
+        raise SystemExit("a malformed frame was accepted: case %%d" %% bad)
+    except RuntimeError as e:
+        assert "status -" in str(e), e
+        n_err += 1
+h.seq_step([dict(pose=pose, sb=sb, imu_new=src.seq.imu[9], imu_merged=None, ids=ids, obs=rows)])
+assert h.seq_info()[0]['status'] == 0
+h.seq_end()
+print("OK refused", n_err, "accepted", n_ok)
+"""
+
+
+def test_malformed_inputs_come_back_as_status_codes():
+    r0 = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True)
+    rt = r0.stdout.strip()
+    if r0.returncode != 0 or not os.path.isabs(rt) or not os.path.exists(rt):
+        pytest.skip("no libasan in this toolchain")
+    b = subprocess.run(["make", "-C", SIMT, "-j", str(os.cpu_count() or 4), "asan"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout[-3000:] + b.stderr[-3000:]
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0",
+               VINS_SIMT_LIB=os.path.join(SIMT, "_build_asan", "libvinsgpu_simt.so"))
+    r = subprocess.run([sys.executable, "-c", _CHILD % dict(root=ROOT)], capture_output=True, text=True, env=env, timeout=1500)
+    assert "AddressSanitizer" not in r.stdout + r.stderr, (r.stdout + r.stderr)[-4000:]
+    assert r.returncode == 0 and "OK refused" in r.stdout, (r.stdout + r.stderr)[-4000:]
