@@ -85,6 +85,31 @@ for bad in range(3):
 h.seq_step([dict(pose=pose, sb=sb, imu_new=src.seq.imu[9], imu_merged=None, ids=ids, obs=rows)])
 assert h.seq_info()[0]['status'] == 0
 h.seq_end()
+# front end: refused calls and calls with hostile values (NaN / huge coordinates, degenerate correspondences) that must run clean
+from vins_mono_amd import fe
+W, H = 256, 160
+a = synth.synth_frame(1, W, H); b = synth.warp_frame(a, 2)
+tr = fe.FrontEnd(h, W, H, 1, 32)
+tr.push_frames([a]); tr.push_frames([b])
+pts = rng.uniform([0, 0], [W, H], (200, 2)).astype(np.float32)
+intr = [461.6, 460.3, 363.0, 248.1, -0.2917, 0.08228, 5.333e-05, -1.578e-04]
+for name, fn in (("track n > max_points", lambda: tr.track(0, pts)), ("track cam out of range", lambda: tr.track(3, pts[:10])),
+                 ("detect more than max_points", lambda: tr.detect(0, 500)), ("detect tiny min_dist", lambda: tr.detect(0, 20, 0.01, 1.0)),
+                 ("reject_with_f n < 8", lambda: tr.reject_with_f(pts[:5], pts[:5], 1.0))):
+    try:
+        fn()
+        raise SystemExit("accepted: " + name)
+    except RuntimeError as e:
+        assert "status -" in str(e), e
+        n_err += 1
+nxt, st, err = tr.track(0, np.full((5, 2), np.nan, np.float32)); assert not st.any()
+nxt, st, err = tr.track(0, np.full((5, 2), 1e30, np.float32)); assert not st.any()
+tr.detect(0, 20, -1.0, 10.0)
+tr.set_mask([pts[:20]], [np.ones(20, np.int32)], 0)
+tr.undistort(np.full((5, 2), np.nan, np.float32), intr)
+stat, Fm = tr.reject_with_f(np.zeros((20, 2), np.float32), np.zeros((20, 2), np.float32), 1.0)
+assert stat.all()                                           # no model: nothing is rejected
+n_ok += 6
 print("OK refused", n_err, "accepted", n_ok)
 """
 
