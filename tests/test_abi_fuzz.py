@@ -53,6 +53,20 @@ for it in range(60):
 # a valid call still works afterwards
 st, sm, pr = h.ba_optimize(base, 0)
 assert sm['status'] == 0
+# non-finite and absurd values in a well-formed problem: a per-window status (VG_ERR_NUMERIC = -4) or a normal result, never a crash
+for what in ("nan_pose", "inf_depth", "zero_quat", "nan_obs", "huge_prior"):
+    p = {k: (np.array(v).copy() if isinstance(v, np.ndarray) else v) for k, v in base.items()}
+    if what == "nan_pose": p['pose'][3, 0] = np.nan
+    if what == "inf_depth": p['inv_depth'][2] = np.inf
+    if what == "zero_quat": p['pose'][4, 3:] = 0
+    if what == "nan_obs": p['obs'][5, 0] = np.nan
+    if what == "huge_prior": p['prior'] = dict(p['prior'], J0=p['prior']['J0'] * 1e200)
+    h.ba_upload([p], [0]); h.ba_run_async()
+    st_, sm_, pr_ = h.ba_download(allow_numeric_failure=True)
+    assert sm_[0]['status'] in (0, -4), (what, sm_[0]['status'])
+    if what in ("nan_pose", "zero_quat", "nan_obs"):
+        assert sm_[0]['status'] == -4 and pr_[0] is None, what      # no prior from a failed window
+    n_ok += 1
 # sequences: bad frame inputs
 src = synth.FrameSource(synth.SyntheticSequence(21, n_frames=14, K=14, L=40), noise_seed=1)
 prob, tracks = synth.sequence_inputs(src.initial_window(11, 0))
