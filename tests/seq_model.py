@@ -384,3 +384,48 @@ def run_handback(h_a, h_b, seeds, K=11, L=70, n_before=2, n_after=2, min_paralla
     got = drive(h_b, src_c, range(K - 1 + n_before, K - 1 + n_total), st_c)
     h_b.seq_end()
     return ref, got, order
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def run_failure_isolation(h):
+    """A window whose solve goes non-finite (a NaN in the new frame's state guess) reports VG_ERR_NUMERIC, leaves the other windows of
+    the batch untouched, and is brought back with vg_ba_seq_import: re-seeded with an exported copy of its neighbour and fed the
+    neighbour's frames, it reproduces the neighbour bit for bit."""
+    K, L = 11, 60
+    src = [synth.FrameSource(synth.SyntheticSequence(s, n_frames=K + 5, K=K + 5, L=L), noise_seed=500 + s) for s in (21, 22)]
+    wins = [s.initial_window(K, 0) for s in src]
+    probs, trks = zip(*[synth.sequence_inputs(w) for w in wins])
+    h.seq_begin(list(probs), list(trks), max_features=256, max_new_obs=256, min_parallax=0.0)       # every frame a key frame: no merges to track
+    try:
+        def frame(i, g, poison=False):
+            ids, rows = src[i].image(g)
+            pose, sb = src[i].guess(g)
+            if poison:
+                pose = pose.copy(); pose[1] = np.nan
+            return dict(pose=pose, sb=sb, imu_new=src[i].seq.imu[g - 1], imu_merged=None, ids=ids, obs=rows)
+        h.seq_step([frame(0, K - 1), frame(1, K - 1)])
+        sts, sms = h.seq_states()
+        assert sms[0]['status'] == 0 and sms[1]['status'] == 0
+        # ---- window 0 fails, window 1 does not notice
+        h.seq_step([frame(0, K, poison=True), frame(1, K)])
+        sts, sms = h.seq_states(allow_numeric_failure=True)
+        assert sms[0]['status'] == -4 and sms[1]['status'] == 0
+        good = sts[1]
+        # ---- re-seed slot 0 with a copy of window 1 (as exported now) and feed both the same frames
+        prob1, trk1 = h.seq_export(1, K)
+        full = dict(src[1].seq._base())
+        full.update(pose=prob1['pose'], sb=prob1['sb'], ex=prob1['ex'], td=prob1['td'], imu=prob1['imu'], prior=prob1['prior'], relo=None,
+                    lm_start=np.zeros(0, np.int32), lm_nobs=np.zeros(0, np.int32), obs_off=np.zeros(0, np.int32), obs=np.zeros((0, 7)), inv_depth=np.zeros(0))
+        h.seq_import(0, full, trk1)
+        for g in (K + 1, K + 2):
+            f1 = frame(1, g)
+            h.seq_step([f1, f1])
+            sts, sms = h.seq_states()
+            assert sms[0]['status'] == 0 and sms[1]['status'] == 0
+            for key in ('pose', 'sb', 'ex'):
+                assert np.array_equal(sts[0][key], sts[1][key]), (g, key)
+            t0, t1 = h.seq_tracks(0, K), h.seq_tracks(1, K)
+            assert np.array_equal(t0['id'], t1['id']) and np.array_equal(t0['depth'], t1['depth'])
+        assert np.isfinite(good['pose']).all()
+    finally:
+        h.seq_end()

@@ -194,3 +194,10 @@ def test_failed_tracks_are_removed_at_the_slide(two_handles):
     still_observed = [i for i in gone if i in survivors[0]]
     assert not still_observed, still_observed               # tracks outside the problem keep their flag: removed at the first slide
     assert any(i in survivors[0] for i in resolved)         # tracks of the problem get a fresh flag from setDepth (their depth is positive)
+
+
+def test_a_failed_window_is_isolated_and_can_be_re_seeded(two_handles):
+    """A window whose solve goes non-finite (a NaN in the new frame's state guess) reports VG_ERR_NUMERIC, leaves the other windows of
+    the batch untouched, and is brought back with vg_ba_seq_import: re-seeded with an exported copy of its neighbour and fed the
+    neighbour's frames, it reproduces the neighbour bit for bit."""
+    M.run_failure_isolation(two_handles[0])
