@@ -1,0 +1,263 @@
+"""TEST INFRASTRUCTURE: an end-to-end run through BOTH hot paths on rendered data (the stand-in for BASELINE configs[0], which needs
+the EuRoC bag + ROS + OpenCV + Ceres): frames are ray-cast from two textured walls along a simulated trajectory (EuRoC camera model
+incl. the radial-tangential distortion, 20 Hz), `vins_replay fe` runs them through the FeatureTracker drop-in (CLAHE, pyramidal LK,
+rejectWithF, setMask, goodFeaturesToTrack, undistortedPoints: everything on the device; replay_main.cpp stamps frame k with 0.05 k s),
+what it publishes per frame -- feature id, undistorted point, pixel, velocity, exactly the fields of the feature_tracker's PointCloud
+message (feature_tracker_node.cpp:122-160) -- is fed together with the simulated IMU to an estimator window that stays on the device
+(vg_ba_seq_*), and the estimated trajectory is compared (a) with the one the same tracks give with geometrically exact observations
+and (b) with the ground truth.  No oracle here: this checks that the two paths fit together (ids, units, time stamps, velocities) and
+that the front end's tracks are accurate against the geometry they were rendered from (median 0.03 px per frame).
+
+Findings while building it (kept, because they bound what the check can show): LK on isolated Gaussian blobs lags the true flow by
+1.5-2.7 % (flat 21x21 windows: noise attenuation) and on magnified or aliased texture by as much -- a scale bias that the estimator
+turns into drift; with texture at about one texel per pixel the gain error is < 0.1 %.  At this trajectory's < 0.1 m/s^2 over half a
+second the metric scale hangs on the accelerometer bias (0.01 m/s^2 of bias error = 10 % of scale, with exact observations too), so
+the scene starts from converged biases; the remaining error against the truth is the initial guess (3 cm) plus 1-2 cm."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+from vins_mono_amd import synth
+from oracle import window_numpy as W
+
+K_DIST = dict(k1=-2.917e-01, k2=8.228e-02, p1=5.333e-05, p2=-1.578e-04)        # config/euroc/euroc_config.yaml:19-22
+
+
+def distort(x, y):
+    """PinholeCamera::distortion (camodocal PinholeCamera.cc:398-428): normalised -> distorted normalised coordinates."""
+    k1, k2, p1, p2 = K_DIST['k1'], K_DIST['k2'], K_DIST['p1'], K_DIST['p2']
+    r2 = x * x + y * y
+    rad = k1 * r2 + k2 * r2 * r2
+    return x + x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x), y + y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+
+
+def undistort(xd, yd):
+    """PinholeCamera::liftProjective's recursive distortion model (camodocal PinholeCamera.cc:474-487): 8 fixed-point steps."""
+    x, y = xd.copy(), yd.copy()
+    for _ in range(8):
+        dx, dy = distort(x, y)
+        x, y = xd - (dx - x), yd - (dy - y)
+    return x, y
+
+
+class Scene:
+    """A slow EuRoC-like trajectory (synth.SyntheticSequence at 20 Hz with a 60 s period) in front of two textured walls at an angle
+    (depths 3.2 ... 7 m, so that the scene is not planar); a frame is rendered by casting the
+    ray of every pixel (undistorted with the EuRoC model) onto the nearer plane and sampling its texture (multi-octave value noise,
+    bilinear)."""
+
+    def __init__(self, seed, n_frames, noise=0.5):
+        self.seq = synth.SyntheticSequence(seed, n_frames=n_frames + 1, K=n_frames + 1, L=10, period=60.0, imu_per_frame=10, frame_dt=0.05)
+        seq, c = self.seq, self.seq.cfg
+        # the window starts with converged IMU biases: at 20 Hz over half a second this trajectory accelerates by < 0.1 m/s^2, so an
+        # accelerometer bias error of 0.01 m/s^2 is a 10 % scale error that no estimator could tell from the images
+        seq.ba_lin, seq.bg_lin = seq.ba_true.copy(), seq.bg_true.copy()
+        rng = np.random.default_rng(seed + 1)
+        m = n_frames // 2
+        Rc = seq.Rm[m] @ c['ric']                                            # camera orientation / centre in the middle of the run
+        Cc = seq.Rm[m] @ c['tic'] + seq.P[m]
+        ax, ay, az = Rc[:, 0], Rc[:, 1], Rc[:, 2]
+        # plane = (point, normal, in-plane axes e1, e2): a wall 7 m ahead, visible in the left quarter of the image, and in front of it a
+        # second wall turned by 35 degrees about the vertical, 7 m ... 3.2 m away from left to right
+        n2 = az * np.cos(np.radians(35)) + ax * np.sin(np.radians(35))
+        e1b = np.cross(ay, n2)
+        self.planes = [(Cc + 7.0 * az, az, ax, ay), (Cc + 5.0 * az, n2, e1b / np.linalg.norm(e1b), ay)]
+        self.tex = []
+        for _ in self.planes:
+            t = np.zeros((1024, 1024))
+            for o, amp in ((6, 60.0), (12, 45.0), (24, 35.0), (48, 25.0), (96, 15.0)):   # value noise, 5 octaves
+                lat = rng.uniform(-1, 1, (1024 // o + 2, 1024 // o + 2))
+                yy, xx = (np.arange(1024) + 0.5) / o, (np.arange(1024) + 0.5) / o
+                y0, x0 = np.floor(yy).astype(int), np.floor(xx).astype(int)
+                fy, fx = (yy - y0)[:, None], (xx - x0)[None, :]
+                t += amp * (lat[y0][:, x0] * (1 - fy) * (1 - fx) + lat[y0][:, x0 + 1] * (1 - fy) * fx + lat[y0 + 1][:, x0] * fy * (1 - fx) + lat[y0 + 1][:, x0 + 1] * fy * fx)
+            self.tex.append(t)
+        self.scale = 80.0                                                    # texels per metre
+        self.noise, self.bg_seed = noise, seed + 2
+        self._rays = None
+
+    def _pixel_rays(self, W_, H_):
+        if self._rays is None:
+            c = self.seq.cfg
+            v, u = np.mgrid[0:H_, 0:W_].astype(np.float64)
+            x, y = undistort((u - c['cx']) / c['fx'], (v - c['cy']) / c['fy'])
+            self._rays = np.stack([x, y, np.ones_like(x)], -1)
+        return self._rays
+
+    def depth_along(self, f, rays):
+        """Depth z of the first plane hit along camera rays [..., 3] (z = 1 normalised) of frame f, and which plane."""
+        seq, c = self.seq, self.seq.cfg
+        Rc, Cc = seq.Rm[f] @ c['ric'], seq.Rm[f] @ c['tic'] + seq.P[f]
+        d = rays @ Rc.T
+        best, which = np.full(rays.shape[:-1], np.inf), np.zeros(rays.shape[:-1], int)
+        for k, (p0, n, e1, e2) in enumerate(self.planes):
+            den = d @ n
+            t = ((p0 - Cc) @ n) / np.where(np.abs(den) < 1e-9, 1e-9, den)
+            ok = (t > 0.3) & (t < best)
+            best, which = np.where(ok, t, best), np.where(ok, k, which)
+        return best, which, Rc, Cc, d
+
+    def render(self, f, W_=752, H_=480):
+        rays = self._pixel_rays(W_, H_)
+        t, which, Rc, Cc, d = self.depth_along(f, rays)
+        X = Cc + d * t[..., None]
+        img = np.full((H_, W_), 118.0)
+        for k, (p0, n, e1, e2) in enumerate(self.planes):
+            m = (which == k) & np.isfinite(t)
+            a, b = (X[m] - p0) @ e1 * self.scale + 512.0, (X[m] - p0) @ e2 * self.scale + 512.0
+            a, b = np.clip(a, 0, 1022.999), np.clip(b, 0, 1022.999)
+            a0, b0 = np.floor(a).astype(int), np.floor(b).astype(int)
+            fa, fb = a - a0, b - b0
+            T = self.tex[k]
+            img[m] += T[b0, a0] * (1 - fb) * (1 - fa) + T[b0, a0 + 1] * (1 - fb) * fa + T[b0 + 1, a0] * fb * (1 - fa) + T[b0 + 1, a0 + 1] * fb * fa
+        img += np.random.default_rng(self.bg_seed + 7919 * f).normal(0, self.noise, img.shape)    # sensor noise, new in every frame
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+    def true_normalised(self, f, u, v):
+        """Ideal undistorted normalised coordinates of pixel positions (what liftProjective should return)."""
+        c = self.seq.cfg
+        return undistort((np.asarray(u, float) - c['cx']) / c['fx'], (np.asarray(v, float) - c['cy']) / c['fy'])
+
+
+def run_front_end(exe, frames, tmp):
+    """`vins_replay fe`: per frame the published features {id: [x, y, 1, u, v, vx, vy]} (track_cnt > 1, as feature_tracker_node.cpp:130)."""
+    n, (H_, W_) = len(frames), frames[0].shape
+    with open(os.path.join(tmp, "frames.bin"), "wb") as f:
+        f.write(struct.pack("<4i", n, W_, H_, 1))
+        for fr in frames:
+            f.write(np.ascontiguousarray(fr).tobytes())
+    r = subprocess.run([exe, "fe", os.path.join(tmp, "frames.bin"), os.path.join(tmp, "fe.txt")], capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, cur = [], None
+    for line in open(os.path.join(tmp, "fe.txt")):
+        t = line.split()
+        if t[0] == "frame":
+            cur = {}
+            out.append(cur)
+        elif int(t[1]) > 1:
+            cur[int(t[0])] = [float(t[4]), float(t[5]), 1.0, float(t[2]), float(t[3]), float(t[6]), float(t[7])]
+    return out
+
+
+def run_estimator(h, scene, images, K=11, min_parallax=10.0 / 460.0, guess_noise=1.0):
+    """The published frames + the simulated IMU through one device-resident window; returns per solved frame (frame index, estimated
+    position of the newest frame, ground truth, key-frame flag, landmarks in the problem)."""
+    seq = scene.seq
+    src = synth.FrameSource(seq, noise_seed=5)
+    pose, sb = zip(*[src.guess(i) for i in range(K - 1)])                  # the initial window: the truth + 3 cm / 0.3 deg / 3 cm/s x guess_noise
+    pose = [np.concatenate([seq.P[i] + guess_noise * (p[:3] - seq.P[i]), p[3:]]) for i, p in enumerate(pose)]
+    sb = [np.concatenate([seq.V[i] + guess_noise * (v[:3] - seq.V[i]), v[3:]]) for i, v in enumerate(sb)]
+    pose, sb = list(pose) + [pose[-1]], list(sb) + [sb[-1]]
+    smp = [src.samples(i) for i in range(K - 2)] + [None]
+    imu = [src.preintegrate(s, seq.ba_lin, seq.bg_lin) for s in smp[:-1]] + [None]
+    feats = {}
+    for f in range(K - 1):
+        for fid in sorted(images[f]):
+            ft = feats.setdefault(fid, dict(id=fid, start=f, obs=[], depth=-1.0))
+            ft['obs'].append(list(images[f][fid]) + [0.0])
+    win = dict(K=K, base=seq._base(), pose=np.array(pose), sb=np.array(sb), imu=imu, samples=smp, tracks=list(feats.values()))
+    prob, tracks = synth.sequence_inputs(win)
+    h.seq_begin([prob], [tracks], max_features=768, max_new_obs=512, init_depth=5.0, min_parallax=min_parallax)
+    newest = (win['pose'][K - 1].copy(), win['sb'][K - 1].copy())
+    prev = dict(samples=list(smp[K - 3]), ba=seq.ba_lin, bg=seq.bg_lin)
+    merged, out = None, []
+    try:
+        for f in range(K - 1, len(images)):
+            s_ = src.samples(f - 1)
+            rec = src.preintegrate(s_, newest[1][3:6], newest[1][6:9])
+            p_, sb_ = W.propagate(newest[0], newest[1], s_, seq.cfg['g_norm'])
+            ids = np.array(sorted(images[f]), np.int32)
+            rows = np.array([images[f][i] for i in ids], float).reshape(-1, 7)
+            h.seq_step([dict(pose=p_, sb=sb_, imu_new=rec, imu_merged=merged, ids=ids, obs=rows)])
+            (st,), (sm,) = h.seq_states()
+            (info,) = h.seq_info()
+            assert info['status'] == 0 and sm['status'] == 0, (f, info, sm['status'])
+            cur = dict(samples=s_, ba=newest[1][3:6].copy(), bg=newest[1][6:9].copy())
+            if info['flag'] == W.NEW:
+                prev['samples'] = prev['samples'] + s_[1:]
+                merged = src.preintegrate(prev['samples'], prev['ba'], prev['bg'])
+            else:
+                prev, merged = cur, None
+            newest = (st['pose'][K - 1].copy(), st['sb'][K - 1].copy())
+            out.append((f, st['pose'][K - 1][:3].copy(), seq.P[f].copy(), info['flag'], info['n_landmarks'], info['n_tracked']))
+    finally:
+        h.seq_end()
+    return out
+
+
+def ideal_images(scene, images):
+    """The same tracks (ids, life spans) with geometrically exact observations: the first observation of a track fixes its 3D point
+    on the scene, every later one is that point's projection (velocity = exact finite difference over the frame interval)."""
+    seq, c = scene.seq, scene.seq.cfg
+    dt = float(seq.frame_dt) if hasattr(seq, 'frame_dt') else 0.05
+    point, out = {}, []
+
+    def proj(X, f):
+        Rc, Cc = seq.Rm[f] @ c['ric'], seq.Rm[f] @ c['tic'] + seq.P[f]
+        pc = (X - Cc) @ Rc
+        return pc[:2] / pc[2]
+
+    for f, im in enumerate(images):
+        cur = {}
+        for i, r in im.items():
+            if i not in point:
+                t, _, Rc, Cc, d = scene.depth_along(f, np.array([[r[0], r[1], 1.0]]))
+                point[i] = (Cc + d * t[:, None])[0]
+            x, y = proj(point[i], f)
+            xp, yp = proj(point[i], max(f - 1, 0))
+            xd, yd = distort(x, y)
+            cur[i] = [x, y, 1.0, c['fx'] * xd + c['cx'], c['fy'] * yd + c['cy'], (x - xp) / dt, (y - yp) / dt]
+        out.append(cur)
+    return out
+
+
+def tracking_error(scene, images):
+    """One-frame tracking error of the published points against the scene's geometry, in pixels: (errors [n, 2], true flows [n, 2],
+    published velocities [n, 2], true velocities [n, 2]) over all tracks and consecutive frame pairs."""
+    seq, c = scene.seq, scene.seq.cfg
+    e, fl, v, vt = [], [], [], []
+    for f in range(2, len(images)):
+        Rc2, Cc2 = seq.Rm[f] @ c['ric'], seq.Rm[f] @ c['tic'] + seq.P[f]
+        for i, r in images[f].items():
+            if i not in images[f - 1]:
+                continue
+            r0 = images[f - 1][i]
+            t, _, Rc, Cc, d = scene.depth_along(f - 1, np.array([[r0[0], r0[1], 1.0]]))
+            pc = ((Cc + d * t[:, None])[0] - Cc2) @ Rc2
+            tr = pc[:2] / pc[2]
+            e.append((np.array(r[:2]) - tr) * c['fx']); fl.append((tr - np.array(r0[:2])) * c['fx'])
+            v.append(r[5:7]); vt.append((tr - np.array(r0[:2])) / 0.05)
+    return np.array(e), np.array(fl), np.array(v), np.array(vt)
+
+
+def check_end_to_end(h, exe, tmp, n_frames=20, seed=3):
+    """The assertions shared by the CPU (emulated kernels) and the GPU test."""
+    scene = Scene(seed, n_frames)
+    frames = [scene.render(f) for f in range(n_frames)]
+    images = run_front_end(exe, frames, tmp)
+    assert len(images) == n_frames and len(images[0]) == 0                    # nothing is published before a track is two frames old
+    assert min(len(im) for im in images[1:]) >= 100, [len(im) for im in images]
+    # 1. the front end against the geometry it was rendered from
+    e, fl, v, vt = tracking_error(scene, images)
+    n = np.linalg.norm(e, axis=1)
+    gain = float((e * fl).sum() / (fl * fl).sum())
+    assert len(e) > 1500 and np.median(n) < 0.1 and np.percentile(n, 90) < 0.3, (len(e), np.median(n), np.percentile(n, 90))
+    assert abs(gain) < 0.005, gain                                            # tracks neither lag nor lead the true flow
+    assert abs(float((v * vt).sum() / (vt * vt).sum()) - 1.0) < 0.02          # published velocity = flow / frame interval
+    # 2. the estimator on what the front end published, against the same tracks with exact observations, and against the truth
+    got = run_estimator(h, scene, images)
+    ref = run_estimator(h, scene, ideal_images(scene, images))
+    assert len(got) == n_frames - 10
+    travelled = float(np.linalg.norm(scene.seq.P[n_frames - 1] - scene.seq.P[10]))
+    for a, b in zip(got, ref):
+        assert a[3] == b[3] and a[4] == b[4], (a[0], a[3:], b[3:])            # same key-frame decision, same landmarks in the problem
+        assert a[4] >= 100
+        assert np.linalg.norm(a[1] - b[1]) < 0.045, (a[0], a[1] - b[1])       # 0.023 m observed
+        assert np.linalg.norm(a[1] - a[2]) < 0.1, (a[0], a[1] - a[2])         # 0.049 m observed, of which 0.036 m is the initial guess
+    assert travelled > 0.4
+    flags = [a[3] for a in got]
+    assert 0 in flags and 1 in flags                                          # both marginalization branches were taken
+    return dict(tracks=len(e), median_px=float(np.median(n)), gain=gain, worst_vs_ideal=max(float(np.linalg.norm(a[1] - b[1])) for a, b in zip(got, ref)),
+                worst_vs_truth=max(float(np.linalg.norm(a[1] - a[2])) for a in got), travelled=travelled)
