@@ -1,6 +1,6 @@
 """End to end through both hot paths on rendered frames, kernels under the CPU emulator (tests/e2e_vio.py): scene -> `vins_replay fe`
 (FeatureTracker::readImage on the emulated library) -> device-resident estimator window (vg_ba_seq_*) -> trajectory against the
-ground truth.  The GPU twin is tests/test_zz_e2e_gpu.py."""
+ground truth.  The GPU twin is tests/test_zz_late_gpu.py."""
 import os
 
 import conftest

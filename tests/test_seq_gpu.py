@@ -166,10 +166,3 @@ def test_cpp_hand_back_and_take_over_again(tmp_path):
         worst = max(worst, max(abs(float(x) - float(y)) for x, y in zip(la[2:12], lb[2:12])))
     assert worst < 2e-4, worst       # (free-running chains after the hand-back: rotation matrices <-> quaternions perturb the last bits)
     print("hand-back in the middle of the run: worst difference to the uninterrupted run", worst)
-
-
-def test_a_failed_window_is_isolated_and_can_be_re_seeded(two_handles):
-    """A window whose solve goes non-finite (a NaN in the new frame's state guess) reports VG_ERR_NUMERIC, leaves the other windows of
-    the batch untouched, and is brought back with vg_ba_seq_import: re-seeded with an exported copy of its neighbour and fed the
-    neighbour's frames, it reproduces the neighbour bit for bit."""
-    M.run_failure_isolation(two_handles[0])
