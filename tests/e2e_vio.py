@@ -213,6 +213,51 @@ def ideal_images(scene, images):
     return out
 
 
+def run_vio_replay(exe, scene, frames, tmp, K=11, min_parallax=10.0 / 460.0, init_depth=5.0):
+    """`vins_replay vio`: the C++ FeatureTracker and ResidentEstimators drop-ins in ONE process, wired like the two nodes (replay_main.cpp).
+    window.bin = the VSQ1 file of `vins_replay seq` for one estimator with no tracks: the state guesses of run_estimator, the IMU
+    samples.  Returns per solved frame (frame index, position of the newest frame, key-frame flag, tracks left, status)."""
+    seq, c = scene.seq, scene.seq.cfg
+    src = synth.FrameSource(seq, noise_seed=5)
+    pose, sb = zip(*[src.guess(i) for i in range(K - 1)])
+    pose, sb = list(pose) + [pose[-1]], list(sb) + [sb[-1]]
+    n_frames, S = len(frames) - (K - 1), seq.imu_per_frame
+    with open(os.path.join(tmp, "frames.bin"), "wb") as f:
+        f.write(struct.pack("<4i", len(frames), frames[0].shape[1], frames[0].shape[0], 1))
+        for fr in frames:
+            f.write(np.ascontiguousarray(fr).tobytes())
+    with open(os.path.join(tmp, "window.bin"), "wb") as f:
+        f.write(struct.pack("<5i", 0x31515356, 1, n_frames, K, S))
+        f.write(np.array([c['acc_n'], c['gyr_n'], c['acc_w'], c['gyr_w']], float).tobytes())
+        f.write(np.array([c['g_norm'], c['focal'], min_parallax, init_depth], float).tobytes())
+        f.write(np.asarray(seq._base()['ex'], float).tobytes())
+        f.write(np.concatenate([seq.ba_lin, seq.bg_lin]).tobytes())
+        for k in range(K):
+            f.write(np.array([seq.times[min(k, K - 2)]], float).tobytes())
+            f.write(np.asarray(pose[k], float).tobytes()); f.write(np.asarray(sb[k], float).tobytes())
+        smp = [src.samples(k) for k in range(K - 2)]
+        for s_ in smp:
+            f.write(np.concatenate([s_[0][1], s_[0][2]]).astype(float).tobytes())
+            for dt, a, g in s_[1:]:
+                f.write(np.concatenate([[dt], a, g]).astype(float).tobytes())
+        f.write(np.concatenate([smp[-1][-1][1], smp[-1][-1][2]]).astype(float).tobytes())
+        f.write(struct.pack("<i", 0))                                         # no tracks: they come from the front end
+        for w in range(n_frames):
+            g = K - 1 + w
+            f.write(np.array([seq.times[g]], float).tobytes())
+            for dt, a, gy in src.samples(g - 1)[1:]:
+                f.write(np.concatenate([[dt], a, gy]).astype(float).tobytes())
+            f.write(struct.pack("<i", 0))
+    r = subprocess.run([exe, "vio", os.path.join(tmp, "window.bin"), os.path.join(tmp, "frames.bin"), os.path.join(tmp, "vio.csv")],
+                       capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = []
+    for w, line in enumerate(open(os.path.join(tmp, "vio.csv"))):
+        t = line.strip().split(",")
+        out.append((K - 1 + w, np.array([float(v) for v in t[2:5]]), int(t[12]), int(t[13]), int(t[14]), int(t[15])))
+    return out
+
+
 def tracking_error(scene, images):
     """One-frame tracking error of the published points against the scene's geometry, in pixels: (errors [n, 2], true flows [n, 2],
     published velocities [n, 2], true velocities [n, 2]) over all tracks and consecutive frame pairs."""
@@ -259,5 +304,15 @@ def check_end_to_end(h, exe, tmp, n_frames=20, seed=3):
     assert travelled > 0.4
     flags = [a[3] for a in got]
     assert 0 in flags and 1 in flags                                          # both marginalization branches were taken
+    # 3. the same in ONE C++ process: FeatureTracker::readImage -> `image` map -> ResidentEstimators::processImage / solve
+    cpp = run_vio_replay(exe, scene, frames, tmp)
+    assert len(cpp) == len(got)
+    for a, b in zip(got, cpp):
+        assert b[4] == 0 and b[5] == 0, b                                     # status, failure_occur
+        assert a[3] == b[2], (a[0], a[3], b[2])                               # key-frame decisions
+        # two free-running chains whose inputs differ in the last bits (propagation and pre-integration in C++ vs NumPy): the
+        # allowance of the other replay tests (tests/test_seq_gpu.py)
+        assert np.linalg.norm(a[1] - b[1]) < 2e-3, (a[0], a[1] - b[1])
     return dict(tracks=len(e), median_px=float(np.median(n)), gain=gain, worst_vs_ideal=max(float(np.linalg.norm(a[1] - b[1])) for a, b in zip(got, ref)),
-                worst_vs_truth=max(float(np.linalg.norm(a[1] - a[2])) for a in got), travelled=travelled)
+                worst_vs_truth=max(float(np.linalg.norm(a[1] - a[2])) for a in got), travelled=travelled,
+                cpp_vs_python=max(float(np.linalg.norm(a[1] - b[1])) for a, b in zip(got, cpp)))

@@ -18,6 +18,13 @@
 //     window as it stands between two frames (states, the IMU samples of its intervals, every track) and then W frames at the level
 //     of the node's callbacks: the IMU samples since the last frame (processIMU) and the `image` map (processImage).  One line per
 //     frame and estimator: index, stamp[ns], P, Q(w x y z), V of frame WINDOW_SIZE as solved, the key-frame decision, tracks left.
+//
+//   vins_replay vio <window.bin> <frames.bin> <out.csv>
+//     Both drop-ins in one process, wired the way the two nodes are (feature_tracker_node.cpp:86-160 publishes id / undistorted
+//     point / pixel / velocity of every feature with track_cnt > 1; estimator_node.cpp:286-306 turns that message into the `image`
+//     map of processImage): `seq` for one estimator whose tracks are NOT in the file (window.bin holds states and IMU samples only,
+//     L = 0 and n = 0) but come from FeatureTracker::readImage over frames.bin -- the first WINDOW_SIZE frames fill the window that
+//     is handed over, every further frame is one processImage + solve.  tests/e2e_vio.py renders the frames.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -174,9 +181,49 @@ static int replay_ba(const char* in, const char* out) {
     return 0;
 }
 
-static int replay_seq(const char* in, const char* out) {
+namespace {
+// the front end of `vio`: one frame through readImage + updateID, returned as the `image` map (features seen at least twice)
+struct FrontEnd {
+    FILE* f = nullptr;
+    int n = 0, w = 0, h = 0, k = 0;
+    std::vector<unsigned char> buf;
+    std::unique_ptr<FeatureTracker> tracker;
+    bool open(const char* path) {
+        f = fopen(path, "rb");
+        int hdr[4];
+        if (!f || fread(hdr, sizeof(int), 4, f) != 4) return false;
+        n = hdr[0]; w = hdr[1]; h = hdr[2];
+        COL = w; ROW = h;
+        buf.resize((size_t)w * h);
+        tracker.reset(new FeatureTracker());
+        return true;
+    }
+    ResidentEstimators::Image next() {
+        if (k >= n || fread(buf.data(), 1, buf.size(), f) != buf.size()) throw std::runtime_error("frames file exhausted");
+        PUB_THIS_FRAME = true;
+        cv::Mat img(h, w, cv::CV_8UC1, buf.data(), (size_t)w);
+        tracker->readImage(img, 0.05 * k++);
+        for (unsigned int i = 0;; i++) if (!tracker->updateID(i)) break;
+        ResidentEstimators::Image image;
+        for (size_t i = 0; i < tracker->cur_pts.size(); ++i) {
+            if (tracker->track_cnt[i] <= 1) continue;
+            Eigen::Matrix<double, 7, 1> p;
+            p(0, 0) = tracker->cur_un_pts[i].x; p(1, 0) = tracker->cur_un_pts[i].y; p(2, 0) = 1.0;
+            p(3, 0) = tracker->cur_pts[i].x; p(4, 0) = tracker->cur_pts[i].y;
+            p(5, 0) = tracker->pts_velocity[i].x; p(6, 0) = tracker->pts_velocity[i].y;
+            image[tracker->ids[i]].emplace_back(0, p);
+        }
+        return image;
+    }
+    ~FrontEnd() { if (f) fclose(f); }
+};
+}  // namespace
+
+static int replay_seq(const char* in, const char* out, const char* frames = nullptr) {
     Reader rd{fopen(in, "rb")};
     if (!rd.f) { perror("frames"); return 2; }
+    FrontEnd fe;
+    if (frames && !fe.open(frames)) { perror("images"); return 2; }
     int hdr[5];
     rd.i(hdr, 5);
     if (hdr[0] != 0x31515356) { fprintf(stderr, "not a VSQ1 file\n"); return 2; }
@@ -225,6 +272,29 @@ static int replay_seq(const char* in, const char* out) {
             }
             est.f_manager.feature.push_back(f);
         }
+        if (frames) {
+            // the window's tracks from the front end: frame k of the window = image k (what addFeatureCheckParallax would have
+            // collected, feature_manager.cpp:45-73, before the first solve of this replay)
+            if (N != 1 || L != 0) { fprintf(stderr, "vio: window.bin must hold one estimator without tracks\n"); return 2; }
+            std::map<int, FeaturePerId*> at;            // list nodes stay where they are
+            for (int k = 0; k < WINDOW_SIZE; ++k) {
+                const ResidentEstimators::Image image = fe.next();
+                for (const auto& id_pts : image) {
+                    auto it = at.find(id_pts.first);
+                    if (it == at.end()) {
+                        FeaturePerId f;
+                        f.feature_id = id_pts.first; f.start_frame = k; f.estimated_depth = -1.0;
+                        est.f_manager.feature.push_back(f);
+                        it = at.emplace(id_pts.first, &est.f_manager.feature.back()).first;
+                    }
+                    const Eigen::Matrix<double, 7, 1>& r = id_pts.second[0].second;
+                    FeaturePerFrame fr;
+                    fr.point = Vector3d(r(0, 0), r(1, 0), r(2, 0)); fr.uv.x() = r(3, 0); fr.uv.y() = r(4, 0);
+                    fr.velocity.x() = r(5, 0); fr.velocity.y() = r(6, 0); fr.cur_td = 0.0;
+                    it->second->feature_per_frame.push_back(fr);
+                }
+            }
+        }
         resp->handOver(i, est, Vector3d(last[0], last[1], last[2]), Vector3d(last[3], last[4], last[5]));
         for (int k = 0; k <= WINDOW_SIZE; ++k) { delete est.pre_integrations[k]; est.pre_integrations[k] = nullptr; }
     }
@@ -249,6 +319,7 @@ static int replay_seq(const char* in, const char* out) {
                 for (int c = 0; c < 7; ++c) p(c, 0) = r[c];
                 image[id].emplace_back(0, p);
             }
+            if (frames) image = fe.next();
             resp->processImage(i, image);
         }
         resp->solve();
@@ -291,6 +362,10 @@ int main(int argc, char** argv) {
         try { return replay_seq(argv[2], argv[3]); }
         catch (const std::exception& e) { fprintf(stderr, "vins_replay seq: %s\n", e.what()); return 1; }
     }
-    fprintf(stderr, "usage: vins_replay fe <frames.bin> <out.txt> | vins_replay ba <sequence.bin> <out.csv> | vins_replay seq <frames.bin> <out.csv>\n");
+    if (argc >= 5 && !strcmp(argv[1], "vio")) {
+        try { return replay_seq(argv[2], argv[4], argv[3]); }
+        catch (const std::exception& e) { fprintf(stderr, "vins_replay vio: %s\n", e.what()); return 1; }
+    }
+    fprintf(stderr, "usage: vins_replay fe <frames.bin> <out.txt> | vins_replay ba <sequence.bin> <out.csv> | vins_replay seq <frames.bin> <out.csv> | vins_replay vio <window.bin> <frames.bin> <out.csv>\n");
     return 2;
 }
