@@ -41,9 +41,9 @@ def test_emulated_kernels_under_address_sanitizer():
     assert r.returncode == 0 and " passed" in r.stdout, tail
 
 
-def test_cpp_host_side_under_address_and_leak_sanitizer(tmp_path):
+def test_cpp_host_side_under_address_and_leak_sanitizer(tmp_path, monkeypatch):
     """The C++ host side (Estimator / FeatureTracker shims, ResidentEstimators incl. handBack / reseed, the replay harness) built with
-    -fsanitize=address against the sanitized emulated library: `vins_replay seq` (plain and with a hand-back), `ba` and `fe`, with the
+    -fsanitize=address against the sanitized emulated library: `vins_replay seq` (plain and with a hand-back), `ba`, `fe` and `vio`, with the
     leak checker on."""
     import struct
     import numpy as np
@@ -73,3 +73,9 @@ def test_cpp_host_side_under_address_and_leak_sanitizer(tmp_path):
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:detect_stack_use_after_return=0", **extra)
         r = subprocess.run([exe, args[0], str(tmp_path / args[1]), str(tmp_path / "out.txt")], capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0 and "Sanitizer" not in r.stderr, (args, extra, r.stderr[-3000:])
+    # `vio`: both drop-ins in one process on rendered frames (tests/e2e_vio.py), the window's ten frames + two solved ones
+    import e2e_vio
+    scene = e2e_vio.Scene(3, 12)
+    monkeypatch.setenv("ASAN_OPTIONS", "detect_leaks=1:detect_stack_use_after_return=0")
+    out = e2e_vio.run_vio_replay(exe, scene, [scene.render(f) for f in range(12)], str(tmp_path))
+    assert len(out) == 2 and all(o[4] == 0 for o in out), out
