@@ -23,6 +23,16 @@ def test_resident_sequence_equals_host_bookkeeping(two_handles, min_parallax, wa
     assert (M.NEW in flat) == want_new
 
 
+@pytest.mark.parametrize("K", [4, 5, 12])
+def test_resident_sequence_at_other_window_sizes(two_handles, K):
+    """The smallest window the sequence kernels take (K = 4: WINDOW_SIZE 3, only tracks anchored at frame 0 are in the problem), an
+    odd one, and the largest (K = 12); both slides at each."""
+    h_seq, h_ref = two_handles
+    flags = M.run_both(h_seq, h_ref, seeds=[21], K=K, L=70, n_steps=4, min_parallax=0.25, max_features=128, check=M.check_step)
+    flat = [f for fr in flags for f in fr]
+    assert M.NEW in flat and M.OLD in flat
+
+
 @pytest.mark.parametrize("order", ["reverse", "shuffle"])
 def test_resident_sequence_under_other_fiber_orders(two_handles, monkeypatch, order):
     """The emulator has no wavefront lock-step: a missing barrier in the sequence kernels (ordered compactions, table builds that

@@ -37,3 +37,17 @@ def test_a_failed_window_is_isolated_and_can_be_re_seeded():
         M.run_failure_isolation(h)
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("K", [4, 12])
+def test_resident_sequence_at_other_window_sizes(K):
+    """The smallest and the largest window the sequence kernels take, against the host bookkeeping (tests/test_seq_simt.py)."""
+    if os.environ.get("VINS_TEST_SIMT") == "1":
+        pytest.skip("the emulated variant is tests/test_seq_simt.py")
+    a, b = conftest.new_handle(), conftest.new_handle()
+    try:
+        flags = M.run_both(a, b, seeds=[21], K=K, L=70, n_steps=4, min_parallax=0.25, max_features=128, check=M.check_step)
+    finally:
+        a.close(); b.close()
+    flat = [f for fr in flags for f in fr]
+    assert M.NEW in flat and M.OLD in flat
