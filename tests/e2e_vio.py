@@ -252,8 +252,9 @@ def run_vio_replay(exe, scene, frames, tmp, K=11, min_parallax=10.0 / 460.0, ini
                        capture_output=True, text=True, timeout=3000)
     assert r.returncode == 0, r.stderr[-2000:]
     out = []
-    for w, line in enumerate(open(os.path.join(tmp, "vio.csv"))):
-        t = line.strip().split(",")
+    rows = [line.strip().split(",") for line in open(os.path.join(tmp, "vio.csv"))]
+    run_vio_replay.timing = np.array([[float(t[2]), float(t[3])] for t in rows if t[0] == "t"])      # per frame: readImage ms, solve ms
+    for w, t in enumerate(t for t in rows if t[0] != "t"):
         out.append((K - 1 + w, np.array([float(v) for v in t[2:5]]), int(t[12]), int(t[13]), int(t[14]), int(t[15])))
     return out
 

@@ -25,6 +25,7 @@
 //     map of processImage): `seq` for one estimator whose tracks are NOT in the file (window.bin holds states and IMU samples only,
 //     L = 0 and n = 0) but come from FeatureTracker::readImage over frames.bin -- the first WINDOW_SIZE frames fill the window that
 //     is handed over, every further frame is one processImage + solve.  tests/e2e_vio.py renders the frames.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -301,6 +302,7 @@ static int replay_seq(const char* in, const char* out, const char* frames = null
     resp->begin();
     FILE* o = fopen(out, "w");
     std::vector<double> smp((size_t)S * 7);
+    double fe_ms = 0;
     for (int w = 0; w < W; ++w) {
         std::vector<double> stamp(N);
         for (int i = 0; i < N; ++i) {
@@ -319,10 +321,16 @@ static int replay_seq(const char* in, const char* out, const char* frames = null
                 for (int c = 0; c < 7; ++c) p(c, 0) = r[c];
                 image[id].emplace_back(0, p);
             }
-            if (frames) image = fe.next();
+            if (frames) {
+                const auto t0 = std::chrono::steady_clock::now();
+                image = fe.next();
+                fe_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
             resp->processImage(i, image);
         }
+        const auto t_solve = std::chrono::steady_clock::now();
         resp->solve();
+        const double solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_solve).count();
         for (int i = 0; i < N; ++i) {
             // (the mirror is post-slide: the frame just solved sits in slot WINDOW_SIZE either way)
             const ResidentEstimators::One& e = (*resp)[i];
@@ -330,6 +338,7 @@ static int replay_seq(const char* in, const char* out, const char* frames = null
             fprintf(o, "%d,%.0f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%d,%d,%d,%d\n", i, stamp[i] * 1e9, e.Ps[WINDOW_SIZE].x(), e.Ps[WINDOW_SIZE].y(),
                     e.Ps[WINDOW_SIZE].z(), q.w(), q.x(), q.y(), q.z(), e.Vs[WINDOW_SIZE].x(), e.Vs[WINDOW_SIZE].y(), e.Vs[WINDOW_SIZE].z(),
                     (int)e.marginalization_flag, e.n_features, e.status, e.failure_occur ? 1 : 0);
+            if (frames) fprintf(o, "t,%d,%.3f,%.3f\n", i, fe_ms, solve_ms);      // vio: wall time of readImage / of processImage's solve, ms
         }
         if (w == handback_frame) {
             std::unique_ptr<ResidentEstimators> next(new ResidentEstimators(N, 512, 512));
