@@ -16,3 +16,14 @@ def test_rendered_frames_through_front_end_and_estimator(tmp_path):
     finally:
         h.close()
     print(r)
+
+
+def test_tracks_on_a_moving_object_do_not_pull_the_estimate(tmp_path):
+    conftest._build_simt()
+    exe = os.path.join(conftest.SIMT_DIR, "_build", "vins_replay_simt")
+    h = conftest._simt_handle()
+    try:
+        r = e2e_vio.check_moving_object(h, exe, str(tmp_path))
+    finally:
+        h.close()
+    print(r)

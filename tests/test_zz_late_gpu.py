@@ -51,3 +51,15 @@ def test_resident_sequence_at_other_window_sizes(K):
         a.close(); b.close()
     flat = [f for fr in flags for f in fr]
     assert M.NEW in flat and M.OLD in flat
+
+
+def test_tracks_on_a_moving_object_do_not_pull_the_estimate(tmp_path):
+    if os.environ.get("VINS_TEST_SIMT") == "1":
+        pytest.skip("the emulated variant is tests/test_e2e_simt.py")
+    exe = os.path.join(conftest.ROOT, "vins-mono_amd", "lib", "vins_replay")
+    h = conftest.new_handle()
+    try:
+        r = e2e_vio.check_moving_object(h, exe, str(tmp_path))
+    finally:
+        h.close()
+    print(r)
