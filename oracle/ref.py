@@ -508,14 +508,17 @@ def factor_tables(prob):
     return pr, pJ, ir, iJ
 
 
-def run_sequence(seq, n_frames, L=None, min_parallax=10.0 / 460.0, noise_seed=0):
+def run_sequence(seq, n_frames, L=None, min_parallax=10.0 / 460.0, noise_seed=0, reset_at=None, collect_priors=True):
     """The reference's own per-frame loop on a synthetic sequence: Estimator::processIMU for every IMU sample and
     Estimator::processImage for every frame (estimator.cpp:81-215) — feature bookkeeping, key-frame decision by parallax,
     triangulation, optimization(), failure detection, slideWindow() for BOTH marginalization flags with the IMU buffers merged
     (:1069-1099), removeFailures.  The SfM bootstrap (initial/*) is bypassed: the first WINDOW_SIZE frames are collected in
     INITIAL mode exactly as the reference does, then the window is given noisy ground-truth states and switched to
     NON_LINEAR (what initialStructure() + visualInitialAlign() hand over).
-    L: lib() (all reference) or lib_gpu() (optimization() = the product's drop-in).  Returns a list of per-frame records."""
+    L: lib() (all reference) or lib_gpu() (optimization() = the product's drop-in).  Returns a list of per-frame records.
+    reset_at: a frame index before which the estimator is reset (clearState + setParameter) and bootstrapped again.
+    collect_priors=False leaves the drop-in's marginalization result on the device between frames (its normal operation;
+    get_prior() fetches it early)."""
     L = L or lib()
     K = K_REF
     c = seq.cfg
@@ -553,36 +556,50 @@ def run_sequence(seq, n_frames, L=None, min_parallax=10.0 / 460.0, noise_seed=0)
         rows = _d(rows)
         L.vref_est_process_image(H, C.c_double(float(seq.times[f])), len(ids), ids.ctypes.data_as(IP), _p(rows))
 
-    out = []
-    try:
+    def bootstrap(f0):
+        """frames f0 .. f0 + WINDOW_SIZE - 1 in INITIAL mode (they are only counted in), then noisy ground-truth states"""
         L.vref_est_set_extrinsic(H, _p(_d(_q2R(base['ex'][3:]))), _p(_d(base['ex'][:3])), C.c_double(0.0))
         L.vref_est_set_g(H, _p(_d([0.0, 0.0, c['g_norm']])))
         zero = np.zeros(3)
         for i in range(K):                             # linearisation biases of the pre-integrations created in INITIAL mode
             L.vref_est_set_frame(H, i, _p(zero), _p(_d(np.eye(3))), _p(zero), _p(_d(seq.ba_lin)), _p(_d(seq.bg_lin)))
-        a0, g0 = seq._imu_sample(seq.times[0])
+        a0, g0 = seq._imu_sample(seq.times[f0])
         L.vref_est_process_imu(H, C.c_double(0.0), _p(_d(a0)), _p(_d(g0)))     # first_imu: acc_0 / gyr_0
-        for f in range(K - 1):                         # frames 0 .. WINDOW_SIZE-1: INITIAL mode only counts them in
-            if f > 0:
+        for f in range(f0, f0 + K - 1):                # frames 0 .. WINDOW_SIZE-1: INITIAL mode only counts them in
+            if f > f0:
                 feed_imu(f - 1)
             image(f)
         assert L.vref_est_get_frame_count(H) == K - 1 and L.vref_est_get_solver_flag(H) == 0
         for i in range(K - 1):
-            pose, sb = noisy_state(i)
+            pose, sb = noisy_state(f0 + i)
             e.set_frame(i, pose, sb)
-        pose, sb = noisy_state(K - 2)                  # slot WINDOW_SIZE starts from the previous frame and is propagated by processIMU
+        pose, sb = noisy_state(f0 + K - 2)             # slot WINDOW_SIZE starts from the previous frame and is propagated by processIMU
         e.set_frame(K - 1, pose, sb)
         L.vref_est_set_solver_flag(H, 1)
         L.vref_est_set_last_from_window(H)
-        for f in range(K - 1, n_frames):
+
+    out = []
+    try:
+        bootstrap(0)
+        f = K - 1
+        while f < n_frames:
+            if reset_at is not None and f == reset_at:
+                # restart_callback (estimator_node.cpp:182-198) between two frames: clearState() + setParameter(), then the
+                # estimator collects a fresh window -- whatever the previous optimization() left behind must not reach it
+                L.vref_est_clear_state(H)
+                bootstrap(f)
+                f += K - 1
+                reset_at = None
+                continue
             feed_imu(f - 1)
             image(f)
             pose, sb, ex, td = e.para()
             feats = e.features()
             out.append(dict(frame=f, flag=int(L.vref_est_get_marginalization_flag(H)), pose=pose.copy(), sb=sb.copy(), ex=ex.copy(), td=td,
                             n_features=len(feats['id']), depth=dict(zip(feats['id'].tolist(), feats['depth'].tolist())),
-                            solver_flag=int(L.vref_est_get_solver_flag(H)), prior=e.get_prior(), iterations=int(L.vref_est_last_iterations(H)),
+                            solver_flag=int(L.vref_est_get_solver_flag(H)), prior=e.get_prior() if collect_priors else False, iterations=int(L.vref_est_last_iterations(H)),
                             trace=e.last_trace()))
+            f += 1
     finally:
         e.close()
     return out

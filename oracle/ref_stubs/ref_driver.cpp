@@ -202,6 +202,12 @@ void vref_est_destroy(void *p) {
     e->~Estimator();
     std::free(p);
 }
+// what restart_callback does (estimator_node.cpp:182-198): clearState() + setParameter()
+void vref_est_clear_state(void *p) {
+    Estimator *e = as_est(p);
+    e->clearState();
+    e->setParameter();
+}
 void vref_est_process_imu(void *p, double dt, const double *acc, const double *gyr) { as_est(p)->processIMU(dt, vec3(acc), vec3(gyr)); }
 // rows of 7: x y z(=1) u v vx vy  (feature_tracker_node.cpp:125-147 -> estimator_node.cpp:262-286)
 void vref_est_process_image(void *p, double stamp, int n, const int *ids, const double *rows7) {

@@ -37,6 +37,11 @@ struct VgSide {
     vg_handle* vg = nullptr;
     bool prior_pending = false;   // optimization() has returned, its marginalization result is still on the device
     bool solver_failed = false;   // the device reported a non-finite solve
+    // What the window looked like when the result was left on the device: the pending prior belongs to the window that
+    // CONTINUES that one.  Both slides leave the newest frame of then at index WINDOW_SIZE - 1 (estimator.cpp:1037-1041,
+    // :1078-1079), and optimization() itself is the only writer of last_marginalization_info besides clearState() (:70-76).
+    double pending_stamp = 0;                               // Headers[WINDOW_SIZE].stamp at that time
+    const MarginalizationInfo* pending_lmi = nullptr;       // last_marginalization_info at that time (not yet replaced)
     vg_ba_summary last;           // trace of the last solve (the reference only logs Summary::BriefReport)
 };
 std::mutex g_mu;
@@ -61,6 +66,15 @@ bool block_of(Estimator& e, const double* addr, int& kind, int& index) {
 void collect_prior(Estimator& e, VgSide& s) {
     if (!s.prior_pending) return;
     s.prior_pending = false;
+    // (before the caller's slideWindow() the frame is still at WINDOW_SIZE; afterwards both slides leave it at WINDOW_SIZE - 1)
+    const bool continues = e.Headers[WINDOW_SIZE - 1].stamp.toSec() == s.pending_stamp || e.Headers[WINDOW_SIZE].stamp.toSec() == s.pending_stamp;
+    if (e.last_marginalization_info != s.pending_lmi || !continues) {
+        // clearState() ran in between (failureDetection() in processImage, estimator.cpp:190-200, or the restart callback,
+        // estimator_node.cpp:182-198): it freed last_marginalization_info and the window now on the host is a fresh one.  The
+        // result on the device describes the trajectory before the reset -- the reference has no prior here, so neither do we.
+        // (Nothing to fetch: the next upload is ordered behind the marginalization kernel on the handle's stream.)
+        return;
+    }
     const int K = WINDOW_SIZE + 1;
     const int cap = 6 * K + 32, capb = K + 8;
     std::vector<int> nkind(capb), nindex(capb);
@@ -238,6 +252,8 @@ void Estimator::optimization() {
     double2vector();                                            // :823 (the reference's)
     s.solver_failed = rc == VG_ERR_NUMERIC;
     s.prior_pending = true;
+    s.pending_stamp = Headers[WINDOW_SIZE].stamp.toSec();
+    s.pending_lmi = last_marginalization_info;
     if (s.solver_failed) collect_prior(*this, s);              // (drops the priors, see there)
 }
 
@@ -245,6 +261,11 @@ void Estimator::optimization() {
 extern "C" {
 // fetch the marginalization result of the last optimization() now (tests, serialisation of last_marginalization_info)
 void vins_gpu_collect_prior(Estimator* e) { collect_prior(*e, side_of(e)); }
+// forget a pending marginalization result: for callers that reset the estimator by other means than clearState()
+void vins_gpu_reset(Estimator* e) {
+    VgSide& s = side_of(e);
+    s.prior_pending = false; s.solver_failed = false;
+}
 // trace of the last solve
 const vg_ba_summary* vins_gpu_last_summary(Estimator* e) { return &side_of(e).last; }
 int vins_gpu_last_iterations(Estimator* e) { return side_of(e).last.num_iterations; }

@@ -1,0 +1,259 @@
+// feature_tracker_readimage.cpp — THE drop-in for the front end: four member functions of the REFERENCE'S `class FeatureTracker`
+// (feature_tracker/src/feature_tracker.h:28-65), on the MI355X path:
+//     void FeatureTracker::readImage(const cv::Mat&, double)    feature_tracker.cpp:81-167
+//     void FeatureTracker::setMask()                            feature_tracker.cpp:36-69
+//     void FeatureTracker::rejectWithF()                        feature_tracker.cpp:169-202
+//     void FeatureTracker::undistortedPoints()                  feature_tracker.cpp:258-306
+//
+// How it is used.  This file includes the reference's own "feature_tracker.h" — `camodocal::CameraPtr m_camera`, the cv::Mat
+// members, `showUndistortion`, the globals of parameters.h all stay what they are — and defines exactly those four members.  In a
+// catkin workspace: add this file and include/vinsgpu.h to feature_tracker, link libvinsgpu.so, and remove the four definitions
+// from feature_tracker.cpp (or weaken them:  objcopy --weaken-symbol=_ZN14FeatureTracker9readImageERKN2cv3MatEd
+// --weaken-symbol=_ZN14FeatureTracker7setMaskEv --weaken-symbol=_ZN14FeatureTracker11rejectWithFEv
+// --weaken-symbol=_ZN14FeatureTracker17undistortedPointsEv).  feature_tracker_node.cpp, parameters.cpp, addPoints / updateID /
+// readIntrinsicParameter / showUndistortion / inBorder / reduceVector and all of camera_model stay the reference's.  Here (no
+// OpenCV / ROS in the image) oracle/Makefile target `ref_fe` does precisely that against the header stand-ins of
+// oracle/ref_stubs_fe and produces oracle/_ref/libvins_ref_fe_gpu.so; tests/test_fe_dropin_*.py drive the reference's
+// img_callback() through it and through the all-reference build side by side.
+//
+// What the bodies do instead of the reference's:
+//   :87-93   cv::createCLAHE(3.0, Size(8,8))->apply          -> vg_fe_push_frames(.., EQUALIZE): upload + CLAHE + pyramid on the device
+//   :113     cv::calcOpticalFlowPyrLK(cur_img, forw_img, ..)  -> vg_fe_track (the pyramid of cur_img is still on the device)
+//   :149     cv::goodFeaturesToTrack(forw_img, .., mask)      -> vg_fe_detect_masked (the mask setMask() built stays on the device)
+//   :191     cv::findFundamentalMat(.., FM_RANSAC, ..)        -> vg_fe_reject_with_f
+//   :48-68   std::sort by track_cnt + mask walk + cv::circle  -> the SAME std::sort call on the host (the order among equal counts is
+//                                                                whatever the platform's std::sort gives: the reference's too), then
+//                                                                vg_fe_set_mask walks that order on the device
+//   :262-267 m_camera->liftProjective per point               -> vg_fe_undistort for a camodocal::PinholeCamera (the EuRoC / default
+//                                                                model); any other camera model lifts through m_camera on the host
+// Differences a caller can see: `forw_img` / `cur_img` / `prev_img` refer to the image as it came in (the equalized image lives on
+// the device: vg_fe_get_level(.., 0, ..) returns it) and `mask` is left empty (vg_fe_get_mask).  The node reads neither.
+// State the reference class has no member for (the device handle) lives in a side table keyed by `this`.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "feature_tracker.h"
+#include "vinsgpu.h"
+
+namespace {
+
+struct FeSide {
+    vg_handle* vg = nullptr;
+    int capacity = 0, width = 0, height = 0;
+    bool pinhole = false;          // m_camera is a camodocal::PinholeCamera: lifting runs on the device
+    double intr[8];                // fx fy cx cy k1 k2 p1 p2
+    const void* camera = nullptr;  // the camera object `intr` was read from
+};
+std::mutex g_mu;
+std::unordered_map<const FeatureTracker*, FeSide> g_side;
+FeSide& side_of(const FeatureTracker* t) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    return g_side[t];
+}
+void chk(int rc, vg_handle* h, const char* what) {
+    if (rc != VG_OK) throw std::runtime_error(std::string(what) + ": " + (h ? vg_last_error(h) : "no handle") + " (no CPU fallback)");
+}
+// the device side of one tracker: created at the first call, re-configured when the image size or MAX_CNT changes
+FeSide& ensure(FeatureTracker* t, int w, int h) {
+    FeSide& s = side_of(t);
+    if (vg_abi_version() != VG_ABI_VERSION) throw std::runtime_error("libvinsgpu.so was built from another include/vinsgpu.h (ABI version mismatch)");
+    if (!s.vg) chk(vg_create(&s.vg), s.vg, "vg_create");
+    const int cap = std::max(MAX_CNT, 1) * 4;
+    if (s.capacity < cap || s.width != w || s.height != h) {
+        chk(vg_fe_configure(s.vg, w, h, 1, cap), s.vg, "vg_fe_configure");
+        s.capacity = cap; s.width = w; s.height = h;
+    }
+    if (s.camera != t->m_camera.get()) {
+        s.camera = t->m_camera.get();
+        camodocal::PinholeCameraPtr pin = boost::dynamic_pointer_cast<camodocal::PinholeCamera>(t->m_camera);
+        s.pinhole = static_cast<bool>(pin);
+        if (pin) {
+            const camodocal::PinholeCamera::Parameters& p = pin->getParameters();
+            const double v[8] = {p.fx(), p.fy(), p.cx(), p.cy(), p.k1(), p.k2(), p.p1(), p.p2()};
+            std::memcpy(s.intr, v, sizeof(v));
+        }
+    }
+    return s;
+}
+
+}  // namespace
+
+void FeatureTracker::setMask() {                                      // feature_tracker.cpp:36-69
+    FeSide& s = ensure(this, COL, ROW);
+    // prefer to keep features that are tracked for long time (:43-51): the reference's own sort, verbatim semantics
+    vector<pair<int, pair<cv::Point2f, int>>> cnt_pts_id;
+    for (unsigned int i = 0; i < forw_pts.size(); i++) cnt_pts_id.push_back(make_pair(track_cnt[i], make_pair(forw_pts[i], ids[i])));
+    sort(cnt_pts_id.begin(), cnt_pts_id.end(),
+         [](const pair<int, pair<cv::Point2f, int>>& a, const pair<int, pair<cv::Point2f, int>>& b) { return a.first > b.first; });
+    const int n = (int)cnt_pts_id.size();
+    if (n > s.capacity) throw std::runtime_error("FeatureTracker::setMask: more points than the configured capacity");
+    std::vector<float> xy((size_t)s.capacity * 2, 0.f);
+    std::vector<int> cnt((size_t)s.capacity, 0), kept((size_t)s.capacity, 0);
+    for (int i = 0; i < n; ++i) { xy[2 * i] = cnt_pts_id[i].second.first.x; xy[2 * i + 1] = cnt_pts_id[i].second.first.y; cnt[i] = cnt_pts_id[i].first; }
+    // :38-41: the fisheye mask or all-255 is the canvas; the walk in sorted order (the device's own sort by count is stable, i.e. the
+    // identity on an already sorted list) keeps a point iff the canvas is still 255 under it and blanks a disc of MIN_DIST around it
+    std::vector<uint8_t> base;
+    const uint8_t* basep[1] = {nullptr};
+    if (FISHEYE) {
+        if (fisheye_mask.rows != ROW || fisheye_mask.cols != COL) throw std::runtime_error("FeatureTracker::setMask: fisheye_mask is not ROW x COL");
+        base.resize((size_t)ROW * COL);
+        for (int y = 0; y < ROW; ++y) std::memcpy(base.data() + (size_t)y * COL, fisheye_mask.data + (size_t)y * fisheye_mask.step, (size_t)COL);
+        basep[0] = base.data();
+    }
+    int nk = 0;
+    chk(vg_fe_set_mask(s.vg, xy.data(), cnt.data(), &n, basep, MIN_DIST, kept.data(), &nk), s.vg, "vg_fe_set_mask");
+    forw_pts.clear();
+    ids.clear();
+    track_cnt.clear();
+    for (int k = 0; k < nk; ++k) {
+        const auto& it = cnt_pts_id[kept[k]];
+        forw_pts.push_back(it.second.first);
+        ids.push_back(it.second.second);
+        track_cnt.push_back(it.first);
+    }
+}
+
+void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {     // feature_tracker.cpp:81-167
+    cur_time = _cur_time;
+    FeSide& s = ensure(this, _img.cols, _img.rows);
+    // EQUALIZE (:85-95) and `forw_img = img` (:97-104): the frame goes to the device, where the (optional) CLAHE and the pyramid
+    // that calcOpticalFlowPyrLK would build of it are formed; the previous frame's pyramid stays where it is
+    const uint8_t* planes[1] = {_img.data};
+    chk(vg_fe_push_frames(s.vg, planes, (int)_img.step, EQUALIZE), s.vg, "vg_fe_push_frames");
+    if (forw_img.empty())
+        prev_img = cur_img = forw_img = _img;
+    else
+        forw_img = _img;
+
+    forw_pts.clear();
+
+    if (cur_pts.size() > 0) {                                                // :108-125
+        vector<uchar> status(cur_pts.size());
+        vector<float> err(cur_pts.size());
+        forw_pts.resize(cur_pts.size());
+        chk(vg_fe_track(s.vg, 0, &cur_pts[0].x, (int)cur_pts.size(), &forw_pts[0].x, status.data(), err.data()), s.vg, "vg_fe_track");
+        for (int i = 0; i < int(forw_pts.size()); i++)
+            if (status[i] && !inBorder(forw_pts[i])) status[i] = 0;
+        reduceVector(prev_pts, status);
+        reduceVector(cur_pts, status);
+        reduceVector(forw_pts, status);
+        reduceVector(ids, status);
+        reduceVector(cur_un_pts, status);
+        reduceVector(track_cnt, status);
+    }
+
+    for (auto& n : track_cnt) n++;                                           // :127-128
+
+    if (PUB_THIS_FRAME) {                                                    // :130-158
+        rejectWithF();
+        setMask();
+        int n_max_cnt = MAX_CNT - static_cast<int>(forw_pts.size());
+        if (n_max_cnt > 0) {
+            n_pts.resize(n_max_cnt);
+            int n = 0;
+            chk(vg_fe_detect_masked(s.vg, 0, n_max_cnt, 0.01, (double)MIN_DIST, &n_pts[0].x, &n), s.vg, "vg_fe_detect_masked");
+            n_pts.resize(n);
+        } else
+            n_pts.clear();
+        addPoints();                                                         // the reference's (:71-79)
+    }
+    prev_img = cur_img;                                                      // :160-166
+    prev_pts = cur_pts;
+    prev_un_pts = cur_un_pts;
+    cur_img = forw_img;
+    cur_pts = forw_pts;
+    undistortedPoints();
+    prev_time = cur_time;
+}
+
+void FeatureTracker::rejectWithF() {                                        // feature_tracker.cpp:169-202
+    if (forw_pts.size() >= 8) {
+        FeSide& s = ensure(this, COL, ROW);
+        // :175-188 as the reference has it: 2 x <= 150 points through camodocal on the host, in double (the float pair handed to the
+        // RANSAC is rounded from FOCAL_LENGTH * x / z + COL / 2)
+        vector<cv::Point2f> un_cur_pts(cur_pts.size()), un_forw_pts(forw_pts.size());
+        for (unsigned int i = 0; i < cur_pts.size(); i++) {
+            Eigen::Vector3d tmp_p;
+            m_camera->liftProjective(Eigen::Vector2d(cur_pts[i].x, cur_pts[i].y), tmp_p);
+            tmp_p.x() = FOCAL_LENGTH * tmp_p.x() / tmp_p.z() + COL / 2.0;
+            tmp_p.y() = FOCAL_LENGTH * tmp_p.y() / tmp_p.z() + ROW / 2.0;
+            un_cur_pts[i] = cv::Point2f(tmp_p.x(), tmp_p.y());
+
+            m_camera->liftProjective(Eigen::Vector2d(forw_pts[i].x, forw_pts[i].y), tmp_p);
+            tmp_p.x() = FOCAL_LENGTH * tmp_p.x() / tmp_p.z() + COL / 2.0;
+            tmp_p.y() = FOCAL_LENGTH * tmp_p.y() / tmp_p.z() + ROW / 2.0;
+            un_forw_pts[i] = cv::Point2f(tmp_p.x(), tmp_p.y());
+        }
+        const int n = (int)forw_pts.size();
+        vector<uchar> status(n);
+        chk(vg_fe_reject_with_f(s.vg, &un_cur_pts[0].x, &un_forw_pts[0].x, n, F_THRESHOLD, status.data(), nullptr, nullptr), s.vg, "vg_fe_reject_with_f");
+        reduceVector(prev_pts, status);
+        reduceVector(cur_pts, status);
+        reduceVector(forw_pts, status);
+        reduceVector(cur_un_pts, status);
+        reduceVector(ids, status);
+        reduceVector(track_cnt, status);
+    }
+}
+
+void FeatureTracker::undistortedPoints() {                                   // feature_tracker.cpp:258-306
+    FeSide& s = ensure(this, COL, ROW);
+    cur_un_pts.clear();
+    cur_un_pts_map.clear();
+    const int n = (int)cur_pts.size();
+    std::vector<float> un((size_t)std::max(n, 1) * 2);
+    if (n > 0 && s.pinhole)
+        chk(vg_fe_undistort(s.vg, &cur_pts[0].x, n, s.intr, un.data()), s.vg, "vg_fe_undistort");
+    else
+        for (int i = 0; i < n; i++) {                                        // MEI / KANNALA_BRANDT / SCARAMUZZA: camodocal on the host (:262-266)
+            Eigen::Vector2d a(cur_pts[i].x, cur_pts[i].y);
+            Eigen::Vector3d b;
+            m_camera->liftProjective(a, b);
+            un[2 * i] = (float)(b.x() / b.z());
+            un[2 * i + 1] = (float)(b.y() / b.z());
+        }
+    for (int i = 0; i < n; i++) {
+        cur_un_pts.push_back(cv::Point2f(un[2 * i], un[2 * i + 1]));
+        cur_un_pts_map.insert(make_pair(ids[i], cv::Point2f(un[2 * i], un[2 * i + 1])));
+    }
+    // caculate points velocity (:270-304)
+    if (!prev_un_pts_map.empty()) {
+        double dt = cur_time - prev_time;
+        pts_velocity.clear();
+        for (unsigned int i = 0; i < cur_un_pts.size(); i++) {
+            if (ids[i] != -1) {
+                std::map<int, cv::Point2f>::iterator it = prev_un_pts_map.find(ids[i]);
+                if (it != prev_un_pts_map.end()) {
+                    double v_x = (cur_un_pts[i].x - it->second.x) / dt;
+                    double v_y = (cur_un_pts[i].y - it->second.y) / dt;
+                    pts_velocity.push_back(cv::Point2f(v_x, v_y));
+                } else
+                    pts_velocity.push_back(cv::Point2f(0, 0));
+            } else {
+                pts_velocity.push_back(cv::Point2f(0, 0));
+            }
+        }
+    } else {
+        for (unsigned int i = 0; i < cur_pts.size(); i++) pts_velocity.push_back(cv::Point2f(0, 0));
+    }
+    prev_un_pts_map = cur_un_pts_map;
+}
+
+// ---- C entry points for the surrounding code (the reference class has no member to hang these on)
+extern "C" {
+// release the device handle of a FeatureTracker that is about to be destroyed or re-used for another stream
+void vins_fe_gpu_release(FeatureTracker* t) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_side.find(t);
+    if (it == g_side.end()) return;
+    if (it->second.vg) vg_destroy(it->second.vg);
+    g_side.erase(it);
+}
+// the device handle (e.g. for vg_fe_get_mask / vg_fe_get_level: the members `mask` and the equalized `cur_img` stay on the device)
+vg_handle* vins_fe_gpu_handle(FeatureTracker* t) { return side_of(t).vg; }
+}

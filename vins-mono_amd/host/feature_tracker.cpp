@@ -83,20 +83,27 @@ static void chk(int rc, vg_handle* h, const char* what) {
 }
 
 void FeatureTracker::setMask() {                             // feature_tracker.cpp:36-69, on the device (vg_fe_set_mask)
-    // The reference sorts with std::sort (unstable); canonicalised to a stable order (hard part 5).
+    // The reference orders the points with std::sort by track_cnt (:48-51): the order among equal counts is whatever the platform's
+    // std::sort gives.  The same call is made here, and the device walks the list in that order (its own sort by count is stable,
+    // i.e. the identity on a sorted list) -- the result is the reference's on the platform this is built on (tests/test_fe_dropin.py).
     // `mask` itself stays on the device: goodFeaturesToTrack below consumes it there (vg_fe_detect_masked).
     const int n = (int)forw_pts.size();
     if (n > fe_capacity_) throw std::runtime_error("FeatureTracker::setMask: more points than the configured capacity");
+    vector<pair<int, pair<cv::Point2f, int>>> cnt_pts_id;
+    for (int i = 0; i < n; i++) cnt_pts_id.push_back(make_pair(track_cnt[i], make_pair(forw_pts[i], ids[i])));
+    sort(cnt_pts_id.begin(), cnt_pts_id.end(),
+         [](const pair<int, pair<cv::Point2f, int>>& a, const pair<int, pair<cv::Point2f, int>>& b) { return a.first > b.first; });
     std::vector<float> xy((size_t)fe_capacity_ * 2, 0.f);
     std::vector<int> cnt((size_t)fe_capacity_, 0), kept((size_t)fe_capacity_, 0);
-    for (int i = 0; i < n; ++i) { xy[2 * i] = forw_pts[i].x; xy[2 * i + 1] = forw_pts[i].y; cnt[i] = track_cnt[i]; }
+    for (int i = 0; i < n; ++i) { xy[2 * i] = cnt_pts_id[i].second.first.x; xy[2 * i + 1] = cnt_pts_id[i].second.first.y; cnt[i] = cnt_pts_id[i].first; }
     const uint8_t* base[1] = {FISHEYE ? fisheye_mask.data : nullptr};
     int nk = 0;
     chk(vg_fe_set_mask(vg_, xy.data(), cnt.data(), &n, base, MIN_DIST, kept.data(), &nk), vg_, "vg_fe_set_mask");
-    vector<cv::Point2f> pts2(nk);
-    vector<int> ids2(nk), cnt2(nk);
-    for (int k = 0; k < nk; ++k) { pts2[k] = forw_pts[kept[k]]; ids2[k] = ids[kept[k]]; cnt2[k] = track_cnt[kept[k]]; }
-    forw_pts.swap(pts2); ids.swap(ids2); track_cnt.swap(cnt2);
+    forw_pts.clear(); ids.clear(); track_cnt.clear();
+    for (int k = 0; k < nk; ++k) {
+        const auto& it = cnt_pts_id[kept[k]];
+        forw_pts.push_back(it.second.first); ids.push_back(it.second.second); track_cnt.push_back(it.first);
+    }
 }
 
 void FeatureTracker::addPoints() {                            // :71-79
