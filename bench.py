@@ -172,6 +172,21 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
     nfeat = sum(len(c) for c in corners)
     res = tr.track_download()
     tracked = int(sum(int(st.sum()) for (_, st, _) in res))
+    last_is_a_to_b = (warmup + steps) % 2 == 1          # the steps alternate A -> B, B -> A with the same start points
+    # the same step with the frames arriving from HOST memory every step (the boundary-inclusive figure; never `value`):
+    # 256 x 361 KB = 92 MB of H2D per step in front of the pyramid build
+    up_frames = [fb, fa]
+    tr.upload_frames(fb)
+    h.sync()
+    t_up = time.perf_counter()
+    for k in range(max(4, steps // 2)):
+        tr.upload_frames(up_frames[k % 2])
+        tr.build_async(False)
+        tr.track_async()
+    h.sync()
+    up_ms = (time.perf_counter() - t_up) / max(4, steps // 2) * 1e3
+    tr.upload_frames(fb if (warmup + steps) % 2 == 0 else fa)      # leave the slots as the alternating steps below expect them
+    slot = tr.frame_slot()
     # the same step with CLAHE(3.0, 8x8) on the incoming frame (EQUALIZE = 1 in the EuRoC configuration,
     # feature_tracker.cpp:87-93)
     def step_eq():
@@ -199,6 +214,9 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
         "gftt_frames_per_s": FE_CAMS / (gftt_ms * 1e-3), "gftt_ms_per_batch": gftt_ms,
         "with_clahe": {"ms_per_step": eq_ms, "features_per_s": nfeat / (eq_ms * 1e-3),
                        "what": "same step with CLAHE(3.0, 8x8) on the incoming frame (EuRoC equalize: 1), HIP events"},
+        "upload_inclusive": {"ms_per_step": up_ms, "features_per_s": nfeat / (up_ms * 1e-3), "h2d_bytes_per_step": FE_CAMS * W * H,
+                             "what": "the same step with every stream's frame uploaded from pageable host memory first (vg_fe_upload_frames: one "
+                                     "hipMemcpy2DAsync per stream, then a stream synchronisation), wall clock; NOT the metric"},
         "roofline": {"kernel": "fe_lk_kernel (+ fe_pyrdown_kernel x3)", "bound": "hbm",
                      "achieved": nfeat * FE_BYTES_PER_FEATURE * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "traffic": fe_traffic(), "event_ms_per_step": ev_ms / steps,
@@ -207,6 +225,21 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
     if with_cpu:
         from oracle import fe_cpu
+        # parity of the TIMED configuration: the last timed step of 8 of the 256 streams (the 8 distinct image pairs) against the oracle
+        npar, nbad, ncmp = min(8, FE_CAMS), 0, 0
+        for c in range(npar):
+            pa, pb = (fa[c], fb[c]) if last_is_a_to_b else (fb[c], fa[c])
+            r_nxt, r_st, r_err = fe_cpu.lk(pa, pb, corners[c])
+            g_nxt, g_st, g_err = res[c]
+            ok = (np.array_equal(r_st, g_st) and np.array_equal(r_nxt.view(np.uint32), g_nxt.view(np.uint32))
+                  and np.array_equal(r_err.view(np.uint32), g_err.view(np.uint32)))
+            nbad += 0 if ok else 1
+            ncmp += len(r_st)
+        out["parity"] = {"streams_checked": npar, "of": FE_CAMS, "tracks_compared": ncmp, "streams_bit_identical": npar - nbad,
+                         "what": "status, positions and err (float bit patterns) of the last timed step vs oracle/fe_cpu.cpp (PARITY UNPINNED "
+                                 "against OpenCV itself: tests/golden/make_golden_opencv.py is the kit)"}
+        if nbad:
+            raise RuntimeError(f"front-end parity failed on {nbad} of {npar} timed streams")
         t = time.perf_counter()
         reps = 0
         while time.perf_counter() - t < (0.2 if QUICK else 5.0):

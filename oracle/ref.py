@@ -32,7 +32,12 @@ def available():
 
 
 def lib():
+    """libvins_ref.so — or, with VINS_REF_LIB=<path> in the environment, another build of the same driver (the diff kit's
+    libvins_ref_real.so: the reference's translation units on the REAL Eigen + Ceres, `make -C oracle ref_real`)."""
     global _lib
+    if _lib is None and os.environ.get("VINS_REF_LIB"):
+        _lib = _prepare(C.CDLL(os.environ["VINS_REF_LIB"]))
+        return _lib
     if _lib is None:
         if os.path.exists(_REF_SRC):          # (re)build when the reference is present; a no-op when up to date
             subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -65,6 +70,30 @@ def lib_gpu():
         _lib_gpu = _prepare(C.CDLL(_LIB_GPU))
         assert _lib_gpu.vref_has_gpu_optimization() == 1
     return _lib_gpu
+
+
+_lib_simt = None
+
+
+def simt_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libvins_ref_simt.so")) or os.path.exists(_REF_SRC)
+
+
+def lib_simt():
+    """libvins_ref_simt.so: libvins_ref_gpu.so's objects linked against the EMULATED kernel library (tests/simt) — the drop-in body
+    of Estimator::optimization() on the CPU, for the `not gpu` suite."""
+    global _lib_simt
+    if _lib_simt is None:
+        lib()
+        if os.path.exists(_REF_SRC):
+            subprocess.check_call(["make", "-C", os.path.join(_HERE, "..", "tests", "simt")], stdout=subprocess.DEVNULL)
+            subprocess.check_call(["make", "-C", _HERE, "ref_simt"], stdout=subprocess.DEVNULL)
+        path = os.path.join(_HERE, "_ref", "libvins_ref_simt.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/_ref/libvins_ref_simt.so is missing")
+        _lib_simt = _prepare(C.CDLL(path))
+        assert _lib_simt.vref_has_gpu_optimization() == 1
+    return _lib_simt
 
 
 def _d(a):

@@ -76,7 +76,7 @@ def write_config(path, width=752, height=480, max_cnt=150, min_dist=30, freq=10,
 class Node:
     """The front-end node from a fresh start: Node(L, config).image(stamp, img) = one message on IMAGE_TOPIC."""
 
-    def __init__(self, L, config=EUROC_CONFIG, vins_folder="/root/reference/", fisheye_mask=None):
+    def __init__(self, L, config, vins_folder="", fisheye_mask=None):
         self.L = L
         rc = L.vfe_start(config.encode(), vins_folder.encode())
         assert rc == 0
@@ -137,6 +137,10 @@ class Node:
         k = self.L.vfe_set_mask(pts.ctypes.data_as(FP), ids.ctypes.data_as(IP), cnt.ctypes.data_as(IP), n, po.ctypes.data_as(FP), io.ctypes.data_as(IP),
                                 co.ctypes.data_as(IP))
         return po[:k], io[:k], co[:k]
+
+    def mask(self, w=752, h=480):
+        out = np.zeros((h, w), np.uint8)
+        return out if self.L.vfe_get_mask(out.ctypes.data_as(C.c_void_p), w, h) else None
 
 
 def same_tracks(a, b):

@@ -134,6 +134,13 @@ struct IterationSummary {
     int exit_reason = 0;   // 0 none, 1 parameter tolerance, 2 function tolerance, 3 gradient tolerance
 };
 
+enum CallbackReturnType { SOLVER_CONTINUE, SOLVER_ABORT, SOLVER_TERMINATE_SUCCESSFULLY };
+class IterationCallback {       // (the stand-in's Solve() reports every iteration summary to the callbacks after the fact)
+  public:
+    virtual ~IterationCallback() {}
+    virtual CallbackReturnType operator()(const IterationSummary &summary) = 0;
+};
+
 class Problem {
   public:
     struct Options {};
@@ -192,6 +199,7 @@ class Solver {
         double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
         int max_num_consecutive_invalid_steps = 5;
         double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+        std::vector<IterationCallback *> callbacks;
     };
     struct Summary {
         TerminationType termination_type = NO_CONVERGENCE;

@@ -553,6 +553,13 @@ static void SolveImpl(const Solver::Options &opt, Problem *problem, Solver::Summ
 Solver::Summary vins_ref_last_summary;   // read by oracle/ref_stubs/ref_driver.cpp (Estimator::optimization keeps its summary local)
 void Solve(const Solver::Options &opt, Problem *problem, Solver::Summary *summary) {
     SolveImpl(opt, problem, summary);
+    // callbacks see Ceres' convention: `cost` is the cost of the point the iteration ENDS at (the candidate's if the step was
+    // accepted), while the stand-in's own rows keep the cost the iteration STARTED from next to `candidate_cost`
+    for (IterationCallback *cb : opt.callbacks)
+        for (IterationSummary it : summary->iterations) {
+            if (it.iteration > 0 && it.step_is_valid && it.step_is_successful) it.cost = it.candidate_cost;
+            (*cb)(it);
+        }
     vins_ref_last_summary = *summary;
 }
 

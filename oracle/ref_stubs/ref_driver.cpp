@@ -32,9 +32,15 @@ bool VisualIMUAlignment(map<double, ImageFrame> &, Vector3d *, Vector3d &, Vecto
 InitialEXRotation::InitialEXRotation() { frame_count = 0; }
 bool InitialEXRotation::CalibrationExRotation(vector<pair<Vector3d, Vector3d>>, Quaterniond, Matrix3d &) { out_of_scope("InitialEXRotation::CalibrationExRotation"); }
 
+#ifdef VINS_REF_REAL_CERES
+#include "ceres_real_trace.h"      // `make -C oracle ref_real`: real Eigen + Ceres, ceres::Solve wrapped at link time to record the trace
+#define VINS_REF_LAST_SUMMARY vins_ref_real::last
+#else
 namespace ceres {
 extern Solver::Summary vins_ref_last_summary;   // ref_stubs/ceres/solver_stub.cc
 }
+#define VINS_REF_LAST_SUMMARY ceres::vins_ref_last_summary
+#endif
 // Present only in libvins_ref_gpu.so (oracle/Makefile `ref_gpu`): the same reference objects with Estimator::optimization()
 // replaced by the product's drop-in body (vins-mono_amd/host/dropin/estimator_optimization.cpp -> libvinsgpu.so).
 extern "C" void vins_gpu_collect_prior(Estimator *) __attribute__((weak));
@@ -62,6 +68,14 @@ Estimator *as_est(void *p) { return static_cast<Estimator *>(p); }
 extern "C" {
 
 int vref_abi_version() { return 1; }
+// 1 = this library was built against the REAL Eigen + Ceres (oracle/Makefile: ref_real), 0 = against the stand-ins of oracle/ref_stubs
+int vref_real_ceres() {
+#ifdef VINS_REF_REAL_CERES
+    return 1;
+#else
+    return 0;
+#endif
+}
 int vref_has_gpu_optimization() { return vins_gpu_collect_prior != nullptr ? 1 : 0; }
 int vref_window_size() { return WINDOW_SIZE; }
 
@@ -507,7 +521,7 @@ int vref_est_failure_detection(void *p) { return as_est(p)->failureDetection() ?
 // trust-region iterations of the last optimization() (Ceres counts the initial evaluation as iteration 0)
 int vref_est_last_iterations(void *p) {
     if (vins_gpu_last_iterations) return vins_gpu_last_iterations(as_est(p));
-    return static_cast<int>(ceres::vins_ref_last_summary.iterations.size()) - 1;
+    return static_cast<int>(VINS_REF_LAST_SUMMARY.iterations.size()) - 1;
 }
 
 // per-iteration trace of the last optimization() of THIS estimator, whichever build: rows of 6
@@ -522,9 +536,9 @@ int vref_est_last_trace(void *p, int cap, double *rows6) {
         }
         return s->num_iterations;
     }
-    const ceres::Solver::Summary &s = ceres::vins_ref_last_summary;
+    const auto &s = VINS_REF_LAST_SUMMARY;
     for (size_t i = 1; i < s.iterations.size() && k < cap; i++, k++) {
-        const ceres::IterationSummary &it = s.iterations[i];
+        const auto &it = s.iterations[i];
         double *r = rows6 + 6 * k;
         r[0] = it.step_is_valid, r[1] = it.step_is_successful, r[2] = it.cost, r[3] = it.candidate_cost, r[4] = it.trust_region_radius, r[5] = it.step_norm;
     }
@@ -534,7 +548,7 @@ int vref_est_last_trace(void *p, int cap, double *rows6) {
 // ---- trace of the last ceres::Solve (restated minimiser): rows of 10
 // [iteration, valid, successful, cost, candidate_cost, model_cost_change, trust_region_radius, step_norm, mu, exit_reason]
 int vref_last_solve_trace(int cap, double *rows10, double *initial_cost, double *final_cost, int *termination) {
-    const ceres::Solver::Summary &s = ceres::vins_ref_last_summary;
+    const auto &s = VINS_REF_LAST_SUMMARY;
     *initial_cost = s.initial_cost;
     *final_cost = s.final_cost;
     *termination = static_cast<int>(s.termination_type);

@@ -152,4 +152,11 @@ int vfe_set_mask(const float* pts, const int* ids, const int* cnt, int n, float*
     for (int i = 0; i < k; ++i) { pts_out[2 * i] = t.forw_pts[i].x; pts_out[2 * i + 1] = t.forw_pts[i].y; ids_out[i] = t.ids[i]; cnt_out[i] = t.track_cnt[i]; }
     return k;
 }
+// the `mask` member as setMask() left it (all-reference build; the drop-in keeps its mask on the device)
+int vfe_get_mask(unsigned char* out, int w, int h) {
+    const cv::Mat& m = trackerData[0].mask;
+    if (m.empty() || m.cols != w || m.rows != h) return 0;
+    for (int y = 0; y < h; ++y) std::memcpy(out + (size_t)y * w, m.data + (size_t)y * m.step, (size_t)w);
+    return 1;
+}
 }  // extern "C"

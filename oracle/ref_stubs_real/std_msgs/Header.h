@@ -1,0 +1,2 @@
+// TEST INFRASTRUCTURE (diff kit, `make -C oracle ref_real`): the ROS / OpenCV NAME stand-ins of ../../ref_stubs without its Eigen / Ceres stand-ins
+#include "../../ref_stubs/std_msgs/Header.h"

@@ -11,7 +11,8 @@
 #include <set>
 #include <string>
 #include <vector>
-#include <ros/console.h>      // ../ref_stubs/ros: logging macros compile to nothing
+#include <boost/shared_ptr.hpp>      // (the stand-in of ref_stubs_fe/boost or the real one: messages travel as boost::shared_ptr, like in ROS)
+#include <ros/console.h>      // logging macros compile to nothing
 #include <ros/assert.h>
 #define ROSCONSOLE_DEFAULT_NAME "ros"
 namespace ros {
@@ -30,7 +31,7 @@ struct Time {
 };
 struct CapturedMessage {
     std::string topic;
-    std::shared_ptr<const void> msg;
+    boost::shared_ptr<const void> msg;
 };
 inline std::vector<CapturedMessage>& captured() {
     static std::vector<CapturedMessage> list;
@@ -40,8 +41,8 @@ class Publisher {
   public:
     Publisher() {}
     explicit Publisher(const std::string& t) : topic_(t) {}
-    template <typename M> void publish(const std::shared_ptr<M>& m) const { captured().push_back({topic_, std::static_pointer_cast<const void>(std::shared_ptr<const M>(m))}); }
-    template <typename M> void publish(const M& m) const { captured().push_back({topic_, std::static_pointer_cast<const void>(std::make_shared<const M>(m))}); }
+    template <typename M> void publish(const boost::shared_ptr<M>& m) const { captured().push_back({topic_, boost::shared_ptr<const void>(boost::shared_ptr<const M>(m))}); }
+    template <typename M> void publish(const M& m) const { captured().push_back({topic_, boost::shared_ptr<const void>(boost::shared_ptr<const M>(new M(m)))}); }
     const std::string& getTopic() const { return topic_; }
   private:
     std::string topic_;

@@ -1,0 +1,29 @@
+"""tests/test_dropin_gpu.py's comparison on the CPU: the reference's processIMU / processImage loop with Estimator::optimization()
+replaced by the product's drop-in body, the kernels of libvinsgpu running under the CPU emulator (oracle/_ref/libvins_ref_simt.so =
+the objects of libvins_ref_gpu.so linked against tests/simt/_build/libvinsgpu_simt.so)."""
+import numpy as np
+import pytest
+
+from oracle import ref as R
+from test_dropin_gpu import _compare
+from vins_mono_amd import synth
+
+pytestmark = pytest.mark.skipif(not (R.available() and R.simt_available()), reason="oracle/_ref libraries are not built")
+
+
+def test_reference_loop_with_the_drop_in_on_emulated_kernels():
+    seq_a = synth.SyntheticSequence(11, n_frames=20, K=20, L=300)
+    seq_b = synth.SyntheticSequence(11, n_frames=20, K=20, L=300)
+    ref = R.run_sequence(seq_a, 16, L=R.lib())
+    got = R.run_sequence(seq_b, 16, L=R.lib_simt())
+    assert len(ref) == 6
+    _compare(ref, got)
+
+
+def test_clear_state_between_two_optimizations_drops_the_pending_prior():
+    """see tests/test_dropin_gpu.py: the stale-prior hazard of the deferred marginalization result"""
+    ref = R.run_sequence(synth.SyntheticSequence(11, n_frames=28, K=28, L=300), 26, L=R.lib(), reset_at=13, collect_priors=False)
+    got = R.run_sequence(synth.SyntheticSequence(11, n_frames=28, K=28, L=300), 26, L=R.lib_simt(), reset_at=13, collect_priors=False)
+    assert [r['frame'] for r in ref] == [10, 11, 12, 23, 24, 25]
+    _compare(ref, got)
+    assert np.abs(got[3]['pose'] - ref[3]['pose']).max() < 1e-8           # the first solve after the reset: no prior on either side

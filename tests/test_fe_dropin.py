@@ -22,8 +22,16 @@ from oracle import ref_fe as RF
 needs_ref = pytest.mark.skipif(not RF.available("ref"), reason="oracle/_ref front-end libraries are not built")
 
 
-def _run(L, frames, config=RF.EUROC_CONFIG, stamps=None, options=(), vins_folder="/root/reference/"):
-    node = RF.Node(L, config, vins_folder=vins_folder)
+def _default_config():
+    """config/euroc/euroc_config.yaml's front-end keys (RF.write_config defaults), written where the GPU box can read it too"""
+    import os
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), "vins_fe_euroc_%d.yaml" % os.getpid())
+    return RF.write_config(path)
+
+
+def _run(L, frames, config=None, stamps=None, options=(), vins_folder=""):
+    node = RF.Node(L, config or _default_config(), vins_folder=vins_folder)
     for k, v in options:
         node.set_option(k, v)
     out = []
@@ -123,3 +131,57 @@ def test_other_image_size_camera_and_limits_on_the_gpu(tmp_path):
     ref = _run(RF.lib(), frames, cfg, stamps, vins_folder=folder)
     assert ref[2] == 1 and ref[0][-1]['n_id'] > 250
     _compare(ref, _run(RF.lib_gpu(), frames, cfg, stamps, vins_folder=folder))
+
+
+# ---- the stand-alone class of vins-mono_amd/host (FeatureTracker look-alike used by the replay harness `vins_replay fe|vio`)
+def _replay_standalone(exe, frames, tmp_path, pub_every=2):
+    import struct
+    import subprocess
+    path, outp = tmp_path / "frames.bin", tmp_path / "out.txt"
+    with open(path, "wb") as f:
+        f.write(struct.pack("4i", len(frames), frames[0].shape[1], frames[0].shape[0], pub_every))
+        for im in frames:
+            f.write(im.tobytes())
+    r = subprocess.run([exe, "fe", str(path), str(outp)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = []
+    for line in open(outp):
+        t = line.split()
+        if t[0] == "frame":
+            got.append([])
+        else:
+            got[-1].append([float(v) for v in t])
+    return [np.array(g, np.float64).reshape(-1, 8) for g in got]
+
+
+def _check_standalone(exe, tmp_path, n):
+    frames = fe_scene.moving_scene(n, seed=14)
+    got = _replay_standalone(exe, frames, tmp_path)
+    node = RF.Node(RF.lib(), _default_config())
+    assert len(got) == n
+    for k, f in enumerate(frames):
+        t = node.read_image(0.05 * k, f, k % 2 == 0)
+        g = got[k]
+        assert np.array_equal(g[:, 0].astype(np.int32), t['ids']) and np.array_equal(g[:, 1].astype(np.int32), t['track_cnt']), k
+        for cols, key in ((slice(2, 4), 'cur_pts'), (slice(4, 6), 'cur_un_pts'), (slice(6, 8), 'pts_velocity')):
+            assert np.array_equal(g[:, cols].astype(np.float32).view(np.uint32), t[key].view(np.uint32)), (k, key)
+    assert len(got[-1]) >= 100 and got[-1][:, 1].max() >= 6
+
+
+@needs_ref
+def test_standalone_class_replay_equals_the_reference_tracker_on_emulated_kernels(tmp_path):
+    """`vins_replay_simt fe` (host/feature_tracker.cpp on the emulated kernels) against the reference's FeatureTracker::readImage +
+    updateID with the same PUB_THIS_FRAME pattern — replaces the Python mirror this harness used to be held to."""
+    import os
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt", "_build", "vins_replay_simt")
+    if not os.path.exists(exe):
+        pytest.skip("tests/simt is not built")
+    _check_standalone(exe, tmp_path, 9)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_standalone_class_replay_equals_the_reference_tracker_on_the_gpu(tmp_path):
+    import os
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vins-mono_amd", "lib", "vins_replay")
+    _check_standalone(exe, tmp_path, 30)

@@ -557,3 +557,34 @@ def test_window_bookkeeping_restatement_follows_the_reference_loop(min_parallax,
             assert e < 1e-9, e                  # one solve on identical windows
     assert n_flips <= max(1, len(ref) // 4)
     print("restated loop vs the reference's loop: worst state difference", worst, "flips", n_flips)
+
+
+def test_link_time_wrap_of_ceres_solve():
+    """The diff kit for the real Ceres (oracle/Makefile: ref_real) records per-iteration summaries by wrapping ceres::Solve at link
+    time (oracle/ref_stubs_real/ceres_real_trace.cc) — the reference keeps its Summary local.  Real Ceres is absent here; the SAME
+    driver (-DVINS_REF_REAL_CERES), the same wrapper and the same --wrap link line built against the stand-in solver
+    (`make -C oracle ref_real_selftest`) must reproduce the stand-in's own trace."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if not os.path.exists("/root/reference/vins_estimator/src/estimator.cpp"):
+        pytest.skip("needs the reference sources to build the self-test library")
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", here, "ref_real_selftest"], stdout=subprocess.DEVNULL)
+    prob = FX.BRANCH_FIXTURES['large_perturbation'][0]()
+    _, sm_ref, _ = R.optimization(prob, 1)
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import conftest; from oracle import ref as R; import ba_fixtures as FX; "
+            "assert R.lib().vref_real_ceres() == 1; _, sm, _ = R.optimization(FX.BRANCH_FIXTURES['large_perturbation'][0](), 1); "
+            "print(json.dumps([[it['valid'], it['accepted'], it['cost'], it['cost_cand'], it['radius'], it['step_norm'], it['model_change']] for it in sm['iterations']]))"
+            % (os.path.dirname(here), os.path.join(os.path.dirname(here), "tests")))
+    env = dict(os.environ, VINS_REF_LIB=os.path.join(here, "_ref", "libvins_ref_selftest.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = json.loads(out.stdout.strip().splitlines()[-1])
+    want = [[it['valid'], it['accepted'], it['cost'], it['cost_cand'], it['radius'], it['step_norm'], it['model_change']] for it in sm_ref['iterations']]
+    assert len(rows) == len(want) == 32
+    for a, b in zip(rows, want):
+        assert a[:2] == b[:2] and np.allclose(a[2:6], b[2:6], rtol=1e-12)
+        if a[0] and b[6] != 0:
+            assert np.isclose(a[6], b[6], rtol=1e-6)          # model change is re-derived from cost_change / relative_decrease
