@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 7    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
+#define VG_ABI_VERSION 8    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
                              * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode; 6: vg_ba_reserve, vg_ba_seq_* (windows that stay on the device);
                              * 7: vg_ba_seq_export / vg_ba_seq_import */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
@@ -293,6 +293,13 @@ enum { VG_LAUNCH_DIRECT = 0, VG_LAUNCH_GRAPH = 1 };
 #endif
 int vg_ba_set_launch_mode(vg_handle* h, int mode);
 int vg_ba_launch_stats(vg_handle* h, int* mode, long long* graph_launches, long long* graph_captures);
+/* ABI 8.  From how many windows per batch on the factors of a round are linearised AND accumulated by ONE kernel with one workgroup per
+ * window (ba_linacc_proj_kernel: IMU factors, prior and projection factors; the projection records stay in LDS, J^T J of the camera
+ * blocks on MFMA) instead of by ba_linearize_imu / ba_linearize_proj / ba_accumulate spread over many workgroups per window.  With few
+ * windows the spread form is faster (the chip is empty), with a full batch the fused one (+18 % solves/s at 256 windows).  Default:
+ * environment VG_BA_FUSED_MIN, else 32; 0 = never.  Windows with extrinsic / td columns or on the large-window path always take the
+ * spread form.  Takes effect at the next upload. */
+int vg_ba_set_fused_min_windows(vg_handle* h, int min_windows);
 
 /* Capacities the layout of every later batch is built for at least (landmarks, projection factors and observation rows per window,
  * rows of the prior): a caller whose windows fluctuate from frame to frame keeps one layout -- no re-allocation, and in

@@ -164,6 +164,44 @@ def test_batch_is_bit_reproducible(handle):
     assert np.array_equal(single['pose'], st_a[1]['pose'])
 
 
+def test_fused_kernel_batch_is_bit_reproducible_and_agrees_with_the_spread_kernels(handle):
+    """A batch of >= 32 windows takes ba_linacc_proj_kernel (IMU factors, prior and projection factors linearised and accumulated by
+    one workgroup per window, camera blocks on MFMA, records in LDS): run to run bit-identical, independent of the window's slot in
+    the batch, and equal to the spread kernels (vg_ba_set_fused_min_windows(0)) to rounding; EuRoC-sized windows (two chunks) with
+    priors, one checked against the oracle."""
+    seqs = [synth.SyntheticSequence(300 + s, L=150 if s < 4 else 40) for s in range(36)]
+    firsts = [q.window(0) for q in seqs]
+    handle.ba_upload(firsts, [ba.VG_MARGIN_OLD] * len(firsts))
+    handle.ba_run_async()
+    st1, _, pr1 = handle.ba_download()
+    probs = [q.next_window(st1[k], pr1[k], 1) for k, q in enumerate(seqs)]
+    flags = [ba.VG_MARGIN_OLD] * len(probs)
+    handle.ba_upload(probs, flags)
+    handle.ba_run_async()
+    st_a, sm_a, pr_a = handle.ba_download()
+    prof = handle.ba_run_profiled()
+    assert prof["ba_accumulate_kernel"][1] == 8 and prof["ba_linearize_imu_kernel+ba_linearize_proj_kernel"][1] == 2       # fused rounds + the cost-only pass
+    handle.ba_upload(list(reversed(probs)), flags)
+    handle.ba_run_async()
+    st_b, sm_b, _ = handle.ba_download()
+    for a, b in zip(st_a, reversed(st_b)):
+        assert np.array_equal(a['pose'], b['pose']) and np.array_equal(a['sb'], b['sb']) and np.array_equal(a['inv_depth'], b['inv_depth'])
+    handle.ba_set_fused_min_windows(0)
+    try:
+        handle.ba_upload(probs, flags)
+        handle.ba_run_async()
+        st_c, sm_c, pr_c = handle.ba_download()
+    finally:
+        handle.ba_set_fused_min_windows(32)
+    for a, c, ma, mc in zip(st_a, st_c, sm_a, sm_c):
+        assert ma['num_iterations'] == mc['num_iterations'] and list(ma['it_flags']) == list(mc['it_flags'])
+        assert np.abs(a['pose'] - c['pose']).max() < 1e-7 and np.abs(a['sb'] - c['sb']).max() < 1e-7
+    x, summ = B.solve(probs[0])
+    ref = B.double2vector(probs[0], x)
+    assert summ['num_iterations'] == sm_a[0]['num_iterations']
+    assert np.abs(st_a[0]['pose'] - ref['pose']).max() < 1e-6 and np.abs(st_a[0]['sb'] - ref['sb']).max() < 1e-6
+
+
 def _check_prior(gp, op, tol=1e-7, dx=1e-12):
     """Prior parity against (A, b) = the Schur complement BEFORE the second eigen-decomposition, recomputed in
     extended precision from the oracle's assembled system (the double-precision eigen pseudo-inverse of Amm, whose

@@ -174,3 +174,42 @@ def test_emulated_ba_under_other_fiber_orders(simt_handle, monkeypatch, order):
         _check_solve(simt_handle, synth.SyntheticSequence(3, L=30).window(0))
     finally:
         simt_handle.ba_set_large_window(False)
+
+
+@pytest.mark.parametrize("seed,L", [(3, 218), (4, 215), (5, 150)])
+def test_emulated_fused_projection_kernel_over_several_chunks(simt_handle, seed, L):
+    """ba_linacc_proj_kernel takes the landmarks in chunks of ~440 factors (LDS).  The first two windows have 882 / 881 factors with
+    the last landmark starting BELOW factor 880: the number of chunks is the last landmark's chunk, not ceil(F / 440) — the version
+    that derived it from F walked into an empty chunk on the hardware (round 4).  Window three: the EuRoC-sized window (two chunks)."""
+    prob = synth.SyntheticSequence(seed, L=L).window(0)
+    prob['max_iters'] = 3
+    F = int(sum(prob['lm_nobs']) - len(prob['lm_nobs']))
+    assert F > 440
+    simt_handle.ba_set_fused_min_windows(1)          # (a single window takes the spread kernels by default)
+    try:
+        _check_solve(simt_handle, prob)
+        simt_handle.ba_upload([prob])
+        prof = simt_handle.ba_run_profiled()
+        assert prof["ba_accumulate_kernel"][1] == 3 and prof["ba_linearize_imu_kernel+ba_linearize_proj_kernel"][1] == 2     # 3 fused rounds + the cost-only pass
+    finally:
+        simt_handle.ba_set_fused_min_windows(32)
+
+
+def test_emulated_fused_and_spread_kernels_agree(simt_handle):
+    """the same window with a prior, IMU factors and two chunks of projection factors through both launch structures: identical
+    decisions, states equal to rounding (the sums run in different orders)"""
+    seq = synth.SyntheticSequence(21, L=90)
+    st, _, pr = simt_handle.ba_optimize(seq.window(0), ba.VG_MARGIN_OLD)
+    prob = seq.next_window(st, pr, 1)
+    out = []
+    for n in (0, 1):
+        simt_handle.ba_set_fused_min_windows(n)
+        try:
+            out.append(simt_handle.ba_optimize(prob, ba.VG_MARGIN_OLD))
+        finally:
+            simt_handle.ba_set_fused_min_windows(32)
+    (sa, ma, pa), (sb, mb, pb) = out
+    assert ma['num_iterations'] == mb['num_iterations'] and list(ma['it_flags']) == list(mb['it_flags'])
+    assert np.abs(sa['pose'] - sb['pose']).max() < 1e-8 and np.abs(sa['sb'] - sb['sb']).max() < 1e-8
+    assert np.isclose(ma['final_cost'], mb['final_cost'], rtol=1e-8)
+    assert pa['n'] == pb['n'] and np.abs(pa['J0'].T @ pa['J0'] - pb['J0'].T @ pb['J0']).max() < 1e-6 * np.abs(pa['J0'].T @ pa['J0']).max()

@@ -12,7 +12,7 @@ VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
 VG_MARG_SQRT, VG_MARG_EIGEN = 0, 1     # vg_ba_set_marg_mode
 VG_OK = 0
-VG_ABI_VERSION = 7          # include/vinsgpu.h
+VG_ABI_VERSION = 8          # include/vinsgpu.h
 VG_LAUNCH_DIRECT, VG_LAUNCH_GRAPH = 0, 1   # vg_ba_set_launch_mode
 VG_LAUNCH_DEFAULT = VG_LAUNCH_DIRECT        # include/vinsgpu.h
 VG_PRIOR_RESIDENT = -1
@@ -242,6 +242,7 @@ class Handle:
         L.vg_ba_set_large_window.argtypes = [C.c_void_p, C.c_int]
         L.vg_ba_set_marg_mode.argtypes = [C.c_void_p, C.c_int]
         L.vg_ba_set_launch_mode.argtypes = [C.c_void_p, C.c_int]
+        L.vg_ba_set_fused_min_windows.argtypes = [C.c_void_p, C.c_int]
         L.vg_ba_launch_stats.argtypes = [C.c_void_p, _pi, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         if hasattr(L, 'vg_ba_rccl_init'):            # (absent from the CPU-emulated build of tests/simt)
             L.vg_ba_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
@@ -313,6 +314,10 @@ class Handle:
     def ba_set_launch_mode(self, mode):
         """VG_LAUNCH_DIRECT (0) / VG_LAUNCH_GRAPH (1): one launch per kernel, or the captured pipeline replayed as a hipGraph."""
         self._chk(self.lib.vg_ba_set_launch_mode(self.h, int(mode)), "vg_ba_set_launch_mode")
+
+    def ba_set_fused_min_windows(self, n):
+        """Batches of at least n windows take the fused linearise + accumulate kernel (0 = never; default 32): vg_ba_set_fused_min_windows."""
+        self._chk(self.lib.vg_ba_set_fused_min_windows(self.h, int(n)), "vg_ba_set_fused_min_windows")
 
     def ba_launch_stats(self):
         mode, nl, ncap = C.c_int(), C.c_longlong(), C.c_longlong()

@@ -204,6 +204,24 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         L.lds_pro = 8 * BA_NW * 256;
         if (8 * L.Ncap * L.Ncap <= 128 * 1024) L.lds_pro = std::max(L.lds_pro, 8 * L.Ncap * L.Ncap);   // J0 staged in LDS when it fits
         if (L.lds_lin > 128 * 1024) { h->err = "prior too large for the linearisation kernel"; return VG_ERR_UNSUPPORTED; }
+        // fused projection kernel (ba_linacc_proj_kernel): LDS = staged records [la_chf][33] | pair blocks [Kp (Kp - 1) / 2][90] |
+        // keys [la_chf] + chunk starts [64] (ints)
+        {
+            static const bool off = getenv("VG_BA_FUSED") && !strcmp(getenv("VG_BA_FUSED"), "0");
+            // few windows: the chip is empty and the separate kernels spread a window over many workgroups (single window: 28 us per
+            // round against 52 us for the one fused workgroup); from a few dozen windows on the fused kernel wins
+            static const int env_min = getenv("VG_BA_FUSED_MIN") ? atoi(getenv("VG_BA_FUSED_MIN")) : 32;
+            const int la_min_windows = h->ba.fused_min >= 0 ? (h->ba.fused_min ? h->ba.fused_min : 1 << 30) : (env_min ? env_min : 1 << 30);
+            const int npair = L.Kp * (L.Kp - 1) / 2;
+            const int avail = 159 * 1024 / 8 - 64;
+            int chf = (int)((avail - npair * 90 - 34) / 33.5);
+            chf = std::min(chf & ~1, 512);
+            L.la_on = (!off && L.nwin >= la_min_windows && !L.big && !L.e && !L.t && L.Kp <= 13 && chf >= 96 && (L.Fcap + chf - 17) / (chf - 16) <= 62) ? 1 : 0;
+            L.la_chf = chf; L.la_chq = chf - 16;
+            L.la_P = up(chf * 33, 2);
+            L.la_key = L.la_P + up(npair * 90, 2);
+            L.lds_linacc = (L.la_key + (chf + 64 + 1) / 2 + 2) * 8;
+        }
     }
     if (L.big) {
         const int nt = (L.Rc + 1 + 15) / 16;
@@ -615,7 +633,9 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
         const double f_acc = it * (F * 416);                                                       // J^T J / J^T r of the projection factors
         const double f_sol = it * (schur + R * R * R / 3 + 2 * R * R + 12 * sumn);                  // Schur complement, Cholesky, back substitution
         const double f_pro = 2 * np * np * np;                                                     // prior J0^T J0
-        B.flops_k[0] += f_pro; B.flops_k[1] += f_lin; B.flops_k[2] += f_acc;
+        // (fused projection kernel: the factor evaluation moves to the class of the kernel that now does it)
+        const double f_move = L.la_on ? it * (F * 750 + 10 * 37000.0 + 4 * np * np) : 0.0;
+        B.flops_k[0] += f_pro; B.flops_k[1] += f_lin - f_move; B.flops_k[2] += f_acc + f_move;
         if (L.big) {
             // large-window path: the landmark Schur complement has a kernel of its own
             B.flops_k[VG_BA_KERNEL_BIG_SCHUR] += it * schur;
@@ -815,6 +835,12 @@ extern "C" int vg_ba_set_launch_mode(vg_handle* h, int mode) {
     if (!h || (mode != VG_LAUNCH_DIRECT && mode != VG_LAUNCH_GRAPH)) return VG_ERR_BAD_ARG;
     h->ba.launch_mode = mode;
     if (mode == VG_LAUNCH_DIRECT) graph_drop(h->ba);
+    return VG_OK;
+}
+extern "C" int vg_ba_set_fused_min_windows(vg_handle* h, int min_windows) {
+    if (!h || min_windows < 0) return VG_ERR_BAD_ARG;
+    h->ba.fused_min = min_windows;
+    h->ba.uploaded = false;
     return VG_OK;
 }
 extern "C" int vg_ba_launch_stats(vg_handle* h, int* mode, long long* graph_launches, long long* graph_captures) {

@@ -93,6 +93,9 @@ struct BaLayout {
     // ---- LDS carve of the solve kernel (offsets in doubles)
     int l_S, l_XC, l_D, l_E, l_dinv, l_vec, l_red, l_wd, l_z, l_pmap, ldc, lds_solve;
     int lds_lin, lds_pro;                     // dynamic LDS bytes of the linearisation / prologue kernels
+    // ---- fused projection kernel (ba_linacc_proj_kernel): eligible windows (la_on), landmarks per chunk by first factor index
+    //      (la_chq), staged-record capacity (la_chf = la_chq + 16), LDS offsets (doubles) of the pair blocks and of the key table
+    int la_on, la_chq, la_chf, la_P, la_key, lds_linacc;
     // ---- large-window path (big != 0): the camera part does not fit the LDS carve above.  S stays in LDS (packed, with
     //      the rhs row), everything else of the carve lives in HBM scratch at so_bigm (the l_* offsets are then relative to
     //      it); the landmark Schur complement is formed by a multi-workgroup kernel into reduce buffer 1.

@@ -932,6 +932,223 @@ extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(con
 }
 
 // ================================================================================================
+// Projection factors, fused: linearise + J^T J / J^T r in ONE kernel, the factor records never reach HBM.
+// ================================================================================================
+// One workgroup per window (no extrinsic / td columns, single-workgroup path; everything else keeps the two kernels above).
+// The window's landmarks are taken in CHUNKS -- chunk c = the landmarks whose first factor index lies in [c la_chq, (c + 1) la_chq);
+// the factor list is landmark-major, so a chunk is a contiguous factor range of at most la_chq + Kp - 2 factors -- and per chunk:
+//   (1) thread per factor: ProjectionFactor::Evaluate + Cauchy corrector (projection_factor.cpp:21-121, corrector.cc) -> the record
+//       goes to LDS as the 2 x 16 block X_f = [Ji (6) | Jj (6) | Jl | r | 0 0] (rows = the two residual components);
+//   (2) camera blocks on MFMA: every factor of the (anchor i, target j) pair contributes X_f^T X_f, whose 16 x 16 product holds
+//       Ji^T Ji, Jj^T Jj, Jj^T Ji, Ji^T r, Jj^T r at once.  A wavefront owns the pairs p = wave (mod 8), finds their factors in the
+//       chunk with a ballot over the pair keys and feeds them two at a time (k = 4) to v_mfma_f64_16x16x4_f64 -- both operands of
+//       X^T X are the SAME register (A[i][k] and B[k][j] sit in the same lane), fixed order -> bit-reproducible; the pair sums
+//       are kept in LDS (90 doubles per pair) across the chunks;
+//   (3) landmark sums (h, b, the W column) by one thread per landmark over its contiguous records, stores coalesced over landmarks.
+// Afterwards the diagonal blocks are summed from the pair blocks in a fixed order and Sp / gp go to the linearisation buffer: what
+// reaches HBM is Sp, gp, h, b, Wt and one cost partial -- the 42-double records (101.7 MB written + 87.9 MB read back per
+// 256-window launch, profiles/r03s_pmc_hbm.txt) are gone, and so is one launch per round.
+#define LA_NT BA_NT                // (imu_pass / prior_pass are written for BA_NT threads)
+#define LA_RS 33                  // doubles per staged record: rows at 0 and 16, odd stride (conflict-free b64 stores by thread)
+#define LA_MAXP 10                // pairs per wavefront: Kp (Kp - 1) / 2 <= 78 for Kp <= 13, 8 wavefronts
+#define LA_PAIR 90                // kept doubles of a pair block: ii 21 | jj 21 | ji 36 (row = target's column, col = anchor's) | gi 6 | gj 6
+extern "C" __global__ __launch_bounds__(LA_NT) void ba_linacc_proj_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout L = layout_load(Lp);
+    Ctx c;
+    ctx_init(c, Lp, P, blockIdx.x);
+    const double* ctl = c.sc + L.so_ctl;
+    if (ctl[C_DONE] != 0.0) return;
+    const int which = uni(((int)ctl[C_CUR]) ^ (ctl[C_PENDING] != 0.0 ? 1 : 0));
+    const double* x = c.sc + L.so_x + which * L.nst;
+    const double* lam = c.sc + L.so_lam + which * L.Lcap;
+    glb_d* buf = AS_GLB(lin_buf(c, which));
+    const glb_i* ia = AS_GLB_CI(c.ia);
+    lds_d* rec = AS_LDS(LDSB);
+    lds_d* Pb = AS_LDS(LDSB + L.la_P);
+    lds_i* key = (lds_i*)(LDSB + L.la_key);
+    lds_i* lstart = key + L.la_chf;
+    __shared__ double red[2 * (LA_NT / 64)];
+    const int Kp = L.Kp, npair = Kp * (Kp - 1) / 2, chq = L.la_chq;
+    const int nL = c.nL, nF = c.nF;
+    // ---- the IMU factors and the prior of the same point, by this workgroup too (they used to be a launch of their own,
+    //      ba_linearize_imu_kernel: ~35 us per round for ~10 us of work -- the rest was launch ramp and first-touch latency).
+    //      Their LDS scratch (sqrt_info copies + weighted panels / dx + partial sums) is the start of the record area.
+    {
+        double share = imu_pass<true>(c, x, lin_buf(c, which) + L.bo_imuJ, 0, L.K - 1);
+        share += prior_pass(c, x, lin_buf(c, which) + L.bo_pr, lin_buf(c, which) + L.bo_gpr, LDSB);
+        const double tot_imu = block_sum(red, LA_NT / 64, c.lane, c.wave, share);
+        for (int g = c.tid; g < L.nbl - L.nbf; g += LA_NT) c.sc[L.so_part + L.nbf + g] = g == 0 ? tot_imu : 0.0;
+        __syncthreads();
+    }
+    const int nchunk = nL > 0 ? uni(ia[L.io_lm_fbeg + nL - 1] / chq + 1) : 0;     // (the LAST landmark's chunk: a chunk is never empty, landmarks have <= Kp - 1 factors)
+    // first landmark of every chunk
+    for (int t = c.tid; t < nL; t += LA_NT) {
+        const int cl = ia[L.io_lm_fbeg + t] / chq;
+        if (t == 0 || ia[L.io_lm_fbeg + t - 1] / chq != cl) lstart[cl] = t;
+    }
+    if (c.tid == 0) lstart[nchunk] = nL;
+    for (int e = c.tid; e < npair * LA_PAIR; e += LA_NT) Pb[e] = 0.0;
+    // the pairs of this wavefront: p = wave + 8 k  <->  (i, j), i < j, p = j (j - 1) / 2 + i
+    int pkey[LA_MAXP];
+#pragma unroll
+    for (int k = 0; k < LA_MAXP; ++k) {
+        const int p = c.wave + 8 * k;
+        int a = 0, b = 0;
+        tri_decode(p < npair ? p : 0, a, b);
+        pkey[k] = p < npair ? uni(b * 16 + a + 1) : -1;
+    }
+    __syncthreads();
+    double cost = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int l0 = lstart[ch], l1 = lstart[ch + 1];
+        const int f0 = ia[L.io_lm_fbeg + l0], f1 = ia[L.io_lm_fbeg + l1];
+        const int nf = uni(f1 - f0);
+        if (nf > L.la_chf) __builtin_trap();                  // (a landmark with more than Kp - 1 factors: the packer never builds one)
+        // ---- (1) linearise
+        if (c.tid < nf) {
+            ProjIn pin;
+            proj_fetch(c, f0 + c.tid, x, lam, pin);
+            double r[2], Ji[12], Jj[12], Jl[2];
+            proj_eval<false, true, false>(pin.pi, pin.pj, pin.ex, pin.lam, pin.oi, pin.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, nullptr, Jl, nullptr);
+            const double s = r[0] * r[0] + r[1] * r[1];
+            const double sq = sqrt(1.0 / (1.0 + s));
+            lds_d* q = rec + c.tid * LA_RS;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                q[k] = sq * Ji[k]; q[16 + k] = sq * Ji[6 + k];
+                q[6 + k] = sq * Jj[k]; q[22 + k] = sq * Jj[6 + k];
+            }
+            q[12] = sq * Jl[0]; q[28] = sq * Jl[1];
+            q[13] = sq * r[0]; q[29] = sq * r[1];
+            key[c.tid] = pin.i * 16 + pin.j;
+            cost += log1p(s);
+        }
+        __syncthreads();
+        // ---- (2) pair blocks on MFMA
+        {
+            double4_t acc[LA_MAXP];
+#pragma unroll
+            for (int k = 0; k < LA_MAXP; ++k) acc[k] = (double4_t){0, 0, 0, 0};
+            const int k4 = c.lane >> 4, col = c.lane & 15;
+            const int xo = (k4 & 1) * 16 + col;               // this lane's element of a record: row k4 & 1, column col
+            for (int b0 = 0; b0 < nf; b0 += 64) {
+                const int kk = b0 + c.lane < nf ? key[b0 + c.lane] : -2;
+#pragma unroll
+                for (int k = 0; k < LA_MAXP; ++k) {
+                    if (pkey[k] < 0) continue;                // (uniform)
+                    unsigned long long m = __ballot(kk == pkey[k]);
+                    while (m) {
+                        const int fa = b0 + (int)__builtin_ctzll(m);
+                        m &= m - 1;
+                        int fb = -1;
+                        if (m) { fb = b0 + (int)__builtin_ctzll(m); m &= m - 1; }
+                        const int fs = (k4 >> 1) ? fb : fa;
+                        const double v = (fs >= 0 && col < 14) ? rec[fs * LA_RS + xo] : 0.0;
+                        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc[k], 0, 0, 0);
+                    }
+                }
+            }
+            // D[row = (lane >> 4) + 4 reg][col = lane & 15] -> the kept entries of the pair block
+#pragma unroll
+            for (int k = 0; k < LA_MAXP; ++k) {
+                if (pkey[k] < 0) continue;
+                lds_d* pb = Pb + (c.wave + 8 * k) * LA_PAIR;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = k4 + 4 * reg;
+                    int idx = -1;
+                    if (row < 6) {
+                        if (col <= row) idx = row * (row + 1) / 2 + col;              // ii
+                        else if (col == 13) idx = 78 + row;                           // gi
+                    } else if (row < 12) {
+                        if (col < 6) idx = 42 + (row - 6) * 6 + col;                  // ji
+                        else if (col <= row && col < 12) idx = 21 + (row - 6) * (row - 5) / 2 + (col - 6);   // jj
+                        else if (col == 13) idx = 84 + (row - 6);                     // gj
+                    }
+                    if (idx >= 0) pb[idx] += acc[k][reg];
+                }
+            }
+        }
+        // ---- (3) landmark sums: thread per landmark of the chunk, its records are contiguous; the W column is written as the
+        //      factors come by (targets ascend), zeros in between, the anchor's rows (a sum over all factors) last
+        if (c.tid < l1 - l0) {
+            const int l = l0 + c.tid;
+            glb_d* Wt = buf + L.bo_Wt + l;
+            const size_t ldw = L.Lcap;
+            const int fb = ia[L.io_lm_fbeg + l] - f0, fe = ia[L.io_lm_fbeg + l + 1] - f0;
+            double h = 0.0, b = 0.0, wi[6] = {0, 0, 0, 0, 0, 0};
+            const int anchor = fb < fe ? key[fb] >> 4 : -1;
+            int jn = 0;
+            for (int f = fb; f < fe; ++f) {
+                const lds_d* q = rec + f * LA_RS;
+                const int j = key[f] & 15;
+                const double l0v = q[12], l1v = q[28];
+                double v[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v[k] = q[6 + k] * l0v + q[22 + k] * l1v;
+                h += l0v * l0v + l1v * l1v;
+                b += l0v * q[13] + l1v * q[29];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) wi[k] += q[k] * l0v + q[16 + k] * l1v;
+                for (; jn < j; ++jn) {
+                    if (jn == anchor) continue;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * jn + k) * ldw] = 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * j + k) * ldw] = v[k];
+                jn = j + 1;
+            }
+            for (; jn < Kp; ++jn) {
+                if (jn == anchor) continue;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * jn + k) * ldw] = 0.0;
+            }
+            if (anchor >= 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * anchor + k) * ldw] = wi[k];
+            }
+            for (int row = 6 * Kp; row < L.RcPad; ++row) Wt[(size_t)row * ldw] = 0.0;
+            buf[L.bo_h + l] = h;
+            buf[L.bo_b + l] = b;
+        }
+        __syncthreads();                                      // records and keys consumed
+    }
+    // ---- the columns of the unused landmark slots
+    for (int w = c.tid; w < (L.Lcap - nL) * L.RcPad; w += LA_NT) {
+        const int row = w / (L.Lcap - nL), l = nL + w % (L.Lcap - nL);
+        buf[L.bo_Wt + (size_t)row * L.Lcap + l] = 0.0;
+    }
+    // ---- camera part: off-diagonal block (j, i) = the pair's Jj^T Ji; diagonal block a = its anchor share over the targets
+    //      j > a, then its target share over the anchors i < a (fixed order)
+    {
+        const int nent = L.Rc * (L.Rc + 1) / 2;
+        for (int e = c.tid; e < nent + L.Rc; e += LA_NT) {
+            double s = 0.0;
+            if (e < nent) {
+                int row, colm;
+                tri_decode(e, row, colm);
+                const int br = row / 6, pr = row - 6 * br, bc = colm / 6, pc = colm - 6 * bc;
+                if (br != bc) s = Pb[(br * (br - 1) / 2 + bc) * LA_PAIR + 42 + pr * 6 + pc];
+                else {
+                    const int t = pr * (pr + 1) / 2 + pc;
+                    for (int j = br + 1; j < Kp; ++j) s += Pb[(j * (j - 1) / 2 + br) * LA_PAIR + t];
+                    for (int i = 0; i < br; ++i) s += Pb[(br * (br - 1) / 2 + i) * LA_PAIR + 21 + t];
+                }
+                buf[L.bo_Sp + e] = s;
+            } else {
+                const int g = e - nent, a = g / 6, k = g - 6 * a;
+                for (int j = a + 1; j < Kp; ++j) s += Pb[(j * (j - 1) / 2 + a) * LA_PAIR + 78 + k];
+                for (int i = 0; i < a; ++i) s += Pb[(a * (a - 1) / 2 + i) * LA_PAIR + 84 + k];
+                buf[L.bo_gp + g] = s;
+            }
+        }
+    }
+    const double tot = block_sum(red, LA_NT / 64, c.lane, c.wave, cost);
+    if (c.tid < L.nbf) c.sc[L.so_part + c.tid] = c.tid == 0 ? tot : 0.0;
+}
+
+// ================================================================================================
 // Solve kernel
 // ================================================================================================
 struct SolveLds {
@@ -3274,6 +3491,7 @@ static hipError_t set_lds_attrs() {
     e = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linacc_proj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     // (these two also hold a few statically allocated LDS words: static + dynamic must stay within 160 KB)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linearize_imu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_eval_factors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -3307,13 +3525,16 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
     if (e != hipSuccess) { g_failed_launch = "hipFuncSetAttribute"; return e; }
     int nev = 0;
     if (ev) { e = hipEventRecord(ev[nev++], stream); if (e != hipSuccess) return e; }
-    const bool forked = fk && fk->aux && !ev;
+    const bool forked = fk && fk->aux && !ev && !L.la_on;
     int nk = 0;
     LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P);
     if (kinds) kinds[nk++] = 0;
     for (int r = 0; r <= rounds; ++r) {
         const int cost_only = r == rounds ? 1 : 0;
-        if (forked) {
+        const bool fused = L.la_on && !cost_only;         // IMU + prior + projection factors linearised AND accumulated by one kernel
+        if (fused) {
+            // (nothing: ba_linacc_proj_kernel below does it)
+        } else if (forked) {
             if ((e = hipEventRecord(fk->fork, stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(fk->aux, fk->fork, 0)) != hipSuccess) return e;
             hipLaunchKernelGGL(ba_linearize_imu_kernel, dim3(L.nig + L.nprw, L.nwin), dim3(BA_NT), L.lds_lin, fk->aux, dL, P, cost_only);
@@ -3322,16 +3543,17 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
         } else {
             LAUNCH(ba_linearize_imu_kernel, dim3(L.nig + L.nprw, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only);
         }
-        LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only);
-        if (kinds) { if (!forked) kinds[nk++] = 1; kinds[nk++] = 1; }
+        if (fused) LAUNCH(ba_linacc_proj_kernel, dim3(L.nwin), dim3(LA_NT), L.lds_linacc, dL, P);
+        else LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only);
+        if (kinds) { if (!forked && !fused) kinds[nk++] = 1; kinds[nk++] = fused ? 2 : 1; }
         if (r == rounds) {
             if (forked && (e = hipStreamWaitEvent(stream, fk->join, 0)) != hipSuccess) return e;
             break;
         }
-        LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P);
+        if (!fused) LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P);
         if (forked && (e = hipStreamWaitEvent(stream, fk->join, 0)) != hipSuccess) return e;
         LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P);
-        if (kinds) { kinds[nk++] = 2; kinds[nk++] = 3; }
+        if (kinds) { if (!fused) kinds[nk++] = 2; kinds[nk++] = 3; }
     }
     LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P);
     if (kinds) kinds[nk++] = 4;
