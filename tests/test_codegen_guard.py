@@ -88,13 +88,24 @@ def test_phase_function_keeps_its_address_spaces(funcs, frag):
 
 
 def test_kernels_do_not_fall_back_to_flat_memory(funcs):
-    for k in ("ba_accumulate_kernel", "ba_linearize_imu_kernel", "ba_linearize_proj_kernel", "ba_solve_kernel", "fe_lk_kernel"):
+    for k in ("ba_accumulate_kernel", "ba_linacc_proj_kernel", "ba_linearize_imu_kernel", "ba_linearize_proj_kernel", "ba_solve_kernel", "fe_lk_kernel"):
         for name in _find(funcs, k):
             ops = funcs[name]
             # the top level of the solve kernel re-reads its context struct from the private stack after the phase calls (its
             # address is handed to them on purpose): a few dozen flat accesses per launch, none in a loop
             limit = 40 if name == "ba_solve_kernel" else 4
             assert _count(ops, "flat_load") + _count(ops, "flat_store") <= limit, name
+
+
+def test_fused_projection_kernel_keeps_its_mfma_and_stays_out_of_scratch(funcs):
+    """ba_linacc_proj_kernel: the camera blocks of the projection factors are X^T X products on v_mfma_f64_16x16x4 (one per pair slot
+    of a wavefront), the staged records live in LDS, and what it keeps in scratch is the context struct of the two non-inlined IMU /
+    prior passes — not the accumulators."""
+    (name,) = [n for n in _find(funcs, "ba_linacc_proj_kernel") if "clone" not in n][:1]
+    ops = funcs[name]
+    assert _count(ops, "v_mfma_f64_16x16x4") >= 10
+    assert _count(ops, "ds_read") >= 30 and _count(ops, "ds_write") >= 20
+    assert _count(ops, "scratch_store") <= 16 and _count(ops, "scratch_load") <= 16
 
 
 def _kernel_metadata():

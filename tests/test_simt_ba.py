@@ -190,7 +190,7 @@ def test_emulated_fused_projection_kernel_over_several_chunks(simt_handle, seed,
         _check_solve(simt_handle, prob)
         simt_handle.ba_upload([prob])
         prof = simt_handle.ba_run_profiled()
-        assert prof["ba_accumulate_kernel"][1] == 3 and prof["ba_linearize_imu_kernel+ba_linearize_proj_kernel"][1] == 2     # 3 fused rounds + the cost-only pass
+        assert prof["ba_linacc_proj_kernel"][1] == 3 and prof["ba_linearize_imu_kernel+ba_linearize_proj_kernel"][1] == 2     # 3 fused rounds + the cost-only pass
     finally:
         simt_handle.ba_set_fused_min_windows(32)
 

@@ -377,12 +377,21 @@ class Handle:
     KERNEL_CLASSES = ("ba_prologue_kernel", "ba_linearize_imu_kernel+ba_linearize_proj_kernel", "ba_accumulate_kernel", "ba_solve_kernel",
                       "ba_final_kernel", "ba_marg_kernel", "ba_big_schur_kernel", "ba_solve_big_kernel", "ba_big_step_kernel")
 
+    def kernel_classes(self):
+        """Names of the launch classes of the uploaded batch (VG_BA_KERNEL_*): with the fused projection kernel the accumulate class
+        IS ba_linacc_proj_kernel (IMU + prior + projection factors: linearise + accumulate) and the linearize class is left with the
+        cost-only pass of the last candidate."""
+        k = list(self.KERNEL_CLASSES)
+        if self.lib.vg_ba_batch_is_fused(self.h) == 1:
+            k[2] = "ba_linacc_proj_kernel"
+        return k
+
     def ba_run_profiled(self):
         """Synchronous run with a HIP event after every launch: {kernel: (summed ms, launches)}."""
         ms = (C.c_float * len(self.KERNEL_CLASSES))()
         n = (C.c_int * len(self.KERNEL_CLASSES))()
         self._chk(self.lib.vg_ba_batch_run_profiled(self.h, ms, n), "vg_ba_batch_run_profiled")
-        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.kernel_classes())}
 
     def ba_info(self):
         fl, bi, bo, lds = C.c_double(), C.c_double(), C.c_double(), C.c_int()
@@ -392,7 +401,7 @@ class Handle:
         fk = (C.c_double * len(self.KERNEL_CLASSES))()
         self._chk(self.lib.vg_ba_batch_flops_by_kernel(self.h, fk), "vg_ba_batch_flops_by_kernel")
         return dict(flops=fl.value, flops_solve=fs.value, flops_marg=fm.value, bytes_in=bi.value, bytes_out=bo.value,
-                    lds_bytes=lds.value, flops_by_kernel={k: float(fk[i]) for i, k in enumerate(self.KERNEL_CLASSES)})
+                    lds_bytes=lds.value, flops_by_kernel={k: float(fk[i]) for i, k in enumerate(self.kernel_classes())})
 
     def ba_prepare_download(self):
         """Allocate the host output buffers of the uploaded batch once (reused by every ba_download_raw())."""

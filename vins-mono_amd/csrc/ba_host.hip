@@ -843,6 +843,10 @@ extern "C" int vg_ba_set_fused_min_windows(vg_handle* h, int min_windows) {
     h->ba.uploaded = false;
     return VG_OK;
 }
+extern "C" int vg_ba_batch_is_fused(vg_handle* h) {
+    if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
+    return h->ba.L.la_on ? 1 : 0;
+}
 extern "C" int vg_ba_launch_stats(vg_handle* h, int* mode, long long* graph_launches, long long* graph_captures) {
     if (!h) return VG_ERR_BAD_ARG;
     if (mode) *mode = h->ba.graph_unavailable ? VG_LAUNCH_DIRECT : resolve_launch_mode(h->ba);

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <chrono>
 #include <vector>
 #include "ba_math.h"
 #include "vg_handle.h"
@@ -104,7 +105,14 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* 
         for (int c = 0; c < 9; ++c) A[i * 9 + c][t] = row[c];
     }
     for (int e = 0; e < 81; ++e) V[e][t] = (e % 10 == 0) ? 1.0 : 0.0;
-    // one-sided Jacobi on the 9 columns: A V = U Sigma; the two columns that end with the smallest norms span the null space
+    // one-sided Jacobi on the 9 columns: A V = U Sigma; the two columns that end with the smallest norms span the null space.
+    // A has rank 7: two columns shrink to rounding noise, and a pair with such a column never passes the orthogonality test (noise
+    // against noise) -- it is still rotated when its turn comes, but only rotations between two columns that carry signal (norm^2
+    // above 1e-26 |A|_F^2) keep the sweeps going: ~7 sweeps instead of all 40 (1.7 -> 0.4 ms for the 1000 samples of a frame; any
+    // basis of the null space gives the same pencil of models, and the inlier masks are held to the oracle's two-sided Jacobi).
+    double scale2 = 0.0;
+    for (int e = 0; e < 63; ++e) scale2 += A[e][t] * A[e][t];
+    const double signal = 1e-26 * scale2;
     for (int sweep = 0; sweep < 40; ++sweep) {
         bool rotated = false;
         for (int p = 0; p < 8; ++p)
@@ -112,7 +120,7 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* 
                 double al = 0.0, be = 0.0, ga = 0.0;
                 for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + p][t], b = A[r * 9 + q][t]; al += a * a; be += b * b; ga += a * b; }
                 if (fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
-                    rotated = true;
+                    rotated = rotated || (al > signal && be > signal);
                     const double zeta = (be - al) / (2.0 * ga);
                     const double tn = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                     const double cs = 1.0 / sqrt(1.0 + tn * tn), sn = cs * tn;
@@ -285,6 +293,9 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
     };
     if (e != hipSuccess) return fail(e);
     // the schedule: what OpenCV's loop would draw in its first maxIters iterations (it depends on the points only)
+    static const bool debug_phases = getenv("VG_DEBUG_RANSAC") != nullptr;      // phase times of this call on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     const bool lmeds = n < 15;                         // findFundamentalMat: RANSAC needs 15 points, LMedS otherwise
     const int maxit = lmeds ? std::max(update_num_iters(0.99, 0.45, 7, 1000), 3) : FE_RANSAC_MAXIT;
     std::vector<int> sched((size_t)maxit * 7);
@@ -294,6 +305,7 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
         for (; nsched < maxit; ++nsched)
             if (!get_subset(rng, cur_un_xy, forw_un_xy, n, sched.data() + (size_t)nsched * 7, lmeds ? 1000 : 10000)) break;
     }
+    const double ms_sched = since(t_begin);
     // One allocation for the life of the handle (n <= FE_RANSAC_MAXPTS): this call sits on the per-frame path, and hipFree
     // synchronises the whole device — it would stall the BA handle's asynchronous marginalization / state download.
     const size_t off_F = sizeof(float) * 4 * FE_RANSAC_MAXPTS, off_m = off_F + sizeof(double) * 9 * FE_RANSAC_MAXIT;
@@ -322,6 +334,7 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
         if ((e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * nsched, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
         if ((e = hipMemcpyAsync(med.data(), d_med, sizeof(double) * nsched, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
         if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail(e);
+        if (debug_phases) fprintf(stderr, "[ransac] n %d, schedule of %d samples %.3f ms (host), upload + kernel + download %.3f ms\n", n, nsched, ms_sched, since(t_begin) - ms_sched);
         // the sequential bookkeeping of the registrator over the per-iteration results
         if (!lmeds) {
             int niters = FE_RANSAC_MAXIT, max_good = 0;
