@@ -23,13 +23,16 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(1.0, np.abs(b).max())
 
 
-def _compare(ref, got, tol=1e-4, tol_after_flip=2e-3):
+def _compare(ref, got, tol=1e-4, tol_after_flip=1.5e-3):
     """Frame by frame.  As long as both runs have taken the same trust-region decisions (number of iterations, accepted /
     rejected steps) in every frame so far they must agree to `tol` (north_star: 1e-4 relative).  Those decisions are thresholds
     (function tolerance 1e-6, step quality rho > 1e-3, radius updates at 0.25 / 0.75): two implementations that agree to 1e-9
     can still land on different sides of one, and then differ by the size of a step (~1e-4 .. 1e-3) until the following frames
-    pull the two runs together again (measured: 5e-4 in the frame of the flip, 3e-5 one frame later).  The frame of such a
-    flip and the two after it are compared at `tol_after_flip`; at most a quarter of the frames may be flips."""
+    pull the two runs together again.  Measured over 100 sequences x 14 solves (profiles/r04g_flip_stats.json, round 4): 40 of 1400
+    frames take a different decision (2.9 %, in 23 of the 100 sequences; the same with the reference's eigen form of the prior, 39 —
+    the square-root form is not the cause); error before any flip <= 7.5e-5 (median 7e-7), in the frame of a flip <= 9.2e-4 (median
+    1.2e-4), in the later frames of such a sequence <= 8.8e-4.  The frame of a flip and the two after it are therefore compared at
+    `tol_after_flip` = 1.5e-3 (round 3: 2e-3, unmeasured); at most a quarter of the frames may be flips (measured worst: 3 of 14)."""
     assert len(ref) == len(got)
     worst, loose_left, n_flips, rows, checks = 0.0, 0, 0, [], []
     for r, g in zip(ref, got):

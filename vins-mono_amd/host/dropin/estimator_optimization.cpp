@@ -21,6 +21,7 @@
 //                                                       own MarginalizationInfo / last_marginalization_parameter_blocks
 // State the reference class has no member for (device handle, pending prior) lives in a side table keyed by `this`.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -129,7 +130,13 @@ void collect_prior(Estimator& e, VgSide& s) {
 void Estimator::optimization() {
     VgSide& s = side_of(this);
     if (vg_abi_version() != VG_ABI_VERSION) throw std::runtime_error("libvinsgpu.so was built from another include/vinsgpu.h (ABI version mismatch)");
-    if (!s.vg && vg_create(&s.vg) != VG_OK) throw std::runtime_error("vg_create failed: no MI355X / libvinsgpu (no CPU fallback)");
+    if (!s.vg) {
+        if (vg_create(&s.vg) != VG_OK) throw std::runtime_error("vg_create failed: no MI355X / libvinsgpu (no CPU fallback)");
+        // form of the prior factor the marginalization hands to the next frame: the pivoted-Cholesky square root (default) or, with
+        // VINS_GPU_MARG_MODE=eigen in the environment, the reference's eigen form (marginalization_factor.cpp:285-296); include/vinsgpu.h
+        const char* mm = getenv("VINS_GPU_MARG_MODE");
+        if (mm && !strcmp(mm, "eigen")) vg_ba_set_marg_mode(s.vg, VG_MARG_EIGEN);
+    }
     collect_prior(*this, s);                                    // the previous frame's marginalization result, if still on the device
     vector2double();                                            // estimator.cpp:701
     const int K = WINDOW_SIZE + 1;
