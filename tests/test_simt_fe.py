@@ -125,3 +125,30 @@ def test_emulated_detection_path_is_bit_exact_in_every_fiber_order(order):
     env = dict(os.environ, SIMT_ORDER=order)
     r = subprocess.run([sys.executable, "-c", _CHILD_D % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_emulated_upload_into_the_previous_images_slot_blocks_tracking_until_the_next_build():
+    """the frame slot is level 0 of its pyramid set, so an upload lands in the slot of the PREVIOUS image.  upload -> build
+    -> track is the normal order; upload -> track would read the new image as the old one and is refused (VG_ERR_BAD_ARG) until a
+    build has rotated the sets — instead of silently tracking against a corrupted pyramid."""
+    import conftest
+    from vins_mono_amd import fe, synth
+    h = conftest._simt_handle()
+    W, H = 256, 160
+    a = synth.synth_frame(31, W, H)
+    b = synth.warp_frame(a, 32)
+    c = synth.warp_frame(b, 33)
+    tr = fe.FrontEnd(h, W, H, 1, 32)
+    d = synth.warp_frame(c, 34)
+    tr.push_frames([a])                                # (the very first frame is copied into a plane of its own, not aliased)
+    tr.push_frames([b])
+    pts = tr.detect(0, 16, min_dist=12.0)
+    tr.push_frames([c])
+    ok, st, _ = tr.track(0, pts)                       # b -> c
+    tr.upload_frames([d])                              # lands in b's slot = level 0 of the previous pyramid (aliased)
+    with pytest.raises(RuntimeError, match="upload -> build -> track"):
+        tr.track(0, pts)
+    tr.build_async(False)                              # c becomes the previous image, d the current one
+    nxt, st2, _ = tr.track(0, ok[st.astype(bool)])     # c -> d works
+    assert st2.sum() >= 8
+    h.close()

@@ -450,6 +450,18 @@ extern "C" __global__ __launch_bounds__(SEQ_NT) void ba_seq_slide_kernel(const B
     if (mi[0]) {
         if (tid == 0) { sp[0] = mi[1]; sp[1] = mi[3]; }
         for (int b = tid; b < K + 4; b += SEQ_NT) { sp[2 + b] = mi[8 + b]; sp[2 + (K + 4) + b] = mi[8 + (K + 4) + b]; }
+    } else if (flag == VG_MARGIN_OLD) {
+        // A MARGIN_OLD step whose marginalization produced nothing (a non-finite solve): the frames and tracks have been shifted
+        // above, the old prior still names the un-shifted blocks -- it must not survive (the drop-in drops last_marginalization_info
+        // in the same situation, host/dropin/estimator_optimization.cpp).  The window goes on without a prior and the
+        // step reports VG_ERR_NUMERIC in info[VG_SEQ_STATUS], so that the caller can re-seed it (vg_ba_seq_import).
+        // (MARGIN_SECOND_NEW without Pose[WINDOW_SIZE - 1] in the prior legitimately produces nothing: the old prior stays, its
+        //  blocks keep their slots, estimator.cpp:933-936.)
+        if (tid == 0) {
+            sp[0] = 0; sp[1] = 0;
+            int* info = S.info + (size_t)w * VG_SEQ_INFO_INTS;
+            if (info[VG_SEQ_STATUS] == VG_OK) info[VG_SEQ_STATUS] = VG_ERR_NUMERIC;
+        }
     }
 }
 

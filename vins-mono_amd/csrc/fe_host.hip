@@ -66,6 +66,7 @@ struct FeState {
     const uint8_t** sm_base_ptrs = nullptr;
     float *lift_in = nullptr, *lift_out = nullptr;
     bool have_prev = false;
+    bool prev_clobbered = false;     // an upload has overwritten the frame slot the PREVIOUS pyramid uses as its level 0: no tracking until the next build
     std::vector<char> pushed_once;
 };
 
@@ -171,6 +172,10 @@ extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int
     // using as its level 0 -- that image is the "previous" one of the next tracking step
     s->raw_sel = s->flip ^ 1;
     s->d.raw = s->raw2[s->raw_sel];
+    // That slot may be level 0 of the PREVIOUS pyramid (frame n - 1, aliased): uploading frame n + 1 before frame n has been tracked
+    // would make vg_fe_track* read the new image as the old one.  The order upload -> build -> track is fine (the build rotates the
+    // sets); upload -> track is refused until a build has run.
+    s->prev_clobbered = s->have_prev && s->alias_on[s->flip ^ 1];
     for (int c = 0; c < s->cams; ++c) {
         HIPCHK(h, hipMemcpy2DAsync(s->raw2[s->raw_sel] + (size_t)c * npix, s->W, imgs[c], stride, s->W, s->H, hipMemcpyHostToDevice, h->stream));
     }
@@ -195,6 +200,7 @@ extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
     FeState* s = h->fe;
     if (equalize && (s->d.W % 8 || s->d.H % 8)) { h->err = "CLAHE needs width and height divisible by 8"; return VG_ERR_UNSUPPORTED; }
     const bool first = !s->have_prev;
+    s->prev_clobbered = false;
     s->flip ^= 1;                                     // previous <- current (only after the arguments are known to be valid)
     // level 0 = the frame slot itself when the frame is used as it is and sits in the slot that belongs to this pyramid set
     // (the normal alternation: upload -> build -> upload -> build); otherwise it is written into the set's own plane
@@ -254,6 +260,10 @@ extern "C" int vg_fe_track_async(vg_handle* h) {
     VG_RANGE("vg_fe_track_async");
     if (!h || !h->fe) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
+    if (s->prev_clobbered) {
+        h->err = "vg_fe_track: a frame was uploaded into the slot of the previous image since the last build (upload -> build -> track)";
+        return VG_ERR_BAD_ARG;
+    }
     int nmax = 0;
     for (int c = 0; c < s->cams; ++c) nmax = nmax > s->h_npts[c] ? nmax : s->h_npts[c];
     if (nmax == 0) return VG_OK;
@@ -285,7 +295,7 @@ extern "C" int vg_fe_track(vg_handle* h, int cam, const float* prev_xy, int n, f
     HIPCHK(h, hipMemcpyAsync(s->prev_xy + o * 2, prev_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(s->npts, s->h_npts.data(), sizeof(int) * s->cams, hipMemcpyHostToDevice, h->stream));
     int rc = vg_fe_track_async(h);
-    if (rc) return rc;
+    if (rc) { s->h_npts = saved; return rc; }
     HIPCHK(h, hipMemcpyAsync(next_xy, s->next_xy + o * 2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(status, s->status + o, n, hipMemcpyDeviceToHost, h->stream));
     if (err) HIPCHK(h, hipMemcpyAsync(err, s->err + o, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));

@@ -159,7 +159,10 @@ void ResidentEstimators::handBack(int i, Estimator& e) {
     }
     for (int k = 0; k + 2 < K; ++k) {                               // imu[k] links frame k -> k + 1 = pre_integrations[k + 1]
         const vg_imu_preint& m = imu[k];
-        if (!m.valid) continue;
+        // valid = 0 with a duration: the interval exceeded 10 s (the device marks it so that its factor is skipped, estimator.cpp:714).
+        // The reference still HOLDS such a pre-integration -- optimization() tests sum_dt itself, slideWindow() merges into it -- so the
+        // object is rebuilt with its sum_dt (and, for slot WINDOW_SIZE - 1, its samples); only a record that was never filled is absent.
+        if (!m.valid && !(m.sum_dt > 0.0)) continue;
         IntegrationBase* p = new IntegrationBase();
         p->sum_dt = m.sum_dt;
         p->delta_p = Vector3d(m.delta_p[0], m.delta_p[1], m.delta_p[2]); p->delta_v = Vector3d(m.delta_v[0], m.delta_v[1], m.delta_v[2]);
