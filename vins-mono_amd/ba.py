@@ -382,8 +382,11 @@ class Handle:
         IS ba_linacc_proj_kernel (IMU + prior + projection factors: linearise + accumulate) and the linearize class is left with the
         cost-only pass of the last candidate."""
         k = list(self.KERNEL_CLASSES)
-        if self.lib.vg_ba_batch_is_fused(self.h) == 1:
+        mode = self.lib.vg_ba_batch_is_fused(self.h)
+        if mode == 1:
             k[2] = "ba_linacc_proj_kernel"
+        elif mode == 2:
+            k[2], k[3] = "ba_linacc_proj_kernel", "ba_round_kernel"      # (no launches in class 2: the factor phases run inside ba_round_kernel)
         return k
 
     def ba_run_profiled(self):

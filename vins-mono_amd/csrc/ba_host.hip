@@ -21,6 +21,7 @@
 #include "../../include/vinsgpu.h"
 
 struct BaFork { hipStream_t aux; hipEvent_t fork, join; };
+extern "C" int ba_round_is_merged();
 extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
                                       hipEvent_t* ev, int* kinds, int* n_launches, const BaFork* fk);
 typedef int (*BaAllReduce)(void* user, double* buf, size_t count, void* stream);
@@ -213,14 +214,15 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
             static const int env_min = getenv("VG_BA_FUSED_MIN") ? atoi(getenv("VG_BA_FUSED_MIN")) : 32;
             const int la_min_windows = h->ba.fused_min >= 0 ? (h->ba.fused_min ? h->ba.fused_min : 1 << 30) : (env_min ? env_min : 1 << 30);
             const int npair = L.Kp * (L.Kp - 1) / 2;
-            const int avail = 159 * 1024 / 8 - 64;
-            int chf = (int)((avail - npair * 90 - 34) / 33.5);
+            // (the per-round kernel reports 8 KB of fixed group segment -- its non-inlined phases -- next to the dynamic LDS: 160 KB in all)
+            const int avail = (160 * 1024 - 8192 - 512) / 8;
+            int chf = (int)((avail - npair * 90 - 34 - (64 + 82 + 8 * 80) / 2) / 34.0);      // per factor: record 33 doubles + key + position (2 ints)
             chf = std::min(chf & ~1, 512);
             L.la_on = (!off && L.nwin >= la_min_windows && !L.big && !L.e && !L.t && L.Kp <= 13 && chf >= 96 && (L.Fcap + chf - 17) / (chf - 16) <= 62) ? 1 : 0;
             L.la_chf = chf; L.la_chq = chf - 16;
             L.la_P = up(chf * 33, 2);
             L.la_key = L.la_P + up(npair * 90, 2);
-            L.lds_linacc = (L.la_key + (chf + 64 + 1) / 2 + 2) * 8;
+            L.lds_linacc = (L.la_key + (2 * chf + 64 + 82 + 8 * 80 + 1) / 2 + 2) * 8;
         }
     }
     if (L.big) {
@@ -635,7 +637,9 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
         const double f_pro = 2 * np * np * np;                                                     // prior J0^T J0
         // (fused projection kernel: the factor evaluation moves to the class of the kernel that now does it)
         const double f_move = L.la_on ? it * (F * 750 + 10 * 37000.0 + 4 * np * np) : 0.0;
-        B.flops_k[0] += f_pro; B.flops_k[1] += f_lin - f_move; B.flops_k[2] += f_acc + f_move;
+        const bool merged = L.la_on && ba_round_is_merged();      // ... and in the launch of the solve phases (ba_round_kernel)
+        B.flops_k[0] += f_pro; B.flops_k[1] += f_lin - f_move;
+        B.flops_k[merged ? 3 : 2] += f_acc + f_move;
         if (L.big) {
             // large-window path: the landmark Schur complement has a kernel of its own
             B.flops_k[VG_BA_KERNEL_BIG_SCHUR] += it * schur;
@@ -845,7 +849,7 @@ extern "C" int vg_ba_set_fused_min_windows(vg_handle* h, int min_windows) {
 }
 extern "C" int vg_ba_batch_is_fused(vg_handle* h) {
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
-    return h->ba.L.la_on ? 1 : 0;
+    return h->ba.L.la_on ? (ba_round_is_merged() ? 2 : 1) : 0;
 }
 extern "C" int vg_ba_launch_stats(vg_handle* h, int* mode, long long* graph_launches, long long* graph_captures) {
     if (!h) return VG_ERR_BAD_ARG;

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <mutex>
+#include <cstring>
+#include <cstdlib>
 #include "ba_layout.h"
 #include "ba_factors.h"
 #include "../../include/vinsgpu.h"
@@ -558,6 +560,86 @@ NOINL double prior_pass(const Ctx& c_in, const double* x, double* pr_, double* g
     return cost;
 }
 
+// prior_pass for the fused factor kernel: J0 (n x n, 46 KB for n = 76) is read from HBM ONCE, into LDS, and both products -- r = r0 +
+// J0 dx and J0^T r -- run from there (prior_pass reads J0^T for the first and J0 for the second: two dependent passes over HBM).
+// All loads of J0 are issued before dx is formed, so their latency runs under that phase.  Same four-way split and the same order of
+// every sum as prior_pass: bit-identical results.  LDS at `lds_`: J0 [n][n + 1] | dx [Ncap] | part [4 Ncap]; needs n^2 <= 12 BA_NT.
+DEV double prior_staged(const Ctx& c, const BaLayout& L, const double* x, double* pr_, double* gpr_, double* lds_) {
+    const int n = c.nprior, ld = n + 1;
+    lds_d* Jl = AS_LDS(lds_);
+    lds_d* dx = Jl + ((n * ld + 1) & ~1);
+    lds_d* part = dx + L.Ncap;
+    glb_d* pr = AS_GLB(pr_);
+    glb_d* gpr = AS_GLB(gpr_);
+    const glb_i* kind = AS_GLB_CI(c.ia + L.io_pb_kind);
+    const glb_i* idx = AS_GLB_CI(c.ia + L.io_pb_idx);
+    const glb_i* off = AS_GLB_CI(c.ia + L.io_pb_off);
+    const glb_i* x0off = AS_GLB_CI(c.ia + L.io_pb_x0off);
+    const glb_d* J0 = AS_GLB_C(c.pri + L.po_J0);
+    double pj[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+        const int e = c.tid + u * BA_NT;
+        const int r = e / n, cc = e - r * n;
+        pj[u] = e < n * n ? J0[r * L.pld + cc] : 0.0;
+    }
+    for (int b = c.tid; b < c.nblk; b += BA_NT) {
+        const glb_d* xb = AS_GLB_C(state_block(L, x, kind[b], idx[b]));
+        const glb_d* x0 = AS_GLB_C(c.pri + L.po_x0 + x0off[b]);
+        lds_d* d = dx + off[b];
+        if (kind[b] == VG_BLK_SPEEDBIAS) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) d[k] = xb[k] - x0[k];
+        } else if (kind[b] == VG_BLK_TD) {
+            d[0] = xb[0] - x0[0];
+        } else {
+            d[0] = xb[0] - x0[0]; d[1] = xb[1] - x0[1]; d[2] = xb[2] - x0[2];
+            const double q0[4] = {x0[3], x0[4], x0[5], x0[6]}, qb[4] = {xb[3], xb[4], xb[5], xb[6]};
+            double qi[4], dq[4];
+            q_inv(q0, qi);
+            q_mul(qi, qb, dq);
+            const double sgn = (dq[3] >= 0) ? 2.0 : -2.0;
+            d[3] = sgn * dq[0]; d[4] = sgn * dq[1]; d[5] = sgn * dq[2];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+        const int e = c.tid + u * BA_NT;
+        const int r = e / n, cc = e - r * n;
+        if (e < n * n) Jl[r * ld + cc] = pj[u];
+    }
+    __syncthreads();
+    const glb_d* r0 = AS_GLB_C(c.pri + L.po_r0);
+    double cost = 0.0;
+    for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
+        const int r = w % L.Ncap, q = w / L.Ncap;
+        double sacc = 0.0;
+        if (r < n)
+            for (int k = q; k < n; k += 4) sacc += Jl[r * ld + k] * dx[k];
+        part[w] = sacc;
+    }
+    __syncthreads();
+    lds_d* rl = dx;                              // the residual replaces dx
+    double rv = 0.0;
+    const bool own = c.tid < n;                  // (n <= Ncap <= BA_NT / 4)
+    if (own) rv = r0[c.tid] + ((part[c.tid] + part[L.Ncap + c.tid]) + (part[2 * L.Ncap + c.tid] + part[3 * L.Ncap + c.tid]));
+    __syncthreads();
+    if (own) { pr[c.tid] = rv; rl[c.tid] = rv; cost += rv * rv; }
+    __syncthreads();
+    for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
+        const int a = w % L.Ncap, q = w / L.Ncap;
+        double sacc = 0.0;
+        if (a < n)
+            for (int k = q; k < n; k += 4) sacc += Jl[k * ld + a] * rl[k];
+        part[w] = sacc;
+    }
+    __syncthreads();
+    for (int a = c.tid; a < n; a += BA_NT)
+        gpr[a] = (part[a] + part[L.Ncap + a]) + (part[2 * L.Ncap + a] + part[3 * L.Ncap + a]);
+    __syncthreads();
+    return cost;
+}
+
 // inputs of one projection factor, copied into registers through global-memory typed loads (the state / observation
 // pointers are generic: reading the factor's 38 doubles through them would be 38 flat_loads)
 struct ProjIn {
@@ -950,9 +1032,14 @@ extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(con
 // 256-window launch, profiles/r03s_pmc_hbm.txt) are gone, and so is one launch per round.
 #define LA_NT BA_NT                // (imu_pass / prior_pass are written for BA_NT threads)
 #define LA_RS 33                  // doubles per staged record: rows at 0 and 16, odd stride (conflict-free b64 stores by thread)
-#define LA_MAXP 10                // pairs per wavefront: Kp (Kp - 1) / 2 <= 78 for Kp <= 13, 8 wavefronts
+#define LA_NPW 6                  // wavefronts that own pair blocks; the other two of the workgroup take the landmark sums
+#define LA_MAXP 13                // pairs per pair wavefront: Kp (Kp - 1) / 2 <= 78 for Kp <= 13
+#define LA_QCAP 80                // pairs a window can have (78 for Kp = 13), padded
 #define LA_PAIR 90                // kept doubles of a pair block: ii 21 | jj 21 | ji 36 (row = target's column, col = anchor's) | gi 6 | gj 6
-extern "C" __global__ __launch_bounds__(LA_NT) void ba_linacc_proj_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+// pairs (i, j), i < j, enumerated by distance d = j - i first: q = (d - 1) Kp - (d - 1) d / 2 + i.  The pairs of one distance -- and the
+// near-diagonal ones carry most factors -- are consecutive, so q mod LA_NPW deals them evenly to the pair wavefronts.
+DEV int la_pair_q(int i, int j, int Kp) { const int d = j - i; return (d - 1) * Kp - (d - 1) * d / 2 + i; }
+__device__ __forceinline__ void linacc_body(const BaLayout* __restrict__ Lp, const BaPtrs& P) {
     const BaLayout L = layout_load(Lp);
     Ctx c;
     ctx_init(c, Lp, P, blockIdx.x);
@@ -965,20 +1052,32 @@ extern "C" __global__ __launch_bounds__(LA_NT) void ba_linacc_proj_kernel(const 
     const glb_i* ia = AS_GLB_CI(c.ia);
     lds_d* rec = AS_LDS(LDSB);
     lds_d* Pb = AS_LDS(LDSB + L.la_P);
-    lds_i* key = (lds_i*)(LDSB + L.la_key);
-    lds_i* lstart = key + L.la_chf;
+    lds_i* key = (lds_i*)(LDSB + L.la_key);          // (anchor << 4 | target) of the factor a chunk thread evaluated
+    lds_i* lstart = key + L.la_chf;                   // [64] first landmark of every chunk
+    lds_i* posx = lstart + 64;                        // [la_chf] where that thread's record was staged (records are grouped by pair)
+    lds_i* pstart = posx + L.la_chf;                  // [LA_QCAP + 1] first record of every pair in the chunk
+    lds_i* wcnt = pstart + LA_QCAP + 2;               // [LA_NT / 64][LA_QCAP] factors of pair q evaluated by wavefront w
     __shared__ double red[2 * (LA_NT / 64)];
     const int Kp = L.Kp, npair = Kp * (Kp - 1) / 2, chq = L.la_chq;
-    const int nL = c.nL, nF = c.nF;
-    // ---- the IMU factors and the prior of the same point, by this workgroup too (they used to be a launch of their own,
-    //      ba_linearize_imu_kernel: ~35 us per round for ~10 us of work -- the rest was launch ramp and first-touch latency).
-    //      Their LDS scratch (sqrt_info copies + weighted panels / dx + partial sums) is the start of the record area.
+    const int nL = c.nL;
+    DP_DECL;
+    // ---- the prior and the IMU factors of the same point, by this workgroup too (they used to be a launch of their own,
+    //      ba_linearize_imu_kernel).  Their LDS scratch (J0 copy, dx, partial sums / sqrt_info copies, weighted panels) is the start
+    //      of the record area.
     {
-        double share = imu_pass<true>(c, x, lin_buf(c, which) + L.bo_imuJ, 0, L.K - 1);
-        share += prior_pass(c, x, lin_buf(c, which) + L.bo_pr, lin_buf(c, which) + L.bo_gpr, LDSB);
+        double share = 0.0;
+        if (c.nprior > 0) {
+            if (c.nprior * c.nprior <= 12 * LA_NT && 4 * L.Ncap <= 4 * LA_NT && (c.nprior * (c.nprior + 1) + 2 + 5 * L.Ncap) <= L.la_P)
+                share = prior_staged(c, L, x, lin_buf(c, which) + L.bo_pr, lin_buf(c, which) + L.bo_gpr, LDSB);
+            else
+                share = prior_pass(c, x, lin_buf(c, which) + L.bo_pr, lin_buf(c, which) + L.bo_gpr, LDSB);
+        }
+        DP_ADD(23);
+        share += imu_pass<true>(c, x, lin_buf(c, which) + L.bo_imuJ, 0, L.K - 1);
         const double tot_imu = block_sum(red, LA_NT / 64, c.lane, c.wave, share);
         for (int g = c.tid; g < L.nbl - L.nbf; g += LA_NT) c.sc[L.so_part + L.nbf + g] = g == 0 ? tot_imu : 0.0;
         __syncthreads();
+        DP_ADD(22);
     }
     const int nchunk = nL > 0 ? uni(ia[L.io_lm_fbeg + nL - 1] / chq + 1) : 0;     // (the LAST landmark's chunk: a chunk is never empty, landmarks have <= Kp - 1 factors)
     // first landmark of every chunk
@@ -988,129 +1087,173 @@ extern "C" __global__ __launch_bounds__(LA_NT) void ba_linacc_proj_kernel(const 
     }
     if (c.tid == 0) lstart[nchunk] = nL;
     for (int e = c.tid; e < npair * LA_PAIR; e += LA_NT) Pb[e] = 0.0;
-    // the pairs of this wavefront: p = wave + 8 k  <->  (i, j), i < j, p = j (j - 1) / 2 + i
-    int pkey[LA_MAXP];
-#pragma unroll
-    for (int k = 0; k < LA_MAXP; ++k) {
-        const int p = c.wave + 8 * k;
-        int a = 0, b = 0;
-        tri_decode(p < npair ? p : 0, a, b);
-        pkey[k] = p < npair ? uni(b * 16 + a + 1) : -1;
-    }
+    // Wavefronts 0 .. LA_NPW-1 own the pair blocks (pair q -> wavefront q mod LA_NPW), the last two the landmark sums: the two phases
+    // of a chunk only READ the staged records, so they run side by side (MFMA + LDS reads there, VALU + HBM stores here).
+    const bool pair_wave = c.wave < LA_NPW;
     __syncthreads();
+    DP_ADD(24);
+    // where the four accumulator entries of this lane go inside a pair block (-1: not kept)
+    int pidx[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = (c.lane >> 4) + 4 * reg, col = c.lane & 15;
+        int idx = -1;
+        if (row < 6) {
+            if (col <= row) idx = row * (row + 1) / 2 + col;              // ii
+            else if (col == 13) idx = 78 + row;                           // gi
+        } else if (row < 12) {
+            if (col < 6) idx = 42 + (row - 6) * 6 + col;                  // ji
+            else if (col <= row && col < 12) idx = 21 + (row - 6) * (row - 5) / 2 + (col - 6);   // jj
+            else if (col == 13) idx = 84 + (row - 6);                     // gj
+        }
+        pidx[reg] = idx;
+    }
     double cost = 0.0;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int l0 = lstart[ch], l1 = lstart[ch + 1];
         const int f0 = ia[L.io_lm_fbeg + l0], f1 = ia[L.io_lm_fbeg + l1];
         const int nf = uni(f1 - f0);
         if (nf > L.la_chf) __builtin_trap();                  // (a landmark with more than Kp - 1 factors: the packer never builds one)
-        // ---- (1) linearise
+        // ---- (1) where every record goes: the records of a chunk are staged GROUPED BY PAIR (a pair's factors are scattered over the
+        //      landmark-major factor list: found by ballots over 64-factor blocks they came one or two per MFMA trip).  Stable
+        //      counting sort by pair index: rank among the same pair inside the wavefront (ballots), wavefront counts and pair
+        //      starts through LDS -- the order inside a pair is the factor order, whatever the timing: bit-reproducible sums.
+        ProjIn pin;
+        int q = -1, rank = 0;
         if (c.tid < nf) {
-            ProjIn pin;
             proj_fetch(c, f0 + c.tid, x, lam, pin);
+            q = la_pair_q(pin.i, pin.j, Kp);
+        }
+        for (int e = c.tid; e < (LA_NT / 64) * LA_QCAP; e += LA_NT) wcnt[e] = 0;
+        __syncthreads();
+        {
+            unsigned long long todo = __ballot(q >= 0);
+            const unsigned long long lt = (1ull << c.lane) - 1ull;
+            while (todo) {
+                const int q0 = __builtin_amdgcn_readlane(q, (int)__builtin_ctzll(todo));      // (v_readlane: the lane index is uniform)
+                const unsigned long long m = __ballot(q == q0);
+                if (q == q0) rank = __popcll(m & lt);
+                if (c.lane == (int)__builtin_ctzll(m)) wcnt[c.wave * LA_QCAP + q0] = __popcll(m);
+                todo &= ~m;
+            }
+        }
+        __syncthreads();
+        if (c.tid < npair) {                                   // pair totals; the wavefront counts become offsets inside the pair
+            int run = 0;
+            for (int w = 0; w < LA_NT / 64; ++w) { const int v = wcnt[w * LA_QCAP + c.tid]; wcnt[w * LA_QCAP + c.tid] = run; run += v; }
+            pstart[c.tid + 1] = run;
+        }
+        __syncthreads();
+        if (c.tid == 0) {
+            int run = 0;
+            pstart[0] = 0;
+            for (int p = 0; p < npair; ++p) { run += pstart[p + 1]; pstart[p + 1] = run; }
+        }
+        __syncthreads();
+        // ---- (2) linearise, record to its sorted place
+        if (c.tid < nf) {
+            const int pos = pstart[q] + wcnt[c.wave * LA_QCAP + q] + rank;
             double r[2], Ji[12], Jj[12], Jl[2];
             proj_eval<false, true, false>(pin.pi, pin.pj, pin.ex, pin.lam, pin.oi, pin.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, nullptr, Jl, nullptr);
             const double s = r[0] * r[0] + r[1] * r[1];
             const double sq = sqrt(1.0 / (1.0 + s));
-            lds_d* q = rec + c.tid * LA_RS;
+            lds_d* qr = rec + pos * LA_RS;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                q[k] = sq * Ji[k]; q[16 + k] = sq * Ji[6 + k];
-                q[6 + k] = sq * Jj[k]; q[22 + k] = sq * Jj[6 + k];
+                qr[k] = sq * Ji[k]; qr[16 + k] = sq * Ji[6 + k];
+                qr[6 + k] = sq * Jj[k]; qr[22 + k] = sq * Jj[6 + k];
             }
-            q[12] = sq * Jl[0]; q[28] = sq * Jl[1];
-            q[13] = sq * r[0]; q[29] = sq * r[1];
+            qr[12] = sq * Jl[0]; qr[28] = sq * Jl[1];
+            qr[13] = sq * r[0]; qr[29] = sq * r[1];
             key[c.tid] = pin.i * 16 + pin.j;
+            posx[c.tid] = pos;
             cost += log1p(s);
         }
         __syncthreads();
-        // ---- (2) pair blocks on MFMA
-        {
+        DP_ADD(25);
+        if (pair_wave) {
+            // ---- (3) pair blocks on MFMA: the factors of a pair are contiguous; four per trip -- both operand reads, then both MFMAs
             double4_t acc[LA_MAXP];
 #pragma unroll
             for (int k = 0; k < LA_MAXP; ++k) acc[k] = (double4_t){0, 0, 0, 0};
             const int k4 = c.lane >> 4, col = c.lane & 15;
             const int xo = (k4 & 1) * 16 + col;               // this lane's element of a record: row k4 & 1, column col
-            for (int b0 = 0; b0 < nf; b0 += 64) {
-                const int kk = b0 + c.lane < nf ? key[b0 + c.lane] : -2;
-#pragma unroll
-                for (int k = 0; k < LA_MAXP; ++k) {
-                    if (pkey[k] < 0) continue;                // (uniform)
-                    unsigned long long m = __ballot(kk == pkey[k]);
-                    while (m) {
-                        const int fa = b0 + (int)__builtin_ctzll(m);
-                        m &= m - 1;
-                        int fb = -1;
-                        if (m) { fb = b0 + (int)__builtin_ctzll(m); m &= m - 1; }
-                        const int fs = (k4 >> 1) ? fb : fa;
-                        const double v = (fs >= 0 && col < 14) ? rec[fs * LA_RS + xo] : 0.0;
-                        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc[k], 0, 0, 0);
-                    }
-                }
-            }
-            // D[row = (lane >> 4) + 4 reg][col = lane & 15] -> the kept entries of the pair block
+            const int hi = k4 >> 1;
+            const bool incol = col < 14;
 #pragma unroll
             for (int k = 0; k < LA_MAXP; ++k) {
-                if (pkey[k] < 0) continue;
-                lds_d* pb = Pb + (c.wave + 8 * k) * LA_PAIR;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int row = k4 + 4 * reg;
-                    int idx = -1;
-                    if (row < 6) {
-                        if (col <= row) idx = row * (row + 1) / 2 + col;              // ii
-                        else if (col == 13) idx = 78 + row;                           // gi
-                    } else if (row < 12) {
-                        if (col < 6) idx = 42 + (row - 6) * 6 + col;                  // ji
-                        else if (col <= row && col < 12) idx = 21 + (row - 6) * (row - 5) / 2 + (col - 6);   // jj
-                        else if (col == 13) idx = 84 + (row - 6);                     // gj
-                    }
-                    if (idx >= 0) pb[idx] += acc[k][reg];
+                const int qk = c.wave + LA_NPW * k;
+                if (qk >= npair) continue;                    // (uniform)
+                const int pb0 = uni(pstart[qk]), pe0 = uni(pstart[qk + 1]);
+                DP_ADD(29);
+                for (int e = pb0; e < pe0; e += 4) {
+                    const int f0r = e + hi, f1r = e + 2 + hi;
+                    const double v0 = (f0r < pe0 && incol) ? rec[f0r * LA_RS + xo] : 0.0;
+                    const double v1 = (f1r < pe0 && incol) ? rec[f1r * LA_RS + xo] : 0.0;
+                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc[k], 0, 0, 0);
+                    if (e + 2 < pe0) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc[k], 0, 0, 0);      // (uniform)
                 }
+                DP_ADD(30);
             }
-        }
-        // ---- (3) landmark sums: thread per landmark of the chunk, its records are contiguous; the W column is written as the
-        //      factors come by (targets ascend), zeros in between, the anchor's rows (a sum over all factors) last
-        if (c.tid < l1 - l0) {
-            const int l = l0 + c.tid;
-            glb_d* Wt = buf + L.bo_Wt + l;
-            const size_t ldw = L.Lcap;
-            const int fb = ia[L.io_lm_fbeg + l] - f0, fe = ia[L.io_lm_fbeg + l + 1] - f0;
-            double h = 0.0, b = 0.0, wi[6] = {0, 0, 0, 0, 0, 0};
-            const int anchor = fb < fe ? key[fb] >> 4 : -1;
-            int jn = 0;
-            for (int f = fb; f < fe; ++f) {
-                const lds_d* q = rec + f * LA_RS;
-                const int j = key[f] & 15;
-                const double l0v = q[12], l1v = q[28];
-                double v[6];
+            // D[row = (lane >> 4) + 4 reg][col = lane & 15] -> the kept entries of the pair block, added to the pair table (the first chunk
+            // stores; later chunks read the four entries of a lane together, then write)
 #pragma unroll
-                for (int k = 0; k < 6; ++k) v[k] = q[6 + k] * l0v + q[22 + k] * l1v;
-                h += l0v * l0v + l1v * l1v;
-                b += l0v * q[13] + l1v * q[29];
+            for (int k = 0; k < LA_MAXP; ++k) {
+                if (c.wave + LA_NPW * k >= npair) continue;
+                lds_d* pb = Pb + (c.wave + LA_NPW * k) * LA_PAIR;
+                double old4[4];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) wi[k] += q[k] * l0v + q[16 + k] * l1v;
-                for (; jn < j; ++jn) {
+                for (int reg = 0; reg < 4; ++reg) old4[reg] = (ch > 0 && pidx[reg] >= 0) ? pb[pidx[reg]] : 0.0;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (pidx[reg] >= 0) pb[pidx[reg]] = old4[reg] + acc[k][reg];
+            }
+            DP_ADD(26);
+        } else {
+            // ---- (3) landmark sums: thread per landmark of the chunk, its records are contiguous; the W column is written as the
+            //      factors come by (targets ascend), zeros in between, the anchor's rows (a sum over all factors) last
+            for (int t = c.tid - LA_NPW * 64; t < l1 - l0; t += LA_NT - LA_NPW * 64) {
+                const int l = l0 + t;
+                glb_d* Wt = buf + L.bo_Wt + l;
+                const size_t ldw = L.Lcap;
+                const int fb = ia[L.io_lm_fbeg + l] - f0, fe = ia[L.io_lm_fbeg + l + 1] - f0;
+                double h = 0.0, b = 0.0, wi[6] = {0, 0, 0, 0, 0, 0};
+                const int anchor = fb < fe ? key[fb] >> 4 : -1;
+                int jn = 0;
+                for (int f = fb; f < fe; ++f) {
+                    const lds_d* q = rec + posx[f] * LA_RS;
+                    const int j = key[f] & 15;
+                    const double l0v = q[12], l1v = q[28];
+                    double v[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) v[k] = q[6 + k] * l0v + q[22 + k] * l1v;
+                    h += l0v * l0v + l1v * l1v;
+                    b += l0v * q[13] + l1v * q[29];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) wi[k] += q[k] * l0v + q[16 + k] * l1v;
+                    for (; jn < j; ++jn) {
+                        if (jn == anchor) continue;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * jn + k) * ldw] = 0.0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * j + k) * ldw] = v[k];
+                    jn = j + 1;
+                }
+                for (; jn < Kp; ++jn) {
                     if (jn == anchor) continue;
 #pragma unroll
                     for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * jn + k) * ldw] = 0.0;
                 }
+                if (anchor >= 0) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * j + k) * ldw] = v[k];
-                jn = j + 1;
+                    for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * anchor + k) * ldw] = wi[k];
+                }
+                for (int row = 6 * Kp; row < L.RcPad; ++row) Wt[(size_t)row * ldw] = 0.0;
+                buf[L.bo_h + l] = h;
+                buf[L.bo_b + l] = b;
             }
-            for (; jn < Kp; ++jn) {
-                if (jn == anchor) continue;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * jn + k) * ldw] = 0.0;
-            }
-            if (anchor >= 0) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) Wt[(size_t)(6 * anchor + k) * ldw] = wi[k];
-            }
-            for (int row = 6 * Kp; row < L.RcPad; ++row) Wt[(size_t)row * ldw] = 0.0;
-            buf[L.bo_h + l] = h;
-            buf[L.bo_b + l] = b;
+            DP_ADD(27);
         }
         __syncthreads();                                      // records and keys consumed
     }
@@ -1129,24 +1272,26 @@ extern "C" __global__ __launch_bounds__(LA_NT) void ba_linacc_proj_kernel(const 
                 int row, colm;
                 tri_decode(e, row, colm);
                 const int br = row / 6, pr = row - 6 * br, bc = colm / 6, pc = colm - 6 * bc;
-                if (br != bc) s = Pb[(br * (br - 1) / 2 + bc) * LA_PAIR + 42 + pr * 6 + pc];
+                if (br != bc) s = Pb[la_pair_q(bc, br, Kp) * LA_PAIR + 42 + pr * 6 + pc];
                 else {
                     const int t = pr * (pr + 1) / 2 + pc;
-                    for (int j = br + 1; j < Kp; ++j) s += Pb[(j * (j - 1) / 2 + br) * LA_PAIR + t];
-                    for (int i = 0; i < br; ++i) s += Pb[(br * (br - 1) / 2 + i) * LA_PAIR + 21 + t];
+                    for (int j = br + 1; j < Kp; ++j) s += Pb[la_pair_q(br, j, Kp) * LA_PAIR + t];
+                    for (int i = 0; i < br; ++i) s += Pb[la_pair_q(i, br, Kp) * LA_PAIR + 21 + t];
                 }
                 buf[L.bo_Sp + e] = s;
             } else {
                 const int g = e - nent, a = g / 6, k = g - 6 * a;
-                for (int j = a + 1; j < Kp; ++j) s += Pb[(j * (j - 1) / 2 + a) * LA_PAIR + 78 + k];
-                for (int i = 0; i < a; ++i) s += Pb[(a * (a - 1) / 2 + i) * LA_PAIR + 84 + k];
+                for (int j = a + 1; j < Kp; ++j) s += Pb[la_pair_q(a, j, Kp) * LA_PAIR + 78 + k];
+                for (int i = 0; i < a; ++i) s += Pb[la_pair_q(i, a, Kp) * LA_PAIR + 84 + k];
                 buf[L.bo_gp + g] = s;
             }
         }
     }
     const double tot = block_sum(red, LA_NT / 64, c.lane, c.wave, cost);
+    DP_ADD(28);
     if (c.tid < L.nbf) c.sc[L.so_part + c.tid] = c.tid == 0 ? tot : 0.0;
 }
+extern "C" __global__ __launch_bounds__(LA_NT) void ba_linacc_proj_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { linacc_body(Lp, P); }
 
 // ================================================================================================
 // Solve kernel
@@ -2232,7 +2377,7 @@ DEV double state_sqnorm_share(const BaLayout& L, const double* x, const double* 
     return s;
 }
 
-extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+__device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, const BaPtrs& P) {
     const BaLayout L = layout_load(Lp);
     Ctx c;
     const int w = blockIdx.x;
@@ -2562,6 +2707,22 @@ extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaL
     __syncthreads();
     if (c.tid == 0) ctl_store(s, ctlp);
     PROF_ADD(PF_TAIL);
+}
+extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { solve_body(Lp, P); }
+
+// One launch per trust-region round (batches that take the fused factor kernel): the factors of the round are linearised and
+// accumulated, then -- same workgroup, same window -- the pending candidate is judged and the next step formed.  The two bodies are
+// the kernels above, unchanged; they hand over through the linearisation buffer in HBM as before (written and read by the same
+// CU: a device-scope fence + barrier in between), so results are bit-identical to the two launches; what goes away is a launch
+// boundary per round and the cold start of the solve kernel (kernarg, instruction fetch, first HBM round trip).
+// (a real call: inlined next to the solve body the two phases' live ranges are allocated together -- 53 spilled VGPRs and 408 B of
+//  private segment against 8 / 168 for the solve kernel alone; nothing is live in the caller at this point, so the call is free)
+NOINL void linacc_call(const BaLayout* Lp, BaPtrs P) { linacc_body(Lp, P); }
+extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_round_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    linacc_call(Lp, P);
+    __threadfence();
+    __syncthreads();
+    solve_body(Lp, P);
 }
 
 // ================================================================================================
@@ -3492,6 +3653,7 @@ static hipError_t set_lds_attrs() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linacc_proj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
     // (these two also hold a few statically allocated LDS words: static + dynamic must stay within 160 KB)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linearize_imu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_eval_factors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -3519,6 +3681,12 @@ extern "C" const char* ba_failed_launch() { return g_failed_launch; }
 // after every launch (ev[0] before the first), kinds[i] = kernel class of the launch that ends at ev[i + 1] (0 prologue,
 // 1 linearize, 2 accumulate, 3 solve, 4 final); the caller provides 4 * rounds + 5 events.
 struct BaFork { hipStream_t aux; hipEvent_t fork, join; };
+// ba_round_kernel (both bodies in ONE launch per round) is kept as an experiment behind VG_BA_ROUND_MERGED=1: measured SLOWER than
+// the two launches (same box, same call, profiles/r04h_bench_{merged,two}.json: 280 us per round against 103 + 149 us, 91.0K against
+// 111.9K solves/s) -- the merged kernel carries the factor phase's frame next to the solve phases' (440 B of private segment) and a
+// device-scope fence, and what it saves (one launch boundary) is a few microseconds.
+static const bool g_round_merged = getenv("VG_BA_ROUND_MERGED") && !strcmp(getenv("VG_BA_ROUND_MERGED"), "1");
+extern "C" int ba_round_is_merged() { return g_round_merged ? 1 : 0; }
 extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
                                       hipEvent_t* ev, int* kinds, int* n_launches, const BaFork* fk) {
     hipError_t e = set_lds_attrs();
@@ -3542,6 +3710,12 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
             if ((e = hipEventRecord(fk->join, fk->aux)) != hipSuccess) return e;
         } else {
             LAUNCH(ba_linearize_imu_kernel, dim3(L.nig + L.nprw, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only);
+        }
+        const bool merged = fused && g_round_merged;      // ... and the solve phases in the same launch
+        if (merged) {
+            LAUNCH(ba_round_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_linacc > L.lds_solve ? L.lds_linacc : L.lds_solve, dL, P);
+            if (kinds) kinds[nk++] = 3;
+            continue;
         }
         if (fused) LAUNCH(ba_linacc_proj_kernel, dim3(L.nwin), dim3(LA_NT), L.lds_linacc, dL, P);
         else LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only);
