@@ -45,6 +45,12 @@ int vg_create(vg_handle** out);                 /* uses the current HIP device, 
 int vg_destroy(vg_handle* h);
 int vg_sync(vg_handle* h);                      /* hipStreamSynchronize(handle stream)           */
 const char* vg_last_error(vg_handle* h);        /* text of the last failure on this handle       */
+/* ABI 8.  Page-lock a host buffer the caller will hand to the upload entry points again and again (an image ring buffer, a staging
+ * area): hipHostRegister / hipHostUnregister.  Uploads from registered memory run at the PCIe rate instead of through the runtime's
+ * pageable-copy staging (measured for 256 frames of 752x480: bench.py fe.upload_inclusive).  Optional: every entry point takes
+ * pageable memory too. */
+int vg_host_register(vg_handle* h, void* p, size_t bytes);
+int vg_host_unregister(vg_handle* h, void* p);
 void* vg_stream(vg_handle* h);                  /* the handle's hipStream_t (as void*)           */
 /* HIP-event stopwatch on the handle's stream (used by bench.py for roofline.achieved) */
 int vg_timer_start(vg_handle* h);

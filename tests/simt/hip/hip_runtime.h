@@ -223,6 +223,9 @@ hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void* p);
+enum { hipHostRegisterDefault = 0 };
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }      // (host memory is host memory here)
+inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = nullptr);
 hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t st = nullptr);

@@ -243,6 +243,8 @@ class Handle:
         L.vg_ba_set_marg_mode.argtypes = [C.c_void_p, C.c_int]
         L.vg_ba_set_launch_mode.argtypes = [C.c_void_p, C.c_int]
         L.vg_ba_set_fused_min_windows.argtypes = [C.c_void_p, C.c_int]
+        L.vg_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.vg_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
         L.vg_ba_launch_stats.argtypes = [C.c_void_p, _pi, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         if hasattr(L, 'vg_ba_rccl_init'):            # (absent from the CPU-emulated build of tests/simt)
             L.vg_ba_rccl_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
@@ -314,6 +316,13 @@ class Handle:
     def ba_set_launch_mode(self, mode):
         """VG_LAUNCH_DIRECT (0) / VG_LAUNCH_GRAPH (1): one launch per kernel, or the captured pipeline replayed as a hipGraph."""
         self._chk(self.lib.vg_ba_set_launch_mode(self.h, int(mode)), "vg_ba_set_launch_mode")
+
+    def host_register(self, arr):
+        """Page-lock a numpy array that will be handed to the upload entry points repeatedly (vg_host_register)."""
+        self._chk(self.lib.vg_host_register(self.h, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes)), "vg_host_register")
+
+    def host_unregister(self, arr):
+        self._chk(self.lib.vg_host_unregister(self.h, C.c_void_p(arr.ctypes.data)), "vg_host_unregister")
 
     def ba_set_fused_min_windows(self, n):
         """Batches of at least n windows take the fused linearise + accumulate kernel (0 = never; default 32): vg_ba_set_fused_min_windows."""

@@ -176,8 +176,17 @@ extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int
     // would make vg_fe_track* read the new image as the old one.  The order upload -> build -> track is fine (the build rotates the
     // sets); upload -> track is refused until a build has run.
     s->prev_clobbered = s->have_prev && s->alias_on[s->flip ^ 1];
-    for (int c = 0; c < s->cams; ++c) {
-        HIPCHK(h, hipMemcpy2DAsync(s->raw2[s->raw_sel] + (size_t)c * npix, s->W, imgs[c], stride, s->W, s->H, hipMemcpyHostToDevice, h->stream));
+    // frames that follow each other in memory without padding (one buffer for all streams: a ring of a capture driver, the bench's
+    // staging area) travel as ONE copy; otherwise one copy per stream (2-D when the rows are padded)
+    bool contiguous = stride == s->W;
+    for (int c = 1; c < s->cams && contiguous; ++c) contiguous = imgs[c] == imgs[c - 1] + npix;
+    if (contiguous) {
+        HIPCHK(h, hipMemcpyAsync(s->raw2[s->raw_sel], imgs[0], npix * s->cams, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int c = 0; c < s->cams; ++c) {
+            if (stride == s->W) HIPCHK(h, hipMemcpyAsync(s->raw2[s->raw_sel] + (size_t)c * npix, imgs[c], npix, hipMemcpyHostToDevice, h->stream));
+            else HIPCHK(h, hipMemcpy2DAsync(s->raw2[s->raw_sel] + (size_t)c * npix, s->W, imgs[c], stride, s->W, s->H, hipMemcpyHostToDevice, h->stream));
+        }
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return VG_OK;

@@ -64,6 +64,18 @@ extern "C" int vg_sync(vg_handle* h) {
 }
 
 extern "C" const char* vg_last_error(vg_handle* h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" int vg_host_register(vg_handle* h, void* p, size_t bytes) {
+    if (!h || !p || !bytes) return VG_ERR_BAD_ARG;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { h->err = std::string("vg_host_register: ") + hipGetErrorString(e); return VG_ERR_HIP; }
+    return VG_OK;
+}
+extern "C" int vg_host_unregister(vg_handle* h, void* p) {
+    if (!h || !p) return VG_ERR_BAD_ARG;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { h->err = std::string("vg_host_unregister: ") + hipGetErrorString(e); return VG_ERR_HIP; }
+    return VG_OK;
+}
 extern "C" void* vg_stream(vg_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 extern "C" int vg_timer_start(vg_handle* h) {
