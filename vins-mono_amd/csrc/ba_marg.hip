@@ -697,6 +697,85 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
 // otherwise) — the same order as the part the eigenvalue cut removes.  75 dependent pivots instead of ~7 Jacobi sweeps of 75
 // rounds: 1.41M -> ~0.1M cycles per window.  b' rides along as an augmented row, so r0 needs no separate substitution.
 // On exit: column k of L at V[k * ld + i] (k < rank; zero for the rows pivoted earlier), y = r0 in cs[2n .. 3n).  Returns rank.
+#ifndef MG_SQRT_RIGHT_LOOKING
+// LEFT-looking (round 4): the Schur complement is never formed.  Column k of L is computed when its pivot p is chosen,
+//     L[i][k] = (A'[i][p] - sum_{j<k} L[i][j] L[p][j]) / sqrt(pivot),
+// by eight lanes per row (lane `part` takes j = part, part + 8, ...; sum on the DPP network), the augmented row i = n carries b'
+// (y_k = (b'_p - sum_j y_j L[p][j]) / l_pp), and the running diagonal d_i -= L[i][k]^2 lives in LDS twice (read one copy, write the
+// other: a wavefront that is already updating must not change what a slower one is still searching) -- ONE barrier per pivot instead
+// of two, and ~k/4 FMAs per lane instead of an update of the whole trailing matrix: 265K -> ~100K cycles per window for n = 76.
+// (The right-looking form -- Schur complement in registers, two barriers per pivot -- is kept behind -DMG_SQRT_RIGHT_LOOKING.)
+// Same pivot rule (largest remaining diagonal, lowest index on ties), same cut, same output layout; the sums run in another order.
+DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, const double* bglob) {
+    const double* A = MG_LDS + offM;          // A' (lower triangle read)
+    double* Lc = MG_LDS + offV;               // column k of L at Lc[k * ld + i]
+    double* dg0 = MG_LDS + offcs;             // running diagonal, copy 0 (-1e300 once pivoted)
+    double* yv = dg0 + 2 * n + 1;             // y = L^-1 P^T b'   (kept for the caller: cs[2n + 1 ..))
+    double* dg1 = yv + n;                     // running diagonal, copy 1
+    (void)offred;
+    __syncthreads();
+    for (int k = c.tid; k < n * ld; k += MG_NT) Lc[k] = 0.0;
+    for (int i = c.tid; i < n; i += MG_NT) { yv[i] = 0.0; dg0[i] = A[i * ld + i]; }
+    // MG_LPR lanes per row (8 with 1024 threads, 4 with 512): rows 0 .. n-1 of L and row n = the augmented one (n <= 96 < 128)
+    enum { MG_LPR = MG_NT / 128, MG_LPR_SHIFT = MG_LPR == 8 ? 3 : 2 };
+    static_assert(MG_LPR == 8 || MG_LPR == 4, "sqrt_factor: 512 or 1024 threads");
+    const int row = c.tid >> MG_LPR_SHIFT, part = c.tid & (MG_LPR - 1);
+    const bool has_row = row <= n;
+    int rank = 0;
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        const double* dgr = (k & 1) ? dg1 : dg0;
+        double* dgw = (k & 1) ? dg0 : dg1;
+        // pivot = largest remaining diagonal (lowest index on ties): every wavefront on its own, two entries per lane
+        const int i0 = c.lane, i1 = c.lane + 64;
+        const double v0 = i0 < n ? dgr[i0] : -1e300;
+        const double v1 = i1 < n ? dgr[i1] : -1e300;
+        const double best = wave_max_all(fmax(v0, v1));
+        const unsigned long long m0 = __ballot(v0 == best), m1 = __ballot(v1 == best);
+        const int p = m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1;
+        if (!(best > MG_EPS)) break;          // (uniform) nothing above eps is left: the rest is what the reference's cut drops
+        const double inv = mg_rsqrt(best);
+        // lane `part` of a row takes j = part, part + 8, ...: two independent partial sums (the LDS reads of two terms in flight)
+        double s0 = 0.0, s1 = 0.0;
+        if (has_row) {
+            int j = part;
+            if (row < n) {
+                for (; j + MG_LPR < k; j += 2 * MG_LPR) {
+                    const double a0 = Lc[j * ld + row], b0 = Lc[j * ld + p], a1 = Lc[(j + MG_LPR) * ld + row], b1 = Lc[(j + MG_LPR) * ld + p];
+                    s0 += a0 * b0; s1 += a1 * b1;
+                }
+                if (j < k) s0 += Lc[j * ld + row] * Lc[j * ld + p];
+            } else {
+                for (; j + MG_LPR < k; j += 2 * MG_LPR) {
+                    const double a0 = yv[j], b0 = Lc[j * ld + p], a1 = yv[j + MG_LPR], b1 = Lc[(j + MG_LPR) * ld + p];
+                    s0 += a0 * b0; s1 += a1 * b1;
+                }
+                if (j < k) s0 += yv[j] * Lc[j * ld + p];
+            }
+        }
+        double sacc = s0 + s1;
+        // sum over the eight lanes of the row on the DPP network (fixed order), result in every lane of the group
+        sacc += dpp_mov_f64<0xB1>(sacc);      // quad_perm [1,0,3,2]
+        sacc += dpp_mov_f64<0x4E>(sacc);      // quad_perm [2,3,0,1]
+        if (MG_LPR == 8) sacc += dpp_mov_f64<0x141>(sacc);     // row_half_mirror
+        if (has_row && part == 0) {
+            if (row < n) {
+                const double d = dgr[row];
+                double v = 0.0;
+                if (row == p) v = best * inv;
+                else if (d > -1e299) v = (A[(row > p ? row : p) * ld + (row > p ? p : row)] - sacc) * inv;
+                Lc[k * ld + row] = v;
+                dgw[row] = (row == p || !(d > -1e299)) ? -1e300 : d - v * v;
+            } else {
+                yv[k] = (bglob[p] - sacc) * inv;
+            }
+        }
+        rank = k + 1;
+    }
+    __syncthreads();
+    return rank;
+}
+#else
 DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, const double* bglob) {
     // Right-looking, the Schur complement in REGISTERS: thread t owns the entries t, t + MG_NT, ... of the lower triangle of A'
     // (packed by rows, tri_decode) and of the augmented row n that carries b'.  Per pivot: every wavefront finds the largest
@@ -774,6 +853,7 @@ DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs,
     return rank;
 }
 
+#endif
 // The same factor for a kept block that does not fit the register-resident form (n > 96: windows of the large-window path, kept
 // dimension up to 6 * 39 + 16): the Schur complement stays where it is (M, n x n in global memory, lower triangle updated in
 // place), running diagonal / current column / y in LDS.  Same pivot rule, same cut, same output layout.
