@@ -461,17 +461,33 @@ NOINL double imu_pass(const Ctx& c_in, const double* x_, double* imuJ_, int fbeg
         }
         __syncthreads();
         if (JAC) {
-            for (int w = c.tid; w < nf * 495; w += BA_NT) {
-                const int ff = w / 495, e = w - 495 * ff;
-                if (!valid[f0 + ff]) continue;
-                const double* panel = panels + ff * 480;
-                int a, b;
-                if (e < 465) tri_decode(e, a, b);
-                else { a = e - 465; b = 30; }
-                double s = 0.0;
+            // H = X^T X of the weighted panel X (15 rows x [30 Jacobian columns | residual]) on v_mfma_f64_16x16x4: per factor the three
+            // lower 16x16 tiles of the 31x31 product, four k-steps each (row 15 does not exist: zero); a wavefront takes the
+            // (factor, tile) tasks t = wave, wave + 8, ...  Row 30 of the product is J^T r (the gradient entries 465 ..).
+            // (Until round 4: 495 dot products of 15 terms per factor from LDS, 30 reads each -- a third of the pass.)
+            const int k4 = c.lane >> 4, col = c.lane & 15;
+            for (int t = c.wave; t < 3 * nf; t += BA_NW) {
+                const int ff = t / 3, tile = t - 3 * ff;
+                if (!valid[f0 + ff]) continue;                 // (uniform)
+                const int tm = tile > 0 ? 1 : 0, tn = tile > 1 ? 1 : 0;
+                const lds_d* panel = AS_LDS_C(panels + ff * 480);
+                double av[4], bv[4];
 #pragma unroll
-                for (int r = 0; r < 15; ++r) s += panel[r * 32 + a] * panel[r * 32 + b];
-                imuJ[(f0 + ff) * 512 + e] = s;
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * q + k4;
+                    av[q] = r < 15 ? panel[r * 32 + 16 * tm + col] : 0.0;
+                    bv[q] = r < 15 ? panel[r * 32 + 16 * tn + col] : 0.0;
+                }
+                double4_t acc = (double4_t){0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+                glb_d* dst = imuJ + (f0 + ff) * 512;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int a = 16 * tm + k4 + 4 * reg, b = 16 * tn + col;      // D[row = (lane >> 4) + 4 reg][col = lane & 15]
+                    if (a < 30 && b <= a) dst[a * (a + 1) / 2 + b] = acc[reg];
+                    else if (a == 30 && b < 30) dst[465 + b] = acc[reg];
+                }
             }
         }
         __syncthreads();
