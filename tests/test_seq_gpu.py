@@ -28,6 +28,20 @@ def test_resident_sequence_equals_host_bookkeeping(two_handles, min_parallax, wa
     assert (M.NEW in flat) == want_new and M.OLD in flat
 
 
+def test_resident_sequence_on_the_fused_factor_kernel(two_handles):
+    """The resident windows through ba_linacc_proj_kernel (vg_ba_set_fused_min_windows(1): normally batches of >= 32 windows take it;
+    a sequence has fixed capacities -- 512 tracks, Fcap 1536 -- so its windows run several chunks) against the host bookkeeping on the
+    spread kernels: same decisions, same tables, states to rounding (M.check_step)."""
+    h_seq, h_ref = two_handles
+    h_seq.ba_set_fused_min_windows(1)
+    try:
+        flags = M.run_both(h_seq, h_ref, seeds=[35, 36, 37], K=11, L=220, n_steps=6, min_parallax=10.0 / 460.0, max_features=512,
+                           check=lambda *a: M.check_step(*a, tol=1e-7, tol_depth=1e-6))      # (the two kernels sum in different orders)
+    finally:
+        h_seq.ba_set_fused_min_windows(32)
+    assert M.OLD in [f for fr in flags for f in fr]
+
+
 def test_resident_sequence_free_running(two_handles):
     """Twelve frames without re-synchronisation: the two runs share nothing but the inputs.  A sliding-window estimator amplifies
     rounding differences from frame to frame (the prior is a square root of an ill-conditioned matrix), so the bar is the

@@ -211,3 +211,16 @@ def test_a_failed_window_is_isolated_and_can_be_re_seeded(two_handles):
     the batch untouched, and is brought back with vg_ba_seq_import: re-seeded with an exported copy of its neighbour and fed the
     neighbour's frames, it reproduces the neighbour bit for bit."""
     M.run_failure_isolation(two_handles[0])
+
+
+def test_resident_sequence_on_the_fused_factor_kernel(two_handles):
+    """the device-built tables (ba_seq_build_kernel) through ba_linacc_proj_kernel (vg_ba_set_fused_min_windows(1)) against the host
+    bookkeeping on the spread kernels: same decisions and tables, states to rounding"""
+    h_seq, h_ref = two_handles
+    h_seq.ba_set_fused_min_windows(1)
+    try:
+        flags = M.run_both(h_seq, h_ref, seeds=[23], K=11, L=70, n_steps=3, min_parallax=10.0 / 460.0, max_features=128,
+                           check=lambda *a: M.check_step(*a, tol=1e-7, tol_depth=1e-6))
+    finally:
+        h_seq.ba_set_fused_min_windows(32)
+    assert M.OLD in [f for fr in flags for f in fr]
