@@ -113,43 +113,85 @@ extern "C" __global__ __launch_bounds__(256) void fe_copy_kernel(FeDev d, uint8_
 }
 
 // ================================================================================================ pyrDown
-// [1 4 6 4 1] x [1 4 6 4 1], BORDER_REFLECT_101, (sum + 128) >> 8  (pyramids.cpp).  Block = 64x4 output tile: the
-// 11 x 136 input tile is staged in LDS (aligned dword rows in the interior, per-byte reflection at the borders),
-// filtered horizontally once (11 x 64 partial sums) and then vertically: ~3x fewer instructions than 25 reflected
-// global byte loads per output pixel, same integers.
+// [1 4 6 4 1] x [1 4 6 4 1], BORDER_REFLECT_101, (sum + 128) >> 8  (pyramids.cpp).  Block = 64 x 16 output tile: the 35 x 136
+// input tile is staged in LDS (aligned dwords wherever the dword lies inside the image row, per-byte reflection for the one or
+// two dwords that straddle an edge), filtered horizontally once (35 x 64 partial sums) and then vertically: ~3x fewer
+// instructions than 25 reflected global byte loads per output pixel, same integers.
+// Round 4: the kernel was bound by VALU issue, not by HBM (~370 instructions per thread for 4 outputs): the horizontal pass now
+// forms FOUR adjacent sums from one 16-byte LDS read (their 11 input bytes start at a multiple of 8: 6 instead of 18
+// instructions per sum), the staging loop walks (row, dword) without a division or 64-bit address arithmetic per element, and
+// border tiles (42 % of the tiles of level 0, 75 % of level 1, all of level 2) no longer stage their whole input per byte.
 #define PD_ROWS 16                              // output rows per workgroup (64 x 16 outputs = 4 per thread)
 #define PD_IN (2 * PD_ROWS + 3)                 // input rows a workgroup reads
+#define PD_TW 144                               // bytes per staged row (136 used: input columns 2 bx0 - 4 .. 2 bx0 + 131)
 extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh) {
-    __shared__ alignas(16) uint8_t tile[PD_IN][136];
+    __shared__ alignas(16) uint8_t tile[PD_IN][PD_TW];
     __shared__ alignas(16) int hs[PD_IN][64];
     const int cam = blockIdx.z;
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * PD_ROWS;
-    const uint8_t* s = src_planes[cam];
+    const glb_u8* s = (const glb_u8*)src_planes[cam];     // (the planes are HBM: global_load, not flat_load)
     const int ix0 = 2 * bx0 - 4, iy0 = 2 * by0 - 2;         // input coordinates of tile[0][0] (ix0 is 4-byte aligned)
-    const bool interior = (sw & 3) == 0 && ix0 >= 0 && ix0 + 136 <= sw && iy0 >= 0 && iy0 + PD_IN <= sh;   // uniform
-    if (interior) {
-        for (int k = threadIdx.x; k < PD_IN * 34; k += 256) {
-            const int r = k / 34, cdw = k - 34 * r;
-            *(uint32_t*)&tile[r][4 * cdw] = *(const uint32_t*)(s + (size_t)(iy0 + r) * sw + ix0 + 4 * cdw);
+    // Columns / rows further out than one reflection are never used by an output inside the image; they are clamped so that the
+    // read stays inside the plane, and what lies beyond sw + 4 / sh + 4 is not read at all.
+    if ((sw & 3) == 0) {
+        const int r0 = (int)threadIdx.x / 34, cdw = (int)threadIdx.x - 34 * r0;      // 7 rows x 34 dwords per pass
+        if (r0 < 7) {
+            const int gx = ix0 + 4 * cdw;
+            const bool whole = gx >= 0 && gx + 4 <= sw, skipx = gx >= sw + 4;
+            for (int r = r0; r < PD_IN; r += 7) {
+                int ry = reflect101(iy0 + r, sh);
+                ry = ry < 0 ? 0 : (ry >= sh ? sh - 1 : ry);
+                const glb_u8* row = s + (unsigned)(ry * sw);
+                uint32_t v = 0;
+                if (whole) v = *(const glb_u32*)(row + gx);
+                else if (!skipx && iy0 + r < sh + 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int rx = reflect101(gx + q, sw);
+                        rx = rx < 0 ? 0 : (rx >= sw ? sw - 1 : rx);
+                        v |= (uint32_t)row[rx] << (8 * q);
+                    }
+                }
+                *(uint32_t*)&tile[r][4 * cdw] = v;
+            }
         }
     } else {
         for (int k = threadIdx.x; k < PD_IN * 136; k += 256) {
             const int r = k / 136, cc = k - 136 * r;
-            tile[r][cc] = s[(size_t)reflect101(iy0 + r, sh) * sw + reflect101(ix0 + cc, sw)];
+            int ry = reflect101(iy0 + r, sh), rx = reflect101(ix0 + cc, sw);
+            ry = ry < 0 ? 0 : (ry >= sh ? sh - 1 : ry);
+            rx = rx < 0 ? 0 : (rx >= sw ? sw - 1 : rx);
+            tile[r][cc] = s[(size_t)ry * sw + rx];
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < PD_IN * 64; k += 256) {
-        const int r = k >> 6, lx = k & 63;
-        const uint8_t* t = &tile[r][2 * lx + 2];           // input column 2x - 2
-        // the five taps start at an even byte: they lie in two aligned dwords (two LDS reads and a funnel shift instead of five
-        // byte reads -- this pass was 44 of the kernel's ~60 LDS instructions per thread): vg_target.h
-        hs[r][lx] = vg_taps5_even(t, 2u * lx + 2u);
+    // horizontal: thread = (row, 4 adjacent sums).  Sum lx reads tile columns 2 lx + 2 .. 2 lx + 6: for lx = 4 j .. 4 j + 3 the
+    // bytes 8 j + 2 .. 8 j + 12 of the row
+    {
+        const int j = threadIdx.x & 15;
+        for (int r = threadIdx.x >> 4; r < PD_IN; r += 16) {
+            const uint2 lo = *(const uint2*)&tile[r][8 * j], hi = *(const uint2*)&tile[r][8 * j + 8];
+            const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+            int4 o;
+            int* po = &o.x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int acc = 0;
+                const int wgt[5] = {1, 4, 6, 4, 1};
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const int byte = 2 + 2 * i + t;
+                    acc += wgt[t] * (int)((w[byte >> 2] >> (8 * (byte & 3))) & 255u);
+                }
+                po[i] = acc;
+            }
+            *(int4*)&hs[r][4 * j] = o;
+        }
     }
     __syncthreads();
-    // thread = 4 horizontally adjacent outputs of one row: five 16-byte LDS reads, one 4-byte store (a byte store per thread
-    // moves 64 bytes per wavefront instruction)
+    // vertical: thread = 4 horizontally adjacent outputs of one row: five 16-byte LDS reads, one 4-byte store (a byte store per
+    // thread moves 64 bytes per wavefront instruction)
     const int lq = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int x = bx0 + 4 * lq, y = by0 + ly;
     if (x >= dw || y >= dh) return;
@@ -183,38 +225,32 @@ struct LkLds {
     int16_t der[22 * 22 * 2];       // Scharr (Ix, Iy) at (ipx + 0..21, ipy + 0..21), 0 outside the image
 };
 
-// exact int64 wavefront sum on the DPP network (VALU only; a 64-bit __shfl_down tree is 12 dependent LDS-crossbar round
-// trips): quad swaps -> half-row mirror -> row mirror give every lane its 16-lane row total, the four row totals are
-// added through SGPRs.  Integer addition is associative, so the result is independent of the order.
-template <int CTRL> FDEV long long dpp_mov_ll(long long v) {
-    int lo = (int)(unsigned)(v & 0xffffffffll), hi = (int)(v >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    return ((long long)hi << 32) | (unsigned)lo;
-}
-FDEV long long readlane_ll(long long v, int lane) {
-    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffll), lane);
-    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
-    return ((long long)hi << 32) | (unsigned)lo;
-}
-// the same for lane values whose 8-lane totals still fit 32 bits (|v| < 2^28): the first three DPP stages in 32 bits, widened
-// for the last one and the four row totals
+// Exact integer wavefront sums on the DPP network (VALU only; a __shfl_down tree is dependent LDS-crossbar round trips): quad
+// swaps -> half-row mirror give every lane its 8-lane total.  Integer addition is associative, so the result is independent of
+// the order.
+// the same for lane values whose 8-lane totals still fit 32 bits (|v| < 2^28): three DPP stages in 32 bits (old = 0 + bound_ctrl
+// lets the compiler fold each move into its add: one v_add_u32_dpp per stage instead of copy + v_mov_dpp + add), then the eight
+// 8-lane totals through SGPRs — sign extension and the 64-bit adds are SALU work, which the VALU-bound kernel has spare
+FDEV int dpp_add_i32_0xB1(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+FDEV int dpp_add_i32_0x4E(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }
+FDEV int dpp_add_i32_0x141(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true); }
 FDEV long long wave_sum_i32(int v) {
-    v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);
-    v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);
-    long long w = v;
-    w += dpp_mov_ll<0x140>(w);
-    return (readlane_ll(w, 0) + readlane_ll(w, 16)) + (readlane_ll(w, 32) + readlane_ll(w, 48));
+    v = dpp_add_i32_0xB1(v);
+    v = dpp_add_i32_0x4E(v);
+    v = dpp_add_i32_0x141(v);
+    long long t = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += (long long)__builtin_amdgcn_readlane(v, 8 * g);
+    return t;
 }
-FDEV long long wave_sum_ll(long long v) {
-    v += dpp_mov_ll<0xB1>(v);
-    v += dpp_mov_ll<0x4E>(v);
-    v += dpp_mov_ll<0x141>(v);
-    v += dpp_mov_ll<0x140>(v);
-    return (readlane_ll(v, 0) + readlane_ll(v, 16)) + (readlane_ll(v, 32) + readlane_ll(v, 48));
+// lane values whose WAVEFRONT total fits 32 bits
+FDEV int wave_sum_small(int v) {
+    v = dpp_add_i32_0xB1(v);
+    v = dpp_add_i32_0x4E(v);
+    v = dpp_add_i32_0x141(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
-
 FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
     w00 = cv_round((1.f - a) * (1.f - b) * (float)(1 << LK_WBITS));
     w01 = cv_round(a * (1.f - b) * (float)(1 << LK_WBITS));
@@ -251,6 +287,9 @@ FDEV void lk_stage_region(uint8_t* reg, const glb_u8* J, int lw, int lh, int ox,
 }
 
 // grid (max_points, cams), block 64 (one wavefront = one track).  LKTrackerInvoker, levels max_level .. 0.
+// (six wavefronts per SIMD: the register allocator is asked for <= 80 VGPRs instead of the 86 it takes unasked -- 73, no spills;
+//  -3 % per launch.  Eight would need <= 64 and was measured slower.)
+VG_WAVES_PER_EU(6)
 extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
     __shared__ LkLds s;
     const int cam = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
@@ -330,7 +369,8 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
         __syncthreads();
         // lane = (window row ly, 7-pixel segment): the template values and gradients of a lane's seven pixels stay in
         // registers for all iterations of the level (VALU issue, not latency, bounds this kernel at full occupancy)
-        long long a11 = 0, a12 = 0, a22 = 0;
+        // (a lane's seven products of two gradients are < 7 * 4080^2 = 1.2e8 < 2^27: lane sums in 32 bits, see wave_sum_i32)
+        int s11 = 0, s12 = 0, s22 = 0;
         int iv[7], ixv[7], iyv[7];
         {
             const uint8_t* p0 = s.ipatch + (lyc + 1) * 24 + (x0 + 1);
@@ -347,10 +387,10 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 const int ixval = descale(tap4(x00, x01, x10, x11, w00, w01, w10, w11), LK_WBITS);
                 const int iyval = descale(tap4(y00, y01, y10, y11, w00, w01, w10, w11), LK_WBITS);
                 iv[q] = (short)ival; ixv[q] = act ? (short)ixval : 0; iyv[q] = act ? (short)iyval : 0;
-                a11 += (long long)mul24(ixv[q], ixv[q]); a12 += (long long)mul24(ixv[q], iyv[q]); a22 += (long long)mul24(iyv[q], iyv[q]);
+                s11 += mul24(ixv[q], ixv[q]); s12 += mul24(ixv[q], iyv[q]); s22 += mul24(iyv[q], iyv[q]);
             }
         }
-        a11 = wave_sum_ll(a11); a12 = wave_sum_ll(a12); a22 = wave_sum_ll(a22);
+        const long long a11 = wave_sum_i32(s11), a12 = wave_sum_i32(s12), a22 = wave_sum_i32(s22);
         const float A11 = (float)a11 * FLT_SCALE, A12 = (float)a12 * FLT_SCALE, A22 = (float)a22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * LK_WIN * LK_WIN);
@@ -414,7 +454,7 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 jox = inx - LK_JS; joy = iny - LK_JS; staged = true; rx = LK_JS; ry = LK_JS;
                 lk_stage_region(s.jreg, J, lw, lh, jox, joy, lane);
             }
-            long long e = 0;
+            int e = 0;               // (|diff| <= 8160: the wavefront total is < 2^22)
             {
                 const uint8_t* p0 = s.jreg + (ry + lyc) * LK_JR + rx + x0;
                 int r0[8], r1[8];
@@ -426,7 +466,7 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                     e += act ? (diff < 0 ? -diff : diff) : 0;
                 }
             }
-            e = wave_sum_ll(e);
+            e = wave_sum_small(e);
             err = ((float)e * 1.f) / (float)(32 * LK_WIN * LK_WIN);      // a division, as OpenCV's expression parses (F3)
         }
     }
