@@ -11,6 +11,7 @@
 //   cv::goodFeaturesToTrack(.., 0.01, MIN_DIST, mask) call site feature_tracker.cpp:149    [featureselect.cpp,
 //        corner.cpp: cornerMinEigenVal = Sobel + cov + boxFilter + calcMinEigenVal]
 // Compile with -ffp-contract=off: the float expressions below are evaluated exactly as written.
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -88,6 +89,9 @@ inline Weights bilinear_weights(float a, float b) {
     return q;
 }
 
+static std::atomic<long long> g_lk_iterations{0};
+extern "C" long long oracle_fe_lk_iterations(int reset) { const long long v = g_lk_iterations; if (reset) g_lk_iterations = 0; return v; }
+
 // LKTrackerInvoker for one point on one level.  A / b sums are exact 64-bit integers converted once to float
 // (oracle/ASSUMPTIONS.md F3: the scalar and SSE builds of OpenCV already differ from each other here).
 void lk_point_level(const Level& I, const Level& J, int level, int max_level, float px, float py, float& nx, float& ny,
@@ -132,6 +136,7 @@ void lk_point_level(const Level& I, const Level& J, int level, int max_level, fl
             if (level == 0) status = 0;
             break;
         }
+        ++g_lk_iterations;                     // (statistics for DESIGN.md: how many iterations a track costs; not part of the result)
         Weights r = bilinear_weights(nextx - inx, nexty - iny);
         int64_t ib1 = 0, ib2 = 0;
         for (int y = 0; y < WIN; ++y)

@@ -222,7 +222,6 @@ struct LkLds {
     alignas(16) uint8_t jreg[LK_JR * LK_JR];    // search REGION (reflect-101), origin (jox, joy): holds every 22x22 search window
                                     // whose origin lies within +-LK_JS px of the window it was staged for
     uint8_t ipatch[24 * 24];        // template neighbourhood (reflect-101), origin (ipx-1, ipy-1)
-    int16_t der[22 * 22 * 2];       // Scharr (Ix, Iy) at (ipx + 0..21, ipy + 0..21), 0 outside the image
 };
 
 // Exact integer wavefront sums on the DPP network (VALU only; a __shfl_down tree is dependent LDS-crossbar round trips): quad
@@ -260,6 +259,16 @@ FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
 
 // Image planes are reached through pointer tables in HBM: a loaded pointer is generic and its accesses would compile to
 // flat_load (which also ties the LDS counter to the image loads); the planes are HBM, say so (glb_u8, vg_target.h).
+
+// descale(tap4(row a bytes q, q + 1; row b bytes q, q + 1), LK_WBITS - 5) for q = 0 .. 6, handed to f(q, value)
+template <int Q, typename F> FDEV void lk_tap_q(const uint2& ra, const uint2& rb, unsigned wt, unsigned wb, F&& f) {
+    const unsigned t = vg_udot2(vg_byte_pair<Q>(rb.y, rb.x), wb, vg_udot2(vg_byte_pair<Q>(ra.y, ra.x), wt, 1u << (LK_WBITS - 5 - 1)));
+    f(Q, (int)(t >> (LK_WBITS - 5)));
+}
+template <typename F> FDEV void lk_taps7(const uint2& ra, const uint2& rb, unsigned wt, unsigned wb, F&& f) {
+    lk_tap_q<0>(ra, rb, wt, wb, f); lk_tap_q<1>(ra, rb, wt, wb, f); lk_tap_q<2>(ra, rb, wt, wb, f); lk_tap_q<3>(ra, rb, wt, wb, f);
+    lk_tap_q<4>(ra, rb, wt, wb, f); lk_tap_q<5>(ra, rb, wt, wb, f); lk_tap_q<6>(ra, rb, wt, wb, f);
+}
 
 // Stage the LK_JR x LK_JR search region with origin (ox, oy) of plane J into LDS (reflect-101 outside the image, exactly
 // the pixels the per-window gather of LKTrackerInvoker reads).  lane = (row, 16-byte half): one unaligned 16-byte load
@@ -337,55 +346,57 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
         // (the patch was written by other lanes of this wavefront: LDS operations of one wavefront complete in order on the
         //  hardware; the wave barrier states the dependency for the compiler and for the CPU emulation of tests/simt)
         __builtin_amdgcn_wave_barrier();
-        // Scharr field on the 22x22 integer positions (calcSharrDeriv; constant-0 border outside the image).
-        // NB the x+-1 / y+-1 taps reflect at the IMAGE edge, which is what the reflect-101 patch holds.
-        // lane = (row yy of the 22x22 lattice, 11-column half): 44 lanes, each walks its 11 positions with a sliding
-        // 3x3 neighbourhood (3 new bytes per position instead of 8): ~40 % fewer instructions than a strided sweep
-        if (lane < 44) {
-            const int yy = lane >> 1, xs = 11 * (lane & 1);
-            const int Y = ipy + yy;
-            const bool yin = Y >= 0 && Y < lh;
-            const uint8_t* p = s.ipatch + (yy + 1) * 24 + (xs + 1);          // centre of the first position
-            int a0 = p[-24 - 1], a1 = p[-1], a2 = p[24 - 1];                  // column x-1 (rows y-1, y, y+1)
-            int b0 = p[-24], b1 = p[0], b2 = p[24];                           // column x
-            int* dq = (int*)s.der + yy * 22 + xs;
-#pragma unroll
-            for (int q = 0; q < 11; ++q) {
-                const int c0 = p[-24 + q + 1], c1 = p[q + 1], c2 = p[24 + q + 1];    // column x+1
-                const int X = ipx + xs + q;
-                int ix = 0, iy = 0;
-                if (yin && X >= 0 && X < lw) {
-                    // (small constants times byte sums: spelled as 24-bit multiplies, see mul24)
-                    const int t0m = mul24(3, a0 + a2) + mul24(10, a1);
-                    const int t0p = mul24(3, c0 + c2) + mul24(10, c1);
-                    const int t1m = a2 - a0, t1c = b2 - b0, t1p = c2 - c0;
-                    ix = t0p - t0m;
-                    iy = mul24(3, t1m + t1p) + mul24(10, t1c);
-                }
-                dq[q] = (int)((unsigned)(ix & 0xffff) | ((unsigned)iy << 16));        // (int16 Ix | int16 Iy << 16)
-                a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
-            }
-        }
-        __syncthreads();
-        // lane = (window row ly, 7-pixel segment): the template values and gradients of a lane's seven pixels stay in
-        // registers for all iterations of the level (VALU issue, not latency, bounds this kernel at full occupancy)
+        // lane = (window row ly, 7-pixel segment): the template values and gradients of a lane's seven pixels stay in registers
+        // for all iterations of the level (VALU issue, not latency, bounds this kernel at full occupancy).
+        // Round 4: the lane forms the Scharr derivatives (calcSharrDeriv; constant-0 border outside the image; NB the x+-1 / y+-1
+        // taps reflect at the IMAGE edge, which is what the reflect-101 patch holds) of ITS 2 x 8 lattice positions from its 4 x 10
+        // patch bytes in registers -- column sums t0 = 3 (up + down) + 10 mid and t1 = down - up are shared by neighbouring
+        // positions (9 instructions per position) -- instead of a 22 x 22 field through LDS (18 per position on 44 lanes, then 16
+        // packed dword reads and 8 unpacks per pixel): one barrier and 1.9 KB of LDS less, -2.5 % per launch.
         // (a lane's seven products of two gradients are < 7 * 4080^2 = 1.2e8 < 2^27: lane sums in 32 bits, see wave_sum_i32)
         int s11 = 0, s12 = 0, s22 = 0;
         int iv[7], ixv[7], iyv[7];
         {
-            const uint8_t* p0 = s.ipatch + (lyc + 1) * 24 + (x0 + 1);
-            const int* dq = (const int*)s.der + lyc * 22 + x0;          // (Ix | Iy << 16)
-            int r0[8], r1[8], d0[8], d1[8];
+            const uint8_t* pp = s.ipatch + lyc * 24 + x0;          // patch rows ly .. ly + 3, columns x0 .. x0 + 9
+            int P[4][10];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[24 + q]; d0[q] = dq[q]; d1[q] = dq[22 + q]; }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 10; ++c) P[r][c] = pp[r * 24 + c];
+            // lattice position (k, c), k = 0, 1, c = 0 .. 7  <->  patch (k + 1, c + 1)  <->  image (ipy + ly + k, ipx + x0 + c)
+            int dx[2][8], dy[2][8];
+            const bool allin = ipx >= 0 && ipx + 22 <= lw && ipy >= 0 && ipy + 22 <= lh;       // uniform: no position outside
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int t0[10], t1[10];
+#pragma unroll
+                for (int c = 0; c < 10; ++c) {
+                    t0[c] = mul24(3, P[k][c] + P[k + 2][c]) + mul24(10, P[k + 1][c]);
+                    t1[c] = P[k + 2][c] - P[k][c];
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    dx[k][c] = t0[c + 2] - t0[c];
+                    dy[k][c] = mul24(3, t1[c] + t1[c + 2]) + mul24(10, t1[c + 1]);
+                }
+            }
+            if (!allin) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int Y = ipy + lyc + k;
+                    const bool yin = Y >= 0 && Y < lh;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int X = ipx + x0 + c;
+                        if (!(yin && X >= 0 && X < lw)) { dx[k][c] = 0; dy[k][c] = 0; }
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
-                const int ival = descale(tap4(r0[q], r0[q + 1], r1[q], r1[q + 1], w00, w01, w10, w11), LK_WBITS - 5);
-                const int x00 = (short)(d0[q] & 0xffff), x01 = (short)(d0[q + 1] & 0xffff);
-                const int x10 = (short)(d1[q] & 0xffff), x11 = (short)(d1[q + 1] & 0xffff);
-                const int y00 = d0[q] >> 16, y01 = d0[q + 1] >> 16, y10 = d1[q] >> 16, y11 = d1[q + 1] >> 16;
-                const int ixval = descale(tap4(x00, x01, x10, x11, w00, w01, w10, w11), LK_WBITS);
-                const int iyval = descale(tap4(y00, y01, y10, y11, w00, w01, w10, w11), LK_WBITS);
+                const int ival = descale(tap4(P[1][q + 1], P[1][q + 2], P[2][q + 1], P[2][q + 2], w00, w01, w10, w11), LK_WBITS - 5);
+                const int ixval = descale(tap4(dx[0][q], dx[0][q + 1], dx[1][q], dx[1][q + 1], w00, w01, w10, w11), LK_WBITS);
+                const int iyval = descale(tap4(dy[0][q], dy[0][q + 1], dy[1][q], dy[1][q + 1], w00, w01, w10, w11), LK_WBITS);
                 iv[q] = (short)ival; ixv[q] = act ? (short)ixval : 0; iyv[q] = act ? (short)iyval : 0;
                 s11 += mul24(ixv[q], ixv[q]); s12 += mul24(ixv[q], iyv[q]); s22 += mul24(iyv[q], iyv[q]);
             }
@@ -418,18 +429,20 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
             }
             long long b1, b2;
             {
+                // the lane's 2 x 8 search-window bytes as four dwords; a bilinear tap = two v_dot2_u32_u16 over (pixel, pixel + 1)
+                // pairs cut out by v_perm_b32, the rounding constant of the descale as the addend (4 instructions instead of four
+                // byte-select multiplies and two three-operand adds; the weights are < 2^15, a tap < 2^22)
                 const uint8_t* p0 = s.jreg + (ry + lyc) * LK_JR + rx + x0;
-                int r0[8], r1[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[LK_JR + q]; }
+                uint2 ra, rb;
+                __builtin_memcpy(&ra, p0, 8); __builtin_memcpy(&rb, p0 + LK_JR, 8);
+                const unsigned wt = (unsigned)r00 | ((unsigned)r01 << 16), wb = (unsigned)r10 | ((unsigned)r11 << 16);
                 // a lane's seven products fit 32 bits with room to spare (|diff| <= 255 * 32, |Ix|, |Iy| <= 16 * 255: < 2.4e8 in
                 // total), so the lane sums are formed in 32 bits and widened once; the wavefront sums stay exact int64
                 int s1 = 0, s2 = 0;
-#pragma unroll
-                for (int q = 0; q < 7; ++q) {
-                    const int diff = descale(tap4(r0[q], r0[q + 1], r1[q], r1[q + 1], r00, r01, r10, r11), LK_WBITS - 5) - iv[q];
+                lk_taps7(ra, rb, wt, wb, [&](int q, int val) {
+                    const int diff = val - iv[q];
                     s1 += mul24(diff, ixv[q]); s2 += mul24(diff, iyv[q]);
-                }
+                });
                 b1 = wave_sum_i32(s1); b2 = wave_sum_i32(s2);       // (|s| <= 7 * 8160 * 4080 = 2.3e8 < 2^28)
             }
             const float fb1 = (float)b1 * FLT_SCALE, fb2 = (float)b2 * FLT_SCALE;
@@ -457,14 +470,13 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
             int e = 0;               // (|diff| <= 8160: the wavefront total is < 2^22)
             {
                 const uint8_t* p0 = s.jreg + (ry + lyc) * LK_JR + rx + x0;
-                int r0[8], r1[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { r0[q] = p0[q]; r1[q] = p0[LK_JR + q]; }
-#pragma unroll
-                for (int q = 0; q < 7; ++q) {
-                    const int diff = descale(tap4(r0[q], r0[q + 1], r1[q], r1[q + 1], r00, r01, r10, r11), LK_WBITS - 5) - iv[q];
+                uint2 ra, rb;
+                __builtin_memcpy(&ra, p0, 8); __builtin_memcpy(&rb, p0 + LK_JR, 8);
+                const unsigned wt = (unsigned)r00 | ((unsigned)r01 << 16), wb = (unsigned)r10 | ((unsigned)r11 << 16);
+                lk_taps7(ra, rb, wt, wb, [&](int q, int val) {
+                    const int diff = val - iv[q];
                     e += act ? (diff < 0 ? -diff : diff) : 0;
-                }
+                });
             }
             e = wave_sum_small(e);
             err = ((float)e * 1.f) / (float)(32 * LK_WIN * LK_WIN);      // a division, as OpenCV's expression parses (F3)

@@ -51,15 +51,14 @@ __device__ __forceinline__ uint4 vg_load16_unaligned(const glb_u8* p) {
     v.x = t4.x; v.y = t4.y; v.z = t4.z; v.w = t4.w;
     return v;
 }
-// ---- t[0] + 4 t[1] + 6 t[2] + 4 t[3] + t[4] over five bytes of LDS starting at an EVEN byte offset (lx2 = that offset): they lie
-//      in two aligned dwords -- two ds_read_b32 and a v_alignbyte_b32 instead of five ds_read_u8
-__device__ __forceinline__ int vg_taps5_even(const uint8_t* t, unsigned lx2) {
-    const unsigned off = lx2 & 3u;                         // 0 or 2
-    const unsigned* w = (const unsigned*)(t - off);
-    const unsigned w0 = w[0], w1 = w[1];
-    const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, off);
-    const unsigned t4 = (off ? w1 >> 16 : w1) & 255u;
-    return (int)((lo & 255u) + 4u * ((lo >> 8) & 255u) + 6u * ((lo >> 16) & 255u) + 4u * (lo >> 24) + t4);
+// ---- bytes q and q + 1 of the eight bytes (hi:lo) as two 16-bit lanes (byte q | byte q + 1 << 16): one v_perm_b32; and the dot
+//      product of two such pairs of unsigned 16-bit lanes plus a 32-bit addend: one v_dot2_u32_u16 (exact: no saturation asked for)
+template <int Q> __device__ __forceinline__ unsigned vg_byte_pair(unsigned hi, unsigned lo) {
+    return __builtin_amdgcn_perm(hi, lo, (unsigned)Q | (0x0Cu << 8) | ((unsigned)(Q + 1) << 16) | (0x0Cu << 24));
+}
+__device__ __forceinline__ unsigned vg_udot2(unsigned a, unsigned b, unsigned c) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
 }
 
 #else   // ------------------------------------------------------------------------------ CPU fiber emulation (tests/simt)
@@ -78,5 +77,9 @@ inline int uni(int v) { return v; }
 inline double uni(double v) { return v; }
 template <typename T> inline T const_load(const T* p) { return *p; }
 inline uint4 vg_load16_unaligned(const glb_u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
-inline int vg_taps5_even(const uint8_t* t, unsigned) { return t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4]; }
+template <int Q> inline unsigned vg_byte_pair(unsigned hi, unsigned lo) {
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    return (unsigned)((v >> (8 * Q)) & 255u) | ((unsigned)((v >> (8 * (Q + 1))) & 255u) << 16);
+}
+inline unsigned vg_udot2(unsigned a, unsigned b, unsigned c) { return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c; }
 #endif
