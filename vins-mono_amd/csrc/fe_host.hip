@@ -24,7 +24,8 @@ extern "C" {
 __global__ void fe_clahe_lut_kernel(FeDev d, int clip_limit, float lut_scale);
 __global__ void fe_clahe_apply_kernel(FeDev d, uint8_t* const* dst_planes);
 __global__ void fe_copy_kernel(FeDev d, uint8_t* const* dst_planes);
-__global__ void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh);
+__global__ void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh, int waves_per_strip);
+__global__ void fe_pyrdown_tile_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh);
 __global__ void fe_lk_kernel(FeDev d);
 __global__ void fe_mineig_kernel(FeDev d);
 __global__ void fe_candidates_kernel(FeDev d, double quality);
@@ -41,6 +42,8 @@ struct FeState {
     int W = 0, H = 0, cams = 0, max_pts = 0;
     int flip = 0;                         // which plane set is "current"
     uint8_t* planes[2] = {nullptr, nullptr};   // two pyramids per camera, all levels, contiguous
+    uint8_t* planes_alloc[2] = {nullptr, nullptr};   // (what hipMalloc returned: planes[k] - FE_SLACK)
+    uint8_t* raw_alloc = nullptr;
     uint8_t** d_ptrs[2] = {nullptr, nullptr};  // device pointer tables [level*cams+cam]
     std::vector<uint8_t*> h_ptrs[2];
     // The same tables with level 0 pointing INTO the frame slot: pyramid set k <-> frame slot k.  A frame that is not equalized
@@ -72,8 +75,8 @@ struct FeState {
 
 extern "C" void fe_state_destroy(FeState* s) {
     if (!s) return;
-    for (int k = 0; k < 2; ++k) { (void)hipFree(s->planes[k]); (void)hipFree(s->d_ptrs[k]); (void)hipFree(s->d_ptrs_alias[k]); }
-    (void)hipFree(s->raw); (void)hipFree(s->lut); (void)hipFree(s->mask); (void)hipFree(s->status);
+    for (int k = 0; k < 2; ++k) { (void)hipFree(s->planes_alloc[k]); (void)hipFree(s->d_ptrs[k]); (void)hipFree(s->d_ptrs_alias[k]); }
+    (void)hipFree(s->raw_alloc); (void)hipFree(s->lut); (void)hipFree(s->mask); (void)hipFree(s->status);
     (void)hipFree(s->prev_xy); (void)hipFree(s->next_xy); (void)hipFree(s->err); (void)hipFree(s->eig);
     (void)hipFree(s->blockmax); (void)hipFree(s->corners); (void)hipFree(s->npts); (void)hipFree(s->max_corners);
     (void)hipFree(s->ncorners); (void)hipFree(s->ncand); (void)hipFree(s->keys);
@@ -116,8 +119,11 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     s->level_off[nl + 1] = off;
     const size_t per_cam = off, npix = (size_t)width * height;
     for (int k = 0; k < 2; ++k) {
-        HIPCHK(h, hipMalloc((void**)&s->planes[k], per_cam * n_cams));
-        HIPCHK(h, hipMemset(s->planes[k], 0, per_cam * n_cams));
+        // (FE_SLACK bytes in front of and behind the planes: fe_pyrdown_kernel's 16-byte windows start 4 bytes before a row and end
+        //  up to 12 bytes after it; what they read there is never used)
+        HIPCHK(h, hipMalloc((void**)&s->planes_alloc[k], per_cam * n_cams + 2 * FE_SLACK));
+        HIPCHK(h, hipMemset(s->planes_alloc[k], 0, per_cam * n_cams + 2 * FE_SLACK));
+        s->planes[k] = s->planes_alloc[k] + FE_SLACK;
         s->h_ptrs[k].resize((size_t)(nl + 1) * n_cams);
         for (int l = 0; l <= nl; ++l)
             for (int c = 0; c < n_cams; ++c) s->h_ptrs[k][(size_t)l * n_cams + c] = s->planes[k] + (size_t)c * per_cam + s->level_off[l];
@@ -126,7 +132,9 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     }
     d.nblk_eig = ((width + 63) / 64) * ((height + 3) / 4);
     d.cand_cap = FE_CAND_CAP;
-    HIPCHK(h, hipMalloc((void**)&s->raw, 2 * npix * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->raw_alloc, 2 * npix * n_cams + 2 * FE_SLACK));
+    HIPCHK(h, hipMemset(s->raw_alloc, 0, 2 * npix * n_cams + 2 * FE_SLACK));
+    s->raw = s->raw_alloc + FE_SLACK;
     s->raw2[0] = s->raw; s->raw2[1] = s->raw + npix * n_cams;
     for (int k = 0; k < 2; ++k) {
         s->h_ptrs_alias[k] = s->h_ptrs[k];
@@ -229,8 +237,15 @@ extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
     }
     for (int l = 1; l <= d.max_level; ++l) {
         const int sw = d.lw[l - 1], sh = d.lh[l - 1];
-        hipLaunchKernelGGL(fe_pyrdown_kernel, dim3(((sw + 1) / 2 + 63) / 64, ((sh + 1) / 2 + 15) / 16, d.cams), dim3(256), 0, h->stream,
-                           (const uint8_t* const*)(cur0 + (size_t)(l - 1) * d.cams), cur0 + (size_t)l * d.cams, sw, sh);
+        if ((sw & 3) == 0) {
+            // thread = 4 output columns x 8 output rows, a wavefront = 256 columns of one strip of rows (fe_kernels.hip)
+            const int dw = sw / 2, dh = (sh + 1) / 2, wps = ((dw + 3) / 4 + 63) / 64, strips = (dh + 7) / 8;
+            hipLaunchKernelGGL(fe_pyrdown_kernel, dim3((strips * wps + 3) / 4, 1, d.cams), dim3(256), 0, h->stream,
+                               (const uint8_t* const*)(cur0 + (size_t)(l - 1) * d.cams), cur0 + (size_t)l * d.cams, sw, sh, wps);
+        } else {
+            hipLaunchKernelGGL(fe_pyrdown_tile_kernel, dim3(((sw + 1) / 2 + 63) / 64, ((sh + 1) / 2 + 15) / 16, d.cams), dim3(256), 0, h->stream,
+                               (const uint8_t* const*)(cur0 + (size_t)(l - 1) * d.cams), cur0 + (size_t)l * d.cams, sw, sh);
+        }
     }
     HIPCHK(h, hipGetLastError());
     if (first) {

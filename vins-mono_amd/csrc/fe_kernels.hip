@@ -124,7 +124,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_copy_kernel(FeDev d, uint8_
 #define PD_ROWS 16                              // output rows per workgroup (64 x 16 outputs = 4 per thread)
 #define PD_IN (2 * PD_ROWS + 3)                 // input rows a workgroup reads
 #define PD_TW 144                               // bytes per staged row (136 used: input columns 2 bx0 - 4 .. 2 bx0 + 131)
-extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh) {
+extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_tile_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh) {
     __shared__ alignas(16) uint8_t tile[PD_IN][PD_TW];
     __shared__ alignas(16) int hs[PD_IN][64];
     const int cam = blockIdx.z;
@@ -139,22 +139,28 @@ extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_
         if (r0 < 7) {
             const int gx = ix0 + 4 * cdw;
             const bool whole = gx >= 0 && gx + 4 <= sw, skipx = gx >= sw + 4;
-            for (int r = r0; r < PD_IN; r += 7) {
+            // all five loads of a thread are issued before the first LDS store (a load -> store loop is five dependent HBM round
+            // trips per workgroup)
+            uint32_t v[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int r = r0 + 7 * u;
                 int ry = reflect101(iy0 + r, sh);
                 ry = ry < 0 ? 0 : (ry >= sh ? sh - 1 : ry);
                 const glb_u8* row = s + (unsigned)(ry * sw);
-                uint32_t v = 0;
-                if (whole) v = *(const glb_u32*)(row + gx);
+                v[u] = 0;
+                if (whole) v[u] = *(const glb_u32*)(row + gx);
                 else if (!skipx && iy0 + r < sh + 4) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         int rx = reflect101(gx + q, sw);
                         rx = rx < 0 ? 0 : (rx >= sw ? sw - 1 : rx);
-                        v |= (uint32_t)row[rx] << (8 * q);
+                        v[u] |= (uint32_t)row[rx] << (8 * q);
                     }
                 }
-                *(uint32_t*)&tile[r][4 * cdw] = v;
             }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) *(uint32_t*)&tile[r0 + 7 * u][4 * cdw] = v[u];
         }
     } else {
         for (int k = threadIdx.x; k < PD_IN * 136; k += 256) {
@@ -209,6 +215,83 @@ extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (x + q < dw) o[q] = (uint8_t)((acc[q] + 128) >> 8);
+    }
+}
+
+// The same filter for rows that start on a dword (sw % 4 == 0: every level of a 752-wide frame) WITHOUT LDS and without barriers
+// (round 4; the tile kernel above stays for other widths): thread = 4 adjacent output columns x PD_R output rows.  An input row
+// costs the thread ONE 16-byte load (input columns 8 tx - 4 .. 8 tx + 11; neighbouring threads overlap by half, which the L1 / TA
+// absorbs) and its four horizontal sums in two registers of two 16-bit lanes (v_perm_b32 cuts the (column, column + 2) pairs out
+// of the window, v_pk_add / v_pk_mad_u16 weigh them: 18 instructions per row, every partial sum < 2^16); the vertical filter runs
+// over the thread's own 2 PD_R + 3 rows of sums, again on 16-bit lanes ((sum + 128) >> 8 <= 255: 13 instructions per 4 outputs).
+// All loads of a thread are issued before the first use.  Edges: the row index is reflected per row (wave-uniform); the first
+// thread of a row takes columns -2, -1 from columns 2, 1 of its own window, the last one column sw from column sw - 2 (one byte
+// each: no output inside the image reads further out); the 4 bytes in front of a row / up to 12 behind it that the window of
+// those threads covers are read and ignored (the planes are allocated with slack on both sides).
+#define PD_R 8
+#define PD_NIN (2 * PD_R + 3)
+template <int A> FDEV unsigned pd_pair(const unsigned (&d)[4]) {          // window bytes A and A + 2 as two 16-bit lanes
+    return vg_perm<(unsigned)(A & 3) | (0x0Cu << 8) | ((unsigned)((A & 3) + 2) << 16) | (0x0Cu << 24)>(d[(A >> 2) + 1 > 3 ? 3 : (A >> 2) + 1], d[A >> 2]);
+}
+template <int K> FDEV unsigned pd_hsum(const unsigned (&d)[4]) {           // [1 4 6 4 1] at window bytes K .. K + 4 and K + 2 .. K + 6
+    const unsigned e = vg_pk_add(pd_pair<K>(d), pd_pair<K + 4>(d));
+    const unsigned o = vg_pk_add(pd_pair<K + 1>(d), pd_pair<K + 3>(d));
+    return vg_pk_mad(pd_pair<K + 2>(d), 6, vg_pk_mad(o, 4, e));
+}
+extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh,
+                                                                    int waves_per_strip) {
+    const int cam = blockIdx.z;
+    const int dw = sw >> 1, dh = (sh + 1) >> 1;
+    const int ntx = (dw + 3) >> 2;
+    const int wave = uni((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), lane = threadIdx.x & 63;
+    const int strip = wave / waves_per_strip, tx = (wave - strip * waves_per_strip) * 64 + lane;
+    const int y0 = strip * PD_R;
+    if (y0 >= dh || tx >= ntx) return;
+    const glb_u8* s = (const glb_u8*)src_planes[cam];
+    const int c0 = 8 * tx - 4;                     // input column of window byte 0
+    const int isw = sw - c0;                       // window index of column sw (8 or 12 in the last thread of a row, larger elsewhere)
+    const bool left = tx == 0, fix8 = isw == 8, fix12 = isw == 12;
+    uint4 w[PD_NIN];
+#pragma unroll
+    for (int r = 0; r < PD_NIN; ++r) {
+        int ry = reflect101(2 * y0 - 2 + r, sh);
+        ry = ry < 0 ? 0 : (ry >= sh ? sh - 1 : ry);
+        w[r] = vg_load16_unaligned(s + (unsigned)(ry * sw) + c0);
+    }
+    unsigned h[PD_NIN][2];
+#pragma unroll
+    for (int r = 0; r < PD_NIN; ++r) {
+        unsigned d[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
+        const unsigned l0 = vg_perm<0x05060100u>(d[1], d[0]);      // bytes 2, 3 <- window bytes 6, 5 (columns 2, 1)
+        const unsigned r3 = vg_perm<0x07060502u>(d[3], d[2]);      // byte 12 <- window byte 10
+        const unsigned r2 = vg_perm<0x07060502u>(d[2], d[1]);      // byte 8 <- window byte 6
+        d[0] = left ? l0 : d[0];
+        d[3] = fix12 ? r3 : d[3];
+        d[2] = fix8 ? r2 : d[2];
+        h[r][0] = pd_hsum<2>(d);
+        h[r][1] = pd_hsum<6>(d);
+    }
+    glb_u8* dst = (glb_u8*)dst_planes[cam];
+    const int x = 4 * tx;
+#pragma unroll
+    for (int i = 0; i < PD_R; ++i) {
+        const int y = y0 + i;
+        if (y >= dh) break;
+        unsigned o[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const unsigned e = vg_pk_add(h[2 * i][m], h[2 * i + 4][m]);
+            const unsigned od = vg_pk_add(h[2 * i + 1][m], h[2 * i + 3][m]);
+            const unsigned a = vg_pk_mad(h[2 * i + 2][m], 6, vg_pk_mad(od, 4, e));
+            o[m] = vg_pk_shr(vg_pk_add(a, 0x00800080u), 8);
+        }
+        const unsigned px = vg_perm<0x06040200u>(o[1], o[0]);     // the four results, one byte each
+        glb_u8* q = dst + (unsigned)(y * dw + x);
+        if (x + 3 < dw && (dw & 3) == 0) *(glb_u32*)q = px;
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (x + k < dw) q[k] = (uint8_t)(px >> (8 * k));
+        }
     }
 }
 
@@ -392,11 +475,15 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                     }
                 }
             }
+            // bilinear taps as 16-bit dot products (the weights are <= 2^14, pixels < 2^8, derivatives |.| <= 4080): a pair of
+            // neighbours packed by one v_perm_b32, two v_dot2 per tap with the rounding constant as the addend
+            const unsigned wt = (unsigned)w00 | ((unsigned)w01 << 16), wb = (unsigned)w10 | ((unsigned)w11 << 16);
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
-                const int ival = descale(tap4(P[1][q + 1], P[1][q + 2], P[2][q + 1], P[2][q + 2], w00, w01, w10, w11), LK_WBITS - 5);
-                const int ixval = descale(tap4(dx[0][q], dx[0][q + 1], dx[1][q], dx[1][q + 1], w00, w01, w10, w11), LK_WBITS);
-                const int iyval = descale(tap4(dy[0][q], dy[0][q + 1], dy[1][q], dy[1][q + 1], w00, w01, w10, w11), LK_WBITS);
+                const int ival = (int)vg_udot2(vg_pack16(P[2][q + 1], P[2][q + 2]), wb,
+                                               vg_udot2(vg_pack16(P[1][q + 1], P[1][q + 2]), wt, 1u << (LK_WBITS - 5 - 1))) >> (LK_WBITS - 5);
+                const int ixval = vg_sdot2(vg_pack16(dx[1][q], dx[1][q + 1]), wb, vg_sdot2(vg_pack16(dx[0][q], dx[0][q + 1]), wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+                const int iyval = vg_sdot2(vg_pack16(dy[1][q], dy[1][q + 1]), wb, vg_sdot2(vg_pack16(dy[0][q], dy[0][q + 1]), wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
                 iv[q] = (short)ival; ixv[q] = act ? (short)ixval : 0; iyv[q] = act ? (short)iyval : 0;
                 s11 += mul24(ixv[q], ixv[q]); s12 += mul24(ixv[q], iyv[q]); s22 += mul24(iyv[q], iyv[q]);
             }

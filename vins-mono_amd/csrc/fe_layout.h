@@ -6,6 +6,7 @@
 #define FE_CAND_CAP 65536           // power of two >= number of 3x3 local maxima of a 752x480 frame
 
 #define FE_CNT_STRIDE 64
+#define FE_SLACK 256                // bytes in front of / behind the image planes and the frame slots that kernels may read (and ignore)
 struct FeDev {
     int W, H, cams, max_level, max_pts, max_count;
     float min_eig_thr;

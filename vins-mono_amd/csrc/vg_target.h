@@ -61,6 +61,27 @@ __device__ __forceinline__ unsigned vg_udot2(unsigned a, unsigned b, unsigned c)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
 }
 
+// ---- v_perm_b32 with a constant selector (result byte i = byte SEL.i of the eight bytes hi:lo, 0x0C = zero), and arithmetic on
+//      two unsigned 16-bit lanes (v_pk_add_u16 / v_pk_mad_u16 / v_pk_lshrrev_b16: wrap-around per lane, the callers stay below 2^16)
+template <unsigned SEL> __device__ __forceinline__ unsigned vg_perm(unsigned hi, unsigned lo) { return __builtin_amdgcn_perm(hi, lo, SEL); }
+typedef unsigned short vg_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned vg_pk_add(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(vg_us2, a) + __builtin_bit_cast(vg_us2, b)); }
+__device__ __forceinline__ unsigned vg_pk_mad(unsigned a, unsigned short k, unsigned c) {
+    const vg_us2 kk = {k, k};
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(vg_us2, a) * kk + __builtin_bit_cast(vg_us2, c));
+}
+__device__ __forceinline__ unsigned vg_pk_shr(unsigned a, unsigned short n) {
+    const vg_us2 nn = {n, n};
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(vg_us2, a) >> nn);
+}
+
+// ---- two int16 lanes from the low halves of two registers (v_perm_b32) and their signed dot product plus addend (v_dot2_i32_i16)
+__device__ __forceinline__ unsigned vg_pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
+__device__ __forceinline__ int vg_sdot2(unsigned a, unsigned b, int c) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b), c, false);
+}
+
 #else   // ------------------------------------------------------------------------------ CPU fiber emulation (tests/simt)
 typedef double lds_d;
 typedef int lds_i;
@@ -81,5 +102,20 @@ template <int Q> inline unsigned vg_byte_pair(unsigned hi, unsigned lo) {
     const unsigned long long v = ((unsigned long long)hi << 32) | lo;
     return (unsigned)((v >> (8 * Q)) & 255u) | ((unsigned)((v >> (8 * (Q + 1))) & 255u) << 16);
 }
+template <unsigned SEL> inline unsigned vg_perm(unsigned hi, unsigned lo) {
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned sel = (SEL >> (8 * i)) & 255u;
+        if (sel < 8) r |= (unsigned)((v >> (8 * sel)) & 255u) << (8 * i);
+        else if (sel != 0x0Cu) { fprintf(stderr, "simt: unmodelled v_perm_b32 selector 0x%x\n", sel); abort(); }
+    }
+    return r;
+}
+inline unsigned vg_pk_add(unsigned a, unsigned b) { return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16); }
+inline unsigned vg_pk_mad(unsigned a, unsigned short k, unsigned c) { return (((a & 0xffffu) * k + (c & 0xffffu)) & 0xffffu) | (((a >> 16) * k + (c >> 16)) << 16); }
+inline unsigned vg_pk_shr(unsigned a, unsigned short n) { return ((a & 0xffffu) >> n) | (((a >> 16) >> n) << 16); }
+inline unsigned vg_pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+inline int vg_sdot2(unsigned a, unsigned b, int c) { return (int)(short)(a & 0xffffu) * (int)(short)(b & 0xffffu) + (int)(short)(a >> 16) * (int)(short)(b >> 16) + c; }
 inline unsigned vg_udot2(unsigned a, unsigned b, unsigned c) { return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c; }
 #endif
