@@ -117,6 +117,19 @@ def test_lk_edge_cases(handle, frames):
         np.array([[0.0, 0.0], [751.0, 479.0], [2.3, 470.9], [748.7, 3.1], [375.5, 0.4], [-4.0, 100.0], [760.0, 200.0]], np.float32),
         rng.uniform([0, 0], [W - 1, H - 1], (40, 2)).astype(np.float32)])
     _check_lk(tr, 0, a, b, pts)
+    # The fourth bilinear weight is 2^14 minus the three rounded ones: for fractions around 3e-5 .. 6e-5 it is -1 or -2 (round 4: the
+    # 16-bit dot-product taps must treat it as signed; found by the 24-frame node replay, pinned here).  Tracking a frame onto itself
+    # puts the same fractions into the search-window weights of the first iteration of level 0.
+    # (coordinates in [74, 138): float32 resolves 7.6e-6 there, before and after the subtraction of the half window)
+    tiny = np.array([[80 + 4 * k + f, 82 + 3 * k + f] for k in range(12) for f in (3.5e-5, 3.8e-5, 4.2e-5)], np.float32)
+    fr = (tiny - np.float32(10.0)) - np.floor(tiny - np.float32(10.0))
+    w00 = np.rint((1 - fr[:, 0]) * (1 - fr[:, 1]) * 16384.0); w01 = np.rint(fr[:, 0] * (1 - fr[:, 1]) * 16384.0); w10 = np.rint((1 - fr[:, 0]) * fr[:, 1] * 16384.0)
+    assert ((16384 - w00 - w01 - w10) < 0).sum() >= 24
+    _check_lk(tr, 0, a, b, tiny)
+    tr_same = fe.FrontEnd(handle, W, H, 1, 64)
+    tr_same.push_frames([a])
+    tr_same.push_frames([a])
+    _check_lk(tr_same, 0, a, a, tiny)
     # flat patches: min-eigenvalue rejection (status 0 at level 0)
     flat = a.copy()
     flat[200:300, 300:420] = 90

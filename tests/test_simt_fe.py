@@ -29,13 +29,20 @@ for lvl in range(3):
     assert np.array_equal(tr.get_level(0, lvl), ref_lvl), lvl
     ref_lvl = F.pyrdown(ref_lvl)
 tr.push_frames([b])
-pts = np.concatenate([F.gftt(a, 24, 0.01, 12.0), np.array([[0.0, 0.0], [255.0, 159.0], [3.2, 150.7], [250.1, 2.5], [-3.0, 80.0]], np.float32)])
+pts = np.concatenate([F.gftt(a, 24, 0.01, 12.0), np.array([[0.0, 0.0], [255.0, 159.0], [3.2, 150.7], [250.1, 2.5], [-3.0, 80.0]], np.float32),
+                      # fractions for which the fourth bilinear weight (2^14 minus the three rounded ones) is negative
+                      # (fractions in (3.05e-5, 4.58e-5); coordinates in [74, 138) where float32 resolves 7.6e-6)
+                      np.array([[80 + 10 * k + f, 78 + 12 * k + f] for k in range(4) for f in (3.5e-5, 4.2e-5)], np.float32)])
 nxt, st, err = tr.track(0, pts)
 rn, rs, re = F.lk(a, b, pts)
 assert np.array_equal(st, rs), (st, rs)
 assert np.array_equal(nxt.view(np.uint32), rn.view(np.uint32))
 assert np.array_equal(err.view(np.uint32), re.view(np.uint32))
 assert st.sum() >= 20
+tr.push_frames([b])                      # b onto itself: the same fractions in the search-window weights of the first iteration
+nxt, st, err = tr.track(0, pts)
+rn, rs, re = F.lk(b, b, pts)
+assert np.array_equal(st, rs) and np.array_equal(nxt.view(np.uint32), rn.view(np.uint32)) and np.array_equal(err.view(np.uint32), re.view(np.uint32))
 print("OK", int(st.sum()))
 """
 

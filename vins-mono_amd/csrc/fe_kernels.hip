@@ -345,8 +345,9 @@ FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
 
 // descale(tap4(row a bytes q, q + 1; row b bytes q, q + 1), LK_WBITS - 5) for q = 0 .. 6, handed to f(q, value)
 template <int Q, typename F> FDEV void lk_tap_q(const uint2& ra, const uint2& rb, unsigned wt, unsigned wb, F&& f) {
-    const unsigned t = vg_udot2(vg_byte_pair<Q>(rb.y, rb.x), wb, vg_udot2(vg_byte_pair<Q>(ra.y, ra.x), wt, 1u << (LK_WBITS - 5 - 1)));
-    f(Q, (int)(t >> (LK_WBITS - 5)));
+    // (signed lanes: the fourth weight is 2^14 minus the three rounded ones and can be -1 or -2, and the tap then negative)
+    const int t = vg_sdot2(vg_byte_pair<Q>(rb.y, rb.x), wb, vg_sdot2(vg_byte_pair<Q>(ra.y, ra.x), wt, 1 << (LK_WBITS - 5 - 1)));
+    f(Q, t >> (LK_WBITS - 5));
 }
 template <typename F> FDEV void lk_taps7(const uint2& ra, const uint2& rb, unsigned wt, unsigned wb, F&& f) {
     lk_tap_q<0>(ra, rb, wt, wb, f); lk_tap_q<1>(ra, rb, wt, wb, f); lk_tap_q<2>(ra, rb, wt, wb, f); lk_tap_q<3>(ra, rb, wt, wb, f);
@@ -475,13 +476,14 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                     }
                 }
             }
-            // bilinear taps as 16-bit dot products (the weights are <= 2^14, pixels < 2^8, derivatives |.| <= 4080): a pair of
-            // neighbours packed by one v_perm_b32, two v_dot2 per tap with the rounding constant as the addend
+            // bilinear taps as signed 16-bit dot products (weights in [-2, 2^14]: the fourth is 2^14 minus the three rounded ones;
+            // pixels < 2^8, derivatives |.| <= 4080): a pair of neighbours packed by one v_perm_b32, two v_dot2_i32_i16 per tap
+            // with the rounding constant as the addend
             const unsigned wt = (unsigned)w00 | ((unsigned)w01 << 16), wb = (unsigned)w10 | ((unsigned)w11 << 16);
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
-                const int ival = (int)vg_udot2(vg_pack16(P[2][q + 1], P[2][q + 2]), wb,
-                                               vg_udot2(vg_pack16(P[1][q + 1], P[1][q + 2]), wt, 1u << (LK_WBITS - 5 - 1))) >> (LK_WBITS - 5);
+                const int ival = vg_sdot2(vg_pack16(P[2][q + 1], P[2][q + 2]), wb,
+                                          vg_sdot2(vg_pack16(P[1][q + 1], P[1][q + 2]), wt, 1 << (LK_WBITS - 5 - 1))) >> (LK_WBITS - 5);
                 const int ixval = vg_sdot2(vg_pack16(dx[1][q], dx[1][q + 1]), wb, vg_sdot2(vg_pack16(dx[0][q], dx[0][q + 1]), wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
                 const int iyval = vg_sdot2(vg_pack16(dy[1][q], dy[1][q + 1]), wb, vg_sdot2(vg_pack16(dy[0][q], dy[0][q + 1]), wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
                 iv[q] = (short)ival; ixv[q] = act ? (short)ixval : 0; iyv[q] = act ? (short)iyval : 0;
@@ -516,9 +518,9 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
             }
             long long b1, b2;
             {
-                // the lane's 2 x 8 search-window bytes as four dwords; a bilinear tap = two v_dot2_u32_u16 over (pixel, pixel + 1)
+                // the lane's 2 x 8 search-window bytes as four dwords; a bilinear tap = two v_dot2_i32_i16 over (pixel, pixel + 1)
                 // pairs cut out by v_perm_b32, the rounding constant of the descale as the addend (4 instructions instead of four
-                // byte-select multiplies and two three-operand adds; the weights are < 2^15, a tap < 2^22)
+                // byte-select multiplies and two three-operand adds; the weights are in [-2, 2^14], |tap| < 2^22)
                 const uint8_t* p0 = s.jreg + (ry + lyc) * LK_JR + rx + x0;
                 uint2 ra, rb;
                 __builtin_memcpy(&ra, p0, 8); __builtin_memcpy(&rb, p0 + LK_JR, 8);

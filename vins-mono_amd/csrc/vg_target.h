@@ -51,14 +51,9 @@ __device__ __forceinline__ uint4 vg_load16_unaligned(const glb_u8* p) {
     v.x = t4.x; v.y = t4.y; v.z = t4.z; v.w = t4.w;
     return v;
 }
-// ---- bytes q and q + 1 of the eight bytes (hi:lo) as two 16-bit lanes (byte q | byte q + 1 << 16): one v_perm_b32; and the dot
-//      product of two such pairs of unsigned 16-bit lanes plus a 32-bit addend: one v_dot2_u32_u16 (exact: no saturation asked for)
+// ---- bytes q and q + 1 of the eight bytes (hi:lo) as two 16-bit lanes (byte q | byte q + 1 << 16): one v_perm_b32
 template <int Q> __device__ __forceinline__ unsigned vg_byte_pair(unsigned hi, unsigned lo) {
     return __builtin_amdgcn_perm(hi, lo, (unsigned)Q | (0x0Cu << 8) | ((unsigned)(Q + 1) << 16) | (0x0Cu << 24));
-}
-__device__ __forceinline__ unsigned vg_udot2(unsigned a, unsigned b, unsigned c) {
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
 }
 
 // ---- v_perm_b32 with a constant selector (result byte i = byte SEL.i of the eight bytes hi:lo, 0x0C = zero), and arithmetic on
@@ -117,5 +112,4 @@ inline unsigned vg_pk_mad(unsigned a, unsigned short k, unsigned c) { return (((
 inline unsigned vg_pk_shr(unsigned a, unsigned short n) { return ((a & 0xffffu) >> n) | (((a >> 16) >> n) << 16); }
 inline unsigned vg_pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
 inline int vg_sdot2(unsigned a, unsigned b, int c) { return (int)(short)(a & 0xffffu) * (int)(short)(b & 0xffffu) + (int)(short)(a >> 16) * (int)(short)(b >> 16) + c; }
-inline unsigned vg_udot2(unsigned a, unsigned b, unsigned c) { return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c; }
 #endif
