@@ -23,9 +23,10 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 8    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
+#define VG_ABI_VERSION 9    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
                              * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode; 6: vg_ba_reserve, vg_ba_seq_* (windows that stay on the device);
-                             * 7: vg_ba_seq_export / vg_ba_seq_import */
+                             * 7: vg_ba_seq_export / vg_ba_seq_import; 8: vg_host_register, vg_ba_set_fused_min_windows, vg_ba_batch_is_fused;
+                             * 9: vg_fe_keep_eig (the min-eigenvalue map is no longer written unless asked for) */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {
@@ -492,8 +493,12 @@ int vg_fe_undistort(vg_handle* h, const float* pts_xy, int n, const double* intr
 int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const float* forw_un_xy, int n, double threshold, uint8_t* status,
                         int* n_inliers, double* F_out);
 /* debugging / parity taps: copy a pyramid level of the current (which = 0) or previous (1) frame, or the
- * min-eigenvalue map of the last detect, to host memory */
+ * min-eigenvalue map of the last detect, to host memory.  The map (cv::cornerMinEigenVal inside cv::goodFeaturesToTrack,
+ * feature_tracker.cpp:149) is an on-chip intermediate of the detection: vg_fe_keep_eig(h, 1) makes every FOLLOWING detection
+ * write it to device memory as well (4 bytes per pixel and stream, allocated at that call); vg_fe_get_eig without it is
+ * VG_ERR_BAD_ARG. */
 int vg_fe_get_level(vg_handle* h, int cam, int which, int level, uint8_t* out, int* w, int* hgt);
+int vg_fe_keep_eig(vg_handle* h, int on);
 int vg_fe_get_eig(vg_handle* h, int cam, float* out);
 int vg_fe_get_mask(vg_handle* h, int cam, uint8_t* out);          /* current device mask of the stream */
 

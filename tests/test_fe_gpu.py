@@ -42,6 +42,10 @@ def test_min_eigen_map_bit_exact(handle, frames):
     tr = fe.FrontEnd(handle, W, H, 1, 150)
     tr.push_frames([frames[0]])
     tr.detect(0, 10)
+    with pytest.raises(RuntimeError):          # the map is an on-chip intermediate of the detection unless it was asked for
+        tr.get_eig(0)
+    tr.keep_eig()
+    tr.detect(0, 10)
     got, ref = tr.get_eig(0), F.mineig(frames[0])
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 

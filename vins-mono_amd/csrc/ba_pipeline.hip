@@ -330,15 +330,30 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
             double* J0s = LDSB;                  // n x n, row stride n
             for (int wk = c.tid; wk < n * n; wk += BA_NT) J0s[wk] = J0[(wk / n) * L.pld + wk % n];
             __syncthreads();
-            for (int wk = c.tid; wk < n * (n + 1) / 2; wk += BA_NT) {
-                int a, bb;
-                tri_decode(wk, a, bb);
-                double s0 = 0.0, s1 = 0.0;
-                int r = 0;
-                for (; r + 1 < n; r += 2) { s0 += J0s[r * n + a] * J0s[r * n + bb]; s1 += J0s[(r + 1) * n + a] * J0s[(r + 1) * n + bb]; }
-                if (r < n) s0 += J0s[r * n + a] * J0s[r * n + bb];
-                Hp[a * L.Ncap + bb] = s0 + s1;
-                if (!L.big) c.sc[L.so_Hpk + wk] = s0 + s1;
+            // J0^T J0 as X^T X on the matrix cores (round 4; it was n (n + 1) / 2 dot products of length n from LDS, two reads per
+            // multiply-add): a wavefront owns lower 16 x 16 tiles (ta >= tb), A[i][k] = J0[4 s + k][16 ta + i] and B[k][j] =
+            // J0[4 s + k][16 tb + j] come from the same staged rows
+            const int T = (n + 15) >> 4, ntile = T * (T + 1) / 2, nks = (n + 3) >> 2;
+            const int wave = c.tid >> 6, lane = c.tid & 63, li = lane & 15, lk = lane >> 4;
+            for (int t = wave; t < ntile; t += BA_NT / 64) {
+                int ta, tb;
+                tri_decode(t, ta, tb);
+                const int ca = 16 * ta + li, cb = 16 * tb + li;
+                double4_t acc = (double4_t){0, 0, 0, 0};
+                for (int ks = 0; ks < nks; ++ks) {
+                    const int r = 4 * ks + lk;
+                    const double av = (r < n && ca < n) ? J0s[r * n + ca] : 0.0;
+                    const double bv = (r < n && cb < n) ? J0s[r * n + cb] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int a = 16 * ta + lk + 4 * q, bb = 16 * tb + li;        // D[row = lk + 4 q][col = li]
+                    if (a < n && bb <= a) {
+                        Hp[a * L.Ncap + bb] = acc[q];
+                        if (!L.big) c.sc[L.so_Hpk + a * (a + 1) / 2 + bb] = acc[q];
+                    }
+                }
             }
         } else {
             const int ld = L.pld;

@@ -27,8 +27,7 @@ __global__ void fe_copy_kernel(FeDev d, uint8_t* const* dst_planes);
 __global__ void fe_pyrdown_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh, int waves_per_strip);
 __global__ void fe_pyrdown_tile_kernel(const uint8_t* const* src_planes, uint8_t* const* dst_planes, int sw, int sh);
 __global__ void fe_lk_kernel(FeDev d);
-__global__ void fe_mineig_kernel(FeDev d);
-__global__ void fe_candidates_kernel(FeDev d, double quality);
+__global__ void fe_mineig_kernel(FeDev d, double quality);
 hipError_t fe_launch_select(const FeDev& d, double quality, float min_dist, hipStream_t stream);
 __global__ void fe_setmask_kernel(FeDev d, const float* pts_xy, const int* track_cnt, const int* npts, const uint8_t* const* base_masks,
                                   int radius, int* kept_index, int* n_kept, int* kept_xy);
@@ -56,7 +55,7 @@ struct FeState {
     uint8_t* raw2[2] = {nullptr, nullptr};
     int raw_sel = 1;
     uint8_t *raw = nullptr, *lut = nullptr, *mask = nullptr, *status = nullptr;
-    float *prev_xy = nullptr, *next_xy = nullptr, *err = nullptr, *eig = nullptr, *blockmax = nullptr, *corners = nullptr;
+    float *prev_xy = nullptr, *next_xy = nullptr, *err = nullptr, *eig = nullptr, *corners = nullptr;
     int *npts = nullptr, *max_corners = nullptr, *ncorners = nullptr;
     unsigned* ncand = nullptr;
     unsigned long long* keys = nullptr;
@@ -78,7 +77,7 @@ extern "C" void fe_state_destroy(FeState* s) {
     for (int k = 0; k < 2; ++k) { (void)hipFree(s->planes_alloc[k]); (void)hipFree(s->d_ptrs[k]); (void)hipFree(s->d_ptrs_alias[k]); }
     (void)hipFree(s->raw_alloc); (void)hipFree(s->lut); (void)hipFree(s->mask); (void)hipFree(s->status);
     (void)hipFree(s->prev_xy); (void)hipFree(s->next_xy); (void)hipFree(s->err); (void)hipFree(s->eig);
-    (void)hipFree(s->blockmax); (void)hipFree(s->corners); (void)hipFree(s->npts); (void)hipFree(s->max_corners);
+    (void)hipFree(s->corners); (void)hipFree(s->npts); (void)hipFree(s->max_corners);
     (void)hipFree(s->ncorners); (void)hipFree(s->ncand); (void)hipFree(s->keys);
     (void)hipFree(s->sm_pts); (void)hipFree(s->sm_cnt); (void)hipFree(s->sm_n); (void)hipFree(s->sm_kidx); (void)hipFree(s->sm_nk);
     (void)hipFree(s->sm_kxy); (void)hipFree(s->sm_base); (void)hipFree((void*)s->sm_base_ptrs); (void)hipFree(s->lift_in); (void)hipFree(s->lift_out);
@@ -130,7 +129,6 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
         HIPCHK(h, hipMalloc((void**)&s->d_ptrs[k], sizeof(uint8_t*) * s->h_ptrs[k].size()));
         HIPCHK(h, hipMemcpy(s->d_ptrs[k], s->h_ptrs[k].data(), sizeof(uint8_t*) * s->h_ptrs[k].size(), hipMemcpyHostToDevice));
     }
-    d.nblk_eig = ((width + 63) / 64) * ((height + 3) / 4);
     d.cand_cap = FE_CAND_CAP;
     HIPCHK(h, hipMalloc((void**)&s->raw_alloc, 2 * npix * n_cams + 2 * FE_SLACK));
     HIPCHK(h, hipMemset(s->raw_alloc, 0, 2 * npix * n_cams + 2 * FE_SLACK));
@@ -150,8 +148,6 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     HIPCHK(h, hipMalloc((void**)&s->prev_xy, sizeof(float) * 2 * n_cams * max_points));
     HIPCHK(h, hipMalloc((void**)&s->next_xy, sizeof(float) * 2 * n_cams * max_points));
     HIPCHK(h, hipMalloc((void**)&s->err, sizeof(float) * n_cams * max_points));
-    HIPCHK(h, hipMalloc((void**)&s->eig, sizeof(float) * npix * n_cams));
-    HIPCHK(h, hipMalloc((void**)&s->blockmax, sizeof(float) * (size_t)d.nblk_eig * n_cams));
     HIPCHK(h, hipMalloc((void**)&s->corners, sizeof(float) * 2 * n_cams * max_points));
     HIPCHK(h, hipMalloc((void**)&s->npts, sizeof(int) * n_cams));
     HIPCHK(h, hipMemset(s->npts, 0, sizeof(int) * n_cams));
@@ -160,7 +156,7 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     HIPCHK(h, hipMalloc((void**)&s->ncand, sizeof(unsigned) * FE_CNT_STRIDE * n_cams));
     HIPCHK(h, hipMalloc((void**)&s->keys, sizeof(unsigned long long) * (size_t)FE_CAND_CAP * n_cams));
     d.raw = s->raw2[s->raw_sel]; d.lut = s->lut; d.npts = s->npts; d.prev_xy = s->prev_xy; d.next_xy = s->next_xy; d.status = s->status;
-    d.err = s->err; d.eig = s->eig; d.mask = s->mask; d.blockmax = s->blockmax; d.ncand = s->ncand; d.keys = s->keys;
+    d.err = s->err; d.eig = nullptr; d.keep_eig = 0; d.mask = s->mask; d.ncand = s->ncand; d.keys = s->keys;
     d.max_corners = s->max_corners; d.corners = s->corners; d.ncorners = s->ncorners;
     s->h_npts.assign(n_cams, 0);
     s->pushed_once.assign(n_cams, 0);
@@ -352,9 +348,9 @@ extern "C" int vg_fe_detect_async(vg_handle* h, double quality, double min_dist)
     const int cell = (int)std::lrint(min_dist) < 1 ? 1 : (int)std::lrint(min_dist);
     if (((d.W + cell - 1) / cell) * ((d.H + cell - 1) / cell) > FE_MAX_CELLS) { h->err = "min_dist too small for the cell grid"; return VG_ERR_UNSUPPORTED; }
     HIPCHK(h, hipMemsetAsync(s->ncand, 0, sizeof(unsigned) * FE_CNT_STRIDE * d.cams, h->stream));
-    const dim3 g((d.W + 63) / 64, (d.H + 3) / 4, d.cams);
-    hipLaunchKernelGGL(fe_mineig_kernel, g, dim3(256), 0, h->stream, d);
-    hipLaunchKernelGGL(fe_candidates_kernel, g, dim3(256), 0, h->stream, d, quality);
+    // min-eigenvalue map + candidates in one kernel (64 x 16 tiles), then the exact threshold, the sort and the min-distance walk
+    const dim3 g((d.W + 63) / 64, (d.H + 15) / 16, d.cams);
+    hipLaunchKernelGGL(fe_mineig_kernel, g, dim3(256), 0, h->stream, d, quality);
     HIPCHK(h, fe_launch_select(d, quality, (float)min_dist, h->stream));
     HIPCHK(h, hipGetLastError());
     return VG_OK;
@@ -502,9 +498,21 @@ extern "C" int vg_fe_get_level(vg_handle* h, int cam, int which, int level, uint
     return VG_OK;
 }
 
+// The min-eigenvalue map is an LDS-only intermediate of the detection since round 4; a caller that wants to look at it (the parity
+// tests do) asks for it before the detection: the map of every following detection is then written to HBM as well.
+extern "C" int vg_fe_keep_eig(vg_handle* h, int on) {
+    if (!h || !h->fe) return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    if (on && !s->eig) HIPCHK(h, hipMalloc((void**)&s->eig, sizeof(float) * (size_t)s->W * s->H * s->cams));
+    s->d.eig = s->eig;
+    s->d.keep_eig = on ? 1 : 0;
+    return VG_OK;
+}
+
 extern "C" int vg_fe_get_eig(vg_handle* h, int cam, float* out) {
     if (!h || !h->fe || cam < 0 || cam >= h->fe->cams || !out) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
+    if (!s->d.keep_eig) { h->err = "vg_fe_get_eig: call vg_fe_keep_eig(h, 1) before the detection whose map is wanted"; return VG_ERR_BAD_ARG; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, s->eig + (size_t)cam * s->W * s->H, sizeof(float) * s->W * s->H, hipMemcpyDeviceToHost));
     return VG_OK;

@@ -580,33 +580,53 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
 }
 
 // ================================================================================================ GFTT
-// min-eigenvalue map (corner.cpp cornerMinEigenVal, blockSize 3, Sobel 3): tile 64x4 + halo 2 in LDS.
-// Also the masked per-block maximum for minMaxLoc.
-extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d) {
-    __shared__ uint8_t tile[8][68];          // rows y-2 .. y+5, cols x-2 .. x+65
-    __shared__ float gx[6][66], gy[6][66];   // gradients on rows y-1 .. y+4, cols x-1 .. x+64
+// min-eigenvalue map (corner.cpp cornerMinEigenVal, blockSize 3, Sobel 3) AND the corner candidates in one pass (round 4: the map
+// used to go to HBM, 1.44 MB per frame, and come back nine times per pixel in a second kernel).  Tile = 64 x 16 pixels; the map of
+// the tile and of a one-pixel ring around it lives in LDS, so the 3 x 3 comparison of goodFeaturesToTrack needs no second pass:
+//   threshold (THRESH_TOZERO at maxVal * quality) + 3x3 dilate equality + mask   ==   value > threshold, value >= its 8 neighbours
+// (a neighbour above the value is above the threshold too), and the second condition does not depend on the threshold.  The threshold
+// does depend on the maximum over the whole (masked) image, which no tile knows: a tile prunes with a LOWER bound of it -- quality x
+// the larger of its own masked maximum and the running maximum the tiles before it have left in HBM (an atomicMax, so the bound and
+// with it the length of the list depend on timing) -- and fe_select_kernel applies the exact threshold before it sorts: the list that
+// survives is the list of the two-pass form whatever the timing.  (Values <= 0 are never corners: the exact threshold is >= 0 whenever
+// the maximum is, and a masked maximum below zero does not occur for the minimum eigenvalue of a sum of outer products beyond
+// rounding; oracle/ASSUMPTIONS.md F10.)
+// key = (ordered float bits << 32) | linear index   (sort descending = value desc, then index desc)
+// The map itself reaches HBM only when the caller asked for it (vg_fe_keep_eig: tests compare it bit by bit).
+#define ME_R 16
+extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d, double quality) {
+    __shared__ uint8_t tile[ME_R + 6][72];                        // rows y0-3 .. y0+R+2, cols x0-3 .. x0+66 (reflected coordinates)
+    __shared__ float gx[ME_R + 4][68], gy[ME_R + 4][68];          // gradients on rows y0-2 .. y0+R+1, cols x0-2 .. x0+65
+    __shared__ float eg[ME_R + 2][66];                            // the map on rows y0-1 .. y0+R, cols x0-1 .. x0+64
     __shared__ float bmax[4];
+    __shared__ unsigned wcount[4], wbase[4], lbound;
     const int cam = blockIdx.z, W = d.W, H = d.H;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * ME_R;
     const glb_u8* img = (const glb_u8*)d.cur_planes[cam];          // level 0
-    for (int k = threadIdx.x; k < 8 * 68; k += 256) {
-        const int yy = k / 68, xx = k % 68;
+    auto PX = [&](int y, int x) {                                  // image pixel at reflected coordinates (clamped beyond one reflection:
+        int ry = reflect101(y, H), rx = reflect101(x, W);          //  nothing an in-image result depends on lies that far out)
+        ry = ry < 0 ? 0 : (ry >= H ? H - 1 : ry);
+        rx = rx < 0 ? 0 : (rx >= W ? W - 1 : rx);
+        return (int)img[(size_t)ry * W + rx];
+    };
+    for (int k = threadIdx.x; k < (ME_R + 6) * 70; k += 256) {
+        const int yy = k / 70, xx = k - 70 * yy;
         // NB: REFLECT_101 is applied per filter stage in OpenCV (Sobel on the image, then boxFilter on cov); the halo
         // below holds image pixels at reflected coordinates, gradients are evaluated at reflected positions too.
-        tile[yy][xx] = img[(size_t)reflect101(y0 - 2 + yy, H) * W + reflect101(x0 - 2 + xx, W)];
+        tile[yy][xx] = (uint8_t)PX(y0 - 3 + yy, x0 - 3 + xx);
     }
     __syncthreads();
     const float k1 = (float)(1.0 / 3060.0), k2 = (float)(2.0 / 3060.0);
-    // gradients at (y0-1+gy_, x0-1+gx_): position may lie outside the image -> the boxFilter's reflect-101 wants the
+    // gradients at (y0-2+yy, x0-2+xx): position may lie outside the image -> the boxFilter's reflect-101 wants the
     // gradient AT THE REFLECTED POSITION, which is not the gradient computed from reflected pixels; handled below by
     // recomputing from global memory for those few halo positions.
-    for (int k = threadIdx.x; k < 6 * 66; k += 256) {
-        const int yy = k / 66, xx = k % 66;
-        int Y = y0 - 1 + yy, X = x0 - 1 + xx;
+    for (int k = threadIdx.x; k < (ME_R + 4) * 68; k += 256) {
+        const int yy = k / 68, xx = k - 68 * yy;
+        int Y = y0 - 2 + yy, X = x0 - 2 + xx;
         float dxv, dyv;
         const int Yr = reflect101(Y, H), Xr = reflect101(X, W);
         if (Yr == Y && Xr == X) {
-            const uint8_t(*t)[68] = tile;
+            const uint8_t(*t)[72] = tile;
             const int ty = yy + 1, tx = xx + 1;       // tile index of (Y, X)
             const float r0 = (float)(t[ty - 1][tx + 1] - t[ty - 1][tx - 1]);
             const float r1 = (float)(t[ty][tx + 1] - t[ty][tx - 1]);
@@ -617,96 +637,99 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d) {
             dyv = s2 - s0;
         } else {
             // gradient at the reflected (in-image) position, from global memory
-            auto P = [&](int y, int x) { return (int)img[(size_t)reflect101(y, H) * W + reflect101(x, W)]; };
-            Y = Yr; X = Xr;
-            const float r0 = (float)(P(Y - 1, X + 1) - P(Y - 1, X - 1));
-            const float r1 = (float)(P(Y, X + 1) - P(Y, X - 1));
-            const float r2 = (float)(P(Y + 1, X + 1) - P(Y + 1, X - 1));
+            Y = Yr < 0 ? 0 : (Yr >= H ? H - 1 : Yr); X = Xr < 0 ? 0 : (Xr >= W ? W - 1 : Xr);
+            const float r0 = (float)(PX(Y - 1, X + 1) - PX(Y - 1, X - 1));
+            const float r1 = (float)(PX(Y, X + 1) - PX(Y, X - 1));
+            const float r2 = (float)(PX(Y + 1, X + 1) - PX(Y + 1, X - 1));
             dxv = k2 * r1 + k1 * (r0 + r2);
-            const float s0 = (float)P(Y - 1, X) * k2 + (float)(P(Y - 1, X - 1) + P(Y - 1, X + 1)) * k1;
-            const float s2 = (float)P(Y + 1, X) * k2 + (float)(P(Y + 1, X - 1) + P(Y + 1, X + 1)) * k1;
+            const float s0 = (float)PX(Y - 1, X) * k2 + (float)(PX(Y - 1, X - 1) + PX(Y - 1, X + 1)) * k1;
+            const float s2 = (float)PX(Y + 1, X) * k2 + (float)(PX(Y + 1, X - 1) + PX(Y + 1, X + 1)) * k1;
             dyv = s2 - s0;
         }
         gx[yy][xx] = dxv; gy[yy][xx] = dyv;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const int x = x0 + lx, y = y0 + ly;
-    float val = -1.f;
-    bool inimg = x < W && y < H;
-    if (inimg) {
-        double sxx = 0, sxy = 0, syy = 0;
-#pragma unroll
-        for (int v = 0; v < 3; ++v)
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const float a = gx[ly + v][lx + u], b = gy[ly + v][lx + u];
-                sxx += (double)(a * a); sxy += (double)(a * b); syy += (double)(b * b);
-            }
-        const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
-        val = (float)((a + c) - sqrtf((a - c) * (a - c) + b * b));
-        d.eig[(size_t)cam * W * H + (size_t)y * W + x] = val;
-    }
-    // masked maximum of this block
+    // the map on the tile and its ring; the masked maximum over the tile's own pixels
     const uint8_t* mask = d.mask + (size_t)cam * W * H;
-    float m = (inimg && mask[(size_t)y * W + x]) ? val : -INFINITY;
+    float m = -INFINITY;
+    for (int k = threadIdx.x; k < (ME_R + 2) * 66; k += 256) {
+        const int ey = k / 66, ex = k - 66 * ey;
+        const int y = y0 - 1 + ey, x = x0 - 1 + ex;
+        float val = -INFINITY;
+        if (x >= 0 && y >= 0 && x < W && y < H) {
+            double sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const float a = gx[ey + v][ex + u], b = gy[ey + v][ex + u];
+                    sxx += (double)(a * a); sxy += (double)(a * b); syy += (double)(b * b);
+                }
+            const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+            val = (float)((a + c) - sqrtf((a - c) * (a - c) + b * b));
+            if (ey >= 1 && ey <= ME_R && ex >= 1 && ex <= 64) {             // the tile's own pixel
+                if (d.keep_eig) d.eig[(size_t)cam * W * H + (size_t)y * W + x] = val;
+                if (mask[(size_t)y * W + x]) m = fmaxf(m, val);
+            }
+        }
+        eg[ey][ex] = val;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
     if ((threadIdx.x & 63) == 0) bmax[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         const float bm = fmaxf(fmaxf(bmax[0], bmax[1]), fmaxf(bmax[2], bmax[3]));
-        d.blockmax[(size_t)cam * d.nblk_eig + blockIdx.y * gridDim.x + blockIdx.x] = bm;
         // per-stream maximum for minMaxLoc (max is order-independent -> deterministic); slot zeroed with ncand
-        if (bm != -INFINITY) atomicMax(&d.ncand[FE_CNT_STRIDE * cam + 32], ford(bm));
+        unsigned seen = 0u;
+        if (bm != -INFINITY) { const unsigned mine = ford(bm); seen = atomicMax(&d.ncand[FE_CNT_STRIDE * cam + 32], mine); seen = seen > mine ? seen : mine; }
+        else seen = atomicMax(&d.ncand[FE_CNT_STRIDE * cam + 32], 0u);          // (a read)
+        lbound = seen;
     }
-}
-
-// threshold (THRESH_TOZERO at maxVal*quality) + 3x3 dilate equality + mask -> candidate keys
-// key = (ordered float bits << 32) | linear index   (sort descending = value desc, then index desc)
-extern "C" __global__ __launch_bounds__(256) void fe_candidates_kernel(FeDev d, double quality) {
-    const int cam = blockIdx.z, W = d.W, H = d.H;
-    const unsigned smax = d.ncand[FE_CNT_STRIDE * cam + 32];          // ordered-uint maximum left by fe_mineig_kernel (0 = none)
-    const float mf = smax ? funord(smax) : -INFINITY;
-    // minMaxLoc over an empty mask leaves maxVal = 0 in the reference
-    const double maxVal = (mf == -INFINITY) ? 0.0 : (double)mf;
-    const float thr = (float)(maxVal * quality);
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool is_cand = false;
-    float val = 0.f;
-    if (x >= 1 && y >= 1 && x < W - 1 && y < H - 1) {
-        const float* e = d.eig + (size_t)cam * W * H;
-        const float raw = e[(size_t)y * W + x];
-        val = raw > thr ? raw : 0.f;
-        if (val != 0.f && d.mask[(size_t)cam * W * H + (size_t)y * W + x]) {
-            float mx = val;
+    __syncthreads();
+    // lower bound of the threshold: the same expression as the exact one (fe_select_kernel), monotone in the maximum
+    const unsigned sb = lbound;
+    const float lbf = sb ? funord(sb) : -INFINITY;
+    const float thr_lb = (float)(((lbf == -INFINITY) ? 0.0 : (double)lbf) * quality);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool is_cand[ME_R / 4];
+    unsigned my[ME_R / 4], tot = 0;
 #pragma unroll
-            for (int v = -1; v <= 1; ++v)
+    for (int i = 0; i < ME_R / 4; ++i) {
+        const int ly = wv + 4 * i, x = x0 + lane, y = y0 + ly;
+        bool cnd = false;
+        if (x >= 1 && y >= 1 && x < W - 1 && y < H - 1) {
+            const float raw = eg[ly + 1][lane + 1];
+            if (raw > 0.f && raw > thr_lb && mask[(size_t)y * W + x]) {
+                float mx = raw;
 #pragma unroll
-                for (int u = -1; u <= 1; ++u) {
-                    const float o = e[(size_t)(y + v) * W + x + u];
-                    mx = fmaxf(mx, o > thr ? o : 0.f);
-                }
-            is_cand = (val == mx);
+                for (int v = 0; v < 3; ++v)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) mx = fmaxf(mx, eg[ly + v][lane + u]);
+                cnd = (raw == mx);
+            }
         }
+        const unsigned long long bal = __ballot(cnd);
+        is_cand[i] = cnd;
+        my[i] = tot + __popcll(bal & ((1ull << lane) - 1ull));
+        tot += __popcll(bal);
     }
     // block-aggregated append: one global atomic per workgroup (the final order comes from the sort)
-    __shared__ unsigned wcount[4], wbase[4];
-    const unsigned long long bal = __ballot(is_cand);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned my = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wcount[wv] = __popcll(bal);
+    if (lane == 0) wcount[wv] = tot;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-        const unsigned base = tot ? atomicAdd(&d.ncand[FE_CNT_STRIDE * cam], tot) : 0u;
+        const unsigned all = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        const unsigned base = all ? atomicAdd(&d.ncand[FE_CNT_STRIDE * cam], all) : 0u;
         wbase[0] = base; wbase[1] = base + wcount[0]; wbase[2] = wbase[1] + wcount[1]; wbase[3] = wbase[2] + wcount[2];
     }
     __syncthreads();
-    if (is_cand) {
-        const unsigned slot = wbase[wv] + my;
+#pragma unroll
+    for (int i = 0; i < ME_R / 4; ++i) {
+        if (!is_cand[i]) continue;
+        const int ly = wv + 4 * i, x = x0 + lane, y = y0 + ly;
+        const unsigned slot = wbase[wv] + my[i];
         if (slot < (unsigned)d.cand_cap)
-            d.keys[(size_t)cam * d.cand_cap + slot] = ((unsigned long long)ford(val) << 32) | (unsigned)(y * W + x);
+            d.keys[(size_t)cam * d.cand_cap + slot] = ((unsigned long long)ford(eg[ly + 1][lane + 1]) << 32) | (unsigned)(y * W + x);
     }
 }
 
@@ -796,11 +819,40 @@ extern "C" __global__ __launch_bounds__(1024) void fe_select_kernel(FeDev d, dou
     w.md2 = (double)min_dist * (double)min_dist;
     w.use_dist = min_dist >= 1.f;
     for (int k = tid; k < w.gw * w.gh; k += 1024) cellcnt[k] = 0;
-    unsigned n = d.ncand[FE_CNT_STRIDE * cam];
-    if (n > (unsigned)d.cand_cap) n = d.cand_cap;
+    unsigned nall = d.ncand[FE_CNT_STRIDE * cam];
+    if (nall > (unsigned)d.cand_cap) nall = d.cand_cap;
     unsigned long long* keys = d.keys + (size_t)cam * d.cand_cap;
     float* corners = d.corners + (size_t)cam * d.max_pts * 2;
     int nacc = 0;
+    // The exact threshold (THRESH_TOZERO at maxVal * quality; minMaxLoc over an empty mask leaves maxVal = 0 in the reference).
+    // fe_mineig_kernel pruned with a lower bound of it: whatever it let through in excess goes here, so the surviving list does not
+    // depend on the order in which the tiles ran.  The survivors are compacted to the front of the list (their order is irrelevant:
+    // everything below sorts).
+    const unsigned smax = d.ncand[FE_CNT_STRIDE * cam + 32];
+    const float mf = smax ? funord(smax) : -INFINITY;
+    const double maxVal = (mf == -INFINITY) ? 0.0 : (double)mf;
+    const float thr = (float)(maxVal * quality);
+    if (tid == 0) ctl[5] = 0;
+    __syncthreads();
+    for (unsigned i0 = 0; i0 < nall; i0 += 1024) {
+        // (in place: a chunk's survivors land at or before the chunk's own start, and every key of the chunk is in a register
+        //  before the first store of the chunk)
+        const unsigned i = i0 + tid;
+        const unsigned long long key = i < nall ? keys[i] : 0ull;
+        const bool keep = i < nall && funord((unsigned)(key >> 32)) > thr;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) grp[wave] = __popcll(bal);
+        __syncthreads();
+        unsigned before = (unsigned)ctl[5];
+        for (int q = 0; q < wave; ++q) before += grp[q];
+        if (keep) keys[before + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+        __syncthreads();
+        if (tid == 0) { unsigned t = 0; for (int q = 0; q < 16; ++q) t += grp[q]; ctl[5] += (int)t; }
+        __syncthreads();
+    }
+    const unsigned n = (unsigned)ctl[5];
+    __threadfence_block();
+    __syncthreads();
     if (n <= FE_SEL_CAP) {
         unsigned np = 1;
         while (np < n) np <<= 1;
@@ -810,11 +862,7 @@ extern "C" __global__ __launch_bounds__(1024) void fe_select_kernel(FeDev d, dou
         if (wave == 0) { nacc = sel_walk(w, sk, n, 0, corners, lane); if (lane == 0) d.ncorners[cam] = nacc; }
         return;
     }
-    // value bins: linear between the threshold and the maximum (same expressions as fe_candidates_kernel)
-    const unsigned smax = d.ncand[FE_CNT_STRIDE * cam + 32];
-    const float mf = smax ? funord(smax) : -INFINITY;
-    const double maxVal = (mf == -INFINITY) ? 0.0 : (double)mf;
-    const float thr = (float)(maxVal * quality);
+    // value bins: linear between the threshold and the maximum
     const float span = (float)maxVal - thr;
     const float scale = span > 0.f ? (float)(FE_SEL_BINS - 1) / span : 0.f;
     auto bin_of = [&](unsigned long long key) {

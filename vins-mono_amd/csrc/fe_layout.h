@@ -21,10 +21,9 @@ struct FeDev {
     float* next_xy;                 // [cams][max_pts][2]
     uint8_t* status;                // [cams][max_pts]
     float* err;                     // [cams][max_pts]
-    float* eig;                     // [cams][H][W]
+    float* eig;                     // [cams][H][W]; allocated by vg_fe_keep_eig
     const uint8_t* mask;            // [cams][H][W]
-    float* blockmax;                // [cams][nblk_eig]
-    int nblk_eig;
+    int keep_eig;                   // write the map to `eig` (vg_fe_keep_eig; it is an LDS-only intermediate otherwise)
     unsigned* ncand;                // [cams][FE_CNT_STRIDE]: [0] candidate count, [32] ordered-uint eig maximum; one
                                     // 256-byte line per stream (same-line atomics of different streams serialise in L2)
     unsigned long long* keys;       // [cams][FE_CAND_CAP]

@@ -31,6 +31,7 @@ class FrontEnd:
         L.vg_fe_detect_download.argtypes = [C.c_void_p, _f4, _i4]
         L.vg_fe_get_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8, _i4, _i4]
         L.vg_fe_get_eig.argtypes = [C.c_void_p, C.c_int, _f4]
+        L.vg_fe_keep_eig.argtypes = [C.c_void_p, C.c_int]
         L.vg_fe_set_mask.argtypes = [C.c_void_p, _f4, _i4, _i4, C.POINTER(_u8), C.c_int, _i4, _i4]
         L.vg_fe_detect_masked.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, _f4, _i4]
         L.vg_fe_get_mask.argtypes = [C.c_void_p, C.c_int, _u8]
@@ -172,6 +173,10 @@ class FrontEnd:
         buf = np.zeros(self.W * self.H, np.uint8)
         self.hd._chk(self.lib.vg_fe_get_level(self.h, cam, int(previous), level, buf.ctypes.data_as(_u8), C.byref(w), C.byref(hh)), "vg_fe_get_level")
         return buf[:w.value * hh.value].reshape(hh.value, w.value).copy()
+
+    def keep_eig(self, on=True):
+        """the min-eigenvalue map of every following detection is written to device memory too (it is an on-chip intermediate otherwise)"""
+        self.hd._chk(self.lib.vg_fe_keep_eig(self.h, 1 if on else 0), "vg_fe_keep_eig")
 
     def get_eig(self, cam):
         out = np.zeros((self.H, self.W), np.float32)
