@@ -99,7 +99,7 @@ tr.push_frames([a, b], equalize=True)
 ea, eb = F.clahe(a), F.clahe(b)
 assert np.array_equal(tr.get_level(0, 0), ea) and np.array_equal(tr.get_level(1, 0), eb)
 assert np.array_equal(tr.get_level(1, 1), F.pyrdown(eb))
-# GFTT (fe_mineig_kernel, fe_candidates_kernel, fe_select_kernel): ordered corner lists, small and large min distance, host mask
+# GFTT (fe_mineig_kernel incl. the candidates, fe_select_kernel): ordered corner lists, small and large min distance, host mask
 for cam, img in ((0, ea), (1, eb)):
     for n, md in ((40, 12.0), (150, 20.0)):
         assert np.array_equal(tr.detect(cam, n, 0.01, md), F.gftt(img, n, 0.01, md)), (cam, n, md)
