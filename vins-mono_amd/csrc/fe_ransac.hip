@@ -87,12 +87,11 @@ DEV bool fr_model_before(const double* Fa, const double* Fb) {
     return false;
 }
 
-// One iteration of the schedule per thread: the best model of its sample (F[k][9]) and that model's inlier count (lmeds == 0)
-// or median error (lmeds != 0, n <= FE_LMEDS_MAXPTS); count -1 = the sample gave no model.
+// First half of an iteration of the schedule, one thread per sample: run7Point -> the up-to-three models of the sample
+// (models[k][3][9]; fe_ransac_count_kernel ranks them: the best model of the sample (F[k][9]) and that model's inlier count
+// (lmeds == 0) or median error (lmeds != 0, n <= FE_LMEDS_MAXPTS); count -1 = the sample gave no model).
 extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n,
-                                                                   float thresh2, int lmeds, const int* __restrict__ sched, int nsched,
-                                                                   double* __restrict__ Fout, int* __restrict__ count,
-                                                                   double* __restrict__ median) {
+                                                                   const int* __restrict__ sched, int nsched, double* __restrict__ models) {
     __shared__ double A[63][64];          // design matrix, element (row r, col c) at A[r * 9 + c][thread]
     __shared__ double V[81][64];          // accumulated right singular vectors
     const int t = threadIdx.x, k = blockIdx.x * 64 + t;
@@ -168,23 +167,49 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* 
     }
     double roots[3] = {0, 0, 0};
     const int nr = fr_solve_cubic(cf, roots);
+    // the up-to-three models of the sample, in the order of the roots; a model that is not finite is marked by F[0] = NaN
+    for (int m = 0; m < 3; ++m) {
+        double F[9];
+        bool ok = (nr >= 1 && nr <= 3) && m < nr;
+        if (ok) {
+            double lambda = roots[m], mu = 1.0;
+            const double sc = f1[8] * roots[m] + f2[8];
+            if (fabs(sc) > 2.220446049250313e-16) { mu = 1.0 / sc; lambda *= mu; F[8] = 1.0; } else F[8] = 0.0;
+            for (int e = 0; e < 8; ++e) F[e] = f1[e] * lambda + f2[e] * mu;
+            for (int e = 0; e < 9; ++e) ok = ok && (F[e] == F[e]) && fabs(F[e]) < 1e300;
+        }
+        if (live)
+            for (int e = 0; e < 9; ++e) models[((size_t)k * 3 + m) * 9 + e] = ok ? F[e] : __builtin_nan("");
+    }
+}
+
+// Second half of an iteration, one WAVEFRONT per sample (round 4: the thread that solved the sample used to walk all n points for each
+// of its models, 3 x 150 error evaluations in sequence -- about half of the 0.4 ms of the call): the lanes share the points, a model's
+// inlier count is a sum of ballots, the selection among the models (most inliers, canonical order on ties: exactly the sequence of
+// comparisons of the one-thread form) is evaluated uniformly, and the inlier set of the chosen model leaves as ceil(n / 64) ballot words
+// so that the host needs no second kernel for the mask.  LMedS (n < 15): lane 0 ranks the errors as before.
+extern "C" __global__ __launch_bounds__(64) void fe_ransac_count_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n, float thresh2,
+                                                                        int lmeds, const double* __restrict__ models, int nsched,
+                                                                        double* __restrict__ Fout, int* __restrict__ count, double* __restrict__ median,
+                                                                        unsigned long long* __restrict__ inl_words) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= nsched) return;
+    const int nw = (n + 63) >> 6;
     double bestF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int bgood = -1;
     double bmed = 0.0;
     bool have = false;
     for (int m = 0; m < 3; ++m) {
-        if (!(nr >= 1 && nr <= 3) || m >= nr) continue;
         double F[9];
-        double lambda = roots[m], mu = 1.0;
-        const double sc = f1[8] * roots[m] + f2[8];
-        if (fabs(sc) > 2.220446049250313e-16) { mu = 1.0 / sc; lambda *= mu; F[8] = 1.0; } else F[8] = 0.0;
-        for (int e = 0; e < 8; ++e) F[e] = f1[e] * lambda + f2[e] * mu;
-        bool finite = true;
-        for (int e = 0; e < 9; ++e) finite = finite && (F[e] == F[e]) && fabs(F[e]) < 1e300;
-        if (!finite) continue;
+        for (int e = 0; e < 9; ++e) F[e] = models[((size_t)k * 3 + m) * 9 + e];
+        if (!(F[0] == F[0])) continue;                      // (uniform: no such model)
         if (!lmeds) {
             int good = 0;
-            for (int i = 0; i < n; ++i) good += fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2 ? 1 : 0;
+            for (int w = 0; w < nw; ++w) {
+                const int i = 64 * w + lane;
+                const bool in = i < n && fr_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2;
+                good += __popcll(__ballot(in));
+            }
             if (!have || good > bgood || (good == bgood && fr_model_before(F, bestF))) {
                 bgood = good; have = true;
                 for (int e = 0; e < 9; ++e) bestF[e] = F[e];
@@ -214,7 +239,14 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* 
             }
         }
     }
-    if (live) {
+    if (have && !lmeds)
+        for (int w = 0; w < nw; ++w) {
+            const int i = 64 * w + lane;
+            const bool in = i < n && fr_error(bestF, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thresh2;
+            const unsigned long long bal = __ballot(in);
+            if (lane == 0) inl_words[(size_t)k * nw + w] = bal;
+        }
+    if (lane == 0) {
         for (int e = 0; e < 9; ++e) Fout[(size_t)k * 9 + e] = bestF[e];
         count[k] = have ? bgood : -1;
         median[k] = bmed;
@@ -310,7 +342,8 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
     // synchronises the whole device — it would stall the BA handle's asynchronous marginalization / state download.
     const size_t off_F = sizeof(float) * 4 * FE_RANSAC_MAXPTS, off_m = off_F + sizeof(double) * 9 * FE_RANSAC_MAXIT;
     const size_t off_i = off_m + sizeof(double) * FE_RANSAC_MAXIT, off_sc = off_i + sizeof(int) * FE_RANSAC_MAXIT;
-    const size_t off_s = off_sc + sizeof(int) * 7 * FE_RANSAC_MAXIT, total = off_s + FE_RANSAC_MAXPTS;
+    const size_t off_s = off_sc + sizeof(int) * 7 * FE_RANSAC_MAXIT, off_md = (off_s + FE_RANSAC_MAXPTS + 255) / 256 * 256;
+    const size_t off_w = off_md + sizeof(double) * 27 * FE_RANSAC_MAXIT, total = off_w + sizeof(unsigned long long) * (FE_RANSAC_MAXPTS / 64) * FE_RANSAC_MAXIT;
     if (!h->ransac_buf && (e = hipMalloc(&h->ransac_buf, total)) != hipSuccess) { h->ransac_buf = nullptr; return fail(e); }
     char* base = (char*)h->ransac_buf;
     float* d_p = (float*)base;
@@ -319,6 +352,8 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
     int* d_cnt = (int*)(base + off_i);
     int* d_sched = (int*)(base + off_sc);
     unsigned char* d_s = (unsigned char*)(base + off_s);
+    double* d_models = (double*)(base + off_md);                              // [iteration][3][9]
+    unsigned long long* d_words = (unsigned long long*)(base + off_w);        // [iteration][ceil(n / 64)] inlier ballots of the iteration's model
     int best = -1, n_in = n;
     double t2_mask = threshold * threshold;
     if (nsched > 0) {
@@ -326,13 +361,22 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
         if ((e = hipMemcpyAsync(d_p + 2 * n, forw_un_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
         if ((e = hipMemcpyAsync(d_sched, sched.data(), sizeof(int) * 7 * nsched, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
         const float thresh2 = (float)(threshold * threshold);
-        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((nsched + 63) / 64), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, thresh2, lmeds ? 1 : 0, d_sched,
-                           nsched, d_F, d_cnt, d_med);
+        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((nsched + 63) / 64), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, d_sched, nsched, d_models);
+        hipLaunchKernelGGL(fe_ransac_count_kernel, dim3(nsched), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, thresh2, lmeds ? 1 : 0, d_models, nsched,
+                           d_F, d_cnt, d_med, d_words);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e);
+        const int nw = (n + 63) / 64;
         std::vector<int> cnt(nsched);
-        std::vector<double> med(nsched);
+        std::vector<double> med(nsched), Fall(lmeds ? 0 : (size_t)nsched * 9);
+        std::vector<unsigned long long> words(lmeds ? 0 : (size_t)nsched * nw);
         if ((e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * nsched, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
         if ((e = hipMemcpyAsync(med.data(), d_med, sizeof(double) * nsched, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
+        // RANSAC: the inlier sets and the models of all iterations come along (a few tens of KB): once the bookkeeping below has picked
+        // the iteration, its mask is already here -- no second kernel, no second synchronisation
+        if (!lmeds) {
+            if ((e = hipMemcpyAsync(words.data(), d_words, sizeof(unsigned long long) * words.size(), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
+            if ((e = hipMemcpyAsync(Fall.data(), d_F, sizeof(double) * Fall.size(), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
+        }
         if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return fail(e);
         if (debug_phases) fprintf(stderr, "[ransac] n %d, schedule of %d samples %.3f ms (host), upload + kernel + download %.3f ms\n", n, nsched, ms_sched, since(t_begin) - ms_sched);
         // the sequential bookkeeping of the registrator over the per-iteration results
@@ -356,7 +400,11 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
                 t2_mask = sigma * sigma;
             }
         }
-        if (best >= 0) {
+        if (best >= 0 && !lmeds) {
+            n_in = 0;
+            for (int i = 0; i < n; ++i) { status[i] = (unsigned char)((words[(size_t)best * nw + (i >> 6)] >> (i & 63)) & 1ull); n_in += status[i]; }
+            if (F_out) for (int q = 0; q < 9; ++q) F_out[q] = Fall[(size_t)best * 9 + q];
+        } else if (best >= 0) {
             hipLaunchKernelGGL(fe_ransac_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_p, d_p + 2 * n, n, (float)t2_mask, d_F, best, d_s);
             if ((e = hipGetLastError()) != hipSuccess) return fail(e);
             if ((e = hipMemcpyAsync(status, d_s, n, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return fail(e);
