@@ -304,7 +304,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_pyrdown_kernel(const uint8_
 struct LkLds {
     alignas(16) uint8_t jreg[LK_JR * LK_JR];    // search REGION (reflect-101), origin (jox, joy): holds every 22x22 search window
                                     // whose origin lies within +-LK_JS px of the window it was staged for
-    uint8_t ipatch[24 * 24];        // template neighbourhood (reflect-101), origin (ipx-1, ipy-1)
+    uint8_t ipatch[24 * 24 + 8];    // template neighbourhood (reflect-101), origin (ipx-1, ipy-1) (+ 8: a lane reads its rows as 12 bytes)
 };
 
 // Exact integer wavefront sums on the DPP network (VALU only; a __shfl_down tree is dependent LDS-crossbar round trips): quad
@@ -441,27 +441,39 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
         int s11 = 0, s12 = 0, s22 = 0;
         int iv[7], ixv[7], iyv[7];
         {
-            const uint8_t* pp = s.ipatch + lyc * 24 + x0;          // patch rows ly .. ly + 3, columns x0 .. x0 + 9
-            int P[4][10];
+            // The lane's 4 x 10 patch bytes (rows ly .. ly + 3, columns x0 .. x0 + 9) as three dwords per row; everything below
+            // works on TWO 16-bit lanes per register (two neighbouring columns; v_perm_b32 cuts the pairs out, v_pk_add / v_pk_sub /
+            // v_pk_mad_u16 do the Scharr arithmetic modulo 2^16: |values| <= 4080).
+            const uint8_t* pp = s.ipatch + lyc * 24 + x0;
+            unsigned R[4][3];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) __builtin_memcpy(R[r], pp + r * 24, 12);
+            // E[r][j] = columns (2 j, 2 j + 1) of patch row r
+            unsigned E[4][5];
 #pragma unroll
-                for (int c = 0; c < 10; ++c) P[r][c] = pp[r * 24 + c];
-            // lattice position (k, c), k = 0, 1, c = 0 .. 7  <->  patch (k + 1, c + 1)  <->  image (ipy + ly + k, ipx + x0 + c)
-            int dx[2][8], dy[2][8];
+            for (int r = 0; r < 4; ++r) {
+                E[r][0] = vg_perm<0x0C010C00u>(R[r][0], R[r][0]); E[r][1] = vg_perm<0x0C030C02u>(R[r][0], R[r][0]);
+                E[r][2] = vg_perm<0x0C010C00u>(R[r][1], R[r][1]); E[r][3] = vg_perm<0x0C030C02u>(R[r][1], R[r][1]);
+                E[r][4] = vg_perm<0x0C010C00u>(R[r][2], R[r][2]);
+            }
+            // lattice position (k, c), k = 0, 1, c = 0 .. 7  <->  patch (k + 1, c + 1)  <->  image (ipy + ly + k, ipx + x0 + c);
+            // DX[k][j] / DY[k][j] = the derivatives at (k, 2 j) and (k, 2 j + 1):  dx(c) = t0(c + 2) - t0(c),
+            // dy(c) = 3 (t1(c) + t1(c + 2)) + 10 t1(c + 1)  with the column sums t0 = 3 (up + down) + 10 mid, t1 = down - up
+            unsigned DX[2][4], DY[2][4];
             const bool allin = ipx >= 0 && ipx + 22 <= lw && ipy >= 0 && ipy + 22 <= lh;       // uniform: no position outside
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                int t0[10], t1[10];
+                unsigned T0[5], T1[5];
 #pragma unroll
-                for (int c = 0; c < 10; ++c) {
-                    t0[c] = mul24(3, P[k][c] + P[k + 2][c]) + mul24(10, P[k + 1][c]);
-                    t1[c] = P[k + 2][c] - P[k][c];
+                for (int j = 0; j < 5; ++j) {
+                    T0[j] = vg_pk_mad(vg_pk_add(E[k][j], E[k + 2][j]), 3, vg_pk_mad(E[k + 1][j], 10, 0u));
+                    T1[j] = vg_pk_sub(E[k + 2][j], E[k][j]);
                 }
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    dx[k][c] = t0[c + 2] - t0[c];
-                    dy[k][c] = mul24(3, t1[c] + t1[c + 2]) + mul24(10, t1[c + 1]);
+                for (int j = 0; j < 4; ++j) {
+                    DX[k][j] = vg_pk_sub(T0[j + 1], T0[j]);
+                    const unsigned mid = vg_perm<0x05040302u>(T1[j + 1], T1[j]);              // (t1(2 j + 1), t1(2 j + 2))
+                    DY[k][j] = vg_pk_mad(vg_pk_add(T1[j], T1[j + 1]), 3, vg_pk_mad(mid, 10, 0u));
                 }
             }
             if (!allin) {
@@ -470,22 +482,36 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                     const int Y = ipy + lyc + k;
                     const bool yin = Y >= 0 && Y < lh;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const int X = ipx + x0 + c;
-                        if (!(yin && X >= 0 && X < lw)) { dx[k][c] = 0; dy[k][c] = 0; }
+                    for (int j = 0; j < 4; ++j) {
+                        const int X = ipx + x0 + 2 * j;
+                        const unsigned keep = ((yin && X >= 0 && X < lw) ? 0x0000ffffu : 0u) | ((yin && X + 1 >= 0 && X + 1 < lw) ? 0xffff0000u : 0u);
+                        DX[k][j] &= keep; DY[k][j] &= keep;
                     }
                 }
             }
             // bilinear taps as signed 16-bit dot products (weights in [-2, 2^14]: the fourth is 2^14 minus the three rounded ones;
-            // pixels < 2^8, derivatives |.| <= 4080): a pair of neighbours packed by one v_perm_b32, two v_dot2_i32_i16 per tap
-            // with the rounding constant as the addend
+            // pixels < 2^8, derivatives |.| <= 4080): two v_dot2_i32_i16 per tap with the rounding constant as the addend; the pair
+            // (q, q + 1) is a register as it stands for even q and one v_perm_b32 of two neighbouring registers for odd q
             const unsigned wt = (unsigned)w00 | ((unsigned)w01 << 16), wb = (unsigned)w10 | ((unsigned)w11 << 16);
+            unsigned PX[2][7], PY[2][7], PI[2][7];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    PX[k][q] = (q & 1) ? vg_perm<0x05040302u>(DX[k][(q + 1) / 2], DX[k][q / 2]) : DX[k][q / 2];
+                    PY[k][q] = (q & 1) ? vg_perm<0x05040302u>(DY[k][(q + 1) / 2], DY[k][q / 2]) : DY[k][q / 2];
+                }
+                // template pixels: columns (q + 1, q + 2) of patch row k + 1
+                PI[k][0] = vg_byte_pair<1>(R[k + 1][1], R[k + 1][0]); PI[k][1] = vg_byte_pair<2>(R[k + 1][1], R[k + 1][0]);
+                PI[k][2] = vg_byte_pair<3>(R[k + 1][1], R[k + 1][0]); PI[k][3] = vg_byte_pair<0>(R[k + 1][2], R[k + 1][1]);
+                PI[k][4] = vg_byte_pair<1>(R[k + 1][2], R[k + 1][1]); PI[k][5] = vg_byte_pair<2>(R[k + 1][2], R[k + 1][1]);
+                PI[k][6] = vg_byte_pair<3>(R[k + 1][2], R[k + 1][1]);
+            }
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
-                const int ival = vg_sdot2(vg_pack16(P[2][q + 1], P[2][q + 2]), wb,
-                                          vg_sdot2(vg_pack16(P[1][q + 1], P[1][q + 2]), wt, 1 << (LK_WBITS - 5 - 1))) >> (LK_WBITS - 5);
-                const int ixval = vg_sdot2(vg_pack16(dx[1][q], dx[1][q + 1]), wb, vg_sdot2(vg_pack16(dx[0][q], dx[0][q + 1]), wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-                const int iyval = vg_sdot2(vg_pack16(dy[1][q], dy[1][q + 1]), wb, vg_sdot2(vg_pack16(dy[0][q], dy[0][q + 1]), wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+                const int ival = vg_sdot2(PI[1][q], wb, vg_sdot2(PI[0][q], wt, 1 << (LK_WBITS - 5 - 1))) >> (LK_WBITS - 5);
+                const int ixval = vg_sdot2(PX[1][q], wb, vg_sdot2(PX[0][q], wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+                const int iyval = vg_sdot2(PY[1][q], wb, vg_sdot2(PY[0][q], wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
                 iv[q] = (short)ival; ixv[q] = act ? (short)ixval : 0; iyv[q] = act ? (short)iyval : 0;
                 s11 += mul24(ixv[q], ixv[q]); s12 += mul24(ixv[q], iyv[q]); s22 += mul24(iyv[q], iyv[q]);
             }

@@ -61,6 +61,7 @@ template <int Q> __device__ __forceinline__ unsigned vg_byte_pair(unsigned hi, u
 template <unsigned SEL> __device__ __forceinline__ unsigned vg_perm(unsigned hi, unsigned lo) { return __builtin_amdgcn_perm(hi, lo, SEL); }
 typedef unsigned short vg_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned vg_pk_add(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(vg_us2, a) + __builtin_bit_cast(vg_us2, b)); }
+__device__ __forceinline__ unsigned vg_pk_sub(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(vg_us2, a) - __builtin_bit_cast(vg_us2, b)); }
 __device__ __forceinline__ unsigned vg_pk_mad(unsigned a, unsigned short k, unsigned c) {
     const vg_us2 kk = {k, k};
     return __builtin_bit_cast(unsigned, __builtin_bit_cast(vg_us2, a) * kk + __builtin_bit_cast(vg_us2, c));
@@ -108,6 +109,7 @@ template <unsigned SEL> inline unsigned vg_perm(unsigned hi, unsigned lo) {
     return r;
 }
 inline unsigned vg_pk_add(unsigned a, unsigned b) { return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16); }
+inline unsigned vg_pk_sub(unsigned a, unsigned b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
 inline unsigned vg_pk_mad(unsigned a, unsigned short k, unsigned c) { return (((a & 0xffffu) * k + (c & 0xffffu)) & 0xffffu) | (((a >> 16) * k + (c >> 16)) << 16); }
 inline unsigned vg_pk_shr(unsigned a, unsigned short n) { return ((a & 0xffffu) >> n) | (((a >> 16) >> n) << 16); }
 inline unsigned vg_pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
