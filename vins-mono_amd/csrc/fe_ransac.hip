@@ -92,44 +92,57 @@ DEV bool fr_model_before(const double* Fa, const double* Fb) {
 // (lmeds == 0) or median error (lmeds != 0, n <= FE_LMEDS_MAXPTS); count -1 = the sample gave no model).
 extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n,
                                                                    const int* __restrict__ sched, int nsched, double* __restrict__ models) {
-    __shared__ double A[63][64];          // design matrix, element (row r, col c) at A[r * 9 + c][thread]
-    __shared__ double V[81][64];          // accumulated right singular vectors
+    // The design matrix (element (row r, col c) at A[r * 9 + c]) and the accumulated right singular vectors live in REGISTERS (round
+    // 4; they were thread-private LDS columns): every loop over rows, columns and column pairs below is unrolled, so every index is
+    // a constant -- 144 register pairs of the 256 a lone wavefront per SIMD may use, no LDS round trip inside the rotations (the
+    // launch has 16 wavefronts: nothing hides a round trip; 0.33 -> see DESIGN.md section 2).  Same arithmetic in the same order.
+    double A[63], V[81];
     const int t = threadIdx.x, k = blockIdx.x * 64 + t;
     const bool live = k < nsched;
     int idx[7];
+#pragma unroll
     for (int i = 0; i < 7; ++i) idx[i] = live ? sched[(size_t)k * 7 + i] : i;
+#pragma unroll
     for (int i = 0; i < 7; ++i) {
         const double x0 = p1[2 * idx[i]], y0 = p1[2 * idx[i] + 1], x1 = p2[2 * idx[i]], y1 = p2[2 * idx[i] + 1];
         const double row[9] = {x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1.0};
-        for (int c = 0; c < 9; ++c) A[i * 9 + c][t] = row[c];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) A[i * 9 + c] = row[c];
     }
-    for (int e = 0; e < 81; ++e) V[e][t] = (e % 10 == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int e = 0; e < 81; ++e) V[e] = (e % 10 == 0) ? 1.0 : 0.0;
     // one-sided Jacobi on the 9 columns: A V = U Sigma; the two columns that end with the smallest norms span the null space.
     // A has rank 7: two columns shrink to rounding noise, and a pair with such a column never passes the orthogonality test (noise
     // against noise) -- it is still rotated when its turn comes, but only rotations between two columns that carry signal (norm^2
     // above 1e-26 |A|_F^2) keep the sweeps going: ~7 sweeps instead of all 40 (1.7 -> 0.4 ms for the 1000 samples of a frame; any
     // basis of the null space gives the same pencil of models, and the inlier masks are held to the oracle's two-sided Jacobi).
     double scale2 = 0.0;
-    for (int e = 0; e < 63; ++e) scale2 += A[e][t] * A[e][t];
+#pragma unroll
+    for (int e = 0; e < 63; ++e) scale2 += A[e] * A[e];
     const double signal = 1e-26 * scale2;
     for (int sweep = 0; sweep < 40; ++sweep) {
         bool rotated = false;
+#pragma unroll
         for (int p = 0; p < 8; ++p)
+#pragma unroll
             for (int q = p + 1; q < 9; ++q) {
                 double al = 0.0, be = 0.0, ga = 0.0;
-                for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + p][t], b = A[r * 9 + q][t]; al += a * a; be += b * b; ga += a * b; }
+#pragma unroll
+                for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + p], b = A[r * 9 + q]; al += a * a; be += b * b; ga += a * b; }
                 if (fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
                     rotated = rotated || (al > signal && be > signal);
                     const double zeta = (be - al) / (2.0 * ga);
                     const double tn = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                     const double cs = 1.0 / sqrt(1.0 + tn * tn), sn = cs * tn;
+#pragma unroll
                     for (int r = 0; r < 7; ++r) {
-                        const double a = A[r * 9 + p][t], b = A[r * 9 + q][t];
-                        A[r * 9 + p][t] = cs * a - sn * b; A[r * 9 + q][t] = sn * a + cs * b;
+                        const double a = A[r * 9 + p], b = A[r * 9 + q];
+                        A[r * 9 + p] = cs * a - sn * b; A[r * 9 + q] = sn * a + cs * b;
                     }
+#pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        const double a = V[r * 9 + p][t], b = V[r * 9 + q][t];
-                        V[r * 9 + p][t] = cs * a - sn * b; V[r * 9 + q][t] = sn * a + cs * b;
+                        const double a = V[r * 9 + p], b = V[r * 9 + q];
+                        V[r * 9 + p] = cs * a - sn * b; V[r * 9 + q] = sn * a + cs * b;
                     }
                 }
             }
@@ -137,21 +150,33 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* 
     }
     int i2 = 0, i1 = -1;                                  // i2: smallest column norm, i1: second smallest
     {
-        double n2 = 0.0, n1 = 0.0;
+        double nrm[9];
+#pragma unroll
         for (int c = 0; c < 9; ++c) {
             double nn = 0.0;
-            for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + c][t]; nn += a * a; }
-            if (c == 0 || nn < n2) { n2 = nn; i2 = c; }
+#pragma unroll
+            for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + c]; nn += a * a; }
+            nrm[c] = nn;
         }
+        double n2 = 0.0, n1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+            if (c == 0 || nrm[c] < n2) { n2 = nrm[c]; i2 = c; }
+#pragma unroll
         for (int c = 0; c < 9; ++c) {
             if (c == i2) continue;
-            double nn = 0.0;
-            for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + c][t]; nn += a * a; }
-            if (i1 < 0 || nn < n1) { n1 = nn; i1 = c; }
+            if (i1 < 0 || nrm[c] < n1) { n1 = nrm[c]; i1 = c; }
         }
     }
+    // (columns i2 and i1 of V picked by compares: a run-time index would send the whole array to scratch memory)
     double f1[9], f2[9];
-    for (int e = 0; e < 9; ++e) { f2[e] = V[e * 9 + i2][t]; f1[e] = V[e * 9 + i1][t] - f2[e]; }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+        double v2 = 0.0, v1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { v2 = (c == i2) ? V[e * 9 + c] : v2; v1 = (c == i1) ? V[e * 9 + c] : v1; }
+        f2[e] = v2; f1[e] = v1 - v2;
+    }
     double cf[4];
     {
         double t0 = f2[4] * f2[8] - f2[5] * f2[7], t1 = f2[3] * f2[8] - f2[5] * f2[6], t2 = f2[3] * f2[7] - f2[4] * f2[6];
