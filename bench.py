@@ -242,7 +242,9 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
         "roofline": {"kernel": "fe_lk_kernel (+ fe_pyrdown_kernel x3)", "bound": "hbm",
                      "achieved": nfeat * FE_BYTES_PER_FEATURE * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "traffic": fe_traffic(), "event_ms_per_step": ev_ms / steps,
-                     "gftt_GBs": FE_CAMS * FE_GFTT_BYTES_PER_FRAME / (gftt_ms * 1e-3) / 1e9},
+                     "gftt_GBs": FE_CAMS * FE_GFTT_BYTES_PER_FRAME / (gftt_ms * 1e-3) / 1e9,
+                     "gftt_note": "SURVEY 8(d) counts the min-eigenvalue map written and read once (2.9 of the 3.6 MB per frame); since round 4 "
+                                  "the map stays in LDS, so the bytes the detection really moves are ~0.8 MB per frame + the candidate keys"},
     }
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
     if with_cpu:
