@@ -44,6 +44,9 @@ for _ in range(12):
     step(tb, tl)
 for _ in range(6):
     h.timer_start(); step(); step(); ts.append(h.timer_stop() / 2)
+tc = []
+for _ in range(6):
+    tr.select_frames(slot); h.timer_start(); tr.build_async(True); tc.append(h.timer_stop()); slot ^= 1
 tg = []
 tr.detect_upload([N] * cams)
 for _ in range(6):
@@ -55,4 +58,4 @@ chk = 0
 for xy, st, er in res:
     chk = zlib.crc32(np.ascontiguousarray(xy).tobytes() + st.tobytes() + np.ascontiguousarray(er).tobytes(), chk)
 print(json.dumps({"lib": name, "pyramid_us": round(np.median(tb) * 1e3, 1), "lk_us": round(np.median(tl) * 1e3, 1), "lk_us_by_direction": [round(np.median(tl[0::2]) * 1e3, 1), round(np.median(tl[1::2]) * 1e3, 1)],
-                  "step_us": round(np.median(ts) * 1e3, 1), "Mfeat_s": round(cams * N / np.median(ts) * 1e-3, 2), "gftt_us": round(np.median(tg) * 1e3, 1), "gftt_crc": zlib.crc32(b"".join(np.ascontiguousarray(c).tobytes() for c in cor)), "checksum": chk}))
+                  "step_us": round(np.median(ts) * 1e3, 1), "Mfeat_s": round(cams * N / np.median(ts) * 1e-3, 2), "clahe_plus_pyramid_us": round(np.median(tc) * 1e3, 1), "gftt_us": round(np.median(tg) * 1e3, 1), "gftt_crc": zlib.crc32(b"".join(np.ascontiguousarray(c).tobytes() for c in cor)), "checksum": chk}))

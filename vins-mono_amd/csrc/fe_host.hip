@@ -227,7 +227,7 @@ extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
         int clip = (int)(3.0 * area / 256);
         clip = clip < 1 ? 1 : clip;
         hipLaunchKernelGGL(fe_clahe_lut_kernel, dim3(64, d.cams), dim3(256), 0, h->stream, d, clip, 255.f / area);
-        hipLaunchKernelGGL(fe_clahe_apply_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, d.cams), dim3(256), 0, h->stream, d, cur0);
+        hipLaunchKernelGGL(fe_clahe_apply_kernel, dim3(9, 9, d.cams), dim3(256), 0, h->stream, d, cur0);      // one workgroup per interpolation cell
     } else if (!alias) {
         hipLaunchKernelGGL(fe_copy_kernel, dim3(256, d.cams), dim3(256), 0, h->stream, d, cur0);
     }

@@ -38,26 +38,44 @@ FDEV float funord(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 
 // grid (64 tiles, cams), block 256: per-tile histogram -> clip / redistribute -> LUT (clahe.cpp CLAHE_CalcLut_Body)
 extern "C" __global__ __launch_bounds__(256) void fe_clahe_lut_kernel(FeDev d, int clip_limit, float lut_scale) {
     __shared__ int hist[256];
-    __shared__ int scan[256];
     const int cam = blockIdx.y, tile = blockIdx.x, tx = tile % 8, ty = tile / 8;
     const int tw = d.W / 8, th = d.H / 8;
     const uint8_t* src = d.raw + (size_t)cam * d.W * d.H;
     hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int k = threadIdx.x; k < tw * th; k += 256) {
-        const int y = k / tw, x = k % tw;
-        atomicAdd(&hist[src[(size_t)(ty * th + y) * d.W + tx * tw + x]], 1);
+    // thread = (tile row, quarter of the row): no division per pixel, all loads of a thread independent of each other; two pixels per
+    // load where the tile width is even (a tile row then starts on an even byte: W % 8 == 0)
+    {
+        const glb_u8* tsrc = (const glb_u8*)src + (size_t)(ty * th) * d.W + tx * tw;
+        const int seg = threadIdx.x & 3, qw = (tw + 3) >> 2;                 // columns [seg * qw, min(tw, (seg + 1) * qw))
+        const int c0 = seg * qw, c1 = (c0 + qw) < tw ? (c0 + qw) : tw;
+        for (int y = threadIdx.x >> 2; y < th; y += 64) {
+            const glb_u8* row = tsrc + (size_t)y * d.W;
+            if (((tw | qw) & 1) == 0) {
+                for (int x = c0; x < c1; x += 2) {
+                    const unsigned v = *(const glb_u16*)(row + x);
+                    atomicAdd(&hist[v & 255u], 1);
+                    atomicAdd(&hist[v >> 8], 1);
+                }
+            } else {
+                for (int x = c0; x < c1; ++x) atomicAdd(&hist[row[x]], 1);
+            }
+        }
     }
     __syncthreads();
-    // clipped excess
+    // clipped excess: its sum over the 256 bins, then the inclusive scan of the redistributed histogram -- both inside the wavefronts
+    // (shuffles) with one exchange of the four wavefront totals through LDS each (round 4: they were two LDS trees with a workgroup
+    // barrier per step, ~25 barriers per tile; integer sums, any order)
+    __shared__ int wtot[4], wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int hv = hist[threadIdx.x];
     int ex = hv > clip_limit ? hv - clip_limit : 0;
     hv = hv > clip_limit ? clip_limit : hv;
-    scan[threadIdx.x] = ex;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ex += __shfl_xor(ex, o, 64);
+    if (lane == 0) wtot[wv] = ex;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) scan[threadIdx.x] += scan[threadIdx.x + o]; __syncthreads(); }
-    const int clipped = scan[0];
-    __syncthreads();
+    const int clipped = (wtot[0] + wtot[1]) + (wtot[2] + wtot[3]);
     const int batch = clipped / 256;
     const int residual = clipped - batch * 256;
     hv += batch;
@@ -67,42 +85,83 @@ extern "C" __global__ __launch_bounds__(256) void fe_clahe_lut_kernel(FeDev d, i
         if ((int)threadIdx.x % step == 0 && (int)threadIdx.x / step < residual) hv += 1;
     }
     // inclusive scan -> LUT
-    scan[threadIdx.x] = hv;
+    int sc = hv;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(sc, o, 64); sc += lane >= o ? v : 0; }
+    if (lane == 63) wsum[wv] = sc;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int v = (int)threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
-        __syncthreads();
-        scan[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int lv = cv_round((float)scan[threadIdx.x] * lut_scale);
+    for (int q = 0; q < wv; ++q) sc += wsum[q];
+    int lv = cv_round((float)sc * lut_scale);
     lv = lv < 0 ? 0 : (lv > 255 ? 255 : lv);
     d.lut[((size_t)cam * 64 + tile) * 256 + threadIdx.x] = (uint8_t)lv;
 }
 
-// per-pixel bilinear blend of the four tile LUTs (CLAHE_Interpolation_Body); writes pyramid level 0 of `cur`
+// per-pixel bilinear blend of the four tile LUTs (CLAHE_Interpolation_Body); writes pyramid level 0 of `cur`.
+// Round 4: one workgroup per INTERPOLATION CELL -- the pixels whose four LUTs are the same: (tx1, ty1) = (floor(x / tw - 0.5),
+// floor(y / th - 0.5)) before clamping, 9 x 9 cells per frame.  The cell's four LUTs sit in LDS interleaved (one 4-byte read per pixel
+// gives all four entries of its grey value; they were four byte gathers from HBM per pixel: 260 us per 256 frames at 0.7 TB/s), a
+// thread handles four adjacent pixels (dword load / store).  A pixel belongs to the cell its OWN float expressions name, not to an
+// integer range: the workgroup walks a range one dword wider than the cell and every pixel tests (tx1, ty1) == (cx - 1, cy - 1), so
+// each pixel is written by exactly one workgroup and the arithmetic is the former kernel's, bit for bit.
 extern "C" __global__ __launch_bounds__(256) void fe_clahe_apply_kernel(FeDev d, uint8_t* const* dst_planes) {
-    const int cam = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= d.W || y >= d.H) return;
-    const int tw = d.W / 8, th = d.H / 8;
+    __shared__ uint32_t lut4[256];
+    const int cam = blockIdx.z, cx = blockIdx.x, cy = blockIdx.y;           // cell: tx1 = cx - 1, ty1 = cy - 1 (unclamped)
+    const int W = d.W, H = d.H, tw = W / 8, th = H / 8;
+    {
+        const int tx1 = cx - 1 < 0 ? 0 : cx - 1, tx2 = cx > 7 ? 7 : cx, ty1 = cy - 1 < 0 ? 0 : cy - 1, ty2 = cy > 7 ? 7 : cy;
+        const uint8_t* lut = d.lut + (size_t)cam * 64 * 256;
+        const int v = threadIdx.x;
+        lut4[v] = (uint32_t)lut[(ty1 * 8 + tx1) * 256 + v] | ((uint32_t)lut[(ty1 * 8 + tx2) * 256 + v] << 8) |
+                  ((uint32_t)lut[(ty2 * 8 + tx1) * 256 + v] << 16) | ((uint32_t)lut[(ty2 * 8 + tx2) * 256 + v] << 24);
+    }
+    __syncthreads();
+    // pixel ranges that certainly contain the cell ((cx - 0.5) tw <= x < (cx + 0.5) tw up to float rounding), x on dwords
+    int x_lo = ((2 * cx - 1) * tw) / 2 - 2, x_hi = ((2 * cx + 1) * tw + 1) / 2 + 2;
+    int y_lo = ((2 * cy - 1) * th) / 2 - 2, y_hi = ((2 * cy + 1) * th + 1) / 2 + 2;
+    x_lo = (x_lo < 0 ? 0 : x_lo) & ~3; x_hi = x_hi > W ? W : x_hi;
+    y_lo = y_lo < 0 ? 0 : y_lo; y_hi = y_hi > H ? H : y_hi;
+    const int ngx = (x_hi - x_lo + 3) >> 2;                                // dwords per row of the walk (<= W / 32 + 2)
     const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
-    const float tyf = y * inv_th - 0.5f;
-    int ty1 = cv_floor(tyf), ty2 = ty1 + 1;
-    const float ya = tyf - ty1, ya1 = 1.0f - ya;
-    ty1 = ty1 < 0 ? 0 : ty1; ty2 = ty2 > 7 ? 7 : ty2;
-    const float txf = x * inv_tw - 0.5f;
-    int tx1 = cv_floor(txf), tx2 = tx1 + 1;
-    const float xa = txf - tx1, xa1 = 1.0f - xa;
-    tx1 = tx1 < 0 ? 0 : tx1; tx2 = tx2 > 7 ? 7 : tx2;
-    const int v = d.raw[(size_t)cam * d.W * d.H + (size_t)y * d.W + x];
-    const uint8_t* lut = d.lut + (size_t)cam * 64 * 256;
-    const float l11 = lut[(ty1 * 8 + tx1) * 256 + v], l12 = lut[(ty1 * 8 + tx2) * 256 + v];
-    const float l21 = lut[(ty2 * 8 + tx1) * 256 + v], l22 = lut[(ty2 * 8 + tx2) * 256 + v];
-    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
-    int o = cv_round(res);
-    o = o < 0 ? 0 : (o > 255 ? 255 : o);
-    dst_planes[cam][(size_t)y * d.W + x] = (uint8_t)o;
+    const glb_u8* src = (const glb_u8*)(d.raw + (size_t)cam * W * H);
+    glb_u8* dst = (glb_u8*)dst_planes[cam];
+    // thread = (dword column g, row r0 of a pass): its four x positions are the same in every row it visits, so what depends on x
+    // alone -- cell membership and the horizontal weights -- is formed once
+    const int rows_per_pass = 256 / ngx, g = threadIdx.x % ngx, r0 = threadIdx.x / ngx;
+    if (r0 >= rows_per_pass) return;
+    const int x = x_lo + 4 * g;                                           // (W % 8 == 0: the dword lies inside the row)
+    float xa[4], xa1[4];
+    unsigned mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float txf = (x + q) * inv_tw - 0.5f;
+        const int tx1 = cv_floor(txf);
+        xa[q] = txf - tx1; xa1[q] = 1.0f - xa[q];
+        if (tx1 == cx - 1) mine |= 1u << q;
+    }
+    if (mine == 0u) return;
+    for (int y = y_lo + r0; y < y_hi; y += rows_per_pass) {
+        const float tyf = y * inv_th - 0.5f;
+        const int ty1 = cv_floor(tyf);
+        if (ty1 != cy - 1) continue;
+        const float ya = tyf - ty1, ya1 = 1.0f - ya;
+        const uint32_t in4 = *(const glb_u32*)(src + (size_t)y * W + x);
+        uint32_t out4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t l = lut4[(in4 >> (8 * q)) & 255u];
+            const float l11 = (float)(l & 255u), l12 = (float)((l >> 8) & 255u), l21 = (float)((l >> 16) & 255u), l22 = (float)(l >> 24);
+            const float res = (l11 * xa1[q] + l12 * xa[q]) * ya1 + (l21 * xa1[q] + l22 * xa[q]) * ya;
+            int o = cv_round(res);
+            o = o < 0 ? 0 : (o > 255 ? 255 : o);
+            out4 |= (uint32_t)o << (8 * q);
+        }
+        glb_u8* po = dst + (size_t)y * W + x;
+        if (mine == 15u) *(glb_u32*)po = out4;
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (mine & (1u << q)) po[q] = (uint8_t)(out4 >> (8 * q));
+        }
+    }
 }
 
 extern "C" __global__ __launch_bounds__(256) void fe_copy_kernel(FeDev d, uint8_t* const* dst_planes) {

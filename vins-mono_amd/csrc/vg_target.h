@@ -16,6 +16,7 @@ typedef __attribute__((address_space(1))) double glb_d;
 typedef __attribute__((address_space(1))) int glb_i;
 typedef __attribute__((address_space(1))) uint8_t glb_u8;
 typedef __attribute__((address_space(1))) uint32_t glb_u32;
+typedef __attribute__((address_space(1))) uint16_t glb_u16;
 #define VG_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 // ---- the kernarg segment (explicit kernel arguments, then the hidden ones): constant address space
 typedef const __attribute__((address_space(4))) char* vg_kernarg_ptr;
@@ -85,6 +86,7 @@ typedef double glb_d;
 typedef int glb_i;
 typedef uint8_t glb_u8;
 typedef uint32_t glb_u32;
+typedef uint16_t glb_u16;
 #define VG_WAVES_PER_EU(n)
 typedef const char* vg_kernarg_ptr;                        // (hipLaunchKernelGGL of the emulator packs the arguments the same way)
 #define BA_WALL_HZ 1e9                                     // (the emulated clock counts nanoseconds)
