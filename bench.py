@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -502,6 +503,29 @@ def fe_traffic():
     return None if any(v is None for v in t) else t[0] + 3 * t[1]
 
 
+def device_info():
+    """What the box reports about its GPU (informational).  The boxes of the pool differ: single-window launches take the same time
+    everywhere, launches that fill all 256 CUs with the BA kernels' latency-bound workgroups are up to 1.4 x slower on some of them
+     -- this object is what a reader can hold such a run against."""
+    info = {}
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(0)
+        info.update({"name": p.name, "compute_units": p.multi_processor_count, "total_memory_GB": round(p.total_memory / 2**30, 1),
+                     "gcn_arch": getattr(p, "gcnArchName", None)})
+    except Exception as ex:                                   # noqa: BLE001
+        info["torch"] = f"unavailable: {ex!r}"
+    try:
+        r = subprocess.run(["rocm-smi", "--showcomputepartition", "--showmemorypartition", "--showclocks", "--showperflevel", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+        j = json.loads(r.stdout) if r.stdout.strip().startswith("{") else {}
+        card = j.get("card0", {})
+        info["rocm_smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("partition", "sclk", "mclk", "fclk", "perf"))}
+    except Exception as ex:                                   # noqa: BLE001
+        info["rocm_smi"] = f"unavailable: {ex!r}"
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -871,6 +895,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": parity,
+            "device": device_info(),
             "step_latency_ms": {"solve_pipeline": solve_ms, "marginalization": marg_ms, "total": solve_ms + marg_ms,
                                 "what": "one 256-window step alone on the GPU (no overlap with other steps), HIP events"},
             "single_window_latency_ms": None,
