@@ -84,7 +84,7 @@ int main() {
     CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms_pair, e0, e1));
     printf("{\"device\": \"%s\", \"compute_units\": %d, \"clock_MHz\": %d, \"memory_clock_MHz\": %d, \"l2_MB\": %.1f, "
            "\"dependent_load_ns\": {\"one_workgroup\": %.0f, \"256_workgroups_median\": %.0f, \"256_workgroups_slowest\": %.0f, "
-           "\"what\": \"2000 dependent 8-byte loads per workgroup through its own 2 MB region, one line per hop\"}, "
+           "\"what\": \"2500 dependent 8-byte loads per workgroup through its own 2 MB region, a new 256-byte line per hop, never revisited (third launch timed)\"}, "
            "\"launch_us\": {\"tiny_kernel_back_to_back\": %.2f, \"write_256MB_kernel\": %.1f, \"tiny_kernel_after_a_write_256MB_kernel\": %.2f}}\n",
            prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.memoryClockRate / 1000, prop.l2CacheSize / 1048576.0, one_med, all_med, all_max,
            ms_tiny * 1e3 / 200, ms_dirty * 1e3 / 50, (ms_pair - ms_dirty) * 1e3 / 50);
