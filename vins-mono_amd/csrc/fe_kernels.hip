@@ -19,15 +19,10 @@
 #define FDEV __device__ __forceinline__
 
 FDEV int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
-FDEV int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 // exact product of two integers known to fit 24 bits (pixels, 14-bit bilinear weights, int16 derivatives, 14-bit differences)
 // whose product fits 32: v_mul_i32_i24 runs at full rate, v_mul_lo_u32 at a quarter of it -- and the LK kernel is bound by
 // VALU issue
 FDEV int mul24(int a, int b) { return vg_mul24(a, b); }
-// sum of four such products (bilinear tap)
-FDEV int tap4(int p00, int p01, int p10, int p11, int w00, int w01, int w10, int w11) {
-    return mul24(p00, w00) + mul24(p01, w01) + mul24(p10, w10) + mul24(p11, w11);
-}
 FDEV int cv_round(float v) { return __float2int_rn(v); }
 FDEV int cv_floor(float v) { return (int)floorf(v); }
 // monotone map float -> unsigned (total order incl. negatives)
@@ -402,7 +397,7 @@ FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
 // Image planes are reached through pointer tables in HBM: a loaded pointer is generic and its accesses would compile to
 // flat_load (which also ties the LDS counter to the image loads); the planes are HBM, say so (glb_u8, vg_target.h).
 
-// descale(tap4(row a bytes q, q + 1; row b bytes q, q + 1), LK_WBITS - 5) for q = 0 .. 6, handed to f(q, value)
+// the bilinear tap (row a bytes q, q + 1; row b bytes q, q + 1) . weights, rounded and shifted by LK_WBITS - 5, for q = 0 .. 6, handed to f(q, value)
 template <int Q, typename F> FDEV void lk_tap_q(const uint2& ra, const uint2& rb, unsigned wt, unsigned wb, F&& f) {
     // (signed lanes: the fourth weight is 2^14 minus the three rounded ones and can be -1 or -2, and the tap then negative)
     const int t = vg_sdot2(vg_byte_pair<Q>(rb.y, rb.x), wb, vg_sdot2(vg_byte_pair<Q>(ra.y, ra.x), wt, 1 << (LK_WBITS - 5 - 1)));

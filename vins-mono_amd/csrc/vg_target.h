@@ -72,8 +72,7 @@ __device__ __forceinline__ unsigned vg_pk_shr(unsigned a, unsigned short n) {
     return __builtin_bit_cast(unsigned, __builtin_bit_cast(vg_us2, a) >> nn);
 }
 
-// ---- two int16 lanes from the low halves of two registers (v_perm_b32) and their signed dot product plus addend (v_dot2_i32_i16)
-__device__ __forceinline__ unsigned vg_pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
+// ---- signed dot product of two pairs of int16 lanes plus a 32-bit addend (v_dot2_i32_i16)
 __device__ __forceinline__ int vg_sdot2(unsigned a, unsigned b, int c) {
     typedef short s2 __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b), c, false);
@@ -114,6 +113,5 @@ inline unsigned vg_pk_add(unsigned a, unsigned b) { return ((a + b) & 0xffffu) |
 inline unsigned vg_pk_sub(unsigned a, unsigned b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
 inline unsigned vg_pk_mad(unsigned a, unsigned short k, unsigned c) { return (((a & 0xffffu) * k + (c & 0xffffu)) & 0xffffu) | (((a >> 16) * k + (c >> 16)) << 16); }
 inline unsigned vg_pk_shr(unsigned a, unsigned short n) { return ((a & 0xffffu) >> n) | (((a >> 16) >> n) << 16); }
-inline unsigned vg_pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
 inline int vg_sdot2(unsigned a, unsigned b, int c) { return (int)(short)(a & 0xffffu) * (int)(short)(b & 0xffffu) + (int)(short)(a >> 16) * (int)(short)(b >> 16) + c; }
 #endif
