@@ -9,8 +9,8 @@
 // corner lists, LK status AND positions are bit-identical to the oracle.
 //
 // Layout: one image plane per (camera, pyramid level), row-major u8, rows contiguous (coalesced row segments);
-// LK: ONE WAVEFRONT PER TRACK (block = 64 threads), the 24x24 template neighbourhood, its 22x22 Scharr field, the
-// 21x21 template / gradient patches and the 22x22 search window live in LDS (~5.6 KB per track).
+// LK: ONE WAVEFRONT PER TRACK (block = 64 threads); the 24x24 template neighbourhood and a 32x32 search region live in LDS
+// (1.6 KB per track), a lane's seven template values / gradients in registers (the Scharr field is formed there, round 4).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "vg_target.h"
