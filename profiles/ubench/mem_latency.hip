@@ -32,6 +32,26 @@ __global__ void dirty_kernel(double* a, size_t n) {
 }
 __global__ void tiny_kernel(double* a) { if (threadIdx.x == 0) a[blockIdx.x * 512] += 1.0; }
 
+// Instruction fetch: the BA kernels are 20 - 100 KB of code that a workgroup walks ONCE (phase after phase, no long loops), the front-end
+// kernels are a few KB of loops.  big_code_kernel executes BIG_N dependent FMAs as straight-line code (~10 bytes each: larger than the
+// 64 KB instruction cache two CUs share), loop_kernel the same chain from a 16-instruction loop.
+#define BIG_N 12288
+#define F1 x = __builtin_fma(x, a, b); b = __builtin_fma(b, a, x);
+#define F8 F1 F1 F1 F1 F1 F1 F1 F1
+#define F64 F8 F8 F8 F8 F8 F8 F8 F8
+#define F512 F64 F64 F64 F64 F64 F64 F64 F64
+__global__ __launch_bounds__(64) void big_code_kernel(double* out, double a) {
+    double x = a + threadIdx.x, b = a * 0.5;
+    F512 F512 F512 F512 F512 F512 F512 F512 F512 F512 F512 F512                      // 12 x 512 x 2 = BIG_N dependent FMAs, ~96 KB of code
+    out[blockIdx.x * 64 + threadIdx.x] = x + b;
+}
+__global__ __launch_bounds__(64) void loop_kernel(double* out, double a, int n) {
+    double x = a + threadIdx.x, b = a * 0.5;
+#pragma unroll 1
+    for (int i = 0; i < n; i += 16) { F8 }
+    out[blockIdx.x * 64 + threadIdx.x] = x + b;
+}
+
 int main() {
     const int nwg = 256, hops = 2500;            // 3 launches x 2500 hops < 8192 lines of a region: no line is visited twice
     const size_t region_bytes = 2u << 20, region_words = region_bytes / 8, slots = region_bytes / 256;      // 2 MB per workgroup, 8192 lines
@@ -82,7 +102,19 @@ int main() {
     CHK(hipEventRecord(e0));
     for (int k = 0; k < 50; ++k) { hipLaunchKernelGGL(dirty_kernel, dim3(2048), dim3(256), 0, 0, d_big, big_n); hipLaunchKernelGGL(tiny_kernel, dim3(256), dim3(256), 0, 0, d_big); }
     CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms_pair, e0, e1));
-    printf("{\"device\": \"%s\", \"compute_units\": %d, \"clock_MHz\": %d, \"memory_clock_MHz\": %d, \"l2_MB\": %.1f, "
+    // straight-line code against a loop, 256 workgroups of one wavefront, each launch after a launch of the other kernel (cold cache)
+    float ms_big = 0, ms_loop = 0;
+    for (int k = 0; k < 3; ++k) { hipLaunchKernelGGL(big_code_kernel, dim3(256), dim3(64), 0, 0, d_big, 1.0000001); hipLaunchKernelGGL(loop_kernel, dim3(256), dim3(64), 0, 0, d_big, 1.0000001, BIG_N); }
+    CHK(hipDeviceSynchronize());
+    for (int k = 0; k < 20; ++k) {
+        float t;
+        CHK(hipEventRecord(e0)); hipLaunchKernelGGL(big_code_kernel, dim3(256), dim3(64), 0, 0, d_big, 1.0000001); CHK(hipEventRecord(e1));
+        CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&t, e0, e1)); ms_big += t;
+        CHK(hipEventRecord(e0)); hipLaunchKernelGGL(loop_kernel, dim3(256), dim3(64), 0, 0, d_big, 1.0000001, BIG_N); CHK(hipEventRecord(e1));
+        CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&t, e0, e1)); ms_loop += t;
+    }
+    printf("{\"instruction_fetch_us\": {\"straight_line_%d_fma\": %.1f, \"same_chain_from_a_loop\": %.1f}, ", BIG_N, ms_big * 1e3 / 20, ms_loop * 1e3 / 20);
+    printf("\"device\": \"%s\", \"compute_units\": %d, \"clock_MHz\": %d, \"memory_clock_MHz\": %d, \"l2_MB\": %.1f, "
            "\"dependent_load_ns\": {\"one_workgroup\": %.0f, \"256_workgroups_median\": %.0f, \"256_workgroups_slowest\": %.0f, "
            "\"what\": \"2500 dependent 8-byte loads per workgroup through its own 2 MB region, a new 256-byte line per hop, never revisited (third launch timed)\"}, "
            "\"launch_us\": {\"tiny_kernel_back_to_back\": %.2f, \"write_256MB_kernel\": %.1f, \"tiny_kernel_after_a_write_256MB_kernel\": %.2f}}\n",
