@@ -121,6 +121,17 @@ for c, img in ((0, ea), (1, eb)):
 intr = [461.6, 460.3, 363.0, 248.1, -0.2917, 0.08228, 5.333e-05, -1.578e-04]
 p = rng.uniform([0, 0], [752, 480], (200, 2)).astype(np.float32)
 assert np.array_equal(tr.undistort(p, intr).view(np.uint32), F.lift(p, intr).view(np.uint32))
+# CLAHE + pyramid again (a FrontEnd re-configures the handle: last) at sizes whose CLAHE tiles are 9 x 7 pixels (odd: the byte walk of the LUT kernel, interpolation cells that start on half
+# pixels) and whose pyramid levels are 72 and 36 wide (the kernel without LDS: last thread of a row patches column sw at window byte 12 / 8)
+for (w2, h2, seed) in ((72, 56, 41), (104, 88, 42)):
+    c2 = synth.synth_frame(seed, w2, h2)
+    t2 = fe.FrontEnd(h, w2, h2, 1, 16)
+    t2.push_frames([c2], equalize=True)
+    e2 = F.clahe(c2)
+    assert np.array_equal(t2.get_level(0, 0), e2), (w2, h2)
+    assert np.array_equal(t2.get_level(0, 1), F.pyrdown(e2)), (w2, h2)
+    t2.push_frames([c2], equalize=False)
+    assert np.array_equal(t2.get_level(0, 1), F.pyrdown(c2)), (w2, h2)
 print("OK")
 """
 
