@@ -285,6 +285,30 @@ def test_tiny_levels(handle):
     _check_lk(tr, 0, a, b, edge)
 
 
+@pytest.mark.parametrize("w,h", [(72, 56), (104, 88), (136, 120)])
+def test_clahe_and_pyramid_at_small_sizes(handle, w, h):
+    """CLAHE tiles of 9 x 7 / 13 x 11 / 17 x 15 pixels (odd sizes: the byte walk of the LUT kernel, interpolation cells that start on
+    half pixels) and pyramid levels 72 / 36, 104 / 52 / 26, 136 / 68 / 34 wide (the pyrDown kernel without LDS: the last thread of a
+    row patches column sw at window byte 12 or 8; 34 is not a multiple of 4: tile kernel)."""
+    c = synth.synth_frame(40 + w, w, h)
+    tr = fe.FrontEnd(handle, w, h, 1, 16)
+    tr.push_frames([c], equalize=True)
+    ref = F.clahe(c)
+    for lvl in range(2):
+        assert np.array_equal(tr.get_level(0, lvl), ref), lvl
+        ref = F.pyrdown(ref)
+    tr.push_frames([c], equalize=False)
+    ref = c
+    lvl = 0
+    while True:
+        got = tr.get_level(0, lvl)
+        assert got.shape == ref.shape and np.array_equal(got, ref), lvl
+        nxt = F.pyrdown(ref)
+        if lvl == 3 or nxt.shape[0] <= 21 or nxt.shape[1] <= 21:
+            break
+        ref, lvl = nxt, lvl + 1
+
+
 @pytest.mark.parametrize("seed,n,n_out", [(3, 120, 25), (4, 120, 25), (5, 120, 25), (6, 150, 60), (7, 20, 3), (8, 14, 2), (9, 12, 2), (10, 9, 0)])
 def test_reject_with_f_matches_restatement(handle, seed, n, n_out):
     """SURVEY 8(f) row 3: FeatureTracker::rejectWithF's findFundamentalMat(FM_RANSAC) after OpenCV's registrators — the host draws
