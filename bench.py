@@ -548,6 +548,22 @@ def main():
                     help="contract self-test WITHOUT a GPU (tests/test_bench_contract.py): the kernel sources under the CPU fiber emulator of "
                          "tests/simt, tiny loop counts; every number it prints is meaningless except that the line has the right shape")
     args = ap.parse_args()
+    # N > 1: one process per GPU.  The driver starts the ranks itself (python -m torch.distributed.run ... bench.py --gpus N); a plain
+    # `python bench.py --gpus N` starts them here, so that the command can never silently time ONE GPU and print n_gpus: 1.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: RCCL across processes needs it on this driver)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if int(os.environ.get("WORLD_SIZE", "1")) != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or let bench.py do it")
     if args.launch_mode:
         os.environ["VG_BA_LAUNCH_MODE"] = args.launch_mode       # read by the library when a handle first launches
 
@@ -567,7 +583,9 @@ def main():
         pkg._lib, pkg.LIB_PATH = ctypes.CDLL(os.path.join(simt, "_build", "libvinsgpu_simt.so"), mode=ctypes.RTLD_LOCAL), "emulated"
         QUICK, FE_CAMS = True, 2
         if world != 1:
-            raise SystemExit("--emulated: one rank only")
+            if args.backend == "nccl":
+                raise SystemExit("--emulated with several ranks: --backend gloo (there is no GPU for RCCL)")
+            D.init(args.backend, local_rank)         # tests/test_bench_contract.py: the N > 1 plumbing (rank seeds, barrier, max / sum over ranks)
     elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.share_device:

@@ -308,8 +308,7 @@ int vg_ba_launch_stats(vg_handle* h, int* mode, long long* graph_launches, long 
  * spread form.  Takes effect at the next upload. */
 int vg_ba_set_fused_min_windows(vg_handle* h, int min_windows);
 int vg_ba_batch_is_fused(vg_handle* h);      /* uploaded batch: 0 = spread kernels; 1 = fused factor kernel (counted as VG_BA_KERNEL_ACCUMULATE) + solve kernel;
-                                              * 2 = ONE launch per round, ba_round_kernel = factor phases + solve phases (counted as VG_BA_KERNEL_SOLVE;
-                                              * only with environment VG_BA_ROUND_MERGED=1: measured slower, kept as an experiment); < 0: error */
+                                              * < 0: error.  (2 = one merged launch per round was an experiment of ABI 8-9; removed) */
 
 /* Capacities the layout of every later batch is built for at least (landmarks, projection factors and observation rows per window,
  * rows of the prior): a caller whose windows fluctuate from frame to frame keeps one layout -- no re-allocation, and in

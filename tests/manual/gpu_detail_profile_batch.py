@@ -19,8 +19,8 @@ h.lib.vg_debug_detail_profile(out.ctypes.data_as(C.POINTER(C.c_double)), 1)
 h.ba_run_async(); h.ba_download()
 h.lib.vg_debug_detail_profile(out.ctypes.data_as(C.POINTER(C.c_double)), 1)
 names = ["chain A work", "chain A wait", "chain B work", "chain B wait", "chol diag", "chol wait1", "chol panel", "chol wait2", "chol trailing",
-         "chol wait3", "schur lsc+chain rows", "schur trip wait", "schur stage", "schur wait", "schur fetch+mfma", "schur end wait",
-         "assemble copy + clear", "assemble wait", "assemble IMU scatter", "assemble IMU wait", "assemble prior scatter", "assemble end wait"]
+         "chol wait3", "chain C (MFMA)", "schur trip wait", "schur stage", "schur wait", "schur fetch+mfma", "schur end wait",
+         "assemble copy + clear", "assemble wait", "chain A: stage issue", "chain A: raw col + scale", "chain A: update", "assemble end wait"]
 print("windows", nwin, "(cycles per round, workgroup 0)")
 print(f"{'phase':<24}{'thread 0':>12}{'thread 128':>12}")
 for i, n in enumerate(names):

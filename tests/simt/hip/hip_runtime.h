@@ -72,6 +72,7 @@ inline void __syncthreads() { simt::sync_block(); }
 inline void __builtin_amdgcn_s_barrier() { simt::sync_block(); }
 inline void __builtin_amdgcn_wave_barrier() { simt::sync_wave(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)      /* (instruction-scheduling fence: nothing to emulate) */
 inline void __threadfence_block() {}
 inline void __threadfence() {}
 inline long long clock64() { return simt::clock(); }

@@ -66,11 +66,10 @@ def _count(ops, prefix):
 # function name fragment -> (max flat accesses, min ds accesses, min MFMAs)
 PHASES = {
     "cholesky_aug": (12, 30, 32),        # 16 pivots x (diagonal block + panel tile) + the trailing update
-    "15chain_eliminateRK3Ctx": (24, 150, 12),    # two 9x9 factors with their neighbour updates (MFMA), column solves in LDS
-    "schur_mfma": (24, 50, 24),
+    "chain_schurILi4E": (8, 150, 60),    # round 5: chain elimination + Schur complement in one phase (two 9x9 factors in lock step, X^T X of the staged rows, landmark tiles)
     "15back_substituteRK3Ctx": (16, 12, 0),
     "build_scaledILb0E": (16, 20, 0),
-    "assembleILb0E": (30, 60, 0),
+    "14assemble_small": (8, 8, 0),       # round 5: plan-driven gather (one LDS store per entry, the pinv reads)
 }
 
 
@@ -144,8 +143,30 @@ def test_solve_kernel_keeps_its_uniform_state_out_of_scratch():
         pytest.skip("llvm-objdump of the ROCm toolchain not found")
     md = _kernel_metadata()
     k = md["ba_solve_kernel"]
-    assert int(k["vgpr_spill_count"]) <= 16, k          # (8: per-lane values the top level really keeps across the phase calls)
-    assert int(k["private_segment_fixed_size"]) <= 256, k
+    # round 5 (4 wavefronts per window, 72 KB of LDS: two windows per CU): the top level now keeps ~70 per-lane values across the
+    # phase calls (pointers into LDS that the compiler does not prove uniform) -- each is stored and re-read ONCE per launch, outside
+    # every loop; what must stay out of scratch is the inner loop of the chain elimination (pinned below)
+    assert int(k["vgpr_spill_count"]) <= 80, k
+    assert int(k["private_segment_fixed_size"]) <= 640, k
+    assert int(k["group_segment_fixed_size"]) == 0, k
+
+
+def test_chain_elimination_loop_stays_out_of_scratch(funcs):
+    """chain_schur<4> (the EuRoC shape: 15 tiles of S over four wavefronts) runs its six elimination steps with the accumulators, the
+    previous block's solved column and the staged raw entries in registers: a handful of scratch accesses at most (the first version
+    of the phase had 30 stores / 39 loads inside the loop and took 57K cycles for the update step alone)."""
+    (name,) = _find(funcs, "chain_schurILi4E")
+    ops = funcs[name]
+    assert _count(ops, "scratch_store") <= 6 and _count(ops, "scratch_load") <= 6, (name, _count(ops, "scratch_store"), _count(ops, "scratch_load"))
+
+
+def test_solve_kernel_fits_two_windows_per_cu():
+    """Occupancy by construction: 256 threads x <= 256 VGPRs = one wavefront per SIMD and workgroup, so two workgroups fit the register
+    file of a CU; the LDS half of the bargain (<= 80 KB for the reference shape) is checked on the layout in tests/test_abi_and_host.py."""
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    k = _kernel_metadata()["ba_solve_kernel"]
+    assert int(k["max_flat_workgroup_size"]) == 256 and int(k["vgpr_count"]) <= 256, k
 
 
 def test_factor_and_marginalization_kernels_stay_within_their_register_budgets():

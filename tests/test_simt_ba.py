@@ -213,3 +213,13 @@ def test_emulated_fused_and_spread_kernels_agree(simt_handle):
     assert np.abs(sa['pose'] - sb['pose']).max() < 1e-8 and np.abs(sa['sb'] - sb['sb']).max() < 1e-8
     assert np.isclose(ma['final_cost'], mb['final_cost'], rtol=1e-8)
     assert pa['n'] == pb['n'] and np.abs(pa['J0'].T @ pa['J0'] - pb['J0'].T @ pb['J0']).max() < 1e-6 * np.abs(pa['J0'].T @ pa['J0']).max()
+
+
+def test_solve_kernel_lds_carve_leaves_room_for_a_second_window_per_cu(simt_handle):
+    """Round 5: the per-round solve kernel of a EuRoC-shape window (K = 11, prior present) must fit HALF a CU's 160 KB of LDS -- the
+    coupling rows no longer live there (chain_schur streams them) -- so that two windows are resident per CU; the other half of the
+    bargain (256 threads x <= 256 VGPRs) is pinned in tests/test_codegen_guard.py."""
+    seq = synth.SyntheticSequence(5, L=150)
+    prob = seq.window(1)
+    simt_handle.ba_upload([ba.PackedProblem(prob)], [ba.VG_MARGIN_NONE])
+    assert simt_handle.ba_info()['lds_bytes'] <= 80 * 1024 - 2048

@@ -394,8 +394,6 @@ class Handle:
         mode = self.lib.vg_ba_batch_is_fused(self.h)
         if mode == 1:
             k[2] = "ba_linacc_proj_kernel"
-        elif mode == 2:
-            k[2], k[3] = "ba_linacc_proj_kernel", "ba_round_kernel"      # (no launches in class 2: the factor phases run inside ba_round_kernel)
         return k
 
     def ba_run_profiled(self):

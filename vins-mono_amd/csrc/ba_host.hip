@@ -21,7 +21,6 @@
 #include "../../include/vinsgpu.h"
 
 struct BaFork { hipStream_t aux; hipEvent_t fork, join; };
-extern "C" int ba_round_is_merged();
 extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
                                       hipEvent_t* ev, int* kinds, int* n_launches, const BaFork* fk);
 typedef int (*BaAllReduce)(void* user, double* buf, size_t count, void* stream);
@@ -111,6 +110,69 @@ struct PriorRef {
     bool resident = false;
 };
 
+// ---- gather plan of assemble_small (ba_pipeline.hip): for every stored entry of the unscaled reduced system of the single-workgroup
+//      path -- camera part S (packed lower), gradient g, chain blocks D_k / E_k -- where its terms come from.  A function of the
+//      layout alone (which IMU factors exist and what the prior holds is decided on the device: the validity bit of the factor
+//      index, the column -> prior-index map).  IMU factor f, local columns: 0-5 pose_f, 6-14 sb_f, 15-20 pose_f+1, 21-29 sb_f+1;
+//      imuJ[f] = 465 packed lower Hessian entries + 30 gradient entries.
+static void build_asm_plan(const BaLayout& L, std::vector<AsmPlanEntry>& plan) {
+    plan.clear();
+    if (L.big) return;
+    const int K = L.K, Rc = L.Rc, R = L.R;
+    auto tri = [](int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
+    // the (at most two) IMU terms of an entry, sorted into (even factor, odd factor): the order the scatter rounds of rounds 2-4 added them in
+    auto imu = [&](int f0, int i0, int f1, int i1) {
+        int ev = 0, od = 0;
+        auto put = [&](int f, int i) { if (f >= 0 && f <= K - 2 && i >= 0) ((f & 1) ? od : ev) = f * 512 + i + 1; };
+        put(f0, i0); put(f1, i1);
+        return ev | (od << 16);
+    };
+    for (int a = 0; a < Rc; ++a)
+        for (int b = 0; b <= a; ++b) {
+            AsmPlanEntry e;
+            e.dst = L.l_S + a * (a + 1) / 2 + b;
+            e.base = L.bo_Sp + a * (a + 1) / 2 + b;
+            e.imu = 0;
+            const int pa = a / 6, oa = a % 6, pb = b / 6, ob = b % 6;
+            if (a < 6 * K) {                                      // frames with IMU factors (not the relocalisation pose, not ex / td)
+                if (pa == pb) e.imu = imu(pa, tri(oa, ob), pa - 1, tri(15 + oa, 15 + ob));
+                else if (pa == pb + 1) e.imu = imu(pb, tri(15 + oa, ob), -1, -1);
+            }
+            e.cols = (a << 16) | b;
+            plan.push_back(e);
+        }
+    for (int k = 0; k < L.Rpad; ++k) {
+        AsmPlanEntry e;
+        e.dst = (L.l_vec + V_G * L.Rpad + k) | (1 << 28);
+        e.base = k < Rc ? L.bo_gp + k : -1;
+        e.imu = 0;
+        if (k < 6 * K) e.imu = imu(k / 6, 465 + k % 6, k / 6 - 1, 465 + 15 + k % 6);
+        else if (k >= Rc && k < R) e.imu = imu((k - Rc) / 9, 465 + 6 + (k - Rc) % 9, (k - Rc) / 9 - 1, 465 + 21 + (k - Rc) % 9);
+        e.cols = k < R ? k : -1;
+        plan.push_back(e);
+    }
+    for (int k = 0; k < K; ++k)
+        for (int ra = 0; ra < 9; ++ra)
+            for (int rb = 0; rb < 9; ++rb) {                      // D_k: full 9x9, both triangles
+                AsmPlanEntry e;
+                e.dst = L.l_D + 81 * k + 9 * ra + rb;
+                e.base = -1;
+                e.imu = imu(k, tri(6 + ra, 6 + rb), k - 1, tri(21 + ra, 21 + rb));
+                e.cols = ((Rc + 9 * k + ra) << 16) | (Rc + 9 * k + rb);
+                plan.push_back(e);
+            }
+    for (int k = 0; k < K; ++k)
+        for (int ra = 0; ra < 9; ++ra)
+            for (int rb = 0; rb < 9; ++rb) {                      // E_k: rows sb_k, columns sb_k-1 (factor k-1: sb_f+1 x sb_f); E_0 = 0
+                AsmPlanEntry e;
+                e.dst = L.l_E + 81 * k + 9 * ra + rb;
+                e.base = -1;
+                e.imu = k > 0 ? imu(k - 1, tri(21 + ra, 6 + rb), -1, -1) : 0;
+                e.cols = k > 0 ? ((Rc + 9 * k + ra) << 16) | (Rc + 9 * (k - 1) + rb) : -1;
+                plan.push_back(e);
+            }
+}
+
 // ---- layout -------------------------------------------------------------------------------------
 static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, const PriorRef* pr, BaLayout& L) {
     memset(&L, 0, sizeof(L));
@@ -187,18 +249,30 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         int o = 0, ob = 0;
         int& oo = L.big ? ob : o;                    // where the movable arrays are carved from
         L.l_S = o; o += up((L.Rc + 1) * (L.Rc + 2) / 2, 2);
-        L.l_XC = oo; oo += up(9 * L.K, L.big ? 8 : 4) * ldc;      // (large path: two k-steps per trip of schur_chain_big)
+        L.l_XC = 0; L.l_ring = 0; L.l_pinv = 0;
+        if (L.big) { L.l_XC = oo; oo += up(9 * L.K, 8) * ldc; }    // (large path: two k-steps per trip of schur_chain_big)
+        else {
+            // single-workgroup path (round 5): the coupling rows are not held for the whole solve any more (100 rows x ldc = 64 KB of
+            // the former 134 KB carve).  Two slots of 18 rows -- the block pair being eliminated and the pair before it -- are all the
+            // chain elimination reads; finished rows are parked in HBM (so_xp) for the back substitution.  The staged landmark tile
+            // of the Schur sweep (l_wd) and the small scratch uses of `wd` alias the ring: they are only live outside the chain.
+            L.l_ring = o; o += 36 * ldc;
+        }
         L.l_D = oo; oo += up(81 * L.K, 2);
         L.l_E = oo; oo += up(81 * L.K, 2);
         L.l_dinv = oo; oo += up(9 * L.K, 2);
         L.l_vec = oo; oo += 9 * L.Rpad;
         L.l_red = o; o += 32;
-        L.l_wd = oo; oo += up(std::max(L.big ? 0 : L.RcPad * 33, std::max(9 * L.K, 162)), 2);   // staged landmark tile [RcPad][32 + 1]
+        if (L.big) { L.l_wd = oo; oo += up(std::max(9 * L.K, 162), 2); }
+        else L.l_wd = L.l_ring;                                    // [RcPad][32 + 1] <= 36 ldc;  SV_NT, 9 K, 162 doubles of scratch likewise
         L.l_z = oo; oo += up(36 * L.K, 2);
-        L.l_pmap = oo; oo += up(L.Ncap, 4) / 2;
+        if (L.big) { L.l_pmap = oo; oo += up(L.Ncap, 4) / 2; }
+        else { L.l_pmap = 0; L.l_pinv = o; o += up(L.R, 4) / 2; }
         if (L.big) { L.l_di = o; o += up(L.Rc + 1, 2); L.l_cz = o; o += 6 * 96; }
         L.lds_solve = o * 8;
         bigm_doubles = ob;
+        if (!L.big && 2 * (L.Rc + 10) > SV_NT - 64) { h->err = "solve kernel: more column tasks than three wavefronts"; return VG_ERR_UNSUPPORTED; }
+        if (!L.big && 36 * ldc < std::max(std::max(L.RcPad * 33, SV_NT), std::max(9 * L.K, 162))) { h->err = "solve kernel: scratch does not fit the coupling-row ring"; return VG_ERR_UNSUPPORTED; }
         if (L.lds_solve > 160 * 1024) { h->err = "solve kernel LDS carve exceeds 160 KB"; return VG_ERR_UNSUPPORTED; }
         const int nib = std::min(std::min(L.K - 1, BA_IMU_BATCH), L.igs);
         L.lds_lin = 8 * std::max(up(nib * 225, 2) + nib * 480, 5 * L.Ncap);
@@ -288,12 +362,9 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.so_gn = o; o += L.Rpad + L.Lcap;
     L.so_yl = o; o += L.Lcap;
     L.so_lsc = o; o += L.Lcap;
-    L.ptab_cap = 0; L.so_ptab = 0; L.so_Hpk = 0;
-    if (!L.big) {
-        L.ptab_cap = up(L.Ncap * (L.Ncap + 1) / 2 + L.Ncap, 2);
-        L.so_ptab = o; o += L.ptab_cap;                          // 2 x ptab_cap ints
-        L.so_Hpk = o; o += up(L.Ncap * (L.Ncap + 1) / 2, 2);
-    }
+    L.ptab_cap = 0; L.so_ptab = 0; L.so_Hpk = 0;               // (the prior scatter table of rounds 3-4: assemble_small() gathers instead)
+    L.so_xp = 0;
+    if (!L.big) { L.so_xp = o; o += up(9 * L.K, 4) * L.ldc; }
     if (L.big) {
         L.so_bigm = o; o += up(bigm_doubles, 8);
         L.so_dgl = o; o += 2 * L.Lcap;
@@ -313,6 +384,9 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     }
     L.so_buf = o; o += 2 * L.buf_stride;
     L.sstride = up(o, 8);
+    // gather plan of assemble_small behind the device copy of this struct (build_asm_plan)
+    L.pl_off = (int)((sizeof(BaLayout) + 255) / 256 * 256);
+    L.pl_n = L.big ? 0 : L.Rc * (L.Rc + 1) / 2 + L.Rpad + 2 * 81 * L.K;
     // ---- outputs
     o = 0;
     L.oo_pose = o; o += up(7 * L.Kp, 2);
@@ -637,9 +711,8 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
         const double f_pro = 2 * np * np * np;                                                     // prior J0^T J0
         // (fused projection kernel: the factor evaluation moves to the class of the kernel that now does it)
         const double f_move = L.la_on ? it * (F * 750 + 10 * 37000.0 + 4 * np * np) : 0.0;
-        const bool merged = L.la_on && ba_round_is_merged();      // ... and in the launch of the solve phases (ba_round_kernel)
         B.flops_k[0] += f_pro; B.flops_k[1] += f_lin - f_move;
-        B.flops_k[merged ? 3 : 2] += f_acc + f_move;
+        B.flops_k[2] += f_acc + f_move;
         if (L.big) {
             // large-window path: the landmark Schur complement has a kernel of its own
             B.flops_k[VG_BA_KERNEL_BIG_SCHUR] += it * schur;
@@ -701,11 +774,24 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
         HIPCHK(h, hipMemsetAsync(B.P.rb1, 0, (size_t)nwin * L.rb1_len * sizeof(double), h->stream));
         HIPCHK(h, hipMemsetAsync(B.P.rb2, 0, (size_t)nwin * RB2_LEN * sizeof(double), h->stream));
     }
-    if (!B.dL) { HIPCHK(h, hipMalloc((void**)&B.dL, sizeof(BaLayout))); B.dL_valid = false; }
-    if (!B.dL_valid || memcmp(&B.dL_host, &B.L, sizeof(BaLayout)) != 0) {      // frame after frame the layout does not change
-        HIPCHK(h, hipMemcpyAsync(B.dL, &B.L, sizeof(BaLayout), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));                            // (&B.L is pageable memory)
-        B.dL_host = B.L; B.dL_valid = true;
+    // device copy of the layout, the gather plan of assemble_small behind it (frame after frame neither changes)
+    {
+        const size_t pl_off = (size_t)B.L.pl_off;
+        const size_t need = pl_off + (size_t)B.L.pl_n * sizeof(AsmPlanEntry);
+        if (!B.dL || B.dL_bytes < need) {
+            if (B.dL) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(B.dL); B.dL = nullptr; }
+            HIPCHK(h, hipMalloc((void**)&B.dL, need));
+            B.dL_bytes = need; B.dL_valid = false;
+        }
+        if (!B.dL_valid || memcmp(&B.dL_host, &B.L, sizeof(BaLayout)) != 0) {
+            std::vector<AsmPlanEntry> plan;
+            build_asm_plan(B.L, plan);
+            if ((int)plan.size() != B.L.pl_n) { h->err = "gather plan size mismatch"; return VG_ERR_UNSUPPORTED; }
+            HIPCHK(h, hipMemcpyAsync(B.dL, &B.L, sizeof(BaLayout), hipMemcpyHostToDevice, h->stream));
+            if (B.L.pl_n) HIPCHK(h, hipMemcpyAsync((char*)B.dL + pl_off, plan.data(), plan.size() * sizeof(AsmPlanEntry), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));                        // (pageable sources)
+            B.dL_host = B.L; B.dL_valid = true;
+        }
     }
     HIPCHK(h, hipMemcpyAsync(B.P.iarr, B.h_ia, n_ia * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(B.P.din, B.h_di, n_di * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -849,7 +935,7 @@ extern "C" int vg_ba_set_fused_min_windows(vg_handle* h, int min_windows) {
 }
 extern "C" int vg_ba_batch_is_fused(vg_handle* h) {
     if (!h || !h->ba.uploaded) return VG_ERR_BAD_ARG;
-    return h->ba.L.la_on ? (ba_round_is_merged() ? 2 : 1) : 0;
+    return h->ba.L.la_on ? 1 : 0;
 }
 extern "C" int vg_ba_launch_stats(vg_handle* h, int* mode, long long* graph_launches, long long* graph_captures) {
     if (!h) return VG_ERR_BAD_ARG;

@@ -13,6 +13,12 @@
 #define BA_NT 512                 // threads per workgroup of the per-window kernels (8 wavefronts)
 #endif
 #define BA_NW (BA_NT / 64)
+// The per-round solve kernel of the single-workgroup path (ba_solve_kernel) runs 4 wavefronts per window and keeps its LDS carve
+// under half a CU's 160 KB for the reference shape (K = 11: 72 KB), so that TWO windows are resident per CU (round 5): every phase
+// of the solve is a latency-bound chain carried by one or two wavefronts, and the only lever on such a kernel is more independent
+// work per CU.  8 waves x 256 VGPRs and 134 KB of LDS had made that impossible.
+#define SV_NT 256
+#define SV_NW (SV_NT / 64)
 #define BA_LIN_NT 256             // projection factors per workgroup of the linearisation kernel
 #define BA_ACC_NT 256             // threads per workgroup of the accumulation kernel
 #define BA_MAX_K 13               // frames incl. relocalisation pose, windows solved by one workgroup out of LDS
@@ -55,6 +61,15 @@ enum { RB2_GNN2 = 0, RB2_GTGN, RB2_QL, RB2_NONFIN };
 #define BA_BIG_ZERO_BLOCKS 8      // workgroups of the Schur kernel that clear the chain blocks XC / D / E for the next assembly
 #define RB2_LEN (4 * BA_BIG_LM_BLOCKS)
 
+// R-vectors of the solve kernels, columns [camera Rc | speed-bias 9K]
+enum { V_G = 0, V_SC, V_DG, V_GT, V_GN, V_U, V_Y, V_T, V_DI, V_NVEC };
+// One entry of the gather plan: where the terms of ONE stored entry of the unscaled reduced system come from.
+//   dst    : LDS slot (doubles from the start of the carve) | kind << 28   (kind 0: Hessian entry, 1: gradient entry)
+//   base   : offset into the linearisation buffer of the projection factors' term (Sp / gp), -1 = none
+//   imu    : (even + 1) | (odd + 1) << 16 with even / odd = f * 512 + local index of the term of the even / odd IMU factor, 0 = none
+//   cols   : Hessian: reduced columns ca << 16 | cb (prior term J0^T J0 [pinv ca][pinv cb]); gradient: column ca (J0^T r [pinv ca])
+struct alignas(16) AsmPlanEntry { int dst, base, imu, cols; };
+
 struct BaLayout {
     int nwin, K, Kp, e, t;
     int Rc, RcPad, R, Rpad;        // RcPad = up(Rc + 1, 16): the rhs travels as the augmented row / column Rc
@@ -79,6 +94,8 @@ struct BaLayout {
     int so_yl, so_lsc;                          // landmark step / sl/sqrt(h~)
     int so_ptab, so_Hpk, ptab_cap;              // prior scatter table (2 x ptab_cap ints: LDS slot of every prior entry and of its
                                                 // mirror, -1 = none; built once per solve by the prologue) and J0^T J0 packed by entry
+    int so_xp;                                  // single-workgroup path: the eliminated speed-bias rows X_k = L_k^-1 [C_k | g_k], [9K][ldc], parked
+                                                // here by the chain elimination for the back substitution (they no longer stay in LDS)
     int so_buf, buf_stride;                     // two linearisation buffers; offsets below are relative to a buffer
     int bo_Sp, bo_gp, bo_h, bo_b, bo_Wt, bo_imuJ, bo_pr, bo_gpr;
     int sstride;
@@ -92,6 +109,12 @@ struct BaLayout {
     int mcap, mg_ld, mg_posmax, mg_cs, mg_lds_bytes; // kept-dimension capacity, LDS eig leading dim, max (m+n)
     // ---- LDS carve of the solve kernel (offsets in doubles)
     int l_S, l_XC, l_D, l_E, l_dinv, l_vec, l_red, l_wd, l_z, l_pmap, ldc, lds_solve;
+    // single-workgroup path: l_ring = two slots of 18 coupling rows [2][18][ldc] (the block pair being eliminated and the pair before
+    // it; l_wd aliases it: the staged landmark tile is only needed after the chain), l_pinv = reduced column -> prior index (R ints)
+    int l_ring, l_pinv;
+    // gather plan of assemble_small (single-workgroup path): pl_n entries of four ints, pl_off bytes behind the start of the device
+    // copy of this struct (built by the host with the layout: it depends on nothing else)
+    int pl_off, pl_n;
     int lds_lin, lds_pro;                     // dynamic LDS bytes of the linearisation / prologue kernels
     // ---- fused projection kernel (ba_linacc_proj_kernel): eligible windows (la_on), landmarks per chunk by first factor index
     //      (la_chq), staged-record capacity (la_chf = la_chq + 16), LDS offsets (doubles) of the pair blocks and of the key table

@@ -75,10 +75,31 @@ extern "C" int vg_debug_detail_profile(double* out64, int reset) {
 #define DP_DECL
 #define DP_ADD(id)
 #endif
+// development aid (build with -DBA_DEBUG_DUMP): window 0 copies its LDS image of the reduced system into a device array after each
+// phase of its first iteration, read back by vg_debug_dump (tests/manual/dbg_dump.py compares the hardware with the emulator)
+#ifdef BA_DEBUG_DUMP
+#define DBG_SLOT 16384
+__device__ double g_dbg[6 * DBG_SLOT];
+__global__ void dbg_copy_kernel(double* out, int n) { for (int k = threadIdx.x; k < n; k += blockDim.x) out[k] = g_dbg[k]; }
+extern "C" int vg_debug_dump(double* out, int n) {
+    n = n < 6 * DBG_SLOT ? n : 6 * DBG_SLOT;
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(double) * n) != hipSuccess) return -2;
+    hipLaunchKernelGGL(dbg_copy_kernel, dim3(1), dim3(256), 0, 0, d, n);
+    const hipError_t e = hipMemcpy(out, d, sizeof(double) * n, hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? 0 : -2;
+}
+#define DBG_DUMP(slot) do { if (blockIdx.x == 0 && s.it == 1 && s.mu <= 1e-8) { __syncthreads(); \
+    for (int k_ = c.tid; k_ < L.lds_solve / 8; k_ += SV_NT) g_dbg[(slot) * DBG_SLOT + k_] = LDSB[k_]; \
+    if ((slot) >= 2) for (int k_ = c.tid; k_ < 9 * L.K * L.ldc; k_ += SV_NT) g_dbg[5 * DBG_SLOT + k_] = m.xp[k_]; \
+    __syncthreads(); } } while (0)
+#else
+#define DBG_DUMP(slot)
+#endif
 enum { PF_JUDGE = 0, PF_ASM, PF_DG, PF_BUILD, PF_CHAIN, PF_SCHUR, PF_CHOL, PF_BACK, PF_CBACK, PF_LMY, PF_NORMS, PF_CAND, PF_TAIL };
 
-// R-vectors of the solve kernel in LDS, columns [camera Rc | speed-bias 9K]
-enum { V_G = 0, V_SC, V_DG, V_GT, V_GN, V_U, V_Y, V_T, V_DI, V_NVEC };
+// (R-vectors of the solve kernel in LDS, V_G .. V_DI: ba_layout.h)
 
 struct Ctx {
     const BaLayout* Lp;      // layout lives in device memory: uniform scalar loads on demand
@@ -351,7 +372,6 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
                     const int a = 16 * ta + lk + 4 * q, bb = 16 * tb + li;        // D[row = lk + 4 q][col = li]
                     if (a < n && bb <= a) {
                         Hp[a * L.Ncap + bb] = acc[q];
-                        if (!L.big) c.sc[L.so_Hpk + a * (a + 1) / 2 + bb] = acc[q];
                     }
                 }
             }
@@ -365,52 +385,6 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
                 for (; r + 1 < n; r += 2) { s0 += J0[r * ld + a] * J0[r * ld + bb]; s1 += J0[(r + 1) * ld + a] * J0[(r + 1) * ld + bb]; }
                 if (r < n) s0 += J0[r * ld + a] * J0[r * ld + bb];
                 Hp[a * L.Ncap + bb] = s0 + s1;
-                if (!L.big) c.sc[L.so_Hpk + wk] = s0 + s1;
-            }
-        }
-        if (!L.big) {
-            // Where every prior entry lands in the solve kernel's LDS image of the reduced system (offsets in doubles from the
-            // start of LDS, as carved by lds_carve): decoded once per solve here, so that assemble() is load + add + store.
-            // Entry wk < n(n+1)/2: Hessian (a, b) -> slot of (pmap[a], pmap[b]) and, inside a speed-bias block, its mirror;
-            // entry n(n+1)/2 + a: gradient -> g[pmap[a]].
-            __syncthreads();
-            int* pmap = (int*)LDSB;
-            {
-                const int* kind = c.ia + L.io_pb_kind;
-                const int* off = c.ia + L.io_pb_off;
-                const int* pcol = c.ia + L.io_pb_col;
-                for (int blk = c.tid; blk < c.nblk; blk += BA_NT) {
-                    const int sz = (kind[blk] == VG_BLK_SPEEDBIAS) ? 9 : (kind[blk] == VG_BLK_TD ? 1 : 6);
-                    for (int k = 0; k < sz; ++k) pmap[off[blk] + k] = pcol[blk] >= 0 ? pcol[blk] + k : -1;
-                }
-            }
-            __syncthreads();
-            int* tab0 = (int*)(c.sc + L.so_ptab);
-            int* tab1 = tab0 + L.ptab_cap;
-            const int ntri = n * (n + 1) / 2, Rc = L.Rc;
-            for (int wk = c.tid; wk < ntri + n; wk += BA_NT) {
-                int d0 = -1, d1 = -1;
-                if (wk >= ntri) {
-                    const int ca = pmap[wk - ntri];
-                    if (ca >= 0) d0 = L.l_vec + V_G * L.Rpad + ca;
-                } else {
-                    int a, bb;
-                    tri_decode(wk, a, bb);
-                    const int ca = pmap[a], cb = pmap[bb];
-                    if (ca >= 0 && cb >= 0) {
-                        const int hi = ca > cb ? ca : cb, lo = ca > cb ? cb : ca;
-                        if (hi < Rc) d0 = L.l_S + tri(hi, lo);
-                        else if (lo < Rc) d0 = L.l_XC + (hi - Rc) * L.ldc + lo;
-                        else {
-                            const int ia = hi - Rc, ib = lo - Rc, ka = ia / 9, kb = ib / 9;
-                            if (ka == kb) {
-                                d0 = L.l_D + 9 * ia + (ib - 9 * kb);
-                                if (ia != ib) d1 = L.l_D + 9 * ib + (ia - 9 * ka);
-                            } else d0 = L.l_E + 9 * ia + (ib - 9 * kb);
-                        }
-                    }
-                }
-                tab0[wk] = d0; tab1[wk] = d1;
             }
         }
     }
@@ -1331,13 +1305,19 @@ struct SolveLds {
     double *S, *XC, *D, *E, *dinv, *vec, *red, *wd, *z, *di;
     int* pmap;
     int ldc;
+    // single-workgroup path: staged coupling rows of the block pair being eliminated (LDS), reduced column -> prior index (LDS),
+    // parked rows X_k (HBM)
+    double* ring;
+    int* pinv;
+    double* xp;
 };
-DEV void lds_carve(const BaLayout& L, SolveLds& m) {
-    m.S = LDSB + L.l_S; m.XC = LDSB + L.l_XC; m.D = LDSB + L.l_D; m.E = LDSB + L.l_E; m.dinv = LDSB + L.l_dinv;
+DEV void lds_carve(const BaLayout& L, double* sc, SolveLds& m) {
+    m.S = LDSB + L.l_S; m.XC = nullptr; m.D = LDSB + L.l_D; m.E = LDSB + L.l_E; m.dinv = LDSB + L.l_dinv;
     m.vec = LDSB + L.l_vec; m.red = LDSB + L.l_red; m.wd = LDSB + L.l_wd; m.z = LDSB + L.l_z;
-    m.pmap = (int*)(LDSB + L.l_pmap);
+    m.pmap = nullptr;
     m.ldc = L.ldc;
     m.di = m.vec + V_DI * L.Rpad;
+    m.ring = LDSB + L.l_ring; m.pinv = (int*)(LDSB + L.l_pinv); m.xp = sc + L.so_xp;
 }
 // large-window carve: S, the reduction scratch and 1/L_jj in LDS, the rest in HBM scratch (generic pointers: the helpers
 // below do not care)
@@ -1348,6 +1328,7 @@ DEV void big_carve(const BaLayout& L, double* sc, SolveLds& m) {
     m.vec = hb + L.l_vec; m.wd = hb + L.l_wd; m.z = hb + L.l_z;
     m.pmap = (int*)(hb + L.l_pmap);
     m.ldc = L.ldc;
+    m.ring = nullptr; m.pinv = nullptr; m.xp = nullptr;
 }
 
 // The phase functions of the solve kernels are not inlined.  A Ctx / SolveLds handed over by reference has to sit in the caller's
@@ -1367,7 +1348,7 @@ DEV void phase_ctx(Ctx& c, BaLayout& L, SolveLds& m, int big) {        // big: 0
     __builtin_memcpy(&P, ka + 8, sizeof(BaPtrs));
     L = layout_load(Lp);
     ctx_init(c, Lp, P, blockIdx.x);
-    if (big < 0 ? L.big != 0 : big != 0) big_carve(L, c.sc, m); else lds_carve(L, m);
+    if (big < 0 ? L.big != 0 : big != 0) big_carve(L, c.sc, m); else lds_carve(L, c.sc, m);
 }
 // the kernels compare what the phases will derive with their real arguments once (a wrong hidden-argument offset must not be silent)
 #define PHASE_SELF_CHECK(cref) do { Ctx c_; BaLayout L_; SolveLds m_; phase_ctx(c_, L_, m_, 0); if (c_.sc != (cref).sc || c_.ia != (cref).ia || c_.pri != (cref).pri) __builtin_trap(); } while (0)
@@ -1416,68 +1397,23 @@ DEV void hess_add(const BaLayout& L, const Q& q, int ca, int cb, double v) {
     }
 }
 
-// Unscaled Gauss-Newton system of the current point: S (camera, packed lower), g, chain blocks D, E, XC.
-// Sp / gp = camera J^T J / J^T r of the projection factors (the buffer's own, or the rank-summed copy of the large-window path)
-template <bool BIG>
-NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, const double* Sp_, const double* gp_) {
-    PHASE_ENTER(BIG);
-    typedef typename MovT<BIG>::D MV;
-    const auto q = sys_ptrs<BIG>(m);
+// Unscaled Gauss-Newton system of the current point, LARGE-WINDOW path: S (camera, packed lower, LDS), g, chain blocks D, E, XC (HBM).
+// Sp / gp = the rank-summed camera J^T J / J^T r of the projection factors.  (Single-workgroup path: assemble_small below.)
+NOINL void assemble_big(const Ctx& c_in, const SolveLds& m_in, const double* buf_, const double* Sp_, const double* gp_) {
+    PHASE_ENTER(true);
+    typedef glb_d MV;
+    const auto q = sys_ptrs<true>(m);
     const glb_d* buf = AS_GLB_C(buf_);
     const glb_d* Sp = AS_GLB_C(Sp_);
     const glb_d* gp = AS_GLB_C(gp_);
-    const int Rc = L.Rc, R = L.R, K = L.K;
+    const int Rc = L.Rc, K = L.K;
     const int camtri = Rc * (Rc + 1) / 2;
     MV* g = q.vec + V_G * L.Rpad;
     __syncthreads();
-    DP_DECL;
-    // Reference window: every HBM value the two scatter phases below need (IMU blocks of both parities, prior entries) is
-    // requested HERE, so that its latency runs under the copy / clear phase instead of in front of each scatter round.
-    const bool pre_imu = !BIG && K - 1 <= 16;
-    const bool pre_pri = !BIG && c.nprior && c.nprior * (c.nprior + 1) / 2 + c.nprior <= 8 * BA_NT;
-    double pv[2][8], qv[8];
-    int pvl[2][8], qd0[8], qd1[8];
-    if (pre_imu) {
-        const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
-        const glb_d* imuJ = buf + L.bo_imuJ;
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) {
-                const int f = 2 * qq + par, fc = f < K - 1 ? f : K - 2;
-                pvl[par][qq] = valid[fc];
-                pv[par][qq] = imuJ[fc * 512 + c.tid];
-            }
-        }
-    }
-    if (pre_pri) {
-        const int n = c.nprior, ntri = n * (n + 1) / 2, nent = ntri + n;
-        const glb_i* tab0 = AS_GLB_CI((const int*)(c.sc + L.so_ptab));
-        const glb_i* tab1 = tab0 + L.ptab_cap;
-        const glb_d* Hpk = AS_GLB_C(c.sc + L.so_Hpk);
-        const glb_d* gpr = buf + L.bo_gpr;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int w = c.tid + u * BA_NT;
-            const int wc = w < nent ? w : nent - 1;
-            qd0[u] = tab0[wc]; qd1[u] = tab1[wc];
-            const double hv = Hpk[wc < ntri ? wc : 0], gv = gpr[wc >= ntri ? wc - ntri : 0];
-            qv[u] = wc < ntri ? hv : gv;
-            if (w >= nent) { qd0[u] = -1; qd1[u] = -1; }
-        }
-    }
-    if (!BIG) {
-        // (large-window path: XC / D / E live in HBM and were cleared by the Schur kernel's extra workgroups)
-        // The clears come first: they wait for nothing, the copies below wait for the loads already in flight.
-        const int nxc = ((9 * K + 3) & ~3) * q.ldc;
-        for (int k = c.tid; k < nxc; k += BA_NT) q.XC[k] = 0.0;
-        for (int k = c.tid; k < 81 * K; k += BA_NT) { q.D[k] = 0.0; q.E[k] = 0.0; }
-    }
+    // (XC / D / E live in HBM and were cleared by the Schur kernel's extra workgroups)
     for (int k = c.tid; k < camtri; k += BA_NT) q.S[k] = Sp[k];
     for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? gp[k] : 0.0;
-    DP_ADD(16);
     __syncthreads();
-    DP_ADD(17);
     // ---- IMU Hessian blocks: factors k and k+1 share the blocks of frame k+1, so even and odd factors are added in two
     //      rounds (inside a round every entry has exactly one writer)
     {
@@ -1490,8 +1426,8 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
             {
                 // Thread = entry e of every factor of this parity, eight factors at a time: all loads of the IMU blocks first,
                 // then the read-modify-writes (inside a round every entry has exactly one writer, so the slots are distinct).
-                // One trip per entry would be a chain of HBM round trips; on the large-window path most targets are in HBM too.
-                // Entries of the camera part live in LDS on both paths: they are added directly.
+                // One trip per entry would be a chain of HBM round trips; most targets are in HBM too.
+                // Entries of the camera part live in LDS: they are added directly.
                 // The destination of entry e is the same for every factor up to a shift by the frame index, so it is decoded ONCE
                 // per thread: camera x camera -> packed S at (6 f + xa, 6 f + xb); everything else -> base + f * stride in the
                 // block that stores it (XC: 9 ldc + 6, D / E: 81, gradient: 6 or 9), D entries off the diagonal with a mirror.
@@ -1524,106 +1460,38 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
                     double v[8], t0[8], t1[8];
                     bool on[8];
                     int vld[8];
-                    if (pre_imu) {
 #pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) { vld[qq] = pvl[par][qq]; v[qq] = pv[par][qq]; }
-                    } else {
-#pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {             // the loads of the chunk, nothing else: value and validity flag
-                            const int f = 2 * (i0 + qq) + par;       // in ONE round trip (clamped addresses, masked afterwards)
-                            const int fc = f < nimu ? f : nimu - 1;
-                            vld[qq] = valid[fc];
-                            v[qq] = imuJ[fc * 512 + e];
-                        }
+                    for (int qq = 0; qq < 8; ++qq) {             // the loads of the chunk, nothing else: value and validity flag
+                        const int f = 2 * (i0 + qq) + par;       // in ONE round trip (clamped addresses, masked afterwards)
+                        const int fc = f < nimu ? f : nimu - 1;
+                        vld[qq] = valid[fc];
+                        v[qq] = imuJ[fc * 512 + e];
                     }
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
                         on[qq] = i0 + qq < nf && e < 495 && vld[qq];
                         v[qq] = on[qq] ? v[qq] : 0.0;
                     }
-                    if constexpr (!BIG) {
-                        // every target is in LDS: lanes without a target aim at a scratch slot and add 0, so the eight
-                        // read-modify-writes of a chunk are straight-line code (no divergent branch per entry)
-                        lds_d* const dummy = AS_LDS(m.wd);
-                        lds_d* a0[8];
-                        lds_d* a1[8];
 #pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {
-                            const int f = 2 * (i0 + qq) + par;
-                            lds_d* t = xa >= 0 ? q.S + tri(6 * f + xa, 6 * f + xb) : (base0 ? base0 + f * stride : dummy);
-                            a0[qq] = on[qq] ? t : dummy;
-                            a1[qq] = (on[qq] && base1) ? base1 + f * stride : dummy;
-                        }
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const int f = 2 * (i0 + qq) + par;
+                        p0[qq] = (on[qq] && base0) ? base0 + f * stride : nullptr;
+                        p1[qq] = (on[qq] && base1) ? base1 + f * stride : nullptr;
+                        if (on[qq] && xa >= 0) q.S[tri(6 * f + xa, 6 * f + xb)] += v[qq];
+                    }
 #pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) { t0[qq] = *a0[qq]; t1[qq] = *a1[qq]; }
+                    for (int qq = 0; qq < 8; ++qq) { t0[qq] = p0[qq] ? *p0[qq] : 0.0; t1[qq] = p1[qq] ? *p1[qq] : 0.0; }
 #pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) { *a0[qq] = t0[qq] + v[qq]; *a1[qq] = t1[qq] + v[qq]; }
-                    } else {
-#pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {
-                            const int f = 2 * (i0 + qq) + par;
-                            p0[qq] = (on[qq] && base0) ? base0 + f * stride : nullptr;
-                            p1[qq] = (on[qq] && base1) ? base1 + f * stride : nullptr;
-                            if (on[qq] && xa >= 0) q.S[tri(6 * f + xa, 6 * f + xb)] += v[qq];
-                        }
-#pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) { t0[qq] = p0[qq] ? *p0[qq] : 0.0; t1[qq] = p1[qq] ? *p1[qq] : 0.0; }
-#pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {
-                            if (p0[qq]) *p0[qq] = t0[qq] + v[qq];
-                            if (p1[qq]) *p1[qq] = t1[qq] + v[qq];
-                        }
+                    for (int qq = 0; qq < 8; ++qq) {
+                        if (p0[qq]) *p0[qq] = t0[qq] + v[qq];
+                        if (p1[qq]) *p1[qq] = t1[qq] + v[qq];
                     }
                 }
             }
-            DP_ADD(18);
             __syncthreads();
-            DP_ADD(19);
         }
     }
-    // ---- prior: H += J0^T J0, g += J0^T r.  Reference window: the slot of every entry was decoded by the prologue kernel
-    //      (so_ptab), the values are packed by entry — per entry two table reads, one value, one or two LDS adds.
-    if constexpr (!BIG) {
-        if (c.nprior) {
-            const int n = c.nprior, ntri = n * (n + 1) / 2, nent = ntri + n;
-            const glb_i* tab0 = AS_GLB_CI((const int*)(c.sc + L.so_ptab));
-            const glb_i* tab1 = tab0 + L.ptab_cap;
-            const glb_d* Hpk = AS_GLB_C(c.sc + L.so_Hpk);
-            const glb_d* gpr = buf + L.bo_gpr;        // J0^T r, formed by the linearisation kernel
-            lds_d* const lds0 = AS_LDS(LDSB);
-            lds_d* const dummy = AS_LDS(m.wd);
-            for (int w0 = 0; w0 < nent; w0 += 8 * BA_NT) {
-                int d0[8], d1[8];
-                double v[8], t0[8], t1[8];
-                if (pre_pri) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { d0[u] = qd0[u]; d1[u] = qd1[u]; v[u] = qv[u]; }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int w = w0 + c.tid + u * BA_NT;
-                        const int wc = w < nent ? w : nent - 1;
-                        d0[u] = tab0[wc]; d1[u] = tab1[wc];
-                        const double hv = Hpk[wc < ntri ? wc : 0], gv = gpr[wc >= ntri ? wc - ntri : 0];
-                        v[u] = wc < ntri ? hv : gv;
-                        if (w >= nent) { d0[u] = -1; d1[u] = -1; }
-                    }
-                }
-                lds_d* a0[8];
-                lds_d* a1[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    a0[u] = d0[u] >= 0 ? lds0 + d0[u] : dummy;
-                    a1[u] = d1[u] >= 0 ? lds0 + d1[u] : dummy;
-                    v[u] = d0[u] >= 0 ? v[u] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { t0[u] = *a0[u]; t1[u] = *a1[u]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { *a0[u] = t0[u] + v[u]; *a1[u] = t1[u] + v[u]; }
-            }
-        }
-    } else
+    // ---- prior: H += J0^T J0, g += J0^T r
     if (c.nprior) {
         const int n = c.nprior;
         const glb_d* Hp = AS_GLB_C(c.sc + L.so_Hp);
@@ -1658,9 +1526,93 @@ NOINL void assemble(const Ctx& c_in, const SolveLds& m_in, const double* buf_, c
             }
         }
     }
-    DP_ADD(20);
     __syncthreads();
-    DP_ADD(21);
+}
+
+// Unscaled Gauss-Newton system of the current point, single-workgroup path (round 5): every STORED entry gathers its terms --
+// camera part S (packed lower) = Sp + IMU pose blocks + prior, g, the chain blocks D_k / E_k -- instead of the former scatter
+// (clear, copy, two parity rounds of read-modify-writes for the IMU blocks, a table-driven round for the prior: four barriers and
+// a slot table the prologue had to build per solve).  Where an entry's terms live is a function of the layout alone, so the host
+// builds the gather plan once per layout (build_asm_plan, ba_host.hip; AsmPlanEntry, ba_layout.h): per entry one 16-byte plan
+// read, up to four value loads (all independent), three adds in the order of the scatter -- projection part, even IMU factor, odd
+// IMU factor, prior -- and one LDS store; one barrier at the end.  Whether an IMU factor exists and what the prior holds is decided
+// here: the validity bit of the factor index, the column -> prior-index map `pinv` (built first; chain_schur uses it too).  The
+// coupling rows sb x camera are NOT assembled: the chain elimination gathers them block by block (chain_schur).
+#define ASM_NB 9                                  // plan entries per thread and trip
+NOINL void assemble_small(const Ctx& c_in, const SolveLds& m_in, const double* buf_) {
+    PHASE_ENTER(false);
+    const glb_d* buf = AS_GLB_C(buf_);
+    const glb_d* imuJ = buf + L.bo_imuJ;
+    const glb_d* gpr = buf + L.bo_gpr;            // J0^T r, formed by the linearisation kernel
+    const glb_d* Hp = AS_GLB_C(c.sc + L.so_Hp);   // J0^T J0 (lower triangle, row stride Ncap), formed by the prologue kernel
+    lds_d* const lds0 = AS_LDS(LDSB);
+    lds_i* const pinv = (lds_i*)m.pinv;
+    const int R = L.R, Ncap = L.Ncap;
+    const AsmPlanEntry* plan = (const AsmPlanEntry*)((const char*)c.Lp + L.pl_off);      // (16 bytes, aligned: one global_load_dwordx4 per entry)
+    const int n = L.pl_n;
+    // the first trip's plan entries are requested before anything else
+    int4 pe[ASM_NB];                               // {dst, base, imu, cols}
+#pragma unroll
+    for (int u = 0; u < ASM_NB; ++u) { const int w = c.tid + u * SV_NT; pe[u] = vg_load_int4(plan + (w < n ? w : n - 1)); }
+    unsigned vm;                                   // bit f: IMU factor f is present
+    {
+        const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
+        const int v = c.lane < L.K - 1 ? valid[c.lane] : 0;
+        vm = (unsigned)__ballot(v != 0);
+    }
+    __syncthreads();
+    for (int k = c.tid; k < R; k += SV_NT) pinv[k] = -1;
+    __syncthreads();
+    if (c.nprior) {
+        const glb_i* kind = AS_GLB_CI(c.ia + L.io_pb_kind);
+        const glb_i* off = AS_GLB_CI(c.ia + L.io_pb_off);
+        const glb_i* pcol = AS_GLB_CI(c.ia + L.io_pb_col);
+        for (int blk = c.tid; blk < c.nblk; blk += SV_NT) {
+            const int kd = kind[blk], o = off[blk], pc = pcol[blk];
+            const int sz = (kd == VG_BLK_SPEEDBIAS) ? 9 : (kd == VG_BLK_TD ? 1 : 6);
+            if (pc >= 0)
+                for (int k = 0; k < sz; ++k) pinv[pc + k] = o + k;
+        }
+    }
+    __syncthreads();
+    DP_DECL;
+    const bool has_prior = c.nprior != 0;
+    for (int w0 = 0; w0 < n; w0 += ASM_NB * SV_NT) {
+        double vb[ASM_NB], ve[ASM_NB], vo[ASM_NB], vp[ASM_NB];
+        int dst[ASM_NB];
+#pragma unroll
+        for (int u = 0; u < ASM_NB; ++u) {
+            const int4 e = pe[u];
+            const bool in = w0 + c.tid + u * SV_NT < n;
+            dst[u] = in ? (e.x & 0x0fffffff) : -1;
+            const int ie = (e.z & 0xffff) - 1, io = ((e.z >> 16) & 0xffff) - 1;
+            const bool one = ie >= 0 && ((vm >> (ie >= 0 ? ie >> 9 : 0)) & 1u), two = io >= 0 && ((vm >> (io >= 0 ? io >> 9 : 0)) & 1u);
+            const double b0 = buf[e.y >= 0 ? e.y : 0], e0 = imuJ[one ? ie : 0], o0 = imuJ[two ? io : 0];
+            vb[u] = e.y >= 0 ? b0 : 0.0;
+            ve[u] = one ? e0 : 0.0;
+            vo[u] = two ? o0 : 0.0;
+            // prior term: Hessian entries J0^T J0 [pinv ca][pinv cb], gradient entries J0^T r [pinv ca]
+            const bool grad = (e.x >> 28) != 0;
+            const int ca = grad ? e.w : (e.w >> 16), cb = grad ? e.w : (e.w & 0xffff);
+            const int ia = e.w >= 0 ? pinv[ca] : -1, ib = e.w >= 0 ? pinv[cb] : -1;
+            const bool pin = has_prior && ia >= 0 && ib >= 0;
+            const int hi = ia > ib ? ia : ib, lo = ia > ib ? ib : ia;
+            const glb_d* pp = grad ? gpr + (pin ? ia : 0) : Hp + (pin ? hi * Ncap + lo : 0);
+            const double p0 = *pp;
+            vp[u] = pin ? p0 : 0.0;
+        }
+        // the next trip's plan entries travel while this trip's values arrive
+        if (w0 + ASM_NB * SV_NT < n) {
+#pragma unroll
+            for (int u = 0; u < ASM_NB; ++u) { const int w = w0 + ASM_NB * SV_NT + c.tid + u * SV_NT; pe[u] = vg_load_int4(plan + (w < n ? w : n - 1)); }
+        }
+#pragma unroll
+        for (int u = 0; u < ASM_NB; ++u)
+            if (dst[u] >= 0) lds0[dst[u]] = ((vb[u] + ve[u]) + vo[u]) + vp[u];
+    }
+    DP_ADD(16);
+    __syncthreads();
+    DP_ADD(17);
 }
 
 // diagonal entry k of the (unscaled) Hessian as stored by assemble()
@@ -1677,6 +1629,7 @@ DEV double hess_diag(const BaLayout& L, const SolveLds& m, int k) {
 template <bool BIG>
 NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_in, double mu) {
     PHASE_ENTER(BIG);
+    constexpr int NT = BIG ? BA_NT : SV_NT;        // threads of the calling kernel
     mu = uni(mu);                             // (arguments arrive in vector registers)
     typedef typename MovT<BIG>::D MV;
     const auto mq = sys_ptrs<BIG>(m);
@@ -1687,7 +1640,7 @@ NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_in, double mu) {
     const int Rc = L.Rc, K = L.K, ldc = mq.ldc;
     const int n = Rc * (Rc + 1) / 2;
     double q = 0.0;
-    for (int w = c.tid; w < n; w += BA_NT) {
+    for (int w = c.tid; w < n; w += NT) {
         int a, b;
         tri_decode(w, a, b);
         double v = mq.S[w] * sc[a] * sc[b];
@@ -1695,9 +1648,9 @@ NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_in, double mu) {
         if (a == b) v += mu * dg[a] * dg[a];
         mq.S[w] = v;
     }
-    for (int k = c.tid; k < Rc; k += BA_NT) mq.S[tri(Rc, k)] = sc[k] * g[k];
+    for (int k = c.tid; k < Rc; k += NT) mq.S[tri(Rc, k)] = sc[k] * g[k];
     if (c.tid == 0) mq.S[tri(Rc, Rc)] = 0.0;
-    for (int w = c.tid; w < 81 * K; w += BA_NT) {
+    for (int w = c.tid; w < 81 * K; w += NT) {
         const int k = w / 81, e = w - 81 * k, r = e / 9, cc = e - 9 * r;
         const int ca = Rc + 9 * k + r, cb = Rc + 9 * k + cc;
         double v = mq.D[w] * sc[ca] * sc[cb];
@@ -1711,24 +1664,13 @@ NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_in, double mu) {
             mq.E[w] = ve;
         }
     }
-    if (!BIG) {
-        for (int w = c.tid; w < 9 * K * (Rc + 1); w += BA_NT) {
-            const int row = w / (Rc + 1), col = w - row * (Rc + 1);
-            const int ca = Rc + row;
-            if (col < Rc) {
-                const double v = mq.XC[row * ldc + col] * sc[ca] * sc[col];
-                q += 2.0 * v * tv[ca] * tv[col];
-                mq.XC[row * ldc + col] = v;
-            } else {
-                mq.XC[row * ldc + Rc] = sc[ca] * g[ca];
-            }
-        }
-    } else {
+    if constexpr (BIG) {
+        // (XC in HBM; the single-workgroup path scales its coupling rows as the chain elimination gathers them: chain_schur)
         // large-window path (XC in HBM): before the elimination a speed-bias row of frame k is non-zero only in the columns of
         // poses k-1, k, k+1 (IMU factors k-1 and k) -- and anywhere if the prior holds that speed-bias block
         const glb_i* kind = AS_GLB_CI(c.ia + L.io_pb_kind);
         const glb_i* idx = AS_GLB_CI(c.ia + L.io_pb_idx);
-        for (int w = c.tid; w < 9 * K * 20; w += BA_NT) {
+        for (int w = c.tid; w < 9 * K * 20; w += NT) {
             const int row = w / 20, e = w - 20 * row, k = row / 9;
             const int ca = Rc + row;
             if (e == 19) { mq.XC[row * ldc + Rc] = sc[ca] * g[ca]; continue; }
@@ -1744,7 +1686,7 @@ NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_in, double mu) {
         for (int b = 0; b < c.nblk; ++b) {
             if (kind[b] != VG_BLK_SPEEDBIAS) continue;
             const int k = idx[b];
-            for (int w = c.tid; w < 9 * Rc; w += BA_NT) {
+            for (int w = c.tid; w < 9 * Rc; w += NT) {
                 const int r = w / Rc, col = w - r * Rc, row = 9 * k + r, ca = Rc + row;
                 const double v = mq.XC[row * ldc + col] * sc[ca] * sc[col];
                 q += 2.0 * v * tv[ca] * tv[col];
@@ -1770,21 +1712,8 @@ DEV double rsqrt_nr(double x) {
     return y;
 }
 
-// Block elimination of the speed-bias chain from BOTH ends towards the middle block mid = K / 2 ("burn at both ends":
-// the two sweeps are independent until they meet, which halves the serial depth of the block-Thomas recursion).
-//   top sweep    k = K-1 .. mid+1 : block k is coupled to k-1 through E_k (rows sb_k, columns sb_k-1)
-//   bottom sweep k = 0 .. mid-1   : block k is coupled to k+1 through E_k+1^T
-//   last         k = mid          : receives the updates of both neighbours
-// One step (both sweeps at once):
-//   (A) wavefront 0 / 1: D_k -= (update of the neighbour eliminated one step earlier), then the 9x9 Cholesky D_k = L L^T in
-//       registers (lane = row, v_readlane pivots), L (lower) and 1/L_rr back to LDS;
-//       other wavefronts: [C_k | g_k] -= (same update) for both blocks
-//   (B) thread per column of [C_k | g_k | coupling block]:  X = L^-1 column  (forward substitution, L broadcast from LDS)
-// Storage after the elimination: XC rows 9k..9k+8 = X_k = L_k^-1 [C_k | g_k];  D_k = L_k;  the coupling block of a pair
-// (k, k-1) lives in the slot E_k: for a TOP block k it holds Xe_k = L_k^-1 E_k as [p][c] (p = row of X_k, c = column sb_k-1),
-// for a BOTTOM block k-1 it holds (L_k-1^-1 E_k^T)^T as [c][p] (c = column sb_k, p = row of X_k-1) — each pair is consumed
-// by exactly one of its two blocks.  The camera system gets  S -= X^T X  in schur_mfma().
-// Returns false (uniform) on a non-positive pivot.
+// 9x9 diagonal block of the speed-bias chain (chain_schur below; chain_eliminate_big on the large-window path): update from the
+// neighbour(s) eliminated earlier, then Cholesky.  Returns false (wave-uniform) on a non-positive pivot.
 // One wavefront, the block in the accumulator layout of v_mfma_f64_16x16x4_f64 (padded to 16x16 with the identity), as in
 // cholesky_aug(): the neighbour update is three MFMAs per coupling block (k = 9 padded to 12; the B operand of A A^T is the A
 // operand itself, negated), a pivot is v_readlane + 1/sqrt + one rank-1 MFMA, and no LDS access sits between the first load
@@ -1851,34 +1780,214 @@ DEV bool chain_factor(int lane, P Dk, P dinvk, int kind, PC Xc, PC Xu) {
     }
     return !__any(!good);
 }
-// x <- L^-1 x for the 9 values at col[0], col[stride], ...
-template <typename PL, typename PD, typename P>
-DEV void chain_col_solve(PL Lk, PD dinvk, P col, int stride) {
-    double x[9];
+// ---- the same factorisation in three parts, so that one wavefront can walk TWO blocks in lock step (their pivot chains are
+//      independent: the second block hides in the latencies of the first)
+struct ChainFac { double4_t dg, ld, di; };
+template <typename P, typename PC>
+DEV void cf_load(ChainFac& f, int lane, P Dk, int kind, PC Xc, PC Xu) {
+    const int jc = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) x[r] = col[r * stride];
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        double s = x[r];
-#pragma unroll
-        for (int q = 0; q < r; ++q) s -= Lk[9 * r + q] * x[q];
-        x[r] = s * dinvk[r];
+    for (int reg = 0; reg < 4; ++reg) {
+        const int i = kq + 4 * reg;
+        const bool in = i < 9 && jc < 9;
+        const double dv = Dk[in ? 9 * (i > jc ? i : jc) + (i > jc ? jc : i) : 0];
+        f.dg[reg] = in ? dv : (i == jc ? 1.0 : 0.0);
     }
+    if (kind & 1) {
+        double av[3];
 #pragma unroll
-    for (int r = 0; r < 9; ++r) col[r * stride] = x[r];
+        for (int s = 0; s < 3; ++s) {
+            const int pp = 4 * s + kq;
+            const bool in = pp < 9 && jc < 9;
+            const double v = Xc[in ? 9 * pp + jc : 0];
+            av[s] = in ? v : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) f.dg = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], -av[s], f.dg, 0, 0, 0);
+    }
+    if (kind & 2) {
+        double av[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int pp = 4 * s + kq;
+            const bool in = pp < 9 && jc < 9;
+            const double v = Xu[in ? 9 * jc + pp : 0];
+            av[s] = in ? v : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) f.dg = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], -av[s], f.dg, 0, 0, 0);
+    }
+    f.ld = (double4_t){0, 0, 0, 0};
+    f.di = (double4_t){0, 0, 0, 0};
 }
-NOINL bool chain_eliminate(const Ctx& c_in, const SolveLds& m_in) {
+template <int r>
+DEV void cf_pivot(ChainFac& f, const double* msk) {
+    const double piv = readlane_d(f.dg[r >> 2], 16 * (r & 3) + r);
+    const double dm = rsqrt_nr(piv) * msk[r & 3];                     // a bad pivot turns everything behind it into NaN / Inf
+    const double lv = f.dg[r >> 2] * dm, nlv = f.dg[r >> 2] * -dm;
+    f.dg = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, nlv, f.dg, 0, 0, 0);
+    f.ld[r >> 2] += lv;
+    f.di[r >> 2] += dm;
+}
+template <typename P>
+DEV bool cf_store(const ChainFac& f, int lane, P Dk, P dinvk) {
+    const int jc = lane & 15, kq = lane >> 4;
+    bool good = true;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int r = kq + 4 * q;
+        if (r < 9) {
+            if (!(f.di[q] > 0.0) || !(f.di[q] < 1e300)) good = false;
+            if (jc >= r && jc < 9) Dk[9 * jc + r] = f.ld[q];
+            if (jc == 0) dinvk[r] = f.di[q];
+        }
+    }
+    return !__any(!good);
+}
+
+// ---- single-workgroup path, round 5: chain elimination and Schur complement in ONE phase, coupling rows not kept in LDS --------
+// The speed-bias chain is eliminated from both ends towards the middle block mid = K / 2 as before ("burn at both ends"):
+//   top sweep    k = K-1 .. mid+1 : block k is coupled to k-1 through E_k (rows sb_k, columns sb_k-1)
+//   bottom sweep k = 0 .. mid-1   : block k is coupled to k+1 through E_k+1^T
+//   last         k = mid          : receives the updates of both neighbours
+// but a THREAD owns a COLUMN of [C_k | g_k | coupling block] for a whole sweep (threads 0 .. Rc+9: top, Rc+10 .. 2 Rc+19: bottom;
+// wavefronts 0-2): the update a block receives from the neighbour eliminated one step earlier involves only the same column of
+// that neighbour -- which this thread solved itself and still holds in registers -- and the neighbour's 9x9 coupling block (LDS).
+// What the former layout kept for the whole solve (100 rows x ldc = 64 KB of LDS: the reason only one window fitted a CU) shrinks
+// to one slot of 18 rows: the solved rows X_k = L_k^-1 [C_k | g_k] of the block pair of the step, staged for the matrix cores, which
+// add S -= X^T X to register accumulators right away; the rows are parked in HBM (so_xp) for the back substitution.  The unscaled
+// coupling rows are not assembled into LDS either: the 9 x 18 entries of a block that the IMU factors touch are gathered one step
+// ahead into a small staging area (two loads per thread), a column scales its nine entries and -- for the Cauchy-point term
+// t^T H~ t -- sums them on the way; a block the prior holds adds its J0^T J0 row.
+// One step (both sweeps at once):
+//   (A) wavefront 3: both diagonal blocks in lock step -- D_k -= (update of the neighbour eliminated one step earlier), 9x9
+//       Cholesky in MFMA accumulators;  every column thread: x = scaled raw column - (coupling block)^T x_prev
+//   (B) x <- L_k^-1 x (L from LDS) -> ring slot, HBM, registers;  coupling-block columns -> Xe / XuT in the slot E_k
+//   (C) all wavefronts: S accumulators += (18 staged rows)^T (18 staged rows) on v_mfma_f64_16x16x4
+// then the landmark columns, 32 at a time, exactly as before.  Storage afterwards: D_k = L_k; the coupling block of a pair
+// (k, k-1) lives in the slot E_k: for a TOP block k it holds Xe_k = L_k^-1 E_k as [p][c] (p = row of X_k, c = column sb_k-1), for
+// a BOTTOM block k-1 it holds (L_k-1^-1 E_k^T)^T as [c][p]; X in HBM.  Returns this thread's share of the coupling part of
+// t^T H~ t; *flag (m.red + 24) = 0 on a non-positive pivot.
+#define SCHUR_LW 32                               // landmarks per staged tile
+#define SCHUR_LD (SCHUR_LW + 1)
+#define SCHUR_PF ((96 * SCHUR_LW + SV_NT - 1) / SV_NT)
+// SCHUR_TPW = 16x16 tiles of S per wavefront: 15 tiles (RcPad = 80) over four wavefronts = 4, 21 tiles (RcPad = 96) = 6
+template <int SCHUR_TPW>
+NOINL double chain_schur(const Ctx& c_in, const SolveLds& m_in, const double* buf_, double mu) {
     PHASE_ENTER(false);
-    const int K = L.K, Rc = L.Rc, ldc = m.ldc;
-    const int mid = K / 2;
-    const int nstep = (K - 1 - mid) > mid ? (K - 1 - mid) : mid;
-    lds_d* const XC = AS_LDS(m.XC);
+    mu = uni(mu);
+    const int K = L.K, Rc = L.Rc, RcPad = L.RcPad, ldc = m.ldc, Ncap = L.Ncap;
+    const int mid = K / 2, nstep = mid;            // (K - 1 - mid <= mid)
+    lds_d* const S = AS_LDS(m.S);
     lds_d* const D = AS_LDS(m.D);
     lds_d* const E = AS_LDS(m.E);
     lds_d* const dinv = AS_LDS(m.dinv);
-    lds_d* const wd = AS_LDS(m.wd);
-    int* flag = (int*)(m.red + 24);
+    lds_d* const ring = AS_LDS(m.ring);            // rows 0..8: top block of the step, rows 9..17: bottom block
+    lds_d* const stage = ring + 18 * ldc;          // [2][9][18]: the IMU part of the raw coupling rows of the NEXT step's two blocks
+    lds_d* const wd = AS_LDS(m.wd);                // (aliases the ring: used after the chain)
+    const lds_d* g = AS_LDS_C(m.vec + V_G * L.Rpad);
+    const lds_d* sc = AS_LDS_C(m.vec + V_SC * L.Rpad);
+    const lds_d* tv = AS_LDS_C(m.vec + V_T * L.Rpad);
+    const lds_i* pinv = (const lds_i*)m.pinv;
+    const glb_d* buf = AS_GLB_C(buf_);
+    const glb_d* imuJ = buf + L.bo_imuJ;
+    const glb_d* Hp = AS_GLB_C(c.sc + L.so_Hp);
+    glb_d* const xp = AS_GLB(m.xp);
+    lds_i* flag = (lds_i*)(m.red + 24);
+    const int wave = uni(c.wave);
+    unsigned vm;                                   // bit f: IMU factor f is present
+    {
+        const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
+        const int v = c.lane < K - 1 ? valid[c.lane] : 0;
+        vm = (unsigned)__ballot(v != 0);
+    }
     if (c.tid == 0) *flag = 1;
+    const int nt = RcPad / 16;
+    const int ntile = nt * (nt + 1) / 2;
+    double4_t acc[SCHUR_TPW];
+    int tm[SCHUR_TPW], tn[SCHUR_TPW];
+#pragma unroll
+    for (int s = 0; s < SCHUR_TPW; ++s) {
+        acc[s] = (double4_t){0, 0, 0, 0};
+        int a, bq;
+        tri_decode(wave + s * SV_NW, a, bq);
+        tm[s] = a; tn[s] = bq;
+    }
+    const int nth = Rc + 10;                                 // tasks of a sweep: Rc + 1 columns of [C_k | g_k], 9 of the coupling block
+    const int half = c.tid >= nth ? 1 : 0, id = c.tid - half * nth;
+    const bool tasked = c.tid < 2 * nth;                     // (2 nth <= 192: wavefronts 0-2; the host checks)
+    const bool col_task = tasked && id <= Rc;
+    const bool cpl_task = tasked && id > Rc;
+    const bool fac_wave = wave == SV_NW - 1;                 // wavefront 3 factors the diagonal blocks
+    // ---- staging of the IMU part of a block's raw coupling rows: entry (r, c18), c18 = 6 (d + 1) + o for the pose column o of frame
+    //      k + d, d = -1, 0, 1.  IMU factor f, local columns: 0-5 pose_f, 6-14 sb_f, 15-20 pose_f+1, 21-29 sb_f+1, packed lower
+    //      triangle in imuJ[f][.]: factor k gives (sb_k, pose_k) and (pose_k+1, sb_k), factor k-1 gives (sb_k, pose_k-1) and (sb_k, pose_k)
+    double sv[2][2];
+    auto stage_issue = [&](int kt_n, int kb_n) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int e2 = c.tid + SV_NT * qq;
+            const int hh = e2 >= 162 ? 1 : 0, e = e2 - 162 * hh;
+            const int k = hh ? kb_n : kt_n;
+            const bool on = e2 < 324 && k >= 0;
+            const int r = e / 18, c18 = e - 18 * r, d = c18 / 6 - 1, o = c18 - 6 * (d + 1);
+            const bool fa_on = on && d >= 0 && k <= K - 2 && ((vm >> (k >= 0 ? k : 0)) & 1u);
+            const bool fb_on = on && d <= 0 && k >= 1 && ((vm >> (k >= 1 ? k - 1 : 0)) & 1u);
+            const int ia = d == 0 ? (6 + r) * (7 + r) / 2 + o : (15 + o) * (16 + o) / 2 + 6 + r;
+            const int ib = (21 + r) * (22 + r) / 2 + (d == 0 ? 15 + o : o);
+            const double va = imuJ[fa_on ? k * 512 + ia : 0], vb = imuJ[fb_on ? (k - 1) * 512 + ib : 0];
+            // even factor first, then the odd one: the order in which the former scatter rounds added them
+            const double a = fa_on ? va : 0.0, b = fb_on ? vb : 0.0;
+            sv[qq][0] = (k & 1) ? b : a;
+            sv[qq][1] = (k & 1) ? a : b;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int e2 = c.tid + SV_NT * qq;
+            if (e2 < 324) stage[e2] = sv[qq][0] + sv[qq][1];
+        }
+    };
+    // the raw column `id` of block k: staged IMU part (+ the prior's J0^T J0 row if the prior holds this speed-bias block), g for the rhs
+    auto raw_col = [&](int k, double* c0) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) c0[r] = 0.0;
+        if (k < 0 || !col_task) return;
+        if (id == Rc) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) c0[r] = g[Rc + 9 * k + r];
+            return;
+        }
+        const int p = id / 6, o = id - 6 * p, d = p - k;
+        if (id < 6 * K && d >= -1 && d <= 1) {
+            const lds_d* st = stage + 162 * half + 6 * (d + 1) + o;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) c0[r] = st[18 * r];
+        }
+        const int pbk = pinv[Rc + 9 * k], pj = pinv[id];
+        if (pbk >= 0 && pj >= 0) {
+            double pv[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int pr_ = pbk + r;
+                const int hi = pr_ > pj ? pr_ : pj, lo = pr_ > pj ? pj : pr_;
+                pv[r] = Hp[hi * Ncap + lo];
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) c0[r] += pv[r];
+        }
+    };
+    double xprev[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) xprev[r] = 0.0;
+    double q = 0.0;
+    {
+        const bool l0 = nstep == 0;
+        const int kt0 = l0 ? mid : K - 1, kb0 = l0 ? -1 : 0;
+        stage_issue((l0 || kt0 > mid) ? kt0 : -1, (!l0 && kb0 < mid) ? kb0 : -1);
+        stage_store();
+    }
     __syncthreads();
     DP_DECL;
     for (int t = 0; t <= nstep; ++t) {
@@ -1886,29 +1995,65 @@ NOINL bool chain_eliminate(const Ctx& c_in, const SolveLds& m_in) {
         // blocks of this step: top kt (coupled downwards), bottom kb (coupled upwards); in the last step only `mid`
         const int kt = last ? mid : K - 1 - t, kb = last ? -1 : t;
         const bool has_t = last || kt > mid, has_b = !last && kb < mid;
-        // updates a block receives: from its already eliminated neighbour(s)
         const bool upd_t_from_above = has_t && kt + 1 <= K - 1 && (last ? (K - 1 > mid) : t > 0);
         const bool upd_mid_from_below = last && mid > 0;
         const bool upd_b = has_b && t > 0;
-        // ---- (A)
-        if (c.wave == 0) {
-            if (has_t) {
-                const int kind = (upd_t_from_above ? 1 : 0) | (upd_mid_from_below ? 2 : 0);
-                if (!chain_factor(c.lane, D + 81 * kt, dinv + 9 * kt, kind, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt)) && c.lane == 0) *flag = 0;
-            }
-        } else if (c.wave == 1) {
-            if (has_b && !chain_factor(c.lane, D + 81 * kb, dinv + 9 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb)) && c.lane == 0) *flag = 0;
-        } else {
-            // [C_k | g_k] -= (coupling block)^T X_neighbour: thread = (three rows of the block, column j); the nine X values of the
-            // column are read once for the three rows, the coupling entries are wavefront-uniform (LDS broadcast reads)
-            const int id = c.tid - 128;
-            const int r3 = 3 * (id >> 7), j = id & 127;
-            if (j <= Rc) {
-                // coef[p * sp + r * sr] = coupling entry (row r of this block, row p of the neighbour's X)
-                auto upd = [&](const lds_d* coef, int sp, int sr, const lds_d* Xn, lds_d* Ck) {
-                    double xn[9], s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        const int k = half == 0 ? kt : kb;
+        const bool act = tasked && (half == 0 ? has_t : has_b);
+        // next step's blocks (their raw rows are requested now, staged behind the first barrier of this step)
+        int ktn = -1, kbn = -1;
+        if (t < nstep) {
+            const bool nlast = t + 1 == nstep;
+            const int k2 = nlast ? mid : K - 2 - t;
+            if (nlast || k2 > mid) ktn = k2;
+            if (!nlast && t + 1 < mid) kbn = t + 1;
+        }
+        double x[9];
 #pragma unroll
-                    for (int p = 0; p < 9; ++p) xn[p] = Xn[p * ldc + j];
+        for (int r = 0; r < 9; ++r) x[r] = 0.0;
+        stage_issue(ktn, kbn);
+        DP_ADD(18);
+        // ---- (A)
+        if (fac_wave) {
+            const int kind_t = (upd_t_from_above ? 1 : 0) | (upd_mid_from_below ? 2 : 0);
+            double msk[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) msk[i] = (c.lane >> 4) == i ? 1.0 : 0.0;
+            bool ok = true;
+            if (has_t && has_b) {
+                ChainFac ft, fb;
+                cf_load(ft, c.lane, D + 81 * kt, kind_t, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt));
+                cf_load(fb, c.lane, D + 81 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb));
+#define CF_STEP(r) cf_pivot<r>(ft, msk); cf_pivot<r>(fb, msk);
+                CF_STEP(0) CF_STEP(1) CF_STEP(2) CF_STEP(3) CF_STEP(4) CF_STEP(5) CF_STEP(6) CF_STEP(7) CF_STEP(8)
+#undef CF_STEP
+                ok = cf_store(ft, c.lane, D + 81 * kt, dinv + 9 * kt);
+                ok = cf_store(fb, c.lane, D + 81 * kb, dinv + 9 * kb) && ok;
+            } else if (has_t) {
+                ok = chain_factor(c.lane, D + 81 * kt, dinv + 9 * kt, kind_t, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt));
+            } else if (has_b) {
+                ok = chain_factor(c.lane, D + 81 * kb, dinv + 9 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb));
+            }
+            if (!ok && c.lane == 0) *flag = 0;
+        }
+        if (act && col_task) {
+            double c0[9];
+            raw_col(k, c0);
+            const double scj = id < Rc ? sc[id] : 1.0, tvj = id < Rc ? tv[id] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int ca = Rc + 9 * k + r;
+                const double v = c0[r] * sc[ca] * scj;
+                q += 2.0 * v * tv[ca] * tvj;
+                x[r] = v;
+            }
+            DP_ADD(19);
+            // x -= (coupling block)^T x_prev;  coef[p * sp + r * sr] = coupling entry (row r of this block, row p of the neighbour's X)
+            // (three rows at a time, the scheduler fenced in between: 81 hoisted LDS reads would not fit the register file)
+            auto upd = [&](const lds_d* coef, int sp, int sr, const double* xn) {
+#pragma unroll
+                for (int r3 = 0; r3 < 9; r3 += 3) {
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
                     const lds_d* cf = coef + r3 * sr;
 #pragma unroll
                     for (int p = 0; p < 9; ++p) {
@@ -1916,150 +2061,148 @@ NOINL bool chain_eliminate(const Ctx& c_in, const SolveLds& m_in) {
                         s1 += cf[p * sp + sr] * xn[p];
                         s2 += cf[p * sp + 2 * sr] * xn[p];
                     }
-                    lds_d* o = Ck + r3 * ldc + j;
-                    const double c0v = o[0], c1v = o[ldc], c2v = o[2 * ldc];
-                    o[0] = c0v - s0; o[ldc] = c1v - s1; o[2 * ldc] = c2v - s2;
-                };
-                if (has_t && upd_t_from_above) upd(E + 81 * (kt + 1), 9, 1, XC + 9 * (kt + 1) * ldc, XC + 9 * kt * ldc);
-                if (has_t && upd_mid_from_below) upd(E + 81 * kt, 1, 9, XC + 9 * (kt - 1) * ldc, XC + 9 * kt * ldc);
-                if (upd_b) upd(E + 81 * kb, 1, 9, XC + 9 * (kb - 1) * ldc, XC + 9 * kb * ldc);
+                    x[r3] -= s0; x[r3 + 1] -= s1; x[r3 + 2] -= s2;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // (one call for both sweeps, operands selected per lane: wavefront 1 holds columns of both)
+            if (half == 0 ? upd_t_from_above : upd_b) upd(half == 0 ? E + 81 * (kt + 1) : E + 81 * kb, half == 0 ? 9 : 1, half == 0 ? 1 : 9, xprev);
+            DP_ADD(20);
+            if (half == 0 && upd_mid_from_below) {
+                double xb[9];
+#pragma unroll
+                for (int p = 0; p < 9; ++p) xb[p] = ring[(9 + p) * ldc + id];      // X of block mid - 1: the bottom sweep's last rows
+                upd(E + 81 * kt, 1, 9, xb);
             }
+        } else if (act && cpl_task && !(half == 0 && last)) {
+            const int cc = id - Rc - 1;
+            // top: column cc of E_kt -> Xe_kt[.][cc];  bottom: row cc of E_kb+1 -> XuT of the pair (kb + 1, kb)
+            const lds_d* e = half == 0 ? E + 81 * kt + cc : E + 81 * (kb + 1) + 9 * cc;
+            const int st = half == 0 ? 9 : 1;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) x[r] = e[r * st];
         }
         DP_ADD(0);
         __syncthreads();
         DP_ADD(1);
         if (*flag == 0) break;
-        // ---- (B) columns: threads 0 .. Rc + 9 serve the top block, 256 .. 256 + Rc + 9 the bottom block (Rc + 10 <= 256)
-        {
-            const int half = c.tid >> 8, id = c.tid & 255;
-            if (half == 0 && has_t) {
-                const lds_d* Lk = D + 81 * kt;
-                if (id <= Rc) chain_col_solve(Lk, dinv + 9 * kt, XC + 9 * kt * ldc + id, ldc);
-                else if (!last && id < Rc + 10) chain_col_solve(Lk, dinv + 9 * kt, E + 81 * kt + (id - Rc - 1), 9);        // column of E_kt -> Xe
-            } else if (half == 1 && has_b) {
-                const lds_d* Lk = D + 81 * kb;
-                if (id <= Rc) chain_col_solve(Lk, dinv + 9 * kb, XC + 9 * kb * ldc + id, ldc);
-                else if (id < Rc + 10) chain_col_solve(Lk, dinv + 9 * kb, E + 81 * (kb + 1) + 9 * (id - Rc - 1), 1);        // row of E_kb+1 -> XuT
+        // ---- (B) x <- L_k^-1 x
+        if (act && (col_task || !(half == 0 && last))) {
+            const lds_d* Lk = D + 81 * k;
+            const lds_d* dk = dinv + 9 * k;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                double s = x[r];
+#pragma unroll
+                for (int qq = 0; qq < r; ++qq) s -= Lk[9 * r + qq] * x[qq];
+                x[r] = s * dk[r];
+            }
+            if (col_task) {
+                lds_d* ro = ring + (half ? 9 : 0) * ldc + id;
+                glb_d* po = xp + (size_t)9 * k * ldc + id;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) { ro[r * ldc] = x[r]; po[(size_t)r * ldc] = x[r]; xprev[r] = x[r]; }
+            } else {
+                const int cc = id - Rc - 1;
+                lds_d* e = half == 0 ? E + 81 * kt + cc : E + 81 * (kb + 1) + 9 * cc;
+                const int st = half == 0 ? 9 : 1;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) e[r * st] = x[r];
             }
         }
+        stage_store();                             // (the staging area's readers -- raw_col in (A) -- are behind the barrier above)
         DP_ADD(2);
         __syncthreads();
         DP_ADD(3);
-    }
-    const bool ok = *flag != 0;
-    __syncthreads();
-    return ok;
-}
-
-// Schur complement on the camera part, rhs as the augmented row Rc:
-//   S -= Wd Wd^T  with the 9K rows of X (chain) and, 32 at a time, the landmark columns
-//   Wd[c][l] = sc[c] * Wt[c][l] * lsc[l],  Wd[Rc][l] = b[l] * lsc[l],  lsc[l] = sl[l] / sqrt(sl^2 h + mu dgl^2).
-// 16x16 tiles accumulate in registers on v_mfma_f64_16x16x4_f64, up to three tiles per wavefront; the Wt values of the
-// next 32 landmarks are fetched into registers while the current tile is multiplied.
-#define SCHUR_LW 32                               // landmarks per staged tile
-#define SCHUR_LD (SCHUR_LW + 1)
-#define SCHUR_PF ((96 * SCHUR_LW + BA_NT - 1) / BA_NT)
-NOINL void schur_mfma(const Ctx& c_in, const SolveLds& m_in, const double* buf, double mu) {
-    PHASE_ENTER(false);
-    const lds_d* sc = AS_LDS_C(m.vec + V_SC * L.Rpad);
-    lds_d* const S = AS_LDS(m.S);
-    lds_d* const wd = AS_LDS(m.wd);
-    const lds_d* const XC = AS_LDS_C(m.XC);
-    const glb_d* Wt = AS_GLB_C(buf + L.bo_Wt);
-    const glb_d* h = AS_GLB_C(buf + L.bo_h);
-    const glb_d* b = AS_GLB_C(buf + L.bo_b);
-    const glb_d* sl = AS_GLB_C(c.sc + L.so_sl);
-    const glb_d* dgl = AS_GLB_C(c.sc + L.so_dg + L.Rpad);
-    glb_d* lsc = AS_GLB(c.sc + L.so_lsc);
-    const int Rc = L.Rc, RcPad = L.RcPad, ldc = m.ldc;
-    const int nt = RcPad / 16;
-    const int ntile = nt * (nt + 1) / 2;
-    DP_DECL;
-    double4_t acc[3];                              // up to 3 tiles per wavefront (21 tiles / 8 wavefronts)
-    int tm[3], tn[3];
+        // ---- (C) S accumulators += X^T X over the staged rows: k-step u covers rows 4u .. 4u+3 of [top 9 | bottom 9]
+        {
+            const int nks = has_b ? 5 : 3;
+            const int kq = c.lane >> 4, jc = c.lane & 15;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        acc[s] = (double4_t){0, 0, 0, 0};
-        const int t = c.wave + s * BA_NW;
-        int a, bq;
-        tri_decode(t, a, bq);
-        tm[s] = a; tn[s] = bq;
-    }
-    for (int l = c.tid; l < c.nL; l += BA_NT) lsc[l] = sl[l] / sqrt(sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l]);
-    // ---- chain rows
-    const int nk = (9 * L.K + 3) / 4;
-    for (int kk0 = 0; kk0 < nk; kk0 += 4) {        // four k-steps per trip: their operand reads first, then the MFMAs
+            for (int s = 0; s < SCHUR_TPW; ++s) {
+                if (wave + s * SV_NW < ntile) {
+                    double av[5], bv[5];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            if (c.wave + s * BA_NW < ntile) {
-                double av[4], bv[4];
+                    for (int u = 0; u < 5; ++u) {
+                        const int row = 4 * u + kq;
+                        const bool on = u < nks && (row < 9 ? has_t : (row < 18 && has_b));
+                        const lds_d* xr = ring + (on ? row : 0) * ldc + jc;
+                        const double a = xr[tm[s] * 16], b = xr[tn[s] * 16];
+                        av[u] = on ? a : 0.0;
+                        bv[u] = on ? b : 0.0;
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int kk = kk0 + u < nk ? kk0 + u : nk - 1;
-                    const lds_d* xr = XC + (kk * 4 + (c.lane >> 4)) * ldc + (c.lane & 15);
-                    av[u] = xr[tm[s] * 16];
-                    bv[u] = xr[tn[s] * 16];
+                    for (int u = 0; u < 5; ++u)
+                        if (u < nks) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc[s], 0, 0, 0);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (kk0 + u < nk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc[s], 0, 0, 0);
             }
         }
+        DP_ADD(10);
     }
-    DP_ADD(10);
-    // ---- landmark columns: element w = tid + BA_NT * i of the (RcPad x SCHUR_LW) tile -> row w / 32, landmark l0 + w % 32.
-    //      fetch(): everything of the next tile that comes from HBM (Wt, the landmark factor, b for the rhs row) into registers
-    double pre[SCHUR_PF], pls[SCHUR_PF];
-    const int nel = RcPad * SCHUR_LW;
-    auto fetch = [&](int l0) {
+    __syncthreads();                               // ring consumed (it is the landmark tile from here on); *flag final
+    // ---- landmark columns: S -= Wd Wd^T,  Wd[c][l] = sc[c] * Wt[c][l] * lsc[l],  Wd[Rc][l] = b[l] * lsc[l],
+    //      lsc[l] = sl[l] / sqrt(sl^2 h + mu dgl^2); the Wt values of the next 32 landmarks are fetched into registers while the
+    //      current tile is multiplied.  Element w = tid + SV_NT * i of the (RcPad x SCHUR_LW) tile -> row w / 32, landmark l0 + w % 32.
+    {
+        const glb_d* Wt = buf + L.bo_Wt;
+        const glb_d* h = buf + L.bo_h;
+        const glb_d* b = buf + L.bo_b;
+        const glb_d* sl = AS_GLB_C(c.sc + L.so_sl);
+        const glb_d* dgl = AS_GLB_C(c.sc + L.so_dg + L.Rpad);
+        glb_d* lsc = AS_GLB(c.sc + L.so_lsc);
+        for (int l = c.tid; l < c.nL; l += SV_NT) lsc[l] = sl[l] / sqrt(sl[l] * sl[l] * h[l] + mu * dgl[l] * dgl[l]);
+        double pre[SCHUR_PF], pls[SCHUR_PF];
+        const int nel = RcPad * SCHUR_LW;
+        auto fetch = [&](int l0) {
 #pragma unroll
-        for (int i = 0; i < SCHUR_PF; ++i) {
-            const int w = c.tid + BA_NT * i;
-            const int row = w / SCHUR_LW, l = l0 + (w % SCHUR_LW);
-            const bool in = w < nel && row <= Rc && l < c.nL;
-            pre[i] = in ? (row < Rc ? Wt[(size_t)row * L.Lcap + l] : b[l]) : 0.0;
-            pls[i] = in ? lsc[l] : 0.0;
-        }
-    };
-    __syncthreads();                               // lsc of this launch visible to every wavefront
-    if (c.nL > 0) fetch(0);
-    for (int l0 = 0; l0 < c.nL; l0 += SCHUR_LW) {
-        __syncthreads();                           // previous tile consumed
-        DP_ADD(11);
-#pragma unroll
-        for (int i = 0; i < SCHUR_PF; ++i) {
-            const int w = c.tid + BA_NT * i;
-            if (w < nel) {
-                const int row = w / SCHUR_LW, k = w % SCHUR_LW;
-                wd[row * SCHUR_LD + k] = (row < Rc ? sc[row] : 1.0) * pre[i] * pls[i];
+            for (int i = 0; i < SCHUR_PF; ++i) {
+                const int w = c.tid + SV_NT * i;
+                const int row = w / SCHUR_LW, l = l0 + (w % SCHUR_LW);
+                const bool in = w < nel && row <= Rc && l < c.nL;
+                pre[i] = in ? (row < Rc ? Wt[(size_t)row * L.Lcap + l] : b[l]) : 0.0;
+                pls[i] = in ? lsc[l] : 0.0;
             }
+        };
+        __syncthreads();                           // lsc of this launch visible to every wavefront
+        if (c.nL > 0) fetch(0);
+        for (int l0 = 0; l0 < c.nL; l0 += SCHUR_LW) {
+            __syncthreads();                       // previous tile consumed
+            DP_ADD(11);
+#pragma unroll
+            for (int i = 0; i < SCHUR_PF; ++i) {
+                const int w = c.tid + SV_NT * i;
+                if (w < nel) {
+                    const int row = w / SCHUR_LW, kk = w % SCHUR_LW;
+                    wd[row * SCHUR_LD + kk] = (row < Rc ? sc[row] : 1.0) * pre[i] * pls[i];
+                }
+            }
+            DP_ADD(12);
+            __syncthreads();
+            DP_ADD(13);
+            if (l0 + SCHUR_LW < c.nL) fetch(l0 + SCHUR_LW);
+#pragma unroll
+            for (int s = 0; s < SCHUR_TPW; ++s) {
+                if (wave + s * SV_NW < ntile) {
+                    // the sixteen operand reads of a tile first, then its eight MFMAs back to back
+                    double av[SCHUR_LW / 4], bv[SCHUR_LW / 4];
+#pragma unroll
+                    for (int kk = 0; kk < SCHUR_LW / 4; ++kk) {
+                        av[kk] = wd[(tm[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
+                        bv[kk] = wd[(tn[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < SCHUR_LW / 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc[s], 0, 0, 0);
+                }
+            }
+            DP_ADD(14);
         }
-        DP_ADD(12);
         __syncthreads();
-        DP_ADD(13);
-        if (l0 + SCHUR_LW < c.nL) fetch(l0 + SCHUR_LW);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            if (c.wave + s * BA_NW < ntile) {
-                // the sixteen operand reads of a tile first, then its eight MFMAs back to back
-                double av[SCHUR_LW / 4], bv[SCHUR_LW / 4];
-#pragma unroll
-                for (int kk = 0; kk < SCHUR_LW / 4; ++kk) {
-                    av[kk] = wd[(tm[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
-                    bv[kk] = wd[(tn[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
-                }
-#pragma unroll
-                for (int kk = 0; kk < SCHUR_LW / 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc[s], 0, 0, 0);
-            }
-        }
-        DP_ADD(14);
+        DP_ADD(15);
     }
-    __syncthreads();
-    DP_ADD(15);
     // D[row = (lane>>4) + 4*reg][col = lane&15]
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        if (c.wave + s * BA_NW < ntile) {
+    for (int s = 0; s < SCHUR_TPW; ++s) {
+        if (wave + s * SV_NW < ntile) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = tm[s] * 16 + (c.lane >> 4) + 4 * reg;
@@ -2069,6 +2212,7 @@ NOINL void schur_mfma(const Ctx& c_in, const SolveLds& m_in, const double* buf, 
         }
     }
     __syncthreads();
+    return q;
 }
 
 // Landmark part of  t^T H~ t  (the Cauchy-point denominator, see build_scaled):  sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ]
@@ -2086,10 +2230,10 @@ NOINL double cauchy_landmark_term(const Ctx& c_in, const SolveLds& m_in, const d
     const double* dgl = c.sc + L.so_dg + L.Rpad;
     const double* gtl = c.sc + L.so_gt + L.Rpad;
     __syncthreads();
-    for (int k = c.tid; k < L.Rc; k += BA_NT) tv[k] = sc[k] * (gt[k] / dg[k]);       // sc .* t on the camera columns
+    for (int k = c.tid; k < L.Rc; k += SV_NT) tv[k] = sc[k] * (gt[k] / dg[k]);       // sc .* t on the camera columns
     __syncthreads();
     double q = 0.0;
-    for (int l = c.tid; l < c.nL; l += BA_NT) {
+    for (int l = c.tid; l < c.nL; l += SV_NT) {
         double wdot = 0.0;
         for (int row = 0; row < L.Rc; ++row) wdot += Wt[(size_t)row * L.Lcap + l] * tv[row];
         const double tl = gtl[l] / dgl[l];
@@ -2118,6 +2262,7 @@ NOINL bool cholesky_aug(const Ctx& c_in, const SolveLds& m_in, int R) {
     const int lane = c.lane;
     R = __builtin_amdgcn_readfirstlane(R);              // arguments arrive in vector registers: tell the compiler they are uniform
     const int wave = __builtin_amdgcn_readfirstlane(c.wave);
+    const int nwv = L.big ? BA_NW : SV_NW;             // wavefronts of the calling kernel (uniform)
     if (c.tid == 0) *flag = 1;
     __syncthreads();
     DP_DECL;
@@ -2139,7 +2284,7 @@ NOINL bool cholesky_aug(const Ctx& c_in, const SolveLds& m_in, int R) {
             dg0[reg] = in ? dv : (i == jc ? 1.0 : 0.0);
         }
         __syncthreads();                               // every wavefront has the block before wavefront 0 overwrites it with L
-        for (int t = wave; t < ntp; t += BA_NW) {
+        for (int t = wave; t < ntp; t += nwv) {
             const int prow = r1 + 16 * t + jc;         // this lane's panel row (column of the transposed tile)
             double4_t dg = dg0, pt;
 #pragma unroll
@@ -2207,7 +2352,7 @@ NOINL bool cholesky_aug(const Ctx& c_in, const SolveLds& m_in, int R) {
             const int nt = (R >> 4) + 1;                 // tile rows covering rows 0..R
             const int mm = nt - t0;
             const int ntile = mm * (mm + 1) / 2;
-            for (int t = wave; t < ntile; t += BA_NW) {
+            for (int t = wave; t < ntile; t += nwv) {
                 int tr_, tc_;
                 tri_decode(t, tr_, tc_);
                 const int ti = t0 + tr_, tk = t0 + tc_;
@@ -2340,7 +2485,6 @@ NOINL void chain_back_substitute(const Ctx& c_in, const SolveLds& m_in) {
     typedef typename MovT<BIG>::D MV;
     const int K = L.K, Rc = L.Rc, ldc = m_.ldc;
     const int mid = K / 2;
-    MV* const XC = (MV*)m_.XC;
     MV* const D = (MV*)m_.D;
     MV* const E = (MV*)m_.E;
     MV* const dinv = (MV*)m_.dinv;
@@ -2348,17 +2492,20 @@ NOINL void chain_back_substitute(const Ctx& c_in, const SolveLds& m_in) {
     MV* const z = (MV*)m_.z;
     MV* y = (MV*)(m_.vec + V_Y * L.Rpad);
     {
+        // (single-workgroup path: the rows X_k were parked in HBM by chain_schur -- every thread's loads are independent)
+        constexpr int NT = BIG ? BA_NT : SV_NT;
+        const glb_d* XR = BIG ? AS_GLB_C(m_.XC) : AS_GLB_C(m_.xp);
         const int nrow = 9 * K;
-        for (int w = c.tid; w < 4 * nrow; w += BA_NT) {
+        for (int w = c.tid; w < 4 * nrow; w += NT) {
             const int row = w >> 2, q = w & 3;
-            const MV* xr = XC + row * ldc;
+            const glb_d* xr = XR + (size_t)row * ldc;
             double s = 0.0;
             for (int j = q; j < Rc; j += 4) s += xr[j] * y[j];
             z[w] = s;
         }
         __syncthreads();
-        for (int row = c.tid; row < nrow; row += BA_NT)
-            wd[row] = XC[row * ldc + Rc] - ((z[4 * row] + z[4 * row + 1]) + (z[4 * row + 2] + z[4 * row + 3]));
+        for (int row = c.tid; row < nrow; row += NT)
+            wd[row] = XR[(size_t)row * ldc + Rc] - ((z[4 * row] + z[4 * row + 1]) + (z[4 * row + 2] + z[4 * row + 3]));
         __syncthreads();
     }
     if (c.wave < 2) {
@@ -2422,7 +2569,12 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
     ctl_load(s, ctlp);
     if (s.done) return;
     SolveLds m;
-    lds_carve(L, m);
+    lds_carve(L, c.sc, m);
+    // What the phase functions are handed is NOT the context (they rebuild it from the kernel arguments, PHASE_ENTER) but two
+    // never-written anchors whose only purpose is an address that keeps the calls out of tail position: the real `c` and `m` never
+    // have their address taken, so they live in (mostly scalar) registers instead of being re-read from the private stack after every call.
+    Ctx pa_c;
+    SolveLds pa_m;
     const int max_iters = c.hdr[H_MAXIT];
     const int R = L.R, Rc = L.Rc, nL = c.nL;
     double* out = P.out + (size_t)w * L.ostride;
@@ -2456,8 +2608,8 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
         // round 0: cost of the initial point
         s.cost = 0.5 * cs_part;
         s.init_cost = s.cost;
-        s.x_norm = sqrt(block_sum(m.red, BA_NW, c.lane, c.wave, state_sqnorm_share(L, c.sc + L.so_x + s.cur * L.nst,
-                                                                                     c.sc + L.so_lam + s.cur * L.Lcap, nL, c.tid, BA_NT)));
+        s.x_norm = sqrt(block_sum(m.red, SV_NW, c.lane, c.wave, state_sqnorm_share(L, c.sc + L.so_x + s.cur * L.nst,
+                                                                                     c.sc + L.so_lam + s.cur * L.Lcap, nL, c.tid, SV_NT)));
         if (!(s.cost == s.cost) || !(s.cost < 1e300)) { s.status = VG_ERR_NUMERIC; s.term = VG_TERM_FAILURE; }
         fresh_point = true;
     }
@@ -2467,21 +2619,21 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
     const double* bb = buf + L.bo_b;
     if (fresh_point && s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK) {
         ctl_uniform(s);
-        assemble<false>(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp);
+        assemble_small(pa_c, pa_m, buf);
         assembled = true;
         if (!s.scaled) {
             // Jacobi scaling from the first Jacobian, fixed for the solve: 1 / (1 + ||J_col||)
-            for (int k = c.tid; k < R; k += BA_NT) c.sc[L.so_sc + k] = 1.0 / (1.0 + sqrt(hess_diag(L, m, k)));
-            for (int k = c.tid; k < nL; k += BA_NT) sl[k] = 1.0 / (1.0 + sqrt(hh[k]));
+            for (int k = c.tid; k < R; k += SV_NT) c.sc[L.so_sc + k] = 1.0 / (1.0 + sqrt(hess_diag(L, m, k)));
+            for (int k = c.tid; k < nL; k += SV_NT) sl[k] = 1.0 / (1.0 + sqrt(hh[k]));
             s.scaled = 1;
             __syncthreads();
         }
         double mx = 0.0;
-        for (int k = c.tid; k < R; k += BA_NT) mx = fmax(mx, fabs(vG[k]));
-        for (int k = c.tid; k < nL; k += BA_NT) mx = fmax(mx, fabs(bb[k]));
-        if (block_max(m.red, BA_NW, c.lane, c.wave, mx) <= 1e-10) s.term = VG_TERM_CONVERGENCE;
+        for (int k = c.tid; k < R; k += SV_NT) mx = fmax(mx, fabs(vG[k]));
+        for (int k = c.tid; k < nL; k += SV_NT) mx = fmax(mx, fabs(bb[k]));
+        if (block_max(m.red, SV_NW, c.lane, c.wave, mx) <= 1e-10) s.term = VG_TERM_CONVERGENCE;
     }
-    for (int k = c.tid; k < R; k += BA_NT) vSC[k] = c.sc[L.so_sc + k];
+    for (int k = c.tid; k < R; k += SV_NT) vSC[k] = c.sc[L.so_sc + k];
     __syncthreads();
     PROF_ADD(PF_ASM);
 
@@ -2501,10 +2653,10 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
         if (!s.reuse) {
             s.reuse = 1;
             ctl_uniform(s);
-            if (!assembled) { assemble<false>(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; }
+            if (!assembled) { assemble_small(pa_c, pa_m, buf); assembled = true; }
             PROF_ADD(PF_ASM);
             // Dg, gt (scaled gradient / Dg), t = gt / Dg
-            for (int k = c.tid; k < R; k += BA_NT) {
+            for (int k = c.tid; k < R; k += SV_NT) {
                 double d2 = vSC[k] * vSC[k] * hess_diag(L, m, k);
                 d2 = d2 < 1e-6 ? 1e-6 : d2;               // std::min(std::max(.)) of dogleg_strategy.cc: NaN propagates
                 d2 = 1e32 < d2 ? 1e32 : d2;
@@ -2513,7 +2665,7 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
                 vGT[k] = vSC[k] * vG[k] / d;
                 vT[k] = vGT[k] / d;
             }
-            for (int k = c.tid; k < nL; k += BA_NT) {
+            for (int k = c.tid; k < nL; k += SV_NT) {
                 double d2 = sl[k] * sl[k] * hh[k];
                 d2 = d2 < 1e-6 ? 1e-6 : d2;
                 d2 = 1e32 < d2 ? 1e32 : d2;
@@ -2524,41 +2676,45 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
             __syncthreads();
             {
                 double sq = 0.0;
-                for (int k = c.tid; k < R; k += BA_NT) sq += vGT[k] * vGT[k];
-                for (int l = c.tid; l < nL; l += BA_NT) sq += gtl[l] * gtl[l];
-                s.gtn2 = block_sum(m.red, BA_NW, c.lane, c.wave, sq);
+                for (int k = c.tid; k < R; k += SV_NT) sq += vGT[k] * vGT[k];
+                for (int l = c.tid; l < nL; l += SV_NT) sq += gtl[l] * gtl[l];
+                s.gtn2 = block_sum(m.red, SV_NW, c.lane, c.wave, sq);
             }
             PROF_ADD(PF_DG);
             // Gauss-Newton step, increasing mu on failure (DoglegStrategy::ComputeGaussNewtonStep)
             bool solved = false;
             while (s.mu < max_mu) {
-                if (!assembled) { assemble<false>(c, m, buf, buf + L.bo_Sp, buf + L.bo_gp); assembled = true; PROF_ADD(PF_ASM); }
+                if (!assembled) { assemble_small(pa_c, pa_m, buf); assembled = true; PROF_ADD(PF_ASM); }
                 ctl_uniform(s);
-                double q = build_scaled<false>(c, m, s.mu);
+                DBG_DUMP(0);
+                double q = build_scaled<false>(pa_c, pa_m, s.mu);
                 assembled = false;
                 __syncthreads();
+                DBG_DUMP(1);
                 PROF_ADD(PF_BUILD);
-                bool cok = chain_eliminate(c, m);
+                q += L.RcPad <= 80 ? chain_schur<4>(pa_c, pa_m, buf, s.mu) : chain_schur<6>(pa_c, pa_m, buf, s.mu);                        // (the coupling rows' share of t^T H~ t)
+                bool cok = *(const int*)(m.red + 24) != 0;                // (uniform: read behind the phase's last barrier)
+                DBG_DUMP(2);
                 PROF_ADD(PF_CHAIN);
-                schur_mfma(c, m, buf, s.mu);
-                s.qcam = block_sum(m.red, BA_NW, c.lane, c.wave, q);      // t^T H~ t without the landmark part
+                s.qcam = block_sum(m.red, SV_NW, c.lane, c.wave, q);      // t^T H~ t without the landmark part
                 s.alpha = -1.0;                  // Cauchy step length |gt|^2 / |J~ (gt/Dg)|^2: completed on demand below
                 PROF_ADD(PF_SCHUR);
-                if (cok) cok = cholesky_aug(c, m, Rc);
+                if (cok) cok = cholesky_aug(pa_c, pa_m, Rc);
+                DBG_DUMP(3);
                 PROF_ADD(PF_CHOL);
                 if (cok) {
-                    back_substitute(c, m, Rc);
+                    back_substitute(pa_c, pa_m, Rc);
                     PROF_ADD(PF_BACK);
-                    chain_back_substitute<false>(c, m);
+                    chain_back_substitute<false>(pa_c, pa_m);
                     PROF_ADD(PF_CBACK);
                     // landmarks: y_l = (bt_l - wt_l . y_cam) / ht_l
                     // four threads per landmark (rows k = q, q + 4, ...; consecutive lanes = consecutive landmarks: coalesced),
                     // eight loads in flight per thread, partial sums combined through LDS in a fixed order
                     const double* Wt = buf + L.bo_Wt;
-                    for (int k = c.tid; k < Rc; k += BA_NT) vU[k] = vSC[k] * vY[k];
+                    for (int k = c.tid; k < Rc; k += SV_NT) vU[k] = vSC[k] * vY[k];
                     __syncthreads();
-                    for (int l0 = 0; l0 < nL; l0 += BA_NT / 4) {
-                        const int l = l0 + (c.tid & (BA_NT / 4 - 1)), qd = c.tid / (BA_NT / 4);
+                    for (int l0 = 0; l0 < nL; l0 += SV_NT / 4) {
+                        const int l = l0 + (c.tid & (SV_NT / 4 - 1)), qd = c.tid / (SV_NT / 4);
                         double acc = 0.0;
                         if (l < nL) {
                             const double* wp = Wt + l;
@@ -2575,16 +2731,16 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
                         m.wd[c.tid] = acc;
                         __syncthreads();
                         if (qd == 0 && l < nL) {
-                            const double a4 = (m.wd[c.tid] + m.wd[c.tid + BA_NT / 4]) + (m.wd[c.tid + BA_NT / 2] + m.wd[c.tid + 3 * BA_NT / 4]);
+                            const double a4 = (m.wd[c.tid] + m.wd[c.tid + SV_NT / 4]) + (m.wd[c.tid + SV_NT / 2] + m.wd[c.tid + 3 * SV_NT / 4]);
                             const double ht = sl[l] * sl[l] * hh[l] + s.mu * dgl[l] * dgl[l];
                             yl[l] = (sl[l] * bb[l] - sl[l] * a4) / ht;
                         }
                         __syncthreads();
                     }
                     double fin = 0.0;
-                    for (int k = c.tid; k < R; k += BA_NT) fin += (vY[k] == vY[k] && fabs(vY[k]) < 1e300) ? 0.0 : 1.0;
-                    for (int k = c.tid; k < nL; k += BA_NT) fin += (yl[k] == yl[k] && fabs(yl[k]) < 1e300) ? 0.0 : 1.0;
-                    const bool finite = block_sum(m.red, BA_NW, c.lane, c.wave, fin) == 0.0;
+                    for (int k = c.tid; k < R; k += SV_NT) fin += (vY[k] == vY[k] && fabs(vY[k]) < 1e300) ? 0.0 : 1.0;
+                    for (int k = c.tid; k < nL; k += SV_NT) fin += (yl[k] == yl[k] && fabs(yl[k]) < 1e300) ? 0.0 : 1.0;
+                    const bool finite = block_sum(m.red, SV_NW, c.lane, c.wave, fin) == 0.0;
                     PROF_ADD(PF_LMY);
                     if (finite) { solved = true; s.mu_solved = s.mu; break; }
                 }
@@ -2593,25 +2749,25 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
             if (!solved) ok = false;
             else {
                 double s1 = 0.0, s2 = 0.0;
-                for (int k = c.tid; k < R; k += BA_NT) {
+                for (int k = c.tid; k < R; k += SV_NT) {
                     vGN[k] = -vY[k] * vDG[k];
                     s1 += vGN[k] * vGN[k];
                     s2 += vGN[k] * vGT[k];
                 }
-                for (int k = c.tid; k < nL; k += BA_NT) {
+                for (int k = c.tid; k < nL; k += SV_NT) {
                     gnl[k] = -yl[k] * dgl[k];
                     s1 += gnl[k] * gnl[k];
                     s2 += gnl[k] * gtl[k];
                 }
-                block_sum2(m.red, BA_NW, c.lane, c.wave, s1, s2);
+                block_sum2(m.red, SV_NW, c.lane, c.wave, s1, s2);
                 s.gnn2 = s1; s.gtgn = s2;
                 // keep Dg, gt, gn of this point for step reuse after a rejection (DoglegStrategy keeps them as members)
-                for (int k = c.tid; k < R; k += BA_NT) {
+                for (int k = c.tid; k < R; k += SV_NT) {
                     c.sc[L.so_dg + k] = vDG[k]; c.sc[L.so_gt + k] = vGT[k]; c.sc[L.so_gn + k] = vGN[k];
                 }
             }
         } else {
-            for (int k = c.tid; k < R; k += BA_NT) {
+            for (int k = c.tid; k < R; k += SV_NT) {
                 vDG[k] = c.sc[L.so_dg + k]; vGT[k] = c.sc[L.so_gt + k]; vGN[k] = c.sc[L.so_gn + k];
             }
             __syncthreads();
@@ -2623,7 +2779,7 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
             // DoglegStrategy::ComputeTraditionalDoglegStep
             const double gtn = sqrt(s.gtn2), gnn = sqrt(s.gnn2);
             if (!(gnn <= s.radius) && s.alpha < 0.0) {
-                const double ql = block_sum(m.red, BA_NW, c.lane, c.wave, cauchy_landmark_term(c, m, buf));
+                const double ql = block_sum(m.red, SV_NW, c.lane, c.wave, cauchy_landmark_term(pa_c, pa_m, buf));
                 s.alpha = s.gtn2 / (s.qcam + ql);
             }
             if (gnn <= s.radius) { c_gt = 0.0; c_gn = 1.0; s.dnorm = gnn; }
@@ -2640,7 +2796,7 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
             }
             __syncthreads();
             // delta = scale .* (s ./ Dg)
-            for (int k = c.tid; k < R; k += BA_NT) vU[k] = vSC[k] * ((c_gt * vGT[k] + c_gn * vGN[k]) / vDG[k]);
+            for (int k = c.tid; k < R; k += SV_NT) vU[k] = vSC[k] * ((c_gt * vGT[k] + c_gn * vGN[k]) / vDG[k]);
             __syncthreads();
             // model cost change  -(J~ s)^T (r + J~ s / 2)  with s = c_gt a + c_gn b  (a = gt/Dg, b = gn/Dg = -y):
             //   a.g~ = |gt|^2, b.g~ = gt.gn, a^T H~ a = |gt|^2 / alpha, and from (H~ + mu Dg^2) y = g~ :
@@ -2683,7 +2839,7 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
             double sd = 0.0, sn = 0.0;
             // poses: threads 0 .. Kp-1; the extrinsic pose + td: thread 64 (another wavefront)
             const bool isex = c.tid == 64;
-            for (int i = isex ? L.Kp : c.tid; i < L.Kp + (isex ? 1 : 0); i += BA_NT) {
+            for (int i = isex ? L.Kp : c.tid; i < L.Kp + (isex ? 1 : 0); i += SV_NT) {
                 const int xo = isex ? 7 * L.Kp + 9 * L.K : 7 * i;
                 double xi[8], o[7], dl[6];
 #pragma unroll
@@ -2708,21 +2864,21 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
                 }
             }
             // speed-bias entries: from the last thread downwards (the first wavefront has the poses)
-            for (int k = BA_NT - 1 - c.tid; k < 9 * L.K; k += BA_NT) {
+            for (int k = SV_NT - 1 - c.tid; k < 9 * L.K; k += SV_NT) {
                 const double xv = xg[7 * L.Kp + k];
                 const double o = xv + vU[col_sb(L, k / 9) + k % 9];
                 xcg[7 * L.Kp + k] = o;
                 const double d = xv - o;
                 sd += d * d; sn += o * o;
             }
-            for (int k = c.tid; k < nL; k += BA_NT) {
+            for (int k = c.tid; k < nL; k += SV_NT) {
                 const double lv = lamg[k];
                 const double o = lv + slg[k] * ((c_gt * gtlg[k] + c_gn * gnlg[k]) / dglg[k]);
                 lamcg[k] = o;
                 const double d = lv - o;
                 sd += d * d; sn += o * o;
             }
-            block_sum2(m.red, BA_NW, c.lane, c.wave, sd, sn);
+            block_sum2(m.red, SV_NW, c.lane, c.wave, sd, sn);
             s.step_norm = sqrt(sd);
             s.x_norm_c = sqrt(sn);
         }
@@ -2739,22 +2895,7 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
     if (c.tid == 0) ctl_store(s, ctlp);
     PROF_ADD(PF_TAIL);
 }
-extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_solve_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { solve_body(Lp, P); }
-
-// One launch per trust-region round (batches that take the fused factor kernel): the factors of the round are linearised and
-// accumulated, then -- same workgroup, same window -- the pending candidate is judged and the next step formed.  The two bodies are
-// the kernels above, unchanged; they hand over through the linearisation buffer in HBM as before (written and read by the same
-// CU: a device-scope fence + barrier in between), so results are bit-identical to the two launches; what goes away is a launch
-// boundary per round and the cold start of the solve kernel (kernarg, instruction fetch, first HBM round trip).
-// (a real call: inlined next to the solve body the two phases' live ranges are allocated together -- 53 spilled VGPRs and 408 B of
-//  private segment against 8 / 168 for the solve kernel alone; nothing is live in the caller at this point, so the call is free)
-NOINL void linacc_call(const BaLayout* Lp, BaPtrs P) { linacc_body(Lp, P); }
-extern "C" __global__ __launch_bounds__(BA_NT, 2) void ba_round_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
-    linacc_call(Lp, P);
-    __threadfence();
-    __syncthreads();
-    solve_body(Lp, P);
-}
+extern "C" __global__ __launch_bounds__(SV_NT, 2) void ba_solve_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { solve_body(Lp, P); }
 
 // ================================================================================================
 // Large-window path (BaLayout::big): windows whose camera part does not fit the LDS carve of ba_solve_kernel (BASELINE
@@ -3266,7 +3407,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     const bool need_system = running && (fresh_point || (trip && !s.reuse));
     if (need_system) {
         const int ntri = Rc * (Rc + 1) / 2;
-        assemble<true>(c, m, buf, rb1, rb1 + ntri);
+        assemble_big(c, m, buf, rb1, rb1 + ntri);
         if (!s.scaled) {
             for (int k = c.tid; k < R; k += BA_NT) c.sc[L.so_sc + k] = 1.0 / (1.0 + sqrt(hess_diag(L, m, k)));
             s.scaled = 1;
@@ -3684,7 +3825,6 @@ static hipError_t set_lds_attrs() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linacc_proj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
     // (these two also hold a few statically allocated LDS words: static + dynamic must stay within 160 KB)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linearize_imu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_eval_factors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -3712,12 +3852,8 @@ extern "C" const char* ba_failed_launch() { return g_failed_launch; }
 // after every launch (ev[0] before the first), kinds[i] = kernel class of the launch that ends at ev[i + 1] (0 prologue,
 // 1 linearize, 2 accumulate, 3 solve, 4 final); the caller provides 4 * rounds + 5 events.
 struct BaFork { hipStream_t aux; hipEvent_t fork, join; };
-// ba_round_kernel (both bodies in ONE launch per round) is kept as an experiment behind VG_BA_ROUND_MERGED=1: measured SLOWER than
-// the two launches (same box, same call, profiles/r04h_bench_{merged,two}.json: 280 us per round against 103 + 149 us, 91.0K against
-// 111.9K solves/s) -- the merged kernel carries the factor phase's frame next to the solve phases' (440 B of private segment) and a
-// device-scope fence, and what it saves (one launch boundary) is a few microseconds.
-static const bool g_round_merged = getenv("VG_BA_ROUND_MERGED") && !strcmp(getenv("VG_BA_ROUND_MERGED"), "1");
-extern "C" int ba_round_is_merged() { return g_round_merged ? 1 : 0; }
+// (A merged kernel -- factor phases and solve phases of a round in ONE launch -- was measured in round 4 and lost: 280 us per round
+//  against 103 + 149 us, profiles/r04h_bench_{merged,two}.json; it is gone since the solve kernel runs 4 wavefronts per window.)
 extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, const BaPtrs& P, int rounds, hipStream_t stream,
                                       hipEvent_t* ev, int* kinds, int* n_launches, const BaFork* fk) {
     hipError_t e = set_lds_attrs();
@@ -3742,12 +3878,6 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
         } else {
             LAUNCH(ba_linearize_imu_kernel, dim3(L.nig + L.nprw, L.nwin), dim3(BA_NT), L.lds_lin, dL, P, cost_only);
         }
-        const bool merged = fused && g_round_merged;      // ... and the solve phases in the same launch
-        if (merged) {
-            LAUNCH(ba_round_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_linacc > L.lds_solve ? L.lds_linacc : L.lds_solve, dL, P);
-            if (kinds) kinds[nk++] = 3;
-            continue;
-        }
         if (fused) LAUNCH(ba_linacc_proj_kernel, dim3(L.nwin), dim3(LA_NT), L.lds_linacc, dL, P);
         else LAUNCH(ba_linearize_proj_kernel, dim3(L.nbf, L.nwin), dim3(BA_LIN_NT), 0, dL, P, cost_only);
         if (kinds) { if (!forked && !fused) kinds[nk++] = 1; kinds[nk++] = fused ? 2 : 1; }
@@ -3757,7 +3887,7 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
         }
         if (!fused) LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P);
         if (forked && (e = hipStreamWaitEvent(stream, fk->join, 0)) != hipSuccess) return e;
-        LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P);
+        LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(SV_NT), L.lds_solve, dL, P);
         if (kinds) { if (!fused) kinds[nk++] = 2; kinds[nk++] = 3; }
     }
     LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P);

@@ -49,7 +49,8 @@ struct BaSeq {
 
 struct BaBatch {
     BaLayout L;
-    BaLayout* dL = nullptr;          // device copy of L (kernels read it through scalar loads)
+    BaLayout* dL = nullptr;          // device copy of L (kernels read it through scalar loads) + the gather plan behind it
+    size_t dL_bytes = 0;
     BaLayout dL_host;                // what dL holds (re-sent only when the layout changes)
     bool dL_valid = false;
     BaPtrs P = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -52,6 +52,15 @@ __device__ __forceinline__ uint4 vg_load16_unaligned(const glb_u8* p) {
     v.x = t4.x; v.y = t4.y; v.z = t4.z; v.w = t4.w;
     return v;
 }
+// ---- four ints from a 16-byte aligned table entry in HBM: one global_load_dwordx4
+__device__ __forceinline__ int4 vg_load_int4(const void* p) {
+    typedef int nv4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const nv4 glb_nv4;
+    const nv4 t4 = *(glb_nv4*)p;
+    int4 v;
+    v.x = t4.x; v.y = t4.y; v.z = t4.z; v.w = t4.w;
+    return v;
+}
 // ---- bytes q and q + 1 of the eight bytes (hi:lo) as two 16-bit lanes (byte q | byte q + 1 << 16): one v_perm_b32
 template <int Q> __device__ __forceinline__ unsigned vg_byte_pair(unsigned hi, unsigned lo) {
     return __builtin_amdgcn_perm(hi, lo, (unsigned)Q | (0x0Cu << 8) | ((unsigned)(Q + 1) << 16) | (0x0Cu << 24));
@@ -95,6 +104,7 @@ inline int uni(int v) { return v; }
 inline double uni(double v) { return v; }
 template <typename T> inline T const_load(const T* p) { return *p; }
 inline uint4 vg_load16_unaligned(const glb_u8* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+inline int4 vg_load_int4(const void* p) { int4 v; __builtin_memcpy(&v, p, 16); return v; }
 template <int Q> inline unsigned vg_byte_pair(unsigned hi, unsigned lo) {
     const unsigned long long v = ((unsigned long long)hi << 32) | lo;
     return (unsigned)((v >> (8 * Q)) & 255u) | ((unsigned)((v >> (8 * (Q + 1))) & 255u) << 16);
