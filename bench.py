@@ -321,8 +321,9 @@ def bench_sharded(args, ba, synth, D, rank, world):
             h.ba_rccl_init(world, rank, ids[0])
             hook_kind = "RCCL in the library (vg_ba_rccl_init)"
         else:
-            h.ba_set_allreduce(shard.torch_allreduce_hook(device_buffers=True))     # (gloo self-test on a shared GPU: staged through the host)
-            hook_kind = "torch.distributed gloo, staged through the host (self-test)" 
+            # (gloo self-test: two ranks on a shared GPU stage through the host; under --emulated the "device" buffers ARE host memory)
+            h.ba_set_allreduce(shard.torch_allreduce_hook(device_buffers=not args.emulated))
+            hook_kind = "torch.distributed gloo, staged through the host (self-test)"
     packed = ba.PackedProblem(sub)
     h.ba_upload([packed], [ba.VG_MARGIN_NONE])
     info = h.ba_info()
