@@ -271,7 +271,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         if (L.big) { L.l_di = o; o += up(L.Rc + 1, 2); L.l_cz = o; o += 6 * 96; }
         L.lds_solve = o * 8;
         bigm_doubles = ob;
-        if (!L.big && 2 * (L.Rc + 10) > SV_NT - 64) { h->err = "solve kernel: more column tasks than three wavefronts"; return VG_ERR_UNSUPPORTED; }
+        if (!L.big && L.Rc + 10 - 64 > 32) { h->err = "solve kernel: more column tasks than three wavefronts"; return VG_ERR_UNSUPPORTED; }
         if (!L.big && 36 * ldc < std::max(std::max(L.RcPad * 33, SV_NT), std::max(9 * L.K, 162))) { h->err = "solve kernel: scratch does not fit the coupling-row ring"; return VG_ERR_UNSUPPORTED; }
         if (L.lds_solve > 160 * 1024) { h->err = "solve kernel LDS carve exceeds 160 KB"; return VG_ERR_UNSUPPORTED; }
         const int nib = std::min(std::min(L.K - 1, BA_IMU_BATCH), L.igs);

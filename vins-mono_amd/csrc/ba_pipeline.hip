@@ -1780,6 +1780,41 @@ DEV bool chain_factor(int lane, P Dk, P dinvk, int kind, PC Xc, PC Xu) {
     }
     return !__any(!good);
 }
+// x -= (coupling block)^T x_n for one column: coef[p * SP + r * SR] = coupling entry (row r of this block, row p of the neighbour's X).
+// Three rows at a time, the scheduler fenced in between (81 hoisted LDS reads would not fit the register file).  _c: strides known at
+// compile time (a wavefront whose lanes all belong to one sweep: immediate offsets, broadcast reads); _v: per lane.
+template <int SP, int SR>
+DEV void chain_upd_c(double* x, const lds_d* coef, const double* xn) {
+#pragma unroll
+    for (int r3 = 0; r3 < 9; r3 += 3) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        const lds_d* cf = coef + r3 * SR;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            s0 += cf[p * SP] * xn[p];
+            s1 += cf[p * SP + SR] * xn[p];
+            s2 += cf[p * SP + 2 * SR] * xn[p];
+        }
+        x[r3] -= s0; x[r3 + 1] -= s1; x[r3 + 2] -= s2;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+DEV void chain_upd_v(double* x, const lds_d* coef, int sp, int sr, const double* xn) {
+#pragma unroll
+    for (int r3 = 0; r3 < 9; r3 += 3) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        const lds_d* cf = coef + r3 * sr;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            s0 += cf[p * sp] * xn[p];
+            s1 += cf[p * sp + sr] * xn[p];
+            s2 += cf[p * sp + 2 * sr] * xn[p];
+        }
+        x[r3] -= s0; x[r3 + 1] -= s1; x[r3 + 2] -= s2;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---- the same factorisation in three parts, so that one wavefront can walk TWO blocks in lock step (their pivot chains are
 //      independent: the second block hides in the latencies of the first)
 struct ChainFac { double4_t dg, ld, di; };
@@ -1913,29 +1948,39 @@ NOINL double chain_schur(const Ctx& c_in, const SolveLds& m_in, const double* bu
         tri_decode(wave + s * SV_NW, a, bq);
         tm[s] = a; tn[s] = bq;
     }
-    const int nth = Rc + 10;                                 // tasks of a sweep: Rc + 1 columns of [C_k | g_k], 9 of the coupling block
-    const int half = c.tid >= nth ? 1 : 0, id = c.tid - half * nth;
-    const bool tasked = c.tid < 2 * nth;                     // (2 nth <= 192: wavefronts 0-2; the host checks)
+    // tasks of a sweep: Rc + 1 columns of [C_k | g_k], 9 of the coupling block.  Wavefront 0 takes the first 64 tasks of the top
+    // sweep, wavefront 1 those of the bottom sweep -- so that inside them the sweep (coupling-block strides, block index) is
+    // wave-uniform -- and wavefront 2 what is left of both (the host checks that it fits); wavefront 3 factors the diagonal blocks.
+    const int nth = Rc + 10, nfull = nth < 64 ? nth : 64, nrem = nth - nfull;
+    const int half = wave < 2 ? wave : (c.lane >= nrem ? 1 : 0);
+    const int id = wave < 2 ? c.lane : 64 + c.lane - half * nrem;
+    const bool tasked = wave < 2 ? c.lane < nfull : (wave == 2 && c.lane < 2 * nrem);
     const bool col_task = tasked && id <= Rc;
     const bool cpl_task = tasked && id > Rc;
-    const bool fac_wave = wave == SV_NW - 1;                 // wavefront 3 factors the diagonal blocks
+    const bool fac_wave = wave == SV_NW - 1;
     // ---- staging of the IMU part of a block's raw coupling rows: entry (r, c18), c18 = 6 (d + 1) + o for the pose column o of frame
     //      k + d, d = -1, 0, 1.  IMU factor f, local columns: 0-5 pose_f, 6-14 sb_f, 15-20 pose_f+1, 21-29 sb_f+1, packed lower
     //      triangle in imuJ[f][.]: factor k gives (sb_k, pose_k) and (pose_k+1, sb_k), factor k-1 gives (sb_k, pose_k-1) and (sb_k, pose_k)
     double sv[2][2];
+    int si_a[2], si_b[2];                                    // this thread's two staged entries: local indices in factor k / factor k-1
+    bool si_on[2], si_fa[2], si_fb[2], si_h[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const int e2 = c.tid + SV_NT * qq;
+        const int hh = e2 >= 162 ? 1 : 0, e = e2 - 162 * hh;
+        const int r = e / 18, c18 = e - 18 * r, d = c18 / 6 - 1, o = c18 - 6 * (d + 1);
+        si_on[qq] = e2 < 324; si_h[qq] = hh != 0; si_fa[qq] = d >= 0; si_fb[qq] = d <= 0;
+        si_a[qq] = d == 0 ? (6 + r) * (7 + r) / 2 + o : (15 + o) * (16 + o) / 2 + 6 + r;
+        si_b[qq] = (21 + r) * (22 + r) / 2 + (d == 0 ? 15 + o : o);
+    }
     auto stage_issue = [&](int kt_n, int kb_n) {
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
-            const int e2 = c.tid + SV_NT * qq;
-            const int hh = e2 >= 162 ? 1 : 0, e = e2 - 162 * hh;
-            const int k = hh ? kb_n : kt_n;
-            const bool on = e2 < 324 && k >= 0;
-            const int r = e / 18, c18 = e - 18 * r, d = c18 / 6 - 1, o = c18 - 6 * (d + 1);
-            const bool fa_on = on && d >= 0 && k <= K - 2 && ((vm >> (k >= 0 ? k : 0)) & 1u);
-            const bool fb_on = on && d <= 0 && k >= 1 && ((vm >> (k >= 1 ? k - 1 : 0)) & 1u);
-            const int ia = d == 0 ? (6 + r) * (7 + r) / 2 + o : (15 + o) * (16 + o) / 2 + 6 + r;
-            const int ib = (21 + r) * (22 + r) / 2 + (d == 0 ? 15 + o : o);
-            const double va = imuJ[fa_on ? k * 512 + ia : 0], vb = imuJ[fb_on ? (k - 1) * 512 + ib : 0];
+            const int k = si_h[qq] ? kb_n : kt_n;
+            const bool on = si_on[qq] && k >= 0;
+            const bool fa_on = on && si_fa[qq] && k <= K - 2 && ((vm >> (k >= 0 ? k : 0)) & 1u);
+            const bool fb_on = on && si_fb[qq] && k >= 1 && ((vm >> (k >= 1 ? k - 1 : 0)) & 1u);
+            const double va = imuJ[fa_on ? k * 512 + si_a[qq] : 0], vb = imuJ[fb_on ? (k - 1) * 512 + si_b[qq] : 0];
             // even factor first, then the odd one: the order in which the former scatter rounds added them
             const double a = fa_on ? va : 0.0, b = fb_on ? vb : 0.0;
             sv[qq][0] = (k & 1) ? b : a;
@@ -2049,30 +2094,16 @@ NOINL double chain_schur(const Ctx& c_in, const SolveLds& m_in, const double* bu
             }
             DP_ADD(19);
             // x -= (coupling block)^T x_prev;  coef[p * sp + r * sr] = coupling entry (row r of this block, row p of the neighbour's X)
-            // (three rows at a time, the scheduler fenced in between: 81 hoisted LDS reads would not fit the register file)
-            auto upd = [&](const lds_d* coef, int sp, int sr, const double* xn) {
-#pragma unroll
-                for (int r3 = 0; r3 < 9; r3 += 3) {
-                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-                    const lds_d* cf = coef + r3 * sr;
-#pragma unroll
-                    for (int p = 0; p < 9; ++p) {
-                        s0 += cf[p * sp] * xn[p];
-                        s1 += cf[p * sp + sr] * xn[p];
-                        s2 += cf[p * sp + 2 * sr] * xn[p];
-                    }
-                    x[r3] -= s0; x[r3 + 1] -= s1; x[r3 + 2] -= s2;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            // (one call for both sweeps, operands selected per lane: wavefront 1 holds columns of both)
-            if (half == 0 ? upd_t_from_above : upd_b) upd(half == 0 ? E + 81 * (kt + 1) : E + 81 * kb, half == 0 ? 9 : 1, half == 0 ? 1 : 9, xprev);
+            if (wave == 0) { if (upd_t_from_above) chain_upd_c<9, 1>(x, E + 81 * (kt + 1), xprev); }
+            else if (wave == 1) { if (upd_b) chain_upd_c<1, 9>(x, E + 81 * kb, xprev); }
+            else if (half == 0 ? upd_t_from_above : upd_b)           // (wavefront 2 holds columns of both sweeps: operands per lane)
+                chain_upd_v(x, half == 0 ? E + 81 * (kt + 1) : E + 81 * kb, half == 0 ? 9 : 1, half == 0 ? 1 : 9, xprev);
             DP_ADD(20);
             if (half == 0 && upd_mid_from_below) {
                 double xb[9];
 #pragma unroll
                 for (int p = 0; p < 9; ++p) xb[p] = ring[(9 + p) * ldc + id];      // X of block mid - 1: the bottom sweep's last rows
-                upd(E + 81 * kt, 1, 9, xb);
+                chain_upd_c<1, 9>(x, E + 81 * kt, xb);
             }
         } else if (act && cpl_task && !(half == 0 && last)) {
             const int cc = id - Rc - 1;
