@@ -132,7 +132,8 @@ def bench_resident(ba, synth, seqs, nthr=4, rounds=3):
 FE_CAMS = 256                # independent camera streams per GPU in the front-end leg (like the 256 windows of the BA leg; with 64 the LK launch is
                              # dominated by its slowest tracks: 137 us for 9600 tracks against 9.7 ns per additional track, tests/manual/gpu_lk_scaling.py)
 FE_BYTES_PER_FEATURE = 8188  # (pyramid 592,200 B + LK 636,000 B) per 752x480 frame / 150 features
-FE_GFTT_BYTES_PER_FRAME = 3609600
+FE_GFTT_BYTES_PER_FRAME = 752 * 480 * (70 * 22) // (64 * 16) + 752 * 480 + 8 * 4096   # what the detection really moves: the frame once with the tile halo (70 x 22 per 64 x 16 tile), the mask, ~4K candidate keys (the map stays in LDS; SURVEY 8(d)'s 3.6 MB counted it written and read back)
+FE_DISTINCT = 256            # distinct image pairs of the front-end leg (one per stream, seed 1 + b)
 
 
 def bench_fe(h, synth, steps, warmup, rank, with_cpu):
@@ -142,10 +143,16 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
     from vins_mono_amd import fe
     W, H, N = 752, 480, 150
     tr = fe.FrontEnd(h, W, H, FE_CAMS, N)
-    base = [synth.synth_frame(1000 + rank * FE_CAMS + c) for c in range(min(FE_CAMS, 8))]
-    nxt = [synth.warp_frame(b, 2000 + c) for c, b in enumerate(base)]
-    fa = [base[c % len(base)] for c in range(FE_CAMS)]
-    fb = [nxt[c % len(nxt)] for c in range(FE_CAMS)]
+    # every stream its own image pair, seed 1 + b for batch item b (ranks take disjoint items) -- the cost of LK
+    # depends on the content (iterations per level), so 256 replicas of 8 pairs are not the stated workload.  (FE_DISTINCT < FE_CAMS
+    # only for profiler passes, --quick-fe: the generator takes ~0.1 s per pair.)
+    ndist = min(FE_CAMS, FE_DISTINCT)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        base = list(ex.map(lambda c: synth.synth_frame(1 + rank * FE_CAMS + c), range(ndist)))
+        nxt = list(ex.map(lambda c: synth.warp_frame(base[c], 100001 + rank * FE_CAMS + c), range(ndist)))
+    fa = [base[c % ndist] for c in range(FE_CAMS)]
+    fb = [nxt[c % ndist] for c in range(FE_CAMS)]
     tr.push_frames(fa)                      # frame A (and its pyramid)
     tr.detect_upload([N] * FE_CAMS)
     tr.detect_async()
@@ -243,16 +250,24 @@ def bench_fe(h, synth, steps, warmup, rank, with_cpu):
         "roofline": {"kernel": "fe_lk_kernel (+ fe_pyrdown_kernel x3)", "bound": "hbm",
                      "achieved": nfeat * FE_BYTES_PER_FEATURE * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "traffic": fe_traffic(), "event_ms_per_step": ev_ms / steps,
-                     "gftt_GBs": FE_CAMS * FE_GFTT_BYTES_PER_FRAME / (gftt_ms * 1e-3) / 1e9,
-                     "gftt_note": "SURVEY 8(d) counts the min-eigenvalue map written and read once (2.9 of the 3.6 MB per frame); since round 4 "
-                                  "the map stays in LDS, so the bytes the detection really moves are ~0.8 MB per frame + the candidate keys"},
+                     # LK is VALU-bound, not HBM-bound: the HBM fraction alone says nothing about headroom, the issue fraction does
+                     "valu_issue_frac": pmc_field("fe_lk_kernel", "valu_issue_frac"),
+                     "waves_parked_frac": pmc_field("fe_lk_kernel", "waves_parked_frac"),
+                     "distinct_image_pairs": ndist,
+                     "gftt": {"kernel": "fe_mineig_kernel (+ fe_select_kernel)", "bytes_per_frame": FE_GFTT_BYTES_PER_FRAME,
+                              "achieved_GBs": FE_CAMS * FE_GFTT_BYTES_PER_FRAME / (gftt_ms * 1e-3) / 1e9,
+                              "frac": FE_CAMS * FE_GFTT_BYTES_PER_FRAME / (gftt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "valu_issue_frac": pmc_field("fe_mineig_kernel", "valu_issue_frac"),
+                              "note": "bytes the detection really moves: the frame read once with its tile halo, the mask, the candidate "
+                                      "keys (the min-eigenvalue map stays in LDS since round 4); VALU-bound, see valu_issue_frac"}},
     }
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
     if with_cpu:
         from oracle import fe_cpu
-        # parity of the TIMED configuration: the last timed step of 8 of the 256 streams (the 8 distinct image pairs) against the oracle
-        npar, nbad, ncmp = min(8, FE_CAMS), 0, 0
-        for c in range(npar):
+        # parity of the TIMED configuration: the last timed step of 32 of the 256 streams (every eighth: distinct image pairs) against the oracle
+        par_streams = list(range(0, FE_CAMS, max(1, FE_CAMS // 32)))[:32]
+        npar, nbad, ncmp = len(par_streams), 0, 0
+        for c in par_streams:
             pa, pb = (fa[c], fb[c]) if last_is_a_to_b else (fb[c], fa[c])
             r_nxt, r_st, r_err = fe_cpu.lk(pa, pb, corners[c])
             g_nxt, g_st, g_err = res[c]
@@ -497,6 +512,15 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_field(kernel, field):
+    """A derived SQ fraction of `kernel` from the committed PMC summary (profiles/summarize_counters.py --merge-into), or None."""
+    pmc_traffic(kernel)                      # (loads the summary, drops it if it belongs to other device code)
+    try:
+        return _PMC["kernels"][kernel][field]
+    except KeyError:
+        return None
+
+
 def fe_traffic():
     """HBM bytes per FE step (one fe_lk launch + 3 fe_pyrdown; the frame is level 0 of its pyramid, there is no copy) from the
     committed PMC summary (per-launch figures of the PMC pass scale with the number of streams of THAT pass)."""
@@ -545,6 +569,7 @@ def main():
                     "2-rank self-test on a 1-GPU box together with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="self-test: all ranks use cuda:0")
     ap.add_argument("--rccl-hook", action="store_true", help="--config sharded with one rank: still route the reductions through RCCL")
+    ap.add_argument("--quick-fe", action="store_true", help="profiler passes: 8 distinct image pairs instead of one per stream (generator time)")
     ap.add_argument("--emulated", action="store_true",
                     help="contract self-test WITHOUT a GPU (tests/test_bench_contract.py): the kernel sources under the CPU fiber emulator of "
                          "tests/simt, tiny loop counts; every number it prints is meaningless except that the line has the right shape")
@@ -573,7 +598,9 @@ def main():
     pkg = graft.load_package()
     from vins_mono_amd import ba, synth, dist_util as D
     rank, local_rank, world = D.env_rank()
-    global QUICK, FE_CAMS
+    global QUICK, FE_CAMS, FE_DISTINCT
+    if args.quick_fe:
+        FE_DISTINCT = 8
     if args.emulated:
         # TEST INFRASTRUCTURE, never a measurement: the emulated library of tests/simt stands in for libvinsgpu.so so that the code of
         # this file (legs, JSON assembly) can be exercised where there is no GPU

@@ -309,6 +309,16 @@ class Estimator:
         n = self.L.vref_est_get_features(C.c_void_p(self.h), cap, ids.ctypes.data_as(IP), st.ctypes.data_as(IP), nb.ctypes.data_as(IP), _p(dep), fl.ctypes.data_as(IP))
         return dict(id=ids[:n], start=st[:n], nobs=nb[:n], depth=dep[:n], solve_flag=fl[:n])
 
+    def gpu_set_option(self, option, value):
+        """Drop-in build only: vins_gpu_set_option (1 = forward SOLVER_TIME as max_solver_time_in_seconds, 2 = eigen form of the prior)."""
+        self.L.vref_est_gpu_set_option.restype = C.c_int
+        rc = self.L.vref_est_gpu_set_option(C.c_void_p(self.h), C.c_int(option), C.c_int(value))
+        if rc:
+            raise RuntimeError(f"vins_gpu_set_option({option}, {value}) -> {rc}")
+
+    def set_solver_time(self, t):
+        self.L.vref_set_solver_time(C.c_double(t))
+
     def last_trace(self):
         """Per-iteration rows [valid, accepted, cost, candidate cost, radius, step norm] of this estimator's last optimization()."""
         rows = np.zeros((40, 6))
@@ -537,7 +547,7 @@ def factor_tables(prob):
     return pr, pJ, ir, iJ
 
 
-def run_sequence(seq, n_frames, L=None, min_parallax=10.0 / 460.0, noise_seed=0, reset_at=None, collect_priors=True):
+def run_sequence(seq, n_frames, L=None, min_parallax=10.0 / 460.0, noise_seed=0, reset_at=None, collect_priors=True, gpu_options=None):
     """The reference's own per-frame loop on a synthetic sequence: Estimator::processIMU for every IMU sample and
     Estimator::processImage for every frame (estimator.cpp:81-215) — feature bookkeeping, key-frame decision by parallax,
     triangulation, optimization(), failure detection, slideWindow() for BOTH marginalization flags with the IMU buffers merged
@@ -547,7 +557,7 @@ def run_sequence(seq, n_frames, L=None, min_parallax=10.0 / 460.0, noise_seed=0,
     L: lib() (all reference) or lib_gpu() (optimization() = the product's drop-in).  Returns a list of per-frame records.
     reset_at: a frame index before which the estimator is reset (clearState + setParameter) and bootstrapped again.
     collect_priors=False leaves the drop-in's marginalization result on the device between frames (its normal operation;
-    get_prior() fetches it early)."""
+    get_prior() fetches it early).  gpu_options: {option: value} for vins_gpu_set_option (drop-in builds)."""
     L = L or lib()
     K = K_REF
     c = seq.cfg
@@ -555,6 +565,8 @@ def run_sequence(seq, n_frames, L=None, min_parallax=10.0 / 460.0, noise_seed=0,
     configure_for(base, c, L=L, min_parallax=min_parallax)
     rng = np.random.default_rng(noise_seed)
     e = Estimator(L=L)
+    for opt, val in (gpu_options or {}).items():
+        e.gpu_set_option(opt, val)
     H = C.c_void_p(e.h)
     h = seq.frame_dt / seq.imu_per_frame
 

@@ -46,6 +46,7 @@ extern Solver::Summary vins_ref_last_summary;   // ref_stubs/ceres/solver_stub.c
 extern "C" void vins_gpu_collect_prior(Estimator *) __attribute__((weak));
 extern "C" void vins_gpu_release(Estimator *) __attribute__((weak));
 extern "C" int vins_gpu_last_iterations(Estimator *) __attribute__((weak));
+extern "C" int vins_gpu_set_option(Estimator *, int, int) __attribute__((weak));
 extern "C" const vg_ba_summary *vins_gpu_last_summary(Estimator *) __attribute__((weak));
 
 namespace {
@@ -517,6 +518,11 @@ void vref_est_optimization(void *p) { as_est(p)->optimization(); }
 void vref_est_solve_odometry(void *p) { as_est(p)->solveOdometry(); }
 void vref_est_slide_window(void *p) { as_est(p)->slideWindow(); }
 int vref_est_failure_detection(void *p) { return as_est(p)->failureDetection() ? 1 : 0; }
+
+// run-time switches of the drop-in (vins_gpu_set_option: 1 = forward SOLVER_TIME, 2 = eigen form of the prior); -2 in the reference build
+int vref_est_gpu_set_option(void *p, int option, int value) { return vins_gpu_set_option ? vins_gpu_set_option(as_est(p), option, value) : -2; }
+// the SOLVER_TIME global of parameters.cpp (max_solver_time of the YAML file)
+void vref_set_solver_time(double t) { SOLVER_TIME = t; }
 
 // trust-region iterations of the last optimization() (Ceres counts the initial evaluation as iteration 0)
 int vref_est_last_iterations(void *p) {

@@ -3,7 +3,7 @@ cost?  (VERDICT r3 item 9: quantify the allowance of tests/test_dropin_gpu.py::_
 
 For `n` seeds the reference's own processIMU / processImage loop runs a 24-frame synthetic sequence (14 solves each) twice: with its
 own Ceres-style optimization() (oracle/_ref/libvins_ref.so, CPU) and with the product's drop-in (libvins_ref_gpu.so), the latter in
-both forms of the prior factor (pivoted-Cholesky square root = default, the reference's eigen form = VINS_GPU_MARG_MODE=eigen).  Per
+both forms of the prior factor (pivoted-Cholesky square root = default, the reference's eigen form = vins_gpu_set_option(e, 2, 1)).  Per
 frame: same iteration count and accept / reject sequence?  state error (relative position / quaternion / velocity / biases, max).
     python tests/manual/gpu_flip_stats.py [n_seeds] > profiles/<tag>_flip_stats.json"""
 import json
@@ -32,16 +32,13 @@ def frame_err(r, g):
 
 out = {}
 for mode in ("sqrt", "eigen"):
-    if mode == "eigen":
-        os.environ["VINS_GPU_MARG_MODE"] = "eigen"
-    else:
-        os.environ.pop("VINS_GPU_MARG_MODE", None)
+    gpu_options = {2: 1} if mode == "eigen" else None      # vins_gpu_set_option(e, VINS_GPU_OPT_MARG_EIGEN, 1)
     n_frames = n_flip_frames = n_seq_with_flip = n_bookkeeping_diff = 0
     err_same, err_flip, err_after = [], [], []          # no flip so far in the sequence / the frame of a flip / the frames after one
     for seed in range(n_seeds):
         mp = 10.0 / 460.0 if seed % 2 == 0 else 0.1     # every other sequence also takes MARGIN_SECOND_NEW
         a = R.run_sequence(synth.SyntheticSequence(1000 + seed, n_frames=26, K=26, L=500), 24, L=R.lib(), min_parallax=mp, collect_priors=False)
-        b = R.run_sequence(synth.SyntheticSequence(1000 + seed, n_frames=26, K=26, L=500), 24, L=R.lib_gpu(), min_parallax=mp, collect_priors=False)
+        b = R.run_sequence(synth.SyntheticSequence(1000 + seed, n_frames=26, K=26, L=500), 24, L=R.lib_gpu(), min_parallax=mp, collect_priors=False, gpu_options=gpu_options)
         flipped = False
         for r, g in zip(a, b):
             n_frames += 1

@@ -104,3 +104,8 @@ def test_clear_state_between_two_optimizations_drops_the_pending_prior():
     got = R.run_sequence(synth.SyntheticSequence(11, n_frames=28, K=28, L=300), 26, L=R.lib_gpu(), reset_at=13, collect_priors=False)
     assert [r['frame'] for r in ref] == [10, 11, 12, 23, 24, 25]
     _compare(ref, got)
+
+
+def test_solver_time_cap_is_a_runtime_switch_of_the_drop_in():
+    from test_dropin_simt import _solver_time_cap_switch
+    _solver_time_cap_switch(R.lib_gpu())

@@ -881,7 +881,8 @@ static int resolve_launch_mode(BaBatch& B) {
 static void graph_key(const BaBatch& B, BaBatch::GraphKey& k) {
     const BaLayout& L = B.L;
     k.dL = B.dL; k.P = B.P;
-    const int d[12] = {L.nwin, L.nig, L.nprw, L.nbf, L.nba, L.lds_pro, L.lds_lin, L.lds_solve, B.rounds, 0, 0, 0};
+    // (la_on / lds_linacc: vg_ba_set_fused_min_windows can flip the kernel sequence while every buffer and size stays the same)
+    const int d[12] = {L.nwin, L.nig, L.nprw, L.nbf, L.nba, L.lds_pro, L.lds_lin, L.lds_solve, B.rounds, L.la_on, L.lds_linacc, L.big};
     memcpy(k.dims, d, sizeof(d));
 }
 static void graph_drop(BaBatch& B) {

@@ -129,7 +129,14 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
         HIPCHK(h, hipMalloc((void**)&s->d_ptrs[k], sizeof(uint8_t*) * s->h_ptrs[k].size()));
         HIPCHK(h, hipMemcpy(s->d_ptrs[k], s->h_ptrs[k].data(), sizeof(uint8_t*) * s->h_ptrs[k].size(), hipMemcpyHostToDevice));
     }
-    d.cand_cap = FE_CAND_CAP;
+    // candidate keys per stream: a power of two (the fall-back sort is bitonic) that holds every 3x3 local maximum of a frame without
+    // ties (W H / 4) -- 65536 for 752 x 480 -- so that the timing-dependent pruning bound of fe_mineig_kernel cannot overflow it on
+    // larger frames either; an overflow (plateaus of equal positive values) is reported, never truncated silently
+    {
+        size_t cap = FE_CAND_CAP;
+        while (cap < npix / 4) cap *= 2;
+        d.cand_cap = (int)cap;
+    }
     HIPCHK(h, hipMalloc((void**)&s->raw_alloc, 2 * npix * n_cams + 2 * FE_SLACK));
     HIPCHK(h, hipMemset(s->raw_alloc, 0, 2 * npix * n_cams + 2 * FE_SLACK));
     s->raw = s->raw_alloc + FE_SLACK;
@@ -154,7 +161,7 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     HIPCHK(h, hipMalloc((void**)&s->max_corners, sizeof(int) * n_cams));
     HIPCHK(h, hipMalloc((void**)&s->ncorners, sizeof(int) * n_cams));
     HIPCHK(h, hipMalloc((void**)&s->ncand, sizeof(unsigned) * FE_CNT_STRIDE * n_cams));
-    HIPCHK(h, hipMalloc((void**)&s->keys, sizeof(unsigned long long) * (size_t)FE_CAND_CAP * n_cams));
+    HIPCHK(h, hipMalloc((void**)&s->keys, sizeof(unsigned long long) * (size_t)d.cand_cap * n_cams));
     d.raw = s->raw2[s->raw_sel]; d.lut = s->lut; d.npts = s->npts; d.prev_xy = s->prev_xy; d.next_xy = s->next_xy; d.status = s->status;
     d.err = s->err; d.eig = nullptr; d.keep_eig = 0; d.mask = s->mask; d.ncand = s->ncand; d.keys = s->keys;
     d.max_corners = s->max_corners; d.corners = s->corners; d.ncorners = s->ncorners;
@@ -212,6 +219,8 @@ extern "C" int vg_fe_build_async(vg_handle* h, int equalize) {
     if (!h || !h->fe) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
     if (equalize && (s->d.W % 8 || s->d.H % 8)) { h->err = "CLAHE needs width and height divisible by 8"; return VG_ERR_UNSUPPORTED; }
+    // (fe_clahe_apply_kernel lays the interpolation cells of a row over the 256 threads of a workgroup: W / 8 / 4 + 3 of them)
+    if (equalize && s->d.W / 8 / 4 + 3 > 256) { h->err = "CLAHE: frame wider than the interpolation-cell tiling (W / 32 + 3 > 256)"; return VG_ERR_UNSUPPORTED; }
     const bool first = !s->have_prev;
     s->prev_clobbered = false;
     s->flip ^= 1;                                     // previous <- current (only after the arguments are known to be valid)
@@ -362,6 +371,8 @@ extern "C" int vg_fe_detect_download(vg_handle* h, float* out_xy, int* out_n) {
     HIPCHK(h, hipMemcpyAsync(out_xy, s->corners, sizeof(float) * 2 * s->cams * s->max_pts, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(out_n, s->ncorners, sizeof(int) * s->cams, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int c = 0; c < s->cams; ++c)
+        if (out_n[c] < 0) { out_n[c] = 0; h->err = "goodFeaturesToTrack: candidate list overflow (more 3x3 maxima than the key buffer holds)"; return VG_ERR_UNSUPPORTED; }
     return VG_OK;
 }
 
@@ -384,6 +395,7 @@ extern "C" int vg_fe_detect(vg_handle* h, int cam, const uint8_t* mask, int max_
     int n = 0;
     HIPCHK(h, hipMemcpyAsync(&n, s->ncorners + cam, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n < 0) { h->err = "goodFeaturesToTrack: candidate list overflow (more 3x3 maxima than the key buffer holds)"; return VG_ERR_UNSUPPORTED; }
     if (n > 0) HIPCHK(h, hipMemcpy(out_xy, s->corners + (size_t)cam * s->max_pts * 2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
     *out_n = n;
     return VG_OK;
@@ -452,6 +464,7 @@ extern "C" int vg_fe_detect_masked(vg_handle* h, int cam, int max_corners, doubl
     int n = 0;
     HIPCHK(h, hipMemcpyAsync(&n, s->ncorners + cam, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n < 0) { h->err = "goodFeaturesToTrack: candidate list overflow (more 3x3 maxima than the key buffer holds)"; return VG_ERR_UNSUPPORTED; }
     if (n > 0) HIPCHK(h, hipMemcpy(out_xy, s->corners + (size_t)cam * s->max_pts * 2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
     *out_n = n;
     return VG_OK;
@@ -503,7 +516,10 @@ extern "C" int vg_fe_get_level(vg_handle* h, int cam, int which, int level, uint
 extern "C" int vg_fe_keep_eig(vg_handle* h, int on) {
     if (!h || !h->fe) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
-    if (on && !s->eig) HIPCHK(h, hipMalloc((void**)&s->eig, sizeof(float) * (size_t)s->W * s->H * s->cams));
+    if (on && !s->eig) {
+        HIPCHK(h, hipMalloc((void**)&s->eig, sizeof(float) * (size_t)s->W * s->H * s->cams));
+        HIPCHK(h, hipMemset(s->eig, 0, sizeof(float) * (size_t)s->W * s->H * s->cams));       // (vg_fe_get_eig before any detection: zeros, not stale memory)
+    }
     s->d.eig = s->eig;
     s->d.keep_eig = on ? 1 : 0;
     return VG_OK;

@@ -900,7 +900,13 @@ extern "C" __global__ __launch_bounds__(1024) void fe_select_kernel(FeDev d, dou
     w.use_dist = min_dist >= 1.f;
     for (int k = tid; k < w.gw * w.gh; k += 1024) cellcnt[k] = 0;
     unsigned nall = d.ncand[FE_CNT_STRIDE * cam];
-    if (nall > (unsigned)d.cand_cap) nall = d.cand_cap;
+    // fe_mineig_kernel prunes with a timing-dependent LOWER bound of the threshold, so on a frame whose strong corners are found late
+    // the list can run long; past the capacity it dropped keys (arbitrary ones): the result would no longer be the reference's
+    // list.  Not silently: the stream reports -1 corners and the host calls return VG_ERR_UNSUPPORTED.
+    if (nall > (unsigned)d.cand_cap) {
+        if (tid == 0) d.ncorners[cam] = -1;
+        return;
+    }
     unsigned long long* keys = d.keys + (size_t)cam * d.cand_cap;
     float* corners = d.corners + (size_t)cam * d.max_pts * 2;
     int nacc = 0;

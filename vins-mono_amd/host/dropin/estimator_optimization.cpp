@@ -44,6 +44,10 @@ struct VgSide {
     double pending_stamp = 0;                               // Headers[WINDOW_SIZE].stamp at that time
     const MarginalizationInfo* pending_lmi = nullptr;       // last_marginalization_info at that time (not yet replaced)
     vg_ba_summary last;           // trace of the last solve (the reference only logs Summary::BriefReport)
+    // run-time behaviour switches (vins_gpu_set_option)
+    bool solver_time_cap = false; // forward SOLVER_TIME as max_solver_time_in_seconds (estimator.cpp:812-815)
+    bool marg_eigen = false;      // the reference's eigen form of the prior instead of the pivoted-Cholesky square root
+    bool marg_mode_dirty = false;
 };
 std::mutex g_mu;
 std::unordered_map<const Estimator*, VgSide> g_side;
@@ -132,11 +136,10 @@ void Estimator::optimization() {
     if (vg_abi_version() != VG_ABI_VERSION) throw std::runtime_error("libvinsgpu.so was built from another include/vinsgpu.h (ABI version mismatch)");
     if (!s.vg) {
         if (vg_create(&s.vg) != VG_OK) throw std::runtime_error("vg_create failed: no MI355X / libvinsgpu (no CPU fallback)");
-        // form of the prior factor the marginalization hands to the next frame: the pivoted-Cholesky square root (default) or, with
-        // VINS_GPU_MARG_MODE=eigen in the environment, the reference's eigen form (marginalization_factor.cpp:285-296); include/vinsgpu.h
-        const char* mm = getenv("VINS_GPU_MARG_MODE");
-        if (mm && !strcmp(mm, "eigen")) vg_ba_set_marg_mode(s.vg, VG_MARG_EIGEN);
     }
+    // form of the prior factor the marginalization hands to the next frame: the pivoted-Cholesky square root (default) or the
+    // reference's eigen form (marginalization_factor.cpp:285-296) -- vins_gpu_set_option(e, VINS_GPU_OPT_MARG_EIGEN, 1); include/vinsgpu.h
+    if (s.marg_mode_dirty) { vg_ba_set_marg_mode(s.vg, s.marg_eigen ? VG_MARG_EIGEN : VG_MARG_SQRT); s.marg_mode_dirty = false; }
     collect_prior(*this, s);                                    // the previous frame's marginalization result, if still on the device
     vector2double();                                            // estimator.cpp:701
     const int K = WINDOW_SIZE + 1;
@@ -228,11 +231,10 @@ void Estimator::optimization() {
     }
     pb.estimate_extrinsic = ESTIMATE_EXTRINSIC ? 1 : 0; pb.estimate_td = ESTIMATE_TD ? 1 : 0; pb.max_iters = NUM_ITERATIONS;
     pb.focal = FOCAL_LENGTH; pb.tr = TR; pb.row = ROW; pb.g_norm = G.z();
-    // options.max_solver_time_in_seconds (:812-815) is NOT forwarded by default: a wall-clock cap makes the result depend on
-    // timing (oracle/ASSUMPTIONS.md C7); define VINS_GPU_SOLVER_TIME_CAP to forward it
-#ifdef VINS_GPU_SOLVER_TIME_CAP
-    pb.max_solver_time_s = marginalization_flag == MARGIN_OLD ? SOLVER_TIME * 4.0 / 5.0 : SOLVER_TIME;
-#endif
+    // options.max_solver_time_in_seconds (:812-815): a wall-clock cap makes the result depend on timing (oracle/ASSUMPTIONS.md C7)
+    // and 40 ms is 30 x what a solve takes here, so it is NOT forwarded unless the caller asks for the reference's contract to the
+    // letter: vins_gpu_set_option(e, VINS_GPU_OPT_SOLVER_TIME_CAP, 1) (a run-time switch)
+    if (s.solver_time_cap) pb.max_solver_time_s = marginalization_flag == MARGIN_OLD ? SOLVER_TIME * 4.0 / 5.0 : SOLVER_TIME;
     // ---- outputs
     std::vector<double> lam(L > 0 ? L : 1);
     double td_out = td;
@@ -272,6 +274,15 @@ void vins_gpu_collect_prior(Estimator* e) { collect_prior(*e, side_of(e)); }
 void vins_gpu_reset(Estimator* e) {
     VgSide& s = side_of(e);
     s.prior_pending = false; s.solver_failed = false;
+}
+// behaviour switches of one Estimator (run time, no environment variables): VINS_GPU_OPT_SOLVER_TIME_CAP forwards SOLVER_TIME as
+// max_solver_time_in_seconds (estimator.cpp:812-815; default off), VINS_GPU_OPT_MARG_EIGEN asks for the reference's eigen form of
+// the prior instead of the square root (default off).  Takes effect at the next optimization().  Returns 0, -1 for an unknown option.
+int vins_gpu_set_option(Estimator* e, int option, int value) {
+    VgSide& s = side_of(e);
+    if (option == 1) { s.solver_time_cap = value != 0; return 0; }                                       // VINS_GPU_OPT_SOLVER_TIME_CAP
+    if (option == 2) { s.marg_eigen = value != 0; s.marg_mode_dirty = true; return 0; }                  // VINS_GPU_OPT_MARG_EIGEN
+    return -1;
 }
 // trace of the last solve
 const vg_ba_summary* vins_gpu_last_summary(Estimator* e) { return &side_of(e).last; }

@@ -120,7 +120,12 @@ void FeatureTracker::setMask() {                                      // feature
 
 void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {     // feature_tracker.cpp:81-167
     cur_time = _cur_time;
-    FeSide& s = ensure(this, _img.cols, _img.rows);
+    // the reference assumes the configured size (COL / ROW: setMask, inBorder, the fisheye mask); a frame of another size would make
+    // this member and the other three re-configure the device side against each other every frame -- tracking would degrade silently
+    if (_img.cols != COL || _img.rows != ROW)
+        throw std::runtime_error("FeatureTracker::readImage: frame is " + std::to_string(_img.cols) + "x" + std::to_string(_img.rows) +
+                                 ", the configuration says " + std::to_string(COL) + "x" + std::to_string(ROW));
+    FeSide& s = ensure(this, COL, ROW);
     // EQUALIZE (:85-95) and `forw_img = img` (:97-104): the frame goes to the device, where the (optional) CLAHE and the pyramid
     // that calcOpticalFlowPyrLK would build of it are formed; the previous frame's pyramid stays where it is
     const uint8_t* planes[1] = {_img.data};
