@@ -528,7 +528,7 @@ def fe_traffic():
     return None if any(v is None for v in t) else t[0] + 3 * t[1]
 
 
-def device_info():
+def device_info(h=None):
     """What the box reports about its GPU (informational).  The boxes of the pool differ: single-window launches take the same time
     everywhere, launches that fill all 256 CUs with the BA kernels' latency-bound workgroups are up to 1.4 x slower on some of them
      -- this object is what a reader can hold such a run against."""
@@ -548,6 +548,13 @@ def device_info():
         info["rocm_smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("partition", "sclk", "mclk", "fclk", "perf"))}
     except Exception as ex:                                   # noqa: BLE001
         info["rocm_smi"] = f"unavailable: {ex!r}"
+    if h is not None:
+        # the clock the box REALLY runs at (rocm-smi reports the same figures on boxes that run the BA kernels 1.4 x apart): a dependent
+        # FP64 FMA has a fixed latency in core cycles, so ns per FMA ~ 1 / clock -- lone wavefront, and with every CU loaded
+        try:
+            info["clock_probe"] = h.probe_clocks()
+        except Exception as ex:                               # noqa: BLE001
+            info["clock_probe"] = f"unavailable: {ex!r}"
     return info
 
 
@@ -942,7 +949,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": parity,
-            "device": device_info(),
+            "device": device_info(h),
             "step_latency_ms": {"solve_pipeline": solve_ms, "marginalization": marg_ms, "total": solve_ms + marg_ms,
                                 "what": "one 256-window step alone on the GPU (no overlap with other steps), HIP events"},
             "single_window_latency_ms": None,

@@ -23,10 +23,11 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 9    /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
+#define VG_ABI_VERSION 10   /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
                              * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode; 6: vg_ba_reserve, vg_ba_seq_* (windows that stay on the device);
                              * 7: vg_ba_seq_export / vg_ba_seq_import; 8: vg_host_register, vg_ba_set_fused_min_windows, vg_ba_batch_is_fused;
-                             * 9: vg_fe_keep_eig (the min-eigenvalue map is no longer written unless asked for) */
+                             * 9: vg_fe_keep_eig (the min-eigenvalue map is no longer written unless asked for);
+                             * 10: vg_config / vg_create_config; vg_ba_batch_is_fused no longer returns 2 */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {
@@ -43,6 +44,23 @@ typedef struct vg_handle vg_handle;
 /* ---- lifecycle ------------------------------------------------------------------------------ */
 int vg_abi_version(void);
 int vg_create(vg_handle** out);                 /* uses the current HIP device, owns one stream  */
+/* The same with everything that shapes a handle's behaviour in ONE struct (ABI 10; SURVEY 8(b): vg_create(const vg_config*, ...)).
+ * A handle created this way NEVER consults the environment: the development variables VG_BA_LAUNCH_MODE, VG_BA_FUSED,
+ * VG_BA_FUSED_MIN and VG_PACK_THREADS are defaults of plain vg_create() only (a drop-in library must not change behaviour with
+ * its host's environment).  Zero-initialise, set struct_size = sizeof(vg_config), fill what differs from the defaults. */
+typedef struct vg_config {
+    int struct_size;             /* sizeof(vg_config) of the caller: fields beyond it take their defaults                         */
+    int device;                  /* HIP device index (hipSetDevice before the streams are created); -1 = the current device       */
+    int launch_mode;             /* VG_LAUNCH_DIRECT + 1 / VG_LAUNCH_GRAPH + 1; 0 = the library's default (vg_ba_set_launch_mode)   */
+    int marg_mode;               /* VG_MARG_SQRT (0, default) / VG_MARG_EIGEN: form of the prior factor (vg_ba_set_marg_mode)     */
+    int fused_min_windows;       /* batches from this many windows on take the fused factor kernel; 0 = default (32), -1 = never  */
+    int pack_threads;            /* host threads that share the packing / unpacking of a batch; 0 = default (8)                   */
+} vg_config;
+int vg_create_config(const vg_config* cfg, vg_handle** out);
+/* What core clock does this box really run at?  out4 = { ns per dependent FP64 FMA with ONE wavefront on the chip, clock64() ticks per
+ * microsecond of wall time during that, the same two with every CU loaded }.  The FMA latency is a constant number of core cycles, so
+ * the first and third figures are inversely proportional to the clock (lone / under load).  bench.py reports them (`device.clock_probe`). */
+int vg_probe_clocks(vg_handle* h, double* out4);
 int vg_destroy(vg_handle* h);
 int vg_sync(vg_handle* h);                      /* hipStreamSynchronize(handle stream)           */
 const char* vg_last_error(vg_handle* h);        /* text of the last failure on this handle       */

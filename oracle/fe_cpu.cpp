@@ -190,13 +190,29 @@ void min_eig_map(const uint8_t* img, int w, int h, float* eig) {
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) rbuf[(size_t)y * w + x] = (float)P(y, x) * k2 + (float)(P(y, x - 1) + P(y, x + 1)) * k1;
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x)
         dy[(size_t)y * w + x] = rbuf[(size_t)reflect101(y + 1, h) * w + x] - rbuf[(size_t)reflect101(y - 1, h) * w + x];
-    // cov = (dx*dx, dx*dy, dy*dy) as float; 3x3 un-normalised box in double; min eigenvalue in float
+    // cov = (dx*dx, dx*dy, dy*dy) as float; 3x3 un-normalised box in double; min eigenvalue in float.
+    // The box is SEPARABLE, as cv::boxFilter runs it (RowSum<float, double> then ColumnSum<double, float>, ksize 3, normalize = false,
+    // BORDER_REFLECT_101): a row sum ((p[x-1] + p[x]) + p[x+1]) in double per channel, then the sum of three row sums ((r[y-1] + r[y]) +
+    // r[y+1]) -- round 5 (ASSUMPTIONS F10): the first version added the nine values in one sequential double sum,
+    // which is neither OpenCV's order nor cheap (27 conversions + 27 FP64 adds per pixel instead of 3 + 12).  OpenCV's row / column
+    // filters slide (s += p[x+2] - p[x-1]): the same sums in exact arithmetic, not reproduced here (a running sum over 752 columns
+    // is a serial chain; the double rounding it would add is far below the float the result is cast to).
+    std::vector<double> rs((size_t)w * h * 3);
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
         double sxx = 0, sxy = 0, syy = 0;
-        for (int v = -1; v <= 1; ++v) for (int u = -1; u <= 1; ++u) {
-            const size_t o = (size_t)reflect101(y + v, h) * w + reflect101(x + u, w);
+        for (int u = -1; u <= 1; ++u) {
+            const size_t o = (size_t)y * w + reflect101(x + u, w);
             const float gx = dx[o], gy = dy[o];
             sxx += (double)(gx * gx); sxy += (double)(gx * gy); syy += (double)(gy * gy);
+        }
+        double* r = &rs[((size_t)y * w + x) * 3];
+        r[0] = sxx; r[1] = sxy; r[2] = syy;
+    }
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        double sxx = 0, sxy = 0, syy = 0;
+        for (int v = -1; v <= 1; ++v) {
+            const double* r = &rs[((size_t)reflect101(y + v, h) * w + x) * 3];
+            sxx += r[0]; sxy += r[1]; syy += r[2];
         }
         const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
         eig[(size_t)y * w + x] = (float)((a + c) - std::sqrt((a - c) * (a - c) + b * b));

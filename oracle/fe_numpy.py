@@ -190,15 +190,14 @@ def mineig(img):
     dy = rr[2:, :] - rr[:-2, :]
     dx, dy = dx.astype(np.float32), dy.astype(np.float32)
     cov = [(dx * dx).astype(np.float32), (dx * dy).astype(np.float32), (dy * dy).astype(np.float32)]
-    box = [ndimage.uniform_filter(c.astype(np.float64), size=3, mode='mirror') * 9.0 for c in cov]   # 'mirror' == REFLECT_101
-    # the box filter of the reference sums 9 float values in double (exact up to ordering); rebuild the exact sum:
+    # the box filter of the reference is separable (RowSum<float, double>, then ColumnSum<double, float>; REFLECT_101): three taps
+    # of a row summed in double, left to right, then three row sums, top to bottom (round 5: the same order as oracle/fe_cpu.cpp)
     box = []
     for c in cov:
         q = _reflect101(c.astype(np.float64), 1)
-        acc = np.zeros(c.shape, np.float64)
-        for dyy in range(3):
-            for dxx in range(3):
-                acc += q[dyy:dyy + c.shape[0], dxx:dxx + c.shape[1]]
+        hh, ww = c.shape
+        rs = (q[:, 0:ww] + q[:, 1:ww + 1]) + q[:, 2:ww + 2]
+        acc = (rs[0:hh] + rs[1:hh + 1]) + rs[2:hh + 2]
         box.append(acc.astype(np.float32))
     a, b, cc = box[0] * f32(0.5), box[1], box[2] * f32(0.5)
     return ((a + cc) - np.sqrt((a - cc) * (a - cc) + b * b, dtype=np.float32)).astype(np.float32)

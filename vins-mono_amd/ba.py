@@ -12,7 +12,7 @@ VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
 VG_MARG_SQRT, VG_MARG_EIGEN = 0, 1     # vg_ba_set_marg_mode
 VG_OK = 0
-VG_ABI_VERSION = 9          # include/vinsgpu.h
+VG_ABI_VERSION = 10         # include/vinsgpu.h
 VG_LAUNCH_DIRECT, VG_LAUNCH_GRAPH = 0, 1   # vg_ba_set_launch_mode
 VG_LAUNCH_DEFAULT = VG_LAUNCH_DIRECT        # include/vinsgpu.h
 VG_PRIOR_RESIDENT = -1
@@ -214,10 +214,17 @@ def summary_dict(s):
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
-class Handle:
-    """vg_create / vg_destroy wrapper; raises RuntimeError with vg_last_error on failures."""
+class Config(C.Structure):
+    """vg_config (include/vinsgpu.h, ABI 10): everything that shapes a handle in one struct; a handle made from it never reads the environment."""
+    _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("launch_mode", C.c_int), ("marg_mode", C.c_int),
+                ("fused_min_windows", C.c_int), ("pack_threads", C.c_int)]
 
-    def __init__(self):
+
+class Handle:
+    """vg_create / vg_destroy wrapper; raises RuntimeError with vg_last_error on failures.  config: a dict of vg_config fields
+    (device, launch_mode = 'graph' | 'direct', marg_mode, fused_min_windows, pack_threads) -> vg_create_config."""
+
+    def __init__(self, config=None):
         self.lib = lib()
         L = self.lib
         L.vg_create.argtypes = [C.POINTER(C.c_void_p)]
@@ -264,7 +271,14 @@ class Handle:
         if L.vg_abi_version() != VG_ABI_VERSION:
             raise RuntimeError(f"libvinsgpu.so reports ABI version {L.vg_abi_version()}, this binding was written for {VG_ABI_VERSION}")
         self.h = C.c_void_p()
-        rc = L.vg_create(C.byref(self.h))
+        if config is None:
+            rc = L.vg_create(C.byref(self.h))
+        else:
+            cfg = Config(struct_size=C.sizeof(Config), device=int(config.get("device", -1)),
+                         launch_mode={None: 0, "direct": 1, "graph": 2}[config.get("launch_mode")], marg_mode=int(config.get("marg_mode", 0)),
+                         fused_min_windows=int(config.get("fused_min_windows", 0)), pack_threads=int(config.get("pack_threads", 0)))
+            L.vg_create_config.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+            rc = L.vg_create_config(C.byref(cfg), C.byref(self.h))
         if rc != VG_OK:
             raise RuntimeError(f"vg_create failed with status {rc} (no HIP device?)")
 
@@ -327,6 +341,14 @@ class Handle:
     def ba_set_fused_min_windows(self, n):
         """Batches of at least n windows take the fused linearise + accumulate kernel (0 = never; default 32): vg_ba_set_fused_min_windows."""
         self._chk(self.lib.vg_ba_set_fused_min_windows(self.h, int(n)), "vg_ba_set_fused_min_windows")
+
+    def probe_clocks(self):
+        """vg_probe_clocks: {ns per dependent FP64 FMA, clock64 ticks per us} with one wavefront / with every CU loaded."""
+        out = (C.c_double * 4)()
+        self.lib.vg_probe_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._chk(self.lib.vg_probe_clocks(self.h, out), "vg_probe_clocks")
+        return {"lone_wave": {"ns_per_dependent_fma": out[0], "clock64_ticks_per_us": out[1]},
+                "all_cus_loaded": {"ns_per_dependent_fma": out[2], "clock64_ticks_per_us": out[3]}}
 
     def ba_launch_stats(self):
         mode, nl, ncap = C.c_int(), C.c_longlong(), C.c_longlong()

@@ -282,7 +282,8 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         // fused projection kernel (ba_linacc_proj_kernel): LDS = staged records [la_chf][33] | pair blocks [Kp (Kp - 1) / 2][90] |
         // keys [la_chf] + chunk starts [64] (ints)
         {
-            static const bool off = getenv("VG_BA_FUSED") && !strcmp(getenv("VG_BA_FUSED"), "0");
+            static const bool env_off = getenv("VG_BA_FUSED") && !strcmp(getenv("VG_BA_FUSED"), "0");       // (development switches:
+            const bool off = env_off && !h->ba.no_env;                                                          //  plain vg_create() only)
             // few windows: the chip is empty and the separate kernels spread a window over many workgroups (single window: 28 us per
             // round against 52 us for the one fused workgroup); from a few dozen windows on the fused kernel wins
             static const int env_min = getenv("VG_BA_FUSED_MIN") ? atoi(getenv("VG_BA_FUSED_MIN")) : 32;
@@ -541,9 +542,10 @@ static int pack_window(vg_handle* h, const BaLayout& L, const vg_ba_problem* p, 
 }
 
 // windows are independent: a few host threads share the packing / unpacking of a batch (strided assignment)
+static thread_local int tl_pack_cap = 0;      // vg_config::pack_threads of the handle whose call is running on this thread (0: not set)
 static int host_threads_for(int nwin) {
-    static const int cap = [] { const char* e = getenv("VG_PACK_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? std::min(v, 64) : 8; }();
-    return std::max(1, std::min(cap, nwin / 16));
+    static const int env_cap = [] { const char* e = getenv("VG_PACK_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? std::min(v, 64) : 8; }();
+    return std::max(1, std::min(tl_pack_cap > 0 ? tl_pack_cap : env_cap, nwin / 16));      // (the handle's setting, else the development variable, else 8)
 }
 template <typename F>
 static void for_windows(int nwin, F&& body) {            // body(thread, window)
@@ -677,6 +679,7 @@ extern "C" int vg_ba_batch_upload(vg_handle* h, int nwin, const vg_ba_problem* c
     // pack: zero-fill + pack of every window's slabs
     {
         std::vector<int> rcs(64, VG_OK);
+        tl_pack_cap = h->ba.pack_threads;
         for_windows(nwin, [&](int t, int w) {
             int* ia = B.h_ia + (size_t)w * L.istride;
             double* di = B.h_di + (size_t)w * L.dstride;
@@ -871,7 +874,7 @@ static int launch_solve(vg_handle* h, hipEvent_t* ev = nullptr, int* kinds = nul
 // handle stays on direct launches: the same kernels either way, never another compute path.
 static int resolve_launch_mode(BaBatch& B) {
     if (B.launch_mode < 0) {
-        const char* e = getenv("VG_BA_LAUNCH_MODE");
+        const char* e = B.no_env ? nullptr : getenv("VG_BA_LAUNCH_MODE");
         B.launch_mode = VG_LAUNCH_DEFAULT;
         if (e && !strcmp(e, "graph")) B.launch_mode = VG_LAUNCH_GRAPH;
         if (e && !strcmp(e, "direct")) B.launch_mode = VG_LAUNCH_DIRECT;
@@ -1076,6 +1079,7 @@ static int unpack_states(vg_handle* h, int nwin, vg_ba_state* const* st, vg_ba_s
     BaBatch& B = h->ba;
     const BaLayout& L = B.L;
     std::vector<int> worst_t(64, VG_OK);
+    tl_pack_cap = h->ba.pack_threads;
     for_windows(nwin, [&](int t, int w) {
         int& worst = worst_t[t];
         const double* o = B.h_out.data() + (size_t)w * L.ostride;
@@ -1118,6 +1122,7 @@ static int unpack_priors(vg_handle* h, int nwin, vg_ba_prior* const* pri) {
     const BaLayout& L = B.L;
     static const bool debug_marg = getenv("VG_DEBUG_MARG") != nullptr;      // phase stamps of -DBA_PROFILE builds
     std::vector<int> too_small(64, 0);
+    tl_pack_cap = h->ba.pack_threads;
     for_windows(nwin, [&](int t, int w) {
         if (pri && pri[w]) {
             vg_ba_prior* q = pri[w];
@@ -1440,6 +1445,7 @@ extern "C" int vg_ba_seq_step_async(vg_handle* h, int nwin, const vg_ba_frame* c
         memcpy(d + 11, m.linearized_ba, 24); memcpy(d + 14, m.linearized_bg, 24);
         memcpy(d + 17, m.jacobian, 225 * 8); memcpy(d + 242, m.covariance, 225 * 8);
     };
+    tl_pack_cap = h->ba.pack_threads;
     for_windows(nwin, [&](int, int w) {
         const vg_ba_frame* f = frames[w];
         int* i = Q.h_in_i.data() + (size_t)w * D.ii_stride;

@@ -678,6 +678,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d, doub
     __shared__ uint8_t tile[ME_R + 6][72];                        // rows y0-3 .. y0+R+2, cols x0-3 .. x0+66 (reflected coordinates)
     __shared__ float gx[ME_R + 4][68], gy[ME_R + 4][68];          // gradients on rows y0-2 .. y0+R+1, cols x0-2 .. x0+65
     __shared__ float eg[ME_R + 2][66];                            // the map on rows y0-1 .. y0+R, cols x0-1 .. x0+64
+
     __shared__ float bmax[4];
     __shared__ unsigned wcount[4], wbase[4], lbound;
     const int cam = blockIdx.z, W = d.W, H = d.H;
@@ -729,30 +730,44 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d, doub
         gx[yy][xx] = dxv; gy[yy][xx] = dyv;
     }
     __syncthreads();
-    // the map on the tile and its ring; the masked maximum over the tile's own pixels
+    // The map on the tile and its ring; the masked maximum over the tile's own pixels.  The 3 x 3 box is SEPARABLE, as cv::boxFilter
+    // runs it (RowSum<float, double>: ((p[x-1] + p[x]) + p[x+1]) per channel, then ColumnSum<double, float>: ((r[y-1] + r[y]) + r[y+1]);
+    // oracle/fe_cpu.cpp, round 5): a thread walks DOWN a column of the map over a strip of six rows and keeps the last three row sums
+    // in registers -- per pixel 12 products / conversions and 14 FP64 adds instead of 27 + 27, no second LDS array.
     const uint8_t* mask = d.mask + (size_t)cam * W * H;
     float m = -INFINITY;
-    for (int k = threadIdx.x; k < (ME_R + 2) * 66; k += 256) {
-        const int ey = k / 66, ex = k - 66 * ey;
-        const int y = y0 - 1 + ey, x = x0 - 1 + ex;
-        float val = -INFINITY;
-        if (x >= 0 && y >= 0 && x < W && y < H) {
-            double sxx = 0, sxy = 0, syy = 0;
+    if (threadIdx.x < 3 * 66) {
+        const int strip = threadIdx.x / 66, ex = threadIdx.x - 66 * strip;
+        const int ey0 = 6 * strip;                                 // map rows ey0 .. ey0+5 of (ME_R + 2) = 18: gradient rows ey0 .. ey0+7
+        const int x = x0 - 1 + ex;
+        double r0[3] = {0, 0, 0}, r1[3] = {0, 0, 0};
 #pragma unroll
-            for (int v = 0; v < 3; ++v)
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const float a = gx[ey + v][ex + u], b = gy[ey + v][ex + u];
-                    sxx += (double)(a * a); sxy += (double)(a * b); syy += (double)(b * b);
-                }
-            const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
-            val = (float)((a + c) - sqrtf((a - c) * (a - c) + b * b));
-            if (ey >= 1 && ey <= ME_R && ex >= 1 && ex <= 64) {             // the tile's own pixel
-                if (d.keep_eig) d.eig[(size_t)cam * W * H + (size_t)y * W + x] = val;
-                if (mask[(size_t)y * W + x]) m = fmaxf(m, val);
+        for (int j = 0; j < 8; ++j) {
+            const int yy = ey0 + j;
+            double rs[3];
+            {
+                const float a0 = gx[yy][ex], b0 = gy[yy][ex], a1 = gx[yy][ex + 1], b1 = gy[yy][ex + 1], a2 = gx[yy][ex + 2], b2 = gy[yy][ex + 2];
+                rs[0] = ((double)(a0 * a0) + (double)(a1 * a1)) + (double)(a2 * a2);
+                rs[1] = ((double)(a0 * b0) + (double)(a1 * b1)) + (double)(a2 * b2);
+                rs[2] = ((double)(b0 * b0) + (double)(b1 * b1)) + (double)(b2 * b2);
             }
+            if (j >= 2) {
+                const int ey = yy - 2, y = y0 - 1 + ey;
+                float val = -INFINITY;
+                if (x >= 0 && y >= 0 && x < W && y < H) {
+                    const double sxx = (r0[0] + r1[0]) + rs[0], sxy = (r0[1] + r1[1]) + rs[1], syy = (r0[2] + r1[2]) + rs[2];
+                    const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+                    val = (float)((a + c) - sqrtf((a - c) * (a - c) + b * b));
+                    if (ey >= 1 && ey <= ME_R && ex >= 1 && ex <= 64) {             // the tile's own pixel
+                        if (d.keep_eig) d.eig[(size_t)cam * W * H + (size_t)y * W + x] = val;
+                        if (mask[(size_t)y * W + x]) m = fmaxf(m, val);
+                    }
+                }
+                eg[ey][ex] = val;
+            }
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) { r0[c3] = r1[c3]; r1[c3] = rs[c3]; }
         }
-        eg[ey][ex] = val;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));

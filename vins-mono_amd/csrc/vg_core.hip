@@ -1,6 +1,9 @@
 // vg_core.hip — handle lifecycle, stream and HIP-event stopwatch of the C-ABI (include/vinsgpu.h).
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <vector>
 #include "vg_handle.h"
+#include "vg_target.h"
 #include "../../include/vinsgpu.h"
 
 extern "C" void fe_state_destroy(FeState* s);
@@ -26,6 +29,32 @@ extern "C" int vg_create(vg_handle** out) {
         return VG_ERR_HIP;
     }
     *out = h;
+    return VG_OK;
+}
+
+extern "C" int vg_create_config(const vg_config* cfg, vg_handle** out) {
+    if (!cfg || !out || cfg->struct_size < (int)(2 * sizeof(int))) return VG_ERR_BAD_ARG;
+    vg_config c;
+    memset(&c, 0, sizeof(c));
+    c.device = -1;
+    memcpy(&c, cfg, (size_t)cfg->struct_size < sizeof(c) ? (size_t)cfg->struct_size : sizeof(c));
+    if (c.launch_mode != 0 && c.launch_mode != VG_LAUNCH_GRAPH + 1 && c.launch_mode != VG_LAUNCH_DIRECT + 1) return VG_ERR_BAD_ARG;
+    if (c.marg_mode != VG_MARG_SQRT && c.marg_mode != VG_MARG_EIGEN) return VG_ERR_BAD_ARG;
+    if (c.fused_min_windows < -1 || c.pack_threads < 0 || c.pack_threads > 64) return VG_ERR_BAD_ARG;
+    if (c.device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return VG_ERR_NO_DEVICE;
+        if (c.device >= ndev) return VG_ERR_BAD_ARG;
+        if (hipSetDevice(c.device) != hipSuccess) return VG_ERR_HIP;
+    }
+    const int rc = vg_create(out);
+    if (rc != VG_OK) return rc;
+    vg_handle* h = *out;
+    h->ba.no_env = true;                                        // every switch below is explicit: the environment is not consulted
+    h->ba.launch_mode = c.launch_mode ? c.launch_mode - 1 : VG_LAUNCH_DEFAULT;
+    h->ba.marg_mode = c.marg_mode;
+    h->ba.fused_min = c.fused_min_windows == 0 ? 32 : (c.fused_min_windows < 0 ? 0 : c.fused_min_windows);
+    h->ba.pack_threads = c.pack_threads ? c.pack_threads : 8;
     return VG_OK;
 }
 
@@ -92,4 +121,47 @@ extern "C" int vg_timer_stop(vg_handle* h, float* ms) {
     if (e == hipSuccess) e = hipEventElapsedTime(ms, h->ev0, h->ev1);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return VG_ERR_HIP; }
     return VG_OK;
+}
+
+// ---- what kind of box is this?  (boxes of the pool run the latency-bound BA kernels up to 1.4 x apart although they
+//      report the same clocks.)  A dependent chain of FP64 FMAs has a fixed latency in CORE cycles, so its wall time (the constant
+//      100 MHz counter) measures the core clock the box really runs at -- once with one lone wavefront, once with every CU loaded
+//      (one workgroup of 4 wavefronts per CU, i.e. still one wavefront per SIMD: a power / clock cap shows as a longer chain) -- and the ratio of the shader-clock counter
+//      to the wall counter says whether clock64() follows that clock.
+__global__ void vg_probe_kernel(double* out, int n) {
+    double x = 1.0 + (double)threadIdx.x * 1e-12;
+    const double a = 1.0000000001, b = 1e-12;
+    const long long w0 = wall_clock64(), c0 = clock64();
+    for (int i = 0; i < n; i += 8) {
+        x = fma(x, a, b); x = fma(x, a, b); x = fma(x, a, b); x = fma(x, a, b);
+        x = fma(x, a, b); x = fma(x, a, b); x = fma(x, a, b); x = fma(x, a, b);
+    }
+    const long long w1 = wall_clock64(), c1 = clock64();
+    if (threadIdx.x == 0) {
+        out[4 * blockIdx.x + 0] = (double)(w1 - w0);
+        out[4 * blockIdx.x + 1] = (double)(c1 - c0);
+        out[4 * blockIdx.x + 2] = x;
+    }
+}
+extern "C" int vg_probe_clocks(vg_handle* h, double* out4) {
+    if (!h || !out4) return VG_ERR_BAD_ARG;
+    const int n = 1 << 18, nblk = 256;
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(double) * 4 * nblk) != hipSuccess) { h->err = "vg_probe_clocks: hipMalloc"; return VG_ERR_HIP; }
+    std::vector<double> host(4 * nblk);
+    int rc = VG_OK;
+    for (int pass = 0; pass < 2 && rc == VG_OK; ++pass) {
+        const int g = pass ? nblk : 1, t = pass ? 256 : 64;
+        hipLaunchKernelGGL(vg_probe_kernel, dim3(g), dim3(t), 0, h->stream, d, 1024);          // warm-up (code fetch)
+        hipLaunchKernelGGL(vg_probe_kernel, dim3(g), dim3(t), 0, h->stream, d, n);
+        if (hipMemcpyAsync(host.data(), d, sizeof(double) * 4 * g, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "vg_probe_clocks: launch / copy failed"; rc = VG_ERR_HIP; break; }
+        double wall = 0.0, clk = 0.0;
+        for (int b = 0; b < g; ++b) { wall += host[4 * b]; clk += host[4 * b + 1]; }
+        wall /= g; clk /= g;
+        out4[2 * pass + 0] = wall / BA_WALL_HZ * 1e9 / n;          // ns per dependent FP64 FMA
+        out4[2 * pass + 1] = wall > 0 ? clk / (wall / BA_WALL_HZ * 1e6) : 0.0;      // clock64() ticks per microsecond of wall time
+    }
+    (void)hipFree(d);
+    return rc;
 }

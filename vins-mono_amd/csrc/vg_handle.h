@@ -69,6 +69,8 @@ struct BaBatch {
     int marg_mode = 0;               // vg_ba_set_marg_mode: VG_MARG_SQRT (default) / VG_MARG_EIGEN
     int res_L = 0, res_F = 0, res_O = 0, res_N = 0;   // vg_ba_reserve: capacities every layout is built for at least
     int fused_min = -1;              // vg_ba_set_fused_min_windows (-1: environment VG_BA_FUSED_MIN, else 32; 0: never)
+    bool no_env = false;             // handle made by vg_create_config: no environment variable shapes its behaviour
+    int pack_threads = 0;            // host threads sharing the packing of a batch (0: environment VG_PACK_THREADS, else 8)
     BaSeq seq;                       // vg_ba_seq_*
     void* allreduce = nullptr;       // vg_allreduce_fn of the large-window path (nullptr: single rank)
     void* allreduce_user = nullptr;
