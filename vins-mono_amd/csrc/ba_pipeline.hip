@@ -1782,7 +1782,7 @@ DEV bool chain_factor(int lane, P Dk, P dinvk, int kind, PC Xc, PC Xu) {
 }
 // x -= (coupling block)^T x_n for one column: coef[p * SP + r * SR] = coupling entry (row r of this block, row p of the neighbour's X).
 // Three rows at a time, the scheduler fenced in between (81 hoisted LDS reads would not fit the register file).  _c: strides known at
-// compile time (a wavefront whose lanes all belong to one sweep: immediate offsets, broadcast reads); _v: per lane.
+// compile time (both sweeps store their coupling blocks as [p][r]: immediate offsets; the block itself may differ per lane).
 template <int SP, int SR>
 DEV void chain_upd_c(double* x, const lds_d* coef, const double* xn) {
 #pragma unroll
@@ -1799,26 +1799,11 @@ DEV void chain_upd_c(double* x, const lds_d* coef, const double* xn) {
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-DEV void chain_upd_v(double* x, const lds_d* coef, int sp, int sr, const double* xn) {
-#pragma unroll
-    for (int r3 = 0; r3 < 9; r3 += 3) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        const lds_d* cf = coef + r3 * sr;
-#pragma unroll
-        for (int p = 0; p < 9; ++p) {
-            s0 += cf[p * sp] * xn[p];
-            s1 += cf[p * sp + sr] * xn[p];
-            s2 += cf[p * sp + 2 * sr] * xn[p];
-        }
-        x[r3] -= s0; x[r3 + 1] -= s1; x[r3 + 2] -= s2;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // ---- the same factorisation in three parts, so that one wavefront can walk TWO blocks in lock step (their pivot chains are
 //      independent: the second block hides in the latencies of the first)
 struct ChainFac { double4_t dg, ld, di; };
-template <typename P, typename PC>
+// (XU_PC: the lower neighbour's block is stored [p][c] like the upper one's -- chain_schur; false: [c][p] -- the large-window path)
+template <bool XU_PC, typename P, typename PC>
 DEV void cf_load(ChainFac& f, int lane, P Dk, int kind, PC Xc, PC Xu) {
     const int jc = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -1846,7 +1831,7 @@ DEV void cf_load(ChainFac& f, int lane, P Dk, int kind, PC Xc, PC Xu) {
         for (int s = 0; s < 3; ++s) {
             const int pp = 4 * s + kq;
             const bool in = pp < 9 && jc < 9;
-            const double v = Xu[in ? 9 * jc + pp : 0];
+            const double v = Xu[in ? (XU_PC ? 9 * pp + jc : 9 * jc + pp) : 0];
             av[s] = in ? v : 0.0;
         }
 #pragma unroll
@@ -1901,7 +1886,7 @@ DEV bool cf_store(const ChainFac& f, int lane, P Dk, P dinvk) {
 //   (C) all wavefronts: S accumulators += (18 staged rows)^T (18 staged rows) on v_mfma_f64_16x16x4
 // then the landmark columns, 32 at a time, exactly as before.  Storage afterwards: D_k = L_k; the coupling block of a pair
 // (k, k-1) lives in the slot E_k: for a TOP block k it holds Xe_k = L_k^-1 E_k as [p][c] (p = row of X_k, c = column sb_k-1), for
-// a BOTTOM block k-1 it holds (L_k-1^-1 E_k^T)^T as [c][p]; X in HBM.  Returns this thread's share of the coupling part of
+// a BOTTOM block k-1 it holds L_k-1^-1 E_k^T as [p][c] too (c = column sb_k; the large-window path keeps [c][p]); X in HBM.  Returns this thread's share of the coupling part of
 // t^T H~ t; *flag (m.red + 24) = 0 on a non-positive pivot.
 #define SCHUR_LW 32                               // landmarks per staged tile
 #define SCHUR_LD (SCHUR_LW + 1)
@@ -2065,20 +2050,29 @@ NOINL double chain_schur(const Ctx& c_in, const SolveLds& m_in, const double* bu
 #pragma unroll
             for (int i = 0; i < 4; ++i) msk[i] = (c.lane >> 4) == i ? 1.0 : 0.0;
             bool ok = true;
+#define CF_STEP1(f) cf_pivot<0>(f, msk); cf_pivot<1>(f, msk); cf_pivot<2>(f, msk); cf_pivot<3>(f, msk); cf_pivot<4>(f, msk); \
+                    cf_pivot<5>(f, msk); cf_pivot<6>(f, msk); cf_pivot<7>(f, msk); cf_pivot<8>(f, msk);
             if (has_t && has_b) {
                 ChainFac ft, fb;
-                cf_load(ft, c.lane, D + 81 * kt, kind_t, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt));
-                cf_load(fb, c.lane, D + 81 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb));
+                cf_load<true>(ft, c.lane, D + 81 * kt, kind_t, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt));
+                cf_load<true>(fb, c.lane, D + 81 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb));
 #define CF_STEP(r) cf_pivot<r>(ft, msk); cf_pivot<r>(fb, msk);
                 CF_STEP(0) CF_STEP(1) CF_STEP(2) CF_STEP(3) CF_STEP(4) CF_STEP(5) CF_STEP(6) CF_STEP(7) CF_STEP(8)
 #undef CF_STEP
                 ok = cf_store(ft, c.lane, D + 81 * kt, dinv + 9 * kt);
                 ok = cf_store(fb, c.lane, D + 81 * kb, dinv + 9 * kb) && ok;
             } else if (has_t) {
-                ok = chain_factor(c.lane, D + 81 * kt, dinv + 9 * kt, kind_t, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt));
+                ChainFac ft;
+                cf_load<true>(ft, c.lane, D + 81 * kt, kind_t, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt));
+                CF_STEP1(ft)
+                ok = cf_store(ft, c.lane, D + 81 * kt, dinv + 9 * kt);
             } else if (has_b) {
-                ok = chain_factor(c.lane, D + 81 * kb, dinv + 9 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb));
+                ChainFac fb;
+                cf_load<true>(fb, c.lane, D + 81 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb));
+                CF_STEP1(fb)
+                ok = cf_store(fb, c.lane, D + 81 * kb, dinv + 9 * kb);
             }
+#undef CF_STEP1
             if (!ok && c.lane == 0) *flag = 0;
         }
         if (act && col_task) {
@@ -2093,17 +2087,18 @@ NOINL double chain_schur(const Ctx& c_in, const SolveLds& m_in, const double* bu
                 x[r] = v;
             }
             DP_ADD(19);
-            // x -= (coupling block)^T x_prev;  coef[p * sp + r * sr] = coupling entry (row r of this block, row p of the neighbour's X)
-            if (wave == 0) { if (upd_t_from_above) chain_upd_c<9, 1>(x, E + 81 * (kt + 1), xprev); }
-            else if (wave == 1) { if (upd_b) chain_upd_c<1, 9>(x, E + 81 * kb, xprev); }
-            else if (half == 0 ? upd_t_from_above : upd_b)           // (wavefront 2 holds columns of both sweeps: operands per lane)
-                chain_upd_v(x, half == 0 ? E + 81 * (kt + 1) : E + 81 * kb, half == 0 ? 9 : 1, half == 0 ? 1 : 9, xprev);
+            // x -= (coupling block)^T x_prev;  coef[9 p + r] = coupling entry (row r of this block, row p of the neighbour's X): both
+            // sweeps keep their coupling block as [p][r] -- one code path, only the block differs per lane in wavefront 2.
+            // (An MFMA form of this update -- 15 MFMAs per block from the staged rows instead of 81 multiply-adds per column -- was
+            //  measured and lost, 59K against 24K cycles per round: five dependent tile trips of index arithmetic and LDS reads on ONE
+            //  wavefront are slower than 64 columns side by side; profiles/r05p_*.)
+            if (half == 0 ? upd_t_from_above : upd_b) chain_upd_c<9, 1>(x, half == 0 ? E + 81 * (kt + 1) : E + 81 * kb, xprev);
             DP_ADD(20);
             if (half == 0 && upd_mid_from_below) {
                 double xb[9];
 #pragma unroll
                 for (int p = 0; p < 9; ++p) xb[p] = ring[(9 + p) * ldc + id];      // X of block mid - 1: the bottom sweep's last rows
-                chain_upd_c<1, 9>(x, E + 81 * kt, xb);
+                chain_upd_c<9, 1>(x, E + 81 * kt, xb);
             }
         } else if (act && cpl_task && !(half == 0 && last)) {
             const int cc = id - Rc - 1;
@@ -2121,6 +2116,7 @@ NOINL double chain_schur(const Ctx& c_in, const SolveLds& m_in, const double* bu
         if (act && (col_task || !(half == 0 && last))) {
             const lds_d* Lk = D + 81 * k;
             const lds_d* dk = dinv + 9 * k;
+
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
                 double s = x[r];
@@ -2134,11 +2130,12 @@ NOINL double chain_schur(const Ctx& c_in, const SolveLds& m_in, const double* bu
 #pragma unroll
                 for (int r = 0; r < 9; ++r) { ro[r * ldc] = x[r]; po[(size_t)r * ldc] = x[r]; xprev[r] = x[r]; }
             } else {
+                // (all reads of the slot -- the cpl loads of (A) -- are behind the barrier: the bottom block's rows can come back
+                //  transposed, as [p][c] like the top sweep's Xe)
                 const int cc = id - Rc - 1;
-                lds_d* e = half == 0 ? E + 81 * kt + cc : E + 81 * (kb + 1) + 9 * cc;
-                const int st = half == 0 ? 9 : 1;
+                lds_d* e = (half == 0 ? E + 81 * kt : E + 81 * (kb + 1)) + cc;
 #pragma unroll
-                for (int r = 0; r < 9; ++r) e[r * st] = x[r];
+                for (int r = 0; r < 9; ++r) e[9 * r] = x[r];
             }
         }
         stage_store();                             // (the staging area's readers -- raw_col in (A) -- are behind the barrier above)
@@ -2555,10 +2552,10 @@ NOINL void chain_back_substitute(const Ctx& c_in, const SolveLds& m_in) {
             }
         } else {
             for (int k = mid - 1; k >= 0; --k) {
-                const MV* Xu = E + 81 * (k + 1);            // [c][p]
+                const MV* Xu = E + 81 * (k + 1);            // large-window path: [c][p]; single-workgroup path (chain_schur): [p][c]
                 double v = wd[9 * k + r];
 #pragma unroll
-                for (int cc = 0; cc < 9; ++cc) v -= Xu[9 * cc + r] * readlane_d(yprev, cc);
+                for (int cc = 0; cc < 9; ++cc) v -= Xu[BIG ? 9 * cc + r : 9 * r + cc] * readlane_d(yprev, cc);
                 yprev = chain_backsolve9(D + 81 * k, dinv + 9 * k, v, r);
                 if (c.lane < 9) y[Rc + 9 * k + c.lane] = yprev;
             }
@@ -2744,7 +2741,12 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
                     const double* Wt = buf + L.bo_Wt;
                     for (int k = c.tid; k < Rc; k += SV_NT) vU[k] = vSC[k] * vY[k];
                     __syncthreads();
-                    for (int l0 = 0; l0 < nL; l0 += SV_NT / 4) {
+                    // (every pass of 64 landmarks has its own SV_NT partial sums in the scratch: ONE barrier for all passes, and the
+                    //  loads of a pass are not fenced behind the previous pass's reduction)
+                    const int npass = (nL + SV_NT / 4 - 1) / (SV_NT / 4);
+                    const bool own_slots = npass * SV_NT <= 36 * L.ldc;
+                    for (int ps = 0; ps < npass; ++ps) {
+                        const int l0 = ps * (SV_NT / 4);
                         const int l = l0 + (c.tid & (SV_NT / 4 - 1)), qd = c.tid / (SV_NT / 4);
                         double acc = 0.0;
                         if (l < nL) {
@@ -2759,14 +2761,21 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
                             }
                             for (; k < Rc; k += 4) acc += wp[(size_t)k * L.Lcap] * vU[k];
                         }
-                        m.wd[c.tid] = acc;
-                        __syncthreads();
-                        if (qd == 0 && l < nL) {
-                            const double a4 = (m.wd[c.tid] + m.wd[c.tid + SV_NT / 4]) + (m.wd[c.tid + SV_NT / 2] + m.wd[c.tid + 3 * SV_NT / 4]);
-                            const double ht = sl[l] * sl[l] * hh[l] + s.mu * dgl[l] * dgl[l];
-                            yl[l] = (sl[l] * bb[l] - sl[l] * a4) / ht;
+                        double* slot = m.wd + (own_slots ? ps * SV_NT : 0);
+                        slot[c.tid] = acc;
+                        if (!own_slots || ps == npass - 1) {
+                            __syncthreads();
+                            for (int p2 = own_slots ? 0 : ps; p2 <= ps; ++p2) {
+                                const double* sl2 = m.wd + (own_slots ? p2 * SV_NT : 0);
+                                const int l2 = p2 * (SV_NT / 4) + (c.tid & (SV_NT / 4 - 1));
+                                if (qd == 0 && l2 < nL) {
+                                    const double a4 = (sl2[c.tid] + sl2[c.tid + SV_NT / 4]) + (sl2[c.tid + SV_NT / 2] + sl2[c.tid + 3 * SV_NT / 4]);
+                                    const double ht = sl[l2] * sl[l2] * hh[l2] + s.mu * dgl[l2] * dgl[l2];
+                                    yl[l2] = (sl[l2] * bb[l2] - sl[l2] * a4) / ht;
+                                }
+                            }
+                            __syncthreads();
                         }
-                        __syncthreads();
                     }
                     double fin = 0.0;
                     for (int k = c.tid; k < R; k += SV_NT) fin += (vY[k] == vY[k] && fabs(vY[k]) < 1e300) ? 0.0 : 1.0;
