@@ -531,7 +531,7 @@ def fe_traffic():
 def device_info(h=None):
     """What the box reports about its GPU (informational).  The boxes of the pool differ: single-window launches take the same time
     everywhere, launches that fill all 256 CUs with the BA kernels' latency-bound workgroups are up to 1.4 x slower on some of them
-    (DESIGN.md 1.6) -- this object is what a reader can hold such a run against."""
+    (DESIGN.md 1.7) -- this object is what a reader can hold such a run against."""
     info = {}
     try:
         import torch
@@ -850,6 +850,10 @@ def main():
                            "achieved_serial": info['flops'] / ((solve_ms + marg_ms) * 1e-3) / 1e12,
                            "achieved_timed_region": info['flops'] * args.steps / elapsed / 1e12,
                            "frac_timed_region": info['flops'] * args.steps / elapsed / 1e12 / FP64_PEAK_TFLOPS},
+            "reading": "frac = flops of the dominant kernel / its STAND-ALONE launch duration (one stream, launches not overlapped).  Since "
+                       "round 5 the solve kernel is built to share a CU with a second window (4 wavefronts, 72 KB of LDS): alone it is slower "
+                       "than the 8-wavefront kernel of round 4, in the batch two of them overlap -- the figure that shows what the "
+                       "restructuring bought is whole_step.frac_timed_region (flops of a step / the timed region), not this one",
             "note": "ms_per_launch = HIP events after every launch on the launch stream (one stream, steps not overlapped), averaged "
                     "over the passes after the timed region; flops = SURVEY.md 8(d) model split per launch class; traffic = HBM bytes "
                     "per launch from the committed rocprofv3 PMC pass (profiles/pmc_latest.json, FETCH_SIZE x2 per the gfx950 note of "

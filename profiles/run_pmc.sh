@@ -19,3 +19,4 @@ python "$ROOT/profiles/summarize_pmc.py" "$(find $OUT/fetch -name '*.db' | head 
        "$ROOT/gpurun_out/${TAG}_pmc_hbm.json" "$TAG: python bench.py --no-cpu-baseline --steps 5 --in-flight 1" "$BUILD" > "$ROOT/gpurun_out/${TAG}_pmc_hbm.txt" 2>&1
 python "$ROOT/profiles/summarize_counters.py" --merge-into "$ROOT/gpurun_out/${TAG}_pmc_hbm.json" "$(find $OUT/sq -name '*.db' | head -1)" > "$ROOT/gpurun_out/${TAG}_sq_counters.txt" 2>&1
 cat "$ROOT/gpurun_out/${TAG}_pmc_hbm.txt"; tail -12 "$ROOT/gpurun_out/${TAG}_sq_counters.txt"
+rm -rf "$OUT"

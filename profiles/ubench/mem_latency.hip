@@ -1,7 +1,7 @@
 // What a DEPENDENT global-memory round trip costs on this box -- alone and when 256 workgroups (one per CU) ask at once -- and what
 // a launch boundary costs after a kernel that left dirty lines behind.  Round 4: the boxes of the pool run every single-window BA
 // launch and the streaming front-end kernels at the same speed, but launches that fill all 256 CUs with the BA kernels'
-// latency-bound workgroups are 1.2 - 1.4 x slower on some of them (DESIGN.md 1.6); this program is the probe for that difference.
+// latency-bound workgroups are 1.2 - 1.4 x slower on some of them (DESIGN.md 1.7); this program is the probe for that difference.
 //   hipcc --offload-arch=gfx950 -O3 mem_latency.hip -o mem_latency && ./mem_latency        (prints one JSON line)
 #include <hip/hip_runtime.h>
 #include <cstdio>

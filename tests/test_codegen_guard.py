@@ -2,7 +2,7 @@
 their explicit address spaces and their MFMA factorisations.
 
 A pointer handed to a non-inlined device function is generic; every access through it compiles to flat_load / flat_store
-(re-typing the operands as address_space(3) / address_space(1) was worth 17 % of the solve kernel).  A refactor
+(docs/DESIGN_history_r1-r4.md 1.6: re-typing the operands as address_space(3) / address_space(1) was worth 17 % of the solve kernel).  A refactor
 that drops a cast silently brings the flat accesses back without failing any parity test, so the instruction mix of the built
 library is pinned here: a handful of flat loads per function (the by-reference context structs), LDS traffic as ds_*, HBM
 traffic as global_*, and v_mfma_f64_16x16x4 where the dense factors are supposed to use it."""
@@ -138,7 +138,7 @@ def test_solve_kernel_keeps_its_uniform_state_out_of_scratch():
     """The solve kernel's top level holds only wave-uniform state between the calls of its phase functions (layout fields through
     the constant address space, control block through readfirstlane, the phases rebuild their context from the kernel
     arguments): nothing of it may be spilled per lane.  Before that arrangement the kernel carried 712 B of private segment
-    and 202 spilled VGPRs — three quarters of its HBM traffic."""
+    and 202 spilled VGPRs — three quarters of its HBM traffic (docs/DESIGN_history_r1-r4.md 1.6)."""
     if not os.path.exists(OBJDUMP):
         pytest.skip("llvm-objdump of the ROCm toolchain not found")
     md = _kernel_metadata()

@@ -123,7 +123,7 @@ extern "C" int vg_timer_stop(vg_handle* h, float* ms) {
     return VG_OK;
 }
 
-// ---- what kind of box is this?  (DESIGN.md 1.6: boxes of the pool run the latency-bound BA kernels up to 1.4 x apart although they
+// ---- what kind of box is this?  (DESIGN.md 1.7: boxes of the pool run the latency-bound BA kernels up to 1.4 x apart although they
 //      report the same clocks.)  A dependent chain of FP64 FMAs has a fixed latency in CORE cycles, so its wall time (the constant
 //      100 MHz counter) measures the core clock the box really runs at -- once with one lone wavefront, once with every CU loaded
 //      (one workgroup of 4 wavefronts per CU, i.e. still one wavefront per SIMD: a power / clock cap shows as a longer chain) -- and the ratio of the shader-clock counter
