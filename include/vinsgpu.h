@@ -23,11 +23,11 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 10   /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
+#define VG_ABI_VERSION 11   /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
                              * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode; 6: vg_ba_reserve, vg_ba_seq_* (windows that stay on the device);
                              * 7: vg_ba_seq_export / vg_ba_seq_import; 8: vg_host_register, vg_ba_set_fused_min_windows, vg_ba_batch_is_fused;
                              * 9: vg_fe_keep_eig (the min-eigenvalue map is no longer written unless asked for);
-                             * 10: vg_config / vg_create_config; vg_ba_batch_is_fused no longer returns 2 */
+                             * 10: vg_config / vg_create_config; vg_ba_batch_is_fused no longer returns 2; 11: vg_fe_read_image */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {
@@ -518,6 +518,60 @@ int vg_fe_get_level(vg_handle* h, int cam, int which, int level, uint8_t* out, i
 int vg_fe_keep_eig(vg_handle* h, int on);
 int vg_fe_get_eig(vg_handle* h, int cam, float* out);
 int vg_fe_get_mask(vg_handle* h, int cam, uint8_t* out);          /* current device mask of the stream */
+
+/* ---- One call per frame (ABI 11): FeatureTracker::readImage() of ONE stream (a handle configured with n_cams == 1) from `forw_img = img`
+ * to undistortedPoints(), feature_tracker.cpp:81-167, without the host between the steps:
+ *   upload (frame + cur_pts, one block) -> CLAHE -> pyramid -> calcOpticalFlowPyrLK -> status && inBorder -> reduceVector
+ *   publish:      -> liftProjective of both point sets -> findFundamentalMat (RANSAC; sample schedule and iteration bounds resident on the
+ *                    device) -> reduceVector -> [status download, `order` callback, order upload] -> setMask walk -> goodFeaturesToTrack
+ *                    with MAX_CNT - kept corners -> addPoints -> liftProjective of the final list -> ONE download
+ *   not publish:  -> liftProjective of the survivors -> ONE download
+ * The one thing a published frame still asks the host in the middle is the ORDER of setMask's walk: the reference sorts by track_cnt with
+ * std::sort (:48), which is not stable -- the order among equal counts is whatever the platform's sort makes of the sequence, so the
+ * caller's own std::sort call decides it (feature_tracker_readimage.cpp passes a callback that runs the reference's sort).  order == NULL:
+ * the list is walked as it stands -- which IS the stable order by count for a caller that keeps the reference's list discipline (kept
+ * points in walk order, then new points with count 1: the counts are then non-increasing along the list at all times).
+ * Two cases go back to the host inside the call (same results, more round trips): 8 <= survivors < 15 (findFundamentalMat switches to
+ * LMedS) and a RANSAC sample OpenCV would have redrawn for collinearity (its schedule then depends on the points).
+ * All pointers of vg_fe_frame_out point into pinned buffers of the handle and stay valid until the next vg_fe_* call on it. */
+typedef struct vg_fe_frame_out {
+    int n1;                      /* survivors of tracking + border test                                           (:115-124) */
+    int n2;                      /* survivors of rejectWithF (== n1 when it did not run)                          (:193-198) */
+    int ransac_ran;              /* publish && n1 >= 8                                                            (:171)     */
+    int n_kept, n_new;           /* setMask's survivors, new corners (publish only)                               (:64, :149) */
+    int n_final;                 /* length of the list the frame ends with: n_kept + n_new, or n1 when not published          */
+    const uint8_t* status_lk;    /* [n]   calcOpticalFlowPyrLK status && inBorder(forw_pts[i])                               */
+    const uint8_t* status_f;     /* [n1]  findFundamentalMat's mask over the tracking survivors (ransac_ran only)            */
+    const float* forw_xy;        /* [n][2] tracked position of every input point                                             */
+    const int* kept;             /* [n_kept] positions IN THE WALK ORDER of the points setMask kept                          */
+    const float* new_xy;         /* [n_new][2] goodFeaturesToTrack's corners                                                 */
+    const float* un_xy;          /* [n_final][2] liftProjective (x/z, y/z) of the final list: kept points in walk order, then new ones */
+    int ransac_best, ransac_niters, fallback;   /* diagnostics: winning iteration, iterations that counted, RI_FB_* bits that sent the
+                                                   estimate back to the host                                                 */
+} vg_fe_frame_out;
+/* called once per published frame after rejectWithF: `after` holds n1, n2, status_lk, status_f, forw_xy; write the walk order into
+ * order[0 .. n2) as indices into the list of the n2 survivors (a permutation); return 0 (anything else aborts the frame with
+ * VG_ERR_BAD_ARG) */
+typedef int (*vg_fe_order_fn)(void* user, const vg_fe_frame_out* after, int* order);
+typedef struct vg_fe_frame_in {
+    int struct_size;             /* sizeof(vg_fe_frame_in) */
+    const uint8_t* img;          /* the frame, width x height of vg_fe_configure */
+    int stride;                  /* bytes per row */
+    int equalize;                /* EQUALIZE */
+    int publish;                 /* PUB_THIS_FRAME */
+    const float* cur_xy;         /* [n][2] cur_pts */
+    int n;
+    int max_cnt;                 /* MAX_CNT  (<= max_points of vg_fe_configure) */
+    int min_dist;                /* MIN_DIST */
+    double quality;              /* goodFeaturesToTrack qualityLevel: 0.01 at :149 */
+    double f_threshold;          /* F_THRESHOLD */
+    double focal_length;         /* FOCAL_LENGTH (rejectWithF's virtual camera, :178) */
+    double intr[8];              /* PinholeCamera: fx fy cx cy k1 k2 p1 p2 */
+    const uint8_t* base_mask;    /* fisheye_mask (height x width, contiguous) or NULL; uploaded when the pointer changes */
+    vg_fe_order_fn order;        /* or NULL */
+    void* user;
+} vg_fe_frame_in;
+int vg_fe_read_image(vg_handle* h, const vg_fe_frame_in* in, vg_fe_frame_out* out);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,13 @@ class Node:
             m = np.ascontiguousarray(fisheye_mask, np.uint8)
             L.vfe_set_fisheye_mask(m.ctypes.data_as(C.c_void_p), m.shape[1], m.shape[0])
 
+    def gpu_stats(self):
+        """vins_fe_gpu_stats of the drop-in: frames through vg_fe_read_image, published, with rejectWithF, estimates that went back to
+        the host (collinear sample / LMedS range), RANSAC iterations that counted, frames through the step-by-step members"""
+        v = (C.c_int * 8)()
+        self.L.vfe_gpu_stats(v)
+        return dict(zip(("frames", "published", "ransac", "fb_collinear", "fb_lmeds", "niters", "stepwise", "_"), list(v)))
+
     def set_option(self, name, value):
         self.L.vfe_set_option(name.encode(), C.c_double(float(value)))
 

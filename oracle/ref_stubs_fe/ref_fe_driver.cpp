@@ -31,6 +31,7 @@ extern bool init_pub;
 void img_callback(const sensor_msgs::ImageConstPtr& img_msg);
 int vins_ref_fe_node_main(int argc, char** argv);
 extern "C" void vins_fe_gpu_release(FeatureTracker*) __attribute__((weak));      // defined by the drop-in build only
+extern "C" void vins_fe_gpu_stats(FeatureTracker*, int*) __attribute__((weak));
 
 namespace {
 std::vector<const sensor_msgs::PointCloud*> clouds() {
@@ -44,6 +45,11 @@ std::vector<const sensor_msgs::PointCloud*> clouds() {
 extern "C" {
 int vfe_abi_version() { return 1; }
 int vfe_has_gpu_readimage() { return vins_fe_gpu_release != nullptr ? 1 : 0; }
+// how the drop-in ran the frames of tracker 0 so far (vins_fe_gpu_stats of feature_tracker_readimage.cpp); zeros in the all-reference build
+void vfe_gpu_stats(int* out8) {
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (vins_fe_gpu_stats) vins_fe_gpu_stats(&trackerData[0], out8);
+}
 
 // the node from a fresh state: its globals as their initialisers leave them, then its main()
 int vfe_start(const char* config_file, const char* vins_folder) {

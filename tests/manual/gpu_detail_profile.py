@@ -1,4 +1,4 @@
-"""Sub-phase timers of chain_eliminate / schur_mfma / cholesky_aug (library built with -DBA_PROFILE_DETAIL:
+"""Sub-phase timers of chain_schur / cholesky_aug (library built with -DBA_PROFILE_DETAIL:
 make -C vins-mono_amd/csrc OBJDIR=../build_dprof LIB=../lib/libvinsgpu_dprof.so EXTRA=-DBA_PROFILE_DETAIL).  Cycles of thread 0
 (wavefront 0) and thread 128 (wavefront 2) of workgroup 0, summed over the rounds of one solve."""
 import ctypes as C, os, sys

@@ -1,4 +1,4 @@
-"""gpu_detail_profile.py inside a full batch: sub-phase timers of chain_eliminate / schur_mfma / cholesky_aug / assemble (workgroup 0)."""
+"""gpu_detail_profile.py inside a full batch: sub-phase timers of chain_schur / cholesky_aug / assemble (workgroup 0)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

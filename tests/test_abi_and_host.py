@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(pkg):
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     lib.vg_abi_version.restype = C.c_int
-    assert lib.vg_abi_version() == 10 == ba.VG_ABI_VERSION
+    assert lib.vg_abi_version() == 11 == ba.VG_ABI_VERSION
 
 
 def test_config_struct_is_validated_before_any_device_is_touched(pkg):

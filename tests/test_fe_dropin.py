@@ -30,6 +30,9 @@ def _default_config():
     return RF.write_config(path)
 
 
+LAST_STATS = {}
+
+
 def _run(L, frames, config=None, stamps=None, options=(), vins_folder=""):
     node = RF.Node(L, config or _default_config(), vins_folder=vins_folder)
     for k, v in options:
@@ -37,7 +40,18 @@ def _run(L, frames, config=None, stamps=None, options=(), vins_folder=""):
     out = []
     for k, f in enumerate(frames):
         out.append(node.image(100.0 + 0.05 * k if stamps is None else stamps[k], f))
+    LAST_STATS.clear(); LAST_STATS.update(node.gpu_stats())
     return out, node.published(), node.restarts()
+
+
+def _one_call_per_frame(n_frames):
+    """the drop-in run that just ended went through vg_fe_read_image on every frame, rejectWithF ran on the device (no estimate was
+    handed back to the host) and its bookkeeping stopped the iterations early, as OpenCV's loop does"""
+    s = LAST_STATS
+    assert s["frames"] == n_frames - 1 and s["stepwise"] == 0 and 0 < s["published"] < n_frames, s      # (the node drops the first image, :33-39)
+    assert s["ransac"] >= s["published"] - 1 and s["fb_collinear"] == 0 and s["fb_lmeds"] == 0, s
+    assert 0 < s["niters"] < 1000 * s["ransac"], s
+    print("drop-in frames:", s)
 
 
 def _write_fisheye_mask(folder, mask):
@@ -82,6 +96,7 @@ def test_reference_node_with_the_drop_in_on_emulated_kernels():
     ref = _run(RF.lib(), frames)
     _interesting(ref, 24)
     _compare(ref, _run(RF.lib_simt(), frames))
+    _one_call_per_frame(24)
 
 
 @needs_ref
@@ -114,6 +129,8 @@ def test_reference_node_with_the_drop_in_on_the_gpu(tmp_path, equalize, freq):
     if freq == 10:
         _interesting(ref, 40)
     _compare(ref, _run(RF.lib_gpu(), frames, cfg))
+    if freq == 10:
+        _one_call_per_frame(40)
 
 
 @needs_ref

@@ -12,7 +12,7 @@ VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
 VG_MARG_SQRT, VG_MARG_EIGEN = 0, 1     # vg_ba_set_marg_mode
 VG_OK = 0
-VG_ABI_VERSION = 10         # include/vinsgpu.h
+VG_ABI_VERSION = 11         # include/vinsgpu.h
 VG_LAUNCH_DIRECT, VG_LAUNCH_GRAPH = 0, 1   # vg_ba_set_launch_mode
 VG_LAUNCH_DEFAULT = VG_LAUNCH_DIRECT        # include/vinsgpu.h
 VG_PRIOR_RESIDENT = -1

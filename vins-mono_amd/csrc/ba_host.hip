@@ -363,7 +363,6 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.so_gn = o; o += L.Rpad + L.Lcap;
     L.so_yl = o; o += L.Lcap;
     L.so_lsc = o; o += L.Lcap;
-    L.ptab_cap = 0; L.so_ptab = 0; L.so_Hpk = 0;               // (the prior scatter table of rounds 3-4: assemble_small() gathers instead)
     L.so_xp = 0;
     if (!L.big) { L.so_xp = o; o += up(9 * L.K, 4) * L.ldc; }
     if (L.big) {

@@ -92,8 +92,6 @@ struct BaLayout {
     int so_J0t;                                 // J0 transposed (row stride Ncap), written by the prologue
     int so_sc, so_sl, so_dg, so_gt, so_gn;      // Jacobi scaling (R / Lcap), saved Dg, gt, gn over [R | Lcap] for step reuse
     int so_yl, so_lsc;                          // landmark step / sl/sqrt(h~)
-    int so_ptab, so_Hpk, ptab_cap;              // prior scatter table (2 x ptab_cap ints: LDS slot of every prior entry and of its
-                                                // mirror, -1 = none; built once per solve by the prologue) and J0^T J0 packed by entry
     int so_xp;                                  // single-workgroup path: the eliminated speed-bias rows X_k = L_k^-1 [C_k | g_k], [9K][ldc], parked
                                                 // here by the chain elimination for the back substitution (they no longer stay in LDS)
     int so_buf, buf_stride;                     // two linearisation buffers; offsets below are relative to a buffer

@@ -61,7 +61,7 @@ typedef double double4_t __attribute__((vector_size(32)));      // v_mfma_f64_16
 #define PROF_ADD(id)
 #endif
 // finer timers for development (build with -DBA_PROFILE_DETAIL): threads 0 and 128 of workgroup 0 accumulate clock deltas of
-// the sub-phases of chain_eliminate / schur_mfma / cholesky_aug into a device array read back by vg_debug_detail_profile
+// the sub-phases of chain_schur / cholesky_aug / assemble_small into a device array read back by vg_debug_detail_profile
 #ifdef BA_PROFILE_DETAIL
 __device__ double g_dprof[64];
 #define DP_DECL long long _dp = clock64()
@@ -2591,7 +2591,7 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
     PHASE_SELF_CHECK(c);
     double* ctlp = c.sc + L.so_ctl;
     // Everything the first phase reads from HBM is requested in one batch (control block, cost partials of the linearisation
-    // kernels).  The prior column map is not needed here: the prologue kernel left a slot table (so_ptab) for assemble().
+    // kernels).
     const double cs_part = sum_partials(AS_GLB_C(c.sc + L.so_part), L.nbl);
     Ctl s;
     ctl_load(s, ctlp);
@@ -3131,7 +3131,7 @@ NOINL void schur_chain_big(const Ctx& c_in, const SolveLds& m_in, const double* 
     __syncthreads();
 }
 
-// chain_eliminate() for the large-window path, where XC lives in HBM: the same elimination from both ends (same storage
+// The chain elimination of the large-window path, where XC lives in HBM: the same elimination from both ends as chain_schur (storage
 // conventions afterwards, so schur_chain_big / chain_back_substitute do not care), organised so that every element of XC is
 // loaded once and stored once.  Thread `id` of the first / second half of the workgroup owns column id of [C_k | g_k] for
 // the top / bottom sweep and keeps the solved column of the block it eliminated last in registers: the update a block

@@ -3,6 +3,7 @@
 // Replaces the OpenCV calls of FeatureTracker::readImage (feature_tracker/src/feature_tracker.cpp:87-93, :113, :149).
 #include "vg_range.h"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -34,7 +35,30 @@ __global__ void fe_setmask_kernel(FeDev d, const float* pts_xy, const int* track
 __global__ void fe_stamp_kernel(FeDev d, const int* n_kept, const int* kept_xy, int radius);
 __global__ void fe_lift_kernel(const float* pts_xy, int n, double fx, double fy, double cx, double cy, double k1, double k2, double p1,
                                double p2, float* out_xy);
+// vg_fe_read_image (fe_frame.hip, fe_ransac.hip)
+__global__ void fe_ri_after_lk_kernel(FeDev d, RiDev r);
+__global__ void fe_ri_pick_kernel(RiDev r);
+__global__ void fe_ri_setmask_kernel(FeDev d, RiDev r);
+__global__ void fe_ri_finish_kernel(FeDev d, RiDev r);
+__global__ void fe_ransac7_kernel(const float* p1, const float* p2, int n, const int* sched, int nsched, double* models, int* ctl);
+__global__ void fe_ransac_count_kernel(const float* p1, const float* p2, int n, float thresh2, int lmeds, const double* models, int nsched,
+                                       double* Fout, int* count, double* median, unsigned long long* inl_words, const int* ctl);
 }
+hipError_t fe_ransac_buffers(vg_handle* h, FeRansacBufs* b);
+void fe_ransac_tables(int nmax, std::vector<int>& sched, std::vector<int>& niters, int stride);
+
+// resident state of vg_fe_read_image: device arrays (one allocation), their pinned host mirrors, the RANSAC tables
+struct RiState {
+    int cap = 0;
+    char* dev = nullptr;
+    char* host = nullptr;              // pinned: [input block | block A | block B | order]
+    size_t in_bytes = 0, a_bytes = 0, b_bytes = 0;
+    char *d_in = nullptr, *d_a = nullptr, *d_b = nullptr;
+    int *d_order = nullptr, *d_sched = nullptr, *d_tab = nullptr;
+    uint8_t* d_base = nullptr;         // copy of the caller's fisheye mask
+    const uint8_t* base_src = nullptr;
+    RiDev r;
+};
 
 struct FeState {
     FeDev d;
@@ -70,6 +94,7 @@ struct FeState {
     bool have_prev = false;
     bool prev_clobbered = false;     // an upload has overwritten the frame slot the PREVIOUS pyramid uses as its level 0: no tracking until the next build
     std::vector<char> pushed_once;
+    RiState* ri = nullptr;
 };
 
 extern "C" void fe_state_destroy(FeState* s) {
@@ -81,6 +106,11 @@ extern "C" void fe_state_destroy(FeState* s) {
     (void)hipFree(s->ncorners); (void)hipFree(s->ncand); (void)hipFree(s->keys);
     (void)hipFree(s->sm_pts); (void)hipFree(s->sm_cnt); (void)hipFree(s->sm_n); (void)hipFree(s->sm_kidx); (void)hipFree(s->sm_nk);
     (void)hipFree(s->sm_kxy); (void)hipFree(s->sm_base); (void)hipFree((void*)s->sm_base_ptrs); (void)hipFree(s->lift_in); (void)hipFree(s->lift_out);
+    if (s->ri) {
+        (void)hipFree(s->ri->dev); (void)hipFree(s->ri->d_sched); (void)hipFree(s->ri->d_tab); (void)hipFree(s->ri->d_base);
+        (void)hipHostFree(s->ri->host);
+        delete s->ri;
+    }
     delete s;
 }
 
@@ -171,8 +201,7 @@ extern "C" int vg_fe_configure(vg_handle* h, int width, int height, int n_cams, 
     return VG_OK;
 }
 
-extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int stride) {
-    VG_RANGE("vg_fe_upload_frames");
+static int fe_upload_async(vg_handle* h, const uint8_t* const* imgs, int stride) {
     if (!h || !h->fe || !imgs) return VG_ERR_BAD_ARG;
     FeState* s = h->fe;
     const size_t npix = (size_t)s->W * s->H;
@@ -199,6 +228,13 @@ extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int
             else HIPCHK(h, hipMemcpy2DAsync(s->raw2[s->raw_sel] + (size_t)c * npix, s->W, imgs[c], stride, s->W, s->H, hipMemcpyHostToDevice, h->stream));
         }
     }
+    return VG_OK;
+}
+
+extern "C" int vg_fe_upload_frames(vg_handle* h, const uint8_t* const* imgs, int stride) {
+    VG_RANGE("vg_fe_upload_frames");
+    const int rc = fe_upload_async(h, imgs, stride);
+    if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return VG_OK;
 }
@@ -531,5 +567,182 @@ extern "C" int vg_fe_get_eig(vg_handle* h, int cam, float* out) {
     if (!s->d.keep_eig) { h->err = "vg_fe_get_eig: call vg_fe_keep_eig(h, 1) before the detection whose map is wanted"; return VG_ERR_BAD_ARG; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, s->eig + (size_t)cam * s->W * s->H, sizeof(float) * s->W * s->H, hipMemcpyDeviceToHost));
+    return VG_OK;
+}
+
+// ================================================================================================ one call per frame
+static size_t ri_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int ri_ensure(vg_handle* h, FeState* s) {
+    if (s->ri) return VG_OK;
+    RiState* q = new RiState();
+    s->ri = q;
+    const size_t cap = (size_t)s->max_pts;
+    q->cap = (int)cap;
+    // input block: control ints | cur_pts;  block A: header | status_lk | status_f | forw_xy | un_xy;  block B: header | kept | new_xy | un_xy
+    q->in_bytes = ri_up(sizeof(int) * RI_CTL_INTS + sizeof(float) * 2 * cap, 256);
+    const size_t a_st = 64, a_sf = a_st + ri_up(cap, 16), a_fw = a_sf + ri_up(cap, 16), a_un = a_fw + sizeof(float) * 2 * cap;
+    q->a_bytes = ri_up(a_un + sizeof(float) * 2 * cap, 256);
+    const size_t b_k = 64, b_nw = b_k + sizeof(int) * cap, b_un = b_nw + sizeof(float) * 2 * cap;
+    q->b_bytes = ri_up(b_un + sizeof(float) * 2 * cap, 256);
+    const size_t o_idx1 = q->in_bytes + q->a_bytes + q->b_bytes, o_idx2 = o_idx1 + sizeof(int) * cap, o_p1 = o_idx2 + sizeof(int) * cap;
+    const size_t o_p2 = o_p1 + sizeof(float) * 2 * cap, o_ord = o_p2 + sizeof(float) * 2 * cap, o_kxy = o_ord + sizeof(int) * cap;
+    const size_t total = o_kxy + sizeof(int) * 2 * cap;
+    HIPCHK(h, hipMalloc((void**)&q->dev, total));
+    HIPCHK(h, hipMemset(q->dev, 0, total));
+    HIPCHK(h, hipHostMalloc((void**)&q->host, q->in_bytes + q->a_bytes + q->b_bytes + sizeof(int) * cap, 0));
+    memset(q->host, 0, q->in_bytes + q->a_bytes + q->b_bytes + sizeof(int) * cap);
+    q->d_in = q->dev; q->d_a = q->dev + q->in_bytes; q->d_b = q->d_a + q->a_bytes;
+    q->d_order = (int*)(q->dev + o_ord);
+    RiDev& r = q->r;
+    memset(&r, 0, sizeof(r));
+    r.ctl = (int*)q->d_in; r.xy_in = (const float*)(q->d_in + sizeof(int) * RI_CTL_INTS); r.cap = (int)cap;
+    r.idx1 = (int*)(q->dev + o_idx1); r.idx2 = (int*)(q->dev + o_idx2); r.p1 = (float*)(q->dev + o_p1); r.p2 = (float*)(q->dev + o_p2);
+    r.kept_xy = (int*)(q->dev + o_kxy);
+    r.a_hdr = (int*)q->d_a; r.a_status_lk = (uint8_t*)(q->d_a + a_st); r.a_status_f = (uint8_t*)(q->d_a + a_sf);
+    r.a_forw_xy = (float*)(q->d_a + a_fw); r.a_un_xy = (float*)(q->d_a + a_un);
+    r.b_hdr = (int*)q->d_b; r.b_kept = (int*)(q->d_b + b_k); r.b_new_xy = (float*)(q->d_b + b_nw); r.b_un_xy = (float*)(q->d_b + b_un);
+    // the point-independent part of OpenCV's sample schedule and the iteration bounds, for every point count the stream can have
+    const int nmax = (int)std::min<size_t>(cap, FE_RANSAC_MAXPTS);
+    std::vector<int> sched, tab;
+    r.tab_stride = nmax + 1;
+    fe_ransac_tables(nmax, sched, tab, r.tab_stride);
+    HIPCHK(h, hipMalloc((void**)&q->d_sched, sizeof(int) * std::max<size_t>(sched.size(), 1)));
+    HIPCHK(h, hipMalloc((void**)&q->d_tab, sizeof(int) * tab.size()));
+    if (!sched.empty()) HIPCHK(h, hipMemcpy(q->d_sched, sched.data(), sizeof(int) * sched.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(q->d_tab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+    r.niters_tab = q->d_tab;
+    return VG_OK;
+}
+
+extern "C" int vg_fe_read_image(vg_handle* h, const vg_fe_frame_in* in, vg_fe_frame_out* out) {
+    VG_RANGE("vg_fe_read_image");
+    if (!h || !h->fe || !in || !out || in->struct_size != (int)sizeof(vg_fe_frame_in) || !in->img || in->n < 0 || (in->n && !in->cur_xy))
+        return VG_ERR_BAD_ARG;
+    FeState* s = h->fe;
+    if (s->cams != 1) { h->err = "vg_fe_read_image: one stream per handle (vg_fe_configure with n_cams == 1)"; return VG_ERR_UNSUPPORTED; }
+    if (s->max_pts > 2048) { h->err = "vg_fe_read_image: max_points > 2048"; return VG_ERR_UNSUPPORTED; }
+    if (in->n > s->max_pts || in->max_cnt < 0 || in->max_cnt > s->max_pts) { h->err = "vg_fe_read_image: n / max_cnt beyond max_points of vg_fe_configure"; return VG_ERR_BAD_ARG; }
+    if (in->publish && (in->min_dist < 0 || !(in->f_threshold > 0) || !(in->quality > 0))) { h->err = "vg_fe_read_image: min_dist / f_threshold / quality"; return VG_ERR_BAD_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ri_ensure(h, s);
+    if (rc) return rc;
+    RiState* q = s->ri;
+    const size_t npix = (size_t)s->W * s->H, cap = (size_t)q->cap;
+    memset(out, 0, sizeof(*out));
+    RiDev r = q->r;
+    r.focal = in->focal_length; r.half_w = s->W / 2.0; r.half_h = s->H / 2.0;
+    r.fx = in->intr[0]; r.fy = in->intr[1]; r.cx = in->intr[2]; r.cy = in->intr[3];
+    r.k1 = in->intr[4]; r.k2 = in->intr[5]; r.pp1 = in->intr[6]; r.pp2 = in->intr[7];
+    r.max_cnt = in->max_cnt; r.radius = in->min_dist;
+    FeRansacBufs rb;
+    { const hipError_t e = fe_ransac_buffers(h, &rb); if (e != hipSuccess) { h->err = std::string("vg_fe_read_image: ") + hipGetErrorString(e); return VG_ERR_HIP; } }
+    r.count = rb.cnt; r.words = rb.words;
+    // the fisheye mask travels once (the reference loads it at start-up, feature_tracker_node.cpp)
+    if (in->publish && in->base_mask && in->base_mask != q->base_src) {
+        if (!q->d_base) HIPCHK(h, hipMalloc((void**)&q->d_base, npix));
+        HIPCHK(h, hipMemcpyAsync(q->d_base, in->base_mask, npix, hipMemcpyHostToDevice, h->stream));
+        q->base_src = in->base_mask;
+    }
+    r.base_mask = (in->publish && in->base_mask) ? q->d_base : nullptr;
+    // ---- upload: the frame, then ONE block with the control ints and cur_pts
+    const uint8_t* planes[1] = {in->img};
+    rc = fe_upload_async(h, planes, in->stride);
+    if (rc) return rc;
+    int* hctl = (int*)q->host;
+    memset(hctl, 0, sizeof(int) * RI_CTL_INTS);
+    hctl[RI_N] = in->n; hctl[RI_PUBLISH] = in->publish ? 1 : 0; hctl[RI_BEST] = -1;
+    if (in->n) memcpy(q->host + sizeof(int) * RI_CTL_INTS, in->cur_xy, sizeof(float) * 2 * in->n);
+    HIPCHK(h, hipMemcpyAsync(q->d_in, q->host, sizeof(int) * RI_CTL_INTS + sizeof(float) * 2 * in->n, hipMemcpyHostToDevice, h->stream));
+    const bool had_prev = s->have_prev;
+    rc = vg_fe_build_async(h, in->equalize);
+    if (rc) return rc;
+    FeDev d = s->d;
+    d.npts = r.ctl + RI_N; d.prev_xy = r.xy_in;
+    const bool track = in->n > 0;
+    if (track && !had_prev) { h->err = "vg_fe_read_image: points to track but no previous frame"; return VG_ERR_BAD_ARG; }
+    if (track) hipLaunchKernelGGL(fe_lk_kernel, dim3(in->n, 1), dim3(64), 0, h->stream, d);
+    hipLaunchKernelGGL(fe_ri_after_lk_kernel, dim3(1), dim3(256), 0, h->stream, d, r);
+    char* hA = q->host + q->in_bytes;
+    char* hB = hA + q->a_bytes;
+    int* horder = (int*)(hB + q->b_bytes);
+    const int* ahdr = (const int*)hA;
+    out->status_lk = (const uint8_t*)(hA + ((const char*)r.a_status_lk - q->d_a));
+    out->status_f = (const uint8_t*)(hA + ((const char*)r.a_status_f - q->d_a));
+    out->forw_xy = (const float*)(hA + ((const char*)r.a_forw_xy - q->d_a));
+    if (!in->publish) {
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(hA, q->d_a, q->a_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        out->n1 = out->n2 = out->n_final = ahdr[RI_N1];
+        out->un_xy = (const float*)(hA + ((const char*)r.a_un_xy - q->d_a));
+        out->ransac_best = -1;
+        return VG_OK;
+    }
+    // ---- rejectWithF (:169-202); the kernels leave at once when fewer than 15 points survived the tracking
+    if (in->n >= 15) {
+        const float thresh2 = (float)(in->f_threshold * in->f_threshold);
+        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((FE_RANSAC_MAXIT + 63) / 64), dim3(64), 0, h->stream, (const float*)r.p1, (const float*)r.p2, 0,
+                           (const int*)q->d_sched, FE_RANSAC_MAXIT, rb.models, r.ctl);
+        hipLaunchKernelGGL(fe_ransac_count_kernel, dim3(FE_RANSAC_MAXIT), dim3(64), 0, h->stream, (const float*)r.p1, (const float*)r.p2, 0, thresh2, 0,
+                           (const double*)rb.models, FE_RANSAC_MAXIT, rb.F, rb.cnt, rb.med, rb.words, (const int*)r.ctl);
+        hipLaunchKernelGGL(fe_ri_pick_kernel, dim3(1), dim3(256), 0, h->stream, r);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(hA, q->d_a, (size_t)((const char*)r.a_un_xy - q->d_a), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out->n1 = ahdr[RI_N1]; out->n2 = ahdr[RI_N2]; out->ransac_ran = ahdr[RI_RANSAC]; out->fallback = ahdr[RI_FALLBACK];
+    out->ransac_best = ahdr[RI_BEST]; out->ransac_niters = ahdr[RI_NITERS];
+    if (out->n1 < 0 || out->n1 > in->n || out->n2 < 0 || out->n2 > out->n1) { h->err = "vg_fe_read_image: inconsistent counts from the device"; return VG_ERR_NUMERIC; }
+    if (out->fallback) {
+        // The device could not finish the estimate by itself (LMedS range, or a sample OpenCV would have redrawn): the lifted point
+        // sets come back, vg_fe_reject_with_f runs the exact schedule, and the survivor list goes up again.
+        const int n1 = out->n1;
+        std::vector<float> pp((size_t)4 * n1);
+        HIPCHK(h, hipMemcpyAsync(pp.data(), r.p1, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(pp.data() + 2 * n1, r.p2, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        uint8_t* sf = (uint8_t*)(hA + ((const char*)r.a_status_f - q->d_a));
+        rc = vg_fe_reject_with_f(h, pp.data(), pp.data() + 2 * n1, n1, in->f_threshold, sf, nullptr, nullptr);
+        if (rc) return rc;
+        std::vector<int> idx2;
+        for (int i = 0, k = 0; i < in->n; ++i)
+            if (out->status_lk[i]) { if (sf[k]) idx2.push_back(i); ++k; }
+        out->n2 = (int)idx2.size();
+        if (out->n2) HIPCHK(h, hipMemcpy(r.idx2, idx2.data(), sizeof(int) * idx2.size(), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(r.ctl + RI_N2, &out->n2, sizeof(int), hipMemcpyHostToDevice));
+        out->ransac_best = -1; out->ransac_niters = 0;
+    }
+    // ---- setMask (:36-69): the order of the walk is the caller's (see include/vinsgpu.h)
+    const int n2 = out->n2;
+    if (in->order && n2 > 0) {
+        for (int k = 0; k < n2; ++k) horder[k] = -1;
+        if (in->order(in->user, out, horder) != 0) { h->err = "vg_fe_read_image: the order callback failed"; return VG_ERR_BAD_ARG; }
+        std::vector<char> seen((size_t)n2, 0);
+        for (int k = 0; k < n2; ++k) {
+            if (horder[k] < 0 || horder[k] >= n2 || seen[horder[k]]) { h->err = "vg_fe_read_image: the order callback did not return a permutation"; return VG_ERR_BAD_ARG; }
+            seen[horder[k]] = 1;
+        }
+        HIPCHK(h, hipMemcpyAsync(q->d_order, horder, sizeof(int) * n2, hipMemcpyHostToDevice, h->stream));
+        r.order = q->d_order;
+    } else
+        r.order = nullptr;
+    if (r.base_mask) HIPCHK(h, hipMemcpyAsync(s->mask, q->d_base, npix, hipMemcpyDeviceToDevice, h->stream));
+    else HIPCHK(h, hipMemsetAsync(s->mask, 255, npix, h->stream));
+    hipLaunchKernelGGL(fe_ri_setmask_kernel, dim3(1), dim3(256), 0, h->stream, d, r);
+    if (n2 > 0) hipLaunchKernelGGL(fe_stamp_kernel, dim3(n2, 1), dim3(256), 0, h->stream, d, (const int*)(r.ctl + RI_NK), (const int*)r.kept_xy, in->min_dist);
+    // ---- goodFeaturesToTrack(forw_img, n_pts, MAX_CNT - forw_pts.size(), 0.01, MIN_DIST, mask) (:144-149) + addPoints + undistortedPoints
+    rc = vg_fe_detect_async(h, in->quality, (double)in->min_dist);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fe_ri_finish_kernel, dim3(1), dim3(256), 0, h->stream, d, r);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(hB, q->d_b, q->b_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int* bhdr = (const int*)hB;
+    if (bhdr[RI_NNEW] < 0) { h->err = "goodFeaturesToTrack: candidate list overflow (more 3x3 maxima than the key buffer holds)"; return VG_ERR_UNSUPPORTED; }
+    out->n_kept = bhdr[RI_NK]; out->n_new = bhdr[RI_NNEW]; out->n_final = out->n_kept + out->n_new;
+    out->kept = (const int*)(hB + ((const char*)r.b_kept - q->d_b));
+    out->new_xy = (const float*)(hB + ((const char*)r.b_new_xy - q->d_b));
+    out->un_xy = (const float*)(hB + ((const char*)r.b_un_xy - q->d_b));
     return VG_OK;
 }

@@ -25,11 +25,10 @@
 #include <chrono>
 #include <vector>
 #include "ba_math.h"
+#include "fe_layout.h"
 #include "vg_handle.h"
 #include "../../include/vinsgpu.h"
 
-#define FE_RANSAC_MAXIT 1000
-#define FE_RANSAC_MAXPTS 1024
 #define FE_LMEDS_MAXPTS 14
 
 // error of correspondence (x1,y1) -> (x2,y2) under F (row-major 3x3), FMEstimatorCallback::computeError
@@ -90,8 +89,35 @@ DEV bool fr_model_before(const double* Fa, const double* Fb) {
 // First half of an iteration of the schedule, one thread per sample: run7Point -> the up-to-three models of the sample
 // (models[k][3][9]; fe_ransac_count_kernel ranks them: the best model of the sample (F[k][9]) and that model's inlier count
 // (lmeds == 0) or median error (lmeds != 0, n <= FE_LMEDS_MAXPTS); count -1 = the sample gave no model).
+// haveCollinearPoints() of the registrator for one point set: is the LAST point of the sample collinear with two earlier ones (the
+// same double expressions as last_point_collinear() below; this file is compiled with -ffp-contract=off)
+DEV bool fr_last_collinear(const float* __restrict__ p, const int* idx) {
+    bool col = false;
+    const double xi = p[2 * idx[6]], yi = p[2 * idx[6] + 1];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double dx1 = (double)p[2 * idx[j]] - xi, dy1 = (double)p[2 * idx[j] + 1] - yi;
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            const double dx2 = (double)p[2 * idx[k]] - xi, dy2 = (double)p[2 * idx[k] + 1] - yi;
+            col = col || fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
+        }
+    }
+    return col;
+}
+
+// `ctl` (vg_fe_read_image: the call runs without the host in between): the number of correspondences is ctl[RI_N1], the schedule
+// is row n - 15 of the resident table of point-independent schedules, and a sample OpenCV would have REDRAWN (its last point
+// collinear with two earlier ones, which depends on the points) raises ctl[RI_FALLBACK] -- the host then repeats the estimate
+// with the exact schedule.  ctl == nullptr: the arguments are what they say (vg_fe_reject_with_f).
 extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n,
-                                                                   const int* __restrict__ sched, int nsched, double* __restrict__ models) {
+                                                                   const int* __restrict__ sched, int nsched, double* __restrict__ models,
+                                                                   int* __restrict__ ctl) {
+    if (ctl) {
+        n = ctl[RI_N1];
+        if (n < 15 || n > FE_RANSAC_MAXPTS || ctl[RI_PUBLISH] == 0) return;
+        sched += (size_t)(n - 15) * 7 * FE_RANSAC_MAXIT;
+    }
     // The design matrix (element (row r, col c) at A[r * 9 + c]) and the accumulated right singular vectors live in REGISTERS (round
     // 4; they were thread-private LDS columns): every loop over rows, columns and column pairs below is unrolled, so every index is
     // a constant -- 144 register pairs of the 256 a lone wavefront per SIMD may use, no LDS round trip inside the rotations (the
@@ -102,6 +128,7 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* 
     int idx[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) idx[i] = live ? sched[(size_t)k * 7 + i] : i;
+    if (ctl && live && (fr_last_collinear(p1, idx) || fr_last_collinear(p2, idx))) atomicOr(&ctl[RI_FALLBACK], RI_FB_COLLINEAR);
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const double x0 = p1[2 * idx[i]], y0 = p1[2 * idx[i] + 1], x1 = p2[2 * idx[i]], y1 = p2[2 * idx[i] + 1];
@@ -216,8 +243,12 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* 
 extern "C" __global__ __launch_bounds__(64) void fe_ransac_count_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n, float thresh2,
                                                                         int lmeds, const double* __restrict__ models, int nsched,
                                                                         double* __restrict__ Fout, int* __restrict__ count, double* __restrict__ median,
-                                                                        unsigned long long* __restrict__ inl_words) {
+                                                                        unsigned long long* __restrict__ inl_words, const int* __restrict__ ctl) {
     const int k = blockIdx.x, lane = threadIdx.x;
+    if (ctl) {
+        n = ctl[RI_N1];
+        if (n < 15 || n > FE_RANSAC_MAXPTS || ctl[RI_PUBLISH] == 0) return;
+    }
     if (k >= nsched) return;
     const int nw = (n + 63) >> 6;
     double bestF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -321,7 +352,7 @@ bool get_subset(CvRng& rng, const float* p1, const float* p2, int n, int* idx, i
             }
             ++i;
         }
-        if (i == 7 && (last_point_collinear(p1, idx, 7) || last_point_collinear(p2, idx, 7))) continue;
+        if (i == 7 && p1 && (last_point_collinear(p1, idx, 7) || last_point_collinear(p2, idx, 7))) continue;     // (p1 == nullptr: the part of the schedule that depends on n only)
         break;
     }
     return i == 7 && iters < max_attempts;
@@ -336,6 +367,40 @@ int update_num_iters(double p, double ep, int model_points, int max_iters) {    
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::nearbyint(num / denom);
 }
 }  // namespace
+
+// Device scratch of the estimate: one allocation for the life of the handle (n <= FE_RANSAC_MAXPTS).  The call sits on the per-frame
+// path, and hipFree synchronises the whole device — it would stall the BA handle's asynchronous marginalization / state download.
+hipError_t fe_ransac_buffers(vg_handle* h, FeRansacBufs* b) {
+    const size_t off_F = sizeof(float) * 4 * FE_RANSAC_MAXPTS, off_m = off_F + sizeof(double) * 9 * FE_RANSAC_MAXIT;
+    const size_t off_i = off_m + sizeof(double) * FE_RANSAC_MAXIT, off_sc = off_i + sizeof(int) * FE_RANSAC_MAXIT;
+    const size_t off_s = off_sc + sizeof(int) * 7 * FE_RANSAC_MAXIT, off_md = (off_s + FE_RANSAC_MAXPTS + 255) / 256 * 256;
+    const size_t off_w = off_md + sizeof(double) * 27 * FE_RANSAC_MAXIT, total = off_w + sizeof(unsigned long long) * (FE_RANSAC_MAXPTS / 64) * FE_RANSAC_MAXIT;
+    if (!h->ransac_buf) {
+        const hipError_t e = hipMalloc(&h->ransac_buf, total);
+        if (e != hipSuccess) { h->ransac_buf = nullptr; return e; }
+    }
+    char* base = (char*)h->ransac_buf;
+    b->p = (float*)base; b->F = (double*)(base + off_F); b->med = (double*)(base + off_m); b->cnt = (int*)(base + off_i);
+    b->sched = (int*)(base + off_sc); b->s = (unsigned char*)(base + off_s); b->models = (double*)(base + off_md);
+    b->words = (unsigned long long*)(base + off_w);
+    return hipSuccess;
+}
+
+// What vg_fe_read_image keeps resident so that rejectWithF needs no host in the middle of a frame: for every n in [15, nmax] the sample
+// schedule as far as it depends on n alone (the draws of cv::RNG((uint64)-1) and the redraws of an index already in the sample; the
+// collinearity redraws depend on the points: fe_ransac7_kernel detects a sample that needed one) and, by inlier count c, the iteration
+// bound RANSACUpdateNumIters(0.99, (n - c) / n, 7, 1000) -- computed HERE, with the host's libm, so that the device's bookkeeping takes
+// the very decisions of the host's.  sched: [(nmax - 14)][FE_RANSAC_MAXIT][7], niters: [(nmax + 1)][stride].
+void fe_ransac_tables(int nmax, std::vector<int>& sched, std::vector<int>& niters, int stride) {
+    sched.assign((size_t)std::max(nmax - 14, 0) * FE_RANSAC_MAXIT * 7, 0);
+    niters.assign((size_t)(nmax + 1) * stride, FE_RANSAC_MAXIT);
+    for (int n = 15; n <= nmax; ++n) {
+        CvRng rng((unsigned long long)-1);
+        int* row = sched.data() + (size_t)(n - 15) * FE_RANSAC_MAXIT * 7;
+        for (int it = 0; it < FE_RANSAC_MAXIT; ++it) get_subset(rng, nullptr, nullptr, n, row + (size_t)it * 7, 10000);
+        for (int c = 0; c <= n; ++c) niters[(size_t)n * stride + c] = update_num_iters(0.99, (double)(n - c) / n, 7, FE_RANSAC_MAXIT);
+    }
+}
 
 extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const float* forw_un_xy, int n, double threshold, uint8_t* status,
                                    int* n_inliers, double* F_out) {
@@ -363,22 +428,13 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
             if (!get_subset(rng, cur_un_xy, forw_un_xy, n, sched.data() + (size_t)nsched * 7, lmeds ? 1000 : 10000)) break;
     }
     const double ms_sched = since(t_begin);
-    // One allocation for the life of the handle (n <= FE_RANSAC_MAXPTS): this call sits on the per-frame path, and hipFree
-    // synchronises the whole device — it would stall the BA handle's asynchronous marginalization / state download.
-    const size_t off_F = sizeof(float) * 4 * FE_RANSAC_MAXPTS, off_m = off_F + sizeof(double) * 9 * FE_RANSAC_MAXIT;
-    const size_t off_i = off_m + sizeof(double) * FE_RANSAC_MAXIT, off_sc = off_i + sizeof(int) * FE_RANSAC_MAXIT;
-    const size_t off_s = off_sc + sizeof(int) * 7 * FE_RANSAC_MAXIT, off_md = (off_s + FE_RANSAC_MAXPTS + 255) / 256 * 256;
-    const size_t off_w = off_md + sizeof(double) * 27 * FE_RANSAC_MAXIT, total = off_w + sizeof(unsigned long long) * (FE_RANSAC_MAXPTS / 64) * FE_RANSAC_MAXIT;
-    if (!h->ransac_buf && (e = hipMalloc(&h->ransac_buf, total)) != hipSuccess) { h->ransac_buf = nullptr; return fail(e); }
-    char* base = (char*)h->ransac_buf;
-    float* d_p = (float*)base;
-    double* d_F = (double*)(base + off_F);
-    double* d_med = (double*)(base + off_m);
-    int* d_cnt = (int*)(base + off_i);
-    int* d_sched = (int*)(base + off_sc);
-    unsigned char* d_s = (unsigned char*)(base + off_s);
-    double* d_models = (double*)(base + off_md);                              // [iteration][3][9]
-    unsigned long long* d_words = (unsigned long long*)(base + off_w);        // [iteration][ceil(n / 64)] inlier ballots of the iteration's model
+    FeRansacBufs rb;
+    if ((e = fe_ransac_buffers(h, &rb)) != hipSuccess) return fail(e);
+    float* d_p = rb.p;
+    double *d_F = rb.F, *d_med = rb.med, *d_models = rb.models;
+    int *d_cnt = rb.cnt, *d_sched = rb.sched;
+    unsigned char* d_s = rb.s;
+    unsigned long long* d_words = rb.words;
     int best = -1, n_in = n;
     double t2_mask = threshold * threshold;
     if (nsched > 0) {
@@ -386,9 +442,9 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
         if ((e = hipMemcpyAsync(d_p + 2 * n, forw_un_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
         if ((e = hipMemcpyAsync(d_sched, sched.data(), sizeof(int) * 7 * nsched, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
         const float thresh2 = (float)(threshold * threshold);
-        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((nsched + 63) / 64), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, d_sched, nsched, d_models);
+        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((nsched + 63) / 64), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, d_sched, nsched, d_models, (int*)nullptr);
         hipLaunchKernelGGL(fe_ransac_count_kernel, dim3(nsched), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, thresh2, lmeds ? 1 : 0, d_models, nsched,
-                           d_F, d_cnt, d_med, d_words);
+                           d_F, d_cnt, d_med, d_words, (const int*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e);
         const int nw = (n + 63) / 64;
         std::vector<int> cnt(nsched);
