@@ -74,7 +74,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_ri_after_lk_kernel(FeDev d,
         double ux, uy;
         ri_lift(r, d.next_xy[2 * i], d.next_xy[2 * i + 1], ux, uy);
         if (!publish) {                                             // undistortedPoints of the list this frame ends with (:262-267)
-            r.a_un_xy[2 * k] = (float)(ux / 1.0); r.a_un_xy[2 * k + 1] = (float)(uy / 1.0);
+            r.a_un_xy[2 * k] = (float)ux; r.a_un_xy[2 * k + 1] = (float)uy;
         } else {
             if (ransac) {                                           // :176-187: FOCAL_LENGTH * x / z + COL / 2.0, rounded to float by cv::Point2f
                 r.p2[2 * k] = (float)(r.focal * ux / 1.0 + r.half_w); r.p2[2 * k + 1] = (float)(r.focal * uy / 1.0 + r.half_h);
@@ -150,49 +150,57 @@ extern "C" __global__ __launch_bounds__(256) void fe_ri_pick_kernel(RiDev r) {
 
 // setMask (:36-69) in a given order: position q of the walk is survivor order[q] (order == nullptr: the list as it stands).  A point is
 // kept iff its rounded position is inside the image, the base mask there is 255 and no previously kept point's filled disc covers it
-// (fe_setmask_kernel of fe_kernels.hip has the derivation; here the rounded positions and the base-mask test are staged in LDS by all
-// threads first, so the sequential walk of wavefront 0 touches LDS only).  Also: n_max_cnt = MAX_CNT - kept (:144) for the detection.
+// (fe_setmask_kernel of fe_kernels.hip has the derivation).  One wavefront, 64 positions of the walk at a time, one per lane:
+//   1. every lane tests ITS point against the points kept in earlier chunks (their coordinates are read from LDS at a uniform address);
+//   2. inside the chunk the walk is sequential over the lanes that are still alive (s_ff1 over the ballot): the first one is kept, its
+//      coordinates go to all lanes through v_readlane, every later lane it covers drops out -- ten instructions per kept point instead of
+//      an LDS round trip per candidate (48 us -> see DESIGN.md for 150 points);
+//   3. the kept lanes store their results side by side (prefix popcount).
+// Also: n_max_cnt = MAX_CNT - kept (:144) for the detection.
 #define RI_SETMASK_MAX 2048
-extern "C" __global__ __launch_bounds__(256) void fe_ri_setmask_kernel(FeDev d, RiDev r) {
-    __shared__ short ox[RI_SETMASK_MAX], oy[RI_SETMASK_MAX], kx[RI_SETMASK_MAX], ky[RI_SETMASK_MAX];
-    __shared__ uint8_t okf[RI_SETMASK_MAX];
-    const int tid = threadIdx.x, lane = tid & 63, W = d.W, H = d.H;
+extern "C" __global__ __launch_bounds__(64) void fe_ri_setmask_kernel(FeDev d, RiDev r) {
+    __shared__ short kx[RI_SETMASK_MAX], ky[RI_SETMASK_MAX];
+    const int lane = threadIdx.x, W = d.W, H = d.H;
     const int n2 = r.ctl[RI_N2];
-    for (int q = tid; q < n2; q += 256) {
-        const int i = r.idx2[r.order ? r.order[q] : q];
-        const int px = __float2int_rn(d.next_xy[2 * i]), py = __float2int_rn(d.next_xy[2 * i + 1]);      // Point2f -> Point: round half to even
-        bool ok = px >= 0 && py >= 0 && px < W && py < H;
-        if (ok && r.base_mask) ok = r.base_mask[(size_t)py * W + px] == 255;
-        ox[q] = (short)px; oy[q] = (short)py; okf[q] = ok ? 1 : 0;
+    const int r2 = r.radius * r.radius;
+    int nk = 0;
+    for (int base = 0; base < n2; base += 64) {
+        const int q = base + lane;
+        int px = 0, py = 0;
+        bool alive = false;
+        if (q < n2) {
+            const int i = r.idx2[r.order ? r.order[q] : q];
+            px = __float2int_rn(d.next_xy[2 * i]); py = __float2int_rn(d.next_xy[2 * i + 1]);      // Point2f -> Point: round half to even
+            alive = px >= 0 && py >= 0 && px < W && py < H;
+            if (alive && r.base_mask) alive = r.base_mask[(size_t)py * W + px] == 255;
+        }
+        for (int j = 0; j < nk; ++j) {
+            const int dx = px - kx[j], dy = py - ky[j];
+            alive = alive && !(dx * dx + dy * dy <= r2);
+        }
+        unsigned long long am = __ballot(alive), keptm = 0ull;
+        while (am) {
+            const int j = __ffsll((long long)am) - 1;
+            keptm |= 1ull << j;
+            const int jx = __shfl(px, j), jy = __shfl(py, j);
+            const int dx = px - jx, dy = py - jy;
+            alive = alive && lane > j && !(dx * dx + dy * dy <= r2);
+            am = __ballot(alive);
+        }
+        if ((keptm >> lane) & 1ull) {
+            const int k = nk + __popcll(keptm & ((1ull << lane) - 1ull));
+            kx[k] = (short)px; ky[k] = (short)py;
+            r.b_kept[k] = q;
+            r.kept_xy[2 * k] = px; r.kept_xy[2 * k + 1] = py;
+        }
+        nk += __popcll(keptm);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    if (tid < 64) {
-        const int r2 = r.radius * r.radius;
-        int nk = 0;
-        for (int q = 0; q < n2; ++q) {
-            if (!okf[q]) continue;
-            const int px = ox[q], py = oy[q];
-            bool cov = false;
-            for (int base = 0; base < nk; base += 64) {
-                const int j = base + lane;
-                if (j < nk) { const int dx = px - kx[j], dy = py - ky[j]; cov = cov || (dx * dx + dy * dy <= r2); }
-            }
-            if (!__any(cov)) {
-                if (lane == 0) {
-                    kx[nk] = (short)px; ky[nk] = (short)py;
-                    r.b_kept[nk] = q;
-                    r.kept_xy[2 * nk] = px; r.kept_xy[2 * nk + 1] = py;
-                }
-                ++nk;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (lane == 0) {
-            r.ctl[RI_NK] = nk;
-            const int room = r.max_cnt - nk;
-            const_cast<int*>(d.max_corners)[0] = room > 0 ? (room < d.max_pts ? room : d.max_pts) : 0;
-        }
+    if (lane == 0) {
+        r.ctl[RI_NK] = nk;
+        const int room = r.max_cnt - nk;
+        const_cast<int*>(d.max_corners)[0] = room > 0 ? (room < d.max_pts ? room : d.max_pts) : 0;
     }
 }
 
@@ -215,7 +223,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_ri_finish_kernel(FeDev d, R
         }
         double ux, uy;
         ri_lift(r, x, y, ux, uy);
-        r.b_un_xy[2 * k] = (float)(ux / 1.0); r.b_un_xy[2 * k + 1] = (float)(uy / 1.0);
+        r.b_un_xy[2 * k] = (float)ux; r.b_un_xy[2 * k + 1] = (float)uy;
     }
     if (tid == 0) {
         r.ctl[RI_NNEW] = nc;

@@ -682,7 +682,7 @@ extern "C" int vg_fe_read_image(vg_handle* h, const vg_fe_frame_in* in, vg_fe_fr
     // ---- rejectWithF (:169-202); the kernels leave at once when fewer than 15 points survived the tracking
     if (in->n >= 15) {
         const float thresh2 = (float)(in->f_threshold * in->f_threshold);
-        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((FE_RANSAC_MAXIT + 63) / 64), dim3(64), 0, h->stream, (const float*)r.p1, (const float*)r.p2, 0,
+        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((FE_RANSAC_MAXIT + 6) / 7), dim3(64), 0, h->stream, (const float*)r.p1, (const float*)r.p2, 0,
                            (const int*)q->d_sched, FE_RANSAC_MAXIT, rb.models, r.ctl);
         hipLaunchKernelGGL(fe_ransac_count_kernel, dim3(FE_RANSAC_MAXIT), dim3(64), 0, h->stream, (const float*)r.p1, (const float*)r.p2, 0, thresh2, 0,
                            (const double*)rb.models, FE_RANSAC_MAXIT, rb.F, rb.cnt, rb.med, rb.words, (const int*)r.ctl);
@@ -729,7 +729,7 @@ extern "C" int vg_fe_read_image(vg_handle* h, const vg_fe_frame_in* in, vg_fe_fr
         r.order = nullptr;
     if (r.base_mask) HIPCHK(h, hipMemcpyAsync(s->mask, q->d_base, npix, hipMemcpyDeviceToDevice, h->stream));
     else HIPCHK(h, hipMemsetAsync(s->mask, 255, npix, h->stream));
-    hipLaunchKernelGGL(fe_ri_setmask_kernel, dim3(1), dim3(256), 0, h->stream, d, r);
+    hipLaunchKernelGGL(fe_ri_setmask_kernel, dim3(1), dim3(64), 0, h->stream, d, r);
     if (n2 > 0) hipLaunchKernelGGL(fe_stamp_kernel, dim3(n2, 1), dim3(256), 0, h->stream, d, (const int*)(r.ctl + RI_NK), (const int*)r.kept_xy, in->min_dist);
     // ---- goodFeaturesToTrack(forw_img, n_pts, MAX_CNT - forw_pts.size(), 0.01, MIN_DIST, mask) (:144-149) + addPoints + undistortedPoints
     rc = vg_fe_detect_async(h, in->quality, (double)in->min_dist);

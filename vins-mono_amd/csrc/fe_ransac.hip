@@ -106,10 +106,20 @@ DEV bool fr_last_collinear(const float* __restrict__ p, const int* idx) {
     return col;
 }
 
+// NINE LANES PER SAMPLE (round 5; one thread per sample before): lane c of a group owns column c of the 7 x 9 design matrix and of
+// the accumulated right singular vectors, and a sweep of the one-sided Jacobi visits the 36 column pairs as 9 rounds of 4 disjoint
+// pairs (round r pairs the columns with i + j = r mod 9; one column rests) -- the two lanes of a pair exchange their 16 numbers through
+// ds_bpermute and both evaluate the rotation from the same operands in the same order, so they agree to the bit.  The launch has a
+// wavefront per SIMD at most: what it costs is the LENGTH of the dependent instruction sequence, and that is a quarter of the
+// one-thread form's (165 -> see DESIGN.md section 2 for 1000 samples).  Any basis of the two-dimensional null space gives the same
+// pencil of models; the inlier masks are held to the oracle's two-sided Jacobi as before.
+//
 // `ctl` (vg_fe_read_image: the call runs without the host in between): the number of correspondences is ctl[RI_N1], the schedule
 // is row n - 15 of the resident table of point-independent schedules, and a sample OpenCV would have REDRAWN (its last point
 // collinear with two earlier ones, which depends on the points) raises ctl[RI_FALLBACK] -- the host then repeats the estimate
 // with the exact schedule.  ctl == nullptr: the arguments are what they say (vg_fe_reject_with_f).
+#define FR_GROUP 9                       // lanes per sample
+#define FR_PER_WAVE (64 / FR_GROUP)      // 7 samples per wavefront; lane 63 idles
 extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int n,
                                                                    const int* __restrict__ sched, int nsched, double* __restrict__ models,
                                                                    int* __restrict__ ctl) {
@@ -118,90 +128,99 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* 
         if (n < 15 || n > FE_RANSAC_MAXPTS || ctl[RI_PUBLISH] == 0) return;
         sched += (size_t)(n - 15) * 7 * FE_RANSAC_MAXIT;
     }
-    // The design matrix (element (row r, col c) at A[r * 9 + c]) and the accumulated right singular vectors live in REGISTERS (round
-    // 4; they were thread-private LDS columns): every loop over rows, columns and column pairs below is unrolled, so every index is
-    // a constant -- 144 register pairs of the 256 a lone wavefront per SIMD may use, no LDS round trip inside the rotations (the
-    // launch has 16 wavefronts: nothing hides a round trip; 0.33 -> see DESIGN.md section 2).  Same arithmetic in the same order.
-    double A[63], V[81];
-    const int t = threadIdx.x, k = blockIdx.x * 64 + t;
-    const bool live = k < nsched;
+    const int lane = threadIdx.x, g = lane / FR_GROUP, c = lane - FR_GROUP * g;
+    const int k = blockIdx.x * FR_PER_WAVE + g;
+    const bool live = g < FR_PER_WAVE && k < nsched;
+    const int gb = g < FR_PER_WAVE ? FR_GROUP * g : 64 - FR_GROUP;      // first lane of the group (lane 63: any valid lanes; its results are dropped)
     int idx[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) idx[i] = live ? sched[(size_t)k * 7 + i] : i;
-    if (ctl && live && (fr_last_collinear(p1, idx) || fr_last_collinear(p2, idx))) atomicOr(&ctl[RI_FALLBACK], RI_FB_COLLINEAR);
+    if (ctl && live && c == 0 && (fr_last_collinear(p1, idx) || fr_last_collinear(p2, idx))) atomicOr(&ctl[RI_FALLBACK], RI_FB_COLLINEAR);
+    // column c of the design matrix (row i = [x1 x0, x1 y0, x1, y1 x0, y1 y0, y1, x0, y0, 1]) and of the identity
+    double a[7], v[9];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const double x0 = p1[2 * idx[i]], y0 = p1[2 * idx[i] + 1], x1 = p2[2 * idx[i]], y1 = p2[2 * idx[i] + 1];
-        const double row[9] = {x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1.0};
-#pragma unroll
-        for (int c = 0; c < 9; ++c) A[i * 9 + c] = row[c];
+        const double u = c < 3 ? x1 : (c < 6 ? y1 : 1.0);
+        const int cm = c - 3 * (c / 3);
+        const double w = cm == 0 ? x0 : (cm == 1 ? y0 : 1.0);
+        a[i] = u * w;
     }
 #pragma unroll
-    for (int e = 0; e < 81; ++e) V[e] = (e % 10 == 0) ? 1.0 : 0.0;
+    for (int e = 0; e < 9; ++e) v[e] = (e == c) ? 1.0 : 0.0;
     // one-sided Jacobi on the 9 columns: A V = U Sigma; the two columns that end with the smallest norms span the null space.
     // A has rank 7: two columns shrink to rounding noise, and a pair with such a column never passes the orthogonality test (noise
     // against noise) -- it is still rotated when its turn comes, but only rotations between two columns that carry signal (norm^2
-    // above 1e-26 |A|_F^2) keep the sweeps going: ~7 sweeps instead of all 40 (1.7 -> 0.4 ms for the 1000 samples of a frame; any
-    // basis of the null space gives the same pencil of models, and the inlier masks are held to the oracle's two-sided Jacobi).
+    // above 1e-26 |A|_F^2) keep the sweeps going: ~7 sweeps instead of all 40.
     double scale2 = 0.0;
+    {
+        double nn = 0.0;
 #pragma unroll
-    for (int e = 0; e < 63; ++e) scale2 += A[e] * A[e];
+        for (int r = 0; r < 7; ++r) nn += a[r] * a[r];
+#pragma unroll
+        for (int q = 0; q < FR_GROUP; ++q) scale2 += __shfl(nn, gb + q);
+    }
     const double signal = 1e-26 * scale2;
+    const unsigned long long gmask = 0x1ffull << gb;
+    bool active = live;                                    // (uniform over the group; lane 63 and the samples past the schedule rest)
     for (int sweep = 0; sweep < 40; ++sweep) {
         bool rotated = false;
+#pragma unroll 1
+        for (int rd = 0; rd < FR_GROUP; ++rd) {
+            int p = rd - c;
+            p = p < 0 ? p + FR_GROUP : p;
+            const bool lo = c < p;
+            double b[7], w[9];
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
+            for (int r = 0; r < 7; ++r) b[r] = __shfl(a[r], gb + p);
 #pragma unroll
-            for (int q = p + 1; q < 9; ++q) {
-                double al = 0.0, be = 0.0, ga = 0.0;
+            for (int e = 0; e < 9; ++e) w[e] = __shfl(v[e], gb + p);
+            // (al, be, ga) of the pair as the column with the smaller index sees them: both lanes form the same sums
+            double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
-                for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + p], b = A[r * 9 + q]; al += a * a; be += b * b; ga += a * b; }
-                if (fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
-                    rotated = rotated || (al > signal && be > signal);
-                    const double zeta = (be - al) / (2.0 * ga);
-                    const double tn = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double cs = 1.0 / sqrt(1.0 + tn * tn), sn = cs * tn;
-#pragma unroll
-                    for (int r = 0; r < 7; ++r) {
-                        const double a = A[r * 9 + p], b = A[r * 9 + q];
-                        A[r * 9 + p] = cs * a - sn * b; A[r * 9 + q] = sn * a + cs * b;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 9; ++r) {
-                        const double a = V[r * 9 + p], b = V[r * 9 + q];
-                        V[r * 9 + p] = cs * a - sn * b; V[r * 9 + q] = sn * a + cs * b;
-                    }
-                }
+            for (int r = 0; r < 7; ++r) {
+                const double x = lo ? a[r] : b[r], y = lo ? b[r] : a[r];
+                al += x * x; be += y * y; ga += x * y;
             }
-        if (!rotated) break;
+            if (active && p != c && fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
+                rotated = rotated || (al > signal && be > signal);
+                const double zeta = (be - al) / (2.0 * ga);
+                const double tn = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + tn * tn), sn = cs * tn;
+                // column lo: cs x - sn y; column hi: sn x + cs y  (x = the lo column, y = the hi column)
+#pragma unroll
+                for (int r = 0; r < 7; ++r) a[r] = lo ? cs * a[r] - sn * b[r] : sn * b[r] + cs * a[r];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) v[e] = lo ? cs * v[e] - sn * w[e] : sn * w[e] + cs * v[e];
+            }
+        }
+        active = active && (__ballot(rotated) & gmask) != 0ull;
+        if (!__any(active)) break;
     }
     int i2 = 0, i1 = -1;                                  // i2: smallest column norm, i1: second smallest
     {
+        double nn = 0.0;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) nn += a[r] * a[r];
         double nrm[9];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            double nn = 0.0;
-#pragma unroll
-            for (int r = 0; r < 7; ++r) { const double a = A[r * 9 + c]; nn += a * a; }
-            nrm[c] = nn;
-        }
+        for (int q = 0; q < FR_GROUP; ++q) nrm[q] = __shfl(nn, gb + q);
         double n2 = 0.0, n1 = 0.0;
 #pragma unroll
-        for (int c = 0; c < 9; ++c)
-            if (c == 0 || nrm[c] < n2) { n2 = nrm[c]; i2 = c; }
+        for (int q = 0; q < 9; ++q)
+            if (q == 0 || nrm[q] < n2) { n2 = nrm[q]; i2 = q; }
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            if (c == i2) continue;
-            if (i1 < 0 || nrm[c] < n1) { n1 = nrm[c]; i1 = c; }
+        for (int q = 0; q < 9; ++q) {
+            if (q == i2) continue;
+            if (i1 < 0 || nrm[q] < n1) { n1 = nrm[q]; i1 = q; }
         }
     }
-    // (columns i2 and i1 of V picked by compares: a run-time index would send the whole array to scratch memory)
+    // the two null vectors = columns i2 and i1 of V, fetched from the lanes that own them; from here on every lane of the group computes
+    // the same numbers and lane 0 of the group stores them
     double f1[9], f2[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) {
-        double v2 = 0.0, v1 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) { v2 = (c == i2) ? V[e * 9 + c] : v2; v1 = (c == i1) ? V[e * 9 + c] : v1; }
+        const double v2 = __shfl(v[e], gb + i2), v1 = __shfl(v[e], gb + i1);
         f2[e] = v2; f1[e] = v1 - v2;
     }
     double cf[4];
@@ -230,7 +249,7 @@ extern "C" __global__ __launch_bounds__(64) void fe_ransac7_kernel(const float* 
             for (int e = 0; e < 8; ++e) F[e] = f1[e] * lambda + f2[e] * mu;
             for (int e = 0; e < 9; ++e) ok = ok && (F[e] == F[e]) && fabs(F[e]) < 1e300;
         }
-        if (live)
+        if (live && c == 0)
             for (int e = 0; e < 9; ++e) models[((size_t)k * 3 + m) * 9 + e] = ok ? F[e] : __builtin_nan("");
     }
 }
@@ -442,7 +461,7 @@ extern "C" int vg_fe_reject_with_f(vg_handle* h, const float* cur_un_xy, const f
         if ((e = hipMemcpyAsync(d_p + 2 * n, forw_un_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
         if ((e = hipMemcpyAsync(d_sched, sched.data(), sizeof(int) * 7 * nsched, hipMemcpyHostToDevice, h->stream)) != hipSuccess) return fail(e);
         const float thresh2 = (float)(threshold * threshold);
-        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((nsched + 63) / 64), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, d_sched, nsched, d_models, (int*)nullptr);
+        hipLaunchKernelGGL(fe_ransac7_kernel, dim3((nsched + 6) / 7), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, d_sched, nsched, d_models, (int*)nullptr);      // 7 samples per wavefront
         hipLaunchKernelGGL(fe_ransac_count_kernel, dim3(nsched), dim3(64), 0, h->stream, d_p, d_p + 2 * n, n, thresh2, lmeds ? 1 : 0, d_models, nsched,
                            d_F, d_cnt, d_med, d_words, (const int*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e);
