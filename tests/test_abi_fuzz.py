@@ -124,6 +124,25 @@ tr.undistort(np.full((5, 2), np.nan, np.float32), intr)
 stat, Fm = tr.reject_with_f(np.zeros((20, 2), np.float32), np.zeros((20, 2), np.float32), 1.0)
 assert stat.all()                                           # no model: nothing is rejected
 n_ok += 6
+# the one-call frame: refused argument sets, then hostile but legal ones (NaN points, all points identical, a callback that misbehaves)
+for name, fn in (("read_image n > max_points", lambda: tr.read_image(b, pts[:100], True, intr, max_cnt=20)),
+                 ("read_image max_cnt > max_points", lambda: tr.read_image(b, pts[:10], True, intr, max_cnt=500)),
+                 ("read_image f_threshold 0", lambda: tr.read_image(b, pts[:10], True, intr, max_cnt=20, f_threshold=0.0)),
+                 ("read_image order not a permutation", lambda: tr.read_image(b, pts[:30], True, intr, max_cnt=30, min_dist=10,
+                                                                              order=lambda st, sf, fw, n2: np.zeros(n2, np.int32))),
+                 ("read_image order of the wrong length", lambda: tr.read_image(b, pts[:30], True, intr, max_cnt=30, min_dist=10,
+                                                                                order=lambda st, sf, fw, n2: np.arange(n2 + 1)))):
+    try:
+        fn()
+        raise SystemExit("accepted: " + name)
+    except RuntimeError as e:
+        assert "status -" in str(e), e
+        n_err += 1
+o = tr.read_image(a, np.full((20, 2), np.nan, np.float32), True, intr, max_cnt=30, min_dist=10); assert o["n1"] == 0 and o["n_new"] > 0
+o = tr.read_image(b, np.full((30, 2), 77.0, np.float32), True, intr, max_cnt=30, min_dist=10)       # 30 identical correspondences
+assert o["n_kept"] <= 1
+o = tr.read_image(a, np.zeros((0, 2), np.float32), False, intr, max_cnt=20); assert o["n_final"] == 0
+n_ok += 3
 print("OK refused", n_err, "accepted", n_ok)
 """
 

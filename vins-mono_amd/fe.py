@@ -8,6 +8,23 @@ _f4 = C.POINTER(C.c_float)
 _i4 = C.POINTER(C.c_int)
 
 
+class FrameOut(C.Structure):
+    """vg_fe_frame_out (include/vinsgpu.h)"""
+    _fields_ = [("n1", C.c_int), ("n2", C.c_int), ("ransac_ran", C.c_int), ("n_kept", C.c_int), ("n_new", C.c_int), ("n_final", C.c_int),
+                ("status_lk", _u8), ("status_f", _u8), ("forw_xy", _f4), ("kept", _i4), ("new_xy", _f4), ("un_xy", _f4),
+                ("ransac_best", C.c_int), ("ransac_niters", C.c_int), ("fallback", C.c_int)]
+
+
+ORDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(FrameOut), _i4)
+
+
+class FrameIn(C.Structure):
+    """vg_fe_frame_in (include/vinsgpu.h)"""
+    _fields_ = [("struct_size", C.c_int), ("img", _u8), ("stride", C.c_int), ("equalize", C.c_int), ("publish", C.c_int), ("cur_xy", _f4),
+                ("n", C.c_int), ("max_cnt", C.c_int), ("min_dist", C.c_int), ("quality", C.c_double), ("f_threshold", C.c_double),
+                ("focal_length", C.c_double), ("intr", C.c_double * 8), ("base_mask", _u8), ("order", ORDER_FN), ("user", C.c_void_p)]
+
+
 class FrontEnd:
     """`n_cams` camera streams on one vg_handle (ba.Handle)."""
 
@@ -37,6 +54,7 @@ class FrontEnd:
         L.vg_fe_get_mask.argtypes = [C.c_void_p, C.c_int, _u8]
         L.vg_fe_undistort.argtypes = [C.c_void_p, _f4, C.c_int, C.POINTER(C.c_double), _f4]
         L.vg_fe_reject_with_f.argtypes = [C.c_void_p, _f4, _f4, C.c_int, C.c_double, _u8, _i4, C.POINTER(C.c_double)]
+        L.vg_fe_read_image.argtypes = [C.c_void_p, C.POINTER(FrameIn), C.POINTER(FrameOut)]
         self.hd._chk(L.vg_fe_configure(self.h, width, height, n_cams, max_points), "vg_fe_configure")
 
     def _imgs(self, frames):
@@ -150,6 +168,60 @@ class FrontEnd:
                                                   st.ctypes.data_as(_u8), C.byref(ni), Fm.ctypes.data_as(C.POINTER(C.c_double))),
                      "vg_fe_reject_with_f")
         return st, Fm.reshape(3, 3)
+
+    def read_image(self, img, cur_pts, publish, intr, max_cnt=150, min_dist=30, equalize=False, f_threshold=1.0, focal_length=460.0,
+                   quality=0.01, base_mask=None, order=None):
+        """vg_fe_read_image: FeatureTracker::readImage of one stream in one call.  `order(status_lk, status_f or None, forw_xy, n2)` returns
+        the walk order of setMask as indices into the n2 survivors (None: the list as it stands).  Returns a dict of numpy copies."""
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.H, self.W)
+        pts = np.ascontiguousarray(cur_pts, np.float32).reshape(-1, 2)
+        n = pts.shape[0]
+        fin = FrameIn()
+        fin.struct_size = C.sizeof(FrameIn)
+        fin.img = img.ctypes.data_as(_u8); fin.stride = self.W; fin.equalize = int(equalize); fin.publish = int(publish)
+        fin.cur_xy = pts.ctypes.data_as(_f4) if n else None
+        fin.n = n; fin.max_cnt = int(max_cnt); fin.min_dist = int(min_dist); fin.quality = float(quality)
+        fin.f_threshold = float(f_threshold); fin.focal_length = float(focal_length)
+        for i, v in enumerate(intr):
+            fin.intr[i] = float(v)
+        if base_mask is not None:
+            self._base = np.ascontiguousarray(base_mask, np.uint8)
+            assert self._base.shape == (self.H, self.W)
+            fin.base_mask = self._base.ctypes.data_as(_u8)
+        seen = {}
+
+        def _cb(_user, after, out_order):
+            a = after.contents
+            st = np.ctypeslib.as_array(a.status_lk, (max(n, 1),))[:n].copy()
+            sf = np.ctypeslib.as_array(a.status_f, (max(a.n1, 1),))[:a.n1].copy() if a.ransac_ran else None
+            fw = np.ctypeslib.as_array(a.forw_xy, (max(n, 1), 2))[:n].copy()
+            perm = np.asarray(order(st, sf, fw, a.n2), np.int32)
+            seen["n2"] = a.n2
+            if perm.shape != (a.n2,):
+                return 1
+            for q in range(a.n2):
+                out_order[q] = int(perm[q])
+            return 0
+
+        cb = ORDER_FN(_cb) if order is not None else C.cast(None, ORDER_FN)
+        fin.order = cb
+        fo = FrameOut()
+        self.hd._chk(self.lib.vg_fe_read_image(self.h, C.byref(fin), C.byref(fo)), "vg_fe_read_image")
+
+        def arr(ptr, shape):
+            m = int(np.prod(shape))
+            return np.ctypeslib.as_array(ptr, shape).copy() if m and ptr else np.zeros(shape, np.float32 if len(shape) == 2 else np.int32)
+
+        out = dict(n1=fo.n1, n2=fo.n2, ransac_ran=bool(fo.ransac_ran), n_kept=fo.n_kept, n_new=fo.n_new, n_final=fo.n_final,
+                   ransac_best=fo.ransac_best, ransac_niters=fo.ransac_niters, fallback=fo.fallback)
+        out["status_lk"] = arr(fo.status_lk, (n,)).astype(np.uint8)
+        out["status_f"] = arr(fo.status_f, (fo.n1,)).astype(np.uint8) if fo.ransac_ran else None
+        out["forw_xy"] = arr(fo.forw_xy, (n, 2))
+        out["kept"] = arr(fo.kept, (fo.n_kept,)).astype(np.int32) if publish else None
+        out["new_xy"] = arr(fo.new_xy, (fo.n_new, 2)) if publish else None
+        out["un_xy"] = arr(fo.un_xy, (fo.n_final, 2))
+        return out
 
     def detect_upload(self, max_corners, masks=None):
         mc = np.ascontiguousarray(max_corners, np.int32)
