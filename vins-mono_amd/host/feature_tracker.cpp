@@ -1,6 +1,7 @@
 // feature_tracker.cpp — see feature_tracker.h.  Control flow follows feature_tracker/src/feature_tracker.cpp of the
 // reference (cited per block); the arithmetic runs on the GPU through libvinsgpu.so.
 #include "feature_tracker.h"
+#include <cstring>
 #include "yaml_config.h"
 #include <algorithm>
 #include <cmath>
@@ -114,6 +115,58 @@ void FeatureTracker::addPoints() {                            // :71-79
     }
 }
 
+// What readImage does with the statuses of a frame (:115-128, :193-198): forw_pts as the tracking left them, reduceVector by
+// `status && inBorder`, track_cnt++, reduceVector by findFundamentalMat's mask
+void FeatureTracker::applyStatuses(const vg_fe_frame_out& a, int n_in) {
+    forw_pts.resize(n_in);
+    for (int i = 0; i < n_in; i++) forw_pts[i] = cv::Point2f(a.forw_xy[2 * i], a.forw_xy[2 * i + 1]);
+    if (n_in > 0) {
+        vector<uchar> status(a.status_lk, a.status_lk + n_in);
+        reduceVector(prev_pts, status);
+        reduceVector(cur_pts, status);
+        reduceVector(forw_pts, status);
+        reduceVector(ids, status);
+        reduceVector(cur_un_pts, status);
+        reduceVector(track_cnt, status);
+    }
+    for (auto& n : track_cnt) n++;
+    if (a.ransac_ran) {
+        vector<uchar> status(a.status_f, a.status_f + a.n1);
+        reduceVector(prev_pts, status);
+        reduceVector(cur_pts, status);
+        reduceVector(forw_pts, status);
+        reduceVector(cur_un_pts, status);
+        reduceVector(ids, status);
+        reduceVector(track_cnt, status);
+    }
+}
+
+namespace {
+struct OrderCtx {
+    FeatureTracker* t;
+    int n_in;
+    bool applied;
+    vector<pair<int, pair<cv::Point2f, int>>> sorted;      // setMask's cnt_pts_id (:43) with the list index in the place of the id
+};
+// The order of setMask's walk = the reference's sort call (:47-51): std::sort by track_cnt is not stable, the order among equal counts is
+// what the platform's std::sort makes of the sequence; its permutation depends on the comparisons only, and those look at the counts.
+int order_callback(void* user, const vg_fe_frame_out* after, int* order) {
+    OrderCtx* c = static_cast<OrderCtx*>(user);
+    c->t->applyStatuses(*after, c->n_in);
+    c->applied = true;
+    if ((int)c->t->forw_pts.size() != after->n2) return 1;
+    for (unsigned int i = 0; i < c->t->forw_pts.size(); i++) c->sorted.push_back(make_pair(c->t->track_cnt[i], make_pair(c->t->forw_pts[i], (int)i)));
+    sort(c->sorted.begin(), c->sorted.end(),
+         [](const pair<int, pair<cv::Point2f, int>>& a, const pair<int, pair<cv::Point2f, int>>& b) { return a.first > b.first; });
+    for (int q = 0; q < after->n2; q++) order[q] = c->sorted[q].second.second;
+    return 0;
+}
+}  // namespace
+
+// ONE library call per frame (vg_fe_read_image): the frame and cur_pts go up in one block; CLAHE, pyramid, LK, the border test,
+// reduceVector and -- on a published frame -- rejectWithF, setMask's walk, goodFeaturesToTrack, addPoints and the lifting of
+// undistortedPoints run on the device without the host in between; the members setMask() / rejectWithF() / undistortedPoints() remain
+// for callers that drive the steps themselves.
 void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {    // :81-167
     cur_time = _cur_time;
     if (!configured_) {
@@ -122,48 +175,44 @@ void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {    // :8
         chk(vg_fe_configure(vg_, COL, ROW, 1, fe_capacity_), vg_, "vg_fe_configure");
         configured_ = true;
     }
-    // EQUALIZE (CLAHE, :87-93) happens on the device; `forw_img = img` (:97-104) = the device pyramid rotation
-    const uint8_t* planes[1] = {_img.data};
-    chk(vg_fe_push_frames(vg_, planes, (int)_img.step, EQUALIZE), vg_, "vg_fe_push_frames");
+    if ((int)cur_pts.size() > fe_capacity_) throw std::runtime_error("FeatureTracker::readImage: more points than the configured capacity");
+    vg_fe_frame_in in;
+    std::memset(&in, 0, sizeof(in));
+    in.struct_size = (int)sizeof(in);
+    in.img = _img.data; in.stride = (int)_img.step; in.equalize = EQUALIZE; in.publish = PUB_THIS_FRAME ? 1 : 0;
+    in.cur_xy = cur_pts.empty() ? nullptr : &cur_pts[0].x; in.n = (int)cur_pts.size();
+    in.max_cnt = MAX_CNT; in.min_dist = MIN_DIST; in.quality = 0.01; in.f_threshold = F_THRESHOLD; in.focal_length = FOCAL_LENGTH;
+    const double intr[8] = {m_camera.fx, m_camera.fy, m_camera.cx, m_camera.cy, m_camera.k1, m_camera.k2, m_camera.p1, m_camera.p2};
+    std::memcpy(in.intr, intr, sizeof(intr));
+    in.base_mask = (FISHEYE && PUB_THIS_FRAME) ? fisheye_mask.data : nullptr;           // :38-41 (contiguous ROW x COL, readFeatureTrackerParameters)
+    OrderCtx ctx{this, in.n, false, {}};
+    in.order = order_callback; in.user = &ctx;
+    vg_fe_frame_out out;
+    chk(vg_fe_read_image(vg_, &in, &out), vg_, "vg_fe_read_image");
     if (forw_img.empty()) prev_img = cur_img = forw_img = _img;
     else forw_img = _img;
-
-    forw_pts.clear();
-    if (cur_pts.size() > 0) {                                                // :108-125
-        vector<uchar> status(cur_pts.size());
-        vector<float> err(cur_pts.size());
-        forw_pts.resize(cur_pts.size());
-        chk(vg_fe_track(vg_, 0, &cur_pts[0].x, (int)cur_pts.size(), &forw_pts[0].x, status.data(), err.data()), vg_, "vg_fe_track");
-        for (int i = 0; i < int(forw_pts.size()); i++)
-            if (status[i] && !inBorder(forw_pts[i])) status[i] = 0;
-        reduceVector(prev_pts, status);
-        reduceVector(cur_pts, status);
-        reduceVector(forw_pts, status);
-        reduceVector(ids, status);
-        reduceVector(cur_un_pts, status);
-        reduceVector(track_cnt, status);
-    }
-    for (auto& n : track_cnt) n++;                                           // :127-128
-
-    if (PUB_THIS_FRAME) {                                                    // :130-158
-        rejectWithF();
-        setMask();
-        int n_max_cnt = MAX_CNT - static_cast<int>(forw_pts.size());
-        if (n_max_cnt > 0) {
-            n_pts.resize(n_max_cnt);
-            int n = 0;
-            chk(vg_fe_detect_masked(vg_, 0, n_max_cnt, 0.01, (double)MIN_DIST, &n_pts[0].x, &n), vg_, "vg_fe_detect_masked");
-            n_pts.resize(n);
-        } else
-            n_pts.clear();
+    if (!ctx.applied) applyStatuses(out, in.n);
+    if (PUB_THIS_FRAME) {
+        vector<cv::Point2f> kept_pts;                                        // setMask's outcome (:53-68): the kept points in walk order
+        vector<int> kept_ids, kept_cnt;
+        for (int k = 0; k < out.n_kept; k++) {
+            const auto& it = ctx.sorted[out.kept[k]];
+            kept_pts.push_back(it.second.first);
+            kept_ids.push_back(ids[it.second.second]);
+            kept_cnt.push_back(it.first);
+        }
+        forw_pts = kept_pts; ids = kept_ids; track_cnt = kept_cnt;
+        n_pts.clear();                                                       // :144-156
+        for (int k = 0; k < out.n_new; k++) n_pts.push_back(cv::Point2f(out.new_xy[2 * k], out.new_xy[2 * k + 1]));
         addPoints();
     }
+    if ((int)forw_pts.size() != out.n_final) throw std::runtime_error("FeatureTracker::readImage: list length differs from the device's");
     prev_img = cur_img;                                                      // :160-166
     prev_pts = cur_pts;
     prev_un_pts = cur_un_pts;
     cur_img = forw_img;
     cur_pts = forw_pts;
-    undistortedPoints();
+    liftedPoints(out.un_xy);
     prev_time = cur_time;
 }
 
@@ -217,12 +266,18 @@ void FeatureTracker::readIntrinsicParameter(const string& calib_file) {
 }
 
 void FeatureTracker::undistortedPoints() {                                   // :258-306, lifting on the device
-    cur_un_pts.clear();
-    cur_un_pts_map.clear();
     const int n = (int)cur_pts.size();
     std::vector<float> un((size_t)std::max(n, 1) * 2);
     const double intr[8] = {m_camera.fx, m_camera.fy, m_camera.cx, m_camera.cy, m_camera.k1, m_camera.k2, m_camera.p1, m_camera.p2};
     if (n > 0) chk(vg_fe_undistort(vg_, &cur_pts[0].x, n, intr, un.data()), vg_, "vg_fe_undistort");
+    liftedPoints(un.data());
+}
+
+// :262-304 given the lifted (x / z, y / z) pairs of cur_pts
+void FeatureTracker::liftedPoints(const float* un) {
+    cur_un_pts.clear();
+    cur_un_pts_map.clear();
+    const int n = (int)cur_pts.size();
     for (int i = 0; i < n; i++) {
         cur_un_pts.push_back(cv::Point2f(un[2 * i], un[2 * i + 1]));
         cur_un_pts_map.insert(make_pair(ids[i], cv::Point2f(un[2 * i], un[2 * i + 1])));

@@ -1,6 +1,7 @@
 // feature_tracker.h — drop-in FeatureTracker for the MI355X path: same class name, members and method signatures as
-// feature_tracker/src/feature_tracker.h:28-65 of the reference; readImage() keeps the control flow of
-// feature_tracker.cpp:81-167 and replaces the three OpenCV calls by the C-ABI (include/vinsgpu.h):
+// feature_tracker/src/feature_tracker.h:28-65 of the reference.  readImage() is ONE library call per frame, vg_fe_read_image
+// (include/vinsgpu.h); the members setMask / rejectWithF / undistortedPoints keep the step-by-step entry points
+// of feature_tracker.cpp:81-167 for callers that drive the steps themselves:
 //   cv::createCLAHE(...)->apply      -> vg_fe_push_frames(.., equalize)     (:87-93)
 //   cv::calcOpticalFlowPyrLK         -> vg_fe_track                          (:113)
 //   cv::goodFeaturesToTrack          -> vg_fe_detect                         (:149)
@@ -46,6 +47,9 @@ class FeatureTracker {
     void readIntrinsicParameter(const string& calib_file);   // PINHOLE section of the configuration file (host/yaml_config.h)
     void rejectWithF();
     void undistortedPoints();
+    // the two halves of readImage around the library call (public for the order callback; not part of the reference's interface)
+    void applyStatuses(const vg_fe_frame_out& after, int n_in);
+    void liftedPoints(const float* un_xy);
 
     cv::Mat mask;
     cv::Mat fisheye_mask;
