@@ -564,7 +564,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=WINDOWS_PER_GPU)
-    ap.add_argument("--in-flight", type=int, default=4, help="independent batches (HIP streams) the steps are spread over")
+    ap.add_argument("--in-flight", type=int, default=8, help="independent batches (HIP streams) the steps are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-mode", choices=["graph", "direct"], default=None,
                     help="VG_BA_LAUNCH_MODE for every handle of the run (default: the library's, see vg_ba_set_launch_mode)")
@@ -642,7 +642,8 @@ def main():
     # different streams.  Since round 5 a solve workgroup is 4 wavefronts / 72 KB of LDS, so the solve kernels of two batches share
     # CUs (two windows per CU); the factor and marginalization kernels still take a CU each, and launches of other batches fill
     # their tails.  Four in flight: equal to two on the fast kind of box (149.5K vs 150.3K), +9 % on the slow kind (131.6K vs
-    # 120.4K; profiles/r05k_in_flight_slow_box.json, r05l_ab_solve_two_per_cu.json).
+    # 120.4K; profiles/r05k_in_flight_slow_box.json, r05l_ab_solve_two_per_cu.json); eight: another +4 % on the slow kind (136.6K ->
+    # 142.3K, 4 / 6 / 8 / 4 / 8 in one call: profiles/r05x_in_flight_4_6_8.txt) -- the default.
     handles = [h] + [ba.Handle() for _ in range(nfl - 1)]
     seed0 = D.window_seeds(rank, nwin)[0]
     probs, seqs = make_windows(h, ba, synth, nwin, seed0=seed0)
