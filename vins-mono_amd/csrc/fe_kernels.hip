@@ -675,15 +675,62 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
 // The map itself reaches HBM only when the caller asked for it (vg_fe_keep_eig: tests compare it bit by bit).
 #define ME_R 16
 extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d, double quality) {
-    __shared__ uint8_t tile[ME_R + 6][72];                        // rows y0-3 .. y0+R+2, cols x0-3 .. x0+66 (reflected coordinates)
-    __shared__ float gx[ME_R + 4][68], gy[ME_R + 4][68];          // gradients on rows y0-2 .. y0+R+1, cols x0-2 .. x0+65
+    __shared__ __attribute__((aligned(16))) uint8_t tile[ME_R + 6][72];   // rows y0-3 .. y0+R+2, cols x0-4 .. x0+67 (reflected coordinates)
+    __shared__ __attribute__((aligned(16))) float gx[ME_R + 4][68], gy[ME_R + 4][68];   // gradients on rows y0-2 .. y0+R+1, cols x0-2 .. x0+65
     __shared__ float eg[ME_R + 2][66];                            // the map on rows y0-1 .. y0+R, cols x0-1 .. x0+64
+    __shared__ __attribute__((aligned(16))) uint8_t mk[ME_R][64];         // the mask under the tile's own pixels (0 outside the image)
 
     __shared__ float bmax[4];
     __shared__ unsigned wcount[4], wbase[4], lbound;
     const int cam = blockIdx.z, W = d.W, H = d.H;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * ME_R;
     const glb_u8* img = (const glb_u8*)d.cur_planes[cam];          // level 0
+    const glb_u8* gmask = (const glb_u8*)(d.mask + (size_t)cam * W * H);
+    const float k1 = (float)(1.0 / 3060.0), k2 = (float)(2.0 / 3060.0);
+    // A tile whose halo lies inside the image (280 of the 360 tiles of a 752 x 480 frame) needs no reflection anywhere: its pixels and its
+    // mask arrive as aligned 32-bit words (x0 is a multiple of 64, W of 4) and a thread forms FOUR neighbouring gradients from six words
+    // of the tile -- the same float expressions as the general path below, evaluated on the same values (round 5: the byte-by-byte
+    // tile load and the per-pixel gradient with its reflection tests were 500 of the ~1150 instructions of a thread).
+    const bool interior = (W & 3) == 0 && x0 >= 4 && x0 + 68 <= W && y0 >= 3 && y0 + ME_R + 3 <= H;
+    if (interior) {
+        const glb_u8* src = img + (size_t)(y0 - 3) * W + (x0 - 4);
+        for (int k = threadIdx.x; k < (ME_R + 6) * 18; k += 256) {
+            const int yy = k / 18, wx = k - 18 * yy;
+            const unsigned v = *(const glb_u32*)(src + (size_t)yy * W + 4 * wx);
+            __builtin_memcpy(&tile[yy][4 * wx], &v, 4);
+        }
+        {
+            const int ly = threadIdx.x >> 4, wx = threadIdx.x & 15;
+            const unsigned v = *(const glb_u32*)(gmask + (size_t)(y0 + ly) * W + x0 + 4 * wx);
+            __builtin_memcpy(&mk[ly][4 * wx], &v, 4);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < (ME_R + 4) * 17; k += 256) {
+            const int yy = k / 17, g = k - 17 * yy;                // gradient row yy, columns 4g .. 4g+3 = tile row yy + 1, columns 4g+2 .. 4g+5
+            int A[6], B[6], C[6];                                  // tile columns 4g+1 .. 4g+6 of the rows above / at / below
+            {
+                unsigned w[6];
+                __builtin_memcpy(&w[0], &tile[yy][4 * g], 8); __builtin_memcpy(&w[2], &tile[yy + 1][4 * g], 8); __builtin_memcpy(&w[4], &tile[yy + 2][4 * g], 8);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int sh = 8 * ((j + 1) & 3), hi = (j + 1) >> 2;
+                    A[j] = (int)((w[0 + hi] >> sh) & 255u); B[j] = (int)((w[2 + hi] >> sh) & 255u); C[j] = (int)((w[4 + hi] >> sh) & 255u);
+                }
+            }
+            float dxv[4], dyv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float r0 = (float)(A[q + 2] - A[q]);
+                const float r1 = (float)(B[q + 2] - B[q]);
+                const float r2 = (float)(C[q + 2] - C[q]);
+                dxv[q] = k2 * r1 + k1 * (r0 + r2);
+                const float s0 = (float)A[q + 1] * k2 + (float)(A[q] + A[q + 2]) * k1;
+                const float s2 = (float)C[q + 1] * k2 + (float)(C[q] + C[q + 2]) * k1;
+                dyv[q] = s2 - s0;
+            }
+            __builtin_memcpy(&gx[yy][4 * g], dxv, 16); __builtin_memcpy(&gy[yy][4 * g], dyv, 16);
+        }
+    } else {
     auto PX = [&](int y, int x) {                                  // image pixel at reflected coordinates (clamped beyond one reflection:
         int ry = reflect101(y, H), rx = reflect101(x, W);          //  nothing an in-image result depends on lies that far out)
         ry = ry < 0 ? 0 : (ry >= H ? H - 1 : ry);
@@ -694,10 +741,13 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d, doub
         const int yy = k / 70, xx = k - 70 * yy;
         // NB: REFLECT_101 is applied per filter stage in OpenCV (Sobel on the image, then boxFilter on cov); the halo
         // below holds image pixels at reflected coordinates, gradients are evaluated at reflected positions too.
-        tile[yy][xx] = (uint8_t)PX(y0 - 3 + yy, x0 - 3 + xx);
+        tile[yy][xx + 1] = (uint8_t)PX(y0 - 3 + yy, x0 - 3 + xx);
+    }
+    for (int k = threadIdx.x; k < ME_R * 64; k += 256) {
+        const int ly = k >> 6, lx = k & 63, y = y0 + ly, x = x0 + lx;
+        mk[ly][lx] = (x < W && y < H) ? (uint8_t)gmask[(size_t)y * W + x] : (uint8_t)0;
     }
     __syncthreads();
-    const float k1 = (float)(1.0 / 3060.0), k2 = (float)(2.0 / 3060.0);
     // gradients at (y0-2+yy, x0-2+xx): position may lie outside the image -> the boxFilter's reflect-101 wants the
     // gradient AT THE REFLECTED POSITION, which is not the gradient computed from reflected pixels; handled below by
     // recomputing from global memory for those few halo positions.
@@ -708,7 +758,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d, doub
         const int Yr = reflect101(Y, H), Xr = reflect101(X, W);
         if (Yr == Y && Xr == X) {
             const uint8_t(*t)[72] = tile;
-            const int ty = yy + 1, tx = xx + 1;       // tile index of (Y, X)
+            const int ty = yy + 1, tx = xx + 2;       // tile index of (Y, X)
             const float r0 = (float)(t[ty - 1][tx + 1] - t[ty - 1][tx - 1]);
             const float r1 = (float)(t[ty][tx + 1] - t[ty][tx - 1]);
             const float r2 = (float)(t[ty + 1][tx + 1] - t[ty + 1][tx - 1]);
@@ -729,12 +779,12 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d, doub
         }
         gx[yy][xx] = dxv; gy[yy][xx] = dyv;
     }
+    }
     __syncthreads();
     // The map on the tile and its ring; the masked maximum over the tile's own pixels.  The 3 x 3 box is SEPARABLE, as cv::boxFilter
     // runs it (RowSum<float, double>: ((p[x-1] + p[x]) + p[x+1]) per channel, then ColumnSum<double, float>: ((r[y-1] + r[y]) + r[y+1]);
     // oracle/fe_cpu.cpp, round 5): a thread walks DOWN a column of the map over a strip of six rows and keeps the last three row sums
     // in registers -- per pixel 12 products / conversions and 14 FP64 adds instead of 27 + 27, no second LDS array.
-    const uint8_t* mask = d.mask + (size_t)cam * W * H;
     float m = -INFINITY;
     if (threadIdx.x < 3 * 66) {
         const int strip = threadIdx.x / 66, ex = threadIdx.x - 66 * strip;
@@ -760,7 +810,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d, doub
                     val = (float)((a + c) - sqrtf((a - c) * (a - c) + b * b));
                     if (ey >= 1 && ey <= ME_R && ex >= 1 && ex <= 64) {             // the tile's own pixel
                         if (d.keep_eig) d.eig[(size_t)cam * W * H + (size_t)y * W + x] = val;
-                        if (mask[(size_t)y * W + x]) m = fmaxf(m, val);
+                        if (mk[ey - 1][ex - 1]) m = fmaxf(m, val);
                     }
                 }
                 eg[ey][ex] = val;
@@ -795,7 +845,7 @@ extern "C" __global__ __launch_bounds__(256) void fe_mineig_kernel(FeDev d, doub
         bool cnd = false;
         if (x >= 1 && y >= 1 && x < W - 1 && y < H - 1) {
             const float raw = eg[ly + 1][lane + 1];
-            if (raw > 0.f && raw > thr_lb && mask[(size_t)y * W + x]) {
+            if (raw > 0.f && raw > thr_lb && mk[ly][lane]) {
                 float mx = raw;
 #pragma unroll
                 for (int v = 0; v < 3; ++v)
