@@ -548,7 +548,7 @@ def device_info(h=None):
         info["rocm_smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("partition", "sclk", "mclk", "fclk", "perf"))}
     except Exception as ex:                                   # noqa: BLE001
         info["rocm_smi"] = f"unavailable: {ex!r}"
-    if h is not None:
+    if h is not None and not QUICK:                           # (--emulated: the probe's FMA chains would be minutes of emulation)
         # the clock the box REALLY runs at (rocm-smi reports the same figures on boxes that run the BA kernels 1.4 x apart): a dependent
         # FP64 FMA has a fixed latency in core cycles, so ns per FMA ~ 1 / clock -- lone wavefront, and with every CU loaded
         try:
@@ -637,7 +637,7 @@ def main():
 
     h = ba.Handle()
     nwin = args.windows
-    nfl = max(1, args.in_flight)
+    nfl = max(1, args.in_flight) if not QUICK else min(max(1, args.in_flight), 2)      # (--emulated: two streams exercise the rotation)
     # `nfl` independent batches of nwin windows each, one vg_handle (= one HIP stream) per batch: consecutive steps go to
     # different streams.  Since round 5 a solve workgroup is 4 wavefronts / 72 KB of LDS, so the solve kernels of two batches share
     # CUs (two windows per CU); the factor and marginalization kernels still take a CU each, and launches of other batches fill

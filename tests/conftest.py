@@ -16,6 +16,41 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _prebuild_for_workers():
+    """Everything a `not gpu` test would (re)build on demand, built ONCE before the worker processes start: afterwards their own `make`
+    calls find nothing to do, and a make that finds nothing to do may run next to another one."""
+    import shutil
+    import subprocess
+    jobs = str(os.cpu_count() or 4)
+    _build_simt()
+    for args, cwd in ((["make", "-j", jobs], os.path.join(ROOT, "oracle")),):
+        subprocess.run(args, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference"):
+        subprocess.run(["make", "ref_simt"], cwd=os.path.join(ROOT, "oracle"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True) if shutil.which("gcc") else None
+    if r is not None and r.returncode == 0 and os.path.isabs(r.stdout.strip()) and os.path.exists(r.stdout.strip()):
+        subprocess.run(["make", "-C", SIMT_DIR, "-j", jobs, "asan"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """`pytest tests -m "not gpu"` spreads the test FILES over worker processes (pytest-xdist, --dist loadfile).  The CPU suite is a dozen
+    independent, subprocess-heavy tests long (the emulated bench, the end-to-end runs on rendered frames, the sanitizer builds): 14
+    minutes in sequence, a few in parallel.  Files stay whole on one worker (module fixtures, fixed rendezvous ports per file).  Not
+    for the GPU suite (one device), not when the caller chose a worker count or VINS_TEST_SERIAL=1 is set."""
+    opt = config.option
+    if (getattr(opt, "markexpr", "") or "").strip() != "not gpu" or os.environ.get("VINS_TEST_SERIAL") == "1":
+        return None
+    if not config.pluginmanager.hasplugin("xdist") or getattr(opt, "numprocesses", None) not in (None, 0) or getattr(opt, "collectonly", False):
+        return None
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        return None
+    _prebuild_for_workers()
+    opt.numprocesses = max(2, min(8, (os.cpu_count() or 4) // 4))
+    opt.dist = "loadfile"
+    return None
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return graft.load_package()

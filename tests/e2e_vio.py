@@ -317,7 +317,7 @@ def check_end_to_end(h, exe, tmp, n_frames=20, seed=3):
         assert a[4] >= 100
         assert np.linalg.norm(a[1] - b[1]) < 0.045, (a[0], a[1] - b[1])       # 0.023 m observed
         assert np.linalg.norm(a[1] - a[2]) < 0.1, (a[0], a[1] - a[2])         # 0.049 m observed, of which 0.036 m is the initial guess
-    assert travelled > 0.4
+    assert travelled > 0.044 * (n_frames - 11), travelled                      # (0.4 m over the 9 solved frames of the 20-frame run)
     flags = [a[3] for a in got]
     assert 0 in flags and 1 in flags                                          # both marginalization branches were taken
     # 3. the same in ONE C++ process: FeatureTracker::readImage -> `image` map -> ResidentEstimators::processImage / solve

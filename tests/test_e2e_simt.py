@@ -12,7 +12,7 @@ def test_rendered_frames_through_front_end_and_estimator(tmp_path):
     exe = os.path.join(conftest.SIMT_DIR, "_build", "vins_replay_simt")
     h = conftest._simt_handle()
     try:
-        r = e2e_vio.check_end_to_end(h, exe, str(tmp_path))
+        r = e2e_vio.check_end_to_end(h, exe, str(tmp_path), n_frames=16)          # (the GPU twin runs 20 frames)
     finally:
         h.close()
     print(r)
@@ -23,7 +23,7 @@ def test_tracks_on_a_moving_object_do_not_pull_the_estimate(tmp_path):
     exe = os.path.join(conftest.SIMT_DIR, "_build", "vins_replay_simt")
     h = conftest._simt_handle()
     try:
-        r = e2e_vio.check_moving_object(h, exe, str(tmp_path))
+        r = e2e_vio.check_moving_object(h, exe, str(tmp_path), n_frames=16)
     finally:
         h.close()
     print(r)
