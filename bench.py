@@ -661,6 +661,12 @@ def main():
         for hh in handles:
             hh.sync()
 
+    # set-up, before the W warm-up steps: every stream runs its batch once.  A handle's first launch loads code objects, sets kernel
+    # attributes and allocates its scratch (hipMalloc synchronises the whole device): with more streams than warm-up steps (8 vs the
+    # driver's W = 5) those first launches would fall into the timed region -- measured: 77K instead of 153K solves/s at W = 3.
+    for hh in handles:
+        hh.ba_run_async()
+    sync_all()
     for k in range(args.warmup):
         handles[k % nfl].ba_run_async()
     sync_all()
@@ -698,6 +704,23 @@ def main():
         for k, (ms, n) in h.ba_run_profiled().items():
             a = prof.setdefault(k, [0.0, 0, 0])
             a[0] += ms; a[1] += n; a[2] += 1
+
+    # the same event pass with TWO batches' worth of windows in one launch (the same windows twice): a kernel that owns a CU takes
+    # twice as long, the solve kernel -- 4 wavefronts, 72 KB of LDS since round 5 -- runs its second 256 workgroups beside the first.
+    # Outside the timed region; reported as roofline.two_per_cu (profiles/r05z_two_windows_per_cu.txt).
+    prof2 = {}
+    if not QUICK and rank == 0:
+        try:
+            h2 = ba.Handle()
+            h2.ba_upload(packed + packed, flags + flags)
+            h2.ba_run_profiled()
+            for _ in range(3):
+                for k, (ms, n) in h2.ba_run_profiled().items():
+                    a = prof2.setdefault(k, [0.0, 0, 0])
+                    a[0] += ms; a[1] += n; a[2] += 1
+            h2.close()
+        except Exception as ex:                       # noqa: BLE001  (informational)
+            prof2 = {"error": repr(ex)}
 
     # boundary-inclusive rate (host buffers in, host buffers out: pack + H2D + all launches + D2H), NOT the metric
     up_ms, dn_ms = [], []
@@ -851,6 +874,15 @@ def main():
                            "achieved_serial": info['flops'] / ((solve_ms + marg_ms) * 1e-3) / 1e12,
                            "achieved_timed_region": info['flops'] * args.steps / elapsed / 1e12,
                            "frac_timed_region": info['flops'] * args.steps / elapsed / 1e12 / FP64_PEAK_TFLOPS},
+            "two_per_cu": ({"error": prof2["error"]} if "error" in prof2 else {
+                "windows_per_launch": 2 * nwin,
+                "ms_per_launch": {k: ms / n for k, (ms, n, runs) in prof2.items() if n},
+                "ratio_to_one_batch": {k: (ms / n) / per_kernel[k]["ms_per_launch"] for k, (ms, n, runs) in prof2.items() if n and k in per_kernel},
+                "dominant_kernel_achieved": (2 * per_kernel[dom]["flops_per_launch"] / (prof2[dom][0] / prof2[dom][1] * 1e-3) / 1e12) if dom in prof2 and prof2[dom][1] else None,
+                "dominant_kernel_frac": (2 * per_kernel[dom]["flops_per_launch"] / (prof2[dom][0] / prof2[dom][1] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if dom in prof2 and prof2[dom][1] else None,
+                "what": "the same per-launch event pass with two batches' worth of windows in ONE launch: kernels that own a CU double, the "
+                        "solve kernel's workgroups pair up on the CUs -- the dominant kernel at the operating point the batch runs it at "
+                        "(several streams in flight); NOT the headline frac, which stays the stand-alone launch of one batch"} if prof2 else None),
             "reading": "frac = flops of the dominant kernel / its STAND-ALONE launch duration (one stream, launches not overlapped).  Since "
                        "round 5 the solve kernel is built to share a CU with a second window (4 wavefronts, 72 KB of LDS): alone it is slower "
                        "than the 8-wavefront kernel of round 4, in the batch two of them overlap -- the figure that shows what the "
