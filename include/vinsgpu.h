@@ -533,7 +533,9 @@ int vg_fe_get_mask(vg_handle* h, int cam, uint8_t* out);          /* current dev
  * points in walk order, then new points with count 1: the counts are then non-increasing along the list at all times).
  * Two cases go back to the host inside the call (same results, more round trips): 8 <= survivors < 15 (findFundamentalMat switches to
  * LMedS) and a RANSAC sample OpenCV would have redrawn for collinearity (its schedule then depends on the points).
- * All pointers of vg_fe_frame_out point into pinned buffers of the handle and stay valid until the next vg_fe_* call on it. */
+ * All pointers of vg_fe_frame_out point into pinned buffers of the handle and stay valid until the next vg_fe_* call on it.
+ * The FIRST call on a stream builds its resident tables (RANSAC schedules for every point count up to max_points: 28 KB each, tens of
+ * milliseconds of host time once); limits: n_cams == 1, max_points <= 2048, rejectWithF on at most 1024 tracking survivors. */
 typedef struct vg_fe_frame_out {
     int n1;                      /* survivors of tracking + border test                                           (:115-124) */
     int n2;                      /* survivors of rejectWithF (== n1 when it did not run)                          (:193-198) */

@@ -59,6 +59,12 @@ struct RiState {
     const uint8_t* base_src = nullptr;
     RiDev r;
 };
+static void ri_free(RiState* q) {
+    if (!q) return;
+    (void)hipFree(q->dev); (void)hipFree(q->d_sched); (void)hipFree(q->d_tab); (void)hipFree(q->d_base);
+    (void)hipHostFree(q->host);
+    delete q;
+}
 
 struct FeState {
     FeDev d;
@@ -106,11 +112,7 @@ extern "C" void fe_state_destroy(FeState* s) {
     (void)hipFree(s->ncorners); (void)hipFree(s->ncand); (void)hipFree(s->keys);
     (void)hipFree(s->sm_pts); (void)hipFree(s->sm_cnt); (void)hipFree(s->sm_n); (void)hipFree(s->sm_kidx); (void)hipFree(s->sm_nk);
     (void)hipFree(s->sm_kxy); (void)hipFree(s->sm_base); (void)hipFree((void*)s->sm_base_ptrs); (void)hipFree(s->lift_in); (void)hipFree(s->lift_out);
-    if (s->ri) {
-        (void)hipFree(s->ri->dev); (void)hipFree(s->ri->d_sched); (void)hipFree(s->ri->d_tab); (void)hipFree(s->ri->d_base);
-        (void)hipHostFree(s->ri->host);
-        delete s->ri;
-    }
+    ri_free(s->ri);
     delete s;
 }
 
@@ -573,10 +575,19 @@ extern "C" int vg_fe_get_eig(vg_handle* h, int cam, float* out) {
 // ================================================================================================ one call per frame
 static size_t ri_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+static int ri_build(vg_handle* h, FeState* s, RiState* q);
+
+// (the state is attached to the stream only when it is complete: a failed allocation leaves nothing half-made behind)
 static int ri_ensure(vg_handle* h, FeState* s) {
     if (s->ri) return VG_OK;
     RiState* q = new RiState();
+    const int rc = ri_build(h, s, q);
+    if (rc != VG_OK) { ri_free(q); return rc; }
     s->ri = q;
+    return VG_OK;
+}
+
+static int ri_build(vg_handle* h, FeState* s, RiState* q) {
     const size_t cap = (size_t)s->max_pts;
     q->cap = (int)cap;
     // input block: control ints | cur_pts;  block A: header | status_lk | status_f | forw_xy | un_xy;  block B: header | kept | new_xy | un_xy
