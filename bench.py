@@ -564,7 +564,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=WINDOWS_PER_GPU)
-    ap.add_argument("--in-flight", type=int, default=8, help="independent batches (HIP streams) the steps are spread over")
+    ap.add_argument("--in-flight", type=int, default=16, help="independent batches (HIP streams) the steps are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-mode", choices=["graph", "direct"], default=None,
                     help="VG_BA_LAUNCH_MODE for every handle of the run (default: the library's, see vg_ba_set_launch_mode)")
@@ -643,7 +643,8 @@ def main():
     # CUs (two windows per CU); the factor and marginalization kernels still take a CU each, and launches of other batches fill
     # their tails.  Four in flight: equal to two on the fast kind of box (149.5K vs 150.3K), +9 % on the slow kind (131.6K vs
     # 120.4K; profiles/r05k_in_flight_slow_box.json, r05l_ab_solve_two_per_cu.json); eight: another +4 % on the slow kind (136.6K ->
-    # 142.3K, 4 / 6 / 8 / 4 / 8 in one call: profiles/r05x_in_flight_4_6_8.txt) -- the default.
+    # 142.3K, 4 / 6 / 8 / 4 / 8 in one call: profiles/r05x_in_flight_4_6_8.txt); sixteen: +4.7 % over eight on the slow kind (141.5K -> 148.2K),
+    # +3 % on the fast kind (153.5K -> 158K; 24 and 32 fall off again: profiles/r05x_in_flight_8_to_32.txt) -- the default.
     handles = [h] + [ba.Handle() for _ in range(nfl - 1)]
     seed0 = D.window_seeds(rank, nwin)[0]
     probs, seqs = make_windows(h, ba, synth, nwin, seed0=seed0)
@@ -662,7 +663,7 @@ def main():
             hh.sync()
 
     # set-up, before the W warm-up steps: every stream runs its batch once.  A handle's first launch loads code objects, sets kernel
-    # attributes and allocates its scratch (hipMalloc synchronises the whole device): with more streams than warm-up steps (8 vs the
+    # attributes and allocates its scratch (hipMalloc synchronises the whole device): with more streams than warm-up steps (16 vs the
     # driver's W = 5) those first launches would fall into the timed region -- measured: 77K instead of 153K solves/s at W = 3.
     for hh in handles:
         hh.ba_run_async()
