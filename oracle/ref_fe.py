@@ -60,14 +60,22 @@ def lib_simt():
 
 
 def write_config(path, width=752, height=480, max_cnt=150, min_dist=30, freq=10, equalize=1, fisheye=0, f_threshold=1.0,
-                 intr=(4.616e+02, 4.603e+02, 3.630e+02, 2.481e+02), dist=(-2.917e-01, 8.228e-02, 5.333e-05, -1.578e-04)):
+                 intr=(4.616e+02, 4.603e+02, 3.630e+02, 2.481e+02), dist=(-2.917e-01, 8.228e-02, 5.333e-05, -1.578e-04), mei_xi=None):
     """A configuration file with the keys feature_tracker/src/parameters.cpp:45-60 and PinholeCamera::Parameters::readFromYamlFile
     (PinholeCamera.cc:144-183) read; defaults = config/euroc/euroc_config.yaml."""
     with open(path, "w") as f:
         f.write("%YAML:1.0\n\nimu_topic: \"/imu0\"\nimage_topic: \"/cam0/image_raw\"\noutput_path: \"/tmp/\"\n\n")
-        f.write("model_type: PINHOLE\ncamera_name: camera\nimage_width: %d\nimage_height: %d\n" % (width, height))
-        f.write("distortion_parameters:\n   k1: %r\n   k2: %r\n   p1: %r\n   p2: %r\n" % tuple(float(v) for v in dist))
-        f.write("projection_parameters:\n   fx: %r\n   fy: %r\n   cx: %r\n   cy: %r\n\n" % tuple(float(v) for v in intr))
+        if mei_xi is None:
+            f.write("model_type: PINHOLE\ncamera_name: camera\nimage_width: %d\nimage_height: %d\n" % (width, height))
+            f.write("distortion_parameters:\n   k1: %r\n   k2: %r\n   p1: %r\n   p2: %r\n" % tuple(float(v) for v in dist))
+            f.write("projection_parameters:\n   fx: %r\n   fy: %r\n   cx: %r\n   cy: %r\n\n" % tuple(float(v) for v in intr))
+        else:
+            # CataCamera::Parameters::readFromYamlFile (CataCamera.cc:161-203): the unified (MEI) model -- a camera whose lifting the
+            # drop-in leaves to camodocal on the host (its step-by-step members)
+            f.write("model_type: MEI\ncamera_name: camera\nimage_width: %d\nimage_height: %d\n" % (width, height))
+            f.write("mirror_parameters:\n   xi: %r\n" % float(mei_xi))
+            f.write("distortion_parameters:\n   k1: %r\n   k2: %r\n   p1: %r\n   p2: %r\n" % tuple(float(v) for v in dist))
+            f.write("projection_parameters:\n   gamma1: %r\n   gamma2: %r\n   u0: %r\n   v0: %r\n\n" % tuple(float(v) for v in intr))
         f.write("max_cnt: %d\nmin_dist: %d\nfreq: %d\nF_threshold: %r\nshow_track: 0\nequalize: %d\nfisheye: %d\n" %
                 (max_cnt, min_dist, freq, float(f_threshold), equalize, fisheye))
     return path

@@ -118,6 +118,21 @@ def test_stream_discontinuity_and_fisheye_mask_on_emulated_kernels(tmp_path):
 
 
 @needs_ref
+@pytest.mark.skipif(not RF.available("simt"), reason="emulated drop-in library is not built")
+def test_other_camera_model_takes_the_step_by_step_members_on_emulated_kernels(tmp_path):
+    """A camera that is not a camodocal::PinholeCamera (here the unified MEI model, CataCamera.cc) is lifted by camodocal on the host, so
+    readImage runs its step-by-step form -- vg_fe_push_frames / vg_fe_track / rejectWithF() / setMask() / vg_fe_detect_masked /
+    undistortedPoints() -- instead of vg_fe_read_image: still bit-identical to the reference's class with the same camera."""
+    frames = fe_scene.moving_scene(10, seed=17, width=320, height=240, velocity=(2.4, -1.1))
+    cfg = RF.write_config(str(tmp_path / "cfg.yaml"), width=320, height=240, max_cnt=60, min_dist=16, equalize=1, freq=10,
+                          intr=(310.0, 309.0, 158.0, 121.5), dist=(-0.11, 0.04, 2e-4, -1e-4), mei_xi=0.9)
+    ref = _run(RF.lib(), frames, cfg)
+    assert any(t['pub'] for t in ref[0]) and len(ref[0][-1]['ids']) >= 30
+    _compare(ref, _run(RF.lib_simt(), frames, cfg))
+    assert LAST_STATS["stepwise"] == 9 and LAST_STATS["frames"] == 0, LAST_STATS
+
+
+@needs_ref
 @pytest.mark.gpu
 @pytest.mark.skipif(not RF.available("gpu"), reason="drop-in library is not built")
 @pytest.mark.parametrize("equalize,freq", [(1, 10), (0, 20)])
