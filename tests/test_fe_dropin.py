@@ -135,6 +135,18 @@ def test_other_camera_model_takes_the_step_by_step_members_on_emulated_kernels(t
 @needs_ref
 @pytest.mark.gpu
 @pytest.mark.skipif(not RF.available("gpu"), reason="drop-in library is not built")
+def test_other_camera_model_takes_the_step_by_step_members_on_the_gpu(tmp_path):
+    """the same on the device, at 752x480 over 24 frames"""
+    frames = fe_scene.moving_scene(24, seed=18)
+    cfg = RF.write_config(str(tmp_path / "cfg.yaml"), intr=(730.0, 728.0, 371.0, 243.5), dist=(-0.11, 0.04, 2e-4, -1e-4), mei_xi=0.9)
+    ref = _run(RF.lib(), frames, cfg)
+    _compare(ref, _run(RF.lib_gpu(), frames, cfg))
+    assert LAST_STATS["stepwise"] == 23 and LAST_STATS["frames"] == 0, LAST_STATS
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.skipif(not RF.available("gpu"), reason="drop-in library is not built")
 @pytest.mark.parametrize("equalize,freq", [(1, 10), (0, 20)])
 def test_reference_node_with_the_drop_in_on_the_gpu(tmp_path, equalize, freq):
     """40 frames at 752x480 through both builds; FREQ 20 publishes (almost) every frame of the 20 Hz stream."""
