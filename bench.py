@@ -458,9 +458,10 @@ def bench_sharded(args, ba, synth, D, rank, world):
 
 def csrc_tag():
     """Identity of the DEVICE code the library carries: sha1 over the .hip_fatbin section of vins-mono_amd/lib/libvinsgpu.so (the
-    embedded gfx950 code objects; first 12 hex).  Byte-identical for the same kernel sources whatever the build directory and
-    whatever changes in host-only code, comments or headers that do not reach the generated code; any change of a kernel changes
-    it.  (Until r03s the tag was a hash of the source text of csrc/, which host-side edits invalidated although the kernels the
+    embedded gfx950 code objects; first 12 hex).  Byte-identical for the same kernel sources built by the in-tree Makefile -- a clean
+    rebuild reproduces it -- whatever changes in host-only code, comments or headers that do not reach the generated code; any change
+    of a kernel changes it, and so does another OBJDIR (hipcc derives a compilation-unit id from its command line, output path
+    included, and that id is part of the code object: checked at the end of round 5).  (Until r03s the tag was a hash of the source text of csrc/, which host-side edits invalidated although the kernels the
     PMC pass had measured were unchanged.)"""
     import hashlib
     import struct
