@@ -161,3 +161,57 @@ def test_landmark_partition_balances_the_schur_work():
         got = [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(world)]
         assert got == [(int(a), int(b)) for a, b in shard.landmark_shards(nobs, world)], (L, world)
         assert got[0][0] == 0 and got[-1][1] == L and all(got[r][1] == got[r + 1][0] for r in range(world - 1))
+
+
+def test_sharded_window_refuses_alike_on_every_rank_before_any_collective():
+    """ADVICE r5 (medium / low): relocalisation matches that fall into some shards only would give the ranks reduced systems of different
+    sizes; VG_PRIOR_RESIDENT would pick up the marginalization handle's own slot; a contiguity error seen by one rank only would leave
+    the others in the all-reduce.  ShardedWindow::optimize refuses all three from the FULL problem -- the same verdict on every rank,
+    whatever its share -- and shard.py raises for the first two.  No transport is installed: reaching a collective would fail differently."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.load_package()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    import pytest
+    h = conftest._simt_handle()
+    from vins_mono_amd import ba, shard, synth
+    SH = C.CDLL(os.path.join(ROOT, "tests", "simt", "_build", "libvins_shard_simt.so"))
+    GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    SH.vins_sharded_create.restype = C.c_void_p
+    SH.vins_sharded_create.argtypes = [C.c_int, C.c_int, GATHER, C.c_void_p]
+    SH.vins_sharded_optimize.argtypes = [C.c_void_p, C.POINTER(ba.Problem), C.c_int, C.POINTER(ba.State), C.POINTER(ba.Summary), C.POINTER(ba.Prior)]
+    SH.vins_sharded_last_error.restype = C.c_char_p
+    SH.vins_sharded_last_error.argtypes = [C.c_void_p]
+    SH.vins_sharded_destroy.argtypes = [C.c_void_p]
+    prob = synth.SyntheticSequence(3, L=30).window(0)
+    L = len(prob["inv_depth"])
+    # every match in the LAST landmarks: rank 0 of 2 would see none of them
+    relo = dict(prob, relo=dict(pose=np.array(prob["pose"][2], float), match=[(L - 1, 0.01, 0.02), (L - 2, -0.03, 0.01)]))
+    assert all(lm >= shard.landmark_shards(prob["lm_nobs"], 2)[0][1] for lm, _, _ in relo["relo"]["match"])
+    holes = dict(prob, obs_off=np.asarray(prob["obs_off"]).copy())
+    holes["obs_off"][L - 1] += 1                                           # a gap before the last landmark: rank 1's share only
+    holes["obs"] = np.concatenate([np.asarray(prob["obs"], float).reshape(-1, 7), np.zeros((1, 7))])
+    K = prob["pose"].shape[0]
+    _p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for rank in (0, 1):
+        w = SH.vins_sharded_create(rank, 2, GATHER(0), None)
+        assert w
+        for case, want, word in ((relo, -3, b"relocalisation"),
+                                 (holes, -1, b"consecutive"), ("resident", -3, b"RESIDENT")):
+            pk = ba.PackedProblem(prob if case == "resident" else case)
+            if case == "resident":
+                pk.struct.prior_n = ba.VG_PRIOR_RESIDENT
+            pose, sb, ex, td, lam, rp = np.zeros((K, 7)), np.zeros((K, 9)), np.zeros(7), np.zeros(1), np.zeros(L), np.zeros(7)
+            st = ba.State(pose=_p(pose), speedbias=_p(sb), ex_pose=_p(ex), td=_p(td), inv_depth=_p(lam), relo_pose=_p(rp))
+            sm = ba.Summary()
+            rc = SH.vins_sharded_optimize(w, C.byref(pk.struct), ba.VG_MARGIN_NONE, C.byref(st), C.byref(sm), None)
+            assert rc == want and word in SH.vins_sharded_last_error(w), (rank, rc, SH.vins_sharded_last_error(w))
+        SH.vins_sharded_destroy(w)
+        with pytest.raises(ValueError, match="relocalisation"):
+            shard.shard_problem(relo, rank, 2)
+        with pytest.raises(ValueError, match="consecutive"):
+            shard.shard_problem(holes, rank, 2)
+    shard.shard_problem(relo, 0, 1)                                        # one rank: relocalisation factors are fine
+    h.close()

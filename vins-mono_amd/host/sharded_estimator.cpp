@@ -120,10 +120,37 @@ int ShardedWindow::gather_frame0(const vg_ba_state& st, std::vector<int>& nobs, 
     return VG_OK;
 }
 
+// The checks of optimize() that depend on the FULL problem only (identical on every rank).
+int ShardedWindow::validate_full(const vg_ba_problem& full) {
+    if (full.L < 0 || (full.L > 0 && (!full.lm_nobs || !full.lm_obs_off))) { err_ = "bad landmark tables"; return VG_ERR_BAD_ARG; }
+    for (int l = 1; l < full.L; ++l)
+        if (full.lm_obs_off[l] != full.lm_obs_off[l - 1] + full.lm_nobs[l - 1]) {
+            err_ = "observation rows of consecutive landmarks must be consecutive";
+            return VG_ERR_BAD_ARG;
+        }
+    // The relocalisation pose (estimator.cpp:769-801) is a block of the reduced camera system only on the ranks that hold one of its
+    // matched landmarks: the ranks would build reduced systems of different sizes and sum them.  Not offered on more than one rank.
+    if (full.relo_n > 0 && t_.world > 1) {
+        err_ = "relocalisation factors are not offered in a window sharded over several ranks";
+        return VG_ERR_UNSUPPORTED;
+    }
+    // A resident prior lives in the slot of the handle that made it; the marginalization handle's slot holds the prior the PREVIOUS
+    // sharded frame produced, the solve handle's slot nothing at all: the caller passes the prior by value.
+    if (full.prior_n == VG_PRIOR_RESIDENT) {
+        err_ = "VG_PRIOR_RESIDENT is not offered by ShardedWindow::optimize: pass the prior by value";
+        return VG_ERR_UNSUPPORTED;
+    }
+    return VG_OK;
+}
+
 int ShardedWindow::optimize(const vg_ba_problem& full, int margin_flag, vg_ba_state* st, vg_ba_summary* sm, vg_ba_prior* new_prior) {
     if (!ok()) return VG_ERR_NO_DEVICE;
     if (!st || !sm || (margin_flag != VG_MARGIN_NONE && !new_prior)) return VG_ERR_BAD_ARG;
-    int rc = shard_problem(full, t_.rank, t_.world, shard_);
+    // Everything that can be refused is refused HERE, from the full problem, so that every rank takes the same decision before the
+    // first collective (a rank that returned early would leave the others blocked in the all-reduce / all-gather).
+    int rc = validate_full(full);
+    if (rc != VG_OK) return rc;
+    rc = shard_problem(full, t_.rank, t_.world, shard_);
     if (rc != VG_OK) { err_ = "observation rows of consecutive landmarks must be consecutive"; return rc; }
     // ---- the solve: this rank's landmarks, the reduced camera system summed over the ranks by the hook of the solve handle
     rc = vg_ba_optimize(solve_, &shard_.pb, VG_MARGIN_NONE, st, sm, nullptr);

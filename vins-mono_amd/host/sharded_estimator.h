@@ -61,9 +61,14 @@ public:
     // identical frame states (st->pose / speedbias / ex_pose / td), the inverse depths of ITS landmarks in st->inv_depth[0 .. hi-lo)
     // and -- margin_flag != VG_MARGIN_NONE -- the identical new prior.  st->inv_depth must hold full.L doubles (only the first
     // hi - lo are written), new_prior may be null with VG_MARGIN_NONE.  Returns a vg_status.
+    // Refused on every rank alike, before any collective: observation rows that are not consecutive over the whole landmark list
+    // (VG_ERR_BAD_ARG), relocalisation factors with world > 1 and VG_PRIOR_RESIDENT (VG_ERR_UNSUPPORTED).  ANY OTHER error return
+    // (a HIP error, a transport failure, a numeric failure of the marginalization on one rank) leaves the ranks unsynchronised:
+    // the caller must tear the group down, not call optimize() again.
     int optimize(const vg_ba_problem& full, int margin_flag, vg_ba_state* st, vg_ba_summary* sm, vg_ba_prior* new_prior);
 
 private:
+    int validate_full(const vg_ba_problem& full);
     int gather_frame0(const vg_ba_state& st, std::vector<int>& nobs, std::vector<double>& inv_depth, std::vector<double>& obs);
     ShardTransport t_;
     vg_handle* solve_ = nullptr;

@@ -36,8 +36,13 @@ def shard_problem(prob, rank, world):
     nob = np.asarray(prob['lm_nobs'], dtype=np.int64)
     o_lo = int(off[lo]) if lo < hi else 0
     o_hi = int(off[hi - 1] + nob[hi - 1]) if lo < hi else 0
-    if lo < hi and not np.all(off[lo + 1:hi] == off[lo:hi - 1] + nob[lo:hi - 1]):
+    # checks on the FULL problem, so that every rank refuses alike before the first collective (host/sharded_estimator.cpp validate_full)
+    if len(off) > 1 and not np.all(off[1:] == off[:-1] + nob[:-1]):
         raise ValueError("observation rows of consecutive landmarks must be consecutive")
+    if world > 1 and prob.get('relo') is not None and len(prob['relo']['match']) > 0:
+        # the relocalisation pose would be a block of the reduced system only on the ranks that hold one of its matched landmarks:
+        # reduced systems of different sizes would be summed
+        raise ValueError("relocalisation factors are not offered in a window sharded over several ranks")
     sub['inv_depth'] = np.asarray(prob['inv_depth'], dtype=np.float64)[lo:hi].copy()
     sub['lm_start'] = np.asarray(prob['lm_start'])[lo:hi].copy()
     sub['lm_nobs'] = np.asarray(prob['lm_nobs'])[lo:hi].copy()
