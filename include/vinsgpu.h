@@ -23,11 +23,12 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 11   /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
+#define VG_ABI_VERSION 12   /* 2: vg_ba_problem::max_solver_time_s, large-window / all-reduce entry points; 3: vg_ba_summary::gauge_*;
                              * 4: VG_PRIOR_RESIDENT; 5: vg_ba_set_launch_mode; 6: vg_ba_reserve, vg_ba_seq_* (windows that stay on the device);
                              * 7: vg_ba_seq_export / vg_ba_seq_import; 8: vg_host_register, vg_ba_set_fused_min_windows, vg_ba_batch_is_fused;
                              * 9: vg_fe_keep_eig (the min-eigenvalue map is no longer written unless asked for);
-                             * 10: vg_config / vg_create_config; vg_ba_batch_is_fused no longer returns 2; 11: vg_fe_read_image */
+                             * 10: vg_config / vg_create_config; vg_ba_batch_is_fused no longer returns 2; 11: vg_fe_read_image;
+                             * 12: vg_config::device is 0 = current device / k + 1 = device k, vg_config::imu_info_mode, vg_ba_set_imu_info_mode */
 #define VG_MAX_ITERS 32          /* capacity of the per-iteration trace in vg_ba_summary */
 
 typedef enum {
@@ -50,11 +51,13 @@ int vg_create(vg_handle** out);                 /* uses the current HIP device, 
  * its host's environment).  Zero-initialise, set struct_size = sizeof(vg_config), fill what differs from the defaults. */
 typedef struct vg_config {
     int struct_size;             /* sizeof(vg_config) of the caller: fields beyond it take their defaults                         */
-    int device;                  /* HIP device index (hipSetDevice before the streams are created); -1 = the current device       */
+    int device;                  /* 0 (or negative) = the CURRENT HIP device; k + 1 = device k (hipSetDevice(k) on the caller's
+                                  * thread before the streams are created).  ABI 12: a zero-initialised struct no longer means device 0 */
     int launch_mode;             /* VG_LAUNCH_DIRECT + 1 / VG_LAUNCH_GRAPH + 1; 0 = the library's default (vg_ba_set_launch_mode)   */
     int marg_mode;               /* VG_MARG_SQRT (0, default) / VG_MARG_EIGEN: form of the prior factor (vg_ba_set_marg_mode)     */
     int fused_min_windows;       /* batches from this many windows on take the fused factor kernel; 0 = default (32), -1 = never  */
     int pack_threads;            /* host threads that share the packing / unpacking of a batch; 0 = default (8)                   */
+    int imu_info_mode;           /* VG_IMU_INFO_FACTOR (0, default) / VG_IMU_INFO_REFERENCE: form of the IMU sqrt_info (vg_ba_set_imu_info_mode) */
 } vg_config;
 int vg_create_config(const vg_config* cfg, vg_handle** out);
 /* What core clock does this box really run at?  out4 = { ns per dependent FP64 FMA with ONE wavefront on the chip, clock64() ticks per
@@ -432,6 +435,15 @@ int vg_ba_seq_end(vg_handle* h);
  * Takes effect at the next upload / vg_ba_optimize. */
 enum { VG_MARG_SQRT = 0, VG_MARG_EIGEN = 1 };
 int vg_ba_set_marg_mode(vg_handle* h, int mode);
+/* ABI 12.  Form of the IMU factors' weight sqrt_info = LLT(covariance^-1).matrixL()^T (factor/imu_factor.h:64).  The Cholesky factor of
+ * the inverse is unique, so both forms are the same matrix up to rounding -- the covariance is badly conditioned, and the rounding of
+ * this factor is one of the inputs of the trust-region decisions (profiles/r06_flip_stats.json):
+ *   VG_IMU_INFO_FACTOR     (default)  U^-1 of covariance = U U^T (U upper): the inverse is never formed;
+ *   VG_IMU_INFO_REFERENCE             covariance.inverse() by partial-pivot LU, then the LLT of its lower triangle, as the reference
+ *                                     spells it (operation order of oracle/ref_stubs' stand-in Eigen, no contraction).
+ * Takes effect at the next upload / vg_ba_optimize. */
+enum { VG_IMU_INFO_FACTOR = 0, VG_IMU_INFO_REFERENCE = 1 };
+int vg_ba_set_imu_info_mode(vg_handle* h, int mode);
 int vg_ba_reduce_layout(vg_handle* h, size_t* count_system, size_t* count_norms);
 
 /* Batched factor evaluation for parity tests (rows B2-B5 of SURVEY.md 8(a)): evaluates every

@@ -38,7 +38,7 @@ def test_config_struct_is_validated_before_any_device_is_touched(pkg):
     h = C.c_void_p()
     assert lib.vg_create_config(None, C.byref(h)) == -1
     for bad in (dict(struct_size=4), dict(launch_mode=7), dict(marg_mode=5), dict(fused_min_windows=-2), dict(pack_threads=65)):
-        cfg = ba.Config(struct_size=C.sizeof(ba.Config), device=-1)
+        cfg = ba.Config(struct_size=C.sizeof(ba.Config), device=0)
         for k, v in bad.items():
             setattr(cfg, k, v)
         assert lib.vg_create_config(C.byref(cfg), C.byref(h)) == -1, bad

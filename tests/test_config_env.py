@@ -23,7 +23,7 @@ if EMULATED:
 from vins_mono_amd import ba, synth
 probs = [ba.PackedProblem(synth.SyntheticSequence(20 + i, L=12).window(0)) for i in range(32)]
 out = {}
-for name, h in (("plain", ba.Handle()), ("config", ba.Handle(config=dict(device=-1, launch_mode="direct")))):
+for name, h in (("plain", ba.Handle()), ("config", ba.Handle(config=dict(device=None, launch_mode="direct")))):
     h.ba_upload(probs, [ba.VG_MARGIN_NONE] * 32)
     h.ba_run_async()
     st, sm, _ = h.ba_download()

@@ -588,3 +588,44 @@ def test_link_time_wrap_of_ceres_solve():
         assert a[:2] == b[:2] and np.allclose(a[2:6], b[2:6], rtol=1e-12)
         if a[0] and b[6] != 0:
             assert np.isclose(a[6], b[6], rtol=1e-6)          # model change is re-derived from cost_change / relative_decrease
+
+
+# ------------------------------------------------------------------------------------------ IMU sqrt_info in the reference's form (round 6)
+def _imu_tables_in_reference_form(h, prob):
+    """vg_ba_set_imu_info_mode(VG_IMU_INFO_REFERENCE): sqrt_info = LLT(covariance.inverse()).matrixL()^T formed as imu_factor.h:64 spells it,
+    in the operation order of the Eigen stand-in oracle/_ref is built on -- the weighted IMU residuals / Jacobians then agree with the
+    reference's Evaluate() to the rounding of the raw residual alone (1e-12 of a row's weight; the default form, U^-1 of cov = U U^T,
+    agrees to 1e-6 of it: the covariance is that badly conditioned)."""
+    _, _, ir, iJ = _ref_factor_tables(prob)
+    worst = {}
+    for mode in (ba.VG_IMU_INFO_REFERENCE, ba.VG_IMU_INFO_FACTOR):
+        h.ba_set_imu_info_mode(mode)
+        out = h.ba_eval_factors(prob)
+        w = 0.0
+        for k in range(prob['pose'].shape[0] - 1):
+            W = np.abs(B.imu_sqrt_info(prob['imu'][k]['covariance'])).sum(axis=1)
+            w = max(w, np.abs((out['imu_r'][k] - ir[k]) / W).max(), np.abs((out['imu_J'][k] - iJ[k]) / W[:, None]).max())
+        worst[mode] = w
+    h.ba_set_imu_info_mode(ba.VG_IMU_INFO_FACTOR)
+    return worst
+
+
+def test_imu_sqrt_info_in_reference_form_emulated(simt_handle):
+    _, _, prob = _window_with_prior(21)
+    worst = _imu_tables_in_reference_form(simt_handle, prob)
+    assert worst[ba.VG_IMU_INFO_REFERENCE] < 2e-14 and worst[ba.VG_IMU_INFO_FACTOR] < 1e-12, worst
+    # and the solve still runs on it: same decisions as the reference's loop on this window
+    simt_handle.ba_set_imu_info_mode(ba.VG_IMU_INFO_REFERENCE)
+    try:
+        st_r, sm_r, _ = R.optimization(prob, 1)
+        st, sm, _ = simt_handle.ba_optimize(prob)
+        assert sm['status'] == 0 and sm['num_iterations'] == sm_r['num_iterations'] and _rel_state_err(st, st_r) < 1e-4
+    finally:
+        simt_handle.ba_set_imu_info_mode(ba.VG_IMU_INFO_FACTOR)
+
+
+@pytest.mark.gpu
+def test_imu_sqrt_info_in_reference_form_on_device(handle):
+    _, _, prob = _window_with_prior(22)
+    worst = _imu_tables_in_reference_form(handle, prob)
+    assert worst[ba.VG_IMU_INFO_REFERENCE] < 2e-14 and worst[ba.VG_IMU_INFO_FACTOR] < 1e-12, worst

@@ -11,8 +11,9 @@ from . import lib
 VG_MAX_ITERS = 32
 VG_MARGIN_OLD, VG_MARGIN_SECOND_NEW, VG_MARGIN_NONE = 0, 1, 2
 VG_MARG_SQRT, VG_MARG_EIGEN = 0, 1     # vg_ba_set_marg_mode
+VG_IMU_INFO_FACTOR, VG_IMU_INFO_REFERENCE = 0, 1     # vg_ba_set_imu_info_mode
 VG_OK = 0
-VG_ABI_VERSION = 11         # include/vinsgpu.h
+VG_ABI_VERSION = 12         # include/vinsgpu.h
 VG_LAUNCH_DIRECT, VG_LAUNCH_GRAPH = 0, 1   # vg_ba_set_launch_mode
 VG_LAUNCH_DEFAULT = VG_LAUNCH_DIRECT        # include/vinsgpu.h
 VG_PRIOR_RESIDENT = -1
@@ -215,14 +216,15 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 
 class Config(C.Structure):
-    """vg_config (include/vinsgpu.h, ABI 10): everything that shapes a handle in one struct; a handle made from it never reads the environment."""
+    """vg_config (include/vinsgpu.h, ABI 12): everything that shapes a handle in one struct; a handle made from it never reads the environment."""
     _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("launch_mode", C.c_int), ("marg_mode", C.c_int),
-                ("fused_min_windows", C.c_int), ("pack_threads", C.c_int)]
+                ("fused_min_windows", C.c_int), ("pack_threads", C.c_int), ("imu_info_mode", C.c_int)]
 
 
 class Handle:
     """vg_create / vg_destroy wrapper; raises RuntimeError with vg_last_error on failures.  config: a dict of vg_config fields
-    (device, launch_mode = 'graph' | 'direct', marg_mode, fused_min_windows, pack_threads) -> vg_create_config."""
+    (device: None = the current one, else the HIP device index; launch_mode = 'graph' | 'direct', marg_mode, fused_min_windows,
+    pack_threads, imu_info_mode) -> vg_create_config."""
 
     def __init__(self, config=None):
         self.lib = lib()
@@ -274,9 +276,11 @@ class Handle:
         if config is None:
             rc = L.vg_create(C.byref(self.h))
         else:
-            cfg = Config(struct_size=C.sizeof(Config), device=int(config.get("device", -1)),
+            dev = config.get("device")                      # vg_config::device: 0 = the current device, k + 1 = device k
+            cfg = Config(struct_size=C.sizeof(Config), device=0 if dev is None or int(dev) < 0 else int(dev) + 1,
                          launch_mode={None: 0, "direct": 1, "graph": 2}[config.get("launch_mode")], marg_mode=int(config.get("marg_mode", 0)),
-                         fused_min_windows=int(config.get("fused_min_windows", 0)), pack_threads=int(config.get("pack_threads", 0)))
+                         fused_min_windows=int(config.get("fused_min_windows", 0)), pack_threads=int(config.get("pack_threads", 0)),
+                         imu_info_mode=int(config.get("imu_info_mode", 0)))
             L.vg_create_config.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
             rc = L.vg_create_config(C.byref(cfg), C.byref(self.h))
         if rc != VG_OK:
@@ -359,6 +363,11 @@ class Handle:
     def ba_set_marg_mode(self, mode):
         """VG_MARG_SQRT (0, default) / VG_MARG_EIGEN (1): form of the prior factor (include/vinsgpu.h)."""
         self._chk(self.lib.vg_ba_set_marg_mode(self.h, int(mode)), "vg_ba_set_marg_mode")
+
+    def ba_set_imu_info_mode(self, mode):
+        """VG_IMU_INFO_FACTOR (0, default) / VG_IMU_INFO_REFERENCE (1): form of the IMU factors' sqrt_info (include/vinsgpu.h)."""
+        self.lib.vg_ba_set_imu_info_mode.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self.lib.vg_ba_set_imu_info_mode(self.h, int(mode)), "vg_ba_set_imu_info_mode")
 
     def rccl_unique_id(self):
         """128 bytes from ncclGetUniqueId (rank 0 calls this and broadcasts them)."""

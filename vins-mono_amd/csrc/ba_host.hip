@@ -215,6 +215,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
     L.NBcap = up(std::max(NBmax, 1), 8);
     L.REC = 28 + 12 * L.e + 2 * L.t;
     L.nst = up(7 * L.Kp + 9 * L.K + 8, 2);
+    L.imu_info = h->ba.imu_info_mode;
     // one workgroup solves a window out of LDS while the camera part fits its tiling; wider windows (and windows the
     // caller shards over ranks) take the large-window path
     L.big = (L.RcPad > 96 || L.Rc > 127 || L.K + 1 > BA_MAX_K || h->ba.force_large) ? 1 : 0;
@@ -276,7 +277,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         if (L.lds_solve > 160 * 1024) { h->err = "solve kernel LDS carve exceeds 160 KB"; return VG_ERR_UNSUPPORTED; }
         const int nib = std::min(std::min(L.K - 1, BA_IMU_BATCH), L.igs);
         L.lds_lin = 8 * std::max(up(nib * 225, 2) + nib * 480, 5 * L.Ncap);
-        L.lds_pro = 8 * BA_NW * 256;
+        L.lds_pro = 8 * BA_NW * (L.imu_info ? 512 : 256);      // imu_sqrt_info / imu_sqrt_info_ref: scratch per wavefront
         if (8 * L.Ncap * L.Ncap <= 128 * 1024) L.lds_pro = std::max(L.lds_pro, 8 * L.Ncap * L.Ncap);   // J0 staged in LDS when it fits
         if (L.lds_lin > 128 * 1024) { h->err = "prior too large for the linearisation kernel"; return VG_ERR_UNSUPPORTED; }
         // fused projection kernel (ba_linacc_proj_kernel): LDS = staged records [la_chf][33] | pair blocks [Kp (Kp - 1) / 2][90] |
@@ -973,6 +974,13 @@ extern "C" int vg_ba_set_large_window(vg_handle* h, int force) {
 extern "C" int vg_ba_set_marg_mode(vg_handle* h, int mode) {
     if (!h || (mode != VG_MARG_SQRT && mode != VG_MARG_EIGEN)) return VG_ERR_BAD_ARG;
     h->ba.marg_mode = mode;
+    h->ba.uploaded = false;
+    return VG_OK;
+}
+// Form of the IMU factors' sqrt_info (imu_sqrt_info / imu_sqrt_info_ref in ba_pipeline.hip).  Takes effect at the next upload.
+extern "C" int vg_ba_set_imu_info_mode(vg_handle* h, int mode) {
+    if (!h || (mode != VG_IMU_INFO_FACTOR && mode != VG_IMU_INFO_REFERENCE)) return VG_ERR_BAD_ARG;
+    h->ba.imu_info_mode = mode;
     h->ba.uploaded = false;
     return VG_OK;
 }

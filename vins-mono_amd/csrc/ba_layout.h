@@ -78,6 +78,7 @@ struct BaLayout {
     int nbf, nbl, nba, ntask;      // workgroups per window: projection tiles, cost partials (nbf + nig + 1), accumulation; owner tasks
     int nig, igs, nprw;            // IMU linearisation: groups per window, factors per group (one workgroup each), workgroups for the prior (0: group 0 does it)
     int nst;                       // doubles of one state copy [pose Kp*7 | sb K*9 | ex 7 | td 1]
+    int imu_info;                  // form of the IMU factors' sqrt_info (vg_ba_set_imu_info_mode): 0 = U^-1 of covariance = U U^T, 1 = inverse() then LLT as imu_factor.h:64 spells it
     // ---- int arrays (offsets in ints, per window)
     int io_hdr, io_lm_start, io_lm_fbeg, io_fac_i, io_fac_j, io_fac_lm, io_fac_oi, io_fac_oj, io_fac_slot,
         io_pair_ptr, io_task_list, io_imu_valid, io_pb_kind, io_pb_idx, io_pb_col, io_pb_off, io_pb_x0off, istride;

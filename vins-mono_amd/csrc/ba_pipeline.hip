@@ -262,6 +262,92 @@ DEV bool judge_candidate(Ctl& s, double cs, const BaLayout& L, double* out, int*
 // LLT(covariance^-1).matrixL().transpose() of imu_factor.h:64 (the Cholesky factor of the inverse is unique) without
 // forming the badly conditioned inverse; J0^T J0 of the prior; state copy 0; control block.
 // ================================================================================================
+// The same factor formed the way imu_factor.h:64 SPELLS it -- covariance.inverse() by partial-pivot LU solved against the identity,
+// then the LLT of the inverse's lower triangle, transposed -- in the operation order of the stand-in Eigen that oracle/_ref is built
+// on (oracle/ref_stubs/eigen3/Eigen/Dense: MatrixBase::inverse(), LLT::compute()) and without contraction: the weights that build
+// uses, bit for bit.  Selected by vg_config::imu_info_mode = VG_IMU_INFO_REFERENCE / vg_ba_set_imu_info_mode (does
+// the form of this factor decide the sequence-level trust-region flips?  measured: profiles/r06_flip_stats.json).  One wavefront
+// per factor, lane = row (LU, LLT) or column (the solve); LDS per wavefront: LU / L [225] | inverse [225] | permutation [15].
+NOINL void imu_sqrt_info_ref(const Ctx& c_in) {
+#pragma clang fp contract(off)
+    const Ctx c = c_in;
+    const BaLayout L = *c.Lp;
+    double* A = LDSB + c.wave * 512;
+    double* V = A + 240;
+    double* Pm = V + 240;
+    const int nimu = L.K - 1;
+    const int* valid = c.ia + L.io_imu_valid;
+    const int i = c.lane;
+    for (int base = 0; base < nimu; base += BA_NW) {
+        const int f = base + c.wave;
+        const bool act = f < nimu && valid[f];
+        const bool row = act && i < 15;
+        const double* cov = c.di + L.do_imu + f * BA_IMU_STRIDE + IM_COV;
+        if (act)
+            for (int k = c.lane; k < 225; k += 64) A[k] = cov[k];
+        if (row) Pm[i] = (double)i;
+        __syncthreads();
+        for (int k = 0; k < 15; ++k) {                 // LU in place, row pivoting: the first row of the largest magnitude
+            const double v = (row && i >= k) ? fabs(A[i * 15 + k]) : -1.0;
+            const double m = wave_max_all(v);
+            const unsigned long long eq = __ballot(row && i >= k && v == m);
+            const int piv = eq ? (int)__builtin_ctzll(eq) : k;
+            __syncthreads();
+            if (row && piv != k) {
+                const double t = A[k * 15 + i];
+                A[k * 15 + i] = A[piv * 15 + i];
+                A[piv * 15 + i] = t;
+                if (i == 0) { const double q = Pm[k]; Pm[k] = Pm[piv]; Pm[piv] = q; }
+            }
+            __syncthreads();
+            if (row && i > k) {
+                const double fk = A[i * 15 + k] / A[k * 15 + k];
+                A[i * 15 + k] = fk;
+                for (int j = k + 1; j < 15; ++j) A[i * 15 + j] -= fk * A[k * 15 + j];
+            }
+            __syncthreads();
+        }
+        if (row) {                                      // column i of the inverse: L U x = P e_i
+            double y[15], x[15];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                double sacc = (Pm[r] == (double)i) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) if (k < r) sacc -= A[r * 15 + k] * y[k];
+                y[r] = sacc;
+            }
+#pragma unroll
+            for (int r = 14; r >= 0; --r) {
+                double sacc = y[r];
+#pragma unroll
+                for (int k = 0; k < 15; ++k) if (k > r) sacc -= A[r * 15 + k] * x[k];
+                x[r] = sacc / A[r * 15 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 15; ++r) V[r * 15 + i] = x[r];
+        }
+        __syncthreads();
+        for (int j = 0; j < 15; ++j) {                  // LLT of the lower triangle of V, L built in A
+            if (row && i == j) {
+                double d = V[j * 15 + j];
+                for (int k = 0; k < j; ++k) d -= A[j * 15 + k] * A[j * 15 + k];
+                A[j * 15 + j] = sqrt(d);
+            }
+            __syncthreads();
+            if (row && i > j) {
+                double sacc = V[i * 15 + j];
+                for (int k = 0; k < j; ++k) sacc -= A[i * 15 + k] * A[j * 15 + k];
+                A[i * 15 + j] = sacc / A[j * 15 + j];
+            }
+            __syncthreads();
+        }
+        double* Uo = c.sc + L.so_imuU + f * 225;        // sqrt_info = L^T (upper), zeros below the diagonal
+        if (row)
+            for (int r = 0; r < 15; ++r) Uo[r * 15 + i] = (i >= r) ? A[i * 15 + r] : 0.0;
+        __syncthreads();
+    }
+}
+
 NOINL void imu_sqrt_info(const Ctx& c_in) {
     const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
     const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
@@ -333,7 +419,8 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
         if (c.tid == C_T0) v = (double)wall_clock64();
         c.sc[L.so_ctl + c.tid] = v;
     }
-    imu_sqrt_info(c);
+    if (L.imu_info) imu_sqrt_info_ref(c);
+    else imu_sqrt_info(c);
     if (c.nprior) {
         // J0^T J0 once per solve, J0 staged in LDS
         const int n = c.nprior;

@@ -35,17 +35,19 @@ extern "C" int vg_create(vg_handle** out) {
 extern "C" int vg_create_config(const vg_config* cfg, vg_handle** out) {
     if (!cfg || !out || cfg->struct_size < (int)(2 * sizeof(int))) return VG_ERR_BAD_ARG;
     vg_config c;
-    memset(&c, 0, sizeof(c));
-    c.device = -1;
+    memset(&c, 0, sizeof(c));                                  // fields beyond the caller's struct_size: their defaults (all zero)
     memcpy(&c, cfg, (size_t)cfg->struct_size < sizeof(c) ? (size_t)cfg->struct_size : sizeof(c));
     if (c.launch_mode != 0 && c.launch_mode != VG_LAUNCH_GRAPH + 1 && c.launch_mode != VG_LAUNCH_DIRECT + 1) return VG_ERR_BAD_ARG;
     if (c.marg_mode != VG_MARG_SQRT && c.marg_mode != VG_MARG_EIGEN) return VG_ERR_BAD_ARG;
     if (c.fused_min_windows < -1 || c.pack_threads < 0 || c.pack_threads > 64) return VG_ERR_BAD_ARG;
-    if (c.device >= 0) {
+    if (c.imu_info_mode != VG_IMU_INFO_FACTOR && c.imu_info_mode != VG_IMU_INFO_REFERENCE) return VG_ERR_BAD_ARG;
+    // device: 0 (what a zero-initialised struct holds) and negative values = the CURRENT device -- a rank that chose its GPU with
+    // hipSetDevice(local_rank) stays there --, k + 1 = device k (the encoding of launch_mode; ABI 12)
+    if (c.device > 0) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return VG_ERR_NO_DEVICE;
-        if (c.device >= ndev) return VG_ERR_BAD_ARG;
-        if (hipSetDevice(c.device) != hipSuccess) return VG_ERR_HIP;
+        if (c.device - 1 >= ndev) return VG_ERR_BAD_ARG;
+        if (hipSetDevice(c.device - 1) != hipSuccess) return VG_ERR_HIP;
     }
     const int rc = vg_create(out);
     if (rc != VG_OK) return rc;
@@ -53,6 +55,7 @@ extern "C" int vg_create_config(const vg_config* cfg, vg_handle** out) {
     h->ba.no_env = true;                                        // every switch below is explicit: the environment is not consulted
     h->ba.launch_mode = c.launch_mode ? c.launch_mode - 1 : VG_LAUNCH_DEFAULT;
     h->ba.marg_mode = c.marg_mode;
+    h->ba.imu_info_mode = c.imu_info_mode;
     h->ba.fused_min = c.fused_min_windows == 0 ? 32 : (c.fused_min_windows < 0 ? 0 : c.fused_min_windows);
     h->ba.pack_threads = c.pack_threads ? c.pack_threads : 8;
     return VG_OK;

@@ -67,6 +67,7 @@ struct BaBatch {
     bool solved_recorded = false;    // ev_fork recorded behind ba_final_kernel of the current run
     bool force_large = false;        // vg_ba_set_large_window: take the large-window path whatever the size
     int marg_mode = 0;               // vg_ba_set_marg_mode: VG_MARG_SQRT (default) / VG_MARG_EIGEN
+    int imu_info_mode = 0;           // vg_ba_set_imu_info_mode: VG_IMU_INFO_FACTOR (default) / VG_IMU_INFO_REFERENCE
     int res_L = 0, res_F = 0, res_O = 0, res_N = 0;   // vg_ba_reserve: capacities every layout is built for at least
     int fused_min = -1;              // vg_ba_set_fused_min_windows (-1: environment VG_BA_FUSED_MIN, else 32; 0: never)
     bool no_env = false;             // handle made by vg_create_config: no environment variable shapes its behaviour

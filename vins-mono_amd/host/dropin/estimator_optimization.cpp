@@ -48,6 +48,7 @@ struct VgSide {
     bool solver_time_cap = false; // forward SOLVER_TIME as max_solver_time_in_seconds (estimator.cpp:812-815)
     bool marg_eigen = false;      // the reference's eigen form of the prior instead of the pivoted-Cholesky square root
     bool marg_mode_dirty = false;
+    bool imu_info_reference = false, imu_info_dirty = false;
 };
 std::mutex g_mu;
 std::unordered_map<const Estimator*, VgSide> g_side;
@@ -140,6 +141,7 @@ void Estimator::optimization() {
     // form of the prior factor the marginalization hands to the next frame: the pivoted-Cholesky square root (default) or the
     // reference's eigen form (marginalization_factor.cpp:285-296) -- vins_gpu_set_option(e, VINS_GPU_OPT_MARG_EIGEN, 1); include/vinsgpu.h
     if (s.marg_mode_dirty) { vg_ba_set_marg_mode(s.vg, s.marg_eigen ? VG_MARG_EIGEN : VG_MARG_SQRT); s.marg_mode_dirty = false; }
+    if (s.imu_info_dirty) { vg_ba_set_imu_info_mode(s.vg, s.imu_info_reference ? VG_IMU_INFO_REFERENCE : VG_IMU_INFO_FACTOR); s.imu_info_dirty = false; }
     collect_prior(*this, s);                                    // the previous frame's marginalization result, if still on the device
     vector2double();                                            // estimator.cpp:701
     const int K = WINDOW_SIZE + 1;
@@ -277,11 +279,13 @@ void vins_gpu_reset(Estimator* e) {
 }
 // behaviour switches of one Estimator (run time, no environment variables): VINS_GPU_OPT_SOLVER_TIME_CAP forwards SOLVER_TIME as
 // max_solver_time_in_seconds (estimator.cpp:812-815; default off), VINS_GPU_OPT_MARG_EIGEN asks for the reference's eigen form of
-// the prior instead of the square root (default off).  Takes effect at the next optimization().  Returns 0, -1 for an unknown option.
+// the prior instead of the square root (default off), VINS_GPU_OPT_IMU_INFO_REFERENCE (3) for the IMU factors' sqrt_info formed as
+// imu_factor.h:64 spells it, inverse() then LLT (vg_ba_set_imu_info_mode; default off).  Takes effect at the next optimization().  Returns 0, -1 for an unknown option.
 int vins_gpu_set_option(Estimator* e, int option, int value) {
     VgSide& s = side_of(e);
     if (option == 1) { s.solver_time_cap = value != 0; return 0; }                                       // VINS_GPU_OPT_SOLVER_TIME_CAP
     if (option == 2) { s.marg_eigen = value != 0; s.marg_mode_dirty = true; return 0; }                  // VINS_GPU_OPT_MARG_EIGEN
+    if (option == 3) { s.imu_info_reference = value != 0; s.imu_info_dirty = true; return 0; }           // VINS_GPU_OPT_IMU_INFO_REFERENCE
     return -1;
 }
 // trace of the last solve
