@@ -565,7 +565,12 @@ typedef struct vg_fe_frame_out {
 } vg_fe_frame_out;
 /* called once per published frame after rejectWithF: `after` holds n1, n2, status_lk, status_f, forw_xy; write the walk order into
  * order[0 .. n2) as indices into the list of the n2 survivors (a permutation); return 0 (anything else aborts the frame with
- * VG_ERR_BAD_ARG) */
+ * VG_ERR_BAD_ARG).
+ * Failure semantics (ABI 12): every error that follows from the arguments alone -- sizes, a point list without a previous frame -- is
+ * returned BEFORE the frame is uploaded: the stream is untouched.  An error after that (the callback's, a detection overflow, a HIP
+ * error) leaves the device stream one frame ahead of the caller; the callback must therefore not change the caller's own state
+ * (work on copies, apply the statuses after VG_OK -- host/dropin/feature_tracker_readimage.cpp), and the caller re-starts the stream
+ * (vg_fe_configure) before it tracks again. */
 typedef int (*vg_fe_order_fn)(void* user, const vg_fe_frame_out* after, int* order);
 typedef struct vg_fe_frame_in {
     int struct_size;             /* sizeof(vg_fe_frame_in) */

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(pkg):
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     lib.vg_abi_version.restype = C.c_int
-    assert lib.vg_abi_version() == 11 == ba.VG_ABI_VERSION
+    assert lib.vg_abi_version() == 12 == ba.VG_ABI_VERSION
 
 
 def test_config_struct_is_validated_before_any_device_is_touched(pkg):
@@ -37,12 +37,12 @@ def test_config_struct_is_validated_before_any_device_is_touched(pkg):
     lib.vg_create_config.argtypes = [C.POINTER(ba.Config), C.POINTER(C.c_void_p)]
     h = C.c_void_p()
     assert lib.vg_create_config(None, C.byref(h)) == -1
-    for bad in (dict(struct_size=4), dict(launch_mode=7), dict(marg_mode=5), dict(fused_min_windows=-2), dict(pack_threads=65)):
+    for bad in (dict(struct_size=4), dict(launch_mode=7), dict(marg_mode=5), dict(fused_min_windows=-2), dict(pack_threads=65), dict(imu_info_mode=2)):
         cfg = ba.Config(struct_size=C.sizeof(ba.Config), device=0)
         for k, v in bad.items():
             setattr(cfg, k, v)
         assert lib.vg_create_config(C.byref(cfg), C.byref(h)) == -1, bad
-    assert C.sizeof(ba.Config) == 24
+    assert C.sizeof(ba.Config) == 28
 
 
 def test_struct_sizes_match_header():

@@ -635,6 +635,8 @@ extern "C" int vg_fe_read_image(vg_handle* h, const vg_fe_frame_in* in, vg_fe_fr
     if (s->max_pts > 2048) { h->err = "vg_fe_read_image: max_points > 2048"; return VG_ERR_UNSUPPORTED; }
     if (in->n > s->max_pts || in->max_cnt < 0 || in->max_cnt > s->max_pts) { h->err = "vg_fe_read_image: n / max_cnt beyond max_points of vg_fe_configure"; return VG_ERR_BAD_ARG; }
     if (in->publish && (in->min_dist < 0 || !(in->f_threshold > 0) || !(in->quality > 0))) { h->err = "vg_fe_read_image: min_dist / f_threshold / quality"; return VG_ERR_BAD_ARG; }
+    // (everything that can be refused from the arguments is refused before the frame goes up and the pyramid ring turns)
+    if (in->n > 0 && !s->have_prev) { h->err = "vg_fe_read_image: points to track but no previous frame"; return VG_ERR_BAD_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = ri_ensure(h, s);
     if (rc) return rc;
@@ -665,13 +667,11 @@ extern "C" int vg_fe_read_image(vg_handle* h, const vg_fe_frame_in* in, vg_fe_fr
     hctl[RI_N] = in->n; hctl[RI_PUBLISH] = in->publish ? 1 : 0; hctl[RI_BEST] = -1;
     if (in->n) memcpy(q->host + sizeof(int) * RI_CTL_INTS, in->cur_xy, sizeof(float) * 2 * in->n);
     HIPCHK(h, hipMemcpyAsync(q->d_in, q->host, sizeof(int) * RI_CTL_INTS + sizeof(float) * 2 * in->n, hipMemcpyHostToDevice, h->stream));
-    const bool had_prev = s->have_prev;
     rc = vg_fe_build_async(h, in->equalize);
     if (rc) return rc;
     FeDev d = s->d;
     d.npts = r.ctl + RI_N; d.prev_xy = r.xy_in;
     const bool track = in->n > 0;
-    if (track && !had_prev) { h->err = "vg_fe_read_image: points to track but no previous frame"; return VG_ERR_BAD_ARG; }
     if (track) hipLaunchKernelGGL(fe_lk_kernel, dim3(in->n, 1), dim3(64), 0, h->stream, d);
     hipLaunchKernelGGL(fe_ri_after_lk_kernel, dim3(1), dim3(256), 0, h->stream, d, r);
     char* hA = q->host + q->in_bytes;

@@ -74,7 +74,9 @@ FeSide& ensure(FeatureTracker* t, int w, int h) {
     FeSide& s = side_of(t);
     if (vg_abi_version() != VG_ABI_VERSION) throw std::runtime_error("libvinsgpu.so was built from another include/vinsgpu.h (ABI version mismatch)");
     if (!s.vg) chk(vg_create(&s.vg), s.vg, "vg_create");
-    const int cap = std::max(MAX_CNT, 1) * 4;
+    // vg_fe_read_image takes streams of up to 2048 points; a list never exceeds MAX_CNT (:144-156), the factor is slack.  MAX_CNT
+    // beyond 2048 takes the step-by-step branch of readImage.
+    const int cap = MAX_CNT <= 2048 ? std::min(std::max(MAX_CNT, 1) * 4, 2048) : MAX_CNT;
     if (s.capacity < cap || s.width != w || s.height != h) {
         chk(vg_fe_configure(s.vg, w, h, 1, cap), s.vg, "vg_fe_configure");
         s.capacity = cap; s.width = w; s.height = h;
@@ -162,18 +164,24 @@ void apply_statuses(FeatureTracker* t, const vg_fe_frame_out* a, int n_in) {
 struct OrderCtx {
     FeatureTracker* t;
     int n_in;
-    bool applied;
     vector<pair<int, pair<cv::Point2f, int>>> sorted;      // setMask's cnt_pts_id (:43), the third field holding the list index instead of the id
 };
 // the order of setMask's walk = the reference's sort call (:47-51): same element type, same comparator, same std::sort -- the permutation
 // of a sort depends on the outcomes of its comparisons only, and those look at the counts
 int order_callback(void* user, const vg_fe_frame_out* after, int* order) {
     OrderCtx* c = static_cast<OrderCtx*>(user);
-    FeatureTracker* t = c->t;
-    apply_statuses(t, after, c->n_in);
-    c->applied = true;
-    if ((int)t->forw_pts.size() != after->n2) return 1;
-    for (unsigned int i = 0; i < t->forw_pts.size(); i++) c->sorted.push_back(make_pair(t->track_cnt[i], make_pair(t->forw_pts[i], (int)i)));
+    const FeatureTracker* t = c->t;
+    // The survivors with their counts (:115-128, :193-198: track_cnt++ after the tracking), formed ON THE SIDE: the class's vectors are
+    // only touched once the library call has returned VG_OK, so a frame that fails later (detection overflow, a HIP error) leaves the
+    // tracker as it was.
+    c->sorted.clear();
+    for (int i = 0, k = 0, idx = 0; i < c->n_in; i++) {
+        if (!after->status_lk[i]) continue;
+        const bool keep = !after->ransac_ran || after->status_f[k];
+        k++;
+        if (keep) c->sorted.push_back(make_pair(t->track_cnt[i] + 1, make_pair(cv::Point2f(after->forw_xy[2 * i], after->forw_xy[2 * i + 1]), idx++)));
+    }
+    if ((int)c->sorted.size() != after->n2) return 1;
     sort(c->sorted.begin(), c->sorted.end(),
          [](const pair<int, pair<cv::Point2f, int>>& a, const pair<int, pair<cv::Point2f, int>>& b) { return a.first > b.first; });
     for (int q = 0; q < after->n2; q++) order[q] = c->sorted[q].second.second;
@@ -190,7 +198,7 @@ void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {     // f
                                  ", the configuration says " + std::to_string(COL) + "x" + std::to_string(ROW));
     FeSide& s = ensure(this, COL, ROW);
     const float* lifted = nullptr;
-    if (s.pinhole) {
+    if (s.pinhole && s.capacity <= 2048) {
         // ---- one call per frame
         vg_fe_frame_in in;
         std::memset(&in, 0, sizeof(in));
@@ -209,7 +217,7 @@ void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {     // f
                 in.base_mask = s.base_copy.data();
             }
         }
-        OrderCtx ctx{this, in.n, false, {}};
+        OrderCtx ctx{this, in.n, {}};
         in.order = order_callback; in.user = &ctx;
         if (in.n > s.capacity) throw std::runtime_error("FeatureTracker::readImage: more points than the configured capacity");
         vg_fe_frame_out out;
@@ -220,7 +228,7 @@ void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {     // f
             prev_img = cur_img = forw_img = _img;
         else
             forw_img = _img;
-        if (!ctx.applied) apply_statuses(this, &out, in.n);                  // (frames that are not published; published frames without a survivor)
+        apply_statuses(this, &out, in.n);                                    // only now: the call returned VG_OK
         if (PUB_THIS_FRAME) {
             // setMask's outcome (:53-68): the kept points in the order of the walk
             vector<cv::Point2f> kept_pts;

@@ -145,17 +145,22 @@ namespace {
 struct OrderCtx {
     FeatureTracker* t;
     int n_in;
-    bool applied;
     vector<pair<int, pair<cv::Point2f, int>>> sorted;      // setMask's cnt_pts_id (:43) with the list index in the place of the id
 };
 // The order of setMask's walk = the reference's sort call (:47-51): std::sort by track_cnt is not stable, the order among equal counts is
 // what the platform's std::sort makes of the sequence; its permutation depends on the comparisons only, and those look at the counts.
 int order_callback(void* user, const vg_fe_frame_out* after, int* order) {
     OrderCtx* c = static_cast<OrderCtx*>(user);
-    c->t->applyStatuses(*after, c->n_in);
-    c->applied = true;
-    if ((int)c->t->forw_pts.size() != after->n2) return 1;
-    for (unsigned int i = 0; i < c->t->forw_pts.size(); i++) c->sorted.push_back(make_pair(c->t->track_cnt[i], make_pair(c->t->forw_pts[i], (int)i)));
+    // the survivors with their counts (:115-128, :193-198), formed on the side: the tracker's own vectors are only touched once the library
+    // call has returned VG_OK, so a frame that fails later leaves the tracker as it was
+    c->sorted.clear();
+    for (int i = 0, k = 0, idx = 0; i < c->n_in; i++) {
+        if (!after->status_lk[i]) continue;
+        const bool keep = !after->ransac_ran || after->status_f[k];
+        k++;
+        if (keep) c->sorted.push_back(make_pair(c->t->track_cnt[i] + 1, make_pair(cv::Point2f(after->forw_xy[2 * i], after->forw_xy[2 * i + 1]), idx++)));
+    }
+    if ((int)c->sorted.size() != after->n2) return 1;
     sort(c->sorted.begin(), c->sorted.end(),
          [](const pair<int, pair<cv::Point2f, int>>& a, const pair<int, pair<cv::Point2f, int>>& b) { return a.first > b.first; });
     for (int q = 0; q < after->n2; q++) order[q] = c->sorted[q].second.second;
@@ -171,7 +176,9 @@ void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {    // :8
     cur_time = _cur_time;
     if (!configured_) {
         chk(vg_create(&vg_), vg_, "vg_create");
-        fe_capacity_ = std::max(MAX_CNT, 1) * 4;
+        // vg_fe_read_image takes streams of up to 2048 points; a list never exceeds MAX_CNT (:144-156), the factor is slack
+        if (MAX_CNT > 2048) throw std::runtime_error("FeatureTracker::readImage: max_cnt > 2048 is not offered (vg_fe_read_image)");
+        fe_capacity_ = std::min(std::max(MAX_CNT, 1) * 4, 2048);
         chk(vg_fe_configure(vg_, COL, ROW, 1, fe_capacity_), vg_, "vg_fe_configure");
         configured_ = true;
     }
@@ -185,13 +192,13 @@ void FeatureTracker::readImage(const cv::Mat& _img, double _cur_time) {    // :8
     const double intr[8] = {m_camera.fx, m_camera.fy, m_camera.cx, m_camera.cy, m_camera.k1, m_camera.k2, m_camera.p1, m_camera.p2};
     std::memcpy(in.intr, intr, sizeof(intr));
     in.base_mask = (FISHEYE && PUB_THIS_FRAME) ? fisheye_mask.data : nullptr;           // :38-41 (contiguous ROW x COL, readFeatureTrackerParameters)
-    OrderCtx ctx{this, in.n, false, {}};
+    OrderCtx ctx{this, in.n, {}};
     in.order = order_callback; in.user = &ctx;
     vg_fe_frame_out out;
     chk(vg_fe_read_image(vg_, &in, &out), vg_, "vg_fe_read_image");
     if (forw_img.empty()) prev_img = cur_img = forw_img = _img;
     else forw_img = _img;
-    if (!ctx.applied) applyStatuses(out, in.n);
+    applyStatuses(out, in.n);                                                // only now: the call returned VG_OK
     if (PUB_THIS_FRAME) {
         vector<cv::Point2f> kept_pts;                                        // setMask's outcome (:53-68): the kept points in walk order
         vector<int> kept_ids, kept_cnt;
