@@ -706,24 +706,67 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
 // of two, and ~k/4 FMAs per lane instead of an update of the whole trailing matrix: 265K -> ~100K cycles per window for n = 76.
 // (The right-looking form -- Schur complement in registers, two barriers per pivot -- is kept behind -DMG_SQRT_RIGHT_LOOKING.)
 // Same pivot rule (largest remaining diagonal, lowest index on ties), same cut, same output layout; the sums run in another order.
+// Round 6: the same pivot rule with SHORT dot products.  The sum over all earlier columns (37 terms on average for n = 75, five
+// dependent LDS-read -> FMA rounds per lane) is what a pivot waits for; after every sixteenth pivot the finished block of columns is
+// now subtracted from what is left of A' -- A' -= L_blk L_blk^T on v_mfma_f64_16x16x4_f64, one lower 16 x 16 tile per wavefront, and
+// b' -= L_blk y_blk -- so a column only needs the columns of its OWN block: at most two terms per lane, one round.  This is LAPACK's
+// blocked pivoted Cholesky (dpstrf): the running diagonal, the search and therefore the pivot sequence are those of the unblocked
+// form, only the order of the sums changes.  (A fixed elimination order on the matrix cores -- no search at all -- was measured
+// 20 % faster still and dropped: it cuts weak directions the pivoted order keeps, profiles/experiments/r06d_*.)
+typedef double mg_d4 __attribute__((vector_size(32)));
 DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, const double* bglob) {
-    const double* A = MG_LDS + offM;          // A' (lower triangle read)
+    double* A = MG_LDS + offM;                // A' (lower triangle read; updated block by block)
     double* Lc = MG_LDS + offV;               // column k of L at Lc[k * ld + i]
     double* dg0 = MG_LDS + offcs;             // running diagonal, copy 0 (-1e300 once pivoted)
     double* yv = dg0 + 2 * n + 1;             // y = L^-1 P^T b'   (kept for the caller: cs[2n + 1 ..))
     double* dg1 = yv + n;                     // running diagonal, copy 1
+    double* bb = dg1 + n;                     // b' minus the finished blocks' share
     (void)offred;
     __syncthreads();
     for (int k = c.tid; k < n * ld; k += MG_NT) Lc[k] = 0.0;
-    for (int i = c.tid; i < n; i += MG_NT) { yv[i] = 0.0; dg0[i] = A[i * ld + i]; }
+    for (int i = c.tid; i < n; i += MG_NT) { yv[i] = 0.0; dg0[i] = A[i * ld + i]; bb[i] = bglob[i]; }
     // MG_LPR lanes per row (8 with 1024 threads, 4 with 512): rows 0 .. n-1 of L and row n = the augmented one (n <= 96 < 128)
     enum { MG_LPR = MG_NT / 128, MG_LPR_SHIFT = MG_LPR == 8 ? 3 : 2 };
     static_assert(MG_LPR == 8 || MG_LPR == 4, "sqrt_factor: 512 or 1024 threads");
     const int row = c.tid >> MG_LPR_SHIFT, part = c.tid & (MG_LPR - 1);
     const bool has_row = row <= n;
+    const int wave = __builtin_amdgcn_readfirstlane(c.wave);
+    const int ntl = (n + 15) >> 4, ntile = ntl * (ntl + 1) / 2;       // lower 16 x 16 tiles of A' (16 ntl <= ld: the rows beyond n are zero in Lc)
     int rank = 0;
     for (int k = 0; k < n; ++k) {
         __syncthreads();
+        const int kb = k & ~15;
+        if (k == kb && k > 0) {
+            // ---- the block of columns [kb - 16, kb) leaves A' and b'
+            const int k0 = kb - 16;
+            const int jc = c.lane & 15, kq = c.lane >> 4;
+            for (int t = wave; t < ntile; t += MG_NW) {
+                int ti, tj;
+                tri_decode(t, ti, tj);
+                const double* pa = Lc + (k0 + kq) * ld + 16 * ti + jc;
+                const double* pb = Lc + (k0 + kq) * ld + 16 * tj + jc;
+                const double a0 = pa[0], a1 = pa[4 * ld], a2 = pa[8 * ld], a3 = pa[12 * ld];
+                const double b0 = pb[0], b1 = pb[4 * ld], b2 = pb[8 * ld], b3 = pb[12 * ld];
+                mg_d4 acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+                const int col = 16 * tj + jc;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = 16 * ti + kq + 4 * reg;       // D[i = kq + 4 reg][j = jc]
+                    if (r < n && col <= r) A[r * ld + col] -= acc[reg];
+                }
+            }
+            for (int i = c.tid; i < n; i += MG_NT) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sacc += Lc[(k0 + j) * ld + i] * yv[k0 + j];
+                bb[i] -= sacc;
+            }
+            __syncthreads();
+        }
         const double* dgr = (k & 1) ? dg1 : dg0;
         double* dgw = (k & 1) ? dg0 : dg1;
         // pivot = largest remaining diagonal (lowest index on ties): every wavefront on its own, two entries per lane
@@ -735,25 +778,20 @@ DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs,
         const int p = m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1;
         if (!(best > MG_EPS)) break;          // (uniform) nothing above eps is left: the rest is what the reference's cut drops
         const double inv = mg_rsqrt(best);
-        // lane `part` of a row takes j = part, part + 8, ...: two independent partial sums (the LDS reads of two terms in flight)
-        double s0 = 0.0, s1 = 0.0;
+        // the columns of this block only: lane `part` of a row takes j = kb + part and kb + part + MG_LPR (one round of LDS reads)
+        double sacc = 0.0;
         if (has_row) {
-            int j = part;
-            if (row < n) {
-                for (; j + MG_LPR < k; j += 2 * MG_LPR) {
-                    const double a0 = Lc[j * ld + row], b0 = Lc[j * ld + p], a1 = Lc[(j + MG_LPR) * ld + row], b1 = Lc[(j + MG_LPR) * ld + p];
-                    s0 += a0 * b0; s1 += a1 * b1;
-                }
-                if (j < k) s0 += Lc[j * ld + row] * Lc[j * ld + p];
+            if (MG_LPR == 8) {
+                const int j0 = kb + part, j1 = kb + part + 8;
+                const bool in0 = j0 < k, in1 = j1 < k;
+                const double b0 = Lc[(in0 ? j0 : kb) * ld + p], b1 = Lc[(in1 ? j1 : kb) * ld + p];
+                const double a0 = row < n ? Lc[(in0 ? j0 : kb) * ld + row] : yv[in0 ? j0 : kb];
+                const double a1 = row < n ? Lc[(in1 ? j1 : kb) * ld + row] : yv[in1 ? j1 : kb];
+                sacc = (in0 ? a0 * b0 : 0.0) + (in1 ? a1 * b1 : 0.0);
             } else {
-                for (; j + MG_LPR < k; j += 2 * MG_LPR) {
-                    const double a0 = yv[j], b0 = Lc[j * ld + p], a1 = yv[j + MG_LPR], b1 = Lc[(j + MG_LPR) * ld + p];
-                    s0 += a0 * b0; s1 += a1 * b1;
-                }
-                if (j < k) s0 += yv[j] * Lc[j * ld + p];
+                for (int j = kb + part; j < k; j += MG_LPR) sacc += (row < n ? Lc[j * ld + row] : yv[j]) * Lc[j * ld + p];
             }
         }
-        double sacc = s0 + s1;
         // sum over the eight lanes of the row on the DPP network (fixed order), result in every lane of the group
         sacc += dpp_mov_f64<0xB1>(sacc);      // quad_perm [1,0,3,2]
         sacc += dpp_mov_f64<0x4E>(sacc);      // quad_perm [2,3,0,1]
@@ -767,7 +805,7 @@ DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs,
                 Lc[k * ld + row] = v;
                 dgw[row] = (row == p || !(d > -1e299)) ? -1e300 : d - v * v;
             } else {
-                yv[k] = (bglob[p] - sacc) * inv;
+                yv[k] = (bb[p] - sacc) * inv;
             }
         }
         rank = k + 1;
