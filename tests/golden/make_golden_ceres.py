@@ -54,7 +54,8 @@ def cases():
     return out
 
 
-def main(force=False):
+def main(force=False, path=None):
+    """path: where to write (default tests/golden/golden_ceres.npz; tests/test_diff_kit.py passes a scratch file)"""
     L = R.lib()
     if not L.vref_real_ceres() and not force:
         sys.exit("oracle/ref.py loaded a library built on the STAND-IN Ceres: goldens of the restatement are not goldens.\n"
@@ -69,7 +70,7 @@ def main(force=False):
             out[name + "/" + k] = np.asarray(st[k])
         out[name + "/td"] = np.array(float(st['td']))
         print("%-32s %2d iterations  %-14s  cost %.6e -> %.6e" % (name, len(sm['iterations']), sm['termination'], sm['initial_cost'], sm['final_cost']))
-    path = os.path.join(HERE, "golden_ceres.npz" if L.vref_real_ceres() else "golden_ceres_STANDIN_DO_NOT_COMMIT.npz")
+    path = path or os.path.join(HERE, "golden_ceres.npz" if L.vref_real_ceres() else "golden_ceres_STANDIN_DO_NOT_COMMIT.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
     return path

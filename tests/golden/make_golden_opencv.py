@@ -57,7 +57,8 @@ def inputs(seed):
     return a, b, mask, centres, p1.astype(np.float32), p2.astype(np.float32)
 
 
-def main():
+def main(path=None):
+    """path: where to write (default tests/golden/golden_opencv.npz; tests/test_diff_kit.py passes a scratch file)"""
     import cv2
     out = dict(cv_version=np.array(cv2.__version__), seeds=np.array(SEEDS))
     print("OpenCV", cv2.__version__)
@@ -100,7 +101,7 @@ def main():
             cv2.circle(canvas, (int(cx), int(cy)), 30, 0, -1)
         out[k + "circles"] = canvas
         out[k + "circle_centres"] = centres
-    path = os.path.join(HERE, "golden_opencv.npz")
+    path = path or os.path.join(HERE, "golden_opencv.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
 
