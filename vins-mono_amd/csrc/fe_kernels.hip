@@ -379,6 +379,18 @@ FDEV long long wave_sum_i32(int v) {
     for (int g = 0; g < 8; ++g) t += (long long)__builtin_amdgcn_readlane(v, 8 * g);
     return t;
 }
+// lane values below 2^27 in magnitude: the 16-lane totals of a DPP row still fit 32 bits -- one more stage (row_mirror), four
+// v_readlane instead of eight
+FDEV long long wave_sum_i27(int v) {
+    v = dpp_add_i32_0xB1(v);
+    v = dpp_add_i32_0x4E(v);
+    v = dpp_add_i32_0x141(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    long long t = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) t += (long long)__builtin_amdgcn_readlane(v, 16 * g);
+    return t;
+}
 // lane values whose WAVEFRONT total fits 32 bits
 FDEV int wave_sum_small(int v) {
     v = dpp_add_i32_0xB1(v);
@@ -397,16 +409,35 @@ FDEV void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
 // Image planes are reached through pointer tables in HBM: a loaded pointer is generic and its accesses would compile to
 // flat_load (which also ties the LDS counter to the image loads); the planes are HBM, say so (glb_u8, vg_target.h).
 
-// the bilinear tap (row a bytes q, q + 1; row b bytes q, q + 1) . weights, rounded and shifted by LK_WBITS - 5, for q = 0 .. 6, handed to f(q, value)
-template <int Q, typename F> FDEV void lk_tap_q(const uint2& ra, const uint2& rb, unsigned wt, unsigned wb, F&& f) {
-    // (signed lanes: the fourth weight is 2^14 minus the three rounded ones and can be -1 or -2, and the tap then negative)
-    const int t = vg_sdot2(vg_byte_pair<Q>(rb.y, rb.x), wb, vg_sdot2(vg_byte_pair<Q>(ra.y, ra.x), wt, 1 << (LK_WBITS - 5 - 1)));
-    f(Q, t >> (LK_WBITS - 5));
+// The bilinear taps of a lane's seven pixels from its 2 x 8 search-window bytes (row a = ra, row b = rb), round 6.  A tap is
+//     t_q = w00 a_q + w01 a_(q+1) + w10 b_q + w11 b_(q+1) + 2^(W-1),   value = t_q >> W,   W = LK_WBITS - 5,
+// and what the iteration needs is value - template.  Three things make it short (VALU issue bounds this kernel):
+//  * the 16-bit pairs are cut by COLUMN, V_q = (a_q, b_q): tap q is V_q . (w00, w10) + V_(q+1) . (w01, w11), so a pair serves two taps
+//    (eight v_perm_b32 instead of fourteen row pairs);
+//  * the template rides in the addend: with c_q = 2^(W-1) - 2^W template_q the shift delivers value - template directly
+//    (floor((x - 2^W i) / 2^W) = floor(x / 2^W) - i exactly; |c_q| < 2^23 and |t_q| < 2^22: no overflow), so the rounding constant
+//    costs no v_mov and the difference no v_sub;
+//  * integer sums are exact in any order: same values as the row-pair form bit for bit.
+// Signed lanes: the fourth weight is 2^14 minus the three rounded ones and can be -1 or -2.
+template <int Q> FDEV unsigned lk_col_pair(const uint2& ra, const uint2& rb) {
+    // (a_Q | b_Q << 16): byte Q & 3 of the dword of row a and of row b
+    return Q < 4 ? vg_perm<(unsigned)(Q & 3) | (0x0Cu << 8) | ((unsigned)(4 + (Q & 3)) << 16) | (0x0Cu << 24)>(rb.x, ra.x)
+                 : vg_perm<(unsigned)(Q & 3) | (0x0Cu << 8) | ((unsigned)(4 + (Q & 3)) << 16) | (0x0Cu << 24)>(rb.y, ra.y);
 }
-template <typename F> FDEV void lk_taps7(const uint2& ra, const uint2& rb, unsigned wt, unsigned wb, F&& f) {
-    lk_tap_q<0>(ra, rb, wt, wb, f); lk_tap_q<1>(ra, rb, wt, wb, f); lk_tap_q<2>(ra, rb, wt, wb, f); lk_tap_q<3>(ra, rb, wt, wb, f);
-    lk_tap_q<4>(ra, rb, wt, wb, f); lk_tap_q<5>(ra, rb, wt, wb, f); lk_tap_q<6>(ra, rb, wt, wb, f);
+// d[q] = (tap q >> W) - template q  for q = 0 .. 6;  cq[q] = 2^(W-1) - 2^W template q;  wl = (w00 | w10 << 16), wr = (w01 | w11 << 16)
+FDEV void lk_diffs7(const uint2& ra, const uint2& rb, unsigned wl, unsigned wr, const int* cq, int* d) {
+    const unsigned v0 = lk_col_pair<0>(ra, rb), v1 = lk_col_pair<1>(ra, rb), v2 = lk_col_pair<2>(ra, rb), v3 = lk_col_pair<3>(ra, rb);
+    const unsigned v4 = lk_col_pair<4>(ra, rb), v5 = lk_col_pair<5>(ra, rb), v6 = lk_col_pair<6>(ra, rb), v7 = lk_col_pair<7>(ra, rb);
+    d[0] = vg_sdot2(v1, wr, vg_sdot2_keep(v0, wl, cq[0])) >> (LK_WBITS - 5);
+    d[1] = vg_sdot2(v2, wr, vg_sdot2_keep(v1, wl, cq[1])) >> (LK_WBITS - 5);
+    d[2] = vg_sdot2(v3, wr, vg_sdot2_keep(v2, wl, cq[2])) >> (LK_WBITS - 5);
+    d[3] = vg_sdot2(v4, wr, vg_sdot2_keep(v3, wl, cq[3])) >> (LK_WBITS - 5);
+    d[4] = vg_sdot2(v5, wr, vg_sdot2_keep(v4, wl, cq[4])) >> (LK_WBITS - 5);
+    d[5] = vg_sdot2(v6, wr, vg_sdot2_keep(v5, wl, cq[5])) >> (LK_WBITS - 5);
+    d[6] = vg_sdot2(v7, wr, vg_sdot2_keep(v6, wl, cq[6])) >> (LK_WBITS - 5);
 }
+// two differences (|d| <= 255 * 32 fits 16 bits) as one register of two int16 lanes: one v_perm_b32
+FDEV unsigned lk_pack16(int lo, int hi) { return vg_perm<0x05040100u>((unsigned)hi, (unsigned)lo); }
 
 // Stage the LK_JR x LK_JR search region with origin (ox, oy) of plane J into LDS (reflect-101 outside the image, exactly
 // the pixels the per-window gather of LKTrackerInvoker reads).  lane = (row, 16-byte half): one unaligned 16-byte load
@@ -493,7 +524,9 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
         // packed dword reads and 8 unpacks per pixel): one barrier and 1.9 KB of LDS less, -2.5 % per launch.
         // (a lane's seven products of two gradients are < 7 * 4080^2 = 1.2e8 < 2^27: lane sums in 32 bits, see wave_sum_i32)
         int s11 = 0, s12 = 0, s22 = 0;
-        int iv[7], ixv[7], iyv[7];
+        int cq[7];                    // 2^(W-1) - 2^W template value (the addend of a tap, lk_diffs7)
+        unsigned gxp[3], gyp[3];      // the gradients of pixels (2 j, 2 j + 1) as two int16 lanes (|Ix|, |Iy| <= 16 * 255)
+        int gx6, gy6;
         {
             // The lane's 4 x 10 patch bytes (rows ly .. ly + 3, columns x0 .. x0 + 9) as three dwords per row; everything below
             // works on TWO 16-bit lanes per register (two neighbouring columns; v_perm_b32 cuts the pairs out, v_pk_add / v_pk_sub /
@@ -544,10 +577,16 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 }
             }
             // bilinear taps as signed 16-bit dot products (weights in [-2, 2^14]: the fourth is 2^14 minus the three rounded ones;
-            // pixels < 2^8, derivatives |.| <= 4080): two v_dot2_i32_i16 per tap with the rounding constant as the addend; the pair
-            // (q, q + 1) is a register as it stands for even q and one v_perm_b32 of two neighbouring registers for odd q
-            const unsigned wt = (unsigned)w00 | ((unsigned)w01 << 16), wb = (unsigned)w10 | ((unsigned)w11 << 16);
-            unsigned PX[2][7], PY[2][7], PI[2][7];
+            // pixels < 2^8, derivatives |.| <= 4080): two v_dot2_i32_i16 per tap, the rounding constant as the addend of the first
+            // (three-operand form: one register holds the constant for all taps).  Gradients: ROW pairs (q, q + 1) -- a register as
+            // it stands for even q, one v_perm_b32 of two neighbouring registers for odd q -- against (w00, w01) / (w10, w11);
+            // template pixels: COLUMN pairs (row k = 0, row k = 1) of patch columns 1 .. 8 against (w00, w10) / (w01, w11), a pair
+            // serves two taps (lk_col_pair).  The idle lane 63 gets zero gradient weights: its gradients are (2^13 >> 14) = 0.
+            // The values fit 16 bits (|gradient tap| <= 4080, template tap <= 255 * 32), as OpenCV's short deriv / patch buffers hold them.
+            const unsigned wtg = act ? ((unsigned)w00 | ((unsigned)w01 << 16)) : 0u, wbg = act ? ((unsigned)w10 | ((unsigned)w11 << 16)) : 0u;
+            const unsigned wl = (unsigned)w00 | ((unsigned)w10 << 16), wr = (unsigned)w01 | ((unsigned)w11 << 16);
+            const int rnd_g = 1 << (LK_WBITS - 1), rnd_i = 1 << (LK_WBITS - 5 - 1);
+            unsigned PX[2][7], PY[2][7];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
 #pragma unroll
@@ -555,22 +594,29 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                     PX[k][q] = (q & 1) ? vg_perm<0x05040302u>(DX[k][(q + 1) / 2], DX[k][q / 2]) : DX[k][q / 2];
                     PY[k][q] = (q & 1) ? vg_perm<0x05040302u>(DY[k][(q + 1) / 2], DY[k][q / 2]) : DY[k][q / 2];
                 }
-                // template pixels: columns (q + 1, q + 2) of patch row k + 1
-                PI[k][0] = vg_byte_pair<1>(R[k + 1][1], R[k + 1][0]); PI[k][1] = vg_byte_pair<2>(R[k + 1][1], R[k + 1][0]);
-                PI[k][2] = vg_byte_pair<3>(R[k + 1][1], R[k + 1][0]); PI[k][3] = vg_byte_pair<0>(R[k + 1][2], R[k + 1][1]);
-                PI[k][4] = vg_byte_pair<1>(R[k + 1][2], R[k + 1][1]); PI[k][5] = vg_byte_pair<2>(R[k + 1][2], R[k + 1][1]);
-                PI[k][6] = vg_byte_pair<3>(R[k + 1][2], R[k + 1][1]);
             }
+            // VI[c - 1] = (patch row 1 byte c | patch row 2 byte c << 16), c = 1 .. 8: byte c & 3 of dword c >> 2 of either row
+            unsigned VI[8];
+            VI[0] = vg_perm<0x0C050C01u>(R[2][0], R[1][0]); VI[1] = vg_perm<0x0C060C02u>(R[2][0], R[1][0]); VI[2] = vg_perm<0x0C070C03u>(R[2][0], R[1][0]);
+            VI[3] = vg_perm<0x0C040C00u>(R[2][1], R[1][1]); VI[4] = vg_perm<0x0C050C01u>(R[2][1], R[1][1]); VI[5] = vg_perm<0x0C060C02u>(R[2][1], R[1][1]);
+            VI[6] = vg_perm<0x0C070C03u>(R[2][1], R[1][1]); VI[7] = vg_perm<0x0C040C00u>(R[2][2], R[1][2]);
+            int ixv[7], iyv[7];
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
-                const int ival = vg_sdot2(PI[1][q], wb, vg_sdot2(PI[0][q], wt, 1 << (LK_WBITS - 5 - 1))) >> (LK_WBITS - 5);
-                const int ixval = vg_sdot2(PX[1][q], wb, vg_sdot2(PX[0][q], wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-                const int iyval = vg_sdot2(PY[1][q], wb, vg_sdot2(PY[0][q], wt, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-                iv[q] = (short)ival; ixv[q] = act ? (short)ixval : 0; iyv[q] = act ? (short)iyval : 0;
-                s11 += mul24(ixv[q], ixv[q]); s12 += mul24(ixv[q], iyv[q]); s22 += mul24(iyv[q], iyv[q]);
+                const int ival = vg_sdot2(VI[q + 1], wr, vg_sdot2_keep(VI[q], wl, rnd_i)) >> (LK_WBITS - 5);
+                ixv[q] = vg_sdot2(PX[1][q], wbg, vg_sdot2_keep(PX[0][q], wtg, rnd_g)) >> LK_WBITS;
+                iyv[q] = vg_sdot2(PY[1][q], wbg, vg_sdot2_keep(PY[0][q], wtg, rnd_g)) >> LK_WBITS;
+                cq[q] = rnd_i - (1 << (LK_WBITS - 5)) * ival;
             }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { gxp[j] = lk_pack16(ixv[2 * j], ixv[2 * j + 1]); gyp[j] = lk_pack16(iyv[2 * j], iyv[2 * j + 1]); }
+            gx6 = ixv[6]; gy6 = iyv[6];
+            // sums of gradient products over the lane's seven pixels: two pixels per v_dot2_i32_i16 (< 7 * 4080^2 = 1.2e8 < 2^27)
+            s11 = mul24(gx6, gx6); s12 = mul24(gx6, gy6); s22 = mul24(gy6, gy6);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { s11 = vg_sdot2(gxp[j], gxp[j], s11); s12 = vg_sdot2(gxp[j], gyp[j], s12); s22 = vg_sdot2(gyp[j], gyp[j], s22); }
         }
-        const long long a11 = wave_sum_i32(s11), a12 = wave_sum_i32(s12), a22 = wave_sum_i32(s22);
+        const long long a11 = wave_sum_i27(s11), a12 = wave_sum_i27(s12), a22 = wave_sum_i27(s22);
         const float A11 = (float)a11 * FLT_SCALE, A12 = (float)a12 * FLT_SCALE, A22 = (float)a22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * LK_WIN * LK_WIN);
@@ -598,20 +644,22 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
             }
             long long b1, b2;
             {
-                // the lane's 2 x 8 search-window bytes as four dwords; a bilinear tap = two v_dot2_i32_i16 over (pixel, pixel + 1)
-                // pairs cut out by v_perm_b32, the rounding constant of the descale as the addend (4 instructions instead of four
-                // byte-select multiplies and two three-operand adds; the weights are in [-2, 2^14], |tap| < 2^22)
+                // the lane's 2 x 8 search-window bytes as four dwords -> seven (value - template) differences (lk_diffs7), then
+                // sum diff Ix and sum diff Iy as v_dot2_i32_i16 over pairs of pixels (the differences packed two to a register)
                 const uint8_t* p0 = s.jreg + (ry + lyc) * LK_JR + rx + x0;
                 uint2 ra, rb;
                 __builtin_memcpy(&ra, p0, 8); __builtin_memcpy(&rb, p0 + LK_JR, 8);
-                const unsigned wt = (unsigned)r00 | ((unsigned)r01 << 16), wb = (unsigned)r10 | ((unsigned)r11 << 16);
+                const unsigned wl = (unsigned)r00 | ((unsigned)r10 << 16), wr = (unsigned)r01 | ((unsigned)r11 << 16);
                 // a lane's seven products fit 32 bits with room to spare (|diff| <= 255 * 32, |Ix|, |Iy| <= 16 * 255: < 2.4e8 in
                 // total), so the lane sums are formed in 32 bits and widened once; the wavefront sums stay exact int64
-                int s1 = 0, s2 = 0;
-                lk_taps7(ra, rb, wt, wb, [&](int q, int val) {
-                    const int diff = val - iv[q];
-                    s1 += mul24(diff, ixv[q]); s2 += mul24(diff, iyv[q]);
-                });
+                int dq[7];
+                lk_diffs7(ra, rb, wl, wr, cq, dq);
+                int s1 = mul24(dq[6], gx6), s2 = mul24(dq[6], gy6);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const unsigned dp = lk_pack16(dq[2 * j], dq[2 * j + 1]);
+                    s1 = vg_sdot2(dp, gxp[j], s1); s2 = vg_sdot2(dp, gyp[j], s2);
+                }
                 b1 = wave_sum_i32(s1); b2 = wave_sum_i32(s2);       // (|s| <= 7 * 8160 * 4080 = 2.3e8 < 2^28)
             }
             const float fb1 = (float)b1 * FLT_SCALE, fb2 = (float)b2 * FLT_SCALE;
@@ -641,11 +689,11 @@ extern "C" __global__ __launch_bounds__(64) void fe_lk_kernel(FeDev d) {
                 const uint8_t* p0 = s.jreg + (ry + lyc) * LK_JR + rx + x0;
                 uint2 ra, rb;
                 __builtin_memcpy(&ra, p0, 8); __builtin_memcpy(&rb, p0 + LK_JR, 8);
-                const unsigned wt = (unsigned)r00 | ((unsigned)r01 << 16), wb = (unsigned)r10 | ((unsigned)r11 << 16);
-                lk_taps7(ra, rb, wt, wb, [&](int q, int val) {
-                    const int diff = val - iv[q];
-                    e += act ? (diff < 0 ? -diff : diff) : 0;
-                });
+                const unsigned wl = (unsigned)r00 | ((unsigned)r10 << 16), wr = (unsigned)r01 | ((unsigned)r11 << 16);
+                int dq[7];
+                lk_diffs7(ra, rb, wl, wr, cq, dq);
+#pragma unroll
+                for (int q = 0; q < 7; ++q) e += act ? (dq[q] < 0 ? -dq[q] : dq[q]) : 0;
             }
             e = wave_sum_small(e);
             err = ((float)e * 1.f) / (float)(32 * LK_WIN * LK_WIN);      // a division, as OpenCV's expression parses (F3)

@@ -86,6 +86,14 @@ __device__ __forceinline__ int vg_sdot2(unsigned a, unsigned b, int c) {
     typedef short s2 __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b), c, false);
 }
+// ---- the same with the addend in a register that stays live (a per-pixel constant reused by every iteration): the compiler
+//      selects the two-operand v_dot2c_i32_i16 (destination = addend) behind a v_mov copy of the addend; the three-operand VOP3P
+//      form needs no copy
+__device__ __forceinline__ int vg_sdot2_keep(unsigned a, unsigned b, int c) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 #else   // ------------------------------------------------------------------------------ CPU fiber emulation (tests/simt)
 typedef double lds_d;
@@ -124,4 +132,5 @@ inline unsigned vg_pk_sub(unsigned a, unsigned b) { return ((a - b) & 0xffffu) |
 inline unsigned vg_pk_mad(unsigned a, unsigned short k, unsigned c) { return (((a & 0xffffu) * k + (c & 0xffffu)) & 0xffffu) | (((a >> 16) * k + (c >> 16)) << 16); }
 inline unsigned vg_pk_shr(unsigned a, unsigned short n) { return ((a & 0xffffu) >> n) | (((a >> 16) >> n) << 16); }
 inline int vg_sdot2(unsigned a, unsigned b, int c) { return (int)(short)(a & 0xffffu) * (int)(short)(b & 0xffffu) + (int)(short)(a >> 16) * (int)(short)(b >> 16) + c; }
+inline int vg_sdot2_keep(unsigned a, unsigned b, int c) { return vg_sdot2(a, b, c); }
 #endif
