@@ -1142,6 +1142,8 @@ static int unpack_priors(vg_handle* h, int nwin, vg_ba_prior* const* pri) {
                     const int* pf = mi + 8 + 2 * (L.K + 4);
                     fprintf(stderr, "[marg] eig1: sweeps=%d attempts=%d | eig2: sweeps=%d attempts=%d | kernel kcyc=%d | stamps: setup %d prior %d imu %d proj %d eig1 %d schur %d eig2 %d out %d\n",
                             mi[4] & 255, mi[4] >> 8, mi[5] & 255, mi[5] >> 8, mi[7], pf[0], pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6]);
+                    fprintf(stderr, "[marg] projection part (sqrt mode): offsets %d evaluate %d sort %d camera (wave 0) %d landmark rows %d\n",
+                            pf[8] - pf[2], pf[9] - pf[8], pf[10] - pf[9], pf[11] - pf[10], pf[3] - pf[11]);
                 }
                 if (mi[0]) {
                     const int n = mi[1], nb = mi[3];

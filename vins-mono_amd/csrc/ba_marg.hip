@@ -22,6 +22,7 @@
 #define MG_NT 1024                 // 16 wavefronts: the Jacobi rounds are LDS-latency bound, more waves in flight
 #endif
 #define MG_NW (MG_NT / 64)
+#define MG_T0W 4                   // wavefronts that share the all-factor product of the projection part (ba_marg_kernel (c))
 #define MG_EPS 1e-8
 #define MG_MAXSWEEP 30
 
@@ -1026,8 +1027,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     double* g2M = gV + (size_t)posmax * posmax;      // second-eig fallback (mcap^2) x 2
     double* g2V = g2M + (size_t)mcap * mcap;
     double* prv = g2V + (size_t)mcap * mcap;         // prior residual (Ncap) + dx (Ncap)
-    double* imuJ = prv + 2 * L.Ncap;         // 450 + 15
-    mp.lm = (int*)(imuJ + 480);
+    mp.lm = (int*)(prv + 2 * L.Ncap + 480);
     mp.l0 = mp.lm + L.Lcap;
 
     // ---- state after the gauge fix (what vector2double() repacks at estimator.cpp:831 / :942)
@@ -1141,13 +1141,22 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
 
     MPROF(0);
     // ---- M1/M3 (a): prior factor at the new state: r = r0 + J0 dx ; A += J0^T J0 ; b += J0^T r
+    // (round 6: dx and r live in LDS -- the eigen-solver tiles are free here --, both products run eight lanes per row with the
+    //  partial sums on the DPP network: ~ten loads in flight per lane instead of one thread walking 75 dependent terms; the prior is the
+    //  FIRST contribution to its entries of the cleared A / bv: plain stores)
     if (nblk > 0) {
-        double* dx = prv + L.Ncap;
+        double* dx = eM;                             // [Ncap]
+        double* prl = eM + L.Ncap;                   // [Ncap] prior residual at the new state
+        int* pcol = li + MGI_RANK;                   // prior row / column -> column of the marginalization system (the rank table is not in use yet)
         for (int b = c.tid; b < nblk; b += MG_NT) {
             const double* xb = pk[b] == VG_BLK_POSE ? x + 7 * pidx[b] : (pk[b] == VG_BLK_SPEEDBIAS ? x + 7 * K + 9 * pidx[b]
                                : (pk[b] == VG_BLK_EXPOSE ? ex : ex + 7));
             const double* x0 = c.pri + L.po_x0 + px0off[b];
             double* d = dx + poff[b];
+            const int sz = pk[b] == VG_BLK_SPEEDBIAS ? 9 : (pk[b] == VG_BLK_TD ? 1 : 6);
+            const int base = pk[b] == VG_BLK_POSE ? mp.pose[pidx[b]] : (pk[b] == VG_BLK_SPEEDBIAS ? mp.sb[pidx[b]]
+                             : (pk[b] == VG_BLK_EXPOSE ? cex : ctd));
+            for (int k = 0; k < sz; ++k) pcol[poff[b] + k] = base + k;
             if (pk[b] == VG_BLK_SPEEDBIAS) { for (int k = 0; k < 9; ++k) d[k] = xb[k] - x0[k]; }
             else if (pk[b] == VG_BLK_TD) d[0] = xb[0] - x0[0];
             else {
@@ -1160,39 +1169,37 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             }
         }
         __syncthreads();
-        const double* J0t = c.sc + L.so_J0t;         // left by the prologue of the solve pipeline
-        for (int r = c.tid; r < nprior; r += MG_NT) {
-            double s = c.pri[L.po_r0 + r];
-            for (int k = 0; k < nprior; ++k) s += J0t[k * L.Ncap + r] * dx[k];
-            prv[r] = s;
+        const glb_d* J0g = (const glb_d*)(c.pri + L.po_J0);        // row-major, leading dimension pld
+        const glb_d* r0g = (const glb_d*)(c.pri + L.po_r0);
+        const int part = c.tid & 7;
+        for (int rb = 0; rb < nprior; rb += MG_NT / 8) {
+            const int r = rb + (c.tid >> 3);
+            double sacc = 0.0;
+            if (r < nprior)
+                for (int k = part; k < nprior; k += 8) sacc += J0g[(size_t)r * L.pld + k] * dx[k];
+            sacc += dpp_mov_f64<0xB1>(sacc);
+            sacc += dpp_mov_f64<0x4E>(sacc);
+            sacc += dpp_mov_f64<0x141>(sacc);
+            if (r < nprior && part == 0) prl[r] = r0g[r] + sacc;
         }
         __syncthreads();
-        const double* Hp = c.sc + L.so_Hp;          // J0^T J0 (lower), left by the solve kernel
-        const double* J0 = c.pri + L.po_J0;
-        // prior row / column -> column of the marginalization system, once (the rank table is not in use yet)
-        int* pcol = li + MGI_RANK;
-        for (int a = c.tid; a < nprior; a += MG_NT) {
-            int ca = -1;
-            for (int blk = 0; blk < nblk; ++blk) {
-                const int sz = pk[blk] == VG_BLK_SPEEDBIAS ? 9 : (pk[blk] == VG_BLK_TD ? 1 : 6);
-                const int base = pk[blk] == VG_BLK_POSE ? mp.pose[pidx[blk]] : (pk[blk] == VG_BLK_SPEEDBIAS ? mp.sb[pidx[blk]]
-                                 : (pk[blk] == VG_BLK_EXPOSE ? cex : ctd));
-                if (a >= poff[blk] && a < poff[blk] + sz) ca = base + a - poff[blk];
-            }
-            pcol[a] = ca;
+        const glb_d* Hp = (const glb_d*)(c.sc + L.so_Hp);          // J0^T J0 (lower), left by the solve pipeline's prologue
+        glb_d* Ag = (glb_d*)A;
+        glb_d* bg = (glb_d*)bv;
+        for (int ab = 0; ab < nprior; ab += MG_NT / 8) {
+            const int a = ab + (c.tid >> 3);
+            double sacc = 0.0;
+            if (a < nprior)
+                for (int r = part; r < nprior; r += 8) sacc += J0g[(size_t)r * L.pld + a] * prl[r];
+            sacc += dpp_mov_f64<0xB1>(sacc);
+            sacc += dpp_mov_f64<0x4E>(sacc);
+            sacc += dpp_mov_f64<0x141>(sacc);
+            if (a < nprior && part == 0) bg[pcol[a]] = sacc;
         }
-        __syncthreads();
-        for (int wk = c.tid; wk < nprior * nprior + nprior; wk += MG_NT) {
-            const bool isg = wk >= nprior * nprior;
-            const int a = isg ? wk - nprior * nprior : wk / nprior, b = isg ? 0 : wk % nprior;
-            const int ca = pcol[a], cb = pcol[b];
-            if (isg) {
-                double s = 0.0;
-                for (int r = 0; r < nprior; ++r) s += J0[r * L.pld + a] * prv[r];
-                bv[ca] += s;
-            } else {
-                A[ca * posmax + cb] += (a >= b) ? Hp[a * L.Ncap + b] : Hp[b * L.Ncap + a];
-            }
+        for (int a = c.wave; a < nprior; a += MG_NW) {
+            const int ca = pcol[a];
+            for (int b2 = c.lane; b2 < nprior; b2 += 64)
+                Ag[(size_t)ca * posmax + pcol[b2]] = (a >= b2) ? Hp[a * L.Ncap + b2] : Hp[b2 * L.Ncap + a];
         }
     }
     __syncthreads();
@@ -1201,6 +1208,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     if (imu0) {
         const double* pre = c.di + L.do_imu;
         const double* U = c.sc + L.so_imuU;
+        double* imuJ = eM + 2 * L.Ncap;             // [15][30] weighted Jacobian | [15] weighted residual, in LDS (behind dx / r of the prior part)
         if (c.tid < 31) {
             ImuCtx ic;
             imu_ctx<true>(pre, x, x + 7 * K, x + 7, x + 7 * K + 9, c.gnorm, ic);
@@ -1239,84 +1247,74 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     MPROF(2);
     // ---- (c) projection factors of the landmarks anchored at frame 0, with the loss correction.
     // Records (42 doubles: r[2] | Ji[12] | Jj[12] | Jex[12] | Jl[2] | Jtd[2], rows as [row][col]) are staged in the LDS
-    // area the eigen-solver uses later, in chunks of whole landmarks; every factor couples {pose 0, pose j, ex, td,
-    // landmark}, so an entry of the camera part that touches pose j only visits the factors of target frame j
-    // (a stable counting sort by j -> fixed summation order -> bit-reproducible), the others visit all of them.
+    // area the eigen-solver uses later, in chunks of whole landmarks.  Every factor couples {pose 0, pose j, ex, td, landmark}.
+    // Round 6: the CAMERA part of the sum runs on the matrix cores.  With the 2 x 16 row blocks of a factor
+    //     a = [Ji (6) | Jex (6) | Jtd | r | 0 0]        b = [Jj (6) | 0 ...]
+    // the sum over ALL factors of a^T a is the (pose 0, ex, td)^2 block with its gradient column, and for every target frame j
+    // the sums over ITS factors of b^T a and b^T b are the (pose j) x (pose 0, ex, td | gradient) and (pose j)^2 blocks:
+    // v_mfma_f64_16x16x4_f64 takes two factors (k = 4 rows) per instruction; wavefront 0 walks all factors for a^T a, the
+    // others take the target frames.  The factors of a chunk are sorted by target frame first (stable counting sort by
+    // ballots: the order inside a bucket is the factor order, whatever the timing -> bit-reproducible sums).  Until round 6
+    // every thread owned three entries of the camera part and walked the records itself -- 2 x 200 dependent LDS reads per
+    // entry of the (pose 0, ex, td) block --, one thread alone built the factor offsets (n0 dependent HBM round trips) and
+    // the sort was two serial passes of one thread per bucket: 150-190K of the kernel's 590K cycles.
     if (flag == VG_MARGIN_OLD && n0 > 0) {
         const int ncam = 6 * K + 7;
-        const int ntri = ncam * (ncam + 1) / 2;
-        const int nent = ntri + ncam;
-        const int cap = (4 * ld * ld) / 87;                  // 42 doubles + jof + sorted list (2 ints) per record
+        // LDS: [records cap x 42 doubles][jof cap ints][sorted list cap ints][landmark of a factor cap ints][compact factor offsets n0 + 1 ints] ... [partial tiles]
+        const int cfb_ints = (n0 + 2) & ~1;
+        const int cap = (4 * ld * ld - cfb_ints - 2 * MG_T0W * 256) / 87;      // (both eigen-solver tiles: 4 ld^2 ints) 84 ints of record + jof + list entry + landmark
         double* recL = eM;
         int* jofL = (int*)(recL + (size_t)cap * 42);         // [cap] target frame or -2
         int* slist = jofL + cap;                             // [cap] compact ids sorted by target frame (stable)
+        int* kofL = slist + cap;                             // [cap] frame-0 landmark (index into l0) of a compact factor
+        int* cfb = kofL + cap;                               // [n0 + 1] compact factor offsets
+        double* t0p = recL + (size_t)(2 * ld * ld - MG_T0W * 256);      // [MG_T0W][256] partial tiles of the a^T a product (end of the area)
         int* bptr = li + MGI_BPTR;                           // [K + 2] bucket pointers
-        int* cfb = mp.l0 + L.Lcap;                           // [n0 + 1] compact factor offsets
-        if (c.tid == 0) {
-            int acc = 0;
-            for (int k = 0; k < n0; ++k) { cfb[k] = acc; acc += c.ia[L.io_lm_fbeg + mp.l0[k] + 1] - c.ia[L.io_lm_fbeg + mp.l0[k]]; }
-            cfb[n0] = acc;
-        }
-        // per-thread camera entries: w = tid + (pass * MAXE + e) * MG_NT < nent.  A window of the single-workgroup path has one
-        // pass (the entries are decoded once and summed in registers over all chunks); wider windows (large-window path: up to
-        // 6 * 39 + 7 camera columns) take several passes per chunk and add every chunk's sums to A directly.
-        constexpr int MAXE = ((6 * BA_MAX_K + 7) * (6 * BA_MAX_K + 8) / 2 + 6 * BA_MAX_K + 7 + MG_NT - 1) / MG_NT;
-        const int npass = (nent + MAXE * MG_NT - 1) / (MAXE * MG_NT);
-        double acc[MAXE];
-        int eo[MAXE];        // packed: oa0 | oa1 << 8 | ob0 << 16 | ob1 << 24
-        int erq[MAXE];       // required target frame, -1 = any, -3 = entry unused
-        int eadr[MAXE];      // destination: A index (>= 0) or -(bv index) - 1
-        int emir[MAXE];      // mirrored A index or -1
-        auto decode_pass = [&](int pass) {
-#pragma unroll
-        for (int e = 0; e < MAXE; ++e) {
-            const int w = c.tid + (pass * MAXE + e) * MG_NT;
-            acc[e] = 0.0; eo[e] = 0; erq[e] = -3; eadr[e] = 0; emir[e] = -1;
-            if (w < nent) {
-                const bool isg = w >= ntri;
-                int a, b;
-                if (isg) { a = w - ntri; b = 0; } else tri_decode(w, a, b);
-                auto classify = [&](int cidx, int& o0, int& o1, int& rq, int& col) {
-                    if (cidx < 6) { o0 = 2 + cidx; o1 = 8 + cidx; rq = -1; col = mp.pose[0] + cidx; }
-                    else if (cidx < 6 * K) { const int f = cidx / 6, kk = cidx - 6 * f; o0 = 14 + kk; o1 = 20 + kk; rq = f; col = mp.pose[f] < 0 ? -1 : mp.pose[f] + kk; }
-                    else if (cidx < 6 * K + 6) { const int q = cidx - 6 * K; o0 = 26 + q; o1 = 32 + q; rq = -1; col = cex < 0 ? -1 : cex + q; }
-                    else { o0 = 40; o1 = 41; rq = -1; col = L.t ? ctd : -1; }
-                };
-                int oa0, oa1, ra, ca, ob0 = 0, ob1 = 1, rb = -1, cb = 0;
-                classify(a, oa0, oa1, ra, ca);
-                if (!isg) classify(b, ob0, ob1, rb, cb);
-                const bool ok = ca >= 0 && cb >= 0 && !(ra >= 0 && rb >= 0 && ra != rb);
-                if (ok) {
-                    eo[e] = oa0 | (oa1 << 8) | (ob0 << 16) | (ob1 << 24);
-                    erq[e] = ra >= 0 ? ra : rb;
-                    eadr[e] = isg ? -ca - 1 : ca * posmax + cb;
-                    emir[e] = (!isg && a != b) ? cb * posmax + ca : -1;
-                }
+        int* wtot = li + MGI_RANK;                           // [waves] (the rank table is not in use yet)
+        {
+            // exclusive prefix of the landmarks' factor counts, by all threads
+            int run = 0;                                     // uniform
+            for (int base = 0; base < n0; base += MG_NT) {
+                const int k = base + c.tid;
+                int cnt = 0;
+                if (k < n0) { const int l = mp.l0[k]; cnt = c.ia[L.io_lm_fbeg + l + 1] - c.ia[L.io_lm_fbeg + l]; }
+                int inc = cnt;
+                for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); inc += c.lane >= o ? v : 0; }
+                __syncthreads();                             // (wtot of the previous trip has been read)
+                if (c.lane == 63) wtot[c.wave] = inc;
+                __syncthreads();
+                int off = run, tot = 0;
+                for (int w2 = 0; w2 < MG_NW; ++w2) { const int cw = wtot[w2]; if (w2 < c.wave) off += cw; tot += cw; }
+                if (k < n0) cfb[k] = off + inc - cnt;
+                run += tot;
             }
+            if (c.tid == 0) cfb[n0] = run;
         }
-        };
-        auto flush_pass = [&]() {
-#pragma unroll
-            for (int e = 0; e < MAXE; ++e) {
-                if (erq[e] == -3) continue;
-                if (eadr[e] < 0) bv[-eadr[e] - 1] += acc[e];
-                else { A[eadr[e]] += acc[e]; if (emir[e] >= 0) A[emir[e]] += acc[e]; }
-                acc[e] = 0.0;
-            }
-        };
-        decode_pass(0);
         __syncthreads();
+        MPROF(8);
+        // this lane's element of a factor's row block inside a record (-1: a zero column): column = lane & 15, row = (lane >> 4) & 1;
+        // lanes 0 .. 31 read the first factor of a pair, lanes 32 .. 63 the second
+        const int mcol = c.lane & 15, mrow = (c.lane >> 4) & 1, msel = c.lane >> 5;
+        const int offa = mcol < 6 ? 2 + 6 * mrow + mcol : (mcol < 12 ? 26 + 6 * mrow + (mcol - 6) : (mcol == 12 ? 40 + mrow : (mcol == 13 ? mrow : -1)));
+        const int offb = mcol < 6 ? 14 + 6 * mrow + mcol : -1;
+        // column of the system behind column t of block a (-1: not in the system, -2: the gradient column)
+        auto acol = [&](int t) { return t < 6 ? mp.pose[0] + t : (t < 12 ? (cex < 0 ? -1 : cex + t - 6) : (t == 12 ? (L.t ? ctd : -1) : (t == 13 ? -2 : -1))); };
         for (int k0 = 0; k0 < n0;) {
-            int k1 = k0 + 1;
-            while (k1 < n0 && cfb[k1 + 1] - cfb[k0] <= cap) ++k1;
+            int k1 = n0;
+            if (cfb[n0] - cfb[k0] > cap) {
+                k1 = k0 + 1;
+                while (k1 < n0 && cfb[k1 + 1] - cfb[k0] <= cap) ++k1;
+            }
             const int cbase = cfb[k0], ncf = cfb[k1] - cbase;           // (a single landmark never exceeds cap: <= K factors)
-            // evaluate: thread per (landmark of the chunk, slot)
-            for (int wk = c.tid; wk < (k1 - k0) * (K + 1); wk += MG_NT) {
-                const int k = k0 + wk / (K + 1), t = wk % (K + 1);
+            // which landmark a compact factor belongs to (thread per landmark of the chunk, <= K stores each), so that the evaluation
+            // runs one thread per FACTOR: (landmark, slot) lanes were 60 % idle and the evaluation is bound by VALU issue
+            for (int k = k0 + c.tid; k < k1; k += MG_NT)
+                for (int cf = cfb[k] - cbase; cf < cfb[k + 1] - cbase; ++cf) kofL[cf] = k;
+            __syncthreads();
+            for (int cf = c.tid; cf < ncf; cf += MG_NT) {
+                const int k = kofL[cf];
                 const int l = mp.l0[k];
-                const int f = c.ia[L.io_lm_fbeg + l] + t;
-                if (f >= c.ia[L.io_lm_fbeg + l + 1]) continue;
-                const int cf = cfb[k] - cbase + t;
+                const int f = c.ia[L.io_lm_fbeg + l] + cf - (cfb[k] - cbase);
                 const int j = c.ia[L.io_fac_j + f];
                 if (j >= K) { jofL[cf] = -2; continue; }   // relocalisation factors are not marginalised (estimator.cpp:864-903)
                 jofL[cf] = j;
@@ -1332,48 +1330,115 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                 for (int q = 0; q < 42; ++q) recL[(size_t)cf * 42 + q] = R[q] * sq;
             }
             __syncthreads();
-            // stable counting sort of the chunk's factors by target frame: lane j of wave 0 owns bucket j
-            if (c.tid <= K) {
-                int cnt = 0;
-                if (c.tid < K) for (int cf = 0; cf < ncf; ++cf) cnt += (jofL[cf] == c.tid) ? 1 : 0;
-                bptr[c.tid + 1] = cnt;
+            MPROF(9);
+            // stable counting sort of the chunk's factors by target frame: a wavefront takes the buckets j = wave, wave + MG_NW, ...
+            // and finds their factors with ballots over 64-factor blocks (twice: totals, then -- behind the prefix -- positions)
+            for (int j = c.wave; j < K; j += MG_NW) {
+                int tot = 0;
+                for (int b0 = 0; b0 < ncf; b0 += 64) {
+                    const int cf = b0 + c.lane;
+                    tot += __popcll(__ballot(cf < ncf && jofL[cf] == j));
+                }
+                if (c.lane == 0) bptr[j + 1] = tot;
             }
             __syncthreads();
-            if (c.tid == 0) { bptr[0] = 0; for (int j = 0; j <= K; ++j) bptr[j + 1] += bptr[j]; }
+            if (c.tid == 0) { bptr[0] = 0; for (int j = 0; j < K; ++j) bptr[j + 1] += bptr[j]; }
             __syncthreads();
-            if (c.tid < K) {
-                int o = bptr[c.tid];
-                for (int cf = 0; cf < ncf; ++cf) if (jofL[cf] == c.tid) slist[o++] = cf;
+            for (int j = c.wave; j < K; j += MG_NW) {
+                int o = bptr[j];
+                for (int b0 = 0; b0 < ncf; b0 += 64) {
+                    const int cf = b0 + c.lane;
+                    const bool mine = cf < ncf && jofL[cf] == j;
+                    const unsigned long long bal = __ballot(mine);
+                    if (mine) slist[o + __popcll(bal & ((1ull << c.lane) - 1ull))] = cf;
+                    o += __popcll(bal);
+                }
             }
             __syncthreads();
-            // camera part
-            for (int pass = 0; pass < npass; ++pass) {
-            if (npass > 1) decode_pass(pass);
+            MPROF(10);
+            // ---- camera part on the matrix cores.  Wavefronts 0 and MG_NW-1 .. MG_NW-MG_T0W+1 share a^T a (the sorted list cut into
+            //      MG_T0W runs of whole pairs; the partial tiles meet in LDS and wavefront 0 adds them in run order behind the chunk's last
+            //      barrier), the wavefronts in between take the target frames.  Every result entry has ONE owner lane: plain
+            //      read-modify-write of A / bv, the reads of a lane issued together.  Index reads are clamped instead of predicated:
+            //      four independent LDS round trips per trip, not eight dependent ones.
+            const int nvalid = bptr[K];
+            const lds_d* recl = (const lds_d*)recL;
+            const lds_i* sl_ = (const lds_i*)slist;
+            glb_d* Ag = (glb_d*)A;
+            glb_d* bg = (glb_d*)bv;
+            const int offa_c = offa >= 0 ? offa : 0, offb_c = offb >= 0 ? offb : 0;
+            const int t0seg = c.wave == 0 ? 0 : (c.wave > MG_NW - MG_T0W ? MG_NW - c.wave : -1);      // (uniform) run of the a^T a product, -1: a target-frame wavefront
+            if (t0seg >= 0) {
+                const int npair = (nvalid + 1) >> 1, per = (npair + MG_T0W - 1) / MG_T0W;
+                const int qa = 2 * per * t0seg, qb = (2 * per * (t0seg + 1) < nvalid) ? 2 * per * (t0seg + 1) : nvalid;
+                mg_d4 acc = {0, 0, 0, 0};
+                for (int q = qa; q < qb; q += 8) {
+                    int cf[4];
+                    double v[4];
 #pragma unroll
-            for (int e = 0; e < MAXE; ++e) {
-                if (erq[e] == -3) continue;
-                const int oa0 = eo[e] & 255, oa1 = (eo[e] >> 8) & 255, ob0 = (eo[e] >> 16) & 255, ob1 = (eo[e] >> 24) & 255;
-                double s = 0.0;
-                if (erq[e] < 0) {
-                    for (int cf = 0; cf < ncf; ++cf) {
-                        const double* R = recL + (size_t)cf * 42;
-                        const double v = R[oa0] * R[ob0] + R[oa1] * R[ob1];
-                        s += jofL[cf] >= 0 ? v : 0.0;
+                    for (int u = 0; u < 4; ++u) { const int qq = q + 2 * u + msel; cf[u] = sl_[qq < qb ? qq : qa]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = recl[vg_mul24(cf[u], 42) + offa_c];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int qq = q + 2 * u + msel; v[u] = (qq < qb && offa >= 0) ? v[u] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (q + 2 * u < qb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);      // (uniform)
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) ((lds_d*)t0p)[t0seg * 256 + reg * 64 + c.lane] = acc[reg];
+            } else {
+                for (int j = c.wave - 1; j < K; j += MG_NW - MG_T0W) {
+                    const int q0 = bptr[j], q1 = bptr[j + 1];
+                    if (q1 == q0 || mp.pose[j] < 0) continue;                          // (uniform)
+                    mg_d4 aba = {0, 0, 0, 0}, abb = {0, 0, 0, 0};
+                    for (int q = q0; q < q1; q += 8) {
+                        int cf[4];
+                        double va[4], vb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int qq = q + 2 * u + msel; cf[u] = sl_[qq < q1 ? qq : q0]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int ro = vg_mul24(cf[u], 42); va[u] = recl[ro + offa_c]; vb[u] = recl[ro + offb_c]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int qq = q + 2 * u + msel;
+                            va[u] = (qq < q1 && offa >= 0) ? va[u] : 0.0;
+                            vb[u] = (qq < q1 && offb >= 0) ? vb[u] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (q + 2 * u < q1) {                                      // (uniform)
+                                aba = __builtin_amdgcn_mfma_f64_16x16x4f64(vb[u], va[u], aba, 0, 0, 0);
+                                abb = __builtin_amdgcn_mfma_f64_16x16x4f64(vb[u], vb[u], abb, 0, 0, 0);
+                            }
+                        }
                     }
-                } else {
-                    for (int q = bptr[erq[e]]; q < bptr[erq[e] + 1]; ++q) {
-                        const double* R = recL + (size_t)slist[q] * 42;
-                        s += R[oa0] * R[ob0] + R[oa1] * R[ob1];
+                    // rows 0 .. 5 of both products = the columns of pose j: the accumulator entries reg 0 (rows 0 .. 3) and reg 1 (rows 4, 5)
+                    const int cj = acol(mcol), pj = mp.pose[j];
+                    const int r0i = pj + (c.lane >> 4), r1i = r0i + 4;
+                    const bool has1 = (c.lane >> 4) < 2;                                // rows 4, 5
+                    if (cj >= 0) {
+                        const double o0 = Ag[(size_t)r0i * posmax + cj], o1 = Ag[(size_t)cj * posmax + r0i];
+                        const double o2 = has1 ? Ag[(size_t)r1i * posmax + cj] : 0.0, o3 = has1 ? Ag[(size_t)cj * posmax + r1i] : 0.0;
+                        Ag[(size_t)r0i * posmax + cj] = o0 + aba[0]; Ag[(size_t)cj * posmax + r0i] = o1 + aba[0];
+                        if (has1) { Ag[(size_t)r1i * posmax + cj] = o2 + aba[1]; Ag[(size_t)cj * posmax + r1i] = o3 + aba[1]; }
+                    } else if (cj == -2) {
+                        const double o0 = bg[r0i], o2 = has1 ? bg[r1i] : 0.0;
+                        bg[r0i] = o0 + aba[0];
+                        if (has1) bg[r1i] = o2 + aba[1];
+                    }
+                    if (mcol < 6) {
+                        const double o0 = Ag[(size_t)r0i * posmax + pj + mcol], o2 = has1 ? Ag[(size_t)r1i * posmax + pj + mcol] : 0.0;
+                        Ag[(size_t)r0i * posmax + pj + mcol] = o0 + abb[0];
+                        if (has1) Ag[(size_t)r1i * posmax + pj + mcol] = o2 + abb[1];
                     }
                 }
-                acc[e] += s;
             }
-            if (npass > 1) flush_pass();
-            }
+            MPROF(11);
             // landmark rows / columns: thread per (landmark, camera column | self | rhs)
             for (int wk = c.tid; wk < (k1 - k0) * (ncam + 2); wk += MG_NT) {
                 const int k = k0 + wk / (ncam + 2), a = wk % (ncam + 2);
-                const int l = mp.l0[k], cl = mp.lm[l];
+                const int cl = mp.misc[7] + k;             // (= mp.lm[mp.l0[k]]: the frame-0 landmarks take consecutive columns)
                 int ca = -2, o0 = 0, o1 = 1, rq = -1;
                 if (a < 6) { ca = mp.pose[0] + a; o0 = 2 + a; o1 = 8 + a; }
                 else if (a < 6 * K) { const int f = a / 6, kk = a - 6 * f; ca = mp.pose[f] < 0 ? -1 : mp.pose[f] + kk; o0 = 14 + kk; o1 = 20 + kk; rq = f; }
@@ -1390,14 +1455,38 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                     const double v = R[o0] * R[38] + R[o1] * R[39];
                     s += (j >= 0 && (rq < 0 || rq == j)) ? v : 0.0;
                 }
-                if (a == ncam) A[cl * posmax + cl] += s;
-                else if (a == ncam + 1) bv[cl] += s;
-                else { A[cl * posmax + ca] += s; A[ca * posmax + cl] += s; }
+                // (nothing else contributes to a landmark's row, column or gradient entry -- A and bv were cleared, a landmark lies in
+                //  one chunk: plain stores, no read-modify-write round trip)
+                if (a == ncam) Ag[(size_t)cl * posmax + cl] = s;
+                else if (a == ncam + 1) bg[cl] = s;
+                else { Ag[(size_t)cl * posmax + ca] = s; Ag[(size_t)ca * posmax + cl] = s; }
             }
             __syncthreads();
+            if (c.wave == 0) {
+                // a^T a of the chunk: the MG_T0W partial tiles in run order (the next chunk does not write them before its own three barriers)
+                const int cj = acol(mcol);
+                double tv[4], ov[4];
+                int ci[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    double sacc = ((const lds_d*)t0p)[reg * 64 + c.lane];
+#pragma unroll
+                    for (int sg = 1; sg < MG_T0W; ++sg) sacc += ((const lds_d*)t0p)[sg * 256 + reg * 64 + c.lane];
+                    tv[reg] = sacc;
+                    ci[reg] = acol((c.lane >> 4) + 4 * reg);                           // D[row = (lane >> 4) + 4 reg][col = lane & 15]
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    ov[reg] = ci[reg] < 0 ? 0.0 : (cj >= 0 ? Ag[(size_t)ci[reg] * posmax + cj] : (cj == -2 ? bg[ci[reg]] : 0.0));
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (ci[reg] < 0) continue;
+                    if (cj >= 0) Ag[(size_t)ci[reg] * posmax + cj] = ov[reg] + tv[reg];
+                    else if (cj == -2) bg[ci[reg]] = ov[reg] + tv[reg];
+                }
+            }
             k0 = k1;
         }
-        if (npass == 1) flush_pass();
     }
     __syncthreads();
 
