@@ -715,29 +715,80 @@ DEV int vh_eig(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int 
 // form, only the order of the sums changes.  (A fixed elimination order on the matrix cores -- no search at all -- was measured
 // 20 % faster still and dropped: it cuts weak directions the pivoted order keeps, profiles/experiments/r06d_*.)
 typedef double mg_d4 __attribute__((vector_size(32)));
+// Round 6 (second form): the pivot chain on ONE wavefront, in registers.  A pivot is a chain of dependent steps -- search, 1 / sqrt,
+// the pivot row's entries, the dot products, the new column -- and with sixteen wavefronts taking part each link of it crossed LDS
+// and a workgroup barrier (2.4K cycles per pivot, 190K of the kernel's 540K).  Now lane t of wavefront 0 owns rows t and t + 64 (the
+// augmented row n, which carries b', among them; n <= 96): the entries of its rows in the CURRENT block of sixteen columns, its
+// running diagonal and its liveness stay in registers; the pivot row's entries reach the other lanes through v_readlane (the pivot
+// index is uniform) straight into the multiply-adds, A'[i][p] is one LDS read issued as soon as p is known, the search is a DPP max
+// plus two ballots.  No barrier inside a block; the other wavefronts wait at the block's end and join for the trailing update
+// (A' -= L_blk L_blk^T on the matrix cores, as before).  Same pivot rule, same cut, same output layout; the dot product of a column
+// runs over the block's earlier columns in order.
+template <int T, int PS>
+DEV void sqrt_dot(const double (&b0)[16], const double (&b1)[16], int pl, double& s0, double& s1) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const double lp = readlane_f64(PS ? b1[j] : b0[j], pl);
+        s0 = fma(b0[j], lp, s0); s1 = fma(b1[j], lp, s1);
+    }
+}
+template <int T>
+DEV bool sqrt_step(int k, int n, int ld, int lane, const double* A, double* Lc, double* yv, const double* bb,
+                   double (&b0)[16], double (&b1)[16], double& d0, double& d1) {
+    const int r0 = lane, r1 = lane + 64;
+    // pivot = largest remaining diagonal (lowest index on ties)
+    const double best = wave_max_all(fmax(d0, d1));
+    const unsigned long long m0 = __ballot(d0 == best), m1 = __ballot(d1 == best);
+    const int p = uni(m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1);
+    if (!(best > MG_EPS)) return false;           // (uniform) nothing above eps is left: the rest is what the reference's cut drops
+    const int pl = p & 63;
+    // (the augmented row n is lane n's first row when n < 64, lane n - 64's second one otherwise: its "A' entry" is b'_p, its
+    //  block entries are y, it has no diagonal.  One unconditional LDS read per row from a selected address -- rows beyond n read
+    //  b'_p too and drop it -- and selects instead of branches: the step is one straight chain)
+    const int ob = (int)(bb - A) + p;
+    const int o0 = r0 < n ? (r0 > p ? r0 * ld + p : p * ld + r0) : ob;
+    const int o1 = r1 < n ? (r1 > p ? r1 * ld + p : p * ld + r1) : ob;
+    const double a0 = ((const lds_d*)A)[o0], a1 = ((const lds_d*)A)[o1];
+    const double inv = mg_rsqrt(best);
+    double s0 = 0.0, s1 = 0.0;
+    if (p < 64) sqrt_dot<T, 0>(b0, b1, pl, s0, s1); else sqrt_dot<T, 1>(b0, b1, pl, s0, s1);      // (uniform)
+    const bool live0 = r0 < n && d0 > -1e299, live1 = r1 < n && d1 > -1e299;
+    const double piv = best * inv;
+    double v0 = (a0 - s0) * inv, v1 = (a1 - s1) * inv;
+    v0 = (live0 || r0 == n) ? v0 : 0.0;
+    v1 = (live1 || r1 == n) ? v1 : 0.0;
+    v0 = r0 == p ? piv : v0;
+    v1 = r1 == p ? piv : v1;
+    b0[T] = v0; b1[T] = v1;
+    d0 = (r0 == p || !live0) ? -1e300 : d0 - v0 * v0;
+    d1 = (r1 == p || !live1) ? -1e300 : d1 - v1 * v1;
+    const int w0 = r0 < n ? (int)(Lc - A) + k * ld + r0 : (int)(yv - A) + k;
+    const int w1 = r1 < n ? (int)(Lc - A) + k * ld + r1 : (int)(yv - A) + k;
+    if (r0 <= n) ((lds_d*)A)[w0] = v0;
+    if (r1 <= n) ((lds_d*)A)[w1] = v1;
+    return true;
+}
 DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs, int offred, const double* bglob) {
     double* A = MG_LDS + offM;                // A' (lower triangle read; updated block by block)
     double* Lc = MG_LDS + offV;               // column k of L at Lc[k * ld + i]
-    double* dg0 = MG_LDS + offcs;             // running diagonal, copy 0 (-1e300 once pivoted)
+    double* dg0 = MG_LDS + offcs;             // (the running diagonal lives in registers now; the layout behind it is the caller's)
     double* yv = dg0 + 2 * n + 1;             // y = L^-1 P^T b'   (kept for the caller: cs[2n + 1 ..))
-    double* dg1 = yv + n;                     // running diagonal, copy 1
-    double* bb = dg1 + n;                     // b' minus the finished blocks' share
-    (void)offred;
+    double* bb = yv + 2 * n;                  // b' minus the finished blocks' share
+    int* flag = (int*)(MG_LDS + offred + 20); // [0] rank so far, [1] stop
     __syncthreads();
     for (int k = c.tid; k < n * ld; k += MG_NT) Lc[k] = 0.0;
-    for (int i = c.tid; i < n; i += MG_NT) { yv[i] = 0.0; dg0[i] = A[i * ld + i]; bb[i] = bglob[i]; }
-    // MG_LPR lanes per row (8 with 1024 threads, 4 with 512): rows 0 .. n-1 of L and row n = the augmented one (n <= 96 < 128)
-    enum { MG_LPR = MG_NT / 128, MG_LPR_SHIFT = MG_LPR == 8 ? 3 : 2 };
-    static_assert(MG_LPR == 8 || MG_LPR == 4, "sqrt_factor: 512 or 1024 threads");
-    const int row = c.tid >> MG_LPR_SHIFT, part = c.tid & (MG_LPR - 1);
-    const bool has_row = row <= n;
+    for (int i = c.tid; i < n; i += MG_NT) { yv[i] = 0.0; bb[i] = bglob[i]; }
+    if (c.tid == 0) { flag[0] = 0; flag[1] = 0; }
     const int wave = __builtin_amdgcn_readfirstlane(c.wave);
     const int ntl = (n + 15) >> 4, ntile = ntl * (ntl + 1) / 2;       // lower 16 x 16 tiles of A' (16 ntl <= ld: the rows beyond n are zero in Lc)
-    int rank = 0;
-    for (int k = 0; k < n; ++k) {
-        __syncthreads();
-        const int kb = k & ~15;
-        if (k == kb && k > 0) {
+    __syncthreads();
+    double d0 = -1e300, d1 = -1e300;
+    if (wave == 0) {
+        if (c.lane < n) d0 = A[c.lane * ld + c.lane];
+        if (c.lane + 64 < n) d1 = A[(c.lane + 64) * ld + c.lane + 64];
+    }
+    for (int kb = 0; kb < n; kb += 16) {
+        if (kb > 0) {
             // ---- the block of columns [kb - 16, kb) leaves A' and b'
             const int k0 = kb - 16;
             const int jc = c.lane & 15, kq = c.lane >> 4;
@@ -768,49 +819,22 @@ DEV int sqrt_factor(const MCtx& c, int offM, int offV, int n, int ld, int offcs,
             }
             __syncthreads();
         }
-        const double* dgr = (k & 1) ? dg1 : dg0;
-        double* dgw = (k & 1) ? dg0 : dg1;
-        // pivot = largest remaining diagonal (lowest index on ties): every wavefront on its own, two entries per lane
-        const int i0 = c.lane, i1 = c.lane + 64;
-        const double v0 = i0 < n ? dgr[i0] : -1e300;
-        const double v1 = i1 < n ? dgr[i1] : -1e300;
-        const double best = wave_max_all(fmax(v0, v1));
-        const unsigned long long m0 = __ballot(v0 == best), m1 = __ballot(v1 == best);
-        const int p = m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1;
-        if (!(best > MG_EPS)) break;          // (uniform) nothing above eps is left: the rest is what the reference's cut drops
-        const double inv = mg_rsqrt(best);
-        // the columns of this block only: lane `part` of a row takes j = kb + part and kb + part + MG_LPR (one round of LDS reads)
-        double sacc = 0.0;
-        if (has_row) {
-            if (MG_LPR == 8) {
-                const int j0 = kb + part, j1 = kb + part + 8;
-                const bool in0 = j0 < k, in1 = j1 < k;
-                const double b0 = Lc[(in0 ? j0 : kb) * ld + p], b1 = Lc[(in1 ? j1 : kb) * ld + p];
-                const double a0 = row < n ? Lc[(in0 ? j0 : kb) * ld + row] : yv[in0 ? j0 : kb];
-                const double a1 = row < n ? Lc[(in1 ? j1 : kb) * ld + row] : yv[in1 ? j1 : kb];
-                sacc = (in0 ? a0 * b0 : 0.0) + (in1 ? a1 * b1 : 0.0);
-            } else {
-                for (int j = kb + part; j < k; j += MG_LPR) sacc += (row < n ? Lc[j * ld + row] : yv[j]) * Lc[j * ld + p];
-            }
+        if (wave == 0) {
+            double b0[16], b1[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { b0[j] = 0.0; b1[j] = 0.0; }
+            int done = 0;
+            bool go = true;
+#define MG_SQRT_STEP(T) if (go && kb + T < n) { go = sqrt_step<T>(kb + T, n, ld, c.lane, A, Lc, yv, bb, b0, b1, d0, d1); done += go ? 1 : 0; }
+            MG_SQRT_STEP(0) MG_SQRT_STEP(1) MG_SQRT_STEP(2) MG_SQRT_STEP(3) MG_SQRT_STEP(4) MG_SQRT_STEP(5) MG_SQRT_STEP(6) MG_SQRT_STEP(7)
+            MG_SQRT_STEP(8) MG_SQRT_STEP(9) MG_SQRT_STEP(10) MG_SQRT_STEP(11) MG_SQRT_STEP(12) MG_SQRT_STEP(13) MG_SQRT_STEP(14) MG_SQRT_STEP(15)
+#undef MG_SQRT_STEP
+            if (c.lane == 0) { flag[0] = kb + done; flag[1] = go ? 0 : 1; }
         }
-        // sum over the eight lanes of the row on the DPP network (fixed order), result in every lane of the group
-        sacc += dpp_mov_f64<0xB1>(sacc);      // quad_perm [1,0,3,2]
-        sacc += dpp_mov_f64<0x4E>(sacc);      // quad_perm [2,3,0,1]
-        if (MG_LPR == 8) sacc += dpp_mov_f64<0x141>(sacc);     // row_half_mirror
-        if (has_row && part == 0) {
-            if (row < n) {
-                const double d = dgr[row];
-                double v = 0.0;
-                if (row == p) v = best * inv;
-                else if (d > -1e299) v = (A[(row > p ? row : p) * ld + (row > p ? p : row)] - sacc) * inv;
-                Lc[k * ld + row] = v;
-                dgw[row] = (row == p || !(d > -1e299)) ? -1e300 : d - v * v;
-            } else {
-                yv[k] = (bb[p] - sacc) * inv;
-            }
-        }
-        rank = k + 1;
+        __syncthreads();
+        if (flag[1]) break;                   // (uniform)
     }
+    const int rank = flag[0];
     __syncthreads();
     return rank;
 }
