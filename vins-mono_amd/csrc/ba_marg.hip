@@ -1516,6 +1516,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
 
     MPROF(3);
     // ---- M4: Amm^+ [Amr | bmm], Schur complement
+    bool direct = false;                   // (uniform) A' / b' already stand in the square root's LDS tile / gV
     {
         const bool in_lds = m <= ld;
         double* Mm = in_lds ? eM : gM;
@@ -1532,6 +1533,207 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         // summed block by block (Amm^-1 = [B11 B12; B12^T B22], B11 = P'^-1, B12 = -P'^-1 W D^-1, B22 = D^-1 - D^-1 W^T B12)
         // without storing B22.  Otherwise (or if P' is not positive definite) the eigen-decomposition below runs.
         const int md = m - n0, ml = n0;
+        // ---- Round 6: the Schur complement of the dropped block in two stages on the matrix cores, without Amm^-1 [Amr | bmm].
+        // With C = the md dropped camera columns followed by the n kept columns and the gradient (q = md + n + 1 indices), Z = the
+        // frame-0 landmarks' rows of A restricted to C (ml x q) and D their diagonal:
+        //     G' = G - Z^T D^-1 Z                              (the landmarks leave: rank-ml update of the q x q system, MFMA, k = ml)
+        //     P' = G'[0:md, 0:md] = L L^T,  X = L^-1 G'[0:md, md:]
+        //     [A' | b'] = G'[md:, md:] - X^T X                 (the dropped pose / speed-bias leave: MFMA, k = md <= 16)
+        // which is the same elimination as X1 / X2 below, with every m-term and ml-term dot product on v_mfma_f64_16x16x4 and the
+        // result written straight into the LDS tile the square root works on (until round 6: T2 through global memory, A' staged in
+        // global memory and copied back -- 190K of the kernel's 460K cycles).  The certificate lambda_min(Amm) > 1e-7 is kept:
+        // ||Amm^-1||_F^2 = ||P'^-1||^2 + 2 ||P'^-1 W D^-1||^2 + ||D^-1 + Y^T Y||^2 with Y = L^-1 W D^-1, and
+        // ||D^-1 + Y^T Y||_F^2 = sum_l (d_l^-2 + 2 d_l^-1 |y_l|^2) + ||Y Y^T||_F^2 -- an md x md product instead of ml^2 entries.
+        {
+            const int q = md + n + 1, qp = 16 * ((q + 15) >> 4), np1 = n + 1, ldx = 16 * ((np1 + 15) >> 4);
+            const bool fits = md >= 1 && md <= 16 && qp <= ld && n <= ld && n * ld + 16 * ldx <= ld * ld
+                              && 2 * md * ml + ml <= n * ld && c.hdr[H_MARGMODE] == 0 && n <= 16 * MG_HROWS;
+            if (fits) {
+                lds_d* Gp = (lds_d*)eV;                      // [qp][ld]   G' (lower tiles)
+                lds_d* Wl = (lds_d*)eM;                      // [md][ml]   W = A[dropped camera][landmark]
+                lds_d* dinv = Wl + md * ml;                  // [ml]       1 / d_l
+                lds_d* Ys = dinv + ml;                       // [md][ml]   Y = L^-1 W D^-1
+                lds_d* Xs = (lds_d*)eM + n * ld;             // [16][ldx]  X = L^-1 U, rows md .. 15 and columns n + 1 .. zero
+                lds_d* Ls = (lds_d*)cs;                      // [16][16]   L, then L^-1 (lower)
+                lds_d* Pi = Ls + 256;                        // [md][md]   P'^-1
+                int* okf = (int*)(red + 18);
+                const glb_d* Ag = (const glb_d*)A;
+                const glb_d* bg = (const glb_d*)bv;
+                if (c.tid == 0) *okf = 1;
+                double bad = 0.0;
+                for (int l = c.tid; l < ml; l += MG_NT) {
+                    const double d = Ag[(size_t)(md + l) * posmax + md + l];
+                    bad += (d > 0.0 && d < 1e300) ? 0.0 : 1.0;
+                    dinv[l] = 1.0 / d;
+                }
+                for (int k = c.tid; k < md * ml; k += MG_NT) {
+                    const int p = k / ml, l = k - p * ml;
+                    Wl[k] = Ag[(size_t)(md + l) * posmax + p];
+                }
+                __syncthreads();
+                // ---- G' = G - Z^T D^-1 Z: a wavefront takes the lower 16 x 16 tiles t = wave, wave + MG_NW, ...
+                {
+                    const int qt = qp >> 4, ntile = qt * (qt + 1) / 2;
+                    const int jc = c.lane & 15, kq = c.lane >> 4;
+                    for (int t = __builtin_amdgcn_readfirstlane(c.wave); t < ntile; t += MG_NW) {
+                        int ti, tj;
+                        tri_decode(t, ti, tj);
+                        const int ia = 16 * ti + jc, ib = 16 * tj + jc;                     // C indices of this lane's operand columns
+                        const int ca = ia < md ? ia : m + ia - md, cb = ib < md ? ib : m + ib - md;      // their columns in A
+                        const bool ga = ia == md + n, gb = ib == md + n;                   // the gradient "column"
+                        const bool za = ia > md + n, zb = ib > md + n;
+                        mg_d4 acc = {0, 0, 0, 0};
+                        for (int l0 = 0; l0 < ml; l0 += 16) {
+                            double av[4], bv4[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int l = l0 + 4 * u + kq;
+                                const int lc = l < ml ? l : 0;
+                                const double za_ = ga ? bg[md + lc] : Ag[(size_t)(md + lc) * posmax + (za ? 0 : ca)];
+                                const double zb_ = gb ? bg[md + lc] : Ag[(size_t)(md + lc) * posmax + (zb ? 0 : cb)];
+                                av[u] = (l < ml && !za) ? za_ * dinv[lc] : 0.0;
+                                bv4[u] = (l < ml && !zb) ? zb_ : 0.0;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (l0 + 4 * u < ml) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv4[u], acc, 0, 0, 0);      // (uniform)
+                        }
+                        double gv[4];
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int i = 16 * ti + kq + 4 * reg;                           // D[row = kq + 4 reg][col = jc]
+                            const int ci = i < md ? i : m + i - md;
+                            const bool gi = i == md + n, zi = i > md + n;
+                            // G[i][ib]: A (symmetric: the lower entry), the gradient for the last index, zero on the padding
+                            double g = 0.0;
+                            if (!zi && !zb && !(gi && gb)) {
+                                if (gi) g = bg[cb];
+                                else if (gb) g = bg[ci];
+                                else g = Ag[(size_t)(ci > cb ? ci : cb) * posmax + (ci > cb ? cb : ci)];
+                            }
+                            gv[reg] = g;
+                        }
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) Gp[(16 * ti + kq + 4 * reg) * ld + ib] = gv[reg] - acc[reg];
+                    }
+                }
+                __syncthreads();
+                // ---- P' = L L^T in registers (lane = row), then L^-1 by lane = column (wavefront 0)
+                if (c.wave == 0) {
+                    double a[16];
+                    const int i = c.lane & 15;
+#pragma unroll
+                    for (int qq = 0; qq < 16; ++qq) a[qq] = (c.lane < md && qq <= i && qq < md) ? Gp[i * ld + qq] : 0.0;
+                    bool good = true;
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) {
+                        if (jj < md) {
+                            const double piv = readlane_f64(a[jj], jj);
+                            if (!(piv > 0.0) || !(piv < 1e300)) good = false;
+                            const double di = mg_rsqrt(piv);
+                            const double l = a[jj] * di;
+                            a[jj] = l;
+#pragma unroll
+                            for (int qq = jj + 1; qq < 16; ++qq) { const double lq = readlane_f64(l, qq); a[qq] -= l * lq; }
+                        }
+                    }
+                    if (c.lane < md) {
+#pragma unroll
+                        for (int qq = 0; qq < 16; ++qq) if (qq <= i && qq < md) Ls[i * 16 + qq] = a[qq];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // column j of L^-1 (lower): forward substitution on e_j
+                    double xx[16];
+                    const int j = c.lane & 15;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        double sacc = (r == j) ? 1.0 : 0.0;
+#pragma unroll
+                        for (int qq = 0; qq < r; ++qq) sacc -= (r < md && qq >= j) ? Ls[r * 16 + qq] * xx[qq] : 0.0;
+                        xx[r] = (r < md && r >= j) ? sacc / Ls[r * 16 + r] : 0.0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (c.lane < 16) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Ls[r * 16 + j] = (r < md && j < md) ? xx[r] : 0.0;      // Ls <- L^-1 (lower, zeros elsewhere)
+                    }
+                    if (!good) *okf = 0;
+                }
+                __syncthreads();
+                // ---- X = L^-1 U (U[p][j] = G'[md + j][p]), Y = L^-1 W D^-1, P'^-1 = L^-T L^-1
+                for (int k = c.tid; k < 16 * ldx; k += MG_NT) {
+                    const int p = k / ldx, j = k - p * ldx;
+                    double sacc = 0.0;
+                    if (p < md && j < np1)
+                        for (int qq = 0; qq <= p; ++qq) sacc += Ls[p * 16 + qq] * Gp[(md + j) * ld + qq];
+                    Xs[k] = sacc;
+                }
+                for (int k = c.tid; k < md * ml; k += MG_NT) {
+                    const int p = k / ml, l = k - p * ml;
+                    double sacc = 0.0;
+                    for (int qq = 0; qq <= p; ++qq) sacc += Ls[p * 16 + qq] * Wl[qq * ml + l];
+                    Ys[k] = sacc * dinv[l];
+                }
+                for (int k = c.tid; k < md * md; k += MG_NT) {
+                    const int i = k / md, j = k - i * md;
+                    double sacc = 0.0;
+                    for (int r = (i > j ? i : j); r < md; ++r) sacc += Ls[r * 16 + i] * Ls[r * 16 + j];
+                    Pi[k] = sacc;
+                }
+                __syncthreads();
+                // ---- the certificate
+                double fro = 0.0;
+                for (int k = c.tid; k < md * md; k += MG_NT) {
+                    const double v = Pi[k];
+                    fro += v * v; bad += (v == v && fabs(v) < 1e300) ? 0.0 : 1.0;
+                    const int i = k / md, j = k - i * md;
+                    double mm = 0.0;                                                     // (Y Y^T)[i][j]
+                    for (int l = 0; l < ml; ++l) mm += Ys[i * ml + l] * Ys[j * ml + l];
+                    fro += mm * mm; bad += (mm == mm && fabs(mm) < 1e300) ? 0.0 : 1.0;
+                }
+                for (int k = c.tid; k < md * ml; k += MG_NT) {                           // B12 = -P'^-1 W D^-1, entry by entry
+                    const int p = k / ml, l = k - p * ml;
+                    double sacc = 0.0;
+                    for (int qq = 0; qq < md; ++qq) sacc += Pi[p * md + qq] * Wl[qq * ml + l];
+                    const double v = sacc * dinv[l];
+                    fro += 2.0 * v * v; bad += (v == v && fabs(v) < 1e300) ? 0.0 : 1.0;
+                }
+                for (int l = c.tid; l < ml; l += MG_NT) {
+                    double yn = 0.0;
+                    for (int p = 0; p < md; ++p) yn += Ys[p * ml + l] * Ys[p * ml + l];
+                    fro += dinv[l] * dinv[l] + 2.0 * dinv[l] * yn;
+                }
+                fro = mg_block_sum(c, red, fro);
+                bad = mg_block_sum(c, red, bad);
+                direct = *okf != 0 && bad == 0.0 && fro > 0.0 && fro < 1e14;              // 1 / sqrt(fro) > 1e-7
+                __syncthreads();
+                if (direct) {
+                    // ---- [A' | b'] = G'[md:, md:] - X^T X  ->  the square root's tile (eM, leading dimension ld) and b' (gV)
+                    const int nt = ldx >> 4, ntile = nt * (nt + 1) / 2;
+                    const int jc = c.lane & 15, kq = c.lane >> 4;
+                    for (int t = __builtin_amdgcn_readfirstlane(c.wave); t < ntile; t += MG_NW) {
+                        int ti, tj;
+                        tri_decode(t, ti, tj);
+                        mg_d4 acc = {0, 0, 0, 0};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(4 * u + kq) * ldx + 16 * ti + jc], Xs[(4 * u + kq) * ldx + 16 * tj + jc], acc, 0, 0, 0);
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int i = 16 * ti + kq + 4 * reg, j = 16 * tj + jc;       // D[row = kq + 4 reg][col = jc]
+                            if (i > n || j > n || j > i) continue;                        // (lower triangle incl. the gradient row i = n)
+                            const double v = Gp[(md + i) * ld + md + j] - acc[reg];
+                            if (i < n) { eM[i * ld + j] = v; eM[j * ld + i] = v; }
+                            else if (j < n) gV[j] = v;
+                        }
+                    }
+                    if (c.tid == 0) mi[4] = 0;       // no sweeps: the dropped block left by block elimination
+                    MPROF(4);
+                    __syncthreads();
+                }
+            }
+        }
+        if (!direct) {
         bool inverse_ok = false;
         if (md >= 1 && md <= 16 && md * ml <= ld * ld) {
             double* dl = cs;                 // [ml <= Lcap] landmark diagonal        (mg_cs >= Lcap + 512 checked on the host)
@@ -1753,6 +1955,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             }
         }
         __syncthreads();
+        }   // !direct
     }
     MPROF(5);
     double* bp = gV;                       // b' (n)
@@ -1760,7 +1963,8 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     double* M2 = n_lds ? eM : g2M;
     double* V2 = n_lds ? eV : g2V;
     const int ld2 = n_lds ? ld : n;
-    for (int k = c.tid; k < n * n; k += MG_NT) M2[(k / n) * ld2 + k % n] = gM[(k / n) * posmax + k % n];
+    if (!direct)
+        for (int k = c.tid; k < n * n; k += MG_NT) M2[(k / n) * ld2 + k % n] = gM[(k / n) * posmax + k % n];
     __syncthreads();
 #ifdef BA_PROFILE
     const long long _t2 = clock64();
