@@ -26,3 +26,10 @@ print("window 0: F =", int(sum(probs[0]['lm_nobs']) - len(probs[0]['lm_nobs'])),
 for i, n in names.items():
     print(f"{n:<44}{out[i] / it:>12.0f}{out[32 + i] / it:>12.0f}")
 print(f"{'total':<44}{sum(out[i] for i in names if i < 29) / it:>12.0f}")
+hi = np.zeros(64)
+h.lib.vg_debug_detail_profile_hi(hi.ctypes.data_as(C.POINTER(C.c_double)), 1)
+h.ba_run_async(); h.sync()
+h.lib.vg_debug_detail_profile_hi(hi.ctypes.data_as(C.POINTER(C.c_double)), 1)
+pro = {45: "factor kernel: fetch (all rounds)", 46: "factor kernel: sort (all rounds)", 40: "prologue: clears, state copy", 41: "prologue: IMU sqrt_info", 42: "prologue: J0^T copy", 43: "prologue: J0 staged", 44: "prologue: J0^T J0 (MFMA)"}
+for i, n in pro.items():
+    print(f"{n:<44}{hi[i - 32]:>12.0f}{hi[i]:>12.0f}   (per solve)")

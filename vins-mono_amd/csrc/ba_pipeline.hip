@@ -63,12 +63,17 @@ typedef double double4_t __attribute__((vector_size(32)));      // v_mfma_f64_16
 // finer timers for development (build with -DBA_PROFILE_DETAIL): threads 0 and 128 of workgroup 0 accumulate clock deltas of
 // the sub-phases of chain_schur / cholesky_aug / assemble_small into a device array read back by vg_debug_detail_profile
 #ifdef BA_PROFILE_DETAIL
-__device__ double g_dprof[64];
+__device__ double g_dprof[128];     // [0, 32) thread 0, ids 0 .. 31 | [32, 64) thread 128 | [64, 128) the same for ids 32 .. 63
 #define DP_DECL long long _dp = clock64()
-#define DP_ADD(id) do { if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 128)) { const long long _n = clock64(); g_dprof[(threadIdx.x ? 32 : 0) + (id)] += (double)(_n - _dp); _dp = _n; } } while (0)
+#define DP_ADD(id) do { if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 128)) { const long long _n = clock64(); g_dprof[(threadIdx.x ? 32 : 0) + ((id) & 31) + ((id) >= 32 ? 64 : 0)] += (double)(_n - _dp); _dp = _n; } } while (0)
 extern "C" int vg_debug_detail_profile(double* out64, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dprof), sizeof(double) * 64);
     if (e == hipSuccess && reset) { double z[64] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_dprof), z, sizeof(z)); }
+    return e == hipSuccess ? 0 : -2;
+}
+extern "C" int vg_debug_detail_profile_hi(double* out64, int reset) {      // ids 32 .. 63
+    hipError_t e = hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dprof), sizeof(double) * 64, sizeof(double) * 64);
+    if (e == hipSuccess && reset) { double z[64] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_dprof), z, sizeof(z), sizeof(double) * 64); }
     return e == hipSuccess ? 0 : -2;
 }
 #else
@@ -351,33 +356,41 @@ NOINL void imu_sqrt_info_ref(const Ctx& c_in) {
 NOINL void imu_sqrt_info(const Ctx& c_in) {
     const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
     const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
-    double* A = LDSB + c.wave * 256;                 // 15x15 scratch per wavefront
+    // Round 6: a factor is one wavefront's business from the load to the store -- lane i holds row i of the 15 x 15 matrix in
+    // registers, a pivot column reaches the other rows through v_readlane, and nothing in between waits for the workgroup (it used
+    // to be three workgroup barriers and an LDS round trip per column, 45 per pass).  Same operations on the same operands in the same
+    // order: the factor is the one the LDS form produced.
+    lds_d* A = AS_LDS(LDSB + c.wave * 256);          // 15x15 scratch per wavefront (the factor, for the column solves below)
     const int nimu = L.K - 1;
-    const int* valid = c.ia + L.io_imu_valid;
+    const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
+    const int li = c.lane < 15 ? c.lane : 14;
     for (int base = 0; base < nimu; base += BA_NW) {
-        const int f = base + c.wave;
-        const bool act = f < nimu && valid[f];
-        const double* cov = c.di + L.do_imu + f * BA_IMU_STRIDE + IM_COV;
-        if (act)
-            for (int k = c.lane; k < 225; k += 64) A[k] = cov[k];
-        __syncthreads();
+        const int f = uni(base + c.wave);
+        if (!(f < nimu && valid[f])) continue;           // (uniform per wavefront; no workgroup barrier below)
+        const glb_d* cov = AS_GLB_C(c.di + L.do_imu + f * BA_IMU_STRIDE + IM_COV);
+        double a[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) a[k] = cov[li * 15 + k];
         // UL factorisation, columns from the last to the first: A = U U^T
+#pragma unroll
         for (int j = 14; j >= 0; --j) {
-            const double d = act ? sqrt(A[j * 15 + j]) : 1.0;
-            __syncthreads();
-            if (act && c.lane < j) A[c.lane * 15 + j] /= d;
-            if (act && c.lane == j) A[j * 15 + j] = d;
-            __syncthreads();
-            if (act)
-                for (int k = c.lane; k < j * j; k += 64) {
-                    const int i = k / j, kk = k % j;
-                    if (kk >= i) A[i * 15 + kk] -= A[i * 15 + j] * A[kk * 15 + j];
-                }
-            __syncthreads();
+            const double d = sqrt(readlane_f64(a[j], j));
+            a[j] = c.lane < j ? a[j] / d : (c.lane == j ? d : a[j]);
+            // row i (< j), entries kk = i .. j-1:  A[i][kk] -= A[i][j] A[kk][j]
+#pragma unroll
+            for (int kk = 0; kk < j; ++kk) {
+                const double ukj = readlane_f64(a[j], kk);
+                a[kk] = (c.lane <= kk) ? a[kk] - a[j] * ukj : a[kk];
+            }
         }
+        if (c.lane < 15) {
+#pragma unroll
+            for (int k = 0; k < 15; ++k) A[c.lane * 15 + k] = a[k];
+        }
+        __builtin_amdgcn_wave_barrier();
         // X = U^-1 (upper): lane = column j, back-substitute upward
-        double* Uo = c.sc + L.so_imuU + f * 225;
-        if (act && c.lane < 15) {
+        glb_d* Uo = AS_GLB(c.sc + L.so_imuU + f * 225);
+        if (c.lane < 15) {
             const int j = c.lane;
             double x[15];
 #pragma unroll
@@ -390,8 +403,9 @@ NOINL void imu_sqrt_info(const Ctx& c_in) {
 #pragma unroll
             for (int i = 0; i < 15; ++i) Uo[i * 15 + j] = x[i];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
 }
 
 extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
@@ -399,6 +413,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
     Ctx c;
     ctx_init(c, Lp, P, blockIdx.x);
     double* x = c.sc + L.so_x;
+    DP_DECL;
     {   // outputs of this window start from zero in every run (status words, iteration trace, "new prior valid" flag)
         double* out = P.out + (size_t)blockIdx.x * L.ostride;
         int* iout = P.iout + (size_t)blockIdx.x * L.oi_stride;
@@ -419,8 +434,10 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
         if (c.tid == C_T0) v = (double)wall_clock64();
         c.sc[L.so_ctl + c.tid] = v;
     }
+    DP_ADD(40);
     if (L.imu_info) imu_sqrt_info_ref(c);
     else imu_sqrt_info(c);
+    DP_ADD(41);
     if (c.nprior) {
         // J0^T J0 once per solve, J0 staged in LDS
         const int n = c.nprior;
@@ -434,10 +451,12 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
         // J0 staged in LDS when it fits (host: lds_pro); the two loops are spelled out so that the staged one keeps its
         // LDS addressing (a pointer that may be either costs flat loads in the inner loop)
         __syncthreads();
+        DP_ADD(42);
         if ((size_t)n * n * 8 <= (size_t)L.lds_pro) {
             double* J0s = LDSB;                  // n x n, row stride n
             for (int wk = c.tid; wk < n * n; wk += BA_NT) J0s[wk] = J0[(wk / n) * L.pld + wk % n];
             __syncthreads();
+            DP_ADD(43);
             // J0^T J0 as X^T X on the matrix cores (round 4; it was n (n + 1) / 2 dot products of length n from LDS, two reads per
             // multiply-add): a wavefront owns lower 16 x 16 tiles (ta >= tb), A[i][k] = J0[4 s + k][16 ta + i] and B[k][j] =
             // J0[4 s + k][16 tb + j] come from the same staged rows
@@ -475,6 +494,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
             }
         }
     }
+    DP_ADD(44);
 }
 
 // ================================================================================================
@@ -1130,6 +1150,16 @@ extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(con
 #define LA_PAIR 90                // kept doubles of a pair block: ii 21 | jj 21 | ji 36 (row = target's column, col = anchor's) | gi 6 | gj 6
 // pairs (i, j), i < j, enumerated by distance d = j - i first: q = (d - 1) Kp - (d - 1) d / 2 + i.  The pairs of one distance -- and the
 // near-diagonal ones carry most factors -- are consecutive, so q mod LA_NPW deals them evenly to the pair wavefronts.
+// inclusive prefix sum over the 64 lanes of a wavefront: four row_shr steps inside the rows of sixteen, the row totals through SGPRs
+DEV int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1 (lanes without a source add 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    return v + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
+}
 DEV int la_pair_q(int i, int j, int Kp) { const int d = j - i; return (d - 1) * Kp - (d - 1) * d / 2 + i; }
 __device__ __forceinline__ void linacc_body(const BaLayout* __restrict__ Lp, const BaPtrs& P) {
     const BaLayout L = layout_load(Lp);
@@ -1218,33 +1248,57 @@ __device__ __forceinline__ void linacc_body(const BaLayout* __restrict__ Lp, con
         }
         for (int e = c.tid; e < (LA_NT / 64) * LA_QCAP; e += LA_NT) wcnt[e] = 0;
         __syncthreads();
+        DP_ADD(45);
         {
-            unsigned long long todo = __ballot(q >= 0);
-            const unsigned long long lt = (1ull << c.lane) - 1ull;
-            while (todo) {
-                const int q0 = __builtin_amdgcn_readlane(q, (int)__builtin_ctzll(todo));      // (v_readlane: the lane index is uniform)
-                const unsigned long long m = __ballot(q == q0);
-                if (q == q0) rank = __popcll(m & lt);
-                if (c.lane == (int)__builtin_ctzll(m)) wcnt[c.wave * LA_QCAP + q0] = __popcll(m);
-                todo &= ~m;
+            // the lanes of this wavefront with the same pair: seven ballots (one per bit of q < 128) instead of one trip per
+            // distinct pair (a wavefront's 64 factors touch 30-40 pairs: ~600 instructions, round 6: ~80)
+            const unsigned long long act = __ballot(q >= 0);
+            unsigned long long same = act;
+#pragma unroll
+            for (int b = 0; b < 7; ++b) {
+                const bool bit = q >= 0 && ((q >> b) & 1);
+                const unsigned long long mb = __ballot(bit);
+                same &= bit ? mb : ~mb;
             }
+            const unsigned long long lt = (1ull << c.lane) - 1ull;
+            rank = __popcll(same & lt);
+            if (q >= 0 && rank == 0) wcnt[c.wave * LA_QCAP + q] = __popcll(same);
         }
         __syncthreads();
-        if (c.tid < npair) {                                   // pair totals; the wavefront counts become offsets inside the pair
-            int run = 0;
-            for (int w = 0; w < LA_NT / 64; ++w) { const int v = wcnt[w * LA_QCAP + c.tid]; wcnt[w * LA_QCAP + c.tid] = run; run += v; }
-            pstart[c.tid + 1] = run;
+        // pair totals, pair starts and the wavefronts' offsets inside a pair, by wavefront 0 alone: lane p takes the pairs p and p + 64
+        // (all reads of a lane issued together, the running sum over the pairs on the DPP network).  It used to be a thread per pair
+        // walking the wavefront counts through LDS and then ONE thread adding up the pair totals: 55 dependent LDS round trips.
+        if (c.wave == 0) {
+            int cw0[LA_NT / 64], cw1[LA_NT / 64];
+            const int p0 = c.lane, p1 = c.lane + 64;
+#pragma unroll
+            for (int w = 0; w < LA_NT / 64; ++w) {
+                cw0[w] = p0 < npair ? wcnt[w * LA_QCAP + p0] : 0;
+                cw1[w] = p1 < npair ? wcnt[w * LA_QCAP + p1] : 0;
+            }
+            int t0 = 0, t1 = 0;
+#pragma unroll
+            for (int w = 0; w < LA_NT / 64; ++w) { const int a = cw0[w], b = cw1[w]; cw0[w] = t0; cw1[w] = t1; t0 += a; t1 += b; }
+            const int i0 = wave_scan_incl(t0);
+            const int tot0 = __builtin_amdgcn_readlane(i0, 63);
+            const int i1 = wave_scan_incl(t1) + tot0;
+            if (p0 < npair) {
+                pstart[p0 + 1] = i0;
+#pragma unroll
+                for (int w = 0; w < LA_NT / 64; ++w) wcnt[w * LA_QCAP + p0] = i0 - t0 + cw0[w];      // first record of (pair, wavefront)
+            }
+            if (p1 < npair) {
+                pstart[p1 + 1] = i1;
+#pragma unroll
+                for (int w = 0; w < LA_NT / 64; ++w) wcnt[w * LA_QCAP + p1] = i1 - t1 + cw1[w];
+            }
+            if (c.lane == 0) pstart[0] = 0;
         }
         __syncthreads();
-        if (c.tid == 0) {
-            int run = 0;
-            pstart[0] = 0;
-            for (int p = 0; p < npair; ++p) { run += pstart[p + 1]; pstart[p + 1] = run; }
-        }
-        __syncthreads();
+        DP_ADD(46);
         // ---- (2) linearise, record to its sorted place
         if (c.tid < nf) {
-            const int pos = pstart[q] + wcnt[c.wave * LA_QCAP + q] + rank;
+            const int pos = wcnt[c.wave * LA_QCAP + q] + rank;
             double r[2], Ji[12], Jj[12], Jl[2];
             proj_eval<false, true, false>(pin.pi, pin.pj, pin.ex, pin.lam, pin.oi, pin.oj, 0.0, c.focal, c.tr, c.row, r, Ji, Jj, nullptr, Jl, nullptr);
             const double s = r[0] * r[0] + r[1] * r[1];
