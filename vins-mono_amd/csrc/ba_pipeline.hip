@@ -522,7 +522,13 @@ NOINL double imu_pass(const Ctx& c_in, const double* x_, double* imuJ_, int fbeg
     const int half = c.lane >> 5, hl = c.lane & 31;
     for (int f0 = fbeg; f0 < nimu; f0 += nb) {
         const int nf = nimu - f0 < nb ? nimu - f0 : nb;
-        for (int k = c.tid; k < nf * 225; k += BA_NT) Us[k] = gU[f0 * 225 + k];
+        for (int k0 = c.tid; k0 < nf * 225; k0 += 8 * BA_NT) {      // (the loads of a thread issued together, then the LDS stores)
+            double uv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = k0 + u * BA_NT; uv[u] = k < nf * 225 ? gU[f0 * 225 + k] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = k0 + u * BA_NT; if (k < nf * 225) Us[k] = uv[u]; }
+        }
         __syncthreads();
         const int fl = c.wave * per + half;                 // factor of this (half-)wavefront inside the pass
         const int f = f0 + fl;
