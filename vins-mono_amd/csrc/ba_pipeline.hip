@@ -644,11 +644,20 @@ NOINL double prior_pass(const Ctx& c_in, const double* x, double* pr_, double* g
     const glb_d* r0 = AS_GLB_C(c.pri + L.po_r0);
     double cost = 0.0;
     // r = r0 + J0 dx, the n-term dot product of every row split over 4 threads (host guarantees 4 Ncap <= BA_NT)
+    // (round 6: the loads of a partial sum are requested TOGETHER, sixteen at a time, from clamped addresses -- the loop over k waited
+    //  for every J0 entry before it asked for the next: 19 dependent HBM round trips per product, most of the cost-only launch and
+    //  of a spread round of a single window.  Terms beyond n enter as exact zeros: the same sums.)
     for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
         const int r = w % L.Ncap, q = w / L.Ncap;
+        const int rc = r < n ? r : 0;
         double s = 0.0;
-        if (r < n)
-            for (int k = q; k < n; k += 4) s += J0t[k * L.Ncap + r] * dx[k];
+        for (int k0 = q; k0 < n; k0 += 64) {
+            double jv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int k = k0 + 4 * u; jv[u] = J0t[(k < n ? k : q) * L.Ncap + rc]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int k = k0 + 4 * u; s += ((r < n && k < n) ? jv[u] : 0.0) * dx[k < n ? k : q]; }
+        }
         part[w] = s;
     }
     __syncthreads();
@@ -666,9 +675,15 @@ NOINL double prior_pass(const Ctx& c_in, const double* x, double* pr_, double* g
         const glb_d* J0 = AS_GLB_C(c.pri + L.po_J0);   // row-major: J0[r*pld + c] coalesced over c
         for (int w = c.tid; w < 4 * L.Ncap; w += BA_NT) {
             const int a = w % L.Ncap, q = w / L.Ncap;
+            const int ac = a < n ? a : 0;
             double s = 0.0;
-            if (a < n)
-                for (int k = q; k < n; k += 4) s += J0[k * L.pld + a] * rl[k];
+            for (int k0 = q; k0 < n; k0 += 64) {
+                double jv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int k = k0 + 4 * u; jv[u] = J0[(k < n ? k : q) * L.pld + ac]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int k = k0 + 4 * u; s += ((a < n && k < n) ? jv[u] : 0.0) * rl[k < n ? k : q]; }
+            }
             part[w] = s;
         }
         __syncthreads();
