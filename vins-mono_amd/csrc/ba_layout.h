@@ -45,6 +45,7 @@ enum {
     // speed-bias shares of |gn|^2, gt.gn, |x - x_cand|^2, |x_cand|^2 (the landmark shares travel through the reduce buffers)
     C_PHASE, C_GNN2C, C_GTGNC, C_STEP2C, C_XN2C,
     C_T0,                          // device wall clock at the start of the solve (vg_ba_problem::max_solver_time_s)
+    C_TIMEDOUT,                    // large-window path: the time test of the round's first half, for its second half
     C_NCTL = 32
 };
 
@@ -124,6 +125,7 @@ struct BaLayout {
     int big;
     int so_bigm;                              // HBM home of XC / D / E / dinv / vec / wd / z / pmap
     int l_di, l_cz;                           // LDS offsets of the 1/L_jj vector and of the chain elimination's scratch (big path)
+    int l_Sg;                                 // big path: the reduced system between the two halves of ba_solve_big_kernel (HBM, offset into so_bigm)
     int so_dgl, so_gtl;                       // landmark Dg, gt per linearisation buffer (2 x Lcap each)
     int rb1_len, rb1_T, rb1_scal;             // reduce buffer 1: doubles per window, offsets of T and of the scalars
     int nts;                                  // lower 16x16 tiles of T = workgroups of the Schur kernel (+ 1 landmark workgroup)

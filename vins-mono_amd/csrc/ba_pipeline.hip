@@ -3233,66 +3233,6 @@ extern "C" __global__ __launch_bounds__(256) void ba_big_schur_kernel(const BaLa
     }
 }
 
-// S -= X^T X over the 9K chain rows (XC in HBM, rhs in column Rc -> augmented row Rc of S) and S -= diag(sc) T diag(sc)
-// (the rank-summed landmark Schur complement; row Rc: rhs).  v_mfma_f64_16x16x4; a wavefront task = tile row tm x up to four
-// column tiles (the A operand is shared), two k-steps per trip so that ten 128-byte row loads are in flight per wavefront:
-// the operands come from L2, the loop is a chain of round trips, not of flops.  XC has up(9K, 8) rows (zero padded).
-NOINL void schur_chain_big(const Ctx& c_in, const SolveLds& m_in, const double* T_) {
-    PHASE_ENTER(true);
-    const glb_d* sc = AS_GLB_C(m.vec + V_SC * L.Rpad);
-    const glb_d* T = AS_GLB_C(T_);
-    const glb_d* XC = AS_GLB_C(m.XC);
-    lds_d* S = AS_LDS(m.S);
-    const int Rc = L.Rc, ldc = m.ldc;
-    const int nt = L.RcPad / 16;
-    const int nk2 = (9 * L.K + 7) / 8;             // trips of two k-steps (4 rows each)
-    int ntask = 0;
-    for (int tm = 0; tm < nt; ++tm) ntask += (tm + 4) / 4;
-    __syncthreads();
-    for (int task = c.wave; task < ntask; task += BA_NW) {
-        int tm = 0, base = 0;
-        while (base + (tm + 4) / 4 <= task) { base += (tm + 4) / 4; ++tm; }
-        const int tn0 = 4 * (task - base);
-        const int nc = (tm + 1 - tn0) < 4 ? (tm + 1 - tn0) : 4;
-        double4_t acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0, 0, 0, 0};
-        const glb_d* xr = XC + (size_t)(c.lane >> 4) * ldc + (c.lane & 15);
-        for (int k2 = 0; k2 < nk2; ++k2) {
-            const glb_d* r0 = xr + (size_t)k2 * 8 * ldc;
-            const glb_d* r1 = r0 + (size_t)4 * ldc;
-            const double a0 = r0[tm * 16], a1 = r1[tm * 16];
-            double b0[4], b1[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                b0[q] = q < nc ? r0[(tn0 + q) * 16] : 0.0;
-                b1[q] = q < nc ? r1[(tn0 + q) * 16] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < nc) {
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[q], acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[q], acc[q], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q < nc) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int row = tm * 16 + (c.lane >> 4) + 4 * reg, col = (tn0 + q) * 16 + (c.lane & 15);
-                    if (row <= Rc && col <= row && col < Rc) {
-                        const double sr = row < Rc ? sc[row] : 1.0;
-                        S[tri(row, col)] -= acc[q][reg] + sr * sc[col] * T[tri(row, col)];
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-
 // The chain elimination of the large-window path, where XC lives in HBM: the same elimination from both ends as chain_schur (storage
 // conventions afterwards, so schur_chain_big / chain_back_substitute do not care), organised so that every element of XC is
 // loaded once and stored once.  Thread `id` of the first / second half of the workgroup owns column id of [C_k | g_k] for
@@ -3474,6 +3414,56 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
     return ok;
 }
 
+// The Schur update of the large-window path on many CUs (round 6; between the two launches of ba_solve_big_kernel, which hands S over
+// in HBM): S -= X^T X over the 9K eliminated chain rows (XC, HBM / L2) and S -= diag(sc) T diag(sc).  grid (lower 16 x 16 tiles,
+// windows), ONE wavefront per tile: it walks the rows in the order the single-workgroup form of rounds 2-5 did (schur_chain_big: two k-steps of
+// four rows per trip, trips in ascending order), so the sums are the same; eight trips' operands are requested together.
+extern "C" __global__ __launch_bounds__(64) void ba_big_chain_schur_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+    const BaLayout& L = *Lp;
+    Ctx c;
+    const int w = blockIdx.y;
+    ctx_init(c, Lp, P, w);
+    const double* ctl = c.sc + L.so_ctl;
+    if (ctl[C_DONE] != 0.0 || (int)ctl[C_PHASE] != 4) return;
+    int tm, tn;
+    tri_decode(blockIdx.x, tm, tn);
+    const int Rc = L.Rc, ldc = L.ldc;
+    const glb_d* XC = AS_GLB_C(c.sc + L.so_bigm + L.l_XC);
+    const glb_d* sc = AS_GLB_C(c.sc + L.so_bigm + L.l_vec + V_SC * L.Rpad);
+    const glb_d* T = AS_GLB_C(P.rb1 + (size_t)w * L.rb1_len + L.rb1_T);
+    glb_d* Sg = AS_GLB(c.sc + L.so_bigm + L.l_Sg);
+    const int nk2 = (9 * L.K + 7) / 8;             // trips of two k-steps (4 rows each); XC has up(9K, 8) rows (zero padded)
+    const int lane = threadIdx.x;
+    const glb_d* xr = XC + (size_t)(lane >> 4) * ldc + (lane & 15);
+    double4_t acc = (double4_t){0, 0, 0, 0};
+    for (int k0 = 0; k0 < nk2; k0 += 8) {
+        double a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k2 = k0 + u < nk2 ? k0 + u : nk2 - 1;
+            const glb_d* r0 = xr + (size_t)k2 * 8 * ldc;
+            const glb_d* r1 = r0 + (size_t)4 * ldc;
+            a0[u] = r0[tm * 16]; a1[u] = r1[tm * 16];
+            b0[u] = r0[tn * 16]; b1[u] = r1[tn * 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (k0 + u < nk2) {                     // (uniform)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = tm * 16 + (lane >> 4) + 4 * reg, col = tn * 16 + (lane & 15);
+        if (row <= Rc && col <= row && col < Rc) {
+            const double sr = row < Rc ? sc[row] : 1.0;
+            Sg[tri(row, col)] -= acc[reg] + sr * sc[col] * T[tri(row, col)];
+        }
+    }
+}
+
 // back substitution L^T y = (row R of S) for R <= 64 NR, one wavefront, lane owns entries lane + 64 q of the running rhs
 template <int NR>
 NOINL void back_substitute_n(const Ctx& c_in, const SolveLds& m_in, int R) {
@@ -3537,7 +3527,16 @@ DEV void big_solve_failed(Ctl& s, const BaLayout& L, double* out, int* iout, int
 }
 
 // 1 workgroup / window, BA_NT threads, LDS: S (packed, rhs row), reduction scratch, 1/L_jj.
-extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
+// Round 6: the kernel runs as TWO launches per round (ba_solve_big_kernel = stage 0, ba_solve_big_tail_kernel = stage 1) with
+// ba_big_chain_schur_kernel between them.  Stage 0 ends behind the
+// chain elimination: the reduced system leaves LDS for HBM (l_Sg) and the control block says "phase 4: Schur update pending";
+// the update S -= X^T X + sc T sc then runs one wavefront per 16 x 16 tile on as many CUs as there are tiles (it was 222K of this
+// kernel's 954K cycles per round: 40 wavefront tasks of 35 L2 round trips each on ONE CU, bound by that CU's L1 bandwidth);
+// stage 1 reloads S and continues with the Cholesky factorisation.  A round that solves nothing (step reuse, failed damping,
+// finished window) ends in stage 0 as before and stage 1 returns at its first branch.  Same operations in the same order.
+// (two kernels with the SAME explicit arguments: the phase functions find them at a fixed distance in front of the hidden ones)
+template <int stage>
+__device__ __forceinline__ void solve_big_body(const BaLayout* __restrict__ Lp, const BaPtrs& P) {
     const BaLayout L = layout_load(Lp);
     Ctx c;
     const int w = blockIdx.x;
@@ -3547,6 +3546,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     Ctl s;
     ctl_load(s, ctlp);
     if (s.done) return;
+    if (stage == 1 && s.phase != 4) return;          // (uniform) nothing was handed over by stage 0
     SolveLds m;
     big_carve(L, c.sc, m);
     const int max_iters = c.hdr[H_MAXIT];
@@ -3567,7 +3567,21 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     double* gnl = c.sc + L.so_gn + L.Rpad;
     double* yl = c.sc + L.so_yl;
     PROF_DECL;
-    if (c.nprior) {
+    const bool resume = stage == 1;                  // (uniform) second half of a round whose first half built and eliminated
+    glb_d* Sg = AS_GLB(c.sc + L.so_bigm + L.l_Sg);
+    const int nS = (Rc + 1) * (Rc + 2) / 2;
+    if (resume) {
+        // the reduced system after ba_big_chain_schur_kernel, back into LDS (the loads of a thread requested together)
+        for (int k0 = c.tid; k0 < nS; k0 += 8 * BA_NT) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = k0 + u * BA_NT; v[u] = k < nS ? Sg[k] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = k0 + u * BA_NT; if (k < nS) m.S[k] = v[u]; }
+        }
+        s.phase = 0;
+    }
+    if (!resume && c.nprior) {
         const int* kind = c.ia + L.io_pb_kind;
         const int* off = c.ia + L.io_pb_off;
         const int* pcol = c.ia + L.io_pb_col;
@@ -3577,13 +3591,14 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
         }
     }
     __syncthreads();
-    const int phase_in = s.phase;
-    s.phase = 0;
+    const int phase_in = resume ? 0 : s.phase;
+    if (!resume) s.phase = 0;
     // cost of the point the linearisation kernels just evaluated: projection factors of all ranks + this rank's copy of the
     // (replicated) IMU / prior factors
     const double cs = scal[RB1_COST] + sum_partials(c.sc + L.so_part + L.nbf, L.nig + L.nprw);
     bool fresh_point = false;
-    if (s.pending) {
+    if (resume) {
+    } else if (s.pending) {
         s.step_norm = sqrt(s.step2c + scal[RB1_STEP2]);
         s.x_norm_c = sqrt(s.xn2c + scal[RB1_LAM2]);
         const bool acc = judge_candidate(s, cs, L, out, iout, c.tid);
@@ -3604,9 +3619,10 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     const double* hh = buf + L.bo_h;
     const double* bb = buf + L.bo_b;
     const bool running = s.term == VG_TERM_NO_CONVERGENCE && s.status == VG_OK;
-    const bool timed_out = time_is_up(ctlp, c.di[L.do_par + P_MAXTIME], m.red + 30, c.tid);
-    const bool trip = running && !timed_out && (phase_in == 3 || s.it < max_iters);
-    const bool need_system = running && (fresh_point || (trip && !s.reuse));
+    // (stage 1 takes the time test of stage 0: one decision per round)
+    const bool timed_out = resume ? uni(ctlp[C_TIMEDOUT]) != 0.0 : time_is_up(ctlp, c.di[L.do_par + P_MAXTIME], m.red + 30, c.tid);
+    const bool trip = resume || (running && !timed_out && (phase_in == 3 || s.it < max_iters));
+    const bool need_system = !resume && running && (fresh_point || (trip && !s.reuse));
     if (need_system) {
         const int ntri = Rc * (Rc + 1) / 2;
         assemble_big(c, m, buf, rb1, rb1 + ntri);
@@ -3625,10 +3641,12 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     __syncthreads();
     PROF_ADD(PF_ASM);
     if (trip && s.term == VG_TERM_NO_CONVERGENCE) {
-        if (phase_in != 3) ++s.it;
-        if (s.reuse) s.phase = 2;
-        else if (!(s.mu < 1.0)) big_solve_failed(s, L, out, iout, c.tid, false);
+        if (!resume && phase_in != 3) ++s.it;
+        if (!resume && s.reuse) s.phase = 2;
+        else if (!resume && !(s.mu < 1.0)) big_solve_failed(s, L, out, iout, c.tid, false);
         else {
+            bool cok = true;
+            if (!resume) {
             const double* dgl = c.sc + L.so_dgl + s.cur * L.Lcap;
             const double* gtl = c.sc + L.so_gtl + s.cur * L.Lcap;
             for (int k = c.tid; k < R; k += BA_NT) {
@@ -3650,10 +3668,18 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
             const double q = build_scaled<true>(c, m, s.mu);
             __syncthreads();
             PROF_ADD(PF_BUILD);
-            bool cok = chain_eliminate_big(c, m, LDSB + L.l_cz);
+            cok = chain_eliminate_big(c, m, LDSB + L.l_cz);
             PROF_ADD(PF_CHAIN);
-            schur_chain_big(c, m, rb1 + L.rb1_T);
             s.qcam = block_sum(m.red, BA_NW, c.lane, c.wave, q);
+            if (cok) {
+                // ---- hand-over: S to HBM, "phase 4", the round continues in ba_big_chain_schur_kernel and in stage 1
+                for (int k = c.tid; k < nS; k += BA_NT) Sg[k] = m.S[k];
+                s.phase = 4;
+                __syncthreads();
+                if (c.tid == 0) { ctl_store(s, ctlp); ctlp[C_TIMEDOUT] = timed_out ? 1.0 : 0.0; }
+                return;
+            }
+            }   // !resume
             PROF_ADD(PF_SCHUR);
             if (cok) cok = cholesky_aug(c, m, Rc);
             PROF_ADD(PF_CHOL);
@@ -3692,6 +3718,8 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const Ba
     __syncthreads();
     if (c.tid == 0) ctl_store(s, ctlp);
 }
+extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { solve_big_body<0>(Lp, P); }
+extern "C" __global__ __launch_bounds__(BA_NT) void ba_solve_big_tail_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { solve_big_body<1>(Lp, P); }
 
 // Landmark part of the Gauss-Newton step (this rank's landmarks): y_l = (bt_l - wt_l . y_cam) / ht_l, and their shares of
 // |gn|^2, gt.gn and the Cauchy-point term  sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ]  (t = gt / Dg).  grid
@@ -4025,6 +4053,7 @@ static hipError_t set_lds_attrs() {
     if (dev >= 0 && dev < 64 && ((done_mask >> dev) & 1ull)) return hipSuccess;
     e = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_big_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_linacc_proj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     // (these two also hold a few statically allocated LDS words: static + dynamic must stay within 160 KB)
@@ -4147,6 +4176,8 @@ extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL,
         REDUCE(P.rb1, n1);
         if (cost_only) break;
         LAUNCH(ba_solve_big_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P); KIND(7);
+        { const int nt16 = L.RcPad / 16; LAUNCH(ba_big_chain_schur_kernel, dim3(nt16 * (nt16 + 1) / 2, L.nwin), dim3(64), 0, dL, P); KIND(7 | 0x100); }
+        LAUNCH(ba_solve_big_tail_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_solve, dL, P); KIND(7 | 0x100);
         LAUNCH(ba_big_landmark_kernel, dim3(BA_BIG_LM_BLOCKS, L.nwin), dim3(256), 0, dL, P); KIND(8);
         REDUCE(P.rb2, n2);
         LAUNCH(ba_big_step_kernel, dim3(L.nwin), dim3(BA_NT), 0, dL, P); KIND(8);
