@@ -1573,7 +1573,14 @@ NOINL void assemble_big(const Ctx& c_in, const SolveLds& m_in, const double* buf
     MV* g = q.vec + V_G * L.Rpad;
     __syncthreads();
     // (XC / D / E live in HBM and were cleared by the Schur kernel's extra workgroups)
-    for (int k = c.tid; k < camtri; k += BA_NT) q.S[k] = Sp[k];
+    // (a copy loop HBM -> LDS waits for every load before its store: eight loads of a thread are requested together, round 6)
+    for (int k0 = c.tid; k0 < camtri; k0 += 8 * BA_NT) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + u * BA_NT; v[u] = Sp[k < camtri ? k : 0]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + u * BA_NT; if (k < camtri) q.S[k] = v[u]; }
+    }
     for (int k = c.tid; k < L.Rpad; k += BA_NT) g[k] = k < Rc ? gp[k] : 0.0;
     __syncthreads();
     // ---- IMU Hessian blocks: factors k and k+1 share the blocks of frame k+1, so even and odd factors are added in two
@@ -1802,6 +1809,35 @@ NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_in, double mu) {
     const int Rc = L.Rc, K = L.K, ldc = mq.ldc;
     const int n = Rc * (Rc + 1) / 2;
     double q = 0.0;
+    if constexpr (BIG) {
+        // large-window path: the vectors live in HBM and every entry of S gathers four of their elements -- the camera parts of the
+        // scaling and of t are staged in the chain elimination's LDS scratch first (free here: 2 Rc <= 576 checked by the layout), so
+        // the 18.7K entries of a 193-wide system read LDS instead of walking 37 dependent HBM round trips per thread
+        lds_d* scs = AS_LDS(LDSB + L.l_cz);
+        lds_d* tvs = scs + Rc;
+        if (2 * Rc <= 6 * 96) {
+            __syncthreads();
+            for (int k = c.tid; k < Rc; k += NT) { scs[k] = sc[k]; tvs[k] = tv[k]; }
+            __syncthreads();
+            for (int w = c.tid; w < n; w += NT) {
+                int a, b;
+                tri_decode(w, a, b);
+                double v = mq.S[w] * scs[a] * scs[b];
+                q += v * tvs[a] * tvs[b] * (a == b ? 1.0 : 2.0);
+                if (a == b) v += mu * dg[a] * dg[a];
+                mq.S[w] = v;
+            }
+        } else {
+            for (int w = c.tid; w < n; w += NT) {
+                int a, b;
+                tri_decode(w, a, b);
+                double v = mq.S[w] * sc[a] * sc[b];
+                q += v * tv[a] * tv[b] * (a == b ? 1.0 : 2.0);
+                if (a == b) v += mu * dg[a] * dg[a];
+                mq.S[w] = v;
+            }
+        }
+    } else {
     for (int w = c.tid; w < n; w += NT) {
         int a, b;
         tri_decode(w, a, b);
@@ -1809,6 +1845,7 @@ NOINL double build_scaled(const Ctx& c_in, const SolveLds& m_in, double mu) {
         q += v * tv[a] * tv[b] * (a == b ? 1.0 : 2.0);
         if (a == b) v += mu * dg[a] * dg[a];
         mq.S[w] = v;
+    }
     }
     for (int k = c.tid; k < Rc; k += NT) mq.S[tri(Rc, k)] = sc[k] * g[k];
     if (c.tid == 0) mq.S[tri(Rc, Rc)] = 0.0;
@@ -2686,11 +2723,19 @@ NOINL void chain_back_substitute(const Ctx& c_in, const SolveLds& m_in) {
         constexpr int NT = BIG ? BA_NT : SV_NT;
         const glb_d* XR = BIG ? AS_GLB_C(m_.XC) : AS_GLB_C(m_.xp);
         const int nrow = 9 * K;
+        // (round 6: sixteen entries of a row requested together from clamped addresses -- the loop over j waited for every entry of the
+        //  parked row before it asked for the next one; entries beyond Rc enter as exact zeros: the same sums)
         for (int w = c.tid; w < 4 * nrow; w += NT) {
             const int row = w >> 2, q = w & 3;
             const glb_d* xr = XR + (size_t)row * ldc;
             double s = 0.0;
-            for (int j = q; j < Rc; j += 4) s += xr[j] * y[j];
+            for (int j0 = q; j0 < Rc; j0 += 64) {
+                double xv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int j = j0 + 4 * u; xv[u] = xr[j < Rc ? j : q]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int j = j0 + 4 * u; s += (j < Rc ? xv[u] : 0.0) * y[j < Rc ? j : q]; }
+            }
             z[w] = s;
         }
         __syncthreads();
@@ -3270,6 +3315,22 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
         const lds_d* XeP = XeB + 96 * ((kt + 1) & 1);          // coupling block of the upper neighbour kt + 1
         const lds_d* XuM = XuB + 96 * (kt & 1);                // (last step) slot E_mid, solved by the bottom block mid - 1
         const lds_d* XuP = XuB + 96 * (kb & 1);                // slot E_kb, solved by the bottom block kb - 1
+        // ---- (round 6) what this step reads from HBM is requested BEFORE the diagonal blocks are factored: a thread's column of
+        //      [C_k | g_k] (or its column / row of the coupling block), the two lanes' entries of D_k -- none of it depends on the step's
+        //      own results, and the round trip used to start behind the barrier of (A)
+        double xq[9], dq0 = 0.0, dq1 = 0.0;
+        {
+            const bool colT = half == 0 && has_t && id <= Rc, colB = half == 1 && has_b && id <= Rc;
+            const bool eT = half == 0 && has_t && !last && id > Rc && id < Rc + 10, eB = half == 1 && has_b && id > Rc && id < Rc + 10;
+            const int cc = id - Rc - 1;
+            const glb_d* src = colT ? XC + (size_t)9 * kt * ldc + id : (colB ? XC + (size_t)9 * kb * ldc + id
+                               : (eT ? E + 81 * kt + cc : (eB ? E + 81 * (kb + 1) + 9 * cc : XC)));
+            const size_t st = (colT || colB) ? (size_t)ldc : (eT ? 9 : (eB ? 1 : 0));
+#pragma unroll
+            for (int r = 0; r < 9; ++r) xq[r] = src[(size_t)r * st];
+            if (c.wave == 0 && has_t) { dq0 = D[81 * kt + c.lane]; dq1 = D[81 * kt + (c.lane + 64 < 81 ? c.lane + 64 : 0)]; }
+            else if (c.wave == 4 && has_b) { dq0 = D[81 * kb + c.lane]; dq1 = D[81 * kb + (c.lane + 64 < 81 ? c.lane + 64 : 0)]; }
+        }
         // ---- (A) diagonal blocks: update + 9x9 Cholesky in LDS, factor back to HBM for the back substitution
         if (c.wave == 0 && has_t) {
             for (int e = c.lane; e < 81; e += 64) {
@@ -3283,7 +3344,7 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
 #pragma unroll
                     for (int p = 0; p < 9; ++p) s += XuM[9 * r + p] * XuM[9 * cc + p];
                 }
-                Lt[e] = D[81 * kt + e] - s;
+                Lt[e] = (e < 64 ? dq0 : dq1) - s;
             }
             __builtin_amdgcn_wave_barrier();
             if (!chain_factor(c.lane, Lt, dit, 0, (const lds_d*)nullptr, (const lds_d*)nullptr) && c.lane == 0) *flag = 0;
@@ -3298,7 +3359,7 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
 #pragma unroll
                     for (int p = 0; p < 9; ++p) s += XuP[9 * r + p] * XuP[9 * cc + p];
                 }
-                Lb[e] = D[81 * kb + e] - s;
+                Lb[e] = (e < 64 ? dq0 : dq1) - s;
             }
             __builtin_amdgcn_wave_barrier();
             if (!chain_factor(c.lane, Lb, dib, 0, (const lds_d*)nullptr, (const lds_d*)nullptr) && c.lane == 0) *flag = 0;
@@ -3314,7 +3375,7 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
                 glb_d* col = XC + (size_t)9 * kt * ldc + id;
                 double x[9];
 #pragma unroll
-                for (int r = 0; r < 9; ++r) x[r] = col[(size_t)r * ldc];
+                for (int r = 0; r < 9; ++r) x[r] = xq[r];
                 if (upd_t_from_above) {
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
@@ -3353,7 +3414,7 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
                 lds_d* xe = XeB + 96 * (kt & 1) + cc;
                 double x[9];
 #pragma unroll
-                for (int r = 0; r < 9; ++r) x[r] = e[9 * r];
+                for (int r = 0; r < 9; ++r) x[r] = xq[r];
 #pragma unroll
                 for (int r = 0; r < 9; ++r) {
                     double s = x[r];
@@ -3369,7 +3430,7 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
                 glb_d* col = XC + (size_t)9 * kb * ldc + id;
                 double x[9];
 #pragma unroll
-                for (int r = 0; r < 9; ++r) x[r] = col[(size_t)r * ldc];
+                for (int r = 0; r < 9; ++r) x[r] = xq[r];
                 if (upd_b) {
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
@@ -3395,7 +3456,7 @@ NOINL bool chain_eliminate_big(const Ctx& c_in, const SolveLds& m_in, double* cz
                 lds_d* xu = XuB + 96 * ((kb + 1) & 1) + 9 * cc;
                 double x[9];
 #pragma unroll
-                for (int r = 0; r < 9; ++r) x[r] = e[r];
+                for (int r = 0; r < 9; ++r) x[r] = xq[r];
 #pragma unroll
                 for (int r = 0; r < 9; ++r) {
                     double s = x[r];
