@@ -294,13 +294,15 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
             const int npair = L.Kp * (L.Kp - 1) / 2;
             // (the per-round kernel reports 8 KB of fixed group segment -- its non-inlined phases -- next to the dynamic LDS: 160 KB in all)
             const int avail = (160 * 1024 - 8192 - 512) / 8;
-            int chf = (int)((avail - npair * 90 - 34 - (64 + 82 + 8 * 80) / 2) / 34.0);      // per factor: record 33 doubles + key + position (2 ints)
+            const int nstl = up(7 * L.Kp + 9 * L.K + 8, 2);                                   // the staged state (round 6)
+            int chf = (int)((avail - nstl - npair * 90 - 34 - (64 + 82 + 8 * 80) / 2) / 34.0);      // per factor: record 33 doubles + key + position (2 ints)
             chf = std::min(chf & ~1, 512);
             L.la_on = (!off && L.nwin >= la_min_windows && !L.big && !L.e && !L.t && L.Kp <= 13 && chf >= 96 && (L.Fcap + chf - 17) / (chf - 16) <= 62) ? 1 : 0;
             L.la_chf = chf; L.la_chq = chf - 16;
             L.la_P = up(chf * 33, 2);
             L.la_key = L.la_P + up(npair * 90, 2);
-            L.lds_linacc = (L.la_key + (2 * chf + 64 + 82 + 8 * 80 + 1) / 2 + 2) * 8;
+            L.la_x = up(L.la_key + (2 * chf + 64 + 82 + 8 * 80 + 1) / 2 + 2, 2);
+            L.lds_linacc = (L.la_x + nstl) * 8;
         }
     }
     if (L.big) {

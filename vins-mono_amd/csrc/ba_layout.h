@@ -118,7 +118,7 @@ struct BaLayout {
     int lds_lin, lds_pro;                     // dynamic LDS bytes of the linearisation / prologue kernels
     // ---- fused projection kernel (ba_linacc_proj_kernel): eligible windows (la_on), landmarks per chunk by first factor index
     //      (la_chq), staged-record capacity (la_chf = la_chq + 16), LDS offsets (doubles) of the pair blocks and of the key table
-    int la_on, la_chq, la_chf, la_P, la_key, lds_linacc;
+    int la_on, la_chq, la_chf, la_P, la_key, la_x, lds_linacc;      // (la_x: the state of the linearisation point, staged once per launch)
     // ---- large-window path (big != 0): the camera part does not fit the LDS carve above.  S stays in LDS (packed, with
     //      the rhs row), everything else of the carve lives in HBM scratch at so_bigm (the l_* offsets are then relative to
     //      it); the landmark Schur complement is formed by a multi-workgroup kernel into reduce buffer 1.

@@ -799,6 +799,27 @@ DEV void proj_fetch(const Ctx& c, int f, const double* x_, const double* lam_, P
     }
     p.lam = AS_GLB_C(lam_)[p.l];
 }
+// the same with the state read from an LDS copy (fused factor kernel, round 6: the poses and the extrinsic pose were 22 of a factor's 39
+// global loads, and a CU's L1 moves 64 B per cycle; the observations and the inverse depth still come from HBM)
+DEV void proj_fetch_staged(const Ctx& c, int f, const lds_d* xs, const double* lam_, ProjIn& p) {
+    const BaLayout& L = *c.Lp;
+    const glb_i* ia = AS_GLB_CI(c.ia);
+    const glb_d* obs = AS_GLB_C(c.di + L.do_obs);
+    p.i = ia[L.io_fac_i + f];
+    p.j = ia[L.io_fac_j + f];
+    p.l = ia[L.io_fac_lm + f];
+    const int oi = ia[L.io_fac_oi + f], oj = ia[L.io_fac_oj + f];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        p.oi[k] = obs[oi * BA_OBS_STRIDE + k];
+        p.oj[k] = obs[oj * BA_OBS_STRIDE + k];
+    }
+    p.lam = AS_GLB_C(lam_)[p.l];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { p.pi[k] = xs[7 * p.i + k]; p.pj[k] = xs[7 * p.j + k]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p.ex[k] = xs[7 * L.Kp + 9 * L.K + k];
+}
 DEV void proj_jac(const Ctx& c, const ProjIn& p, double* r, double* Ji, double* Jj, double* Jex,
                   double* Jl, double* Jtd) {
     const BaLayout& L = *c.Lp;
@@ -1222,6 +1243,8 @@ __device__ __forceinline__ void linacc_body(const BaLayout* __restrict__ Lp, con
         __syncthreads();
         DP_ADD(22);
     }
+    lds_d* xs = AS_LDS(LDSB + L.la_x);
+    for (int k = c.tid; k < 7 * L.Kp + 9 * L.K + 8; k += LA_NT) xs[k] = AS_GLB_C(x)[k];
     const int nchunk = nL > 0 ? uni(ia[L.io_lm_fbeg + nL - 1] / chq + 1) : 0;     // (the LAST landmark's chunk: a chunk is never empty, landmarks have <= Kp - 1 factors)
     // first landmark of every chunk
     for (int t = c.tid; t < nL; t += LA_NT) {
@@ -1264,7 +1287,7 @@ __device__ __forceinline__ void linacc_body(const BaLayout* __restrict__ Lp, con
         ProjIn pin;
         int q = -1, rank = 0;
         if (c.tid < nf) {
-            proj_fetch(c, f0 + c.tid, x, lam, pin);
+            proj_fetch_staged(c, f0 + c.tid, xs, lam, pin);
             q = la_pair_q(pin.i, pin.j, Kp);
         }
         for (int e = c.tid; e < (LA_NT / 64) * LA_QCAP; e += LA_NT) wcnt[e] = 0;
