@@ -41,7 +41,11 @@ def test_bench_line_has_the_contract_shape():
     hb = d["host_boundary_inclusive"]
     assert hb["resident_sequence_solves_per_s"] and "error" not in hb["resident_sequence"], hb["resident_sequence"]
     fe = d["fe"]
-    assert fe["unit"] == "features/s" and fe["roofline"]["bound"] == "hbm" and fe["roofline"]["unit"] == "GB/s" and fe["tracked_last_step"] > 0
+    # (the front end is booked against the roof its SQ counters name -- VALU issue -- when profiles/pmc_latest.json was collected on the
+    #  device code of this tree, against HBM as SURVEY 8(d) says otherwise; the HBM figure stays as a side value either way)
+    rf_fe = fe["roofline"]
+    assert fe["unit"] == "features/s" and fe["tracked_last_step"] > 0
+    assert (rf_fe["bound"] == "hbm" and rf_fe["unit"] == "GB/s") or (rf_fe["bound"] == "valu" and rf_fe["hbm"]["unit"] == "GB/s" and 0 < rf_fe["frac"])
     assert d["single_window"]["solve_pipeline_ms"] > 0 and d["single_window_latency_ms"] > 0
 
 
