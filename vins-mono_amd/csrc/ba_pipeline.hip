@@ -1189,6 +1189,7 @@ extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(con
 #define LA_NPW 6                  // wavefronts that own pair blocks; the other two of the workgroup take the landmark sums
 #define LA_MAXP 13                // pairs per pair wavefront: Kp (Kp - 1) / 2 <= 78 for Kp <= 13
 #define LA_QCAP 80                // pairs a window can have (78 for Kp = 13), padded
+static_assert(LA_QCAP <= 128, "the pair prefix of ba_linacc_proj_kernel takes two pairs per lane of one wavefront");
 #define LA_PAIR 90                // kept doubles of a pair block: ii 21 | jj 21 | ji 36 (row = target's column, col = anchor's) | gi 6 | gj 6
 // pairs (i, j), i < j, enumerated by distance d = j - i first: q = (d - 1) Kp - (d - 1) d / 2 + i.  The pairs of one distance -- and the
 // near-diagonal ones carry most factors -- are consecutive, so q mod LA_NPW deals them evenly to the pair wavefronts.
