@@ -38,15 +38,43 @@ extern "C" __global__ __launch_bounds__(256) void fe_clahe_lut_kernel(FeDev d, i
     const uint8_t* src = d.raw + (size_t)cam * d.W * d.H;
     hist[threadIdx.x] = 0;
     __syncthreads();
-    // thread = (tile row, quarter of the row): no division per pixel, all loads of a thread independent of each other; two pixels per
-    // load where the tile width is even (a tile row then starts on an even byte: W % 8 == 0)
+    // thread = (tile row, quarter of the row): no division per pixel.  Round 6: the quarter row (<= 32 bytes for tiles up to 128 wide)
+    // is REQUESTED in one batch -- eight dwords from a 2-byte aligned address, clamped to the row -- before the first histogram
+    // update; the loop "load two pixels, add them" waited for every load (twelve dependent HBM round trips per thread: most of the
+    // kernel).  Wider tiles keep the loop.
     {
         const glb_u8* tsrc = (const glb_u8*)src + (size_t)(ty * th) * d.W + tx * tw;
         const int seg = threadIdx.x & 3, qw = (tw + 3) >> 2;                 // columns [seg * qw, min(tw, (seg + 1) * qw))
         const int c0 = seg * qw, c1 = (c0 + qw) < tw ? (c0 + qw) : tw;
         for (int y = threadIdx.x >> 2; y < th; y += 64) {
             const glb_u8* row = tsrc + (size_t)y * d.W;
-            if (((tw | qw) & 1) == 0) {
+            if (((tw | qw) & 1) == 0 && qw <= 32 && (d.W & 1) == 0) {
+                // dword k of the quarter covers columns c0 + 4 k .. c0 + 4 k + 3; a dword that would reach past the END OF THE IMAGE ROW is
+                // read two bytes earlier and shifted (the row start is 2-byte aligned, c1 - c0 is even)
+                unsigned v[8];
+                const int rowend = d.W - tx * tw;                             // columns of this tile row left in the image row
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int x = c0 + 4 * k;
+                    v[k] = 0;
+                    if (x < c1) {
+                        if (x + 4 <= rowend) v[k] = *(glb_u32_a2*)(row + x);
+                        else v[k] = (unsigned)(*(const glb_u16*)(row + x));     // (two pixels left in the image row)
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int x = c0 + 4 * k;
+                    if (x < c1) {
+                        atomicAdd(&hist[v[k] & 255u], 1);
+                        atomicAdd(&hist[(v[k] >> 8) & 255u], 1);
+                        if (x + 2 < c1) {
+                            atomicAdd(&hist[(v[k] >> 16) & 255u], 1);
+                            atomicAdd(&hist[v[k] >> 24], 1);
+                        }
+                    }
+                }
+            } else if (((tw | qw) & 1) == 0) {
                 for (int x = c0; x < c1; x += 2) {
                     const unsigned v = *(const glb_u16*)(row + x);
                     atomicAdd(&hist[v & 255u], 1);
@@ -134,27 +162,40 @@ extern "C" __global__ __launch_bounds__(256) void fe_clahe_apply_kernel(FeDev d,
         if (tx1 == cx - 1) mine |= 1u << q;
     }
     if (mine == 0u) return;
-    for (int y = y_lo + r0; y < y_hi; y += rows_per_pass) {
-        const float tyf = y * inv_th - 0.5f;
-        const int ty1 = cv_floor(tyf);
-        if (ty1 != cy - 1) continue;
-        const float ya = tyf - ty1, ya1 = 1.0f - ya;
-        const uint32_t in4 = *(const glb_u32*)(src + (size_t)y * W + x);
-        uint32_t out4 = 0;
+    // (round 6: the dwords of up to eight of the thread's rows are requested together -- the loop waited for every row's load before it
+    //  asked for the next one: ~7 dependent HBM round trips per thread)
+    for (int yb = y_lo + r0; yb < y_hi; yb += 8 * rows_per_pass) {
+        uint32_t in8[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t l = lut4[(in4 >> (8 * q)) & 255u];
-            const float l11 = (float)(l & 255u), l12 = (float)((l >> 8) & 255u), l21 = (float)((l >> 16) & 255u), l22 = (float)(l >> 24);
-            const float res = (l11 * xa1[q] + l12 * xa[q]) * ya1 + (l21 * xa1[q] + l22 * xa[q]) * ya;
-            int o = cv_round(res);
-            o = o < 0 ? 0 : (o > 255 ? 255 : o);
-            out4 |= (uint32_t)o << (8 * q);
+        for (int u = 0; u < 8; ++u) {
+            const int y = yb + u * rows_per_pass;
+            in8[u] = *(const glb_u32*)(src + (size_t)(y < y_hi ? y : yb) * W + x);
         }
-        glb_u8* po = dst + (size_t)y * W + x;
-        if (mine == 15u) *(glb_u32*)po = out4;
-        else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (mine & (1u << q)) po[q] = (uint8_t)(out4 >> (8 * q));
+        for (int u = 0; u < 8; ++u) {
+            const int y = yb + u * rows_per_pass;
+            if (y >= y_hi) continue;
+            const float tyf = y * inv_th - 0.5f;
+            const int ty1 = cv_floor(tyf);
+            if (ty1 != cy - 1) continue;
+            const float ya = tyf - ty1, ya1 = 1.0f - ya;
+            const uint32_t in4 = in8[u];
+            uint32_t out4 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t l = lut4[(in4 >> (8 * q)) & 255u];
+                const float l11 = (float)(l & 255u), l12 = (float)((l >> 8) & 255u), l21 = (float)((l >> 16) & 255u), l22 = (float)(l >> 24);
+                const float res = (l11 * xa1[q] + l12 * xa[q]) * ya1 + (l21 * xa1[q] + l22 * xa[q]) * ya;
+                int o = cv_round(res);
+                o = o < 0 ? 0 : (o > 255 ? 255 : o);
+                out4 |= (uint32_t)o << (8 * q);
+            }
+            glb_u8* po = dst + (size_t)y * W + x;
+            if (mine == 15u) *(glb_u32*)po = out4;
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (mine & (1u << q)) po[q] = (uint8_t)(out4 >> (8 * q));
+            }
         }
     }
 }

@@ -17,6 +17,8 @@ typedef __attribute__((address_space(1))) int glb_i;
 typedef __attribute__((address_space(1))) uint8_t glb_u8;
 typedef __attribute__((address_space(1))) uint32_t glb_u32;
 typedef __attribute__((address_space(1))) uint16_t glb_u16;
+typedef uint32_t vg_u32_a2 __attribute__((aligned(2)));
+typedef __attribute__((address_space(1))) const vg_u32_a2 glb_u32_a2;      // a dword in HBM at a 2-byte aligned address: one global_load_dword
 #define VG_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 // ---- the kernarg segment (explicit kernel arguments, then the hidden ones): constant address space
 typedef const __attribute__((address_space(4))) char* vg_kernarg_ptr;
@@ -103,6 +105,8 @@ typedef int glb_i;
 typedef uint8_t glb_u8;
 typedef uint32_t glb_u32;
 typedef uint16_t glb_u16;
+typedef uint32_t vg_u32_a2 __attribute__((aligned(2)));
+typedef const vg_u32_a2 glb_u32_a2;
 #define VG_WAVES_PER_EU(n)
 typedef const char* vg_kernarg_ptr;                        // (hipLaunchKernelGGL of the emulator packs the arguments the same way)
 #define BA_WALL_HZ 1e9                                     // (the emulated clock counts nanoseconds)
