@@ -989,13 +989,36 @@ struct SelWalk {
 };
 // wave 0 only: visit `cnt` sorted keys, append accepted corners; returns the new acceptance count
 FDEV int sel_walk(const SelWalk& w, const unsigned long long* keys, unsigned cnt, int nacc, float* corners, int lane) {
+    // The walk over the sorted candidates is a serial chain on one wavefront (a candidate is tested against everything accepted before
+    // it).  Round 6 takes out of the chain what does not belong there: every lane decodes ITS candidate of the pass once (two integer
+    // divisions by the image width and the cell size were ~150 instructions per visit), and tests it against the grid AS IT STANDS AT THE
+    // START OF THE PASS -- 64 candidates in parallel; a candidate too close to a corner accepted in an earlier pass stays rejected
+    // whatever this pass adds (the grid only grows), so the serial loop visits the survivors only and gives the same list.
     for (unsigned base = 0; base < cnt && nacc < w.maxc; base += 64) {
         const unsigned long long mykey = (base + lane < cnt) ? keys[base + lane] : 0ull;
         const int m = (cnt - base) < 64u ? (int)(cnt - base) : 64;
-        for (int j = 0; j < m && nacc < w.maxc; ++j) {
-            const unsigned idx = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mykey & 0xffffffffull), j);
-            const int y = idx / w.W, x = idx % w.W;
-            const int xc = x / w.cell, yc = y / w.cell;
+        const unsigned myidx = (unsigned)(mykey & 0xffffffffull);
+        const int my = (int)(myidx / (unsigned)w.W), mx = (int)(myidx - (unsigned)my * (unsigned)w.W);
+        const int mxc = mx / w.cell, myc = my / w.cell;
+        bool pre_bad = false;
+        if (w.use_dist && lane < m) {
+            for (int nb = 0; nb < 9; ++nb) {
+                const int cx = mxc - 1 + nb % 3, cy = myc - 1 + nb / 3;
+                if (cx < 0 || cy < 0 || cx >= w.gw || cy >= w.gh) continue;
+                const int c = cy * w.gw + cx;
+                const int kc = w.cellcnt[c];
+                for (int slot = 0; slot < kc; ++slot) {
+                    const float dx = (float)(mx - (int)w.cellxy[c][slot][0]), dy = (float)(my - (int)w.cellxy[c][slot][1]);
+                    pre_bad = pre_bad || (double)(dx * dx + dy * dy) < w.md2;
+                }
+            }
+        }
+        unsigned long long todo = __ballot(lane < m && !pre_bad);
+        while (todo && nacc < w.maxc) {
+            const int j = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int x = __builtin_amdgcn_readlane(mx, j), y = __builtin_amdgcn_readlane(my, j);
+            const int xc = __builtin_amdgcn_readlane(mxc, j), yc = __builtin_amdgcn_readlane(myc, j);
             bool bad = false;
             if (w.use_dist && lane < 63) {
                 const int nb = lane / 7, slot = lane % 7;          // 9 neighbour cells x 7 slots
@@ -1093,7 +1116,12 @@ extern "C" __global__ __launch_bounds__(1024) void fe_select_kernel(FeDev d, dou
     const unsigned n = (unsigned)ctl[5];
     __threadfence_block();
     __syncthreads();
-    if (n <= FE_SEL_CAP) {
+    // (round 6) the walk stops at max_corners accepted corners and rarely looks past the first few hundred candidates, so neither path
+    // sorts more than it has to: lists up to `target` keys are sorted whole, longer ones leave in chunks of about `target` keys from
+    // the top value bins (the next chunk only if the walk runs out of candidates; the order of the walk, and with it the result, does
+    // not depend on where the chunks are cut)
+    const unsigned target = (unsigned)(8 * w.maxc < 512 ? 512 : (8 * w.maxc > FE_SEL_CAP ? FE_SEL_CAP : 8 * w.maxc));
+    if (n <= target) {
         unsigned np = 1;
         while (np < n) np <<= 1;
         for (unsigned i = tid; i < np; i += 1024) sk[i] = i < n ? keys[i] : 0ull;
@@ -1127,8 +1155,9 @@ extern "C" __global__ __launch_bounds__(1024) void fe_select_kernel(FeDev d, dou
             if (lane == 0) {
                 unsigned tot = 0;
                 int b = b_hi, gi = 0;
-                while (gi < 64 && b - 63 >= 0 && tot + grp[gi] <= FE_SEL_CAP) { tot += grp[gi]; b -= 64; ++gi; }
-                while (b >= 0 && tot + hist[b] <= FE_SEL_CAP) { tot += hist[b]; --b; }
+                while (gi < 64 && b - 63 >= 0 && tot + grp[gi] <= target) { tot += grp[gi]; b -= 64; ++gi; }
+                while (b >= 0 && tot + hist[b] <= target) { tot += hist[b]; --b; }
+                if (b == b_hi && hist[b] <= FE_SEL_CAP) { tot = hist[b]; --b; }      // (a single bin above the target, below the capacity)
                 ctl[0] = b + 1;                               // b_lo
                 ctl[1] = (int)tot;
                 ctl[2] = (b == b_hi) ? 1 : 0;                 // a single bin exceeds the capacity -> fallback
