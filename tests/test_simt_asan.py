@@ -12,6 +12,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMT = os.path.join(ROOT, "tests", "simt")
+# the sanitizer build lives OUTSIDE the repository (the GPU pool refuses repository snapshots that carry -fsanitize=address objects)
+import tempfile  # noqa: E402
+ASAN_OUT = os.path.join(tempfile.gettempdir(), "vins_simt_build_asan_%d" % os.getuid())
 
 
 def _asan_runtime():
@@ -24,10 +27,10 @@ def test_emulated_kernels_under_address_sanitizer():
     rt = _asan_runtime()
     if rt is None:
         pytest.skip("no libasan in this toolchain")
-    b = subprocess.run(["make", "-C", SIMT, "-j", str(os.cpu_count() or 4), "asan"], capture_output=True, text=True)
+    b = subprocess.run(["make", "-C", SIMT, "-j", str(os.cpu_count() or 4), "asan", "ASAN_OUT=" + ASAN_OUT], capture_output=True, text=True)
     assert b.returncode == 0, b.stdout[-3000:] + b.stderr[-3000:]
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0",
-               VINS_SIMT_LIB=os.path.join(SIMT, "_build_asan", "libvinsgpu_simt.so"))
+               VINS_SIMT_LIB=os.path.join(ASAN_OUT, "libvinsgpu_simt.so"))
     sel = ("test_emulated_solve_matches_oracle or test_emulated_marginalization_matches_oracle or test_emulated_large_window_path_matches_oracle "
            "or test_emulated_enlarged_window_marginalization or test_resident_sequence_equals_host_bookkeeping or test_hand_back_and_reseed "
            "or test_emulated_detection_path_is_bit_exact_in_every_fiber_order or test_emulated_lk_is_bit_exact_in_every_fiber_order")
@@ -53,9 +56,9 @@ def test_cpp_host_side_under_address_and_leak_sanitizer(tmp_path, monkeypatch):
     from vins_mono_amd import synth
     if _asan_runtime() is None:
         pytest.skip("no libasan in this toolchain")
-    b = subprocess.run(["make", "-C", SIMT, "-j", str(os.cpu_count() or 4), "asan"], capture_output=True, text=True)
+    b = subprocess.run(["make", "-C", SIMT, "-j", str(os.cpu_count() or 4), "asan", "ASAN_OUT=" + ASAN_OUT], capture_output=True, text=True)
     assert b.returncode == 0, b.stdout[-3000:] + b.stderr[-3000:]
-    exe = os.path.join(SIMT, "_build_asan", "vins_replay_simt")
+    exe = os.path.join(ASAN_OUT, "vins_replay_simt")
     K, n_frames = 11, 3
     src = [M.FrameSource(synth.SyntheticSequence(s, n_frames=K + n_frames + 1, K=K + n_frames + 1, L=70), noise_seed=200 + s) for s in (21, 22)]
     M.write_seq_file(tmp_path / "frames.bin", src, K, n_frames, min_parallax=0.25)

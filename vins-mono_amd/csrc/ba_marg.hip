@@ -19,7 +19,7 @@
 #include "../../include/vinsgpu.h"
 
 #ifndef MG_NT
-#define MG_NT 1024                 // 16 wavefronts: the Jacobi rounds are LDS-latency bound, more waves in flight
+#define MG_NT 512                  // round 6: 8 wavefronts x 256 VGPRs (no spills in the factor evaluations; the long phases are one-wavefront chains or MFMA tiles now: 190 -> 166 us; 1024 threads until then, -DMG_NT=1024 still builds)
 #endif
 #define MG_NW (MG_NT / 64)
 #define MG_T0W 4                   // wavefronts that share the all-factor product of the projection part (ba_marg_kernel (c))
@@ -1892,7 +1892,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
             Mm[i * ldm + j] = 0.5 * (A[i * posmax + j] + A[j * posmax + i]);
         }
         __syncthreads();
-        const bool fast1 = in_lds && m >= 1 && m <= 16 * MG_HROWS;
+        const bool fast1 = in_lds && m >= 1 && m <= 16 * MG_HROWS && (m + 1) / 2 <= MG_NT / 16;      // (vh_eig: a 16-lane group per column pair)
         const int sw1 = fast1 ? vh_eig(c, 0, ld * ld, m, ldm, offcs, offred, 0.0, 2e-16, 0.0, 10)
                       : in_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, m, ldm, offcs, offred, true)
                                : jacobi_eig<false>(c, Mm, Vm, 0, 0, m, ldm, offcs, offred, true);
@@ -1971,6 +1971,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
 #endif
     const int offcs2 = (int)(cs - MG_LDS), offred2 = (int)(red - MG_LDS);
     const bool fast2 = n_lds && n >= 1 && n <= 16 * MG_HROWS;
+    const bool fast2_eig = fast2 && (n + 1) / 2 <= MG_NT / 16;      // (vh_eig: a 16-lane group per column pair; the square root has no such limit)
     if ((fast2 || !n_lds) && c.hdr[H_MARGMODE] == 0) {
         // square-root form by pivoted Cholesky (see sqrt_factor): J0 = L^T, r0 = L^-1 b'
         const int rk = fast2 ? sqrt_factor(c, 0, ld * ld, n, ld2, offcs2, offred2, bp)
@@ -1991,7 +1992,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     // largest |g_p.g_q| / (|g_p||g_q|) per sweep runs 0.66, 0.44, 0.41, 6e-2, 7e-3, 1e-5, 9e-8, 8e-9, 1e-10 -- each further
     // decade costs a full sweep of 75 rounds.  The last of them used to be a pure verification sweep (no rotation): the loop
     // now ends after the first sweep whose largest rotated pair was below 1e-7 (what it leaves is ~theta^2).
-    const int sw2 = fast2 ? vh_eig(c, 0, ld * ld, n, ld2, offcs2, offred2, 2e-8, 1e-9, 1e-7, 16)
+    const int sw2 = fast2_eig ? vh_eig(c, 0, ld * ld, n, ld2, offcs2, offred2, 2e-8, 1e-9, 1e-7, 16)
                   : n_lds ? jacobi_eig<true>(c, nullptr, nullptr, 0, ld * ld, n, ld2, offcs2, offred2, false)
                           : jacobi_eig<false>(c, M2, V2, 0, 0, n, ld2, offcs2, offred2, false);
 #ifdef BA_PROFILE
