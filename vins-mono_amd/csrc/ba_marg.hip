@@ -22,6 +22,7 @@
 #define MG_NT 512                  // round 6: 8 wavefronts x 256 VGPRs (no spills in the factor evaluations; the long phases are one-wavefront chains or MFMA tiles now: 190 -> 166 us; 1024 threads until then, -DMG_NT=1024 still builds)
 #endif
 #define MG_NW (MG_NT / 64)
+static_assert(MG_NT / 64 > 4, "ba_marg_kernel (c): four wavefronts share the all-factor product, the others take the target frames");
 #define MG_T0W 4                   // wavefronts that share the all-factor product of the projection part (ba_marg_kernel (c))
 #define MG_EPS 1e-8
 #define MG_MAXSWEEP 30
