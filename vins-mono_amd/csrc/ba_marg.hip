@@ -1460,31 +1460,42 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                 }
             }
             MPROF(11);
-            // landmark rows / columns: thread per (landmark, camera column | self | rhs)
-            for (int wk = c.tid; wk < (k1 - k0) * (ncam + 2); wk += MG_NT) {
-                const int k = k0 + wk / (ncam + 2), a = wk % (ncam + 2);
-                const int cl = mp.misc[7] + k;             // (= mp.lm[mp.l0[k]]: the frame-0 landmarks take consecutive columns)
-                int ca = -2, o0 = 0, o1 = 1, rq = -1;
-                if (a < 6) { ca = mp.pose[0] + a; o0 = 2 + a; o1 = 8 + a; }
-                else if (a < 6 * K) { const int f = a / 6, kk = a - 6 * f; ca = mp.pose[f] < 0 ? -1 : mp.pose[f] + kk; o0 = 14 + kk; o1 = 20 + kk; rq = f; }
-                else if (a < 6 * K + 6) { ca = cex < 0 ? -1 : cex + a - 6 * K; o0 = 26 + a - 6 * K; o1 = 32 + a - 6 * K; }
-                else if (a == 6 * K + 6) { ca = L.t ? ctd : -1; o0 = 40; o1 = 41; }
-                else if (a == ncam) { o0 = 38; o1 = 39; }              // (l, l)
+            // landmark rows / columns (round 6, second form).  The entries a landmark shares with the pose of a TARGET frame have one
+            // term -- the factor of that frame -- so they are a thread per (factor, column of its target pose), no loop; what sums over
+            // the landmark's factors (pose 0, extrinsic pose, td, the landmark's own diagonal entry and its gradient entry: 15 per
+            // landmark) is a thread per entry walking the factors in their order.  Entries of frames the landmark is not seen from
+            // are not written at all (A was cleared).  It was a thread per (landmark, every camera column) with the factor loop in
+            // each: 5400 looped tasks for 72 landmarks, most of them storing zeros.
+            const int lmb = mp.misc[7];
+            for (int wk = c.tid; wk < 6 * ncf; wk += MG_NT) {
+                const int cf = wk / 6, kk = wk - 6 * cf;
+                const int j = jofL[cf];
+                if (j < 0 || mp.pose[j] < 0) continue;
+                const lds_d* R = recl + vg_mul24(cf, 42);
+                const double v = R[14 + kk] * R[38] + R[20 + kk] * R[39];
+                const int cl = lmb + kofL[cf], ca = mp.pose[j] + kk;
+                Ag[(size_t)cl * posmax + ca] = v; Ag[(size_t)ca * posmax + cl] = v;
+            }
+            for (int wk = c.tid; wk < 15 * (k1 - k0); wk += MG_NT) {
+                const int k = k0 + wk / 15, e = wk - 15 * (wk / 15);
+                int ca, o0, o1;
+                if (e < 6) { ca = mp.pose[0] + e; o0 = 2 + e; o1 = 8 + e; }
+                else if (e < 12) { ca = cex < 0 ? -1 : cex + e - 6; o0 = 26 + e - 6; o1 = 32 + e - 6; }
+                else if (e == 12) { ca = L.t ? ctd : -1; o0 = 40; o1 = 41; }
+                else if (e == 13) { ca = -2; o0 = 38; o1 = 39; }          // (l, l)
+                else { ca = -3; o0 = 0; o1 = 1; }                          // gradient
                 if (ca == -1) continue;
-                double s = 0.0;
-                const int nfl = cfb[k + 1] - cfb[k];
-                for (int t = 0; t < nfl; ++t) {
-                    const int cf = cfb[k] - cbase + t;
-                    const int j = jofL[cf];
-                    const double* R = recL + (size_t)cf * 42;
+                double sacc = 0.0;
+                const int fb = cfb[k] - cbase, fe = cfb[k + 1] - cbase;
+                for (int cf = fb; cf < fe; ++cf) {
+                    const lds_d* R = recl + vg_mul24(cf, 42);
                     const double v = R[o0] * R[38] + R[o1] * R[39];
-                    s += (j >= 0 && (rq < 0 || rq == j)) ? v : 0.0;
+                    sacc += jofL[cf] >= 0 ? v : 0.0;
                 }
-                // (nothing else contributes to a landmark's row, column or gradient entry -- A and bv were cleared, a landmark lies in
-                //  one chunk: plain stores, no read-modify-write round trip)
-                if (a == ncam) Ag[(size_t)cl * posmax + cl] = s;
-                else if (a == ncam + 1) bg[cl] = s;
-                else { Ag[(size_t)cl * posmax + ca] = s; Ag[(size_t)ca * posmax + cl] = s; }
+                const int cl = lmb + k;
+                if (ca == -2) Ag[(size_t)cl * posmax + cl] = sacc;
+                else if (ca == -3) bg[cl] = sacc;
+                else { Ag[(size_t)cl * posmax + ca] = sacc; Ag[(size_t)ca * posmax + cl] = sacc; }
             }
             __syncthreads();
             if (c.wave == 0) {
