@@ -1148,6 +1148,8 @@ static int unpack_priors(vg_handle* h, int nwin, vg_ba_prior* const* pri) {
                             mi[4] & 255, mi[4] >> 8, mi[5] & 255, mi[5] >> 8, mi[7], pf[0], pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6]);
                     fprintf(stderr, "[marg] projection part (sqrt mode): offsets %d evaluate %d sort %d camera (wave 0) %d landmark rows %d\n",
                             pf[8] - pf[2], pf[9] - pf[8], pf[10] - pf[9], pf[11] - pf[10], pf[3] - pf[11]);
+                    fprintf(stderr, "[marg] elimination (direct path): landmarks leave (MFMA, global operands) %d | Cholesky + inverse %d | X, Y, P'^-1 %d | certificate %d | kept tiles %d\n",
+                            pf[12] - pf[3], pf[13] - pf[12], pf[14] - pf[13], pf[15] - pf[14], pf[4] - pf[15]);
                 }
                 if (mi[0]) {
                     const int n = mi[1], nb = mi[3];

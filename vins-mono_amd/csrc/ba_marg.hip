@@ -1196,29 +1196,31 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
         __syncthreads();
         const glb_d* J0g = (const glb_d*)(c.pri + L.po_J0);        // row-major, leading dimension pld
         const glb_d* r0g = (const glb_d*)(c.pri + L.po_r0);
-        const int part = c.tid & 7;
-        for (int rb = 0; rb < nprior; rb += MG_NT / 8) {
-            const int r = rb + (c.tid >> 3);
+        // (eight lanes per row with sixteen wavefronts, four with eight: one pass over the rows either way)
+        constexpr int PLR = MG_NT >= 1024 ? 8 : 4, PLS = MG_NT >= 1024 ? 3 : 2;
+        const int part = c.tid & (PLR - 1);
+        for (int rb = 0; rb < nprior; rb += MG_NT / PLR) {
+            const int r = rb + (c.tid >> PLS);
             double sacc = 0.0;
             if (r < nprior)
-                for (int k = part; k < nprior; k += 8) sacc += J0g[(size_t)r * L.pld + k] * dx[k];
+                for (int k = part; k < nprior; k += PLR) sacc += J0g[(size_t)r * L.pld + k] * dx[k];
             sacc += dpp_mov_f64<0xB1>(sacc);
             sacc += dpp_mov_f64<0x4E>(sacc);
-            sacc += dpp_mov_f64<0x141>(sacc);
+            if (PLR == 8) sacc += dpp_mov_f64<0x141>(sacc);
             if (r < nprior && part == 0) prl[r] = r0g[r] + sacc;
         }
         __syncthreads();
         const glb_d* Hp = (const glb_d*)(c.sc + L.so_Hp);          // J0^T J0 (lower), left by the solve pipeline's prologue
         glb_d* Ag = (glb_d*)A;
         glb_d* bg = (glb_d*)bv;
-        for (int ab = 0; ab < nprior; ab += MG_NT / 8) {
-            const int a = ab + (c.tid >> 3);
+        for (int ab = 0; ab < nprior; ab += MG_NT / PLR) {
+            const int a = ab + (c.tid >> PLS);
             double sacc = 0.0;
             if (a < nprior)
-                for (int r = part; r < nprior; r += 8) sacc += J0g[(size_t)r * L.pld + a] * prl[r];
+                for (int r = part; r < nprior; r += PLR) sacc += J0g[(size_t)r * L.pld + a] * prl[r];
             sacc += dpp_mov_f64<0xB1>(sacc);
             sacc += dpp_mov_f64<0x4E>(sacc);
-            sacc += dpp_mov_f64<0x141>(sacc);
+            if (PLR == 8) sacc += dpp_mov_f64<0x141>(sacc);
             if (a < nprior && part == 0) bg[pcol[a]] = sacc;
         }
         for (int a = c.wave; a < nprior; a += MG_NW) {
@@ -1630,6 +1632,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                     }
                 }
                 __syncthreads();
+                MPROF(12);
                 // ---- P' = L L^T in registers (lane = row), then L^-1 by lane = column (wavefront 0)
                 if (c.wave == 0) {
                     double a[16];
@@ -1672,6 +1675,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                     if (!good) *okf = 0;
                 }
                 __syncthreads();
+                MPROF(13);
                 // ---- X = L^-1 U (U[p][j] = G'[md + j][p]), Y = L^-1 W D^-1, P'^-1 = L^-T L^-1
                 for (int k = c.tid; k < 16 * ldx; k += MG_NT) {
                     const int p = k / ldx, j = k - p * ldx;
@@ -1693,6 +1697,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                     Pi[k] = sacc;
                 }
                 __syncthreads();
+                MPROF(14);
                 // ---- the certificate
                 double fro = 0.0;
                 for (int k = c.tid; k < md * md; k += MG_NT) {
@@ -1719,6 +1724,7 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
                 bad = mg_block_sum(c, red, bad);
                 direct = *okf != 0 && bad == 0.0 && fro > 0.0 && fro < 1e14;              // 1 / sqrt(fro) > 1e-7
                 __syncthreads();
+                MPROF(15);
                 if (direct) {
                     // ---- [A' | b'] = G'[md:, md:] - X^T X  ->  the square root's tile (eM, leading dimension ld) and b' (gV)
                     const int nt = ldx >> 4, ntile = nt * (nt + 1) / 2;
