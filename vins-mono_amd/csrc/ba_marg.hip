@@ -1160,7 +1160,9 @@ extern "C" __global__ __launch_bounds__(MG_NT) void ba_marg_kernel(const BaLayou
     if (!mp.misc[6]) { if (c.tid == 0) { mi[0] = 0; mi[1] = 0; } return; }
     const int cex = mp.misc[0], ctd = mp.misc[1];
 
-    for (int k = c.tid; k < pos * pos; k += MG_NT) A[(k / pos) * posmax + k % pos] = 0.0;
+    // (row by wavefront, column by lane: no division per element)
+    for (int r = c.wave; r < pos; r += MG_NW)
+        for (int cc = c.lane; cc < pos; cc += 64) ((glb_d*)A)[(size_t)r * posmax + cc] = 0.0;
     for (int k = c.tid; k < pos; k += MG_NT) bv[k] = 0.0;
     __syncthreads();
 
