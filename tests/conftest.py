@@ -29,7 +29,11 @@ def _prebuild_for_workers():
         subprocess.run(["make", "ref_simt"], cwd=os.path.join(ROOT, "oracle"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     r = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True) if shutil.which("gcc") else None
     if r is not None and r.returncode == 0 and os.path.isabs(r.stdout.strip()) and os.path.exists(r.stdout.strip()):
-        subprocess.run(["make", "-C", SIMT_DIR, "-j", jobs, "asan"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # (outside the repository, where test_simt_asan.py / test_abi_fuzz.py look for it: the GPU pool refuses repository snapshots that carry
+        #  -fsanitize=address objects)
+        import tempfile
+        asan_out = os.path.join(tempfile.gettempdir(), "vins_simt_build_asan_%d" % os.getuid())
+        subprocess.run(["make", "-C", SIMT_DIR, "-j", jobs, "asan", "ASAN_OUT=" + asan_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 @pytest.hookimpl(tryfirst=True)

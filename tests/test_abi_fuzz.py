@@ -152,10 +152,14 @@ def test_malformed_inputs_come_back_as_status_codes():
     rt = r0.stdout.strip()
     if r0.returncode != 0 or not os.path.isabs(rt) or not os.path.exists(rt):
         pytest.skip("no libasan in this toolchain")
-    b = subprocess.run(["make", "-C", SIMT, "-j", str(os.cpu_count() or 4), "asan"], capture_output=True, text=True)
+    # (the sanitizer build lives outside the repository, where tests/test_simt_asan.py puts it: the GPU pool refuses snapshots that
+    #  carry -fsanitize=address objects)
+    import tempfile
+    asan_out = os.path.join(tempfile.gettempdir(), "vins_simt_build_asan_%d" % os.getuid())
+    b = subprocess.run(["make", "-C", SIMT, "-j", str(os.cpu_count() or 4), "asan", "ASAN_OUT=" + asan_out], capture_output=True, text=True)
     assert b.returncode == 0, b.stdout[-3000:] + b.stderr[-3000:]
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0",
-               VINS_SIMT_LIB=os.path.join(SIMT, "_build_asan", "libvinsgpu_simt.so"))
+               VINS_SIMT_LIB=os.path.join(asan_out, "libvinsgpu_simt.so"))
     r = subprocess.run([sys.executable, "-c", _CHILD % dict(root=ROOT)], capture_output=True, text=True, env=env, timeout=1500)
     assert "AddressSanitizer" not in r.stdout + r.stderr, (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0 and "OK refused" in r.stdout, (r.stdout + r.stderr)[-4000:]
