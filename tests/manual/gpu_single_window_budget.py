@@ -4,7 +4,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as g
-g.load_package()
+pkg = g.load_package()
+if len(sys.argv) > 1:                      # another build of the library: vins-mono_amd/lib/<name>
+    pkg.LIB_PATH = os.path.join(os.path.dirname(pkg.LIB_PATH), sys.argv[1])
 from vins_mono_amd import ba, synth
 h = ba.Handle()
 seq = synth.SyntheticSequence(5, L=150)

@@ -223,3 +223,23 @@ def test_solve_kernel_lds_carve_leaves_room_for_a_second_window_per_cu(simt_hand
     prob = seq.window(1)
     simt_handle.ba_upload([ba.PackedProblem(prob)], [ba.VG_MARGIN_NONE])
     assert simt_handle.ba_info()['lds_bytes'] <= 80 * 1024 - 2048
+
+
+def test_emulated_both_builds_of_the_solve_kernel_agree(simt_handle):
+    """ba_solve_kernel (4 wavefronts per window: batches) and ba_solve_w8_kernel (8 wavefronts: fewer than 32 windows, the drop-in's
+    single window) are the same source compiled for two thread counts (csrc/ba_solve_w8.hip).  A batch of 32 small windows takes the
+    first, each window alone the second: same accept / reject trace, states equal to rounding (sums strided over the threads of a
+    workgroup are grouped differently), both equal to the oracle.  The GPU form of this test: test_throughput_and_latency_layouts_agree."""
+    probs = [synth.SyntheticSequence(300 + s, K=5, L=8).window(0) for s in range(32)]
+    simt_handle.ba_upload(probs, [ba.VG_MARGIN_NONE] * len(probs))
+    simt_handle.ba_run_async()
+    st, sm, _ = simt_handle.ba_download()
+    for i in (0, 13, 31):
+        s1, m1, _ = simt_handle.ba_optimize(probs[i])
+        assert sm[i]['status'] == 0 and m1['status'] == 0 and sm[i]['num_iterations'] == m1['num_iterations']
+        assert np.array_equal(sm[i]['it_flags'], m1['it_flags'])
+        assert np.abs(st[i]['pose'] - s1['pose']).max() < 1e-9 and np.abs(st[i]['sb'] - s1['sb']).max() < 1e-9
+        assert np.isclose(sm[i]['final_cost'], m1['final_cost'], rtol=1e-10)
+        x, summ = B.solve(probs[i])
+        ref = B.double2vector(probs[i], x)
+        assert np.abs(s1['pose'] - ref['pose']).max() < 1e-6 and np.abs(st[i]['pose'] - ref['pose']).max() < 1e-6

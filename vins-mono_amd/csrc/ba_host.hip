@@ -275,7 +275,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         L.lds_solve = o * 8;
         bigm_doubles = ob;
         if (!L.big && L.Rc + 10 - 64 > 32) { h->err = "solve kernel: more column tasks than three wavefronts"; return VG_ERR_UNSUPPORTED; }
-        if (!L.big && 36 * ldc < std::max(std::max(L.RcPad * 33, SV_NT), std::max(9 * L.K, 162))) { h->err = "solve kernel: scratch does not fit the coupling-row ring"; return VG_ERR_UNSUPPORTED; }
+        if (!L.big && 36 * ldc < std::max(std::max(L.RcPad * 33, 2 * SV_NT), std::max(9 * L.K, 162))) { h->err = "solve kernel: scratch does not fit the coupling-row ring"; return VG_ERR_UNSUPPORTED; }
         if (L.lds_solve > 160 * 1024) { h->err = "solve kernel LDS carve exceeds 160 KB"; return VG_ERR_UNSUPPORTED; }
         const int nib = std::min(std::min(L.K - 1, BA_IMU_BATCH), L.igs);
         L.lds_lin = 8 * std::max(up(nib * 225, 2) + nib * 480, 5 * L.Ncap);
@@ -303,6 +303,14 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
             L.la_key = L.la_P + up(npair * 90, 2);
             L.la_x = up(L.la_key + (2 * chf + 64 + 82 + 8 * 80 + 1) / 2 + 2, 2);
             L.lds_linacc = (L.la_x + nstl) * 8;
+        }
+        // which build of the per-round solve kernel: 4 wavefronts per window (two windows per CU, the batch) or 8 (ba_solve_w8.hip: a
+        // few windows on an otherwise empty chip).  Below 32 windows -- where the factor side is in its latency
+        // mode as well -- the second window per CU does not exist and the wavefront slots go to the same window.
+        {
+            static const int env_max = getenv("VG_BA_SOLVE_W8_BELOW") ? atoi(getenv("VG_BA_SOLVE_W8_BELOW")) : -1;      // (development switch:
+            const int below = (env_max >= 0 && !h->ba.no_env) ? env_max : 32;                                             //  plain vg_create() only)
+            L.sv_w8 = (!L.big && L.nwin < below) ? 1 : 0;
         }
     }
     if (L.big) {

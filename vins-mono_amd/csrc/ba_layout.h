@@ -17,8 +17,13 @@
 // under half a CU's 160 KB for the reference shape (K = 11: 72 KB), so that TWO windows are resident per CU (round 5): every phase
 // of the solve is a latency-bound chain carried by one or two wavefronts, and the only lever on such a kernel is more independent
 // work per CU.  8 waves x 256 VGPRs and 134 KB of LDS had made that impossible.
+// A batch of a few windows (the drop-in's single window) has the CU to itself: it takes the same kernel source built for 8
+// wavefronts (ba_solve_w8.hip defines SV_NT = 512 before this header and compiles ba_pipeline.hip a second time).
+#ifndef SV_NT
 #define SV_NT 256
+#endif
 #define SV_NW (SV_NT / 64)
+#define SV_WG_PER_CU (SV_NT <= 256 ? 2 : 1)   // workgroups the register budget of ba_solve_kernel is cut for
 #define BA_LIN_NT 256             // projection factors per workgroup of the linearisation kernel
 #define BA_ACC_NT 256             // threads per workgroup of the accumulation kernel
 #define BA_MAX_K 13               // frames incl. relocalisation pose, windows solved by one workgroup out of LDS
@@ -119,6 +124,8 @@ struct BaLayout {
     // ---- fused projection kernel (ba_linacc_proj_kernel): eligible windows (la_on), landmarks per chunk by first factor index
     //      (la_chq), staged-record capacity (la_chf = la_chq + 16), LDS offsets (doubles) of the pair blocks and of the key table
     int la_on, la_chq, la_chf, la_P, la_key, la_x, lds_linacc;      // (la_x: the state of the linearisation point, staged once per launch)
+    // ---- host only: the batch is solved by ba_solve_w8_kernel (8 wavefronts per window) instead of ba_solve_kernel (4): few windows
+    int sv_w8;
     // ---- large-window path (big != 0): the camera part does not fit the LDS carve above.  S stays in LDS (packed, with
     //      the rhs row), everything else of the carve lives in HBM scratch at so_bigm (the l_* offsets are then relative to
     //      it); the landmark Schur complement is formed by a multi-workgroup kernel into reduce buffer 1.

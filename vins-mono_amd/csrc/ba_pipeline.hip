@@ -32,6 +32,19 @@
 #include "ba_factors.h"
 #include "../../include/vinsgpu.h"
 
+extern __shared__ __attribute__((aligned(16))) char bp_smem[];
+
+// The per-round solve kernel is built twice from this one source (round 6): ba_solve_kernel on 4 wavefronts
+// (two windows per CU: the form a batch runs) here, and ba_solve_w8_kernel on 8 wavefronts (one window per CU: the form a few
+// windows on an otherwise empty chip run -- the drop-in's operating point) by ba_solve_w8.hip, which includes this file with
+// SV_NT = 512 and BA_SOLVE_W8_TU defined: every phase function is then compiled a second time inside namespace vg_w8, the other
+// kernels and the host code of this file are left out.  The phase functions take their thread count from SV_NT / SV_NW only.
+#ifdef BA_SOLVE_W8_TU
+#undef BA_PROFILE_DETAIL                    // (the development timers / dumps and their host entry points belong to the main unit)
+#undef BA_DEBUG_DUMP
+namespace vg_w8 {
+#endif
+
 #define NOINL __device__ __noinline__
 // Pointers handed to a non-inlined phase function are generic, and generic accesses compile to flat_load / flat_store even
 // when they always hit LDS (slower issue and latency than ds_read / ds_write, and they tie up both memory counters).  The
@@ -47,7 +60,6 @@
 template <bool BIG> struct MovT { typedef lds_d D; typedef lds_i I; };
 template <> struct MovT<true> { typedef glb_d D; typedef glb_i I; };
 
-extern __shared__ __attribute__((aligned(16))) char bp_smem[];
 #define LDSB ((double*)bp_smem)
 typedef double double4_t __attribute__((vector_size(32)));      // v_mfma_f64_16x16x4 accumulator (4 VGPR pairs)
 
@@ -408,6 +420,7 @@ NOINL void imu_sqrt_info(const Ctx& c_in) {
     __syncthreads();
 }
 
+#ifndef BA_SOLVE_W8_TU
 extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
     const BaLayout& L = *Lp;
     Ctx c;
@@ -496,6 +509,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
     }
     DP_ADD(44);
 }
+#endif
 
 // ================================================================================================
 // Linearisation kernel
@@ -875,6 +889,7 @@ NOINL double proj_cost(const Ctx& c_in, int f, const double* x, const double* la
 #ifndef BA_PROJ_WAVES
 #define BA_PROJ_WAVES 1
 #endif
+#ifndef BA_SOLVE_W8_TU
 extern "C" __global__ __launch_bounds__(BA_LIN_NT, BA_PROJ_WAVES) void ba_linearize_proj_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
     const BaLayout& L = *Lp;
     Ctx c;
@@ -892,8 +907,10 @@ extern "C" __global__ __launch_bounds__(BA_LIN_NT, BA_PROJ_WAVES) void ba_linear
     const double tot = block_sum(red, BA_LIN_NT / 64, c.lane, c.wave, share);
     if (c.tid == 0) c.sc[L.so_part + b] = tot;
 }
+#endif
 
 // IMU factors + prior: one workgroup per window (LDS: sqrt_info copies + weighted Jacobian panels).
+#ifndef BA_SOLVE_W8_TU
 extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_imu_kernel(const BaLayout* __restrict__ Lp, BaPtrs P, int cost_only) {
     const BaLayout& L = *Lp;
     Ctx c;
@@ -920,6 +937,7 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_linearize_imu_kernel(cons
     const double tot = block_sum(red, BA_NW, c.lane, c.wave, share);
     if (c.tid == 0) c.sc[L.so_part + L.nbf + g] = tot;
 }
+#endif
 
 // ================================================================================================
 // Accumulation kernel: J^T J / J^T r of the projection factors from their records.
@@ -1141,6 +1159,7 @@ DEV void landmark_task(const Ctx& c, int l, const double* recs, double* buf) {
 // only.  Inside a window: workgroups 0 .. Kp-1 = the diagonal pose blocks; workgroup Kp = the blocks among ex / td (if
 // estimated); afterwards wavefront tasks: the other owner blocks (host table io_task_list of packed-triangle block
 // indices), then 64 landmarks per wavefront.
+#ifndef BA_SOLVE_W8_TU
 extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) {
     const BaLayout& L = *Lp;
     const int bid = blockIdx.x;
@@ -1166,6 +1185,7 @@ extern "C" __global__ __launch_bounds__(BA_ACC_NT) void ba_accumulate_kernel(con
         if (l < L.Lcap) landmark_task(c, l, recs, buf);
     }
 }
+#endif
 
 // ================================================================================================
 // Projection factors, fused: linearise + J^T J / J^T r in ONE kernel, the factor records never reach HBM.
@@ -1482,7 +1502,9 @@ __device__ __forceinline__ void linacc_body(const BaLayout* __restrict__ Lp, con
     DP_ADD(28);
     if (c.tid < L.nbf) c.sc[L.so_part + c.tid] = c.tid == 0 ? tot : 0.0;
 }
+#ifndef BA_SOLVE_W8_TU
 extern "C" __global__ __launch_bounds__(LA_NT) void ba_linacc_proj_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { linacc_body(Lp, P); }
+#endif
 
 // ================================================================================================
 // Solve kernel
@@ -2951,7 +2973,7 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
                 __syncthreads();
                 DBG_DUMP(1);
                 PROF_ADD(PF_BUILD);
-                q += L.RcPad <= 80 ? chain_schur<4>(pa_c, pa_m, buf, s.mu) : chain_schur<6>(pa_c, pa_m, buf, s.mu);                        // (the coupling rows' share of t^T H~ t)
+                q += L.RcPad <= 80 ? chain_schur<(15 + SV_NW - 1) / SV_NW>(pa_c, pa_m, buf, s.mu) : chain_schur<(21 + SV_NW - 1) / SV_NW>(pa_c, pa_m, buf, s.mu);                        // (the coupling rows' share of t^T H~ t)
                 bool cok = *(const int*)(m.red + 24) != 0;                // (uniform: read behind the phase's last barrier)
                 DBG_DUMP(2);
                 PROF_ADD(PF_CHAIN);
@@ -3166,7 +3188,13 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
     if (c.tid == 0) ctl_store(s, ctlp);
     PROF_ADD(PF_TAIL);
 }
-extern "C" __global__ __launch_bounds__(SV_NT, 2) void ba_solve_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { solve_body(Lp, P); }
+#ifndef BA_SOLVE_W8_TU
+extern "C" __global__ __launch_bounds__(SV_NT, SV_WG_PER_CU) void ba_solve_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { solve_body(Lp, P); }
+#else
+extern "C" __global__ __launch_bounds__(SV_NT, SV_WG_PER_CU) void ba_solve_w8_kernel(const BaLayout* __restrict__ Lp, BaPtrs P) { solve_body(Lp, P); }
+}   // namespace vg_w8
+#endif
+#ifndef BA_SOLVE_W8_TU                  // (from here to the end of the file: the main translation unit only)
 
 // ================================================================================================
 // Large-window path (BaLayout::big): windows whose camera part does not fit the LDS carve of ba_solve_kernel (BASELINE
@@ -4128,6 +4156,8 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_eval_factors_kernel(const
 // Host-side launch sequence of one batch solve (rounds = max over the windows of max_iters).
 // hipFuncSetAttribute applies to the function object of the CURRENT device: the set-up is tracked per device (a process may hold
 // handles on several GPUs) under a mutex (handles may be driven from several host threads).
+// (defined by ba_solve_w8.hip: this file compiled once more with SV_NT = 512, see the top of the file)
+extern "C" __global__ void ba_solve_w8_kernel(const BaLayout* __restrict__ Lp, BaPtrs P);
 static hipError_t set_lds_attrs() {
     static std::mutex mu;
     static unsigned long long done_mask = 0;      // bit d: device d is set up
@@ -4137,6 +4167,7 @@ static hipError_t set_lds_attrs() {
     std::lock_guard<std::mutex> lock(mu);
     if (dev >= 0 && dev < 64 && ((done_mask >> dev) & 1ull)) return hipSuccess;
     e = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_w8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_solve_big_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ba_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -4203,7 +4234,8 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
         }
         if (!fused) LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P);
         if (forked && (e = hipStreamWaitEvent(stream, fk->join, 0)) != hipSuccess) return e;
-        LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(SV_NT), L.lds_solve, dL, P);
+        if (L.sv_w8) LAUNCH(ba_solve_w8_kernel, dim3(L.nwin), dim3(2 * SV_NT), L.lds_solve, dL, P);     // few windows: 8 wavefronts per window
+        else LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(SV_NT), L.lds_solve, dL, P);
         if (kinds) { if (!fused) kinds[nk++] = 2; kinds[nk++] = 3; }
     }
     LAUNCH(ba_final_kernel, dim3(L.nwin), dim3(256), 0, dL, P);
@@ -4285,3 +4317,4 @@ extern "C" hipError_t ba_launch_eval_factors(const BaLayout& L, const BaLayout* 
     LAUNCH(ba_eval_factors_kernel, dim3(1), dim3(BA_NT), L.lds_lin, dL, P, proj_r, proj_J, imu_r, imu_J, prior_r);
     return hipSuccess;
 }
+#endif   // BA_SOLVE_W8_TU
