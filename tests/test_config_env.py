@@ -1,5 +1,5 @@
 """vg_create_config (ABI 10, VERDICT r4 'structure' item 12): a handle made from a vg_config never consults the environment -- the
-development variables VG_BA_LAUNCH_MODE / VG_BA_FUSED / VG_BA_FUSED_MIN / VG_PACK_THREADS only shape handles of plain vg_create().
+development variables VG_BA_LAUNCH_MODE / VG_BA_FUSED / VG_BA_FUSED_MIN / VG_BA_SOLVE_W8_BELOW / VG_PACK_THREADS only shape handles of plain vg_create().
 Run in a subprocess (the library reads those variables once per process)."""
 import json
 import os
