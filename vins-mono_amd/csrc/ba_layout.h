@@ -126,6 +126,8 @@ struct BaLayout {
     int la_on, la_chq, la_chf, la_P, la_key, la_x, lds_linacc;      // (la_x: the state of the linearisation point, staged once per launch)
     // ---- host only: the batch is solved by ba_solve_w8_kernel (8 wavefronts per window) instead of ba_solve_kernel (4): few windows
     int sv_w8;
+    // ---- host only: the prologue's independent pieces run as workgroups side by side (the latency layout: few windows on an empty chip)
+    int pro_split;
     // ---- large-window path (big != 0): the camera part does not fit the LDS carve above.  S stays in LDS (packed, with
     //      the rhs row), everything else of the carve lives in HBM scratch at so_bigm (the l_* offsets are then relative to
     //      it); the landmark Schur complement is formed by a multi-workgroup kernel into reduce buffer 1.

@@ -285,17 +285,17 @@ DEV bool judge_candidate(Ctl& s, double cs, const BaLayout& L, double* out, int*
 // uses, bit for bit.  Selected by vg_config::imu_info_mode = VG_IMU_INFO_REFERENCE / vg_ba_set_imu_info_mode (does
 // the form of this factor decide the sequence-level trust-region flips?  measured: profiles/r06_flip_stats.json).  One wavefront
 // per factor, lane = row (LU, LLT) or column (the solve); LDS per wavefront: LU / L [225] | inverse [225] | permutation [15].
-NOINL void imu_sqrt_info_ref(const Ctx& c_in) {
+NOINL void imu_sqrt_info_ref(const Ctx& c_in, int fbeg, int fend) {
 #pragma clang fp contract(off)
     const Ctx c = c_in;
     const BaLayout L = *c.Lp;
     double* A = LDSB + c.wave * 512;
     double* V = A + 240;
     double* Pm = V + 240;
-    const int nimu = L.K - 1;
+    const int nimu = fend < L.K - 1 ? fend : L.K - 1;      // this workgroup's factors: [fbeg, fend) in passes of BA_NW
     const int* valid = c.ia + L.io_imu_valid;
     const int i = c.lane;
-    for (int base = 0; base < nimu; base += BA_NW) {
+    for (int base = fbeg; base < nimu; base += BA_NW) {
         const int f = base + c.wave;
         const bool act = f < nimu && valid[f];
         const bool row = act && i < 15;
@@ -365,7 +365,7 @@ NOINL void imu_sqrt_info_ref(const Ctx& c_in) {
     }
 }
 
-NOINL void imu_sqrt_info(const Ctx& c_in) {
+NOINL void imu_sqrt_info(const Ctx& c_in, int fbeg, int fend) {
     const Ctx c = c_in;                       // local copies: fields read through the references would be re-loaded (flat_load +
     const BaLayout L = *c.Lp;                 // full s_waitcnt) after every store that might alias them
     // Round 6: a factor is one wavefront's business from the load to the store -- lane i holds row i of the 15 x 15 matrix in
@@ -373,10 +373,10 @@ NOINL void imu_sqrt_info(const Ctx& c_in) {
     // to be three workgroup barriers and an LDS round trip per column, 45 per pass).  Same operations on the same operands in the same
     // order: the factor is the one the LDS form produced.
     lds_d* A = AS_LDS(LDSB + c.wave * 256);          // 15x15 scratch per wavefront (the factor, for the column solves below)
-    const int nimu = L.K - 1;
+    const int nimu = fend < L.K - 1 ? fend : L.K - 1;      // this workgroup's factors: [fbeg, fend) in passes of BA_NW
     const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
     const int li = c.lane < 15 ? c.lane : 14;
-    for (int base = 0; base < nimu; base += BA_NW) {
+    for (int base = fbeg; base < nimu; base += BA_NW) {
         const int f = uni(base + c.wave);
         if (!(f < nimu && valid[f])) continue;           // (uniform per wavefront; no workgroup barrier below)
         const glb_d* cov = AS_GLB_C(c.di + L.do_imu + f * BA_IMU_STRIDE + IM_COV);
@@ -427,6 +427,15 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
     ctx_init(c, Lp, P, blockIdx.x);
     double* x = c.sc + L.so_x;
     DP_DECL;
+    // A full batch runs one workgroup per window through everything below (gridDim.y == 1).  A few windows on an empty chip (the
+    // latency layout, BaLayout::pro_split: the same windows whose IMU / prior linearisation is spread over workgroups) put the
+    // independent pieces side by side, grid (nwin, 1 + ceil((K-1) / BA_NW) + 2): part 0 the clears, the state copy and the control
+    // block; parts 1 .. nI one pass of BA_NW sqrt_info factors each; part nI+1 the transposed copy of J0; part nI+2 J0^T J0.  The
+    // pieces write disjoint arrays and read only the caller's inputs: the launch lasts as long as its longest piece (one window:
+    // 40 -> ~12 us).  Same operations per piece: identical results.
+    const bool all = gridDim.y == 1;
+    const int part = blockIdx.y, nI = (L.K - 1 + BA_NW - 1) / BA_NW;
+    if (all || part == 0)
     {   // outputs of this window start from zero in every run (status words, iteration trace, "new prior valid" flag)
         double* out = P.out + (size_t)blockIdx.x * L.ostride;
         int* iout = P.iout + (size_t)blockIdx.x * L.oi_stride;
@@ -435,29 +444,35 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
         for (int k = c.tid; k < L.oi_stride; k += BA_NT) iout[k] = 0;
         for (int k = c.tid; k < L.mi_stride; k += BA_NT) miout[k] = 0;
     }
-    for (int k = c.tid; k < 7 * L.Kp; k += BA_NT) x[k] = c.di[L.do_pose + k];
-    for (int k = c.tid; k < 9 * L.K; k += BA_NT) x[7 * L.Kp + k] = c.di[L.do_sb + k];
-    if (c.tid < 7) x[7 * L.Kp + 9 * L.K + c.tid] = c.di[L.do_ex + c.tid];
-    if (c.tid == 7) x[7 * L.Kp + 9 * L.K + 7] = c.di[L.do_td];
-    for (int k = c.tid; k < c.nL; k += BA_NT) c.sc[L.so_lam + k] = c.di[L.do_lam + k];
-    if (c.tid < C_NCTL) {
-        double v = 0.0;
-        if (c.tid == C_RADIUS) v = 1e4;
-        if (c.tid == C_MU || c.tid == C_MUSOLVED) v = 1e-8;
-        if (c.tid == C_T0) v = (double)wall_clock64();
-        c.sc[L.so_ctl + c.tid] = v;
+    if (all || part == 0) {
+        for (int k = c.tid; k < 7 * L.Kp; k += BA_NT) x[k] = c.di[L.do_pose + k];
+        for (int k = c.tid; k < 9 * L.K; k += BA_NT) x[7 * L.Kp + k] = c.di[L.do_sb + k];
+        if (c.tid < 7) x[7 * L.Kp + 9 * L.K + c.tid] = c.di[L.do_ex + c.tid];
+        if (c.tid == 7) x[7 * L.Kp + 9 * L.K + 7] = c.di[L.do_td];
+        for (int k = c.tid; k < c.nL; k += BA_NT) c.sc[L.so_lam + k] = c.di[L.do_lam + k];
+        if (c.tid < C_NCTL) {
+            double v = 0.0;
+            if (c.tid == C_RADIUS) v = 1e4;
+            if (c.tid == C_MU || c.tid == C_MUSOLVED) v = 1e-8;
+            if (c.tid == C_T0) v = (double)wall_clock64();
+            c.sc[L.so_ctl + c.tid] = v;
+        }
     }
     DP_ADD(40);
-    if (L.imu_info) imu_sqrt_info_ref(c);
-    else imu_sqrt_info(c);
+    if (all || (part >= 1 && part <= nI)) {
+        const int fbeg = all ? 0 : (part - 1) * BA_NW, fend = all ? L.K - 1 : part * BA_NW;
+        if (L.imu_info) imu_sqrt_info_ref(c, fbeg, fend);
+        else imu_sqrt_info(c, fbeg, fend);
+    }
     DP_ADD(41);
-    if (c.nprior) {
+    if (c.nprior && (all || part > nI)) {
+        const bool do_copy = all || part == nI + 1, do_prod = all || part == nI + 2;
         // J0^T J0 once per solve, J0 staged in LDS
         const int n = c.nprior;
         const double* J0 = c.pri + L.po_J0;
         double* Hp = c.sc + L.so_Hp;
         // the transposed copy the linearisation reads (its dot products run down the columns of J0)
-        {
+        if (do_copy) {
             double* J0t = c.sc + L.so_J0t;
             for (int wk = c.tid; wk < n * n; wk += BA_NT) { const int r = wk / n, cc = wk % n; J0t[cc * L.Ncap + r] = J0[r * L.pld + cc]; }
         }
@@ -465,7 +480,9 @@ extern "C" __global__ __launch_bounds__(BA_NT) void ba_prologue_kernel(const BaL
         // LDS addressing (a pointer that may be either costs flat loads in the inner loop)
         __syncthreads();
         DP_ADD(42);
-        if ((size_t)n * n * 8 <= (size_t)L.lds_pro) {
+        if (!do_prod) {
+            // (this workgroup's piece was the transposed copy)
+        } else if ((size_t)n * n * 8 <= (size_t)L.lds_pro) {
             double* J0s = LDSB;                  // n x n, row stride n
             for (int wk = c.tid; wk < n * n; wk += BA_NT) J0s[wk] = J0[(wk / n) * L.pld + wk % n];
             __syncthreads();
@@ -4209,7 +4226,7 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
     if (ev) { e = hipEventRecord(ev[nev++], stream); if (e != hipSuccess) return e; }
     const bool forked = fk && fk->aux && !ev && !L.la_on;
     int nk = 0;
-    LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P);
+    LAUNCH(ba_prologue_kernel, dim3(L.nwin, L.pro_split ? 1 + (L.K - 1 + BA_NW - 1) / BA_NW + 2 : 1), dim3(BA_NT), L.lds_pro, dL, P);
     if (kinds) kinds[nk++] = 0;
     for (int r = 0; r <= rounds; ++r) {
         const int cost_only = r == rounds ? 1 : 0;
