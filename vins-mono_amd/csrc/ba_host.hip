@@ -229,7 +229,7 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
         L.igs = split ? BA_IMU_GROUP : L.K - 1;
         L.nig = split ? nsplit : 1;
         L.nprw = split ? 1 : 0;
-        L.pro_split = (split && !L.big) ? 1 : 0;       // (ba_prologue_kernel: its pieces side by side, see the kernel)
+        L.pro_split = split ? 1 : 0;                   // (ba_prologue_kernel: its pieces side by side, see the kernel)
     }
     L.nbl = L.nbf + L.nig + L.nprw;
     {

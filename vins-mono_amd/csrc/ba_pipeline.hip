@@ -3313,27 +3313,47 @@ extern "C" __global__ __launch_bounds__(256) void ba_big_schur_kernel(const BaLa
     const double* pa = Wt + (size_t)(tm * 16 + r) * L.Lcap + 4 * kk;
     const double* pb = Wt + (size_t)(tn * 16 + r) * L.Lcap + 4 * kk;
     double4_t acc = {0, 0, 0, 0};
-    for (int l0 = 16 * c.wave; l0 < nL; l0 += 64) {
-        const int lb = l0 + 4 * kk;
-        double a[4], bq[4], om[4];
+    // Round 6: BS_PF groups of 16 landmarks per trip -- the loads of all of them (operands, h, landmark scaling) are requested before the
+    // first weight is formed.  The loop used to wait for a group's eight operand loads, form its four weights (a square root and a
+    // division each) and only then ask for the next group: 31 dependent HBM round trips per wavefront, 68 us per launch for 2000
+    // landmarks.  Same weights, same products, the MFMAs in the same order: the same T bit for bit.
+    constexpr int BS_PF = 4;
+    auto omega = [&](double h, double s0) {
+        const double s = scaled ? s0 : 1.0 / (1.0 + sqrt(h));
+        double d2 = s * s * h;
+        d2 = d2 < 1e-6 ? 1e-6 : d2;
+        d2 = 1e32 < d2 ? 1e32 : d2;
+        return s * s / (s * s * h + mu * d2);
+    };
+    for (int l0 = 16 * c.wave; l0 < nL; l0 += 64 * BS_PF) {
+        double a[BS_PF][4], bq[BS_PF][4], hv[BS_PF][4], sv[BS_PF][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            a[q] = pa[l0 + q];                      // (Lcap is a multiple of 16 and columns nL .. Lcap-1 of Wt are zero)
-            bq[q] = pb[l0 + q];
-            const int l = lb + q;
-            double o = 0.0;
-            if (l < nL) {
-                const double h = hh[l];
-                const double s = scaled ? sl[l] : 1.0 / (1.0 + sqrt(h));
-                double d2 = s * s * h;
-                d2 = d2 < 1e-6 ? 1e-6 : d2;
-                d2 = 1e32 < d2 ? 1e32 : d2;
-                o = s * s / (s * s * h + mu * d2);
+        for (int u = 0; u < BS_PF; ++u) {
+            const int lu = l0 + 64 * u;
+            const bool on = lu < nL;                 // (uniform per wavefront; a group past the end contributes exact zeros)
+            const int lc = on ? lu : l0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double av = pa[lc + q], bv = pb[lc + q];      // (Lcap is a multiple of 16 and columns nL .. Lcap-1 of Wt are zero)
+                a[u][q] = on ? av : 0.0;
+                bq[u][q] = on ? bv : 0.0;
+                const int l = lc + 4 * kk + q;
+                const bool in = on && l < nL;
+                const double h = hh[in ? l : 0], s0 = sl[in ? l : 0];
+                hv[u][q] = in ? h : -1.0;            // (-1: no such landmark)
+                sv[u][q] = s0;
             }
-            om[q] = o;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q] * om[q], bq[q], acc, 0, 0, 0);
+        for (int u = 0; u < BS_PF; ++u) {
+            double om[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) om[q] = hv[u][q] != -1.0 ? omega(hv[u][q], sv[u][q]) : 0.0;
+            if (l0 + 64 * u < nL) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][q] * om[q], bq[u][q], acc, 0, 0, 0);
+            }
+        }
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) sh[c.wave * 256 + reg * 64 + c.lane] = acc[reg];
@@ -4283,7 +4303,7 @@ extern "C" hipError_t ba_launch_solve_big(const BaLayout& L, const BaLayout* dL,
     } while (0)
 #define KIND(k) do { if (kinds) kinds[nk++] = (k); } while (0)
     // (profiling: the all-reduce sits in the gap before the kernel that consumes it and is counted with that kernel)
-    LAUNCH(ba_prologue_kernel, dim3(L.nwin), dim3(BA_NT), L.lds_pro, dL, P); KIND(0);
+    LAUNCH(ba_prologue_kernel, dim3(L.nwin, L.pro_split ? 1 + (L.K - 1 + BA_NW - 1) / BA_NW + 2 : 1), dim3(BA_NT), L.lds_pro, dL, P); KIND(0);
     // `rounds` = max_iters + slack: a failed factorisation retries in the NEXT round (the new T needs the collective), so a solve
     // can need more rounds than iterations.  Usually it does not: once the nominal number of rounds has been issued the host
     // looks at the windows' DONE flags (one strided 8-byte-per-window copy + a stream synchronisation) before every further
