@@ -1012,6 +1012,14 @@ def main():
             "algorithmic_bytes_per_batch": info['bytes_in'] + info['bytes_out'],
             "hbm_GBs_algorithmic": (info['bytes_in'] + info['bytes_out']) * args.steps / elapsed / 1e9,
         }
+        # HBM bytes of a whole step from the PMC pass: per-launch traffic x launches per step, summed over the launch
+        # classes; null while any class has no entry (summary recorded for other device code)
+        # (a class 'a+b' is one launch of each kernel per pass and its traffic the sum of the two: counted once per pass)
+        tr = [v["traffic"] * v["launches_per_step"] / len(k.split("+")) if v["traffic"] is not None else None for k, v in per_kernel.items()]
+        roofline["traffic_per_step"] = None if any(t is None for t in tr) else float(sum(tr))
+        roofline["traffic_per_step_over_algorithmic"] = (roofline["traffic_per_step"] / roofline["algorithmic_bytes_per_batch"]
+                                                         if roofline["traffic_per_step"] else None)
+        roofline["hbm_GBs_traffic_timed_region"] = (roofline["traffic_per_step"] * args.steps / elapsed / 1e9 if roofline["traffic_per_step"] else None)
         cpu = None
         parity = None
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (bench contract)

@@ -31,6 +31,8 @@ def test_bench_line_has_the_contract_shape():
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["traffic"] is None or rf["traffic"] > 0
+    # HBM bytes of a whole step (per-launch PMC traffic x launches per step): present, null only while the PMC summary is for other device code
+    assert "traffic_per_step" in rf and (rf["traffic_per_step"] is None or rf["traffic_per_step"] >= rf["traffic"])
     assert set(rf["kernels"]) >= {"ba_prologue_kernel", "ba_accumulate_kernel", "ba_solve_kernel", "ba_marg_kernel"}
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
