@@ -47,7 +47,7 @@ int vg_abi_version(void);
 int vg_create(vg_handle** out);                 /* uses the current HIP device, owns one stream  */
 /* The same with everything that shapes a handle's behaviour in ONE struct (ABI 10; SURVEY 8(b): vg_create(const vg_config*, ...)).
  * A handle created this way NEVER consults the environment: the development variables VG_BA_LAUNCH_MODE, VG_BA_FUSED,
- * VG_BA_FUSED_MIN and VG_PACK_THREADS are defaults of plain vg_create() only (a drop-in library must not change behaviour with
+ * VG_BA_FUSED_MIN, VG_BA_SOLVE_W8_BELOW and VG_PACK_THREADS are defaults of plain vg_create() only (a drop-in library must not change behaviour with
  * its host's environment).  Zero-initialise, set struct_size = sizeof(vg_config), fill what differs from the defaults. */
 typedef struct vg_config {
     int struct_size;             /* sizeof(vg_config) of the caller: fields beyond it take their defaults                         */
