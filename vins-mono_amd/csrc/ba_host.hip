@@ -312,6 +312,11 @@ static int build_layout(vg_handle* h, int nwin, const vg_ba_problem* const* in, 
             static const int env_max = getenv("VG_BA_SOLVE_W8_BELOW") ? atoi(getenv("VG_BA_SOLVE_W8_BELOW")) : -1;      // (development switch:
             const int below = (env_max >= 0 && !h->ba.no_env) ? env_max : 32;                                             //  plain vg_create() only)
             L.sv_w8 = (!L.big && L.nwin < below) ? 1 : 0;
+            // (the 8-wavefront build stages the landmark tile of its Schur phase, [RcPad][32 + 1] doubles, behind the carve -- the ring it
+            //  aliases in the 4-wavefront kernel is live beside it there; a shape that leaves no room keeps the 4-wavefront kernel)
+            L.l_wd8 = L.lds_solve / 8;
+            L.lds_solve_w8 = L.lds_solve + 8 * L.RcPad * 33;
+            if (L.lds_solve_w8 > 160 * 1024) L.sv_w8 = 0;
         }
     }
     if (L.big) {

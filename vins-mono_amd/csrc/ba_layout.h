@@ -126,6 +126,9 @@ struct BaLayout {
     int la_on, la_chq, la_chf, la_P, la_key, la_x, lds_linacc;      // (la_x: the state of the linearisation point, staged once per launch)
     // ---- host only: the batch is solved by ba_solve_w8_kernel (8 wavefronts per window) instead of ba_solve_kernel (4): few windows
     int sv_w8;
+    // ---- ba_solve_w8_kernel: the landmark tile of its side-by-side Schur phase (chain_schur_split) behind the carve: offset in doubles;
+    //      lds_solve_w8 = dynamic LDS bytes of that launch (host only)
+    int l_wd8, lds_solve_w8;
     // ---- host only: the prologue's independent pieces run as workgroups side by side (the latency layout: few windows on an empty chip)
     int pro_split;
     // ---- large-window path (big != 0): the camera part does not fit the LDS carve above.  S stays in LDS (packed, with

@@ -2505,6 +2505,412 @@ NOINL double chain_schur(const Ctx& c_in, const SolveLds& m_in, const double* bu
     return q;
 }
 
+#if SV_NW >= 8
+// ---- 8-wavefront build only (ba_solve_w8_kernel: one window per CU, the drop-in's operating point): the two halves of chain_schur SIDE BY
+// SIDE.  The landmark part of the Schur complement (S -= Wd Wd^T, ~22K of the kernel's ~190K cycles per round) does not depend on the
+// elimination of the speed-bias chain (~57K): wavefronts 0 .. 3 run the chain exactly as the 4-wavefront kernel does (same roles, same
+// tile ownership, same sums), wavefronts 4 .. 7 run the landmark trips with the thread mapping of the 4-wavefront kernel, both inside ONE
+// loop whose iteration is a chain step beside a landmark trip (two workgroup barriers each: the step's A | B | C phases line up with the
+// trip's "previous tile consumed" | stage | multiply).  The landmark tile gets its own LDS behind the carve (BaLayout::l_wd8; the ring it
+// aliases in chain_schur is live now).  S -= (chain accumulators) and S -= (landmark accumulators) are two passes: the same sums as
+// chain_schur up to the order of these two subtractions.
+#define CS_NW 4
+#define CS_NT (64 * CS_NW)
+#define CS_PF ((96 * SCHUR_LW + CS_NT - 1) / CS_NT)
+template <int SCHUR_TPW>
+NOINL double chain_schur_split(const Ctx& c_in, const SolveLds& m_in, const double* buf_, double mu) {
+    PHASE_ENTER(false);
+    mu = uni(mu);
+    const int K = L.K, Rc = L.Rc, RcPad = L.RcPad, ldc = m.ldc, Ncap = L.Ncap;
+    const int mid = K / 2, nstep = mid;            // (K - 1 - mid <= mid)
+    lds_d* const S = AS_LDS(m.S);
+    lds_d* const D = AS_LDS(m.D);
+    lds_d* const E = AS_LDS(m.E);
+    lds_d* const dinv = AS_LDS(m.dinv);
+    lds_d* const ring = AS_LDS(m.ring);            // rows 0..8: top block of the step, rows 9..17: bottom block
+    lds_d* const stage = ring + 18 * ldc;          // [2][9][18]: the IMU part of the raw coupling rows of the NEXT step's two blocks
+    lds_d* const wd = AS_LDS(LDSB + L.l_wd8);      // (its own tile behind the carve: the ring is live beside it)
+    const lds_d* g = AS_LDS_C(m.vec + V_G * L.Rpad);
+    const lds_d* sc = AS_LDS_C(m.vec + V_SC * L.Rpad);
+    const lds_d* tv = AS_LDS_C(m.vec + V_T * L.Rpad);
+    const lds_i* pinv = (const lds_i*)m.pinv;
+    const glb_d* buf = AS_GLB_C(buf_);
+    const glb_d* imuJ = buf + L.bo_imuJ;
+    const glb_d* Hp = AS_GLB_C(c.sc + L.so_Hp);
+    glb_d* const xp = AS_GLB(m.xp);
+    lds_i* flag = (lds_i*)(m.red + 24);
+    const int wave = uni(c.wave);
+    const bool lm_grp = wave >= CS_NW;             // wavefronts 0 .. 3: the chain; 4 .. 7: the landmark columns
+    const int ltid = c.tid - CS_NT;                // thread of the landmark group
+    unsigned vm;                                   // bit f: IMU factor f is present
+    {
+        const glb_i* valid = AS_GLB_CI(c.ia + L.io_imu_valid);
+        const int v = c.lane < K - 1 ? valid[c.lane] : 0;
+        vm = (unsigned)__ballot(v != 0);
+    }
+    if (c.tid == 0) *flag = 1;
+    const int nt = RcPad / 16;
+    const int ntile = nt * (nt + 1) / 2;
+    double4_t acc[SCHUR_TPW];
+    int tm[SCHUR_TPW], tn[SCHUR_TPW];
+#pragma unroll
+    for (int s = 0; s < SCHUR_TPW; ++s) {
+        acc[s] = (double4_t){0, 0, 0, 0};
+        int a, bq;
+        tri_decode((wave & (CS_NW - 1)) + s * CS_NW, a, bq);
+        tm[s] = a; tn[s] = bq;
+    }
+    // tasks of a sweep: Rc + 1 columns of [C_k | g_k], 9 of the coupling block.  Wavefront 0 takes the first 64 tasks of the top
+    // sweep, wavefront 1 those of the bottom sweep -- so that inside them the sweep (coupling-block strides, block index) is
+    // wave-uniform -- and wavefront 2 what is left of both (the host checks that it fits); wavefront 3 factors the diagonal blocks.
+    const int nth = Rc + 10, nfull = nth < 64 ? nth : 64, nrem = nth - nfull;
+    const int half = wave < 2 ? wave : (c.lane >= nrem ? 1 : 0);
+    const int id = wave < 2 ? c.lane : 64 + c.lane - half * nrem;
+    const bool tasked = wave < 2 ? c.lane < nfull : (wave == 2 && c.lane < 2 * nrem);
+    const bool col_task = tasked && id <= Rc;
+    const bool cpl_task = tasked && id > Rc;
+    const bool fac_wave = wave == CS_NW - 1;
+    // ---- staging of the IMU part of a block's raw coupling rows: entry (r, c18), c18 = 6 (d + 1) + o for the pose column o of frame
+    //      k + d, d = -1, 0, 1.  IMU factor f, local columns: 0-5 pose_f, 6-14 sb_f, 15-20 pose_f+1, 21-29 sb_f+1, packed lower
+    //      triangle in imuJ[f][.]: factor k gives (sb_k, pose_k) and (pose_k+1, sb_k), factor k-1 gives (sb_k, pose_k-1) and (sb_k, pose_k)
+    double sv[2][2];
+    int si_a[2], si_b[2];                                    // this thread's two staged entries: local indices in factor k / factor k-1
+    bool si_on[2], si_fa[2], si_fb[2], si_h[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const int e2 = (lm_grp ? 324 : c.tid) + CS_NT * qq;      // (the landmark group stages nothing: e2 >= 324)
+        const int hh = e2 >= 162 ? 1 : 0, e = e2 - 162 * hh;
+        const int r = e / 18, c18 = e - 18 * r, d = c18 / 6 - 1, o = c18 - 6 * (d + 1);
+        si_on[qq] = e2 < 324; si_h[qq] = hh != 0; si_fa[qq] = d >= 0; si_fb[qq] = d <= 0;
+        si_a[qq] = d == 0 ? (6 + r) * (7 + r) / 2 + o : (15 + o) * (16 + o) / 2 + 6 + r;
+        si_b[qq] = (21 + r) * (22 + r) / 2 + (d == 0 ? 15 + o : o);
+    }
+    auto stage_issue = [&](int kt_n, int kb_n) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int k = si_h[qq] ? kb_n : kt_n;
+            const bool on = si_on[qq] && k >= 0;
+            const bool fa_on = on && si_fa[qq] && k <= K - 2 && ((vm >> (k >= 0 ? k : 0)) & 1u);
+            const bool fb_on = on && si_fb[qq] && k >= 1 && ((vm >> (k >= 1 ? k - 1 : 0)) & 1u);
+            const double va = imuJ[fa_on ? k * 512 + si_a[qq] : 0], vb = imuJ[fb_on ? (k - 1) * 512 + si_b[qq] : 0];
+            // even factor first, then the odd one: the order in which the former scatter rounds added them
+            const double a = fa_on ? va : 0.0, b = fb_on ? vb : 0.0;
+            sv[qq][0] = (k & 1) ? b : a;
+            sv[qq][1] = (k & 1) ? a : b;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int e2 = (lm_grp ? 324 : c.tid) + CS_NT * qq;
+            if (e2 < 324) stage[e2] = sv[qq][0] + sv[qq][1];
+        }
+    };
+    // the raw column `id` of block k: staged IMU part (+ the prior's J0^T J0 row if the prior holds this speed-bias block), g for the rhs
+    auto raw_col = [&](int k, double* c0) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) c0[r] = 0.0;
+        if (k < 0 || !col_task) return;
+        if (id == Rc) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) c0[r] = g[Rc + 9 * k + r];
+            return;
+        }
+        const int p = id / 6, o = id - 6 * p, d = p - k;
+        if (id < 6 * K && d >= -1 && d <= 1) {
+            const lds_d* st = stage + 162 * half + 6 * (d + 1) + o;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) c0[r] = st[18 * r];
+        }
+        const int pbk = pinv[Rc + 9 * k], pj = pinv[id];
+        if (pbk >= 0 && pj >= 0) {
+            double pv[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int pr_ = pbk + r;
+                const int hi = pr_ > pj ? pr_ : pj, lo = pr_ > pj ? pj : pr_;
+                pv[r] = Hp[hi * Ncap + lo];
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) c0[r] += pv[r];
+        }
+    };
+    double xprev[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) xprev[r] = 0.0;
+    double q = 0.0;
+    {
+        const bool l0 = nstep == 0;
+        const int kt0 = l0 ? mid : K - 1, kb0 = l0 ? -1 : 0;
+        stage_issue((l0 || kt0 > mid) ? kt0 : -1, (!l0 && kb0 < mid) ? kb0 : -1);
+        stage_store();
+    }
+    // ---- landmark group: its inputs and the scaling of its landmarks (visible to its own wavefronts behind the first barrier)
+    const glb_d* Wt = buf + L.bo_Wt;
+    const glb_d* hl = buf + L.bo_h;
+    const glb_d* bl = buf + L.bo_b;
+    const glb_d* sl = AS_GLB_C(c.sc + L.so_sl);
+    const glb_d* dgl = AS_GLB_C(c.sc + L.so_dg + L.Rpad);
+    glb_d* lsc = AS_GLB(c.sc + L.so_lsc);
+    if (lm_grp)
+        for (int l = ltid; l < c.nL; l += CS_NT) lsc[l] = sl[l] / sqrt(sl[l] * sl[l] * hl[l] + mu * dgl[l] * dgl[l]);
+    double pre[CS_PF], pl = 0.0;           // (element w = ltid + CS_NT i: its landmark l0 + w % 32 is the same for every i)
+#pragma unroll
+    for (int i = 0; i < CS_PF; ++i) pre[i] = 0.0;
+    const int nel = RcPad * SCHUR_LW;
+    auto fetch = [&](int l0) {
+#pragma unroll
+        for (int i = 0; i < CS_PF; ++i) {
+            const int w = ltid + CS_NT * i;
+            const int row = w / SCHUR_LW, l = l0 + (w % SCHUR_LW);
+            const bool in = w < nel && row <= Rc && l < c.nL;
+            pre[i] = in ? (row < Rc ? Wt[(size_t)row * L.Lcap + l] : bl[l]) : 0.0;
+        }
+        const int lme = l0 + ((ltid >= 0 ? ltid : 0) % SCHUR_LW);
+        const double lv = lsc[lme < c.nL ? lme : 0];
+        pl = lme < c.nL ? lv : 0.0;
+    };
+    // (C) of a chain step is shared by ALL eight wavefronts (tile wave + 8 s): accumulators of their own beside the landmark group's
+    constexpr int CS_TPC = (SCHUR_TPW * CS_NW + SV_NW - 1) / SV_NW;
+    double4_t accC[CS_TPC];
+    int tmc[CS_TPC], tnc[CS_TPC];
+#pragma unroll
+    for (int s = 0; s < CS_TPC; ++s) {
+        accC[s] = (double4_t){0, 0, 0, 0};
+        int a, bq;
+        tri_decode(wave + s * SV_NW, a, bq);
+        tmc[s] = a; tnc[s] = bq;
+    }
+    auto c_tiles = [&](bool has_t, bool has_b) {
+        // k-step u covers rows 4u .. 4u+3 of [top 9 | bottom 9] of the staged rows
+        const int nks = has_b ? 5 : 3;
+        const int kq = c.lane >> 4, jc = c.lane & 15;
+#pragma unroll
+        for (int s = 0; s < CS_TPC; ++s) {
+            if (wave + s * SV_NW < ntile) {
+                double av[5], bv[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int row = 4 * u + kq;
+                    const bool on = u < nks && (row < 9 ? has_t : (row < 18 && has_b));
+                    const lds_d* xr = ring + (on ? row : 0) * ldc + jc;
+                    const double a = xr[tmc[s] * 16], b = xr[tnc[s] * 16];
+                    av[u] = on ? a : 0.0;
+                    bv[u] = on ? b : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u)
+                    if (u < nks) accC[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], accC[s], 0, 0, 0);
+            }
+        }
+    };
+    __syncthreads();                               // chain: the first step's staged rows; landmark group: lsc
+    if (lm_grp && c.nL > 0) fetch(0);
+    DP_DECL;
+    const int ntrip = (c.nL + SCHUR_LW - 1) / SCHUR_LW;
+    const int niter = nstep + 1 > ntrip ? nstep + 1 : ntrip;
+    // Two loops with the SAME number of workgroup barriers (s_barrier counts wavefronts, not program locations) and the same exit test:
+    // written apart, the registers of a chain step (solved columns, staged entries) and those of a landmark trip (the prefetched tile)
+    // do not add up in one live range -- in one loop body the function spilled 133 registers.
+    if (!lm_grp) {
+    for (int t = 0; t < niter; ++t) {
+        const bool ch_on = t <= nstep;
+        const bool last = t >= nstep;
+        // blocks of this step: top kt (coupled downwards), bottom kb (coupled upwards); in the last step only `mid`
+        const int kt = last ? mid : K - 1 - t, kb = last ? -1 : t;
+        const bool has_t = last || kt > mid, has_b = !last && kb < mid;
+        const bool upd_t_from_above = has_t && kt + 1 <= K - 1 && (last ? (K - 1 > mid) : t > 0);
+        const bool upd_mid_from_below = last && mid > 0;
+        const bool upd_b = has_b && t > 0;
+        const int k = half == 0 ? kt : kb;
+        const bool act = tasked && (half == 0 ? has_t : has_b);
+        // next step's blocks (their raw rows are requested now, staged behind the first barrier of this step)
+        int ktn = -1, kbn = -1;
+        if (t < nstep) {
+            const bool nlast = t + 1 == nstep;
+            const int k2 = nlast ? mid : K - 2 - t;
+            if (nlast || k2 > mid) ktn = k2;
+            if (!nlast && t + 1 < mid) kbn = t + 1;
+        }
+        double x[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) x[r] = 0.0;
+        if (ch_on) stage_issue(ktn, kbn);
+        DP_ADD(18);
+        // ---- (A)
+        if (ch_on && fac_wave) {
+            const int kind_t = (upd_t_from_above ? 1 : 0) | (upd_mid_from_below ? 2 : 0);
+            double msk[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) msk[i] = (c.lane >> 4) == i ? 1.0 : 0.0;
+            bool ok = true;
+#define CF_STEP1(f) cf_pivot<0>(f, msk); cf_pivot<1>(f, msk); cf_pivot<2>(f, msk); cf_pivot<3>(f, msk); cf_pivot<4>(f, msk); \
+                    cf_pivot<5>(f, msk); cf_pivot<6>(f, msk); cf_pivot<7>(f, msk); cf_pivot<8>(f, msk);
+            if (has_t && has_b) {
+                ChainFac ft, fb;
+                cf_load<true>(ft, c.lane, D + 81 * kt, kind_t, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt));
+                cf_load<true>(fb, c.lane, D + 81 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb));
+#define CF_STEP(r) cf_pivot<r>(ft, msk); cf_pivot<r>(fb, msk);
+                CF_STEP(0) CF_STEP(1) CF_STEP(2) CF_STEP(3) CF_STEP(4) CF_STEP(5) CF_STEP(6) CF_STEP(7) CF_STEP(8)
+#undef CF_STEP
+                ok = cf_store(ft, c.lane, D + 81 * kt, dinv + 9 * kt);
+                ok = cf_store(fb, c.lane, D + 81 * kb, dinv + 9 * kb) && ok;
+            } else if (has_t) {
+                ChainFac ft;
+                cf_load<true>(ft, c.lane, D + 81 * kt, kind_t, (const lds_d*)(E + 81 * (kt + 1)), (const lds_d*)(E + 81 * kt));
+                CF_STEP1(ft)
+                ok = cf_store(ft, c.lane, D + 81 * kt, dinv + 9 * kt);
+            } else if (has_b) {
+                ChainFac fb;
+                cf_load<true>(fb, c.lane, D + 81 * kb, upd_b ? 2 : 0, (const lds_d*)nullptr, (const lds_d*)(E + 81 * kb));
+                CF_STEP1(fb)
+                ok = cf_store(fb, c.lane, D + 81 * kb, dinv + 9 * kb);
+            }
+#undef CF_STEP1
+            if (!ok && c.lane == 0) *flag = 0;
+        }
+        if (ch_on && act && col_task) {
+            double c0[9];
+            raw_col(k, c0);
+            const double scj = id < Rc ? sc[id] : 1.0, tvj = id < Rc ? tv[id] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int ca = Rc + 9 * k + r;
+                const double v = c0[r] * sc[ca] * scj;
+                q += 2.0 * v * tv[ca] * tvj;
+                x[r] = v;
+            }
+            DP_ADD(19);
+            // x -= (coupling block)^T x_prev;  coef[9 p + r] = coupling entry (row r of this block, row p of the neighbour's X): both
+            // sweeps keep their coupling block as [p][r] -- one code path, only the block differs per lane in wavefront 2.
+            // (An MFMA form of this update -- 15 MFMAs per block from the staged rows instead of 81 multiply-adds per column -- was
+            //  measured and lost, 59K against 24K cycles per round: five dependent tile trips of index arithmetic and LDS reads on ONE
+            //  wavefront are slower than 64 columns side by side; profiles/r05p_*.)
+            if (half == 0 ? upd_t_from_above : upd_b) chain_upd_c<9, 1>(x, half == 0 ? E + 81 * (kt + 1) : E + 81 * kb, xprev);
+            DP_ADD(20);
+            if (half == 0 && upd_mid_from_below) {
+                double xb[9];
+#pragma unroll
+                for (int p = 0; p < 9; ++p) xb[p] = ring[(9 + p) * ldc + id];      // X of block mid - 1: the bottom sweep's last rows
+                chain_upd_c<9, 1>(x, E + 81 * kt, xb);
+            }
+        } else if (ch_on && act && cpl_task && !(half == 0 && last)) {
+            const int cc = id - Rc - 1;
+            // top: column cc of E_kt -> Xe_kt[.][cc];  bottom: row cc of E_kb+1 -> XuT of the pair (kb + 1, kb)
+            const lds_d* e = half == 0 ? E + 81 * kt + cc : E + 81 * (kb + 1) + 9 * cc;
+            const int st = half == 0 ? 9 : 1;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) x[r] = e[r * st];
+        }
+        DP_ADD(0);
+        __syncthreads();                           // chain: A done | landmark group: the previous tile is consumed
+        if (*flag == 0) break;                     // (every thread of the workgroup reads the same value)
+        DP_ADD(1);
+        // ---- (B) x <- L_k^-1 x
+        if (ch_on && act && (col_task || !(half == 0 && last))) {
+            const lds_d* Lk = D + 81 * k;
+            const lds_d* dk = dinv + 9 * k;
+
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                double s = x[r];
+#pragma unroll
+                for (int qq = 0; qq < r; ++qq) s -= Lk[9 * r + qq] * x[qq];
+                x[r] = s * dk[r];
+            }
+            if (col_task) {
+                lds_d* ro = ring + (half ? 9 : 0) * ldc + id;
+                glb_d* po = xp + (size_t)9 * k * ldc + id;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) { ro[r * ldc] = x[r]; po[(size_t)r * ldc] = x[r]; xprev[r] = x[r]; }
+            } else {
+                // (all reads of the slot -- the cpl loads of (A) -- are behind the barrier: the bottom block's rows can come back
+                //  transposed, as [p][c] like the top sweep's Xe)
+                const int cc = id - Rc - 1;
+                lds_d* e = (half == 0 ? E + 81 * kt : E + 81 * (kb + 1)) + cc;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) e[9 * r] = x[r];
+            }
+        }
+        if (ch_on) stage_store();                             // (the staging area's readers -- raw_col in (A) -- are behind the barrier above)
+        DP_ADD(2);
+        __syncthreads();                           // chain: the solved rows are staged | landmark group: the tile is staged
+        DP_ADD(3);
+        if (ch_on) c_tiles(has_t, has_b);           // (C) this wavefront's share of S accumulators += X^T X over the staged rows
+        DP_ADD(10);
+    }
+    } else {
+    for (int t = 0; t < niter; ++t) {
+        const bool lm_on = t < ntrip;
+        const int l0 = t * SCHUR_LW;
+        __syncthreads();                           // (chain: A done) the previous tile is consumed
+        if (*flag == 0) break;
+        if (lm_on) {
+#pragma unroll
+            for (int i = 0; i < CS_PF; ++i) {
+                const int w = ltid + CS_NT * i;
+                if (w < nel) {
+                    const int row = w / SCHUR_LW, kk = w % SCHUR_LW;
+                    wd[row * SCHUR_LD + kk] = (row < Rc ? sc[row] : 1.0) * pre[i] * pl;
+                }
+            }
+        }
+        __syncthreads();                           // the tile is staged (chain: the solved rows of step t are staged)
+        if (t <= nstep) {
+            const bool last = t >= nstep;
+            const int kt = last ? mid : K - 1 - t, kb = last ? -1 : t;
+            c_tiles(last || kt > mid, !last && kb < mid);
+        }
+        if (lm_on) {
+            if (l0 + SCHUR_LW < c.nL) fetch(l0 + SCHUR_LW);
+#pragma unroll
+            for (int s = 0; s < SCHUR_TPW; ++s) {
+                if ((wave & (CS_NW - 1)) + s * CS_NW < ntile) {
+                    double av[SCHUR_LW / 4], bv[SCHUR_LW / 4];
+#pragma unroll
+                    for (int kk = 0; kk < SCHUR_LW / 4; ++kk) {
+                        av[kk] = wd[(tm[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
+                        bv[kk] = wd[(tn[s] * 16 + (c.lane & 15)) * SCHUR_LD + kk * 4 + (c.lane >> 4)];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < SCHUR_LW / 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc[s], 0, 0, 0);
+                }
+            }
+        }
+    }
+    }
+    __syncthreads();                               // *flag final; every accumulator complete
+    // D[row = (lane>>4) + 4*reg][col = lane&15]: the chain rows' share (every wavefront, tiles wave + 8 s), then the landmark group's
+#pragma unroll
+    for (int s = 0; s < CS_TPC; ++s) {
+        if (wave + s * SV_NW < ntile) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = tmc[s] * 16 + (c.lane >> 4) + 4 * reg;
+                const int col = tnc[s] * 16 + (c.lane & 15);
+                if (row <= Rc && col <= row && col < Rc) S[tri(row, col)] -= accC[s][reg];
+            }
+        }
+    }
+    __syncthreads();
+    if (lm_grp) {
+#pragma unroll
+        for (int s = 0; s < SCHUR_TPW; ++s) {
+            if ((wave & (CS_NW - 1)) + s * CS_NW < ntile) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = tm[s] * 16 + (c.lane >> 4) + 4 * reg;
+                    const int col = tn[s] * 16 + (c.lane & 15);
+                    if (row <= Rc && col <= row && col < Rc) S[tri(row, col)] -= acc[s][reg];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return q;
+}
+#endif
+
 // Landmark part of  t^T H~ t  (the Cauchy-point denominator, see build_scaled):  sum_l [ h~_l t_l^2 + 2 t_l (w~_l . t_cam) ]
 // with t = gt / Dg.  Only needed when the Gauss-Newton step leaves the trust region, so it is evaluated on demand
 // (thread per landmark, one pass over Wt).  Returns this thread's share.
@@ -2990,7 +3396,14 @@ __device__ __forceinline__ void solve_body(const BaLayout* __restrict__ Lp, cons
                 __syncthreads();
                 DBG_DUMP(1);
                 PROF_ADD(PF_BUILD);
-                q += L.RcPad <= 80 ? chain_schur<(15 + SV_NW - 1) / SV_NW>(pa_c, pa_m, buf, s.mu) : chain_schur<(21 + SV_NW - 1) / SV_NW>(pa_c, pa_m, buf, s.mu);                        // (the coupling rows' share of t^T H~ t)
+                
+#if SV_NW >= 8
+                // (8-wavefront build: chain elimination on wavefronts 0 .. 3 and landmark columns on 4 .. 7 side by side, tiles owned as in the 4-wavefront kernel)
+                q += L.RcPad <= 80 ? chain_schur_split<4>(pa_c, pa_m, buf, s.mu) : chain_schur_split<6>(pa_c, pa_m, buf, s.mu);
+#else
+                q += L.RcPad <= 80 ? chain_schur<(15 + SV_NW - 1) / SV_NW>(pa_c, pa_m, buf, s.mu) : chain_schur<(21 + SV_NW - 1) / SV_NW>(pa_c, pa_m, buf, s.mu);
+#endif
+                        // (the coupling rows' share of t^T H~ t)
                 bool cok = *(const int*)(m.red + 24) != 0;                // (uniform: read behind the phase's last barrier)
                 DBG_DUMP(2);
                 PROF_ADD(PF_CHAIN);
@@ -4271,7 +4684,7 @@ extern "C" hipError_t ba_launch_solve(const BaLayout& L, const BaLayout* dL, con
         }
         if (!fused) LAUNCH(ba_accumulate_kernel, dim3(L.nba * ((L.nwin + 7) / 8) * 8), dim3(BA_ACC_NT), 0, dL, P);
         if (forked && (e = hipStreamWaitEvent(stream, fk->join, 0)) != hipSuccess) return e;
-        if (L.sv_w8) LAUNCH(ba_solve_w8_kernel, dim3(L.nwin), dim3(2 * SV_NT), L.lds_solve, dL, P);     // few windows: 8 wavefronts per window
+        if (L.sv_w8) LAUNCH(ba_solve_w8_kernel, dim3(L.nwin), dim3(2 * SV_NT), L.lds_solve_w8, dL, P);     // few windows: 8 wavefronts per window
         else LAUNCH(ba_solve_kernel, dim3(L.nwin), dim3(SV_NT), L.lds_solve, dL, P);
         if (kinds) { if (!fused) kinds[nk++] = 2; kinds[nk++] = 3; }
     }
