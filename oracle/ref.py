@@ -75,6 +75,19 @@ def lib_gpu():
 _lib_simt = None
 
 
+def dlopen_own_scope(path):
+    """ctypes.CDLL of a library that is linked against the EMULATED kernel library (tests/simt/_build/libvinsgpu_simt.so) such that its
+    vg_* references bind to THAT library even when the process has the product's libvinsgpu.so in the global scope already
+    (vins-mono_amd/__init__.py loads it RTLD_GLOBAL: an xdist worker that ran an ABI test first handed the emulated drop-ins the real
+    library's vg_create -- "no device" on this GPU-less box, an order-dependent failure).  RTLD_DEEPBIND puts the library's own
+    dependency chain in front of the global scope; the sanitizer runtimes refuse that flag, so a process that preloads one (the ASAN
+    runs of tests/test_simt_asan.py, which never load the product library) gets the plain local load."""
+    mode = os.RTLD_NOW | os.RTLD_LOCAL
+    if "asan" not in os.environ.get("LD_PRELOAD", "") and "ubsan" not in os.environ.get("LD_PRELOAD", ""):
+        mode |= getattr(os, "RTLD_DEEPBIND", 0)
+    return C.CDLL(path, mode=mode)
+
+
 def simt_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libvins_ref_simt.so")) or os.path.exists(_REF_SRC)
 
@@ -91,7 +104,7 @@ def lib_simt():
         path = os.path.join(_HERE, "_ref", "libvins_ref_simt.so")
         if not os.path.exists(path):
             raise RuntimeError("oracle/_ref/libvins_ref_simt.so is missing")
-        _lib_simt = _prepare(C.CDLL(path))
+        _lib_simt = _prepare(dlopen_own_scope(path))
         assert _lib_simt.vref_has_gpu_optimization() == 1
     return _lib_simt
 

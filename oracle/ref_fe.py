@@ -40,7 +40,11 @@ def _load(kind):
             subprocess.check_call(["make", "-C", _HERE, "ref_simt" if kind == "simt" else "ref_fe"], stdout=subprocess.DEVNULL)
         if not os.path.exists(_path(kind)):
             raise RuntimeError(_path(kind) + " is missing and /root/reference is not here to build it")
-        L = C.CDLL(_path(kind))
+        if kind == "simt":
+            from oracle.ref import dlopen_own_scope
+            L = dlopen_own_scope(_path(kind))      # (its vg_* references must bind to the emulated library: see there)
+        else:
+            L = C.CDLL(_path(kind))
         assert L.vfe_abi_version() == 1 and L.vfe_has_gpu_readimage() == (0 if kind == "ref" else 1)
         L.vfe_published_stamp.restype = C.c_double
         _LIBS[kind] = L

@@ -152,7 +152,8 @@ def test_landmark_partition_balances_the_schur_work():
     import conftest
     conftest._build_simt()
     from vins_mono_amd import shard
-    SH = C.CDLL(os.path.join(ROOT, "tests", "simt", "_build", "libvins_shard_simt.so"))
+    from oracle.ref import dlopen_own_scope
+    SH = dlopen_own_scope(os.path.join(ROOT, "tests", "simt", "_build", "libvins_shard_simt.so"))
     rng = np.random.default_rng(5)
     for L, world in ((1, 2), (7, 3), (200, 8), (2000, 8), (5, 8)):
         nobs = rng.integers(2, 12, L).astype(np.int32)
@@ -177,7 +178,8 @@ def test_sharded_window_refuses_alike_on_every_rank_before_any_collective():
     import pytest
     h = conftest._simt_handle()
     from vins_mono_amd import ba, shard, synth
-    SH = C.CDLL(os.path.join(ROOT, "tests", "simt", "_build", "libvins_shard_simt.so"))
+    from oracle.ref import dlopen_own_scope
+    SH = dlopen_own_scope(os.path.join(ROOT, "tests", "simt", "_build", "libvins_shard_simt.so"))
     GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
     SH.vins_sharded_create.restype = C.c_void_p
     SH.vins_sharded_create.argtypes = [C.c_int, C.c_int, GATHER, C.c_void_p]
